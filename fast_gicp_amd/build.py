@@ -1,0 +1,33 @@
+"""Builds libfast_vgicp_hip.so (the C-ABI HIP engine) in-tree for gfx950."""
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_DIR = os.path.join(_HERE, "lib")
+LIB_PATH = os.path.join(LIB_DIR, "libfast_vgicp_hip.so")
+SOURCES = [os.path.join(_HERE, "csrc", f) for f in ("fvh_capi.hip", "kernels_cost.hpp", "kernels_cov.hpp", "kernels_voxelmap.hpp", "dev_math.hpp")]
+HEADER = os.path.join(os.path.dirname(_HERE), "include", "fast_vgicp_hip.h")
+
+
+def is_stale():
+    if not os.path.exists(LIB_PATH):
+        return True
+    t = os.path.getmtime(LIB_PATH)
+    return any(os.path.exists(s) and os.path.getmtime(s) > t for s in SOURCES + [HEADER])
+
+
+def build_lib(force=False, verbose=False):
+    """hipcc --offload-arch=gfx950 -> fast_gicp_amd/lib/libfast_vgicp_hip.so (cross-compiles without a GPU)."""
+    if not force and not is_stale():
+        return LIB_PATH
+    os.makedirs(LIB_DIR, exist_ok=True)
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-munsafe-fp-atomics", "-o", LIB_PATH, SOURCES[0], "-ldl"]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return LIB_PATH
+
+
+if __name__ == "__main__":
+    print(build_lib(force=True, verbose=True))

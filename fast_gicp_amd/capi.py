@@ -1,0 +1,323 @@
+"""ctypes binding of the C ABI in include/fast_vgicp_hip.h (libfast_vgicp_hip.so).
+
+This is the only way Python reaches the engine: plain pointers and sizes, no torch types.
+There is no CPU fallback -- if the shared library is missing, importing the handles fails loudly.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import build as _build
+
+# enum ordinals (== the reference's enum class ordinals, gicp_settings.hpp:7-11 / ndt_settings.hpp:6)
+REG_NONE, REG_MIN_EIG, REG_NORMALIZED_MIN_EIG, REG_PLANE, REG_FROBENIUS = range(5)
+DIRECT27, DIRECT7, DIRECT1, DIRECT_RADIUS = range(4)
+NDT_P2D, NDT_D2D = 0, 1
+COMPUTE_FP64, COMPUTE_FP32 = 0, 1
+
+EXPORTED_SYMBOLS = None  # filled by _declared_symbols()
+
+
+class LmParams(C.Structure):
+    _fields_ = [("max_iterations", C.c_int), ("rotation_epsilon", C.c_double), ("transformation_epsilon", C.c_double), ("lm_max_iterations", C.c_int),
+                ("lm_init_lambda_factor", C.c_double)]
+
+
+class LmResult(C.Structure):
+    _fields_ = [("T", C.c_double * 16), ("H", C.c_double * 36), ("final_error", C.c_double), ("converged", C.c_int), ("nr_iterations", C.c_int),
+                ("num_linearize", C.c_int), ("num_error_evals", C.c_int), ("lm_failed", C.c_int), ("num_launches", C.c_int)]
+
+
+class FvhError(RuntimeError):
+    pass
+
+
+_LIB = None
+
+
+def lib_path():
+    return _build.LIB_PATH
+
+
+def load():
+    global _LIB
+    if _LIB is None:
+        path = lib_path()
+        if not os.path.exists(path):
+            raise FvhError("libfast_vgicp_hip.so is not built (%s). Run `python -c 'import __graft_entry__ as g; g.build()'`; there is no CPU fallback." % path)
+        L = C.CDLL(path)
+        L.fvh_vgicp_last_error.restype = C.c_char_p
+        L.fvh_ndt_last_error.restype = C.c_char_p
+        _LIB = L
+    return _LIB
+
+
+def declared_symbols():
+    """Every function declared in include/fast_vgicp_hip.h (parsed from the header)."""
+    import re
+    hdr = open(_build.HEADER).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    return sorted(set(re.findall(r"\b(fvh_[a-z0-9_]+)\s*\(", hdr)))
+
+
+def _f32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def _colmajor16(T):
+    return np.ascontiguousarray(np.asarray(T, dtype=np.float64).reshape(4, 4).T)
+
+
+def _lm_params(max_iterations=64, rotation_epsilon=2e-3, transformation_epsilon=5e-4, lm_max_iterations=10, lm_init_lambda_factor=1e-9):
+    return LmParams(max_iterations, rotation_epsilon, transformation_epsilon, lm_max_iterations, lm_init_lambda_factor)
+
+
+def _result_dict(r):
+    return dict(T=np.array(r.T).reshape(4, 4).T.copy(), H=np.array(r.H).reshape(6, 6).T.copy(), final_error=r.final_error, converged=bool(r.converged),
+                nr_iterations=r.nr_iterations, iterations=r.nr_iterations + 1, num_linearize=r.num_linearize, num_error_evals=r.num_error_evals,
+                lm_failed=bool(r.lm_failed), num_launches=r.num_launches)
+
+
+class _Core:
+    _prefix = ""
+
+    def __init__(self, device=0):
+        self._lib = load()
+        self.h = C.c_void_p()
+        rc = getattr(self._lib, self._prefix + "create")(int(device), C.byref(self.h))
+        if rc != 0:
+            raise FvhError("%screate failed with status %d" % (self._prefix, rc))
+
+    def close(self):
+        if getattr(self, "h", None) is not None and self.h:
+            getattr(self._lib, self._prefix + "destroy")(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _call(self, name, *args):
+        rc = getattr(self._lib, self._prefix + name)(self.h, *args)
+        if rc != 0:
+            msg = getattr(self._lib, self._prefix + "last_error")(self.h)
+            raise FvhError("%s%s: status %d: %s" % (self._prefix, name, rc, msg.decode() if msg else ""))
+
+    # ---- shared API ----
+    def set_resolution(self, r):
+        self._call("set_resolution", C.c_double(r))
+
+    def set_neighbor_search_method(self, method, radius=-1.0):
+        self._call("set_neighbor_search_method", int(method), C.c_double(radius))
+
+    def set_precision(self, p):
+        self._call("set_precision", int(p))
+
+    def swap_source_and_target(self):
+        self._call("swap_source_and_target")
+
+    def set_source_cloud(self, xyz):
+        a = _f32(xyz)
+        self._call("set_source_cloud", _p(a), len(a))
+
+    def set_target_cloud(self, xyz):
+        a = _f32(xyz)
+        self._call("set_target_cloud", _p(a), len(a))
+
+    def set_source_cloud_device(self, ptr, n, stride=3):
+        self._call("set_source_cloud_device", C.c_void_p(ptr), int(n), int(stride))
+
+    def set_target_cloud_device(self, ptr, n, stride=3):
+        self._call("set_target_cloud_device", C.c_void_p(ptr), int(n), int(stride))
+
+    def update_correspondences(self, T):
+        t = _colmajor16(T)
+        self._call("update_correspondences", _p(t))
+
+    def compute_error(self, T, derivatives=True):
+        t = _colmajor16(T)
+        err = C.c_double(0)
+        if derivatives:
+            H = np.empty((6, 6), np.float64)
+            b = np.empty(6, np.float64)
+            self._call("compute_error", _p(t), _p(H), _p(b), C.byref(err))
+            return err.value, H.T.copy(), b
+        self._call("compute_error", _p(t), None, None, C.byref(err))
+        return err.value
+
+    def linearize(self, T):
+        """LsqRegistration::linearize of the reference wrappers: update_correspondences + compute_error."""
+        self.update_correspondences(T)
+        return self.compute_error(T, True)
+
+    def align(self, guess=None, **lm):
+        g = _colmajor16(np.eye(4) if guess is None else guess)
+        p = _lm_params(**lm)
+        r = LmResult()
+        self._call("align", _p(g), C.byref(p), C.byref(r))
+        return _result_dict(r)
+
+    def fitness_score(self, T, max_range=1.7976931348623157e308):
+        t = _colmajor16(T)
+        s = C.c_double(0)
+        self._call("fitness_score", _p(t), C.c_double(max_range), C.byref(s))
+        return s.value
+
+    def synchronize(self):
+        self._call("synchronize")
+
+    def comm_init(self, unique_id, nranks, rank):
+        buf = (C.c_char * 128).from_buffer_copy(bytes(unique_id))
+        self._call("comm_init", buf, int(nranks), int(rank))
+
+    def comm_destroy(self):
+        self._call("comm_destroy")
+
+    def get_num_correspondences(self):
+        n = C.c_int(0)
+        self._call("get_num_correspondences", C.byref(n))
+        return n.value
+
+
+def comm_unique_id():
+    buf = (C.c_char * 128)()
+    rc = load().fvh_comm_unique_id(buf)
+    if rc != 0:
+        raise FvhError("fvh_comm_unique_id failed: %d" % rc)
+    return bytes(buf)
+
+
+def device_count():
+    n = C.c_int(0)
+    rc = load().fvh_device_count(C.byref(n))
+    return n.value if rc == 0 else 0
+
+
+class VGICPCore(_Core):
+    """fast_gicp::cuda::FastVGICPCudaCore on the HIP engine (same method names, snake_case as in the .cuh)."""
+    _prefix = "fvh_vgicp_"
+
+    def set_kernel_params(self, kernel_width, kernel_max_dist):
+        self._call("set_kernel_params", C.c_double(kernel_width), C.c_double(kernel_max_dist))
+
+    def num_points(self, which):
+        n = C.c_int(0)
+        self._call("get_num_%s_points" % which, C.byref(n))
+        return n.value
+
+    def set_source_neighbors(self, k, idx):
+        a = np.ascontiguousarray(idx, np.int32)
+        self._call("set_source_neighbors", int(k), _p(a))
+
+    def set_target_neighbors(self, k, idx):
+        a = np.ascontiguousarray(idx, np.int32)
+        self._call("set_target_neighbors", int(k), _p(a))
+
+    def find_source_neighbors(self, k):
+        self._call("find_source_neighbors", int(k))
+
+    def find_target_neighbors(self, k):
+        self._call("find_target_neighbors", int(k))
+
+    def calculate_source_covariances(self, method=REG_PLANE):
+        self._call("calculate_source_covariances", int(method))
+
+    def calculate_target_covariances(self, method=REG_PLANE):
+        self._call("calculate_target_covariances", int(method))
+
+    def calculate_source_covariances_rbf(self, method=REG_PLANE):
+        self._call("calculate_source_covariances_rbf", int(method))
+
+    def calculate_target_covariances_rbf(self, method=REG_PLANE):
+        self._call("calculate_target_covariances_rbf", int(method))
+
+    def set_source_covariances(self, covs):
+        a = np.ascontiguousarray(covs, np.float64)
+        self._call("set_source_covariances", _p(a))
+
+    def set_target_covariances(self, covs):
+        a = np.ascontiguousarray(covs, np.float64)
+        self._call("set_target_covariances", _p(a))
+
+    def get_neighbors(self, which):
+        k = C.c_int(0)
+        self._call("get_%s_neighbors" % which, C.byref(k), None)
+        out = np.empty((self.num_points(which), k.value), np.int32)
+        self._call("get_%s_neighbors" % which, C.byref(k), _p(out))
+        return out
+
+    def get_covariances(self, which):
+        out = np.empty((self.num_points(which), 3, 3), np.float32)
+        self._call("get_%s_covariances" % which, _p(out))
+        return out
+
+    def create_target_voxelmap(self):
+        self._call("create_target_voxelmap")
+
+    def get_voxelmap(self):
+        n = C.c_int(0)
+        self._call("get_num_voxels", C.byref(n))
+        nv = n.value
+        coords = np.empty((nv, 3), np.int32)
+        num = np.empty(nv, np.int32)
+        means = np.empty((nv, 3), np.float32)
+        covs = np.empty((nv, 3, 3), np.float32)
+        self._call("get_voxel_coords", _p(coords))
+        self._call("get_voxel_num_points", _p(num))
+        self._call("get_voxel_means", _p(means))
+        self._call("get_voxel_covs", _p(covs))
+        return coords, num, means, covs
+
+    def get_voxel_correspondences(self):
+        n = self.get_num_correspondences()
+        out = np.empty((n, 2), np.int32)
+        self._call("get_voxel_correspondences", _p(out))
+        return out
+
+    def profile_enable(self, on=True):
+        self._call("profile_enable", int(on))
+
+    def profile_reset(self):
+        self._call("profile_reset")
+
+    def profile_get(self, cls):
+        ms = C.c_double(0)
+        n = C.c_int(0)
+        self._call("profile_get", cls.encode(), C.byref(ms), C.byref(n))
+        return ms.value, n.value
+
+
+class NDTCore(_Core):
+    """fast_gicp::cuda::NDTCudaCore on the HIP engine."""
+    _prefix = "fvh_ndt_"
+
+    def set_distance_mode(self, mode):
+        self._call("set_distance_mode", int(mode))
+
+    def create_voxelmaps(self):
+        self._call("create_voxelmaps")
+
+    def create_target_voxelmap(self):
+        self._call("create_target_voxelmap")
+
+    def create_source_voxelmap(self):
+        self._call("create_source_voxelmap")
+
+    def get_voxelmap(self, which):
+        w = 1 if which == "target" else 0
+        n = C.c_int(0)
+        self._call("get_num_voxels", w, C.byref(n))
+        nv = n.value
+        coords = np.empty((nv, 3), np.int32)
+        num = np.empty(nv, np.int32)
+        means = np.empty((nv, 3), np.float32)
+        covs = np.empty((nv, 3, 3), np.float32)
+        self._call("get_voxels", w, _p(coords), _p(num), _p(means), _p(covs))
+        return coords, num, means, covs

@@ -1,0 +1,210 @@
+// Register-resident small-matrix math for the gfx950 kernels. Everything is 3x3 / 6x6 and stays
+// in VGPRs (no MFMA, no LDS): symmetric matrices are 6 scalars (xx xy xz yy yz zz).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace fvh {
+
+template <typename T>
+struct Sym3 {  // symmetric 3x3
+  T xx, xy, xz, yy, yz, zz;
+};
+
+template <typename T>
+struct Vec3 {
+  T x, y, z;
+};
+
+// rigid pose: row-major rotation + translation
+template <typename T>
+struct Pose {
+  T r[9];
+  T t[3];
+};
+
+struct PoseD {  // kernel-argument form (always double; cast inside)
+  double r[9];
+  double t[3];
+};
+
+template <typename T>
+__device__ __forceinline__ Pose<T> pose_cast(const PoseD& p) {
+  Pose<T> q;
+#pragma unroll
+  for (int i = 0; i < 9; i++) q.r[i] = (T)p.r[i];
+#pragma unroll
+  for (int i = 0; i < 3; i++) q.t[i] = (T)p.t[i];
+  return q;
+}
+
+template <typename T>
+__device__ __forceinline__ Vec3<T> transform(const Pose<T>& P, const Vec3<T>& a) {
+  Vec3<T> q;
+  q.x = P.r[0] * a.x + P.r[1] * a.y + P.r[2] * a.z + P.t[0];
+  q.y = P.r[3] * a.x + P.r[4] * a.y + P.r[5] * a.z + P.t[1];
+  q.z = P.r[6] * a.x + P.r[7] * a.y + P.r[8] * a.z + P.t[2];
+  return q;
+}
+
+// R C R^T for symmetric C
+template <typename T>
+__device__ __forceinline__ Sym3<T> rotate_cov(const T* R, const Sym3<T>& C) {
+  // M = R C
+  T m00 = R[0] * C.xx + R[1] * C.xy + R[2] * C.xz, m01 = R[0] * C.xy + R[1] * C.yy + R[2] * C.yz, m02 = R[0] * C.xz + R[1] * C.yz + R[2] * C.zz;
+  T m10 = R[3] * C.xx + R[4] * C.xy + R[5] * C.xz, m11 = R[3] * C.xy + R[4] * C.yy + R[5] * C.yz, m12 = R[3] * C.xz + R[4] * C.yz + R[5] * C.zz;
+  T m20 = R[6] * C.xx + R[7] * C.xy + R[8] * C.xz, m21 = R[6] * C.xy + R[7] * C.yy + R[8] * C.yz, m22 = R[6] * C.xz + R[7] * C.yz + R[8] * C.zz;
+  Sym3<T> S;
+  S.xx = m00 * R[0] + m01 * R[1] + m02 * R[2];
+  S.xy = m00 * R[3] + m01 * R[4] + m02 * R[5];
+  S.xz = m00 * R[6] + m01 * R[7] + m02 * R[8];
+  S.yy = m10 * R[3] + m11 * R[4] + m12 * R[5];
+  S.yz = m10 * R[6] + m11 * R[7] + m12 * R[8];
+  S.zz = m20 * R[6] + m21 * R[7] + m22 * R[8];
+  return S;
+}
+
+// inverse of a symmetric 3x3 by cofactors (what Eigen's fixed-size inverse does)
+template <typename T>
+__device__ __forceinline__ Sym3<T> inverse(const Sym3<T>& A) {
+  Sym3<T> C;
+  C.xx = A.yy * A.zz - A.yz * A.yz;
+  C.xy = A.xz * A.yz - A.xy * A.zz;
+  C.xz = A.xy * A.yz - A.xz * A.yy;
+  C.yy = A.xx * A.zz - A.xz * A.xz;
+  C.yz = A.xy * A.xz - A.xx * A.yz;
+  C.zz = A.xx * A.yy - A.xy * A.xy;
+  T det = A.xx * C.xx + A.xy * C.xy + A.xz * C.xz;
+  T inv = (T)1 / det;
+  C.xx *= inv; C.xy *= inv; C.xz *= inv; C.yy *= inv; C.yz *= inv; C.zz *= inv;
+  return C;
+}
+
+template <typename T>
+__device__ __forceinline__ Vec3<T> mul(const Sym3<T>& M, const Vec3<T>& v) {
+  Vec3<T> r;
+  r.x = M.xx * v.x + M.xy * v.y + M.xz * v.z;
+  r.y = M.xy * v.x + M.yy * v.y + M.yz * v.z;
+  r.z = M.xz * v.x + M.yz * v.y + M.zz * v.z;
+  return r;
+}
+
+template <typename T>
+__device__ __forceinline__ Vec3<T> cross(const Vec3<T>& a, const Vec3<T>& b) {
+  Vec3<T> c;
+  c.x = a.y * b.z - a.z * b.y;
+  c.y = a.z * b.x - a.x * b.z;
+  c.z = a.x * b.y - a.y * b.x;
+  return c;
+}
+
+// Symmetric 3x3 eigen-decomposition, cyclic Jacobi, fp64. Eigenvalues ascending in w,
+// eigenvectors in the COLUMNS of V (row-major V[r*3+c]).
+__device__ inline void sym_eig3(const Sym3<double>& S, double w[3], double V[9]) {
+  double a00 = S.xx, a01 = S.xy, a02 = S.xz, a11 = S.yy, a12 = S.yz, a22 = S.zz;
+  double v[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+#define FVH_JACOBI_ROT(app, aqq, apq, arp, arq, p, q)                                   \
+  if (apq != 0.0) {                                                                      \
+    double theta = (aqq - app) / (2.0 * apq);                                            \
+    double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));    \
+    double c = 1.0 / sqrt(t * t + 1.0), s = t * c;                                       \
+    app -= t * apq;                                                                      \
+    aqq += t * apq;                                                                      \
+    apq = 0.0;                                                                           \
+    double rp = arp, rq = arq;                                                           \
+    arp = c * rp - s * rq;                                                               \
+    arq = s * rp + c * rq;                                                               \
+    _Pragma("unroll") for (int k = 0; k < 3; k++) {                                      \
+      double vp = v[k * 3 + p], vq = v[k * 3 + q];                                       \
+      v[k * 3 + p] = c * vp - s * vq;                                                    \
+      v[k * 3 + q] = s * vp + c * vq;                                                    \
+    }                                                                                    \
+  }
+  for (int sweep = 0; sweep < 12; sweep++) {
+    double off = a01 * a01 + a02 * a02 + a12 * a12;
+    double diag = a00 * a00 + a11 * a11 + a22 * a22;
+    if (off <= 1e-300 || off <= 1e-32 * diag) break;
+    FVH_JACOBI_ROT(a00, a11, a01, a02, a12, 0, 1)  // (p,q)=(0,1), r=2
+    FVH_JACOBI_ROT(a00, a22, a02, a01, a12, 0, 2)  // (0,2), r=1
+    FVH_JACOBI_ROT(a11, a22, a12, a01, a02, 1, 2)  // (1,2), r=0
+  }
+#undef FVH_JACOBI_ROT
+  // sort ascending (3-element network), permuting columns of v
+  double e0 = a00, e1 = a11, e2 = a22;
+  int i0 = 0, i1 = 1, i2 = 2;
+  if (e0 > e1) { double t = e0; e0 = e1; e1 = t; int ti = i0; i0 = i1; i1 = ti; }
+  if (e1 > e2) { double t = e1; e1 = e2; e2 = t; int ti = i1; i1 = i2; i2 = ti; }
+  if (e0 > e1) { double t = e0; e0 = e1; e1 = t; int ti = i0; i0 = i1; i1 = ti; }
+  w[0] = e0; w[1] = e1; w[2] = e2;
+#pragma unroll
+  for (int k = 0; k < 3; k++) {
+    double c0 = v[k * 3 + 0], c1 = v[k * 3 + 1], c2 = v[k * 3 + 2];
+    V[k * 3 + 0] = i0 == 0 ? c0 : (i0 == 1 ? c1 : c2);
+    V[k * 3 + 1] = i1 == 0 ? c0 : (i1 == 1 ? c1 : c2);
+    V[k * 3 + 2] = i2 == 0 ? c0 : (i2 == 1 ? c1 : c2);
+  }
+}
+
+// V diag(d) V^T
+__device__ __forceinline__ Sym3<double> vdvt(const double V[9], const double d[3]) {
+  Sym3<double> C;
+  C.xx = V[0] * d[0] * V[0] + V[1] * d[1] * V[1] + V[2] * d[2] * V[2];
+  C.xy = V[0] * d[0] * V[3] + V[1] * d[1] * V[4] + V[2] * d[2] * V[5];
+  C.xz = V[0] * d[0] * V[6] + V[1] * d[1] * V[7] + V[2] * d[2] * V[8];
+  C.yy = V[3] * d[0] * V[3] + V[4] * d[1] * V[4] + V[5] * d[2] * V[5];
+  C.yz = V[3] * d[0] * V[6] + V[4] * d[1] * V[7] + V[5] * d[2] * V[8];
+  C.zz = V[6] * d[0] * V[6] + V[7] * d[1] * V[7] + V[8] * d[2] * V[8];
+  return C;
+}
+
+// RegularizationMethod (ordinals of gicp_settings.hpp:7): reference CPU fast_gicp_impl.hpp:267-297,
+// GPU covariance_regularization.cu:34-124. NONE and NORMALIZED_MIN_EIG are unimplemented on the
+// reference GPU; implemented here with the CPU semantics.
+__device__ inline Sym3<double> regularize_cov(const Sym3<double>& C, int method) {
+  if (method == 0) return C;
+  if (method == 4) {  // FROBENIUS
+    Sym3<double> A = C;
+    A.xx += 1e-3; A.yy += 1e-3; A.zz += 1e-3;
+    Sym3<double> Ai = inverse(A);
+    double nrm = sqrt(Ai.xx * Ai.xx + Ai.yy * Ai.yy + Ai.zz * Ai.zz + 2.0 * (Ai.xy * Ai.xy + Ai.xz * Ai.xz + Ai.yz * Ai.yz));
+    double s = 1.0 / nrm;
+    Ai.xx *= s; Ai.xy *= s; Ai.xz *= s; Ai.yy *= s; Ai.yz *= s; Ai.zz *= s;
+    return inverse(Ai);
+  }
+  double w[3], V[9], d[3];
+  sym_eig3(C, w, V);
+  if (method == 3) { d[0] = 1e-3; d[1] = 1.0; d[2] = 1.0; }                                            // PLANE
+  else if (method == 1) { d[0] = fmax(w[0], 1e-3); d[1] = fmax(w[1], 1e-3); d[2] = fmax(w[2], 1e-3); }  // MIN_EIG
+  else { d[0] = fmax(w[0] / w[2], 1e-3); d[1] = fmax(w[1] / w[2], 1e-3); d[2] = fmax(w[2] / w[2], 1e-3); }  // NORMALIZED_MIN_EIG
+  return vdvt(V, d);
+}
+
+// ---- voxel keys -------------------------------------------------------------------------------
+// coord = floor(p / res - 0.5)  (fast_vgicp_voxel.hpp:158-160 / vector3_hash.cuh:35-38), packed 21
+// bits per axis into one 64-bit key so bucket claims are a single 64-bit CAS.
+#define FVH_EMPTY_KEY 0xFFFFFFFFFFFFFFFFull
+#define FVH_COORD_BIAS (1 << 20)
+
+__device__ __forceinline__ unsigned long long pack_key(int x, int y, int z) {
+  return (unsigned long long)(unsigned)(x + FVH_COORD_BIAS) | ((unsigned long long)(unsigned)(y + FVH_COORD_BIAS) << 21) |
+         ((unsigned long long)(unsigned)(z + FVH_COORD_BIAS) << 42);
+}
+__host__ __device__ __forceinline__ void unpack_key(unsigned long long k, int& x, int& y, int& z) {
+  x = (int)(k & 0x1FFFFF) - FVH_COORD_BIAS;
+  y = (int)((k >> 21) & 0x1FFFFF) - FVH_COORD_BIAS;
+  z = (int)((k >> 42) & 0x1FFFFF) - FVH_COORD_BIAS;
+}
+__device__ __forceinline__ bool coord_in_range(int x, int y, int z) {
+  return (unsigned)(x + FVH_COORD_BIAS) < (1u << 21) && (unsigned)(y + FVH_COORD_BIAS) < (1u << 21) && (unsigned)(z + FVH_COORD_BIAS) < (1u << 21);
+}
+// 64-bit mix (murmur3 finaliser); the bucket layout is private so the hash is ours to choose
+__device__ __forceinline__ unsigned hash_key(unsigned long long k) {
+  k ^= k >> 33;
+  k *= 0xff51afd7ed558ccdull;
+  k ^= k >> 33;
+  k *= 0xc4ceb9fe1a85ec53ull;
+  k ^= k >> 33;
+  return (unsigned)k;
+}
+
+}  // namespace fvh

@@ -1,0 +1,850 @@
+// libfast_vgicp_hip.so -- host side of the engine + the extern "C" boundary declared in
+// include/fast_vgicp_hip.h. Mirrors the sequencing of the reference's FastVGICPCudaCore
+// (src/fast_gicp/cuda/fast_vgicp_cuda.cu) and NDTCudaCore (src/fast_gicp/cuda/ndt_cuda.cu)
+// on top of the gfx950 kernels in kernels_*.hpp. No Thrust, no torch types, one HIP stream per handle.
+#include <hip/hip_runtime.h>
+#include <dlfcn.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "../../include/fast_vgicp_hip.h"
+#include "kernels_cost.hpp"
+#include "kernels_cov.hpp"
+#include "kernels_voxelmap.hpp"
+
+using namespace fvh;
+
+namespace {
+
+constexpr int MAX_COST_BLOCKS = 512;
+
+struct DevBuf {
+  void* p = nullptr;
+  size_t cap = 0;
+  hipError_t ensure(size_t bytes) {
+    if (bytes <= cap) return hipSuccess;
+    if (p) { hipError_t e = hipFree(p); p = nullptr; cap = 0; if (e != hipSuccess) return e; }
+    size_t want = bytes + bytes / 4 + 256;
+    hipError_t e = hipMalloc(&p, want);
+    if (e == hipSuccess) cap = want;
+    return e;
+  }
+  void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+  template <typename T> T* as() const { return reinterpret_cast<T*>(p); }
+};
+
+struct CloudDev {
+  int n = 0, k = 0;
+  DevBuf pts, cov, nbr;
+  bool has_pts = false, has_cov = false, has_nbr = false;
+  void swap(CloudDev& o) { std::swap(*this, o); }
+  void release() { pts.release(); cov.release(); nbr.release(); }
+};
+
+struct VoxelMapDev {
+  double res = 1.0;
+  unsigned capacity = 0;
+  DevBuf table, acc, occupied, compact_pts, compact_cov, counters;  // counters: [0] num_voxels [1] dropped
+  bool valid = false;
+  // lazily fetched host copies (getters only)
+  bool host_valid = false;
+  std::vector<uint4> h_table;
+  std::vector<int> h_occupied;
+  std::unordered_map<int, int> bucket_to_index;
+  void invalidate() { valid = false; host_valid = false; }
+  void release() { table.release(); acc.release(); occupied.release(); compact_pts.release(); compact_cov.release(); counters.release(); }
+};
+
+struct Profiler {
+  bool on = false;
+  struct Rec { std::vector<std::pair<hipEvent_t, hipEvent_t>> ev; size_t used = 0; };
+  std::map<std::string, Rec> recs;
+  hipEvent_t begin(const char* cls, hipStream_t s, hipEvent_t* stop_out) {
+    Rec& r = recs[cls];
+    if (r.used == r.ev.size()) {
+      hipEvent_t a, b;
+      (void)hipEventCreate(&a); (void)hipEventCreate(&b);
+      r.ev.push_back({a, b});
+    }
+    auto& pr = r.ev[r.used++];
+    (void)hipEventRecord(pr.first, s);
+    *stop_out = pr.second;
+    return pr.first;
+  }
+  void reset() { for (auto& kv : recs) kv.second.used = 0; }
+  void destroy() { for (auto& kv : recs) for (auto& pr : kv.second.ev) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); } recs.clear(); }
+};
+
+// RCCL is dlopen'ed on first use so single-GPU users never load it.
+struct Rccl {
+  struct UID { char b[128]; };  // ncclUniqueId (passed by value)
+  void* lib = nullptr;
+  int (*GetUniqueId)(void*) = nullptr;
+  int (*CommInitRank)(void**, int, UID, int) = nullptr;
+  int (*CommDestroy)(void*) = nullptr;
+  int (*AllReduce)(const void*, void*, size_t, int, int, void*, hipStream_t) = nullptr;
+  bool load() {
+    if (lib) return true;
+    lib = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+    if (!lib) lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+    if (!lib) return false;
+    GetUniqueId = (decltype(GetUniqueId))dlsym(lib, "ncclGetUniqueId");
+    CommInitRank = (decltype(CommInitRank))dlsym(lib, "ncclCommInitRank");
+    CommDestroy = (decltype(CommDestroy))dlsym(lib, "ncclCommDestroy");
+    AllReduce = (decltype(AllReduce))dlsym(lib, "ncclAllReduce");
+    return GetUniqueId && CommInitRank && CommDestroy && AllReduce;
+  }
+};
+Rccl g_rccl;
+
+struct Engine {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  std::string err;
+  int precision = FVH_COMPUTE_FP64;
+  std::vector<int> offsets_host{0, 0, 0};
+  int n_off = 1;
+  DevBuf offsets_dev, state, partials, ticket, corr, misc, fit, staging;
+  void* pinned = nullptr;  // sizeof(LmState) + slack
+  PoseD lin;               // pose of the last update_correspondences()
+  bool has_corr = false;
+  int corr_n_src = 0;
+  int last_steps = 0;
+  Profiler prof;
+  void* comm = nullptr;
+  int nranks = 1, rank = 0;
+
+  int fail(int code, const std::string& m) { err = m; return code; }
+  int hipfail(hipError_t e, const char* what) { err = std::string(what) + ": " + hipGetErrorString(e); return FVH_ERR_HIP; }
+
+  int init(int dev) {
+    device = dev;
+    hipError_t e = hipSetDevice(dev);
+    if (e != hipSuccess) return hipfail(e, "hipSetDevice");
+    if ((e = hipStreamCreateWithFlags(&stream, hipStreamNonBlocking)) != hipSuccess) return hipfail(e, "hipStreamCreate");
+    if ((e = hipHostMalloc(&pinned, sizeof(LmState) + 1024, hipHostMallocDefault)) != hipSuccess) return hipfail(e, "hipHostMalloc");
+    if ((e = state.ensure(sizeof(LmState))) != hipSuccess) return hipfail(e, "hipMalloc");
+    if ((e = partials.ensure(sizeof(double) * PART_STRIDE * MAX_COST_BLOCKS)) != hipSuccess) return hipfail(e, "hipMalloc");
+    if ((e = ticket.ensure(64)) != hipSuccess) return hipfail(e, "hipMalloc");
+    if ((e = misc.ensure(256)) != hipSuccess) return hipfail(e, "hipMalloc");
+    if ((e = fit.ensure(64)) != hipSuccess) return hipfail(e, "hipMalloc");
+    (void)hipMemsetAsync(state.p, 0, sizeof(LmState), stream);
+    (void)hipMemsetAsync(ticket.p, 0, 64, stream);
+    (void)hipMemsetAsync(misc.p, 0, 256, stream);
+    std::memset(&lin, 0, sizeof(lin));
+    lin.r[0] = lin.r[4] = lin.r[8] = 1.0;
+    int rc = upload_offsets();
+    if (rc) return rc;
+    if ((e = hipStreamSynchronize(stream)) != hipSuccess) return hipfail(e, "hipStreamSynchronize");  // "warming up GPU" (fast_vgicp_cuda.cu:19-20)
+    return FVH_OK;
+  }
+  void shutdown() {
+    (void)hipSetDevice(device);
+    if (stream) (void)hipStreamSynchronize(stream);
+    if (comm && g_rccl.CommDestroy) g_rccl.CommDestroy(comm);
+    comm = nullptr;
+    prof.destroy();
+    offsets_dev.release(); state.release(); partials.release(); ticket.release(); corr.release(); misc.release(); fit.release(); staging.release();
+    if (pinned) (void)hipHostFree(pinned);
+    if (stream) (void)hipStreamDestroy(stream);
+  }
+  int upload_offsets() {
+    hipError_t e = offsets_dev.ensure(offsets_host.size() * sizeof(int));
+    if (e != hipSuccess) return hipfail(e, "hipMalloc");
+    e = hipMemcpyAsync(offsets_dev.p, offsets_host.data(), offsets_host.size() * sizeof(int), hipMemcpyHostToDevice, stream);
+    if (e != hipSuccess) return hipfail(e, "hipMemcpyAsync");
+    e = hipStreamSynchronize(stream);  // offsets_host may be reassigned by the caller right after
+    if (e != hipSuccess) return hipfail(e, "hipStreamSynchronize");
+    has_corr = false;
+    return FVH_OK;
+  }
+  // FastVGICPCudaCore::set_neighbor_search_method (fast_vgicp_cuda.cu:41-94)
+  int set_offsets(int method, double radius) {
+    std::vector<int> o;
+    switch (method) {
+      case FVH_DIRECT1: o = {0, 0, 0}; break;
+      case FVH_DIRECT7: o = {0, 0, 0, 1, 0, 0, -1, 0, 0, 0, 1, 0, 0, -1, 0, 0, 0, 1, 0, 0, -1}; break;
+      case FVH_DIRECT27:
+        for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) for (int k = 0; k < 3; k++) { o.push_back(i - 1); o.push_back(j - 1); o.push_back(k - 1); }
+        break;
+      case FVH_DIRECT_RADIUS: {
+        int range = (int)std::ceil(radius);
+        for (int i = -range; i <= range; i++) for (int j = -range; j <= range; j++) for (int k = -range; k <= range; k++)
+          if (std::sqrt((double)(i * i + j * j + k * k)) <= radius + 1e-3) { o.push_back(i); o.push_back(j); o.push_back(k); }
+        if (o.empty()) return fail(FVH_ERR_INVALID_ARGUMENT, "DIRECT_RADIUS: no offsets within radius");
+      } break;
+      default: return fail(FVH_ERR_INVALID_ARGUMENT, "unknown neighbor search method");
+    }
+    offsets_host = o;
+    n_off = (int)o.size() / 3;
+    return upload_offsets();
+  }
+};
+
+#define HIP_OR_FAIL(E, expr)                                   \
+  do {                                                         \
+    hipError_t _e = (expr);                                    \
+    if (_e != hipSuccess) return (E)->hipfail(_e, #expr);      \
+  } while (0)
+
+struct ProfScope {
+  Engine* e; hipEvent_t stop = nullptr;
+  ProfScope(Engine* e_, const char* cls) : e(e_) { if (e->prof.on) e->prof.begin(cls, e->stream, &stop); }
+  ~ProfScope() { if (stop) (void)hipEventRecord(stop, e->stream); }
+};
+
+inline PoseD pose_from_colmajor16(const double* T) {
+  PoseD p;
+  for (int i = 0; i < 3; i++) { for (int j = 0; j < 3; j++) p.r[i * 3 + j] = T[j * 4 + i]; p.t[i] = T[12 + i]; }
+  return p;
+}
+inline void pose_to_colmajor16(const PoseD& p, double* T) {
+  for (int i = 0; i < 3; i++) { for (int j = 0; j < 3; j++) T[j * 4 + i] = p.r[i * 3 + j]; T[12 + i] = p.t[i]; T[i * 4 + 3] = 0.0; }
+  T[15] = 1.0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// shared building blocks
+// ---------------------------------------------------------------------------------------------
+int upload_cloud(Engine* e, CloudDev& c, const float* xyz, int n, int stride, bool on_device) {
+  if (n < 0 || (n > 0 && !xyz)) return e->fail(FVH_ERR_INVALID_ARGUMENT, "set_cloud: null points");
+  if (stride != 3 && stride != 4) return e->fail(FVH_ERR_INVALID_ARGUMENT, "set_cloud: stride must be 3 or 4 floats");
+  HIP_OR_FAIL(e, c.pts.ensure(sizeof(float4) * (size_t)std::max(n, 1)));
+  c.n = n;
+  c.has_pts = true;
+  if (n == 0) return FVH_OK;
+  if (on_device) {
+    pack_points_kernel<<<(n + 255) / 256, 256, 0, e->stream>>>(xyz, n, stride, c.pts.as<float4>());
+    HIP_OR_FAIL(e, hipGetLastError());
+  } else {
+    // H2D the packed xyz into a staging buffer, then widen to float4 on device
+    HIP_OR_FAIL(e, e->staging.ensure(sizeof(float) * 3 * (size_t)n));
+    HIP_OR_FAIL(e, hipMemcpyAsync(e->staging.p, xyz, sizeof(float) * 3 * (size_t)n, hipMemcpyHostToDevice, e->stream));
+    pack_points_kernel<<<(n + 255) / 256, 256, 0, e->stream>>>(e->staging.as<float>(), n, 3, c.pts.as<float4>());
+    HIP_OR_FAIL(e, hipGetLastError());
+    HIP_OR_FAIL(e, hipStreamSynchronize(e->stream));  // caller may free xyz on return (reference copies too)
+  }
+  return FVH_OK;
+}
+
+int set_neighbors(Engine* e, CloudDev& c, int k, const int* idx) {
+  if (!c.has_pts) return e->fail(FVH_ERR_BAD_STATE, "set_neighbors: cloud not set");
+  if (k <= 0 || !idx) return e->fail(FVH_ERR_INVALID_ARGUMENT, "set_neighbors: bad k / null");
+  HIP_OR_FAIL(e, c.nbr.ensure(sizeof(int) * (size_t)c.n * k));
+  HIP_OR_FAIL(e, hipMemcpyAsync(c.nbr.p, idx, sizeof(int) * (size_t)c.n * k, hipMemcpyHostToDevice, e->stream));
+  HIP_OR_FAIL(e, hipStreamSynchronize(e->stream));
+  c.k = k;
+  c.has_nbr = true;
+  return FVH_OK;
+}
+
+int find_neighbors(Engine* e, CloudDev& c, int k) {
+  if (!c.has_pts) return e->fail(FVH_ERR_BAD_STATE, "find_neighbors: cloud not set");
+  if (k <= 0 || k > 64) return e->fail(FVH_ERR_INVALID_ARGUMENT, "find_neighbors: k must be in [1, 64]");
+  if (c.n < k) return e->fail(FVH_ERR_INVALID_ARGUMENT, "find_neighbors: fewer points than k");
+  HIP_OR_FAIL(e, c.nbr.ensure(sizeof(int) * (size_t)c.n * k));
+  {
+    ProfScope ps(e, "knn");
+    const int waves = (c.n + KNN_Q - 1) / KNN_Q;
+    knn_bruteforce_kernel<<<(waves + 3) / 4, 256, 0, e->stream>>>(c.pts.as<float4>(), c.n, k, c.nbr.as<int>());
+  }
+  HIP_OR_FAIL(e, hipGetLastError());
+  c.k = k;
+  c.has_nbr = true;
+  return FVH_OK;
+}
+
+int calc_cov_knn(Engine* e, CloudDev& c, int method) {
+  if (!c.has_pts || !c.has_nbr) return e->fail(FVH_ERR_BAD_STATE, "calculate_covariances: cloud or neighbours not set");
+  if (method < 0 || method > 4) return e->fail(FVH_ERR_INVALID_ARGUMENT, "unknown regularization method");
+  HIP_OR_FAIL(e, c.cov.ensure(sizeof(float4) * 2 * (size_t)std::max(c.n, 1)));
+  if (c.n) {
+    ProfScope ps(e, "cov");
+    cov_from_neighbors_kernel<<<(c.n + 255) / 256, 256, 0, e->stream>>>(c.pts.as<float4>(), c.n, c.k, c.nbr.as<int>(), method, c.cov.as<float4>());
+  }
+  HIP_OR_FAIL(e, hipGetLastError());
+  c.has_cov = true;
+  return FVH_OK;
+}
+
+int calc_cov_rbf(Engine* e, CloudDev& c, double kernel_width, double max_dist, int method) {
+  if (!c.has_pts) return e->fail(FVH_ERR_BAD_STATE, "calculate_covariances_rbf: cloud not set");
+  if (method < 0 || method > 4) return e->fail(FVH_ERR_INVALID_ARGUMENT, "unknown regularization method");
+  HIP_OR_FAIL(e, c.cov.ensure(sizeof(float4) * 2 * (size_t)std::max(c.n, 1)));
+  if (c.n) {
+    ProfScope ps(e, "rbf");
+    const int waves = (c.n + RBF_Q - 1) / RBF_Q;
+    const float md = (float)max_dist;
+    cov_rbf_kernel<<<(waves + 3) / 4, 256, 0, e->stream>>>(c.pts.as<float4>(), c.n, (float)kernel_width, md * md, method, c.cov.as<float4>());
+  }
+  HIP_OR_FAIL(e, hipGetLastError());
+  c.has_cov = true;
+  return FVH_OK;
+}
+
+int set_cov_host(Engine* e, CloudDev& c, const double* covs9) {
+  if (!c.has_pts) return e->fail(FVH_ERR_BAD_STATE, "set_covariances: cloud not set");
+  if (!covs9) return e->fail(FVH_ERR_INVALID_ARGUMENT, "set_covariances: null");
+  std::vector<float4> h(2 * (size_t)c.n);
+  for (int i = 0; i < c.n; i++) {
+    const double* m = covs9 + 9 * (size_t)i;
+    h[2 * i] = make_float4((float)m[0], (float)m[1], (float)m[2], (float)m[4]);
+    h[2 * i + 1] = make_float4((float)m[5], (float)m[8], 0.f, 0.f);
+  }
+  HIP_OR_FAIL(e, c.cov.ensure(sizeof(float4) * 2 * (size_t)std::max(c.n, 1)));
+  HIP_OR_FAIL(e, hipMemcpyAsync(c.cov.p, h.data(), sizeof(float4) * h.size(), hipMemcpyHostToDevice, e->stream));
+  HIP_OR_FAIL(e, hipStreamSynchronize(e->stream));
+  c.has_cov = true;
+  return FVH_OK;
+}
+
+int get_cov_host(Engine* e, CloudDev& c, float* covs9) {
+  if (!c.has_cov) return e->fail(FVH_ERR_BAD_STATE, "get_covariances: covariances not computed");
+  std::vector<float4> h(2 * (size_t)c.n);
+  HIP_OR_FAIL(e, hipMemcpyAsync(h.data(), c.cov.p, sizeof(float4) * h.size(), hipMemcpyDeviceToHost, e->stream));
+  HIP_OR_FAIL(e, hipStreamSynchronize(e->stream));
+  for (int i = 0; i < c.n; i++) {
+    const float4 a = h[2 * i], b = h[2 * i + 1];
+    float* m = covs9 + 9 * (size_t)i;
+    m[0] = a.x; m[1] = a.y; m[2] = a.z; m[3] = a.y; m[4] = a.w; m[5] = b.x; m[6] = a.z; m[7] = b.x; m[8] = b.y;
+  }
+  return FVH_OK;
+}
+
+int get_nbr_host(Engine* e, CloudDev& c, int* k, int* out) {
+  if (!c.has_nbr) return e->fail(FVH_ERR_BAD_STATE, "get_neighbors: neighbours not set");
+  if (k) *k = c.k;
+  if (out) {
+    HIP_OR_FAIL(e, hipMemcpyAsync(out, c.nbr.p, sizeof(int) * (size_t)c.n * c.k, hipMemcpyDeviceToHost, e->stream));
+    HIP_OR_FAIL(e, hipStreamSynchronize(e->stream));
+  }
+  return FVH_OK;
+}
+
+// GaussianVoxelMap::create_voxelmap (gaussian_voxelmap.cu:208-257) -- two kernels, no retry loop
+template <int MODE>
+int build_voxelmap(Engine* e, const CloudDev& c, VoxelMapDev& vm, double res, bool want_compact) {
+  if (!c.has_pts) return e->fail(FVH_ERR_BAD_STATE, "create_voxelmap: cloud not set");
+  if (MODE == 0 && !c.has_cov) return e->fail(FVH_ERR_BAD_STATE, "create_voxelmap: covariances not computed");
+  if (!(res > 0)) return e->fail(FVH_ERR_INVALID_ARGUMENT, "create_voxelmap: resolution must be > 0");
+  unsigned cap = 1024;
+  while (cap < 2u * (unsigned)std::max(c.n, 1)) cap <<= 1;
+  vm.res = res;
+  vm.capacity = cap;
+  vm.invalidate();
+  HIP_OR_FAIL(e, vm.table.ensure((size_t)cap * 64));
+  HIP_OR_FAIL(e, vm.acc.ensure((size_t)cap * VM_ACC_STRIDE * sizeof(double)));
+  HIP_OR_FAIL(e, vm.occupied.ensure(sizeof(int) * (size_t)std::max(c.n, 1)));
+  HIP_OR_FAIL(e, vm.counters.ensure(64));
+  if (want_compact) {
+    HIP_OR_FAIL(e, vm.compact_pts.ensure(sizeof(float4) * (size_t)std::max(c.n, 1)));
+    HIP_OR_FAIL(e, vm.compact_cov.ensure(sizeof(float4) * 2 * (size_t)std::max(c.n, 1)));
+  }
+  {
+    ProfScope ps(e, "voxelmap");
+    HIP_OR_FAIL(e, hipMemsetAsync(vm.table.p, 0xFF, (size_t)cap * 64, e->stream));
+    HIP_OR_FAIL(e, hipMemsetAsync(vm.acc.p, 0, (size_t)cap * VM_ACC_STRIDE * sizeof(double), e->stream));
+    HIP_OR_FAIL(e, hipMemsetAsync(vm.counters.p, 0, 64, e->stream));
+    if (c.n) {
+      vm_accumulate_kernel<MODE><<<(c.n + 255) / 256, 256, 0, e->stream>>>(c.pts.as<float4>(), c.cov.as<float4>(), c.n, res, vm.table.as<unsigned long long>(), cap - 1,
+                                                                           vm.acc.as<double>(), vm.counters.as<int>() + 1);
+      vm_finalize_kernel<MODE><<<(cap + 255) / 256, 256, 0, e->stream>>>(vm.table.as<uint4>(), cap, vm.acc.as<double>(), vm.counters.as<int>(), vm.occupied.as<int>(),
+                                                                        want_compact ? vm.compact_pts.as<float4>() : nullptr, want_compact ? vm.compact_cov.as<float4>() : nullptr);
+    }
+  }
+  HIP_OR_FAIL(e, hipGetLastError());
+  vm.valid = true;
+  e->has_corr = false;
+  return FVH_OK;
+}
+
+int fetch_voxelmap_host(Engine* e, VoxelMapDev& vm) {
+  if (!vm.valid) return e->fail(FVH_ERR_BAD_STATE, "voxel map not built");
+  if (vm.host_valid) return FVH_OK;
+  int counters[2] = {0, 0};
+  HIP_OR_FAIL(e, hipMemcpyAsync(counters, vm.counters.p, sizeof(counters), hipMemcpyDeviceToHost, e->stream));
+  HIP_OR_FAIL(e, hipStreamSynchronize(e->stream));
+  vm.h_occupied.resize(counters[0]);
+  vm.h_table.resize((size_t)vm.capacity * 4);
+  if (counters[0]) HIP_OR_FAIL(e, hipMemcpyAsync(vm.h_occupied.data(), vm.occupied.p, sizeof(int) * counters[0], hipMemcpyDeviceToHost, e->stream));
+  HIP_OR_FAIL(e, hipMemcpyAsync(vm.h_table.data(), vm.table.p, (size_t)vm.capacity * 64, hipMemcpyDeviceToHost, e->stream));
+  HIP_OR_FAIL(e, hipStreamSynchronize(e->stream));
+  vm.bucket_to_index.clear();
+  for (int i = 0; i < counters[0]; i++) vm.bucket_to_index[vm.h_occupied[i]] = i;
+  vm.host_valid = true;
+  return FVH_OK;
+}
+
+int get_voxels_host(Engine* e, VoxelMapDev& vm, int* coords3, int* num_points, float* means3, float* covs9) {
+  int rc = fetch_voxelmap_host(e, vm);
+  if (rc) return rc;
+  for (size_t i = 0; i < vm.h_occupied.size(); i++) {
+    const uint4* q = &vm.h_table[(size_t)vm.h_occupied[i] * 4];
+    if (coords3) {
+      unsigned long long key = (unsigned long long)q[0].x | ((unsigned long long)q[0].y << 32);
+      unpack_key(key, coords3[3 * i], coords3[3 * i + 1], coords3[3 * i + 2]);
+    }
+    if (num_points) num_points[i] = (int)q[0].z;
+    const float* f1 = reinterpret_cast<const float*>(&q[1]);
+    const float* f2 = reinterpret_cast<const float*>(&q[2]);
+    const float* f3 = reinterpret_cast<const float*>(&q[3]);
+    if (means3) { means3[3 * i] = f1[0]; means3[3 * i + 1] = f1[1]; means3[3 * i + 2] = f1[2]; }
+    if (covs9) {
+      float* m = covs9 + 9 * i;
+      m[0] = f2[0]; m[1] = f2[1]; m[2] = f2[2]; m[3] = f2[1]; m[4] = f2[3]; m[5] = f3[0]; m[6] = f2[2]; m[7] = f3[0]; m[8] = f3[1];
+    }
+  }
+  return FVH_OK;
+}
+
+struct CostSource {
+  const float4* pts; const float4* cov; const int* d_n; int n_upper;
+};
+
+template <int MODE>
+int launch_cost(Engine* e, const CostSource& src, const VoxelMapDev& vm, int host_phase, const PoseD* lin, const PoseD* ev) {
+  CostParams P;
+  std::memset(&P, 0, sizeof(P));
+  P.src_pts = src.pts; P.src_cov = src.cov; P.d_n_src = src.d_n; P.n_src = src.n_upper;
+  P.table = vm.table.as<uint4>(); P.mask = vm.capacity - 1; P.res = vm.res;
+  P.offsets = e->offsets_dev.as<int>(); P.n_off = e->n_off;
+  const long long target_items = 256LL * 256 * 2;
+  int groups = (int)std::min<long long>(e->n_off, std::max<long long>(1, target_items / std::max(src.n_upper, 1)));
+  P.group = (e->n_off + groups - 1) / groups;
+  P.groups_per_src = (e->n_off + P.group - 1) / P.group;
+  P.corr = e->corr.as<int>();
+  P.st = e->state.as<LmState>(); P.partials = e->partials.as<double>(); P.ticket = e->ticket.as<unsigned>();
+  P.d_num_corr = e->misc.as<int>();
+  P.host_phase = host_phase;
+  P.defer_lm = (e->comm != nullptr) ? 1 : 0;
+  if (lin) P.lin = *lin;
+  if (ev) P.ev = *ev;
+  const long long items = (long long)src.n_upper * P.groups_per_src;
+  const int blocks = (int)std::max<long long>(1, std::min<long long>(MAX_COST_BLOCKS, (items + 255) / 256));
+  {
+    ProfScope ps(e, "cost");
+    if (e->precision == FVH_COMPUTE_FP32) cost_kernel<float, MODE><<<blocks, 256, 0, e->stream>>>(P);
+    else cost_kernel<double, MODE><<<blocks, 256, 0, e->stream>>>(P);
+  }
+  HIP_OR_FAIL(e, hipGetLastError());
+  return FVH_OK;
+}
+
+int allreduce_sums(Engine* e) {
+  LmState* st = e->state.as<LmState>();
+  int rc = g_rccl.AllReduce(st->sums, st->sums, PART_STRIDE, /*ncclDouble*/ 8, /*ncclSum*/ 0, e->comm, e->stream);
+  if (rc != 0) return e->fail(FVH_ERR_COMM, "ncclAllReduce failed with code " + std::to_string(rc));
+  return FVH_OK;
+}
+
+template <int MODE>
+int do_update_correspondences(Engine* e, const CostSource& src, const VoxelMapDev& vm, const double* T16) {
+  if (!T16) return e->fail(FVH_ERR_INVALID_ARGUMENT, "update_correspondences: null pose");
+  if (!vm.valid) return e->fail(FVH_ERR_BAD_STATE, "update_correspondences: target voxel map not built");
+  HIP_OR_FAIL(e, e->corr.ensure(sizeof(int) * (size_t)std::max(src.n_upper, 1) * e->n_off));
+  e->lin = pose_from_colmajor16(T16);
+  HIP_OR_FAIL(e, hipMemsetAsync(e->misc.p, 0, sizeof(int), e->stream));
+  int rc = launch_cost<MODE>(e, src, vm, PH_FIND_ONLY, &e->lin, &e->lin);
+  if (rc) return rc;
+  e->has_corr = true;
+  e->corr_n_src = src.n_upper;
+  return FVH_OK;
+}
+
+template <int MODE>
+int do_compute_error(Engine* e, const CostSource& src, const VoxelMapDev& vm, const double* T16, double* H36, double* b6, double* error) {
+  if (!T16 || !error) return e->fail(FVH_ERR_INVALID_ARGUMENT, "compute_error: null argument");
+  if (!e->has_corr) return e->fail(FVH_ERR_BAD_STATE, "compute_error: call update_correspondences first");
+  const bool deriv = (H36 != nullptr && b6 != nullptr);
+  PoseD ev = pose_from_colmajor16(T16);
+  int rc = launch_cost<MODE>(e, src, vm, deriv ? PH_EVAL_DERIV : PH_EVAL_ERROR, &e->lin, &ev);
+  if (rc) return rc;
+  if (e->comm) { rc = allreduce_sums(e); if (rc) return rc; }
+  double* h = reinterpret_cast<double*>(e->pinned);
+  HIP_OR_FAIL(e, hipMemcpyAsync(h, e->state.as<LmState>()->sums, sizeof(double) * PART_STRIDE, hipMemcpyDeviceToHost, e->stream));
+  HIP_OR_FAIL(e, hipStreamSynchronize(e->stream));
+  *error = h[0];
+  if (deriv) {
+    double Hr[36];
+    unpack_sums(h, Hr, b6);
+    for (int i = 0; i < 6; i++) for (int j = 0; j < 6; j++) H36[j * 6 + i] = Hr[i * 6 + j];  // column-major (symmetric)
+  }
+  return FVH_OK;
+}
+
+template <int MODE>
+int do_align(Engine* e, const CostSource& src, const VoxelMapDev& vm, const double* guess16, const fvh_lm_params* params, fvh_lm_result* result) {
+  if (!guess16 || !result) return e->fail(FVH_ERR_INVALID_ARGUMENT, "align: null argument");
+  if (!vm.valid) return e->fail(FVH_ERR_BAD_STATE, "align: target voxel map not built");
+  fvh_lm_params p;
+  if (params) p = *params; else fvh_default_lm_params(&p);
+  HIP_OR_FAIL(e, e->corr.ensure(sizeof(int) * (size_t)std::max(src.n_upper, 1) * e->n_off));
+  LmState* st = e->state.as<LmState>();
+  lm_init_kernel<<<1, 64, 0, e->stream>>>(st, pose_from_colmajor16(guess16), p.rotation_epsilon, p.transformation_epsilon, p.lm_init_lambda_factor, p.max_iterations,
+                                          p.lm_max_iterations, e->ticket.as<unsigned>());
+  HIP_OR_FAIL(e, hipGetLastError());
+  const long long budget = (long long)std::max(p.max_iterations, 0) * (1 + (long long)std::max(p.lm_max_iterations, 0)) + 1;
+  long long launched = 0;
+  int batch = e->last_steps > 0 ? e->last_steps + 1 : 12;
+  LmState* h = reinterpret_cast<LmState*>(e->pinned);
+  while (true) {
+    for (int s = 0; s < batch; s++) {
+      int rc = launch_cost<MODE>(e, src, vm, -1, nullptr, nullptr);
+      if (rc) return rc;
+      if (e->comm) {
+        rc = allreduce_sums(e);
+        if (rc) return rc;
+        lm_update_kernel<<<1, 64, 0, e->stream>>>(st);
+      }
+    }
+    launched += batch;
+    HIP_OR_FAIL(e, hipMemcpyAsync(h, st, sizeof(LmState), hipMemcpyDeviceToHost, e->stream));
+    HIP_OR_FAIL(e, hipStreamSynchronize(e->stream));
+    if (h->phase == PH_DONE || launched >= budget) break;
+    batch = 4;
+  }
+  e->last_steps = h->num_linearize + h->num_error_evals;
+  e->lin = h->x0;
+  e->has_corr = true;  // correspondences of the last linearisation stay valid for compute_error()
+  e->corr_n_src = src.n_upper;
+  pose_to_colmajor16(h->x0, result->T);
+  for (int i = 0; i < 6; i++) for (int j = 0; j < 6; j++) result->H[j * 6 + i] = h->final_H[i * 6 + j];
+  result->final_error = h->y0;
+  result->converged = h->converged;
+  result->nr_iterations = h->nr_iterations;
+  result->num_linearize = h->num_linearize;
+  result->num_error_evals = h->num_error_evals;
+  result->lm_failed = h->lm_failed;
+  result->num_launches = (int)launched + 1;
+  return FVH_OK;
+}
+
+int do_fitness(Engine* e, const CloudDev& src, const CloudDev& tgt, const double* T16, double max_range, double* score) {
+  if (!T16 || !score) return e->fail(FVH_ERR_INVALID_ARGUMENT, "fitness_score: null argument");
+  if (!src.has_pts || !tgt.has_pts || src.n == 0 || tgt.n == 0) return e->fail(FVH_ERR_BAD_STATE, "fitness_score: clouds not set");
+  float T12[12];
+  for (int i = 0; i < 3; i++) { for (int j = 0; j < 3; j++) T12[i * 4 + j] = (float)T16[j * 4 + i]; T12[i * 4 + 3] = (float)T16[12 + i]; }
+  char* base = (char*)e->fit.p;
+  HIP_OR_FAIL(e, hipMemsetAsync(base, 0, 16, e->stream));
+  HIP_OR_FAIL(e, hipMemcpyAsync(base + 16, T12, sizeof(T12), hipMemcpyHostToDevice, e->stream));
+  {
+    ProfScope ps(e, "fitness");
+    const int waves = (src.n + FIT_Q - 1) / FIT_Q;
+    fitness_kernel<<<(waves + 3) / 4, 256, 0, e->stream>>>(src.pts.as<float4>(), src.n, tgt.pts.as<float4>(), tgt.n, (const float*)(base + 16), max_range, (double*)base);
+  }
+  HIP_OR_FAIL(e, hipGetLastError());
+  double out[2];
+  HIP_OR_FAIL(e, hipMemcpyAsync(out, base, 16, hipMemcpyDeviceToHost, e->stream));
+  HIP_OR_FAIL(e, hipStreamSynchronize(e->stream));
+  *score = out[1] > 0 ? out[0] / out[1] : 1.7976931348623157e308;
+  return FVH_OK;
+}
+
+int comm_init(Engine* e, const void* id128, int nranks, int rank) {
+  if (!id128 || nranks < 1 || rank < 0 || rank >= nranks) return e->fail(FVH_ERR_INVALID_ARGUMENT, "comm_init: bad arguments");
+  if (!g_rccl.load()) return e->fail(FVH_ERR_COMM, std::string("cannot load librccl.so: ") + (dlerror() ? dlerror() : "missing symbols"));
+  if (e->comm) { g_rccl.CommDestroy(e->comm); e->comm = nullptr; }
+  Rccl::UID uid;
+  std::memcpy(uid.b, id128, 128);
+  HIP_OR_FAIL(e, hipSetDevice(e->device));
+  int rc = g_rccl.CommInitRank(&e->comm, nranks, uid, rank);
+  if (rc != 0) { e->comm = nullptr; return e->fail(FVH_ERR_COMM, "ncclCommInitRank failed with code " + std::to_string(rc)); }
+  e->nranks = nranks; e->rank = rank;
+  return FVH_OK;
+}
+
+int profile_get(Engine* e, const char* cls, double* total_ms, int* launches) {
+  if (!cls) return e->fail(FVH_ERR_INVALID_ARGUMENT, "profile_get: null class");
+  HIP_OR_FAIL(e, hipStreamSynchronize(e->stream));
+  double tot = 0; int n = 0;
+  auto it = e->prof.recs.find(cls);
+  if (it != e->prof.recs.end())
+    for (size_t i = 0; i < it->second.used; i++) {
+      float ms = 0;
+      if (hipEventElapsedTime(&ms, it->second.ev[i].first, it->second.ev[i].second) == hipSuccess) { tot += ms; n++; }
+    }
+  if (total_ms) *total_ms = tot;
+  if (launches) *launches = n;
+  return FVH_OK;
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------
+// opaque handles
+// ---------------------------------------------------------------------------------------------
+struct fvh_vgicp {
+  Engine e;
+  double resolution = 1.0, kernel_width = 0.25, kernel_max_dist = 3.0;  // fast_vgicp_cuda.cu:22-26
+  CloudDev source, target;
+  VoxelMapDev voxelmap;
+  CostSource cost_source() const { return CostSource{source.pts.as<float4>(), source.cov.as<float4>(), nullptr, source.n}; }
+};
+
+struct fvh_ndt {
+  Engine e;
+  double resolution = 1.0;          // ndt_cuda.cu:15
+  int distance_mode = FVH_NDT_D2D;  // ndt_cuda.cu:21
+  CloudDev source, target;
+  VoxelMapDev source_vm, target_vm;
+  CostSource cost_source() const {
+    if (distance_mode == FVH_NDT_P2D) return CostSource{source.pts.as<float4>(), nullptr, nullptr, source.n};
+    return CostSource{source_vm.compact_pts.as<float4>(), source_vm.compact_cov.as<float4>(), source_vm.counters.as<int>(), source.n};
+  }
+};
+
+#define CHECK_HANDLE(h) \
+  if (!(h)) return FVH_ERR_INVALID_ARGUMENT; \
+  { hipError_t _e = hipSetDevice((h)->e.device); if (_e != hipSuccess) return (h)->e.hipfail(_e, "hipSetDevice"); }
+
+extern "C" {
+
+void fvh_default_lm_params(fvh_lm_params* p) {
+  if (!p) return;
+  p->max_iterations = 64; p->rotation_epsilon = 2e-3; p->transformation_epsilon = 5e-4; p->lm_max_iterations = 10; p->lm_init_lambda_factor = 1e-9;
+}
+int fvh_device_count(int* count) {
+  if (!count) return FVH_ERR_INVALID_ARGUMENT;
+  return hipGetDeviceCount(count) == hipSuccess ? FVH_OK : FVH_ERR_HIP;
+}
+
+// ---- VGICP -------------------------------------------------------------------------------------
+int fvh_vgicp_create(int device, fvh_vgicp** out) {
+  if (!out) return FVH_ERR_INVALID_ARGUMENT;
+  *out = nullptr;
+  fvh_vgicp* h = new (std::nothrow) fvh_vgicp();
+  if (!h) return FVH_ERR_HIP;
+  int rc = h->e.init(device);
+  if (rc) { std::fprintf(stderr, "fvh_vgicp_create: %s\n", h->e.err.c_str()); h->e.shutdown(); delete h; return rc; }
+  *out = h;
+  return FVH_OK;
+}
+int fvh_vgicp_destroy(fvh_vgicp* h) {
+  if (!h) return FVH_ERR_INVALID_ARGUMENT;
+  (void)hipSetDevice(h->e.device);
+  if (h->e.stream) (void)hipStreamSynchronize(h->e.stream);
+  h->source.release(); h->target.release(); h->voxelmap.release();
+  h->e.shutdown();
+  delete h;
+  return FVH_OK;
+}
+const char* fvh_vgicp_last_error(const fvh_vgicp* h) { return h ? h->e.err.c_str() : "null handle"; }
+int fvh_vgicp_set_resolution(fvh_vgicp* h, double r) { CHECK_HANDLE(h); if (!(r > 0)) return h->e.fail(FVH_ERR_INVALID_ARGUMENT, "resolution must be > 0"); h->resolution = r; return FVH_OK; }
+int fvh_vgicp_set_kernel_params(fvh_vgicp* h, double w, double d) { CHECK_HANDLE(h); h->kernel_width = w; h->kernel_max_dist = d; return FVH_OK; }
+int fvh_vgicp_set_neighbor_search_method(fvh_vgicp* h, int m, double radius) { CHECK_HANDLE(h); return h->e.set_offsets(m, radius); }
+int fvh_vgicp_set_precision(fvh_vgicp* h, int p) { CHECK_HANDLE(h); if (p != FVH_COMPUTE_FP64 && p != FVH_COMPUTE_FP32) return h->e.fail(FVH_ERR_INVALID_ARGUMENT, "bad precision"); h->e.precision = p; return FVH_OK; }
+
+int fvh_vgicp_create_target_voxelmap(fvh_vgicp* h) { CHECK_HANDLE(h); return build_voxelmap<0>(&h->e, h->target, h->voxelmap, h->resolution, false); }
+int fvh_vgicp_swap_source_and_target(fvh_vgicp* h) {
+  CHECK_HANDLE(h);
+  h->source.swap(h->target);
+  h->e.has_corr = false;
+  if (!h->target.has_pts || !h->target.has_cov) { h->voxelmap.invalidate(); return FVH_OK; }  // fast_vgicp_cuda.cu:102-104
+  return build_voxelmap<0>(&h->e, h->target, h->voxelmap, h->resolution, false);
+}
+static void cloud_replaced(CloudDev& c) { c.has_cov = false; c.has_nbr = false; }
+int fvh_vgicp_set_source_cloud(fvh_vgicp* h, const float* xyz, int n) { CHECK_HANDLE(h); h->e.has_corr = false; cloud_replaced(h->source); return upload_cloud(&h->e, h->source, xyz, n, 3, false); }
+int fvh_vgicp_set_target_cloud(fvh_vgicp* h, const float* xyz, int n) { CHECK_HANDLE(h); h->voxelmap.invalidate(); cloud_replaced(h->target); return upload_cloud(&h->e, h->target, xyz, n, 3, false); }
+int fvh_vgicp_set_source_cloud_device(fvh_vgicp* h, const float* d, int n, int stride) { CHECK_HANDLE(h); h->e.has_corr = false; cloud_replaced(h->source); return upload_cloud(&h->e, h->source, d, n, stride, true); }
+int fvh_vgicp_set_target_cloud_device(fvh_vgicp* h, const float* d, int n, int stride) { CHECK_HANDLE(h); h->voxelmap.invalidate(); cloud_replaced(h->target); return upload_cloud(&h->e, h->target, d, n, stride, true); }
+int fvh_vgicp_set_source_neighbors(fvh_vgicp* h, int k, const int* idx) { CHECK_HANDLE(h); return set_neighbors(&h->e, h->source, k, idx); }
+int fvh_vgicp_set_target_neighbors(fvh_vgicp* h, int k, const int* idx) { CHECK_HANDLE(h); return set_neighbors(&h->e, h->target, k, idx); }
+int fvh_vgicp_find_source_neighbors(fvh_vgicp* h, int k) { CHECK_HANDLE(h); return find_neighbors(&h->e, h->source, k); }
+int fvh_vgicp_find_target_neighbors(fvh_vgicp* h, int k) { CHECK_HANDLE(h); return find_neighbors(&h->e, h->target, k); }
+int fvh_vgicp_calculate_source_covariances(fvh_vgicp* h, int m) { CHECK_HANDLE(h); return calc_cov_knn(&h->e, h->source, m); }
+int fvh_vgicp_calculate_target_covariances(fvh_vgicp* h, int m) { CHECK_HANDLE(h); return calc_cov_knn(&h->e, h->target, m); }
+int fvh_vgicp_calculate_source_covariances_rbf(fvh_vgicp* h, int m) { CHECK_HANDLE(h); return calc_cov_rbf(&h->e, h->source, h->kernel_width, h->kernel_max_dist, m); }
+int fvh_vgicp_calculate_target_covariances_rbf(fvh_vgicp* h, int m) { CHECK_HANDLE(h); return calc_cov_rbf(&h->e, h->target, h->kernel_width, h->kernel_max_dist, m); }
+int fvh_vgicp_set_source_covariances(fvh_vgicp* h, const double* c) { CHECK_HANDLE(h); return set_cov_host(&h->e, h->source, c); }
+int fvh_vgicp_set_target_covariances(fvh_vgicp* h, const double* c) { CHECK_HANDLE(h); return set_cov_host(&h->e, h->target, c); }
+
+int fvh_vgicp_get_num_source_points(const fvh_vgicp* h, int* n) { if (!h || !n) return FVH_ERR_INVALID_ARGUMENT; *n = h->source.has_pts ? h->source.n : 0; return FVH_OK; }
+int fvh_vgicp_get_num_target_points(const fvh_vgicp* h, int* n) { if (!h || !n) return FVH_ERR_INVALID_ARGUMENT; *n = h->target.has_pts ? h->target.n : 0; return FVH_OK; }
+int fvh_vgicp_get_source_neighbors(fvh_vgicp* h, int* k, int* out) { CHECK_HANDLE(h); return get_nbr_host(&h->e, h->source, k, out); }
+int fvh_vgicp_get_target_neighbors(fvh_vgicp* h, int* k, int* out) { CHECK_HANDLE(h); return get_nbr_host(&h->e, h->target, k, out); }
+int fvh_vgicp_get_source_covariances(fvh_vgicp* h, float* c) { CHECK_HANDLE(h); return get_cov_host(&h->e, h->source, c); }
+int fvh_vgicp_get_target_covariances(fvh_vgicp* h, float* c) { CHECK_HANDLE(h); return get_cov_host(&h->e, h->target, c); }
+int fvh_vgicp_get_num_voxels(fvh_vgicp* h, int* n) { CHECK_HANDLE(h); if (!n) return FVH_ERR_INVALID_ARGUMENT; int rc = fetch_voxelmap_host(&h->e, h->voxelmap); if (rc) return rc; *n = (int)h->voxelmap.h_occupied.size(); return FVH_OK; }
+int fvh_vgicp_get_voxel_num_points(fvh_vgicp* h, int* o) { CHECK_HANDLE(h); return get_voxels_host(&h->e, h->voxelmap, nullptr, o, nullptr, nullptr); }
+int fvh_vgicp_get_voxel_means(fvh_vgicp* h, float* o) { CHECK_HANDLE(h); return get_voxels_host(&h->e, h->voxelmap, nullptr, nullptr, o, nullptr); }
+int fvh_vgicp_get_voxel_covs(fvh_vgicp* h, float* o) { CHECK_HANDLE(h); return get_voxels_host(&h->e, h->voxelmap, nullptr, nullptr, nullptr, o); }
+int fvh_vgicp_get_voxel_coords(fvh_vgicp* h, int* o) { CHECK_HANDLE(h); return get_voxels_host(&h->e, h->voxelmap, o, nullptr, nullptr, nullptr); }
+
+static int fetch_corr(Engine* e, int n_src, std::vector<int>& corr) {
+  if (!e->has_corr) return e->fail(FVH_ERR_BAD_STATE, "no correspondences: call update_correspondences first");
+  corr.resize((size_t)n_src * e->n_off);
+  if (corr.empty()) return FVH_OK;
+  HIP_OR_FAIL(e, hipMemcpyAsync(corr.data(), e->corr.p, sizeof(int) * corr.size(), hipMemcpyDeviceToHost, e->stream));
+  HIP_OR_FAIL(e, hipStreamSynchronize(e->stream));
+  return FVH_OK;
+}
+int fvh_vgicp_get_num_correspondences(fvh_vgicp* h, int* n) {
+  CHECK_HANDLE(h);
+  if (!n) return FVH_ERR_INVALID_ARGUMENT;
+  std::vector<int> corr;
+  int rc = fetch_corr(&h->e, h->e.corr_n_src, corr);
+  if (rc) return rc;
+  int c = 0;
+  for (int v : corr) c += (v >= 0);
+  *n = c;
+  return FVH_OK;
+}
+// offset-major then source index, invalid pairs removed: the order of find_voxel_correspondences.cu:93-110
+int fvh_vgicp_get_voxel_correspondences(fvh_vgicp* h, int* pairs) {
+  CHECK_HANDLE(h);
+  if (!pairs) return FVH_ERR_INVALID_ARGUMENT;
+  std::vector<int> corr;
+  int rc = fetch_corr(&h->e, h->e.corr_n_src, corr);
+  if (rc) return rc;
+  rc = fetch_voxelmap_host(&h->e, h->voxelmap);
+  if (rc) return rc;
+  size_t w = 0;
+  for (int o = 0; o < h->e.n_off; o++)
+    for (int i = 0; i < h->e.corr_n_src; i++) {
+      int b = corr[(size_t)i * h->e.n_off + o];
+      if (b < 0) continue;
+      pairs[2 * w] = i;
+      pairs[2 * w + 1] = h->voxelmap.bucket_to_index[b];
+      w++;
+    }
+  return FVH_OK;
+}
+
+int fvh_vgicp_update_correspondences(fvh_vgicp* h, const double* T) {
+  CHECK_HANDLE(h);
+  if (!h->source.has_pts || !h->source.has_cov) return h->e.fail(FVH_ERR_BAD_STATE, "update_correspondences: source cloud/covariances not set");
+  return do_update_correspondences<MODE_VGICP>(&h->e, h->cost_source(), h->voxelmap, T);
+}
+int fvh_vgicp_compute_error(fvh_vgicp* h, const double* T, double* H, double* b, double* err) {
+  CHECK_HANDLE(h);
+  return do_compute_error<MODE_VGICP>(&h->e, h->cost_source(), h->voxelmap, T, H, b, err);
+}
+int fvh_vgicp_align(fvh_vgicp* h, const double* guess, const fvh_lm_params* p, fvh_lm_result* r) {
+  CHECK_HANDLE(h);
+  if (!h->source.has_pts || !h->source.has_cov) return h->e.fail(FVH_ERR_BAD_STATE, "align: source cloud/covariances not set");
+  return do_align<MODE_VGICP>(&h->e, h->cost_source(), h->voxelmap, guess, p, r);
+}
+int fvh_vgicp_fitness_score(fvh_vgicp* h, const double* T, double max_range, double* score) { CHECK_HANDLE(h); return do_fitness(&h->e, h->source, h->target, T, max_range, score); }
+int fvh_vgicp_profile_enable(fvh_vgicp* h, int on) { CHECK_HANDLE(h); h->e.prof.on = on != 0; return FVH_OK; }
+int fvh_vgicp_profile_reset(fvh_vgicp* h) { CHECK_HANDLE(h); HIP_OR_FAIL(&h->e, hipStreamSynchronize(h->e.stream)); h->e.prof.reset(); return FVH_OK; }
+int fvh_vgicp_profile_get(fvh_vgicp* h, const char* cls, double* ms, int* n) { CHECK_HANDLE(h); return profile_get(&h->e, cls, ms, n); }
+int fvh_vgicp_synchronize(fvh_vgicp* h) { CHECK_HANDLE(h); HIP_OR_FAIL(&h->e, hipStreamSynchronize(h->e.stream)); return FVH_OK; }
+
+int fvh_comm_unique_id(void* id128) {
+  if (!id128) return FVH_ERR_INVALID_ARGUMENT;
+  if (!g_rccl.load()) return FVH_ERR_COMM;
+  return g_rccl.GetUniqueId(id128) == 0 ? FVH_OK : FVH_ERR_COMM;
+}
+int fvh_vgicp_comm_init(fvh_vgicp* h, const void* id, int nranks, int rank) { CHECK_HANDLE(h); return comm_init(&h->e, id, nranks, rank); }
+int fvh_vgicp_comm_destroy(fvh_vgicp* h) { CHECK_HANDLE(h); if (h->e.comm) { g_rccl.CommDestroy(h->e.comm); h->e.comm = nullptr; } h->e.nranks = 1; h->e.rank = 0; return FVH_OK; }
+
+// ---- NDT ---------------------------------------------------------------------------------------
+int fvh_ndt_create(int device, fvh_ndt** out) {
+  if (!out) return FVH_ERR_INVALID_ARGUMENT;
+  *out = nullptr;
+  fvh_ndt* h = new (std::nothrow) fvh_ndt();
+  if (!h) return FVH_ERR_HIP;
+  int rc = h->e.init(device);
+  if (!rc) rc = h->e.set_offsets(FVH_DIRECT7, 0.0);  // ndt_cuda.cu:22
+  if (rc) { std::fprintf(stderr, "fvh_ndt_create: %s\n", h->e.err.c_str()); h->e.shutdown(); delete h; return rc; }
+  *out = h;
+  return FVH_OK;
+}
+int fvh_ndt_destroy(fvh_ndt* h) {
+  if (!h) return FVH_ERR_INVALID_ARGUMENT;
+  (void)hipSetDevice(h->e.device);
+  if (h->e.stream) (void)hipStreamSynchronize(h->e.stream);
+  h->source.release(); h->target.release(); h->source_vm.release(); h->target_vm.release();
+  h->e.shutdown();
+  delete h;
+  return FVH_OK;
+}
+const char* fvh_ndt_last_error(const fvh_ndt* h) { return h ? h->e.err.c_str() : "null handle"; }
+int fvh_ndt_set_distance_mode(fvh_ndt* h, int m) { CHECK_HANDLE(h); if (m != FVH_NDT_P2D && m != FVH_NDT_D2D) return h->e.fail(FVH_ERR_INVALID_ARGUMENT, "bad distance mode"); h->distance_mode = m; h->e.has_corr = false; return FVH_OK; }
+int fvh_ndt_set_resolution(fvh_ndt* h, double r) { CHECK_HANDLE(h); if (!(r > 0)) return h->e.fail(FVH_ERR_INVALID_ARGUMENT, "resolution must be > 0"); h->resolution = r; return FVH_OK; }
+int fvh_ndt_set_neighbor_search_method(fvh_ndt* h, int m, double radius) { CHECK_HANDLE(h); return h->e.set_offsets(m, radius); }
+int fvh_ndt_set_precision(fvh_ndt* h, int p) { CHECK_HANDLE(h); if (p != FVH_COMPUTE_FP64 && p != FVH_COMPUTE_FP32) return h->e.fail(FVH_ERR_INVALID_ARGUMENT, "bad precision"); h->e.precision = p; return FVH_OK; }
+int fvh_ndt_swap_source_and_target(fvh_ndt* h) {
+  CHECK_HANDLE(h);
+  h->source.swap(h->target);
+  std::swap(h->source_vm, h->target_vm);
+  h->e.has_corr = false;
+  return FVH_OK;
+}
+int fvh_ndt_set_source_cloud(fvh_ndt* h, const float* xyz, int n) { CHECK_HANDLE(h); h->e.has_corr = false; h->source_vm.invalidate(); return upload_cloud(&h->e, h->source, xyz, n, 3, false); }
+int fvh_ndt_set_target_cloud(fvh_ndt* h, const float* xyz, int n) { CHECK_HANDLE(h); h->e.has_corr = false; h->target_vm.invalidate(); return upload_cloud(&h->e, h->target, xyz, n, 3, false); }
+int fvh_ndt_set_source_cloud_device(fvh_ndt* h, const float* d, int n, int s) { CHECK_HANDLE(h); h->e.has_corr = false; h->source_vm.invalidate(); return upload_cloud(&h->e, h->source, d, n, s, true); }
+int fvh_ndt_set_target_cloud_device(fvh_ndt* h, const float* d, int n, int s) { CHECK_HANDLE(h); h->e.has_corr = false; h->target_vm.invalidate(); return upload_cloud(&h->e, h->target, d, n, s, true); }
+int fvh_ndt_create_source_voxelmap(fvh_ndt* h) {
+  CHECK_HANDLE(h);
+  // a swapped-in target map has no compact arrays: rebuild in that case
+  if (h->distance_mode == FVH_NDT_P2D) return FVH_OK;  // ndt_cuda.cu:122
+  if (h->source_vm.valid && h->source_vm.compact_pts.p) return FVH_OK;
+  return build_voxelmap<1>(&h->e, h->source, h->source_vm, h->resolution, true);
+}
+int fvh_ndt_create_target_voxelmap(fvh_ndt* h) {
+  CHECK_HANDLE(h);
+  if (h->target_vm.valid) return FVH_OK;  // ndt_cuda.cu:133-135
+  return build_voxelmap<1>(&h->e, h->target, h->target_vm, h->resolution, true);
+}
+int fvh_ndt_create_voxelmaps(fvh_ndt* h) { int rc = fvh_ndt_create_source_voxelmap(h); if (rc) return rc; return fvh_ndt_create_target_voxelmap(h); }
+static int ndt_ready(fvh_ndt* h) {
+  if (!h->source.has_pts) return h->e.fail(FVH_ERR_BAD_STATE, "source cloud not set");
+  if (!h->target_vm.valid) return h->e.fail(FVH_ERR_BAD_STATE, "target voxel map not built (create_voxelmaps)");
+  if (h->distance_mode == FVH_NDT_D2D && !(h->source_vm.valid && h->source_vm.compact_pts.p)) return h->e.fail(FVH_ERR_BAD_STATE, "source voxel map not built (create_voxelmaps)");
+  return FVH_OK;
+}
+int fvh_ndt_update_correspondences(fvh_ndt* h, const double* T) {
+  CHECK_HANDLE(h);
+  int rc = ndt_ready(h); if (rc) return rc;
+  if (h->distance_mode == FVH_NDT_P2D) return do_update_correspondences<MODE_NDT_P2D>(&h->e, h->cost_source(), h->target_vm, T);
+  return do_update_correspondences<MODE_NDT_D2D>(&h->e, h->cost_source(), h->target_vm, T);
+}
+int fvh_ndt_compute_error(fvh_ndt* h, const double* T, double* H, double* b, double* err) {
+  CHECK_HANDLE(h);
+  int rc = ndt_ready(h); if (rc) return rc;
+  if (h->distance_mode == FVH_NDT_P2D) return do_compute_error<MODE_NDT_P2D>(&h->e, h->cost_source(), h->target_vm, T, H, b, err);
+  return do_compute_error<MODE_NDT_D2D>(&h->e, h->cost_source(), h->target_vm, T, H, b, err);
+}
+int fvh_ndt_align(fvh_ndt* h, const double* guess, const fvh_lm_params* p, fvh_lm_result* r) {
+  CHECK_HANDLE(h);
+  int rc = fvh_ndt_create_voxelmaps(h);  // NDTCuda::computeTransformation (ndt_cuda_impl.hpp:76-79)
+  if (rc) return rc;
+  rc = ndt_ready(h); if (rc) return rc;
+  if (h->distance_mode == FVH_NDT_P2D) return do_align<MODE_NDT_P2D>(&h->e, h->cost_source(), h->target_vm, guess, p, r);
+  return do_align<MODE_NDT_D2D>(&h->e, h->cost_source(), h->target_vm, guess, p, r);
+}
+int fvh_ndt_fitness_score(fvh_ndt* h, const double* T, double max_range, double* score) { CHECK_HANDLE(h); return do_fitness(&h->e, h->source, h->target, T, max_range, score); }
+int fvh_ndt_get_num_voxels(fvh_ndt* h, int which, int* n) {
+  CHECK_HANDLE(h);
+  if (!n) return FVH_ERR_INVALID_ARGUMENT;
+  VoxelMapDev& vm = which ? h->target_vm : h->source_vm;
+  int rc = fetch_voxelmap_host(&h->e, vm); if (rc) return rc;
+  *n = (int)vm.h_occupied.size();
+  return FVH_OK;
+}
+int fvh_ndt_get_voxels(fvh_ndt* h, int which, int* coords3, int* num_points, float* means3, float* covs9) {
+  CHECK_HANDLE(h);
+  return get_voxels_host(&h->e, which ? h->target_vm : h->source_vm, coords3, num_points, means3, covs9);
+}
+int fvh_ndt_get_num_correspondences(fvh_ndt* h, int* n) {
+  CHECK_HANDLE(h);
+  if (!n) return FVH_ERR_INVALID_ARGUMENT;
+  if (!h->e.has_corr) return h->e.fail(FVH_ERR_BAD_STATE, "no correspondences");
+  int v = 0;
+  HIP_OR_FAIL(&h->e, hipMemcpyAsync(&v, h->e.misc.p, sizeof(int), hipMemcpyDeviceToHost, h->e.stream));
+  HIP_OR_FAIL(&h->e, hipStreamSynchronize(h->e.stream));
+  *n = v;
+  return FVH_OK;
+}
+int fvh_ndt_synchronize(fvh_ndt* h) { CHECK_HANDLE(h); HIP_OR_FAIL(&h->e, hipStreamSynchronize(h->e.stream)); return FVH_OK; }
+int fvh_ndt_comm_init(fvh_ndt* h, const void* id, int nranks, int rank) { CHECK_HANDLE(h); return comm_init(&h->e, id, nranks, rank); }
+int fvh_ndt_comm_destroy(fvh_ndt* h) { CHECK_HANDLE(h); if (h->e.comm) { g_rccl.CommDestroy(h->e.comm); h->e.comm = nullptr; } h->e.nranks = 1; h->e.rank = 0; return FVH_OK; }
+
+}  // extern "C"

@@ -1,0 +1,426 @@
+// The GN/LM hot loop for gfx950: ONE kernel per linearize() / compute_error().
+//
+// Replaces SURVEY 2.2 K18-K23 + X2: find_voxel_correspondences (N_off launches + remove_if,
+// find_voxel_correspondences.cu:16-111), compute_derivatives (transform_reduce of 43-float tuples,
+// compute_derivatives.cu:18-184), the NDT variants (ndt_compute_derivatives.cu:33-231), the three
+// tiny H2D copies and the blocking D2H per evaluation, and -- in device-LM mode -- the host side
+// of LsqRegistration::step_lm (lsq_registration_impl.hpp:123-168).
+//
+// Work item = (source element i, offset group g). Adjacent lanes share the source element
+// (broadcast loads). Per item: transform, voxel coordinate (fp64 like the CPU reference or fp32 like
+// the CUDA one), probe the 64-B bucket table, Mahalanobis M = (C_B + R C_A R^T)^-1 with R of the
+// LINEARISATION pose (fast_vgicp_impl.hpp:101-115 caches it; compute_derivatives.cu:71-72), residual
+// and the 28 unique values {err, b(6), H_rr(6), H_rt(9), H_tt(6)} accumulated per thread in fp64
+// registers. 3x3/6x6 math stays in VGPRs (no MFMA). Reduction: wave shuffles -> LDS across the 4
+// waves -> one 28-double partial per workgroup written through to L2 (sc1) -> the LAST workgroup
+// (atomic ticket) sums the partials in a fixed order and, in device-LM mode, runs the LM step
+// (6x6 LDL^T, se3_exp, rho test, lambda schedule, convergence) so the next launch finds the new
+// pose in HBM. No host round trip inside the loop.
+#pragma once
+#include "dev_math.hpp"
+
+namespace fvh {
+
+constexpr int NSUM = 28;       // err(1) b(6) Hrr(6) Hrt(9) Htt(6)
+constexpr int PART_STRIDE = 32;
+
+enum CostMode { MODE_VGICP = 0, MODE_NDT_P2D = 1, MODE_NDT_D2D = 2 };
+enum Phase { PH_LINEARIZE = 0, PH_TRIAL = 1, PH_DONE = 2, PH_FIND_ONLY = 3, PH_EVAL_DERIV = 4, PH_EVAL_ERROR = 5 };
+
+struct LmState {
+  PoseD x0;        // current estimate == linearisation pose
+  PoseD xi;        // trial pose
+  PoseD delta;     // se3_exp(d) of the last step
+  double H[36], b[6], d[6];
+  double y0, lambda, nu;
+  double final_H[36];
+  double sums[PART_STRIDE];  // reduced {err, b, H...} of the last evaluation (all-reduced in multi-GPU mode)
+  // parameters
+  double rotation_epsilon, transformation_epsilon, lm_init_lambda_factor;
+  int max_iterations, lm_max_iterations;
+  // status
+  int phase, outer_iter, inner_iter, converged, lm_failed, num_linearize, num_error_evals, nr_iterations;
+  int num_correspondences;
+  int pad_;
+};
+
+struct CostParams {
+  const float4* src_pts;
+  const float4* src_cov;      // null for P2D
+  const int* d_n_src;         // device-side count (D2D source voxels) or null
+  int n_src;
+  const uint4* table;
+  unsigned mask;
+  double res;
+  const int* offsets;         // n_off x 3
+  int n_off;
+  int group;                  // offsets per work item
+  int groups_per_src;         // ceil(n_off / group)
+  int* corr;                  // [n_src][n_off] bucket index or -1
+  LmState* st;
+  double* partials;           // [gridDim.x][PART_STRIDE]
+  unsigned* ticket;
+  int* d_num_corr;            // optional counter of valid correspondences (find phases)
+  int host_phase;             // -1: device-LM mode (phase from st); else PH_FIND_ONLY / PH_EVAL_*
+  int defer_lm;               // 1: multi-GPU -- only publish st->sums, LM step runs after the all-reduce
+  PoseD lin, ev;              // host mode poses
+};
+
+// ------------------------------------------------------------------------------------------------
+// LM step on one thread (lsq_registration_impl.hpp:82-91,123-168; so3.hpp:58-104)
+// ------------------------------------------------------------------------------------------------
+__device__ inline void dev_se3_exp(const double a[6], PoseD& T) {
+  const double ox = a[0], oy = a[1], oz = a[2];
+  const double theta_sq = ox * ox + oy * oy + oz * oz;
+  double imag, real;
+  if (theta_sq < 1e-10) {
+    const double tq = theta_sq * theta_sq;
+    imag = 0.5 - 1.0 / 48.0 * theta_sq + 1.0 / 3840.0 * tq;
+    real = 1.0 - 1.0 / 8.0 * theta_sq + 1.0 / 384.0 * tq;
+  } else {
+    const double th = sqrt(theta_sq), half = 0.5 * th;
+    imag = sin(half) / th;
+    real = cos(half);
+  }
+  const double qw = real, qx = imag * ox, qy = imag * oy, qz = imag * oz;
+  const double tx = 2 * qx, ty = 2 * qy, tz = 2 * qz;
+  const double twx = tx * qw, twy = ty * qw, twz = tz * qw, txx = tx * qx, txy = ty * qx, txz = tz * qx, tyy = ty * qy, tyz = tz * qy, tzz = tz * qz;
+  T.r[0] = 1 - (tyy + tzz); T.r[1] = txy - twz;       T.r[2] = txz + twy;
+  T.r[3] = txy + twz;       T.r[4] = 1 - (txx + tzz); T.r[5] = tyz - twx;
+  T.r[6] = txz - twy;       T.r[7] = tyz + twx;       T.r[8] = 1 - (txx + tyy);
+  const double theta = sqrt(theta_sq);
+  double V[9];
+  if (theta < 1e-10) {
+#pragma unroll
+    for (int i = 0; i < 9; i++) V[i] = T.r[i];
+  } else {
+    const double tsq = theta * theta;
+    const double A = (1.0 - cos(theta)) / tsq, B = (theta - sin(theta)) / (tsq * theta);
+    // Omega = skew(omega), Omega^2
+    const double O[9] = {0, -oz, oy, oz, 0, -ox, -oy, ox, 0};
+    double O2[9];
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+      for (int j = 0; j < 3; j++) O2[i * 3 + j] = O[i * 3 + 0] * O[0 * 3 + j] + O[i * 3 + 1] * O[1 * 3 + j] + O[i * 3 + 2] * O[2 * 3 + j];
+#pragma unroll
+    for (int i = 0; i < 9; i++) V[i] = ((i % 4 == 0) ? 1.0 : 0.0) + A * O[i] + B * O2[i];
+  }
+#pragma unroll
+  for (int i = 0; i < 3; i++) T.t[i] = V[i * 3 + 0] * a[3] + V[i * 3 + 1] * a[4] + V[i * 3 + 2] * a[5];
+}
+
+__device__ inline void dev_pose_mul(const PoseD& A, const PoseD& B, PoseD& C) {  // C = A * B
+#pragma unroll
+  for (int i = 0; i < 3; i++) {
+#pragma unroll
+    for (int j = 0; j < 3; j++) C.r[i * 3 + j] = A.r[i * 3 + 0] * B.r[0 * 3 + j] + A.r[i * 3 + 1] * B.r[1 * 3 + j] + A.r[i * 3 + 2] * B.r[2 * 3 + j];
+    C.t[i] = A.r[i * 3 + 0] * B.t[0] + A.r[i * 3 + 1] * B.t[1] + A.r[i * 3 + 2] * B.t[2] + A.t[i];
+  }
+}
+
+__device__ inline void dev_ldlt6_solve(const double* A, const double* rhs, double* x) {
+  double L[36], D[6], y[6];
+  for (int i = 0; i < 36; i++) L[i] = 0.0;
+  for (int j = 0; j < 6; j++) {
+    double dj = A[j * 6 + j];
+    for (int k = 0; k < j; k++) dj -= L[j * 6 + k] * L[j * 6 + k] * D[k];
+    D[j] = dj;
+    L[j * 6 + j] = 1.0;
+    for (int i = j + 1; i < 6; i++) {
+      double s = A[i * 6 + j];
+      for (int k = 0; k < j; k++) s -= L[i * 6 + k] * L[j * 6 + k] * D[k];
+      L[i * 6 + j] = s / dj;
+    }
+  }
+  for (int i = 0; i < 6; i++) { double s = rhs[i]; for (int k = 0; k < i; k++) s -= L[i * 6 + k] * y[k]; y[i] = s; }
+  for (int i = 0; i < 6; i++) y[i] /= D[i];
+  for (int i = 5; i >= 0; i--) { double s = y[i]; for (int k = i + 1; k < 6; k++) s -= L[k * 6 + i] * x[k]; x[i] = s; }
+}
+
+__device__ inline bool dev_is_converged(const LmState* st, const PoseD& delta) {
+  double rmax = 0, tmax = 0;
+  for (int i = 0; i < 9; i++) rmax = fmax(rmax, fabs(delta.r[i] - ((i % 4 == 0) ? 1.0 : 0.0)) / st->rotation_epsilon);
+  for (int i = 0; i < 3; i++) tmax = fmax(tmax, fabs(delta.t[i]) / st->transformation_epsilon);
+  return fmax(rmax, tmax) < 1;
+}
+
+// sums -> symmetric 6x6 H (row-major) and b
+__device__ __host__ inline void unpack_sums(const double* s, double* H, double* b) {
+  for (int i = 0; i < 6; i++) b[i] = s[1 + i];
+  const double* rr = s + 7;   // xx xy xz yy yz zz
+  const double* rt = s + 13;  // 3x3 row-major
+  const double* tt = s + 22;
+  const int sym[3][3] = {{0, 1, 2}, {1, 3, 4}, {2, 4, 5}};
+  for (int i = 0; i < 3; i++)
+    for (int j = 0; j < 3; j++) {
+      H[i * 6 + j] = rr[sym[i][j]];
+      H[i * 6 + 3 + j] = rt[i * 3 + j];
+      H[(3 + j) * 6 + i] = rt[i * 3 + j];
+      H[(3 + i) * 6 + 3 + j] = tt[sym[i][j]];
+    }
+}
+
+__device__ inline void dev_lm_propose(LmState* st) {  // d = (H + lambda I)^-1 (-b); xi = exp(d) * x0
+  double A[36], nb[6];
+  for (int i = 0; i < 36; i++) A[i] = st->H[i];
+  for (int j = 0; j < 6; j++) { A[j * 6 + j] += st->lambda; nb[j] = -st->b[j]; }
+  double d[6];
+  dev_ldlt6_solve(A, nb, d);
+  for (int j = 0; j < 6; j++) st->d[j] = d[j];
+  PoseD delta;
+  dev_se3_exp(d, delta);
+  st->delta = delta;
+  dev_pose_mul(delta, st->x0, st->xi);
+}
+
+// One transition of the {linearize -> trial* -> accept} machine; exactly the control flow of
+// LsqRegistration::computeTransformation + step_lm.
+__device__ inline void dev_lm_step(LmState* st, const double* sums) {
+  if (st->phase == PH_LINEARIZE) {
+    st->y0 = sums[0];
+    unpack_sums(sums, st->H, st->b);
+    st->num_linearize++;
+    st->nr_iterations = st->outer_iter;
+    if (st->lambda < 0.0) {
+      double mx = 0;
+      for (int i = 0; i < 6; i++) mx = fmax(mx, fabs(st->H[i * 6 + i]));
+      st->lambda = st->lm_init_lambda_factor * mx;
+    }
+    st->nu = 2.0;
+    st->inner_iter = 0;
+    if (st->lm_max_iterations <= 0) { st->lm_failed = 1; st->phase = PH_DONE; return; }
+    dev_lm_propose(st);
+    st->phase = PH_TRIAL;
+    return;
+  }
+  // PH_TRIAL
+  const double yi = sums[0];
+  st->num_error_evals++;
+  double denom = 0;
+  for (int j = 0; j < 6; j++) denom += st->d[j] * (st->lambda * st->d[j] - st->b[j]);
+  const double rho = (st->y0 - yi) / denom;
+  bool step_done = false;
+  if (rho < 0) {
+    if (dev_is_converged(st, st->delta)) {
+      step_done = true;  // returns true with x0 unchanged
+    } else {
+      st->lambda = st->nu * st->lambda;
+      st->nu = 2 * st->nu;
+      st->inner_iter++;
+      if (st->inner_iter >= st->lm_max_iterations) { st->lm_failed = 1; st->phase = PH_DONE; return; }  // "lm not converged!!"
+      dev_lm_propose(st);
+      return;  // stay in PH_TRIAL
+    }
+  } else {
+    st->x0 = st->xi;
+    st->lambda = st->lambda * fmax(1.0 / 3.0, 1 - pow(2 * rho - 1, 3));
+    for (int i = 0; i < 36; i++) st->final_H[i] = st->H[i];
+    step_done = true;
+  }
+  if (step_done) {
+    st->converged = dev_is_converged(st, st->delta) ? 1 : 0;
+    st->outer_iter++;
+    st->phase = (st->converged || st->outer_iter >= st->max_iterations) ? PH_DONE : PH_LINEARIZE;
+  }
+}
+
+// tiny kernels for the multi-GPU path and for (re)initialising the state
+__global__ void lm_init_kernel(LmState* st, PoseD guess, double rot_eps, double trans_eps, double lambda_factor, int max_iter, int lm_max_iter, unsigned* ticket) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  st->x0 = guess; st->xi = guess;
+  st->rotation_epsilon = rot_eps; st->transformation_epsilon = trans_eps; st->lm_init_lambda_factor = lambda_factor;
+  st->max_iterations = max_iter; st->lm_max_iterations = lm_max_iter;
+  st->lambda = -1.0; st->nu = 2.0; st->y0 = 0.0;
+  st->phase = max_iter > 0 ? PH_LINEARIZE : PH_DONE;
+  st->outer_iter = 0; st->inner_iter = 0; st->converged = 0; st->lm_failed = 0; st->num_linearize = 0; st->num_error_evals = 0; st->nr_iterations = 0;
+  for (int i = 0; i < 36; i++) st->final_H[i] = (i % 7 == 0) ? 1.0 : 0.0;
+  *ticket = 0;
+}
+__global__ void lm_update_kernel(LmState* st) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  if (st->phase == PH_DONE) return;
+  dev_lm_step(st, st->sums);
+}
+
+// ------------------------------------------------------------------------------------------------
+// per-correspondence terms
+// ------------------------------------------------------------------------------------------------
+template <typename Real>
+__device__ __forceinline__ void accumulate_term(double* acc, const Vec3<Real>& q, const Vec3<Real>& mu, const Sym3<Real>& M, Real w, bool deriv) {
+  const Vec3<Real> e = {mu.x - q.x, mu.y - q.y, mu.z - q.z};
+  const Vec3<Real> Me = mul(M, e);
+  acc[0] += (double)(w * (e.x * Me.x + e.y * Me.y + e.z * Me.z));
+  if (!deriv) return;
+  // J = [skew(q), -I]:  b = w J^T M e = w [Me x q ; -Me]
+  const Vec3<Real> bq = cross(Me, q);
+  acc[1] += (double)(w * bq.x); acc[2] += (double)(w * bq.y); acc[3] += (double)(w * bq.z);
+  acc[4] -= (double)(w * Me.x); acc[5] -= (double)(w * Me.y); acc[6] -= (double)(w * Me.z);
+  // P = skew(q) M (columns q x M_col) ; H = w [[P S^T, P], [P^T, M]]
+  const Vec3<Real> c0 = {M.xx, M.xy, M.xz}, c1 = {M.xy, M.yy, M.yz}, c2 = {M.xz, M.yz, M.zz};
+  const Vec3<Real> p0 = cross(q, c0), p1 = cross(q, c1), p2 = cross(q, c2);  // P_ij = p_j[i]
+  const Vec3<Real> r0 = {p0.x, p1.x, p2.x}, r1 = {p0.y, p1.y, p2.y}, r2 = {p0.z, p1.z, p2.z};  // rows of P
+  const Vec3<Real> h0 = cross(q, r0), h1 = cross(q, r1), h2 = cross(q, r2);  // rows of H_rr
+  acc[7] += (double)(w * h0.x); acc[8] += (double)(w * h0.y); acc[9] += (double)(w * h0.z);
+  acc[10] += (double)(w * h1.y); acc[11] += (double)(w * h1.z); acc[12] += (double)(w * h2.z);
+  acc[13] += (double)(w * r0.x); acc[14] += (double)(w * r0.y); acc[15] += (double)(w * r0.z);
+  acc[16] += (double)(w * r1.x); acc[17] += (double)(w * r1.y); acc[18] += (double)(w * r1.z);
+  acc[19] += (double)(w * r2.x); acc[20] += (double)(w * r2.y); acc[21] += (double)(w * r2.z);
+  acc[22] += (double)(w * M.xx); acc[23] += (double)(w * M.xy); acc[24] += (double)(w * M.xz);
+  acc[25] += (double)(w * M.yy); acc[26] += (double)(w * M.yz); acc[27] += (double)(w * M.zz);
+}
+
+__device__ __forceinline__ int probe_table(const uint4* __restrict__ table, unsigned mask, unsigned long long key, int& num_points) {
+  unsigned slot = hash_key(key) & mask;
+  for (unsigned it = 0; it <= mask; it++) {
+    const uint4 q0 = table[(size_t)slot * 4];
+    const unsigned long long k = (unsigned long long)q0.x | ((unsigned long long)q0.y << 32);
+    if (k == key) { num_points = (int)q0.z; return (int)slot; }
+    if (k == FVH_EMPTY_KEY) return -1;  // first empty bucket ends the probe (find_voxel_correspondences.cu:46-48)
+    slot = (slot + 1) & mask;
+  }
+  return -1;
+}
+
+template <typename Real, int MODE>
+__global__ __launch_bounds__(256) void cost_kernel(CostParams P) {
+  __shared__ double red[4][PART_STRIDE];
+  __shared__ double fin[8][PART_STRIDE];
+  __shared__ int s_last;
+  LmState* st = P.st;
+  int phase;
+  PoseD lin_d, ev_d;
+  if (P.host_phase >= 0) {
+    phase = P.host_phase;
+    lin_d = P.lin;
+    ev_d = P.ev;
+  } else {
+    phase = st->phase;
+    if (phase == PH_DONE) return;
+    lin_d = st->x0;
+    ev_d = (phase == PH_LINEARIZE) ? st->x0 : st->xi;
+  }
+  const bool do_find = (phase == PH_LINEARIZE) || (phase == PH_FIND_ONLY);
+  const bool do_cost = (phase != PH_FIND_ONLY);
+  const bool do_deriv = (phase == PH_LINEARIZE) || (phase == PH_EVAL_DERIV);
+  const Pose<Real> lin = pose_cast<Real>(lin_d);
+  const Pose<Real> ev = pose_cast<Real>(ev_d);
+  const Real res = (Real)P.res;
+  const int n_src = P.d_n_src ? *P.d_n_src : P.n_src;
+  const long long n_items = (long long)n_src * P.groups_per_src;
+
+  double acc[NSUM];
+#pragma unroll
+  for (int v = 0; v < NSUM; v++) acc[v] = 0.0;
+  int n_found = 0;
+
+  const float4* tf = reinterpret_cast<const float4*>(P.table);
+  for (long long w = (long long)blockIdx.x * 256 + threadIdx.x; w < n_items; w += (long long)gridDim.x * 256) {
+    const int i = (int)(w / P.groups_per_src);
+    const int g = (int)(w - (long long)i * P.groups_per_src);
+    const float4 a4 = P.src_pts[i];
+    const Vec3<Real> a = {(Real)a4.x, (Real)a4.y, (Real)a4.z};
+    Sym3<Real> RCR = {0, 0, 0, 0, 0, 0};
+    if (MODE != MODE_NDT_P2D && do_cost) {
+      const float4 c0 = P.src_cov[2 * i], c1 = P.src_cov[2 * i + 1];
+      const Sym3<Real> CA = {(Real)c0.x, (Real)c0.y, (Real)c0.z, (Real)c0.w, (Real)c1.x, (Real)c1.y};
+      RCR = rotate_cov(lin.r, CA);
+    }
+    const Vec3<Real> q = transform(ev, a);
+    int cx = 0, cy = 0, cz = 0;
+    if (do_find) {
+      const Vec3<Real> ql = transform(lin, a);
+      cx = (int)floor(ql.x / res - (Real)0.5);
+      cy = (int)floor(ql.y / res - (Real)0.5);
+      cz = (int)floor(ql.z / res - (Real)0.5);
+    }
+    const int o_begin = g * P.group, o_end = min(P.n_off, o_begin + P.group);
+    for (int o = o_begin; o < o_end; o++) {
+      int b, npts = 0;
+      if (do_find) {
+        const int x = cx + P.offsets[3 * o], y = cy + P.offsets[3 * o + 1], z = cz + P.offsets[3 * o + 2];
+        b = coord_in_range(x, y, z) ? probe_table(P.table, P.mask, pack_key(x, y, z), npts) : -1;
+        P.corr[(size_t)i * P.n_off + o] = b;
+        n_found += (b >= 0);
+      } else {
+        b = P.corr[(size_t)i * P.n_off + o];
+      }
+      if (b < 0 || !do_cost) continue;
+      const float4 q1 = tf[(size_t)b * 4 + 1], q2 = tf[(size_t)b * 4 + 2], q3 = tf[(size_t)b * 4 + 3];
+      npts = (int)q1.w;
+      const Vec3<Real> mu = {(Real)q1.x, (Real)q1.y, (Real)q1.z};
+      Sym3<Real> A = {(Real)q2.x + RCR.xx, (Real)q2.y + RCR.xy, (Real)q2.z + RCR.xz, (Real)q2.w + RCR.yy, (Real)q3.x + RCR.yz, (Real)q3.y + RCR.zz};
+      Real wgt;
+      if (MODE == MODE_VGICP) {
+        if (npts <= 0) continue;
+        wgt = sqrt((Real)npts);  // fast_vgicp_impl.hpp:149, compute_derivatives.cu:78
+      } else {
+        if (npts <= 6) continue;  // ndt_compute_derivatives.cu:61,133
+        const Real ex = mu.x - q.x, ey = mu.y - q.y, ez = mu.z - q.z;
+        const Real ksq = res * res;
+        wgt = ksq / (ksq + (ex * ex + ey * ey + ez * ez));  // cauchy(resolution, |e|) :15-18
+      }
+      const Sym3<Real> M = inverse(A);
+      accumulate_term<Real>(acc, q, mu, M, wgt, do_deriv);
+    }
+  }
+
+  // ---- workgroup reduction: wave shuffles, then LDS across the 4 waves ----
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  if (do_find && P.d_num_corr) {
+    int nf = n_found;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) nf += __shfl_xor(nf, off);
+    if (lane == 0 && nf) atomicAdd(P.d_num_corr, nf);
+  }
+  if (!do_cost) return;
+  const int nsum = do_deriv ? NSUM : 1;
+#pragma unroll
+  for (int v = 0; v < NSUM; v++) {  // static indexing keeps acc[] in VGPRs
+    if (v < nsum) {
+      double x = acc[v];
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) x += __shfl_xor(x, off);
+      if (lane == 0) red[wv][v] = x;
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x < PART_STRIDE) {
+    const int v = threadIdx.x;
+    const double s = (v < nsum) ? (red[0][v] + red[1][v]) + (red[2][v] + red[3][v]) : 0.0;
+    // write-through (sc1) so the last workgroup can read it from L2 without a release fence
+    __hip_atomic_store(&P.partials[(size_t)blockIdx.x * PART_STRIDE + v], s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const unsigned t = atomicAdd(P.ticket, 1u);
+    s_last = (t == gridDim.x - 1);
+  }
+  __syncthreads();
+  if (!s_last) return;
+
+  // ---- last workgroup: fixed-order sum of the partials (deterministic), then the LM step ----
+  {
+    const int v = threadIdx.x & 31, chunk = threadIdx.x >> 5;  // 8 chunks x 32 values
+    double s = 0.0;
+    for (unsigned b = chunk; b < gridDim.x; b += 8) s += __hip_atomic_load(&P.partials[(size_t)b * PART_STRIDE + v], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    fin[chunk][v] = s;
+  }
+  __syncthreads();
+  if (threadIdx.x < PART_STRIDE) {
+    const int v = threadIdx.x;
+    double s = 0.0;
+#pragma unroll
+    for (int c = 0; c < 8; c++) s += fin[c][v];
+    red[0][v] = s;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    *P.ticket = 0;
+    for (int v = 0; v < PART_STRIDE; v++) st->sums[v] = red[0][v];
+    if (P.host_phase < 0 && !P.defer_lm) dev_lm_step(st, red[0]);
+  }
+}
+
+}  // namespace fvh

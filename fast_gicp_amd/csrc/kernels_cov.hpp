@@ -1,0 +1,217 @@
+// Per-point covariance estimation for gfx950 (wave64).
+//
+// Replaces SURVEY 2.2 K1/K3 (brute_force_knn.cu:16-108: one thread per query, heap in global
+// memory), K4 (covariance_estimation.cu:16-51), K5/K6 (covariance_estimation_rbf.cu:11-151: one
+// launch per 512-point block + N x ceil(N/512) x 52 B scratch) and K7-K9
+// (covariance_regularization.cu:15-125).
+//
+// Brute-force k-NN: a WAVE owns Q queries; the 64 lanes sweep the candidates 64 at a time
+// (coalesced float4 loads, every candidate register reused by the Q queries). The running top-k of
+// a query lives ACROSS the lanes of the wave (lane j = j-th smallest so far) and the k-th distance
+// is a wave-uniform scalar threshold: a batch whose ballot(d < tau) is empty costs ~9 instructions
+// for 64 candidates; an accepted candidate is inserted with one ballot + one wave shift.
+// Distances are fp32 ((dx*dx + dy*dy) + dz*dz, no FMA) and ties go to the lower index, so the
+// neighbour SETS are bit-reproducible and equal to the oracle's kd-tree result.
+#pragma once
+#include "dev_math.hpp"
+
+namespace fvh {
+
+__device__ __forceinline__ float sqdist_nofma(const float4& p, float qx, float qy, float qz) {
+  const float dx = __fsub_rn(p.x, qx), dy = __fsub_rn(p.y, qy), dz = __fsub_rn(p.z, qz);
+  return __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
+}
+
+constexpr int KNN_Q = 8;  // queries per wave
+
+// out_idx: [n][k] neighbour indices, ascending (distance, index); k <= 64
+__global__ __launch_bounds__(256) void knn_bruteforce_kernel(const float4* __restrict__ pts, int n, int k, int* __restrict__ out_idx) {
+  const int lane = threadIdx.x & 63;
+  const int wave = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int q_base = wave * KNN_Q;
+  if (q_base >= n) return;
+  float qx[KNN_Q], qy[KNN_Q], qz[KNN_Q];
+  float ld[KNN_Q];  // lane j: j-th smallest distance so far
+  int li[KNN_Q];    //         and its index
+  float tau[KNN_Q]; // wave-uniform: current k-th smallest distance
+#pragma unroll
+  for (int j = 0; j < KNN_Q; j++) {
+    const float4 q = pts[min(q_base + j, n - 1)];
+    qx[j] = q.x; qy[j] = q.y; qz[j] = q.z;
+    ld[j] = __builtin_inff(); li[j] = -1; tau[j] = __builtin_inff();
+  }
+  for (int base = 0; base < n; base += 64) {
+    const int c = base + lane;
+    const float4 p = pts[min(c, n - 1)];
+#pragma unroll
+    for (int j = 0; j < KNN_Q; j++) {
+      float d = sqdist_nofma(p, qx[j], qy[j], qz[j]);
+      d = c < n ? d : __builtin_inff();
+      unsigned long long mask = __ballot(d < tau[j]);
+      while (mask) {  // wave-uniform
+        const int src = __ffsll((long long)mask) - 1;
+        mask &= mask - 1;
+        const float cd = __shfl(d, src);
+        if (!(cd < tau[j])) continue;  // tau may have tightened since the ballot
+        const int pos = __popcll(__ballot(ld[j] <= cd));
+        const float sd = __shfl_up(ld[j], 1);
+        const int si = __shfl_up(li[j], 1);
+        if (lane > pos) { ld[j] = sd; li[j] = si; }
+        else if (lane == pos) { ld[j] = cd; li[j] = base + src; }
+        tau[j] = __shfl(ld[j], k - 1);
+      }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < KNN_Q; j++)
+    if (q_base + j < n && lane < k) out_idx[(size_t)(q_base + j) * k + lane] = li[j];
+}
+
+__device__ __forceinline__ void store_cov(float4* __restrict__ cov, int i, const Sym3<double>& C) {
+  cov[2 * i] = make_float4((float)C.xx, (float)C.xy, (float)C.xz, (float)C.yy);
+  cov[2 * i + 1] = make_float4((float)C.yz, (float)C.zz, 0.f, 0.f);
+}
+
+// K4 + K7/8/9 fused: centred fp64 covariance of the k neighbours (CPU semantics,
+// fast_gicp_impl.hpp:259-265; the CUDA path's uncentred fp32 sum loses ~2 digits at 50 m range),
+// then regularisation, one thread per point.
+__global__ __launch_bounds__(256) void cov_from_neighbors_kernel(const float4* __restrict__ pts, int n, int k, const int* __restrict__ nbr, int method,
+                                                                 float4* __restrict__ cov) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const int* nb = nbr + (size_t)i * k;
+  double mx = 0, my = 0, mz = 0;
+  for (int j = 0; j < k; j++) {
+    const float4 p = pts[nb[j]];
+    mx += (double)p.x; my += (double)p.y; mz += (double)p.z;
+  }
+  mx /= k; my /= k; mz /= k;
+  Sym3<double> C = {0, 0, 0, 0, 0, 0};
+  for (int j = 0; j < k; j++) {
+    const float4 p = pts[nb[j]];
+    const double dx = (double)p.x - mx, dy = (double)p.y - my, dz = (double)p.z - mz;
+    C.xx += dx * dx; C.xy += dx * dy; C.xz += dx * dz; C.yy += dy * dy; C.yz += dy * dz; C.zz += dz * dz;
+  }
+  const double inv = 1.0 / k;
+  C.xx *= inv; C.xy *= inv; C.xz *= inv; C.yy *= inv; C.yz *= inv; C.zz *= inv;
+  store_cov(cov, i, regularize_cov(C, method));
+}
+
+__global__ __launch_bounds__(256) void regularize_kernel(float4* __restrict__ cov, int n, int method) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const float4 a = cov[2 * i], b = cov[2 * i + 1];
+  Sym3<double> C = {a.x, a.y, a.z, a.w, b.x, b.y};
+  store_cov(cov, i, regularize_cov(C, method));
+}
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+  return v;
+}
+
+constexpr int RBF_Q = 8;
+
+// K5 + K6 + K7 fused, single pass, no scratch: w = exp(-kernel_width * d^2) for d^2 <= max_dist^2
+// (covariance_estimation_rbf.cu:67-85), weighted mean/cov (:40-52), evaluated centred on the query
+// (identical maths, fp32-safe), wave-reduced in fp64, regularised. The reference's unmasked
+// zero-padding of the last 512-block (:127-129) is NOT replicated.
+__global__ __launch_bounds__(256) void cov_rbf_kernel(const float4* __restrict__ pts, int n, float kernel_width, float max_dist_sq, int method,
+                                                      float4* __restrict__ cov) {
+  const int lane = threadIdx.x & 63;
+  const int wave = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int q_base = wave * RBF_Q;
+  if (q_base >= n) return;
+  float qx[RBF_Q], qy[RBF_Q], qz[RBF_Q];
+  float sw[RBF_Q], sx[RBF_Q], sy[RBF_Q], sz[RBF_Q], sxx[RBF_Q], sxy[RBF_Q], sxz[RBF_Q], syy[RBF_Q], syz[RBF_Q], szz[RBF_Q];
+#pragma unroll
+  for (int j = 0; j < RBF_Q; j++) {
+    const float4 q = pts[min(q_base + j, n - 1)];
+    qx[j] = q.x; qy[j] = q.y; qz[j] = q.z;
+    sw[j] = sx[j] = sy[j] = sz[j] = sxx[j] = sxy[j] = sxz[j] = syy[j] = syz[j] = szz[j] = 0.f;
+  }
+  for (int base = 0; base < n; base += 64) {
+    const int c = base + lane;
+    const float4 p = pts[min(c, n - 1)];
+#pragma unroll
+    for (int j = 0; j < RBF_Q; j++) {
+      const float dx = __fsub_rn(p.x, qx[j]), dy = __fsub_rn(p.y, qy[j]), dz = __fsub_rn(p.z, qz[j]);
+      const float sq = __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
+      const bool in = (c < n) && !(sq > max_dist_sq);
+      const float w = in ? __expf(-kernel_width * sq) : 0.f;
+      sw[j] += w;
+      const float wx = w * dx, wy = w * dy, wz = w * dz;
+      sx[j] += wx; sy[j] += wy; sz[j] += wz;
+      sxx[j] += wx * dx; sxy[j] += wx * dy; sxz[j] += wx * dz; syy[j] += wy * dy; syz[j] += wy * dz; szz[j] += wz * dz;
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < RBF_Q; j++) {
+    const double W = wave_sum((double)sw[j]);
+    const double X = wave_sum((double)sx[j]), Y = wave_sum((double)sy[j]), Z = wave_sum((double)sz[j]);
+    const double XX = wave_sum((double)sxx[j]), XY = wave_sum((double)sxy[j]), XZ = wave_sum((double)sxz[j]);
+    const double YY = wave_sum((double)syy[j]), YZ = wave_sum((double)syz[j]), ZZ = wave_sum((double)szz[j]);
+    if (lane == 0 && q_base + j < n) {
+      const double iw = 1.0 / W;
+      const double mx = X * iw, my = Y * iw, mz = Z * iw;
+      Sym3<double> C;
+      C.xx = XX * iw - mx * mx; C.xy = XY * iw - mx * my; C.xz = XZ * iw - mx * mz;
+      C.yy = YY * iw - my * my; C.yz = YZ * iw - my * mz; C.zz = ZZ * iw - mz * mz;
+      store_cov(cov, q_base + j, regularize_cov(C, method));
+    }
+  }
+}
+
+constexpr int FIT_Q = 8;
+
+// pcl::Registration::getFitnessScore restated for the device: transform the source by the FLOAT
+// pose (final_transformation_ is float), exact 1-NN by tiled brute force, sum d^2 <= max_range.
+// out[0] += sum, out[1] += count (fp64 atomics).
+__global__ __launch_bounds__(256) void fitness_kernel(const float4* __restrict__ src, int ns, const float4* __restrict__ tgt, int nt, const float* __restrict__ T12 /* row-major 3x4 */,
+                                                      double max_range, double* __restrict__ out) {
+  const int lane = threadIdx.x & 63;
+  const int wave = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int q_base = wave * FIT_Q;
+  if (q_base >= ns) return;
+  float qx[FIT_Q], qy[FIT_Q], qz[FIT_Q], best[FIT_Q];
+#pragma unroll
+  for (int j = 0; j < FIT_Q; j++) {
+    const float4 p = src[min(q_base + j, ns - 1)];
+    // (x*m0 + y*m1) + (z*m2 + m3): pcl::transformPointCloud's SSE association
+    qx[j] = __fadd_rn(__fadd_rn(__fmul_rn(p.x, T12[0]), __fmul_rn(p.y, T12[1])), __fadd_rn(__fmul_rn(p.z, T12[2]), T12[3]));
+    qy[j] = __fadd_rn(__fadd_rn(__fmul_rn(p.x, T12[4]), __fmul_rn(p.y, T12[5])), __fadd_rn(__fmul_rn(p.z, T12[6]), T12[7]));
+    qz[j] = __fadd_rn(__fadd_rn(__fmul_rn(p.x, T12[8]), __fmul_rn(p.y, T12[9])), __fadd_rn(__fmul_rn(p.z, T12[10]), T12[11]));
+    best[j] = __builtin_inff();
+  }
+  for (int base = 0; base < nt; base += 64) {
+    const int c = base + lane;
+    const float4 p = tgt[min(c, nt - 1)];
+#pragma unroll
+    for (int j = 0; j < FIT_Q; j++) {
+      const float d = sqdist_nofma(p, qx[j], qy[j], qz[j]);
+      best[j] = (c < nt && d < best[j]) ? d : best[j];
+    }
+  }
+  double sum = 0.0, cnt = 0.0;
+#pragma unroll
+  for (int j = 0; j < FIT_Q; j++) {
+    float b = best[j];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) b = fminf(b, __shfl_xor(b, off));
+    if (q_base + j < ns && (double)b <= max_range) { sum += (double)b; cnt += 1.0; }
+  }
+  if (lane == 0) {
+    atomicAdd(&out[0], sum);
+    atomicAdd(&out[1], cnt);
+  }
+}
+
+// float xyz (stride 3 or 4) -> float4 (w = 0)
+__global__ __launch_bounds__(256) void pack_points_kernel(const float* __restrict__ xyz, int n, int stride, float4* __restrict__ out) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  out[i] = make_float4(xyz[(size_t)i * stride], xyz[(size_t)i * stride + 1], xyz[(size_t)i * stride + 2], 0.f);
+}
+
+}  // namespace fvh

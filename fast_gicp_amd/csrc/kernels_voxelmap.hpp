@@ -1,0 +1,156 @@
+// Gaussian voxel map build for gfx950: spatial-hash insert + LDS-staged bucket accumulation.
+//
+// Replaces the reference's K10-K17 chain: voxel_coord_kernel,
+// voxel_bucket_assignment_kernel (+ host retry loop that drops up to 1 % of the points),
+// voxel_coord_select_kernel, accumulate_points_kernel (13 global float atomics per point),
+// finalize_voxels_kernel / ndt_finalize_voxels_kernel  (src/fast_gicp/cuda/gaussian_voxelmap.cu:9-289).
+//
+// HBM layout
+//   table : capacity x 64-byte bucket (capacity = pow2 >= 2 * N_t, so no point is ever dropped)
+//           q0 = {key_lo, key_hi, num_points, 0}   q1 = {mean.xyz, (float)num_points}
+//           q2 = {c_xx, c_xy, c_xz, c_yy}          q3 = {c_yz, c_zz, 0, 0}
+//           -> a probe that hits finds key AND the voxel record in one 64-B line (no id indirection,
+//              the bucket index *is* the voxel id).
+//   acc   : capacity x 10 doubles scratch {sum p (3), sum C or sum pp^T (6), count}; fp64 so the
+//           result is independent of the atomic arrival order to ~1e-16.
+//
+// Pass 1 (vm_accumulate): one point per thread. Each workgroup first aggregates its 256 points in
+// an LDS mini hash table (ds_cmpst_rtn_b64 claim + ds_add_f64), then flushes each occupied LDS slot
+// with ONE global claim (global_atomic_cmpswap_x2) and 10 global_atomic_add_f64 -- instead of 13
+// global atomics per point. Scan-ordered clouds put 10-40 points of a block in the same voxel.
+// Pass 2 (vm_finalize): one thread per bucket: mean/cov from the sums (+ MIN_EIG for NDT), written
+// into the bucket; occupied buckets are also listed compactly (getters, D2D source iteration).
+#pragma once
+#include "dev_math.hpp"
+
+namespace fvh {
+
+constexpr int VM_LDS_SLOTS = 512;
+constexpr int VM_LDS_PROBES = 8;
+constexpr int VM_ACC_STRIDE = 10;
+
+__device__ __forceinline__ unsigned global_claim(unsigned long long* table_keys64 /* bucket stride = 8 u64 */, unsigned mask, unsigned long long key) {
+  unsigned slot = hash_key(key) & mask;
+  for (unsigned it = 0; it <= mask; it++) {
+    unsigned long long* addr = table_keys64 + (size_t)slot * 8;
+    unsigned long long cur = __hip_atomic_load(addr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (cur == key) return slot;
+    if (cur == FVH_EMPTY_KEY) {
+      unsigned long long old = atomicCAS(addr, FVH_EMPTY_KEY, key);
+      if (old == FVH_EMPTY_KEY || old == key) return slot;
+    }
+    slot = (slot + 1) & mask;
+  }
+  return 0xFFFFFFFFu;  // table full: cannot happen with capacity >= 2 N
+}
+
+// MODE 0: VGICP (sum of points and of point covariances); MODE 1: NDT (sum of points and p p^T)
+template <int MODE>
+__global__ __launch_bounds__(256) void vm_accumulate_kernel(const float4* __restrict__ pts, const float4* __restrict__ cov, int n, double res,
+                                                            unsigned long long* __restrict__ table_keys, unsigned mask, double* __restrict__ acc,
+                                                            int* __restrict__ dropped) {
+  __shared__ unsigned long long lkey[VM_LDS_SLOTS];
+  __shared__ double lacc[VM_LDS_SLOTS * VM_ACC_STRIDE];
+  const int tid = threadIdx.x;
+  for (int s = tid; s < VM_LDS_SLOTS; s += 256) lkey[s] = FVH_EMPTY_KEY;
+  for (int s = tid; s < VM_LDS_SLOTS * VM_ACC_STRIDE; s += 256) lacc[s] = 0.0;
+  __syncthreads();
+
+  const int i = blockIdx.x * 256 + tid;
+  if (i < n) {
+    const float4 p = pts[i];
+    // fp64 coordinate, as the CPU reference (fast_vgicp_voxel.hpp:158-160)
+    const int cx = (int)floor((double)p.x / res - 0.5), cy = (int)floor((double)p.y / res - 0.5), cz = (int)floor((double)p.z / res - 0.5);
+    if (!coord_in_range(cx, cy, cz)) {
+      atomicAdd(dropped, 1);
+    } else {
+      const unsigned long long key = pack_key(cx, cy, cz);
+      double v[VM_ACC_STRIDE];
+      v[0] = p.x; v[1] = p.y; v[2] = p.z;
+      if (MODE == 0) {
+        const float4 c0 = cov[2 * i], c1 = cov[2 * i + 1];
+        v[3] = c0.x; v[4] = c0.y; v[5] = c0.z; v[6] = c0.w; v[7] = c1.x; v[8] = c1.y;
+      } else {
+        const double x = p.x, y = p.y, z = p.z;
+        v[3] = x * x; v[4] = x * y; v[5] = x * z; v[6] = y * y; v[7] = y * z; v[8] = z * z;
+      }
+      v[9] = 1.0;
+      // stage in the workgroup's LDS mini table
+      unsigned slot = (hash_key(key) >> 16) & (VM_LDS_SLOTS - 1);
+      bool staged = false;
+#pragma unroll 1
+      for (int pr = 0; pr < VM_LDS_PROBES; pr++) {
+        unsigned long long old = atomicCAS(&lkey[slot], FVH_EMPTY_KEY, key);
+        if (old == FVH_EMPTY_KEY || old == key) { staged = true; break; }
+        slot = (slot + 1) & (VM_LDS_SLOTS - 1);
+      }
+      if (staged) {
+#pragma unroll
+        for (int j = 0; j < VM_ACC_STRIDE; j++) atomicAdd(&lacc[slot * VM_ACC_STRIDE + j], v[j]);
+      } else {  // LDS table crowded: go straight to the global table
+        unsigned b = global_claim(table_keys, mask, key);
+        if (b != 0xFFFFFFFFu) {
+#pragma unroll
+          for (int j = 0; j < VM_ACC_STRIDE; j++) atomicAdd(&acc[(size_t)b * VM_ACC_STRIDE + j], v[j]);
+        } else {
+          atomicAdd(dropped, 1);
+        }
+      }
+    }
+  }
+  __syncthreads();
+  // flush: one global claim + 10 fp64 atomics per (workgroup, voxel)
+  for (int s = tid; s < VM_LDS_SLOTS; s += 256) {
+    const unsigned long long key = lkey[s];
+    if (key == FVH_EMPTY_KEY) continue;
+    unsigned b = global_claim(table_keys, mask, key);
+    if (b == 0xFFFFFFFFu) { atomicAdd(dropped, 1); continue; }
+#pragma unroll
+    for (int j = 0; j < VM_ACC_STRIDE; j++) atomicAdd(&acc[(size_t)b * VM_ACC_STRIDE + j], lacc[s * VM_ACC_STRIDE + j]);
+  }
+}
+
+// One thread per bucket. MODE 0: AdditiveGaussianVoxel::finalize (fast_vgicp_voxel.hpp:118-121,
+// gaussian_voxelmap.cu:164-171). MODE 1: ndt_finalize_voxels_kernel (gaussian_voxelmap.cu:184-193)
+// + MIN_EIG regularisation (ndt_cuda.cu:128,139).
+template <int MODE>
+__global__ __launch_bounds__(256) void vm_finalize_kernel(uint4* __restrict__ table, unsigned capacity, const double* __restrict__ acc, int* __restrict__ num_voxels,
+                                                          int* __restrict__ occupied, float4* __restrict__ compact_pts, float4* __restrict__ compact_cov) {
+  const unsigned b = blockIdx.x * 256 + threadIdx.x;
+  if (b >= capacity) return;
+  uint4 q0 = table[(size_t)b * 4];
+  const unsigned long long key = (unsigned long long)q0.x | ((unsigned long long)q0.y << 32);
+  if (key == FVH_EMPTY_KEY) return;
+  const double* a = acc + (size_t)b * VM_ACC_STRIDE;
+  const double cnt = a[9];
+  const double inv = 1.0 / cnt;
+  const double mx = a[0] * inv, my = a[1] * inv, mz = a[2] * inv;
+  Sym3<double> C;
+  if (MODE == 0) {
+    C.xx = a[3] * inv; C.xy = a[4] * inv; C.xz = a[5] * inv; C.yy = a[6] * inv; C.yz = a[7] * inv; C.zz = a[8] * inv;
+  } else {
+    C.xx = (a[3] - mx * a[0]) * inv; C.xy = (a[4] - mx * a[1]) * inv; C.xz = (a[5] - mx * a[2]) * inv;
+    C.yy = (a[6] - my * a[1]) * inv; C.yz = (a[7] - my * a[2]) * inv; C.zz = (a[8] - mz * a[2]) * inv;
+    C = regularize_cov(C, 1 /* MIN_EIG */);
+  }
+  const int n = (int)cnt;
+  q0.z = (unsigned)n;
+  q0.w = 0;
+  const float4 q1 = make_float4((float)mx, (float)my, (float)mz, (float)n);
+  const float4 q2 = make_float4((float)C.xx, (float)C.xy, (float)C.xz, (float)C.yy);
+  const float4 q3 = make_float4((float)C.yz, (float)C.zz, 0.f, 0.f);
+  float4* tf = reinterpret_cast<float4*>(table);
+  table[(size_t)b * 4] = q0;
+  tf[(size_t)b * 4 + 1] = q1;
+  tf[(size_t)b * 4 + 2] = q2;
+  tf[(size_t)b * 4 + 3] = q3;
+  const int id = atomicAdd(num_voxels, 1);
+  occupied[id] = (int)b;
+  if (compact_pts) {  // D2D NDT: the source voxels are the "source cloud"
+    compact_pts[id] = make_float4((float)mx, (float)my, (float)mz, 0.f);
+    compact_cov[2 * id] = q2;
+    compact_cov[2 * id + 1] = q3;
+  }
+}
+
+}  // namespace fvh

@@ -1,0 +1,180 @@
+/*
+ * fast_vgicp_hip.h -- C ABI of libfast_vgicp_hip.so, the MI355X (gfx950) engine that drops in where
+ * the reference's nvcc-built libfast_vgicp_cuda.so sits (the pimpl classes
+ * fast_gicp::cuda::FastVGICPCudaCore and fast_gicp::cuda::NDTCudaCore).
+ *
+ * Reference files cited below are relative to koide3/fast_gicp @ 2024-10-22:
+ *   [VC]  include/fast_gicp/cuda/fast_vgicp_cuda.cuh   (class FastVGICPCudaCore, lines 28-92)
+ *   [VCU] src/fast_gicp/cuda/fast_vgicp_cuda.cu
+ *   [NC]  include/fast_gicp/cuda/ndt_cuda.cuh          (class NDTCudaCore, lines 28-68)
+ *   [NCU] src/fast_gicp/cuda/ndt_cuda.cu
+ *
+ * Conventions
+ *   - Every function returns an int status (FVH_OK == 0); fvh_*_last_error() gives the message.
+ *     Nothing throws across the ABI.  (The reference has no error reporting: asserts/abort.)
+ *   - The library owns all device memory behind the opaque handle; inputs are copied
+ *     (caller keeps its buffers), outputs go to caller-allocated buffers -- same ownership
+ *     as the reference's std::vector-by-const-ref / out-param style.
+ *   - A handle is used from one host thread at a time; distinct handles may be used
+ *     concurrently.  Each handle owns one HIP stream; calls are synchronous unless noted.
+ *   - Poses are 4x4 double, COLUMN-MAJOR, i.e. exactly Eigen::Isometry3d::data(); H is 6x6
+ *     double column-major (Eigen::Matrix<double,6,6>::data(), it is symmetric), b is 6 doubles.
+ *     Twist order is (rot xyz, trans xyz) as in the reference.
+ *   - Point clouds are packed float xyz (Eigen::Vector3f layout, 12 B/point).
+ *   - 3x3 covariances returned by getters are 9 floats column-major (Eigen::Matrix3f layout).
+ *   - Enum values equal the reference's enum class ordinals (gicp_settings.hpp:7-11,
+ *     ndt_settings.hpp:6) so a static_cast<int>() in the shim is enough.
+ */
+#ifndef FAST_VGICP_HIP_H
+#define FAST_VGICP_HIP_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct fvh_vgicp fvh_vgicp; /* replaces fast_gicp::cuda::FastVGICPCudaCore */
+typedef struct fvh_ndt fvh_ndt;     /* replaces fast_gicp::cuda::NDTCudaCore */
+
+enum fvh_status { FVH_OK = 0, FVH_ERR_INVALID_ARGUMENT = 1, FVH_ERR_BAD_STATE = 2, FVH_ERR_HIP = 3, FVH_ERR_UNSUPPORTED = 4, FVH_ERR_COMM = 5 };
+
+/* fast_gicp::RegularizationMethod (gicp_settings.hpp:7) */
+enum fvh_regularization { FVH_REG_NONE = 0, FVH_REG_MIN_EIG = 1, FVH_REG_NORMALIZED_MIN_EIG = 2, FVH_REG_PLANE = 3, FVH_REG_FROBENIUS = 4 };
+/* fast_gicp::NeighborSearchMethod (gicp_settings.hpp:9) */
+enum fvh_neighbor_search { FVH_DIRECT27 = 0, FVH_DIRECT7 = 1, FVH_DIRECT1 = 2, FVH_DIRECT_RADIUS = 3 };
+/* fast_gicp::NDTDistanceMode (ndt_settings.hpp:6) */
+enum fvh_ndt_distance_mode { FVH_NDT_P2D = 0, FVH_NDT_D2D = 1 };
+/* arithmetic of the per-correspondence cost math: fp64 matches the CPU FastVGICP (default),
+ * fp32 matches the CUDA path's float arithmetic (sums are still accumulated in fp64). */
+enum fvh_precision { FVH_COMPUTE_FP64 = 0, FVH_COMPUTE_FP32 = 1 };
+
+/* LsqRegistration parameters (lsq_registration_impl.hpp:9-22 defaults) for the device-resident LM */
+typedef struct fvh_lm_params {
+  int max_iterations;            /* 64   pcl max_iterations_ */
+  double rotation_epsilon;       /* 2e-3 */
+  double transformation_epsilon; /* 5e-4 */
+  int lm_max_iterations;         /* 10 */
+  double lm_init_lambda_factor;  /* 1e-9 */
+} fvh_lm_params;
+
+typedef struct fvh_lm_result {
+  double T[16];        /* final pose x0, column-major double (reference casts it to float) */
+  double H[36];        /* final_hessian_ (last accepted, undamped) */
+  double final_error;  /* y0 of the last linearisation */
+  int converged;       /* converged_ */
+  int nr_iterations;   /* nr_iterations_ (index of the last outer iteration) */
+  int num_linearize;   /* calls to linearize() */
+  int num_error_evals; /* calls to compute_error() */
+  int lm_failed;       /* 1 = "lm not converged!!" (lsq_registration_impl.hpp:69-72) */
+  int num_launches;    /* kernel launches used by this align */
+} fvh_lm_result;
+
+void fvh_default_lm_params(fvh_lm_params* p);
+int fvh_device_count(int* count);
+
+/* ---------------------------------------------------------------------------------------------
+ * FastVGICPCudaCore
+ * ------------------------------------------------------------------------------------------- */
+/* [VC]:37 ctor ([VCU]:18-30: res 1.0, kernel 0.25/3.0, offsets {0,0,0}) / [VC]:38 dtor */
+int fvh_vgicp_create(int device, fvh_vgicp** out);
+int fvh_vgicp_destroy(fvh_vgicp* h);
+const char* fvh_vgicp_last_error(const fvh_vgicp* h);
+
+int fvh_vgicp_set_resolution(fvh_vgicp* h, double resolution);                               /* [VC]:40 */
+int fvh_vgicp_set_kernel_params(fvh_vgicp* h, double kernel_width, double kernel_max_dist);  /* [VC]:41 */
+int fvh_vgicp_set_neighbor_search_method(fvh_vgicp* h, int method, double radius);           /* [VC]:42, [VCU]:41-94 */
+int fvh_vgicp_set_precision(fvh_vgicp* h, int precision);                                    /* new */
+
+int fvh_vgicp_swap_source_and_target(fvh_vgicp* h);                                          /* [VC]:44, [VCU]:97-107 */
+int fvh_vgicp_set_source_cloud(fvh_vgicp* h, const float* xyz, int n);                       /* [VC]:45 */
+int fvh_vgicp_set_target_cloud(fvh_vgicp* h, const float* xyz, int n);                       /* [VC]:46 */
+/* same, but the cloud is already in device memory (stride_floats = 3 or 4); D2D copy on the handle's stream */
+int fvh_vgicp_set_source_cloud_device(fvh_vgicp* h, const float* d_xyz, int n, int stride_floats);
+int fvh_vgicp_set_target_cloud_device(fvh_vgicp* h, const float* d_xyz, int n, int stride_floats);
+
+int fvh_vgicp_set_source_neighbors(fvh_vgicp* h, int k, const int* neighbors /* n*k */);     /* [VC]:48 */
+int fvh_vgicp_set_target_neighbors(fvh_vgicp* h, int k, const int* neighbors);               /* [VC]:49 */
+int fvh_vgicp_find_source_neighbors(fvh_vgicp* h, int k);                                    /* [VC]:50 brute-force k-NN incl. self */
+int fvh_vgicp_find_target_neighbors(fvh_vgicp* h, int k);                                    /* [VC]:51 */
+
+int fvh_vgicp_calculate_source_covariances(fvh_vgicp* h, int regularization);                /* [VC]:53 */
+int fvh_vgicp_calculate_target_covariances(fvh_vgicp* h, int regularization);                /* [VC]:54 */
+int fvh_vgicp_calculate_source_covariances_rbf(fvh_vgicp* h, int regularization);            /* [VC]:56 */
+int fvh_vgicp_calculate_target_covariances_rbf(fvh_vgicp* h, int regularization);            /* [VC]:57 */
+/* new: inject covariances computed elsewhere (9 doubles per point, symmetric, any major) */
+int fvh_vgicp_set_source_covariances(fvh_vgicp* h, const double* covs9);
+int fvh_vgicp_set_target_covariances(fvh_vgicp* h, const double* covs9);
+
+int fvh_vgicp_get_num_source_points(const fvh_vgicp* h, int* n);
+int fvh_vgicp_get_num_target_points(const fvh_vgicp* h, int* n);
+int fvh_vgicp_get_source_neighbors(fvh_vgicp* h, int* k, int* neighbors /* n*k, may be NULL to query k */);
+int fvh_vgicp_get_target_neighbors(fvh_vgicp* h, int* k, int* neighbors);
+int fvh_vgicp_get_source_covariances(fvh_vgicp* h, float* covs9);                            /* [VC]:59 */
+int fvh_vgicp_get_target_covariances(fvh_vgicp* h, float* covs9);                            /* [VC]:60 */
+int fvh_vgicp_get_num_voxels(fvh_vgicp* h, int* num_voxels);
+int fvh_vgicp_get_voxel_num_points(fvh_vgicp* h, int* num_points);                           /* [VC]:62 */
+int fvh_vgicp_get_voxel_means(fvh_vgicp* h, float* means3);                                  /* [VC]:63 */
+int fvh_vgicp_get_voxel_covs(fvh_vgicp* h, float* covs9);                                    /* [VC]:64 */
+int fvh_vgicp_get_voxel_coords(fvh_vgicp* h, int* coords3);                                  /* new (same order as the three above) */
+int fvh_vgicp_get_num_correspondences(fvh_vgicp* h, int* n);
+int fvh_vgicp_get_voxel_correspondences(fvh_vgicp* h, int* pairs /* n*2: (source index, voxel index in getter order) */); /* [VC]:65 */
+
+int fvh_vgicp_create_target_voxelmap(fvh_vgicp* h);                                          /* [VC]:67 */
+int fvh_vgicp_update_correspondences(fvh_vgicp* h, const double* T16);                       /* [VC]:69 */
+/* [VC]:71 -- H36/b6 may both be NULL (error only).  Reuses the correspondences and the
+ * linearisation rotation of the last update_correspondences(). */
+int fvh_vgicp_compute_error(fvh_vgicp* h, const double* T16, double* H36, double* b6, double* error);
+
+/* new: the whole LsqRegistration::computeTransformation loop (lsq_registration_impl.hpp:53-168)
+ * on device: one fused kernel per linearize()/compute_error(), LM step on device, one D2H. */
+int fvh_vgicp_align(fvh_vgicp* h, const double* guess16, const fvh_lm_params* params, fvh_lm_result* result);
+/* new: pcl::Registration::getFitnessScore(max_range) -- mean squared exact-NN distance of
+ * (float)T * source to the target cloud (brute-force tiled 1-NN on device). */
+int fvh_vgicp_fitness_score(fvh_vgicp* h, const double* T16, double max_range, double* score);
+
+/* new: per-kernel-class HIP-event timing on the handle's stream (for bench.py's roofline leg) */
+int fvh_vgicp_profile_enable(fvh_vgicp* h, int on);
+int fvh_vgicp_profile_reset(fvh_vgicp* h);
+/* kernel_class in {"cost", "knn", "cov", "rbf", "voxelmap", "fitness"}; sums over launches since reset */
+int fvh_vgicp_profile_get(fvh_vgicp* h, const char* kernel_class, double* total_ms, int* launches);
+int fvh_vgicp_synchronize(fvh_vgicp* h);
+
+/* new: multi-GPU (one process per GPU).  Every rank holds a spatial-tile shard of the source
+ * cloud and the target voxel map; the 28-value normal-equation block (err, b, upper H) is
+ * all-reduced over RCCL on the handle's stream after every cost evaluation. */
+int fvh_comm_unique_id(void* id128 /* 128 bytes out */);
+int fvh_vgicp_comm_init(fvh_vgicp* h, const void* id128, int nranks, int rank);
+int fvh_vgicp_comm_destroy(fvh_vgicp* h);
+
+/* ---------------------------------------------------------------------------------------------
+ * NDTCudaCore
+ * ------------------------------------------------------------------------------------------- */
+int fvh_ndt_create(int device, fvh_ndt** out);                                               /* [NC]:34-35, [NCU]:13-23 (D2D, DIRECT7, res 1.0) */
+int fvh_ndt_destroy(fvh_ndt* h);
+const char* fvh_ndt_last_error(const fvh_ndt* h);
+int fvh_ndt_set_distance_mode(fvh_ndt* h, int mode);                                         /* [NC]:37 */
+int fvh_ndt_set_resolution(fvh_ndt* h, double resolution);                                   /* [NC]:38 */
+int fvh_ndt_set_neighbor_search_method(fvh_ndt* h, int method, double radius);               /* [NC]:39 */
+int fvh_ndt_set_precision(fvh_ndt* h, int precision);
+int fvh_ndt_swap_source_and_target(fvh_ndt* h);                                              /* [NC]:41, [NCU]:90-93 */
+int fvh_ndt_set_source_cloud(fvh_ndt* h, const float* xyz, int n);                           /* [NC]:42 (invalidates the source voxel map) */
+int fvh_ndt_set_target_cloud(fvh_ndt* h, const float* xyz, int n);                           /* [NC]:43 */
+int fvh_ndt_set_source_cloud_device(fvh_ndt* h, const float* d_xyz, int n, int stride_floats);
+int fvh_ndt_set_target_cloud_device(fvh_ndt* h, const float* d_xyz, int n, int stride_floats);
+int fvh_ndt_create_voxelmaps(fvh_ndt* h);                                                    /* [NC]:45 (lazy; source skipped in P2D) */
+int fvh_ndt_create_target_voxelmap(fvh_ndt* h);                                              /* [NC]:46 */
+int fvh_ndt_create_source_voxelmap(fvh_ndt* h);                                              /* [NC]:47 */
+int fvh_ndt_update_correspondences(fvh_ndt* h, const double* T16);                           /* [NC]:49 */
+int fvh_ndt_compute_error(fvh_ndt* h, const double* T16, double* H36, double* b6, double* error); /* [NC]:50 */
+int fvh_ndt_align(fvh_ndt* h, const double* guess16, const fvh_lm_params* params, fvh_lm_result* result);
+int fvh_ndt_fitness_score(fvh_ndt* h, const double* T16, double max_range, double* score);
+int fvh_ndt_get_num_voxels(fvh_ndt* h, int which /* 0 source, 1 target */, int* num_voxels);
+int fvh_ndt_get_voxels(fvh_ndt* h, int which, int* coords3, int* num_points, float* means3, float* covs9);
+int fvh_ndt_get_num_correspondences(fvh_ndt* h, int* n);
+int fvh_ndt_synchronize(fvh_ndt* h);
+int fvh_ndt_comm_init(fvh_ndt* h, const void* id128, int nranks, int rank);
+int fvh_ndt_comm_destroy(fvh_ndt* h);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FAST_VGICP_HIP_H */

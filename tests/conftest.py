@@ -1,0 +1,25 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def _has_gpu():
+    try:
+        from fast_gicp_amd import capi
+        return capi.device_count() > 0
+    except Exception:
+        return False
+
+
+@pytest.fixture(scope="session")
+def gpu_available():
+    return _has_gpu()
