@@ -17,9 +17,17 @@
 
 namespace fvh {
 
+// fp32 squared distance with a fixed association and NO fma contraction (hipcc's __fmul_rn is a
+// plain '*' that -ffp-contract=fast would fuse): bit-identical to the oracle's sqdist_f32.
 __device__ __forceinline__ float sqdist_nofma(const float4& p, float qx, float qy, float qz) {
-  const float dx = __fsub_rn(p.x, qx), dy = __fsub_rn(p.y, qy), dz = __fsub_rn(p.z, qz);
-  return __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
+#pragma clang fp contract(off)
+  const float dx = p.x - qx, dy = p.y - qy, dz = p.z - qz;
+  return (dx * dx + dy * dy) + dz * dz;
+}
+// (x*m0 + y*m1) + (z*m2 + m3): pcl::transformPointCloud's SSE association, no contraction
+__device__ __forceinline__ float transform_row_nofma(const float4& p, const float* m) {
+#pragma clang fp contract(off)
+  return (p.x * m[0] + p.y * m[1]) + (p.z * m[2] + m[3]);
 }
 
 constexpr int KNN_Q = 8;  // queries per wave
@@ -136,8 +144,8 @@ __global__ __launch_bounds__(256) void cov_rbf_kernel(const float4* __restrict__
     const float4 p = pts[min(c, n - 1)];
 #pragma unroll
     for (int j = 0; j < RBF_Q; j++) {
-      const float dx = __fsub_rn(p.x, qx[j]), dy = __fsub_rn(p.y, qy[j]), dz = __fsub_rn(p.z, qz[j]);
-      const float sq = __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
+      const float dx = p.x - qx[j], dy = p.y - qy[j], dz = p.z - qz[j];
+      const float sq = sqdist_nofma(p, qx[j], qy[j], qz[j]);
       const bool in = (c < n) && !(sq > max_dist_sq);
       const float w = in ? __expf(-kernel_width * sq) : 0.f;
       sw[j] += w;
@@ -178,10 +186,9 @@ __global__ __launch_bounds__(256) void fitness_kernel(const float4* __restrict__
 #pragma unroll
   for (int j = 0; j < FIT_Q; j++) {
     const float4 p = src[min(q_base + j, ns - 1)];
-    // (x*m0 + y*m1) + (z*m2 + m3): pcl::transformPointCloud's SSE association
-    qx[j] = __fadd_rn(__fadd_rn(__fmul_rn(p.x, T12[0]), __fmul_rn(p.y, T12[1])), __fadd_rn(__fmul_rn(p.z, T12[2]), T12[3]));
-    qy[j] = __fadd_rn(__fadd_rn(__fmul_rn(p.x, T12[4]), __fmul_rn(p.y, T12[5])), __fadd_rn(__fmul_rn(p.z, T12[6]), T12[7]));
-    qz[j] = __fadd_rn(__fadd_rn(__fmul_rn(p.x, T12[8]), __fmul_rn(p.y, T12[9])), __fadd_rn(__fmul_rn(p.z, T12[10]), T12[11]));
+    qx[j] = transform_row_nofma(p, T12 + 0);
+    qy[j] = transform_row_nofma(p, T12 + 4);
+    qz[j] = transform_row_nofma(p, T12 + 8);
     best[j] = __builtin_inff();
   }
   for (int base = 0; base < nt; base += 64) {

@@ -1,0 +1,184 @@
+"""CPU tests: pin the oracle (the fp64 restatement of the reference's CPU FastVGICP) against every
+known answer the reference holds for the hot path and against an independent numpy twin."""
+import os
+
+import numpy as np
+import pytest
+
+from tests import util
+
+
+@pytest.fixture(scope="module")
+def O():
+    from oracle import oracle
+    oracle.build()
+    return oracle
+
+
+def test_readme_point_counts(O):
+    """README.md:116 'target:17249[pts] source:17518[pts]' -- produced by ApproximateVoxelGrid(0.1) WITHOUT the
+    origin filter that HEAD's align.cpp:127-133 added later; with the filter HEAD gives 17,047 / 17,334."""
+    t, s = util.bundled_pair(origin_filter=False)
+    assert (len(t), len(s)) == (17249, 17518)
+    t, s = util.bundled_pair(origin_filter=True)
+    assert (len(t), len(s)) == (17047, 17334)
+
+
+def test_gicp_test_input_counts(O):
+    """gicp_test.cpp:55-65: exact VoxelGrid leaf 0.2, no origin filter."""
+    t, s = util.bundled_pair(origin_filter=False, leaf=0.2, exact_voxelgrid=True)
+    assert (len(t), len(s)) == (7908, 8061)
+
+
+@pytest.mark.parametrize("method", ["VGICP", "NDT"])
+def test_gicp_test_scenarios(O, method):
+    """The reference's only correctness pin (gicp_test.cpp:147-201): forward / backward / swap-and-set-source /
+    swap-and-set-target, each within 0.05 m and 1 deg of data/relative.txt and converged."""
+    t, s = util.bundled_pair(origin_filter=False, leaf=0.2, exact_voxelgrid=True)
+    gt = util.relative_pose()
+    make = (lambda: O.FastVGICP()) if method == "VGICP" else (lambda: O.NDT())
+
+    def check(T, conv, label):
+        te, re_ = util.pose_error(gt, T)
+        assert te < 0.05 and re_ < np.radians(1.0) and conv, label
+
+    reg = make()
+    reg.set_target(t); reg.set_source(s)
+    r = reg.align(); check(r["T"], r["converged"], "forward")
+    reg.set_target(s); reg.set_source(t)
+    r = reg.align(); check(np.linalg.inv(r["T"]), r["converged"], "backward")
+    reg = make()
+    reg.set_source(t); reg.swap(); reg.set_source(s)
+    r = reg.align(); check(r["T"], r["converged"], "swap and set source")
+    reg = make()
+    reg.set_target(s); reg.swap(); reg.set_target(t)
+    r = reg.align(); check(r["T"], r["converged"], "swap and set target")
+
+
+def test_readme_fitness_band(O):
+    """README.md:126-128 vgicp fitness 0.204067 (stale revision) -> +-1 % sanity band (SURVEY 6 caveat 3)."""
+    t, s = util.bundled_pair(origin_filter=True)
+    g = O.FastVGICP()
+    g.set_target(t); g.set_source(s)
+    r = g.align()
+    f = g.fitness()
+    assert abs(f - 0.204067) / 0.204067 < 0.01
+    # values recorded in SURVEY 8(c)(4) for HEAD preprocessing, res 1.0, DIRECT1
+    assert r["iterations"] == 4
+    np.testing.assert_allclose(r["T"][:3, 3], [0.498359, 0.117208, -0.029736], atol=2e-6)
+    assert abs(f - 0.205022) < 2e-6
+
+
+def test_direct27_recorded_values(O):
+    t, s = util.bundled_pair(origin_filter=True)
+    g = O.FastVGICP(search=O.DIRECT27)
+    g.set_target(t); g.set_source(s)
+    r = g.align()
+    np.testing.assert_allclose(r["T"][:3, 3], [0.503962, 0.074634, -0.025146], atol=2e-6)
+    assert abs(g.fitness() - 0.198792) < 2e-6
+    coords, num, _, _ = g.get_voxelmap()
+    assert len(coords) == 1087 and num.max() == 171 and num.sum() == len(t)
+
+
+# ---------------------------------------------------------------------------------------------
+# independent numpy / scipy twin
+# ---------------------------------------------------------------------------------------------
+def test_knn_vs_scipy(O):
+    from scipy.spatial import cKDTree
+    _, s = util.bundled_pair()
+    s = s[:4000]
+    idx = O.knn(s, 20)
+    d, ref = cKDTree(s.astype(np.float64)).query(s.astype(np.float64), k=20)
+    # same neighbour sets wherever the 20th/21st distances are not (nearly) tied
+    d21 = cKDTree(s.astype(np.float64)).query(s.astype(np.float64), k=21)[0][:, 20]
+    clear = (d21 - d[:, 19]) > 1e-5
+    same = np.array([set(a) == set(b) for a, b in zip(idx, ref)])
+    assert same[clear].all()
+    assert (idx[:, 0] == np.arange(len(s))).mean() > 0.99  # self is the nearest neighbour
+
+
+def test_covariance_and_regularisation_vs_numpy(O):
+    from tests import np_twin
+    _, s = util.bundled_pair()
+    s = s[:3000]
+    idx = O.knn(s, 20)
+    for reg in (O.NONE, O.PLANE, O.MIN_EIG, O.NORMALIZED_MIN_EIG, O.FROBENIUS):
+        got = O.covariances_knn(s, 20, reg, idx=idx)
+        ref = np_twin.covariances(s, idx, reg)
+        err = np.abs(got - ref).max(axis=(1, 2)) / np.abs(ref).max(axis=(1, 2))
+        assert np.quantile(err, 0.999) < 1e-7, (reg, err.max())
+
+
+def test_voxelmap_and_linearize_vs_numpy(O):
+    from tests import np_twin
+    t, s = util.bundled_pair()
+    t, s = t[:5000], s[:5000]
+    ct, cs = O.covariances_knn(t, 20, O.PLANE), O.covariances_knn(s, 20, O.PLANE)
+    coords, num, means, covs = O.voxelmap_vgicp(t, ct, 1.0)
+    vm = np_twin.voxelmap(t, ct, 1.0)
+    assert set(map(tuple, coords)) == set(vm)
+    for c, n, m, cv in zip(coords, num, means, covs):
+        n2, m2, c2 = vm[tuple(c)]
+        assert n == n2
+        np.testing.assert_allclose(m, m2, rtol=1e-12, atol=1e-12)
+        np.testing.assert_allclose(cv, c2, rtol=1e-12, atol=1e-14)
+    for search in (O.DIRECT1, O.DIRECT7, O.DIRECT27):
+        g = O.FastVGICP(search=search)
+        g.set_target(t); g.set_source(s); g.set_target_covs(ct); g.set_source_covs(cs); g.prepare()
+        T = util.random_pose(np.random.default_rng(3), 1.0, 0.3)
+        e, H, b = g.linearize(T)
+        e2, H2, b2, nc = np_twin.linearize(s, cs, vm, 1.0, O.neighbor_offsets(search), T)
+        assert nc == g.num_correspondences()
+        assert abs(e - e2) < 1e-10 * abs(e2)
+        assert util.rel_err(H, H2) < 1e-10 and util.rel_err(b, b2) < 1e-10
+
+
+def test_se3_exp_vs_scipy(O):
+    from scipy.linalg import expm
+    rng = np.random.default_rng(0)
+    for scale in (1e-7, 1e-3, 0.3, 2.0):
+        a = rng.normal(size=6) * scale
+        W = np.zeros((4, 4))
+        W[:3, :3] = [[0, -a[2], a[1]], [a[2], 0, -a[0]], [-a[1], a[0], 0]]
+        W[:3, 3] = a[3:]
+        np.testing.assert_allclose(O.se3_exp(a), expm(W), atol=1e-12)
+
+
+def test_ndt_voxelmap_vs_numpy(O):
+    t, _ = util.bundled_pair()
+    t = t[:6000]
+    coords, num, means, covs = O.voxelmap_ndt(t, 1.0)
+    keys = np.floor(t.astype(np.float64) / 1.0 - 0.5).astype(np.int64)
+    for c, n, m, cv in list(zip(coords, num, means, covs))[:200]:
+        sel = t[(keys == c).all(axis=1)].astype(np.float64)
+        assert len(sel) == n
+        np.testing.assert_allclose(m, sel.mean(axis=0), atol=1e-12)
+        C = (sel - sel.mean(0)).T @ (sel - sel.mean(0)) / n
+        w, V = np.linalg.eigh(C)
+        ref = (V * np.maximum(w, 1e-3)) @ V.T
+        np.testing.assert_allclose(cv, ref, atol=1e-9)
+
+
+def test_rbf_covariance_vs_numpy(O):
+    _, s = util.bundled_pair()
+    s = s[:1500]
+    got = O.covariances_rbf(s, 0.5, 2.5, O.NONE)
+    p = s.astype(np.float64)
+    for i in range(0, len(s), 97):
+        d = p - p[i]
+        sq = (s[:, 0] - s[i, 0]) ** 2 + (s[:, 1] - s[i, 1]) ** 2 + (s[:, 2] - s[i, 2]) ** 2
+        m = sq <= np.float32(2.5) ** 2
+        w = np.exp(-0.5 * sq[m].astype(np.float64))
+        mu = (w[:, None] * p[m]).sum(0) / w.sum()
+        C = ((w[:, None, None] * p[m][:, :, None] * p[m][:, None, :]).sum(0) - np.outer(mu, (w[:, None] * p[m]).sum(0))) / w.sum()
+        np.testing.assert_allclose(got[i], C, atol=1e-9 * max(1, np.abs(p[i]).max() ** 2))
+
+
+def test_product_preprocessing_matches_oracle(O):
+    """fast_gicp_amd.preprocess (product host code) against the oracle restatement and the README counts."""
+    from fast_gicp_amd import preprocess as P
+    t, s = P.bundled_pair(util.DATA)
+    ot, os_ = util.bundled_pair()
+    assert np.array_equal(t, ot) and np.array_equal(s, os_)
+    t2, s2 = P.bundled_pair(util.DATA, origin_filter=False)
+    assert (len(t2), len(s2)) == (17249, 17518)
