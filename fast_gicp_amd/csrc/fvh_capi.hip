@@ -7,6 +7,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <string>
@@ -414,7 +415,8 @@ int launch_cost(Engine* e, const CostSource& src, const VoxelMapDev& vm, int hos
   P.src_pts = src.pts; P.src_cov = src.cov; P.d_n_src = src.d_n; P.n_src = src.n_upper;
   P.table = vm.table.as<uint4>(); P.mask = vm.capacity - 1; P.res = vm.res;
   P.offsets = e->offsets_dev.as<int>(); P.n_off = e->n_off;
-  const long long target_items = 256LL * 256 * 2;
+  static const long long target_items = [] { const char* v = getenv("FVH_COST_TARGET_ITEMS"); return v ? atoll(v) : 256LL * 256 * 2; }();
+  static const int max_blocks = [] { const char* v = getenv("FVH_COST_MAX_BLOCKS"); int b = v ? atoi(v) : MAX_COST_BLOCKS; return b < 1 ? 1 : (b > MAX_COST_BLOCKS ? MAX_COST_BLOCKS : b); }();
   int groups = (int)std::min<long long>(e->n_off, std::max<long long>(1, target_items / std::max(src.n_upper, 1)));
   P.group = (e->n_off + groups - 1) / groups;
   P.groups_per_src = (e->n_off + P.group - 1) / P.group;
@@ -426,7 +428,7 @@ int launch_cost(Engine* e, const CostSource& src, const VoxelMapDev& vm, int hos
   if (lin) P.lin = *lin;
   if (ev) P.ev = *ev;
   const long long items = (long long)src.n_upper * P.groups_per_src;
-  const int blocks = (int)std::max<long long>(1, std::min<long long>(MAX_COST_BLOCKS, (items + 255) / 256));
+  const int blocks = (int)std::max<long long>(1, std::min<long long>(max_blocks, (items + 255) / 256));
   {
     ProfScope ps(e, "cost");
     if (e->precision == FVH_COMPUTE_FP32) cost_kernel<float, MODE><<<blocks, 256, 0, e->stream>>>(P);

@@ -214,7 +214,7 @@ __device__ inline void dev_lm_step(LmState* st, const double* sums) {
     }
   } else {
     st->x0 = st->xi;
-    st->lambda = st->lambda * fmax(1.0 / 3.0, 1 - pow(2 * rho - 1, 3));
+    { const double u = 2 * rho - 1; st->lambda = st->lambda * fmax(1.0 / 3.0, 1 - u * u * u); }
     for (int i = 0; i < 36; i++) st->final_H[i] = st->H[i];
     step_done = true;
   }

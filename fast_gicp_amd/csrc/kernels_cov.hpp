@@ -32,41 +32,63 @@ __device__ __forceinline__ float transform_row_nofma(const float4& p, const floa
 
 constexpr int KNN_Q = 8;  // queries per wave
 
-// out_idx: [n][k] neighbour indices, ascending (distance, index); k <= 64
+// lane i <- lane i-1 (lane 0 keeps `fill`): one v_mov_b32_dpp wave_shr:1, no LDS crossbar
+__device__ __forceinline__ float wave_shr1(float v, float fill) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, fill), __builtin_bit_cast(int, v), 0x138, 0xF, 0xF, false));
+}
+__device__ __forceinline__ int wave_shr1(int v, int fill) { return __builtin_amdgcn_update_dpp(fill, v, 0x138, 0xF, 0xF, false); }
+// value of a wave-uniform lane -> SGPR (v_readlane_b32); __shfl() would go through the LDS crossbar
+__device__ __forceinline__ float read_lane(float v, int l) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l)); }
+__device__ __forceinline__ int read_lane(int v, int l) { return __builtin_amdgcn_readlane(v, l); }
+
+// out_idx: [n][k] neighbour indices, ascending (distance, index); k <= 64.
+// Candidate batches are visited own-batch-first, then zig-zag outwards (b0, b0+1, b0-1, ...):
+// LiDAR clouds are scan-ordered, so the first few batches already contain most true neighbours and
+// tau is tight for the rest of the sweep (index-ascending order makes EVERY approaching candidate an
+// insertion: measured 1.57 ms vs the k*ln(N/k) model's ~0.1 ms on the 17k cloud). The list order is
+// the total order (distance, index), so the result does not depend on the visiting order.
 __global__ __launch_bounds__(256) void knn_bruteforce_kernel(const float4* __restrict__ pts, int n, int k, int* __restrict__ out_idx) {
   const int lane = threadIdx.x & 63;
   const int wave = blockIdx.x * 4 + (threadIdx.x >> 6);
   const int q_base = wave * KNN_Q;
   if (q_base >= n) return;
   float qx[KNN_Q], qy[KNN_Q], qz[KNN_Q];
-  float ld[KNN_Q];  // lane j: j-th smallest distance so far
-  int li[KNN_Q];    //         and its index
-  float tau[KNN_Q]; // wave-uniform: current k-th smallest distance
+  float ld[KNN_Q];   // lane j: j-th smallest (distance, index) so far
+  int li[KNN_Q];
+  float tau_d[KNN_Q];  // wave-uniform: the current k-th entry
+  int tau_i[KNN_Q];
 #pragma unroll
   for (int j = 0; j < KNN_Q; j++) {
     const float4 q = pts[min(q_base + j, n - 1)];
     qx[j] = q.x; qy[j] = q.y; qz[j] = q.z;
-    ld[j] = __builtin_inff(); li[j] = -1; tau[j] = __builtin_inff();
+    ld[j] = __builtin_inff(); li[j] = 0x7fffffff; tau_d[j] = __builtin_inff(); tau_i[j] = 0x7fffffff;
   }
-  for (int base = 0; base < n; base += 64) {
+  const int nb = (n + 63) >> 6;
+  const int b0 = q_base >> 6;
+  for (int s = 0; s < nb; s++) {
+    int b = (s & 1) ? b0 + ((s + 1) >> 1) : b0 - (s >> 1);
+    b = b < 0 ? b + nb : (b >= nb ? b - nb : b);
+    const int base = b << 6;
     const int c = base + lane;
     const float4 p = pts[min(c, n - 1)];
 #pragma unroll
     for (int j = 0; j < KNN_Q; j++) {
       float d = sqdist_nofma(p, qx[j], qy[j], qz[j]);
       d = c < n ? d : __builtin_inff();
-      unsigned long long mask = __ballot(d < tau[j]);
+      unsigned long long mask = __ballot(d <= tau_d[j]);  // cheap superset test; exact test below
       while (mask) {  // wave-uniform
         const int src = __ffsll((long long)mask) - 1;
         mask &= mask - 1;
-        const float cd = __shfl(d, src);
-        if (!(cd < tau[j])) continue;  // tau may have tightened since the ballot
-        const int pos = __popcll(__ballot(ld[j] <= cd));
-        const float sd = __shfl_up(ld[j], 1);
-        const int si = __shfl_up(li[j], 1);
+        const float cd = read_lane(d, src);
+        const int ci = base + src;
+        if (!(cd < tau_d[j] || (cd == tau_d[j] && ci < tau_i[j]))) continue;
+        const int pos = __popcll(__ballot(ld[j] < cd || (ld[j] == cd && li[j] < ci)));
+        const float sd = wave_shr1(ld[j], ld[j]);
+        const int si = wave_shr1(li[j], li[j]);
         if (lane > pos) { ld[j] = sd; li[j] = si; }
-        else if (lane == pos) { ld[j] = cd; li[j] = base + src; }
-        tau[j] = __shfl(ld[j], k - 1);
+        else if (lane == pos) { ld[j] = cd; li[j] = ci; }
+        tau_d[j] = read_lane(ld[j], k - 1);
+        tau_i[j] = read_lane(li[j], k - 1);
       }
     }
   }
