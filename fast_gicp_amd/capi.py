@@ -281,6 +281,14 @@ class VGICPCore(_Core):
         self._call("get_voxel_correspondences", _p(out))
         return out
 
+    def debug_set_voxel_hint(self, n):
+        self._call("debug_set_voxel_hint", int(n))
+
+    def debug_table_capacity(self):
+        n = C.c_int(0)
+        self._call("debug_get_table_capacity", C.byref(n))
+        return n.value
+
     def profile_enable(self, on=True):
         self._call("profile_enable", int(on))
 

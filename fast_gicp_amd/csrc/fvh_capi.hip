@@ -9,6 +9,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
 #include <map>
 #include <string>
 #include <unordered_map>
@@ -53,6 +54,7 @@ struct VoxelMapDev {
   unsigned capacity = 0;
   DevBuf table, acc, occupied, compact_pts, compact_cov, counters;  // counters: [0] num_voxels [1] dropped
   bool valid = false;
+  int nv_hint = -1;      // voxel count of the last build seen through a readback; sizes the next table
   // lazily fetched host copies (getters only)
   bool host_valid = false;
   std::vector<uint4> h_table;
@@ -330,12 +332,18 @@ int get_nbr_host(Engine* e, CloudDev& c, int* k, int* out) {
 
 // GaussianVoxelMap::create_voxelmap (gaussian_voxelmap.cu:208-257) -- two kernels, no retry loop
 template <int MODE>
-int build_voxelmap(Engine* e, const CloudDev& c, VoxelMapDev& vm, double res, bool want_compact) {
+int build_voxelmap(Engine* e, const CloudDev& c, VoxelMapDev& vm, double res, bool want_compact, bool force_safe = false) {
   if (!c.has_pts) return e->fail(FVH_ERR_BAD_STATE, "create_voxelmap: cloud not set");
   if (MODE == 0 && !c.has_cov) return e->fail(FVH_ERR_BAD_STATE, "create_voxelmap: covariances not computed");
   if (!(res > 0)) return e->fail(FVH_ERR_INVALID_ARGUMENT, "create_voxelmap: resolution must be > 0");
-  unsigned cap = 1024;
-  while (cap < 2u * (unsigned)std::max(c.n, 1)) cap <<= 1;
+  unsigned safe = 1024;
+  while (safe < 2u * (unsigned)std::max(c.n, 1)) safe <<= 1;
+  unsigned cap = safe;  // can never overflow
+  if (!force_safe && vm.nv_hint >= 0) {  // keep the table L2-resident: 4x the last voxel count
+    cap = 1024;
+    while (cap < 4u * (unsigned)vm.nv_hint) cap <<= 1;
+    cap = std::min(cap, safe);
+  }
   vm.res = res;
   vm.capacity = cap;
   vm.invalidate();
@@ -406,6 +414,7 @@ int get_voxels_host(Engine* e, VoxelMapDev& vm, int* coords3, int* num_points, f
 
 struct CostSource {
   const float4* pts; const float4* cov; const int* d_n; int n_upper;
+  const int* counters2;  // source voxel map counters (D2D) or null
 };
 
 template <int MODE>
@@ -423,6 +432,8 @@ int launch_cost(Engine* e, const CostSource& src, const VoxelMapDev& vm, int hos
   P.corr = e->corr.as<int>();
   P.st = e->state.as<LmState>(); P.partials = e->partials.as<double>(); P.ticket = e->ticket.as<unsigned>();
   P.d_num_corr = e->misc.as<int>();
+  P.vm_counters = vm.counters.as<int>();
+  P.vm_counters2 = src.counters2;
   P.host_phase = host_phase;
   P.defer_lm = (e->comm != nullptr) ? 1 : 0;
   if (lin) P.lin = *lin;
@@ -446,7 +457,7 @@ int allreduce_sums(Engine* e) {
 }
 
 template <int MODE>
-int do_update_correspondences(Engine* e, const CostSource& src, const VoxelMapDev& vm, const double* T16) {
+int do_update_correspondences(Engine* e, const CostSource& src, VoxelMapDev& vm, const double* T16) {
   if (!T16) return e->fail(FVH_ERR_INVALID_ARGUMENT, "update_correspondences: null pose");
   if (!vm.valid) return e->fail(FVH_ERR_BAD_STATE, "update_correspondences: target voxel map not built");
   HIP_OR_FAIL(e, e->corr.ensure(sizeof(int) * (size_t)std::max(src.n_upper, 1) * e->n_off));
@@ -459,29 +470,44 @@ int do_update_correspondences(Engine* e, const CostSource& src, const VoxelMapDe
   return FVH_OK;
 }
 
+using Rebuild = std::function<int()>;
+
 template <int MODE>
-int do_compute_error(Engine* e, const CostSource& src, const VoxelMapDev& vm, const double* T16, double* H36, double* b6, double* error) {
+int do_compute_error(Engine* e, const CostSource& src, VoxelMapDev& vm, const double* T16, double* H36, double* b6, double* error, const Rebuild& rebuild_safe) {
   if (!T16 || !error) return e->fail(FVH_ERR_INVALID_ARGUMENT, "compute_error: null argument");
   if (!e->has_corr) return e->fail(FVH_ERR_BAD_STATE, "compute_error: call update_correspondences first");
   const bool deriv = (H36 != nullptr && b6 != nullptr);
   PoseD ev = pose_from_colmajor16(T16);
-  int rc = launch_cost<MODE>(e, src, vm, deriv ? PH_EVAL_DERIV : PH_EVAL_ERROR, &e->lin, &ev);
-  if (rc) return rc;
-  if (e->comm) { rc = allreduce_sums(e); if (rc) return rc; }
-  double* h = reinterpret_cast<double*>(e->pinned);
-  HIP_OR_FAIL(e, hipMemcpyAsync(h, e->state.as<LmState>()->sums, sizeof(double) * PART_STRIDE, hipMemcpyDeviceToHost, e->stream));
-  HIP_OR_FAIL(e, hipStreamSynchronize(e->stream));
-  *error = h[0];
+  LmState* h = reinterpret_cast<LmState*>(e->pinned);
+  for (int attempt = 0; attempt < 2; attempt++) {
+    int rc = launch_cost<MODE>(e, src, vm, deriv ? PH_EVAL_DERIV : PH_EVAL_ERROR, &e->lin, &ev);
+    if (rc) return rc;
+    if (e->comm) { rc = allreduce_sums(e); if (rc) return rc; }
+    HIP_OR_FAIL(e, hipMemcpyAsync(h, e->state.p, sizeof(LmState), hipMemcpyDeviceToHost, e->stream));
+    HIP_OR_FAIL(e, hipStreamSynchronize(e->stream));
+    vm.nv_hint = h->vm_num_voxels;
+    if (h->vm_dropped == 0 || attempt == 1) break;
+    // the hint-sized table overflowed: rebuild at the safe size, redo the correspondences, evaluate again
+    rc = rebuild_safe();
+    if (rc) return rc;
+    HIP_OR_FAIL(e, hipMemsetAsync(e->misc.p, 0, sizeof(int), e->stream));
+    rc = launch_cost<MODE>(e, src, vm, PH_FIND_ONLY, &e->lin, &e->lin);
+    if (rc) return rc;
+    e->has_corr = true;
+  }
+  if (h->vm_dropped) return e->fail(FVH_ERR_BAD_STATE, "voxel map overflow persists after safe rebuild");
+  *error = h->sums[0];
   if (deriv) {
     double Hr[36];
-    unpack_sums(h, Hr, b6);
+    unpack_sums(h->sums, Hr, b6);
     for (int i = 0; i < 6; i++) for (int j = 0; j < 6; j++) H36[j * 6 + i] = Hr[i * 6 + j];  // column-major (symmetric)
   }
   return FVH_OK;
 }
 
 template <int MODE>
-int do_align(Engine* e, const CostSource& src, const VoxelMapDev& vm, const double* guess16, const fvh_lm_params* params, fvh_lm_result* result) {
+int do_align(Engine* e, const CostSource& src, VoxelMapDev& vm, const double* guess16, const fvh_lm_params* params, fvh_lm_result* result, const Rebuild& rebuild_safe,
+             bool retried = false) {
   if (!guess16 || !result) return e->fail(FVH_ERR_INVALID_ARGUMENT, "align: null argument");
   if (!vm.valid) return e->fail(FVH_ERR_BAD_STATE, "align: target voxel map not built");
   fvh_lm_params p;
@@ -510,6 +536,13 @@ int do_align(Engine* e, const CostSource& src, const VoxelMapDev& vm, const doub
     HIP_OR_FAIL(e, hipStreamSynchronize(e->stream));
     if (h->phase == PH_DONE || launched >= budget) break;
     batch = 4;
+  }
+  vm.nv_hint = h->vm_num_voxels;
+  if (h->vm_dropped > 0) {  // hint-sized table overflowed: rebuild at the safe size and run again (rare)
+    if (retried) return e->fail(FVH_ERR_BAD_STATE, "voxel map overflow persists after safe rebuild");
+    int rc = rebuild_safe();
+    if (rc) return rc;
+    return do_align<MODE>(e, src, vm, guess16, params, result, rebuild_safe, true);
   }
   e->last_steps = h->num_linearize + h->num_error_evals;
   e->lin = h->x0;
@@ -586,7 +619,8 @@ struct fvh_vgicp {
   double resolution = 1.0, kernel_width = 0.25, kernel_max_dist = 3.0;  // fast_vgicp_cuda.cu:22-26
   CloudDev source, target;
   VoxelMapDev voxelmap;
-  CostSource cost_source() const { return CostSource{source.pts.as<float4>(), source.cov.as<float4>(), nullptr, source.n}; }
+  CostSource cost_source() const { return CostSource{source.pts.as<float4>(), source.cov.as<float4>(), nullptr, source.n, nullptr}; }
+  Rebuild rebuild_safe() { return [this] { return build_voxelmap<0>(&e, target, voxelmap, voxelmap.res, false, true); }; }
 };
 
 struct fvh_ndt {
@@ -596,8 +630,15 @@ struct fvh_ndt {
   CloudDev source, target;
   VoxelMapDev source_vm, target_vm;
   CostSource cost_source() const {
-    if (distance_mode == FVH_NDT_P2D) return CostSource{source.pts.as<float4>(), nullptr, nullptr, source.n};
-    return CostSource{source_vm.compact_pts.as<float4>(), source_vm.compact_cov.as<float4>(), source_vm.counters.as<int>(), source.n};
+    if (distance_mode == FVH_NDT_P2D) return CostSource{source.pts.as<float4>(), nullptr, nullptr, source.n, nullptr};
+    return CostSource{source_vm.compact_pts.as<float4>(), source_vm.compact_cov.as<float4>(), source_vm.counters.as<int>(), source.n, source_vm.counters.as<int>()};
+  }
+  Rebuild rebuild_safe() {
+    return [this] {
+      int rc = build_voxelmap<1>(&e, target, target_vm, target_vm.res, true, true);
+      if (!rc && distance_mode == FVH_NDT_D2D) rc = build_voxelmap<1>(&e, source, source_vm, source_vm.res, true, true);
+      return rc;
+    };
   }
 };
 
@@ -725,17 +766,19 @@ int fvh_vgicp_update_correspondences(fvh_vgicp* h, const double* T) {
 }
 int fvh_vgicp_compute_error(fvh_vgicp* h, const double* T, double* H, double* b, double* err) {
   CHECK_HANDLE(h);
-  return do_compute_error<MODE_VGICP>(&h->e, h->cost_source(), h->voxelmap, T, H, b, err);
+  return do_compute_error<MODE_VGICP>(&h->e, h->cost_source(), h->voxelmap, T, H, b, err, h->rebuild_safe());
 }
 int fvh_vgicp_align(fvh_vgicp* h, const double* guess, const fvh_lm_params* p, fvh_lm_result* r) {
   CHECK_HANDLE(h);
   if (!h->source.has_pts || !h->source.has_cov) return h->e.fail(FVH_ERR_BAD_STATE, "align: source cloud/covariances not set");
-  return do_align<MODE_VGICP>(&h->e, h->cost_source(), h->voxelmap, guess, p, r);
+  return do_align<MODE_VGICP>(&h->e, h->cost_source(), h->voxelmap, guess, p, r, h->rebuild_safe());
 }
 int fvh_vgicp_fitness_score(fvh_vgicp* h, const double* T, double max_range, double* score) { CHECK_HANDLE(h); return do_fitness(&h->e, h->source, h->target, T, max_range, score); }
 int fvh_vgicp_profile_enable(fvh_vgicp* h, int on) { CHECK_HANDLE(h); h->e.prof.on = on != 0; return FVH_OK; }
 int fvh_vgicp_profile_reset(fvh_vgicp* h) { CHECK_HANDLE(h); HIP_OR_FAIL(&h->e, hipStreamSynchronize(h->e.stream)); h->e.prof.reset(); return FVH_OK; }
 int fvh_vgicp_profile_get(fvh_vgicp* h, const char* cls, double* ms, int* n) { CHECK_HANDLE(h); return profile_get(&h->e, cls, ms, n); }
+int fvh_vgicp_debug_set_voxel_hint(fvh_vgicp* h, int num_voxels) { CHECK_HANDLE(h); h->voxelmap.nv_hint = num_voxels; return FVH_OK; }
+int fvh_vgicp_debug_get_table_capacity(fvh_vgicp* h, int* capacity) { CHECK_HANDLE(h); if (!capacity) return FVH_ERR_INVALID_ARGUMENT; *capacity = (int)h->voxelmap.capacity; return FVH_OK; }
 int fvh_vgicp_synchronize(fvh_vgicp* h) { CHECK_HANDLE(h); HIP_OR_FAIL(&h->e, hipStreamSynchronize(h->e.stream)); return FVH_OK; }
 
 int fvh_comm_unique_id(void* id128) {
@@ -811,16 +854,16 @@ int fvh_ndt_update_correspondences(fvh_ndt* h, const double* T) {
 int fvh_ndt_compute_error(fvh_ndt* h, const double* T, double* H, double* b, double* err) {
   CHECK_HANDLE(h);
   int rc = ndt_ready(h); if (rc) return rc;
-  if (h->distance_mode == FVH_NDT_P2D) return do_compute_error<MODE_NDT_P2D>(&h->e, h->cost_source(), h->target_vm, T, H, b, err);
-  return do_compute_error<MODE_NDT_D2D>(&h->e, h->cost_source(), h->target_vm, T, H, b, err);
+  if (h->distance_mode == FVH_NDT_P2D) return do_compute_error<MODE_NDT_P2D>(&h->e, h->cost_source(), h->target_vm, T, H, b, err, h->rebuild_safe());
+  return do_compute_error<MODE_NDT_D2D>(&h->e, h->cost_source(), h->target_vm, T, H, b, err, h->rebuild_safe());
 }
 int fvh_ndt_align(fvh_ndt* h, const double* guess, const fvh_lm_params* p, fvh_lm_result* r) {
   CHECK_HANDLE(h);
   int rc = fvh_ndt_create_voxelmaps(h);  // NDTCuda::computeTransformation (ndt_cuda_impl.hpp:76-79)
   if (rc) return rc;
   rc = ndt_ready(h); if (rc) return rc;
-  if (h->distance_mode == FVH_NDT_P2D) return do_align<MODE_NDT_P2D>(&h->e, h->cost_source(), h->target_vm, guess, p, r);
-  return do_align<MODE_NDT_D2D>(&h->e, h->cost_source(), h->target_vm, guess, p, r);
+  if (h->distance_mode == FVH_NDT_P2D) return do_align<MODE_NDT_P2D>(&h->e, h->cost_source(), h->target_vm, guess, p, r, h->rebuild_safe());
+  return do_align<MODE_NDT_D2D>(&h->e, h->cost_source(), h->target_vm, guess, p, r, h->rebuild_safe());
 }
 int fvh_ndt_fitness_score(fvh_ndt* h, const double* T, double max_range, double* score) { CHECK_HANDLE(h); return do_fitness(&h->e, h->source, h->target, T, max_range, score); }
 int fvh_ndt_get_num_voxels(fvh_ndt* h, int which, int* n) {

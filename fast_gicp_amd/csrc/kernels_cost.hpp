@@ -40,8 +40,8 @@ struct LmState {
   int max_iterations, lm_max_iterations;
   // status
   int phase, outer_iter, inner_iter, converged, lm_failed, num_linearize, num_error_evals, nr_iterations;
-  int num_correspondences;
-  int pad_;
+  int vm_num_voxels;  // copied from the voxel map's counters by the last workgroup: capacity hint for the next build
+  int vm_dropped;     // > 0: the hint-sized table overflowed -> host rebuilds at the safe size and re-runs
 };
 
 struct CostParams {
@@ -61,6 +61,8 @@ struct CostParams {
   double* partials;           // [gridDim.x][PART_STRIDE]
   unsigned* ticket;
   int* d_num_corr;            // optional counter of valid correspondences (find phases)
+  const int* vm_counters;     // target map {num_voxels, dropped}
+  const int* vm_counters2;    // source map (D2D NDT) or null
   int host_phase;             // -1: device-LM mode (phase from st); else PH_FIND_ONLY / PH_EVAL_*
   int defer_lm;               // 1: multi-GPU -- only publish st->sums, LM step runs after the all-reduce
   PoseD lin, ev;              // host mode poses
@@ -419,6 +421,8 @@ __global__ __launch_bounds__(256) void cost_kernel(CostParams P) {
   if (threadIdx.x == 0) {
     *P.ticket = 0;
     for (int v = 0; v < PART_STRIDE; v++) st->sums[v] = red[0][v];
+    st->vm_num_voxels = P.vm_counters[0];
+    st->vm_dropped = P.vm_counters[1] + (P.vm_counters2 ? P.vm_counters2[1] : 0);
     if (P.host_phase < 0 && !P.defer_lm) dev_lm_step(st, red[0]);
   }
 }

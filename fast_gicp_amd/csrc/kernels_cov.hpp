@@ -41,17 +41,60 @@ __device__ __forceinline__ int wave_shr1(int v, int fill) { return __builtin_amd
 __device__ __forceinline__ float read_lane(float v, int l) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l)); }
 __device__ __forceinline__ int read_lane(int v, int l) { return __builtin_amdgcn_readlane(v, l); }
 
+// ------------------------------------------------------------------------------------------------
+// LDS-tiled candidate sweep shared by the O(N^2) kernels (k-NN, RBF, fitness).
+// A workgroup (4 waves x Q queries) walks the candidate cloud in tiles of 512 points staged in LDS
+// (8 KB, double buffered): the global loads of tile s+1 are issued before the compute on tile s, so
+// the L2/HBM latency hides behind ~2.5k VALU instructions, and each candidate is fetched from L2
+// once per workgroup instead of once per wave. Tiles are visited own-tile-first, then zig-zag
+// outwards (t0, t0+1, t0-1, ...): LiDAR clouds are scan-ordered, so the k-NN threshold is tight
+// after the first tile. body(c, p): c = candidate index of this lane (may be >= n: masked by the
+// caller), p = the candidate.
+// ------------------------------------------------------------------------------------------------
+constexpr int SWEEP_TILE = 512;
+
+template <typename F>
+__device__ __forceinline__ void sweep_candidates(const float4* __restrict__ pts, int n, int first_tile, float4 (*tile)[SWEEP_TILE], F&& body) {
+  const int nt = (n + SWEEP_TILE - 1) / SWEEP_TILE;
+  const int tid = threadIdx.x, lane = threadIdx.x & 63;
+  auto tile_of = [&](int s) {
+    int t = (s & 1) ? first_tile + ((s + 1) >> 1) : first_tile - (s >> 1);
+    return t < 0 ? t + nt : (t >= nt ? t - nt : t);
+  };
+  {
+    const int base = tile_of(0) * SWEEP_TILE;
+    tile[0][tid] = pts[min(base + tid, n - 1)];
+    tile[0][tid + 256] = pts[min(base + tid + 256, n - 1)];
+  }
+  __syncthreads();
+  for (int s = 0; s < nt; s++) {
+    float4 n0, n1;
+    const bool more = (s + 1 < nt);
+    if (more) {
+      const int nbase = tile_of(s + 1) * SWEEP_TILE;
+      n0 = pts[min(nbase + tid, n - 1)];
+      n1 = pts[min(nbase + tid + 256, n - 1)];
+    }
+    const int base = tile_of(s) * SWEEP_TILE;
+    const float4* cur = tile[s & 1];
+#pragma unroll 2
+    for (int bb = 0; bb < SWEEP_TILE / 64; bb++) body(base + bb * 64 + lane, cur[bb * 64 + lane]);
+    if (more) {
+      tile[(s + 1) & 1][tid] = n0;
+      tile[(s + 1) & 1][tid + 256] = n1;
+    }
+    __syncthreads();
+  }
+}
+
 // out_idx: [n][k] neighbour indices, ascending (distance, index); k <= 64.
-// Candidate batches are visited own-batch-first, then zig-zag outwards (b0, b0+1, b0-1, ...):
-// LiDAR clouds are scan-ordered, so the first few batches already contain most true neighbours and
-// tau is tight for the rest of the sweep (index-ascending order makes EVERY approaching candidate an
-// insertion: measured 1.57 ms vs the k*ln(N/k) model's ~0.1 ms on the 17k cloud). The list order is
-// the total order (distance, index), so the result does not depend on the visiting order.
+// The running top-k list is ordered by the total order (distance, index), so the result does not
+// depend on the visiting order of the tiles.
 __global__ __launch_bounds__(256) void knn_bruteforce_kernel(const float4* __restrict__ pts, int n, int k, int* __restrict__ out_idx) {
+  __shared__ float4 tile[2][SWEEP_TILE];
   const int lane = threadIdx.x & 63;
   const int wave = blockIdx.x * 4 + (threadIdx.x >> 6);
   const int q_base = wave * KNN_Q;
-  if (q_base >= n) return;
   float qx[KNN_Q], qy[KNN_Q], qz[KNN_Q];
   float ld[KNN_Q];   // lane j: j-th smallest (distance, index) so far
   int li[KNN_Q];
@@ -63,14 +106,7 @@ __global__ __launch_bounds__(256) void knn_bruteforce_kernel(const float4* __res
     qx[j] = q.x; qy[j] = q.y; qz[j] = q.z;
     ld[j] = __builtin_inff(); li[j] = 0x7fffffff; tau_d[j] = __builtin_inff(); tau_i[j] = 0x7fffffff;
   }
-  const int nb = (n + 63) >> 6;
-  const int b0 = q_base >> 6;
-  for (int s = 0; s < nb; s++) {
-    int b = (s & 1) ? b0 + ((s + 1) >> 1) : b0 - (s >> 1);
-    b = b < 0 ? b + nb : (b >= nb ? b - nb : b);
-    const int base = b << 6;
-    const int c = base + lane;
-    const float4 p = pts[min(c, n - 1)];
+  sweep_candidates(pts, n, min(blockIdx.x * 4 * KNN_Q, n - 1) / SWEEP_TILE, tile, [&](int c, const float4& p) {
 #pragma unroll
     for (int j = 0; j < KNN_Q; j++) {
       float d = sqdist_nofma(p, qx[j], qy[j], qz[j]);
@@ -80,7 +116,7 @@ __global__ __launch_bounds__(256) void knn_bruteforce_kernel(const float4* __res
         const int src = __ffsll((long long)mask) - 1;
         mask &= mask - 1;
         const float cd = read_lane(d, src);
-        const int ci = base + src;
+        const int ci = c - lane + src;
         if (!(cd < tau_d[j] || (cd == tau_d[j] && ci < tau_i[j]))) continue;
         const int pos = __popcll(__ballot(ld[j] < cd || (ld[j] == cd && li[j] < ci)));
         const float sd = wave_shr1(ld[j], ld[j]);
@@ -91,7 +127,7 @@ __global__ __launch_bounds__(256) void knn_bruteforce_kernel(const float4* __res
         tau_i[j] = read_lane(li[j], k - 1);
       }
     }
-  }
+  });
 #pragma unroll
   for (int j = 0; j < KNN_Q; j++)
     if (q_base + j < n && lane < k) out_idx[(size_t)(q_base + j) * k + lane] = li[j];
@@ -149,10 +185,10 @@ constexpr int RBF_Q = 8;
 // zero-padding of the last 512-block (:127-129) is NOT replicated.
 __global__ __launch_bounds__(256) void cov_rbf_kernel(const float4* __restrict__ pts, int n, float kernel_width, float max_dist_sq, int method,
                                                       float4* __restrict__ cov) {
+  __shared__ float4 tile[2][SWEEP_TILE];
   const int lane = threadIdx.x & 63;
   const int wave = blockIdx.x * 4 + (threadIdx.x >> 6);
   const int q_base = wave * RBF_Q;
-  if (q_base >= n) return;
   float qx[RBF_Q], qy[RBF_Q], qz[RBF_Q];
   float sw[RBF_Q], sx[RBF_Q], sy[RBF_Q], sz[RBF_Q], sxx[RBF_Q], sxy[RBF_Q], sxz[RBF_Q], syy[RBF_Q], syz[RBF_Q], szz[RBF_Q];
 #pragma unroll
@@ -161,9 +197,7 @@ __global__ __launch_bounds__(256) void cov_rbf_kernel(const float4* __restrict__
     qx[j] = q.x; qy[j] = q.y; qz[j] = q.z;
     sw[j] = sx[j] = sy[j] = sz[j] = sxx[j] = sxy[j] = sxz[j] = syy[j] = syz[j] = szz[j] = 0.f;
   }
-  for (int base = 0; base < n; base += 64) {
-    const int c = base + lane;
-    const float4 p = pts[min(c, n - 1)];
+  sweep_candidates(pts, n, 0, tile, [&](int c, const float4& p) {
 #pragma unroll
     for (int j = 0; j < RBF_Q; j++) {
       const float dx = p.x - qx[j], dy = p.y - qy[j], dz = p.z - qz[j];
@@ -175,7 +209,7 @@ __global__ __launch_bounds__(256) void cov_rbf_kernel(const float4* __restrict__
       sx[j] += wx; sy[j] += wy; sz[j] += wz;
       sxx[j] += wx * dx; sxy[j] += wx * dy; sxz[j] += wx * dz; syy[j] += wy * dy; syz[j] += wy * dz; szz[j] += wz * dz;
     }
-  }
+  });
 #pragma unroll
   for (int j = 0; j < RBF_Q; j++) {
     const double W = wave_sum((double)sw[j]);
@@ -200,10 +234,10 @@ constexpr int FIT_Q = 8;
 // out[0] += sum, out[1] += count (fp64 atomics).
 __global__ __launch_bounds__(256) void fitness_kernel(const float4* __restrict__ src, int ns, const float4* __restrict__ tgt, int nt, const float* __restrict__ T12 /* row-major 3x4 */,
                                                       double max_range, double* __restrict__ out) {
+  __shared__ float4 tile[2][SWEEP_TILE];
   const int lane = threadIdx.x & 63;
   const int wave = blockIdx.x * 4 + (threadIdx.x >> 6);
   const int q_base = wave * FIT_Q;
-  if (q_base >= ns) return;
   float qx[FIT_Q], qy[FIT_Q], qz[FIT_Q], best[FIT_Q];
 #pragma unroll
   for (int j = 0; j < FIT_Q; j++) {
@@ -213,15 +247,13 @@ __global__ __launch_bounds__(256) void fitness_kernel(const float4* __restrict__
     qz[j] = transform_row_nofma(p, T12 + 8);
     best[j] = __builtin_inff();
   }
-  for (int base = 0; base < nt; base += 64) {
-    const int c = base + lane;
-    const float4 p = tgt[min(c, nt - 1)];
+  sweep_candidates(tgt, nt, 0, tile, [&](int c, const float4& p) {
 #pragma unroll
     for (int j = 0; j < FIT_Q; j++) {
       const float d = sqdist_nofma(p, qx[j], qy[j], qz[j]);
       best[j] = (c < nt && d < best[j]) ? d : best[j];
     }
-  }
+  });
   double sum = 0.0, cnt = 0.0;
 #pragma unroll
   for (int j = 0; j < FIT_Q; j++) {
@@ -230,7 +262,7 @@ __global__ __launch_bounds__(256) void fitness_kernel(const float4* __restrict__
     for (int off = 32; off > 0; off >>= 1) b = fminf(b, __shfl_xor(b, off));
     if (q_base + j < ns && (double)b <= max_range) { sum += (double)b; cnt += 1.0; }
   }
-  if (lane == 0) {
+  if (lane == 0 && (sum != 0.0 || cnt != 0.0)) {
     atomicAdd(&out[0], sum);
     atomicAdd(&out[1], cnt);
   }

@@ -6,7 +6,10 @@
 // finalize_voxels_kernel / ndt_finalize_voxels_kernel  (src/fast_gicp/cuda/gaussian_voxelmap.cu:9-289).
 //
 // HBM layout
-//   table : capacity x 64-byte bucket (capacity = pow2 >= 2 * N_t, so no point is ever dropped)
+//   table : capacity x 64-byte bucket. capacity = pow2 >= 4 x (voxel count of the previous build on
+//           this handle) so the table stays L2-resident (1,087 voxels -> 8,192 buckets = 512 KB instead
+//           of 4 MB); first build / overflow fallback: pow2 >= 2 * N_t, which can never overflow.
+//           No point is ever dropped: an exhausted probe budget is reported and the host rebuilds.
 //           q0 = {key_lo, key_hi, num_points, 0}   q1 = {mean.xyz, (float)num_points}
 //           q2 = {c_xx, c_xy, c_xz, c_yy}          q3 = {c_yz, c_zz, 0, 0}
 //           -> a probe that hits finds key AND the voxel record in one 64-B line (no id indirection,
@@ -28,10 +31,12 @@ namespace fvh {
 constexpr int VM_LDS_SLOTS = 512;
 constexpr int VM_LDS_PROBES = 8;
 constexpr int VM_ACC_STRIDE = 10;
+constexpr unsigned VM_MAX_PROBE = 255;
 
 __device__ __forceinline__ unsigned global_claim(unsigned long long* table_keys64 /* bucket stride = 8 u64 */, unsigned mask, unsigned long long key) {
   unsigned slot = hash_key(key) & mask;
-  for (unsigned it = 0; it <= mask; it++) {
+  const unsigned max_probe = mask < VM_MAX_PROBE ? mask : VM_MAX_PROBE;
+  for (unsigned it = 0; it <= max_probe; it++) {
     unsigned long long* addr = table_keys64 + (size_t)slot * 8;
     unsigned long long cur = __hip_atomic_load(addr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (cur == key) return slot;
@@ -41,7 +46,7 @@ __device__ __forceinline__ unsigned global_claim(unsigned long long* table_keys6
     }
     slot = (slot + 1) & mask;
   }
-  return 0xFFFFFFFFu;  // table full: cannot happen with capacity >= 2 N
+  return 0xFFFFFFFFu;  // probe budget exhausted: the caller counts it in `dropped` and the host rebuilds at the safe size
 }
 
 // MODE 0: VGICP (sum of points and of point covariances); MODE 1: NDT (sum of points and p p^T)

@@ -137,6 +137,10 @@ int fvh_vgicp_profile_reset(fvh_vgicp* h);
 /* kernel_class in {"cost", "knn", "cov", "rbf", "voxelmap", "fitness"}; sums over launches since reset */
 int fvh_vgicp_profile_get(fvh_vgicp* h, const char* kernel_class, double* total_ms, int* launches);
 int fvh_vgicp_synchronize(fvh_vgicp* h);
+/* testing hooks: the bucket table is sized from the previous build's voxel count (4x, pow2); a wrong
+ * hint must only cost a rebuild at the safe size (2 x N_t), never points. */
+int fvh_vgicp_debug_set_voxel_hint(fvh_vgicp* h, int num_voxels);
+int fvh_vgicp_debug_get_table_capacity(fvh_vgicp* h, int* capacity);
 
 /* new: multi-GPU (one process per GPU).  Every rank holds a spatial-tile shard of the source
  * cloud and the target voxel map; the 28-value normal-equation block (err, b, upper H) is

@@ -194,3 +194,29 @@ def test_fitness_matches_oracle(O, pair):
         fo = O.fitness(src, tgt, T)
         assert abs(f - fo) <= 1e-9 * fo
     c.close()
+
+
+def test_voxel_table_hint_overflow_falls_back(O, pair, oracle_covs):
+    """A too-small capacity hint must cost a rebuild, never points: results identical to the safe-sized table."""
+    tgt, src = pair
+    cov_t, cov_s = oracle_covs
+    ref = None
+    for hint in (-1, 1, 100000):
+        c = _core()
+        c.set_resolution(0.5)  # 2,587 voxels > the 1,024-bucket table a hint of 1 gives
+        c.set_target_cloud(tgt); c.set_source_cloud(src)
+        c.set_target_covariances(cov_t); c.set_source_covariances(cov_s)
+        c.debug_set_voxel_hint(hint)
+        c.create_target_voxelmap()
+        cap0 = c.debug_table_capacity()
+        r = c.align()
+        e, H, b = c.linearize(np.eye(4))
+        coords, num, _, _ = c.get_voxelmap()
+        assert int(num.sum()) == len(tgt) and len(coords) == 2587
+        if hint == 1:
+            assert cap0 == 1024 and c.debug_table_capacity() == 65536  # overflow detected -> rebuilt at 2 x N_t
+        if ref is None:
+            ref = (r["T"], e, H)
+        else:
+            assert util.rel_err(r["T"], ref[0]) < 1e-12 and abs(e - ref[1]) <= 1e-12 * abs(ref[1]) and util.rel_err(H, ref[2]) < 1e-12
+        c.close()
