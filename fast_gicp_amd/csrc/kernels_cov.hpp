@@ -49,9 +49,16 @@ __device__ __forceinline__ int read_lane(int v, int l) { return __builtin_amdgcn
 // once per workgroup instead of once per wave. Tiles are visited own-tile-first, then zig-zag
 // outwards (t0, t0+1, t0-1, ...): LiDAR clouds are scan-ordered, so the k-NN threshold is tight
 // after the first tile. body(c, p): c = candidate index of this lane (may be >= n: masked by the
-// caller), p = the candidate.
+// caller), p = the candidate. Slots past the end of the cloud hold a far-away point (distance ~1e37,
+// finite) so the per-query code needs no range check and stays branch-free.
 // ------------------------------------------------------------------------------------------------
 constexpr int SWEEP_TILE = 512;
+
+__device__ __forceinline__ float4 load_candidate(const float4* __restrict__ pts, int i, int n) {
+  const float4 p = pts[min(i, n - 1)];
+  const float far = 3.0e18f;
+  return i < n ? p : make_float4(far, far, far, 0.f);
+}
 
 template <typename F>
 __device__ __forceinline__ void sweep_candidates(const float4* __restrict__ pts, int n, int first_tile, float4 (*tile)[SWEEP_TILE], F&& body) {
@@ -63,8 +70,8 @@ __device__ __forceinline__ void sweep_candidates(const float4* __restrict__ pts,
   };
   {
     const int base = tile_of(0) * SWEEP_TILE;
-    tile[0][tid] = pts[min(base + tid, n - 1)];
-    tile[0][tid + 256] = pts[min(base + tid + 256, n - 1)];
+    tile[0][tid] = load_candidate(pts, base + tid, n);
+    tile[0][tid + 256] = load_candidate(pts, base + tid + 256, n);
   }
   __syncthreads();
   for (int s = 0; s < nt; s++) {
@@ -72,8 +79,8 @@ __device__ __forceinline__ void sweep_candidates(const float4* __restrict__ pts,
     const bool more = (s + 1 < nt);
     if (more) {
       const int nbase = tile_of(s + 1) * SWEEP_TILE;
-      n0 = pts[min(nbase + tid, n - 1)];
-      n1 = pts[min(nbase + tid + 256, n - 1)];
+      n0 = load_candidate(pts, nbase + tid, n);
+      n1 = load_candidate(pts, nbase + tid + 256, n);
     }
     const int base = tile_of(s) * SWEEP_TILE;
     const float4* cur = tile[s & 1];
@@ -109,8 +116,7 @@ __global__ __launch_bounds__(256) void knn_bruteforce_kernel(const float4* __res
   sweep_candidates(pts, n, min(blockIdx.x * 4 * KNN_Q, n - 1) / SWEEP_TILE, tile, [&](int c, const float4& p) {
 #pragma unroll
     for (int j = 0; j < KNN_Q; j++) {
-      float d = sqdist_nofma(p, qx[j], qy[j], qz[j]);
-      d = c < n ? d : __builtin_inff();
+      const float d = sqdist_nofma(p, qx[j], qy[j], qz[j]);
       unsigned long long mask = __ballot(d <= tau_d[j]);  // cheap superset test; exact test below
       while (mask) {  // wave-uniform
         const int src = __ffsll((long long)mask) - 1;
@@ -202,8 +208,7 @@ __global__ __launch_bounds__(256) void cov_rbf_kernel(const float4* __restrict__
     for (int j = 0; j < RBF_Q; j++) {
       const float dx = p.x - qx[j], dy = p.y - qy[j], dz = p.z - qz[j];
       const float sq = sqdist_nofma(p, qx[j], qy[j], qz[j]);
-      const bool in = (c < n) && !(sq > max_dist_sq);
-      const float w = in ? __expf(-kernel_width * sq) : 0.f;
+      const float w = (sq > max_dist_sq) ? 0.f : __expf(-kernel_width * sq);
       sw[j] += w;
       const float wx = w * dx, wy = w * dy, wz = w * dz;
       sx[j] += wx; sy[j] += wy; sz[j] += wz;
@@ -250,8 +255,7 @@ __global__ __launch_bounds__(256) void fitness_kernel(const float4* __restrict__
   sweep_candidates(tgt, nt, 0, tile, [&](int c, const float4& p) {
 #pragma unroll
     for (int j = 0; j < FIT_Q; j++) {
-      const float d = sqdist_nofma(p, qx[j], qy[j], qz[j]);
-      best[j] = (c < nt && d < best[j]) ? d : best[j];
+      best[j] = fminf(best[j], sqdist_nofma(p, qx[j], qy[j], qz[j]));
     }
   });
   double sum = 0.0, cnt = 0.0;

