@@ -229,6 +229,7 @@ __device__ inline void dev_lm_step(LmState* st, const double* sums) {
 
 // tiny kernels for the multi-GPU path and for (re)initialising the state
 __global__ void lm_init_kernel(LmState* st, PoseD guess, double rot_eps, double trans_eps, double lambda_factor, int max_iter, int lm_max_iter, unsigned* ticket) {
+  if (blockIdx.x == 0 && threadIdx.x <= 8) ticket[threadIdx.x] = 0;
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
   st->x0 = guess; st->xi = guess;
   st->rotation_epsilon = rot_eps; st->transformation_epsilon = trans_eps; st->lm_init_lambda_factor = lambda_factor;
@@ -237,7 +238,6 @@ __global__ void lm_init_kernel(LmState* st, PoseD guess, double rot_eps, double 
   st->phase = max_iter > 0 ? PH_LINEARIZE : PH_DONE;
   st->outer_iter = 0; st->inner_iter = 0; st->converged = 0; st->lm_failed = 0; st->num_linearize = 0; st->num_error_evals = 0; st->nr_iterations = 0;
   for (int i = 0; i < 36; i++) st->final_H[i] = (i % 7 == 0) ? 1.0 : 0.0;
-  *ticket = 0;
 }
 __global__ void lm_update_kernel(LmState* st) {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
@@ -272,17 +272,20 @@ __device__ __forceinline__ void accumulate_term(double* acc, const Vec3<Real>& q
   acc[25] += (double)(w * M.yy); acc[26] += (double)(w * M.yz); acc[27] += (double)(w * M.zz);
 }
 
-__device__ __forceinline__ int probe_table(const uint4* __restrict__ table, unsigned mask, unsigned long long key, int& num_points) {
-  unsigned slot = hash_key(key) & mask;
-  for (unsigned it = 0; it <= mask; it++) {
+// Continue a linear probe from `slot` (the first bucket has already been inspected).
+__device__ __forceinline__ int probe_continue(const uint4* __restrict__ table, unsigned mask, unsigned long long key, unsigned slot) {
+  for (unsigned it = 0; it < mask; it++) {
+    slot = (slot + 1) & mask;
     const uint4 q0 = table[(size_t)slot * 4];
     const unsigned long long k = (unsigned long long)q0.x | ((unsigned long long)q0.y << 32);
-    if (k == key) { num_points = (int)q0.z; return (int)slot; }
+    if (k == key) return (int)slot;
     if (k == FVH_EMPTY_KEY) return -1;  // first empty bucket ends the probe (find_voxel_correspondences.cu:46-48)
-    slot = (slot + 1) & mask;
   }
   return -1;
 }
+
+constexpr int COST_CH = 4;     // voxel lookups a thread keeps in flight at once
+constexpr int TICKET_GROUPS = 8;  // hierarchical arrival counters (one per XCD-sized group of workgroups) + 1 top counter
 
 template <typename Real, int MODE>
 __global__ __launch_bounds__(256) void cost_kernel(CostParams P) {
@@ -309,7 +312,7 @@ __global__ __launch_bounds__(256) void cost_kernel(CostParams P) {
   const Pose<Real> ev = pose_cast<Real>(ev_d);
   const Real res = (Real)P.res;
   const int n_src = P.d_n_src ? *P.d_n_src : P.n_src;
-  const long long n_items = (long long)n_src * P.groups_per_src;
+  const int n_items = n_src * P.groups_per_src;
 
   double acc[NSUM];
 #pragma unroll
@@ -317,14 +320,16 @@ __global__ __launch_bounds__(256) void cost_kernel(CostParams P) {
   int n_found = 0;
 
   const float4* tf = reinterpret_cast<const float4*>(P.table);
-  for (long long w = (long long)blockIdx.x * 256 + threadIdx.x; w < n_items; w += (long long)gridDim.x * 256) {
-    const int i = (int)(w / P.groups_per_src);
-    const int g = (int)(w - (long long)i * P.groups_per_src);
+  for (int w = blockIdx.x * 256 + threadIdx.x; w < n_items; w += gridDim.x * 256) {
+    const int i = w / P.groups_per_src;
+    const int g = w - i * P.groups_per_src;
+    // ---- round trip 1: the source element ----
     const float4 a4 = P.src_pts[i];
+    float4 c0 = make_float4(0, 0, 0, 0), c1 = c0;
+    if (MODE != MODE_NDT_P2D && do_cost) { c0 = P.src_cov[2 * i]; c1 = P.src_cov[2 * i + 1]; }
     const Vec3<Real> a = {(Real)a4.x, (Real)a4.y, (Real)a4.z};
     Sym3<Real> RCR = {0, 0, 0, 0, 0, 0};
     if (MODE != MODE_NDT_P2D && do_cost) {
-      const float4 c0 = P.src_cov[2 * i], c1 = P.src_cov[2 * i + 1];
       const Sym3<Real> CA = {(Real)c0.x, (Real)c0.y, (Real)c0.z, (Real)c0.w, (Real)c1.x, (Real)c1.y};
       RCR = rotate_cov(lin.r, CA);
     }
@@ -337,33 +342,66 @@ __global__ __launch_bounds__(256) void cost_kernel(CostParams P) {
       cz = (int)floor(ql.z / res - (Real)0.5);
     }
     const int o_begin = g * P.group, o_end = min(P.n_off, o_begin + P.group);
-    for (int o = o_begin; o < o_end; o++) {
-      int b, npts = 0;
+    for (int oc = o_begin; oc < o_end; oc += COST_CH) {
+      int b[COST_CH];
+      // ---- round trip 2: COST_CH independent lookups in flight (first probe of each, or the stored ids) ----
       if (do_find) {
-        const int x = cx + P.offsets[3 * o], y = cy + P.offsets[3 * o + 1], z = cz + P.offsets[3 * o + 2];
-        b = coord_in_range(x, y, z) ? probe_table(P.table, P.mask, pack_key(x, y, z), npts) : -1;
-        P.corr[(size_t)i * P.n_off + o] = b;
-        n_found += (b >= 0);
+        unsigned long long key[COST_CH];
+        unsigned slot[COST_CH];
+        uint4 q0[COST_CH];
+        bool live[COST_CH];
+#pragma unroll
+        for (int c = 0; c < COST_CH; c++) {
+          const int o = min(oc + c, o_end - 1);
+          const int x = cx + P.offsets[3 * o], y = cy + P.offsets[3 * o + 1], z = cz + P.offsets[3 * o + 2];
+          live[c] = (oc + c < o_end) && coord_in_range(x, y, z);
+          key[c] = pack_key(x, y, z);
+          slot[c] = hash_key(key[c]) & P.mask;
+          q0[c] = P.table[(size_t)slot[c] * 4];
+        }
+#pragma unroll
+        for (int c = 0; c < COST_CH; c++) {
+          const unsigned long long k = (unsigned long long)q0[c].x | ((unsigned long long)q0[c].y << 32);
+          int r = -1;
+          if (live[c]) {
+            if (k == key[c]) r = (int)slot[c];
+            else if (k != FVH_EMPTY_KEY) r = probe_continue(P.table, P.mask, key[c], slot[c]);  // rare at load <= 0.25
+          }
+          b[c] = r;
+          if (oc + c < o_end) P.corr[(size_t)i * P.n_off + oc + c] = r;
+          n_found += (r >= 0);
+        }
       } else {
-        b = P.corr[(size_t)i * P.n_off + o];
+#pragma unroll
+        for (int c = 0; c < COST_CH; c++) b[c] = (oc + c < o_end) ? P.corr[(size_t)i * P.n_off + oc + c] : -1;
       }
-      if (b < 0 || !do_cost) continue;
-      const float4 q1 = tf[(size_t)b * 4 + 1], q2 = tf[(size_t)b * 4 + 2], q3 = tf[(size_t)b * 4 + 3];
-      npts = (int)q1.w;
-      const Vec3<Real> mu = {(Real)q1.x, (Real)q1.y, (Real)q1.z};
-      Sym3<Real> A = {(Real)q2.x + RCR.xx, (Real)q2.y + RCR.xy, (Real)q2.z + RCR.xz, (Real)q2.w + RCR.yy, (Real)q3.x + RCR.yz, (Real)q3.y + RCR.zz};
-      Real wgt;
-      if (MODE == MODE_VGICP) {
-        if (npts <= 0) continue;
-        wgt = sqrt((Real)npts);  // fast_vgicp_impl.hpp:149, compute_derivatives.cu:78
-      } else {
-        if (npts <= 6) continue;  // ndt_compute_derivatives.cu:61,133
-        const Real ex = mu.x - q.x, ey = mu.y - q.y, ez = mu.z - q.z;
-        const Real ksq = res * res;
-        wgt = ksq / (ksq + (ex * ex + ey * ey + ez * ez));  // cauchy(resolution, |e|) :15-18
+      if (!do_cost) continue;
+      // ---- round trip 3: the voxel records of all hits, unconditional loads (bucket 0 for misses) ----
+      float4 q1[COST_CH], q2[COST_CH], q3[COST_CH];
+#pragma unroll
+      for (int c = 0; c < COST_CH; c++) {
+        const size_t base = (size_t)max(b[c], 0) * 4;
+        q1[c] = tf[base + 1]; q2[c] = tf[base + 2]; q3[c] = tf[base + 3];
       }
-      const Sym3<Real> M = inverse(A);
-      accumulate_term<Real>(acc, q, mu, M, wgt, do_deriv);
+#pragma unroll
+      for (int c = 0; c < COST_CH; c++) {
+        if (b[c] < 0) continue;
+        const int npts = (int)q1[c].w;
+        const Vec3<Real> mu = {(Real)q1[c].x, (Real)q1[c].y, (Real)q1[c].z};
+        const Sym3<Real> A = {(Real)q2[c].x + RCR.xx, (Real)q2[c].y + RCR.xy, (Real)q2[c].z + RCR.xz, (Real)q2[c].w + RCR.yy, (Real)q3[c].x + RCR.yz, (Real)q3[c].y + RCR.zz};
+        Real wgt;
+        if (MODE == MODE_VGICP) {
+          if (npts <= 0) continue;
+          wgt = sqrt((Real)npts);  // fast_vgicp_impl.hpp:149, compute_derivatives.cu:78
+        } else {
+          if (npts <= 6) continue;  // ndt_compute_derivatives.cu:61,133
+          const Real ex = mu.x - q.x, ey = mu.y - q.y, ez = mu.z - q.z;
+          const Real ksq = res * res;
+          wgt = ksq / (ksq + (ex * ex + ey * ey + ez * ez));  // cauchy(resolution, |e|) :15-18
+        }
+        const Sym3<Real> M = inverse(A);
+        accumulate_term<Real>(acc, q, mu, M, wgt, do_deriv);
+      }
     }
   }
 
@@ -396,8 +434,14 @@ __global__ __launch_bounds__(256) void cost_kernel(CostParams P) {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   if (threadIdx.x == 0) {
-    const unsigned t = atomicAdd(P.ticket, 1u);
-    s_last = (t == gridDim.x - 1);
+    // two-level arrival: 8 group counters (workgroup b -> group b % 8, i.e. its XCD under the observed
+    // dispatch order) + 1 top counter, so no single address sees more than ~gridDim/8 + 8 atomics
+    const unsigned grp = blockIdx.x % TICKET_GROUPS;
+    const unsigned ngroups = min((unsigned)TICKET_GROUPS, gridDim.x);
+    const unsigned gsize = (gridDim.x - grp + TICKET_GROUPS - 1) / TICKET_GROUPS;
+    int last = 0;
+    if (atomicAdd(&P.ticket[grp], 1u) == gsize - 1) last = (atomicAdd(&P.ticket[TICKET_GROUPS], 1u) == ngroups - 1);
+    s_last = last;
   }
   __syncthreads();
   if (!s_last) return;
@@ -417,9 +461,9 @@ __global__ __launch_bounds__(256) void cost_kernel(CostParams P) {
     for (int c = 0; c < 8; c++) s += fin[c][v];
     red[0][v] = s;
   }
+  if (threadIdx.x <= TICKET_GROUPS) P.ticket[threadIdx.x] = 0;  // re-arm for the next launch
   __syncthreads();
   if (threadIdx.x == 0) {
-    *P.ticket = 0;
     for (int v = 0; v < PART_STRIDE; v++) st->sums[v] = red[0][v];
     st->vm_num_voxels = P.vm_counters[0];
     st->vm_dropped = P.vm_counters[1] + (P.vm_counters2 ? P.vm_counters2[1] : 0);
