@@ -24,7 +24,7 @@ using namespace fvh;
 
 namespace {
 
-constexpr int MAX_COST_BLOCKS = 512;
+constexpr int MAX_COST_BLOCKS = MAX_PARTIAL_ROWS;
 
 struct DevBuf {
   void* p = nullptr;
@@ -133,7 +133,7 @@ struct Engine {
     if ((e = hipStreamCreateWithFlags(&stream, hipStreamNonBlocking)) != hipSuccess) return hipfail(e, "hipStreamCreate");
     if ((e = hipHostMalloc(&pinned, sizeof(LmState) + 1024, hipHostMallocDefault)) != hipSuccess) return hipfail(e, "hipHostMalloc");
     if ((e = state.ensure(sizeof(LmState))) != hipSuccess) return hipfail(e, "hipMalloc");
-    if ((e = partials.ensure(sizeof(double) * PART_STRIDE * MAX_COST_BLOCKS)) != hipSuccess) return hipfail(e, "hipMalloc");
+    if ((e = partials.ensure(sizeof(double) * PART_STRIDE * (MAX_COST_BLOCKS + TICKET_GROUPS))) != hipSuccess) return hipfail(e, "hipMalloc");
     if ((e = ticket.ensure(64)) != hipSuccess) return hipfail(e, "hipMalloc");
     if ((e = misc.ensure(256)) != hipSuccess) return hipfail(e, "hipMalloc");
     if ((e = fit.ensure(64)) != hipSuccess) return hipfail(e, "hipMalloc");
@@ -431,7 +431,6 @@ int launch_cost(Engine* e, const CostSource& src, const VoxelMapDev& vm, int hos
   P.groups_per_src = (e->n_off + P.group - 1) / P.group;
   P.corr = e->corr.as<int>();
   P.st = e->state.as<LmState>(); P.partials = e->partials.as<double>(); P.ticket = e->ticket.as<unsigned>();
-  P.d_num_corr = e->misc.as<int>();
   P.vm_counters = vm.counters.as<int>();
   P.vm_counters2 = src.counters2;
   P.host_phase = host_phase;
@@ -462,7 +461,6 @@ int do_update_correspondences(Engine* e, const CostSource& src, VoxelMapDev& vm,
   if (!vm.valid) return e->fail(FVH_ERR_BAD_STATE, "update_correspondences: target voxel map not built");
   HIP_OR_FAIL(e, e->corr.ensure(sizeof(int) * (size_t)std::max(src.n_upper, 1) * e->n_off));
   e->lin = pose_from_colmajor16(T16);
-  HIP_OR_FAIL(e, hipMemsetAsync(e->misc.p, 0, sizeof(int), e->stream));
   int rc = launch_cost<MODE>(e, src, vm, PH_FIND_ONLY, &e->lin, &e->lin);
   if (rc) return rc;
   e->has_corr = true;
@@ -490,7 +488,6 @@ int do_compute_error(Engine* e, const CostSource& src, VoxelMapDev& vm, const do
     // the hint-sized table overflowed: rebuild at the safe size, redo the correspondences, evaluate again
     rc = rebuild_safe();
     if (rc) return rc;
-    HIP_OR_FAIL(e, hipMemsetAsync(e->misc.p, 0, sizeof(int), e->stream));
     rc = launch_cost<MODE>(e, src, vm, PH_FIND_ONLY, &e->lin, &e->lin);
     if (rc) return rc;
     e->has_corr = true;
@@ -881,11 +878,18 @@ int fvh_ndt_get_voxels(fvh_ndt* h, int which, int* coords3, int* num_points, flo
 int fvh_ndt_get_num_correspondences(fvh_ndt* h, int* n) {
   CHECK_HANDLE(h);
   if (!n) return FVH_ERR_INVALID_ARGUMENT;
-  if (!h->e.has_corr) return h->e.fail(FVH_ERR_BAD_STATE, "no correspondences");
-  int v = 0;
-  HIP_OR_FAIL(&h->e, hipMemcpyAsync(&v, h->e.misc.p, sizeof(int), hipMemcpyDeviceToHost, h->e.stream));
-  HIP_OR_FAIL(&h->e, hipStreamSynchronize(h->e.stream));
-  *n = v;
+  std::vector<int> corr;
+  int rc = fetch_corr(&h->e, h->e.corr_n_src, corr);
+  if (rc) return rc;
+  int nsrc = h->e.corr_n_src;
+  if (h->distance_mode == FVH_NDT_D2D) {  // only the first num_source_voxels rows are live
+    rc = fetch_voxelmap_host(&h->e, h->source_vm);
+    if (rc) return rc;
+    nsrc = (int)h->source_vm.h_occupied.size();
+  }
+  int c = 0;
+  for (size_t i = 0; i < (size_t)nsrc * h->e.n_off; i++) c += (corr[i] >= 0);
+  *n = c;
   return FVH_OK;
 }
 int fvh_ndt_synchronize(fvh_ndt* h) { CHECK_HANDLE(h); HIP_OR_FAIL(&h->e, hipStreamSynchronize(h->e.stream)); return FVH_OK; }

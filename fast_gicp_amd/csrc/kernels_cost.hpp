@@ -23,6 +23,7 @@ namespace fvh {
 
 constexpr int NSUM = 28;       // err(1) b(6) Hrr(6) Hrt(9) Htt(6)
 constexpr int PART_STRIDE = 32;
+constexpr int MAX_PARTIAL_ROWS = 512;  // workgroup rows; 8 group rows follow
 
 enum CostMode { MODE_VGICP = 0, MODE_NDT_P2D = 1, MODE_NDT_D2D = 2 };
 enum Phase { PH_LINEARIZE = 0, PH_TRIAL = 1, PH_DONE = 2, PH_FIND_ONLY = 3, PH_EVAL_DERIV = 4, PH_EVAL_ERROR = 5 };
@@ -60,7 +61,6 @@ struct CostParams {
   LmState* st;
   double* partials;           // [gridDim.x][PART_STRIDE]
   unsigned* ticket;
-  int* d_num_corr;            // optional counter of valid correspondences (find phases)
   const int* vm_counters;     // target map {num_voxels, dropped}
   const int* vm_counters2;    // source map (D2D NDT) or null
   int host_phase;             // -1: device-LM mode (phase from st); else PH_FIND_ONLY / PH_EVAL_*
@@ -317,7 +317,6 @@ __global__ __launch_bounds__(256) void cost_kernel(CostParams P) {
   double acc[NSUM];
 #pragma unroll
   for (int v = 0; v < NSUM; v++) acc[v] = 0.0;
-  int n_found = 0;
 
   const float4* tf = reinterpret_cast<const float4*>(P.table);
   for (int w = blockIdx.x * 256 + threadIdx.x; w < n_items; w += gridDim.x * 256) {
@@ -369,7 +368,6 @@ __global__ __launch_bounds__(256) void cost_kernel(CostParams P) {
           }
           b[c] = r;
           if (oc + c < o_end) P.corr[(size_t)i * P.n_off + oc + c] = r;
-          n_found += (r >= 0);
         }
       } else {
 #pragma unroll
@@ -407,12 +405,6 @@ __global__ __launch_bounds__(256) void cost_kernel(CostParams P) {
 
   // ---- workgroup reduction: wave shuffles, then LDS across the 4 waves ----
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  if (do_find && P.d_num_corr) {
-    int nf = n_found;
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) nf += __shfl_xor(nf, off);
-    if (lane == 0 && nf) atomicAdd(P.d_num_corr, nf);
-  }
   if (!do_cost) return;
   const int nsum = do_deriv ? NSUM : 1;
 #pragma unroll
@@ -428,30 +420,58 @@ __global__ __launch_bounds__(256) void cost_kernel(CostParams P) {
   if (threadIdx.x < PART_STRIDE) {
     const int v = threadIdx.x;
     const double s = (v < nsum) ? (red[0][v] + red[1][v]) + (red[2][v] + red[3][v]) : 0.0;
-    // write-through (sc1) so the last workgroup can read it from L2 without a release fence
+    // write-through (sc1) so another workgroup can read it from L2 without a release fence
     __hip_atomic_store(&P.partials[(size_t)blockIdx.x * PART_STRIDE + v], s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
-  if (threadIdx.x == 0) {
-    // two-level arrival: 8 group counters (workgroup b -> group b % 8, i.e. its XCD under the observed
-    // dispatch order) + 1 top counter, so no single address sees more than ~gridDim/8 + 8 atomics
-    const unsigned grp = blockIdx.x % TICKET_GROUPS;
-    const unsigned ngroups = min((unsigned)TICKET_GROUPS, gridDim.x);
-    const unsigned gsize = (gridDim.x - grp + TICKET_GROUPS - 1) / TICKET_GROUPS;
-    int last = 0;
-    if (atomicAdd(&P.ticket[grp], 1u) == gsize - 1) last = (atomicAdd(&P.ticket[TICKET_GROUPS], 1u) == ngroups - 1);
-    s_last = last;
-  }
+
+  // ---- two-level arrival + two-level reduction ----------------------------------------------
+  // Workgroup b belongs to group b % 8 (its XCD under the observed dispatch order). The last arriver
+  // of a group sums that group's partial rows with all 256 threads (<= 8 independent sc1 loads per
+  // thread, fixed order), publishes one group row and arrives at the top counter; the last group
+  // sums the <= 8 group rows and runs the LM step. No address sees more than gridDim/8 + 8 atomics
+  // and no thread walks a long chain of dependent L2 round trips.
+  const unsigned grp = blockIdx.x % TICKET_GROUPS;
+  const unsigned ngroups = min((unsigned)TICKET_GROUPS, gridDim.x);
+  const unsigned gsize = (gridDim.x - grp + TICKET_GROUPS - 1) / TICKET_GROUPS;
+  if (threadIdx.x == 0) s_last = (atomicAdd(&P.ticket[grp], 1u) == gsize - 1);
   __syncthreads();
   if (!s_last) return;
-
-  // ---- last workgroup: fixed-order sum of the partials (deterministic), then the LM step ----
   {
     const int v = threadIdx.x & 31, chunk = threadIdx.x >> 5;  // 8 chunks x 32 values
     double s = 0.0;
-    for (unsigned b = chunk; b < gridDim.x; b += 8) s += __hip_atomic_load(&P.partials[(size_t)b * PART_STRIDE + v], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (unsigned j0 = chunk; j0 < gsize; j0 += 8 * 8) {
+      double t[8];
+#pragma unroll
+      for (int u = 0; u < 8; u++) {
+        const unsigned j = j0 + 8 * u;
+        t[u] = (j < gsize) ? __hip_atomic_load(&P.partials[(size_t)(grp + j * TICKET_GROUPS) * PART_STRIDE + v], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
+      }
+#pragma unroll
+      for (int u = 0; u < 8; u++) s += t[u];
+    }
     fin[chunk][v] = s;
+  }
+  __syncthreads();
+  if (threadIdx.x < PART_STRIDE) {
+    const int v = threadIdx.x;
+    double s = 0.0;
+#pragma unroll
+    for (int c = 0; c < 8; c++) s += fin[c][v];
+    __hip_atomic_store(&P.partials[(size_t)(MAX_PARTIAL_ROWS + grp) * PART_STRIDE + v], s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (threadIdx.x == 0) s_last = (atomicAdd(&P.ticket[TICKET_GROUPS], 1u) == ngroups - 1);
+  __syncthreads();
+  if (!s_last) return;
+
+  // ---- the very last workgroup: sum the group rows in group order (deterministic), LM step ----
+  {
+    const int v = threadIdx.x & 31;
+    const unsigned g = threadIdx.x >> 5;
+    fin[g][v] = (g < ngroups) ? __hip_atomic_load(&P.partials[(size_t)(MAX_PARTIAL_ROWS + g) * PART_STRIDE + v], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
   }
   __syncthreads();
   if (threadIdx.x < PART_STRIDE) {
