@@ -43,10 +43,10 @@ struct DevBuf {
 
 struct CloudDev {
   int n = 0, k = 0;
-  DevBuf pts, cov, nbr;
-  bool has_pts = false, has_cov = false, has_nbr = false;
+  DevBuf pts, cov, nbr, bbox;
+  bool has_pts = false, has_cov = false, has_nbr = false, has_bbox = false;
   void swap(CloudDev& o) { std::swap(*this, o); }
-  void release() { pts.release(); cov.release(); nbr.release(); }
+  void release() { pts.release(); cov.release(); nbr.release(); bbox.release(); }
 };
 
 struct VoxelMapDev {
@@ -221,6 +221,7 @@ int upload_cloud(Engine* e, CloudDev& c, const float* xyz, int n, int stride, bo
   HIP_OR_FAIL(e, c.pts.ensure(sizeof(float4) * (size_t)std::max(n, 1)));
   c.n = n;
   c.has_pts = true;
+  c.has_bbox = false;
   if (n == 0) return FVH_OK;
   if (on_device) {
     pack_points_kernel<<<(n + 255) / 256, 256, 0, e->stream>>>(xyz, n, stride, c.pts.as<float4>());
@@ -252,10 +253,21 @@ int find_neighbors(Engine* e, CloudDev& c, int k) {
   if (k <= 0 || k > 64) return e->fail(FVH_ERR_INVALID_ARGUMENT, "find_neighbors: k must be in [1, 64]");
   if (c.n < k) return e->fail(FVH_ERR_INVALID_ARGUMENT, "find_neighbors: fewer points than k");
   HIP_OR_FAIL(e, c.nbr.ensure(sizeof(int) * (size_t)c.n * k));
+  static const int knn_mode = [] { const char* v = getenv("FVH_KNN_MODE"); return v ? atoi(v) : 1; }();  // 0: full LDS-tiled sweep, 1: tile-culled
   {
     ProfScope ps(e, "knn");
     const int waves = (c.n + KNN_Q - 1) / KNN_Q;
-    knn_bruteforce_kernel<<<(waves + 3) / 4, 256, 0, e->stream>>>(c.pts.as<float4>(), c.n, k, c.nbr.as<int>());
+    if (knn_mode == 0) {
+      knn_bruteforce_kernel<<<(waves + 3) / 4, 256, 0, e->stream>>>(c.pts.as<float4>(), c.n, k, c.nbr.as<int>());
+    } else {
+      const int ntiles = (c.n + 63) / 64;
+      if (!c.has_bbox) {
+        HIP_OR_FAIL(e, c.bbox.ensure(sizeof(float4) * 2 * (size_t)ntiles));
+        tile_bbox_kernel<<<(ntiles + 3) / 4, 256, 0, e->stream>>>(c.pts.as<float4>(), c.n, c.bbox.as<float4>());
+        c.has_bbox = true;
+      }
+      knn_tiled_kernel<<<(waves + 3) / 4, 256, 0, e->stream>>>(c.pts.as<float4>(), c.bbox.as<float4>(), c.n, k, c.nbr.as<int>(), nullptr);
+    }
   }
   HIP_OR_FAIL(e, hipGetLastError());
   c.k = k;

@@ -139,6 +139,114 @@ __global__ __launch_bounds__(256) void knn_bruteforce_kernel(const float4* __res
     if (q_base + j < n && lane < k) out_idx[(size_t)(q_base + j) * k + lane] = li[j];
 }
 
+// ------------------------------------------------------------------------------------------------
+// Tile-culled exact k-NN. Points are taken in the order given (LiDAR clouds are scan-ordered, so 64
+// consecutive points form a spatially compact tile). tile_bbox_kernel stores each tile's bounding
+// box; a query wave (Q consecutive queries) seeds its threshold from its own tile and the two
+// adjacent ones, then scans the boxes 64 at a time (lane = tile) and only sweeps tiles whose
+// box-to-box distance can still beat the current k-th distance. Same list machinery, same total
+// order (distance, index): the result is identical to the full sweep for ANY point order; only the
+// amount of skipped work depends on how coherent the order is.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void tile_bbox_kernel(const float4* __restrict__ pts, int n, float4* __restrict__ bbox) {
+  const int lane = threadIdx.x & 63;
+  const int t = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (t * 64 >= n) return;
+  const float4 p = pts[min(t * 64 + lane, n - 1)];
+  float lo[3] = {p.x, p.y, p.z}, hi[3] = {p.x, p.y, p.z};
+#pragma unroll
+  for (int a = 0; a < 3; a++)
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      lo[a] = fminf(lo[a], __shfl_xor(lo[a], off));
+      hi[a] = fmaxf(hi[a], __shfl_xor(hi[a], off));
+    }
+  if (lane == 0) {
+    bbox[2 * t] = make_float4(lo[0], lo[1], lo[2], 0.f);
+    bbox[2 * t + 1] = make_float4(hi[0], hi[1], hi[2], 0.f);
+  }
+}
+
+__global__ __launch_bounds__(256) void knn_tiled_kernel(const float4* __restrict__ pts, const float4* __restrict__ bbox, int n, int k, int* __restrict__ out_idx,
+                                                        unsigned* __restrict__ stats) {
+  const int lane = threadIdx.x & 63;
+  const int wave = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int q_base = wave * KNN_Q;
+  if (q_base >= n) return;
+  const int ntiles = (n + 63) >> 6;
+  float qx[KNN_Q], qy[KNN_Q], qz[KNN_Q];
+  float ld[KNN_Q];
+  int li[KNN_Q];
+  float tau_d[KNN_Q];
+  int tau_i[KNN_Q];
+  float gmin[3] = {3e38f, 3e38f, 3e38f}, gmax[3] = {-3e38f, -3e38f, -3e38f};  // box of this wave's queries
+#pragma unroll
+  for (int j = 0; j < KNN_Q; j++) {
+    const float4 q = pts[min(q_base + j, n - 1)];
+    qx[j] = q.x; qy[j] = q.y; qz[j] = q.z;
+    gmin[0] = fminf(gmin[0], q.x); gmin[1] = fminf(gmin[1], q.y); gmin[2] = fminf(gmin[2], q.z);
+    gmax[0] = fmaxf(gmax[0], q.x); gmax[1] = fmaxf(gmax[1], q.y); gmax[2] = fmaxf(gmax[2], q.z);
+    ld[j] = __builtin_inff(); li[j] = 0x7fffffff; tau_d[j] = __builtin_inff(); tau_i[j] = 0x7fffffff;
+  }
+  unsigned swept = 0;
+  auto sweep_tile = [&](int t) {
+    swept++;
+    const int base = t << 6;
+    const float4 p = load_candidate(pts, base + lane, n);
+#pragma unroll
+    for (int j = 0; j < KNN_Q; j++) {
+      const float d = sqdist_nofma(p, qx[j], qy[j], qz[j]);
+      unsigned long long mask = __ballot(d <= tau_d[j]);
+      while (mask) {
+        const int src = __ffsll((long long)mask) - 1;
+        mask &= mask - 1;
+        const float cd = read_lane(d, src);
+        const int ci = base + src;
+        if (!(cd < tau_d[j] || (cd == tau_d[j] && ci < tau_i[j]))) continue;
+        const int pos = __popcll(__ballot(ld[j] < cd || (ld[j] == cd && li[j] < ci)));
+        const float sd = wave_shr1(ld[j], ld[j]);
+        const int si = wave_shr1(li[j], li[j]);
+        if (lane > pos) { ld[j] = sd; li[j] = si; }
+        else if (lane == pos) { ld[j] = cd; li[j] = ci; }
+        tau_d[j] = read_lane(ld[j], k - 1);
+        tau_i[j] = read_lane(li[j], k - 1);
+      }
+    }
+  };
+  // seed: own tile and its two neighbours
+  const int t0 = q_base >> 6;
+  sweep_tile(t0);
+  if (t0 + 1 < ntiles) sweep_tile(t0 + 1);
+  if (t0 > 0) sweep_tile(t0 - 1);
+  // cull: 64 tile boxes per step
+  for (int chunk = 0; chunk < ntiles; chunk += 64) {
+    const int t = chunk + lane;
+    const float4 bl = bbox[2 * min(t, ntiles - 1)], bh = bbox[2 * min(t, ntiles - 1) + 1];
+    const float gx = fmaxf(0.f, fmaxf(bl.x - gmax[0], gmin[0] - bh.x));
+    const float gy = fmaxf(0.f, fmaxf(bl.y - gmax[1], gmin[1] - bh.y));
+    const float gz = fmaxf(0.f, fmaxf(bl.z - gmax[2], gmin[2] - bh.z));
+    const float lb = (gx * gx + gy * gy + gz * gz) * 0.99999f;  // conservative w.r.t. fp32 rounding of the exact distance
+    const bool fresh = (t < ntiles) && (t < t0 - 1 || t > t0 + 1);
+    float tmax = tau_d[0];
+#pragma unroll
+    for (int j = 1; j < KNN_Q; j++) tmax = fmaxf(tmax, tau_d[j]);
+    unsigned long long mask = __ballot(fresh && lb <= tmax);
+    while (mask) {
+      const int src = __ffsll((long long)mask) - 1;
+      mask &= mask - 1;
+      tmax = tau_d[0];
+#pragma unroll
+      for (int j = 1; j < KNN_Q; j++) tmax = fmaxf(tmax, tau_d[j]);
+      if (read_lane(lb, src) > tmax) continue;  // the threshold tightened since the ballot
+      sweep_tile(chunk + src);
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < KNN_Q; j++)
+    if (q_base + j < n && lane < k) out_idx[(size_t)(q_base + j) * k + lane] = li[j];
+  if (stats && lane == 0) atomicAdd(stats, swept);
+}
+
 __device__ __forceinline__ void store_cov(float4* __restrict__ cov, int i, const Sym3<double>& C) {
   cov[2 * i] = make_float4((float)C.xx, (float)C.xy, (float)C.xz, (float)C.yy);
   cov[2 * i + 1] = make_float4((float)C.yz, (float)C.zz, 0.f, 0.f);
