@@ -18,6 +18,7 @@
 #include "../../include/fast_vgicp_hip.h"
 #include "kernels_cost.hpp"
 #include "kernels_cov.hpp"
+#include "kernels_sort.hpp"
 #include "kernels_voxelmap.hpp"
 
 using namespace fvh;
@@ -43,10 +44,10 @@ struct DevBuf {
 
 struct CloudDev {
   int n = 0, k = 0;
-  DevBuf pts, cov, nbr, bbox;
-  bool has_pts = false, has_cov = false, has_nbr = false, has_bbox = false;
+  DevBuf pts, cov, nbr, bbox, sorted;  // sorted: Morton-ordered copy, .w = original index; bbox: boxes of its 64-point tiles
+  bool has_pts = false, has_cov = false, has_nbr = false, has_sorted = false;
   void swap(CloudDev& o) { std::swap(*this, o); }
-  void release() { pts.release(); cov.release(); nbr.release(); bbox.release(); }
+  void release() { pts.release(); cov.release(); nbr.release(); bbox.release(); sorted.release(); }
 };
 
 struct VoxelMapDev {
@@ -113,7 +114,7 @@ struct Engine {
   int precision = FVH_COMPUTE_FP64;
   std::vector<int> offsets_host{0, 0, 0};
   int n_off = 1;
-  DevBuf offsets_dev, state, partials, ticket, corr, misc, fit, staging;
+  DevBuf offsets_dev, state, partials, ticket, corr, misc, fit, staging, sort_keys, sort_idx, sort_hist;
   void* pinned = nullptr;  // sizeof(LmState) + slack
   PoseD lin;               // pose of the last update_correspondences()
   bool has_corr = false;
@@ -153,7 +154,7 @@ struct Engine {
     if (comm && g_rccl.CommDestroy) g_rccl.CommDestroy(comm);
     comm = nullptr;
     prof.destroy();
-    offsets_dev.release(); state.release(); partials.release(); ticket.release(); corr.release(); misc.release(); fit.release(); staging.release();
+    offsets_dev.release(); state.release(); partials.release(); ticket.release(); corr.release(); misc.release(); fit.release(); staging.release(); sort_keys.release(); sort_idx.release(); sort_hist.release();
     if (pinned) (void)hipHostFree(pinned);
     if (stream) (void)hipStreamDestroy(stream);
   }
@@ -221,7 +222,7 @@ int upload_cloud(Engine* e, CloudDev& c, const float* xyz, int n, int stride, bo
   HIP_OR_FAIL(e, c.pts.ensure(sizeof(float4) * (size_t)std::max(n, 1)));
   c.n = n;
   c.has_pts = true;
-  c.has_bbox = false;
+  c.has_sorted = false;
   if (n == 0) return FVH_OK;
   if (on_device) {
     pack_points_kernel<<<(n + 255) / 256, 256, 0, e->stream>>>(xyz, n, stride, c.pts.as<float4>());
@@ -248,26 +249,55 @@ int set_neighbors(Engine* e, CloudDev& c, int k, const int* idx) {
   return FVH_OK;
 }
 
+// Morton-sort the cloud (kernels_sort.hpp) and box its 64-point tiles; cached until the cloud changes.
+int ensure_sorted(Engine* e, CloudDev& c) {
+  if (c.has_sorted) return FVH_OK;
+  const int n = c.n;
+  const int nwaves = (n + SORT_ITEMS_PER_WAVE - 1) / SORT_ITEMS_PER_WAVE;
+  const int ntiles = (n + 63) / 64;
+  HIP_OR_FAIL(e, c.sorted.ensure(sizeof(float4) * (size_t)n));
+  HIP_OR_FAIL(e, c.bbox.ensure(sizeof(float4) * 2 * (size_t)ntiles));
+  HIP_OR_FAIL(e, e->sort_keys.ensure(sizeof(unsigned) * 2 * (size_t)n + 64));
+  HIP_OR_FAIL(e, e->sort_idx.ensure(sizeof(int) * 2 * (size_t)n));
+  HIP_OR_FAIL(e, e->sort_hist.ensure(sizeof(unsigned) * (size_t)RADIX_BINS * nwaves));
+  ProfScope ps(e, "sort");
+  unsigned* box = reinterpret_cast<unsigned*>(e->sort_keys.as<unsigned>() + 2 * (size_t)n);
+  HIP_OR_FAIL(e, hipMemsetAsync(box, 0xFF, 12, e->stream));
+  HIP_OR_FAIL(e, hipMemsetAsync(box + 3, 0, 12, e->stream));
+  cloud_bbox_kernel<<<std::min(256, (n + 255) / 256), 256, 0, e->stream>>>(c.pts.as<float4>(), n, box);
+  unsigned* keys[2] = {e->sort_keys.as<unsigned>(), e->sort_keys.as<unsigned>() + n};
+  int* idx[2] = {e->sort_idx.as<int>(), e->sort_idx.as<int>() + n};
+  morton_keys_kernel<<<(n + 255) / 256, 256, 0, e->stream>>>(c.pts.as<float4>(), n, box, keys[0], idx[0]);
+  const int wblocks = (nwaves + 3) / 4;
+  for (int pass = 0; pass < RADIX_PASSES; pass++) {
+    const int in = pass & 1, out = in ^ 1, shift = pass * RADIX_BITS;
+    radix_hist_kernel<<<wblocks, 256, 0, e->stream>>>(keys[in], n, shift, nwaves, e->sort_hist.as<unsigned>());
+    radix_scan_kernel<<<1, 1024, 0, e->stream>>>(e->sort_hist.as<unsigned>(), RADIX_BINS * nwaves);
+    const bool last = (pass == RADIX_PASSES - 1);
+    radix_scatter_kernel<<<wblocks, 256, 0, e->stream>>>(keys[in], idx[in], n, shift, nwaves, e->sort_hist.as<unsigned>(), keys[out], idx[out], last ? c.pts.as<float4>() : nullptr,
+                                                         last ? c.sorted.as<float4>() : nullptr);
+  }
+  tile_bbox_kernel<<<(ntiles + 3) / 4, 256, 0, e->stream>>>(c.sorted.as<float4>(), n, c.bbox.as<float4>());
+  HIP_OR_FAIL(e, hipGetLastError());
+  c.has_sorted = true;
+  return FVH_OK;
+}
+
 int find_neighbors(Engine* e, CloudDev& c, int k) {
   if (!c.has_pts) return e->fail(FVH_ERR_BAD_STATE, "find_neighbors: cloud not set");
   if (k <= 0 || k > 64) return e->fail(FVH_ERR_INVALID_ARGUMENT, "find_neighbors: k must be in [1, 64]");
   if (c.n < k) return e->fail(FVH_ERR_INVALID_ARGUMENT, "find_neighbors: fewer points than k");
   HIP_OR_FAIL(e, c.nbr.ensure(sizeof(int) * (size_t)c.n * k));
-  static const int knn_mode = [] { const char* v = getenv("FVH_KNN_MODE"); return v ? atoi(v) : 1; }();  // 0: full LDS-tiled sweep, 1: tile-culled
-  {
+  static const int knn_mode = [] { const char* v = getenv("FVH_KNN_MODE"); return v ? atoi(v) : 1; }();  // 0: full LDS-tiled sweep, 1: Morton order + tile culling
+  const int waves = (c.n + KNN_Q - 1) / KNN_Q;
+  if (knn_mode == 0) {
     ProfScope ps(e, "knn");
-    const int waves = (c.n + KNN_Q - 1) / KNN_Q;
-    if (knn_mode == 0) {
-      knn_bruteforce_kernel<<<(waves + 3) / 4, 256, 0, e->stream>>>(c.pts.as<float4>(), c.n, k, c.nbr.as<int>());
-    } else {
-      const int ntiles = (c.n + 63) / 64;
-      if (!c.has_bbox) {
-        HIP_OR_FAIL(e, c.bbox.ensure(sizeof(float4) * 2 * (size_t)ntiles));
-        tile_bbox_kernel<<<(ntiles + 3) / 4, 256, 0, e->stream>>>(c.pts.as<float4>(), c.n, c.bbox.as<float4>());
-        c.has_bbox = true;
-      }
-      knn_tiled_kernel<<<(waves + 3) / 4, 256, 0, e->stream>>>(c.pts.as<float4>(), c.bbox.as<float4>(), c.n, k, c.nbr.as<int>(), nullptr);
-    }
+    knn_bruteforce_kernel<<<(waves + 3) / 4, 256, 0, e->stream>>>(c.pts.as<float4>(), c.n, k, c.nbr.as<int>());
+  } else {
+    int rc = ensure_sorted(e, c);
+    if (rc) return rc;
+    ProfScope ps(e, "knn");
+    knn_tiled_kernel<<<(waves + 3) / 4, 256, 0, e->stream>>>(c.sorted.as<float4>(), c.bbox.as<float4>(), c.n, k, c.nbr.as<int>(), nullptr);
   }
   HIP_OR_FAIL(e, hipGetLastError());
   c.k = k;
@@ -293,10 +323,18 @@ int calc_cov_rbf(Engine* e, CloudDev& c, double kernel_width, double max_dist, i
   if (method < 0 || method > 4) return e->fail(FVH_ERR_INVALID_ARGUMENT, "unknown regularization method");
   HIP_OR_FAIL(e, c.cov.ensure(sizeof(float4) * 2 * (size_t)std::max(c.n, 1)));
   if (c.n) {
-    ProfScope ps(e, "rbf");
+    static const int rbf_mode = [] { const char* v = getenv("FVH_RBF_MODE"); return v ? atoi(v) : 1; }();  // 0: full sweep, 1: Morton order + tile culling
     const int waves = (c.n + RBF_Q - 1) / RBF_Q;
     const float md = (float)max_dist;
-    cov_rbf_kernel<<<(waves + 3) / 4, 256, 0, e->stream>>>(c.pts.as<float4>(), c.n, (float)kernel_width, md * md, method, c.cov.as<float4>());
+    if (rbf_mode == 0) {
+      ProfScope ps(e, "rbf");
+      cov_rbf_kernel<<<(waves + 3) / 4, 256, 0, e->stream>>>(c.pts.as<float4>(), c.n, (float)kernel_width, md * md, method, c.cov.as<float4>());
+    } else {
+      int rc = ensure_sorted(e, c);
+      if (rc) return rc;
+      ProfScope ps(e, "rbf");
+      cov_rbf_tiled_kernel<<<(waves + 3) / 4, 256, 0, e->stream>>>(c.sorted.as<float4>(), c.bbox.as<float4>(), c.n, (float)kernel_width, md * md, method, c.cov.as<float4>());
+    }
   }
   HIP_OR_FAIL(e, hipGetLastError());
   c.has_cov = true;
@@ -569,7 +607,7 @@ int do_align(Engine* e, const CostSource& src, VoxelMapDev& vm, const double* gu
   return FVH_OK;
 }
 
-int do_fitness(Engine* e, const CloudDev& src, const CloudDev& tgt, const double* T16, double max_range, double* score) {
+int do_fitness(Engine* e, CloudDev& src, CloudDev& tgt, const double* T16, double max_range, double* score) {
   if (!T16 || !score) return e->fail(FVH_ERR_INVALID_ARGUMENT, "fitness_score: null argument");
   if (!src.has_pts || !tgt.has_pts || src.n == 0 || tgt.n == 0) return e->fail(FVH_ERR_BAD_STATE, "fitness_score: clouds not set");
   float T12[12];
@@ -577,10 +615,20 @@ int do_fitness(Engine* e, const CloudDev& src, const CloudDev& tgt, const double
   char* base = (char*)e->fit.p;
   HIP_OR_FAIL(e, hipMemsetAsync(base, 0, 16, e->stream));
   HIP_OR_FAIL(e, hipMemcpyAsync(base + 16, T12, sizeof(T12), hipMemcpyHostToDevice, e->stream));
+  static const int fit_mode = [] { const char* v = getenv("FVH_FIT_MODE"); return v ? atoi(v) : 1; }();
+  if (fit_mode != 0) {
+    int rc = ensure_sorted(e, src);
+    if (!rc) rc = ensure_sorted(e, tgt);
+    if (rc) return rc;
+  }
   {
     ProfScope ps(e, "fitness");
     const int waves = (src.n + FIT_Q - 1) / FIT_Q;
-    fitness_kernel<<<(waves + 3) / 4, 256, 0, e->stream>>>(src.pts.as<float4>(), src.n, tgt.pts.as<float4>(), tgt.n, (const float*)(base + 16), max_range, (double*)base);
+    if (fit_mode == 0)
+      fitness_kernel<<<(waves + 3) / 4, 256, 0, e->stream>>>(src.pts.as<float4>(), src.n, tgt.pts.as<float4>(), tgt.n, (const float*)(base + 16), max_range, (double*)base);
+    else
+      fitness_tiled_kernel<<<(waves + 3) / 4, 256, 0, e->stream>>>(src.sorted.as<float4>(), src.n, tgt.sorted.as<float4>(), tgt.bbox.as<float4>(), tgt.n, (const float*)(base + 16), max_range,
+                                                                    (double*)base);
   }
   HIP_OR_FAIL(e, hipGetLastError());
   double out[2];

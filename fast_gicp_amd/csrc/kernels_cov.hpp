@@ -167,7 +167,18 @@ __global__ __launch_bounds__(256) void tile_bbox_kernel(const float4* __restrict
   }
 }
 
-__global__ __launch_bounds__(256) void knn_tiled_kernel(const float4* __restrict__ pts, const float4* __restrict__ bbox, int n, int k, int* __restrict__ out_idx,
+// box-to-box lower bound of the squared distance, shrunk so that it never exceeds the fp32-rounded
+// exact distance of any point pair inside the boxes
+__device__ __forceinline__ float box_gap_sq(const float4& bl, const float4& bh, const float* gmin, const float* gmax) {
+  const float gx = fmaxf(0.f, fmaxf(bl.x - gmax[0], gmin[0] - bh.x));
+  const float gy = fmaxf(0.f, fmaxf(bl.y - gmax[1], gmin[1] - bh.y));
+  const float gz = fmaxf(0.f, fmaxf(bl.z - gmax[2], gmin[2] - bh.z));
+  return (gx * gx + gy * gy + gz * gz) * 0.99999f;
+}
+
+// spts: Morton-sorted cloud, .w = original index (bit pattern). out_idx rows/values are ORIGINAL
+// indices, each row ascending in (distance, original index).
+__global__ __launch_bounds__(256) void knn_tiled_kernel(const float4* __restrict__ spts, const float4* __restrict__ bbox, int n, int k, int* __restrict__ out_idx,
                                                         unsigned* __restrict__ stats) {
   const int lane = threadIdx.x & 63;
   const int wave = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -175,6 +186,7 @@ __global__ __launch_bounds__(256) void knn_tiled_kernel(const float4* __restrict
   if (q_base >= n) return;
   const int ntiles = (n + 63) >> 6;
   float qx[KNN_Q], qy[KNN_Q], qz[KNN_Q];
+  int qo[KNN_Q];
   float ld[KNN_Q];
   int li[KNN_Q];
   float tau_d[KNN_Q];
@@ -182,8 +194,8 @@ __global__ __launch_bounds__(256) void knn_tiled_kernel(const float4* __restrict
   float gmin[3] = {3e38f, 3e38f, 3e38f}, gmax[3] = {-3e38f, -3e38f, -3e38f};  // box of this wave's queries
 #pragma unroll
   for (int j = 0; j < KNN_Q; j++) {
-    const float4 q = pts[min(q_base + j, n - 1)];
-    qx[j] = q.x; qy[j] = q.y; qz[j] = q.z;
+    const float4 q = spts[min(q_base + j, n - 1)];
+    qx[j] = q.x; qy[j] = q.y; qz[j] = q.z; qo[j] = __float_as_int(q.w);
     gmin[0] = fminf(gmin[0], q.x); gmin[1] = fminf(gmin[1], q.y); gmin[2] = fminf(gmin[2], q.z);
     gmax[0] = fmaxf(gmax[0], q.x); gmax[1] = fmaxf(gmax[1], q.y); gmax[2] = fmaxf(gmax[2], q.z);
     ld[j] = __builtin_inff(); li[j] = 0x7fffffff; tau_d[j] = __builtin_inff(); tau_i[j] = 0x7fffffff;
@@ -191,8 +203,8 @@ __global__ __launch_bounds__(256) void knn_tiled_kernel(const float4* __restrict
   unsigned swept = 0;
   auto sweep_tile = [&](int t) {
     swept++;
-    const int base = t << 6;
-    const float4 p = load_candidate(pts, base + lane, n);
+    const float4 p = load_candidate(spts, (t << 6) + lane, n);
+    const int po = __float_as_int(p.w);
 #pragma unroll
     for (int j = 0; j < KNN_Q; j++) {
       const float d = sqdist_nofma(p, qx[j], qy[j], qz[j]);
@@ -201,7 +213,7 @@ __global__ __launch_bounds__(256) void knn_tiled_kernel(const float4* __restrict
         const int src = __ffsll((long long)mask) - 1;
         mask &= mask - 1;
         const float cd = read_lane(d, src);
-        const int ci = base + src;
+        const int ci = read_lane(po, src);
         if (!(cd < tau_d[j] || (cd == tau_d[j] && ci < tau_i[j]))) continue;
         const int pos = __popcll(__ballot(ld[j] < cd || (ld[j] == cd && li[j] < ci)));
         const float sd = wave_shr1(ld[j], ld[j]);
@@ -213,7 +225,7 @@ __global__ __launch_bounds__(256) void knn_tiled_kernel(const float4* __restrict
       }
     }
   };
-  // seed: own tile and its two neighbours
+  // seed: own tile and its two neighbours in Morton order
   const int t0 = q_base >> 6;
   sweep_tile(t0);
   if (t0 + 1 < ntiles) sweep_tile(t0 + 1);
@@ -221,11 +233,7 @@ __global__ __launch_bounds__(256) void knn_tiled_kernel(const float4* __restrict
   // cull: 64 tile boxes per step
   for (int chunk = 0; chunk < ntiles; chunk += 64) {
     const int t = chunk + lane;
-    const float4 bl = bbox[2 * min(t, ntiles - 1)], bh = bbox[2 * min(t, ntiles - 1) + 1];
-    const float gx = fmaxf(0.f, fmaxf(bl.x - gmax[0], gmin[0] - bh.x));
-    const float gy = fmaxf(0.f, fmaxf(bl.y - gmax[1], gmin[1] - bh.y));
-    const float gz = fmaxf(0.f, fmaxf(bl.z - gmax[2], gmin[2] - bh.z));
-    const float lb = (gx * gx + gy * gy + gz * gz) * 0.99999f;  // conservative w.r.t. fp32 rounding of the exact distance
+    const float lb = box_gap_sq(bbox[2 * min(t, ntiles - 1)], bbox[2 * min(t, ntiles - 1) + 1], gmin, gmax);
     const bool fresh = (t < ntiles) && (t < t0 - 1 || t > t0 + 1);
     float tmax = tau_d[0];
 #pragma unroll
@@ -243,7 +251,7 @@ __global__ __launch_bounds__(256) void knn_tiled_kernel(const float4* __restrict
   }
 #pragma unroll
   for (int j = 0; j < KNN_Q; j++)
-    if (q_base + j < n && lane < k) out_idx[(size_t)(q_base + j) * k + lane] = li[j];
+    if (q_base + j < n && lane < k) out_idx[(size_t)qo[j] * k + lane] = li[j];
   if (stats && lane == 0) atomicAdd(stats, swept);
 }
 
@@ -375,6 +383,137 @@ __global__ __launch_bounds__(256) void fitness_kernel(const float4* __restrict__
     if (q_base + j < ns && (double)b <= max_range) { sum += (double)b; cnt += 1.0; }
   }
   if (lane == 0 && (sum != 0.0 || cnt != 0.0)) {
+    atomicAdd(&out[0], sum);
+    atomicAdd(&out[1], cnt);
+  }
+}
+
+// RBF covariances on the Morton-sorted cloud: only tiles whose box is within max_dist of the wave's
+// query box are swept (fixed-radius culling). cov is indexed by ORIGINAL point index.
+__global__ __launch_bounds__(256) void cov_rbf_tiled_kernel(const float4* __restrict__ spts, const float4* __restrict__ bbox, int n, float kernel_width, float max_dist_sq,
+                                                            int method, float4* __restrict__ cov) {
+  const int lane = threadIdx.x & 63;
+  const int wave = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int q_base = wave * RBF_Q;
+  if (q_base >= n) return;
+  const int ntiles = (n + 63) >> 6;
+  float qx[RBF_Q], qy[RBF_Q], qz[RBF_Q];
+  int qo[RBF_Q];
+  float sw[RBF_Q], sx[RBF_Q], sy[RBF_Q], sz[RBF_Q], sxx[RBF_Q], sxy[RBF_Q], sxz[RBF_Q], syy[RBF_Q], syz[RBF_Q], szz[RBF_Q];
+  float gmin[3] = {3e38f, 3e38f, 3e38f}, gmax[3] = {-3e38f, -3e38f, -3e38f};
+#pragma unroll
+  for (int j = 0; j < RBF_Q; j++) {
+    const float4 q = spts[min(q_base + j, n - 1)];
+    qx[j] = q.x; qy[j] = q.y; qz[j] = q.z; qo[j] = __float_as_int(q.w);
+    gmin[0] = fminf(gmin[0], q.x); gmin[1] = fminf(gmin[1], q.y); gmin[2] = fminf(gmin[2], q.z);
+    gmax[0] = fmaxf(gmax[0], q.x); gmax[1] = fmaxf(gmax[1], q.y); gmax[2] = fmaxf(gmax[2], q.z);
+    sw[j] = sx[j] = sy[j] = sz[j] = sxx[j] = sxy[j] = sxz[j] = syy[j] = syz[j] = szz[j] = 0.f;
+  }
+  for (int chunk = 0; chunk < ntiles; chunk += 64) {
+    const int t = chunk + lane;
+    const float lb = box_gap_sq(bbox[2 * min(t, ntiles - 1)], bbox[2 * min(t, ntiles - 1) + 1], gmin, gmax);
+    unsigned long long mask = __ballot(t < ntiles && lb <= max_dist_sq);
+    while (mask) {
+      const int src = __ffsll((long long)mask) - 1;
+      mask &= mask - 1;
+      const float4 p = load_candidate(spts, ((chunk + src) << 6) + lane, n);
+#pragma unroll
+      for (int j = 0; j < RBF_Q; j++) {
+        const float dx = p.x - qx[j], dy = p.y - qy[j], dz = p.z - qz[j];
+        const float sq = sqdist_nofma(p, qx[j], qy[j], qz[j]);
+        const float w = (sq > max_dist_sq) ? 0.f : __expf(-kernel_width * sq);
+        sw[j] += w;
+        const float wx = w * dx, wy = w * dy, wz = w * dz;
+        sx[j] += wx; sy[j] += wy; sz[j] += wz;
+        sxx[j] += wx * dx; sxy[j] += wx * dy; sxz[j] += wx * dz; syy[j] += wy * dy; syz[j] += wy * dz; szz[j] += wz * dz;
+      }
+    }
+  }
+  for (int j = 0; j < RBF_Q; j++) {
+    const double W = wave_sum((double)sw[j]);
+    const double X = wave_sum((double)sx[j]), Y = wave_sum((double)sy[j]), Z = wave_sum((double)sz[j]);
+    const double XX = wave_sum((double)sxx[j]), XY = wave_sum((double)sxy[j]), XZ = wave_sum((double)sxz[j]);
+    const double YY = wave_sum((double)syy[j]), YZ = wave_sum((double)syz[j]), ZZ = wave_sum((double)szz[j]);
+    if (lane == 0 && q_base + j < n) {
+      const double iw = 1.0 / W;
+      const double mx = X * iw, my = Y * iw, mz = Z * iw;
+      Sym3<double> C;
+      C.xx = XX * iw - mx * mx; C.xy = XY * iw - mx * my; C.xz = XZ * iw - mx * mz;
+      C.yy = YY * iw - my * my; C.yz = YZ * iw - my * mz; C.zz = ZZ * iw - mz * mz;
+      store_cov(cov, qo[j], regularize_cov(C, method));
+    }
+  }
+}
+
+// getFitnessScore on the Morton-sorted clouds: the wave first sweeps the target tile whose box is
+// nearest to its (transformed) query box, then every tile that can still beat the current minima.
+__global__ __launch_bounds__(256) void fitness_tiled_kernel(const float4* __restrict__ ssrc, int ns, const float4* __restrict__ stgt, const float4* __restrict__ tbox, int nt,
+                                                            const float* __restrict__ T12, double max_range, double* __restrict__ out) {
+  const int lane = threadIdx.x & 63;
+  const int wave = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int q_base = wave * FIT_Q;
+  if (q_base >= ns) return;
+  const int ntiles = (nt + 63) >> 6;
+  float qx[FIT_Q], qy[FIT_Q], qz[FIT_Q], best[FIT_Q];
+  float gmin[3] = {3e38f, 3e38f, 3e38f}, gmax[3] = {-3e38f, -3e38f, -3e38f};
+#pragma unroll
+  for (int j = 0; j < FIT_Q; j++) {
+    const float4 p = ssrc[min(q_base + j, ns - 1)];
+    qx[j] = transform_row_nofma(p, T12 + 0);
+    qy[j] = transform_row_nofma(p, T12 + 4);
+    qz[j] = transform_row_nofma(p, T12 + 8);
+    gmin[0] = fminf(gmin[0], qx[j]); gmin[1] = fminf(gmin[1], qy[j]); gmin[2] = fminf(gmin[2], qz[j]);
+    gmax[0] = fmaxf(gmax[0], qx[j]); gmax[1] = fmaxf(gmax[1], qy[j]); gmax[2] = fmaxf(gmax[2], qz[j]);
+    best[j] = __builtin_inff();
+  }
+  auto sweep_tile = [&](int t) {
+    const float4 p = load_candidate(stgt, (t << 6) + lane, nt);
+#pragma unroll
+    for (int j = 0; j < FIT_Q; j++) {
+      float d = sqdist_nofma(p, qx[j], qy[j], qz[j]);
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) d = fminf(d, __shfl_xor(d, off));
+      best[j] = fminf(best[j], d);  // wave-uniform
+    }
+  };
+  // pass 1: nearest box first
+  float lb_min = __builtin_inff();
+  int t_min = 0;
+  for (int chunk = 0; chunk < ntiles; chunk += 64) {
+    const int t = chunk + lane;
+    const float lb = (t < ntiles) ? box_gap_sq(tbox[2 * t], tbox[2 * t + 1], gmin, gmax) : __builtin_inff();
+    if (lb < lb_min) { lb_min = lb; t_min = t; }
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    const float ol = __shfl_xor(lb_min, off);
+    const int ot = __shfl_xor(t_min, off);
+    if (ol < lb_min || (ol == lb_min && ot < t_min)) { lb_min = ol; t_min = ot; }
+  }
+  sweep_tile(t_min);
+  // pass 2: everything that can still improve one of the minima
+  for (int chunk = 0; chunk < ntiles; chunk += 64) {
+    const int t = chunk + lane;
+    const float lb = box_gap_sq(tbox[2 * min(t, ntiles - 1)], tbox[2 * min(t, ntiles - 1) + 1], gmin, gmax);
+    float bmax = best[0];
+#pragma unroll
+    for (int j = 1; j < FIT_Q; j++) bmax = fmaxf(bmax, best[j]);
+    unsigned long long mask = __ballot(t < ntiles && t != t_min && lb <= bmax);
+    while (mask) {
+      const int src = __ffsll((long long)mask) - 1;
+      mask &= mask - 1;
+      bmax = best[0];
+#pragma unroll
+      for (int j = 1; j < FIT_Q; j++) bmax = fmaxf(bmax, best[j]);
+      if (read_lane(lb, src) > bmax) continue;
+      sweep_tile(chunk + src);
+    }
+  }
+  double sum = 0.0, cnt = 0.0;
+#pragma unroll
+  for (int j = 0; j < FIT_Q; j++)
+    if (q_base + j < ns && (double)best[j] <= max_range) { sum += (double)best[j]; cnt += 1.0; }
+  if (lane == 0) {
     atomicAdd(&out[0], sum);
     atomicAdd(&out[1], cnt);
   }
