@@ -44,10 +44,11 @@ struct DevBuf {
 
 struct CloudDev {
   int n = 0, k = 0;
+  DevBuf bbox2;                        // boxes of 64 consecutive tile boxes
   DevBuf pts, cov, nbr, bbox, sorted;  // sorted: Morton-ordered copy, .w = original index; bbox: boxes of its 64-point tiles
   bool has_pts = false, has_cov = false, has_nbr = false, has_sorted = false;
   void swap(CloudDev& o) { std::swap(*this, o); }
-  void release() { pts.release(); cov.release(); nbr.release(); bbox.release(); sorted.release(); }
+  void release() { pts.release(); cov.release(); nbr.release(); bbox.release(); bbox2.release(); sorted.release(); }
 };
 
 struct VoxelMapDev {
@@ -278,6 +279,9 @@ int ensure_sorted(Engine* e, CloudDev& c) {
                                                          last ? c.sorted.as<float4>() : nullptr);
   }
   tile_bbox_kernel<<<(ntiles + 3) / 4, 256, 0, e->stream>>>(c.sorted.as<float4>(), n, c.bbox.as<float4>());
+  const int nsuper = (ntiles + 63) / 64;
+  HIP_OR_FAIL(e, c.bbox2.ensure(sizeof(float4) * 2 * (size_t)nsuper));
+  super_bbox_kernel<<<(nsuper + 3) / 4, 256, 0, e->stream>>>(c.bbox.as<float4>(), ntiles, c.bbox2.as<float4>());
   HIP_OR_FAIL(e, hipGetLastError());
   c.has_sorted = true;
   return FVH_OK;
@@ -296,8 +300,27 @@ int find_neighbors(Engine* e, CloudDev& c, int k) {
   } else {
     int rc = ensure_sorted(e, c);
     if (rc) return rc;
-    ProfScope ps(e, "knn");
-    knn_tiled_kernel<<<(waves + 3) / 4, 256, 0, e->stream>>>(c.sorted.as<float4>(), c.bbox.as<float4>(), c.n, k, c.nbr.as<int>(), nullptr);
+    static const bool knn_stats = getenv("FVH_KNN_STATS") != nullptr;
+    static const int knn_dbg = [] { const char* v = getenv("FVH_KNN_DEBUG"); return v ? atoi(v) : 0; }();
+    unsigned* d_stats = knn_stats ? e->misc.as<unsigned>() + 8 : nullptr;
+    if (knn_stats) HIP_OR_FAIL(e, hipMemsetAsync(d_stats, 0, 16, e->stream));
+    {
+      ProfScope ps(e, "knn");
+      static const int knn_q = [] { const char* v = getenv("FVH_KNN_Q"); return v ? atoi(v) : 0; }();
+      const int qwaves = knn_q > 0 ? (c.n + knn_q - 1) / knn_q : c.n;
+      const dim3 grid((qwaves + 3) / 4);
+      if (knn_q == 0) knn_tiled1_kernel<<<(c.n + 3) / 4, 256, 0, e->stream>>>(c.sorted.as<float4>(), c.bbox.as<float4>(), c.bbox2.as<float4>(), c.n, k, c.nbr.as<int>());
+      else if (knn_q == 8) knn_tiled_kernel<8><<<grid, 256, 0, e->stream>>>(c.sorted.as<float4>(), c.bbox.as<float4>(), c.n, k, c.nbr.as<int>(), d_stats, knn_dbg);
+      else if (knn_q == 4) knn_tiled_kernel<4><<<grid, 256, 0, e->stream>>>(c.sorted.as<float4>(), c.bbox.as<float4>(), c.n, k, c.nbr.as<int>(), d_stats, knn_dbg);
+      else if (knn_q == 1) knn_tiled_kernel<1><<<grid, 256, 0, e->stream>>>(c.sorted.as<float4>(), c.bbox.as<float4>(), c.n, k, c.nbr.as<int>(), d_stats, knn_dbg);
+      else knn_tiled_kernel<2><<<grid, 256, 0, e->stream>>>(c.sorted.as<float4>(), c.bbox.as<float4>(), c.n, k, c.nbr.as<int>(), d_stats, knn_dbg);
+    }
+    if (knn_stats) {
+      unsigned hs[4] = {0, 0, 0, 0};
+      HIP_OR_FAIL(e, hipMemcpyAsync(hs, d_stats, 16, hipMemcpyDeviceToHost, e->stream));
+      HIP_OR_FAIL(e, hipStreamSynchronize(e->stream));
+      std::fprintf(stderr, "[knn stats] n=%d waves=%d tiles=%d swept/wave=%.1f (max %u) insertions/query=%.1f\n", c.n, waves, (c.n + 63) / 64, (double)hs[0] / waves, hs[2], (double)hs[1] / c.n);
+    }
   }
   HIP_OR_FAIL(e, hipGetLastError());
   c.k = k;

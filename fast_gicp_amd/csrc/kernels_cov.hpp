@@ -167,6 +167,25 @@ __global__ __launch_bounds__(256) void tile_bbox_kernel(const float4* __restrict
   }
 }
 
+// Wave-wide bitonic sort of one (distance, index) pair per lane, ascending in the total order
+// (distance, index): 21 compare-exchange stages. Seeds a query's top-k list from a whole 64-point tile
+// at once -- ~250 instructions instead of ~43 serial insertions of ~50 dependent instructions each.
+__device__ __forceinline__ void wave_bitonic_sort(float& d, int& i, int lane) {
+#pragma unroll
+  for (int k2 = 2; k2 <= 64; k2 <<= 1) {
+#pragma unroll
+    for (int j2 = k2 >> 1; j2 > 0; j2 >>= 1) {
+      const float od = __shfl_xor(d, j2);
+      const int oi = __shfl_xor(i, j2);
+      const bool want_min = (((lane & j2) == 0) == ((lane & k2) == 0));
+      const bool less = (od < d) || (od == d && oi < i);  // partner < me (indices are unique: no ties)
+      const bool take = want_min ? less : !less;
+      d = take ? od : d;
+      i = take ? oi : i;
+    }
+  }
+}
+
 // box-to-box lower bound of the squared distance, shrunk so that it never exceeds the fp32-rounded
 // exact distance of any point pair inside the boxes
 __device__ __forceinline__ float box_gap_sq(const float4& bl, const float4& bh, const float* gmin, const float* gmax) {
@@ -176,83 +195,234 @@ __device__ __forceinline__ float box_gap_sq(const float4& bl, const float4& bh, 
   return (gx * gx + gy * gy + gz * gz) * 0.99999f;
 }
 
+// lane l <- v (v wave-uniform), other lanes keep `old`
+__device__ __forceinline__ float write_lane(float v, int l, float old) { return ((int)(threadIdx.x & 63) == l) ? v : old; }
+__device__ __forceinline__ int write_lane(int v, int l, int old) { return ((int)(threadIdx.x & 63) == l) ? v : old; }
+
 // spts: Morton-sorted cloud, .w = original index (bit pattern). out_idx rows/values are ORIGINAL
 // indices, each row ascending in (distance, original index).
+//
+// Code-size discipline: an earlier version unrolled everything over the Q queries (24 inlined copies
+// of the insertion loop + 8 bitonic sorts, ~40 KB of ISA) and ran 10x slower than its instruction
+// count because 16 waves per CU thrashed the instruction cache. Here all per-query state is
+// dynamically indexable by a wave-uniform j -- queries and thresholds live in lane j of a register
+// (v_readlane / v_writelane), the top-k lists in a per-wave LDS row (each lane touches only its own
+// slot) -- so there is ONE sweep site, ONE insertion loop and a non-unrolled seed loop.
+template <int Q>
 __global__ __launch_bounds__(256) void knn_tiled_kernel(const float4* __restrict__ spts, const float4* __restrict__ bbox, int n, int k, int* __restrict__ out_idx,
-                                                        unsigned* __restrict__ stats) {
-  const int lane = threadIdx.x & 63;
-  const int wave = blockIdx.x * 4 + (threadIdx.x >> 6);
-  const int q_base = wave * KNN_Q;
-  if (q_base >= n) return;
+                                                        unsigned* __restrict__ stats, int dbg) {
+  __shared__ float s_ld[4][Q][64];
+  __shared__ int s_li[4][Q][64];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int wave = blockIdx.x * 4 + wv;
+  const int q_base = wave * Q;
+  if (q_base >= n) return;  // no workgroup barrier below: waves are independent
   const int ntiles = (n + 63) >> 6;
-  float qx[KNN_Q], qy[KNN_Q], qz[KNN_Q];
-  int qo[KNN_Q];
-  float ld[KNN_Q];
-  int li[KNN_Q];
-  float tau_d[KNN_Q];
-  int tau_i[KNN_Q];
-  float gmin[3] = {3e38f, 3e38f, 3e38f}, gmax[3] = {-3e38f, -3e38f, -3e38f};  // box of this wave's queries
-#pragma unroll
-  for (int j = 0; j < KNN_Q; j++) {
-    const float4 q = spts[min(q_base + j, n - 1)];
-    qx[j] = q.x; qy[j] = q.y; qz[j] = q.z; qo[j] = __float_as_int(q.w);
-    gmin[0] = fminf(gmin[0], q.x); gmin[1] = fminf(gmin[1], q.y); gmin[2] = fminf(gmin[2], q.z);
-    gmax[0] = fmaxf(gmax[0], q.x); gmax[1] = fmaxf(gmax[1], q.y); gmax[2] = fmaxf(gmax[2], q.z);
-    ld[j] = __builtin_inff(); li[j] = 0x7fffffff; tau_d[j] = __builtin_inff(); tau_i[j] = 0x7fffffff;
-  }
-  unsigned swept = 0;
-  auto sweep_tile = [&](int t) {
+  float (*L_d)[64] = s_ld[wv];
+  int (*L_i)[64] = s_li[wv];
+  const float4 qv = spts[min(q_base + (lane & (Q - 1)), n - 1)];  // lane j (< Q) holds query j
+  float tau_dv = __builtin_inff();  // lane j: current k-th distance of query j
+  int tau_iv = 0x7fffffff;          //         and its index
+  unsigned swept = 0, inserted = 0;
+
+  // ---- seed: bitonic-sort the own tile for every query ----
+  const int t0 = q_base >> 6;
+  {
+    const float4 p = load_candidate(spts, (t0 << 6) + lane, n);
+    const int po = (((t0 << 6) + lane) < n) ? __float_as_int(p.w) : 0x7fffffff;
+#pragma unroll 1
+    for (int j = 0; j < Q; j++) {
+      float d = sqdist_nofma(p, read_lane(qv.x, j), read_lane(qv.y, j), read_lane(qv.z, j));
+      int i = po;
+      wave_bitonic_sort(d, i, lane);
+      L_d[j][lane] = d;
+      L_i[j][lane] = i;
+      tau_dv = write_lane(read_lane(d, k - 1), j, tau_dv);
+      tau_iv = write_lane(read_lane(i, k - 1), j, tau_iv);
+    }
     swept++;
-    const float4 p = load_candidate(spts, (t << 6) + lane, n);
-    const int po = __float_as_int(p.w);
+  }
+
+  // ---- all other tiles: pseudo-chunk -64 = the two Morton neighbours, then 64 tile boxes per step ----
+  for (int chunk = (dbg & 2) ? 0 : -64; chunk < ((dbg & 1) ? 0 : ntiles); chunk += 64) {
+    int t;
+    bool cand;
+    float lb[Q];
+    if (chunk < 0) {
+      t = (lane == 0) ? t0 + 1 : t0 - 1;
+      cand = (lane < 2) && t >= 0 && t < ntiles;
 #pragma unroll
-    for (int j = 0; j < KNN_Q; j++) {
-      const float d = sqdist_nofma(p, qx[j], qy[j], qz[j]);
-      unsigned long long mask = __ballot(d <= tau_d[j]);
-      while (mask) {
-        const int src = __ffsll((long long)mask) - 1;
-        mask &= mask - 1;
-        const float cd = read_lane(d, src);
-        const int ci = read_lane(po, src);
-        if (!(cd < tau_d[j] || (cd == tau_d[j] && ci < tau_i[j]))) continue;
-        const int pos = __popcll(__ballot(ld[j] < cd || (ld[j] == cd && li[j] < ci)));
-        const float sd = wave_shr1(ld[j], ld[j]);
-        const int si = wave_shr1(li[j], li[j]);
-        if (lane > pos) { ld[j] = sd; li[j] = si; }
-        else if (lane == pos) { ld[j] = cd; li[j] = ci; }
-        tau_d[j] = read_lane(ld[j], k - 1);
-        tau_i[j] = read_lane(li[j], k - 1);
+      for (int j = 0; j < Q; j++) lb[j] = 0.f;
+    } else {
+      t = chunk + lane;
+      const float4 bl = bbox[2 * min(t, ntiles - 1)], bh = bbox[2 * min(t, ntiles - 1) + 1];
+      bool any = false;
+#pragma unroll
+      for (int j = 0; j < Q; j++) {  // per-QUERY point-to-box lower bounds
+        const float x = read_lane(qv.x, j), y = read_lane(qv.y, j), z = read_lane(qv.z, j);
+        const float gx = fmaxf(0.f, fmaxf(bl.x - x, x - bh.x));
+        const float gy = fmaxf(0.f, fmaxf(bl.y - y, y - bh.y));
+        const float gz = fmaxf(0.f, fmaxf(bl.z - z, z - bh.z));
+        lb[j] = (gx * gx + gy * gy + gz * gz) * 0.99999f;  // never above the fp32-rounded exact distance
+        any |= (lb[j] <= read_lane(tau_dv, j));
+      }
+      cand = (t < ntiles) && (t < t0 - 1 || t > t0 + 1) && any;
+    }
+    unsigned long long tmask = __ballot(cand);
+    while (tmask) {  // wave-uniform: one surviving tile at a time
+      const int src = __ffsll((long long)tmask) - 1;
+      tmask &= tmask - 1;
+      const int tt = read_lane(t, src);
+      unsigned need = 0;
+#pragma unroll
+      for (int j = 0; j < Q; j++) need |= (read_lane(lb[j], src) <= read_lane(tau_dv, j)) ? (1u << j) : 0u;  // thresholds may have tightened
+      if (!need || (dbg & 4)) continue;
+      swept++;
+      const float4 p = load_candidate(spts, (tt << 6) + lane, n);
+      const int po = __float_as_int(p.w);
+      while (need) {  // the single insertion site
+        const int j = __ffs(need) - 1;
+        need &= need - 1;
+        const float d = sqdist_nofma(p, read_lane(qv.x, j), read_lane(qv.y, j), read_lane(qv.z, j));
+        float td = read_lane(tau_dv, j);
+        int ti = read_lane(tau_iv, j);
+        unsigned long long mask = __ballot(d <= td);
+        if (!mask) continue;
+        float ld = L_d[j][lane];
+        int li = L_i[j][lane];
+        while (mask) {
+          const int c = __ffsll((long long)mask) - 1;
+          mask &= mask - 1;
+          const float cd = read_lane(d, c);
+          const int ci = read_lane(po, c);
+          if (!(cd < td || (cd == td && ci < ti))) continue;
+          inserted++;
+          const int pos = __popcll(__ballot(ld < cd || (ld == cd && li < ci)));
+          const float sd = wave_shr1(ld, ld);
+          const int si = wave_shr1(li, li);
+          ld = (lane > pos) ? sd : ((lane == pos) ? cd : ld);
+          li = (lane > pos) ? si : ((lane == pos) ? ci : li);
+          td = read_lane(ld, k - 1);
+          ti = read_lane(li, k - 1);
+        }
+        L_d[j][lane] = ld;
+        L_i[j][lane] = li;
+        tau_dv = write_lane(td, j, tau_dv);
+        tau_iv = write_lane(ti, j, tau_iv);
       }
     }
-  };
-  // seed: own tile and its two neighbours in Morton order
-  const int t0 = q_base >> 6;
-  sweep_tile(t0);
-  if (t0 + 1 < ntiles) sweep_tile(t0 + 1);
-  if (t0 > 0) sweep_tile(t0 - 1);
-  // cull: 64 tile boxes per step
-  for (int chunk = 0; chunk < ntiles; chunk += 64) {
-    const int t = chunk + lane;
-    const float lb = box_gap_sq(bbox[2 * min(t, ntiles - 1)], bbox[2 * min(t, ntiles - 1) + 1], gmin, gmax);
-    const bool fresh = (t < ntiles) && (t < t0 - 1 || t > t0 + 1);
-    float tmax = tau_d[0];
+  }
+#pragma unroll 1
+  for (int j = 0; j < Q; j++)
+    if (q_base + j < n && lane < k) out_idx[(size_t)read_lane(__float_as_int(qv.w), j) * k + lane] = L_i[j][lane];
+  if (stats && lane == 0) { atomicAdd(stats, swept); atomicAdd(stats + 1, inserted); atomicMax(stats + 2, swept); }
+}
+
+// boxes of 64 consecutive level-1 boxes (one wave per super tile)
+__global__ __launch_bounds__(256) void super_bbox_kernel(const float4* __restrict__ bbox1, int ntiles, float4* __restrict__ bbox2) {
+  const int lane = threadIdx.x & 63;
+  const int s = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (s * 64 >= ntiles) return;
+  const int t = min(s * 64 + lane, ntiles - 1);
+  const float4 l = bbox1[2 * t], h = bbox1[2 * t + 1];
+  float lo[3] = {l.x, l.y, l.z}, hi[3] = {h.x, h.y, h.z};
 #pragma unroll
-    for (int j = 1; j < KNN_Q; j++) tmax = fmaxf(tmax, tau_d[j]);
-    unsigned long long mask = __ballot(fresh && lb <= tmax);
+  for (int a = 0; a < 3; a++)
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      lo[a] = fminf(lo[a], __shfl_xor(lo[a], off));
+      hi[a] = fmaxf(hi[a], __shfl_xor(hi[a], off));
+    }
+  if (lane == 0) {
+    bbox2[2 * s] = make_float4(lo[0], lo[1], lo[2], 0.f);
+    bbox2[2 * s + 1] = make_float4(hi[0], hi[1], hi[2], 0.f);
+  }
+}
+
+__device__ __forceinline__ float point_box_sq(const float4& bl, const float4& bh, float x, float y, float z) {
+  const float gx = fmaxf(0.f, fmaxf(bl.x - x, x - bh.x));
+  const float gy = fmaxf(0.f, fmaxf(bl.y - y, y - bh.y));
+  const float gz = fmaxf(0.f, fmaxf(bl.z - z, z - bh.z));
+  return (gx * gx + gy * gy + gz * gz) * 0.99999f;  // never above the fp32-rounded exact distance
+}
+
+// ONE query per wave (the regime is latency-chain bound, not throughput bound: measured time was
+// proportional to the queries per wave). Seed = bitonic sort of the own tile; two-level box culling
+// (super tiles of 64 tiles, then tiles); the next surviving tile is prefetched while the current one
+// is merged, so the L2 round trips overlap with the insertion chain.
+__global__ __launch_bounds__(256) void knn_tiled1_kernel(const float4* __restrict__ spts, const float4* __restrict__ bbox1, const float4* __restrict__ bbox2, int n, int k,
+                                                         int* __restrict__ out_idx) {
+  const int lane = threadIdx.x & 63;
+  const int q = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (q >= n) return;
+  const int ntiles = (n + 63) >> 6, nsuper = (ntiles + 63) >> 6;
+  const float4 qv = spts[q];
+  const float qx = read_lane(qv.x, 0), qy = read_lane(qv.y, 0), qz = read_lane(qv.z, 0);
+  const int t0 = q >> 6;
+  // issue the three seed loads together
+  const float4 p0 = load_candidate(spts, (t0 << 6) + lane, n);
+  const float4 pa = load_candidate(spts, (min(t0 + 1, ntiles - 1) << 6) + lane, n);
+  const float4 pb = load_candidate(spts, (max(t0 - 1, 0) << 6) + lane, n);
+  float ld = sqdist_nofma(p0, qx, qy, qz);
+  int li = (((t0 << 6) + lane) < n) ? __float_as_int(p0.w) : 0x7fffffff;
+  wave_bitonic_sort(ld, li, lane);
+  float td = read_lane(ld, k - 1);
+  int ti = read_lane(li, k - 1);
+
+  auto merge_tile = [&](const float4& p) __attribute__((always_inline)) {
+    const float d = sqdist_nofma(p, qx, qy, qz);
+    const int po = __float_as_int(p.w);
+    unsigned long long mask = __ballot(d <= td);
     while (mask) {
-      const int src = __ffsll((long long)mask) - 1;
+      const int c = __ffsll((long long)mask) - 1;
       mask &= mask - 1;
-      tmax = tau_d[0];
-#pragma unroll
-      for (int j = 1; j < KNN_Q; j++) tmax = fmaxf(tmax, tau_d[j]);
-      if (read_lane(lb, src) > tmax) continue;  // the threshold tightened since the ballot
-      sweep_tile(chunk + src);
+      const float cd = read_lane(d, c);
+      const int ci = read_lane(po, c);
+      if (!(cd < td || (cd == td && ci < ti))) continue;
+      const int pos = __popcll(__ballot(ld < cd || (ld == cd && li < ci)));
+      const float sd = wave_shr1(ld, ld);
+      const int si = wave_shr1(li, li);
+      ld = (lane > pos) ? sd : ((lane == pos) ? cd : ld);
+      li = (lane > pos) ? si : ((lane == pos) ? ci : li);
+      td = read_lane(ld, k - 1);
+      ti = read_lane(li, k - 1);
+    }
+  };
+  if (t0 + 1 < ntiles) merge_tile(pa);
+  if (t0 > 0) merge_tile(pb);
+
+  for (int sc = 0; sc < nsuper; sc += 64) {
+    const int s = sc + lane;
+    const float lb2 = (s < nsuper) ? point_box_sq(bbox2[2 * s], bbox2[2 * s + 1], qx, qy, qz) : __builtin_inff();
+    unsigned long long smask = __ballot(lb2 <= td);
+    while (smask) {
+      const int ssrc = __ffsll((long long)smask) - 1;
+      smask &= smask - 1;
+      if (read_lane(lb2, ssrc) > td) continue;
+      const int t = ((sc + ssrc) << 6) + lane;
+      const float lb = (t < ntiles) ? point_box_sq(bbox1[2 * t], bbox1[2 * t + 1], qx, qy, qz) : __builtin_inff();
+      unsigned long long tmask = __ballot(lb <= td && (t < t0 - 1 || t > t0 + 1));
+      if (!tmask) continue;
+      // software pipeline: the load of the next surviving tile is in flight while this one is merged
+      int cur = __ffsll((long long)tmask) - 1;
+      tmask &= tmask - 1;
+      float4 pcur = load_candidate(spts, ((((sc + ssrc) << 6) + cur) << 6) + lane, n);
+      while (true) {
+        int nxt = -1;
+        float4 pnxt = pcur;
+        if (tmask) {
+          nxt = __ffsll((long long)tmask) - 1;
+          tmask &= tmask - 1;
+          pnxt = load_candidate(spts, ((((sc + ssrc) << 6) + nxt) << 6) + lane, n);
+        }
+        if (read_lane(lb, cur) <= td) merge_tile(pcur);
+        if (nxt < 0) break;
+        cur = nxt;
+        pcur = pnxt;
+      }
     }
   }
-#pragma unroll
-  for (int j = 0; j < KNN_Q; j++)
-    if (q_base + j < n && lane < k) out_idx[(size_t)qo[j] * k + lane] = li[j];
-  if (stats && lane == 0) atomicAdd(stats, swept);
+  if (lane < k) out_idx[(size_t)__float_as_int(qv.w) * k + lane] = li;
 }
 
 __device__ __forceinline__ void store_cov(float4* __restrict__ cov, int i, const Sym3<double>& C) {
