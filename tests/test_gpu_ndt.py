@@ -1,0 +1,110 @@
+"""GPU parity of the NDT path (NDTCudaCore replacement) against the oracle's fp64 restatement of
+ndt_cuda.cu / ndt_compute_derivatives.cu, through the C ABI.
+
+Tolerances: voxel sets / counts exact; voxel means fp32 rounding; MIN_EIG-regularised covariances
+1e-5 of the entry scale (fp32 storage); err/H/b at fixed poses rel 2e-5 (fp32-stored voxel data);
+final pose within 1e-4 relative, and the reference's own gicp_test tolerance vs data/relative.txt."""
+import numpy as np
+import pytest
+
+from tests import util
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def O():
+    from oracle import oracle
+    return oracle
+
+
+@pytest.fixture(scope="module")
+def pair():
+    return util.bundled_pair()
+
+
+def _ndt():
+    from fast_gicp_amd import capi
+    return capi.NDTCore(0)
+
+
+def test_ndt_voxelmaps_match_oracle(O, pair):
+    tgt, src = pair
+    c = _ndt()
+    c.set_target_cloud(tgt); c.set_source_cloud(src)
+    c.create_voxelmaps()
+    for which, cloud in (("target", tgt), ("source", src)):
+        coords, num, means, covs = c.get_voxelmap(which)
+        oc, on, om, ocv = O.voxelmap_ndt(cloud, 1.0)
+        got, ref = util.voxel_dict(coords, num, means, covs), util.voxel_dict(oc, on, om, ocv)
+        assert set(got) == set(ref)
+        assert int(num.sum()) == len(cloud)
+        for k in ref:
+            assert got[k][0] == ref[k][0]
+            np.testing.assert_allclose(got[k][1], ref[k][1], rtol=0, atol=4e-6 * max(1.0, np.abs(ref[k][1]).max()))
+            np.testing.assert_allclose(got[k][2], ref[k][2], rtol=0, atol=1e-5 * max(1e-3, np.abs(ref[k][2]).max()))
+    c.close()
+
+
+@pytest.mark.parametrize("mode,search", [(1, 1), (0, 1), (1, 2), (1, 0)])
+def test_ndt_linearize_matches_oracle(O, pair, mode, search):
+    tgt, src = pair
+    c = _ndt()
+    c.set_distance_mode(mode); c.set_neighbor_search_method(search)
+    c.set_target_cloud(tgt); c.set_source_cloud(src)
+    c.create_voxelmaps()
+    g = O.NDT(mode=mode, search=search)
+    g.set_target(tgt); g.set_source(src); g.prepare()
+    for T in (np.eye(4), util.relative_pose(), util.random_pose(np.random.default_rng(5))):
+        e, H, b = c.linearize(T)
+        eo, Ho, bo = g.linearize(T)
+        assert c.get_num_correspondences() == g.num_correspondences()
+        assert abs(e - eo) <= 2e-5 * abs(eo)
+        assert util.rel_err(H, Ho) <= 2e-5 and util.rel_err(b, bo) <= 2e-5
+        T2 = util.random_pose(np.random.default_rng(9), 0.2, 0.05) @ T
+        assert abs(c.compute_error(T2, derivatives=False) - g.compute_error(T2)) <= 2e-5 * abs(g.compute_error(T2))
+    c.close()
+
+
+@pytest.fixture(scope="module")
+def gicp_test_pair():
+    """gicp_test.cpp:55-65 input: exact VoxelGrid leaf 0.2, no origin filter (7,908 / 8,061 points)."""
+    return util.bundled_pair(origin_filter=False, leaf=0.2, exact_voxelgrid=True)
+
+
+@pytest.mark.parametrize("mode", [1, 0])
+def test_ndt_align_matches_oracle(O, gicp_test_pair, mode):
+    tgt, src = gicp_test_pair
+    c = _ndt()
+    c.set_distance_mode(mode)
+    c.set_target_cloud(tgt); c.set_source_cloud(src)
+    r = c.align()
+    g = O.NDT(mode=mode)
+    g.set_target(tgt); g.set_source(src)
+    ro = g.align()
+    assert r["converged"] and ro["converged"]
+    assert util.rel_err(r["T"], ro["T"]) < 1e-4
+    te, re_ = util.pose_error(util.relative_pose(), r["T"])
+    # gicp_test.cpp:148-149 tolerance applies to what it tests: NDTCuda defaults = D2D; P2D only gets a sanity band
+    assert (te < 0.05 if mode == 1 else te < 0.1) and re_ < np.radians(1.0)
+    f, fo = c.fitness_score(r["T"].astype(np.float32).astype(np.float64)), g.fitness()
+    assert abs(f - fo) <= 1e-4 * fo
+    c.close()
+
+
+def test_ndt_swap_reuses_voxelmaps(O, gicp_test_pair):
+    """NDTCudaCore::swap_source_and_target swaps the maps (ndt_cuda.cu:90-93); registering the reverse
+    direction after a swap must equal a fresh reverse registration."""
+    tgt, src = gicp_test_pair
+    c = _ndt()
+    c.set_target_cloud(tgt); c.set_source_cloud(src)
+    r1 = c.align()
+    c.swap_source_and_target()
+    r2 = c.align()
+    d = _ndt()
+    d.set_target_cloud(src); d.set_source_cloud(tgt)
+    r3 = d.align()
+    assert util.rel_err(r2["T"], r3["T"]) < 1e-9
+    te, re_ = util.pose_error(util.relative_pose(), np.linalg.inv(r2["T"]))
+    assert te < 0.05 and re_ < np.radians(1.0)
+    c.close(); d.close()
