@@ -1,0 +1,96 @@
+// gicp_align on the MI355X engine -- the reference's benchmark driver (src/align.cpp:51-215) for the
+// methods this engine provides (the ndt_cuda and vgicp_cuda rows), same call sequence, same
+// "single / 100times / 100times_reuse / fitness_score" output line (README.md:118-134).
+#include <algorithm>
+#include <chrono>
+#include <iostream>
+
+#include "fast_gicp_amd/pcd_io.hpp"
+#include "fast_gicp_amd/registration.hpp"
+#include "fast_gicp_amd/voxelgrid.hpp"
+
+using namespace fast_gicp;
+using Cloud = PointCloud<PointXYZ>;
+
+template <typename Registration>
+void test(Registration& reg, const Cloud::ConstPtr& target, const Cloud::ConstPtr& source) {  // align.cpp:51-104
+  Cloud aligned;
+  auto t1 = std::chrono::high_resolution_clock::now();
+  reg.clearTarget();
+  reg.clearSource();
+  reg.setInputTarget(target);
+  reg.setInputSource(source);
+  reg.align(aligned);
+  auto t2 = std::chrono::high_resolution_clock::now();
+  const double fitness_score = reg.getFitnessScore();
+  std::cout << "single:" << std::chrono::duration_cast<std::chrono::nanoseconds>(t2 - t1).count() / 1e6 << "[msec] " << std::flush;
+
+  t1 = std::chrono::high_resolution_clock::now();
+  for (int i = 0; i < 100; i++) {
+    reg.clearTarget();
+    reg.clearSource();
+    reg.setInputTarget(target);
+    reg.setInputSource(source);
+    reg.align(aligned);
+  }
+  t2 = std::chrono::high_resolution_clock::now();
+  std::cout << "100times:" << std::chrono::duration_cast<std::chrono::nanoseconds>(t2 - t1).count() / 1e6 << "[msec] " << std::flush;
+
+  t1 = std::chrono::high_resolution_clock::now();
+  Cloud::ConstPtr target_ = target, source_ = source;
+  for (int i = 0; i < 100; i++) {
+    reg.swapSourceAndTarget();
+    reg.clearSource();
+    reg.setInputTarget(target_);
+    reg.setInputSource(source_);
+    reg.align(aligned);
+    target_.swap(source_);
+  }
+  t2 = std::chrono::high_resolution_clock::now();
+  std::cout << "100times_reuse:" << std::chrono::duration_cast<std::chrono::nanoseconds>(t2 - t1).count() / 1e6 << "[msec] fitness_score:" << fitness_score << std::endl;
+}
+
+int main(int argc, char** argv) {
+  if (argc < 3) {
+    std::cout << "usage: gicp_align target_pcd source_pcd" << std::endl;
+    return 0;
+  }
+  auto target_cloud = std::make_shared<Cloud>(), source_cloud = std::make_shared<Cloud>();
+  if (loadPCDFile(argv[1], *target_cloud)) { std::cerr << "failed to open " << argv[1] << std::endl; return 1; }
+  if (loadPCDFile(argv[2], *source_cloud)) { std::cerr << "failed to open " << argv[2] << std::endl; return 1; }
+  // remove invalid points around origin (align.cpp:127-133)
+  auto near_origin = [](const PointXYZ& p) { return (double)(p.x * p.x + p.y * p.y + p.z * p.z) < 1e-3; };
+  source_cloud->points.erase(std::remove_if(source_cloud->points.begin(), source_cloud->points.end(), near_origin), source_cloud->points.end());
+  target_cloud->points.erase(std::remove_if(target_cloud->points.begin(), target_cloud->points.end(), near_origin), target_cloud->points.end());
+  // downsampling (align.cpp:136-147)
+  auto ft = std::make_shared<Cloud>(), fs = std::make_shared<Cloud>();
+  approximate_voxel_grid(*target_cloud, 0.1f, *ft);
+  approximate_voxel_grid(*source_cloud, 0.1f, *fs);
+  std::cout << "target:" << ft->size() << "[pts] source:" << fs->size() << "[pts]" << std::endl;
+
+  std::cout << "--- ndt_hip (P2D) ---" << std::endl;
+  NDTCuda<PointXYZ, PointXYZ> ndt;
+  ndt.setResolution(1.0);
+  ndt.setDistanceMode(NDTDistanceMode::P2D);
+  test(ndt, ft, fs);
+  std::cout << "--- ndt_hip (D2D) ---" << std::endl;
+  ndt.setDistanceMode(NDTDistanceMode::D2D);
+  test(ndt, ft, fs);
+
+  std::cout << "--- vgicp_hip (parallel_kdtree) ---" << std::endl;
+  FastVGICPCuda<PointXYZ, PointXYZ> vgicp;
+  vgicp.setResolution(1.0);
+  test(vgicp, ft, fs);
+  std::cout << "--- vgicp_hip (gpu_bruteforce) ---" << std::endl;
+  vgicp.setNearestNeighborSearchMethod(NearestNeighborMethod::GPU_BRUTEFORCE);
+  test(vgicp, ft, fs);
+  std::cout << "--- vgicp_hip (gpu_rbf_kernel) ---" << std::endl;
+  vgicp.setNearestNeighborSearchMethod(NearestNeighborMethod::GPU_RBF_KERNEL);
+  vgicp.setKernelWidth(0.5);
+  test(vgicp, ft, fs);
+  std::cout << "--- vgicp_hip (gpu_bruteforce, DIRECT27) ---" << std::endl;
+  vgicp.setNearestNeighborSearchMethod(NearestNeighborMethod::GPU_BRUTEFORCE);
+  vgicp.setNeighborSearchMethod(NeighborSearchMethod::DIRECT27);
+  test(vgicp, ft, fs);
+  return 0;
+}

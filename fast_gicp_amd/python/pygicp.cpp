@@ -1,0 +1,207 @@
+// pygicp -- Python bindings with the surface of the reference's src/python/main.cpp:152-223, on the
+// host-side C++ mirror (include/fast_gicp_amd/registration.hpp) -> C ABI -> HIP engine.
+// Eigen is not available here, so Nx3 / 4x4 arguments are numpy arrays (same shapes and dtypes the
+// reference's pybind11/eigen.h conversions accept and return).
+#include <pybind11/numpy.h>
+#include <pybind11/pybind11.h>
+#include <pybind11/stl.h>
+
+#include <iostream>
+
+#include "fast_gicp_amd/registration.hpp"
+#include "fast_gicp_amd/voxelgrid.hpp"
+
+namespace py = pybind11;
+using namespace fast_gicp;
+
+using Cloud = PointCloud<PointXYZ>;
+using Lsq = LsqRegistration<PointXYZ, PointXYZ>;
+using VGICPCuda = FastVGICPCuda<PointXYZ, PointXYZ>;
+using NDT = NDTCuda<PointXYZ, PointXYZ>;
+using Points = py::array_t<double, py::array::c_style | py::array::forcecast>;
+using Mat4 = py::array_t<double, py::array::c_style | py::array::forcecast>;
+
+static NeighborSearchMethod search_method(const std::string& s) {  // main.cpp:21-34
+  if (s == "DIRECT1") return NeighborSearchMethod::DIRECT1;
+  if (s == "DIRECT7") return NeighborSearchMethod::DIRECT7;
+  if (s == "DIRECT27") return NeighborSearchMethod::DIRECT27;
+  if (s == "DIRECT_RADIUS") return NeighborSearchMethod::DIRECT_RADIUS;
+  std::cerr << "error: unknown neighbor search method " << s << std::endl;
+  return NeighborSearchMethod::DIRECT1;
+}
+static RegularizationMethod regularization_method(const std::string& s) {
+  if (s == "NONE") return RegularizationMethod::NONE;
+  if (s == "MIN_EIG") return RegularizationMethod::MIN_EIG;
+  if (s == "NORMALIZED_MIN_EIG") return RegularizationMethod::NORMALIZED_MIN_EIG;
+  if (s == "PLANE") return RegularizationMethod::PLANE;
+  if (s == "FROBENIUS") return RegularizationMethod::FROBENIUS;
+  throw std::invalid_argument("unknown regularization method " + s);
+}
+static NearestNeighborMethod nn_method(const std::string& s) {
+  if (s == "CPU_PARALLEL_KDTREE") return NearestNeighborMethod::CPU_PARALLEL_KDTREE;
+  if (s == "GPU_BRUTEFORCE") return NearestNeighborMethod::GPU_BRUTEFORCE;
+  if (s == "GPU_RBF_KERNEL") return NearestNeighborMethod::GPU_RBF_KERNEL;
+  throw std::invalid_argument("unknown nearest neighbor method " + s);
+}
+
+static Cloud::Ptr numpy2cloud(const Points& pts) {  // eigen2pcl, main.cpp:36-44
+  if (pts.ndim() != 2 || pts.shape(1) != 3) throw std::invalid_argument("points must be an (N, 3) array");
+  auto cloud = std::make_shared<Cloud>();
+  cloud->resize(pts.shape(0));
+  auto r = pts.unchecked<2>();
+  for (py::ssize_t i = 0; i < pts.shape(0); i++) {
+    cloud->points[i].x = (float)r(i, 0); cloud->points[i].y = (float)r(i, 1); cloud->points[i].z = (float)r(i, 2);
+  }
+  return cloud;
+}
+static py::array_t<double> cloud2numpy(const Cloud& c) {
+  py::array_t<double> out({(py::ssize_t)c.size(), (py::ssize_t)3});
+  auto w = out.mutable_unchecked<2>();
+  for (size_t i = 0; i < c.size(); i++) { w(i, 0) = c.points[i].x; w(i, 1) = c.points[i].y; w(i, 2) = c.points[i].z; }
+  return out;
+}
+static Matrix4f numpy2mat4(const Mat4& m) {
+  if (m.ndim() != 2 || m.shape(0) != 4 || m.shape(1) != 4) throw std::invalid_argument("pose must be a (4, 4) array");
+  Matrix4f M;
+  auto r = m.unchecked<2>();
+  for (int i = 0; i < 4; i++) for (int j = 0; j < 4; j++) M(i, j) = (float)r(i, j);
+  return M;
+}
+static py::array_t<float> mat4_to_numpy(const Matrix4f& M) {
+  py::array_t<float> out({4, 4});
+  auto w = out.mutable_unchecked<2>();
+  for (int i = 0; i < 4; i++) for (int j = 0; j < 4; j++) w(i, j) = M(i, j);
+  return out;
+}
+static py::array_t<double> identity4() {
+  py::array_t<double> I({4, 4});
+  auto w = I.mutable_unchecked<2>();
+  for (int i = 0; i < 4; i++) for (int j = 0; j < 4; j++) w(i, j) = i == j ? 1.0 : 0.0;
+  return I;
+}
+
+static py::array_t<double> downsample(const Points& points, double resolution) {  // main.cpp:46-62
+  Cloud filtered;
+  approximate_voxel_grid(*numpy2cloud(points), (float)resolution, filtered);
+  return cloud2numpy(filtered);
+}
+
+// align_points, main.cpp:64-150. "VGICP" (the CPU FastVGICP in the reference) runs on the same GPU
+// engine in its fp64 CPU-parity arithmetic with k_correspondences honoured; "GICP" (kd-tree
+// correspondences, no voxels) is outside this engine's hot path.
+static py::array_t<double> align_points(const Points& target, const Points& source, const std::string& method, double downsample_resolution, int k_correspondences,
+                                        double /*max_correspondence_distance*/, double voxel_resolution, int /*num_threads*/, const std::string& neighbor_search_method,
+                                        double neighbor_search_radius, const Mat4& initial_guess) {
+  Cloud::Ptr target_cloud = numpy2cloud(target), source_cloud = numpy2cloud(source);
+  if (downsample_resolution > 0.0) {
+    auto ft = std::make_shared<Cloud>(), fs = std::make_shared<Cloud>();
+    approximate_voxel_grid(*target_cloud, (float)downsample_resolution, *ft);
+    approximate_voxel_grid(*source_cloud, (float)downsample_resolution, *fs);
+    target_cloud = ft; source_cloud = fs;
+  }
+  std::shared_ptr<Lsq> reg;
+  if (method == "VGICP_CUDA" || method == "VGICP") {
+    auto vgicp = std::make_shared<VGICPCuda>();
+    vgicp->setCorrespondenceRandomness(k_correspondences);  // a no-op, as in the reference (k = 20)
+    vgicp->setNeighborSearchMethod(search_method(neighbor_search_method), neighbor_search_radius);
+    vgicp->setResolution(voxel_resolution);
+    reg = vgicp;
+  } else if (method == "NDT_CUDA") {
+    auto ndt = std::make_shared<NDT>();
+    ndt->setResolution(voxel_resolution);
+    ndt->setNeighborSearchMethod(search_method(neighbor_search_method), neighbor_search_radius);
+    reg = ndt;
+  } else {
+    std::cerr << "error: registration method " << method << " is not provided by the MI355X engine (VGICP_CUDA, VGICP, NDT_CUDA)" << std::endl;
+    return identity4();
+  }
+  reg->setInputTarget(target_cloud);
+  reg->setInputSource(source_cloud);
+  Cloud aligned;
+  reg->align(aligned, numpy2mat4(initial_guess));
+  py::array_t<double> out({4, 4});
+  auto w = out.mutable_unchecked<2>();
+  const Matrix4f& M = reg->getFinalTransformation();
+  for (int i = 0; i < 4; i++) for (int j = 0; j < 4; j++) w(i, j) = M(i, j);
+  return out;
+}
+
+PYBIND11_MODULE(pygicp, m) {
+  m.doc() = "pygicp on the MI355X HIP engine (surface of koide3/fast_gicp src/python/main.cpp)";
+  m.def("downsample", &downsample, "downsample points", py::arg("points"), py::arg("downsample_resolution"));
+  m.def("align_points", &align_points, "align two point sets", py::arg("target"), py::arg("source"), py::arg("method") = "VGICP_CUDA", py::arg("downsample_resolution") = -1.0,
+        py::arg("k_correspondences") = 15, py::arg("max_correspondence_distance") = std::numeric_limits<double>::max(), py::arg("voxel_resolution") = 1.0,
+        py::arg("num_threads") = 0, py::arg("neighbor_search_method") = "DIRECT1", py::arg("neighbor_search_radius") = 1.5, py::arg("initial_guess") = identity4());
+
+  py::class_<Lsq, std::shared_ptr<Lsq>>(m, "LsqRegistration")
+      .def("set_input_target", [](Lsq& reg, const Points& p) { reg.setInputTarget(numpy2cloud(p)); })
+      .def("set_input_source", [](Lsq& reg, const Points& p) { reg.setInputSource(numpy2cloud(p)); })
+      .def("swap_source_and_target", &Lsq::swapSourceAndTarget)
+      .def("clear_source", &Lsq::clearSource)
+      .def("clear_target", &Lsq::clearTarget)
+      .def("get_final_hessian", [](Lsq& reg) {
+        py::array_t<double> H({6, 6});
+        std::memcpy(H.mutable_data(), reg.getFinalHessian().data(), 36 * sizeof(double));
+        return H;
+      })
+      .def("get_final_transformation", [](Lsq& reg) { return mat4_to_numpy(reg.getFinalTransformation()); })
+      .def("get_fitness_score", [](Lsq& reg, double max_range) { return reg.getFitnessScore(max_range); }, py::arg("max_range") = std::numeric_limits<double>::max())
+      .def("has_converged", &Lsq::hasConverged)
+      .def("set_maximum_iterations", &Lsq::setMaximumIterations)
+      .def("set_transformation_epsilon", &Lsq::setTransformationEpsilon)
+      .def("set_rotation_epsilon", &Lsq::setRotationEpsilon)
+      .def("set_initial_lambda_factor", &Lsq::setInitialLambdaFactor)
+      .def("set_debug_print", &Lsq::setDebugPrint)
+      .def("set_use_device_lm", &Lsq::setUseDeviceLM)
+      .def("evaluate_cost", [](Lsq& reg, const Mat4& pose) {
+        Matrix6d H; Vector6d b;
+        const double e = reg.evaluateCost(numpy2mat4(pose), &H, &b);
+        py::array_t<double> Hn({6, 6}), bn(6);
+        std::memcpy(Hn.mutable_data(), H.data(), 36 * sizeof(double));
+        std::memcpy(bn.mutable_data(), b.data(), 6 * sizeof(double));
+        return py::make_tuple(e, Hn, bn);
+      })
+      .def("align", [](Lsq& reg, const Mat4& initial_guess) {
+        Cloud aligned;
+        reg.align(aligned, numpy2mat4(initial_guess));
+        return mat4_to_numpy(reg.getFinalTransformation());
+      }, py::arg("initial_guess") = identity4());
+
+  py::class_<VGICPCuda, Lsq, std::shared_ptr<VGICPCuda>>(m, "FastVGICPCuda")
+      .def(py::init([](int device) { return std::make_shared<VGICPCuda>(device); }), py::arg("device") = 0)
+      .def("set_resolution", &VGICPCuda::setResolution)
+      .def("set_neighbor_search_method", [](VGICPCuda& v, const std::string& method, double radius) { v.setNeighborSearchMethod(search_method(method), radius); },
+           py::arg("method") = "DIRECT1", py::arg("radius") = 1.5)
+      .def("set_correspondence_randomness", &VGICPCuda::setCorrespondenceRandomness)
+      .def("set_kernel_width", &VGICPCuda::setKernelWidth, py::arg("kernel_width"), py::arg("max_dist") = -1.0)
+      .def("set_regularization_method", [](VGICPCuda& v, const std::string& s) { v.setRegularizationMethod(regularization_method(s)); })
+      .def("set_nearest_neighbor_search_method", [](VGICPCuda& v, const std::string& s) { v.setNearestNeighborSearchMethod(nn_method(s)); });
+
+  // The reference's CPU class name, served by the GPU engine in its fp64 CPU-parity arithmetic.
+  m.attr("FastVGICP") = m.attr("FastVGICPCuda");
+
+  py::class_<NDT, Lsq, std::shared_ptr<NDT>>(m, "NDTCuda")
+      .def(py::init([](int device) { return std::make_shared<NDT>(device); }), py::arg("device") = 0)
+      .def("set_neighbor_search_method", [](NDT& n, const std::string& method, double radius) { n.setNeighborSearchMethod(search_method(method), radius); },
+           py::arg("method") = "DIRECT1", py::arg("radius") = 1.5)
+      .def("set_resolution", &NDT::setResolution)
+      .def("set_distance_mode", [](NDT& n, const std::string& s) {
+        if (s == "P2D") n.setDistanceMode(NDTDistanceMode::P2D);
+        else if (s == "D2D") n.setDistanceMode(NDTDistanceMode::D2D);
+        else throw std::invalid_argument("unknown NDT distance mode " + s);
+      });
+
+  // testing hook: the host kd-tree behind NearestNeighborMethod::CPU_PARALLEL_KDTREE
+  m.def("_kdtree_knn", [](const Points& points, int k) {
+    auto cloud = numpy2cloud(points);
+    const std::vector<float> xyz = detail::pack_xyz(*cloud);
+    const int n = (int)cloud->size();
+    host::KdTree tree(xyz.data(), n);
+    py::array_t<int> out({(py::ssize_t)n, (py::ssize_t)k});
+    int* o = out.mutable_data();
+#pragma omp parallel for schedule(guided, 8)
+    for (int i = 0; i < n; i++) tree.knn(&xyz[3 * (size_t)i], k, o + (size_t)i * k);
+    return out;
+  });
+  m.attr("__version__") = "dev";
+}

@@ -1,0 +1,103 @@
+// Exact k-NN on the host for NearestNeighborMethod::CPU_PARALLEL_KDTREE -- stands in for
+// pcl::search::KdTree / FLANN in FastVGICPCuda::find_neighbors_parallel_kdtree
+// (impl/fast_vgicp_cuda_impl.hpp:152-167). Node-less median kd-tree: the points' permutation IS the
+// tree (the median of every index range is its node), only the split axis per node is stored.
+// Distances are fp32 ((dx*dx + dy*dy) + dz*dz) with ties to the lower index, the same total order the
+// device k-NN uses, so both neighbour methods yield identical index sets.
+#pragma once
+#include <algorithm>
+#include <cfloat>
+#include <numeric>
+#include <vector>
+
+namespace fast_gicp {
+namespace host {
+
+class KdTree {
+public:
+  KdTree(const float* xyz, int n) : xyz_(xyz), n_(n), perm_(n), axis_(n, 0) {
+    std::iota(perm_.begin(), perm_.end(), 0);
+    if (n > 0) build(0, n);
+  }
+
+  /// k nearest neighbours of q (ascending (distance, index)); out has k entries (-1 padded if n < k)
+  void knn(const float* q, int k, int* out) const {
+    std::vector<float> d(k);
+    std::vector<int> id(k);
+    Best best{k, 0, d.data(), id.data()};
+    if (n_ > 0) search(0, n_, q, best);
+    for (int j = 0; j < k; j++) out[j] = j < best.count ? best.i[j] : -1;
+  }
+
+private:
+  struct Best {
+    int k, count;
+    float* d;
+    int* i;
+    bool full() const { return count == k; }
+    float worst() const { return d[count - 1]; }
+    void offer(float dist, int idx) {  // sorted insertion, k is small (20)
+      if (count == k && !(dist < d[k - 1] || (dist == d[k - 1] && idx < i[k - 1]))) return;
+      int pos = count < k ? count : k - 1;
+      while (pos > 0 && (dist < d[pos - 1] || (dist == d[pos - 1] && idx < i[pos - 1]))) {
+        d[pos] = d[pos - 1];
+        i[pos] = i[pos - 1];
+        pos--;
+      }
+      d[pos] = dist;
+      i[pos] = idx;
+      if (count < k) count++;
+    }
+  };
+  static float sqdist(const float* a, const float* b) {
+    const float dx = a[0] - b[0], dy = a[1] - b[1], dz = a[2] - b[2];
+    return (dx * dx + dy * dy) + dz * dz;
+  }
+
+  void build(int lo, int hi) {
+    if (hi - lo <= kLeaf) return;
+    float mn[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, mx[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
+    for (int i = lo; i < hi; i++)
+      for (int a = 0; a < 3; a++) {
+        const float v = xyz_[3 * (size_t)perm_[i] + a];
+        mn[a] = std::min(mn[a], v);
+        mx[a] = std::max(mx[a], v);
+      }
+    int ax = 0;
+    if (mx[1] - mn[1] > mx[ax] - mn[ax]) ax = 1;
+    if (mx[2] - mn[2] > mx[ax] - mn[ax]) ax = 2;
+    const int mid = lo + (hi - lo) / 2;
+    std::nth_element(perm_.begin() + lo, perm_.begin() + mid, perm_.begin() + hi, [&](int a, int b) { return xyz_[3 * (size_t)a + ax] < xyz_[3 * (size_t)b + ax]; });
+    axis_[mid] = (unsigned char)ax;
+    build(lo, mid);
+    build(mid + 1, hi);
+  }
+
+  void search(int lo, int hi, const float* q, Best& best) const {
+    if (hi - lo <= kLeaf) {
+      for (int i = lo; i < hi; i++) best.offer(sqdist(&xyz_[3 * (size_t)perm_[i]], q), perm_[i]);
+      return;
+    }
+    const int mid = lo + (hi - lo) / 2;
+    const int ax = axis_[mid];
+    const int pm = perm_[mid];
+    best.offer(sqdist(&xyz_[3 * (size_t)pm], q), pm);
+    const float diff = q[ax] - xyz_[3 * (size_t)pm + ax];
+    if (diff < 0) {
+      search(lo, mid, q, best);
+      if (!best.full() || diff * diff <= best.worst()) search(mid + 1, hi, q, best);
+    } else {
+      search(mid + 1, hi, q, best);
+      if (!best.full() || diff * diff <= best.worst()) search(lo, mid, q, best);
+    }
+  }
+
+  static constexpr int kLeaf = 8;
+  const float* xyz_;
+  int n_;
+  std::vector<int> perm_;
+  std::vector<unsigned char> axis_;
+};
+
+}  // namespace host
+}  // namespace fast_gicp

@@ -1,0 +1,527 @@
+// Host-side mirror of the reference's registration classes on top of the C ABI (fast_vgicp_hip.h).
+//
+//   fast_gicp::LsqRegistration   <- include/fast_gicp/gicp/lsq_registration.hpp + impl/lsq_registration_impl.hpp
+//   fast_gicp::FastVGICPCuda     <- include/fast_gicp/gicp/fast_vgicp_cuda.hpp  + impl/fast_vgicp_cuda_impl.hpp
+//   fast_gicp::NDTCuda           <- include/fast_gicp/ndt/ndt_cuda.hpp          + impl/ndt_cuda_impl.hpp
+//
+// Same class / method / enum names, argument meaning and defaults as the reference, so code written
+// against it (gicp_align, gicp_test, pygicp) reads the same. PCL and Eigen are not available in this
+// build environment (the reference does not vendor them), so the PCL base class is replaced by the
+// few members of pcl::Registration the reference's callers use, on a minimal PointCloud / Matrix4
+// type. INTEGRATION.md shows the 1:1 PCL-templated shim for a tree that has PCL.
+//
+// Two ways to run the optimiser:
+//   * setUseDeviceLM(true)  (default): fvh_*_align -- the whole LM loop on the GPU, one D2H.
+//   * setUseDeviceLM(false): the reference's host loop (step_lm below) calling the virtuals
+//     linearize() / compute_error() -> fvh_*_update_correspondences / fvh_*_compute_error,
+//     i.e. exactly the reference's call sequence. Both give the same result to fp64 rounding.
+#pragma once
+#include <array>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <limits>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../fast_vgicp_hip.h"
+#include "kdtree.hpp"
+
+namespace fast_gicp {
+
+// gicp_settings.hpp:7-11, ndt_settings.hpp:6, fast_vgicp_cuda.hpp:18 (same ordinals)
+enum class RegularizationMethod { NONE, MIN_EIG, NORMALIZED_MIN_EIG, PLANE, FROBENIUS };
+enum class NeighborSearchMethod { DIRECT27, DIRECT7, DIRECT1, DIRECT_RADIUS };
+enum class VoxelAccumulationMode { ADDITIVE, ADDITIVE_WEIGHTED, MULTIPLICATIVE };
+enum class NDTDistanceMode { P2D, D2D };
+enum class NearestNeighborMethod { CPU_PARALLEL_KDTREE, GPU_BRUTEFORCE, GPU_RBF_KERNEL };
+enum class LSQ_OPTIMIZER_TYPE { GaussNewton, LevenbergMarquardt };
+
+struct PointXYZ {
+  float x = 0, y = 0, z = 0;
+};
+
+template <typename PointT>
+struct PointCloud {
+  using Ptr = std::shared_ptr<PointCloud<PointT>>;
+  using ConstPtr = std::shared_ptr<const PointCloud<PointT>>;
+  std::vector<PointT> points;
+  size_t size() const { return points.size(); }
+  bool empty() const { return points.empty(); }
+  const PointT& at(size_t i) const { return points.at(i); }
+  void resize(size_t n) { points.resize(n); }
+};
+
+struct Matrix4f {  // row-major 4x4 (Eigen::Matrix4f stand-in)
+  float m[16];
+  static Matrix4f Identity() { Matrix4f I; std::memset(I.m, 0, sizeof(I.m)); I.m[0] = I.m[5] = I.m[10] = I.m[15] = 1.f; return I; }
+  float& operator()(int r, int c) { return m[r * 4 + c]; }
+  float operator()(int r, int c) const { return m[r * 4 + c]; }
+};
+
+using Matrix6d = std::array<double, 36>;  // row-major (symmetric)
+using Vector6d = std::array<double, 6>;
+
+struct Isometry3d {  // row-major R | t, double
+  double R[9];
+  double t[3];
+  static Isometry3d Identity() { Isometry3d T; std::memset(&T, 0, sizeof(T)); T.R[0] = T.R[4] = T.R[8] = 1.0; return T; }
+  static Isometry3d from(const Matrix4f& M) {
+    Isometry3d T;
+    for (int i = 0; i < 3; i++) { for (int j = 0; j < 3; j++) T.R[i * 3 + j] = M(i, j); T.t[i] = M(i, 3); }
+    return T;
+  }
+  Matrix4f cast_float() const {
+    Matrix4f M = Matrix4f::Identity();
+    for (int i = 0; i < 3; i++) { for (int j = 0; j < 3; j++) M(i, j) = (float)R[i * 3 + j]; M(i, 3) = (float)t[i]; }
+    return M;
+  }
+  void to_colmajor16(double* T16) const {
+    for (int i = 0; i < 3; i++) { for (int j = 0; j < 3; j++) T16[j * 4 + i] = R[i * 3 + j]; T16[12 + i] = t[i]; T16[i * 4 + 3] = 0.0; }
+    T16[15] = 1.0;
+  }
+  static Isometry3d from_colmajor16(const double* T16) {
+    Isometry3d T;
+    for (int i = 0; i < 3; i++) { for (int j = 0; j < 3; j++) T.R[i * 3 + j] = T16[j * 4 + i]; T.t[i] = T16[12 + i]; }
+    return T;
+  }
+  Isometry3d operator*(const Isometry3d& B) const {
+    Isometry3d C;
+    for (int i = 0; i < 3; i++) {
+      for (int j = 0; j < 3; j++) C.R[i * 3 + j] = R[i * 3] * B.R[j] + R[i * 3 + 1] * B.R[3 + j] + R[i * 3 + 2] * B.R[6 + j];
+      C.t[i] = R[i * 3] * B.t[0] + R[i * 3 + 1] * B.t[1] + R[i * 3 + 2] * B.t[2] + t[i];
+    }
+    return C;
+  }
+};
+
+// so3.hpp:58-104 (rotation first)
+inline Isometry3d se3_exp(const Vector6d& a) {
+  const double ox = a[0], oy = a[1], oz = a[2];
+  const double theta_sq = ox * ox + oy * oy + oz * oz;
+  double imag, real;
+  if (theta_sq < 1e-10) {
+    const double tq = theta_sq * theta_sq;
+    imag = 0.5 - theta_sq / 48.0 + tq / 3840.0;
+    real = 1.0 - theta_sq / 8.0 + tq / 384.0;
+  } else {
+    const double th = std::sqrt(theta_sq);
+    imag = std::sin(0.5 * th) / th;
+    real = std::cos(0.5 * th);
+  }
+  const double qw = real, qx = imag * ox, qy = imag * oy, qz = imag * oz;
+  Isometry3d T;
+  T.R[0] = 1 - 2 * (qy * qy + qz * qz); T.R[1] = 2 * (qx * qy - qz * qw);     T.R[2] = 2 * (qx * qz + qy * qw);
+  T.R[3] = 2 * (qx * qy + qz * qw);     T.R[4] = 1 - 2 * (qx * qx + qz * qz); T.R[5] = 2 * (qy * qz - qx * qw);
+  T.R[6] = 2 * (qx * qz - qy * qw);     T.R[7] = 2 * (qy * qz + qx * qw);     T.R[8] = 1 - 2 * (qx * qx + qy * qy);
+  const double theta = std::sqrt(theta_sq);
+  double V[9];
+  if (theta < 1e-10) {
+    std::memcpy(V, T.R, sizeof(V));
+  } else {
+    const double A = (1.0 - std::cos(theta)) / theta_sq, B = (theta - std::sin(theta)) / (theta_sq * theta);
+    const double O[9] = {0, -oz, oy, oz, 0, -ox, -oy, ox, 0};
+    for (int i = 0; i < 3; i++)
+      for (int j = 0; j < 3; j++) {
+        double o2 = O[i * 3] * O[j] + O[i * 3 + 1] * O[3 + j] + O[i * 3 + 2] * O[6 + j];
+        V[i * 3 + j] = (i == j ? 1.0 : 0.0) + A * O[i * 3 + j] + B * o2;
+      }
+  }
+  for (int i = 0; i < 3; i++) T.t[i] = V[i * 3] * a[3] + V[i * 3 + 1] * a[4] + V[i * 3 + 2] * a[5];
+  return T;
+}
+
+namespace detail {
+inline void ldlt6_solve(const Matrix6d& A, const Vector6d& rhs, Vector6d& x) {
+  double L[36] = {0}, D[6], y[6];
+  for (int j = 0; j < 6; j++) {
+    double d = A[j * 6 + j];
+    for (int k = 0; k < j; k++) d -= L[j * 6 + k] * L[j * 6 + k] * D[k];
+    D[j] = d;
+    L[j * 6 + j] = 1.0;
+    for (int i = j + 1; i < 6; i++) {
+      double s = A[i * 6 + j];
+      for (int k = 0; k < j; k++) s -= L[i * 6 + k] * L[j * 6 + k] * D[k];
+      L[i * 6 + j] = s / d;
+    }
+  }
+  for (int i = 0; i < 6; i++) { double s = rhs[i]; for (int k = 0; k < i; k++) s -= L[i * 6 + k] * y[k]; y[i] = s; }
+  for (int i = 0; i < 6; i++) y[i] /= D[i];
+  for (int i = 5; i >= 0; i--) { double s = y[i]; for (int k = i + 1; k < 6; k++) s -= L[k * 6 + i] * x[k]; x[i] = s; }
+}
+template <typename PointT>
+inline std::vector<float> pack_xyz(const PointCloud<PointT>& c) {
+  std::vector<float> xyz(c.size() * 3);
+  for (size_t i = 0; i < c.size(); i++) { xyz[3 * i] = c.points[i].x; xyz[3 * i + 1] = c.points[i].y; xyz[3 * i + 2] = c.points[i].z; }
+  return xyz;
+}
+}  // namespace detail
+
+/// LsqRegistration (lsq_registration.hpp:14-83) minus the PCL base: the members of pcl::Registration its callers use.
+template <typename PointSource, typename PointTarget>
+class LsqRegistration {
+public:
+  using PointCloudSource = PointCloud<PointSource>;
+  using PointCloudSourceConstPtr = typename PointCloudSource::ConstPtr;
+  using PointCloudTarget = PointCloud<PointTarget>;
+  using PointCloudTargetConstPtr = typename PointCloudTarget::ConstPtr;
+
+  LsqRegistration() { final_hessian_.fill(0.0); for (int i = 0; i < 6; i++) final_hessian_[i * 7] = 1.0; }  // lsq_registration_impl.hpp:9-22
+  virtual ~LsqRegistration() {}
+
+  void setRotationEpsilon(double eps) { rotation_epsilon_ = eps; }
+  void setTransformationEpsilon(double eps) { transformation_epsilon_ = eps; }
+  void setMaximumIterations(int n) { max_iterations_ = n; }
+  void setInitialLambdaFactor(double f) { lm_init_lambda_factor_ = f; }
+  void setDebugPrint(bool p) { lm_debug_print_ = p; }
+  void setUseDeviceLM(bool on) { use_device_lm_ = on; }
+  const Matrix6d& getFinalHessian() const { return final_hessian_; }
+  const Matrix4f& getFinalTransformation() const { return final_transformation_; }
+  bool hasConverged() const { return converged_; }
+  int getNumIterations() const { return nr_iterations_; }
+
+  double evaluateCost(const Matrix4f& relative_pose, Matrix6d* H = nullptr, Vector6d* b = nullptr) { return this->linearize(Isometry3d::from(relative_pose), H, b); }
+
+  virtual void swapSourceAndTarget() {}
+  virtual void clearSource() {}
+  virtual void clearTarget() {}
+  virtual void setInputSource(const PointCloudSourceConstPtr& cloud) { input_ = cloud; }
+  virtual void setInputTarget(const PointCloudTargetConstPtr& cloud) { target_ = cloud; }
+  PointCloudSourceConstPtr getInputSource() const { return input_; }
+  PointCloudTargetConstPtr getInputTarget() const { return target_; }
+
+  /// pcl::Registration::align
+  void align(PointCloudSource& output, const Matrix4f& guess = Matrix4f::Identity()) {
+    if (!input_ || !target_) throw std::invalid_argument("align: source / target cloud not set");
+    computeTransformation(output, guess);
+  }
+  /// pcl::Registration::getFitnessScore(max_range): mean squared exact-NN distance of T*source to the target
+  virtual double getFitnessScore(double max_range = std::numeric_limits<double>::max()) = 0;
+
+protected:
+  virtual void computeTransformation(PointCloudSource& output, const Matrix4f& guess) {  // lsq_registration_impl.hpp:53-79
+    Isometry3d x0 = Isometry3d::from(guess);
+    lm_lambda_ = -1.0;
+    converged_ = false;
+    if (use_device_lm_ && device_align(x0)) {
+      // whole loop ran on the GPU
+    } else {
+      for (int i = 0; i < max_iterations_ && !converged_; i++) {
+        nr_iterations_ = i;
+        Isometry3d delta;
+        if (!step_lm(x0, delta)) {
+          std::fprintf(stderr, "lm not converged!!\n");
+          break;
+        }
+        converged_ = is_converged(delta);
+      }
+    }
+    final_transformation_ = x0.cast_float();
+    output.points.resize(input_->size());  // pcl::transformPointCloud(*input_, output, final_transformation_)
+    for (size_t i = 0; i < input_->size(); i++) {
+      const auto& p = input_->points[i];
+      const float* m = final_transformation_.m;
+      output.points[i] = p;
+      output.points[i].x = m[0] * p.x + m[1] * p.y + m[2] * p.z + m[3];
+      output.points[i].y = m[4] * p.x + m[5] * p.y + m[6] * p.z + m[7];
+      output.points[i].z = m[8] * p.x + m[9] * p.y + m[10] * p.z + m[11];
+    }
+  }
+
+  bool is_converged(const Isometry3d& delta) const {  // :82-91
+    double rmax = 0, tmax = 0;
+    for (int i = 0; i < 9; i++) rmax = std::max(rmax, std::fabs(delta.R[i] - (i % 4 == 0 ? 1.0 : 0.0)) / rotation_epsilon_);
+    for (int i = 0; i < 3; i++) tmax = std::max(tmax, std::fabs(delta.t[i]) / transformation_epsilon_);
+    return std::max(rmax, tmax) < 1;
+  }
+
+  virtual double linearize(const Isometry3d& trans, Matrix6d* H = nullptr, Vector6d* b = nullptr) = 0;
+  virtual double compute_error(const Isometry3d& trans) = 0;
+  /// subclasses with a device-resident LM return true after updating x0 / converged_ / nr_iterations_ / final_hessian_
+  virtual bool device_align(Isometry3d& x0) { (void)x0; return false; }
+
+  bool step_lm(Isometry3d& x0, Isometry3d& delta) {  // :123-168
+    Matrix6d H;
+    Vector6d b;
+    const double y0 = linearize(x0, &H, &b);
+    if (lm_lambda_ < 0.0) {
+      double mx = 0;
+      for (int i = 0; i < 6; i++) mx = std::max(mx, std::fabs(H[i * 7]));
+      lm_lambda_ = lm_init_lambda_factor_ * mx;
+    }
+    double nu = 2.0;
+    for (int i = 0; i < lm_max_iterations_; i++) {
+      Matrix6d A = H;
+      Vector6d nb, d;
+      for (int j = 0; j < 6; j++) { A[j * 7] += lm_lambda_; nb[j] = -b[j]; }
+      detail::ldlt6_solve(A, nb, d);
+      delta = se3_exp(d);
+      const Isometry3d xi = delta * x0;
+      const double yi = compute_error(xi);
+      double denom = 0;
+      for (int j = 0; j < 6; j++) denom += d[j] * (lm_lambda_ * d[j] - b[j]);
+      const double rho = (y0 - yi) / denom;
+      if (lm_debug_print_) {
+        double dn = 0;
+        for (int j = 0; j < 6; j++) dn += d[j] * d[j];
+        if (i == 0) std::printf("--- LM optimization ---\n%5s %15s %15s %15s %15s %15s %5s\n", "i", "y0", "yi", "rho", "lambda", "|delta|", "dec");
+        std::printf("%5d %15g %15g %15g %15g %15g %5c\n", i, y0, yi, rho, lm_lambda_, std::sqrt(dn), rho > 0.0 ? 'x' : ' ');
+      }
+      if (rho < 0) {
+        if (is_converged(delta)) return true;
+        lm_lambda_ = nu * lm_lambda_;
+        nu = 2 * nu;
+        continue;
+      }
+      x0 = xi;
+      lm_lambda_ = lm_lambda_ * std::max(1.0 / 3.0, 1 - std::pow(2 * rho - 1, 3));
+      final_hessian_ = H;
+      return true;
+    }
+    return false;
+  }
+
+protected:
+  PointCloudSourceConstPtr input_;
+  PointCloudTargetConstPtr target_;
+  Matrix4f final_transformation_ = Matrix4f::Identity();
+  int nr_iterations_ = 0;
+  int max_iterations_ = 64;               // :11
+  double transformation_epsilon_ = 5e-4;  // :13
+  bool converged_ = false;
+  double rotation_epsilon_ = 2e-3;        // :12
+  LSQ_OPTIMIZER_TYPE lsq_optimizer_type_ = LSQ_OPTIMIZER_TYPE::LevenbergMarquardt;
+  int lm_max_iterations_ = 10;            // :17
+  double lm_init_lambda_factor_ = 1e-9;   // :18
+  double lm_lambda_ = -1.0;
+  bool lm_debug_print_ = false;
+  bool use_device_lm_ = true;
+  Matrix6d final_hessian_;
+};
+
+namespace detail {
+inline void check(int rc, const char* what, const char* err) {
+  if (rc != 0) throw std::runtime_error(std::string(what) + " failed (status " + std::to_string(rc) + "): " + (err ? err : ""));
+}
+}  // namespace detail
+
+/// FastVGICPCuda (fast_vgicp_cuda.hpp:24-85, impl/fast_vgicp_cuda_impl.hpp)
+template <typename PointSource, typename PointTarget>
+class FastVGICPCuda : public LsqRegistration<PointSource, PointTarget> {
+  using Base = LsqRegistration<PointSource, PointTarget>;
+  using Base::input_;
+  using Base::target_;
+
+public:
+  using PointCloudSource = typename Base::PointCloudSource;
+  using PointCloudSourceConstPtr = typename Base::PointCloudSourceConstPtr;
+  using PointCloudTargetConstPtr = typename Base::PointCloudTargetConstPtr;
+
+  explicit FastVGICPCuda(int device = 0) {  // fast_vgicp_cuda_impl.hpp:21-32
+    detail::check(fvh_vgicp_create(device, &core_), "fvh_vgicp_create", "cannot create the HIP engine (no GPU? there is no CPU fallback)");
+    call(fvh_vgicp_set_resolution(core_, voxel_resolution_), "set_resolution");
+    call(fvh_vgicp_set_kernel_params(core_, 0.5, 3.0), "set_kernel_params");
+  }
+  ~FastVGICPCuda() override { if (core_) fvh_vgicp_destroy(core_); }
+  FastVGICPCuda(const FastVGICPCuda&) = delete;
+  FastVGICPCuda& operator=(const FastVGICPCuda&) = delete;
+
+  void setCorrespondenceRandomness(int) {}  // empty in the reference too (:38): k stays 20
+  void setResolution(double resolution) { call(fvh_vgicp_set_resolution(core_, resolution), "set_resolution"); }
+  void setKernelWidth(double kernel_width, double max_dist = -1.0) {  // :45-51
+    if (max_dist <= 0.0) max_dist = kernel_width * 5.0;
+    call(fvh_vgicp_set_kernel_params(core_, kernel_width, max_dist), "set_kernel_params");
+  }
+  void setRegularizationMethod(RegularizationMethod method) { regularization_method_ = method; }
+  void setNeighborSearchMethod(NeighborSearchMethod method, double radius = -1.0) { call(fvh_vgicp_set_neighbor_search_method(core_, (int)method, radius), "set_neighbor_search_method"); }
+  void setNearestNeighborSearchMethod(NearestNeighborMethod method) { neighbor_search_method_ = method; }
+  void setComputePrecision(int fvh_precision) { call(fvh_vgicp_set_precision(core_, fvh_precision), "set_precision"); }
+
+  void swapSourceAndTarget() override {  // :69-72
+    call(fvh_vgicp_swap_source_and_target(core_), "swap_source_and_target");
+    input_.swap(target_);
+  }
+  void clearSource() override { input_.reset(); }
+  void clearTarget() override { target_.reset(); }
+
+  void setInputSource(const PointCloudSourceConstPtr& cloud) override {  // :85-111
+    if (cloud == input_) return;
+    input_ = cloud;
+    const std::vector<float> xyz = detail::pack_xyz(*cloud);
+    call(fvh_vgicp_set_source_cloud(core_, xyz.data(), (int)cloud->size()), "set_source_cloud");
+    switch (neighbor_search_method_) {
+      case NearestNeighborMethod::CPU_PARALLEL_KDTREE: {
+        const std::vector<int> nb = find_neighbors_parallel_kdtree(k_correspondences_, xyz);
+        call(fvh_vgicp_set_source_neighbors(core_, k_correspondences_, nb.data()), "set_source_neighbors");
+        call(fvh_vgicp_calculate_source_covariances(core_, (int)regularization_method_), "calculate_source_covariances");
+      } break;
+      case NearestNeighborMethod::GPU_BRUTEFORCE:
+        call(fvh_vgicp_find_source_neighbors(core_, k_correspondences_), "find_source_neighbors");
+        call(fvh_vgicp_calculate_source_covariances(core_, (int)regularization_method_), "calculate_source_covariances");
+        break;
+      case NearestNeighborMethod::GPU_RBF_KERNEL:
+        call(fvh_vgicp_calculate_source_covariances_rbf(core_, (int)regularization_method_), "calculate_source_covariances_rbf");
+        break;
+    }
+  }
+  void setInputTarget(const PointCloudTargetConstPtr& cloud) override {  // :114-141
+    if (cloud == target_) return;
+    target_ = cloud;
+    const std::vector<float> xyz = detail::pack_xyz(*cloud);
+    call(fvh_vgicp_set_target_cloud(core_, xyz.data(), (int)cloud->size()), "set_target_cloud");
+    switch (neighbor_search_method_) {
+      case NearestNeighborMethod::CPU_PARALLEL_KDTREE: {
+        const std::vector<int> nb = find_neighbors_parallel_kdtree(k_correspondences_, xyz);
+        call(fvh_vgicp_set_target_neighbors(core_, k_correspondences_, nb.data()), "set_target_neighbors");
+        call(fvh_vgicp_calculate_target_covariances(core_, (int)regularization_method_), "calculate_target_covariances");
+      } break;
+      case NearestNeighborMethod::GPU_BRUTEFORCE:
+        call(fvh_vgicp_find_target_neighbors(core_, k_correspondences_), "find_target_neighbors");
+        call(fvh_vgicp_calculate_target_covariances(core_, (int)regularization_method_), "calculate_target_covariances");
+        break;
+      case NearestNeighborMethod::GPU_RBF_KERNEL:
+        call(fvh_vgicp_calculate_target_covariances_rbf(core_, (int)regularization_method_), "calculate_target_covariances_rbf");
+        break;
+    }
+    call(fvh_vgicp_create_target_voxelmap(core_), "create_target_voxelmap");
+  }
+
+  double getFitnessScore(double max_range = std::numeric_limits<double>::max()) override {
+    double T16[16], score = 0;
+    Isometry3d::from(this->final_transformation_).to_colmajor16(T16);
+    call(fvh_vgicp_fitness_score(core_, T16, max_range, &score), "fitness_score");
+    return score;
+  }
+  fvh_vgicp* core() { return core_; }
+
+protected:
+  double linearize(const Isometry3d& trans, Matrix6d* H, Vector6d* b) override {  // :170-173
+    double T16[16], err = 0, Hc[36];
+    trans.to_colmajor16(T16);
+    call(fvh_vgicp_update_correspondences(core_, T16), "update_correspondences");
+    call(fvh_vgicp_compute_error(core_, T16, (H && b) ? Hc : nullptr, (H && b) ? b->data() : nullptr, &err), "compute_error");
+    if (H && b) for (int i = 0; i < 6; i++) for (int j = 0; j < 6; j++) (*H)[i * 6 + j] = Hc[j * 6 + i];
+    return err;
+  }
+  double compute_error(const Isometry3d& trans) override {  // :176-178
+    double T16[16], err = 0;
+    trans.to_colmajor16(T16);
+    call(fvh_vgicp_compute_error(core_, T16, nullptr, nullptr, &err), "compute_error");
+    return err;
+  }
+  bool device_align(Isometry3d& x0) override {
+    double g16[16];
+    x0.to_colmajor16(g16);
+    fvh_lm_params p{this->max_iterations_, this->rotation_epsilon_, this->transformation_epsilon_, this->lm_max_iterations_, this->lm_init_lambda_factor_};
+    fvh_lm_result r;
+    call(fvh_vgicp_align(core_, g16, &p, &r), "align");
+    x0 = Isometry3d::from_colmajor16(r.T);
+    this->converged_ = r.converged != 0;
+    this->nr_iterations_ = r.nr_iterations;
+    for (int i = 0; i < 6; i++) for (int j = 0; j < 6; j++) this->final_hessian_[i * 6 + j] = r.H[j * 6 + i];
+    if (r.lm_failed) std::fprintf(stderr, "lm not converged!!\n");
+    return true;
+  }
+  /// find_neighbors_parallel_kdtree (:152-167): host kd-tree + OpenMP
+  std::vector<int> find_neighbors_parallel_kdtree(int k, const std::vector<float>& xyz) const {
+    const int n = (int)(xyz.size() / 3);
+    host::KdTree tree(xyz.data(), n);
+    std::vector<int> neighbors((size_t)n * k);
+#pragma omp parallel for schedule(guided, 8)
+    for (int i = 0; i < n; i++) tree.knn(&xyz[3 * (size_t)i], k, &neighbors[(size_t)i * k]);
+    return neighbors;
+  }
+  void call(int rc, const char* what) const { detail::check(rc, what, fvh_vgicp_last_error(core_)); }
+
+private:
+  int k_correspondences_ = 20;                                                                   // :24
+  double voxel_resolution_ = 1.0;                                                                // :25
+  RegularizationMethod regularization_method_ = RegularizationMethod::PLANE;                     // :26
+  NearestNeighborMethod neighbor_search_method_ = NearestNeighborMethod::CPU_PARALLEL_KDTREE;    // :27
+  fvh_vgicp* core_ = nullptr;
+};
+
+/// NDTCuda (ndt_cuda.hpp:23-69, impl/ndt_cuda_impl.hpp)
+template <typename PointSource, typename PointTarget>
+class NDTCuda : public LsqRegistration<PointSource, PointTarget> {
+  using Base = LsqRegistration<PointSource, PointTarget>;
+  using Base::input_;
+  using Base::target_;
+
+public:
+  using PointCloudSourceConstPtr = typename Base::PointCloudSourceConstPtr;
+  using PointCloudTargetConstPtr = typename Base::PointCloudTargetConstPtr;
+
+  explicit NDTCuda(int device = 0) { detail::check(fvh_ndt_create(device, &core_), "fvh_ndt_create", "cannot create the HIP engine (no GPU? there is no CPU fallback)"); }
+  ~NDTCuda() override { if (core_) fvh_ndt_destroy(core_); }
+  NDTCuda(const NDTCuda&) = delete;
+  NDTCuda& operator=(const NDTCuda&) = delete;
+
+  void setDistanceMode(NDTDistanceMode mode) { call(fvh_ndt_set_distance_mode(core_, (int)mode), "set_distance_mode"); }
+  void setResolution(double resolution) { call(fvh_ndt_set_resolution(core_, resolution), "set_resolution"); }
+  void setNeighborSearchMethod(NeighborSearchMethod method, double radius = -1.0) { call(fvh_ndt_set_neighbor_search_method(core_, (int)method, radius), "set_neighbor_search_method"); }
+
+  void swapSourceAndTarget() override { call(fvh_ndt_swap_source_and_target(core_), "swap_source_and_target"); input_.swap(target_); }
+  void clearSource() override { input_.reset(); }
+  void clearTarget() override { target_.reset(); }
+  void setInputSource(const PointCloudSourceConstPtr& cloud) override {  // ndt_cuda_impl.hpp:52-60
+    if (cloud == input_) return;
+    input_ = cloud;
+    const std::vector<float> xyz = detail::pack_xyz(*cloud);
+    call(fvh_ndt_set_source_cloud(core_, xyz.data(), (int)cloud->size()), "set_source_cloud");
+  }
+  void setInputTarget(const PointCloudTargetConstPtr& cloud) override {  // :63-73
+    if (cloud == target_) return;
+    target_ = cloud;
+    const std::vector<float> xyz = detail::pack_xyz(*cloud);
+    call(fvh_ndt_set_target_cloud(core_, xyz.data(), (int)cloud->size()), "set_target_cloud");
+  }
+  double getFitnessScore(double max_range = std::numeric_limits<double>::max()) override {
+    double T16[16], score = 0;
+    Isometry3d::from(this->final_transformation_).to_colmajor16(T16);
+    call(fvh_ndt_fitness_score(core_, T16, max_range, &score), "fitness_score");
+    return score;
+  }
+  fvh_ndt* core() { return core_; }
+
+protected:
+  void computeTransformation(typename Base::PointCloudSource& output, const Matrix4f& guess) override {  // :76-79
+    call(fvh_ndt_create_voxelmaps(core_), "create_voxelmaps");
+    Base::computeTransformation(output, guess);
+  }
+  double linearize(const Isometry3d& trans, Matrix6d* H, Vector6d* b) override {
+    double T16[16], err = 0, Hc[36];
+    trans.to_colmajor16(T16);
+    call(fvh_ndt_update_correspondences(core_, T16), "update_correspondences");
+    call(fvh_ndt_compute_error(core_, T16, (H && b) ? Hc : nullptr, (H && b) ? b->data() : nullptr, &err), "compute_error");
+    if (H && b) for (int i = 0; i < 6; i++) for (int j = 0; j < 6; j++) (*H)[i * 6 + j] = Hc[j * 6 + i];
+    return err;
+  }
+  double compute_error(const Isometry3d& trans) override {
+    double T16[16], err = 0;
+    trans.to_colmajor16(T16);
+    call(fvh_ndt_compute_error(core_, T16, nullptr, nullptr, &err), "compute_error");
+    return err;
+  }
+  bool device_align(Isometry3d& x0) override {
+    double g16[16];
+    x0.to_colmajor16(g16);
+    fvh_lm_params p{this->max_iterations_, this->rotation_epsilon_, this->transformation_epsilon_, this->lm_max_iterations_, this->lm_init_lambda_factor_};
+    fvh_lm_result r;
+    call(fvh_ndt_align(core_, g16, &p, &r), "align");
+    x0 = Isometry3d::from_colmajor16(r.T);
+    this->converged_ = r.converged != 0;
+    this->nr_iterations_ = r.nr_iterations;
+    for (int i = 0; i < 6; i++) for (int j = 0; j < 6; j++) this->final_hessian_[i * 6 + j] = r.H[j * 6 + i];
+    if (r.lm_failed) std::fprintf(stderr, "lm not converged!!\n");
+    return true;
+  }
+  void call(int rc, const char* what) const { detail::check(rc, what, fvh_ndt_last_error(core_)); }
+
+private:
+  fvh_ndt* core_ = nullptr;
+};
+
+}  // namespace fast_gicp

@@ -1,0 +1,96 @@
+"""GPU tests through the host C++ classes / pygicp: the reference's own test (src/test/gicp_test.cpp:147-201) re-stated --
+forward / backward / swap-and-set-source / swap-and-set-target for VGICP_CUDA and NDT_CUDA with default parameters,
+tolerances 0.05 m / 1 deg / hasConverged -- plus equality of the host-LM and device-LM paths and of the neighbour methods."""
+import numpy as np
+import pytest
+
+from tests import util
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def pygicp():
+    import pygicp
+    return pygicp
+
+
+@pytest.fixture(scope="module")
+def data():
+    t, s = util.bundled_pair(origin_filter=False, leaf=0.2, exact_voxelgrid=True)  # gicp_test.cpp:55-65
+    return t.astype(np.float64), s.astype(np.float64), util.relative_pose()
+
+
+def _check(gt, T, converged, label):
+    te, re_ = util.pose_error(gt, np.asarray(T, np.float64))
+    assert te < 0.05, (label, te)
+    assert re_ < np.radians(1.0), (label, re_)
+    assert converged, label
+
+
+@pytest.mark.parametrize("method", ["VGICP_CUDA", "NDT_CUDA"])
+def test_gicp_test_alignment(pygicp, data, method):
+    target, source, gt = data
+    create = (lambda: pygicp.FastVGICPCuda()) if method == "VGICP_CUDA" else (lambda: pygicp.NDTCuda())
+    reg = create()
+    reg.set_input_target(target); reg.set_input_source(source)
+    _check(gt, reg.align(), reg.has_converged(), "FORWARD TEST")
+    reg.set_input_target(source); reg.set_input_source(target)
+    _check(gt, np.linalg.inv(reg.align().astype(np.float64)), reg.has_converged(), "BACKWARD TEST")
+    reg = create()
+    reg.set_input_source(target); reg.swap_source_and_target(); reg.set_input_source(source)
+    _check(gt, reg.align(), reg.has_converged(), "SWAP AND SET SOURCE TEST")
+    reg = create()
+    reg.set_input_target(source); reg.swap_source_and_target(); reg.set_input_target(target)
+    _check(gt, reg.align(), reg.has_converged(), "SWAP AND SET TARGET TEST")
+
+
+@pytest.mark.parametrize("cls", ["FastVGICPCuda", "NDTCuda"])
+def test_host_lm_equals_device_lm(pygicp, data, cls):
+    """The reference's host loop (linearize / compute_error virtuals -> update_correspondences + compute_error) and the
+    device-resident loop must agree to fp64 rounding."""
+    target, source, _ = data
+    out = []
+    for dev in (True, False):
+        reg = getattr(pygicp, cls)()
+        reg.set_use_device_lm(dev)
+        reg.set_input_target(target); reg.set_input_source(source)
+        T = reg.align()
+        out.append((T, reg.get_final_hessian(), reg.has_converged(), reg.get_fitness_score()))
+    assert np.array_equal(out[0][0], out[1][0])  # float32 final_transformation_
+    assert util.rel_err(out[0][1], out[1][1]) < 1e-10
+    assert out[0][2] and out[1][2]
+    assert out[0][3] == out[1][3]
+
+
+def test_neighbor_methods_agree(pygicp, data):
+    """CPU_PARALLEL_KDTREE (host kd-tree, reference default) and GPU_BRUTEFORCE give the same neighbours -> same result."""
+    target, source, _ = data
+    res = []
+    for m in ("CPU_PARALLEL_KDTREE", "GPU_BRUTEFORCE"):
+        reg = pygicp.FastVGICPCuda()
+        reg.set_nearest_neighbor_search_method(m)
+        reg.set_input_target(target); reg.set_input_source(source)
+        res.append(reg.align())
+    assert np.array_equal(res[0], res[1])
+
+
+def test_align_points_and_evaluate_cost(pygicp, data):
+    target, source, gt = data
+    for method in ("VGICP_CUDA", "NDT_CUDA"):
+        T = pygicp.align_points(target, source, method=method, neighbor_search_method="DIRECT7")
+        te, re_ = util.pose_error(gt, T)
+        assert te < 0.06 and re_ < np.radians(1.0)
+    reg = pygicp.FastVGICPCuda()
+    reg.set_input_target(target); reg.set_input_source(source)
+    e, H, b = reg.evaluate_cost(np.eye(4))
+    assert e > 0 and np.allclose(H, H.T) and np.all(np.linalg.eigvalsh(H) > 0) and b.shape == (6,)
+
+
+def test_rbf_kernel_mode(pygicp, data):
+    target, source, gt = data
+    reg = pygicp.FastVGICPCuda()
+    reg.set_nearest_neighbor_search_method("GPU_RBF_KERNEL")
+    reg.set_kernel_width(0.5)
+    reg.set_input_target(target); reg.set_input_source(source)
+    _check(gt, reg.align(), reg.has_converged(), "RBF")

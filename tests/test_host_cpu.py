@@ -1,0 +1,60 @@
+"""CPU tests of the host layer: pygicp builds/imports with the reference's binding surface, the PCL stand-ins
+(ApproximateVoxelGrid, kd-tree k-NN) are right, and nothing falls back to the CPU for the registration itself."""
+import re
+
+import numpy as np
+import pytest
+
+from tests import util
+
+
+@pytest.fixture(scope="module")
+def pygicp():
+    from fast_gicp_amd import build_host
+    build_host.build_all()
+    import pygicp
+    return pygicp
+
+
+def test_binding_surface_matches_reference_main_cpp(pygicp):
+    """src/python/main.cpp:152-223: functions, classes and snake_case methods exposed for the CUDA classes."""
+    assert callable(pygicp.downsample) and callable(pygicp.align_points)
+    for cls in ("LsqRegistration", "FastVGICPCuda", "NDTCuda"):
+        assert hasattr(pygicp, cls)
+    lsq = {"set_input_target", "set_input_source", "swap_source_and_target", "get_final_hessian", "get_final_transformation", "get_fitness_score", "align"}
+    assert lsq <= set(dir(pygicp.LsqRegistration))
+    assert {"set_resolution", "set_neighbor_search_method", "set_correspondence_randomness"} <= set(dir(pygicp.FastVGICPCuda))
+    assert {"set_resolution", "set_neighbor_search_method"} <= set(dir(pygicp.NDTCuda))
+    assert issubclass(pygicp.FastVGICPCuda, pygicp.LsqRegistration) and issubclass(pygicp.NDTCuda, pygicp.LsqRegistration)
+    doc = pygicp.align_points.__doc__
+    for kw in ("target", "source", "method", "downsample_resolution", "k_correspondences", "max_correspondence_distance", "voxel_resolution", "num_threads",
+               "neighbor_search_method", "neighbor_search_radius", "initial_guess"):
+        assert re.search(r"\b%s\b" % kw, doc), kw
+
+
+def test_downsample_is_pcl_approximate_voxelgrid(pygicp):
+    from oracle import oracle as O
+    import os
+    raw = O.load_pcd(os.path.join(util.DATA, "251370668.pcd"))
+    got = pygicp.downsample(raw.astype(np.float64), 0.1)
+    assert len(got) == 17249  # README.md:116
+    ref = O.approx_voxelgrid(raw, 0.1)
+    assert np.array_equal(got.astype(np.float32), ref)
+
+
+def test_host_kdtree_equals_oracle_knn(pygicp):
+    from oracle import oracle as O
+    _, s = util.bundled_pair()
+    s = s[:5000]
+    got = pygicp._kdtree_knn(s.astype(np.float64), 20)
+    assert np.array_equal(got, O.knn(s, 20))
+
+
+def test_engine_without_gpu_raises(pygicp):
+    from fast_gicp_amd import capi
+    if capi.device_count() > 0:
+        pytest.skip("GPU present")
+    with pytest.raises(RuntimeError):
+        pygicp.FastVGICPCuda()
+    with pytest.raises(RuntimeError):
+        pygicp.NDTCuda()
