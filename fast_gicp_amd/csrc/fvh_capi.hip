@@ -96,7 +96,10 @@ struct Rccl {
   int (*AllReduce)(const void*, void*, size_t, int, int, void*, hipStream_t) = nullptr;
   bool load() {
     if (lib) return true;
-    lib = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+    // reuse the RCCL the process already has (e.g. the one torch.distributed loaded) before loading another copy
+    lib = dlopen("librccl.so", RTLD_NOW | RTLD_NOLOAD);
+    if (!lib) lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_NOLOAD);
+    if (!lib) lib = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
     if (!lib) lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
     if (!lib) return false;
     GetUniqueId = (decltype(GetUniqueId))dlsym(lib, "ncclGetUniqueId");

@@ -1,0 +1,188 @@
+"""Multi-GPU registration: one process per GPU, source cloud sharded by spatial tile, the 28-value
+normal-equation block {err, b(6), upper H(21)} all-reduced once per cost evaluation.
+
+The reference has no multi-GPU path ("Collectives: none"); this follows BASELINE.json's
+north_star.  Every correspondence contributes independently to (err, H, b), so the only coupling
+between shards is the sum:
+
+  * partition : contiguous ranges of the Morton order of the SOURCE cloud = spatial tiles
+                (`spatial_tile_partition`); the target Gaussian voxel map is replicated on every GPU
+                (64 B per bucket -- a 1M-point map is ~100 MB of a 288 GB HBM), so no halo exchange
+                is needed for DIRECT7/27 lookups;
+  * exchange  : one all-reduce (sum) of 32 doubles per linearize() / compute_error(); 256 B, pure
+                latency.  On GPUs it runs inside libfast_vgicp_hip.so as ncclAllReduce on the handle's
+                own stream (RCCL over xGMI, no host sync), and the LM step is then computed redundantly
+                on every rank from bit-identical sums, so no broadcast is needed;
+  * the host-driven variant below (`ShardedLsq`) does the same through a caller-supplied all-reduce
+    (torch.distributed gloo on CPU in the tests, NCCL/RCCL tensors on GPUs) and is what the
+    world_size=2 CPU tests exercise.
+"""
+import numpy as np
+
+
+def morton_order(xyz, bits=10):
+    """Permutation that sorts points along a 3*bits-bit Morton curve over the cloud's bounding cube."""
+    p = np.asarray(xyz, np.float64)
+    lo = p.min(axis=0)
+    extent = max(float((p.max(axis=0) - lo).max()), 1e-9)
+    q = np.minimum(((p - lo) * ((2 ** bits - 1e-3) / extent)).astype(np.uint64), 2 ** bits - 1)
+    key = np.zeros(len(p), np.uint64)
+    for b in range(bits):
+        for a in range(3):
+            key |= ((q[:, a] >> np.uint64(b)) & np.uint64(1)) << np.uint64(3 * b + a)
+    return np.argsort(key, kind="stable")
+
+
+def spatial_tile_partition(xyz, nranks):
+    """List of index arrays, one per rank: contiguous, equally sized ranges of the Morton order (spatial tiles)."""
+    order = morton_order(xyz)
+    bounds = np.linspace(0, len(order), nranks + 1).astype(np.int64)
+    return [order[bounds[r]:bounds[r + 1]] for r in range(nranks)]
+
+
+def se3_exp(a):
+    """fast_gicp::se3_exp (so3.hpp:80-104), numpy."""
+    a = np.asarray(a, np.float64)
+    w, v = a[:3], a[3:]
+    th2 = float(w @ w)
+    if th2 < 1e-10:
+        imag = 0.5 - th2 / 48.0 + th2 * th2 / 3840.0
+        real = 1.0 - th2 / 8.0 + th2 * th2 / 384.0
+    else:
+        th = np.sqrt(th2)
+        imag, real = np.sin(0.5 * th) / th, np.cos(0.5 * th)
+    qw, (qx, qy, qz) = real, imag * w
+    R = np.array([[1 - 2 * (qy * qy + qz * qz), 2 * (qx * qy - qz * qw), 2 * (qx * qz + qy * qw)],
+                  [2 * (qx * qy + qz * qw), 1 - 2 * (qx * qx + qz * qz), 2 * (qy * qz - qx * qw)],
+                  [2 * (qx * qz - qy * qw), 2 * (qy * qz + qx * qw), 1 - 2 * (qx * qx + qy * qy)]])
+    th = np.sqrt(th2)
+    if th < 1e-10:
+        V = R
+    else:
+        O = np.array([[0, -w[2], w[1]], [w[2], 0, -w[0]], [-w[1], w[0], 0]])
+        V = np.eye(3) + (1 - np.cos(th)) / th2 * O + (th - np.sin(th)) / (th2 * th) * (O @ O)
+    T = np.eye(4)
+    T[:3, :3] = R
+    T[:3, 3] = V @ v
+    return T
+
+
+class ShardedLsq:
+    """LsqRegistration::computeTransformation / step_lm (lsq_registration_impl.hpp:53-168) where every cost
+    evaluation is the all-reduced sum of the ranks' local evaluations.
+
+    local_linearize(T) -> (err, H 6x6, b 6) and local_error(T) -> err evaluate THIS rank's shard;
+    allreduce(vec) sums a float64 vector over the ranks in place / returns the sum.  All ranks run the same
+    (deterministic) LM recursion on identical sums, so they stay in lock-step without any broadcast."""
+
+    def __init__(self, local_linearize, local_error, allreduce, max_iterations=64, rotation_epsilon=2e-3, transformation_epsilon=5e-4, lm_max_iterations=10,
+                 lm_init_lambda_factor=1e-9):
+        self.local_linearize, self.local_error, self.allreduce = local_linearize, local_error, allreduce
+        self.max_iterations, self.rotation_epsilon, self.transformation_epsilon = max_iterations, rotation_epsilon, transformation_epsilon
+        self.lm_max_iterations, self.lm_init_lambda_factor = lm_max_iterations, lm_init_lambda_factor
+        self.num_allreduce = 0
+
+    def linearize(self, T):
+        e, H, b = self.local_linearize(T)
+        v = np.concatenate([[e], np.asarray(b, np.float64), np.asarray(H, np.float64).reshape(-1)])
+        v = np.asarray(self.allreduce(v), np.float64)
+        self.num_allreduce += 1
+        return float(v[0]), v[7:].reshape(6, 6), v[1:7]
+
+    def compute_error(self, T):
+        v = np.asarray(self.allreduce(np.array([self.local_error(T)], np.float64)), np.float64)
+        self.num_allreduce += 1
+        return float(v[0])
+
+    def _is_converged(self, delta):
+        r = np.abs(delta[:3, :3] - np.eye(3)).max() / self.rotation_epsilon
+        t = np.abs(delta[:3, 3]).max() / self.transformation_epsilon
+        return max(r, t) < 1
+
+    def align(self, guess=None):
+        x0 = np.eye(4) if guess is None else np.asarray(guess, np.float64).copy()
+        lam, converged, iters, final_H = -1.0, False, 0, np.eye(6)
+        for i in range(self.max_iterations):
+            if converged:
+                break
+            iters = i
+            y0, H, b = self.linearize(x0)
+            if lam < 0.0:
+                lam = self.lm_init_lambda_factor * np.abs(np.diag(H)).max()
+            nu, ok, delta = 2.0, False, np.eye(4)
+            for _ in range(self.lm_max_iterations):
+                d = np.linalg.solve(H + lam * np.eye(6), -b)
+                delta = se3_exp(d)
+                xi = delta @ x0
+                yi = self.compute_error(xi)
+                rho = (y0 - yi) / (d @ (lam * d - b))
+                if rho < 0:
+                    if self._is_converged(delta):
+                        ok = True
+                        break
+                    lam, nu = nu * lam, 2 * nu
+                    continue
+                x0, final_H, ok = xi, H, True
+                lam = lam * max(1.0 / 3.0, 1 - (2 * rho - 1) ** 3)
+                break
+            if not ok:
+                break
+            converged = self._is_converged(delta)
+        return dict(T=x0, H=final_H, converged=converged, nr_iterations=iters)
+
+
+class ShardedVGICP:
+    """VGICP with the source cloud sharded over the ranks of a torch.distributed process group (one GPU each).
+
+    Every rank: replicated target (covariances + voxel map), its own spatial tile of the source.  With
+    `device_collective=True` (GPUs) the all-reduce runs inside the engine as RCCL on the handle's stream and the
+    whole LM loop stays on the device (fvh_vgicp_align); otherwise the host-driven `ShardedLsq` is used with
+    `torch.distributed.all_reduce`."""
+
+    def __init__(self, core, rank, world_size, dist=None, device_collective=True):
+        self.core, self.rank, self.world_size, self.dist = core, rank, world_size, dist
+        self.device_collective = device_collective and world_size >= 1
+        self._comm_ready = False
+
+    def init_device_collective(self, unique_id_bytes):
+        """unique_id_bytes: the 128-byte RCCL id created on rank 0 (capi.comm_unique_id()) and broadcast to all ranks."""
+        self.core.comm_init(unique_id_bytes, self.world_size, self.rank)
+        self._comm_ready = True
+
+    def set_target(self, xyz, k=20, regularization=3):
+        self.core.set_target_cloud(xyz)
+        self.core.find_target_neighbors(k)
+        self.core.calculate_target_covariances(regularization)
+        self.core.create_target_voxelmap()
+
+    def set_source(self, full_xyz, k=20, regularization=3):
+        """Covariances need neighbours across tile borders, so they are computed on the full cloud (cheap: culled
+        k-NN) and the rank then keeps only its tile for the cost evaluations."""
+        full_xyz = np.ascontiguousarray(full_xyz, np.float32)
+        tile = spatial_tile_partition(full_xyz, self.world_size)[self.rank]
+        self.core.set_source_cloud(full_xyz)
+        self.core.find_source_neighbors(k)
+        self.core.calculate_source_covariances(regularization)
+        covs = self.core.get_covariances("source").astype(np.float64)
+        self.core.set_source_cloud(full_xyz[tile])
+        self.core.set_source_covariances(covs[tile])
+        self.tile = tile
+
+    def align(self, guess=None, **lm):
+        if self.device_collective:
+            if not self._comm_ready:
+                raise RuntimeError("call init_device_collective() first")
+            return self.core.align(guess, **lm)
+        import torch
+
+        def allreduce(v):
+            t = torch.from_numpy(np.ascontiguousarray(v, np.float64))
+            if self.dist is not None and self.world_size > 1:
+                self.dist.all_reduce(t)
+            return t.numpy()
+
+        lsq = ShardedLsq(lambda T: self.core.linearize(T), lambda T: self.core.compute_error(T, derivatives=False), allreduce, **{
+            "max_iterations": lm.get("max_iterations", 64), "rotation_epsilon": lm.get("rotation_epsilon", 2e-3),
+            "transformation_epsilon": lm.get("transformation_epsilon", 5e-4), "lm_max_iterations": lm.get("lm_max_iterations", 10),
+            "lm_init_lambda_factor": lm.get("lm_init_lambda_factor", 1e-9)})
+        return lsq.align(guess)

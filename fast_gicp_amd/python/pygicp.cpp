@@ -199,7 +199,7 @@ PYBIND11_MODULE(pygicp, m) {
     host::KdTree tree(xyz.data(), n);
     py::array_t<int> out({(py::ssize_t)n, (py::ssize_t)k});
     int* o = out.mutable_data();
-#pragma omp parallel for schedule(guided, 8)
+#pragma omp parallel for schedule(guided, 8) num_threads(host::omp_threads_for(n))
     for (int i = 0; i < n; i++) tree.knn(&xyz[3 * (size_t)i], k, o + (size_t)i * k);
     return out;
   });

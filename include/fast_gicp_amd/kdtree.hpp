@@ -10,8 +10,22 @@
 #include <numeric>
 #include <vector>
 
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
 namespace fast_gicp {
 namespace host {
+
+/// at most one thread per ~512 queries, never more than 32 (or the OpenMP default)
+inline int omp_threads_for(int n) {
+#ifdef _OPENMP
+  return std::max(1, std::min(std::min(omp_get_max_threads(), 32), n / 512));
+#else
+  (void)n;
+  return 1;
+#endif
+}
 
 class KdTree {
 public:

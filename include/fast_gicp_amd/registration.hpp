@@ -429,7 +429,8 @@ protected:
     const int n = (int)(xyz.size() / 3);
     host::KdTree tree(xyz.data(), n);
     std::vector<int> neighbors((size_t)n * k);
-#pragma omp parallel for schedule(guided, 8)
+    const int threads = host::omp_threads_for(n);  // hundreds of threads on a 17k-point loop only add contention
+#pragma omp parallel for schedule(guided, 8) num_threads(threads)
     for (int i = 0; i < n; i++) tree.knn(&xyz[3 * (size_t)i], k, &neighbors[(size_t)i * k]);
     return neighbors;
   }

@@ -220,3 +220,26 @@ def test_voxel_table_hint_overflow_falls_back(O, pair, oracle_covs):
         else:
             assert util.rel_err(r["T"], ref[0]) < 1e-12 and abs(e - ref[1]) <= 1e-12 * abs(ref[1]) and util.rel_err(H, ref[2]) < 1e-12
         c.close()
+
+
+def test_sharded_path_single_rank_rccl(O, pair):
+    """The multi-GPU code path on the 1-GPU box: a 1-rank RCCL communicator is attached, so every evaluation goes
+    cost kernel -> ncclAllReduce(32 doubles, on the handle's stream) -> lm_update kernel.  Must equal the fused path."""
+    from fast_gicp_amd import capi, distributed as D
+    tgt, src = pair
+    a = _core()
+    ra = _engine_register(a, tgt, src)
+    b = _core()
+    sh = D.ShardedVGICP(b, rank=0, world_size=1)
+    sh.init_device_collective(capi.comm_unique_id())
+    sh.set_target(tgt); sh.set_source(src)
+    rb = sh.align()
+    assert rb["converged"] and rb["num_linearize"] == ra["num_linearize"]
+    assert util.rel_err(rb["T"], ra["T"]) < 1e-12 and util.rel_err(rb["H"], ra["H"]) < 1e-12
+    # host-driven variant (all-reduce outside the engine) on the same data
+    c = _core()
+    sh2 = D.ShardedVGICP(c, rank=0, world_size=1, device_collective=False)
+    sh2.set_target(tgt); sh2.set_source(src)
+    rc = sh2.align()
+    assert util.rel_err(rc["T"], ra["T"]) < 1e-9
+    a.close(); b.close(); c.close()
