@@ -99,8 +99,10 @@ struct Rccl {
     // reuse the RCCL the process already has (e.g. the one torch.distributed loaded) before loading another copy
     lib = dlopen("librccl.so", RTLD_NOW | RTLD_NOLOAD);
     if (!lib) lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_NOLOAD);
-    if (!lib) lib = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
-    if (!lib) lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+    // RTLD_LOCAL: a process may also hold torch's bundled RCCL; two copies with globally visible symbols
+    // interpose each other and corrupt the heap at exit
+    if (!lib) lib = dlopen("librccl.so", RTLD_NOW | RTLD_LOCAL);
+    if (!lib) lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL);
     if (!lib) return false;
     GetUniqueId = (decltype(GetUniqueId))dlsym(lib, "ncclGetUniqueId");
     CommInitRank = (decltype(CommInitRank))dlsym(lib, "ncclCommInitRank");
