@@ -125,6 +125,7 @@ struct Engine {
   PoseD lin;               // pose of the last update_correspondences()
   bool has_corr = false;
   int corr_n_src = 0;
+  int corr_sel = 0;        // which of the two correspondence buffers the host-mode calls use
   int last_steps = 0;
   Profiler prof;
   void* comm = nullptr;
@@ -508,6 +509,8 @@ int launch_cost(Engine* e, const CostSource& src, const VoxelMapDev& vm, int hos
   P.group = (e->n_off + groups - 1) / groups;
   P.groups_per_src = (e->n_off + P.group - 1) / P.group;
   P.corr = e->corr.as<int>();
+  P.corr_stride = (size_t)std::max(src.n_upper, 1) * e->n_off;
+  P.host_corr_sel = e->corr_sel;
   P.st = e->state.as<LmState>(); P.partials = e->partials.as<double>(); P.ticket = e->ticket.as<unsigned>();
   P.vm_counters = vm.counters.as<int>();
   P.vm_counters2 = src.counters2;
@@ -537,8 +540,9 @@ template <int MODE>
 int do_update_correspondences(Engine* e, const CostSource& src, VoxelMapDev& vm, const double* T16) {
   if (!T16) return e->fail(FVH_ERR_INVALID_ARGUMENT, "update_correspondences: null pose");
   if (!vm.valid) return e->fail(FVH_ERR_BAD_STATE, "update_correspondences: target voxel map not built");
-  HIP_OR_FAIL(e, e->corr.ensure(sizeof(int) * (size_t)std::max(src.n_upper, 1) * e->n_off));
+  HIP_OR_FAIL(e, e->corr.ensure(2 * sizeof(int) * (size_t)std::max(src.n_upper, 1) * e->n_off));
   e->lin = pose_from_colmajor16(T16);
+  e->corr_sel = 0;
   int rc = launch_cost<MODE>(e, src, vm, PH_FIND_ONLY, &e->lin, &e->lin);
   if (rc) return rc;
   e->has_corr = true;
@@ -587,14 +591,14 @@ int do_align(Engine* e, const CostSource& src, VoxelMapDev& vm, const double* gu
   if (!vm.valid) return e->fail(FVH_ERR_BAD_STATE, "align: target voxel map not built");
   fvh_lm_params p;
   if (params) p = *params; else fvh_default_lm_params(&p);
-  HIP_OR_FAIL(e, e->corr.ensure(sizeof(int) * (size_t)std::max(src.n_upper, 1) * e->n_off));
+  HIP_OR_FAIL(e, e->corr.ensure(2 * sizeof(int) * (size_t)std::max(src.n_upper, 1) * e->n_off));
   LmState* st = e->state.as<LmState>();
   lm_init_kernel<<<1, 64, 0, e->stream>>>(st, pose_from_colmajor16(guess16), p.rotation_epsilon, p.transformation_epsilon, p.lm_init_lambda_factor, p.max_iterations,
                                           p.lm_max_iterations, e->ticket.as<unsigned>());
   HIP_OR_FAIL(e, hipGetLastError());
   const long long budget = (long long)std::max(p.max_iterations, 0) * (1 + (long long)std::max(p.lm_max_iterations, 0)) + 1;
   long long launched = 0;
-  int batch = e->last_steps > 0 ? e->last_steps + 1 : 12;
+  int batch = e->last_steps > 0 ? e->last_steps + 1 : 8;
   LmState* h = reinterpret_cast<LmState*>(e->pinned);
   while (true) {
     for (int s = 0; s < batch; s++) {
@@ -610,7 +614,7 @@ int do_align(Engine* e, const CostSource& src, VoxelMapDev& vm, const double* gu
     HIP_OR_FAIL(e, hipMemcpyAsync(h, st, sizeof(LmState), hipMemcpyDeviceToHost, e->stream));
     HIP_OR_FAIL(e, hipStreamSynchronize(e->stream));
     if (h->phase == PH_DONE || launched >= budget) break;
-    batch = 4;
+    batch = 3;
   }
   vm.nv_hint = h->vm_num_voxels;
   if (h->vm_dropped > 0) {  // hint-sized table overflowed: rebuild at the safe size and run again (rare)
@@ -619,9 +623,10 @@ int do_align(Engine* e, const CostSource& src, VoxelMapDev& vm, const double* gu
     if (rc) return rc;
     return do_align<MODE>(e, src, vm, guess16, params, result, rebuild_safe, true);
   }
-  e->last_steps = h->num_linearize + h->num_error_evals;
-  e->lin = h->x0;
-  e->has_corr = true;  // correspondences of the last linearisation stay valid for compute_error()
+  e->last_steps = 1 + h->num_error_evals;  // launches this align needed: the first linearize + one fused launch per trial
+  e->lin = h->x_lin;
+  e->corr_sel = h->corr_cur;
+  e->has_corr = true;  // correspondences of the last consumed linearisation stay valid for compute_error()
   e->corr_n_src = src.n_upper;
   pose_to_colmajor16(h->x0, result->T);
   for (int i = 0; i < 6; i++) for (int j = 0; j < 6; j++) result->H[j * 6 + i] = h->final_H[i * 6 + j];
@@ -808,7 +813,7 @@ static int fetch_corr(Engine* e, int n_src, std::vector<int>& corr) {
   if (!e->has_corr) return e->fail(FVH_ERR_BAD_STATE, "no correspondences: call update_correspondences first");
   corr.resize((size_t)n_src * e->n_off);
   if (corr.empty()) return FVH_OK;
-  HIP_OR_FAIL(e, hipMemcpyAsync(corr.data(), e->corr.p, sizeof(int) * corr.size(), hipMemcpyDeviceToHost, e->stream));
+  HIP_OR_FAIL(e, hipMemcpyAsync(corr.data(), e->corr.as<int>() + (size_t)e->corr_sel * corr.size(), sizeof(int) * corr.size(), hipMemcpyDeviceToHost, e->stream));
   HIP_OR_FAIL(e, hipStreamSynchronize(e->stream));
   return FVH_OK;
 }

@@ -27,11 +27,13 @@ constexpr int MAX_PARTIAL_ROWS = 512;  // workgroup rows; 8 group rows follow
 
 enum CostMode { MODE_VGICP = 0, MODE_NDT_P2D = 1, MODE_NDT_D2D = 2 };
 enum Phase { PH_LINEARIZE = 0, PH_TRIAL = 1, PH_DONE = 2, PH_FIND_ONLY = 3, PH_EVAL_DERIV = 4, PH_EVAL_ERROR = 5 };
+// PH_TRIAL in device-LM mode is the FUSED launch: trial error with the old correspondences + speculative linearisation at the trial pose
 
 struct LmState {
   PoseD x0;        // current estimate == linearisation pose
   PoseD xi;        // trial pose
   PoseD delta;     // se3_exp(d) of the last step
+  PoseD x_lin;     // pose at which the CURRENT correspondence buffer was computed (reference: linearized_x)
   double H[36], b[6], d[6];
   double y0, lambda, nu;
   double final_H[36];
@@ -41,6 +43,7 @@ struct LmState {
   int max_iterations, lm_max_iterations;
   // status
   int phase, outer_iter, inner_iter, converged, lm_failed, num_linearize, num_error_evals, nr_iterations;
+  int corr_cur;       // which of the two correspondence buffers is current (device-LM mode flips it on accept)
   int vm_num_voxels;  // copied from the voxel map's counters by the last workgroup: capacity hint for the next build
   int vm_dropped;     // > 0: the hint-sized table overflowed -> host rebuilds at the safe size and re-runs
 };
@@ -57,7 +60,9 @@ struct CostParams {
   int n_off;
   int group;                  // offsets per work item
   int groups_per_src;         // ceil(n_off / group)
-  int* corr;                  // [n_src][n_off] bucket index or -1
+  int* corr;                  // 2 x [n_src][n_off] bucket index or -1 (double buffered for the speculative linearisation)
+  size_t corr_stride;         // elements per buffer
+  int host_corr_sel;          // host-mode launches: buffer to use
   LmState* st;
   double* partials;           // [gridDim.x][PART_STRIDE]
   unsigned* ticket;
@@ -177,54 +182,64 @@ __device__ inline void dev_lm_propose(LmState* st) {  // d = (H + lambda I)^-1 (
 }
 
 // One transition of the {linearize -> trial* -> accept} machine; exactly the control flow of
-// LsqRegistration::computeTransformation + step_lm.
+// LsqRegistration::computeTransformation + step_lm.  sums[0..27] = {err, b, H} of the linearisation this
+// launch computed (at x0 for PH_LINEARIZE, speculatively at xi for the fused PH_TRIAL launch), sums[28] =
+// trial error y_i at xi with the OLD correspondences (fused launch only).
+__device__ inline void dev_lm_consume_linearization(LmState* st, const double* sums) {
+  st->y0 = sums[0];
+  unpack_sums(sums, st->H, st->b);
+  st->num_linearize++;
+  st->nr_iterations = st->outer_iter;
+  if (st->lambda < 0.0) {
+    double mx = 0;
+    for (int i = 0; i < 6; i++) mx = fmax(mx, fabs(st->H[i * 6 + i]));
+    st->lambda = st->lm_init_lambda_factor * mx;
+  }
+  st->nu = 2.0;
+  st->inner_iter = 0;
+}
+
 __device__ inline void dev_lm_step(LmState* st, const double* sums) {
   if (st->phase == PH_LINEARIZE) {
-    st->y0 = sums[0];
-    unpack_sums(sums, st->H, st->b);
-    st->num_linearize++;
-    st->nr_iterations = st->outer_iter;
-    if (st->lambda < 0.0) {
-      double mx = 0;
-      for (int i = 0; i < 6; i++) mx = fmax(mx, fabs(st->H[i * 6 + i]));
-      st->lambda = st->lm_init_lambda_factor * mx;
-    }
-    st->nu = 2.0;
-    st->inner_iter = 0;
+    st->x_lin = st->x0;
+    dev_lm_consume_linearization(st, sums);
     if (st->lm_max_iterations <= 0) { st->lm_failed = 1; st->phase = PH_DONE; return; }
     dev_lm_propose(st);
     st->phase = PH_TRIAL;
     return;
   }
-  // PH_TRIAL
-  const double yi = sums[0];
+  // PH_TRIAL (fused)
+  const double yi = sums[28];
   st->num_error_evals++;
   double denom = 0;
   for (int j = 0; j < 6; j++) denom += st->d[j] * (st->lambda * st->d[j] - st->b[j]);
   const double rho = (st->y0 - yi) / denom;
-  bool step_done = false;
   if (rho < 0) {
-    if (dev_is_converged(st, st->delta)) {
-      step_done = true;  // returns true with x0 unchanged
-    } else {
-      st->lambda = st->nu * st->lambda;
-      st->nu = 2 * st->nu;
-      st->inner_iter++;
-      if (st->inner_iter >= st->lm_max_iterations) { st->lm_failed = 1; st->phase = PH_DONE; return; }  // "lm not converged!!"
-      dev_lm_propose(st);
-      return;  // stay in PH_TRIAL
+    if (dev_is_converged(st, st->delta)) {  // step_lm returns true with x0 unchanged -> converged_ = true
+      st->converged = 1;
+      st->outer_iter++;
+      st->phase = PH_DONE;
+      return;
     }
-  } else {
-    st->x0 = st->xi;
-    { const double u = 2 * rho - 1; st->lambda = st->lambda * fmax(1.0 / 3.0, 1 - u * u * u); }
-    for (int i = 0; i < 36; i++) st->final_H[i] = st->H[i];
-    step_done = true;
+    st->lambda = st->nu * st->lambda;
+    st->nu = 2 * st->nu;
+    st->inner_iter++;
+    if (st->inner_iter >= st->lm_max_iterations) { st->lm_failed = 1; st->phase = PH_DONE; return; }  // "lm not converged!!"
+    dev_lm_propose(st);  // new trial from the SAME (H, b); the speculative linearisation of this launch is discarded
+    return;
   }
-  if (step_done) {
-    st->converged = dev_is_converged(st, st->delta) ? 1 : 0;
-    st->outer_iter++;
-    st->phase = (st->converged || st->outer_iter >= st->max_iterations) ? PH_DONE : PH_LINEARIZE;
-  }
+  // accepted
+  st->x0 = st->xi;
+  { const double u = 2 * rho - 1; st->lambda = st->lambda * fmax(1.0 / 3.0, 1 - u * u * u); }
+  for (int i = 0; i < 36; i++) st->final_H[i] = st->H[i];
+  st->converged = dev_is_converged(st, st->delta) ? 1 : 0;
+  st->outer_iter++;
+  if (st->converged || st->outer_iter >= st->max_iterations) { st->phase = PH_DONE; return; }
+  // the speculative linearisation at xi (== the new x0) is exactly the next step_lm's linearize()
+  st->corr_cur ^= 1;
+  st->x_lin = st->x0;
+  dev_lm_consume_linearization(st, sums);
+  dev_lm_propose(st);
 }
 
 // tiny kernels for the multi-GPU path and for (re)initialising the state
@@ -236,6 +251,7 @@ __global__ void lm_init_kernel(LmState* st, PoseD guess, double rot_eps, double 
   st->max_iterations = max_iter; st->lm_max_iterations = lm_max_iter;
   st->lambda = -1.0; st->nu = 2.0; st->y0 = 0.0;
   st->phase = max_iter > 0 ? PH_LINEARIZE : PH_DONE;
+  st->corr_cur = 0; st->x_lin = guess;
   st->outer_iter = 0; st->inner_iter = 0; st->converged = 0; st->lm_failed = 0; st->num_linearize = 0; st->num_error_evals = 0; st->nr_iterations = 0;
   for (int i = 0; i < 36; i++) st->final_H[i] = (i % 7 == 0) ? 1.0 : 0.0;
 }
@@ -293,30 +309,36 @@ __global__ __launch_bounds__(256) void cost_kernel(CostParams P) {
   __shared__ double fin[8][PART_STRIDE];
   __shared__ int s_last;
   LmState* st = P.st;
-  int phase;
+  int phase, corr_sel;
   PoseD lin_d, ev_d;
   if (P.host_phase >= 0) {
     phase = P.host_phase;
     lin_d = P.lin;
     ev_d = P.ev;
+    corr_sel = P.host_corr_sel;
   } else {
     phase = st->phase;
     if (phase == PH_DONE) return;
-    lin_d = st->x0;
+    lin_d = st->x_lin;  // == x0 for PH_LINEARIZE
     ev_d = (phase == PH_LINEARIZE) ? st->x0 : st->xi;
+    corr_sel = st->corr_cur;
   }
-  const bool do_find = (phase == PH_LINEARIZE) || (phase == PH_FIND_ONLY);
+  const bool fused = (P.host_phase < 0) && (phase == PH_TRIAL);  // trial error (old ids) + speculative linearisation at xi (new ids)
+  const bool do_find = (phase == PH_LINEARIZE) || (phase == PH_FIND_ONLY) || fused;
   const bool do_cost = (phase != PH_FIND_ONLY);
-  const bool do_deriv = (phase == PH_LINEARIZE) || (phase == PH_EVAL_DERIV);
-  const Pose<Real> lin = pose_cast<Real>(lin_d);
-  const Pose<Real> ev = pose_cast<Real>(ev_d);
+  const bool do_deriv = (phase == PH_LINEARIZE) || (phase == PH_EVAL_DERIV) || fused;
+  const Pose<Real> lin = pose_cast<Real>(lin_d);   // rotation used by the cached Mahalanobis of the OLD ids
+  const Pose<Real> ev = pose_cast<Real>(ev_d);     // evaluation pose; also the linearisation pose of the NEW ids
   const Real res = (Real)P.res;
   const int n_src = P.d_n_src ? *P.d_n_src : P.n_src;
   const int n_items = n_src * P.groups_per_src;
+  int* corr_old = P.corr + (size_t)corr_sel * P.corr_stride;                      // read (stored ids)
+  int* corr_new = fused ? P.corr + (size_t)(corr_sel ^ 1) * P.corr_stride : corr_old;  // written by the find
 
   double acc[NSUM];
 #pragma unroll
   for (int v = 0; v < NSUM; v++) acc[v] = 0.0;
+  double acc_y = 0.0;  // fused: trial error with the old ids
 
   const float4* tf = reinterpret_cast<const float4*>(P.table);
   for (int w = blockIdx.x * 256 + threadIdx.x; w < n_items; w += gridDim.x * 256) {
@@ -327,23 +349,29 @@ __global__ __launch_bounds__(256) void cost_kernel(CostParams P) {
     float4 c0 = make_float4(0, 0, 0, 0), c1 = c0;
     if (MODE != MODE_NDT_P2D && do_cost) { c0 = P.src_cov[2 * i]; c1 = P.src_cov[2 * i + 1]; }
     const Vec3<Real> a = {(Real)a4.x, (Real)a4.y, (Real)a4.z};
-    Sym3<Real> RCR = {0, 0, 0, 0, 0, 0};
+    Sym3<Real> RCR = {0, 0, 0, 0, 0, 0}, RCR_old = {0, 0, 0, 0, 0, 0};
     if (MODE != MODE_NDT_P2D && do_cost) {
       const Sym3<Real> CA = {(Real)c0.x, (Real)c0.y, (Real)c0.z, (Real)c0.w, (Real)c1.x, (Real)c1.y};
-      RCR = rotate_cov(lin.r, CA);
+      // the ids found by THIS launch are linearised at `ev` when fused, at `lin` otherwise
+      RCR = rotate_cov(fused ? ev.r : lin.r, CA);
+      if (fused) RCR_old = rotate_cov(lin.r, CA);
     }
     const Vec3<Real> q = transform(ev, a);
     int cx = 0, cy = 0, cz = 0;
     if (do_find) {
-      const Vec3<Real> ql = transform(lin, a);
+      const Vec3<Real> ql = fused ? q : transform(lin, a);
       cx = (int)floor(ql.x / res - (Real)0.5);
       cy = (int)floor(ql.y / res - (Real)0.5);
       cz = (int)floor(ql.z / res - (Real)0.5);
     }
     const int o_begin = g * P.group, o_end = min(P.n_off, o_begin + P.group);
     for (int oc = o_begin; oc < o_end; oc += COST_CH) {
-      int b[COST_CH];
-      // ---- round trip 2: COST_CH independent lookups in flight (first probe of each, or the stored ids) ----
+      int b[COST_CH], bo[COST_CH];
+      // ---- round trip 2: COST_CH independent lookups in flight (first probe of each, and/or the stored ids) ----
+      if (fused) {
+#pragma unroll
+        for (int c = 0; c < COST_CH; c++) bo[c] = (oc + c < o_end) ? corr_old[(size_t)i * P.n_off + oc + c] : -1;
+      }
       if (do_find) {
         unsigned long long key[COST_CH];
         unsigned slot[COST_CH];
@@ -367,11 +395,11 @@ __global__ __launch_bounds__(256) void cost_kernel(CostParams P) {
             else if (k != FVH_EMPTY_KEY) r = probe_continue(P.table, P.mask, key[c], slot[c]);  // rare at load <= 0.25
           }
           b[c] = r;
-          if (oc + c < o_end) P.corr[(size_t)i * P.n_off + oc + c] = r;
+          if (oc + c < o_end) corr_new[(size_t)i * P.n_off + oc + c] = r;
         }
       } else {
 #pragma unroll
-        for (int c = 0; c < COST_CH; c++) b[c] = (oc + c < o_end) ? P.corr[(size_t)i * P.n_off + oc + c] : -1;
+        for (int c = 0; c < COST_CH; c++) b[c] = (oc + c < o_end) ? corr_old[(size_t)i * P.n_off + oc + c] : -1;
       }
       if (!do_cost) continue;
       // ---- round trip 3: the voxel records of all hits, unconditional loads (bucket 0 for misses) ----
@@ -380,6 +408,30 @@ __global__ __launch_bounds__(256) void cost_kernel(CostParams P) {
       for (int c = 0; c < COST_CH; c++) {
         const size_t base = (size_t)max(b[c], 0) * 4;
         q1[c] = tf[base + 1]; q2[c] = tf[base + 2]; q3[c] = tf[base + 3];
+      }
+      if (fused) {  // trial error with the OLD ids (usually the same buckets -> the lines are already on their way)
+#pragma unroll
+        for (int c = 0; c < COST_CH; c++) {
+          if (bo[c] < 0) continue;
+          const size_t base = (size_t)bo[c] * 4;
+          const float4 o1 = tf[base + 1], o2 = tf[base + 2], o3 = tf[base + 3];
+          const int npts = (int)o1.w;
+          const Vec3<Real> mu = {(Real)o1.x, (Real)o1.y, (Real)o1.z};
+          const Sym3<Real> A = {(Real)o2.x + RCR_old.xx, (Real)o2.y + RCR_old.xy, (Real)o2.z + RCR_old.xz, (Real)o2.w + RCR_old.yy, (Real)o3.x + RCR_old.yz, (Real)o3.y + RCR_old.zz};
+          const Vec3<Real> e = {mu.x - q.x, mu.y - q.y, mu.z - q.z};
+          Real wgt;
+          if (MODE == MODE_VGICP) {
+            if (npts <= 0) continue;
+            wgt = sqrt((Real)npts);
+          } else {
+            if (npts <= 6) continue;
+            const Real ksq = res * res;
+            wgt = ksq / (ksq + (e.x * e.x + e.y * e.y + e.z * e.z));
+          }
+          const Sym3<Real> M = inverse(A);
+          const Vec3<Real> Me = mul(M, e);
+          acc_y += (double)(wgt * (e.x * Me.x + e.y * Me.y + e.z * Me.z));
+        }
       }
 #pragma unroll
       for (int c = 0; c < COST_CH; c++) {
@@ -416,10 +468,18 @@ __global__ __launch_bounds__(256) void cost_kernel(CostParams P) {
       if (lane == 0) red[wv][v] = x;
     }
   }
+  {
+    double y = acc_y;  // slot 28: fused trial error
+    if (fused) {
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) y += __shfl_xor(y, off);
+    }
+    if (lane == 0) red[wv][28] = y;
+  }
   __syncthreads();
   if (threadIdx.x < PART_STRIDE) {
     const int v = threadIdx.x;
-    const double s = (v < nsum) ? (red[0][v] + red[1][v]) + (red[2][v] + red[3][v]) : 0.0;
+    const double s = (v < nsum || v == 28) ? (red[0][v] + red[1][v]) + (red[2][v] + red[3][v]) : 0.0;
     // write-through (sc1) so another workgroup can read it from L2 without a release fence
     __hip_atomic_store(&P.partials[(size_t)blockIdx.x * PART_STRIDE + v], s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
