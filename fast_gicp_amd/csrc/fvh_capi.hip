@@ -260,14 +260,27 @@ int set_neighbors(Engine* e, CloudDev& c, int k, const int* idx) {
 int ensure_sorted(Engine* e, CloudDev& c) {
   if (c.has_sorted) return FVH_OK;
   const int n = c.n;
-  const int nwaves = (n + SORT_ITEMS_PER_WAVE - 1) / SORT_ITEMS_PER_WAVE;
+  static const int items_env = [] { const char* v = getenv("FVH_SORT_ITEMS"); return v ? atoi(v) : 0; }();
+  const int items = items_env > 0 ? items_env : (n <= 65536 ? 256 : SORT_ITEMS_MAX);  // more, shorter waves for small clouds (latency-bound)
+  const int nwaves = (n + items - 1) / items;
   const int ntiles = (n + 63) / 64;
   HIP_OR_FAIL(e, c.sorted.ensure(sizeof(float4) * (size_t)n));
   HIP_OR_FAIL(e, c.bbox.ensure(sizeof(float4) * 2 * (size_t)ntiles));
   HIP_OR_FAIL(e, e->sort_keys.ensure(sizeof(unsigned) * 2 * (size_t)n + 64));
   HIP_OR_FAIL(e, e->sort_idx.ensure(sizeof(int) * 2 * (size_t)n));
   HIP_OR_FAIL(e, e->sort_hist.ensure(sizeof(unsigned) * (size_t)RADIX_BINS * nwaves));
+  const int nsuper_small = (ntiles + 63) / 64;
+  HIP_OR_FAIL(e, c.bbox2.ensure(sizeof(float4) * 2 * (size_t)nsuper_small));
   ProfScope ps(e, "sort");
+  static const int sort_mode = [] { const char* v = getenv("FVH_SORT_MODE"); return v ? atoi(v) : 1; }();  // 1: single-workgroup path for small clouds
+  if (sort_mode == 1 && n <= SORT_SMALL_MAX) {
+    sort_small_kernel<<<1, 1024, 0, e->stream>>>(c.pts.as<float4>(), n, e->sort_keys.as<unsigned>(), e->sort_idx.as<int>(), e->sort_keys.as<unsigned>() + n, e->sort_idx.as<int>() + n);
+    gather_tiles_kernel<<<(ntiles + 3) / 4, 256, 0, e->stream>>>(c.pts.as<float4>(), e->sort_idx.as<int>(), n, c.sorted.as<float4>(), c.bbox.as<float4>());
+    super_bbox_kernel<<<(nsuper_small + 3) / 4, 256, 0, e->stream>>>(c.bbox.as<float4>(), ntiles, c.bbox2.as<float4>());
+    HIP_OR_FAIL(e, hipGetLastError());
+    c.has_sorted = true;
+    return FVH_OK;
+  }
   unsigned* box = reinterpret_cast<unsigned*>(e->sort_keys.as<unsigned>() + 2 * (size_t)n);
   HIP_OR_FAIL(e, hipMemsetAsync(box, 0xFF, 12, e->stream));
   HIP_OR_FAIL(e, hipMemsetAsync(box + 3, 0, 12, e->stream));
@@ -278,10 +291,10 @@ int ensure_sorted(Engine* e, CloudDev& c) {
   const int wblocks = (nwaves + 3) / 4;
   for (int pass = 0; pass < RADIX_PASSES; pass++) {
     const int in = pass & 1, out = in ^ 1, shift = pass * RADIX_BITS;
-    radix_hist_kernel<<<wblocks, 256, 0, e->stream>>>(keys[in], n, shift, nwaves, e->sort_hist.as<unsigned>());
+    radix_hist_kernel<<<wblocks, 256, 0, e->stream>>>(keys[in], n, shift, nwaves, items, e->sort_hist.as<unsigned>());
     radix_scan_kernel<<<1, 1024, 0, e->stream>>>(e->sort_hist.as<unsigned>(), RADIX_BINS * nwaves);
     const bool last = (pass == RADIX_PASSES - 1);
-    radix_scatter_kernel<<<wblocks, 256, 0, e->stream>>>(keys[in], idx[in], n, shift, nwaves, e->sort_hist.as<unsigned>(), keys[out], idx[out], last ? c.pts.as<float4>() : nullptr,
+    radix_scatter_kernel<<<wblocks, 256, 0, e->stream>>>(keys[in], idx[in], n, shift, nwaves, items, e->sort_hist.as<unsigned>(), keys[out], idx[out], last ? c.pts.as<float4>() : nullptr,
                                                          last ? c.sorted.as<float4>() : nullptr);
   }
   tile_bbox_kernel<<<(ntiles + 3) / 4, 256, 0, e->stream>>>(c.sorted.as<float4>(), n, c.bbox.as<float4>());

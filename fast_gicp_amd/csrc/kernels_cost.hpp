@@ -455,33 +455,38 @@ __global__ __launch_bounds__(256) void cost_kernel(CostParams P) {
     }
   }
 
-  // ---- workgroup reduction: wave shuffles, then LDS across the 4 waves ----
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  // ---- workgroup reduction through an LDS transpose ------------------------------------------
+  // Every thread stores its values to tile[v][thread] (row stride 264 doubles: conflict-free for
+  // both phases), then thread (v = t/8, part = t%8) sums the 32 entries part, part+8, ... of row v
+  // and 3 shuffle steps combine the 8 parts. ~66 LDS operations per thread instead of the 336
+  // ds_bpermute of a per-value wave-shuffle tree (measured: the (H,b) launch cost 7 us more than
+  // the error-only launch, almost all of it crossbar traffic).
   if (!do_cost) return;
+  constexpr int RED_ROWS = NSUM + 1, RED_STRIDE = 264;
+  __shared__ double tile[RED_ROWS * RED_STRIDE];
   const int nsum = do_deriv ? NSUM : 1;
+  const int t = threadIdx.x;
 #pragma unroll
-  for (int v = 0; v < NSUM; v++) {  // static indexing keeps acc[] in VGPRs
-    if (v < nsum) {
-      double x = acc[v];
-#pragma unroll
-      for (int off = 32; off > 0; off >>= 1) x += __shfl_xor(x, off);
-      if (lane == 0) red[wv][v] = x;
-    }
-  }
-  {
-    double y = acc_y;  // slot 28: fused trial error
-    if (fused) {
-#pragma unroll
-      for (int off = 32; off > 0; off >>= 1) y += __shfl_xor(y, off);
-    }
-    if (lane == 0) red[wv][28] = y;
-  }
+  for (int v = 0; v < NSUM; v++)
+    if (v < nsum) tile[v * RED_STRIDE + t] = acc[v];  // static indexing keeps acc[] in VGPRs
+  if (fused) tile[NSUM * RED_STRIDE + t] = acc_y;
   __syncthreads();
-  if (threadIdx.x < PART_STRIDE) {
-    const int v = threadIdx.x;
-    const double s = (v < nsum || v == 28) ? (red[0][v] + red[1][v]) + (red[2][v] + red[3][v]) : 0.0;
-    // write-through (sc1) so another workgroup can read it from L2 without a release fence
-    __hip_atomic_store(&P.partials[(size_t)blockIdx.x * PART_STRIDE + v], s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  {
+    const int v = t >> 3, part = t & 7;
+    const bool live = (v < nsum) || (fused && v == NSUM);
+    double x = 0.0;
+    if (v < RED_ROWS && live) {
+      const double* row = tile + v * RED_STRIDE + part;
+#pragma unroll 8
+      for (int j = 0; j < 32; j++) x += row[8 * j];
+    }
+#pragma unroll
+    for (int off = 4; off > 0; off >>= 1) x += __shfl_xor(x, off);
+    // write-through (sc1) so another workgroup can read it from L2 without a release fence;
+    // row slot v: sums 0..27, fused trial error at 28 (== NSUM), 29..31 zero
+    if (part == 0 && v < PART_STRIDE) {
+      __hip_atomic_store(&P.partials[(size_t)blockIdx.x * PART_STRIDE + v], (v < RED_ROWS && live) ? x : 0.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
@@ -542,13 +547,26 @@ __global__ __launch_bounds__(256) void cost_kernel(CostParams P) {
     red[0][v] = s;
   }
   if (threadIdx.x <= TICKET_GROUPS) P.ticket[threadIdx.x] = 0;  // re-arm for the next launch
+  // The LM step is one thread of dependent fp64 math; run it on an LDS copy of the state (a global
+  // round trip per st-> access would cost more than the arithmetic) and write the state back with all lanes.
+  __shared__ LmState s_st;
+  static_assert(sizeof(LmState) % 8 == 0, "LmState is copied as 64-bit words");
+  constexpr int ST_WORDS = sizeof(LmState) / 8;
+  for (int i = threadIdx.x; i < ST_WORDS; i += 256) reinterpret_cast<unsigned long long*>(&s_st)[i] = reinterpret_cast<const unsigned long long*>(st)[i];
+  int vm_nv = 0, vm_dr = 0;
+  if (threadIdx.x == 0) {
+    vm_nv = P.vm_counters[0];
+    vm_dr = P.vm_counters[1] + (P.vm_counters2 ? P.vm_counters2[1] : 0);
+  }
   __syncthreads();
   if (threadIdx.x == 0) {
-    for (int v = 0; v < PART_STRIDE; v++) st->sums[v] = red[0][v];
-    st->vm_num_voxels = P.vm_counters[0];
-    st->vm_dropped = P.vm_counters[1] + (P.vm_counters2 ? P.vm_counters2[1] : 0);
-    if (P.host_phase < 0 && !P.defer_lm) dev_lm_step(st, red[0]);
+    for (int v = 0; v < PART_STRIDE; v++) s_st.sums[v] = red[0][v];
+    s_st.vm_num_voxels = vm_nv;
+    s_st.vm_dropped = vm_dr;
+    if (P.host_phase < 0 && !P.defer_lm) dev_lm_step(&s_st, red[0]);
   }
+  __syncthreads();
+  for (int i = threadIdx.x; i < ST_WORDS; i += 256) reinterpret_cast<unsigned long long*>(st)[i] = reinterpret_cast<const unsigned long long*>(&s_st)[i];
 }
 
 }  // namespace fvh

@@ -16,7 +16,7 @@ namespace fvh {
 constexpr int RADIX_BITS = 9;
 constexpr int RADIX_BINS = 1 << RADIX_BITS;
 constexpr int RADIX_PASSES = 3;
-constexpr int SORT_ITEMS_PER_WAVE = 1024;  // contiguous items a wave owns per pass (16 steps of 64)
+constexpr int SORT_ITEMS_MAX = 1024;  // contiguous items a wave owns per pass (runtime: 256 for small clouds -> more, shorter waves)
 
 // order-preserving float <-> uint mapping for atomicMin/Max
 __device__ __forceinline__ unsigned float_to_ordered(float f) {
@@ -80,14 +80,14 @@ __global__ __launch_bounds__(256) void morton_keys_kernel(const float4* __restri
 }
 
 // hist[bin * nwaves + wave]
-__global__ __launch_bounds__(256) void radix_hist_kernel(const unsigned* __restrict__ keys, int n, int shift, int nwaves, unsigned* __restrict__ hist) {
+__global__ __launch_bounds__(256) void radix_hist_kernel(const unsigned* __restrict__ keys, int n, int shift, int nwaves, int items, unsigned* __restrict__ hist) {
   __shared__ unsigned h[4][RADIX_BINS];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int wave = blockIdx.x * 4 + wv;
   for (int b = lane; b < RADIX_BINS; b += 64) h[wv][b] = 0;
   __syncthreads();
   if (wave < nwaves) {
-    const int begin = wave * SORT_ITEMS_PER_WAVE, end = min(n, begin + SORT_ITEMS_PER_WAVE);
+    const int begin = wave * items, end = min(n, begin + items);
     for (int i = begin + lane; i < end; i += 64) atomicAdd(&h[wv][(keys[i] >> shift) & (RADIX_BINS - 1)], 1u);
   }
   __syncthreads();
@@ -127,7 +127,7 @@ __global__ __launch_bounds__(1024) void radix_scan_kernel(unsigned* __restrict__
 
 // stable scatter of (key, idx); on the last pass also gathers the point into the sorted cloud with
 // its original index in .w
-__global__ __launch_bounds__(256) void radix_scatter_kernel(const unsigned* __restrict__ keys_in, const int* __restrict__ idx_in, int n, int shift, int nwaves,
+__global__ __launch_bounds__(256) void radix_scatter_kernel(const unsigned* __restrict__ keys_in, const int* __restrict__ idx_in, int n, int shift, int nwaves, int items,
                                                             const unsigned* __restrict__ offsets /* scanned hist */, unsigned* __restrict__ keys_out, int* __restrict__ idx_out,
                                                             const float4* __restrict__ pts, float4* __restrict__ sorted_pts) {
   __shared__ unsigned cur[4][RADIX_BINS];
@@ -137,7 +137,7 @@ __global__ __launch_bounds__(256) void radix_scatter_kernel(const unsigned* __re
   for (int b = lane; b < RADIX_BINS; b += 64) cur[wv][b] = offsets[(size_t)b * nwaves + wave];
   // the cursors are private to this wave: wave-level ordering is enough (no workgroup barrier)
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-  const int begin = wave * SORT_ITEMS_PER_WAVE, end = min(n, begin + SORT_ITEMS_PER_WAVE);
+  const int begin = wave * items, end = min(n, begin + items);
   const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
   for (int base = begin; base < end; base += 64) {
     const int i = base + lane;
@@ -171,6 +171,196 @@ __global__ __launch_bounds__(256) void radix_scatter_kernel(const unsigned* __re
         sorted_pts[dst] = p;
       }
     }
+  }
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// Small clouds (n <= SORT_SMALL_MAX): the whole ordering in ONE launch of ONE 1024-thread workgroup.
+// The multi-kernel path above costs ~105 us at 17k points -- nine dependent launches of a handful of
+// waves each, plus a 512 x n_waves histogram matrix to scan -- where the actual work is a few
+// microseconds. Here: bounding box -> 24-bit Morton keys (8 bits/axis) -> three stable 8-bit passes
+// with per-wave LDS histograms (16 waves x 256 bins) -> sorted float4 cloud (.w = original index) ->
+// boxes of its 64-point tiles -> boxes of 64 tiles. (key, idx) ping-pong through global memory (L2
+// resident); all hand-offs are workgroup-local, ordered by __syncthreads().
+// ------------------------------------------------------------------------------------------------
+constexpr int SORT_SMALL_MAX = 32768;
+constexpr int SMALL_BITS = 9, SMALL_BINS = 512, SMALL_WAVES = 16, SMALL_PASSES = 2, SMALL_AXIS_BITS = 6;  // 18-bit Morton: ~1.3 m cells on an 84 m cloud
+
+__device__ __forceinline__ unsigned spread3_8(unsigned v) {  // up to 8 bits -> every third bit
+  v &= 0xFF;
+  v = (v | (v << 8)) & 0x00F00F;
+  v = (v | (v << 4)) & 0x0C30C3;
+  v = (v | (v << 2)) & 0x249249;
+  return v;
+}
+
+__global__ __launch_bounds__(1024) void sort_small_kernel(const float4* __restrict__ pts, int n, unsigned* keysA, int* idxA, unsigned* keysB, int* idxB) {
+  __shared__ unsigned hist[SMALL_WAVES][SMALL_BINS];  // per-wave digit counts, then per-wave scatter cursors
+  __shared__ unsigned bin_total[SMALL_BINS];
+  __shared__ float s_lo[SMALL_WAVES][3], s_hi[SMALL_WAVES][3];
+  __shared__ float s_box[6];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+
+  // ---- bounding cube ----
+  float lo[3] = {3e38f, 3e38f, 3e38f}, hi[3] = {-3e38f, -3e38f, -3e38f};
+  for (int i = tid; i < n; i += 1024) {
+    const float4 p = pts[i];
+    lo[0] = fminf(lo[0], p.x); lo[1] = fminf(lo[1], p.y); lo[2] = fminf(lo[2], p.z);
+    hi[0] = fmaxf(hi[0], p.x); hi[1] = fmaxf(hi[1], p.y); hi[2] = fmaxf(hi[2], p.z);
+  }
+#pragma unroll
+  for (int a = 0; a < 3; a++) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      lo[a] = fminf(lo[a], __shfl_xor(lo[a], off));
+      hi[a] = fmaxf(hi[a], __shfl_xor(hi[a], off));
+    }
+    if (lane == 0) { s_lo[wv][a] = lo[a]; s_hi[wv][a] = hi[a]; }
+  }
+  __syncthreads();
+  if (tid < 3) {
+    float l = s_lo[0][tid], h = s_hi[0][tid];
+    for (int w = 1; w < SMALL_WAVES; w++) { l = fminf(l, s_lo[w][tid]); h = fmaxf(h, s_hi[w][tid]); }
+    s_box[tid] = l;
+    s_box[3 + tid] = h;
+  }
+  __syncthreads();
+  const float lx = s_box[0], ly = s_box[1], lz = s_box[2];
+  const float extent = fmaxf(fmaxf(s_box[3] - lx, s_box[4] - ly), fmaxf(s_box[5] - lz, 1e-6f));
+  const float qmax = (float)((1 << SMALL_AXIS_BITS) - 1);
+  const float scale = (qmax + 0.999f) / extent;
+
+  // each wave owns a contiguous chunk (multiple of 64) -> stable order = (wave, step, lane)
+  const int chunk = (((n + SMALL_WAVES - 1) / SMALL_WAVES) + 63) & ~63;
+  const int begin = wv * chunk, end = min(n, begin + chunk);
+  const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+
+  constexpr int HALF = 16;                                              // 64-item steps held in registers at once
+  constexpr int NHALF = SORT_SMALL_MAX / (SMALL_WAVES * 64 * HALF);      // 2
+  for (int pass = 0; pass < SMALL_PASSES; pass++) {
+    // pass 0 computes keys and writes B, pass 1 reads B and writes A: the final order is always in idxA
+    const unsigned* kin = keysB;
+    const int* iin = idxB;
+    unsigned* kout = (pass == SMALL_PASSES - 1) ? keysA : keysB;
+    int* iout = (pass == SMALL_PASSES - 1) ? idxA : idxB;
+    const int shift = pass * SMALL_BITS;
+    // A half chunk (16 steps x 64 items) goes to registers at once: 16 independent loads in flight instead of
+    // one dependent L2 round trip per step (that chain, not the arithmetic, was the first version's 35 us/pass).
+    auto load_half = [&](int h, unsigned (&key)[HALF], int (&id)[HALF]) {
+#pragma unroll
+      for (int u = 0; u < HALF; u++) {
+        const int i = begin + (h * HALF + u) * 64 + lane;
+        key[u] = 0xFFFFFFFFu;
+        id[u] = -1;
+        if (i < end) {
+          if (pass == 0) {
+            const float4 p = pts[i];
+            const unsigned ix = (unsigned)fminf(qmax, fmaxf(0.f, (p.x - lx) * scale));
+            const unsigned iy = (unsigned)fminf(qmax, fmaxf(0.f, (p.y - ly) * scale));
+            const unsigned iz = (unsigned)fminf(qmax, fmaxf(0.f, (p.z - lz) * scale));
+            key[u] = spread3_8(ix) | (spread3_8(iy) << 1) | (spread3_8(iz) << 2);
+            id[u] = i;
+          } else {
+            key[u] = kin[i];
+            id[u] = iin[i];
+          }
+        }
+      }
+    };
+    for (int b = lane; b < SMALL_BINS; b += 64) hist[wv][b] = 0;
+    __syncthreads();
+#pragma unroll 1
+    for (int h = 0; h < NHALF; h++) {
+      if (begin + h * HALF * 64 >= end) break;
+      unsigned key[HALF];
+      int id[HALF];
+      load_half(h, key, id);
+#pragma unroll
+      for (int u = 0; u < HALF; u++)
+        if (begin + (h * HALF + u) * 64 + lane < end) atomicAdd(&hist[wv][(key[u] >> shift) & (SMALL_BINS - 1)], 1u);
+    }
+    __syncthreads();
+    if (tid < SMALL_BINS) {  // per bin: exclusive prefix over the waves, and the bin total
+      unsigned run = 0;
+      for (int w = 0; w < SMALL_WAVES; w++) { const unsigned c = hist[w][tid]; hist[w][tid] = run; run += c; }
+      bin_total[tid] = run;
+    }
+    __syncthreads();
+    if (wv == 0) {  // exclusive scan of the bin totals: BINS/64 per lane
+      constexpr int PER = SMALL_BINS / 64;
+      unsigned v[PER], sum = 0;
+#pragma unroll
+      for (int j = 0; j < PER; j++) { v[j] = bin_total[lane * PER + j]; sum += v[j]; }
+      unsigned x = sum;
+#pragma unroll
+      for (int off = 1; off < 64; off <<= 1) { const unsigned y = __shfl_up(x, off); if (lane >= off) x += y; }
+      unsigned run = x - sum;
+#pragma unroll
+      for (int j = 0; j < PER; j++) { bin_total[lane * PER + j] = run; run += v[j]; }
+    }
+    __syncthreads();
+    for (int b = lane; b < SMALL_BINS; b += 64) hist[wv][b] += bin_total[b];  // this wave's scatter cursors
+    // (own row only: LDS operations of one wave complete in order, no barrier needed)
+#pragma unroll 1
+    for (int h = 0; h < NHALF; h++) {
+      if (begin + h * HALF * 64 >= end) break;
+      unsigned key[HALF];
+      int id[HALF];
+      load_half(h, key, id);
+#pragma unroll
+      for (int u = 0; u < HALF; u++) {
+        const int i0 = begin + (h * HALF + u) * 64;
+        if (i0 >= end) break;  // wave-uniform
+        const bool valid = (i0 + lane) < end;
+        const unsigned d = (key[u] >> shift) & (SMALL_BINS - 1);
+        unsigned long long peers = __ballot(valid);
+#pragma unroll
+        for (int bit = 0; bit < SMALL_BITS; bit++) {
+          const unsigned long long m = __ballot((d >> bit) & 1);
+          peers &= ((d >> bit) & 1) ? m : ~m;
+        }
+        const int rank = __popcll(peers & lt_mask);
+        const int leader = __ffsll((long long)peers) - 1;
+        unsigned dst_base = 0;
+        if (valid && lane == leader) {
+          dst_base = hist[wv][d];
+          hist[wv][d] = dst_base + (unsigned)__popcll(peers);
+        }
+        dst_base = __shfl(dst_base, leader);
+        if (valid) {
+          kout[dst_base + rank] = key[u];
+          iout[dst_base + rank] = id[u];
+        }
+      }
+    }
+    __syncthreads();  // orders this pass's global writes before the next pass's reads (same workgroup)
+  }
+}
+
+// One wave per 64-point tile: gather the tile's points in sorted order (.w = original index) and
+// box them. Runs on the whole GPU (N/64 independent waves) right after the single-workgroup sort.
+__global__ __launch_bounds__(256) void gather_tiles_kernel(const float4* __restrict__ pts, const int* __restrict__ order, int n, float4* __restrict__ sorted,
+                                                           float4* __restrict__ bbox1) {
+  const int lane = threadIdx.x & 63;
+  const int t = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (t * 64 >= n) return;
+  const int j = t * 64 + lane;
+  const int src = order[min(j, n - 1)];
+  float4 p = pts[src];
+  p.w = __int_as_float(src);
+  if (j < n) sorted[j] = p;
+  float lo[3] = {p.x, p.y, p.z}, hi[3] = {p.x, p.y, p.z};
+#pragma unroll
+  for (int a = 0; a < 3; a++)
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      lo[a] = fminf(lo[a], __shfl_xor(lo[a], off));
+      hi[a] = fmaxf(hi[a], __shfl_xor(hi[a], off));
+    }
+  if (lane == 0) {
+    bbox1[2 * t] = make_float4(lo[0], lo[1], lo[2], 0.f);
+    bbox1[2 * t + 1] = make_float4(hi[0], hi[1], hi[2], 0.f);
   }
 }
 
