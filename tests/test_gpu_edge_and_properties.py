@@ -1,0 +1,207 @@
+"""GPU tests: edge cases of the C ABI, and size-independent properties at BASELINE.json's full sizes (100k / 1M points)
+where the oracle cannot finish in seconds."""
+import numpy as np
+import pytest
+
+from tests import util
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def O():
+    from oracle import oracle
+    return oracle
+
+
+def _core():
+    from fast_gicp_amd import capi
+    return capi.VGICPCore(0)
+
+
+# ---------------------------------------------------------------------------------------------
+# edge cases
+# ---------------------------------------------------------------------------------------------
+def test_error_codes_not_crashes():
+    from fast_gicp_amd import capi
+    c = _core()
+    with pytest.raises(capi.FvhError):
+        c.find_source_neighbors(20)            # no cloud yet
+    with pytest.raises(capi.FvhError):
+        c.create_target_voxelmap()             # no target
+    with pytest.raises(capi.FvhError):
+        c.align()                              # nothing set
+    pts = np.random.default_rng(0).normal(size=(10, 3)).astype(np.float32)
+    c.set_source_cloud(pts)
+    with pytest.raises(capi.FvhError):
+        c.find_source_neighbors(20)            # fewer points than k
+    with pytest.raises(capi.FvhError):
+        c.find_source_neighbors(0)
+    with pytest.raises(capi.FvhError):
+        c.find_source_neighbors(65)            # k > 64 unsupported
+    with pytest.raises(capi.FvhError):
+        c.calculate_source_covariances(7)      # unknown regularisation
+    with pytest.raises(capi.FvhError):
+        c.set_resolution(0.0)
+    with pytest.raises(capi.FvhError):
+        c.set_neighbor_search_method(9)
+    with pytest.raises(capi.FvhError):
+        c.compute_error(np.eye(4))             # no correspondences yet
+    c.set_source_cloud(np.zeros((0, 3), np.float32))  # empty cloud is accepted, then refused where it matters
+    assert c.num_points("source") == 0
+    with pytest.raises(capi.FvhError):
+        c.find_source_neighbors(1)
+    c.close()
+
+
+@pytest.mark.parametrize("n", [20, 21, 63, 64, 65, 129, 1000])
+def test_small_and_ragged_clouds_knn_and_voxelmap(O, n):
+    """Sizes around the 64-point tile and the k boundary, with duplicated points (exact distance ties -> lower index wins)."""
+    rng = np.random.default_rng(n)
+    pts = rng.uniform(-5, 5, size=(n, 3)).astype(np.float32)
+    pts[n // 3] = pts[0]            # exact duplicates
+    pts[n // 2] = pts[1]
+    c = _core()
+    c.set_source_cloud(pts)
+    c.find_source_neighbors(20)
+    assert np.array_equal(c.get_neighbors("source"), O.knn(pts, 20))
+    c.calculate_source_covariances(3)
+    c.swap_source_and_target()      # becomes the target: voxel map from covariances
+    coords, num, means, covs = c.get_voxelmap()
+    oc, on, om, _ = O.voxelmap_vgicp(pts, O.covariances_knn(pts, 20, O.PLANE), 1.0)
+    assert set(map(tuple, coords)) == set(map(tuple, oc)) and int(num.sum()) == n
+    c.close()
+
+
+def test_points_on_voxel_boundaries(O):
+    """coord = floor(p/res - 0.5): boundaries sit at half-integers; fp64 like the CPU reference."""
+    g = np.arange(-3, 4, dtype=np.float64)
+    xs = np.concatenate([g + 0.5, g + 0.5 - 1e-7, g + 0.5 + 1e-7, g])
+    pts = np.stack(np.meshgrid(xs, xs[:5], xs[:3], indexing="ij"), -1).reshape(-1, 3).astype(np.float32)
+    cov = np.tile(np.eye(3), (len(pts), 1, 1))
+    c = _core()
+    c.set_target_cloud(pts); c.set_target_covariances(cov); c.create_target_voxelmap()
+    coords, num, _, _ = c.get_voxelmap()
+    oc, on, _, _ = O.voxelmap_vgicp(pts, cov, 1.0)
+    assert util.voxel_dict(coords, num) == util.voxel_dict(oc, on)
+    c.close()
+
+
+def test_tiny_registration_matches_oracle(O):
+    tgt, src, T = util.synthetic_pair(3000, 2500, seed=7, extent=15.0)
+    c = _core()
+    c.set_neighbor_search_method(1)
+    c.set_target_cloud(tgt); c.find_target_neighbors(20); c.calculate_target_covariances(3); c.create_target_voxelmap()
+    c.set_source_cloud(src); c.find_source_neighbors(20); c.calculate_source_covariances(3)
+    r = c.align()
+    g = O.FastVGICP(search=O.DIRECT7)
+    g.set_target(tgt); g.set_source(src)
+    ro = g.align()
+    assert r["converged"] == ro["converged"] and util.rel_err(r["T"], ro["T"]) < 1e-4
+    te, re_ = util.pose_error(T, r["T"])
+    assert te < 0.05 and re_ < np.radians(0.5)
+    c.close()
+
+
+# ---------------------------------------------------------------------------------------------
+# full-size properties
+# ---------------------------------------------------------------------------------------------
+@pytest.fixture(scope="module")
+def big():
+    return util.synthetic_pair(1_000_000, 100_000, seed=44, extent=150.0)
+
+
+def test_knn_optimality_and_order_invariance_100k(big):
+    _, src, _ = big
+    c = _core()
+    c.set_source_cloud(src); c.find_source_neighbors(20)
+    nb = c.get_neighbors("source")
+    assert nb.shape == (len(src), 20) and nb.min() >= 0 and nb.max() < len(src)
+    assert (nb[:, 0] == np.arange(len(src))).mean() > 0.999          # self first (distance 0)
+    rng = np.random.default_rng(1)
+    p64 = src.astype(np.float64)
+    for q in rng.integers(0, len(src), 40):                           # brute-force check on a sample of queries
+        d = ((p64 - p64[q]) ** 2).sum(1)
+        kth = np.partition(d, 19)[19]
+        assert d[nb[q]].max() <= kth * (1 + 1e-6) + 1e-12
+        assert np.all(np.diff(d[nb[q]]) >= -1e-9)                     # ascending
+    # permutation invariance: same neighbour SETS (as points) when the input order is shuffled
+    perm = rng.permutation(len(src))
+    c2 = _core()
+    c2.set_source_cloud(src[perm]); c2.find_source_neighbors(20)
+    nb2 = c2.get_neighbors("source")
+    inv = np.empty_like(perm); inv[perm] = np.arange(len(perm))
+    sample = rng.integers(0, len(src), 2000)
+    d_a = np.sort(((p64[nb[sample]] - p64[sample][:, None]) ** 2).sum(-1), axis=1)
+    d_b = np.sort(((p64[perm][nb2[inv[sample]]] - p64[sample][:, None]) ** 2).sum(-1), axis=1)
+    assert np.array_equal(d_a, d_b)
+    c.close(); c2.close()
+
+
+def test_voxelmap_conservation_and_order_invariance_1m(big):
+    tgt, _, _ = big
+    rng = np.random.default_rng(2)
+    c = _core()
+    c.set_resolution(0.5)
+    c.set_target_cloud(tgt); c.calculate_target_covariances_rbf(3); c.create_target_voxelmap()
+    coords, num, means, covs = c.get_voxelmap()
+    assert int(num.sum()) == len(tgt)                                 # no point dropped
+    assert len(np.unique(coords, axis=0)) == len(coords)              # no duplicate voxel
+    keys = np.floor(tgt.astype(np.float64) / 0.5 - 0.5).astype(np.int64)
+    assert len(np.unique(keys, axis=0)) == len(coords)                # exactly the occupied voxels
+    # count-weighted mean of the voxel means = cloud mean (linearity of the accumulation)
+    np.testing.assert_allclose((means.astype(np.float64) * num[:, None]).sum(0) / len(tgt), tgt.astype(np.float64).mean(0), atol=2e-5)
+    sel = rng.integers(0, len(coords), 200)
+    for s in sel:
+        m = (keys == coords[s]).all(1)
+        assert m.sum() == num[s]
+        np.testing.assert_allclose(means[s], tgt[m].astype(np.float64).mean(0), atol=1e-5)
+    c.close()
+
+
+def test_cost_shard_additivity_and_determinism_100k(big):
+    """err/H/b of the whole source == sum over spatial tiles (what the multi-GPU all-reduce relies on); repeated
+    evaluations are bit-identical (fixed-order reduction)."""
+    from fast_gicp_amd import distributed as D
+    tgt, src, T = big
+    tgt = tgt[:300_000]
+    c = _core()
+    c.set_resolution(0.5); c.set_neighbor_search_method(1)
+    c.set_target_cloud(tgt); c.calculate_target_covariances_rbf(3); c.create_target_voxelmap()
+    c.set_source_cloud(src); c.calculate_source_covariances_rbf(3)
+    covs = c.get_covariances("source").astype(np.float64)
+    e, H, b = c.linearize(T)
+    e2, H2, b2 = c.linearize(T)
+    assert e == e2 and np.array_equal(H, H2) and np.array_equal(b, b2)
+    n_all = c.get_num_correspondences()
+    tot = np.zeros(43); n_sum = 0
+    for tile in D.spatial_tile_partition(src, 4):
+        c.set_source_cloud(src[tile]); c.set_source_covariances(covs[tile])
+        et, Ht, bt = c.linearize(T)
+        tot += np.concatenate([[et], bt, Ht.reshape(-1)])
+        n_sum += c.get_num_correspondences()
+    assert n_sum == n_all
+    assert abs(tot[0] - e) <= 1e-11 * abs(e)
+    assert util.rel_err(tot[7:].reshape(6, 6), H) < 1e-11 and util.rel_err(tot[1:7], b) < 1e-11
+    c.close()
+
+
+def test_registration_recovers_ground_truth_1m_map(big):
+    """BASELINE configs[4] shape on one GPU: 1M-point map <-> 100k scan, DIRECT7, res 0.5."""
+    tgt, src, T = big
+    c = _core()
+    c.set_resolution(0.5); c.set_neighbor_search_method(1)
+    c.set_target_cloud(tgt); c.find_target_neighbors(20); c.calculate_target_covariances(3); c.create_target_voxelmap()
+    c.set_source_cloud(src); c.find_source_neighbors(20); c.calculate_source_covariances(3)
+    r = c.align()
+    assert r["converged"]
+    te, re_ = util.pose_error(T, r["T"])
+    assert te < 0.02 and re_ < np.radians(0.1)
+    # rigid equivariance: moving the scan by a known G must give T * G^-1
+    G = util.random_pose(np.random.default_rng(5), 1.0, 0.3)
+    src2 = (src.astype(np.float64) @ G[:3, :3].T + G[:3, 3]).astype(np.float32)
+    c.set_source_cloud(src2); c.find_source_neighbors(20); c.calculate_source_covariances(3)
+    r2 = c.align()
+    te2, re2 = util.pose_error(T @ np.linalg.inv(G), r2["T"])
+    assert r2["converged"] and te2 < 0.02 and re2 < np.radians(0.1)
+    c.close()
