@@ -33,7 +33,7 @@ def parse():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--workload", default="bundled17k", choices=["bundled17k", "synth100k", "synth1m"])
-    ap.add_argument("--search", default="DIRECT27", choices=["DIRECT1", "DIRECT7", "DIRECT27"])
+    ap.add_argument("--search", default=None, choices=["DIRECT1", "DIRECT7", "DIRECT27"])
     ap.add_argument("--cov", default="knn", choices=["knn", "rbf"])
     ap.add_argument("--precision", default="fp64", choices=["fp64", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -113,6 +113,8 @@ def main():
     dev = torch.device("cuda", local_rank)
 
     tgt, src, res, desc = make_workload(args.workload)
+    if args.search is None:
+        args.search = "DIRECT7" if args.workload == "synth1m" else "DIRECT27"
     search = {"DIRECT27": capi.DIRECT27, "DIRECT7": capi.DIRECT7, "DIRECT1": capi.DIRECT1}[args.search]
     K = 20
     d_clouds = [torch.from_numpy(tgt).to(dev).contiguous(), torch.from_numpy(src).to(dev).contiguous()]  # inputs resident in HBM
@@ -145,14 +147,22 @@ def main():
 
     state = {"next": 0, "last": first}  # after "single": target = cloud 0, source = cloud 1
 
-    def step():
-        # reg.swapSourceAndTarget(); reg.clearSource(); reg.setInputTarget(target_) [no-op]; reg.setInputSource(source_); reg.align()
-        core.swap_source_and_target()
-        i = state["next"]
-        core.set_source_cloud_device(d_clouds[i].data_ptr(), n_pts[i], 3)
-        estimate_cov("source")
-        state["last"] = core.align()
-        state["next"] = 1 - i
+    if args.workload == "synth1m":
+        # map-vs-scan localisation (BASELINE configs[4] shape): the 1M-point map stays the target, every step registers a scan
+        def step():
+            core.set_source_cloud_device(d_clouds[1].data_ptr(), n_pts[1], 3)
+            estimate_cov("source")
+            state["last"] = core.align()
+            state["next"] = 0
+    else:
+        def step():
+            # reg.swapSourceAndTarget(); reg.clearSource(); reg.setInputTarget(target_) [no-op]; reg.setInputSource(source_); reg.align()
+            core.swap_source_and_target()
+            i = state["next"]
+            core.set_source_cloud_device(d_clouds[i].data_ptr(), n_pts[i], 3)
+            estimate_cov("source")
+            state["last"] = core.align()
+            state["next"] = 1 - i
 
     for _ in range(args.warmup):
         step()
@@ -208,10 +218,17 @@ def main():
         if cost_n:
             avg_s = cost_ms / cost_n * 1e-3
             achieved = bytes_eval / avg_s / 1e9
+            traffic = None
+            try:  # HBM bytes per launch from the committed PMC pass (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate runs; FETCH doubled per the gfx950 note)
+                pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_cost_kernel.json")))
+                traffic = pmc.get(args.workload, {}).get("hbm_bytes_per_launch")
+            except Exception:
+                pass
             roofline = {"kernel": "cost_kernel<double,VGICP>" if args.precision == "fp64" else "cost_kernel<float,VGICP>", "bound": "hbm", "achieved": round(achieved, 2),
-                        "peak": 8000.0, "unit": "GB/s", "frac": round(achieved / 8000.0, 5), "traffic": None, "algorithmic_bytes_per_launch": bytes_eval,
+                        "peak": 8000.0, "unit": "GB/s", "frac": round(achieved / 8000.0, 5), "traffic": traffic, "algorithmic_bytes_per_launch": bytes_eval,
                         "avg_launch_us": round(avg_s * 1e6, 3), "launches": cost_n,
-                        "note": "17k-point working set (~3 MB) is L2/Infinity-Cache resident: this kernel is latency/launch bound, not HBM bound"}
+                        "note": ("17k-point working set (~3 MB) is L2/Infinity-Cache resident: this kernel is latency/launch bound, not HBM bound" if args.workload == "bundled17k"
+                                 else "launch average includes the early-exit launches issued after convergence")}
     if args.cov == "knn" and "knn" in stage_ms:
         n = n_src
         flops = 8.0 * n * n

@@ -45,11 +45,17 @@ struct DevBuf {
 struct CloudDev {
   int n = 0, k = 0;
   DevBuf bbox2;                        // boxes of 64 consecutive tile boxes
+  DevBuf order;                        // Morton permutation: order[j] = original index of the j-th point along the curve
   DevBuf pts, cov, nbr, bbox, sorted;  // sorted: Morton-ordered copy, .w = original index; bbox: boxes of its 64-point tiles
   bool has_pts = false, has_cov = false, has_nbr = false, has_sorted = false;
   void swap(CloudDev& o) { std::swap(*this, o); }
-  void release() { pts.release(); cov.release(); nbr.release(); bbox.release(); bbox2.release(); sorted.release(); }
+  void release() { pts.release(); cov.release(); nbr.release(); bbox.release(); bbox2.release(); sorted.release(); order.release(); }
 };
+
+// Clouds of this size and up are walked in Morton order (PMC: 2.8x HBM over-fetch on a randomly ordered 100k scan
+// against a 1M-point map). Below it everything is L2-resident and the extra index load is not worth it.
+constexpr int COHERENT_MIN_POINTS = 32768;
+inline const int* coherent_order(const CloudDev& c) { return (c.has_sorted && c.n >= COHERENT_MIN_POINTS) ? c.order.as<int>() : nullptr; }
 
 struct VoxelMapDev {
   double res = 1.0;
@@ -267,15 +273,16 @@ int ensure_sorted(Engine* e, CloudDev& c) {
   HIP_OR_FAIL(e, c.sorted.ensure(sizeof(float4) * (size_t)n));
   HIP_OR_FAIL(e, c.bbox.ensure(sizeof(float4) * 2 * (size_t)ntiles));
   HIP_OR_FAIL(e, e->sort_keys.ensure(sizeof(unsigned) * 2 * (size_t)n + 64));
-  HIP_OR_FAIL(e, e->sort_idx.ensure(sizeof(int) * 2 * (size_t)n));
+  HIP_OR_FAIL(e, e->sort_idx.ensure(sizeof(int) * (size_t)n));
+  HIP_OR_FAIL(e, c.order.ensure(sizeof(int) * (size_t)n));
   HIP_OR_FAIL(e, e->sort_hist.ensure(sizeof(unsigned) * (size_t)RADIX_BINS * nwaves));
   const int nsuper_small = (ntiles + 63) / 64;
   HIP_OR_FAIL(e, c.bbox2.ensure(sizeof(float4) * 2 * (size_t)nsuper_small));
   ProfScope ps(e, "sort");
   static const int sort_mode = [] { const char* v = getenv("FVH_SORT_MODE"); return v ? atoi(v) : 1; }();  // 1: single-workgroup path for small clouds
   if (sort_mode == 1 && n <= SORT_SMALL_MAX) {
-    sort_small_kernel<<<1, 1024, 0, e->stream>>>(c.pts.as<float4>(), n, e->sort_keys.as<unsigned>(), e->sort_idx.as<int>(), e->sort_keys.as<unsigned>() + n, e->sort_idx.as<int>() + n);
-    gather_tiles_kernel<<<(ntiles + 3) / 4, 256, 0, e->stream>>>(c.pts.as<float4>(), e->sort_idx.as<int>(), n, c.sorted.as<float4>(), c.bbox.as<float4>());
+    sort_small_kernel<<<1, 1024, 0, e->stream>>>(c.pts.as<float4>(), n, e->sort_keys.as<unsigned>(), c.order.as<int>(), e->sort_keys.as<unsigned>() + n, e->sort_idx.as<int>());
+    gather_tiles_kernel<<<(ntiles + 3) / 4, 256, 0, e->stream>>>(c.pts.as<float4>(), c.order.as<int>(), n, c.sorted.as<float4>(), c.bbox.as<float4>());
     super_bbox_kernel<<<(nsuper_small + 3) / 4, 256, 0, e->stream>>>(c.bbox.as<float4>(), ntiles, c.bbox2.as<float4>());
     HIP_OR_FAIL(e, hipGetLastError());
     c.has_sorted = true;
@@ -286,7 +293,7 @@ int ensure_sorted(Engine* e, CloudDev& c) {
   HIP_OR_FAIL(e, hipMemsetAsync(box + 3, 0, 12, e->stream));
   cloud_bbox_kernel<<<std::min(256, (n + 255) / 256), 256, 0, e->stream>>>(c.pts.as<float4>(), n, box);
   unsigned* keys[2] = {e->sort_keys.as<unsigned>(), e->sort_keys.as<unsigned>() + n};
-  int* idx[2] = {e->sort_idx.as<int>(), e->sort_idx.as<int>() + n};
+  int* idx[2] = {e->sort_idx.as<int>(), c.order.as<int>()};  // 3 passes: the final permutation lands in idx[1] = the cloud's own buffer
   morton_keys_kernel<<<(n + 255) / 256, 256, 0, e->stream>>>(c.pts.as<float4>(), n, box, keys[0], idx[0]);
   const int wblocks = (nwaves + 3) / 4;
   for (int pass = 0; pass < RADIX_PASSES; pass++) {
@@ -454,7 +461,7 @@ int build_voxelmap(Engine* e, const CloudDev& c, VoxelMapDev& vm, double res, bo
     HIP_OR_FAIL(e, hipMemsetAsync(vm.counters.p, 0, 64, e->stream));
     if (c.n) {
       vm_accumulate_kernel<MODE><<<(c.n + 255) / 256, 256, 0, e->stream>>>(c.pts.as<float4>(), c.cov.as<float4>(), c.n, res, vm.table.as<unsigned long long>(), cap - 1,
-                                                                           vm.acc.as<double>(), vm.counters.as<int>() + 1);
+                                                                           vm.acc.as<double>(), vm.counters.as<int>() + 1, coherent_order(c));
       vm_finalize_kernel<MODE><<<(cap + 255) / 256, 256, 0, e->stream>>>(vm.table.as<uint4>(), cap, vm.acc.as<double>(), vm.counters.as<int>(), vm.occupied.as<int>(),
                                                                         want_compact ? vm.compact_pts.as<float4>() : nullptr, want_compact ? vm.compact_cov.as<float4>() : nullptr);
     }
@@ -507,13 +514,14 @@ int get_voxels_host(Engine* e, VoxelMapDev& vm, int* coords3, int* num_points, f
 struct CostSource {
   const float4* pts; const float4* cov; const int* d_n; int n_upper;
   const int* counters2;  // source voxel map counters (D2D) or null
+  const int* order;      // Morton permutation of the source (large clouds) or null
 };
 
 template <int MODE>
 int launch_cost(Engine* e, const CostSource& src, const VoxelMapDev& vm, int host_phase, const PoseD* lin, const PoseD* ev) {
   CostParams P;
   std::memset(&P, 0, sizeof(P));
-  P.src_pts = src.pts; P.src_cov = src.cov; P.d_n_src = src.d_n; P.n_src = src.n_upper;
+  P.src_pts = src.pts; P.src_cov = src.cov; P.d_n_src = src.d_n; P.n_src = src.n_upper; P.order = src.order;
   P.table = vm.table.as<uint4>(); P.mask = vm.capacity - 1; P.res = vm.res;
   P.offsets = e->offsets_dev.as<int>(); P.n_off = e->n_off;
   static const long long target_items = [] { const char* v = getenv("FVH_COST_TARGET_ITEMS"); return v ? atoll(v) : 256LL * 256 * 2; }();
@@ -722,7 +730,7 @@ struct fvh_vgicp {
   double resolution = 1.0, kernel_width = 0.25, kernel_max_dist = 3.0;  // fast_vgicp_cuda.cu:22-26
   CloudDev source, target;
   VoxelMapDev voxelmap;
-  CostSource cost_source() const { return CostSource{source.pts.as<float4>(), source.cov.as<float4>(), nullptr, source.n, nullptr}; }
+  CostSource cost_source() const { return CostSource{source.pts.as<float4>(), source.cov.as<float4>(), nullptr, source.n, nullptr, coherent_order(source)}; }
   Rebuild rebuild_safe() { return [this] { return build_voxelmap<0>(&e, target, voxelmap, voxelmap.res, false, true); }; }
 };
 
@@ -733,8 +741,8 @@ struct fvh_ndt {
   CloudDev source, target;
   VoxelMapDev source_vm, target_vm;
   CostSource cost_source() const {
-    if (distance_mode == FVH_NDT_P2D) return CostSource{source.pts.as<float4>(), nullptr, nullptr, source.n, nullptr};
-    return CostSource{source_vm.compact_pts.as<float4>(), source_vm.compact_cov.as<float4>(), source_vm.counters.as<int>(), source.n, source_vm.counters.as<int>()};
+    if (distance_mode == FVH_NDT_P2D) return CostSource{source.pts.as<float4>(), nullptr, nullptr, source.n, nullptr, coherent_order(source)};
+    return CostSource{source_vm.compact_pts.as<float4>(), source_vm.compact_cov.as<float4>(), source_vm.counters.as<int>(), source.n, source_vm.counters.as<int>(), nullptr};
   }
   Rebuild rebuild_safe() {
     return [this] {

@@ -52,6 +52,7 @@ struct CostParams {
   const float4* src_pts;
   const float4* src_cov;      // null for P2D
   const int* d_n_src;         // device-side count (D2D source voxels) or null
+  const int* order;           // optional Morton permutation of the source: work item w handles element order[w] (coherent lookups)
   int n_src;
   const uint4* table;
   unsigned mask;
@@ -342,8 +343,9 @@ __global__ __launch_bounds__(256) void cost_kernel(CostParams P) {
 
   const float4* tf = reinterpret_cast<const float4*>(P.table);
   for (int w = blockIdx.x * 256 + threadIdx.x; w < n_items; w += gridDim.x * 256) {
-    const int i = w / P.groups_per_src;
-    const int g = w - i * P.groups_per_src;
+    const int i0 = w / P.groups_per_src;
+    const int g = w - i0 * P.groups_per_src;
+    const int i = P.order ? P.order[i0] : i0;
     // ---- round trip 1: the source element ----
     const float4 a4 = P.src_pts[i];
     float4 c0 = make_float4(0, 0, 0, 0), c1 = c0;

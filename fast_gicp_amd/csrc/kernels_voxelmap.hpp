@@ -53,7 +53,7 @@ __device__ __forceinline__ unsigned global_claim(unsigned long long* table_keys6
 template <int MODE>
 __global__ __launch_bounds__(256) void vm_accumulate_kernel(const float4* __restrict__ pts, const float4* __restrict__ cov, int n, double res,
                                                             unsigned long long* __restrict__ table_keys, unsigned mask, double* __restrict__ acc,
-                                                            int* __restrict__ dropped) {
+                                                            int* __restrict__ dropped, const int* __restrict__ order) {
   __shared__ unsigned long long lkey[VM_LDS_SLOTS];
   __shared__ double lacc[VM_LDS_SLOTS * VM_ACC_STRIDE];
   const int tid = threadIdx.x;
@@ -61,8 +61,9 @@ __global__ __launch_bounds__(256) void vm_accumulate_kernel(const float4* __rest
   for (int s = tid; s < VM_LDS_SLOTS * VM_ACC_STRIDE; s += 256) lacc[s] = 0.0;
   __syncthreads();
 
-  const int i = blockIdx.x * 256 + tid;
-  if (i < n) {
+  const int i0 = blockIdx.x * 256 + tid;
+  if (i0 < n) {
+    const int i = order ? order[i0] : i0;  // Morton order: a workgroup's 256 points share a handful of voxels -> the LDS stage absorbs them
     const float4 p = pts[i];
     // fp64 coordinate, as the CPU reference (fast_vgicp_voxel.hpp:158-160)
     const int cx = (int)floor((double)p.x / res - 0.5), cy = (int)floor((double)p.y / res - 0.5), cz = (int)floor((double)p.z / res - 0.5);
