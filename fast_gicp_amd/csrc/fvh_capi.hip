@@ -132,7 +132,7 @@ struct Engine {
   bool has_corr = false;
   int corr_n_src = 0;
   int corr_sel = 0;        // which of the two correspondence buffers the host-mode calls use
-  int last_steps = 0;
+  int last_steps = 0, prev_steps = 0;  // launches the last two aligns needed (odometry loops alternate directions)
   Profiler prof;
   void* comm = nullptr;
   int nranks = 1, rank = 0;
@@ -326,27 +326,8 @@ int find_neighbors(Engine* e, CloudDev& c, int k) {
   } else {
     int rc = ensure_sorted(e, c);
     if (rc) return rc;
-    static const bool knn_stats = getenv("FVH_KNN_STATS") != nullptr;
-    static const int knn_dbg = [] { const char* v = getenv("FVH_KNN_DEBUG"); return v ? atoi(v) : 0; }();
-    unsigned* d_stats = knn_stats ? e->misc.as<unsigned>() + 8 : nullptr;
-    if (knn_stats) HIP_OR_FAIL(e, hipMemsetAsync(d_stats, 0, 16, e->stream));
-    {
-      ProfScope ps(e, "knn");
-      static const int knn_q = [] { const char* v = getenv("FVH_KNN_Q"); return v ? atoi(v) : 0; }();
-      const int qwaves = knn_q > 0 ? (c.n + knn_q - 1) / knn_q : c.n;
-      const dim3 grid((qwaves + 3) / 4);
-      if (knn_q == 0) knn_tiled1_kernel<<<(c.n + 3) / 4, 256, 0, e->stream>>>(c.sorted.as<float4>(), c.bbox.as<float4>(), c.bbox2.as<float4>(), c.n, k, c.nbr.as<int>());
-      else if (knn_q == 8) knn_tiled_kernel<8><<<grid, 256, 0, e->stream>>>(c.sorted.as<float4>(), c.bbox.as<float4>(), c.n, k, c.nbr.as<int>(), d_stats, knn_dbg);
-      else if (knn_q == 4) knn_tiled_kernel<4><<<grid, 256, 0, e->stream>>>(c.sorted.as<float4>(), c.bbox.as<float4>(), c.n, k, c.nbr.as<int>(), d_stats, knn_dbg);
-      else if (knn_q == 1) knn_tiled_kernel<1><<<grid, 256, 0, e->stream>>>(c.sorted.as<float4>(), c.bbox.as<float4>(), c.n, k, c.nbr.as<int>(), d_stats, knn_dbg);
-      else knn_tiled_kernel<2><<<grid, 256, 0, e->stream>>>(c.sorted.as<float4>(), c.bbox.as<float4>(), c.n, k, c.nbr.as<int>(), d_stats, knn_dbg);
-    }
-    if (knn_stats) {
-      unsigned hs[4] = {0, 0, 0, 0};
-      HIP_OR_FAIL(e, hipMemcpyAsync(hs, d_stats, 16, hipMemcpyDeviceToHost, e->stream));
-      HIP_OR_FAIL(e, hipStreamSynchronize(e->stream));
-      std::fprintf(stderr, "[knn stats] n=%d waves=%d tiles=%d swept/wave=%.1f (max %u) insertions/query=%.1f\n", c.n, waves, (c.n + 63) / 64, (double)hs[0] / waves, hs[2], (double)hs[1] / c.n);
-    }
+    ProfScope ps(e, "knn");
+    knn_tiled1_kernel<<<(c.n + 3) / 4, 256, 0, e->stream>>>(c.sorted.as<float4>(), c.bbox.as<float4>(), c.bbox2.as<float4>(), c.n, k, c.nbr.as<int>());
   }
   HIP_OR_FAIL(e, hipGetLastError());
   c.k = k;
@@ -619,7 +600,7 @@ int do_align(Engine* e, const CostSource& src, VoxelMapDev& vm, const double* gu
   HIP_OR_FAIL(e, hipGetLastError());
   const long long budget = (long long)std::max(p.max_iterations, 0) * (1 + (long long)std::max(p.lm_max_iterations, 0)) + 1;
   long long launched = 0;
-  int batch = e->last_steps > 0 ? e->last_steps + 1 : 8;
+  int batch = e->last_steps > 0 ? std::max(e->last_steps, e->prev_steps) + 1 : 8;
   LmState* h = reinterpret_cast<LmState*>(e->pinned);
   while (true) {
     for (int s = 0; s < batch; s++) {
@@ -644,6 +625,7 @@ int do_align(Engine* e, const CostSource& src, VoxelMapDev& vm, const double* gu
     if (rc) return rc;
     return do_align<MODE>(e, src, vm, guess16, params, result, rebuild_safe, true);
   }
+  e->prev_steps = e->last_steps;
   e->last_steps = 1 + h->num_error_evals;  // launches this align needed: the first linearize + one fused launch per trial
   e->lin = h->x_lin;
   e->corr_sel = h->corr_cur;

@@ -195,129 +195,6 @@ __device__ __forceinline__ float box_gap_sq(const float4& bl, const float4& bh, 
   return (gx * gx + gy * gy + gz * gz) * 0.99999f;
 }
 
-// lane l <- v (v wave-uniform), other lanes keep `old`
-__device__ __forceinline__ float write_lane(float v, int l, float old) { return ((int)(threadIdx.x & 63) == l) ? v : old; }
-__device__ __forceinline__ int write_lane(int v, int l, int old) { return ((int)(threadIdx.x & 63) == l) ? v : old; }
-
-// spts: Morton-sorted cloud, .w = original index (bit pattern). out_idx rows/values are ORIGINAL
-// indices, each row ascending in (distance, original index).
-//
-// Code-size discipline: an earlier version unrolled everything over the Q queries (24 inlined copies
-// of the insertion loop + 8 bitonic sorts, ~40 KB of ISA) and ran 10x slower than its instruction
-// count because 16 waves per CU thrashed the instruction cache. Here all per-query state is
-// dynamically indexable by a wave-uniform j -- queries and thresholds live in lane j of a register
-// (v_readlane / v_writelane), the top-k lists in a per-wave LDS row (each lane touches only its own
-// slot) -- so there is ONE sweep site, ONE insertion loop and a non-unrolled seed loop.
-template <int Q>
-__global__ __launch_bounds__(256) void knn_tiled_kernel(const float4* __restrict__ spts, const float4* __restrict__ bbox, int n, int k, int* __restrict__ out_idx,
-                                                        unsigned* __restrict__ stats, int dbg) {
-  __shared__ float s_ld[4][Q][64];
-  __shared__ int s_li[4][Q][64];
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  const int wave = blockIdx.x * 4 + wv;
-  const int q_base = wave * Q;
-  if (q_base >= n) return;  // no workgroup barrier below: waves are independent
-  const int ntiles = (n + 63) >> 6;
-  float (*L_d)[64] = s_ld[wv];
-  int (*L_i)[64] = s_li[wv];
-  const float4 qv = spts[min(q_base + (lane & (Q - 1)), n - 1)];  // lane j (< Q) holds query j
-  float tau_dv = __builtin_inff();  // lane j: current k-th distance of query j
-  int tau_iv = 0x7fffffff;          //         and its index
-  unsigned swept = 0, inserted = 0;
-
-  // ---- seed: bitonic-sort the own tile for every query ----
-  const int t0 = q_base >> 6;
-  {
-    const float4 p = load_candidate(spts, (t0 << 6) + lane, n);
-    const int po = (((t0 << 6) + lane) < n) ? __float_as_int(p.w) : 0x7fffffff;
-#pragma unroll 1
-    for (int j = 0; j < Q; j++) {
-      float d = sqdist_nofma(p, read_lane(qv.x, j), read_lane(qv.y, j), read_lane(qv.z, j));
-      int i = po;
-      wave_bitonic_sort(d, i, lane);
-      L_d[j][lane] = d;
-      L_i[j][lane] = i;
-      tau_dv = write_lane(read_lane(d, k - 1), j, tau_dv);
-      tau_iv = write_lane(read_lane(i, k - 1), j, tau_iv);
-    }
-    swept++;
-  }
-
-  // ---- all other tiles: pseudo-chunk -64 = the two Morton neighbours, then 64 tile boxes per step ----
-  for (int chunk = (dbg & 2) ? 0 : -64; chunk < ((dbg & 1) ? 0 : ntiles); chunk += 64) {
-    int t;
-    bool cand;
-    float lb[Q];
-    if (chunk < 0) {
-      t = (lane == 0) ? t0 + 1 : t0 - 1;
-      cand = (lane < 2) && t >= 0 && t < ntiles;
-#pragma unroll
-      for (int j = 0; j < Q; j++) lb[j] = 0.f;
-    } else {
-      t = chunk + lane;
-      const float4 bl = bbox[2 * min(t, ntiles - 1)], bh = bbox[2 * min(t, ntiles - 1) + 1];
-      bool any = false;
-#pragma unroll
-      for (int j = 0; j < Q; j++) {  // per-QUERY point-to-box lower bounds
-        const float x = read_lane(qv.x, j), y = read_lane(qv.y, j), z = read_lane(qv.z, j);
-        const float gx = fmaxf(0.f, fmaxf(bl.x - x, x - bh.x));
-        const float gy = fmaxf(0.f, fmaxf(bl.y - y, y - bh.y));
-        const float gz = fmaxf(0.f, fmaxf(bl.z - z, z - bh.z));
-        lb[j] = (gx * gx + gy * gy + gz * gz) * 0.99999f;  // never above the fp32-rounded exact distance
-        any |= (lb[j] <= read_lane(tau_dv, j));
-      }
-      cand = (t < ntiles) && (t < t0 - 1 || t > t0 + 1) && any;
-    }
-    unsigned long long tmask = __ballot(cand);
-    while (tmask) {  // wave-uniform: one surviving tile at a time
-      const int src = __ffsll((long long)tmask) - 1;
-      tmask &= tmask - 1;
-      const int tt = read_lane(t, src);
-      unsigned need = 0;
-#pragma unroll
-      for (int j = 0; j < Q; j++) need |= (read_lane(lb[j], src) <= read_lane(tau_dv, j)) ? (1u << j) : 0u;  // thresholds may have tightened
-      if (!need || (dbg & 4)) continue;
-      swept++;
-      const float4 p = load_candidate(spts, (tt << 6) + lane, n);
-      const int po = __float_as_int(p.w);
-      while (need) {  // the single insertion site
-        const int j = __ffs(need) - 1;
-        need &= need - 1;
-        const float d = sqdist_nofma(p, read_lane(qv.x, j), read_lane(qv.y, j), read_lane(qv.z, j));
-        float td = read_lane(tau_dv, j);
-        int ti = read_lane(tau_iv, j);
-        unsigned long long mask = __ballot(d <= td);
-        if (!mask) continue;
-        float ld = L_d[j][lane];
-        int li = L_i[j][lane];
-        while (mask) {
-          const int c = __ffsll((long long)mask) - 1;
-          mask &= mask - 1;
-          const float cd = read_lane(d, c);
-          const int ci = read_lane(po, c);
-          if (!(cd < td || (cd == td && ci < ti))) continue;
-          inserted++;
-          const int pos = __popcll(__ballot(ld < cd || (ld == cd && li < ci)));
-          const float sd = wave_shr1(ld, ld);
-          const int si = wave_shr1(li, li);
-          ld = (lane > pos) ? sd : ((lane == pos) ? cd : ld);
-          li = (lane > pos) ? si : ((lane == pos) ? ci : li);
-          td = read_lane(ld, k - 1);
-          ti = read_lane(li, k - 1);
-        }
-        L_d[j][lane] = ld;
-        L_i[j][lane] = li;
-        tau_dv = write_lane(td, j, tau_dv);
-        tau_iv = write_lane(ti, j, tau_iv);
-      }
-    }
-  }
-#pragma unroll 1
-  for (int j = 0; j < Q; j++)
-    if (q_base + j < n && lane < k) out_idx[(size_t)read_lane(__float_as_int(qv.w), j) * k + lane] = L_i[j][lane];
-  if (stats && lane == 0) { atomicAdd(stats, swept); atomicAdd(stats + 1, inserted); atomicMax(stats + 2, swept); }
-}
-
 // boxes of 64 consecutive level-1 boxes (one wave per super tile)
 __global__ __launch_bounds__(256) void super_bbox_kernel(const float4* __restrict__ bbox1, int ntiles, float4* __restrict__ bbox2) {
   const int lane = threadIdx.x & 63;

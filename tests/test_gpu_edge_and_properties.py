@@ -205,3 +205,35 @@ def test_registration_recovers_ground_truth_1m_map(big):
     te2, re2 = util.pose_error(T @ np.linalg.inv(G), r2["T"])
     assert r2["converged"] and te2 < 0.02 and re2 < np.radians(0.1)
     c.close()
+
+
+def test_full_sweep_modes_agree_with_culled_modes():
+    """The un-culled LDS-tiled sweeps (FVH_KNN_MODE/FVH_RBF_MODE/FVH_FIT_MODE=0) ship as selectable modes: same results."""
+    import os
+    import subprocess
+    import sys
+    code = r'''
+import sys, numpy as np
+sys.path.insert(0, %r)
+from tests import util
+from fast_gicp_amd import capi
+tgt, src = util.bundled_pair()
+src = src[:9000]
+c = capi.VGICPCore(0)
+c.set_kernel_params(0.5, 2.5)
+c.set_target_cloud(tgt); c.set_source_cloud(src)
+c.find_source_neighbors(20); nb = c.get_neighbors("source")
+c.calculate_source_covariances_rbf(3); cov = c.get_covariances("source")
+f = c.fitness_score(util.relative_pose())
+np.savez(sys.argv[1], nb=nb, cov=cov, f=f)
+''' % util.ROOT
+    out = []
+    for mode in ("1", "0"):
+        env = dict(os.environ, FVH_KNN_MODE=mode, FVH_RBF_MODE=mode, FVH_FIT_MODE=mode)
+        path = os.path.join(util.ROOT, "gpurun_out", "modes_%s.npz" % mode)
+        os.makedirs(os.path.dirname(path), exist_ok=True)
+        subprocess.check_call([sys.executable, "-c", code, path], env=env)
+        out.append(np.load(path))
+    assert np.array_equal(out[0]["nb"], out[1]["nb"])
+    assert np.abs(out[0]["cov"] - out[1]["cov"]).max() < 2e-5   # fp32 partial sums in a different order
+    assert abs(float(out[0]["f"]) - float(out[1]["f"])) <= 1e-12 * float(out[1]["f"])
