@@ -437,9 +437,7 @@ int build_voxelmap(Engine* e, const CloudDev& c, VoxelMapDev& vm, double res, bo
   }
   {
     ProfScope ps(e, "voxelmap");
-    HIP_OR_FAIL(e, hipMemsetAsync(vm.table.p, 0xFF, (size_t)cap * 64, e->stream));
-    HIP_OR_FAIL(e, hipMemsetAsync(vm.acc.p, 0, (size_t)cap * VM_ACC_STRIDE * sizeof(double), e->stream));
-    HIP_OR_FAIL(e, hipMemsetAsync(vm.counters.p, 0, 64, e->stream));
+    vm_clear_kernel<<<(cap * 5 + 255) / 256, 256, 0, e->stream>>>(vm.table.as<uint4>(), vm.acc.as<double>(), cap, vm.counters.as<int>());
     if (c.n) {
       vm_accumulate_kernel<MODE><<<(c.n + 255) / 256, 256, 0, e->stream>>>(c.pts.as<float4>(), c.cov.as<float4>(), c.n, res, vm.table.as<unsigned long long>(), cap - 1,
                                                                            vm.acc.as<double>(), vm.counters.as<int>() + 1, coherent_order(c));
@@ -499,7 +497,7 @@ struct CostSource {
 };
 
 template <int MODE>
-int launch_cost(Engine* e, const CostSource& src, const VoxelMapDev& vm, int host_phase, const PoseD* lin, const PoseD* ev) {
+int launch_cost(Engine* e, const CostSource& src, const VoxelMapDev& vm, int host_phase, const PoseD* lin, const PoseD* ev, const fvh_lm_params* init = nullptr) {
   CostParams P;
   std::memset(&P, 0, sizeof(P));
   P.src_pts = src.pts; P.src_cov = src.cov; P.d_n_src = src.d_n; P.n_src = src.n_upper; P.order = src.order;
@@ -520,6 +518,11 @@ int launch_cost(Engine* e, const CostSource& src, const VoxelMapDev& vm, int hos
   P.defer_lm = (e->comm != nullptr) ? 1 : 0;
   if (lin) P.lin = *lin;
   if (ev) P.ev = *ev;
+  if (init) {
+    P.init = 1;
+    P.max_iterations = init->max_iterations; P.lm_max_iterations = init->lm_max_iterations;
+    P.rotation_epsilon = init->rotation_epsilon; P.transformation_epsilon = init->transformation_epsilon; P.lm_init_lambda_factor = init->lm_init_lambda_factor;
+  }
   const long long items = (long long)src.n_upper * P.groups_per_src;
   const int blocks = (int)std::max<long long>(1, std::min<long long>(max_blocks, (items + 255) / 256));
   {
@@ -595,16 +598,21 @@ int do_align(Engine* e, const CostSource& src, VoxelMapDev& vm, const double* gu
   if (params) p = *params; else fvh_default_lm_params(&p);
   HIP_OR_FAIL(e, e->corr.ensure(2 * sizeof(int) * (size_t)std::max(src.n_upper, 1) * e->n_off));
   LmState* st = e->state.as<LmState>();
-  lm_init_kernel<<<1, 64, 0, e->stream>>>(st, pose_from_colmajor16(guess16), p.rotation_epsilon, p.transformation_epsilon, p.lm_init_lambda_factor, p.max_iterations,
-                                          p.lm_max_iterations, e->ticket.as<unsigned>());
-  HIP_OR_FAIL(e, hipGetLastError());
+  const PoseD guess = pose_from_colmajor16(guess16);
+  const bool degenerate = p.max_iterations <= 0;  // nothing to launch: only the state has to say "done"
+  if (degenerate) {
+    lm_init_kernel<<<1, 64, 0, e->stream>>>(st, guess, p.rotation_epsilon, p.transformation_epsilon, p.lm_init_lambda_factor, p.max_iterations, p.lm_max_iterations, e->ticket.as<unsigned>());
+    HIP_OR_FAIL(e, hipGetLastError());
+  }
   const long long budget = (long long)std::max(p.max_iterations, 0) * (1 + (long long)std::max(p.lm_max_iterations, 0)) + 1;
   long long launched = 0;
   int batch = e->last_steps > 0 ? std::max(e->last_steps, e->prev_steps) + 1 : 8;
   LmState* h = reinterpret_cast<LmState*>(e->pinned);
   while (true) {
     for (int s = 0; s < batch; s++) {
-      int rc = launch_cost<MODE>(e, src, vm, -1, nullptr, nullptr);
+      // the first launch carries the initial guess and the LM parameters and (re)initialises the device state
+      const bool first = (launched == 0 && s == 0 && !degenerate);
+      int rc = launch_cost<MODE>(e, src, vm, -1, first ? &guess : nullptr, nullptr, first ? &p : nullptr);
       if (rc) return rc;
       if (e->comm) {
         rc = allreduce_sums(e);
@@ -639,7 +647,7 @@ int do_align(Engine* e, const CostSource& src, VoxelMapDev& vm, const double* gu
   result->num_linearize = h->num_linearize;
   result->num_error_evals = h->num_error_evals;
   result->lm_failed = h->lm_failed;
-  result->num_launches = (int)launched + 1;
+  result->num_launches = (int)launched;
   return FVH_OK;
 }
 

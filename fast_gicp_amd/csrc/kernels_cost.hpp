@@ -71,7 +71,10 @@ struct CostParams {
   const int* vm_counters2;    // source map (D2D NDT) or null
   int host_phase;             // -1: device-LM mode (phase from st); else PH_FIND_ONLY / PH_EVAL_*
   int defer_lm;               // 1: multi-GPU -- only publish st->sums, LM step runs after the all-reduce
-  PoseD lin, ev;              // host mode poses
+  PoseD lin, ev;              // host mode poses; device-LM first launch (init = 1): lin = initial guess
+  int init;                   // 1: this is the first launch of an align -- start from P.lin and (re)initialise the LM state
+  int max_iterations, lm_max_iterations;
+  double rotation_epsilon, transformation_epsilon, lm_init_lambda_factor;
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -317,6 +320,11 @@ __global__ __launch_bounds__(256) void cost_kernel(CostParams P) {
     lin_d = P.lin;
     ev_d = P.ev;
     corr_sel = P.host_corr_sel;
+  } else if (P.init) {  // first launch of an align: the state in memory is stale, everything comes from the kernel arguments
+    phase = PH_LINEARIZE;
+    lin_d = P.lin;
+    ev_d = P.lin;
+    corr_sel = 0;
   } else {
     phase = st->phase;
     if (phase == PH_DONE) return;
@@ -565,6 +573,15 @@ __global__ __launch_bounds__(256) void cost_kernel(CostParams P) {
     for (int v = 0; v < PART_STRIDE; v++) s_st.sums[v] = red[0][v];
     s_st.vm_num_voxels = vm_nv;
     s_st.vm_dropped = vm_dr;
+    if (P.host_phase < 0 && P.init) {  // what lm_init_kernel would have written
+      s_st.x0 = P.lin; s_st.xi = P.lin; s_st.x_lin = P.lin;
+      s_st.rotation_epsilon = P.rotation_epsilon; s_st.transformation_epsilon = P.transformation_epsilon; s_st.lm_init_lambda_factor = P.lm_init_lambda_factor;
+      s_st.max_iterations = P.max_iterations; s_st.lm_max_iterations = P.lm_max_iterations;
+      s_st.lambda = -1.0; s_st.nu = 2.0; s_st.y0 = 0.0;
+      s_st.phase = PH_LINEARIZE; s_st.corr_cur = 0;
+      s_st.outer_iter = 0; s_st.inner_iter = 0; s_st.converged = 0; s_st.lm_failed = 0; s_st.num_linearize = 0; s_st.num_error_evals = 0; s_st.nr_iterations = 0;
+      for (int i = 0; i < 36; i++) s_st.final_H[i] = (i % 7 == 0) ? 1.0 : 0.0;
+    }
     if (P.host_phase < 0 && !P.defer_lm) dev_lm_step(&s_st, red[0]);
   }
   __syncthreads();

@@ -249,13 +249,12 @@ __global__ __launch_bounds__(256) void knn_tiled1_kernel(const float4* __restric
   auto merge_tile = [&](const float4& p) __attribute__((always_inline)) {
     const float d = sqdist_nofma(p, qx, qy, qz);
     const int po = __float_as_int(p.w);
-    unsigned long long mask = __ballot(d <= td);
+    // exact acceptance test per lane: (d, idx) below the current k-th entry in the total order
+    unsigned long long mask = __ballot(d < td || (d == td && po < ti));
     while (mask) {
       const int c = __ffsll((long long)mask) - 1;
-      mask &= mask - 1;
       const float cd = read_lane(d, c);
       const int ci = read_lane(po, c);
-      if (!(cd < td || (cd == td && ci < ti))) continue;
       const int pos = __popcll(__ballot(ld < cd || (ld == cd && li < ci)));
       const float sd = wave_shr1(ld, ld);
       const int si = wave_shr1(li, li);
@@ -263,6 +262,8 @@ __global__ __launch_bounds__(256) void knn_tiled1_kernel(const float4* __restric
       li = (lane > pos) ? si : ((lane == pos) ? ci : li);
       td = read_lane(ld, k - 1);
       ti = read_lane(li, k - 1);
+      // the threshold tightened: candidates that no longer qualify leave the mask here instead of costing an iteration each
+      mask &= __ballot(d < td || (d == td && po < ti)) & ~(1ull << c);
     }
   };
   if (t0 + 1 < ntiles) merge_tile(pa);

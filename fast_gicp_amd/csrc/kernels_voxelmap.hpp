@@ -49,6 +49,14 @@ __device__ __forceinline__ unsigned global_claim(unsigned long long* table_keys6
   return 0xFFFFFFFFu;  // probe budget exhausted: the caller counts it in `dropped` and the host rebuilds at the safe size
 }
 
+// one launch instead of three fills: every bucket key -> EMPTY (whole 64-B bucket = 0xFF), accumulators and counters -> 0
+__global__ __launch_bounds__(256) void vm_clear_kernel(uint4* __restrict__ table, double* __restrict__ acc, unsigned capacity, int* __restrict__ counters) {
+  const unsigned i = blockIdx.x * 256 + threadIdx.x;  // one 16-byte quad of the table per thread
+  if (i < capacity * 4) table[i] = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);
+  if (i < capacity * 5) reinterpret_cast<uint4*>(acc)[i] = make_uint4(0, 0, 0, 0);  // 10 doubles = 5 quads per bucket
+  if (i < 16) counters[i] = 0;
+}
+
 // MODE 0: VGICP (sum of points and of point covariances); MODE 1: NDT (sum of points and p p^T)
 template <int MODE>
 __global__ __launch_bounds__(256) void vm_accumulate_kernel(const float4* __restrict__ pts, const float4* __restrict__ cov, int n, double res,
