@@ -237,3 +237,29 @@ np.savez(sys.argv[1], nb=nb, cov=cov, f=f)
     assert np.array_equal(out[0]["nb"], out[1]["nb"])
     assert np.abs(out[0]["cov"] - out[1]["cov"]).max() < 2e-5   # fp32 partial sums in a different order
     assert abs(float(out[0]["f"]) - float(out[1]["f"])) <= 1e-12 * float(out[1]["f"])
+
+
+def test_covariance_state_machine_is_consistent(O):
+    """The k-NN kernel regularises speculatively with the last-used method; every call order must still give the
+    covariances of the method that was actually requested."""
+    _, src = util.bundled_pair()
+    src = src[:3000]
+    c = _core()
+    c.set_source_cloud(src)
+
+    def check(method):
+        got = c.get_covariances("source").astype(np.float64)
+        ref = O.covariances_knn(src, 20, method)
+        err = np.abs(got - ref).max(axis=(1, 2)) / np.abs(ref).max(axis=(1, 2))
+        assert np.quantile(err, 0.999) < 2e-5, method
+
+    c.find_source_neighbors(20); c.calculate_source_covariances(3); check(3)     # speculation hit (PLANE)
+    c.calculate_source_covariances(1); check(1)                                   # different method from the same raw covariances
+    c.find_source_neighbors(20); c.calculate_source_covariances(1); check(1)     # speculation now follows MIN_EIG
+    c.calculate_source_covariances_rbf(3)
+    c.calculate_source_covariances(1); check(1)                                   # RBF overwrote cov: must be recomputed
+    c.set_source_covariances(np.tile(np.eye(3), (len(src), 1, 1)))
+    c.calculate_source_covariances(4); check(4)
+    nb = O.knn(src, 20)
+    c.set_source_neighbors(20, nb); c.calculate_source_covariances(3); check(3)  # host-supplied neighbours: gather kernel
+    c.close()
