@@ -104,20 +104,29 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the product path has no CPU fallback)")
+    # test-only knobs to walk the N > 1 control flow on a single-GPU box: all ranks on device 0, gloo for the barrier
+    share_gpu = os.environ.get("FVH_BENCH_SHARE_GPU") == "1"
+    backend = os.environ.get("FVH_BENCH_BACKEND", "nccl")
+    if share_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    dev = torch.device("cuda", local_rank)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
+    dev = torch.device("cuda", local_rank) if backend == "nccl" else torch.device("cpu")
 
     tgt, src, res, desc = make_workload(args.workload)
     if args.search is None:
         args.search = "DIRECT7" if args.workload == "synth1m" else "DIRECT27"
     search = {"DIRECT27": capi.DIRECT27, "DIRECT7": capi.DIRECT7, "DIRECT1": capi.DIRECT1}[args.search]
     K = 20
-    d_clouds = [torch.from_numpy(tgt).to(dev).contiguous(), torch.from_numpy(src).to(dev).contiguous()]  # inputs resident in HBM
+    gpu = torch.device("cuda", local_rank)
+    d_clouds = [torch.from_numpy(tgt).to(gpu).contiguous(), torch.from_numpy(src).to(gpu).contiguous()]  # inputs resident in HBM
     n_pts = [len(tgt), len(src)]
 
     core = capi.VGICPCore(local_rank)
@@ -194,7 +203,7 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    sharded = sharded_leg(args, dist, rank, world, local_rank, dev) if world > 1 else None
+    sharded = sharded_leg(args, dist, rank, world, local_rank, dev) if (world > 1 and not share_gpu) else None
     if rank != 0:
         if dist is not None:
             dist.destroy_process_group()
