@@ -49,6 +49,7 @@ def load():
         L = C.CDLL(path)
         L.fvh_vgicp_last_error.restype = C.c_char_p
         L.fvh_ndt_last_error.restype = C.c_char_p
+        L.fvh_voxelgrid_last_error.restype = C.c_char_p
         _LIB = L
     return _LIB
 
@@ -299,6 +300,63 @@ class VGICPCore(_Core):
         ms = C.c_double(0)
         n = C.c_int(0)
         self._call("profile_get", cls.encode(), C.byref(ms), C.byref(n))
+        return ms.value, n.value
+
+
+class VoxelGrid:
+    """pcl::VoxelGrid / pcl::ApproximateVoxelGrid on the device (fvh_voxelgrid_*): same output points in the same
+    order as the PCL filters the reference's callers run before registration (src/align.cpp:136-147)."""
+
+    EXACT, APPROXIMATE = 0, 1
+
+    def __init__(self, device=0):
+        self._lib = load()
+        self._h = C.c_void_p()
+        rc = self._lib.fvh_voxelgrid_create(int(device), C.byref(self._h))
+        if rc != 0:
+            raise FvhError("fvh_voxelgrid_create failed: %d" % rc)
+
+    def close(self):
+        if self._h:
+            self._lib.fvh_voxelgrid_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc, what):
+        if rc != 0:
+            raise FvhError("%s: %s (code %d)" % (what, (self._lib.fvh_voxelgrid_last_error(self._h) or b"").decode(), rc))
+
+    def filter(self, xyz, leaf, method=APPROXIMATE):
+        """Host array in, host array out (float32 Nx3)."""
+        a = _f32(np.asarray(xyz).reshape(-1, 3))
+        n = C.c_int(0)
+        self._check(self._lib.fvh_voxelgrid_filter(self._h, int(method), _p(a), len(a), C.c_float(leaf), C.byref(n)), "fvh_voxelgrid_filter")
+        out = np.empty((n.value, 3), np.float32)
+        self._check(self._lib.fvh_voxelgrid_get_points(self._h, _p(out)), "fvh_voxelgrid_get_points")
+        return out
+
+    def filter_device(self, d_ptr, n, leaf, method=APPROXIMATE, stride=3):
+        """Device pointer in (n points, `stride` floats apart); returns (device pointer to packed xyz, count) valid until the next filter call."""
+        m = C.c_int(0)
+        self._check(self._lib.fvh_voxelgrid_filter_device(self._h, int(method), C.c_void_p(d_ptr), int(n), int(stride), C.c_float(leaf), C.byref(m)), "fvh_voxelgrid_filter_device")
+        ptr = C.c_void_p()
+        self._check(self._lib.fvh_voxelgrid_device_points(self._h, C.byref(ptr), C.byref(m)), "fvh_voxelgrid_device_points")
+        return ptr.value or 0, m.value
+
+    def profile_enable(self, on=True):
+        self._check(self._lib.fvh_voxelgrid_profile_enable(self._h, int(on)), "profile_enable")
+
+    def profile_reset(self):
+        self._check(self._lib.fvh_voxelgrid_profile_reset(self._h), "profile_reset")
+
+    def profile_get(self):
+        ms, n = C.c_double(0), C.c_int(0)
+        self._check(self._lib.fvh_voxelgrid_profile_get(self._h, C.byref(ms), C.byref(n)), "profile_get")
         return ms.value, n.value
 
 

@@ -18,6 +18,7 @@
 #include "../../include/fast_vgicp_hip.h"
 #include "kernels_cost.hpp"
 #include "kernels_cov.hpp"
+#include "kernels_downsample.hpp"
 #include "kernels_sort.hpp"
 #include "kernels_voxelmap.hpp"
 
@@ -710,6 +711,136 @@ int profile_get(Engine* e, const char* cls, double* total_ms, int* launches) {
   return FVH_OK;
 }
 
+// ---------------------------------------------------------------------------------------------
+// voxel-grid downsampling (kernels_downsample.hpp)
+// ---------------------------------------------------------------------------------------------
+struct DownsampleDev {
+  CloudDev cloud;                 // the input, widened to float4
+  DevBuf keys, idx, head, trig, scan, bsums, slots, out;
+  int out_n = 0;
+  void release() { cloud.release(); keys.release(); idx.release(); head.release(); trig.release(); scan.release(); bsums.release(); slots.release(); out.release(); }
+};
+
+// exclusive scan of n unsigned values (in -> out, may alias); the grand total lands in bsums[nb]
+int device_scan(Engine* e, DevBuf& bsums, const unsigned* in, int n, unsigned* out, const unsigned** total) {
+  const int nb = (n + SCAN_BLOCK_ITEMS - 1) / SCAN_BLOCK_ITEMS;
+  HIP_OR_FAIL(e, bsums.ensure(sizeof(unsigned) * (size_t)(nb + 1)));
+  HIP_OR_FAIL(e, hipMemsetAsync(bsums.as<unsigned>() + nb, 0, sizeof(unsigned), e->stream));
+  scan_block_sums_kernel<<<nb, 256, 0, e->stream>>>(in, n, bsums.as<unsigned>());
+  radix_scan_kernel<<<1, 1024, 0, e->stream>>>(bsums.as<unsigned>(), nb + 1);
+  scan_apply_kernel<<<nb, 256, 0, e->stream>>>(in, n, bsums.as<unsigned>(), out);
+  HIP_OR_FAIL(e, hipGetLastError());
+  *total = bsums.as<unsigned>() + nb;
+  return FVH_OK;
+}
+
+// stable LSD radix sort of (key, idx) pairs on `bits` key bits; returns the index (0/1) of the buffer pair holding the result
+int radix_sort_pairs(Engine* e, unsigned* keys[2], int* idx[2], int n, int bits, int* result) {
+  const int items = n <= 65536 ? 256 : SORT_ITEMS_MAX;
+  const int nwaves = (n + items - 1) / items;
+  HIP_OR_FAIL(e, e->sort_hist.ensure(sizeof(unsigned) * (size_t)RADIX_BINS * nwaves));
+  const int wblocks = (nwaves + 3) / 4;
+  const int passes = std::max(1, (bits + RADIX_BITS - 1) / RADIX_BITS);
+  for (int pass = 0; pass < passes; pass++) {
+    const int in = pass & 1, out = in ^ 1, shift = pass * RADIX_BITS;
+    radix_hist_kernel<<<wblocks, 256, 0, e->stream>>>(keys[in], n, shift, nwaves, items, e->sort_hist.as<unsigned>());
+    radix_scan_kernel<<<1, 1024, 0, e->stream>>>(e->sort_hist.as<unsigned>(), RADIX_BINS * nwaves);
+    radix_scatter_kernel<<<wblocks, 256, 0, e->stream>>>(keys[in], idx[in], n, shift, nwaves, items, e->sort_hist.as<unsigned>(), keys[out], idx[out], nullptr, nullptr);
+  }
+  HIP_OR_FAIL(e, hipGetLastError());
+  *result = passes & 1;
+  return FVH_OK;
+}
+
+inline float host_ordered_to_float(unsigned u) {
+  const unsigned v = (u & 0x80000000u) ? (u & 0x7fffffffu) : ~u;
+  float f;
+  std::memcpy(&f, &v, 4);
+  return f;
+}
+
+int downsample(Engine* e, DownsampleDev& d, int method, const float* xyz, int n, int stride, bool on_device, float leaf, int* out_n) {
+  if (!out_n) return e->fail(FVH_ERR_INVALID_ARGUMENT, "voxelgrid: null out_n");
+  if (method != FVH_VOXELGRID_EXACT && method != FVH_VOXELGRID_APPROXIMATE) return e->fail(FVH_ERR_INVALID_ARGUMENT, "voxelgrid: unknown method");
+  if (!(leaf > 0.f)) return e->fail(FVH_ERR_INVALID_ARGUMENT, "voxelgrid: leaf size must be > 0");
+  int rc = upload_cloud(e, d.cloud, xyz, n, stride, on_device);
+  if (rc) return rc;
+  d.out_n = 0;
+  *out_n = 0;
+  if (n == 0) return FVH_OK;
+  ProfScope ps(e, "downsample");
+  const float inv = 1.0f / leaf;
+  const float4* pts = d.cloud.pts.as<float4>();
+  HIP_OR_FAIL(e, d.keys.ensure(sizeof(unsigned) * 2 * (size_t)n + 128));
+  HIP_OR_FAIL(e, d.idx.ensure(sizeof(int) * 2 * (size_t)n));
+  HIP_OR_FAIL(e, d.head.ensure(sizeof(unsigned) * (size_t)n));
+  HIP_OR_FAIL(e, d.scan.ensure(sizeof(unsigned) * (size_t)n));
+  HIP_OR_FAIL(e, d.out.ensure(sizeof(float) * 3 * (size_t)n));
+  unsigned* keys[2] = {d.keys.as<unsigned>(), d.keys.as<unsigned>() + n};
+  int* idx[2] = {d.idx.as<int>(), d.idx.as<int>() + n};
+  const int blocks = (n + 255) / 256;
+  unsigned* h_total = reinterpret_cast<unsigned*>(e->pinned);
+  unsigned* bad = d.keys.as<unsigned>() + 2 * (size_t)n + 8;  // set by the key kernels on a non-finite coordinate
+  HIP_OR_FAIL(e, hipMemsetAsync(bad, 0, sizeof(unsigned), e->stream));
+  int sorted = 0;
+  if (method == FVH_VOXELGRID_EXACT) {
+    // pcl::VoxelGrid: lattice over the bounding box (getMinMax3D), linear voxel index, points grouped by index
+    unsigned* box = d.keys.as<unsigned>() + 2 * (size_t)n;
+    HIP_OR_FAIL(e, hipMemsetAsync(box, 0xFF, 12, e->stream));
+    HIP_OR_FAIL(e, hipMemsetAsync(box + 3, 0, 12, e->stream));
+    cloud_bbox_kernel<<<std::min(256, blocks), 256, 0, e->stream>>>(pts, n, box);
+    HIP_OR_FAIL(e, hipMemcpyAsync(h_total, box, 24, hipMemcpyDeviceToHost, e->stream));
+    HIP_OR_FAIL(e, hipStreamSynchronize(e->stream));
+    VgGrid g;
+    long long total = 1;
+    for (int a = 0; a < 3; a++) {
+      const float mn = host_ordered_to_float(h_total[a]), mx = host_ordered_to_float(h_total[3 + a]);
+      if (!std::isfinite(mn) || !std::isfinite(mx)) return e->fail(FVH_ERR_INVALID_ARGUMENT, "voxelgrid: non-finite coordinates");
+      const float lo = std::floor(mn * inv), hi = std::floor(mx * inv);
+      if (std::fabs(lo) > 2.0e9f || std::fabs(hi) > 2.0e9f) return e->fail(FVH_ERR_INVALID_ARGUMENT, "voxelgrid: leaf size too small for the input (voxel index overflow)");
+      g.minb[a] = (int)lo;
+      g.divb[a] = (int)hi - g.minb[a] + 1;
+      total *= g.divb[a];
+      if (total > 0x7fffffffLL) return e->fail(FVH_ERR_INVALID_ARGUMENT, "voxelgrid: leaf size too small for the input (voxel index overflow)");  // PCL refuses too
+    }
+    int bits = 1;
+    while (bits < 31 && (1LL << bits) < total) bits++;
+    vg_keys_exact_kernel<<<blocks, 256, 0, e->stream>>>(pts, n, inv, g, keys[0], idx[0], bad);
+    if ((rc = radix_sort_pairs(e, keys, idx, n, bits, &sorted))) return rc;
+    vg_mark_exact_kernel<<<blocks, 256, 0, e->stream>>>(keys[sorted], n, d.head.as<unsigned>());
+    const unsigned* total_dev = nullptr;
+    if ((rc = device_scan(e, d.bsums, d.head.as<unsigned>(), n, d.scan.as<unsigned>(), &total_dev))) return rc;
+    vg_emit_kernel<false><<<blocks, 256, 0, e->stream>>>(keys[sorted], idx[sorted], pts, n, d.head.as<unsigned>(), d.scan.as<unsigned>(), nullptr, nullptr, d.out.as<float>());
+    HIP_OR_FAIL(e, hipGetLastError());
+    HIP_OR_FAIL(e, hipMemcpyAsync(h_total, total_dev, sizeof(unsigned), hipMemcpyDeviceToHost, e->stream));
+    HIP_OR_FAIL(e, hipMemcpyAsync(h_total + 2, bad, sizeof(unsigned), hipMemcpyDeviceToHost, e->stream));
+    HIP_OR_FAIL(e, hipStreamSynchronize(e->stream));
+    d.out_n = (int)h_total[0];
+  } else {
+    // pcl::ApproximateVoxelGrid, slot-parallel (see kernels_downsample.hpp)
+    HIP_OR_FAIL(e, d.trig.ensure(sizeof(unsigned) * (size_t)n));
+    HIP_OR_FAIL(e, d.slots.ensure(sizeof(unsigned) * (AVG_SLOTS + 1)));
+    HIP_OR_FAIL(e, hipMemsetAsync(d.trig.p, 0, sizeof(unsigned) * (size_t)n, e->stream));
+    HIP_OR_FAIL(e, hipMemsetAsync(d.slots.p, 0, sizeof(unsigned) * (AVG_SLOTS + 1), e->stream));
+    vg_keys_approx_kernel<<<blocks, 256, 0, e->stream>>>(pts, n, inv, keys[0], idx[0], bad);
+    if ((rc = radix_sort_pairs(e, keys, idx, n, RADIX_BITS, &sorted))) return rc;
+    vg_mark_approx_kernel<<<blocks, 256, 0, e->stream>>>(keys[sorted], idx[sorted], pts, n, inv, d.head.as<unsigned>(), d.trig.as<unsigned>(), d.slots.as<unsigned>());
+    const unsigned* trig_total = nullptr;
+    if ((rc = device_scan(e, d.bsums, d.trig.as<unsigned>(), n, d.scan.as<unsigned>(), &trig_total))) return rc;
+    radix_scan_kernel<<<1, 1024, 0, e->stream>>>(d.slots.as<unsigned>(), AVG_SLOTS + 1);
+    vg_emit_kernel<true><<<blocks, 256, 0, e->stream>>>(keys[sorted], idx[sorted], pts, n, d.head.as<unsigned>(), d.scan.as<unsigned>(), d.slots.as<unsigned>(), trig_total, d.out.as<float>());
+    HIP_OR_FAIL(e, hipGetLastError());
+    HIP_OR_FAIL(e, hipMemcpyAsync(h_total, trig_total, sizeof(unsigned), hipMemcpyDeviceToHost, e->stream));
+    HIP_OR_FAIL(e, hipMemcpyAsync(h_total + 1, d.slots.as<unsigned>() + AVG_SLOTS, sizeof(unsigned), hipMemcpyDeviceToHost, e->stream));
+    HIP_OR_FAIL(e, hipMemcpyAsync(h_total + 2, bad, sizeof(unsigned), hipMemcpyDeviceToHost, e->stream));
+    HIP_OR_FAIL(e, hipStreamSynchronize(e->stream));
+    d.out_n = (int)(h_total[0] + h_total[1]);
+  }
+  if (h_total[2]) { d.out_n = 0; return e->fail(FVH_ERR_INVALID_ARGUMENT, "voxelgrid: non-finite coordinates in the input"); }
+  *out_n = d.out_n;
+  return FVH_OK;
+}
+
 }  // namespace
 
 // ---------------------------------------------------------------------------------------------
@@ -741,6 +872,11 @@ struct fvh_ndt {
       return rc;
     };
   }
+};
+
+struct fvh_voxelgrid {
+  Engine e;
+  DownsampleDev d;
 };
 
 #define CHECK_HANDLE(h) \
@@ -999,5 +1135,47 @@ int fvh_ndt_get_num_correspondences(fvh_ndt* h, int* n) {
 int fvh_ndt_synchronize(fvh_ndt* h) { CHECK_HANDLE(h); HIP_OR_FAIL(&h->e, hipStreamSynchronize(h->e.stream)); return FVH_OK; }
 int fvh_ndt_comm_init(fvh_ndt* h, const void* id, int nranks, int rank) { CHECK_HANDLE(h); return comm_init(&h->e, id, nranks, rank); }
 int fvh_ndt_comm_destroy(fvh_ndt* h) { CHECK_HANDLE(h); if (h->e.comm) { g_rccl.CommDestroy(h->e.comm); h->e.comm = nullptr; } h->e.nranks = 1; h->e.rank = 0; return FVH_OK; }
+
+// ---- voxel-grid downsampling ----
+int fvh_voxelgrid_create(int device, fvh_voxelgrid** out) {
+  if (!out) return FVH_ERR_INVALID_ARGUMENT;
+  *out = nullptr;
+  auto* h = new (std::nothrow) fvh_voxelgrid();
+  if (!h) return FVH_ERR_HIP;
+  int rc = h->e.init(device);
+  if (rc) { fprintf(stderr, "fvh_voxelgrid_create: %s\n", h->e.err.c_str()); h->e.shutdown(); delete h; return rc; }
+  *out = h;
+  return FVH_OK;
+}
+int fvh_voxelgrid_destroy(fvh_voxelgrid* h) {
+  if (!h) return FVH_ERR_INVALID_ARGUMENT;
+  (void)hipSetDevice(h->e.device);
+  if (h->e.stream) (void)hipStreamSynchronize(h->e.stream);
+  h->d.release();
+  h->e.shutdown();
+  delete h;
+  return FVH_OK;
+}
+const char* fvh_voxelgrid_last_error(const fvh_voxelgrid* h) { return h ? h->e.err.c_str() : "null handle"; }
+int fvh_voxelgrid_filter(fvh_voxelgrid* h, int method, const float* xyz, int n, float leaf, int* out_n) { CHECK_HANDLE(h); return downsample(&h->e, h->d, method, xyz, n, 3, false, leaf, out_n); }
+int fvh_voxelgrid_filter_device(fvh_voxelgrid* h, int method, const float* d_xyz, int n, int stride, float leaf, int* out_n) { CHECK_HANDLE(h); return downsample(&h->e, h->d, method, d_xyz, n, stride, true, leaf, out_n); }
+int fvh_voxelgrid_get_points(fvh_voxelgrid* h, float* out_xyz) {
+  CHECK_HANDLE(h);
+  if (h->d.out_n == 0) return FVH_OK;
+  if (!out_xyz) return h->e.fail(FVH_ERR_INVALID_ARGUMENT, "voxelgrid: null output");
+  HIP_OR_FAIL(&h->e, hipMemcpyAsync(out_xyz, h->d.out.p, sizeof(float) * 3 * (size_t)h->d.out_n, hipMemcpyDefault, h->e.stream));
+  HIP_OR_FAIL(&h->e, hipStreamSynchronize(h->e.stream));
+  return FVH_OK;
+}
+int fvh_voxelgrid_device_points(fvh_voxelgrid* h, const float** d_xyz, int* n) {
+  CHECK_HANDLE(h);
+  if (!d_xyz || !n) return h->e.fail(FVH_ERR_INVALID_ARGUMENT, "voxelgrid: null output");
+  *d_xyz = h->d.out_n ? h->d.out.as<float>() : nullptr;
+  *n = h->d.out_n;
+  return FVH_OK;
+}
+int fvh_voxelgrid_profile_enable(fvh_voxelgrid* h, int on) { CHECK_HANDLE(h); h->e.prof.on = on != 0; return FVH_OK; }
+int fvh_voxelgrid_profile_reset(fvh_voxelgrid* h) { CHECK_HANDLE(h); HIP_OR_FAIL(&h->e, hipStreamSynchronize(h->e.stream)); h->e.prof.reset(); return FVH_OK; }
+int fvh_voxelgrid_profile_get(fvh_voxelgrid* h, double* ms, int* n) { CHECK_HANDLE(h); return profile_get(&h->e, "downsample", ms, n); }
 
 }  // extern "C"

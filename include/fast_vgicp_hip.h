@@ -178,6 +178,28 @@ int fvh_ndt_synchronize(fvh_ndt* h);
 int fvh_ndt_comm_init(fvh_ndt* h, const void* id128, int nranks, int rank);
 int fvh_ndt_comm_destroy(fvh_ndt* h);
 
+/* ---------------------------------------------------------------------------------------------------
+ * Voxel-grid downsampling on device -- the filter every caller of the reference runs on the raw scan
+ * right before the registration path: pcl::ApproximateVoxelGrid in src/align.cpp:136-147, src/kitti.cpp:80-82,117-119
+ * and pygicp's downsample()/align_points() (src/python/main.cpp:46-62,80-92); pcl::VoxelGrid in
+ * src/test/gicp_test.cpp:55-65.  Output points AND their order are bit-identical to those filters on PointXYZ
+ * (fp32 sums in input order).  Non-finite coordinates are rejected (FVH_ERR_INVALID_ARGUMENT).
+ * The output stays on the device (packed xyz, 3 floats per point) until the next filter call, so it can be handed
+ * straight to fvh_*_set_*_cloud_device(ptr, n, 3).
+ * --------------------------------------------------------------------------------------------------- */
+typedef struct fvh_voxelgrid fvh_voxelgrid;
+enum fvh_voxelgrid_method { FVH_VOXELGRID_EXACT = 0 /* pcl::VoxelGrid */, FVH_VOXELGRID_APPROXIMATE = 1 /* pcl::ApproximateVoxelGrid */ };
+int fvh_voxelgrid_create(int device, fvh_voxelgrid** out);
+int fvh_voxelgrid_destroy(fvh_voxelgrid* h);
+const char* fvh_voxelgrid_last_error(const fvh_voxelgrid* h);
+int fvh_voxelgrid_filter(fvh_voxelgrid* h, int method, const float* xyz, int n, float leaf, int* out_n);                       /* setLeafSize(l,l,l); setInputCloud; filter */
+int fvh_voxelgrid_filter_device(fvh_voxelgrid* h, int method, const float* d_xyz, int n, int stride_floats, float leaf, int* out_n);
+int fvh_voxelgrid_get_points(fvh_voxelgrid* h, float* out_xyz /* host or device, 3*out_n floats */);
+int fvh_voxelgrid_device_points(fvh_voxelgrid* h, const float** d_xyz, int* n);
+int fvh_voxelgrid_profile_enable(fvh_voxelgrid* h, int on);
+int fvh_voxelgrid_profile_reset(fvh_voxelgrid* h);
+int fvh_voxelgrid_profile_get(fvh_voxelgrid* h, double* total_ms, int* launches);
+
 #ifdef __cplusplus
 }
 #endif

