@@ -5,7 +5,7 @@ import subprocess
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_DIR = os.path.join(_HERE, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libfast_vgicp_hip.so")
-SOURCES = [os.path.join(_HERE, "csrc", f) for f in ("fvh_capi.hip", "kernels_cost.hpp", "kernels_cov.hpp", "kernels_voxelmap.hpp", "kernels_sort.hpp", "dev_math.hpp")]
+SOURCES = [os.path.join(_HERE, "csrc", f) for f in ("fvh_capi.hip", "kernels_cost.hpp", "kernels_cov.hpp", "kernels_voxelmap.hpp", "kernels_sort.hpp", "kernels_downsample.hpp", "dev_math.hpp")]
 HEADER = os.path.join(os.path.dirname(_HERE), "include", "fast_vgicp_hip.h")
 
 
@@ -22,7 +22,7 @@ def build_lib(force=False, verbose=False):
         return LIB_PATH
     os.makedirs(LIB_DIR, exist_ok=True)
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-munsafe-fp-atomics", "-o", LIB_PATH, SOURCES[0], "-ldl"]
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-munsafe-fp-atomics", "-o", LIB_PATH, SOURCES[0], "-ldl"] + os.environ.get("FVH_EXTRA_HIPCC_FLAGS", "").split()
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)

@@ -37,7 +37,7 @@ _LIB = None
 
 
 def lib_path():
-    return _build.LIB_PATH
+    return os.environ.get("FVH_LIB_PATH") or _build.LIB_PATH  # override: A/B runs against another build of the same ABI
 
 
 def load():
@@ -174,6 +174,18 @@ class _Core:
     def synchronize(self):
         self._call("synchronize")
 
+    def profile_enable(self, on=True):
+        self._call("profile_enable", int(on))
+
+    def profile_reset(self):
+        self._call("profile_reset")
+
+    def profile_get(self, cls):
+        ms = C.c_double(0)
+        n = C.c_int(0)
+        self._call("profile_get", cls.encode(), C.byref(ms), C.byref(n))
+        return ms.value, n.value
+
     def comm_init(self, unique_id, nranks, rank):
         buf = (C.c_char * 128).from_buffer_copy(bytes(unique_id))
         self._call("comm_init", buf, int(nranks), int(rank))
@@ -290,17 +302,6 @@ class VGICPCore(_Core):
         self._call("debug_get_table_capacity", C.byref(n))
         return n.value
 
-    def profile_enable(self, on=True):
-        self._call("profile_enable", int(on))
-
-    def profile_reset(self):
-        self._call("profile_reset")
-
-    def profile_get(self, cls):
-        ms = C.c_double(0)
-        n = C.c_int(0)
-        self._call("profile_get", cls.encode(), C.byref(ms), C.byref(n))
-        return ms.value, n.value
 
 
 class VoxelGrid:

@@ -8,6 +8,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <atomic>
 #include <cstring>
 #include <functional>
 #include <map>
@@ -119,6 +120,7 @@ struct Rccl {
   }
 };
 Rccl g_rccl;
+std::atomic<int> g_active_aligns{0};  // aligns in flight in this process (persistent kernels want the device to themselves)
 
 struct Engine {
   int device = 0;
@@ -127,6 +129,7 @@ struct Engine {
   int precision = FVH_COMPUTE_FP64;
   std::vector<int> offsets_host{0, 0, 0};
   int n_off = 1;
+  DevBuf pticket;  // arrival counters of the persistent LM kernel (zeroed before every launch)
   DevBuf offsets_dev, state, partials, ticket, corr, misc, fit, staging, sort_keys, sort_idx, sort_hist;
   void* pinned = nullptr;  // sizeof(LmState) + slack
   PoseD lin;               // pose of the last update_correspondences()
@@ -134,6 +137,7 @@ struct Engine {
   int corr_n_src = 0;
   int corr_sel = 0;        // which of the two correspondence buffers the host-mode calls use
   int last_steps = 0, prev_steps = 0;  // launches the last two aligns needed (odometry loops alternate directions)
+  int persist_aborts = 0;               // persistent launches the watchdog turned into multi-launch retries
   Profiler prof;
   void* comm = nullptr;
   int nranks = 1, rank = 0;
@@ -148,8 +152,9 @@ struct Engine {
     if ((e = hipStreamCreateWithFlags(&stream, hipStreamNonBlocking)) != hipSuccess) return hipfail(e, "hipStreamCreate");
     if ((e = hipHostMalloc(&pinned, sizeof(LmState) + 1024, hipHostMallocDefault)) != hipSuccess) return hipfail(e, "hipHostMalloc");
     if ((e = state.ensure(sizeof(LmState))) != hipSuccess) return hipfail(e, "hipMalloc");
-    if ((e = partials.ensure(sizeof(double) * PART_STRIDE * (MAX_COST_BLOCKS + TICKET_GROUPS))) != hipSuccess) return hipfail(e, "hipMalloc");
+    if ((e = partials.ensure(sizeof(double) * PART_STRIDE * (MAX_COST_BLOCKS + 2 * TICKET_GROUPS))) != hipSuccess) return hipfail(e, "hipMalloc");
     if ((e = ticket.ensure(64)) != hipSuccess) return hipfail(e, "hipMalloc");
+    if ((e = pticket.ensure(PERSIST_TICKET_BYTES)) != hipSuccess) return hipfail(e, "hipMalloc");
     if ((e = misc.ensure(256)) != hipSuccess) return hipfail(e, "hipMalloc");
     if ((e = fit.ensure(64)) != hipSuccess) return hipfail(e, "hipMalloc");
     (void)hipMemsetAsync(state.p, 0, sizeof(LmState), stream);
@@ -168,7 +173,7 @@ struct Engine {
     if (comm && g_rccl.CommDestroy) g_rccl.CommDestroy(comm);
     comm = nullptr;
     prof.destroy();
-    offsets_dev.release(); state.release(); partials.release(); ticket.release(); corr.release(); misc.release(); fit.release(); staging.release(); sort_keys.release(); sort_idx.release(); sort_hist.release();
+    pticket.release(); offsets_dev.release(); state.release(); partials.release(); ticket.release(); corr.release(); misc.release(); fit.release(); staging.release(); sort_keys.release(); sort_idx.release(); sort_hist.release();
     if (pinned) (void)hipHostFree(pinned);
     if (stream) (void)hipStreamDestroy(stream);
   }
@@ -497,8 +502,26 @@ struct CostSource {
   const int* order;      // Morton permutation of the source (large clouds) or null
 };
 
+// Persistent LM kernel (kernels_cost.hpp, PERSIST): co-resident workgroup capacity of the device for this instantiation.
+constexpr unsigned long long PERSIST_WATCHDOG_TICKS = 5'000'000ull;  // 50 ms of the 100 MHz wall clock
+constexpr long long PERSIST_MAX_ITEMS = 4'000'000;                   // beyond this a trip is no longer latency-bound: multi-launch path
 template <int MODE>
-int launch_cost(Engine* e, const CostSource& src, const VoxelMapDev& vm, int host_phase, const PoseD* lin, const PoseD* ev, const fvh_lm_params* init = nullptr) {
+int persistent_capacity(Engine* e) {
+  static int cap[2] = {-1, -1};
+  const int pi = e->precision == FVH_COMPUTE_FP32 ? 1 : 0;
+  if (cap[pi] < 0) {
+    int per_cu = 0, cus = 0;
+    hipError_t r = pi ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, cost_kernel<float, MODE, true>, 256, 0)
+                      : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, cost_kernel<double, MODE, true>, 256, 0);
+    if (r != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, e->device) != hipSuccess) return 0;
+    cap[pi] = per_cu * cus;
+  }
+  return cap[pi];
+}
+
+template <int MODE>
+int launch_cost(Engine* e, const CostSource& src, const VoxelMapDev& vm, int host_phase, const PoseD* lin, const PoseD* ev, const fvh_lm_params* init = nullptr,
+                bool persistent = false) {
   CostParams P;
   std::memset(&P, 0, sizeof(P));
   P.src_pts = src.pts; P.src_cov = src.cov; P.d_n_src = src.d_n; P.n_src = src.n_upper; P.order = src.order;
@@ -525,11 +548,24 @@ int launch_cost(Engine* e, const CostSource& src, const VoxelMapDev& vm, int hos
     P.rotation_epsilon = init->rotation_epsilon; P.transformation_epsilon = init->transformation_epsilon; P.lm_init_lambda_factor = init->lm_init_lambda_factor;
   }
   const long long items = (long long)src.n_upper * P.groups_per_src;
-  const int blocks = (int)std::max<long long>(1, std::min<long long>(max_blocks, (items + 255) / 256));
-  {
+  int blocks = (int)std::max<long long>(1, std::min<long long>(max_blocks, (items + 255) / 256));
+  if (persistent) {
+    // every workgroup must be resident at once: clamp the grid to what the device can hold (the kernel is grid-stride)
+    const int cap = persistent_capacity<MODE>(e);
+    if (cap <= 0) return e->fail(FVH_ERR_HIP, "persistent cost kernel: occupancy query failed");
+    blocks = std::min(blocks, cap);
+    P.watchdog_ticks = PERSIST_WATCHDOG_TICKS;
+    // abort word = 0 (the last 8 bytes of the state; never covered by the state write-back); arrival counters = 0
+    HIP_OR_FAIL(e, hipMemsetAsync(reinterpret_cast<char*>(e->state.p) + sizeof(LmState) - 8, 0, 8, e->stream));
+    HIP_OR_FAIL(e, hipMemsetAsync(e->pticket.p, 0, PERSIST_TICKET_BYTES, e->stream));
+    P.ticket = e->pticket.as<unsigned>();
     ProfScope ps(e, "cost");
-    if (e->precision == FVH_COMPUTE_FP32) cost_kernel<float, MODE><<<blocks, 256, 0, e->stream>>>(P);
-    else cost_kernel<double, MODE><<<blocks, 256, 0, e->stream>>>(P);
+    if (e->precision == FVH_COMPUTE_FP32) cost_kernel<float, MODE, true><<<blocks, 256, 0, e->stream>>>(P);
+    else cost_kernel<double, MODE, true><<<blocks, 256, 0, e->stream>>>(P);
+  } else {
+    ProfScope ps(e, "cost");
+    if (e->precision == FVH_COMPUTE_FP32) cost_kernel<float, MODE, false><<<blocks, 256, 0, e->stream>>>(P);
+    else cost_kernel<double, MODE, false><<<blocks, 256, 0, e->stream>>>(P);
   }
   HIP_OR_FAIL(e, hipGetLastError());
   return FVH_OK;
@@ -592,7 +628,7 @@ int do_compute_error(Engine* e, const CostSource& src, VoxelMapDev& vm, const do
 
 template <int MODE>
 int do_align(Engine* e, const CostSource& src, VoxelMapDev& vm, const double* guess16, const fvh_lm_params* params, fvh_lm_result* result, const Rebuild& rebuild_safe,
-             bool retried = false) {
+             bool retried = false, bool no_persist = false) {
   if (!guess16 || !result) return e->fail(FVH_ERR_INVALID_ARGUMENT, "align: null argument");
   if (!vm.valid) return e->fail(FVH_ERR_BAD_STATE, "align: target voxel map not built");
   fvh_lm_params p;
@@ -609,7 +645,25 @@ int do_align(Engine* e, const CostSource& src, VoxelMapDev& vm, const double* gu
   long long launched = 0;
   int batch = e->last_steps > 0 ? std::max(e->last_steps, e->prev_steps) + 1 : 8;
   LmState* h = reinterpret_cast<LmState*>(e->pinned);
-  while (true) {
+  // One persistent launch for the whole LM loop when the problem is in the latency-bound regime, this handle is the only
+  // one aligning in the process right now (two persistent grids could starve each other of CU slots; the watchdog
+  // would catch it, but slowly) and there is no collective between evaluations.
+  static const int persist_env = [] { const char* v = getenv("FVH_PERSISTENT"); return v ? atoi(v) : 1; }();
+  const int active_before = g_active_aligns.fetch_add(1);
+  struct Leave { ~Leave() { g_active_aligns.fetch_sub(1); } } leave;
+  bool persistent = persist_env != 0 && !degenerate && !e->comm && !no_persist && active_before == 0 && (long long)src.n_upper * e->n_off <= PERSIST_MAX_ITEMS;
+  if (persistent) {
+    int rc = launch_cost<MODE>(e, src, vm, -1, &guess, nullptr, &p, true);
+    if (rc) return rc;
+    HIP_OR_FAIL(e, hipMemcpyAsync(h, st, sizeof(LmState), hipMemcpyDeviceToHost, e->stream));
+    HIP_OR_FAIL(e, hipStreamSynchronize(e->stream));
+    if (h->aborted || h->phase != PH_DONE) {  // the barrier watchdog fired (workgroups not co-resident): redo with one launch per transition
+      e->persist_aborts++;
+      return do_align<MODE>(e, src, vm, guess16, params, result, rebuild_safe, retried, true);
+    }
+    launched = 1;
+  }
+  while (!persistent) {
     for (int s = 0; s < batch; s++) {
       // the first launch carries the initial guess and the LM parameters and (re)initialises the device state
       const bool first = (launched == 0 && s == 0 && !degenerate);
@@ -632,7 +686,7 @@ int do_align(Engine* e, const CostSource& src, VoxelMapDev& vm, const double* gu
     if (retried) return e->fail(FVH_ERR_BAD_STATE, "voxel map overflow persists after safe rebuild");
     int rc = rebuild_safe();
     if (rc) return rc;
-    return do_align<MODE>(e, src, vm, guess16, params, result, rebuild_safe, true);
+    return do_align<MODE>(e, src, vm, guess16, params, result, rebuild_safe, true, no_persist);
   }
   e->prev_steps = e->last_steps;
   e->last_steps = 1 + h->num_error_evals;  // launches this align needed: the first linearize + one fused launch per trial
@@ -1018,6 +1072,14 @@ int fvh_vgicp_debug_set_voxel_hint(fvh_vgicp* h, int num_voxels) { CHECK_HANDLE(
 int fvh_vgicp_debug_get_table_capacity(fvh_vgicp* h, int* capacity) { CHECK_HANDLE(h); if (!capacity) return FVH_ERR_INVALID_ARGUMENT; *capacity = (int)h->voxelmap.capacity; return FVH_OK; }
 int fvh_vgicp_synchronize(fvh_vgicp* h) { CHECK_HANDLE(h); HIP_OR_FAIL(&h->e, hipStreamSynchronize(h->e.stream)); return FVH_OK; }
 
+#ifdef FVH_COST_TIMING
+// debug build only (not declared in the public header): out[0] = earliest workgroup start, out[1..7] = epilogue stamps of the last workgroup, 100 MHz ticks
+int fvh_debug_cost_timing(unsigned long long* out16, int reset) {
+  if (out16 && hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_cost_timing), sizeof(unsigned long long) * 16) != hipSuccess) return FVH_ERR_HIP;
+  if (reset) { unsigned long long init[16]; for (auto& v : init) v = ~0ull; if (hipMemcpyToSymbol(HIP_SYMBOL(g_cost_timing), init, sizeof(init)) != hipSuccess) return FVH_ERR_HIP; }
+  return FVH_OK;
+}
+#endif
 int fvh_comm_unique_id(void* id128) {
   if (!id128) return FVH_ERR_INVALID_ARGUMENT;
   if (!g_rccl.load()) return FVH_ERR_COMM;
@@ -1132,6 +1194,9 @@ int fvh_ndt_get_num_correspondences(fvh_ndt* h, int* n) {
   *n = c;
   return FVH_OK;
 }
+int fvh_ndt_profile_enable(fvh_ndt* h, int on) { CHECK_HANDLE(h); h->e.prof.on = on != 0; return FVH_OK; }
+int fvh_ndt_profile_reset(fvh_ndt* h) { CHECK_HANDLE(h); HIP_OR_FAIL(&h->e, hipStreamSynchronize(h->e.stream)); h->e.prof.reset(); return FVH_OK; }
+int fvh_ndt_profile_get(fvh_ndt* h, const char* cls, double* ms, int* n) { CHECK_HANDLE(h); return profile_get(&h->e, cls, ms, n); }
 int fvh_ndt_synchronize(fvh_ndt* h) { CHECK_HANDLE(h); HIP_OR_FAIL(&h->e, hipStreamSynchronize(h->e.stream)); return FVH_OK; }
 int fvh_ndt_comm_init(fvh_ndt* h, const void* id, int nranks, int rank) { CHECK_HANDLE(h); return comm_init(&h->e, id, nranks, rank); }
 int fvh_ndt_comm_destroy(fvh_ndt* h) { CHECK_HANDLE(h); if (h->e.comm) { g_rccl.CommDestroy(h->e.comm); h->e.comm = nullptr; } h->e.nranks = 1; h->e.rank = 0; return FVH_OK; }

@@ -17,6 +17,8 @@
 // (6x6 LDL^T, se3_exp, rho test, lambda schedule, convergence) so the next launch finds the new
 // pose in HBM. No host round trip inside the loop.
 #pragma once
+#include <cstddef>
+
 #include "dev_math.hpp"
 
 namespace fvh {
@@ -46,7 +48,12 @@ struct LmState {
   int corr_cur;       // which of the two correspondence buffers is current (device-LM mode flips it on accept)
   int vm_num_voxels;  // copied from the voxel map's counters by the last workgroup: capacity hint for the next build
   int vm_dropped;     // > 0: the hint-sized table overflowed -> host rebuilds at the safe size and re-runs
+  int pad_;
+  // LAST 8 bytes are never covered by the state write-back: `aborted` is raised by the persistent kernel's barrier
+  // watchdog (the host zeroes the word before the launch and falls back to one launch per transition if it is set)
+  unsigned gen, aborted;
 };
+static_assert(sizeof(LmState) % 8 == 0 && offsetof(LmState, gen) == sizeof(LmState) - 8, "barrier word must be the last 64-bit word of LmState");
 
 struct CostParams {
   const float4* src_pts;
@@ -73,6 +80,7 @@ struct CostParams {
   int defer_lm;               // 1: multi-GPU -- only publish st->sums, LM step runs after the all-reduce
   PoseD lin, ev;              // host mode poses; device-LM first launch (init = 1): lin = initial guess
   int init;                   // 1: this is the first launch of an align -- start from P.lin and (re)initialise the LM state
+  unsigned long long watchdog_ticks;  // persistent kernel: 100 MHz ticks a workgroup may wait at the barrier before it aborts the launch
   int max_iterations, lm_max_iterations;
   double rotation_epsilon, transformation_epsilon, lm_init_lambda_factor;
 };
@@ -305,14 +313,49 @@ __device__ __forceinline__ int probe_continue(const uint4* __restrict__ table, u
 }
 
 constexpr int COST_CH = 4;     // voxel lookups a thread keeps in flight at once
+constexpr int PERSIST_OPEN_WORD = 64;  // persistent kernel: index (in unsigned) of the barrier word {trips opened, abort}, 256 B away from the arrival counters
+constexpr int PERSIST_TICKET_BYTES = 512;
 constexpr int TICKET_GROUPS = 8;  // hierarchical arrival counters (one per XCD-sized group of workgroups) + 1 top counter
 
-template <typename Real, int MODE>
+// PERSIST = true: ONE launch runs the whole LM loop. Every trip of the outer loop is what one launch of the
+// non-persistent kernel does; instead of exiting, the workgroups wait at a barrier (monotonic arrival counters polled
+// with agent-scope loads), then every workgroup finishes the reduction and runs the LM step itself on its own LDS
+// copy of the state, and goes again until the state says PH_DONE. This removes the per-launch
+// dispatch + ramp (~4.5 us of an 18 us launch at 17k points, FVH_COST_TIMING) and the speculative no-op launches.
+// All workgroups must be co-resident (the host clamps the grid to the occupancy limit); a watchdog turns a stuck
+// barrier into an abort flag + fallback to the multi-launch path instead of a hang.
+__device__ __forceinline__ double uniform_f64(double x) {  // wave-uniform value -> SGPR pair
+  const unsigned long long u = (unsigned long long)__double_as_longlong(x);
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)u), hi = __builtin_amdgcn_readfirstlane((unsigned)(u >> 32));
+  return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+
+#ifdef FVH_COST_TIMING
+// Debug build only (-DFVH_COST_TIMING): 100 MHz wall-clock stamps of the LAST workgroup's walk through the epilogue
+// (slot 0 = earliest workgroup start of the launch, slot 9 = the last workgroup's own start). Read with
+// fvh_debug_cost_timing(); tools/cost_timing.py prints the breakdown.
+__device__ unsigned long long g_cost_timing[16];
+#define FVH_STAMP(i) do { if (threadIdx.x == 0) stamp[i] = wall_clock64(); } while (0)
+#else
+#define FVH_STAMP(i) do { } while (0)
+#endif
+
+template <typename Real, int MODE, bool PERSIST>
 __global__ __launch_bounds__(256) void cost_kernel(CostParams P) {
+#ifdef FVH_COST_TIMING
+  __shared__ unsigned long long stamp[12];  // LDS, not registers: must not change the kernel being measured
+  if (threadIdx.x == 0) { stamp[0] = wall_clock64(); atomicMin(&g_cost_timing[0], stamp[0]); }
+#endif
   __shared__ double red[4][PART_STRIDE];
   __shared__ double fin[8][PART_STRIDE];
   __shared__ int s_last;
+  __shared__ LmState s_st;
+  static_assert(sizeof(LmState) % 8 == 0, "LmState is copied as 64-bit words");
+  constexpr int ST_WORDS = sizeof(LmState) / 8 - 1;  // without the barrier word
+  static_assert(ST_WORDS <= 256, "one state word per thread after the barrier");
   LmState* st = P.st;
+  unsigned long long* st_words = reinterpret_cast<unsigned long long*>(st);
+  unsigned gen = 0;  // PERSIST: barrier generations this workgroup has passed
   int phase, corr_sel;
   PoseD lin_d, ev_d;
   if (P.host_phase >= 0) {
@@ -332,6 +375,7 @@ __global__ __launch_bounds__(256) void cost_kernel(CostParams P) {
     ev_d = (phase == PH_LINEARIZE) ? st->x0 : st->xi;
     corr_sel = st->corr_cur;
   }
+  for (;;) {  // PERSIST: one trip per LM transition; otherwise exactly one trip
   const bool fused = (P.host_phase < 0) && (phase == PH_TRIAL);  // trial error (old ids) + speculative linearisation at xi (new ids)
   const bool do_find = (phase == PH_LINEARIZE) || (phase == PH_FIND_ONLY) || fused;
   const bool do_cost = (phase != PH_FIND_ONLY);
@@ -471,7 +515,8 @@ __global__ __launch_bounds__(256) void cost_kernel(CostParams P) {
   // and 3 shuffle steps combine the 8 parts. ~66 LDS operations per thread instead of the 336
   // ds_bpermute of a per-value wave-shuffle tree (measured: the (H,b) launch cost 7 us more than
   // the error-only launch, almost all of it crossbar traffic).
-  if (!do_cost) return;
+  if (!do_cost) return;  // host-mode PH_FIND_ONLY (never persistent)
+  FVH_STAMP(1);
   constexpr int RED_ROWS = NSUM + 1, RED_STRIDE = 264;
   __shared__ double tile[RED_ROWS * RED_STRIDE];
   const int nsum = do_deriv ? NSUM : 1;
@@ -500,6 +545,7 @@ __global__ __launch_bounds__(256) void cost_kernel(CostParams P) {
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
+  FVH_STAMP(2);
 
   // ---- two-level arrival + two-level reduction ----------------------------------------------
   // Workgroup b belongs to group b % 8 (its XCD under the observed dispatch order). The last arriver
@@ -510,82 +556,185 @@ __global__ __launch_bounds__(256) void cost_kernel(CostParams P) {
   const unsigned grp = blockIdx.x % TICKET_GROUPS;
   const unsigned ngroups = min((unsigned)TICKET_GROUPS, gridDim.x);
   const unsigned gsize = (gridDim.x - grp + TICKET_GROUPS - 1) / TICKET_GROUPS;
-  if (threadIdx.x == 0) s_last = (atomicAdd(&P.ticket[grp], 1u) == gsize - 1);
-  __syncthreads();
-  if (!s_last) return;
-  {
-    const int v = threadIdx.x & 31, chunk = threadIdx.x >> 5;  // 8 chunks x 32 values
-    double s = 0.0;
-    for (unsigned j0 = chunk; j0 < gsize; j0 += 8 * 8) {
-      double t[8];
+  // sum of this group's partial rows -> fin[chunk][v] -> one group row (fixed order: deterministic)
+  auto reduce_group_rows = [&](size_t out_row) {
+    {
+      const int v = threadIdx.x & 31, chunk = threadIdx.x >> 5;  // 8 chunks x 32 values
+      double s = 0.0;
+      for (unsigned j0 = chunk; j0 < gsize; j0 += 8 * 8) {
+        double t[8];
 #pragma unroll
-      for (int u = 0; u < 8; u++) {
-        const unsigned j = j0 + 8 * u;
-        t[u] = (j < gsize) ? __hip_atomic_load(&P.partials[(size_t)(grp + j * TICKET_GROUPS) * PART_STRIDE + v], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
+        for (int u = 0; u < 8; u++) {
+          const unsigned j = j0 + 8 * u;
+          t[u] = (j < gsize) ? __hip_atomic_load(&P.partials[(size_t)(grp + j * TICKET_GROUPS) * PART_STRIDE + v], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; u++) s += t[u];
       }
-#pragma unroll
-      for (int u = 0; u < 8; u++) s += t[u];
+      fin[chunk][v] = s;
     }
-    fin[chunk][v] = s;
-  }
-  __syncthreads();
-  if (threadIdx.x < PART_STRIDE) {
-    const int v = threadIdx.x;
-    double s = 0.0;
+    __syncthreads();
+    if (threadIdx.x < PART_STRIDE) {
+      const int v = threadIdx.x;
+      double s = 0.0;
 #pragma unroll
-    for (int c = 0; c < 8; c++) s += fin[c][v];
-    __hip_atomic_store(&P.partials[(size_t)(MAX_PARTIAL_ROWS + grp) * PART_STRIDE + v], s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  if (threadIdx.x == 0) s_last = (atomicAdd(&P.ticket[TICKET_GROUPS], 1u) == ngroups - 1);
-  __syncthreads();
-  if (!s_last) return;
+      for (int c = 0; c < 8; c++) s += fin[c][v];
+      __hip_atomic_store(&P.partials[out_row * PART_STRIDE + v], s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  };
+  // sum of the <= 8 group rows in group order -> red[0][v]
+  auto reduce_final = [&](size_t first_row) {
+    {
+      const int v = threadIdx.x & 31;
+      const unsigned g = threadIdx.x >> 5;
+      fin[g][v] = (g < ngroups) ? __hip_atomic_load(&P.partials[(first_row + g) * PART_STRIDE + v], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
+    }
+    __syncthreads();
+    if (threadIdx.x < PART_STRIDE) {
+      const int v = threadIdx.x;
+      double s = 0.0;
+#pragma unroll
+      for (int c = 0; c < 8; c++) s += fin[c][v];
+      red[0][v] = s;
+    }
+  };
+  // what lm_init_kernel would have written (first evaluation of an align), on the LDS copy of the state
+  auto init_state = [&]() {
+    s_st.x0 = P.lin; s_st.xi = P.lin; s_st.x_lin = P.lin;
+    s_st.rotation_epsilon = P.rotation_epsilon; s_st.transformation_epsilon = P.transformation_epsilon; s_st.lm_init_lambda_factor = P.lm_init_lambda_factor;
+    s_st.max_iterations = P.max_iterations; s_st.lm_max_iterations = P.lm_max_iterations;
+    s_st.lambda = -1.0; s_st.nu = 2.0; s_st.y0 = 0.0;
+    s_st.phase = PH_LINEARIZE; s_st.corr_cur = 0;
+    s_st.outer_iter = 0; s_st.inner_iter = 0; s_st.converged = 0; s_st.lm_failed = 0; s_st.num_linearize = 0; s_st.num_error_evals = 0; s_st.nr_iterations = 0;
+    for (int i = 0; i < 36; i++) s_st.final_H[i] = (i % 7 == 0) ? 1.0 : 0.0;
+  };
 
-  // ---- the very last workgroup: sum the group rows in group order (deterministic), LM step ----
-  {
-    const int v = threadIdx.x & 31;
-    const unsigned g = threadIdx.x >> 5;
-    fin[g][v] = (g < ngroups) ? __hip_atomic_load(&P.partials[(size_t)(MAX_PARTIAL_ROWS + g) * PART_STRIDE + v], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
-  }
-  __syncthreads();
-  if (threadIdx.x < PART_STRIDE) {
-    const int v = threadIdx.x;
-    double s = 0.0;
-#pragma unroll
-    for (int c = 0; c < 8; c++) s += fin[c][v];
-    red[0][v] = s;
-  }
-  if (threadIdx.x <= TICKET_GROUPS) P.ticket[threadIdx.x] = 0;  // re-arm for the next launch
-  // The LM step is one thread of dependent fp64 math; run it on an LDS copy of the state (a global
-  // round trip per st-> access would cost more than the arithmetic) and write the state back with all lanes.
-  __shared__ LmState s_st;
-  static_assert(sizeof(LmState) % 8 == 0, "LmState is copied as 64-bit words");
-  constexpr int ST_WORDS = sizeof(LmState) / 8;
-  for (int i = threadIdx.x; i < ST_WORDS; i += 256) reinterpret_cast<unsigned long long*>(&s_st)[i] = reinterpret_cast<const unsigned long long*>(st)[i];
-  int vm_nv = 0, vm_dr = 0;
-  if (threadIdx.x == 0) {
-    vm_nv = P.vm_counters[0];
-    vm_dr = P.vm_counters[1] + (P.vm_counters2 ? P.vm_counters2[1] : 0);
-  }
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    for (int v = 0; v < PART_STRIDE; v++) s_st.sums[v] = red[0][v];
-    s_st.vm_num_voxels = vm_nv;
-    s_st.vm_dropped = vm_dr;
-    if (P.host_phase < 0 && P.init) {  // what lm_init_kernel would have written
-      s_st.x0 = P.lin; s_st.xi = P.lin; s_st.x_lin = P.lin;
-      s_st.rotation_epsilon = P.rotation_epsilon; s_st.transformation_epsilon = P.transformation_epsilon; s_st.lm_init_lambda_factor = P.lm_init_lambda_factor;
-      s_st.max_iterations = P.max_iterations; s_st.lm_max_iterations = P.lm_max_iterations;
-      s_st.lambda = -1.0; s_st.nu = 2.0; s_st.y0 = 0.0;
-      s_st.phase = PH_LINEARIZE; s_st.corr_cur = 0;
-      s_st.outer_iter = 0; s_st.inner_iter = 0; s_st.converged = 0; s_st.lm_failed = 0; s_st.num_linearize = 0; s_st.num_error_evals = 0; s_st.nr_iterations = 0;
-      for (int i = 0; i < 36; i++) s_st.final_H[i] = (i % 7 == 0) ? 1.0 : 0.0;
+  if constexpr (!PERSIST) {
+    // ---- two-level arrival + two-level reduction --------------------------------------------
+    // Workgroup b belongs to group b % 8 (its XCD under the observed dispatch order). The last arriver
+    // of a group sums that group's partial rows with all 256 threads (<= 8 independent sc1 loads per
+    // thread, fixed order), publishes one group row and arrives at the top counter; the last group
+    // sums the <= 8 group rows and runs the LM step. No address sees more than gridDim/8 + 8 atomics
+    // and no thread walks a long chain of dependent L2 round trips.
+    if (threadIdx.x == 0) s_last = (atomicAdd(&P.ticket[grp], 1u) == gsize - 1);
+    __syncthreads();
+    if (!s_last) return;
+    FVH_STAMP(3);
+    reduce_group_rows((size_t)MAX_PARTIAL_ROWS + grp);
+    if (threadIdx.x == 0) s_last = (atomicAdd(&P.ticket[TICKET_GROUPS], 1u) == ngroups - 1);
+    __syncthreads();
+    if (!s_last) return;
+    FVH_STAMP(4);
+
+    // ---- the very last workgroup: sum the group rows in group order (deterministic), LM step ----
+    reduce_final((size_t)MAX_PARTIAL_ROWS);
+    if (threadIdx.x <= TICKET_GROUPS) P.ticket[threadIdx.x] = 0;  // re-arm for the next launch
+    // The LM step is one thread of dependent fp64 math; run it on an LDS copy of the state (a global
+    // round trip per st-> access would cost more than the arithmetic) and write the state back with all lanes.
+    for (int i = threadIdx.x; i < ST_WORDS; i += 256) reinterpret_cast<unsigned long long*>(&s_st)[i] = st_words[i];
+    int vm_nv = 0, vm_dr = 0;
+    if (threadIdx.x == 0) {
+      vm_nv = P.vm_counters[0];
+      vm_dr = P.vm_counters[1] + (P.vm_counters2 ? P.vm_counters2[1] : 0);
     }
-    if (P.host_phase < 0 && !P.defer_lm) dev_lm_step(&s_st, red[0]);
+    __syncthreads();
+    FVH_STAMP(5);
+    if (threadIdx.x == 0) {
+      for (int v = 0; v < PART_STRIDE; v++) s_st.sums[v] = red[0][v];
+      s_st.vm_num_voxels = vm_nv;
+      s_st.vm_dropped = vm_dr;
+      if (P.host_phase < 0 && P.init) init_state();
+      if (P.host_phase < 0 && !P.defer_lm) dev_lm_step(&s_st, red[0]);
+    }
+    FVH_STAMP(6);
+    __syncthreads();
+    for (int i = threadIdx.x; i < ST_WORDS; i += 256) st_words[i] = reinterpret_cast<const unsigned long long*>(&s_st)[i];
+#ifdef FVH_COST_TIMING
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (threadIdx.x == 0) {
+      stamp[7] = wall_clock64();
+      for (int i = 1; i <= 7; i++) g_cost_timing[i] = stamp[i];
+      g_cost_timing[8] = gridDim.x;
+      g_cost_timing[9] = stamp[0];
+    }
+#endif
+    return;
+  } else {
+    // ---- persistent trip: the same two-level arrival, but nobody leaves -------------------------
+    // Counters are monotonic over the launch (the host zeroes them before it): the last arriver of a group in trip t
+    // is the one that draws gsize * (t + 1) - 1; the barrier opens when the top counter reaches ngroups * (t + 1).
+    // After the barrier EVERY workgroup sums the <= 8 group rows itself (one load per thread) and runs the LM step
+    // on its own LDS copy of the state: identical inputs, identical instruction stream -> identical state in all
+    // workgroups, with no publish-and-reload of the state on the critical path. Group rows are double-buffered by
+    // trip parity: a workgroup can be at most one trip ahead of a group row's last reader (it cannot pass the next
+    // barrier before every workgroup has arrived there, i.e. has finished reading this one).
+    const unsigned trip = gen;
+    const size_t grow0 = (size_t)MAX_PARTIAL_ROWS + (size_t)(trip & 1u) * TICKET_GROUPS;
+    if (threadIdx.x == 0) s_last = (atomicAdd(&P.ticket[grp], 1u) == gsize * (trip + 1) - 1);
+    __syncthreads();
+    if (s_last) {
+      reduce_group_rows(grow0 + grp);
+      // the last group opens the barrier through a word on ITS OWN cache line: ~500 pollers on the line of the
+      // arrival counters slowed every arrival atomic down (measured: +10 us per trip)
+      if (threadIdx.x == 0 && atomicAdd(&P.ticket[TICKET_GROUPS], 1u) == ngroups * (trip + 1) - 1)
+        __hip_atomic_store(&P.ticket[PERSIST_OPEN_WORD], trip + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (threadIdx.x == 0) {
+      const unsigned long long* word = reinterpret_cast<const unsigned long long*>(&P.ticket[PERSIST_OPEN_WORD]);  // {trips opened, abort flag}
+      const unsigned want = trip + 1;
+      const unsigned long long t0 = wall_clock64();
+      int ok = 1;
+      for (;;) {
+        const unsigned long long wv = __hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if ((wv >> 32) != 0) { ok = 0; break; }
+        if ((unsigned)wv >= want) break;
+        if (wall_clock64() - t0 > P.watchdog_ticks) {  // not every workgroup is resident / something is stuck: never hang the GPU
+          __hip_atomic_store(&P.ticket[PERSIST_OPEN_WORD + 1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          __hip_atomic_store(&st->aborted, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          ok = 0;
+          break;
+        }
+        __builtin_amdgcn_s_sleep(1);
+      }
+      s_last = ok;
+    }
+    __syncthreads();
+    if (!s_last) return;
+    reduce_final(grow0);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      if (trip == 0) {
+        init_state();
+        s_st.vm_num_voxels = P.vm_counters[0];
+        s_st.vm_dropped = P.vm_counters[1] + (P.vm_counters2 ? P.vm_counters2[1] : 0);
+      }
+      for (int v = 0; v < PART_STRIDE; v++) s_st.sums[v] = red[0][v];
+      dev_lm_step(&s_st, red[0]);
+    }
+    __syncthreads();
+    gen++;
+    // LDS loads land in VGPRs; these values are wave-uniform, so move them to SGPRs (two PoseD in VGPRs cost the
+    // kernel its second wave per SIMD, i.e. half of the co-resident workgroups the barrier needs)
+    phase = __builtin_amdgcn_readfirstlane(s_st.phase);
+    if (phase == PH_DONE) {
+      if (blockIdx.x == 0)
+        for (int i = threadIdx.x; i < ST_WORDS; i += 256) st_words[i] = reinterpret_cast<const unsigned long long*>(&s_st)[i];
+      return;
+    }
+    corr_sel = __builtin_amdgcn_readfirstlane(s_st.corr_cur);
+    {
+      const PoseD& pl = s_st.x_lin;
+      const PoseD& pe = (phase == PH_LINEARIZE) ? s_st.x0 : s_st.xi;
+#pragma unroll
+      for (int i = 0; i < 9; i++) { lin_d.r[i] = uniform_f64(pl.r[i]); ev_d.r[i] = uniform_f64(pe.r[i]); }
+#pragma unroll
+      for (int i = 0; i < 3; i++) { lin_d.t[i] = uniform_f64(pl.t[i]); ev_d.t[i] = uniform_f64(pe.t[i]); }
+    }
+    __syncthreads();  // thread 0 rewrites s_st after the next barrier
   }
-  __syncthreads();
-  for (int i = threadIdx.x; i < ST_WORDS; i += 256) reinterpret_cast<unsigned long long*>(st)[i] = reinterpret_cast<const unsigned long long*>(&s_st)[i];
+  }  // trips
 }
 
 }  // namespace fvh

@@ -174,6 +174,9 @@ int fvh_ndt_fitness_score(fvh_ndt* h, const double* T16, double max_range, doubl
 int fvh_ndt_get_num_voxels(fvh_ndt* h, int which /* 0 source, 1 target */, int* num_voxels);
 int fvh_ndt_get_voxels(fvh_ndt* h, int which, int* coords3, int* num_points, float* means3, float* covs9);
 int fvh_ndt_get_num_correspondences(fvh_ndt* h, int* n);
+int fvh_ndt_profile_enable(fvh_ndt* h, int on);                                              /* HIP-event timing per kernel class, as fvh_vgicp_profile_* */
+int fvh_ndt_profile_reset(fvh_ndt* h);
+int fvh_ndt_profile_get(fvh_ndt* h, const char* kernel_class, double* total_ms, int* launches);
 int fvh_ndt_synchronize(fvh_ndt* h);
 int fvh_ndt_comm_init(fvh_ndt* h, const void* id128, int nranks, int rank);
 int fvh_ndt_comm_destroy(fvh_ndt* h);
