@@ -297,6 +297,11 @@ class VGICPCore(_Core):
     def debug_set_voxel_hint(self, n):
         self._call("debug_set_voxel_hint", int(n))
 
+    def debug_persist_aborts(self):
+        n = C.c_int(0)
+        self._call("debug_get_persist_aborts", C.byref(n))
+        return n.value
+
     def debug_table_capacity(self):
         n = C.c_int(0)
         self._call("debug_get_table_capacity", C.byref(n))

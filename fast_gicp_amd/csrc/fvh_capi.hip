@@ -130,6 +130,8 @@ struct Engine {
   std::vector<int> offsets_host{0, 0, 0};
   int n_off = 1;
   DevBuf pticket;  // arrival counters of the persistent LM kernel (zeroed before every launch)
+  DevBuf bcast;    // its broadcast rows (tagged with persist_seq, never cleared)
+  unsigned long long persist_seq = 0;
   DevBuf offsets_dev, state, partials, ticket, corr, misc, fit, staging, sort_keys, sort_idx, sort_hist;
   void* pinned = nullptr;  // sizeof(LmState) + slack
   PoseD lin;               // pose of the last update_correspondences()
@@ -155,6 +157,8 @@ struct Engine {
     if ((e = partials.ensure(sizeof(double) * PART_STRIDE * (MAX_COST_BLOCKS + 2 * TICKET_GROUPS))) != hipSuccess) return hipfail(e, "hipMalloc");
     if ((e = ticket.ensure(64)) != hipSuccess) return hipfail(e, "hipMalloc");
     if ((e = pticket.ensure(PERSIST_TICKET_BYTES)) != hipSuccess) return hipfail(e, "hipMalloc");
+    if ((e = bcast.ensure(sizeof(double) * PERSIST_REPLICAS * BCAST_SLOTS)) != hipSuccess) return hipfail(e, "hipMalloc");
+    (void)hipMemsetAsync(bcast.p, 0, sizeof(double) * PERSIST_REPLICAS * BCAST_SLOTS, stream);
     if ((e = misc.ensure(256)) != hipSuccess) return hipfail(e, "hipMalloc");
     if ((e = fit.ensure(64)) != hipSuccess) return hipfail(e, "hipMalloc");
     (void)hipMemsetAsync(state.p, 0, sizeof(LmState), stream);
@@ -173,7 +177,7 @@ struct Engine {
     if (comm && g_rccl.CommDestroy) g_rccl.CommDestroy(comm);
     comm = nullptr;
     prof.destroy();
-    pticket.release(); offsets_dev.release(); state.release(); partials.release(); ticket.release(); corr.release(); misc.release(); fit.release(); staging.release(); sort_keys.release(); sort_idx.release(); sort_hist.release();
+    pticket.release(); bcast.release(); offsets_dev.release(); state.release(); partials.release(); ticket.release(); corr.release(); misc.release(); fit.release(); staging.release(); sort_keys.release(); sort_idx.release(); sort_hist.release();
     if (pinned) (void)hipHostFree(pinned);
     if (stream) (void)hipStreamDestroy(stream);
   }
@@ -554,7 +558,10 @@ int launch_cost(Engine* e, const CostSource& src, const VoxelMapDev& vm, int hos
     const int cap = persistent_capacity<MODE>(e);
     if (cap <= 0) return e->fail(FVH_ERR_HIP, "persistent cost kernel: occupancy query failed");
     blocks = std::min(blocks, cap);
-    P.watchdog_ticks = PERSIST_WATCHDOG_TICKS;
+    { const char* v = getenv("FVH_PERSIST_WATCHDOG_TICKS"); P.watchdog_ticks = v ? strtoull(v, nullptr, 10) : PERSIST_WATCHDOG_TICKS; }  // test hook: 0 forces the abort + fallback path
+    { const char* v = getenv("FVH_POLL_PRESLEEP"); P.poll_presleep = v ? atoi(v) : 0; }
+    P.bcast = e->bcast.as<double>();
+    P.launch_tag = ++e->persist_seq;
     // abort word = 0 (the last 8 bytes of the state; never covered by the state write-back); arrival counters = 0
     HIP_OR_FAIL(e, hipMemsetAsync(reinterpret_cast<char*>(e->state.p) + sizeof(LmState) - 8, 0, 8, e->stream));
     HIP_OR_FAIL(e, hipMemsetAsync(e->pticket.p, 0, PERSIST_TICKET_BYTES, e->stream));
@@ -651,7 +658,7 @@ int do_align(Engine* e, const CostSource& src, VoxelMapDev& vm, const double* gu
   static const int persist_env = [] { const char* v = getenv("FVH_PERSISTENT"); return v ? atoi(v) : 1; }();
   const int active_before = g_active_aligns.fetch_add(1);
   struct Leave { ~Leave() { g_active_aligns.fetch_sub(1); } } leave;
-  bool persistent = persist_env != 0 && !degenerate && !e->comm && !no_persist && active_before == 0 && (long long)src.n_upper * e->n_off <= PERSIST_MAX_ITEMS;
+  bool persistent = persist_env != 0 && !degenerate && !e->comm && !no_persist && active_before == 0 && budget < 4000 && (long long)src.n_upper * e->n_off <= PERSIST_MAX_ITEMS;
   if (persistent) {
     int rc = launch_cost<MODE>(e, src, vm, -1, &guess, nullptr, &p, true);
     if (rc) return rc;
@@ -1069,11 +1076,21 @@ int fvh_vgicp_profile_enable(fvh_vgicp* h, int on) { CHECK_HANDLE(h); h->e.prof.
 int fvh_vgicp_profile_reset(fvh_vgicp* h) { CHECK_HANDLE(h); HIP_OR_FAIL(&h->e, hipStreamSynchronize(h->e.stream)); h->e.prof.reset(); return FVH_OK; }
 int fvh_vgicp_profile_get(fvh_vgicp* h, const char* cls, double* ms, int* n) { CHECK_HANDLE(h); return profile_get(&h->e, cls, ms, n); }
 int fvh_vgicp_debug_set_voxel_hint(fvh_vgicp* h, int num_voxels) { CHECK_HANDLE(h); h->voxelmap.nv_hint = num_voxels; return FVH_OK; }
+int fvh_vgicp_debug_get_persist_aborts(fvh_vgicp* h, int* n) { CHECK_HANDLE(h); if (!n) return FVH_ERR_INVALID_ARGUMENT; *n = h->e.persist_aborts; return FVH_OK; }
 int fvh_vgicp_debug_get_table_capacity(fvh_vgicp* h, int* capacity) { CHECK_HANDLE(h); if (!capacity) return FVH_ERR_INVALID_ARGUMENT; *capacity = (int)h->voxelmap.capacity; return FVH_OK; }
 int fvh_vgicp_synchronize(fvh_vgicp* h) { CHECK_HANDLE(h); HIP_OR_FAIL(&h->e, hipStreamSynchronize(h->e.stream)); return FVH_OK; }
 
 #ifdef FVH_COST_TIMING
 // debug build only (not declared in the public header): out[0] = earliest workgroup start, out[1..7] = epilogue stamps of the last workgroup, 100 MHz ticks
+int fvh_debug_persist_timing(unsigned long long* out, int reset) {  // out: [16][512][12]
+  const size_t bytes = sizeof(unsigned long long) * 16 * 512 * 12;
+  if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(g_ptime), bytes) != hipSuccess) return FVH_ERR_HIP;
+  if (reset) {
+    void* p = nullptr;
+    if (hipGetSymbolAddress(&p, HIP_SYMBOL(g_ptime)) != hipSuccess || hipMemset(p, 0, bytes) != hipSuccess) return FVH_ERR_HIP;
+  }
+  return FVH_OK;
+}
 int fvh_debug_cost_timing(unsigned long long* out16, int reset) {
   if (out16 && hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_cost_timing), sizeof(unsigned long long) * 16) != hipSuccess) return FVH_ERR_HIP;
   if (reset) { unsigned long long init[16]; for (auto& v : init) v = ~0ull; if (hipMemcpyToSymbol(HIP_SYMBOL(g_cost_timing), init, sizeof(init)) != hipSuccess) return FVH_ERR_HIP; }

@@ -80,6 +80,9 @@ struct CostParams {
   int defer_lm;               // 1: multi-GPU -- only publish st->sums, LM step runs after the all-reduce
   PoseD lin, ev;              // host mode poses; device-LM first launch (init = 1): lin = initial guess
   int init;                   // 1: this is the first launch of an align -- start from P.lin and (re)initialise the LM state
+  int poll_presleep;          // persistent kernel (experiment): units of s_sleep(16) before the first poll
+  double* bcast;              // persistent kernel: [PERSIST_REPLICAS][BCAST_SLOTS] broadcast rows
+  unsigned long long launch_tag;  // persistent kernel: sequence number of this launch (tags of older launches never match)
   unsigned long long watchdog_ticks;  // persistent kernel: 100 MHz ticks a workgroup may wait at the barrier before it aborts the launch
   int max_iterations, lm_max_iterations;
   double rotation_epsilon, transformation_epsilon, lm_init_lambda_factor;
@@ -89,17 +92,24 @@ struct CostParams {
 // LM step on one thread (lsq_registration_impl.hpp:82-91,123-168; so3.hpp:58-104)
 // ------------------------------------------------------------------------------------------------
 __device__ inline void dev_se3_exp(const double a[6], PoseD& T) {
+  // This runs on ONE lane between two evaluations of the cost, so its instruction count is latency on the critical path
+  // of every LM transition (measured: four libm calls + 21 divisions made the persistent kernel 36 us slower per align).
+  // One sincos of the half angle; the full-angle terms of the V matrix follow from the double-angle identities
+  //   1 - cos(t) = 2 sin^2(t/2),   sin(t) = 2 sin(t/2) cos(t/2)
+  // (so3.hpp:58-104 calls sin/cos four times; oracle probe ORC_LM_ARITH_VARIANT=2: converged poses agree to 5e-15).
   const double ox = a[0], oy = a[1], oz = a[2];
   const double theta_sq = ox * ox + oy * oy + oz * oz;
+  const double theta = sqrt(theta_sq);
+  double sh = 0.0, ch = 1.0;
+  if (theta >= 1e-10) sincos(0.5 * theta, &sh, &ch);  // needed by the V matrix even when the quaternion takes its Taylor branch
   double imag, real;
   if (theta_sq < 1e-10) {
     const double tq = theta_sq * theta_sq;
     imag = 0.5 - 1.0 / 48.0 * theta_sq + 1.0 / 3840.0 * tq;
     real = 1.0 - 1.0 / 8.0 * theta_sq + 1.0 / 384.0 * tq;
   } else {
-    const double th = sqrt(theta_sq), half = 0.5 * th;
-    imag = sin(half) / th;
-    real = cos(half);
+    imag = sh / theta;
+    real = ch;
   }
   const double qw = real, qx = imag * ox, qy = imag * oy, qz = imag * oz;
   const double tx = 2 * qx, ty = 2 * qy, tz = 2 * qz;
@@ -107,14 +117,13 @@ __device__ inline void dev_se3_exp(const double a[6], PoseD& T) {
   T.r[0] = 1 - (tyy + tzz); T.r[1] = txy - twz;       T.r[2] = txz + twy;
   T.r[3] = txy + twz;       T.r[4] = 1 - (txx + tzz); T.r[5] = tyz - twx;
   T.r[6] = txz - twy;       T.r[7] = tyz + twx;       T.r[8] = 1 - (txx + tyy);
-  const double theta = sqrt(theta_sq);
   double V[9];
   if (theta < 1e-10) {
 #pragma unroll
     for (int i = 0; i < 9; i++) V[i] = T.r[i];
   } else {
-    const double tsq = theta * theta;
-    const double A = (1.0 - cos(theta)) / tsq, B = (theta - sin(theta)) / (tsq * theta);
+    const double inv_tsq = 1.0 / theta_sq;
+    const double A = 2.0 * sh * sh * inv_tsq, B = (theta - 2.0 * sh * ch) * inv_tsq / theta;
     // Omega = skew(omega), Omega^2
     const double O[9] = {0, -oz, oy, oz, 0, -ox, -oy, ox, 0};
     double O2[9];
@@ -139,29 +148,32 @@ __device__ inline void dev_pose_mul(const PoseD& A, const PoseD& B, PoseD& C) { 
 }
 
 __device__ inline void dev_ldlt6_solve(const double* A, const double* rhs, double* x) {
-  double L[36], D[6], y[6];
-  for (int i = 0; i < 36; i++) L[i] = 0.0;
+  // one reciprocal per pivot (6 divisions instead of 21: each fp64 division is ~12 dependent instructions on the one
+  // lane that runs this; oracle probe ORC_LM_ARITH_VARIANT=1: converged poses agree to 2e-17); only the strictly
+  // lower part of L is used
+  double L[36], D[6], Dinv[6], y[6];
   for (int j = 0; j < 6; j++) {
     double dj = A[j * 6 + j];
     for (int k = 0; k < j; k++) dj -= L[j * 6 + k] * L[j * 6 + k] * D[k];
     D[j] = dj;
-    L[j * 6 + j] = 1.0;
+    Dinv[j] = 1.0 / dj;
     for (int i = j + 1; i < 6; i++) {
       double s = A[i * 6 + j];
       for (int k = 0; k < j; k++) s -= L[i * 6 + k] * L[j * 6 + k] * D[k];
-      L[i * 6 + j] = s / dj;
+      L[i * 6 + j] = s * Dinv[j];
     }
   }
   for (int i = 0; i < 6; i++) { double s = rhs[i]; for (int k = 0; k < i; k++) s -= L[i * 6 + k] * y[k]; y[i] = s; }
-  for (int i = 0; i < 6; i++) y[i] /= D[i];
+  for (int i = 0; i < 6; i++) y[i] *= Dinv[i];
   for (int i = 5; i >= 0; i--) { double s = y[i]; for (int k = i + 1; k < 6; k++) s -= L[k * 6 + i] * x[k]; x[i] = s; }
 }
 
 __device__ inline bool dev_is_converged(const LmState* st, const PoseD& delta) {
+  // lsq_registration_impl.hpp:82-91: (|R - I|.max / rot_eps, |t|.max / trans_eps).max < 1 -- the max first, two divisions
   double rmax = 0, tmax = 0;
-  for (int i = 0; i < 9; i++) rmax = fmax(rmax, fabs(delta.r[i] - ((i % 4 == 0) ? 1.0 : 0.0)) / st->rotation_epsilon);
-  for (int i = 0; i < 3; i++) tmax = fmax(tmax, fabs(delta.t[i]) / st->transformation_epsilon);
-  return fmax(rmax, tmax) < 1;
+  for (int i = 0; i < 9; i++) rmax = fmax(rmax, fabs(delta.r[i] - ((i % 4 == 0) ? 1.0 : 0.0)));
+  for (int i = 0; i < 3; i++) tmax = fmax(tmax, fabs(delta.t[i]));
+  return fmax(rmax / st->rotation_epsilon, tmax / st->transformation_epsilon) < 1;
 }
 
 // sums -> symmetric 6x6 H (row-major) and b
@@ -313,8 +325,9 @@ __device__ __forceinline__ int probe_continue(const uint4* __restrict__ table, u
 }
 
 constexpr int COST_CH = 4;     // voxel lookups a thread keeps in flight at once
-constexpr int PERSIST_OPEN_WORD = 64;  // persistent kernel: index (in unsigned) of the barrier word {trips opened, abort}, 256 B away from the arrival counters
-constexpr int PERSIST_TICKET_BYTES = 512;
+constexpr int PERSIST_TICKET_BYTES = 9 * 128;  // persistent kernel: 8 group counters + top counter, one 128-B line each
+constexpr int PERSIST_REPLICAS = 32;           // copies of the broadcast row; workgroup b polls copy b % PERSIST_REPLICAS
+constexpr int BCAST_SLOTS = 40;                // 5 segments of 64 B = 7 sums + 1 tag each (35 >= 29 sums)
 constexpr int TICKET_GROUPS = 8;  // hierarchical arrival counters (one per XCD-sized group of workgroups) + 1 top counter
 
 // PERSIST = true: ONE launch runs the whole LM loop. Every trip of the outer loop is what one launch of the
@@ -335,9 +348,14 @@ __device__ __forceinline__ double uniform_f64(double x) {  // wave-uniform value
 // (slot 0 = earliest workgroup start of the launch, slot 9 = the last workgroup's own start). Read with
 // fvh_debug_cost_timing(); tools/cost_timing.py prints the breakdown.
 __device__ unsigned long long g_cost_timing[16];
+__device__ unsigned long long g_ptime[16][512][12];  // persistent kernel, per trip and workgroup: {start, main end, arrival, open (opener only), seen, LM done}; plain stores, no shared address
 #define FVH_STAMP(i) do { if (threadIdx.x == 0) stamp[i] = wall_clock64(); } while (0)
+#define FVH_PT_MIN(trip, k) do { if (threadIdx.x == 0 && (trip) < 16 && blockIdx.x < 512) g_ptime[trip][blockIdx.x][k] = wall_clock64(); } while (0)
+#define FVH_PT_MAX(trip, k) FVH_PT_MIN(trip, k)
 #else
 #define FVH_STAMP(i) do { } while (0)
+#define FVH_PT_MIN(trip, k) do { } while (0)
+#define FVH_PT_MAX(trip, k) do { } while (0)
 #endif
 
 template <typename Real, int MODE, bool PERSIST>
@@ -376,6 +394,7 @@ __global__ __launch_bounds__(256) void cost_kernel(CostParams P) {
     corr_sel = st->corr_cur;
   }
   for (;;) {  // PERSIST: one trip per LM transition; otherwise exactly one trip
+  if (PERSIST) FVH_PT_MIN(gen, 0);
   const bool fused = (P.host_phase < 0) && (phase == PH_TRIAL);  // trial error (old ids) + speculative linearisation at xi (new ids)
   const bool do_find = (phase == PH_LINEARIZE) || (phase == PH_FIND_ONLY) || fused;
   const bool do_cost = (phase != PH_FIND_ONLY);
@@ -517,6 +536,7 @@ __global__ __launch_bounds__(256) void cost_kernel(CostParams P) {
   // the error-only launch, almost all of it crossbar traffic).
   if (!do_cost) return;  // host-mode PH_FIND_ONLY (never persistent)
   FVH_STAMP(1);
+  if (PERSIST) FVH_PT_MAX(gen, 1);
   constexpr int RED_ROWS = NSUM + 1, RED_STRIDE = 264;
   __shared__ double tile[RED_ROWS * RED_STRIDE];
   const int nsum = do_deriv ? NSUM : 1;
@@ -664,75 +684,123 @@ __global__ __launch_bounds__(256) void cost_kernel(CostParams P) {
   } else {
     // ---- persistent trip: the same two-level arrival, but nobody leaves -------------------------
     // Counters are monotonic over the launch (the host zeroes them before it): the last arriver of a group in trip t
-    // is the one that draws gsize * (t + 1) - 1; the barrier opens when the top counter reaches ngroups * (t + 1).
-    // After the barrier EVERY workgroup sums the <= 8 group rows itself (one load per thread) and runs the LM step
-    // on its own LDS copy of the state: identical inputs, identical instruction stream -> identical state in all
-    // workgroups, with no publish-and-reload of the state on the critical path. Group rows are double-buffered by
-    // trip parity: a workgroup can be at most one trip ahead of a group row's last reader (it cannot pass the next
-    // barrier before every workgroup has arrived there, i.e. has finished reading this one).
+    // draws gsize * (t + 1) - 1, the last group draws ngroups * (t + 1) - 1 at the top counter. That workgroup (the
+    // "opener") sums the <= 8 group rows, runs the LM step on the state (global memory, write-through) and BROADCASTS
+    // what the next trip needs -- phase, correspondence buffer, the two poses: 26 values -- as PERSIST_REPLICAS copies
+    // of a 40-double row in which every 64-byte segment is 7 values + a tag (launch sequence, trip), written by 8
+    // adjacent lanes of one store instruction. Workgroup b polls copy b % PERSIST_REPLICAS with ONE 40-lane load per
+    // poll: when all 5 tags match, the values in the same segments are this trip's -- barrier and payload in a single
+    // memory round trip, and no address is read by more than ~8 workgroups.
+    // Dead ends measured on the way (474 workgroups, 17k points): one barrier word on the line of the arrival counters
+    // (+10 us per trip); one barrier word + every workgroup reloading the state (21.6 us per trip: ~500 readers of the
+    // same lines queue at their memory channel); every workgroup running the LM step redundantly on its own copy
+    // (22.7 us per trip: the step takes 5 us instead of 1.5 when ~500 waves fetch its code at once).
+    // Group rows alternate by trip parity; only the opener reads them, and trip t + 1's rows are written after every
+    // workgroup -- the opener of trip t included -- has arrived at trip t + 1.
     const unsigned trip = gen;
+    const double want_tag = (double)(P.launch_tag * 4096ull + trip + 1);
+    const double abort_tag = -(double)(P.launch_tag * 4096ull);  // launch-specific: a poisoned row of an older launch means nothing
     const size_t grow0 = (size_t)MAX_PARTIAL_ROWS + (size_t)(trip & 1u) * TICKET_GROUPS;
-    if (threadIdx.x == 0) s_last = (atomicAdd(&P.ticket[grp], 1u) == gsize * (trip + 1) - 1);
+    __shared__ double bc[BCAST_SLOTS];  // payload of the broadcast row as seen by this workgroup
+    bool opener = false;
+    if (threadIdx.x == 0) s_last = (atomicAdd(&P.ticket[grp * 32], 1u) == gsize * (trip + 1) - 1);
+    FVH_PT_MAX(trip, 2);
     __syncthreads();
     if (s_last) {
       reduce_group_rows(grow0 + grp);
-      // the last group opens the barrier through a word on ITS OWN cache line: ~500 pollers on the line of the
-      // arrival counters slowed every arrival atomic down (measured: +10 us per trip)
-      if (threadIdx.x == 0 && atomicAdd(&P.ticket[TICKET_GROUPS], 1u) == ngroups * (trip + 1) - 1)
-        __hip_atomic_store(&P.ticket[PERSIST_OPEN_WORD], trip + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    if (threadIdx.x == 0) {
-      const unsigned long long* word = reinterpret_cast<const unsigned long long*>(&P.ticket[PERSIST_OPEN_WORD]);  // {trips opened, abort flag}
-      const unsigned want = trip + 1;
-      const unsigned long long t0 = wall_clock64();
-      int ok = 1;
-      for (;;) {
-        const unsigned long long wv = __hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if ((wv >> 32) != 0) { ok = 0; break; }
-        if ((unsigned)wv >= want) break;
-        if (wall_clock64() - t0 > P.watchdog_ticks) {  // not every workgroup is resident / something is stuck: never hang the GPU
-          __hip_atomic_store(&P.ticket[PERSIST_OPEN_WORD + 1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          __hip_atomic_store(&st->aborted, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          ok = 0;
-          break;
+      FVH_PT_MAX(trip, 5);
+      if (threadIdx.x == 0) s_last = (atomicAdd(&P.ticket[TICKET_GROUPS * 32], 1u) == ngroups * (trip + 1) - 1);
+      __syncthreads();
+      opener = s_last != 0;
+      if (opener) FVH_PT_MAX(trip, 6);
+      if (opener) {
+        // the state as the previous opener left it (its stores completed before it arrived at this trip's counters)
+        unsigned long long stw = 0;
+        if (trip > 0 && threadIdx.x < ST_WORDS) stw = __hip_atomic_load(&st_words[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        reduce_final(grow0);
+        if (trip > 0 && threadIdx.x < ST_WORDS) reinterpret_cast<unsigned long long*>(&s_st)[threadIdx.x] = stw;
+        __syncthreads();
+        FVH_PT_MAX(trip, 7);
+        if (trip == 0 && threadIdx.x == 0) {
+          init_state();
+          s_st.vm_num_voxels = P.vm_counters[0];
+          s_st.vm_dropped = P.vm_counters[1] + (P.vm_counters2 ? P.vm_counters2[1] : 0);
         }
-        __builtin_amdgcn_s_sleep(1);
+        if (threadIdx.x >= 64 && threadIdx.x < 64 + PART_STRIDE) s_st.sums[threadIdx.x - 64] = red[0][threadIdx.x - 64];  // (a lane each, not 32 round trips of lane 0)
+        __syncthreads();
+        FVH_PT_MAX(trip, 8);
+        if (threadIdx.x == 0) dev_lm_step(&s_st, red[0]);
+        FVH_PT_MAX(trip, 9);
+        __syncthreads();
+        if (threadIdx.x < 26) {  // payload: phase, correspondence buffer, x_lin, evaluation pose of the next trip
+          const int ph = s_st.phase;
+          const PoseD& pe = (ph == PH_LINEARIZE) ? s_st.x0 : s_st.xi;
+          const int d = threadIdx.x;
+          double v;
+          if (d == 0) v = (double)ph;
+          else if (d == 1) v = (double)s_st.corr_cur;
+          else if (d < 11) v = s_st.x_lin.r[d - 2];
+          else if (d < 14) v = s_st.x_lin.t[d - 11];
+          else if (d < 23) v = pe.r[d - 14];
+          else v = pe.t[d - 23];
+          bc[d] = v;
+        }
+        __syncthreads();
+        FVH_PT_MAX(trip, 10);
+        for (int idx = threadIdx.x; idx < PERSIST_REPLICAS * BCAST_SLOTS; idx += 256) {
+          const int slot = idx % BCAST_SLOTS, seg = slot >> 3, k = slot & 7, d = seg * 7 + k;
+          const double val = (k == 7) ? want_tag : (d < 26 ? bc[d] : 0.0);
+          __hip_atomic_store(&P.bcast[idx], val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        FVH_PT_MAX(trip, 3);
+        for (int i = threadIdx.x; i < ST_WORDS; i += 256)
+          __hip_atomic_store(&st_words[i], reinterpret_cast<const unsigned long long*>(&s_st)[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the next opener reads the state after our next arrival
       }
-      s_last = ok;
+      __syncthreads();
     }
-    __syncthreads();
-    if (!s_last) return;
-    reduce_final(grow0);
-    __syncthreads();
-    if (threadIdx.x == 0) {
-      if (trip == 0) {
-        init_state();
-        s_st.vm_num_voxels = P.vm_counters[0];
-        s_st.vm_dropped = P.vm_counters[1] + (P.vm_counters2 ? P.vm_counters2[1] : 0);
+    if (!opener) {
+      if (threadIdx.x < 64) {  // wave 0 polls this workgroup's copy
+        const double* rep = P.bcast + (size_t)(blockIdx.x % PERSIST_REPLICAS) * BCAST_SLOTS;
+        const int lane = threadIdx.x;
+        const bool is_slot = lane < BCAST_SLOTS, is_tag = is_slot && ((lane & 7) == 7);
+        const unsigned long long t0 = wall_clock64();
+        int ok = 0;
+        for (int k = 0; k < P.poll_presleep; k++) __builtin_amdgcn_s_sleep(16);  // experiment: keep early arrivers quiet (~0.5 us per unit)
+        for (;;) {
+          const double v = is_slot ? __hip_atomic_load(&rep[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
+          if (__any(is_tag && v == abort_tag)) break;  // another workgroup's watchdog aborted THIS launch
+          if (__all(!is_tag || v == want_tag)) {
+            const int d = (lane >> 3) * 7 + (lane & 7);
+            if (is_slot && !is_tag && d < 26) bc[d] = v;
+            ok = 1;
+            break;
+          }
+          if (__builtin_amdgcn_readfirstlane((int)(wall_clock64() - t0 > P.watchdog_ticks))) {
+            // not every workgroup is resident / something is stuck: never hang the GPU -- poison every tag and leave
+            for (int idx = lane; idx < PERSIST_REPLICAS * BCAST_SLOTS / 8; idx += 64) __hip_atomic_store(&P.bcast[idx * 8 + 7], abort_tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (lane == 0) __hip_atomic_store(&st->aborted, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            break;
+          }
+          __builtin_amdgcn_s_sleep(1);
+        }
+        if (lane == 0) s_last = ok;
       }
-      for (int v = 0; v < PART_STRIDE; v++) s_st.sums[v] = red[0][v];
-      dev_lm_step(&s_st, red[0]);
+      __syncthreads();
+      if (!s_last) return;
     }
-    __syncthreads();
+    FVH_PT_MAX(trip, 4);
     gen++;
     // LDS loads land in VGPRs; these values are wave-uniform, so move them to SGPRs (two PoseD in VGPRs cost the
     // kernel its second wave per SIMD, i.e. half of the co-resident workgroups the barrier needs)
-    phase = __builtin_amdgcn_readfirstlane(s_st.phase);
-    if (phase == PH_DONE) {
-      if (blockIdx.x == 0)
-        for (int i = threadIdx.x; i < ST_WORDS; i += 256) st_words[i] = reinterpret_cast<const unsigned long long*>(&s_st)[i];
-      return;
-    }
-    corr_sel = __builtin_amdgcn_readfirstlane(s_st.corr_cur);
-    {
-      const PoseD& pl = s_st.x_lin;
-      const PoseD& pe = (phase == PH_LINEARIZE) ? s_st.x0 : s_st.xi;
+    phase = (int)uniform_f64(bc[0]);
+    if (phase == PH_DONE) return;
+    corr_sel = (int)uniform_f64(bc[1]);
 #pragma unroll
-      for (int i = 0; i < 9; i++) { lin_d.r[i] = uniform_f64(pl.r[i]); ev_d.r[i] = uniform_f64(pe.r[i]); }
+    for (int i = 0; i < 9; i++) { lin_d.r[i] = uniform_f64(bc[2 + i]); ev_d.r[i] = uniform_f64(bc[14 + i]); }
 #pragma unroll
-      for (int i = 0; i < 3; i++) { lin_d.t[i] = uniform_f64(pl.t[i]); ev_d.t[i] = uniform_f64(pe.t[i]); }
-    }
-    __syncthreads();  // thread 0 rewrites s_st after the next barrier
+    for (int i = 0; i < 3; i++) { lin_d.t[i] = uniform_f64(bc[11 + i]); ev_d.t[i] = uniform_f64(bc[23 + i]); }
+    __syncthreads();  // bc[] is rewritten after the next barrier
   }
   }  // trips
 }

@@ -141,6 +141,7 @@ int fvh_vgicp_synchronize(fvh_vgicp* h);
  * hint must only cost a rebuild at the safe size (2 x N_t), never points. */
 int fvh_vgicp_debug_set_voxel_hint(fvh_vgicp* h, int num_voxels);
 int fvh_vgicp_debug_get_table_capacity(fvh_vgicp* h, int* capacity);
+int fvh_vgicp_debug_get_persist_aborts(fvh_vgicp* h, int* n);  /* persistent-LM launches whose barrier watchdog fired (each was redone with one launch per LM transition) */
 
 /* new: multi-GPU (one process per GPU).  Every rank holds a spatial-tile shard of the source
  * cloud and the target voxel map; the 28-value normal-equation block (err, b, upper H) is

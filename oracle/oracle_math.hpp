@@ -5,6 +5,7 @@
 // handful of 3x3 / 6x6 operations it calls.
 #pragma once
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <algorithm>
 
@@ -159,6 +160,15 @@ inline V3 iso_apply(const Iso3& T, const V3& p) {
 }
 inline M3 iso_rot(const Iso3& T) { M3 R; std::memcpy(R.m, T.R, sizeof(R.m)); return R; }
 
+// Sensitivity probe (tests only): ORC_LM_ARITH_VARIANT bit 0 = one reciprocal per LDLT pivot instead of a division per
+// entry, bit 1 = full-angle terms of se3_exp from the half-angle sincos (double-angle identities). Both variants are
+// rounding-level rearrangements of the same formulas; tests use them to measure how far a 1-ulp change in the LM step
+// moves the converged pose (it is NOT the reference arithmetic, which is the default 0).
+inline int lm_arith_variant() {
+  static const int v = [] { const char* e = std::getenv("ORC_LM_ARITH_VARIANT"); return e ? std::atoi(e) : 0; }();
+  return v;
+}
+
 // se3_exp / so3_exp, reference include/fast_gicp/so3/so3.hpp:58-104 (rotation first).
 inline Iso3 se3_exp(const double a[6]) {
   const double ox = a[0], oy = a[1], oz = a[2];
@@ -196,6 +206,10 @@ inline Iso3 se3_exp(const double a[6]) {
     V = R;  // so3.matrix()
   } else {
     const double tsq = theta * theta;
+    if (lm_arith_variant() & 2) {
+      const double sh = std::sin(0.5 * theta), ch = std::cos(0.5 * theta), inv = 1.0 / theta_sq;
+      V = m3_add(m3_identity(), m3_add(m3_scale(Om, 2.0 * sh * sh * inv), m3_scale(Om2, (theta - 2.0 * sh * ch) * inv / theta)));
+    } else
     V = m3_add(m3_identity(), m3_add(m3_scale(Om, (1.0 - std::cos(theta)) / tsq), m3_scale(Om2, (theta - std::sin(theta)) / (tsq * theta))));
   }
   Iso3 T;
@@ -218,12 +232,12 @@ inline void ldlt6_solve(const double A_in[36], const double rhs[6], double x[6])
     for (int i = j + 1; i < 6; i++) {
       double s = A_in[i * 6 + j];
       for (int k = 0; k < j; k++) s -= L[i * 6 + k] * L[j * 6 + k] * D[k];
-      L[i * 6 + j] = s / d;
+      L[i * 6 + j] = (lm_arith_variant() & 1) ? s * (1.0 / d) : s / d;
     }
   }
   double y[6];
   for (int i = 0; i < 6; i++) { double s = rhs[i]; for (int k = 0; k < i; k++) s -= L[i * 6 + k] * y[k]; y[i] = s; }
-  for (int i = 0; i < 6; i++) y[i] /= D[i];
+  for (int i = 0; i < 6; i++) y[i] = (lm_arith_variant() & 1) ? y[i] * (1.0 / D[i]) : y[i] / D[i];
   for (int i = 5; i >= 0; i--) { double s = y[i]; for (int k = i + 1; k < 6; k++) s -= L[k * 6 + i] * x[k]; x[i] = s; }
 }
 

@@ -243,3 +243,24 @@ def test_sharded_path_single_rank_rccl(O, pair):
     rc = sh2.align()
     assert util.rel_err(rc["T"], ra["T"]) < 1e-9
     a.close(); b.close(); c.close()
+
+
+def test_persistent_and_multi_launch_paths_agree(O, pair, monkeypatch):
+    """The LM loop runs as ONE persistent launch by default; its barrier watchdog must turn a stuck barrier into a clean
+    fallback to one launch per LM transition. Forcing the watchdog (0 ticks) and disabling the persistent kernel must
+    both give the bit-identical result of the persistent run (same sums, same fixed summation order)."""
+    tgt, src = pair
+    c = _core()
+    c.set_neighbor_search_method(2)
+    r0 = _engine_register(c, tgt, src)
+    assert r0["num_launches"] == 1 and c.debug_persist_aborts() == 0
+    monkeypatch.setenv("FVH_PERSIST_WATCHDOG_TICKS", "0")
+    r1 = c.align()
+    assert c.debug_persist_aborts() == 1 and r1["num_launches"] > 1
+    monkeypatch.delenv("FVH_PERSIST_WATCHDOG_TICKS")
+    r2 = c.align()
+    assert c.debug_persist_aborts() == 1 and r2["num_launches"] == 1
+    for r in (r1, r2):
+        assert r["converged"] and r["num_linearize"] == r0["num_linearize"] and r["num_error_evals"] == r0["num_error_evals"]
+        assert np.array_equal(r["T"], r0["T"]) and np.array_equal(r["H"], r0["H"])
+    c.close()
