@@ -257,6 +257,7 @@ def main():
     backend = os.environ.get("FVH_BENCH_BACKEND", "nccl")
     if share_gpu:
         local_rank = 0
+        os.environ.setdefault("FVH_PERSISTENT", "0")  # several processes on one GPU: their persistent grids would starve each other (the watchdog recovers, slowly)
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
@@ -377,18 +378,26 @@ def main():
                 stage_ms[cls] = {"total_ms": round(ms, 3), "launches": n, "avg_us": round(ms / n * 1e3, 3)}
         if cost_n:
             avg_s = cost_ms / cost_n * 1e-3
-            achieved = bytes_eval / avg_s / 1e9
+            # a registration's cost evaluations move (n_lin + n_err) * B_eval algorithmic bytes. One launch of the
+            # persistent LM kernel runs ALL of them (kernel_launches_lm == 1); the multi-launch path spreads them over its launches.
+            evals_per_launch = (n_lin + n_err) / max(n_launch, 1)
+            bytes_launch = bytes_eval * evals_per_launch
+            achieved = bytes_launch / avg_s / 1e9
             traffic = None
             try:  # HBM bytes per launch from the committed PMC pass (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate runs; FETCH doubled per the gfx950 note)
                 pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_cost_kernel.json")))
-                traffic = pmc.get(args.workload, {}).get("hbm_bytes_per_launch")
+                traffic = pmc.get(args.workload + ("_persistent" if n_launch == args.steps else ""), {}).get("hbm_bytes_per_launch")
             except Exception:
                 pass
-            roofline = {"kernel": "cost_kernel<double,VGICP>" if args.precision == "fp64" else "cost_kernel<float,VGICP>", "bound": "hbm", "achieved": round(achieved, 2),
-                        "peak": 8000.0, "unit": "GB/s", "frac": round(achieved / 8000.0, 5), "traffic": traffic, "algorithmic_bytes_per_launch": bytes_eval,
+            kname = "cost_kernel<%s,VGICP,%s>" % ("double" if args.precision == "fp64" else "float", "persistent" if n_launch == args.steps else "per-transition")
+            roofline = {"kernel": kname, "bound": "hbm", "achieved": round(achieved, 2),
+                        "peak": 8000.0, "unit": "GB/s", "frac": round(achieved / 8000.0, 5), "traffic": traffic, "algorithmic_bytes_per_launch": int(bytes_launch),
+                        "algorithmic_bytes_per_evaluation": bytes_eval, "evaluations_per_launch": round(evals_per_launch, 3),
                         "avg_launch_us": round(avg_s * 1e6, 3), "launches": cost_n,
-                        "note": ("17k-point working set (~3 MB) is L2/Infinity-Cache resident: this kernel is latency/launch bound, not HBM bound" if args.workload == "bundled17k"
-                                 else "launch average includes the early-exit launches issued after convergence")}
+                        "note": ("17k-point working set (~3 MB) is L2/Infinity-Cache resident and the fused trips share their loads between the trial evaluation and the next "
+                                 "linearisation: this kernel is bound by the latency chain of its %d barrier-separated trips, not by HBM; `traffic` (PMC) is what actually reaches HBM"
+                                 % round((n_err / args.steps) + 1) if args.workload == "bundled17k"
+                                 else "launch average over the LM launches of the timed region")}
     if args.cov == "knn" and "knn" in stage_ms:
         n = n_src
         flops = 8.0 * n * n

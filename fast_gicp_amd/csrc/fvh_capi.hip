@@ -559,7 +559,6 @@ int launch_cost(Engine* e, const CostSource& src, const VoxelMapDev& vm, int hos
     if (cap <= 0) return e->fail(FVH_ERR_HIP, "persistent cost kernel: occupancy query failed");
     blocks = std::min(blocks, cap);
     { const char* v = getenv("FVH_PERSIST_WATCHDOG_TICKS"); P.watchdog_ticks = v ? strtoull(v, nullptr, 10) : PERSIST_WATCHDOG_TICKS; }  // test hook: 0 forces the abort + fallback path
-    { const char* v = getenv("FVH_POLL_PRESLEEP"); P.poll_presleep = v ? atoi(v) : 0; }
     P.bcast = e->bcast.as<double>();
     P.launch_tag = ++e->persist_seq;
     // abort word = 0 (the last 8 bytes of the state; never covered by the state write-back); arrival counters = 0

@@ -80,7 +80,6 @@ struct CostParams {
   int defer_lm;               // 1: multi-GPU -- only publish st->sums, LM step runs after the all-reduce
   PoseD lin, ev;              // host mode poses; device-LM first launch (init = 1): lin = initial guess
   int init;                   // 1: this is the first launch of an align -- start from P.lin and (re)initialise the LM state
-  int poll_presleep;          // persistent kernel (experiment): units of s_sleep(16) before the first poll
   double* bcast;              // persistent kernel: [PERSIST_REPLICAS][BCAST_SLOTS] broadcast rows
   unsigned long long launch_tag;  // persistent kernel: sequence number of this launch (tags of older launches never match)
   unsigned long long watchdog_ticks;  // persistent kernel: 100 MHz ticks a workgroup may wait at the barrier before it aborts the launch
@@ -358,8 +357,13 @@ __device__ unsigned long long g_ptime[16][512][12];  // persistent kernel, per t
 #define FVH_PT_MAX(trip, k) do { } while (0)
 #endif
 
+#ifdef FVH_COST_TIMING
+#define FVH_COST_BOUNDS __launch_bounds__(256, 2)  // keep the instrumented build at the product's 2 workgroups per CU
+#else
+#define FVH_COST_BOUNDS __launch_bounds__(256)
+#endif
 template <typename Real, int MODE, bool PERSIST>
-__global__ __launch_bounds__(256) void cost_kernel(CostParams P) {
+__global__ FVH_COST_BOUNDS void cost_kernel(CostParams P) {
 #ifdef FVH_COST_TIMING
   __shared__ unsigned long long stamp[12];  // LDS, not registers: must not change the kernel being measured
   if (threadIdx.x == 0) { stamp[0] = wall_clock64(); atomicMin(&g_cost_timing[0], stamp[0]); }
@@ -766,7 +770,6 @@ __global__ __launch_bounds__(256) void cost_kernel(CostParams P) {
         const bool is_slot = lane < BCAST_SLOTS, is_tag = is_slot && ((lane & 7) == 7);
         const unsigned long long t0 = wall_clock64();
         int ok = 0;
-        for (int k = 0; k < P.poll_presleep; k++) __builtin_amdgcn_s_sleep(16);  // experiment: keep early arrivers quiet (~0.5 us per unit)
         for (;;) {
           const double v = is_slot ? __hip_atomic_load(&rep[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
           if (__any(is_tag && v == abort_tag)) break;  // another workgroup's watchdog aborted THIS launch
