@@ -277,7 +277,7 @@ int ensure_sorted(Engine* e, CloudDev& c) {
   if (c.has_sorted) return FVH_OK;
   const int n = c.n;
   static const int items_env = [] { const char* v = getenv("FVH_SORT_ITEMS"); return v ? atoi(v) : 0; }();
-  const int items = items_env > 0 ? items_env : (n <= 65536 ? 256 : SORT_ITEMS_MAX);  // more, shorter waves for small clouds (latency-bound)
+  const int items = items_env > 0 ? items_env : (n <= 262144 ? 256 : (n <= 1048576 ? 512 : SORT_ITEMS_MAX));  // more, shorter waves for small clouds (latency-bound)
   const int nwaves = (n + items - 1) / items;
   const int ntiles = (n + 63) / 64;
   HIP_OR_FAIL(e, c.sorted.ensure(sizeof(float4) * (size_t)n));
@@ -285,7 +285,7 @@ int ensure_sorted(Engine* e, CloudDev& c) {
   HIP_OR_FAIL(e, e->sort_keys.ensure(sizeof(unsigned) * 2 * (size_t)n + 64));
   HIP_OR_FAIL(e, e->sort_idx.ensure(sizeof(int) * (size_t)n));
   HIP_OR_FAIL(e, c.order.ensure(sizeof(int) * (size_t)n));
-  HIP_OR_FAIL(e, e->sort_hist.ensure(sizeof(unsigned) * (size_t)RADIX_BINS * nwaves));
+  HIP_OR_FAIL(e, e->sort_hist.ensure(sizeof(unsigned) * (size_t)RADIX_BINS * (nwaves + 1)));
   const int nsuper_small = (ntiles + 63) / 64;
   HIP_OR_FAIL(e, c.bbox2.ensure(sizeof(float4) * 2 * (size_t)nsuper_small));
   ProfScope ps(e, "sort");
@@ -308,10 +308,12 @@ int ensure_sorted(Engine* e, CloudDev& c) {
   const int wblocks = (nwaves + 3) / 4;
   for (int pass = 0; pass < RADIX_PASSES; pass++) {
     const int in = pass & 1, out = in ^ 1, shift = pass * RADIX_BITS;
+    unsigned* bin_tot = e->sort_hist.as<unsigned>() + (size_t)RADIX_BINS * nwaves;
     radix_hist_kernel<<<wblocks, 256, 0, e->stream>>>(keys[in], n, shift, nwaves, items, e->sort_hist.as<unsigned>());
-    radix_scan_kernel<<<1, 1024, 0, e->stream>>>(e->sort_hist.as<unsigned>(), RADIX_BINS * nwaves);
+    radix_binscan_kernel<<<RADIX_BINS / 4, 256, 0, e->stream>>>(e->sort_hist.as<unsigned>(), nwaves, bin_tot);
+    radix_scan_kernel<<<1, 1024, 0, e->stream>>>(bin_tot, RADIX_BINS);
     const bool last = (pass == RADIX_PASSES - 1);
-    radix_scatter_kernel<<<wblocks, 256, 0, e->stream>>>(keys[in], idx[in], n, shift, nwaves, items, e->sort_hist.as<unsigned>(), keys[out], idx[out], last ? c.pts.as<float4>() : nullptr,
+    radix_scatter_kernel<<<wblocks, 256, 0, e->stream>>>(keys[in], idx[in], n, shift, nwaves, items, e->sort_hist.as<unsigned>(), bin_tot, keys[out], idx[out], last ? c.pts.as<float4>() : nullptr,
                                                          last ? c.sorted.as<float4>() : nullptr);
   }
   tile_bbox_kernel<<<(ntiles + 3) / 4, 256, 0, e->stream>>>(c.sorted.as<float4>(), n, c.bbox.as<float4>());
@@ -796,16 +798,18 @@ int device_scan(Engine* e, DevBuf& bsums, const unsigned* in, int n, unsigned* o
 
 // stable LSD radix sort of (key, idx) pairs on `bits` key bits; returns the index (0/1) of the buffer pair holding the result
 int radix_sort_pairs(Engine* e, unsigned* keys[2], int* idx[2], int n, int bits, int* result) {
-  const int items = n <= 65536 ? 256 : SORT_ITEMS_MAX;
+  const int items = n <= 262144 ? 256 : (n <= 1048576 ? 512 : SORT_ITEMS_MAX);
   const int nwaves = (n + items - 1) / items;
-  HIP_OR_FAIL(e, e->sort_hist.ensure(sizeof(unsigned) * (size_t)RADIX_BINS * nwaves));
+  HIP_OR_FAIL(e, e->sort_hist.ensure(sizeof(unsigned) * (size_t)RADIX_BINS * (nwaves + 1)));
+  unsigned* bin_tot = e->sort_hist.as<unsigned>() + (size_t)RADIX_BINS * nwaves;
   const int wblocks = (nwaves + 3) / 4;
   const int passes = std::max(1, (bits + RADIX_BITS - 1) / RADIX_BITS);
   for (int pass = 0; pass < passes; pass++) {
     const int in = pass & 1, out = in ^ 1, shift = pass * RADIX_BITS;
     radix_hist_kernel<<<wblocks, 256, 0, e->stream>>>(keys[in], n, shift, nwaves, items, e->sort_hist.as<unsigned>());
-    radix_scan_kernel<<<1, 1024, 0, e->stream>>>(e->sort_hist.as<unsigned>(), RADIX_BINS * nwaves);
-    radix_scatter_kernel<<<wblocks, 256, 0, e->stream>>>(keys[in], idx[in], n, shift, nwaves, items, e->sort_hist.as<unsigned>(), keys[out], idx[out], nullptr, nullptr);
+    radix_binscan_kernel<<<RADIX_BINS / 4, 256, 0, e->stream>>>(e->sort_hist.as<unsigned>(), nwaves, bin_tot);
+    radix_scan_kernel<<<1, 1024, 0, e->stream>>>(bin_tot, RADIX_BINS);
+    radix_scatter_kernel<<<wblocks, 256, 0, e->stream>>>(keys[in], idx[in], n, shift, nwaves, items, e->sort_hist.as<unsigned>(), bin_tot, keys[out], idx[out], nullptr, nullptr);
   }
   HIP_OR_FAIL(e, hipGetLastError());
   *result = passes & 1;

@@ -4,8 +4,8 @@
 // order is what makes the exact k-NN / RBF / fitness sweeps cullable by tile bounding boxes, and a
 // contiguous range of the sorted cloud is a spatial tile for the multi-GPU shard.
 //
-// Per pass: radix_hist (per-wave digit histograms in LDS -> hist[bin][wave]), radix_scan (one
-// workgroup, exclusive scan over bins x waves = scatter bases), radix_scatter (each wave walks its
+// Per pass: radix_hist (per-wave digit histograms in LDS -> hist[bin][wave]), radix_binscan (one wave per
+// bin: prefixes over the waves + bin total), radix_scan (512 bin totals), radix_scatter (each wave walks its
 // contiguous range 64 items at a time; same-digit lanes find each other with 9 ballots, the lowest
 // lane of a digit group advances the wave's cursor, rank = popcount of lower peers -> stable).
 #pragma once
@@ -125,16 +125,42 @@ __global__ __launch_bounds__(1024) void radix_scan_kernel(unsigned* __restrict__
   }
 }
 
+// Scatter bases of a pass without scanning the whole bins x waves matrix on one workgroup (that single-workgroup scan
+// was 32 us at 118k keys and ~300 us at 1M -- more than the rest of the pass): one wave per bin turns the bin's row of
+// per-wave counts into exclusive prefixes and emits the bin total; radix_scan_kernel then scans the 512 totals, and
+// the scatter adds bin_base[bin] to the in-bin prefix.
+__global__ __launch_bounds__(256) void radix_binscan_kernel(unsigned* __restrict__ hist /* [bins][nwaves] */, int nwaves, unsigned* __restrict__ totals /* [bins] */) {
+  const int lane = threadIdx.x & 63;
+  const int bin = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (bin >= RADIX_BINS) return;
+  unsigned* row = hist + (size_t)bin * nwaves;
+  unsigned run = 0;
+  for (int base = 0; base < nwaves; base += 64) {
+    const int w = base + lane;
+    const unsigned v = (w < nwaves) ? row[w] : 0u;
+    unsigned x = v;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const unsigned y = __shfl_up(x, off);
+      if (lane >= off) x += y;
+    }
+    if (w < nwaves) row[w] = run + x - v;
+    run += __shfl(x, 63);
+  }
+  if (lane == 0) totals[bin] = run;
+}
+
 // stable scatter of (key, idx); on the last pass also gathers the point into the sorted cloud with
 // its original index in .w
 __global__ __launch_bounds__(256) void radix_scatter_kernel(const unsigned* __restrict__ keys_in, const int* __restrict__ idx_in, int n, int shift, int nwaves, int items,
-                                                            const unsigned* __restrict__ offsets /* scanned hist */, unsigned* __restrict__ keys_out, int* __restrict__ idx_out,
+                                                            const unsigned* __restrict__ offsets /* in-bin prefixes */, const unsigned* __restrict__ bin_base /* scanned bin totals */,
+                                                            unsigned* __restrict__ keys_out, int* __restrict__ idx_out,
                                                             const float4* __restrict__ pts, float4* __restrict__ sorted_pts) {
   __shared__ unsigned cur[4][RADIX_BINS];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int wave = blockIdx.x * 4 + wv;
   if (wave >= nwaves) return;
-  for (int b = lane; b < RADIX_BINS; b += 64) cur[wv][b] = offsets[(size_t)b * nwaves + wave];
+  for (int b = lane; b < RADIX_BINS; b += 64) cur[wv][b] = offsets[(size_t)b * nwaves + wave] + bin_base[b];
   // the cursors are private to this wave: wave-level ordering is enough (no workgroup barrier)
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   const int begin = wave * items, end = min(n, begin + items);
