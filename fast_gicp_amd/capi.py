@@ -297,6 +297,38 @@ class VGICPCore(_Core):
     def debug_set_voxel_hint(self, n):
         self._call("debug_set_voxel_hint", int(n))
 
+    # ---- FastGICP (nearest target point) on the same handle ----
+    def gicp_set_max_correspondence_distance(self, d):
+        self._call("gicp_set_max_correspondence_distance", C.c_double(d))
+
+    def gicp_swap_source_and_target(self):
+        self._call("gicp_swap_source_and_target")
+
+    def gicp_update_correspondences(self, T):
+        t = _colmajor16(T)
+        self._call("gicp_update_correspondences", _p(t))
+
+    def gicp_compute_error(self, T, derivatives=True):
+        t = _colmajor16(T)
+        err = C.c_double(0)
+        if derivatives:
+            H = np.empty((6, 6), np.float64)
+            b = np.empty(6, np.float64)
+            self._call("gicp_compute_error", _p(t), _p(H), _p(b), C.byref(err))
+            return err.value, H.T.copy(), b
+        self._call("gicp_compute_error", _p(t), None, None, C.byref(err))
+        return err.value
+
+    def gicp_linearize(self, T):
+        """FastGICP::linearize (fast_gicp_impl.hpp:159-213): update_correspondences + sums."""
+        self.gicp_update_correspondences(T)
+        return self.gicp_compute_error(T, True)
+
+    def gicp_get_correspondences(self):
+        out = np.empty(self.num_points("source"), np.int32)
+        self._call("gicp_get_correspondences", _p(out))
+        return out
+
     def debug_persist_aborts(self):
         n = C.c_int(0)
         self._call("debug_get_persist_aborts", C.byref(n))

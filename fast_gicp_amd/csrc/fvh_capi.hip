@@ -136,6 +136,7 @@ struct Engine {
   void* pinned = nullptr;  // sizeof(LmState) + slack
   PoseD lin;               // pose of the last update_correspondences()
   bool has_corr = false;
+  int corr_kind = 0;       // 0: voxel correspondences (VGICP / NDT), 1: nearest-point correspondences (GICP)
   int corr_n_src = 0;
   int corr_sel = 0;        // which of the two correspondence buffers the host-mode calls use
   int last_steps = 0, prev_steps = 0;  // launches the last two aligns needed (odometry loops alternate directions)
@@ -506,6 +507,7 @@ struct CostSource {
   const float4* pts; const float4* cov; const int* d_n; int n_upper;
   const int* counters2;  // source voxel map counters (D2D) or null
   const int* order;      // Morton permutation of the source (large clouds) or null
+  int n_off_override = 0;  // > 0: correspondences per source element regardless of the handle's offset list (GICP: 1)
 };
 
 // Persistent LM kernel (kernels_cost.hpp, PERSIST): co-resident workgroup capacity of the device for this instantiation.
@@ -532,14 +534,15 @@ int launch_cost(Engine* e, const CostSource& src, const VoxelMapDev& vm, int hos
   std::memset(&P, 0, sizeof(P));
   P.src_pts = src.pts; P.src_cov = src.cov; P.d_n_src = src.d_n; P.n_src = src.n_upper; P.order = src.order;
   P.table = vm.table.as<uint4>(); P.mask = vm.capacity - 1; P.res = vm.res;
-  P.offsets = e->offsets_dev.as<int>(); P.n_off = e->n_off;
+  const int n_off = src.n_off_override > 0 ? src.n_off_override : e->n_off;
+  P.offsets = e->offsets_dev.as<int>(); P.n_off = n_off;
   static const long long target_items = [] { const char* v = getenv("FVH_COST_TARGET_ITEMS"); return v ? atoll(v) : 256LL * 256 * 2; }();
   static const int max_blocks = [] { const char* v = getenv("FVH_COST_MAX_BLOCKS"); int b = v ? atoi(v) : MAX_COST_BLOCKS; return b < 1 ? 1 : (b > MAX_COST_BLOCKS ? MAX_COST_BLOCKS : b); }();
-  int groups = (int)std::min<long long>(e->n_off, std::max<long long>(1, target_items / std::max(src.n_upper, 1)));
-  P.group = (e->n_off + groups - 1) / groups;
-  P.groups_per_src = (e->n_off + P.group - 1) / P.group;
+  int groups = (int)std::min<long long>(n_off, std::max<long long>(1, target_items / std::max(src.n_upper, 1)));
+  P.group = (n_off + groups - 1) / groups;
+  P.groups_per_src = (n_off + P.group - 1) / P.group;
   P.corr = e->corr.as<int>();
-  P.corr_stride = (size_t)std::max(src.n_upper, 1) * e->n_off;
+  P.corr_stride = (size_t)std::max(src.n_upper, 1) * n_off;
   P.host_corr_sel = e->corr_sel;
   P.st = e->state.as<LmState>(); P.partials = e->partials.as<double>(); P.ticket = e->ticket.as<unsigned>();
   P.vm_counters = vm.counters.as<int>();
@@ -774,6 +777,45 @@ int profile_get(Engine* e, const char* cls, double* total_ms, int* launches) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// FastGICP on the device: nearest-target-point correspondences + the VGICP cost kernel on per-point records
+// ---------------------------------------------------------------------------------------------
+int gicp_update_correspondences(Engine* e, CloudDev& src, CloudDev& tgt, VoxelMapDev& records, const double* T16, double max_dist) {
+  if (!T16) return e->fail(FVH_ERR_INVALID_ARGUMENT, "gicp_update_correspondences: null pose");
+  if (!src.has_pts || !tgt.has_pts || src.n == 0 || tgt.n == 0) return e->fail(FVH_ERR_BAD_STATE, "gicp_update_correspondences: clouds not set");
+  if (!src.has_cov || !tgt.has_cov) return e->fail(FVH_ERR_BAD_STATE, "gicp_update_correspondences: covariances not set");
+  if (!(max_dist > 0)) return e->fail(FVH_ERR_INVALID_ARGUMENT, "gicp_update_correspondences: max correspondence distance must be > 0");
+  int rc = ensure_sorted(e, src);
+  if (!rc) rc = ensure_sorted(e, tgt);
+  if (rc) return rc;
+  // per-target-point records in the voxel-bucket layout (1 MB at 17k points: rebuilt every time rather than tracked)
+  HIP_OR_FAIL(e, records.table.ensure(sizeof(float4) * 4 * (size_t)tgt.n));
+  HIP_OR_FAIL(e, records.counters.ensure(4 * sizeof(int)));
+  HIP_OR_FAIL(e, hipMemsetAsync(records.counters.p, 0, 4 * sizeof(int), e->stream));
+  gicp_records_kernel<<<(tgt.n + 255) / 256, 256, 0, e->stream>>>(tgt.pts.as<float4>(), tgt.cov.as<float4>(), tgt.n, records.table.as<float4>());
+  records.capacity = 1; records.res = 1.0; records.valid = true;
+  HIP_OR_FAIL(e, e->corr.ensure(2 * sizeof(int) * (size_t)src.n));
+  float T12[12];
+  for (int i = 0; i < 3; i++) { for (int j = 0; j < 3; j++) T12[i * 4 + j] = (float)T16[j * 4 + i]; T12[i * 4 + 3] = (float)T16[12 + i]; }  // trans.cast<float>()
+  char* base = (char*)e->fit.p;
+  HIP_OR_FAIL(e, hipMemcpyAsync(base + 16, T12, sizeof(T12), hipMemcpyHostToDevice, e->stream));
+  const double thr = std::min(max_dist, 1.8446743e19);  // threshold^2 must stay finite in fp64 (reference default: float max)
+  {
+    ProfScope ps(e, "gicp_nn");
+    const int waves = (src.n + FIT_Q - 1) / FIT_Q;
+    nn_corr_tiled_kernel<<<(waves + 3) / 4, 256, 0, e->stream>>>(src.sorted.as<float4>(), src.n, tgt.sorted.as<float4>(), tgt.bbox.as<float4>(), tgt.n, reinterpret_cast<const float*>(base + 16), thr * thr,
+                                                                 e->corr.as<int>());
+  }
+  HIP_OR_FAIL(e, hipGetLastError());
+  HIP_OR_FAIL(e, hipStreamSynchronize(e->stream));  // T12 is a stack buffer
+  e->lin = pose_from_colmajor16(T16);
+  e->corr_sel = 0;
+  e->has_corr = true;
+  e->corr_kind = 1;
+  e->corr_n_src = src.n;
+  return FVH_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
 // voxel-grid downsampling (kernels_downsample.hpp)
 // ---------------------------------------------------------------------------------------------
 struct DownsampleDev {
@@ -915,7 +957,10 @@ struct fvh_vgicp {
   double resolution = 1.0, kernel_width = 0.25, kernel_max_dist = 3.0;  // fast_vgicp_cuda.cu:22-26
   CloudDev source, target;
   VoxelMapDev voxelmap;
+  VoxelMapDev gicp_records;  // per-target-point records for the nearest-point (GICP) cost
+  double gicp_max_dist = 3.4028234663852886e38;
   CostSource cost_source() const { return CostSource{source.pts.as<float4>(), source.cov.as<float4>(), nullptr, source.n, nullptr, coherent_order(source)}; }
+  CostSource gicp_cost_source() const { CostSource c{source.pts.as<float4>(), source.cov.as<float4>(), nullptr, source.n, nullptr, nullptr}; c.n_off_override = 1; return c; }
   Rebuild rebuild_safe() { return [this] { return build_voxelmap<0>(&e, target, voxelmap, voxelmap.res, false, true); }; }
 };
 
@@ -973,7 +1018,7 @@ int fvh_vgicp_destroy(fvh_vgicp* h) {
   if (!h) return FVH_ERR_INVALID_ARGUMENT;
   (void)hipSetDevice(h->e.device);
   if (h->e.stream) (void)hipStreamSynchronize(h->e.stream);
-  h->source.release(); h->target.release(); h->voxelmap.release();
+  h->source.release(); h->target.release(); h->voxelmap.release(); h->gicp_records.release();
   h->e.shutdown();
   delete h;
   return FVH_OK;
@@ -991,6 +1036,13 @@ int fvh_vgicp_swap_source_and_target(fvh_vgicp* h) {
   h->e.has_corr = false;
   if (!h->target.has_pts || !h->target.has_cov) { h->voxelmap.invalidate(); return FVH_OK; }  // fast_vgicp_cuda.cu:102-104
   return build_voxelmap<0>(&h->e, h->target, h->voxelmap, h->resolution, false);
+}
+int fvh_vgicp_gicp_swap_source_and_target(fvh_vgicp* h) {  // FastGICP::swapSourceAndTarget (fast_gicp_impl.hpp:56-62): no voxel map to rebuild
+  CHECK_HANDLE(h);
+  h->source.swap(h->target);
+  h->e.has_corr = false;
+  h->voxelmap.invalidate();
+  return FVH_OK;
 }
 static void cloud_replaced(CloudDev& c) { c.has_cov = false; c.has_nbr = false; }
 int fvh_vgicp_set_source_cloud(fvh_vgicp* h, const float* xyz, int n) { CHECK_HANDLE(h); h->e.has_corr = false; cloud_replaced(h->source); return upload_cloud(&h->e, h->source, xyz, n, 3, false); }
@@ -1022,7 +1074,7 @@ int fvh_vgicp_get_voxel_coords(fvh_vgicp* h, int* o) { CHECK_HANDLE(h); return g
 
 static int fetch_corr(Engine* e, int n_src, std::vector<int>& corr) {
   if (!e->has_corr) return e->fail(FVH_ERR_BAD_STATE, "no correspondences: call update_correspondences first");
-  corr.resize((size_t)n_src * e->n_off);
+  corr.resize((size_t)n_src * (e->corr_kind == 1 ? 1 : e->n_off));
   if (corr.empty()) return FVH_OK;
   HIP_OR_FAIL(e, hipMemcpyAsync(corr.data(), e->corr.as<int>() + (size_t)e->corr_sel * corr.size(), sizeof(int) * corr.size(), hipMemcpyDeviceToHost, e->stream));
   HIP_OR_FAIL(e, hipStreamSynchronize(e->stream));
@@ -1063,10 +1115,38 @@ int fvh_vgicp_get_voxel_correspondences(fvh_vgicp* h, int* pairs) {
 int fvh_vgicp_update_correspondences(fvh_vgicp* h, const double* T) {
   CHECK_HANDLE(h);
   if (!h->source.has_pts || !h->source.has_cov) return h->e.fail(FVH_ERR_BAD_STATE, "update_correspondences: source cloud/covariances not set");
+  h->e.corr_kind = 0;
   return do_update_correspondences<MODE_VGICP>(&h->e, h->cost_source(), h->voxelmap, T);
+}
+// ---- FastGICP (nearest target point) on the same handle: fast_gicp_impl.hpp:118-240 ----
+int fvh_vgicp_gicp_set_max_correspondence_distance(fvh_vgicp* h, double d) {
+  CHECK_HANDLE(h);
+  if (!(d > 0)) return h->e.fail(FVH_ERR_INVALID_ARGUMENT, "max correspondence distance must be > 0");
+  h->gicp_max_dist = d;
+  return FVH_OK;
+}
+int fvh_vgicp_gicp_update_correspondences(fvh_vgicp* h, const double* T) {
+  CHECK_HANDLE(h);
+  return gicp_update_correspondences(&h->e, h->source, h->target, h->gicp_records, T, h->gicp_max_dist);
+}
+int fvh_vgicp_gicp_compute_error(fvh_vgicp* h, const double* T, double* H, double* b, double* err) {
+  CHECK_HANDLE(h);
+  if (!h->e.has_corr || h->e.corr_kind != 1) return h->e.fail(FVH_ERR_BAD_STATE, "gicp_compute_error: call gicp_update_correspondences first");
+  return do_compute_error<MODE_VGICP>(&h->e, h->gicp_cost_source(), h->gicp_records, T, H, b, err, [] { return (int)FVH_OK; });
+}
+int fvh_vgicp_gicp_get_correspondences(fvh_vgicp* h, int* target_index_per_source_point) {
+  CHECK_HANDLE(h);
+  if (!target_index_per_source_point) return FVH_ERR_INVALID_ARGUMENT;
+  if (!h->e.has_corr || h->e.corr_kind != 1) return h->e.fail(FVH_ERR_BAD_STATE, "gicp_get_correspondences: call gicp_update_correspondences first");
+  std::vector<int> corr;
+  int rc = fetch_corr(&h->e, h->e.corr_n_src, corr);
+  if (rc) return rc;
+  std::memcpy(target_index_per_source_point, corr.data(), sizeof(int) * corr.size());
+  return FVH_OK;
 }
 int fvh_vgicp_compute_error(fvh_vgicp* h, const double* T, double* H, double* b, double* err) {
   CHECK_HANDLE(h);
+  if (h->e.has_corr && h->e.corr_kind != 0) return h->e.fail(FVH_ERR_BAD_STATE, "compute_error: the stored correspondences are nearest-point (GICP) ones; call update_correspondences first");
   return do_compute_error<MODE_VGICP>(&h->e, h->cost_source(), h->voxelmap, T, H, b, err, h->rebuild_safe());
 }
 int fvh_vgicp_align(fvh_vgicp* h, const double* guess, const fvh_lm_params* p, fvh_lm_result* r) {

@@ -567,6 +567,101 @@ __global__ __launch_bounds__(256) void fitness_tiled_kernel(const float4* __rest
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// FastGICP correspondences (fast_gicp_impl.hpp:118-156): for every source point the exact nearest
+// TARGET POINT of its transformed position (fp32 transform and distance, as the reference's trans.cast<float>() and
+// the kd-tree), kept when the squared distance < threshold^2. Same sweep as fitness_tiled_kernel, carrying the
+// winner's ORIGINAL index; equal distances -> lower index (the oracle's kd-tree order). corr[original source index] =
+// original target index or -1.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void nn_corr_tiled_kernel(const float4* __restrict__ ssrc, int ns, const float4* __restrict__ stgt, const float4* __restrict__ tbox, int nt,
+                                                            const float* __restrict__ T12, double thr_sq, int* __restrict__ corr) {
+  const int lane = threadIdx.x & 63;
+  const int wave = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int q_base = wave * FIT_Q;
+  if (q_base >= ns) return;
+  const int ntiles = (nt + 63) >> 6;
+  float qx[FIT_Q], qy[FIT_Q], qz[FIT_Q], best[FIT_Q];
+  int besti[FIT_Q], qid[FIT_Q];
+  float gmin[3] = {3e38f, 3e38f, 3e38f}, gmax[3] = {-3e38f, -3e38f, -3e38f};
+#pragma unroll
+  for (int j = 0; j < FIT_Q; j++) {
+    const float4 p = ssrc[min(q_base + j, ns - 1)];
+    qid[j] = __float_as_int(p.w);
+    qx[j] = transform_row_nofma(p, T12 + 0);
+    qy[j] = transform_row_nofma(p, T12 + 4);
+    qz[j] = transform_row_nofma(p, T12 + 8);
+    gmin[0] = fminf(gmin[0], qx[j]); gmin[1] = fminf(gmin[1], qy[j]); gmin[2] = fminf(gmin[2], qz[j]);
+    gmax[0] = fmaxf(gmax[0], qx[j]); gmax[1] = fmaxf(gmax[1], qy[j]); gmax[2] = fmaxf(gmax[2], qz[j]);
+    best[j] = __builtin_inff();
+    besti[j] = 0x7fffffff;
+  }
+  auto sweep_tile = [&](int t) {
+    const float4 p = load_candidate(stgt, (t << 6) + lane, nt);
+    const int pid = ((t << 6) + lane < nt) ? __float_as_int(p.w) : 0x7fffffff;
+#pragma unroll
+    for (int j = 0; j < FIT_Q; j++) {
+      const float d = sqdist_nofma(p, qx[j], qy[j], qz[j]);
+      float dm = d;
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) dm = fminf(dm, __shfl_xor(dm, off));
+      if (dm > best[j]) continue;  // wave-uniform
+      int im = (d == dm) ? pid : 0x7fffffff;
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) im = min(im, __shfl_xor(im, off));
+      if (dm < best[j] || im < besti[j]) { best[j] = dm; besti[j] = im; }
+    }
+  };
+  float lb_min = __builtin_inff();
+  int t_min = 0;
+  for (int chunk = 0; chunk < ntiles; chunk += 64) {
+    const int t = chunk + lane;
+    const float lb = (t < ntiles) ? box_gap_sq(tbox[2 * t], tbox[2 * t + 1], gmin, gmax) : __builtin_inff();
+    if (lb < lb_min) { lb_min = lb; t_min = t; }
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    const float ol = __shfl_xor(lb_min, off);
+    const int ot = __shfl_xor(t_min, off);
+    if (ol < lb_min || (ol == lb_min && ot < t_min)) { lb_min = ol; t_min = ot; }
+  }
+  sweep_tile(t_min);
+  for (int chunk = 0; chunk < ntiles; chunk += 64) {
+    const int t = chunk + lane;
+    const float lb = box_gap_sq(tbox[2 * min(t, ntiles - 1)], tbox[2 * min(t, ntiles - 1) + 1], gmin, gmax);
+    float bmax = best[0];
+#pragma unroll
+    for (int j = 1; j < FIT_Q; j++) bmax = fmaxf(bmax, best[j]);
+    unsigned long long mask = __ballot(t < ntiles && t != t_min && lb <= bmax);  // <=: an equally near point with a lower index may live there
+    while (mask) {
+      const int src = __ffsll((long long)mask) - 1;
+      mask &= mask - 1;
+      bmax = best[0];
+#pragma unroll
+      for (int j = 1; j < FIT_Q; j++) bmax = fmaxf(bmax, best[j]);
+      if (read_lane(lb, src) > bmax) continue;
+      sweep_tile(chunk + src);
+    }
+  }
+  if (lane == 0) {
+#pragma unroll
+    for (int j = 0; j < FIT_Q; j++)
+      if (q_base + j < ns) corr[qid[j]] = ((double)best[j] < thr_sq) ? besti[j] : -1;
+  }
+}
+
+// One 64-byte record per target point in the layout of a voxel bucket ({key (unused), q1 = point + count 1, q2/q3 =
+// covariance}), so cost_kernel<Real, MODE_VGICP> evaluates FastGICP's cost unchanged: weight sqrt(1) = 1, mean = point.
+__global__ __launch_bounds__(256) void gicp_records_kernel(const float4* __restrict__ pts, const float4* __restrict__ cov, int n, float4* __restrict__ table) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const float4 p = pts[i];
+  table[4 * (size_t)i + 0] = make_float4(0.f, 0.f, __int_as_float(1), 0.f);
+  table[4 * (size_t)i + 1] = make_float4(p.x, p.y, p.z, 1.0f);
+  table[4 * (size_t)i + 2] = cov[2 * (size_t)i];
+  table[4 * (size_t)i + 3] = cov[2 * (size_t)i + 1];
+}
+
 // float xyz (stride 3 or 4) -> float4 (w = 0)
 __global__ __launch_bounds__(256) void pack_points_kernel(const float* __restrict__ xyz, int n, int stride, float4* __restrict__ out) {
   const int i = blockIdx.x * 256 + threadIdx.x;

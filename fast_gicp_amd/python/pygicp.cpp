@@ -17,6 +17,7 @@ using namespace fast_gicp;
 using Cloud = PointCloud<PointXYZ>;
 using Lsq = LsqRegistration<PointXYZ, PointXYZ>;
 using VGICPCuda = FastVGICPCuda<PointXYZ, PointXYZ>;
+using GICP = FastGICP<PointXYZ, PointXYZ>;
 using NDT = NDTCuda<PointXYZ, PointXYZ>;
 using Points = py::array_t<double, py::array::c_style | py::array::forcecast>;
 using Mat4 = py::array_t<double, py::array::c_style | py::array::forcecast>;
@@ -86,11 +87,31 @@ static py::array_t<double> downsample(const Points& points, double resolution) {
   return cloud2numpy(filtered);
 }
 
+// downsample on the device: the same filter (pcl::ApproximateVoxelGrid semantics, or pcl::VoxelGrid with exact=True), bit-identical
+// output in the same order, computed by fvh_voxelgrid_* (kernels_downsample.hpp)
+static py::array_t<double> downsample_device(const Points& points, double resolution, bool exact, int device) {
+  auto cloud = numpy2cloud(points);
+  const std::vector<float> xyz = detail::pack_xyz(*cloud);
+  fvh_voxelgrid* vg = nullptr;
+  detail::check(fvh_voxelgrid_create(device, &vg), "fvh_voxelgrid_create", "cannot create the HIP engine (no GPU? there is no CPU fallback)");
+  int n = 0;
+  int rc = fvh_voxelgrid_filter(vg, exact ? FVH_VOXELGRID_EXACT : FVH_VOXELGRID_APPROXIMATE, xyz.data(), (int)cloud->size(), (float)resolution, &n);
+  std::vector<float> out((size_t)3 * n);
+  if (!rc) rc = fvh_voxelgrid_get_points(vg, out.data());
+  const std::string err = rc ? fvh_voxelgrid_last_error(vg) : "";
+  fvh_voxelgrid_destroy(vg);
+  detail::check(rc, "fvh_voxelgrid_filter", err.c_str());
+  py::array_t<double> res({(py::ssize_t)n, (py::ssize_t)3});
+  auto w = res.mutable_unchecked<2>();
+  for (int i = 0; i < n; i++) for (int a = 0; a < 3; a++) w(i, a) = out[3 * (size_t)i + a];
+  return res;
+}
+
 // align_points, main.cpp:64-150. "VGICP" (the CPU FastVGICP in the reference) runs on the same GPU
-// engine in its fp64 CPU-parity arithmetic with k_correspondences honoured; "GICP" (kd-tree
-// correspondences, no voxels) is outside this engine's hot path.
+// engine in its fp64 CPU-parity arithmetic with k_correspondences honoured; "GICP" (nearest-point
+// correspondences, no voxels) runs its correspondence search and cost sums on the device too.
 static py::array_t<double> align_points(const Points& target, const Points& source, const std::string& method, double downsample_resolution, int k_correspondences,
-                                        double /*max_correspondence_distance*/, double voxel_resolution, int /*num_threads*/, const std::string& neighbor_search_method,
+                                        double max_correspondence_distance, double voxel_resolution, int /*num_threads*/, const std::string& neighbor_search_method,
                                         double neighbor_search_radius, const Mat4& initial_guess) {
   Cloud::Ptr target_cloud = numpy2cloud(target), source_cloud = numpy2cloud(source);
   if (downsample_resolution > 0.0) {
@@ -111,8 +132,13 @@ static py::array_t<double> align_points(const Points& target, const Points& sour
     ndt->setResolution(voxel_resolution);
     ndt->setNeighborSearchMethod(search_method(neighbor_search_method), neighbor_search_radius);
     reg = ndt;
+  } else if (method == "GICP") {  // main.cpp:96-101
+    auto gicp = std::make_shared<GICP>();
+    gicp->setMaxCorrespondenceDistance(max_correspondence_distance);
+    gicp->setCorrespondenceRandomness(k_correspondences);
+    reg = gicp;
   } else {
-    std::cerr << "error: registration method " << method << " is not provided by the MI355X engine (VGICP_CUDA, VGICP, NDT_CUDA)" << std::endl;
+    std::cerr << "error: registration method " << method << " is not provided by the MI355X engine (GICP, VGICP, VGICP_CUDA, NDT_CUDA)" << std::endl;
     return identity4();
   }
   reg->setInputTarget(target_cloud);
@@ -129,6 +155,8 @@ static py::array_t<double> align_points(const Points& target, const Points& sour
 PYBIND11_MODULE(pygicp, m) {
   m.doc() = "pygicp on the MI355X HIP engine (surface of koide3/fast_gicp src/python/main.cpp)";
   m.def("downsample", &downsample, "downsample points", py::arg("points"), py::arg("downsample_resolution"));
+  m.def("downsample_device", &downsample_device, "downsample points on the GPU (bit-identical to downsample; exact=True: pcl::VoxelGrid)", py::arg("points"),
+        py::arg("downsample_resolution"), py::arg("exact") = false, py::arg("device") = 0);
   m.def("align_points", &align_points, "align two point sets", py::arg("target"), py::arg("source"), py::arg("method") = "VGICP_CUDA", py::arg("downsample_resolution") = -1.0,
         py::arg("k_correspondences") = 15, py::arg("max_correspondence_distance") = std::numeric_limits<double>::max(), py::arg("voxel_resolution") = 1.0,
         py::arg("num_threads") = 0, py::arg("neighbor_search_method") = "DIRECT1", py::arg("neighbor_search_radius") = 1.5, py::arg("initial_guess") = identity4());
@@ -176,6 +204,13 @@ PYBIND11_MODULE(pygicp, m) {
       .def("set_kernel_width", &VGICPCuda::setKernelWidth, py::arg("kernel_width"), py::arg("max_dist") = -1.0)
       .def("set_regularization_method", [](VGICPCuda& v, const std::string& s) { v.setRegularizationMethod(regularization_method(s)); })
       .def("set_nearest_neighbor_search_method", [](VGICPCuda& v, const std::string& s) { v.setNearestNeighborSearchMethod(nn_method(s)); });
+
+  py::class_<GICP, Lsq, std::shared_ptr<GICP>>(m, "FastGICP")  // main.cpp:183-190
+      .def(py::init([](int device) { return std::make_shared<GICP>(device); }), py::arg("device") = 0)
+      .def("set_num_threads", &GICP::setNumThreads)
+      .def("set_correspondence_randomness", &GICP::setCorrespondenceRandomness)
+      .def("set_max_correspondence_distance", &GICP::setMaxCorrespondenceDistance)
+      .def("set_regularization_method", [](GICP& g, const std::string& s) { g.setRegularizationMethod(regularization_method(s)); });
 
   // The reference's CPU class name, served by the GPU engine in its fp64 CPU-parity arithmetic.
   m.attr("FastVGICP") = m.attr("FastVGICPCuda");

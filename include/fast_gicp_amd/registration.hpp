@@ -444,6 +444,87 @@ private:
   fvh_vgicp* core_ = nullptr;
 };
 
+/// FastGICP (gicp/fast_gicp.hpp:24-98, impl/fast_gicp_impl.hpp) on the HIP engine: the reference class is CPU/OpenMP only;
+/// here the covariances (exact k-NN + regularisation), the nearest-target-point correspondences and the cost sums run on
+/// the device, the LM recursion is the reference's host loop (LsqRegistration::step_lm).
+template <typename PointSource, typename PointTarget>
+class FastGICP : public LsqRegistration<PointSource, PointTarget> {
+  using Base = LsqRegistration<PointSource, PointTarget>;
+  using Base::input_;
+  using Base::target_;
+
+public:
+  using PointCloudSource = typename Base::PointCloudSource;
+  using PointCloudSourceConstPtr = typename Base::PointCloudSourceConstPtr;
+  using PointCloudTargetConstPtr = typename Base::PointCloudTargetConstPtr;
+
+  explicit FastGICP(int device = 0) {  // fast_gicp_impl.hpp:9-23
+    detail::check(fvh_vgicp_create(device, &core_), "fvh_vgicp_create", "cannot create the HIP engine (no GPU? there is no CPU fallback)");
+    this->use_device_lm_ = false;
+  }
+  ~FastGICP() override { if (core_) fvh_vgicp_destroy(core_); }
+  FastGICP(const FastGICP&) = delete;
+  FastGICP& operator=(const FastGICP&) = delete;
+
+  void setNumThreads(int) {}  // :29-38: OpenMP threads of the CPU class; the device needs none
+  void setCorrespondenceRandomness(int k) { k_correspondences_ = k; }  // :41-43
+  void setRegularizationMethod(RegularizationMethod method) { regularization_method_ = method; }  // :46-48
+  void setMaxCorrespondenceDistance(double d) { call(fvh_vgicp_gicp_set_max_correspondence_distance(core_, d), "gicp_set_max_correspondence_distance"); }  // pcl::Registration
+
+  void swapSourceAndTarget() override {  // :51-62
+    call(fvh_vgicp_gicp_swap_source_and_target(core_), "gicp_swap_source_and_target");
+    input_.swap(target_);
+  }
+  void clearSource() override { input_.reset(); }  // :65-68
+  void clearTarget() override { target_.reset(); }  // :71-74
+
+  void setInputSource(const PointCloudSourceConstPtr& cloud) override {  // :77-85 (covariances: :103-112, computed eagerly here)
+    if (cloud == input_) return;
+    input_ = cloud;
+    const std::vector<float> xyz = detail::pack_xyz(*cloud);
+    call(fvh_vgicp_set_source_cloud(core_, xyz.data(), (int)cloud->size()), "set_source_cloud");
+    call(fvh_vgicp_find_source_neighbors(core_, k_correspondences_), "find_source_neighbors");
+    call(fvh_vgicp_calculate_source_covariances(core_, (int)regularization_method_), "calculate_source_covariances");
+  }
+  void setInputTarget(const PointCloudTargetConstPtr& cloud) override {  // :88-95
+    if (cloud == target_) return;
+    target_ = cloud;
+    const std::vector<float> xyz = detail::pack_xyz(*cloud);
+    call(fvh_vgicp_set_target_cloud(core_, xyz.data(), (int)cloud->size()), "set_target_cloud");
+    call(fvh_vgicp_find_target_neighbors(core_, k_correspondences_), "find_target_neighbors");
+    call(fvh_vgicp_calculate_target_covariances(core_, (int)regularization_method_), "calculate_target_covariances");
+  }
+  double getFitnessScore(double max_range = std::numeric_limits<double>::max()) override {
+    double T16[16], score = 0;
+    Isometry3d::from(this->final_transformation_).to_colmajor16(T16);
+    call(fvh_vgicp_fitness_score(core_, T16, max_range, &score), "fitness_score");
+    return score;
+  }
+  fvh_vgicp* core() { return core_; }
+
+protected:
+  double linearize(const Isometry3d& trans, Matrix6d* H, Vector6d* b) override {  // :159-213
+    double T16[16], err = 0, Hc[36];
+    trans.to_colmajor16(T16);
+    call(fvh_vgicp_gicp_update_correspondences(core_, T16), "gicp_update_correspondences");
+    call(fvh_vgicp_gicp_compute_error(core_, T16, (H && b) ? Hc : nullptr, (H && b) ? b->data() : nullptr, &err), "gicp_compute_error");
+    if (H && b) for (int i = 0; i < 6; i++) for (int j = 0; j < 6; j++) (*H)[i * 6 + j] = Hc[j * 6 + i];
+    return err;
+  }
+  double compute_error(const Isometry3d& trans) override {  // :216-240
+    double T16[16], err = 0;
+    trans.to_colmajor16(T16);
+    call(fvh_vgicp_gicp_compute_error(core_, T16, nullptr, nullptr, &err), "gicp_compute_error");
+    return err;
+  }
+  void call(int rc, const char* what) const { detail::check(rc, what, fvh_vgicp_last_error(core_)); }
+
+private:
+  int k_correspondences_ = 20;                                                // :17
+  RegularizationMethod regularization_method_ = RegularizationMethod::PLANE;  // :21
+  fvh_vgicp* core_ = nullptr;
+};
+
 /// NDTCuda (ndt_cuda.hpp:23-69, impl/ndt_cuda_impl.hpp)
 template <typename PointSource, typename PointTarget>
 class NDTCuda : public LsqRegistration<PointSource, PointTarget> {

@@ -131,6 +131,18 @@ int fvh_vgicp_align(fvh_vgicp* h, const double* guess16, const fvh_lm_params* pa
  * (float)T * source to the target cloud (brute-force tiled 1-NN on device). */
 int fvh_vgicp_fitness_score(fvh_vgicp* h, const double* T16, double max_range, double* score);
 
+/* ---- FastGICP on the device: nearest-target-point correspondences instead of voxels, on the same handle.
+ * Reference: fast_gicp::FastGICP (CPU/OpenMP only), include/fast_gicp/gicp/impl/fast_gicp_impl.hpp:
+ *   update_correspondences :118-156 (query = trans.cast<float>() * p, exact 1-NN in the target, kept when the squared
+ *   distance < corr_dist_threshold_^2; mahalanobis = (C_B + T C_A T^T)^-1), linearize :159-213, compute_error :216-240,
+ *   setMaxCorrespondenceDistance = pcl::Registration (default float max, :18).
+ * Needs both clouds and both covariance sets (calculate_*_covariances or set_*_covariances); no voxel map. ---- */
+int fvh_vgicp_gicp_set_max_correspondence_distance(fvh_vgicp* h, double max_distance);
+int fvh_vgicp_gicp_swap_source_and_target(fvh_vgicp* h);                                    /* fast_gicp_impl.hpp:56-62: swaps clouds, neighbours, covariances; no voxel map */
+int fvh_vgicp_gicp_update_correspondences(fvh_vgicp* h, const double* T16);
+int fvh_vgicp_gicp_compute_error(fvh_vgicp* h, const double* T16, double* H36, double* b6, double* error);
+int fvh_vgicp_gicp_get_correspondences(fvh_vgicp* h, int* target_index_per_source_point /* num_source_points ints, -1 = none */);
+
 /* new: per-kernel-class HIP-event timing on the handle's stream (for bench.py's roofline leg) */
 int fvh_vgicp_profile_enable(fvh_vgicp* h, int on);
 int fvh_vgicp_profile_reset(fvh_vgicp* h);

@@ -235,6 +235,10 @@ class FastVGICP(_Reg):
         self.h = lib().orc_vgicp_create()
         self._call("set_params", threads, k, reg, C.c_double(resolution), search, cov_mode, C.c_double(kernel_width), C.c_double(kernel_max_dist), int(round_fp32))
 
+    def set_gicp_mode(self, on=True, max_correspondence_distance=3.4028234663852886e38):
+        """FastGICP (fast_gicp_impl.hpp:118-240): nearest-target-point correspondences instead of voxels."""
+        self._call("set_gicp_mode", int(on), C.c_double(max_correspondence_distance))
+
     def set_target_covs(self, covs):
         c = _f64(covs)
         self._call("set_target_covs", _p(c))

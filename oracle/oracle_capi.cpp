@@ -118,6 +118,11 @@ double orc_fitness(const float* src, int ns, const float* tgt, int nt, const dou
 // ---------------- FastVGICP handle ----------------
 void* orc_vgicp_create() { return new FastVGICP(); }
 void orc_vgicp_destroy(void* h) { delete (FastVGICP*)h; }
+void orc_vgicp_set_gicp_mode(void* h, int on, double max_corr_dist) {
+  auto* g = static_cast<FastVGICP*>(h);
+  g->gicp_mode = on != 0;
+  g->max_correspondence_distance = max_corr_dist;
+}
 void orc_vgicp_set_params(void* h, int threads, int k, int reg, double res, int search, int cov_mode, double kw, double kmax, int round_fp32) {
   auto* g = (FastVGICP*)h;
   if (threads > 0) g->num_threads = threads;

@@ -576,6 +576,33 @@ double FastVGICP::getFitnessScore() const {
 
 void FastVGICP::update_correspondences(const Iso3& T) {
   voxel_correspondences.clear();
+  if (gicp_mode) {
+    // FastGICP::update_correspondences (fast_gicp_impl.hpp:118-156): query = trans.cast<float>() * point (fp32), exact 1-NN
+    // in the target, kept when the fp32 squared distance < threshold^2; mahalanobis = (C_B + T C_A T^T)^-1 in fp64.
+    float m[12];
+    for (int i = 0; i < 3; i++) { for (int j = 0; j < 3; j++) m[i * 4 + j] = (float)T.R[i * 3 + j]; m[i * 4 + 3] = (float)T.t[i]; }
+    const int n = (int)input->size();
+    std::vector<int> nn(n);
+    const double thr_sq = max_correspondence_distance * max_correspondence_distance;
+#pragma omp parallel for num_threads(num_threads) schedule(guided, 8)
+    for (int i = 0; i < n; i++) {
+      const float* p = input->pt(i);
+      float q[3];
+      for (int r = 0; r < 3; r++) q[r] = (p[0] * m[r * 4 + 0] + p[1] * m[r * 4 + 1]) + (p[2] * m[r * 4 + 2] + m[r * 4 + 3]);
+      int idx; float d;
+      search_target->knn(q, 1, &idx, &d);
+      nn[i] = ((double)d < thr_sq) ? idx : -1;
+    }
+    for (int i = 0; i < n; i++) if (nn[i] >= 0) voxel_correspondences.push_back({i, nn[i]});
+    voxel_mahalanobis.resize(voxel_correspondences.size());
+    const M3 R = iso_rot(T), Rt = m3_transpose(R);
+#pragma omp parallel for num_threads(num_threads) schedule(guided, 8)
+    for (int i = 0; i < (int)voxel_correspondences.size(); i++) {
+      const auto& corr = voxel_correspondences[i];
+      voxel_mahalanobis[i] = m3_inverse(m3_add(target_covs[corr.second], m3_mul(m3_mul(R, source_covs[corr.first]), Rt)));
+    }
+    return;
+  }
   auto offsets = neighbor_offsets(search_method);
   std::vector<std::vector<std::pair<int, int>>> corrs(num_threads);
   for (auto& c : corrs) c.reserve((input->size() * offsets.size()) / num_threads);
@@ -603,7 +630,7 @@ void FastVGICP::update_correspondences(const Iso3& T) {
 }
 
 double FastVGICP::linearize(const Iso3& T, double* H, double* b) {
-  if (!voxelmap) {
+  if (!gicp_mode && !voxelmap) {
     voxelmap.reset(new VoxelMap(voxel_resolution));
     voxelmap->create_vgicp(*target, target_covs);
     if (round_storage_fp32)
@@ -617,12 +644,13 @@ double FastVGICP::linearize(const Iso3& T, double* H, double* b) {
 #pragma omp parallel for num_threads(num_threads) reduction(+ : sum_errors) schedule(guided, 8)
   for (int i = 0; i < (int)voxel_correspondences.size(); i++) {
     const auto& corr = voxel_correspondences[i];
-    const Voxel& vox = voxelmap->voxels[corr.second];
+    double mu[3], w;
+    if (gicp_mode) { for (int a = 0; a < 3; a++) mu[a] = (double)target->pt(corr.second)[a]; w = 1.0; }   // fast_gicp_impl.hpp:176-183
+    else { const Voxel& vox = voxelmap->voxels[corr.second]; for (int a = 0; a < 3; a++) mu[a] = vox.mean[a]; w = std::sqrt((double)vox.num_points); }
     V3 a = {{(double)input->pt(corr.first)[0], (double)input->pt(corr.first)[1], (double)input->pt(corr.first)[2]}};
     V3 q = iso_apply(T, a);
-    V3 e = {{vox.mean[0] - q[0], vox.mean[1] - q[1], vox.mean[2] - q[2]}};
+    V3 e = {{mu[0] - q[0], mu[1] - q[1], mu[2] - q[2]}};
     const M3& M = voxel_mahalanobis[i];
-    double w = std::sqrt((double)vox.num_points);
     V3 Me = m3_mulv(M, e);
     sum_errors += w * (e[0] * Me[0] + e[1] * Me[1] + e[2] * Me[2]);
     if (H == nullptr || b == nullptr) continue;
@@ -651,12 +679,14 @@ double FastVGICP::compute_error(const Iso3& T) {
 #pragma omp parallel for num_threads(num_threads) reduction(+ : sum_errors)
   for (int i = 0; i < (int)voxel_correspondences.size(); i++) {
     const auto& corr = voxel_correspondences[i];
-    const Voxel& vox = voxelmap->voxels[corr.second];
+    double mu[3], w;
+    if (gicp_mode) { for (int a = 0; a < 3; a++) mu[a] = (double)target->pt(corr.second)[a]; w = 1.0; }   // fast_gicp_impl.hpp:216-238
+    else { const Voxel& vox = voxelmap->voxels[corr.second]; for (int a = 0; a < 3; a++) mu[a] = vox.mean[a]; w = std::sqrt((double)vox.num_points); }
     V3 a = {{(double)input->pt(corr.first)[0], (double)input->pt(corr.first)[1], (double)input->pt(corr.first)[2]}};
     V3 q = iso_apply(T, a);
-    V3 e = {{vox.mean[0] - q[0], vox.mean[1] - q[1], vox.mean[2] - q[2]}};
+    V3 e = {{mu[0] - q[0], mu[1] - q[1], mu[2] - q[2]}};
     V3 Me = m3_mulv(voxel_mahalanobis[i], e);
-    sum_errors += std::sqrt((double)vox.num_points) * (e[0] * Me[0] + e[1] * Me[1] + e[2] * Me[2]);
+    sum_errors += w * (e[0] * Me[0] + e[1] * Me[1] + e[2] * Me[2]);
   }
   return sum_errors;
 }

@@ -124,6 +124,10 @@ struct FastVGICP : LsqBase {
   // when true, regularised covariances / voxel means+covs are rounded to fp32 before use,
   // mirroring the fp32 HBM storage of the HIP engine (diagnostic only).
   bool round_storage_fp32 = false;
+  // FastGICP (the base class of FastVGICP in the reference, fast_gicp_impl.hpp:118-240): correspondences are the
+  // nearest TARGET POINT within corr_dist_threshold_ instead of voxels; weight 1, target point covariances.
+  bool gicp_mode = false;
+  double max_correspondence_distance = 3.4028234663852886e38;  // fast_gicp_impl.hpp:18 (float max)
 
   CloudPtr input, target;
   std::shared_ptr<KdTree> search_source, search_target, pcl_tree;  // pcl_tree = PCL Registration::tree_

@@ -39,6 +39,20 @@ def main():
             e, H, b = h.linearize(T)
             case["linearize"][pn] = {"error": e, "H": H.tolist(), "b": b.tolist(), "num_correspondences": h.num_correspondences()}
         out["cases"][name] = case
+    for name, max_dist in (("gicp", None), ("gicp_maxdist1", 1.0)):  # FastGICP (nearest target point), fast_gicp_impl.hpp:118-240
+        g = O.FastVGICP()
+        g.set_gicp_mode(True, 3.4028234663852886e38 if max_dist is None else max_dist)
+        g.set_target(tgt); g.set_source(src)
+        r = g.align()
+        case = {"T": r["T"].tolist(), "H": r["H"].tolist(), "converged": r["converged"], "iterations": r["iterations"], "fitness": g.fitness(), "max_correspondence_distance": max_dist,
+                "linearize": {}}
+        h = O.FastVGICP()
+        h.set_gicp_mode(True, 3.4028234663852886e38 if max_dist is None else max_dist)
+        h.set_target(tgt); h.set_source(src); h.prepare()
+        for pn, T in poses.items():
+            e, H, b = h.linearize(T)
+            case["linearize"][pn] = {"error": e, "H": H.tolist(), "b": b.tolist(), "num_correspondences": h.num_correspondences()}
+        out["cases"][name] = case
     for name, mode in (("ndt_d2d", O.D2D), ("ndt_p2d", O.P2D)):
         g = O.NDT(mode=mode)
         g.set_target(tgt); g.set_source(src)

@@ -65,3 +65,41 @@ def test_engine_matches_golden_ndt(case, mode):
     f = c.fitness_score(r["T"].astype(np.float32).astype(np.float64))
     assert abs(f - ref["fitness"]) <= 1e-4 * ref["fitness"]
     c.close()
+
+
+@pytest.mark.parametrize("case", ["gicp", "gicp_maxdist1"])
+def test_oracle_reproduces_golden_gicp(case):
+    from oracle import oracle as O
+    tgt, src = util.bundled_pair()
+    ref = GOLD["cases"][case]
+    g = O.FastVGICP()
+    g.set_gicp_mode(True, 3.4028234663852886e38 if ref["max_correspondence_distance"] is None else ref["max_correspondence_distance"])
+    g.set_target(tgt); g.set_source(src)
+    r = g.align()
+    assert util.rel_err(r["T"], ref["T"]) < 1e-9 and r["iterations"] == ref["iterations"]
+    assert abs(g.fitness() - ref["fitness"]) < 1e-9
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", ["gicp", "gicp_maxdist1"])
+def test_engine_matches_golden_gicp(case):
+    from fast_gicp_amd import capi, distributed as D
+    tgt, src = util.bundled_pair()
+    ref = GOLD["cases"][case]
+    c = capi.VGICPCore(0)
+    c.set_target_cloud(tgt); c.find_target_neighbors(20); c.calculate_target_covariances(3)
+    c.set_source_cloud(src); c.find_source_neighbors(20); c.calculate_source_covariances(3)
+    if ref["max_correspondence_distance"] is not None:
+        c.gicp_set_max_correspondence_distance(ref["max_correspondence_distance"])
+    for pn, T in (("identity", np.eye(4)), ("relative_txt", util.relative_pose())):
+        e, H, b = c.gicp_linearize(T)
+        lin = ref["linearize"][pn]
+        assert int((c.gicp_get_correspondences() >= 0).sum()) == lin["num_correspondences"]
+        assert abs(e - lin["error"]) <= 1e-5 * abs(lin["error"])   # fp32-stored covariances vs the all-fp64 oracle
+        assert util.rel_err(H, lin["H"]) < 1e-5 and util.rel_err(b, lin["b"]) < 1e-5
+    r = D.ShardedLsq(lambda T: c.gicp_linearize(T), lambda T: c.gicp_compute_error(T, derivatives=False), lambda v: v).align()
+    assert r["converged"] == ref["converged"]
+    assert util.rel_err(r["T"], ref["T"]) < 1e-4 and util.rel_err(r["H"], ref["H"]) < 1e-4   # north_star tolerance
+    f = c.fitness_score(r["T"].astype(np.float32).astype(np.float64))
+    assert abs(f - ref["fitness"]) <= 1e-4 * ref["fitness"]
+    c.close()

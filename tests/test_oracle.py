@@ -30,13 +30,19 @@ def test_gicp_test_input_counts(O):
     assert (len(t), len(s)) == (7908, 8061)
 
 
-@pytest.mark.parametrize("method", ["VGICP", "NDT"])
+def _gicp(O):
+    g = O.FastVGICP()
+    g.set_gicp_mode(True)
+    return g
+
+
+@pytest.mark.parametrize("method", ["VGICP", "NDT", "GICP"])
 def test_gicp_test_scenarios(O, method):
     """The reference's only correctness pin (gicp_test.cpp:147-201): forward / backward / swap-and-set-source /
     swap-and-set-target, each within 0.05 m and 1 deg of data/relative.txt and converged."""
     t, s = util.bundled_pair(origin_filter=False, leaf=0.2, exact_voxelgrid=True)
     gt = util.relative_pose()
-    make = (lambda: O.FastVGICP()) if method == "VGICP" else (lambda: O.NDT())
+    make = {"VGICP": (lambda: O.FastVGICP()), "NDT": (lambda: O.NDT()), "GICP": (lambda: _gicp(O))}[method]
 
     def check(T, conv, label):
         te, re_ = util.pose_error(gt, T)
@@ -67,6 +73,16 @@ def test_readme_fitness_band(O):
     assert r["iterations"] == 4
     np.testing.assert_allclose(r["T"][:3, 3], [0.498359, 0.117208, -0.029736], atol=2e-6)
     assert abs(f - 0.205022) < 2e-6
+
+
+def test_readme_fitness_band_fastgicp(O):
+    """README.md:122-124 fgicp_st 0.204379 / fgicp_mt 0.204412 -> +-1 % band for the FastGICP (nearest-point) restatement."""
+    t, s = util.bundled_pair(origin_filter=True)
+    g = _gicp(O)
+    g.set_target(t); g.set_source(s)
+    r = g.align()
+    assert r["converged"]
+    assert abs(g.fitness() - 0.204379) / 0.204379 < 0.01
 
 
 def test_direct27_recorded_values(O):
