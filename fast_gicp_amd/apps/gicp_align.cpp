@@ -1,5 +1,5 @@
 // gicp_align on the MI355X engine -- the reference's benchmark driver (src/align.cpp:51-215) for the
-// methods this engine provides (the ndt_cuda and vgicp_cuda rows), same call sequence, same
+// methods this engine provides (the fgicp, ndt_cuda and vgicp_cuda rows), same call sequence, same
 // "single / 100times / 100times_reuse / fitness_score" output line (README.md:118-134).
 #include <algorithm>
 #include <chrono>
@@ -68,6 +68,11 @@ int main(int argc, char** argv) {
   approximate_voxel_grid(*source_cloud, 0.1f, *fs);
   std::cout << "target:" << ft->size() << "[pts] source:" << fs->size() << "[pts]" << std::endl;
 
+  std::cout << "--- fgicp_hip ---" << std::endl;  // align.cpp:171-178 (fgicp_st / fgicp_mt): nearest-point GICP, correspondences and sums on the device
+  {
+    FastGICP<PointXYZ, PointXYZ> fgicp;
+    test(fgicp, ft, fs);
+  }
   std::cout << "--- ndt_hip (P2D) ---" << std::endl;
   NDTCuda<PointXYZ, PointXYZ> ndt;
   ndt.setResolution(1.0);
