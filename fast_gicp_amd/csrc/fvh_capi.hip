@@ -801,9 +801,15 @@ int gicp_update_correspondences(Engine* e, CloudDev& src, CloudDev& tgt, VoxelMa
   const double thr = std::min(max_dist, 1.8446743e19);  // threshold^2 must stay finite in fp64 (reference default: float max)
   {
     ProfScope ps(e, "gicp_nn");
-    const int waves = (src.n + FIT_Q - 1) / FIT_Q;
-    nn_corr_tiled_kernel<<<(waves + 3) / 4, 256, 0, e->stream>>>(src.sorted.as<float4>(), src.n, tgt.sorted.as<float4>(), tgt.bbox.as<float4>(), tgt.n, reinterpret_cast<const float*>(base + 16), thr * thr,
-                                                                 e->corr.as<int>());
+    static const int nn_mode = [] { const char* v = getenv("FVH_GICP_NN_MODE"); return v ? atoi(v) : 1; }();  // 1: one query per wave, 0: 8 queries per wave
+    if (nn_mode == 1) {
+      nn1_corr_kernel<<<(src.n + 3) / 4, 256, 0, e->stream>>>(src.sorted.as<float4>(), src.n, tgt.sorted.as<float4>(), tgt.bbox.as<float4>(), tgt.bbox2.as<float4>(), tgt.n,
+                                                              reinterpret_cast<const float*>(base + 16), thr * thr, e->corr.as<int>());
+    } else {
+      const int waves = (src.n + FIT_Q - 1) / FIT_Q;
+      nn_corr_tiled_kernel<<<(waves + 3) / 4, 256, 0, e->stream>>>(src.sorted.as<float4>(), src.n, tgt.sorted.as<float4>(), tgt.bbox.as<float4>(), tgt.n, reinterpret_cast<const float*>(base + 16), thr * thr,
+                                                                   e->corr.as<int>());
+    }
   }
   HIP_OR_FAIL(e, hipGetLastError());
   HIP_OR_FAIL(e, hipStreamSynchronize(e->stream));  // T12 is a stack buffer

@@ -650,6 +650,93 @@ __global__ __launch_bounds__(256) void nn_corr_tiled_kernel(const float4* __rest
   }
 }
 
+// Same search, ONE query per wave (like knn_tiled1_kernel: the regime is a latency chain per query, so 17k short waves
+// beat 2k long ones -- the 8-queries-per-wave sweep above took 430 us per search at 17k x 17k, 4 per GICP registration).
+// Seed = nearest tile by box distance through the two box levels, then every tile whose box can still hold a point at
+// least as near (ties resolve to the lower original index).
+__global__ __launch_bounds__(256) void nn1_corr_kernel(const float4* __restrict__ ssrc, int ns, const float4* __restrict__ stgt, const float4* __restrict__ bbox1,
+                                                       const float4* __restrict__ bbox2, int nt, const float* __restrict__ T12, double thr_sq, int* __restrict__ corr) {
+  const int lane = threadIdx.x & 63;
+  const int q = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (q >= ns) return;
+  const int ntiles = (nt + 63) >> 6, nsuper = (ntiles + 63) >> 6;
+  const float4 qv = ssrc[q];
+  const float qx = transform_row_nofma(qv, T12 + 0), qy = transform_row_nofma(qv, T12 + 4), qz = transform_row_nofma(qv, T12 + 8);
+  float best = __builtin_inff();
+  int besti = 0x7fffffff;
+  auto sweep = [&](const float4& p, int base) __attribute__((always_inline)) {
+    const float d = sqdist_nofma(p, qx, qy, qz);
+    float dm = d;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) dm = fminf(dm, __shfl_xor(dm, off));
+    if (dm > best) return;  // wave-uniform
+    int im = (d == dm && base + lane < nt) ? __float_as_int(p.w) : 0x7fffffff;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) im = min(im, __shfl_xor(im, off));
+    if (dm < best || im < besti) { best = dm; besti = im; }
+  };
+  // wave argmin of (value, index): value ties -> lower index
+  auto argmin = [&](float v, int i, float& vo, int& io) __attribute__((always_inline)) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      const float ov = __shfl_xor(v, off);
+      const int oi = __shfl_xor(i, off);
+      if (ov < v || (ov == v && oi < i)) { v = ov; i = oi; }
+    }
+    vo = v; io = i;
+  };
+  // ---- seed: the tile whose box is nearest ----
+  float sv = __builtin_inff();
+  int si = 0;
+  for (int sc = 0; sc < nsuper; sc += 64) {
+    const int s = sc + lane;
+    const float lb2 = (s < nsuper) ? point_box_sq(bbox2[2 * s], bbox2[2 * s + 1], qx, qy, qz) : __builtin_inff();
+    float v; int i;
+    argmin(lb2, s, v, i);
+    if (v < sv) { sv = v; si = i; }
+  }
+  int t_seed;
+  {
+    const int t = (si << 6) + lane;
+    const float lb = (t < ntiles) ? point_box_sq(bbox1[2 * t], bbox1[2 * t + 1], qx, qy, qz) : __builtin_inff();
+    float v;
+    argmin(lb, t, v, t_seed);
+  }
+  sweep(load_candidate(stgt, (t_seed << 6) + lane, nt), t_seed << 6);
+  // ---- everything that can still be at least as near ----
+  for (int sc = 0; sc < nsuper; sc += 64) {
+    const int s = sc + lane;
+    const float lb2 = (s < nsuper) ? point_box_sq(bbox2[2 * s], bbox2[2 * s + 1], qx, qy, qz) : __builtin_inff();
+    unsigned long long smask = __ballot(lb2 <= best);
+    while (smask) {
+      const int ssrc_l = __ffsll((long long)smask) - 1;
+      smask &= smask - 1;
+      if (read_lane(lb2, ssrc_l) > best) continue;
+      const int t = ((sc + ssrc_l) << 6) + lane;
+      const float lb = (t < ntiles) ? point_box_sq(bbox1[2 * t], bbox1[2 * t + 1], qx, qy, qz) : __builtin_inff();
+      unsigned long long tmask = __ballot(lb <= best && t != t_seed);
+      if (!tmask) continue;
+      int cur = __ffsll((long long)tmask) - 1;
+      tmask &= tmask - 1;
+      float4 pcur = load_candidate(stgt, ((((sc + ssrc_l) << 6) + cur) << 6) + lane, nt);
+      while (true) {  // the next surviving tile is in flight while this one is reduced
+        int nxt = -1;
+        float4 pnxt = pcur;
+        if (tmask) {
+          nxt = __ffsll((long long)tmask) - 1;
+          tmask &= tmask - 1;
+          pnxt = load_candidate(stgt, ((((sc + ssrc_l) << 6) + nxt) << 6) + lane, nt);
+        }
+        if (read_lane(lb, cur) <= best) sweep(pcur, (((sc + ssrc_l) << 6) + cur) << 6);
+        if (nxt < 0) break;
+        cur = nxt;
+        pcur = pnxt;
+      }
+    }
+  }
+  if (lane == 0) corr[__float_as_int(qv.w)] = ((double)best < thr_sq) ? besti : -1;
+}
+
 // One 64-byte record per target point in the layout of a voxel bucket ({key (unused), q1 = point + count 1, q2/q3 =
 // covariance}), so cost_kernel<Real, MODE_VGICP> evaluates FastGICP's cost unchanged: weight sqrt(1) = 1, mean = point.
 __global__ __launch_bounds__(256) void gicp_records_kernel(const float4* __restrict__ pts, const float4* __restrict__ cov, int n, float4* __restrict__ table) {
