@@ -207,4 +207,11 @@ __device__ __forceinline__ unsigned hash_key(unsigned long long k) {
   return (unsigned)k;
 }
 
+// order-preserving float <-> uint mapping for atomicMin/Max
+__device__ __forceinline__ unsigned float_to_ordered(float f) {
+  const unsigned u = __float_as_uint(f);
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float ordered_to_float(unsigned u) { return __uint_as_float((u & 0x80000000u) ? (u & 0x7fffffffu) : ~u); }
+
 }  // namespace fvh

@@ -46,12 +46,13 @@ struct DevBuf {
 
 struct CloudDev {
   int n = 0, k = 0;
+  DevBuf box;                          // bounding cube {~ordered(min) x3, ordered(max) x3}, reduced by pack_points_kernel
   DevBuf bbox2;                        // boxes of 64 consecutive tile boxes
   DevBuf order;                        // Morton permutation: order[j] = original index of the j-th point along the curve
   DevBuf pts, cov, nbr, bbox, sorted;  // sorted: Morton-ordered copy, .w = original index; bbox: boxes of its 64-point tiles
   bool has_pts = false, has_cov = false, has_nbr = false, has_sorted = false;
   void swap(CloudDev& o) { std::swap(*this, o); }
-  void release() { pts.release(); cov.release(); nbr.release(); bbox.release(); bbox2.release(); sorted.release(); order.release(); }
+  void release() { box.release(); pts.release(); cov.release(); nbr.release(); bbox.release(); bbox2.release(); sorted.release(); order.release(); }
 };
 
 // Clouds of this size and up are walked in Morton order (PMC: 2.8x HBM over-fetch on a randomly ordered 100k scan
@@ -120,6 +121,7 @@ struct Rccl {
   }
 };
 Rccl g_rccl;
+std::atomic<int> g_live_engines{0};    // engine handles alive in this process
 std::atomic<int> g_active_aligns{0};  // aligns in flight in this process (persistent kernels want the device to themselves)
 
 struct Engine {
@@ -129,6 +131,7 @@ struct Engine {
   int precision = FVH_COMPUTE_FP64;
   std::vector<int> offsets_host{0, 0, 0};
   int n_off = 1;
+  DevBuf sort_coop;  // SortCoopState + histograms of the cooperative small sort
   DevBuf pticket;  // arrival counters of the persistent LM kernel (zeroed before every launch)
   DevBuf bcast;    // its broadcast rows (tagged with persist_seq, never cleared)
   unsigned long long persist_seq = 0;
@@ -170,15 +173,19 @@ struct Engine {
     int rc = upload_offsets();
     if (rc) return rc;
     if ((e = hipStreamSynchronize(stream)) != hipSuccess) return hipfail(e, "hipStreamSynchronize");  // "warming up GPU" (fast_vgicp_cuda.cu:19-20)
+    g_live_engines.fetch_add(1);
+    counted = true;
     return FVH_OK;
   }
+  bool counted = false;
   void shutdown() {
+    if (counted) { g_live_engines.fetch_sub(1); counted = false; }
     (void)hipSetDevice(device);
     if (stream) (void)hipStreamSynchronize(stream);
     if (comm && g_rccl.CommDestroy) g_rccl.CommDestroy(comm);
     comm = nullptr;
     prof.destroy();
-    pticket.release(); bcast.release(); offsets_dev.release(); state.release(); partials.release(); ticket.release(); corr.release(); misc.release(); fit.release(); staging.release(); sort_keys.release(); sort_idx.release(); sort_hist.release();
+    sort_coop.release(); pticket.release(); bcast.release(); offsets_dev.release(); state.release(); partials.release(); ticket.release(); corr.release(); misc.release(); fit.release(); staging.release(); sort_keys.release(); sort_idx.release(); sort_hist.release();
     if (pinned) (void)hipHostFree(pinned);
     if (stream) (void)hipStreamDestroy(stream);
   }
@@ -248,14 +255,16 @@ int upload_cloud(Engine* e, CloudDev& c, const float* xyz, int n, int stride, bo
   c.has_pts = true;
   c.has_sorted = false;
   if (n == 0) return FVH_OK;
+  HIP_OR_FAIL(e, c.box.ensure(64));
+  HIP_OR_FAIL(e, hipMemsetAsync(c.box.p, 0, 64, e->stream));
   if (on_device) {
-    pack_points_kernel<<<(n + 255) / 256, 256, 0, e->stream>>>(xyz, n, stride, c.pts.as<float4>());
+    pack_points_kernel<<<(n + 255) / 256, 256, 0, e->stream>>>(xyz, n, stride, c.pts.as<float4>(), c.box.as<unsigned>());
     HIP_OR_FAIL(e, hipGetLastError());
   } else {
     // H2D the packed xyz into a staging buffer, then widen to float4 on device
     HIP_OR_FAIL(e, e->staging.ensure(sizeof(float) * 3 * (size_t)n));
     HIP_OR_FAIL(e, hipMemcpyAsync(e->staging.p, xyz, sizeof(float) * 3 * (size_t)n, hipMemcpyHostToDevice, e->stream));
-    pack_points_kernel<<<(n + 255) / 256, 256, 0, e->stream>>>(e->staging.as<float>(), n, 3, c.pts.as<float4>());
+    pack_points_kernel<<<(n + 255) / 256, 256, 0, e->stream>>>(e->staging.as<float>(), n, 3, c.pts.as<float4>(), c.box.as<unsigned>());
     HIP_OR_FAIL(e, hipGetLastError());
     HIP_OR_FAIL(e, hipStreamSynchronize(e->stream));  // caller may free xyz on return (reference copies too)
   }
@@ -290,11 +299,28 @@ int ensure_sorted(Engine* e, CloudDev& c) {
   const int nsuper_small = (ntiles + 63) / 64;
   HIP_OR_FAIL(e, c.bbox2.ensure(sizeof(float4) * 2 * (size_t)nsuper_small));
   ProfScope ps(e, "sort");
-  static const int sort_mode = [] { const char* v = getenv("FVH_SORT_MODE"); return v ? atoi(v) : 1; }();  // 1: single-workgroup path for small clouds
-  if (sort_mode == 1 && n <= SORT_SMALL_MAX) {
-    sort_small_kernel<<<1, 1024, 0, e->stream>>>(c.pts.as<float4>(), n, e->sort_keys.as<unsigned>(), c.order.as<int>(), e->sort_keys.as<unsigned>() + n, e->sort_idx.as<int>());
-    gather_tiles_kernel<<<(ntiles + 3) / 4, 256, 0, e->stream>>>(c.pts.as<float4>(), c.order.as<int>(), n, c.sorted.as<float4>(), c.bbox.as<float4>());
-    super_bbox_kernel<<<(nsuper_small + 3) / 4, 256, 0, e->stream>>>(c.bbox.as<float4>(), ntiles, c.bbox2.as<float4>());
+  static const int sort_mode = [] { const char* v = getenv("FVH_SORT_MODE"); return v ? atoi(v) : 2; }();  // 0: multi-kernel radix, 1: single workgroup, 2: cooperative (single-engine processes), 3: cooperative always
+  if (sort_mode >= 1 && n <= SORT_SMALL_MAX) {
+    // cooperative kernel (32 workgroups meeting at grid barriers) when this is the only engine of the process: two
+    // gang kernels from two streams could starve each other of CU slots (the watchdog + fallback would recover, slowly)
+    const bool coop = (sort_mode == 2 && g_live_engines.load() == 1) || sort_mode == 3;
+    if (coop) {
+      HIP_OR_FAIL(e, e->sort_coop.ensure(sizeof(SortCoopState) + sizeof(unsigned) * 2 * SMALL_BINS * COOP_WGS));
+      SortCoopState* cs = e->sort_coop.as<SortCoopState>();
+      unsigned* chist = reinterpret_cast<unsigned*>(cs + 1);
+      HIP_OR_FAIL(e, hipMemsetAsync(cs, 0, sizeof(SortCoopState), e->stream));
+      unsigned long long wd = 2'000'000ull;  // 20 ms
+      { const char* v = getenv("FVH_SORT_COOP_WATCHDOG_TICKS"); if (v) wd = strtoull(v, nullptr, 10); }  // test hook: 0 forces the fallback
+      sort_coop_kernel<<<COOP_WGS, COOP_THREADS, 0, e->stream>>>(c.pts.as<float4>(), n, e->sort_keys.as<unsigned>() + n, e->sort_idx.as<int>(), c.order.as<int>(), c.sorted.as<float4>(),
+                                                                 c.bbox.as<float4>(), c.box.as<unsigned>(), chist, cs, wd);
+      // normally the super boxes only; when the cooperative kernel did not finish, one workgroup redoes everything
+      sort_coop_finish_kernel<<<1, 1024, 0, e->stream>>>(c.pts.as<float4>(), n, e->sort_keys.as<unsigned>(), c.order.as<int>(), e->sort_keys.as<unsigned>() + n, e->sort_idx.as<int>(),
+                                                         c.sorted.as<float4>(), c.bbox.as<float4>(), c.bbox2.as<float4>(), cs);
+    } else {
+      sort_small_kernel<<<1, 1024, 0, e->stream>>>(c.pts.as<float4>(), n, e->sort_keys.as<unsigned>(), c.order.as<int>(), e->sort_keys.as<unsigned>() + n, e->sort_idx.as<int>());
+      gather_tiles_kernel<<<(ntiles + 3) / 4, 256, 0, e->stream>>>(c.pts.as<float4>(), c.order.as<int>(), n, c.sorted.as<float4>(), c.bbox.as<float4>());
+      super_bbox_kernel<<<(nsuper_small + 3) / 4, 256, 0, e->stream>>>(c.bbox.as<float4>(), ntiles, c.bbox2.as<float4>());
+    }
     HIP_OR_FAIL(e, hipGetLastError());
     c.has_sorted = true;
     return FVH_OK;

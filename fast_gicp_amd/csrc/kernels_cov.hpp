@@ -749,11 +749,38 @@ __global__ __launch_bounds__(256) void gicp_records_kernel(const float4* __restr
   table[4 * (size_t)i + 3] = cov[2 * (size_t)i + 1];
 }
 
-// float xyz (stride 3 or 4) -> float4 (w = 0)
-__global__ __launch_bounds__(256) void pack_points_kernel(const float* __restrict__ xyz, int n, int stride, float4* __restrict__ out) {
+// float xyz (stride 3 or 4) -> float4 (w = 0); optionally reduces the cloud's bounding cube into box[0..2] = ~ordered(min),
+// box[3..5] = ordered(max) (zero-initialised by the host; both are atomicMax) for the cooperative sort
+__global__ __launch_bounds__(256) void pack_points_kernel(const float* __restrict__ xyz, int n, int stride, float4* __restrict__ out, unsigned* __restrict__ box) {
+  __shared__ float s_lo[4][3], s_hi[4][3];
   const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= n) return;
-  out[i] = make_float4(xyz[(size_t)i * stride], xyz[(size_t)i * stride + 1], xyz[(size_t)i * stride + 2], 0.f);
+  float lo[3] = {3e38f, 3e38f, 3e38f}, hi[3] = {-3e38f, -3e38f, -3e38f};
+  if (i < n) {
+    const float x = xyz[(size_t)i * stride], y = xyz[(size_t)i * stride + 1], z = xyz[(size_t)i * stride + 2];
+    out[i] = make_float4(x, y, z, 0.f);
+    lo[0] = hi[0] = x; lo[1] = hi[1] = y; lo[2] = hi[2] = z;
+  }
+  if (!box) return;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+  for (int a = 0; a < 3; a++) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      lo[a] = fminf(lo[a], __shfl_xor(lo[a], off));
+      hi[a] = fmaxf(hi[a], __shfl_xor(hi[a], off));
+    }
+    if (lane == 0) { s_lo[wv][a] = lo[a]; s_hi[wv][a] = hi[a]; }
+  }
+  __syncthreads();
+  if (threadIdx.x < 3) {
+    const int a = threadIdx.x;
+    const float l = fminf(fminf(s_lo[0][a], s_lo[1][a]), fminf(s_lo[2][a], s_lo[3][a]));
+    const float h = fmaxf(fmaxf(s_hi[0][a], s_hi[1][a]), fmaxf(s_hi[2][a], s_hi[3][a]));
+    if (l <= h) {
+      atomicMax(&box[a], ~float_to_ordered(l));
+      atomicMax(&box[3 + a], float_to_ordered(h));
+    }
+  }
 }
 
 }  // namespace fvh

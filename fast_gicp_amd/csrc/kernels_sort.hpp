@@ -18,12 +18,6 @@ constexpr int RADIX_BINS = 1 << RADIX_BITS;
 constexpr int RADIX_PASSES = 3;
 constexpr int SORT_ITEMS_MAX = 1024;  // contiguous items a wave owns per pass (runtime: 256 for small clouds -> more, shorter waves)
 
-// order-preserving float <-> uint mapping for atomicMin/Max
-__device__ __forceinline__ unsigned float_to_ordered(float f) {
-  const unsigned u = __float_as_uint(f);
-  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
-}
-__device__ __forceinline__ float ordered_to_float(unsigned u) { return __uint_as_float((u & 0x80000000u) ? (u & 0x7fffffffu) : ~u); }
 
 // box[0..2] = min xyz, box[3..5] = max xyz (ordered-uint encoded); host pre-sets min = 0xFFFFFFFF, max = 0
 __global__ __launch_bounds__(256) void cloud_bbox_kernel(const float4* __restrict__ pts, int n, unsigned* __restrict__ box) {
@@ -221,7 +215,51 @@ __device__ __forceinline__ unsigned spread3_8(unsigned v) {  // up to 8 bits -> 
   return v;
 }
 
-__global__ __launch_bounds__(1024) void sort_small_kernel(const float4* __restrict__ pts, int n, unsigned* keysA, int* idxA, unsigned* keysB, int* idxB) {
+// Tail of the single-workgroup fallback (sort_small_kernel with `sorted` given): sorted copy and both box levels
+// by the same 1024-thread workgroup.
+__device__ inline void sort_small_tail(const float4* __restrict__ pts, const int* order, int n, float4* __restrict__ sorted, float4* bbox1, float4* __restrict__ bbox2) {
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int ntiles = (n + 63) >> 6, nsuper = (ntiles + 63) >> 6;
+  for (int t = wv; t < ntiles; t += 16) {
+    const int j = t * 64 + lane;
+    const int src = order[min(j, n - 1)];
+    float4 q = pts[src];
+    q.w = __int_as_float(src);
+    if (j < n) sorted[j] = q;
+    float l3[3] = {q.x, q.y, q.z}, h3[3] = {q.x, q.y, q.z};
+#pragma unroll
+    for (int a = 0; a < 3; a++)
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) {
+        l3[a] = fminf(l3[a], __shfl_xor(l3[a], off));
+        h3[a] = fmaxf(h3[a], __shfl_xor(h3[a], off));
+      }
+    if (lane == 0) {
+      bbox1[2 * t] = make_float4(l3[0], l3[1], l3[2], 0.f);
+      bbox1[2 * t + 1] = make_float4(h3[0], h3[1], h3[2], 0.f);
+    }
+  }
+  __threadfence_block();
+  __syncthreads();
+  for (int s2 = wv; s2 < nsuper; s2 += 16) {
+    const int t = min(s2 * 64 + lane, ntiles - 1);
+    const float4 l = bbox1[2 * t], h = bbox1[2 * t + 1];
+    float l3[3] = {l.x, l.y, l.z}, h3[3] = {h.x, h.y, h.z};
+#pragma unroll
+    for (int a = 0; a < 3; a++)
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) {
+        l3[a] = fminf(l3[a], __shfl_xor(l3[a], off));
+        h3[a] = fmaxf(h3[a], __shfl_xor(h3[a], off));
+      }
+    if (lane == 0) {
+      bbox2[2 * s2] = make_float4(l3[0], l3[1], l3[2], 0.f);
+      bbox2[2 * s2 + 1] = make_float4(h3[0], h3[1], h3[2], 0.f);
+    }
+  }
+}
+
+__device__ inline void sort_small_impl(const float4* __restrict__ pts, int n, unsigned* keysA, int* idxA, unsigned* keysB, int* idxB) {
   __shared__ unsigned hist[SMALL_WAVES][SMALL_BINS];  // per-wave digit counts, then per-wave scatter cursors
   __shared__ unsigned bin_total[SMALL_BINS];
   __shared__ float s_lo[SMALL_WAVES][3], s_hi[SMALL_WAVES][3];
@@ -361,6 +399,234 @@ __global__ __launch_bounds__(1024) void sort_small_kernel(const float4* __restri
       }
     }
     __syncthreads();  // orders this pass's global writes before the next pass's reads (same workgroup)
+  }
+}
+
+__global__ __launch_bounds__(1024) void sort_small_kernel(const float4* __restrict__ pts, int n, unsigned* keysA, int* idxA, unsigned* keysB, int* idxB) {
+  sort_small_impl(pts, n, keysA, idxA, keysB, idxB);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Small clouds, cooperative version: the same 18-bit Morton order as sort_small_kernel (identical output), but on
+// COOP_WGS workgroups that meet at grid barriers instead of one workgroup doing everything (62 us at 17k points on
+// one CU, + 10 us for the tile / super boxes). Phases: keys + digit-0 histograms | scatter 0 | digit-1 histograms |
+// scatter 1 + gather | tile boxes (bounding cube: pack_points_kernel before; super boxes: the finish kernel after); between phases every wave waits for its
+// (write-through) stores, the workgroup arrives at a monotonic counter and waits for all COOP_WGS arrivals.
+// Each wave owns a contiguous chunk of <= 128 keys (2 steps of 64), so stable order = (workgroup, wave, step, lane).
+// The per-pass scan is done redundantly by every workgroup from the 512 x COOP_WGS matrix of workgroup totals.
+// A stuck barrier (workgroups not co-resident) trips a watchdog: fewer than COOP_WGS workgroups finish and
+// sort_coop_finish_kernel, launched right behind, does the whole job on one workgroup instead.
+// ------------------------------------------------------------------------------------------------
+constexpr int COOP_WGS = 32, COOP_THREADS = 512, COOP_WAVES = COOP_THREADS / 64, COOP_STEPS = 2;
+static_assert(COOP_WGS * COOP_WAVES * COOP_STEPS * 64 >= SORT_SMALL_MAX, "every key needs a slot");
+static_assert(COOP_THREADS == SMALL_BINS, "one thread per bin in the scans");
+
+struct SortCoopState {     // zeroed by the host before every launch
+  unsigned arrivals;        // monotonic barrier counter
+  unsigned abort;
+  unsigned finished;        // workgroups that ran to the end; COOP_WGS = the cooperative kernel did the whole job
+  unsigned pad[13];
+};
+
+template <typename T> __device__ __forceinline__ void st_agent(T* p, T v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }  // write-through (sc1)
+template <typename T> __device__ __forceinline__ T ld_agent(const T* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }     // bypasses the non-coherent L2
+
+__device__ __forceinline__ bool coop_barrier(SortCoopState* st, unsigned phase, unsigned long long watchdog_ticks, int* s_flag) {
+  // no __threadfence(): a release/acquire pair at agent scope writes back and invalidates the whole L2 of the XCD at
+  // every barrier (measured: the kernel took ~100 us). Everything that crosses workgroups is stored write-through and
+  // loaded L2-bypassing instead (st_agent / ld_agent), so waiting for this wave's stores is all the release needed.
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int ok = 1;
+    atomicAdd(&st->arrivals, 1u);
+    const unsigned want = (phase + 1) * COOP_WGS;
+    const unsigned long long t0 = wall_clock64();
+    while (__hip_atomic_load(&st->arrivals, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {
+      if (__hip_atomic_load(&st->abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) || wall_clock64() - t0 > watchdog_ticks) {
+        __hip_atomic_store(&st->abort, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        ok = 0;
+        break;
+      }
+      __builtin_amdgcn_s_sleep(1);
+    }
+    *s_flag = ok;
+  }
+  __syncthreads();
+  return *s_flag != 0;
+}
+
+__global__ __launch_bounds__(COOP_THREADS) void sort_coop_kernel(const float4* __restrict__ pts, int n, unsigned* keysB, int* idxB, int* order, float4* sorted, float4* bbox1,
+                                                                const unsigned* __restrict__ box /* {~ordered(min) x3, ordered(max) x3} */, unsigned* hist /* [2][SMALL_BINS][COOP_WGS] */,
+                                                                SortCoopState* st, unsigned long long watchdog_ticks) {
+  __shared__ unsigned wh[COOP_WAVES][SMALL_BINS];  // per-wave digit counts -> exclusive prefix over the waves of this workgroup -> scatter cursors
+  __shared__ unsigned wsum[COOP_WAVES];
+  __shared__ int s_flag;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, wg = blockIdx.x;
+  const int gw = wg * COOP_WAVES + wv;  // global wave index
+  const int chunk = ((((n + COOP_WGS * COOP_WAVES - 1) / (COOP_WGS * COOP_WAVES)) + 63) & ~63);
+  const int begin = gw * chunk, end = min(n, begin + chunk);
+  const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+
+  // ---- keys (the arithmetic of sort_small_kernel); the bounding cube was reduced by pack_points_kernel when the cloud was set ----
+  float4 p[COOP_STEPS];
+#pragma unroll
+  for (int u = 0; u < COOP_STEPS; u++) {
+    const int i = begin + u * 64 + lane;
+    p[u] = (i < end) ? pts[i] : make_float4(0, 0, 0, 0);
+  }
+  const float lx = ordered_to_float(~box[0]), ly = ordered_to_float(~box[1]), lz = ordered_to_float(~box[2]);
+  const float hx = ordered_to_float(box[3]), hy = ordered_to_float(box[4]), hz = ordered_to_float(box[5]);
+  const float extent = fmaxf(fmaxf(hx - lx, hy - ly), fmaxf(hz - lz, 1e-6f));
+  const float qmax = (float)((1 << SMALL_AXIS_BITS) - 1);
+  const float scale = (qmax + 0.999f) / extent;
+  unsigned key[COOP_STEPS];
+  int id[COOP_STEPS];
+#pragma unroll
+  for (int u = 0; u < COOP_STEPS; u++) {
+    const int i = begin + u * 64 + lane;
+    const unsigned ix = (unsigned)fminf(qmax, fmaxf(0.f, (p[u].x - lx) * scale));
+    const unsigned iy = (unsigned)fminf(qmax, fmaxf(0.f, (p[u].y - ly) * scale));
+    const unsigned iz = (unsigned)fminf(qmax, fmaxf(0.f, (p[u].z - lz) * scale));
+    key[u] = (i < end) ? (spread3_8(ix) | (spread3_8(iy) << 1) | (spread3_8(iz) << 2)) : 0xFFFFFFFFu;
+    id[u] = (i < end) ? i : -1;
+  }
+
+  for (int pass = 0; pass < SMALL_PASSES; pass++) {
+    const int shift = pass * SMALL_BITS;
+    unsigned* gh = hist + (size_t)pass * SMALL_BINS * COOP_WGS;
+    if (pass > 0) {  // reload this wave's chunk in the order pass 0 produced
+#pragma unroll
+      for (int u = 0; u < COOP_STEPS; u++) {
+        const int i = begin + u * 64 + lane;
+        key[u] = (i < end) ? ld_agent(&keysB[i]) : 0xFFFFFFFFu;
+        id[u] = (i < end) ? ld_agent(&idxB[i]) : -1;
+      }
+    }
+    // per-wave digit histogram
+    for (int b = lane; b < SMALL_BINS; b += 64) wh[wv][b] = 0;
+#pragma unroll
+    for (int u = 0; u < COOP_STEPS; u++)
+      if (begin + u * 64 + lane < end) atomicAdd(&wh[wv][(key[u] >> shift) & (SMALL_BINS - 1)], 1u);
+    __syncthreads();
+    {  // thread = bin: exclusive prefix over this workgroup's waves; workgroup total -> global
+      unsigned run = 0;
+#pragma unroll
+      for (int w = 0; w < COOP_WAVES; w++) { const unsigned c = wh[w][tid]; wh[w][tid] = run; run += c; }
+      st_agent(&gh[(size_t)tid * COOP_WGS + wg], run);
+    }
+    if (!coop_barrier(st, 2 * pass, watchdog_ticks, &s_flag)) return;
+    {  // thread = bin: total over all workgroups and the part before this workgroup; then the bins are scanned
+      const unsigned long long* row = reinterpret_cast<const unsigned long long*>(gh + (size_t)tid * COOP_WGS);
+      unsigned long long v[COOP_WGS / 2];
+#pragma unroll
+      for (int j = 0; j < COOP_WGS / 2; j++) v[j] = ld_agent(&row[j]);  // independent loads, one round trip
+      unsigned total = 0, before = 0;
+#pragma unroll
+      for (int j = 0; j < COOP_WGS / 2; j++) {
+        const unsigned a = (unsigned)v[j], b = (unsigned)(v[j] >> 32);
+        total += a + b;
+        before += ((2 * j < wg) ? a : 0u) + ((2 * j + 1 < wg) ? b : 0u);
+      }
+      unsigned x = total;
+#pragma unroll
+      for (int off = 1; off < 64; off <<= 1) { const unsigned y = __shfl_up(x, off); if (lane >= off) x += y; }
+      if (lane == 63) wsum[wv] = x;
+      __syncthreads();
+      unsigned base = x - total + before;
+      for (int w = 0; w < wv; w++) base += wsum[w];
+#pragma unroll
+      for (int w = 0; w < COOP_WAVES; w++) wh[w][tid] += base;  // scatter cursor of wave w for this bin
+    }
+    __syncthreads();
+    const bool last = (pass == SMALL_PASSES - 1);
+#pragma unroll
+    for (int u = 0; u < COOP_STEPS; u++) {
+      const int i0 = begin + u * 64;
+      if (i0 >= end) break;  // wave-uniform
+      const bool valid = (i0 + lane) < end;
+      const unsigned d = (key[u] >> shift) & (SMALL_BINS - 1);
+      unsigned long long peers = __ballot(valid);
+#pragma unroll
+      for (int bit = 0; bit < SMALL_BITS; bit++) {
+        const unsigned long long m = __ballot((d >> bit) & 1);
+        peers &= ((d >> bit) & 1) ? m : ~m;
+      }
+      const int rank = __popcll(peers & lt_mask);
+      const int leader = __ffsll((long long)peers) - 1;
+      unsigned dst_base = 0;
+      if (valid && lane == leader) {
+        dst_base = wh[wv][d];
+        wh[wv][d] = dst_base + (unsigned)__popcll(peers);
+      }
+      dst_base = __shfl(dst_base, leader);
+      if (valid) {
+        const unsigned dst = dst_base + rank;
+        if (!last) {
+          st_agent(&keysB[dst], key[u]);
+          st_agent(&idxB[dst], id[u]);
+        } else {
+          st_agent(&order[dst], id[u]);
+          float4 q = pts[id[u]];
+          q.w = __int_as_float(id[u]);
+          sorted[dst] = q;
+        }
+      }
+    }
+    if (!coop_barrier(st, 2 * pass + 1, watchdog_ticks, &s_flag)) return;
+  }
+
+  // ---- boxes of the 64-point tiles, then of 64 tiles ----
+  const int ntiles = (n + 63) >> 6, nsuper = (ntiles + 63) >> 6;
+  for (int t = gw; t < ntiles; t += COOP_WGS * COOP_WAVES) {
+    const float4 q = pts[ld_agent(&order[min(t * 64 + lane, n - 1)])];  // (the sorted copy was written by other workgroups with plain stores)
+    float l3[3] = {q.x, q.y, q.z}, h3[3] = {q.x, q.y, q.z};
+#pragma unroll
+    for (int a = 0; a < 3; a++)
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) {
+        l3[a] = fminf(l3[a], __shfl_xor(l3[a], off));
+        h3[a] = fmaxf(h3[a], __shfl_xor(h3[a], off));
+      }
+    if (lane < 8) {  // 2 x float4 = 8 floats, one write-through store per lane
+      const float v8[8] = {l3[0], l3[1], l3[2], 0.f, h3[0], h3[1], h3[2], 0.f};
+      float out = v8[0];
+#pragma unroll
+      for (int c = 1; c < 8; c++) out = (lane == c) ? v8[c] : out;
+      st_agent(reinterpret_cast<float*>(bbox1 + 2 * t) + lane, out);
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (tid == 0) atomicAdd(&st->finished, 1u);  // the boxes of 64 tiles are left to sort_coop_finish_kernel (a kernel boundary is the cheapest barrier)
+}
+
+// Runs right behind sort_coop_kernel on one workgroup: normally just the <= 8 super boxes; when the cooperative kernel
+// did not finish (barrier watchdog), the whole job: same order, sorted copy and both box levels.
+__global__ __launch_bounds__(1024) void sort_coop_finish_kernel(const float4* __restrict__ pts, int n, unsigned* keysA, int* order, unsigned* keysB, int* idxB, float4* sorted,
+                                                                float4* bbox1, float4* bbox2, const SortCoopState* st) {
+  if (st->finished != COOP_WGS || st->abort) {
+    sort_small_impl(pts, n, keysA, order, keysB, idxB);
+    sort_small_tail(pts, order, n, sorted, bbox1, bbox2);
+    return;
+  }
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int ntiles = (n + 63) >> 6, nsuper = (ntiles + 63) >> 6;
+  for (int s2 = wv; s2 < nsuper; s2 += 16) {
+    const int t = min(s2 * 64 + lane, ntiles - 1);
+    const float4 l = bbox1[2 * t], h = bbox1[2 * t + 1];
+    float l3[3] = {l.x, l.y, l.z}, h3[3] = {h.x, h.y, h.z};
+#pragma unroll
+    for (int a = 0; a < 3; a++)
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) {
+        l3[a] = fminf(l3[a], __shfl_xor(l3[a], off));
+        h3[a] = fmaxf(h3[a], __shfl_xor(h3[a], off));
+      }
+    if (lane == 0) {
+      bbox2[2 * s2] = make_float4(l3[0], l3[1], l3[2], 0.f);
+      bbox2[2 * s2 + 1] = make_float4(h3[0], h3[1], h3[2], 0.f);
+    }
   }
 }
 

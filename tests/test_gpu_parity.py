@@ -264,3 +264,23 @@ def test_persistent_and_multi_launch_paths_agree(O, pair, monkeypatch):
         assert r["converged"] and r["num_linearize"] == r0["num_linearize"] and r["num_error_evals"] == r0["num_error_evals"]
         assert np.array_equal(r["T"], r0["T"]) and np.array_equal(r["H"], r0["H"])
     c.close()
+
+
+@pytest.mark.parametrize("n", [17334, 4099, 64, 20])
+def test_cooperative_sort_and_its_fallback_give_the_same_knn(O, pair, monkeypatch, n):
+    """Small clouds are Morton-sorted by a cooperative kernel (32 workgroups meeting at grid barriers) with a
+    single-workgroup kernel behind it that takes over when the barrier watchdog fires. Both routes must feed the exact
+    k-NN the same way: identical neighbour lists, equal to the oracle's."""
+    _, src = pair
+    src = np.ascontiguousarray(src[:n])
+    k = min(20, n)
+    ref = O.knn(src, k)
+    c = _core()  # the only engine alive in this process at this point -> cooperative path
+    c.set_source_cloud(src); c.find_source_neighbors(k)
+    got = c.get_neighbors("source")
+    monkeypatch.setenv("FVH_SORT_COOP_WATCHDOG_TICKS", "0")
+    c.set_source_cloud(src); c.find_source_neighbors(k)
+    got_fb = c.get_neighbors("source")
+    monkeypatch.delenv("FVH_SORT_COOP_WATCHDOG_TICKS")
+    assert np.array_equal(got, ref) and np.array_equal(got_fb, ref)
+    c.close()
