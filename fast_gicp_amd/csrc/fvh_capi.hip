@@ -51,6 +51,7 @@ struct CloudDev {
   DevBuf order;                        // Morton permutation: order[j] = original index of the j-th point along the curve
   DevBuf pts, cov, nbr, bbox, sorted;  // sorted: Morton-ordered copy, .w = original index; bbox: boxes of its 64-point tiles
   bool has_pts = false, has_cov = false, has_nbr = false, has_sorted = false;
+  bool box_dirty = false;              // box holds the cube of a cloud (cleared again by the cooperative sort that consumes it)
   void swap(CloudDev& o) { std::swap(*this, o); }
   void release() { box.release(); pts.release(); cov.release(); nbr.release(); bbox.release(); bbox2.release(); sorted.release(); order.release(); }
 };
@@ -132,7 +133,11 @@ struct Engine {
   std::vector<int> offsets_host{0, 0, 0};
   int n_off = 1;
   DevBuf sort_coop;  // SortCoopState + histograms of the cooperative small sort
-  DevBuf pticket;  // arrival counters of the persistent LM kernel (zeroed before every launch)
+  DevBuf pticket;  // arrival counters of the persistent LM kernel: monotonic, the host tracks their values in pticket_base
+  unsigned pticket_trips = 0;  // trips run since the counters were cleared (all launches since then had last_persist_blocks workgroups)
+  bool pticket_dirty = true;   // unknown counter values (first use / after an aborted launch): clear them
+  bool abort_word_dirty = false;
+  int last_persist_blocks = 0;
   DevBuf bcast;    // its broadcast rows (tagged with persist_seq, never cleared)
   unsigned long long persist_seq = 0;
   DevBuf offsets_dev, state, partials, ticket, corr, misc, fit, staging, sort_keys, sort_idx, sort_hist;
@@ -255,8 +260,10 @@ int upload_cloud(Engine* e, CloudDev& c, const float* xyz, int n, int stride, bo
   c.has_pts = true;
   c.has_sorted = false;
   if (n == 0) return FVH_OK;
+  const bool fresh_box = c.box.p == nullptr;
   HIP_OR_FAIL(e, c.box.ensure(64));
-  HIP_OR_FAIL(e, hipMemsetAsync(c.box.p, 0, 64, e->stream));
+  if (fresh_box || c.box_dirty) HIP_OR_FAIL(e, hipMemsetAsync(c.box.p, 0, 64, e->stream));  // (the cooperative sort's finish kernel leaves it cleared)
+  c.box_dirty = true;
   if (on_device) {
     pack_points_kernel<<<(n + 255) / 256, 256, 0, e->stream>>>(xyz, n, stride, c.pts.as<float4>(), c.box.as<unsigned>());
     HIP_OR_FAIL(e, hipGetLastError());
@@ -305,17 +312,19 @@ int ensure_sorted(Engine* e, CloudDev& c) {
     // gang kernels from two streams could starve each other of CU slots (the watchdog + fallback would recover, slowly)
     const bool coop = (sort_mode == 2 && g_live_engines.load() == 1) || sort_mode == 3;
     if (coop) {
+      const bool fresh = e->sort_coop.p == nullptr;
       HIP_OR_FAIL(e, e->sort_coop.ensure(sizeof(SortCoopState) + sizeof(unsigned) * 2 * SMALL_BINS * COOP_WGS));
       SortCoopState* cs = e->sort_coop.as<SortCoopState>();
       unsigned* chist = reinterpret_cast<unsigned*>(cs + 1);
-      HIP_OR_FAIL(e, hipMemsetAsync(cs, 0, sizeof(SortCoopState), e->stream));
+      if (fresh) HIP_OR_FAIL(e, hipMemsetAsync(cs, 0, sizeof(SortCoopState), e->stream));  // afterwards the finish kernel leaves it zeroed for the next sort
       unsigned long long wd = 2'000'000ull;  // 20 ms
       { const char* v = getenv("FVH_SORT_COOP_WATCHDOG_TICKS"); if (v) wd = strtoull(v, nullptr, 10); }  // test hook: 0 forces the fallback
       sort_coop_kernel<<<COOP_WGS, COOP_THREADS, 0, e->stream>>>(c.pts.as<float4>(), n, e->sort_keys.as<unsigned>() + n, e->sort_idx.as<int>(), c.order.as<int>(), c.sorted.as<float4>(),
                                                                  c.bbox.as<float4>(), c.box.as<unsigned>(), chist, cs, wd);
       // normally the super boxes only; when the cooperative kernel did not finish, one workgroup redoes everything
       sort_coop_finish_kernel<<<1, 1024, 0, e->stream>>>(c.pts.as<float4>(), n, e->sort_keys.as<unsigned>(), c.order.as<int>(), e->sort_keys.as<unsigned>() + n, e->sort_idx.as<int>(),
-                                                         c.sorted.as<float4>(), c.bbox.as<float4>(), c.bbox2.as<float4>(), cs);
+                                                         c.sorted.as<float4>(), c.bbox.as<float4>(), c.bbox2.as<float4>(), cs, c.box.as<unsigned>());
+      c.box_dirty = false;  // consumed and cleared by the finish kernel
     } else {
       sort_small_kernel<<<1, 1024, 0, e->stream>>>(c.pts.as<float4>(), n, e->sort_keys.as<unsigned>(), c.order.as<int>(), e->sort_keys.as<unsigned>() + n, e->sort_idx.as<int>());
       gather_tiles_kernel<<<(ntiles + 3) / 4, 256, 0, e->stream>>>(c.pts.as<float4>(), c.order.as<int>(), n, c.sorted.as<float4>(), c.bbox.as<float4>());
@@ -593,8 +602,17 @@ int launch_cost(Engine* e, const CostSource& src, const VoxelMapDev& vm, int hos
     P.bcast = e->bcast.as<double>();
     P.launch_tag = ++e->persist_seq;
     // abort word = 0 (the last 8 bytes of the state; never covered by the state write-back); arrival counters = 0
-    HIP_OR_FAIL(e, hipMemsetAsync(reinterpret_cast<char*>(e->state.p) + sizeof(LmState) - 8, 0, 8, e->stream));
-    HIP_OR_FAIL(e, hipMemsetAsync(e->pticket.p, 0, PERSIST_TICKET_BYTES, e->stream));
+    if (e->abort_word_dirty) {
+      HIP_OR_FAIL(e, hipMemsetAsync(reinterpret_cast<char*>(e->state.p) + sizeof(LmState) - 8, 0, 8, e->stream));
+      e->abort_word_dirty = false;
+    }
+    if (e->pticket_dirty || blocks != e->last_persist_blocks || e->pticket_trips > 1000000u) {
+      HIP_OR_FAIL(e, hipMemsetAsync(e->pticket.p, 0, PERSIST_TICKET_BYTES, e->stream));
+      e->pticket_trips = 0;
+      e->pticket_dirty = false;
+    }
+    P.trips_base = e->pticket_trips;
+    e->last_persist_blocks = blocks;
     P.ticket = e->pticket.as<unsigned>();
     ProfScope ps(e, "cost");
     if (e->precision == FVH_COMPUTE_FP32) cost_kernel<float, MODE, true><<<blocks, 256, 0, e->stream>>>(P);
@@ -696,9 +714,12 @@ int do_align(Engine* e, const CostSource& src, VoxelMapDev& vm, const double* gu
     HIP_OR_FAIL(e, hipStreamSynchronize(e->stream));
     if (h->aborted || h->phase != PH_DONE) {  // the barrier watchdog fired (workgroups not co-resident): redo with one launch per transition
       e->persist_aborts++;
+      e->pticket_dirty = true;
+      e->abort_word_dirty = true;
       return do_align<MODE>(e, src, vm, guess16, params, result, rebuild_safe, retried, true);
     }
     launched = 1;
+    e->pticket_trips += 1u + (unsigned)h->num_error_evals;  // every workgroup arrived once per trip
   }
   while (!persistent) {
     for (int s = 0; s < batch; s++) {

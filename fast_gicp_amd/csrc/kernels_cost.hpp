@@ -80,6 +80,7 @@ struct CostParams {
   int defer_lm;               // 1: multi-GPU -- only publish st->sums, LM step runs after the all-reduce
   PoseD lin, ev;              // host mode poses; device-LM first launch (init = 1): lin = initial guess
   int init;                   // 1: this is the first launch of an align -- start from P.lin and (re)initialise the LM state
+  unsigned trips_base;        // persistent kernel: trips all earlier launches of this grid size ran since the arrival counters were last cleared
   double* bcast;              // persistent kernel: [PERSIST_REPLICAS][BCAST_SLOTS] broadcast rows
   unsigned long long launch_tag;  // persistent kernel: sequence number of this launch (tags of older launches never match)
   unsigned long long watchdog_ticks;  // persistent kernel: 100 MHz ticks a workgroup may wait at the barrier before it aborts the launch
@@ -357,11 +358,9 @@ __device__ unsigned long long g_ptime[16][512][12];  // persistent kernel, per t
 #define FVH_PT_MAX(trip, k) do { } while (0)
 #endif
 
-#ifdef FVH_COST_TIMING
-#define FVH_COST_BOUNDS __launch_bounds__(256, 2)  // keep the instrumented build at the product's 2 workgroups per CU
-#else
-#define FVH_COST_BOUNDS __launch_bounds__(256)
-#endif
+// 2 workgroups per CU are part of the design (the persistent grid must be co-resident, 66 KB of LDS each): tell the
+// register allocator, which otherwise drifts over 256 VGPRs + AGPRs with small code changes and halves the grid.
+#define FVH_COST_BOUNDS __launch_bounds__(256, 2)
 template <typename Real, int MODE, bool PERSIST>
 __global__ FVH_COST_BOUNDS void cost_kernel(CostParams P) {
 #ifdef FVH_COST_TIMING
@@ -397,14 +396,21 @@ __global__ FVH_COST_BOUNDS void cost_kernel(CostParams P) {
     ev_d = (phase == PH_LINEARIZE) ? st->x0 : st->xi;
     corr_sel = st->corr_cur;
   }
+  __shared__ Pose<Real> s_pose[2];
+  if (threadIdx.x == 0) { s_pose[0] = pose_cast<Real>(lin_d); s_pose[1] = pose_cast<Real>(ev_d); }
+  __syncthreads();
   for (;;) {  // PERSIST: one trip per LM transition; otherwise exactly one trip
   if (PERSIST) FVH_PT_MIN(gen, 0);
   const bool fused = (P.host_phase < 0) && (phase == PH_TRIAL);  // trial error (old ids) + speculative linearisation at xi (new ids)
   const bool do_find = (phase == PH_LINEARIZE) || (phase == PH_FIND_ONLY) || fused;
   const bool do_cost = (phase != PH_FIND_ONLY);
   const bool do_deriv = (phase == PH_LINEARIZE) || (phase == PH_EVAL_DERIV) || fused;
-  const Pose<Real> lin = pose_cast<Real>(lin_d);   // rotation used by the cached Mahalanobis of the OLD ids
-  const Pose<Real> ev = pose_cast<Real>(ev_d);     // evaluation pose; also the linearisation pose of the NEW ids
+  // The two poses are wave-uniform: as scalars they cost 48 SGPRs for the whole main loop, and this kernel already
+  // spills hundreds of SGPRs into VGPR lanes (446 in the persistent variant, which pushed it one register past the 256
+  // VGPRs two workgroups per CU allow). They live in LDS instead and are read per element, where their registers die
+  // before the lookups start.
+  // (s_pose[0] = lin: rotation used by the cached Mahalanobis of the OLD ids; s_pose[1] = ev: evaluation pose, also the
+  // linearisation pose of the NEW ids; filled before the first trip and by the barrier code of every persistent trip)
   const Real res = (Real)P.res;
   const int n_src = P.d_n_src ? *P.d_n_src : P.n_src;
   const int n_items = n_src * P.groups_per_src;
@@ -426,6 +432,9 @@ __global__ FVH_COST_BOUNDS void cost_kernel(CostParams P) {
     float4 c0 = make_float4(0, 0, 0, 0), c1 = c0;
     if (MODE != MODE_NDT_P2D && do_cost) { c0 = P.src_cov[2 * i]; c1 = P.src_cov[2 * i + 1]; }
     const Vec3<Real> a = {(Real)a4.x, (Real)a4.y, (Real)a4.z};
+    const Pose<Real>* pose_ptr = s_pose;
+    asm volatile("" : "+v"(pose_ptr));  // opaque: the loads below stay inside the iteration instead of becoming 48 loop-invariant registers
+    const Pose<Real> lin = pose_ptr[0], ev = pose_ptr[1];
     Sym3<Real> RCR = {0, 0, 0, 0, 0, 0}, RCR_old = {0, 0, 0, 0, 0, 0};
     if (MODE != MODE_NDT_P2D && do_cost) {
       const Sym3<Real> CA = {(Real)c0.x, (Real)c0.y, (Real)c0.z, (Real)c0.w, (Real)c1.x, (Real)c1.y};
@@ -687,8 +696,9 @@ __global__ FVH_COST_BOUNDS void cost_kernel(CostParams P) {
     return;
   } else {
     // ---- persistent trip: the same two-level arrival, but nobody leaves -------------------------
-    // Counters are monotonic over the launch (the host zeroes them before it): the last arriver of a group in trip t
-    // draws gsize * (t + 1) - 1, the last group draws ngroups * (t + 1) - 1 at the top counter. That workgroup (the
+    // Counters are monotonic -- over the launch and across launches (the host passes the number of trips earlier
+    // launches ran instead of clearing them: a memset is a 3.5 us operation on the stream): with T = trips_base + t the last
+    // arriver of a group draws gsize * (T + 1) - 1, the last group draws ngroups * (T + 1) - 1 at the top counter. That workgroup (the
     // "opener") sums the <= 8 group rows, runs the LM step on the state (global memory, write-through) and BROADCASTS
     // what the next trip needs -- phase, correspondence buffer, the two poses: 26 values -- as PERSIST_REPLICAS copies
     // of a 40-double row in which every 64-byte segment is 7 values + a tag (launch sequence, trip), written by 8
@@ -707,13 +717,13 @@ __global__ FVH_COST_BOUNDS void cost_kernel(CostParams P) {
     const size_t grow0 = (size_t)MAX_PARTIAL_ROWS + (size_t)(trip & 1u) * TICKET_GROUPS;
     __shared__ double bc[BCAST_SLOTS];  // payload of the broadcast row as seen by this workgroup
     bool opener = false;
-    if (threadIdx.x == 0) s_last = (atomicAdd(&P.ticket[grp * 32], 1u) == gsize * (trip + 1) - 1);
+    if (threadIdx.x == 0) s_last = (atomicAdd(&P.ticket[grp * 32], 1u) == gsize * (P.trips_base + trip + 1) - 1);
     FVH_PT_MAX(trip, 2);
     __syncthreads();
     if (s_last) {
       reduce_group_rows(grow0 + grp);
       FVH_PT_MAX(trip, 5);
-      if (threadIdx.x == 0) s_last = (atomicAdd(&P.ticket[TICKET_GROUPS * 32], 1u) == ngroups * (trip + 1) - 1);
+      if (threadIdx.x == 0) s_last = (atomicAdd(&P.ticket[TICKET_GROUPS * 32], 1u) == ngroups * (P.trips_base + trip + 1) - 1);
       __syncthreads();
       opener = s_last != 0;
       if (opener) FVH_PT_MAX(trip, 6);
@@ -799,11 +809,14 @@ __global__ FVH_COST_BOUNDS void cost_kernel(CostParams P) {
     phase = (int)uniform_f64(bc[0]);
     if (phase == PH_DONE) return;
     corr_sel = (int)uniform_f64(bc[1]);
-#pragma unroll
-    for (int i = 0; i < 9; i++) { lin_d.r[i] = uniform_f64(bc[2 + i]); ev_d.r[i] = uniform_f64(bc[14 + i]); }
-#pragma unroll
-    for (int i = 0; i < 3; i++) { lin_d.t[i] = uniform_f64(bc[11 + i]); ev_d.t[i] = uniform_f64(bc[23 + i]); }
-    __syncthreads();  // bc[] is rewritten after the next barrier
+    // payload 2..13 = x_lin (r[9], t[3]), 14..25 = evaluation pose -> s_pose[0], s_pose[1] (every reader of the previous
+    // poses is past the barrier above)
+    if (threadIdx.x < 24) {
+      const int which = threadIdx.x / 12, k = threadIdx.x % 12;
+      const Real v = (Real)bc[2 + threadIdx.x];
+      if (k < 9) s_pose[which].r[k] = v; else s_pose[which].t[k - 9] = v;
+    }
+    __syncthreads();  // bc[] is rewritten after the next barrier; s_pose is read by the next trip
   }
   }  // trips
 }

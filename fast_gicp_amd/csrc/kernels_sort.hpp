@@ -604,8 +604,13 @@ __global__ __launch_bounds__(COOP_THREADS) void sort_coop_kernel(const float4* _
 // Runs right behind sort_coop_kernel on one workgroup: normally just the <= 8 super boxes; when the cooperative kernel
 // did not finish (barrier watchdog), the whole job: same order, sorted copy and both box levels.
 __global__ __launch_bounds__(1024) void sort_coop_finish_kernel(const float4* __restrict__ pts, int n, unsigned* keysA, int* order, unsigned* keysB, int* idxB, float4* sorted,
-                                                                float4* bbox1, float4* bbox2, const SortCoopState* st) {
-  if (st->finished != COOP_WGS || st->abort) {
+                                                                float4* bbox1, float4* bbox2, SortCoopState* st, unsigned* box) {
+  const bool redo = (st->finished != COOP_WGS) || (st->abort != 0);
+  __syncthreads();
+  // leave the barrier state and the cloud's bounding cube cleared for the next cloud (saves two memsets on the stream)
+  if (threadIdx.x < 3) reinterpret_cast<unsigned*>(st)[threadIdx.x] = 0u;
+  if (threadIdx.x >= 64 && threadIdx.x < 70) box[threadIdx.x - 64] = 0u;
+  if (redo) {
     sort_small_impl(pts, n, keysA, order, keysB, idxB);
     sort_small_tail(pts, order, n, sorted, bbox1, bbox2);
     return;
