@@ -223,6 +223,34 @@ __device__ __forceinline__ float point_box_sq(const float4& bl, const float4& bh
   return (gx * gx + gy * gy + gz * gz) * 0.99999f;  // never above the fp32-rounded exact distance
 }
 
+// (distance, index) as ONE 64-bit key: squared distances are non-negative floats, whose bit patterns order like unsigned
+// integers (+inf, the poison of out-of-range candidates, above every finite value), so the lexicographic
+// (distance, original index) order of the exact k-NN is a single u64 compare. The two-float-compare form compiled to
+// short-circuit branches on the exec mask: the 21-stage sort alone was ~470 instructions of a 999-instruction kernel
+// that is VALU-issue bound (~2,400 issued instructions per query).
+__device__ __forceinline__ unsigned long long knn_key(float d, int idx) { return ((unsigned long long)__float_as_uint(d) << 32) | (unsigned)idx; }
+__device__ __forceinline__ unsigned long long read_lane64(unsigned long long v, int l) {
+  return ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(v >> 32), l) << 32) | (unsigned)__builtin_amdgcn_readlane((int)v, l);
+}
+__device__ __forceinline__ unsigned long long wave_shr1_64(unsigned long long v) {
+  return ((unsigned long long)(unsigned)wave_shr1((int)(v >> 32), (int)(v >> 32)) << 32) | (unsigned)wave_shr1((int)v, (int)v);
+}
+__device__ __forceinline__ unsigned long long shfl_xor64(unsigned long long v, int m) {
+  return ((unsigned long long)(unsigned)__shfl_xor((int)(v >> 32), m) << 32) | (unsigned)__shfl_xor((int)v, m);
+}
+__device__ __forceinline__ void wave_bitonic_sort64(unsigned long long& key, int lane) {
+#pragma unroll
+  for (int k2 = 2; k2 <= 64; k2 <<= 1) {
+#pragma unroll
+    for (int j2 = k2 >> 1; j2 > 0; j2 >>= 1) {
+      const unsigned long long other = shfl_xor64(key, j2);
+      const bool want_min = (((lane & j2) == 0) == ((lane & k2) == 0));
+      const bool less = other < key;  // keys are unique (indices are)
+      key = (want_min == less) ? other : key;
+    }
+  }
+}
+
 // ONE query per wave (the regime is latency-chain bound, not throughput bound: measured time was
 // proportional to the queries per wave). Seed = bitonic sort of the own tile; two-level box culling
 // (super tiles of 64 tiles, then tiles); the next surviving tile is prefetched while the current one
@@ -240,31 +268,26 @@ __global__ __launch_bounds__(256) void knn_tiled1_kernel(const float4* __restric
   const float4 p0 = load_candidate(spts, (t0 << 6) + lane, n);
   const float4 pa = load_candidate(spts, (min(t0 + 1, ntiles - 1) << 6) + lane, n);
   const float4 pb = load_candidate(spts, (max(t0 - 1, 0) << 6) + lane, n);
-  float ld = sqdist_nofma(p0, qx, qy, qz);
-  int li = (((t0 << 6) + lane) < n) ? __float_as_int(p0.w) : 0x7fffffff;
-  wave_bitonic_sort(ld, li, lane);
-  float td = read_lane(ld, k - 1);
-  int ti = read_lane(li, k - 1);
+  unsigned long long lk = knn_key(sqdist_nofma(p0, qx, qy, qz), (((t0 << 6) + lane) < n) ? __float_as_int(p0.w) : 0x7fffffff);
+  wave_bitonic_sort64(lk, lane);
+  unsigned long long tk = read_lane64(lk, k - 1);  // the current k-th entry: the acceptance threshold
+  float td = __uint_as_float((unsigned)(tk >> 32));
 
   auto merge_tile = [&](const float4& p) __attribute__((always_inline)) {
-    const float d = sqdist_nofma(p, qx, qy, qz);
-    const int po = __float_as_int(p.w);
+    const unsigned long long ck = knn_key(sqdist_nofma(p, qx, qy, qz), __float_as_int(p.w));
     // exact acceptance test per lane: (d, idx) below the current k-th entry in the total order
-    unsigned long long mask = __ballot(d < td || (d == td && po < ti));
+    unsigned long long mask = __ballot(ck < tk);
     while (mask) {
       const int c = __ffsll((long long)mask) - 1;
-      const float cd = read_lane(d, c);
-      const int ci = read_lane(po, c);
-      const int pos = __popcll(__ballot(ld < cd || (ld == cd && li < ci)));
-      const float sd = wave_shr1(ld, ld);
-      const int si = wave_shr1(li, li);
-      ld = (lane > pos) ? sd : ((lane == pos) ? cd : ld);
-      li = (lane > pos) ? si : ((lane == pos) ? ci : li);
-      td = read_lane(ld, k - 1);
-      ti = read_lane(li, k - 1);
+      const unsigned long long cc = read_lane64(ck, c);
+      const int pos = __popcll(__ballot(lk < cc));
+      const unsigned long long sh = wave_shr1_64(lk);
+      lk = (lane > pos) ? sh : ((lane == pos) ? cc : lk);
+      tk = read_lane64(lk, k - 1);
       // the threshold tightened: candidates that no longer qualify leave the mask here instead of costing an iteration each
-      mask &= __ballot(d < td || (d == td && po < ti)) & ~(1ull << c);
+      mask &= __ballot(ck < tk) & ~(1ull << c);
     }
+    td = __uint_as_float((unsigned)(tk >> 32));
   };
   if (t0 + 1 < ntiles) merge_tile(pa);
   if (t0 > 0) merge_tile(pb);
@@ -300,7 +323,7 @@ __global__ __launch_bounds__(256) void knn_tiled1_kernel(const float4* __restric
       }
     }
   }
-  if (lane < k) out_idx[(size_t)__float_as_int(qv.w) * k + lane] = li;
+  if (lane < k) out_idx[(size_t)__float_as_int(qv.w) * k + lane] = (int)(unsigned)lk;
 }
 
 __device__ __forceinline__ void store_cov(float4* __restrict__ cov, int i, const Sym3<double>& C) {
