@@ -4,6 +4,11 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+// Contraction only inside one source expression (not across statements, which is hipcc's default "fast"): whether a
+// multiply and an add fuse must not depend on what the optimiser happens to see around them -- the persistent and the
+// per-transition instantiations of the cost kernel have to produce bit-identical sums.
+#pragma clang fp contract(on)
+
 namespace fvh {
 
 template <typename T>

@@ -21,6 +21,11 @@
 
 #include "dev_math.hpp"
 
+// Contraction only inside one source expression (not across statements, which is hipcc's default "fast"): whether a
+// multiply and an add fuse must not depend on what the optimiser happens to see around them -- the persistent and the
+// per-transition instantiations of the cost kernel have to produce bit-identical sums.
+#pragma clang fp contract(on)
+
 namespace fvh {
 
 constexpr int NSUM = 28;       // err(1) b(6) Hrr(6) Hrt(9) Htt(6)
