@@ -258,6 +258,7 @@ def main():
     if share_gpu:
         local_rank = 0
         os.environ.setdefault("FVH_PERSISTENT", "0")  # several processes on one GPU: their persistent grids would starve each other (the watchdog recovers, slowly)
+        os.environ.setdefault("FVH_SORT_MODE", "1")   # same for the cooperative sort
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
