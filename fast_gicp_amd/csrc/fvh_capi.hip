@@ -386,10 +386,14 @@ int find_neighbors(Engine* e, CloudDev& c, int k) {
 int calc_cov_knn(Engine* e, CloudDev& c, int method) {
   if (!c.has_pts || !c.has_nbr) return e->fail(FVH_ERR_BAD_STATE, "calculate_covariances: cloud or neighbours not set");
   if (method < 0 || method > 4) return e->fail(FVH_ERR_INVALID_ARGUMENT, "unknown regularization method");
+  if (c.k > COV_LANES * COV_MAX_PER_LANE) return e->fail(FVH_ERR_UNSUPPORTED, "calculate_covariances: more than 64 neighbours per point");
   HIP_OR_FAIL(e, c.cov.ensure(sizeof(float4) * 2 * (size_t)std::max(c.n, 1)));
   if (c.n) {
     ProfScope ps(e, "cov");
-    cov_from_neighbors_kernel<<<(c.n + 255) / 256, 256, 0, e->stream>>>(c.pts.as<float4>(), c.n, c.k, c.nbr.as<int>(), method, c.cov.as<float4>());
+    const int blocks = (int)(((long long)c.n * COV_LANES + 255) / 256);
+    if (c.k <= 20) cov_from_neighbors_kernel<5><<<blocks, 256, 0, e->stream>>>(c.pts.as<float4>(), c.n, c.k, c.nbr.as<int>(), method, c.cov.as<float4>());
+    else if (c.k <= 32) cov_from_neighbors_kernel<8><<<blocks, 256, 0, e->stream>>>(c.pts.as<float4>(), c.n, c.k, c.nbr.as<int>(), method, c.cov.as<float4>());
+    else cov_from_neighbors_kernel<16><<<blocks, 256, 0, e->stream>>>(c.pts.as<float4>(), c.n, c.k, c.nbr.as<int>(), method, c.cov.as<float4>());
   }
   HIP_OR_FAIL(e, hipGetLastError());
   c.has_cov = true;
