@@ -703,8 +703,8 @@ __global__ FVH_COST_BOUNDS void cost_kernel(CostParams P) {
     // ---- persistent trip: the same two-level arrival, but nobody leaves -------------------------
     // Counters are monotonic -- over the launch and across launches (the host passes the number of trips earlier
     // launches ran instead of clearing them: a memset is a 3.5 us operation on the stream): with T = trips_base + t the last
-    // arriver of a group draws gsize * (T + 1) - 1, the last group draws ngroups * (T + 1) - 1 at the top counter. That workgroup (the
-    // "opener") sums the <= 8 group rows, runs the LM step on the state (global memory, write-through) and BROADCASTS
+    // arriver of a group draws gsize * (T + 1) - 1 and, after reducing its group's rows, bumps the top counter. Workgroup 0
+    // (the "opener") waits for ngroups * (T + 1) there, sums the <= 8 group rows, runs the LM step and BROADCASTS
     // what the next trip needs -- phase, correspondence buffer, the two poses: 26 values -- as PERSIST_REPLICAS copies
     // of a 40-double row in which every 64-byte segment is 7 values + a tag (launch sequence, trip), written by 8
     // adjacent lanes of one store instruction. Workgroup b polls copy b % PERSIST_REPLICAS with ONE 40-lane load per
@@ -715,68 +715,80 @@ __global__ FVH_COST_BOUNDS void cost_kernel(CostParams P) {
     // same lines queue at their memory channel); every workgroup running the LM step redundantly on its own copy
     // (22.7 us per trip: the step takes 5 us instead of 1.5 when ~500 waves fetch its code at once).
     // Group rows alternate by trip parity; only the opener reads them, and trip t + 1's rows are written after every
-    // workgroup -- the opener of trip t included -- has arrived at trip t + 1.
+    // workgroup -- the opener included -- has arrived at trip t + 1.
     const unsigned trip = gen;
     const double want_tag = (double)(P.launch_tag * 4096ull + trip + 1);
     const double abort_tag = -(double)(P.launch_tag * 4096ull);  // launch-specific: a poisoned row of an older launch means nothing
     const size_t grow0 = (size_t)MAX_PARTIAL_ROWS + (size_t)(trip & 1u) * TICKET_GROUPS;
     __shared__ double bc[BCAST_SLOTS];  // payload of the broadcast row as seen by this workgroup
-    bool opener = false;
     if (threadIdx.x == 0) s_last = (atomicAdd(&P.ticket[grp * 32], 1u) == gsize * (P.trips_base + trip + 1) - 1);
     FVH_PT_MAX(trip, 2);
     __syncthreads();
     if (s_last) {
       reduce_group_rows(grow0 + grp);
       FVH_PT_MAX(trip, 5);
-      if (threadIdx.x == 0) s_last = (atomicAdd(&P.ticket[TICKET_GROUPS * 32], 1u) == ngroups * (P.trips_base + trip + 1) - 1);
+      if (threadIdx.x == 0) atomicAdd(&P.ticket[TICKET_GROUPS * 32], 1u);
       __syncthreads();
-      opener = s_last != 0;
-      if (opener) FVH_PT_MAX(trip, 6);
-      if (opener) {
-        // the state as the previous opener left it (its stores completed before it arrived at this trip's counters)
-        unsigned long long stw = 0;
-        if (trip > 0 && threadIdx.x < ST_WORDS) stw = __hip_atomic_load(&st_words[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        reduce_final(grow0);
-        if (trip > 0 && threadIdx.x < ST_WORDS) reinterpret_cast<unsigned long long*>(&s_st)[threadIdx.x] = stw;
-        __syncthreads();
-        FVH_PT_MAX(trip, 7);
-        if (trip == 0 && threadIdx.x == 0) {
-          init_state();
-          s_st.vm_num_voxels = P.vm_counters[0];
-          s_st.vm_dropped = P.vm_counters[1] + (P.vm_counters2 ? P.vm_counters2[1] : 0);
+    }
+    // The opener is always workgroup 0 (not whoever arrives last): the LM step is ~20 KB of code that runs once per
+    // trip -- on a random CU it is fetched cold every time; on a fixed CU it stays in the instruction cache, and the LM
+    // state stays in this workgroup's LDS for the whole launch instead of travelling through memory each trip.
+    const bool opener = (blockIdx.x == 0);
+    if (opener) {
+      if (threadIdx.x == 0) {  // wait for the last group (its own arrival included)
+        const unsigned want = ngroups * (P.trips_base + trip + 1);
+        const unsigned long long t0 = wall_clock64();
+        int ok = 1;
+        while (__hip_atomic_load(&P.ticket[TICKET_GROUPS * 32], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {
+          if (wall_clock64() - t0 > P.watchdog_ticks) { ok = 0; break; }
+          __builtin_amdgcn_s_sleep(1);
         }
-        if (threadIdx.x >= 64 && threadIdx.x < 64 + PART_STRIDE) s_st.sums[threadIdx.x - 64] = red[0][threadIdx.x - 64];  // (a lane each, not 32 round trips of lane 0)
-        __syncthreads();
-        FVH_PT_MAX(trip, 8);
-        if (threadIdx.x == 0) dev_lm_step(&s_st, red[0]);
-        FVH_PT_MAX(trip, 9);
-        __syncthreads();
-        if (threadIdx.x < 26) {  // payload: phase, correspondence buffer, x_lin, evaluation pose of the next trip
-          const int ph = s_st.phase;
-          const PoseD& pe = (ph == PH_LINEARIZE) ? s_st.x0 : s_st.xi;
-          const int d = threadIdx.x;
-          double v;
-          if (d == 0) v = (double)ph;
-          else if (d == 1) v = (double)s_st.corr_cur;
-          else if (d < 11) v = s_st.x_lin.r[d - 2];
-          else if (d < 14) v = s_st.x_lin.t[d - 11];
-          else if (d < 23) v = pe.r[d - 14];
-          else v = pe.t[d - 23];
-          bc[d] = v;
-        }
-        __syncthreads();
-        FVH_PT_MAX(trip, 10);
-        for (int idx = threadIdx.x; idx < PERSIST_REPLICAS * BCAST_SLOTS; idx += 256) {
-          const int slot = idx % BCAST_SLOTS, seg = slot >> 3, k = slot & 7, d = seg * 7 + k;
-          const double val = (k == 7) ? want_tag : (d < 26 ? bc[d] : 0.0);
-          __hip_atomic_store(&P.bcast[idx], val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        FVH_PT_MAX(trip, 3);
-        for (int i = threadIdx.x; i < ST_WORDS; i += 256)
-          __hip_atomic_store(&st_words[i], reinterpret_cast<const unsigned long long*>(&s_st)[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the next opener reads the state after our next arrival
+        s_last = ok;
       }
       __syncthreads();
+      if (!s_last) {  // not every workgroup is resident / something is stuck: never hang the GPU -- poison every tag and leave
+        for (int idx = threadIdx.x; idx < PERSIST_REPLICAS * BCAST_SLOTS / 8; idx += 256) __hip_atomic_store(&P.bcast[idx * 8 + 7], abort_tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (threadIdx.x == 0) __hip_atomic_store(&st->aborted, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return;
+      }
+      FVH_PT_MAX(trip, 6);
+      reduce_final(grow0);
+      __syncthreads();
+      FVH_PT_MAX(trip, 7);
+      if (trip == 0 && threadIdx.x == 0) {
+        init_state();
+        s_st.vm_num_voxels = P.vm_counters[0];
+        s_st.vm_dropped = P.vm_counters[1] + (P.vm_counters2 ? P.vm_counters2[1] : 0);
+      }
+      if (threadIdx.x >= 64 && threadIdx.x < 64 + PART_STRIDE) s_st.sums[threadIdx.x - 64] = red[0][threadIdx.x - 64];  // (a lane each, not 32 round trips of lane 0)
+      __syncthreads();
+      FVH_PT_MAX(trip, 8);
+      if (threadIdx.x == 0) dev_lm_step(&s_st, red[0]);
+      FVH_PT_MAX(trip, 9);
+      __syncthreads();
+      if (threadIdx.x < 26) {  // payload: phase, correspondence buffer, x_lin, evaluation pose of the next trip
+        const int ph = s_st.phase;
+        const PoseD& pe = (ph == PH_LINEARIZE) ? s_st.x0 : s_st.xi;
+        const int d = threadIdx.x;
+        double v;
+        if (d == 0) v = (double)ph;
+        else if (d == 1) v = (double)s_st.corr_cur;
+        else if (d < 11) v = s_st.x_lin.r[d - 2];
+        else if (d < 14) v = s_st.x_lin.t[d - 11];
+        else if (d < 23) v = pe.r[d - 14];
+        else v = pe.t[d - 23];
+        bc[d] = v;
+      }
+      __syncthreads();
+      FVH_PT_MAX(trip, 10);
+      for (int idx = threadIdx.x; idx < PERSIST_REPLICAS * BCAST_SLOTS; idx += 256) {
+        const int slot = idx % BCAST_SLOTS, seg = slot >> 3, k = slot & 7, d = seg * 7 + k;
+        const double val = (k == 7) ? want_tag : (d < 26 ? bc[d] : 0.0);
+        __hip_atomic_store(&P.bcast[idx], val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      FVH_PT_MAX(trip, 3);
+      if (s_st.phase == PH_DONE)  // the state leaves the LDS once, at the end (the kernel boundary makes it visible)
+        for (int i = threadIdx.x; i < ST_WORDS; i += 256) st_words[i] = reinterpret_cast<const unsigned long long*>(&s_st)[i];
     }
     if (!opener) {
       if (threadIdx.x < 64) {  // wave 0 polls this workgroup's copy
