@@ -1,0 +1,120 @@
+// gicp_kitti on the MI355X engine -- the reference's odometry driver (src/kitti.cpp:70-153) without the PCL visualiser:
+// frames %06d.bin (x, y, z, intensity as float32, kitti.cpp:22-69) -> ApproximateVoxelGrid 0.25 ON THE DEVICE (the raw
+// xyzi buffer goes to the GPU as it is) -> setInputSource -> align -> swapSourceAndTarget -> pose accumulation; prints the
+// running frame rate and writes the trajectory in KITTI format (12 values per line, kitti.cpp:141-153).
+//   usage: gicp_kitti /path/to/sequences/00/velodyne [ndt|vgicp|gicp] [trajectory.txt]
+#include <chrono>
+#include <cstdio>
+#include <deque>
+#include <fstream>
+#include <iostream>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "fast_gicp_amd/registration.hpp"
+
+using namespace fast_gicp;
+using Cloud = PointCloud<PointXYZ>;
+
+class KittiLoader {  // kitti.cpp:22-69
+public:
+  explicit KittiLoader(const std::string& dataset_path) : dataset_path_(dataset_path) {
+    for (num_frames_ = 0;; num_frames_++) {
+      FILE* f = std::fopen(filename(num_frames_).c_str(), "rb");
+      if (!f) break;
+      std::fclose(f);
+    }
+    if (num_frames_ == 0) std::cerr << "error: no files in " << dataset_path << std::endl;
+  }
+  size_t size() const { return num_frames_; }
+  // raw xyzi floats of frame i (the reference reads at most 1,000,000 floats per frame)
+  std::vector<float> frame(size_t i) const {
+    std::vector<float> buffer(1000000);
+    FILE* file = std::fopen(filename(i).c_str(), "rb");
+    if (!file) { std::cerr << "error: failed to load " << filename(i) << std::endl; return {}; }
+    const size_t n = std::fread(buffer.data(), sizeof(float), buffer.size(), file) / 4;
+    std::fclose(file);
+    buffer.resize(n * 4);
+    return buffer;
+  }
+
+private:
+  std::string filename(size_t i) const { char name[32]; std::snprintf(name, sizeof(name), "/%06zu.bin", i); return dataset_path_ + name; }
+  size_t num_frames_ = 0;
+  std::string dataset_path_;
+};
+
+static Cloud::Ptr downsample_on_device(fvh_voxelgrid* vg, const std::vector<float>& xyzi, float leaf) {
+  int n = 0;
+  detail::check(fvh_voxelgrid_filter_strided(vg, FVH_VOXELGRID_APPROXIMATE, xyzi.data(), (int)(xyzi.size() / 4), 4, leaf, &n), "fvh_voxelgrid_filter_strided", fvh_voxelgrid_last_error(vg));
+  std::vector<float> xyz((size_t)3 * n);
+  detail::check(fvh_voxelgrid_get_points(vg, xyz.data()), "fvh_voxelgrid_get_points", fvh_voxelgrid_last_error(vg));
+  auto cloud = std::make_shared<Cloud>();
+  cloud->points.resize(n);
+  for (int i = 0; i < n; i++) { cloud->points[i].x = xyz[3 * i]; cloud->points[i].y = xyz[3 * i + 1]; cloud->points[i].z = xyz[3 * i + 2]; }
+  return cloud;
+}
+
+int main(int argc, char** argv) {
+  if (argc < 2) {
+    std::cout << "usage: gicp_kitti /your/kitti/path/sequences/00/velodyne [ndt|vgicp|gicp] [trajectory.txt]" << std::endl;
+    return 0;
+  }
+  const std::string method = argc > 2 ? argv[2] : "gicp";  // the reference's default is FastGICP (kitti.cpp:85)
+  const std::string traj_path = argc > 3 ? argv[3] : "/tmp/traj.txt";
+  KittiLoader kitti(argv[1]);
+  if (kitti.size() == 0) return 1;
+
+  const float downsample_resolution = 0.25f;  // kitti.cpp:79
+  fvh_voxelgrid* vg = nullptr;
+  detail::check(fvh_voxelgrid_create(0, &vg), "fvh_voxelgrid_create", "cannot create the HIP engine (no GPU? there is no CPU fallback)");
+
+  std::shared_ptr<LsqRegistration<PointXYZ, PointXYZ>> reg;
+  if (method == "ndt") {
+    auto ndt = std::make_shared<NDTCuda<PointXYZ, PointXYZ>>();
+    ndt->setResolution(1.0);  // kitti.cpp:89-90
+    reg = ndt;
+  } else if (method == "vgicp") {
+    auto vgicp = std::make_shared<FastVGICPCuda<PointXYZ, PointXYZ>>();
+    vgicp->setResolution(1.0);
+    vgicp->setNearestNeighborSearchMethod(NearestNeighborMethod::GPU_BRUTEFORCE);
+    reg = vgicp;
+  } else {
+    auto gicp = std::make_shared<FastGICP<PointXYZ, PointXYZ>>();
+    gicp->setMaxCorrespondenceDistance(1.0);  // kitti.cpp:92
+    reg = gicp;
+  }
+
+  // set initial frame as target (kitti.cpp:95-99)
+  reg->setInputTarget(downsample_on_device(vg, kitti.frame(0), downsample_resolution));
+  std::vector<Isometry3d> poses(kitti.size());
+  poses[0] = Isometry3d::Identity();
+  std::deque<std::chrono::high_resolution_clock::time_point> stamps;  // boost::circular_buffer(30) in the reference
+  stamps.push_back(std::chrono::high_resolution_clock::now());
+
+  for (size_t i = 1; i < kitti.size(); i++) {
+    // set the current frame as source, align, swap for the next registration (kitti.cpp:115-125)
+    reg->setInputSource(downsample_on_device(vg, kitti.frame(i), downsample_resolution));
+    Cloud aligned;
+    reg->align(aligned);
+    reg->swapSourceAndTarget();
+    poses[i] = poses[i - 1] * Isometry3d::from(reg->getFinalTransformation());  // accumulate pose (kitti.cpp:128)
+    stamps.push_back(std::chrono::high_resolution_clock::now());
+    if (stamps.size() > 30) stamps.pop_front();
+    std::cout << stamps.size() / (std::chrono::duration_cast<std::chrono::nanoseconds>(stamps.back() - stamps.front()).count() / 1e9) << "fps" << std::endl;
+  }
+  fvh_voxelgrid_destroy(vg);
+
+  std::ofstream ofs(traj_path);  // kitti.cpp:141-153
+  ofs.precision(9);
+  for (const auto& pose : poses) {
+    for (int i = 0; i < 3; i++)
+      for (int j = 0; j < 4; j++) {
+        if (i || j) ofs << " ";
+        ofs << (j < 3 ? pose.R[i * 3 + j] : pose.t[i]);
+      }
+    ofs << std::endl;
+  }
+  return 0;
+}

@@ -42,8 +42,23 @@ def build_align(force=False):
     return ALIGN_BIN
 
 
+KITTI_SRC = os.path.join(os.path.dirname(ALIGN_SRC), "gicp_kitti.cpp")
+KITTI_BIN = os.path.join(os.path.dirname(ALIGN_BIN), "gicp_kitti")
+
+
+def build_kitti(force=False):
+    if not os.path.exists(KITTI_SRC):
+        return None
+    _build.build_lib()
+    if not force and not _stale(KITTI_BIN, [KITTI_SRC] + HEADERS):
+        return KITTI_BIN
+    cmd = ["g++", "-O2", "-std=c++17", "-fopenmp", "-ffp-contract=off", "-I", INCLUDE, KITTI_SRC, "-o", KITTI_BIN, "-L", _build.LIB_DIR, "-lfast_vgicp_hip", "-Wl,-rpath,$ORIGIN/../lib"]
+    subprocess.check_call(cmd)
+    return KITTI_BIN
+
+
 def build_all(force=False):
-    return [build_pygicp(force), build_align(force)]
+    return [build_pygicp(force), build_align(force), build_kitti(force)]
 
 
 if __name__ == "__main__":

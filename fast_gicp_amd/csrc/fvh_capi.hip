@@ -268,10 +268,10 @@ int upload_cloud(Engine* e, CloudDev& c, const float* xyz, int n, int stride, bo
     pack_points_kernel<<<(n + 255) / 256, 256, 0, e->stream>>>(xyz, n, stride, c.pts.as<float4>(), c.box.as<unsigned>());
     HIP_OR_FAIL(e, hipGetLastError());
   } else {
-    // H2D the packed xyz into a staging buffer, then widen to float4 on device
-    HIP_OR_FAIL(e, e->staging.ensure(sizeof(float) * 3 * (size_t)n));
-    HIP_OR_FAIL(e, hipMemcpyAsync(e->staging.p, xyz, sizeof(float) * 3 * (size_t)n, hipMemcpyHostToDevice, e->stream));
-    pack_points_kernel<<<(n + 255) / 256, 256, 0, e->stream>>>(e->staging.as<float>(), n, 3, c.pts.as<float4>(), c.box.as<unsigned>());
+    // H2D the xyz (stride 3) / xyzi (stride 4, e.g. a KITTI .bin buffer) array into a staging buffer, then widen to float4 on device
+    HIP_OR_FAIL(e, e->staging.ensure(sizeof(float) * stride * (size_t)n));
+    HIP_OR_FAIL(e, hipMemcpyAsync(e->staging.p, xyz, sizeof(float) * stride * (size_t)n, hipMemcpyHostToDevice, e->stream));
+    pack_points_kernel<<<(n + 255) / 256, 256, 0, e->stream>>>(e->staging.as<float>(), n, stride, c.pts.as<float4>(), c.box.as<unsigned>());
     HIP_OR_FAIL(e, hipGetLastError());
     HIP_OR_FAIL(e, hipStreamSynchronize(e->stream));  // caller may free xyz on return (reference copies too)
   }
@@ -1380,6 +1380,7 @@ int fvh_voxelgrid_destroy(fvh_voxelgrid* h) {
 }
 const char* fvh_voxelgrid_last_error(const fvh_voxelgrid* h) { return h ? h->e.err.c_str() : "null handle"; }
 int fvh_voxelgrid_filter(fvh_voxelgrid* h, int method, const float* xyz, int n, float leaf, int* out_n) { CHECK_HANDLE(h); return downsample(&h->e, h->d, method, xyz, n, 3, false, leaf, out_n); }
+int fvh_voxelgrid_filter_strided(fvh_voxelgrid* h, int method, const float* xyz, int n, int stride, float leaf, int* out_n) { CHECK_HANDLE(h); return downsample(&h->e, h->d, method, xyz, n, stride, false, leaf, out_n); }
 int fvh_voxelgrid_filter_device(fvh_voxelgrid* h, int method, const float* d_xyz, int n, int stride, float leaf, int* out_n) { CHECK_HANDLE(h); return downsample(&h->e, h->d, method, d_xyz, n, stride, true, leaf, out_n); }
 int fvh_voxelgrid_get_points(fvh_voxelgrid* h, float* out_xyz) {
   CHECK_HANDLE(h);

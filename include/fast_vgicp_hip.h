@@ -209,6 +209,7 @@ int fvh_voxelgrid_create(int device, fvh_voxelgrid** out);
 int fvh_voxelgrid_destroy(fvh_voxelgrid* h);
 const char* fvh_voxelgrid_last_error(const fvh_voxelgrid* h);
 int fvh_voxelgrid_filter(fvh_voxelgrid* h, int method, const float* xyz, int n, float leaf, int* out_n);                       /* setLeafSize(l,l,l); setInputCloud; filter */
+int fvh_voxelgrid_filter_strided(fvh_voxelgrid* h, int method, const float* xyz, int n, int stride_floats /* 3, or 4 for xyzi (KITTI .bin, kitti.cpp:48-60) */, float leaf, int* out_n);
 int fvh_voxelgrid_filter_device(fvh_voxelgrid* h, int method, const float* d_xyz, int n, int stride_floats, float leaf, int* out_n);
 int fvh_voxelgrid_get_points(fvh_voxelgrid* h, float* out_xyz /* host or device, 3*out_n floats */);
 int fvh_voxelgrid_device_points(fvh_voxelgrid* h, const float** d_xyz, int* n);
