@@ -132,6 +132,7 @@ struct Engine {
   int precision = FVH_COMPUTE_FP64;
   std::vector<int> offsets_host{0, 0, 0};
   int n_off = 1;
+  DevBuf fit_best;   // squared nearest-neighbour distance per source point (fitness score)
   DevBuf sort_coop;  // SortCoopState + histograms of the cooperative small sort
   DevBuf pticket;  // arrival counters of the persistent LM kernel: monotonic, the host tracks their values in pticket_base
   unsigned pticket_trips = 0;  // trips run since the counters were cleared (all launches since then had last_persist_blocks workgroups)
@@ -190,7 +191,7 @@ struct Engine {
     if (comm && g_rccl.CommDestroy) g_rccl.CommDestroy(comm);
     comm = nullptr;
     prof.destroy();
-    sort_coop.release(); pticket.release(); bcast.release(); offsets_dev.release(); state.release(); partials.release(); ticket.release(); corr.release(); misc.release(); fit.release(); staging.release(); sort_keys.release(); sort_idx.release(); sort_hist.release();
+    fit_best.release(); sort_coop.release(); pticket.release(); bcast.release(); offsets_dev.release(); state.release(); partials.release(); ticket.release(); corr.release(); misc.release(); fit.release(); staging.release(); sort_keys.release(); sort_idx.release(); sort_hist.release();
     if (pinned) (void)hipHostFree(pinned);
     if (stream) (void)hipStreamDestroy(stream);
   }
@@ -785,11 +786,17 @@ int do_fitness(Engine* e, CloudDev& src, CloudDev& tgt, const double* T16, doubl
   {
     ProfScope ps(e, "fitness");
     const int waves = (src.n + FIT_Q - 1) / FIT_Q;
-    if (fit_mode == 0)
+    if (fit_mode == 0) {
       fitness_kernel<<<(waves + 3) / 4, 256, 0, e->stream>>>(src.pts.as<float4>(), src.n, tgt.pts.as<float4>(), tgt.n, (const float*)(base + 16), max_range, (double*)base);
-    else
+    } else if (fit_mode == 2) {
       fitness_tiled_kernel<<<(waves + 3) / 4, 256, 0, e->stream>>>(src.sorted.as<float4>(), src.n, tgt.sorted.as<float4>(), tgt.bbox.as<float4>(), tgt.n, (const float*)(base + 16), max_range,
                                                                     (double*)base);
+    } else {  // one query per wave (the k = 1 search of the GICP path), then a fixed-order reduction
+      HIP_OR_FAIL(e, e->fit_best.ensure(sizeof(float) * (size_t)src.n));
+      nn1_corr_kernel<<<(src.n + 3) / 4, 256, 0, e->stream>>>(src.sorted.as<float4>(), src.n, tgt.sorted.as<float4>(), tgt.bbox.as<float4>(), tgt.bbox2.as<float4>(), tgt.n,
+                                                              (const float*)(base + 16), 0.0, nullptr, e->fit_best.as<float>());
+      fitness_reduce_kernel<<<1, 1024, 0, e->stream>>>(e->fit_best.as<float>(), src.n, max_range, (double*)base);
+    }
   }
   HIP_OR_FAIL(e, hipGetLastError());
   double out[2];

@@ -699,7 +699,8 @@ __global__ __launch_bounds__(256) void nn_corr_tiled_kernel(const float4* __rest
 // Seed = nearest tile by box distance through the two box levels, then every tile whose box can still hold a point at
 // least as near (ties resolve to the lower original index).
 __global__ __launch_bounds__(256) void nn1_corr_kernel(const float4* __restrict__ ssrc, int ns, const float4* __restrict__ stgt, const float4* __restrict__ bbox1,
-                                                       const float4* __restrict__ bbox2, int nt, const float* __restrict__ T12, double thr_sq, int* __restrict__ corr) {
+                                                       const float4* __restrict__ bbox2, int nt, const float* __restrict__ T12, double thr_sq, int* __restrict__ corr,
+                                                       float* __restrict__ best_out = nullptr /* getFitnessScore: squared NN distance per query, in the order of ssrc */) {
   const int lane = threadIdx.x & 63;
   const int q = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (q >= ns) return;
@@ -778,7 +779,32 @@ __global__ __launch_bounds__(256) void nn1_corr_kernel(const float4* __restrict_
       }
     }
   }
-  if (lane == 0) corr[__float_as_int(qv.w)] = ((double)best < thr_sq) ? besti : -1;
+  if (lane == 0) {
+    if (corr) corr[__float_as_int(qv.w)] = ((double)best < thr_sq) ? besti : -1;
+    if (best_out) best_out[q] = best;
+  }
+}
+
+// pcl::Registration::getFitnessScore: mean of the squared nearest-neighbour distances not above max_range. One workgroup,
+// fixed summation order (thread t sums entries t, t + 1024, ... in fp64, then a fixed tree): bit-reproducible, unlike
+// per-wave atomics. out[0] = sum, out[1] = count.
+__global__ __launch_bounds__(1024) void fitness_reduce_kernel(const float* __restrict__ best, int n, double max_range, double* __restrict__ out) {
+  __shared__ double s_sum[16], s_cnt[16];
+  double sum = 0.0, cnt = 0.0;
+  for (int i = threadIdx.x; i < n; i += 1024) {
+    const double d = (double)best[i];
+    if (d <= max_range) { sum += d; cnt += 1.0; }
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) { sum += __shfl_xor(sum, off); cnt += __shfl_xor(cnt, off); }
+  if ((threadIdx.x & 63) == 0) { s_sum[threadIdx.x >> 6] = sum; s_cnt[threadIdx.x >> 6] = cnt; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double a = 0.0, c = 0.0;
+    for (int w = 0; w < 16; w++) { a += s_sum[w]; c += s_cnt[w]; }
+    out[0] = a;
+    out[1] = c;
+  }
 }
 
 // One 64-byte record per target point in the layout of a voxel bucket ({key (unused), q1 = point + count 1, q2/q3 =
