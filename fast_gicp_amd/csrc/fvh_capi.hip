@@ -135,7 +135,7 @@ struct Engine {
   DevBuf fit_best;   // squared nearest-neighbour distance per source point (fitness score)
   DevBuf sort_coop;  // SortCoopState + histograms of the cooperative small sort
   DevBuf pticket;  // arrival counters of the persistent LM kernel: monotonic, the host tracks their values in pticket_base
-  unsigned pticket_trips = 0;  // trips run since the counters were cleared (all launches since then had last_persist_blocks workgroups)
+  unsigned pticket_base[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};  // where the 8 group counters + the top counter stand
   bool pticket_dirty = true;   // unknown counter values (first use / after an aborted launch): clear them
   bool abort_word_dirty = false;
   int last_persist_blocks = 0;
@@ -611,12 +611,13 @@ int launch_cost(Engine* e, const CostSource& src, const VoxelMapDev& vm, int hos
       HIP_OR_FAIL(e, hipMemsetAsync(reinterpret_cast<char*>(e->state.p) + sizeof(LmState) - 8, 0, 8, e->stream));
       e->abort_word_dirty = false;
     }
-    if (e->pticket_dirty || blocks != e->last_persist_blocks || e->pticket_trips > 1000000u) {
+    if (e->pticket_dirty || e->pticket_base[TICKET_GROUPS] > 0x70000000u) {
       HIP_OR_FAIL(e, hipMemsetAsync(e->pticket.p, 0, PERSIST_TICKET_BYTES, e->stream));
-      e->pticket_trips = 0;
+      std::memset(e->pticket_base, 0, sizeof(e->pticket_base));
       e->pticket_dirty = false;
     }
-    P.trips_base = e->pticket_trips;
+    P.tb0 = e->pticket_base[0]; P.tb1 = e->pticket_base[1]; P.tb2 = e->pticket_base[2]; P.tb3 = e->pticket_base[3]; P.tb4 = e->pticket_base[4];
+    P.tb5 = e->pticket_base[5]; P.tb6 = e->pticket_base[6]; P.tb7 = e->pticket_base[7]; P.tb_top = e->pticket_base[8];
     e->last_persist_blocks = blocks;
     P.ticket = e->pticket.as<unsigned>();
     ProfScope ps(e, "cost");
@@ -724,7 +725,11 @@ int do_align(Engine* e, const CostSource& src, VoxelMapDev& vm, const double* gu
       return do_align<MODE>(e, src, vm, guess16, params, result, rebuild_safe, retried, true);
     }
     launched = 1;
-    e->pticket_trips += 1u + (unsigned)h->num_error_evals;  // every workgroup arrived once per trip
+    {  // where the arrival counters stand now: every workgroup arrived once per trip, every group's last arriver bumped the top counter
+      const unsigned trips = 1u + (unsigned)h->num_error_evals, B = (unsigned)e->last_persist_blocks;
+      for (unsigned g = 0; g < (unsigned)TICKET_GROUPS; g++) e->pticket_base[g] += (g < B ? (B - g + TICKET_GROUPS - 1) / TICKET_GROUPS : 0u) * trips;
+      e->pticket_base[TICKET_GROUPS] += std::min((unsigned)TICKET_GROUPS, B) * trips;
+    }
   }
   while (!persistent) {
     for (int s = 0; s < batch; s++) {

@@ -85,7 +85,9 @@ struct CostParams {
   int defer_lm;               // 1: multi-GPU -- only publish st->sums, LM step runs after the all-reduce
   PoseD lin, ev;              // host mode poses; device-LM first launch (init = 1): lin = initial guess
   int init;                   // 1: this is the first launch of an align -- start from P.lin and (re)initialise the LM state
-  unsigned trips_base;        // persistent kernel: trips all earlier launches of this grid size ran since the arrival counters were last cleared
+  // persistent kernel: values of the 8 group counters + the top counter when this launch starts (they are not cleared between
+  // launches). Separate scalars, not an array: an indexed kernel-argument array is copied to scratch memory.
+  unsigned tb0, tb1, tb2, tb3, tb4, tb5, tb6, tb7, tb_top;
   double* bcast;              // persistent kernel: [PERSIST_REPLICAS][BCAST_SLOTS] broadcast rows
   unsigned long long launch_tag;  // persistent kernel: sequence number of this launch (tags of older launches never match)
   unsigned long long watchdog_ticks;  // persistent kernel: 100 MHz ticks a workgroup may wait at the barrier before it aborts the launch
@@ -701,10 +703,10 @@ __global__ FVH_COST_BOUNDS void cost_kernel(CostParams P) {
     return;
   } else {
     // ---- persistent trip: the same two-level arrival, but nobody leaves -------------------------
-    // Counters are monotonic -- over the launch and across launches (the host passes the number of trips earlier
-    // launches ran instead of clearing them: a memset is a 3.5 us operation on the stream): with T = trips_base + t the last
-    // arriver of a group draws gsize * (T + 1) - 1 and, after reducing its group's rows, bumps the top counter. Workgroup 0
-    // (the "opener") waits for ngroups * (T + 1) there, sums the <= 8 group rows, runs the LM step and BROADCASTS
+    // Counters are monotonic -- over the launch and across launches (the host passes their starting values instead
+    // of clearing them: a memset is a 3.5 us operation on the stream): in trip t the last arriver of a group draws
+    // tbase + gsize * (t + 1) - 1 and, after reducing its group's rows, bumps the top counter. Workgroup 0 (the "opener")
+    // waits for tbase + ngroups * (t + 1) there, sums the <= 8 group rows, runs the LM step and BROADCASTS
     // what the next trip needs -- phase, correspondence buffer, the two poses: 26 values -- as PERSIST_REPLICAS copies
     // of a 40-double row in which every 64-byte segment is 7 values + a tag (launch sequence, trip), written by 8
     // adjacent lanes of one store instruction. Workgroup b polls copy b % PERSIST_REPLICAS with ONE 40-lane load per
@@ -721,7 +723,9 @@ __global__ FVH_COST_BOUNDS void cost_kernel(CostParams P) {
     const double abort_tag = -(double)(P.launch_tag * 4096ull);  // launch-specific: a poisoned row of an older launch means nothing
     const size_t grow0 = (size_t)MAX_PARTIAL_ROWS + (size_t)(trip & 1u) * TICKET_GROUPS;
     __shared__ double bc[BCAST_SLOTS];  // payload of the broadcast row as seen by this workgroup
-    if (threadIdx.x == 0) s_last = (atomicAdd(&P.ticket[grp * 32], 1u) == gsize * (P.trips_base + trip + 1) - 1);
+    static_assert(TICKET_GROUPS == 8, "tb0..tb7");
+    const unsigned tb = grp == 0 ? P.tb0 : grp == 1 ? P.tb1 : grp == 2 ? P.tb2 : grp == 3 ? P.tb3 : grp == 4 ? P.tb4 : grp == 5 ? P.tb5 : grp == 6 ? P.tb6 : P.tb7;
+    if (threadIdx.x == 0) s_last = (atomicAdd(&P.ticket[grp * 32], 1u) == tb + gsize * (trip + 1) - 1);
     FVH_PT_MAX(trip, 2);
     __syncthreads();
     if (s_last) {
@@ -736,7 +740,7 @@ __global__ FVH_COST_BOUNDS void cost_kernel(CostParams P) {
     const bool opener = (blockIdx.x == 0);
     if (opener) {
       if (threadIdx.x == 0) {  // wait for the last group (its own arrival included)
-        const unsigned want = ngroups * (P.trips_base + trip + 1);
+        const unsigned want = P.tb_top + ngroups * (trip + 1);
         const unsigned long long t0 = wall_clock64();
         int ok = 1;
         while (__hip_atomic_load(&P.ticket[TICKET_GROUPS * 32], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {
