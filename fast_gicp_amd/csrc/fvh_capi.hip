@@ -59,7 +59,10 @@ struct CloudDev {
 // Clouds of this size and up are walked in Morton order (PMC: 2.8x HBM over-fetch on a randomly ordered 100k scan
 // against a 1M-point map). Below it everything is L2-resident and the extra index load is not worth it.
 constexpr int COHERENT_MIN_POINTS = 32768;
-inline const int* coherent_order(const CloudDev& c) { return (c.has_sorted && c.n >= COHERENT_MIN_POINTS) ? c.order.as<int>() : nullptr; }
+inline const int* coherent_order(const CloudDev& c) {
+  static const int min_pts = [] { const char* v = getenv("FVH_COHERENT_MIN_POINTS"); return v ? atoi(v) : COHERENT_MIN_POINTS; }();
+  return (c.has_sorted && c.n >= min_pts) ? c.order.as<int>() : nullptr;
+}
 
 struct VoxelMapDev {
   double res = 1.0;

@@ -430,6 +430,8 @@ __global__ FVH_COST_BOUNDS void cost_kernel(CostParams P) {
   double acc_y = 0.0;  // fused: trial error with the old ids
 
   const float4* tf = reinterpret_cast<const float4*>(P.table);
+  // (consecutive threads take consecutive items on purpose: spreading a workgroup's items over the cloud made the launch
+  // 24 % slower -- the loop is sensitive to how many distinct cache lines a wave touches)
   for (int w = blockIdx.x * 256 + threadIdx.x; w < n_items; w += gridDim.x * 256) {
     const int i0 = w / P.groups_per_src;
     const int g = w - i0 * P.groups_per_src;
