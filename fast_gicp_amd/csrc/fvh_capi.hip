@@ -142,10 +142,13 @@ struct Engine {
   bool pticket_dirty = true;   // unknown counter values (first use / after an aborted launch): clear them
   bool abort_word_dirty = false;
   int last_persist_blocks = 0;
+  bool zero_copy_armed = false;  // the last persistent launch writes its result to result_host
   DevBuf bcast;    // its broadcast rows (tagged with persist_seq, never cleared)
   unsigned long long persist_seq = 0;
   DevBuf offsets_dev, state, partials, ticket, corr, misc, fit, staging, sort_keys, sort_idx, sort_hist;
   void* pinned = nullptr;  // sizeof(LmState) + slack
+  void* result_host = nullptr;            // mapped pinned memory the persistent kernel writes the final state + a sequence word to
+  unsigned long long* result_dev = nullptr;  // its device address
   PoseD lin;               // pose of the last update_correspondences()
   bool has_corr = false;
   int corr_kind = 0;       // 0: voxel correspondences (VGICP / NDT), 1: nearest-point correspondences (GICP)
@@ -166,6 +169,12 @@ struct Engine {
     if (e != hipSuccess) return hipfail(e, "hipSetDevice");
     if ((e = hipStreamCreateWithFlags(&stream, hipStreamNonBlocking)) != hipSuccess) return hipfail(e, "hipStreamCreate");
     if ((e = hipHostMalloc(&pinned, sizeof(LmState) + 1024, hipHostMallocDefault)) != hipSuccess) return hipfail(e, "hipHostMalloc");
+    if (hipHostMalloc(&result_host, sizeof(LmState) + 64, hipHostMallocMapped) == hipSuccess) {
+      std::memset(result_host, 0, sizeof(LmState) + 64);
+      void* dp = nullptr;
+      if (hipHostGetDevicePointer(&dp, result_host, 0) == hipSuccess) result_dev = reinterpret_cast<unsigned long long*>(dp);
+    }
+    (void)hipGetLastError();  // zero-copy results are optional
     if ((e = state.ensure(sizeof(LmState))) != hipSuccess) return hipfail(e, "hipMalloc");
     if ((e = partials.ensure(sizeof(double) * PART_STRIDE * (MAX_COST_BLOCKS + 2 * TICKET_GROUPS))) != hipSuccess) return hipfail(e, "hipMalloc");
     if ((e = ticket.ensure(64)) != hipSuccess) return hipfail(e, "hipMalloc");
@@ -196,6 +205,7 @@ struct Engine {
     prof.destroy();
     fit_best.release(); sort_coop.release(); pticket.release(); bcast.release(); offsets_dev.release(); state.release(); partials.release(); ticket.release(); corr.release(); misc.release(); fit.release(); staging.release(); sort_keys.release(); sort_idx.release(); sort_hist.release();
     if (pinned) (void)hipHostFree(pinned);
+    if (result_host) (void)hipHostFree(result_host);
     if (stream) (void)hipStreamDestroy(stream);
   }
   int upload_offsets() {
@@ -607,6 +617,9 @@ int launch_cost(Engine* e, const CostSource& src, const VoxelMapDev& vm, int hos
     if (cap <= 0) return e->fail(FVH_ERR_HIP, "persistent cost kernel: occupancy query failed");
     blocks = std::min(blocks, cap);
     { const char* v = getenv("FVH_PERSIST_WATCHDOG_TICKS"); P.watchdog_ticks = v ? strtoull(v, nullptr, 10) : PERSIST_WATCHDOG_TICKS; }  // test hook: 0 forces the abort + fallback path
+    static const int zc = [] { const char* v = getenv("FVH_ZEROCOPY_RESULT"); return v ? atoi(v) : 1; }();
+    P.result_host = (zc && !e->prof.on) ? e->result_dev : nullptr;  // (event profiling needs the stream drained anyway)
+    e->zero_copy_armed = P.result_host != nullptr;
     P.bcast = e->bcast.as<double>();
     P.launch_tag = ++e->persist_seq;
     // abort word = 0 (the last 8 bytes of the state; never covered by the state write-back); arrival counters = 0
@@ -719,8 +732,25 @@ int do_align(Engine* e, const CostSource& src, VoxelMapDev& vm, const double* gu
   if (persistent) {
     int rc = launch_cost<MODE>(e, src, vm, -1, &guess, nullptr, &p, true);
     if (rc) return rc;
-    HIP_OR_FAIL(e, hipMemcpyAsync(h, st, sizeof(LmState), hipMemcpyDeviceToHost, e->stream));
-    HIP_OR_FAIL(e, hipStreamSynchronize(e->stream));
+    bool have_result = false;
+    if (e->result_dev && e->zero_copy_armed) {
+      // spin on the sequence word the kernel writes after the state (mapped pinned memory); if the stream drains without it
+      // (watchdog abort) fall through to the copy
+      volatile unsigned long long* seq = reinterpret_cast<volatile unsigned long long*>(e->result_host) + sizeof(LmState) / 8;
+      for (unsigned long long spins = 0;; spins++) {
+        if (*seq == e->persist_seq) { have_result = true; break; }
+        if ((spins & 0x3ff) == 0x3ff && hipStreamQuery(e->stream) == hipSuccess) { have_result = (*seq == e->persist_seq); break; }
+      }
+      if (have_result) {
+        std::atomic_thread_fence(std::memory_order_acquire);
+        std::memcpy(h, e->result_host, sizeof(LmState) - 8);
+        h->gen = 0; h->aborted = 0;
+      }
+    }
+    if (!have_result) {
+      HIP_OR_FAIL(e, hipMemcpyAsync(h, st, sizeof(LmState), hipMemcpyDeviceToHost, e->stream));
+      HIP_OR_FAIL(e, hipStreamSynchronize(e->stream));
+    }
     if (h->aborted || h->phase != PH_DONE) {  // the barrier watchdog fired (workgroups not co-resident): redo with one launch per transition
       e->persist_aborts++;
       e->pticket_dirty = true;

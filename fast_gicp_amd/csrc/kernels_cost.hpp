@@ -90,6 +90,7 @@ struct CostParams {
   unsigned tb0, tb1, tb2, tb3, tb4, tb5, tb6, tb7, tb_top;
   double* bcast;              // persistent kernel: [PERSIST_REPLICAS][BCAST_SLOTS] broadcast rows
   unsigned long long launch_tag;  // persistent kernel: sequence number of this launch (tags of older launches never match)
+  unsigned long long* result_host;  // persistent kernel: mapped pinned host memory, [sizeof(LmState)/8 words of state][sequence word] (null: not used)
   unsigned long long watchdog_ticks;  // persistent kernel: 100 MHz ticks a workgroup may wait at the barrier before it aborts the launch
   int max_iterations, lm_max_iterations;
   double rotation_epsilon, transformation_epsilon, lm_init_lambda_factor;
@@ -793,8 +794,18 @@ __global__ FVH_COST_BOUNDS void cost_kernel(CostParams P) {
         __hip_atomic_store(&P.bcast[idx], val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
       FVH_PT_MAX(trip, 3);
-      if (s_st.phase == PH_DONE)  // the state leaves the LDS once, at the end (the kernel boundary makes it visible)
+      if (s_st.phase == PH_DONE) {  // the state leaves the LDS once, at the end (the kernel boundary makes it visible)
         for (int i = threadIdx.x; i < ST_WORDS; i += 256) st_words[i] = reinterpret_cast<const unsigned long long*>(&s_st)[i];
+        if (P.result_host) {
+          // ... and goes straight to the host through mapped pinned memory: the caller spins on the sequence word instead of
+          // paying a device-to-host copy kernel and a stream synchronisation (~8 us of a 300 us registration)
+          for (int i = threadIdx.x; i < ST_WORDS; i += 256)
+            __hip_atomic_store(&P.result_host[i], reinterpret_cast<const unsigned long long*>(&s_st)[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          __syncthreads();
+          if (threadIdx.x == 0) __hip_atomic_store(&P.result_host[ST_WORDS + 1], P.launch_tag, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+      }
     }
     if (!opener) {
       if (threadIdx.x < 64) {  // wave 0 polls this workgroup's copy
