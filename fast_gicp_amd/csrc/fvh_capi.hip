@@ -169,7 +169,7 @@ struct Engine {
     if (e != hipSuccess) return hipfail(e, "hipSetDevice");
     if ((e = hipStreamCreateWithFlags(&stream, hipStreamNonBlocking)) != hipSuccess) return hipfail(e, "hipStreamCreate");
     if ((e = hipHostMalloc(&pinned, sizeof(LmState) + 1024, hipHostMallocDefault)) != hipSuccess) return hipfail(e, "hipHostMalloc");
-    if (hipHostMalloc(&result_host, sizeof(LmState) + 64, hipHostMallocMapped) == hipSuccess) {
+    if (hipHostMalloc(&result_host, sizeof(LmState) + 64, hipHostMallocMapped | hipHostMallocCoherent) == hipSuccess) {
       std::memset(result_host, 0, sizeof(LmState) + 64);
       void* dp = nullptr;
       if (hipHostGetDevicePointer(&dp, result_host, 0) == hipSuccess) result_dev = reinterpret_cast<unsigned long long*>(dp);
