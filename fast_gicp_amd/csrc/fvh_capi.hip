@@ -429,7 +429,8 @@ int calc_cov_rbf(Engine* e, CloudDev& c, double kernel_width, double max_dist, i
       int rc = ensure_sorted(e, c);
       if (rc) return rc;
       ProfScope ps(e, "rbf");
-      cov_rbf_tiled_kernel<<<(waves + 3) / 4, 256, 0, e->stream>>>(c.sorted.as<float4>(), c.bbox.as<float4>(), c.n, (float)kernel_width, md * md, method, c.cov.as<float4>());
+      if (rbf_mode == 2) cov_rbf_tiled_kernel<<<(waves + 3) / 4, 256, 0, e->stream>>>(c.sorted.as<float4>(), c.bbox.as<float4>(), c.n, (float)kernel_width, md * md, method, c.cov.as<float4>());
+      else cov_rbf1_kernel<<<(c.n + 3) / 4, 256, 0, e->stream>>>(c.sorted.as<float4>(), c.bbox.as<float4>(), c.bbox2.as<float4>(), c.n, (float)kernel_width, md * md, method, c.cov.as<float4>());
     }
   }
   HIP_OR_FAIL(e, hipGetLastError());
