@@ -51,6 +51,7 @@ struct CloudDev {
   DevBuf order;                        // Morton permutation: order[j] = original index of the j-th point along the curve
   DevBuf pts, cov, nbr, bbox, sorted;  // sorted: Morton-ordered copy, .w = original index; bbox: boxes of its 64-point tiles
   bool has_pts = false, has_cov = false, has_nbr = false, has_sorted = false;
+  bool has_box = false;                // box holds the bounding cube of the CURRENT points (uploads that skip it: NDT, downsampler)
   bool box_dirty = false;              // box holds the cube of a cloud (cleared again by the cooperative sort that consumes it)
   void swap(CloudDev& o) { std::swap(*this, o); }
   void release() { box.release(); pts.release(); cov.release(); nbr.release(); bbox.release(); bbox2.release(); sorted.release(); order.release(); }
@@ -266,7 +267,7 @@ inline void pose_to_colmajor16(const PoseD& p, double* T) {
 // ---------------------------------------------------------------------------------------------
 // shared building blocks
 // ---------------------------------------------------------------------------------------------
-int upload_cloud(Engine* e, CloudDev& c, const float* xyz, int n, int stride, bool on_device) {
+int upload_cloud(Engine* e, CloudDev& c, const float* xyz, int n, int stride, bool on_device, bool want_box = true /* the cooperative sort's bounding cube (VGICP clouds) */) {
   if (n < 0 || (n > 0 && !xyz)) return e->fail(FVH_ERR_INVALID_ARGUMENT, "set_cloud: null points");
   if (stride != 3 && stride != 4) return e->fail(FVH_ERR_INVALID_ARGUMENT, "set_cloud: stride must be 3 or 4 floats");
   HIP_OR_FAIL(e, c.pts.ensure(sizeof(float4) * (size_t)std::max(n, 1)));
@@ -274,18 +275,23 @@ int upload_cloud(Engine* e, CloudDev& c, const float* xyz, int n, int stride, bo
   c.has_pts = true;
   c.has_sorted = false;
   if (n == 0) return FVH_OK;
-  const bool fresh_box = c.box.p == nullptr;
-  HIP_OR_FAIL(e, c.box.ensure(64));
-  if (fresh_box || c.box_dirty) HIP_OR_FAIL(e, hipMemsetAsync(c.box.p, 0, 64, e->stream));  // (the cooperative sort's finish kernel leaves it cleared)
-  c.box_dirty = true;
+  unsigned* boxp = nullptr;
+  c.has_box = want_box;
+  if (want_box) {
+    const bool fresh_box = c.box.p == nullptr;
+    HIP_OR_FAIL(e, c.box.ensure(64));
+    if (fresh_box || c.box_dirty) HIP_OR_FAIL(e, hipMemsetAsync(c.box.p, 0, 64, e->stream));  // (the cooperative sort's finish kernel leaves it cleared)
+    c.box_dirty = true;
+    boxp = c.box.as<unsigned>();
+  }
   if (on_device) {
-    pack_points_kernel<<<(n + 255) / 256, 256, 0, e->stream>>>(xyz, n, stride, c.pts.as<float4>(), c.box.as<unsigned>());
+    pack_points_kernel<<<(n + 255) / 256, 256, 0, e->stream>>>(xyz, n, stride, c.pts.as<float4>(), boxp);
     HIP_OR_FAIL(e, hipGetLastError());
   } else {
     // H2D the xyz (stride 3) / xyzi (stride 4, e.g. a KITTI .bin buffer) array into a staging buffer, then widen to float4 on device
     HIP_OR_FAIL(e, e->staging.ensure(sizeof(float) * stride * (size_t)n));
     HIP_OR_FAIL(e, hipMemcpyAsync(e->staging.p, xyz, sizeof(float) * stride * (size_t)n, hipMemcpyHostToDevice, e->stream));
-    pack_points_kernel<<<(n + 255) / 256, 256, 0, e->stream>>>(e->staging.as<float>(), n, stride, c.pts.as<float4>(), c.box.as<unsigned>());
+    pack_points_kernel<<<(n + 255) / 256, 256, 0, e->stream>>>(e->staging.as<float>(), n, stride, c.pts.as<float4>(), boxp);
     HIP_OR_FAIL(e, hipGetLastError());
     HIP_OR_FAIL(e, hipStreamSynchronize(e->stream));  // caller may free xyz on return (reference copies too)
   }
@@ -324,7 +330,7 @@ int ensure_sorted(Engine* e, CloudDev& c) {
   if (sort_mode >= 1 && n <= SORT_SMALL_MAX) {
     // cooperative kernel (32 workgroups meeting at grid barriers) when this is the only engine of the process: two
     // gang kernels from two streams could starve each other of CU slots (the watchdog + fallback would recover, slowly)
-    const bool coop = (sort_mode == 2 && g_live_engines.load() == 1) || sort_mode == 3;
+    const bool coop = c.has_box && ((sort_mode == 2 && g_live_engines.load() == 1) || sort_mode == 3);
     if (coop) {
       const bool fresh = e->sort_coop.p == nullptr;
       HIP_OR_FAIL(e, e->sort_coop.ensure(sizeof(SortCoopState) + sizeof(unsigned) * 2 * SMALL_BINS * COOP_WGS));
@@ -932,7 +938,6 @@ struct DownsampleDev {
 int device_scan(Engine* e, DevBuf& bsums, const unsigned* in, int n, unsigned* out, const unsigned** total) {
   const int nb = (n + SCAN_BLOCK_ITEMS - 1) / SCAN_BLOCK_ITEMS;
   HIP_OR_FAIL(e, bsums.ensure(sizeof(unsigned) * (size_t)(nb + 1)));
-  HIP_OR_FAIL(e, hipMemsetAsync(bsums.as<unsigned>() + nb, 0, sizeof(unsigned), e->stream));
   scan_block_sums_kernel<<<nb, 256, 0, e->stream>>>(in, n, bsums.as<unsigned>());
   radix_scan_kernel<<<1, 1024, 0, e->stream>>>(bsums.as<unsigned>(), nb + 1);
   scan_apply_kernel<<<nb, 256, 0, e->stream>>>(in, n, bsums.as<unsigned>(), out);
@@ -972,7 +977,7 @@ int downsample(Engine* e, DownsampleDev& d, int method, const float* xyz, int n,
   if (!out_n) return e->fail(FVH_ERR_INVALID_ARGUMENT, "voxelgrid: null out_n");
   if (method != FVH_VOXELGRID_EXACT && method != FVH_VOXELGRID_APPROXIMATE) return e->fail(FVH_ERR_INVALID_ARGUMENT, "voxelgrid: unknown method");
   if (!(leaf > 0.f)) return e->fail(FVH_ERR_INVALID_ARGUMENT, "voxelgrid: leaf size must be > 0");
-  int rc = upload_cloud(e, d.cloud, xyz, n, stride, on_device);
+  int rc = upload_cloud(e, d.cloud, xyz, n, stride, on_device, false);
   if (rc) return rc;
   d.out_n = 0;
   *out_n = 0;
@@ -990,9 +995,9 @@ int downsample(Engine* e, DownsampleDev& d, int method, const float* xyz, int n,
   const int blocks = (n + 255) / 256;
   unsigned* h_total = reinterpret_cast<unsigned*>(e->pinned);
   unsigned* bad = d.keys.as<unsigned>() + 2 * (size_t)n + 8;  // set by the key kernels on a non-finite coordinate
-  HIP_OR_FAIL(e, hipMemsetAsync(bad, 0, sizeof(unsigned), e->stream));
   int sorted = 0;
   if (method == FVH_VOXELGRID_EXACT) {
+    HIP_OR_FAIL(e, hipMemsetAsync(bad, 0, sizeof(unsigned), e->stream));
     // pcl::VoxelGrid: lattice over the bounding box (getMinMax3D), linear voxel index, points grouped by index
     unsigned* box = d.keys.as<unsigned>() + 2 * (size_t)n;
     HIP_OR_FAIL(e, hipMemsetAsync(box, 0xFF, 12, e->stream));
@@ -1019,29 +1024,30 @@ int downsample(Engine* e, DownsampleDev& d, int method, const float* xyz, int n,
     vg_mark_exact_kernel<<<blocks, 256, 0, e->stream>>>(keys[sorted], n, d.head.as<unsigned>());
     const unsigned* total_dev = nullptr;
     if ((rc = device_scan(e, d.bsums, d.head.as<unsigned>(), n, d.scan.as<unsigned>(), &total_dev))) return rc;
-    vg_emit_kernel<false><<<blocks, 256, 0, e->stream>>>(keys[sorted], idx[sorted], pts, n, d.head.as<unsigned>(), d.scan.as<unsigned>(), nullptr, nullptr, d.out.as<float>());
+    vg_emit_kernel<false><<<blocks, 256, 0, e->stream>>>(keys[sorted], idx[sorted], pts, n, d.head.as<unsigned>(), d.scan.as<unsigned>(), nullptr, nullptr, d.out.as<float>(), nullptr, nullptr);
     HIP_OR_FAIL(e, hipGetLastError());
     HIP_OR_FAIL(e, hipMemcpyAsync(h_total, total_dev, sizeof(unsigned), hipMemcpyDeviceToHost, e->stream));
     HIP_OR_FAIL(e, hipMemcpyAsync(h_total + 2, bad, sizeof(unsigned), hipMemcpyDeviceToHost, e->stream));
     HIP_OR_FAIL(e, hipStreamSynchronize(e->stream));
     d.out_n = (int)h_total[0];
   } else {
-    // pcl::ApproximateVoxelGrid, slot-parallel (see kernels_downsample.hpp)
+    // pcl::ApproximateVoxelGrid, slot-parallel (see kernels_downsample.hpp). Housekeeping on the stream is kept to ONE small
+    // memset and ONE 16-byte copy: the key kernel clears the trigger flags, `bad` sits behind the slot flags, the scan's
+    // spare entry is cleared by its first kernel, and the emit kernel gathers the three numbers the host needs.
     HIP_OR_FAIL(e, d.trig.ensure(sizeof(unsigned) * (size_t)n));
-    HIP_OR_FAIL(e, d.slots.ensure(sizeof(unsigned) * (AVG_SLOTS + 1)));
-    HIP_OR_FAIL(e, hipMemsetAsync(d.trig.p, 0, sizeof(unsigned) * (size_t)n, e->stream));
-    HIP_OR_FAIL(e, hipMemsetAsync(d.slots.p, 0, sizeof(unsigned) * (AVG_SLOTS + 1), e->stream));
-    vg_keys_approx_kernel<<<blocks, 256, 0, e->stream>>>(pts, n, inv, keys[0], idx[0], bad);
+    HIP_OR_FAIL(e, d.slots.ensure(sizeof(unsigned) * (AVG_SLOTS + 1 + 1 + 4)));
+    unsigned* bad2 = d.slots.as<unsigned>() + AVG_SLOTS + 1;
+    unsigned* result = bad2 + 1;  // {trigger count, used slots, bad}
+    HIP_OR_FAIL(e, hipMemsetAsync(d.slots.p, 0, sizeof(unsigned) * (AVG_SLOTS + 2), e->stream));
+    vg_keys_approx_kernel<<<blocks, 256, 0, e->stream>>>(pts, n, inv, keys[0], idx[0], bad2, d.trig.as<unsigned>());
     if ((rc = radix_sort_pairs(e, keys, idx, n, RADIX_BITS, &sorted))) return rc;
     vg_mark_approx_kernel<<<blocks, 256, 0, e->stream>>>(keys[sorted], idx[sorted], pts, n, inv, d.head.as<unsigned>(), d.trig.as<unsigned>(), d.slots.as<unsigned>());
     const unsigned* trig_total = nullptr;
     if ((rc = device_scan(e, d.bsums, d.trig.as<unsigned>(), n, d.scan.as<unsigned>(), &trig_total))) return rc;
     radix_scan_kernel<<<1, 1024, 0, e->stream>>>(d.slots.as<unsigned>(), AVG_SLOTS + 1);
-    vg_emit_kernel<true><<<blocks, 256, 0, e->stream>>>(keys[sorted], idx[sorted], pts, n, d.head.as<unsigned>(), d.scan.as<unsigned>(), d.slots.as<unsigned>(), trig_total, d.out.as<float>());
+    vg_emit_kernel<true><<<blocks, 256, 0, e->stream>>>(keys[sorted], idx[sorted], pts, n, d.head.as<unsigned>(), d.scan.as<unsigned>(), d.slots.as<unsigned>(), trig_total, d.out.as<float>(), bad2, result);
     HIP_OR_FAIL(e, hipGetLastError());
-    HIP_OR_FAIL(e, hipMemcpyAsync(h_total, trig_total, sizeof(unsigned), hipMemcpyDeviceToHost, e->stream));
-    HIP_OR_FAIL(e, hipMemcpyAsync(h_total + 1, d.slots.as<unsigned>() + AVG_SLOTS, sizeof(unsigned), hipMemcpyDeviceToHost, e->stream));
-    HIP_OR_FAIL(e, hipMemcpyAsync(h_total + 2, bad, sizeof(unsigned), hipMemcpyDeviceToHost, e->stream));
+    HIP_OR_FAIL(e, hipMemcpyAsync(h_total, result, 3 * sizeof(unsigned), hipMemcpyDeviceToHost, e->stream));
     HIP_OR_FAIL(e, hipStreamSynchronize(e->stream));
     d.out_n = (int)(h_total[0] + h_total[1]);
   }
@@ -1324,10 +1330,10 @@ int fvh_ndt_swap_source_and_target(fvh_ndt* h) {
   h->e.has_corr = false;
   return FVH_OK;
 }
-int fvh_ndt_set_source_cloud(fvh_ndt* h, const float* xyz, int n) { CHECK_HANDLE(h); h->e.has_corr = false; h->source_vm.invalidate(); return upload_cloud(&h->e, h->source, xyz, n, 3, false); }
-int fvh_ndt_set_target_cloud(fvh_ndt* h, const float* xyz, int n) { CHECK_HANDLE(h); h->e.has_corr = false; h->target_vm.invalidate(); return upload_cloud(&h->e, h->target, xyz, n, 3, false); }
-int fvh_ndt_set_source_cloud_device(fvh_ndt* h, const float* d, int n, int s) { CHECK_HANDLE(h); h->e.has_corr = false; h->source_vm.invalidate(); return upload_cloud(&h->e, h->source, d, n, s, true); }
-int fvh_ndt_set_target_cloud_device(fvh_ndt* h, const float* d, int n, int s) { CHECK_HANDLE(h); h->e.has_corr = false; h->target_vm.invalidate(); return upload_cloud(&h->e, h->target, d, n, s, true); }
+int fvh_ndt_set_source_cloud(fvh_ndt* h, const float* xyz, int n) { CHECK_HANDLE(h); h->e.has_corr = false; h->source_vm.invalidate(); return upload_cloud(&h->e, h->source, xyz, n, 3, false, false); }
+int fvh_ndt_set_target_cloud(fvh_ndt* h, const float* xyz, int n) { CHECK_HANDLE(h); h->e.has_corr = false; h->target_vm.invalidate(); return upload_cloud(&h->e, h->target, xyz, n, 3, false, false); }
+int fvh_ndt_set_source_cloud_device(fvh_ndt* h, const float* d, int n, int s) { CHECK_HANDLE(h); h->e.has_corr = false; h->source_vm.invalidate(); return upload_cloud(&h->e, h->source, d, n, s, true, false); }
+int fvh_ndt_set_target_cloud_device(fvh_ndt* h, const float* d, int n, int s) { CHECK_HANDLE(h); h->e.has_corr = false; h->target_vm.invalidate(); return upload_cloud(&h->e, h->target, d, n, s, true, false); }
 int fvh_ndt_create_source_voxelmap(fvh_ndt* h) {
   CHECK_HANDLE(h);
   // a swapped-in target map has no compact arrays: rebuild in that case

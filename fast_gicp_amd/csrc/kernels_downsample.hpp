@@ -26,6 +26,7 @@ constexpr int AVG_SLOTS = 512;          // pcl::ApproximateVoxelGrid histsize_
 // ---- generic exclusive scan of n unsigned values: block sums -> radix_scan_kernel on the sums -> apply ----
 __global__ __launch_bounds__(256) void scan_block_sums_kernel(const unsigned* __restrict__ data, int n, unsigned* __restrict__ block_sums) {
   __shared__ unsigned ws[4];
+  if (blockIdx.x == 0 && threadIdx.x == 0) block_sums[gridDim.x] = 0u;  // the spare entry that receives the grand total in the scan
   const int base = blockIdx.x * SCAN_BLOCK_ITEMS + threadIdx.x * 4;
   unsigned s = 0;
 #pragma unroll
@@ -88,9 +89,10 @@ __device__ __forceinline__ void avg_voxel(const float4 p, float inv, int& ix, in
 }
 
 __global__ __launch_bounds__(256) void vg_keys_approx_kernel(const float4* __restrict__ pts, int n, float inv, unsigned* __restrict__ keys, int* __restrict__ idx,
-                                                             unsigned* __restrict__ bad) {
+                                                             unsigned* __restrict__ bad, unsigned* __restrict__ trig /* cleared here: saves a memset */) {
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
+  trig[i] = 0u;
   int ix, iy, iz;
   if (!finite3(pts[i])) *bad = 1u;
   avg_voxel(pts[i], inv, ix, iy, iz);
@@ -136,7 +138,9 @@ template <bool APPROX>
 __global__ __launch_bounds__(256) void vg_emit_kernel(const unsigned* __restrict__ keys, const int* __restrict__ idx, const float4* __restrict__ pts, int n,
                                                       const unsigned* __restrict__ head, const unsigned* __restrict__ pos_scan /* exact: scan(head) by j; approx: scan(trig) by original index */,
                                                       const unsigned* __restrict__ slot_rank /* approx: exclusive scan of slot_used, [AVG_SLOTS] = #used */,
-                                                      const unsigned* __restrict__ trig_total /* approx: number of flush-triggering points */, float* __restrict__ out) {
+                                                      const unsigned* __restrict__ trig_total /* approx: number of flush-triggering points */, float* __restrict__ out,
+                                                      const unsigned* __restrict__ bad, unsigned* __restrict__ result /* approx: {trigger count, used slots, bad} for ONE host copy */) {
+  if (APPROX && result && blockIdx.x == 0 && threadIdx.x == 0) { result[0] = *trig_total; result[1] = slot_rank[AVG_SLOTS]; result[2] = *bad; }
   const int j = blockIdx.x * 256 + threadIdx.x;
   if (j >= n || !head[j]) return;
   float cx = 0.f, cy = 0.f, cz = 0.f;
