@@ -746,7 +746,7 @@ int do_align(Engine* e, const CostSource& src, VoxelMapDev& vm, const double* gu
       volatile unsigned long long* seq = reinterpret_cast<volatile unsigned long long*>(e->result_host) + sizeof(LmState) / 8;
       for (unsigned long long spins = 0;; spins++) {
         if (*seq == e->persist_seq) { have_result = true; break; }
-        if ((spins & 0x3ff) == 0x3ff && hipStreamQuery(e->stream) == hipSuccess) { have_result = (*seq == e->persist_seq); break; }
+        if ((spins & 0x3ff) == 0x3ff && hipStreamQuery(e->stream) != hipErrorNotReady) { have_result = (*seq == e->persist_seq); break; }  // drained (or failed: the copy below reports it)
       }
       if (have_result) {
         std::atomic_thread_fence(std::memory_order_acquire);
