@@ -263,3 +263,39 @@ def test_covariance_state_machine_is_consistent(O):
     nb = O.knn(src, 20)
     c.set_source_neighbors(20, nb); c.calculate_source_covariances(3); check(3)  # host-supplied neighbours: gather kernel
     c.close()
+
+
+@pytest.mark.parametrize("n,search", [(150, 0), (700, 2), (2500, 1), (9000, 0), (40000, 1), (40000, 0)])
+def test_persistent_barrier_logic_over_grid_sizes(monkeypatch, n, search):
+    """The persistent LM kernel's grid goes from 1 workgroup (fewer groups than arrival counters) to the co-residency cap;
+    whatever the size, it must give the bit-identical result of the per-transition launches (forced here through the
+    barrier watchdog), for VGICP and both NDT modes."""
+    from fast_gicp_amd import capi
+    tgt, src, _ = util.synthetic_pair(n, n, seed=7 + n, extent=20.0 if n < 5000 else 60.0)
+    c = capi.VGICPCore(0)
+    c.set_resolution(1.0); c.set_neighbor_search_method(search)
+    k = min(20, n)
+    c.set_target_cloud(tgt); c.find_target_neighbors(k); c.calculate_target_covariances(); c.create_target_voxelmap()
+    c.set_source_cloud(src); c.find_source_neighbors(k); c.calculate_source_covariances()
+    r0 = c.align()
+    assert r0["num_launches"] == 1
+    monkeypatch.setenv("FVH_PERSIST_WATCHDOG_TICKS", "0")
+    r1 = c.align()
+    monkeypatch.delenv("FVH_PERSIST_WATCHDOG_TICKS")
+    r2 = c.align()
+    assert r2["num_launches"] == 1 and r1["num_launches"] >= 1
+    for r in (r1, r2):
+        assert r["converged"] == r0["converged"] and r["num_linearize"] == r0["num_linearize"] and r["num_error_evals"] == r0["num_error_evals"]
+        assert np.array_equal(r["T"], r0["T"]) and np.array_equal(r["H"], r0["H"])
+    c.close()
+    for mode in ((1, 0) if n >= 9000 else ()):  # (sparser clouds leave NDT without a voxel of more than 6 points: H = 0)
+        d = capi.NDTCore(0)
+        d.set_distance_mode(mode); d.set_neighbor_search_method(1)
+        d.set_target_cloud(tgt); d.set_source_cloud(src)
+        a = d.align()
+        monkeypatch.setenv("FVH_PERSIST_WATCHDOG_TICKS", "0")
+        b = d.align()
+        monkeypatch.delenv("FVH_PERSIST_WATCHDOG_TICKS")
+        assert a["num_launches"] == 1
+        assert np.isfinite(a["T"]).all() and np.array_equal(a["T"], b["T"]) and a["num_error_evals"] == b["num_error_evals"]
+        d.close()
