@@ -1272,6 +1272,9 @@ int fvh_vgicp_debug_get_persist_aborts(fvh_vgicp* h, int* n) { CHECK_HANDLE(h); 
 int fvh_vgicp_debug_get_table_capacity(fvh_vgicp* h, int* capacity) { CHECK_HANDLE(h); if (!capacity) return FVH_ERR_INVALID_ARGUMENT; *capacity = (int)h->voxelmap.capacity; return FVH_OK; }
 int fvh_vgicp_synchronize(fvh_vgicp* h) { CHECK_HANDLE(h); HIP_OR_FAIL(&h->e, hipStreamSynchronize(h->e.stream)); return FVH_OK; }
 
+#ifdef FVH_KNN_TIMING
+int fvh_debug_knn_timing(unsigned long long* out) { return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_knn_time), sizeof(unsigned long long) * 32768 * 8) == hipSuccess ? FVH_OK : FVH_ERR_HIP; }
+#endif
 #ifdef FVH_COST_TIMING
 // debug build only (not declared in the public header): out[0] = earliest workgroup start, out[1..7] = epilogue stamps of the last workgroup, 100 MHz ticks
 int fvh_debug_persist_timing(unsigned long long* out, int reset) {  // out: [16][512][12]

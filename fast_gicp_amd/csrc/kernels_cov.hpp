@@ -255,11 +255,19 @@ __device__ __forceinline__ void wave_bitonic_sort64(unsigned long long& key, int
 // proportional to the queries per wave). Seed = bitonic sort of the own tile; two-level box culling
 // (super tiles of 64 tiles, then tiles); the next surviving tile is prefetched while the current one
 // is merged, so the L2 round trips overlap with the insertion chain.
+#ifdef FVH_KNN_TIMING
+__device__ unsigned long long g_knn_time[32768][8];  // debug build: per query {start, seeds loaded, sorted, neighbours merged, culled sweep done, #tiles swept, #insertions}
+#define KNN_STAMP(i) do { if (lane == 0 && q < 32768) g_knn_time[q][i] = wall_clock64(); } while (0)
+#else
+#define KNN_STAMP(i) do { } while (0)
+#endif
 __global__ __launch_bounds__(256) void knn_tiled1_kernel(const float4* __restrict__ spts, const float4* __restrict__ bbox1, const float4* __restrict__ bbox2, int n, int k,
                                                          int* __restrict__ out_idx) {
   const int lane = threadIdx.x & 63;
   const int q = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (q >= n) return;
+  KNN_STAMP(0);
+  int dbg_tiles = 0, dbg_ins = 0;
   const int ntiles = (n + 63) >> 6, nsuper = (ntiles + 63) >> 6;
   const float4 qv = spts[q];
   const float qx = read_lane(qv.x, 0), qy = read_lane(qv.y, 0), qz = read_lane(qv.z, 0);
@@ -269,7 +277,12 @@ __global__ __launch_bounds__(256) void knn_tiled1_kernel(const float4* __restric
   const float4 pa = load_candidate(spts, (min(t0 + 1, ntiles - 1) << 6) + lane, n);
   const float4 pb = load_candidate(spts, (max(t0 - 1, 0) << 6) + lane, n);
   unsigned long long lk = knn_key(sqdist_nofma(p0, qx, qy, qz), (((t0 << 6) + lane) < n) ? __float_as_int(p0.w) : 0x7fffffff);
+#ifdef FVH_KNN_TIMING
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+  KNN_STAMP(1);
   wave_bitonic_sort64(lk, lane);
+  KNN_STAMP(2);
   unsigned long long tk = read_lane64(lk, k - 1);  // the current k-th entry: the acceptance threshold
   float td = __uint_as_float((unsigned)(tk >> 32));
 
@@ -277,7 +290,9 @@ __global__ __launch_bounds__(256) void knn_tiled1_kernel(const float4* __restric
     const unsigned long long ck = knn_key(sqdist_nofma(p, qx, qy, qz), __float_as_int(p.w));
     // exact acceptance test per lane: (d, idx) below the current k-th entry in the total order
     unsigned long long mask = __ballot(ck < tk);
+    dbg_tiles++;
     while (mask) {
+      dbg_ins++;
       const int c = __ffsll((long long)mask) - 1;
       const unsigned long long cc = read_lane64(ck, c);
       const int pos = __popcll(__ballot(lk < cc));
@@ -291,6 +306,7 @@ __global__ __launch_bounds__(256) void knn_tiled1_kernel(const float4* __restric
   };
   if (t0 + 1 < ntiles) merge_tile(pa);
   if (t0 > 0) merge_tile(pb);
+  KNN_STAMP(3);
 
   for (int sc = 0; sc < nsuper; sc += 64) {
     const int s = sc + lane;
@@ -324,6 +340,10 @@ __global__ __launch_bounds__(256) void knn_tiled1_kernel(const float4* __restric
     }
   }
   if (lane < k) out_idx[(size_t)__float_as_int(qv.w) * k + lane] = (int)(unsigned)lk;
+  KNN_STAMP(4);
+#ifdef FVH_KNN_TIMING
+  if (lane == 0 && q < 32768) { g_knn_time[q][5] = dbg_tiles; g_knn_time[q][6] = dbg_ins; }
+#endif
 }
 
 __device__ __forceinline__ void store_cov(float4* __restrict__ cov, int i, const Sym3<double>& C) {
