@@ -238,12 +238,21 @@ __device__ __forceinline__ unsigned long long wave_shr1_64(unsigned long long v)
 __device__ __forceinline__ unsigned long long shfl_xor64(unsigned long long v, int m) {
   return ((unsigned long long)(unsigned)__shfl_xor((int)(v >> 32), m) << 32) | (unsigned)__shfl_xor((int)v, m);
 }
+// lane ^ 1 / lane ^ 2 through DPP quad permutes (VALU moves, no trip through the LDS crossbar): 11 of the 21 stages of the
+// 64-lane bitonic sort
+template <int XOR>
+__device__ __forceinline__ unsigned long long quad_xor64(unsigned long long v) {
+  constexpr int ctrl = (XOR == 1) ? 0xB1 /* quad_perm [1,0,3,2] */ : 0x4E /* quad_perm [2,3,0,1] */;
+  const int hi = __builtin_amdgcn_update_dpp(0, (int)(v >> 32), ctrl, 0xF, 0xF, false);
+  const int lo = __builtin_amdgcn_update_dpp(0, (int)v, ctrl, 0xF, 0xF, false);
+  return ((unsigned long long)(unsigned)hi << 32) | (unsigned)lo;
+}
 __device__ __forceinline__ void wave_bitonic_sort64(unsigned long long& key, int lane) {
 #pragma unroll
   for (int k2 = 2; k2 <= 64; k2 <<= 1) {
 #pragma unroll
     for (int j2 = k2 >> 1; j2 > 0; j2 >>= 1) {
-      const unsigned long long other = shfl_xor64(key, j2);
+      const unsigned long long other = (j2 == 1) ? quad_xor64<1>(key) : (j2 == 2) ? quad_xor64<2>(key) : shfl_xor64(key, j2);
       const bool want_min = (((lane & j2) == 0) == ((lane & k2) == 0));
       const bool less = other < key;  // keys are unique (indices are)
       key = (want_min == less) ? other : key;
