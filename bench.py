@@ -150,7 +150,19 @@ def stream_main(args):
     if int(os.environ.get("WORLD_SIZE", "1")) != 1:
         raise SystemExit("lidar_stream is a single-GPU workload")
     F = 10
-    frames = [util.lidar_frame(i) for i in range(F)]
+    kitti_dir = os.environ.get("FVH_KITTI_DIR")  # e.g. .../sequences/00/velodyne: the real frames instead of the simulator (kitti.cpp:22-69 format)
+    if kitti_dir:
+        frames = []
+        for i in range(F):
+            path = os.path.join(kitti_dir, "%06d.bin" % i)
+            if not os.path.exists(path):
+                break
+            frames.append(np.ascontiguousarray(np.fromfile(path, np.float32)[: 1000000 // 4 * 4].reshape(-1, 4)[:, :3]))
+        if len(frames) < 2:
+            raise SystemExit("FVH_KITTI_DIR holds fewer than two %06d.bin frames")
+        F = len(frames)
+    else:
+        frames = [util.lidar_frame(i) for i in range(F)]
     gpu = torch.device("cuda", 0)
     d_frames = [torch.from_numpy(f).to(gpu).contiguous() for f in frames]
     vg, ndt = capi.VoxelGrid(0), capi.NDTCore(0)
@@ -180,8 +192,9 @@ def stream_main(args):
     ndt.set_target_cloud_device(ptr, n, 3)
     for i in range(1, F):
         step()
-        gt = np.linalg.inv(util.lidar_pose(i - 1)) @ util.lidar_pose(i)
-        errs.append(util.pose_error(gt, state["last"]["T"])[0])
+        if not kitti_dir:  # ground truth exists for the simulator only
+            gt = np.linalg.inv(util.lidar_pose(i - 1)) @ util.lidar_pose(i)
+            errs.append(util.pose_error(gt, state["last"]["T"])[0])
     state["k"] = F - 1
     profile = not args.no_profile
     ndt.profile_reset(); vg.profile_reset()
@@ -231,11 +244,11 @@ def stream_main(args):
                "sample": "%d frames of the same loop: oracle ApproximateVoxelGrid (1 thread, as PCL) + oracle NDT D2D (OpenMP, %d threads)" % (loops, cores)}
     out = {"metric": "registrations/sec (frame-by-frame odometry, kitti.cpp loop incl. downsampling)", "value": round(args.steps / elapsed, 3), "unit": "registrations/sec", "n_gpus": 1,
            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 5), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-           "dtype": "f64" if args.precision == "fp64" else "f32", "data": "synthetic",
-           "config": {"workload": "simulated 64-ring LiDAR, %d raw pts/frame -> ApproximateVoxelGrid 0.25 -> %d pts; NDT D2D, DIRECT7, res 1.0; %d-frame sequence walked back and forth" % (n_raw, n_ds, F),
+           "dtype": "f64" if args.precision == "fp64" else "f32", "data": "KITTI" if kitti_dir else "synthetic",
+           "config": {"workload": "%s, %d raw pts/frame -> ApproximateVoxelGrid 0.25 -> %d pts; NDT D2D, DIRECT7, res 1.0; %d-frame sequence walked back and forth" % ("KITTI frames from FVH_KITTI_DIR" if kitti_dir else "simulated 64-ring LiDAR", n_raw, n_ds, F),
                       "method": "NDT_D2D", "neighbor_search": "DIRECT7", "voxel_resolution": 1.0, "parallelism": "single GPU"},
            "per_registration": {"cost_evaluations": n_eval / args.steps, "converged": bool(state["last"]["converged"])},
-           "accuracy": {"max_frame_translation_error_m": round(float(max(errs)), 4), "mean_frame_translation_error_m": round(float(np.mean(errs)), 4)},
+           "accuracy": ({"max_frame_translation_error_m": round(float(max(errs)), 4), "mean_frame_translation_error_m": round(float(np.mean(errs)), 4)} if errs else None),
            "roofline": roofline, "cpu_baseline": cpu, "stages": stage_ms}
     print(json.dumps(out))
 
