@@ -124,11 +124,15 @@ int fvh_vgicp_update_correspondences(fvh_vgicp* h, const double* T16);          
  * linearisation rotation of the last update_correspondences(). */
 int fvh_vgicp_compute_error(fvh_vgicp* h, const double* T16, double* H36, double* b6, double* error);
 
-/* new: the whole LsqRegistration::computeTransformation loop (lsq_registration_impl.hpp:53-168)
- * on device: one fused kernel per linearize()/compute_error(), LM step on device, one D2H. */
+/* new: the whole LsqRegistration::computeTransformation loop (lsq_registration_impl.hpp:53-168) on the device.
+ * Normally ONE persistent kernel launch per call (every LM transition is a trip through an in-kernel barrier; the
+ * result comes back through mapped pinned memory, result->num_launches == 1); one launch per LM transition when a
+ * RCCL communicator is attached, when another handle of the process is aligning at the same moment, for > 4 M voxel
+ * lookups per evaluation, or after the barrier watchdog aborted a persistent launch (FVH_PERSISTENT=0 forces it).
+ * All routes produce bit-identical results. */
 int fvh_vgicp_align(fvh_vgicp* h, const double* guess16, const fvh_lm_params* params, fvh_lm_result* result);
 /* new: pcl::Registration::getFitnessScore(max_range) -- mean squared exact-NN distance of
- * (float)T * source to the target cloud (brute-force tiled 1-NN on device). */
+ * (float)T * source to the target cloud (exact tile-culled 1-NN on device, fixed-order fp64 sum: bit-reproducible). */
 int fvh_vgicp_fitness_score(fvh_vgicp* h, const double* T16, double max_range, double* score);
 
 /* ---- FastGICP on the device: nearest-target-point correspondences instead of voxels, on the same handle.
