@@ -378,6 +378,15 @@ class VoxelGrid:
         self._check(self._lib.fvh_voxelgrid_get_points(self._h, _p(out)), "fvh_voxelgrid_get_points")
         return out
 
+    def filter_strided(self, buf, stride, leaf, method=APPROXIMATE):
+        """Host array of n x `stride` floats (e.g. a KITTI xyzi buffer, stride 4); only the first three of each row are used."""
+        a = _f32(np.asarray(buf).reshape(-1, stride))
+        n = C.c_int(0)
+        self._check(self._lib.fvh_voxelgrid_filter_strided(self._h, int(method), _p(a), len(a), int(stride), C.c_float(leaf), C.byref(n)), "fvh_voxelgrid_filter_strided")
+        out = np.empty((n.value, 3), np.float32)
+        self._check(self._lib.fvh_voxelgrid_get_points(self._h, _p(out)), "fvh_voxelgrid_get_points")
+        return out
+
     def filter_device(self, d_ptr, n, leaf, method=APPROXIMATE, stride=3):
         """Device pointer in (n points, `stride` floats apart); returns (device pointer to packed xyz, count) valid until the next filter call."""
         m = C.c_int(0)

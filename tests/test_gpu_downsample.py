@@ -129,3 +129,11 @@ def test_device_pointer_round_trip(O, vg):
     assert c.num_points("source") == n
     assert c.fitness_score(np.eye(4)) == 0.0  # identical clouds: every nearest neighbour at distance 0
     c.close()
+
+
+def test_strided_host_input_equals_packed(O, vg):
+    """A KITTI-style xyzi buffer (stride 4) goes to the device as it is (kitti.cpp:48-60 reads x, y, z and skips intensity)."""
+    f = util.lidar_frame(2)
+    xyzi = np.column_stack([f, np.random.default_rng(1).uniform(0, 1, len(f)).astype(np.float32)])
+    for m, ref in ((vg.APPROXIMATE, O.approx_voxelgrid), (vg.EXACT, O.voxelgrid)):
+        _same(vg.filter_strided(xyzi, 4, 0.25, m), ref(f, 0.25))
