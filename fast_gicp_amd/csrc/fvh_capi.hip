@@ -126,7 +126,7 @@ struct Rccl {
   }
 };
 Rccl g_rccl;
-std::atomic<int> g_live_engines{0};    // engine handles alive in this process
+std::atomic<int> g_live_engines{0};    // engine handles alive in this process that can launch gang kernels (registration handles)
 std::atomic<int> g_active_aligns{0};  // aligns in flight in this process (persistent kernels want the device to themselves)
 
 struct Engine {
@@ -164,7 +164,7 @@ struct Engine {
   int fail(int code, const std::string& m) { err = m; return code; }
   int hipfail(hipError_t e, const char* what) { err = std::string(what) + ": " + hipGetErrorString(e); return FVH_ERR_HIP; }
 
-  int init(int dev) {
+  int init(int dev, bool gang_kernels = true /* false: this engine never launches a persistent / cooperative kernel (voxel-grid filter) */) {
     device = dev;
     hipError_t e = hipSetDevice(dev);
     if (e != hipSuccess) return hipfail(e, "hipSetDevice");
@@ -192,8 +192,7 @@ struct Engine {
     int rc = upload_offsets();
     if (rc) return rc;
     if ((e = hipStreamSynchronize(stream)) != hipSuccess) return hipfail(e, "hipStreamSynchronize");  // "warming up GPU" (fast_vgicp_cuda.cu:19-20)
-    g_live_engines.fetch_add(1);
-    counted = true;
+    if (gang_kernels) { g_live_engines.fetch_add(1); counted = true; }
     return FVH_OK;
   }
   bool counted = false;
@@ -1419,7 +1418,7 @@ int fvh_voxelgrid_create(int device, fvh_voxelgrid** out) {
   *out = nullptr;
   auto* h = new (std::nothrow) fvh_voxelgrid();
   if (!h) return FVH_ERR_HIP;
-  int rc = h->e.init(device);
+  int rc = h->e.init(device, false);
   if (rc) { fprintf(stderr, "fvh_voxelgrid_create: %s\n", h->e.err.c_str()); h->e.shutdown(); delete h; return rc; }
   *out = h;
   return FVH_OK;
