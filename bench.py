@@ -450,7 +450,8 @@ def main():
         "config": {"workload": desc, "method": "VGICP", "neighbor_search": args.search, "k_correspondences": K, "covariance": args.cov, "regularization": "PLANE",
                    "voxel_resolution": res, "parallelism": "1 registration stream per GPU" if world > 1 else "single GPU"},
         "fitness_score": round(fitness, 6), "single_ms": round(single_ms, 3),
-        "per_registration": {"linearize": n_lin / args.steps, "error_evals": n_err / args.steps, "kernel_launches_lm": n_launch / args.steps, "converged": bool(state["last"]["converged"])},
+        "per_registration": {"linearize": n_lin / args.steps, "error_evals": n_err / args.steps, "kernel_launches_lm": n_launch / args.steps, "converged": bool(state["last"]["converged"]),
+                             "persistent_launches_aborted_by_watchdog": core.debug_persist_aborts()},
         "roofline": roofline, "cpu_baseline": cpu, "stages": stage_ms, "profiled_timed_region": ("every %dth registration" % PROFILE_EVERY) if profile else False,
     }
     if sharded is not None:
