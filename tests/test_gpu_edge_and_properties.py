@@ -299,3 +299,59 @@ def test_persistent_barrier_logic_over_grid_sizes(monkeypatch, n, search):
         assert a["num_launches"] == 1
         assert np.isfinite(a["T"]).all() and np.array_equal(a["T"], b["T"]) and a["num_error_evals"] == b["num_error_evals"]
         d.close()
+
+
+def test_direct_radius_offsets(O):
+    """DIRECT_RADIUS (fast_vgicp_cuda.cu:77-91: all integer offsets within radius + 1e-3 of the query voxel). NDT: against the
+    oracle, which restates the same offset list; VGICP: radius 1.0 is the DIRECT7 set in another order -> same sums."""
+    from fast_gicp_amd import capi
+    tgt, src = util.bundled_pair()
+    for radius in (1.5, 2.0):
+        assert len(O.neighbor_offsets(O.DIRECT_RADIUS, radius)) in (19, 33)
+        c = capi.NDTCore(0)
+        c.set_distance_mode(1); c.set_neighbor_search_method(3, radius)
+        c.set_target_cloud(tgt); c.set_source_cloud(src); c.create_voxelmaps()
+        g = O.NDT(mode=1, search=O.DIRECT_RADIUS, radius=radius)
+        g.set_target(tgt); g.set_source(src); g.prepare()
+        for T in (np.eye(4), util.relative_pose()):
+            e, H, b = c.linearize(T)
+            eo, Ho, bo = g.linearize(T)
+            assert c.get_num_correspondences() == g.num_correspondences()
+            assert abs(e - eo) <= 2e-5 * abs(eo) and util.rel_err(H, Ho) <= 2e-5 and util.rel_err(b, bo) <= 2e-5
+        r, ro = c.align(), g.align()
+        assert r["converged"] and ro["converged"] and util.rel_err(r["T"], ro["T"]) < 1e-4
+        c.close()
+    v = capi.VGICPCore(0)
+    v.set_target_cloud(tgt); v.find_target_neighbors(20); v.calculate_target_covariances(); v.create_target_voxelmap()
+    v.set_source_cloud(src); v.find_source_neighbors(20); v.calculate_source_covariances()
+    v.set_neighbor_search_method(1)  # DIRECT7
+    e7, H7, b7 = v.linearize(util.relative_pose())
+    r7 = v.align()
+    v.set_neighbor_search_method(3, 1.0)
+    er, Hr, br = v.linearize(util.relative_pose())
+    rr = v.align()
+    assert abs(e7 - er) <= 1e-12 * abs(e7) and util.rel_err(Hr, H7) <= 1e-12 and util.rel_err(br, b7) <= 1e-12
+    assert util.rel_err(rr["T"], r7["T"]) < 1e-9 and rr["num_error_evals"] == r7["num_error_evals"]
+    v.close()
+
+
+def test_fp32_compute_mode_stays_within_the_reference_tolerance(O):
+    """FVH_COMPUTE_FP32 (per-correspondence math in float, sums in double -- the arithmetic class of the reference's CUDA
+    kernels): against the fp64 default, and against data/relative.txt with the reference's own tolerance."""
+    from fast_gicp_amd import capi
+    tgt, src = util.bundled_pair()
+    out = {}
+    for prec in (capi.COMPUTE_FP64, capi.COMPUTE_FP32):
+        c = capi.VGICPCore(0)
+        c.set_precision(prec); c.set_neighbor_search_method(0)
+        c.set_target_cloud(tgt); c.find_target_neighbors(20); c.calculate_target_covariances(); c.create_target_voxelmap()
+        c.set_source_cloud(src); c.find_source_neighbors(20); c.calculate_source_covariances()
+        e, H, b = c.linearize(util.relative_pose())
+        r = c.align()
+        out[prec] = (e, H, b, r)
+        c.close()
+    (e64, H64, b64, r64), (e32, H32, b32, r32) = out[capi.COMPUTE_FP64], out[capi.COMPUTE_FP32]
+    assert abs(e32 - e64) <= 1e-4 * abs(e64) and util.rel_err(H32, H64) <= 1e-4 and util.rel_err(b32, b64) <= 1e-3
+    assert r32["converged"] and util.rel_err(r32["T"], r64["T"]) < 1e-3
+    te, re_ = util.pose_error(util.relative_pose(), r32["T"])
+    assert te < 0.05 and re_ < np.radians(1.0)
