@@ -38,6 +38,7 @@ def parse():
     ap.add_argument("--precision", default="fp64", choices=["fp64", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="do not bracket the cost kernel with HIP events in the timed region")
+    ap.add_argument("--sharded-deadline", type=int, default=240, help="--gpus > 1: seconds the extra spatially-sharded leg may take before it is abandoned")
     ap.add_argument("--streams", type=int, default=4, help="extra leg: S independent engine handles (own HIP streams, host threads) running the same loop concurrently on this GPU")
     ap.add_argument("--cpu-loops", type=int, default=0, help="oracle registrations to time (0 = auto-bound to ~15 s)")
     return ap.parse_args()
@@ -56,6 +57,24 @@ def make_workload(name):
     return tgt, src, 0.5, "synthetic 1M map <-> 100k scan, seed 44"
 
 
+def run_with_deadline(fn, seconds):
+    """(result, hung): fn() on a worker thread; hung=True if it is still running after `seconds` (the thread is abandoned)."""
+    import threading
+    box = {}
+    th = threading.Thread(target=lambda: box.__setitem__("r", fn()), daemon=True)
+    th.start()
+    th.join(seconds)
+    return box.get("r"), th.is_alive()
+
+
+def finish(dist, hung):
+    if hung:  # a worker thread sits in a collective that will never complete: leave without running any destructor
+        sys.stdout.flush()
+        os._exit(0)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
 def sharded_leg(args, dist, rank, world, local_rank, dev):
     """BASELINE.json configs[4]: 1M-point map <-> 100k-point scan, DIRECT7, res 0.5; the scan is sharded by spatial tile
     over the ranks, the 32-double normal-equation block is all-reduced by RCCL inside the device LM loop."""
@@ -63,6 +82,7 @@ def sharded_leg(args, dist, rank, world, local_rank, dev):
     from fast_gicp_amd import capi, distributed as D
     from tests import util
     try:
+        torch.cuda.set_device(local_rank)  # this leg runs on a worker thread (run_with_deadline): the current device is per thread
         tgt, src, _ = util.synthetic_pair(1_000_000, 100_000, seed=44, extent=150.0)
         core = capi.VGICPCore(local_rank)
         core.set_resolution(0.5)
@@ -368,10 +388,14 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    sharded = sharded_leg(args, dist, rank, world, local_rank, dev) if (world > 1 and not share_gpu) else None
+    sharded, sharded_hung = None, False
+    if world > 1 and not share_gpu:
+        # the headline number is already measured: a stuck collective in this extra leg must not take the JSON line with it
+        sharded, sharded_hung = run_with_deadline(lambda: sharded_leg(args, dist, rank, world, local_rank, dev), args.sharded_deadline)
+        if sharded_hung:
+            sharded = {"error": "sharded leg did not finish within %d s on rank %d" % (args.sharded_deadline, rank)}
     if rank != 0:
-        if dist is not None:
-            dist.destroy_process_group()
+        finish(dist, sharded_hung)
         return
 
     total_regs = args.steps * world
@@ -458,9 +482,8 @@ def main():
         out["sharded"] = sharded
     if conc is not None:
         out["concurrent_streams"] = conc
-    print(json.dumps(out))
-    if dist is not None:
-        dist.destroy_process_group()
+    print(json.dumps(out), flush=True)
+    finish(dist, sharded_hung)
 
 
 if __name__ == "__main__":
