@@ -68,7 +68,13 @@ inline const int* coherent_order(const CloudDev& c) {
 struct VoxelMapDev {
   double res = 1.0;
   unsigned capacity = 0;
-  DevBuf table, acc, occupied, compact_pts, compact_cov, counters;  // counters: [0] num_voxels [1] dropped
+  DevBuf table, acc, occupied, compact_pts, compact_cov;
+  DevBuf keys[2];   // voxel keys, double buffered: keys[cur] belongs to the live map, the other one is what the next build fills
+  DevBuf counters;  // 2 sets of 16 ints, [0] num_voxels [1] dropped; set `cur` belongs to the live map
+  int cur = 0;
+  unsigned clean_cap = 0;  // keys[cur ^ 1], counter set cur ^ 1 and acc are clean (EMPTY / 0) over this capacity; 0 = unknown
+  int* counters_cur() const { return counters.as<int>() + 16 * cur; }
+  const unsigned long long* keys_cur() const { return keys[cur].as<unsigned long long>(); }
   bool valid = false;
   int nv_hint = -1;      // voxel count of the last build seen through a readback; sizes the next table
   // lazily fetched host copies (getters only)
@@ -77,7 +83,7 @@ struct VoxelMapDev {
   std::vector<int> h_occupied;
   std::unordered_map<int, int> bucket_to_index;
   void invalidate() { valid = false; host_valid = false; }
-  void release() { table.release(); acc.release(); occupied.release(); compact_pts.release(); compact_cov.release(); counters.release(); }
+  void release() { table.release(); acc.release(); occupied.release(); compact_pts.release(); compact_cov.release(); counters.release(); keys[0].release(); keys[1].release(); clean_cap = 0; }
 };
 
 struct Profiler {
@@ -499,23 +505,36 @@ int build_voxelmap(Engine* e, const CloudDev& c, VoxelMapDev& vm, double res, bo
   vm.res = res;
   vm.capacity = cap;
   vm.invalidate();
-  HIP_OR_FAIL(e, vm.table.ensure((size_t)cap * 64));
-  HIP_OR_FAIL(e, vm.acc.ensure((size_t)cap * VM_ACC_STRIDE * sizeof(double)));
+  {  // a reallocation hands back dirty memory
+    void* before[4] = {vm.keys[0].p, vm.keys[1].p, vm.acc.p, vm.counters.p};
+    HIP_OR_FAIL(e, vm.table.ensure((size_t)cap * 64));
+    HIP_OR_FAIL(e, vm.keys[0].ensure((size_t)cap * 8));
+    HIP_OR_FAIL(e, vm.keys[1].ensure((size_t)cap * 8));
+    HIP_OR_FAIL(e, vm.acc.ensure((size_t)cap * VM_ACC_STRIDE * sizeof(double)));
+    HIP_OR_FAIL(e, vm.counters.ensure(2 * 16 * sizeof(int)));
+    if (before[0] != vm.keys[0].p || before[1] != vm.keys[1].p || before[2] != vm.acc.p || before[3] != vm.counters.p) vm.clean_cap = 0;
+  }
   HIP_OR_FAIL(e, vm.occupied.ensure(sizeof(int) * (size_t)std::max(c.n, 1)));
-  HIP_OR_FAIL(e, vm.counters.ensure(64));
   if (want_compact) {
     HIP_OR_FAIL(e, vm.compact_pts.ensure(sizeof(float4) * (size_t)std::max(c.n, 1)));
     HIP_OR_FAIL(e, vm.compact_cov.ensure(sizeof(float4) * 2 * (size_t)std::max(c.n, 1)));
   }
   {
     ProfScope ps(e, "voxelmap");
-    vm_clear_kernel<<<(cap * 5 + 255) / 256, 256, 0, e->stream>>>(vm.table.as<uint4>(), vm.acc.as<double>(), cap, vm.counters.as<int>());
+    const int fill = vm.cur ^ 1;
+    unsigned long long* keys = vm.keys[fill].as<unsigned long long>();
+    int* counters = vm.counters.as<int>() + 16 * fill;
+    if (vm.clean_cap != cap) vm_clear_kernel<<<(cap * 5 + 255) / 256, 256, 0, e->stream>>>(keys, vm.acc.as<double>(), cap, counters);
+    vm.clean_cap = 0;  // keys[fill] is in use from here on; the finalize pass below makes the OTHER pair clean
     if (c.n) {
-      vm_accumulate_kernel<MODE><<<(c.n + 255) / 256, 256, 0, e->stream>>>(c.pts.as<float4>(), c.cov.as<float4>(), c.n, res, vm.table.as<unsigned long long>(), cap - 1,
-                                                                           vm.acc.as<double>(), vm.counters.as<int>() + 1, coherent_order(c));
-      vm_finalize_kernel<MODE><<<(cap + 255) / 256, 256, 0, e->stream>>>(vm.table.as<uint4>(), cap, vm.acc.as<double>(), vm.counters.as<int>(), vm.occupied.as<int>(),
-                                                                        want_compact ? vm.compact_pts.as<float4>() : nullptr, want_compact ? vm.compact_cov.as<float4>() : nullptr);
+      vm_accumulate_kernel<MODE><<<(c.n + 255) / 256, 256, 0, e->stream>>>(c.pts.as<float4>(), c.cov.as<float4>(), c.n, res, keys, cap - 1, vm.acc.as<double>(), counters + 1,
+                                                                           coherent_order(c));
+      vm_finalize_kernel<MODE><<<(cap + 255) / 256, 256, 0, e->stream>>>(keys, vm.table.as<uint4>(), cap, vm.acc.as<double>(), counters, vm.occupied.as<int>(),
+                                                                        want_compact ? vm.compact_pts.as<float4>() : nullptr, want_compact ? vm.compact_cov.as<float4>() : nullptr,
+                                                                        vm.keys[vm.cur].as<unsigned long long>(), vm.counters.as<int>() + 16 * vm.cur);
+      vm.clean_cap = cap;
     }
+    vm.cur = fill;
   }
   HIP_OR_FAIL(e, hipGetLastError());
   vm.valid = true;
@@ -527,7 +546,7 @@ int fetch_voxelmap_host(Engine* e, VoxelMapDev& vm) {
   if (!vm.valid) return e->fail(FVH_ERR_BAD_STATE, "voxel map not built");
   if (vm.host_valid) return FVH_OK;
   int counters[2] = {0, 0};
-  HIP_OR_FAIL(e, hipMemcpyAsync(counters, vm.counters.p, sizeof(counters), hipMemcpyDeviceToHost, e->stream));
+  HIP_OR_FAIL(e, hipMemcpyAsync(counters, vm.counters_cur(), sizeof(counters), hipMemcpyDeviceToHost, e->stream));
   HIP_OR_FAIL(e, hipStreamSynchronize(e->stream));
   vm.h_occupied.resize(counters[0]);
   vm.h_table.resize((size_t)vm.capacity * 4);
@@ -592,19 +611,24 @@ int launch_cost(Engine* e, const CostSource& src, const VoxelMapDev& vm, int hos
   CostParams P;
   std::memset(&P, 0, sizeof(P));
   P.src_pts = src.pts; P.src_cov = src.cov; P.d_n_src = src.d_n; P.n_src = src.n_upper; P.order = src.order;
-  P.table = vm.table.as<uint4>(); P.mask = vm.capacity - 1; P.res = vm.res;
+  P.table = vm.table.as<uint4>(); P.keys = vm.keys_cur(); P.mask = vm.capacity - 1; P.res = vm.res;
   const int n_off = src.n_off_override > 0 ? src.n_off_override : e->n_off;
   P.offsets = e->offsets_dev.as<int>(); P.n_off = n_off;
   static const long long target_items = [] { const char* v = getenv("FVH_COST_TARGET_ITEMS"); return v ? atoll(v) : 256LL * 256 * 2; }();
   static const int max_blocks = [] { const char* v = getenv("FVH_COST_MAX_BLOCKS"); int b = v ? atoi(v) : MAX_COST_BLOCKS; return b < 1 ? 1 : (b > MAX_COST_BLOCKS ? MAX_COST_BLOCKS : b); }();
-  int groups = (int)std::min<long long>(n_off, std::max<long long>(1, target_items / std::max(src.n_upper, 1)));
+  // A work item is (source element, group of offsets). Small clouds: enough items to cover the chip (target_items). Large
+  // clouds: still at most COST_CH..group_max offsets per item -- one thread walking all 27 offsets of its point left 24 %
+  // of the resident threads without work at 100k points and made the launch 18 % slower than 4 offsets per item
+  // (measured at 100k x DIRECT27: group 27: 423 us, 14: 426, 9: 361, 7: 386, 6: 368, 5: 423, 4: 358, 3: 355, 2: 459, 1: 615).
+  static const int group_max = [] { const char* v = getenv("FVH_COST_GROUP_MAX"); return v ? std::max(1, atoi(v)) : COST_CH; }();
+  int groups = (int)std::min<long long>(n_off, std::max<long long>((n_off + group_max - 1) / group_max, target_items / std::max(src.n_upper, 1)));
   P.group = (n_off + groups - 1) / groups;
   P.groups_per_src = (n_off + P.group - 1) / P.group;
   P.corr = e->corr.as<int>();
   P.corr_stride = (size_t)std::max(src.n_upper, 1) * n_off;
   P.host_corr_sel = e->corr_sel;
   P.st = e->state.as<LmState>(); P.partials = e->partials.as<double>(); P.ticket = e->ticket.as<unsigned>();
-  P.vm_counters = vm.counters.as<int>();
+  P.vm_counters = vm.counters_cur();
   P.vm_counters2 = src.counters2;
   P.host_phase = host_phase;
   P.defer_lm = (e->comm != nullptr) ? 1 : 0;
@@ -1080,7 +1104,7 @@ struct fvh_ndt {
   VoxelMapDev source_vm, target_vm;
   CostSource cost_source() const {
     if (distance_mode == FVH_NDT_P2D) return CostSource{source.pts.as<float4>(), nullptr, nullptr, source.n, nullptr, coherent_order(source)};
-    return CostSource{source_vm.compact_pts.as<float4>(), source_vm.compact_cov.as<float4>(), source_vm.counters.as<int>(), source.n, source_vm.counters.as<int>(), nullptr};
+    return CostSource{source_vm.compact_pts.as<float4>(), source_vm.compact_cov.as<float4>(), source_vm.counters_cur(), source.n, source_vm.counters_cur(), nullptr};
   }
   Rebuild rebuild_safe() {
     return [this] {

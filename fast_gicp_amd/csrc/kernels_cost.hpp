@@ -66,7 +66,8 @@ struct CostParams {
   const int* d_n_src;         // device-side count (D2D source voxels) or null
   const int* order;           // optional Morton permutation of the source: work item w handles element order[w] (coherent lookups)
   int n_src;
-  const uint4* table;
+  const uint4* table;                // voxel records (64 B per bucket)
+  const unsigned long long* keys;    // voxel keys of the same buckets, dense (kernels_voxelmap.hpp)
   unsigned mask;
   double res;
   const int* offsets;         // n_off x 3
@@ -321,11 +322,10 @@ __device__ __forceinline__ void accumulate_term(double* acc, const Vec3<Real>& q
 }
 
 // Continue a linear probe from `slot` (the first bucket has already been inspected).
-__device__ __forceinline__ int probe_continue(const uint4* __restrict__ table, unsigned mask, unsigned long long key, unsigned slot) {
+__device__ __forceinline__ int probe_continue(const unsigned long long* __restrict__ keys, unsigned mask, unsigned long long key, unsigned slot) {
   for (unsigned it = 0; it < mask; it++) {
     slot = (slot + 1) & mask;
-    const uint4 q0 = table[(size_t)slot * 4];
-    const unsigned long long k = (unsigned long long)q0.x | ((unsigned long long)q0.y << 32);
+    const unsigned long long k = keys[slot];
     if (k == key) return (int)slot;
     if (k == FVH_EMPTY_KEY) return -1;  // first empty bucket ends the probe (find_voxel_correspondences.cu:46-48)
   }
@@ -471,7 +471,7 @@ __global__ FVH_COST_BOUNDS void cost_kernel(CostParams P) {
       if (do_find) {
         unsigned long long key[COST_CH];
         unsigned slot[COST_CH];
-        uint4 q0[COST_CH];
+        unsigned long long k0[COST_CH];
         bool live[COST_CH];
 #pragma unroll
         for (int c = 0; c < COST_CH; c++) {
@@ -480,15 +480,15 @@ __global__ FVH_COST_BOUNDS void cost_kernel(CostParams P) {
           live[c] = (oc + c < o_end) && coord_in_range(x, y, z);
           key[c] = pack_key(x, y, z);
           slot[c] = hash_key(key[c]) & P.mask;
-          q0[c] = P.table[(size_t)slot[c] * 4];
+          k0[c] = P.keys[slot[c]];
         }
 #pragma unroll
         for (int c = 0; c < COST_CH; c++) {
-          const unsigned long long k = (unsigned long long)q0[c].x | ((unsigned long long)q0[c].y << 32);
+          const unsigned long long k = k0[c];
           int r = -1;
           if (live[c]) {
             if (k == key[c]) r = (int)slot[c];
-            else if (k != FVH_EMPTY_KEY) r = probe_continue(P.table, P.mask, key[c], slot[c]);  // rare at load <= 0.25
+            else if (k != FVH_EMPTY_KEY) r = probe_continue(P.keys, P.mask, key[c], slot[c]);  // rare at load <= 0.25
           }
           b[c] = r;
           if (oc + c < o_end) corr_new[(size_t)i * P.n_off + oc + c] = r;

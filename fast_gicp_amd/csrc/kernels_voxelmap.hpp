@@ -6,16 +6,22 @@
 // finalize_voxels_kernel / ndt_finalize_voxels_kernel  (src/fast_gicp/cuda/gaussian_voxelmap.cu:9-289).
 //
 // HBM layout
-//   table : capacity x 64-byte bucket. capacity = pow2 >= 4 x (voxel count of the previous build on
-//           this handle) so the table stays L2-resident (1,087 voxels -> 8,192 buckets = 512 KB instead
-//           of 4 MB); first build / overflow fallback: pow2 >= 2 * N_t, which can never overflow.
-//           No point is ever dropped: an exhausted probe budget is reported and the host rebuilds.
+//   keys  : capacity x u64 voxel key (EMPTY = ~0). capacity = pow2 >= 4 x (voxel count of the previous
+//           build on this handle); first build / overflow fallback: pow2 >= 2 * N_t, which can never
+//           overflow. No point is ever dropped: an exhausted probe budget is reported and the host rebuilds.
+//           The keys are their own dense array because most probes of the cost kernel MISS (DIRECT27 on
+//           a 100k-point scene: 65 %): a miss touches 8 B of a 2 MB array that stays in the XCD's L2
+//           instead of a 64-B line of a 16 MB table.
+//   table : capacity x 64-byte voxel record, bucket index == key slot (no id indirection):
 //           q0 = {key_lo, key_hi, num_points, 0}   q1 = {mean.xyz, (float)num_points}
 //           q2 = {c_xx, c_xy, c_xz, c_yy}          q3 = {c_yz, c_zz, 0, 0}
-//           -> a probe that hits finds key AND the voxel record in one 64-B line (no id indirection,
-//              the bucket index *is* the voxel id).
+//           Only occupied buckets are ever written or (meaningfully) read: the table is never cleared.
 //   acc   : capacity x 10 doubles scratch {sum p (3), sum C or sum pp^T (6), count}; fp64 so the
 //           result is independent of the atomic arrival order to ~1e-16.
+//   The keys (and the two counters) are double buffered and the finalize pass of build N clears the
+//   buffers build N+1 will fill and zeroes the accumulators it consumed, so a steady-state rebuild
+//   (swapSourceAndTarget in the reference's loop) is two launches; vm_clear_kernel only runs for the
+//   first build at a capacity.
 //
 // Pass 1 (vm_accumulate): one point per thread. Each workgroup first aggregates its 256 points in
 // an LDS mini hash table (ds_cmpst_rtn_b64 claim + ds_add_f64), then flushes each occupied LDS slot
@@ -33,11 +39,11 @@ constexpr int VM_LDS_PROBES = 8;
 constexpr int VM_ACC_STRIDE = 10;
 constexpr unsigned VM_MAX_PROBE = 255;
 
-__device__ __forceinline__ unsigned global_claim(unsigned long long* table_keys64 /* bucket stride = 8 u64 */, unsigned mask, unsigned long long key) {
+__device__ __forceinline__ unsigned global_claim(unsigned long long* keys, unsigned mask, unsigned long long key) {
   unsigned slot = hash_key(key) & mask;
   const unsigned max_probe = mask < VM_MAX_PROBE ? mask : VM_MAX_PROBE;
   for (unsigned it = 0; it <= max_probe; it++) {
-    unsigned long long* addr = table_keys64 + (size_t)slot * 8;
+    unsigned long long* addr = keys + slot;
     unsigned long long cur = __hip_atomic_load(addr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (cur == key) return slot;
     if (cur == FVH_EMPTY_KEY) {
@@ -49,10 +55,10 @@ __device__ __forceinline__ unsigned global_claim(unsigned long long* table_keys6
   return 0xFFFFFFFFu;  // probe budget exhausted: the caller counts it in `dropped` and the host rebuilds at the safe size
 }
 
-// one launch instead of three fills: every bucket key -> EMPTY (whole 64-B bucket = 0xFF), accumulators and counters -> 0
-__global__ __launch_bounds__(256) void vm_clear_kernel(uint4* __restrict__ table, double* __restrict__ acc, unsigned capacity, int* __restrict__ counters) {
-  const unsigned i = blockIdx.x * 256 + threadIdx.x;  // one 16-byte quad of the table per thread
-  if (i < capacity * 4) table[i] = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);
+// first build at a capacity (afterwards vm_finalize_kernel leaves everything clean): keys -> EMPTY, accumulators and counters -> 0
+__global__ __launch_bounds__(256) void vm_clear_kernel(unsigned long long* __restrict__ keys, double* __restrict__ acc, unsigned capacity, int* __restrict__ counters) {
+  const unsigned i = blockIdx.x * 256 + threadIdx.x;
+  if (i < capacity) keys[i] = FVH_EMPTY_KEY;
   if (i < capacity * 5) reinterpret_cast<uint4*>(acc)[i] = make_uint4(0, 0, 0, 0);  // 10 doubles = 5 quads per bucket
   if (i < 16) counters[i] = 0;
 }
@@ -128,14 +134,27 @@ __global__ __launch_bounds__(256) void vm_accumulate_kernel(const float4* __rest
 // gaussian_voxelmap.cu:164-171). MODE 1: ndt_finalize_voxels_kernel (gaussian_voxelmap.cu:184-193)
 // + MIN_EIG regularisation (ndt_cuda.cu:128,139).
 template <int MODE>
-__global__ __launch_bounds__(256) void vm_finalize_kernel(uint4* __restrict__ table, unsigned capacity, const double* __restrict__ acc, int* __restrict__ num_voxels,
-                                                          int* __restrict__ occupied, float4* __restrict__ compact_pts, float4* __restrict__ compact_cov) {
+__global__ __launch_bounds__(256) void vm_finalize_kernel(const unsigned long long* __restrict__ keys, uint4* __restrict__ table, unsigned capacity, double* __restrict__ acc,
+                                                          int* __restrict__ num_voxels, int* __restrict__ occupied, float4* __restrict__ compact_pts, float4* __restrict__ compact_cov,
+                                                          unsigned long long* __restrict__ next_keys, int* __restrict__ next_counters) {
   const unsigned b = blockIdx.x * 256 + threadIdx.x;
   if (b >= capacity) return;
-  uint4 q0 = table[(size_t)b * 4];
-  const unsigned long long key = (unsigned long long)q0.x | ((unsigned long long)q0.y << 32);
+  next_keys[b] = FVH_EMPTY_KEY;  // the buffers of the NEXT build (the map before this one is dead)
+  if (b < 16) next_counters[b] = 0;
+  const unsigned long long key = keys[b];
   if (key == FVH_EMPTY_KEY) return;
-  const double* a = acc + (size_t)b * VM_ACC_STRIDE;
+  uint4 q0 = make_uint4((unsigned)key, (unsigned)(key >> 32), 0u, 0u);
+  double a[VM_ACC_STRIDE];
+  {
+    uint4* aq = reinterpret_cast<uint4*>(acc + (size_t)b * VM_ACC_STRIDE);  // 80 B per bucket, 16-B aligned
+#pragma unroll
+    for (int j = 0; j < VM_ACC_STRIDE / 2; j++) {
+      const uint4 v = aq[j];
+      a[2 * j] = __hiloint2double((int)v.y, (int)v.x);
+      a[2 * j + 1] = __hiloint2double((int)v.w, (int)v.z);
+      aq[j] = make_uint4(0, 0, 0, 0);  // consumed: clean for the next build
+    }
+  }
   const double cnt = a[9];
   const double inv = 1.0 / cnt;
   const double mx = a[0] * inv, my = a[1] * inv, mz = a[2] * inv;
