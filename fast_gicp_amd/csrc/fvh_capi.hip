@@ -359,13 +359,18 @@ int ensure_sorted(Engine* e, CloudDev& c) {
     c.has_sorted = true;
     return FVH_OK;
   }
-  unsigned* box = reinterpret_cast<unsigned*>(e->sort_keys.as<unsigned>() + 2 * (size_t)n);
-  HIP_OR_FAIL(e, hipMemsetAsync(box, 0xFF, 12, e->stream));
-  HIP_OR_FAIL(e, hipMemsetAsync(box + 3, 0, 12, e->stream));
-  cloud_bbox_kernel<<<std::min(256, (n + 255) / 256), 256, 0, e->stream>>>(c.pts.as<float4>(), n, box);
   unsigned* keys[2] = {e->sort_keys.as<unsigned>(), e->sort_keys.as<unsigned>() + n};
   int* idx[2] = {e->sort_idx.as<int>(), c.order.as<int>()};  // 3 passes: the final permutation lands in idx[1] = the cloud's own buffer
-  morton_keys_kernel<<<(n + 255) / 256, 256, 0, e->stream>>>(c.pts.as<float4>(), n, box, keys[0], idx[0]);
+  const bool packed_box = c.has_box;  // the upload already reduced the bounding cube (pack_points_kernel): no memsets, no extra pass over the cloud
+  if (packed_box) {
+    morton_keys_kernel<<<(n + 255) / 256, 256, 0, e->stream>>>(c.pts.as<float4>(), n, c.box.as<unsigned>(), keys[0], idx[0], 1);
+  } else {
+    unsigned* box = reinterpret_cast<unsigned*>(e->sort_keys.as<unsigned>() + 2 * (size_t)n);
+    HIP_OR_FAIL(e, hipMemsetAsync(box, 0xFF, 12, e->stream));
+    HIP_OR_FAIL(e, hipMemsetAsync(box + 3, 0, 12, e->stream));
+    cloud_bbox_kernel<<<std::min(256, (n + 255) / 256), 256, 0, e->stream>>>(c.pts.as<float4>(), n, box);
+    morton_keys_kernel<<<(n + 255) / 256, 256, 0, e->stream>>>(c.pts.as<float4>(), n, box, keys[0], idx[0], 0);
+  }
   const int wblocks = (nwaves + 3) / 4;
   for (int pass = 0; pass < RADIX_PASSES; pass++) {
     const int in = pass & 1, out = in ^ 1, shift = pass * RADIX_BITS;
@@ -380,8 +385,9 @@ int ensure_sorted(Engine* e, CloudDev& c) {
   tile_bbox_kernel<<<(ntiles + 3) / 4, 256, 0, e->stream>>>(c.sorted.as<float4>(), n, c.bbox.as<float4>());
   const int nsuper = (ntiles + 63) / 64;
   HIP_OR_FAIL(e, c.bbox2.ensure(sizeof(float4) * 2 * (size_t)nsuper));
-  super_bbox_kernel<<<(nsuper + 3) / 4, 256, 0, e->stream>>>(c.bbox.as<float4>(), ntiles, c.bbox2.as<float4>());
+  super_bbox_kernel<<<(nsuper + 3) / 4, 256, 0, e->stream>>>(c.bbox.as<float4>(), ntiles, c.bbox2.as<float4>(), packed_box ? c.box.as<unsigned>() : nullptr);
   HIP_OR_FAIL(e, hipGetLastError());
+  if (packed_box) { c.has_box = false; c.box_dirty = false; }  // consumed by the key kernel, zeroed again by the last kernel of the chain
   c.has_sorted = true;
   return FVH_OK;
 }

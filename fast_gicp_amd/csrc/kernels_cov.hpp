@@ -196,7 +196,9 @@ __device__ __forceinline__ float box_gap_sq(const float4& bl, const float4& bh, 
 }
 
 // boxes of 64 consecutive level-1 boxes (one wave per super tile)
-__global__ __launch_bounds__(256) void super_bbox_kernel(const float4* __restrict__ bbox1, int ntiles, float4* __restrict__ bbox2) {
+__global__ __launch_bounds__(256) void super_bbox_kernel(const float4* __restrict__ bbox1, int ntiles, float4* __restrict__ bbox2,
+                                                         unsigned* __restrict__ clear_box = nullptr /* the cloud's bounding cube, consumed earlier in the chain: left zeroed for the next upload */) {
+  if (clear_box && blockIdx.x == 0 && threadIdx.x < 6) clear_box[threadIdx.x] = 0u;
   const int lane = threadIdx.x & 63;
   const int s = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (s * 64 >= ntiles) return;

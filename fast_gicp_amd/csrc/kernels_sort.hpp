@@ -57,11 +57,13 @@ __device__ __forceinline__ unsigned spread3_9(unsigned v) {  // 9 bits -> every 
   return v;
 }
 
+// min_inverted: the box comes from pack_points_kernel (box[0..2] = ~ordered(min)), not from cloud_bbox_kernel
 __global__ __launch_bounds__(256) void morton_keys_kernel(const float4* __restrict__ pts, int n, const unsigned* __restrict__ box, unsigned* __restrict__ keys,
-                                                          int* __restrict__ idx) {
+                                                          int* __restrict__ idx, int min_inverted) {
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
-  const float lx = ordered_to_float(box[0]), ly = ordered_to_float(box[1]), lz = ordered_to_float(box[2]);
+  const unsigned flip = min_inverted ? 0xFFFFFFFFu : 0u;
+  const float lx = ordered_to_float(box[0] ^ flip), ly = ordered_to_float(box[1] ^ flip), lz = ordered_to_float(box[2] ^ flip);
   const float ex = ordered_to_float(box[3]) - lx, ey = ordered_to_float(box[4]) - ly, ez = ordered_to_float(box[5]) - lz;
   const float extent = fmaxf(fmaxf(ex, ey), fmaxf(ez, 1e-6f));
   const float scale = 511.999f / extent;  // cubic cells so the key is isotropic

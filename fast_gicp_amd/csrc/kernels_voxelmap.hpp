@@ -177,7 +177,12 @@ __global__ __launch_bounds__(256) void vm_finalize_kernel(const unsigned long lo
   tf[(size_t)b * 4 + 1] = q1;
   tf[(size_t)b * 4 + 2] = q2;
   tf[(size_t)b * 4 + 3] = q3;
-  const int id = atomicAdd(num_voxels, 1);
+  // one atomic per wave, not per voxel: 60k same-address atomics made this kernel 50 us on a 100k-point scene
+  const unsigned long long live = __ballot(1);
+  const int lane = threadIdx.x & 63, leader = __ffsll((long long)live) - 1;
+  int base = 0;
+  if (lane == leader) base = atomicAdd(num_voxels, __popcll(live));
+  const int id = __shfl(base, leader) + __popcll(live & ((1ull << lane) - 1ull));
   occupied[id] = (int)b;
   if (compact_pts) {  // D2D NDT: the source voxels are the "source cloud"
     compact_pts[id] = make_float4((float)mx, (float)my, (float)mz, 0.f);
