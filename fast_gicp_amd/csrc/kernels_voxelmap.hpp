@@ -39,20 +39,19 @@ constexpr int VM_LDS_PROBES = 8;
 constexpr int VM_ACC_STRIDE = 10;
 constexpr unsigned VM_MAX_PROBE = 255;
 
-__device__ __forceinline__ unsigned global_claim(unsigned long long* keys, unsigned mask, unsigned long long key) {
-  unsigned slot = hash_key(key) & mask;
+// Claim (or find) the bucket of `key`, linear probing from `slot`. CAS first: an atomic goes to the memory side (the
+// XCDs' L2s are not coherent), ~2 us per round trip, and the CAS alone answers both "free" and "already this key".
+__device__ __forceinline__ unsigned global_claim_from(unsigned long long* keys, unsigned mask, unsigned long long key, unsigned slot, unsigned probes_done) {
   const unsigned max_probe = mask < VM_MAX_PROBE ? mask : VM_MAX_PROBE;
-  for (unsigned it = 0; it <= max_probe; it++) {
-    unsigned long long* addr = keys + slot;
-    unsigned long long cur = __hip_atomic_load(addr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (cur == key) return slot;
-    if (cur == FVH_EMPTY_KEY) {
-      unsigned long long old = atomicCAS(addr, FVH_EMPTY_KEY, key);
-      if (old == FVH_EMPTY_KEY || old == key) return slot;
-    }
+  for (unsigned it = probes_done; it <= max_probe; it++) {
+    const unsigned long long old = atomicCAS(keys + slot, FVH_EMPTY_KEY, key);
+    if (old == FVH_EMPTY_KEY || old == key) return slot;
     slot = (slot + 1) & mask;
   }
   return 0xFFFFFFFFu;  // probe budget exhausted: the caller counts it in `dropped` and the host rebuilds at the safe size
+}
+__device__ __forceinline__ unsigned global_claim(unsigned long long* keys, unsigned mask, unsigned long long key) {
+  return global_claim_from(keys, mask, key, hash_key(key) & mask, 0);
 }
 
 // first build at a capacity (afterwards vm_finalize_kernel leaves everything clean): keys -> EMPTY, accumulators and counters -> 0
@@ -119,11 +118,24 @@ __global__ __launch_bounds__(256) void vm_accumulate_kernel(const float4* __rest
     }
   }
   __syncthreads();
-  // flush: one global claim + 10 fp64 atomics per (workgroup, voxel)
-  for (int s = tid; s < VM_LDS_SLOTS; s += 256) {
-    const unsigned long long key = lkey[s];
-    if (key == FVH_EMPTY_KEY) continue;
-    unsigned b = global_claim(table_keys, mask, key);
+  // flush: one global claim + 10 fp64 atomics per (workgroup, voxel). A thread owns two LDS slots: the first probes of
+  // both are in flight together (each is a memory-side round trip).
+  static_assert(VM_LDS_SLOTS == 512, "two LDS slots per thread of a 256-thread workgroup");
+  unsigned long long fk[2], fold[2];
+  unsigned fslot[2];
+#pragma unroll
+  for (int u = 0; u < 2; u++) {
+    fk[u] = lkey[tid + 256 * u];
+    fslot[u] = hash_key(fk[u]) & mask;
+    fold[u] = FVH_EMPTY_KEY;
+    if (fk[u] != FVH_EMPTY_KEY) fold[u] = atomicCAS(table_keys + fslot[u], FVH_EMPTY_KEY, fk[u]);
+  }
+#pragma unroll
+  for (int u = 0; u < 2; u++) {
+    if (fk[u] == FVH_EMPTY_KEY) continue;
+    const int s = tid + 256 * u;
+    unsigned b = fslot[u];
+    if (fold[u] != FVH_EMPTY_KEY && fold[u] != fk[u]) b = global_claim_from(table_keys, mask, fk[u], (fslot[u] + 1) & mask, 1);
     if (b == 0xFFFFFFFFu) { atomicAdd(dropped, 1); continue; }
 #pragma unroll
     for (int j = 0; j < VM_ACC_STRIDE; j++) atomicAdd(&acc[(size_t)b * VM_ACC_STRIDE + j], lacc[s * VM_ACC_STRIDE + j]);
