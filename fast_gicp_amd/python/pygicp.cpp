@@ -152,6 +152,19 @@ static py::array_t<double> align_points(const Points& target, const Points& sour
   return out;
 }
 
+static py::array_t<double> covs_to_numpy(const GICP::Covariances& covs) {
+  py::array_t<double> out({(py::ssize_t)covs.size(), (py::ssize_t)3, (py::ssize_t)3});
+  double* o = out.mutable_data();
+  for (size_t i = 0; i < covs.size(); i++) std::memcpy(o + 9 * i, covs[i].data(), 9 * sizeof(double));
+  return out;
+}
+static GICP::Covariances numpy_to_covs(const py::array_t<double, py::array::c_style | py::array::forcecast>& c) {
+  if (c.ndim() != 3 || c.shape(1) != 3 || c.shape(2) != 3) throw std::invalid_argument("covariances must be an (N, 3, 3) array");
+  GICP::Covariances covs((size_t)c.shape(0));
+  for (size_t i = 0; i < covs.size(); i++) std::memcpy(covs[i].data(), c.data() + 9 * i, 9 * sizeof(double));
+  return covs;
+}
+
 PYBIND11_MODULE(pygicp, m) {
   m.doc() = "pygicp on the MI355X HIP engine (surface of koide3/fast_gicp src/python/main.cpp)";
   m.def("downsample", &downsample, "downsample points", py::arg("points"), py::arg("downsample_resolution"));
@@ -210,7 +223,12 @@ PYBIND11_MODULE(pygicp, m) {
       .def("set_num_threads", &GICP::setNumThreads)
       .def("set_correspondence_randomness", &GICP::setCorrespondenceRandomness)
       .def("set_max_correspondence_distance", &GICP::setMaxCorrespondenceDistance)
-      .def("set_regularization_method", [](GICP& g, const std::string& s) { g.setRegularizationMethod(regularization_method(s)); });
+      .def("set_regularization_method", [](GICP& g, const std::string& s) { g.setRegularizationMethod(regularization_method(s)); })
+      // not in the reference's bindings (its C++ class has them: gicp/fast_gicp.hpp:60-70): (N, 3, 3) arrays
+      .def("get_source_covariances", [](GICP& g) { return covs_to_numpy(g.getSourceCovariances()); })
+      .def("get_target_covariances", [](GICP& g) { return covs_to_numpy(g.getTargetCovariances()); })
+      .def("set_source_covariances", [](GICP& g, const py::array_t<double, py::array::c_style | py::array::forcecast>& c) { g.setSourceCovariances(numpy_to_covs(c)); })
+      .def("set_target_covariances", [](GICP& g, const py::array_t<double, py::array::c_style | py::array::forcecast>& c) { g.setTargetCovariances(numpy_to_covs(c)); });
 
   // The reference's CPU class name, served by the GPU engine in its fp64 CPU-parity arithmetic.
   m.attr("FastVGICP") = m.attr("FastVGICPCuda");

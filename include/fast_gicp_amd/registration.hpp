@@ -494,6 +494,20 @@ public:
     call(fvh_vgicp_find_target_neighbors(core_, k_correspondences_), "find_target_neighbors");
     call(fvh_vgicp_calculate_target_covariances(core_, (int)regularization_method_), "calculate_target_covariances");
   }
+  /// gicp/fast_gicp.hpp:60-70: covariances computed elsewhere / read back. The reference carries them as 4x4 doubles with a
+  /// zero last row and column; here a covariance is its 3x3 block, 9 doubles per point (symmetric, so any major).
+  using Covariances = std::vector<std::array<double, 9>>;
+  void setSourceCovariances(const Covariances& covs) {
+    if (!input_ || covs.size() != input_->size()) throw std::invalid_argument("setSourceCovariances: one covariance per source point, after setInputSource");
+    call(fvh_vgicp_set_source_covariances(core_, covs.empty() ? nullptr : covs[0].data()), "set_source_covariances");
+  }
+  void setTargetCovariances(const Covariances& covs) {
+    if (!target_ || covs.size() != target_->size()) throw std::invalid_argument("setTargetCovariances: one covariance per target point, after setInputTarget");
+    call(fvh_vgicp_set_target_covariances(core_, covs.empty() ? nullptr : covs[0].data()), "set_target_covariances");
+  }
+  Covariances getSourceCovariances() const { return get_covariances(input_ ? input_->size() : 0, true); }
+  Covariances getTargetCovariances() const { return get_covariances(target_ ? target_->size() : 0, false); }
+
   double getFitnessScore(double max_range = std::numeric_limits<double>::max()) override {
     double T16[16], score = 0;
     Isometry3d::from(this->final_transformation_).to_colmajor16(T16);
@@ -503,6 +517,13 @@ public:
   fvh_vgicp* core() { return core_; }
 
 protected:
+  Covariances get_covariances(size_t n, bool source) const {
+    std::vector<float> f(9 * n);
+    if (n) call(source ? fvh_vgicp_get_source_covariances(core_, f.data()) : fvh_vgicp_get_target_covariances(core_, f.data()), "get_covariances");
+    Covariances out(n);
+    for (size_t i = 0; i < n; i++) for (int j = 0; j < 9; j++) out[i][j] = f[9 * i + j];
+    return out;
+  }
   double linearize(const Isometry3d& trans, Matrix6d* H, Vector6d* b) override {  // :159-213
     double T16[16], err = 0, Hc[36];
     trans.to_colmajor16(T16);

@@ -94,3 +94,28 @@ def test_rbf_kernel_mode(pygicp, data):
     reg.set_kernel_width(0.5)
     reg.set_input_target(target); reg.set_input_source(source)
     _check(gt, reg.align(), reg.has_converged(), "RBF")
+
+
+def test_fast_gicp_covariance_accessors(pygicp, data):
+    """gicp/fast_gicp.hpp:60-70: get*Covariances returns what setInput* estimated (k-NN + PLANE: eigenvalues 1e-3, 1, 1);
+    set*Covariances replaces them -- feeding the read-back values gives the same alignment, isotropic ones a different one."""
+    target, source, gt = data
+    reg = pygicp.FastGICP()
+    reg.set_input_target(target); reg.set_input_source(source)
+    T0 = reg.align()
+    cs, ct = reg.get_source_covariances(), reg.get_target_covariances()
+    assert cs.shape == (len(source), 3, 3) and ct.shape == (len(target), 3, 3)
+    assert np.allclose(cs, np.swapaxes(cs, 1, 2))
+    w = np.linalg.eigvalsh(cs[::97])
+    assert np.allclose(w, [1e-3, 1.0, 1.0], atol=1e-4)
+    reg2 = pygicp.FastGICP()
+    reg2.set_input_target(target); reg2.set_input_source(source)
+    reg2.set_source_covariances(cs); reg2.set_target_covariances(ct)
+    T1 = reg2.align()
+    assert util.rel_err(T1, T0) < 1e-6
+    reg2.set_source_covariances(np.tile(np.eye(3), (len(source), 1, 1))); reg2.set_target_covariances(np.tile(np.eye(3), (len(target), 1, 1)))
+    T2 = reg2.align()  # plain point-to-point ICP weights
+    _check(gt, T2, reg2.has_converged(), "isotropic covariances")
+    assert util.rel_err(T2, T0) > 1e-6
+    with pytest.raises(Exception):
+        reg2.set_source_covariances(cs[:10])
