@@ -187,12 +187,12 @@ struct Engine {
     if ((e = ticket.ensure(64)) != hipSuccess) return hipfail(e, "hipMalloc");
     if ((e = pticket.ensure(PERSIST_TICKET_BYTES)) != hipSuccess) return hipfail(e, "hipMalloc");
     if ((e = bcast.ensure(sizeof(double) * PERSIST_REPLICAS * BCAST_SLOTS)) != hipSuccess) return hipfail(e, "hipMalloc");
-    (void)hipMemsetAsync(bcast.p, 0, sizeof(double) * PERSIST_REPLICAS * BCAST_SLOTS, stream);
+    if ((e = hipMemsetAsync(bcast.p, 0, sizeof(double) * PERSIST_REPLICAS * BCAST_SLOTS, stream)) != hipSuccess) return hipfail(e, "hipMemsetAsync");
     if ((e = misc.ensure(256)) != hipSuccess) return hipfail(e, "hipMalloc");
     if ((e = fit.ensure(64)) != hipSuccess) return hipfail(e, "hipMalloc");
-    (void)hipMemsetAsync(state.p, 0, sizeof(LmState), stream);
-    (void)hipMemsetAsync(ticket.p, 0, 64, stream);
-    (void)hipMemsetAsync(misc.p, 0, 256, stream);
+    if ((e = hipMemsetAsync(state.p, 0, sizeof(LmState), stream)) != hipSuccess) return hipfail(e, "hipMemsetAsync");
+    if ((e = hipMemsetAsync(ticket.p, 0, 64, stream)) != hipSuccess) return hipfail(e, "hipMemsetAsync");
+    if ((e = hipMemsetAsync(misc.p, 0, 256, stream)) != hipSuccess) return hipfail(e, "hipMemsetAsync");
     std::memset(&lin, 0, sizeof(lin));
     lin.r[0] = lin.r[4] = lin.r[8] = 1.0;
     int rc = upload_offsets();
