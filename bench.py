@@ -460,6 +460,12 @@ def main():
         ms, _ = g.bench(tgt, src, 2, loops)
         cpu = {"value": round(loops / (ms * 1e-3), 3), "unit": "registrations/sec", "cores": cores, "kind": "port",
                "sample": "%d iterations of the 100times_reuse loop on the same pair/config (oracle/liboracle.so, OpenMP, %d threads)" % (loops, cores)}
+        if args.workload == "bundled17k":  # OMP_NUM_THREADS in {1, nproc}
+            g1 = O.FastVGICP(threads=1, search={"DIRECT27": O.DIRECT27, "DIRECT7": O.DIRECT7, "DIRECT1": O.DIRECT1}[args.search], resolution=res,
+                             cov_mode=1 if args.cov == "rbf" else 0, kernel_width=0.5, kernel_max_dist=2.5)
+            g1.bench(tgt, src, 0, 1)
+            ms1, _ = g1.bench(tgt, src, 2, 5)
+            cpu["single_thread"] = {"value": round(5 / (ms1 * 1e-3), 3), "unit": "registrations/sec", "cores": 1, "sample": "5 iterations of the same loop, 1 thread"}
 
     conc = None
     if args.streams > 1 and world == 1 and args.cov == "knn" and args.workload != "synth1m":
