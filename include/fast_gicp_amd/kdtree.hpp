@@ -1,7 +1,9 @@
 // Exact k-NN on the host for NearestNeighborMethod::CPU_PARALLEL_KDTREE -- stands in for
 // pcl::search::KdTree / FLANN in FastVGICPCuda::find_neighbors_parallel_kdtree
 // (impl/fast_vgicp_cuda_impl.hpp:152-167). Node-less median kd-tree: the points' permutation IS the
-// tree (the median of every index range is its node), only the split axis per node is stored.
+// tree (the median of every index range is its node), only the split axis per node is stored. The
+// points are copied once in tree order so that a leaf scan reads consecutive memory, and a query
+// keeps its candidate list on the stack (a heap allocation per query serialised the OpenMP loop).
 // Distances are fp32 ((dx*dx + dy*dy) + dz*dz) with ties to the lower index, the same total order the
 // device k-NN uses, so both neighbour methods yield identical index sets.
 #pragma once
@@ -29,16 +31,24 @@ inline int omp_threads_for(int n) {
 
 class KdTree {
 public:
-  KdTree(const float* xyz, int n) : xyz_(xyz), n_(n), perm_(n), axis_(n, 0) {
+  KdTree(const float* xyz, int n) : xyz_(xyz), n_(n), perm_(n), axis_(n, 0), sorted_(3 * (size_t)n) {
     std::iota(perm_.begin(), perm_.end(), 0);
     if (n > 0) build(0, n);
+    for (int i = 0; i < n; i++)
+      for (int a = 0; a < 3; a++) sorted_[3 * (size_t)i + a] = xyz[3 * (size_t)perm_[i] + a];
   }
 
   /// k nearest neighbours of q (ascending (distance, index)); out has k entries (-1 padded if n < k)
   void knn(const float* q, int k, int* out) const {
-    std::vector<float> d(k);
-    std::vector<int> id(k);
-    Best best{k, 0, d.data(), id.data()};
+    constexpr int kStack = 64;
+    float dstack[kStack];
+    int istack[kStack];
+    std::vector<float> dheap;
+    std::vector<int> iheap;
+    float* d = dstack;
+    int* id = istack;
+    if (k > kStack) { dheap.resize(k); iheap.resize(k); d = dheap.data(); id = iheap.data(); }
+    Best best{k, 0, d, id};
     if (n_ > 0) search(0, n_, q, best);
     for (int j = 0; j < k; j++) out[j] = j < best.count ? best.i[j] : -1;
   }
@@ -89,14 +99,14 @@ private:
 
   void search(int lo, int hi, const float* q, Best& best) const {
     if (hi - lo <= kLeaf) {
-      for (int i = lo; i < hi; i++) best.offer(sqdist(&xyz_[3 * (size_t)perm_[i]], q), perm_[i]);
+      for (int i = lo; i < hi; i++) best.offer(sqdist(&sorted_[3 * (size_t)i], q), perm_[i]);
       return;
     }
     const int mid = lo + (hi - lo) / 2;
     const int ax = axis_[mid];
-    const int pm = perm_[mid];
-    best.offer(sqdist(&xyz_[3 * (size_t)pm], q), pm);
-    const float diff = q[ax] - xyz_[3 * (size_t)pm + ax];
+    const float* pmid = &sorted_[3 * (size_t)mid];
+    best.offer(sqdist(pmid, q), perm_[mid]);
+    const float diff = q[ax] - pmid[ax];
     if (diff < 0) {
       search(lo, mid, q, best);
       if (!best.full() || diff * diff <= best.worst()) search(mid + 1, hi, q, best);
@@ -111,6 +121,7 @@ private:
   int n_;
   std::vector<int> perm_;
   std::vector<unsigned char> axis_;
+  std::vector<float> sorted_;  // the points in tree order (xyz of perm_[i] at 3 i)
 };
 
 }  // namespace host
