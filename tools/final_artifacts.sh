@@ -14,7 +14,7 @@ F=$(find $O/pmc_FETCH_SIZE -name "*counter_collection.csv" | head -1)
 W=$(find $O/pmc_WRITE_SIZE -name "*counter_collection.csv" | head -1)
 if [ -n "$F" ] && [ -n "$W" ]; then
   timeout 30 python tools/pmc_traffic.py $O/pmc_new.json bundled17k_persistent:cost_kernel:$F:$W > /dev/null 2>$O/pmc_traffic.err < /dev/null
-  timeout 30 python - <<PY < /dev/null
+  timeout 30 python - <<PY
 import json
 p = "$R/profiles/r01_pmc_cost_kernel.json"
 d = json.load(open(p)); n = json.load(open("$O/pmc_new.json"))
