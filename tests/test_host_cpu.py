@@ -58,3 +58,14 @@ def test_engine_without_gpu_raises(pygicp):
         pygicp.FastVGICPCuda()
     with pytest.raises(RuntimeError):
         pygicp.NDTCuda()
+
+
+def test_bench_deadline_helper_abandons_a_stuck_leg():
+    """bench.py --gpus N: the extra spatially sharded leg runs under a deadline so that a stuck collective cannot take the
+    already measured headline line with it."""
+    import time
+    import bench
+    assert bench.run_with_deadline(lambda: {"ok": 1}, 5) == ({"ok": 1}, False)
+    t0 = time.perf_counter()
+    res, hung = bench.run_with_deadline(lambda: time.sleep(30), 0.2)
+    assert res is None and hung and time.perf_counter() - t0 < 5
