@@ -339,6 +339,10 @@ class VGICPCore(_Core):
         self._call("debug_get_table_capacity", C.byref(n))
         return n.value
 
+    def debug_skipped_points(self):
+        n = C.c_int(0)
+        self._call("debug_get_skipped_points", C.byref(n))
+        return n.value
 
 
 class VoxelGrid:

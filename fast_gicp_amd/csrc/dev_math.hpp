@@ -202,6 +202,13 @@ __host__ __device__ __forceinline__ void unpack_key(unsigned long long k, int& x
 __device__ __forceinline__ bool coord_in_range(int x, int y, int z) {
   return (unsigned)(x + FVH_COORD_BIAS) < (1u << 21) && (unsigned)(y + FVH_COORD_BIAS) < (1u << 21) && (unsigned)(z + FVH_COORD_BIAS) < (1u << 21);
 }
+// (int)floor(v) is undefined for NaN/inf/huge v (a lidar return at infinity, a 1e9 outlier): test the floating value first.
+// |f| < 2^20 - 2^12 leaves room for any neighbour offset the engine accepts and keeps the key inside its 21 bits.
+template <typename T>
+__device__ __forceinline__ bool voxel_index_ok(T fx, T fy, T fz) {
+  const T lim = (T)(FVH_COORD_BIAS - 4096);
+  return fabs(fx) < lim && fabs(fy) < lim && fabs(fz) < lim;  // false for NaN
+}
 // 64-bit mix (murmur3 finaliser); the bucket layout is private so the hash is ours to choose
 __device__ __forceinline__ unsigned hash_key(unsigned long long k) {
   k ^= k >> 33;

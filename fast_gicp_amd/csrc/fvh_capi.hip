@@ -77,6 +77,7 @@ struct VoxelMapDev {
   const unsigned long long* keys_cur() const { return keys[cur].as<unsigned long long>(); }
   bool valid = false;
   int nv_hint = -1;      // voxel count of the last build seen through a readback; sizes the next table
+  int num_skipped = 0;   // points of the last fetched build that belong to no voxel (non-finite / out of the 21-bit range)
   // lazily fetched host copies (getters only)
   bool host_valid = false;
   std::vector<uint4> h_table;
@@ -306,6 +307,9 @@ int upload_cloud(Engine* e, CloudDev& c, const float* xyz, int n, int stride, bo
 int set_neighbors(Engine* e, CloudDev& c, int k, const int* idx) {
   if (!c.has_pts) return e->fail(FVH_ERR_BAD_STATE, "set_neighbors: cloud not set");
   if (k <= 0 || !idx) return e->fail(FVH_ERR_INVALID_ARGUMENT, "set_neighbors: bad k / null");
+  // the covariance kernel gathers pts[idx]: an index outside [0, n) (e.g. a -1 pad of a k-NN on fewer than k points) must not reach it
+  for (size_t j = 0, m = (size_t)c.n * k; j < m; j++)
+    if ((unsigned)idx[j] >= (unsigned)c.n) return e->fail(FVH_ERR_INVALID_ARGUMENT, "set_neighbors: neighbour index " + std::to_string(idx[j]) + " outside [0, " + std::to_string(c.n) + ")");
   HIP_OR_FAIL(e, c.nbr.ensure(sizeof(int) * (size_t)c.n * k));
   HIP_OR_FAIL(e, hipMemcpyAsync(c.nbr.p, idx, sizeof(int) * (size_t)c.n * k, hipMemcpyHostToDevice, e->stream));
   HIP_OR_FAIL(e, hipStreamSynchronize(e->stream));
@@ -548,12 +552,24 @@ int build_voxelmap(Engine* e, const CloudDev& c, VoxelMapDev& vm, double res, bo
   return FVH_OK;
 }
 
-int fetch_voxelmap_host(Engine* e, VoxelMapDev& vm) {
+using Rebuild = std::function<int()>;
+
+// `rebuild_safe`: what to do when the hint-sized table of this map overflowed (counter [1]): rebuild at the safe size and
+// read again, as align / compute_error do -- the getters must never hand out a silently truncated map.
+int fetch_voxelmap_host(Engine* e, VoxelMapDev& vm, const Rebuild* rebuild_safe = nullptr) {
   if (!vm.valid) return e->fail(FVH_ERR_BAD_STATE, "voxel map not built");
   if (vm.host_valid) return FVH_OK;
-  int counters[2] = {0, 0};
-  HIP_OR_FAIL(e, hipMemcpyAsync(counters, vm.counters_cur(), sizeof(counters), hipMemcpyDeviceToHost, e->stream));
-  HIP_OR_FAIL(e, hipStreamSynchronize(e->stream));
+  int counters[3] = {0, 0, 0};
+  for (int attempt = 0;; attempt++) {
+    HIP_OR_FAIL(e, hipMemcpyAsync(counters, vm.counters_cur(), sizeof(counters), hipMemcpyDeviceToHost, e->stream));
+    HIP_OR_FAIL(e, hipStreamSynchronize(e->stream));
+    if (counters[1] == 0) break;
+    if (attempt == 1 || !rebuild_safe) return e->fail(FVH_ERR_BAD_STATE, "voxel map table overflowed (" + std::to_string(counters[1]) + " entries dropped)");
+    int rc = (*rebuild_safe)();
+    if (rc) return rc;
+  }
+  vm.nv_hint = counters[0];
+  vm.num_skipped = counters[2];
   vm.h_occupied.resize(counters[0]);
   vm.h_table.resize((size_t)vm.capacity * 4);
   if (counters[0]) HIP_OR_FAIL(e, hipMemcpyAsync(vm.h_occupied.data(), vm.occupied.p, sizeof(int) * counters[0], hipMemcpyDeviceToHost, e->stream));
@@ -565,8 +581,8 @@ int fetch_voxelmap_host(Engine* e, VoxelMapDev& vm) {
   return FVH_OK;
 }
 
-int get_voxels_host(Engine* e, VoxelMapDev& vm, int* coords3, int* num_points, float* means3, float* covs9) {
-  int rc = fetch_voxelmap_host(e, vm);
+int get_voxels_host(Engine* e, VoxelMapDev& vm, int* coords3, int* num_points, float* means3, float* covs9, const Rebuild* rebuild_safe = nullptr) {
+  int rc = fetch_voxelmap_host(e, vm, rebuild_safe);
   if (rc) return rc;
   for (size_t i = 0; i < vm.h_occupied.size(); i++) {
     const uint4* q = &vm.h_table[(size_t)vm.h_occupied[i] * 4];
@@ -701,16 +717,16 @@ int do_update_correspondences(Engine* e, const CostSource& src, VoxelMapDev& vm,
   int rc = launch_cost<MODE>(e, src, vm, PH_FIND_ONLY, &e->lin, &e->lin);
   if (rc) return rc;
   e->has_corr = true;
+  e->corr_kind = 0;
   e->corr_n_src = src.n_upper;
   return FVH_OK;
 }
-
-using Rebuild = std::function<int()>;
 
 template <int MODE>
 int do_compute_error(Engine* e, const CostSource& src, VoxelMapDev& vm, const double* T16, double* H36, double* b6, double* error, const Rebuild& rebuild_safe) {
   if (!T16 || !error) return e->fail(FVH_ERR_INVALID_ARGUMENT, "compute_error: null argument");
   if (!e->has_corr) return e->fail(FVH_ERR_BAD_STATE, "compute_error: call update_correspondences first");
+  if (!vm.valid) return e->fail(FVH_ERR_BAD_STATE, "compute_error: the target voxel map / target records were invalidated (target cloud replaced); rebuild and call update_correspondences");
   const bool deriv = (H36 != nullptr && b6 != nullptr);
   PoseD ev = pose_from_colmajor16(T16);
   LmState* h = reinterpret_cast<LmState*>(e->pinned);
@@ -830,6 +846,7 @@ int do_align(Engine* e, const CostSource& src, VoxelMapDev& vm, const double* gu
   e->lin = h->x_lin;
   e->corr_sel = h->corr_cur;
   e->has_corr = true;  // correspondences of the last consumed linearisation stay valid for compute_error()
+  e->corr_kind = 0;    // voxel-bucket ids (a nearest-point list of an earlier gicp_update_correspondences is gone)
   e->corr_n_src = src.n_upper;
   pose_to_colmajor16(h->x0, result->T);
   for (int i = 0; i < 6; i++) for (int j = 0; j < 6; j++) result->H[j * 6 + i] = h->final_H[i * 6 + j];
@@ -1184,9 +1201,9 @@ int fvh_vgicp_gicp_swap_source_and_target(fvh_vgicp* h) {  // FastGICP::swapSour
 }
 static void cloud_replaced(CloudDev& c) { c.has_cov = false; c.has_nbr = false; }
 int fvh_vgicp_set_source_cloud(fvh_vgicp* h, const float* xyz, int n) { CHECK_HANDLE(h); h->e.has_corr = false; cloud_replaced(h->source); return upload_cloud(&h->e, h->source, xyz, n, 3, false); }
-int fvh_vgicp_set_target_cloud(fvh_vgicp* h, const float* xyz, int n) { CHECK_HANDLE(h); h->voxelmap.invalidate(); cloud_replaced(h->target); return upload_cloud(&h->e, h->target, xyz, n, 3, false); }
+int fvh_vgicp_set_target_cloud(fvh_vgicp* h, const float* xyz, int n) { CHECK_HANDLE(h); h->e.has_corr = false; h->voxelmap.invalidate(); h->gicp_records.invalidate(); cloud_replaced(h->target); return upload_cloud(&h->e, h->target, xyz, n, 3, false); }
 int fvh_vgicp_set_source_cloud_device(fvh_vgicp* h, const float* d, int n, int stride) { CHECK_HANDLE(h); h->e.has_corr = false; cloud_replaced(h->source); return upload_cloud(&h->e, h->source, d, n, stride, true); }
-int fvh_vgicp_set_target_cloud_device(fvh_vgicp* h, const float* d, int n, int stride) { CHECK_HANDLE(h); h->voxelmap.invalidate(); cloud_replaced(h->target); return upload_cloud(&h->e, h->target, d, n, stride, true); }
+int fvh_vgicp_set_target_cloud_device(fvh_vgicp* h, const float* d, int n, int stride) { CHECK_HANDLE(h); h->e.has_corr = false; h->voxelmap.invalidate(); h->gicp_records.invalidate(); cloud_replaced(h->target); return upload_cloud(&h->e, h->target, d, n, stride, true); }
 int fvh_vgicp_set_source_neighbors(fvh_vgicp* h, int k, const int* idx) { CHECK_HANDLE(h); return set_neighbors(&h->e, h->source, k, idx); }
 int fvh_vgicp_set_target_neighbors(fvh_vgicp* h, int k, const int* idx) { CHECK_HANDLE(h); return set_neighbors(&h->e, h->target, k, idx); }
 int fvh_vgicp_find_source_neighbors(fvh_vgicp* h, int k) { CHECK_HANDLE(h); return find_neighbors(&h->e, h->source, k); }
@@ -1204,11 +1221,11 @@ int fvh_vgicp_get_source_neighbors(fvh_vgicp* h, int* k, int* out) { CHECK_HANDL
 int fvh_vgicp_get_target_neighbors(fvh_vgicp* h, int* k, int* out) { CHECK_HANDLE(h); return get_nbr_host(&h->e, h->target, k, out); }
 int fvh_vgicp_get_source_covariances(fvh_vgicp* h, float* c) { CHECK_HANDLE(h); return get_cov_host(&h->e, h->source, c); }
 int fvh_vgicp_get_target_covariances(fvh_vgicp* h, float* c) { CHECK_HANDLE(h); return get_cov_host(&h->e, h->target, c); }
-int fvh_vgicp_get_num_voxels(fvh_vgicp* h, int* n) { CHECK_HANDLE(h); if (!n) return FVH_ERR_INVALID_ARGUMENT; int rc = fetch_voxelmap_host(&h->e, h->voxelmap); if (rc) return rc; *n = (int)h->voxelmap.h_occupied.size(); return FVH_OK; }
-int fvh_vgicp_get_voxel_num_points(fvh_vgicp* h, int* o) { CHECK_HANDLE(h); return get_voxels_host(&h->e, h->voxelmap, nullptr, o, nullptr, nullptr); }
-int fvh_vgicp_get_voxel_means(fvh_vgicp* h, float* o) { CHECK_HANDLE(h); return get_voxels_host(&h->e, h->voxelmap, nullptr, nullptr, o, nullptr); }
-int fvh_vgicp_get_voxel_covs(fvh_vgicp* h, float* o) { CHECK_HANDLE(h); return get_voxels_host(&h->e, h->voxelmap, nullptr, nullptr, nullptr, o); }
-int fvh_vgicp_get_voxel_coords(fvh_vgicp* h, int* o) { CHECK_HANDLE(h); return get_voxels_host(&h->e, h->voxelmap, o, nullptr, nullptr, nullptr); }
+int fvh_vgicp_get_num_voxels(fvh_vgicp* h, int* n) { CHECK_HANDLE(h); if (!n) return FVH_ERR_INVALID_ARGUMENT; const Rebuild rb = h->rebuild_safe(); int rc = fetch_voxelmap_host(&h->e, h->voxelmap, &rb); if (rc) return rc; *n = (int)h->voxelmap.h_occupied.size(); return FVH_OK; }
+int fvh_vgicp_get_voxel_num_points(fvh_vgicp* h, int* o) { CHECK_HANDLE(h); const Rebuild rb = h->rebuild_safe(); return get_voxels_host(&h->e, h->voxelmap, nullptr, o, nullptr, nullptr, &rb); }
+int fvh_vgicp_get_voxel_means(fvh_vgicp* h, float* o) { CHECK_HANDLE(h); const Rebuild rb = h->rebuild_safe(); return get_voxels_host(&h->e, h->voxelmap, nullptr, nullptr, o, nullptr, &rb); }
+int fvh_vgicp_get_voxel_covs(fvh_vgicp* h, float* o) { CHECK_HANDLE(h); const Rebuild rb = h->rebuild_safe(); return get_voxels_host(&h->e, h->voxelmap, nullptr, nullptr, nullptr, o, &rb); }
+int fvh_vgicp_get_voxel_coords(fvh_vgicp* h, int* o) { CHECK_HANDLE(h); const Rebuild rb = h->rebuild_safe(); return get_voxels_host(&h->e, h->voxelmap, o, nullptr, nullptr, nullptr, &rb); }
 
 static int fetch_corr(Engine* e, int n_src, std::vector<int>& corr) {
   if (!e->has_corr) return e->fail(FVH_ERR_BAD_STATE, "no correspondences: call update_correspondences first");
@@ -1233,10 +1250,12 @@ int fvh_vgicp_get_num_correspondences(fvh_vgicp* h, int* n) {
 int fvh_vgicp_get_voxel_correspondences(fvh_vgicp* h, int* pairs) {
   CHECK_HANDLE(h);
   if (!pairs) return FVH_ERR_INVALID_ARGUMENT;
-  std::vector<int> corr;
-  int rc = fetch_corr(&h->e, h->e.corr_n_src, corr);
+  // the map first: if its hint-sized table overflowed it is rebuilt here, which drops the correspondences (BAD_STATE below)
+  const Rebuild rb = h->rebuild_safe();
+  int rc = fetch_voxelmap_host(&h->e, h->voxelmap, &rb);
   if (rc) return rc;
-  rc = fetch_voxelmap_host(&h->e, h->voxelmap);
+  std::vector<int> corr;
+  rc = fetch_corr(&h->e, h->e.corr_n_src, corr);
   if (rc) return rc;
   size_t w = 0;
   for (int o = 0; o < h->e.n_off; o++)
@@ -1299,6 +1318,14 @@ int fvh_vgicp_profile_get(fvh_vgicp* h, const char* cls, double* ms, int* n) { C
 int fvh_vgicp_debug_set_voxel_hint(fvh_vgicp* h, int num_voxels) { CHECK_HANDLE(h); h->voxelmap.nv_hint = num_voxels; return FVH_OK; }
 int fvh_vgicp_debug_get_persist_aborts(fvh_vgicp* h, int* n) { CHECK_HANDLE(h); if (!n) return FVH_ERR_INVALID_ARGUMENT; *n = h->e.persist_aborts; return FVH_OK; }
 int fvh_vgicp_debug_get_table_capacity(fvh_vgicp* h, int* capacity) { CHECK_HANDLE(h); if (!capacity) return FVH_ERR_INVALID_ARGUMENT; *capacity = (int)h->voxelmap.capacity; return FVH_OK; }
+int fvh_vgicp_debug_get_skipped_points(fvh_vgicp* h, int* n) {
+  CHECK_HANDLE(h);
+  if (!n) return FVH_ERR_INVALID_ARGUMENT;
+  if (!h->voxelmap.valid) return h->e.fail(FVH_ERR_BAD_STATE, "voxel map not built");
+  HIP_OR_FAIL(&h->e, hipMemcpyAsync(n, h->voxelmap.counters_cur() + 2, sizeof(int), hipMemcpyDeviceToHost, h->e.stream));
+  HIP_OR_FAIL(&h->e, hipStreamSynchronize(h->e.stream));
+  return FVH_OK;
+}
 int fvh_vgicp_synchronize(fvh_vgicp* h) { CHECK_HANDLE(h); HIP_OR_FAIL(&h->e, hipStreamSynchronize(h->e.stream)); return FVH_OK; }
 
 #ifdef FVH_KNN_TIMING
@@ -1410,13 +1437,15 @@ int fvh_ndt_get_num_voxels(fvh_ndt* h, int which, int* n) {
   CHECK_HANDLE(h);
   if (!n) return FVH_ERR_INVALID_ARGUMENT;
   VoxelMapDev& vm = which ? h->target_vm : h->source_vm;
-  int rc = fetch_voxelmap_host(&h->e, vm); if (rc) return rc;
+  const Rebuild rb = h->rebuild_safe();
+  int rc = fetch_voxelmap_host(&h->e, vm, &rb); if (rc) return rc;
   *n = (int)vm.h_occupied.size();
   return FVH_OK;
 }
 int fvh_ndt_get_voxels(fvh_ndt* h, int which, int* coords3, int* num_points, float* means3, float* covs9) {
   CHECK_HANDLE(h);
-  return get_voxels_host(&h->e, which ? h->target_vm : h->source_vm, coords3, num_points, means3, covs9);
+  const Rebuild rb = h->rebuild_safe();
+  return get_voxels_host(&h->e, which ? h->target_vm : h->source_vm, coords3, num_points, means3, covs9, &rb);
 }
 int fvh_ndt_get_num_correspondences(fvh_ndt* h, int* n) {
   CHECK_HANDLE(h);
@@ -1426,7 +1455,7 @@ int fvh_ndt_get_num_correspondences(fvh_ndt* h, int* n) {
   if (rc) return rc;
   int nsrc = h->e.corr_n_src;
   if (h->distance_mode == FVH_NDT_D2D) {  // only the first num_source_voxels rows are live
-    rc = fetch_voxelmap_host(&h->e, h->source_vm);
+    rc = fetch_voxelmap_host(&h->e, h->source_vm);  // (an overflow of either map was already answered by the evaluation that made `corr`)
     if (rc) return rc;
     nsrc = (int)h->source_vm.h_occupied.size();
   }

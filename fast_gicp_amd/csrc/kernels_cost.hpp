@@ -159,17 +159,20 @@ __device__ inline void dev_pose_mul(const PoseD& A, const PoseD& B, PoseD& C) { 
 __device__ inline void dev_ldlt6_solve(const double* A, const double* rhs, double* x) {
   // one reciprocal per pivot (6 divisions instead of 21: each fp64 division is ~12 dependent instructions on the one
   // lane that runs this; oracle probe ORC_LM_ARITH_VARIANT=1: converged poses agree to 2e-17); only the strictly
-  // lower part of L is used
+  // lower part of L is used. A pivot with |d| <= DBL_MIN is treated the way Eigen::LDLT does (the column stays unscaled,
+  // the solve uses the pseudo-inverse of D): with no correspondences at all H = 0, lambda = 0 and the step is d = 0, so the
+  // reference returns the initial guess flagged converged (lsq_registration_impl.hpp:111-168) instead of a NaN pose.
   double L[36], D[6], Dinv[6], y[6];
   for (int j = 0; j < 6; j++) {
     double dj = A[j * 6 + j];
     for (int k = 0; k < j; k++) dj -= L[j * 6 + k] * L[j * 6 + k] * D[k];
     D[j] = dj;
-    Dinv[j] = 1.0 / dj;
+    const bool pivot_ok = fabs(dj) > 2.2250738585072014e-308;
+    Dinv[j] = pivot_ok ? 1.0 / dj : 0.0;
     for (int i = j + 1; i < 6; i++) {
       double s = A[i * 6 + j];
       for (int k = 0; k < j; k++) s -= L[i * 6 + k] * L[j * 6 + k] * D[k];
-      L[i * 6 + j] = s * Dinv[j];
+      L[i * 6 + j] = pivot_ok ? s * Dinv[j] : s;
     }
   }
   for (int i = 0; i < 6; i++) { double s = rhs[i]; for (int k = 0; k < i; k++) s -= L[i * 6 + k] * y[k]; y[i] = s; }
@@ -454,11 +457,14 @@ __global__ FVH_COST_BOUNDS void cost_kernel(CostParams P) {
     }
     const Vec3<Real> q = transform(ev, a);
     int cx = 0, cy = 0, cz = 0;
+    bool coord_ok = true;  // false: non-finite / out-of-range source point -> no correspondences (and no (int)floor(NaN))
     if (do_find) {
       const Vec3<Real> ql = fused ? q : transform(lin, a);
-      cx = (int)floor(ql.x / res - (Real)0.5);
-      cy = (int)floor(ql.y / res - (Real)0.5);
-      cz = (int)floor(ql.z / res - (Real)0.5);
+      const Real fx = floor(ql.x / res - (Real)0.5), fy = floor(ql.y / res - (Real)0.5), fz = floor(ql.z / res - (Real)0.5);
+      coord_ok = voxel_index_ok(fx, fy, fz);
+      cx = coord_ok ? (int)fx : 0;
+      cy = coord_ok ? (int)fy : 0;
+      cz = coord_ok ? (int)fz : 0;
     }
     const int o_begin = g * P.group, o_end = min(P.n_off, o_begin + P.group);
     for (int oc = o_begin; oc < o_end; oc += COST_CH) {
@@ -477,7 +483,7 @@ __global__ FVH_COST_BOUNDS void cost_kernel(CostParams P) {
         for (int c = 0; c < COST_CH; c++) {
           const int o = min(oc + c, o_end - 1);
           const int x = cx + P.offsets[3 * o], y = cy + P.offsets[3 * o + 1], z = cz + P.offsets[3 * o + 2];
-          live[c] = (oc + c < o_end) && coord_in_range(x, y, z);
+          live[c] = (oc + c < o_end) && coord_ok && coord_in_range(x, y, z);
           key[c] = pack_key(x, y, z);
           slot[c] = hash_key(key[c]) & P.mask;
           k0[c] = P.keys[slot[c]];

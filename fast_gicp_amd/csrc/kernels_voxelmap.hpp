@@ -79,9 +79,13 @@ __global__ __launch_bounds__(256) void vm_accumulate_kernel(const float4* __rest
     const int i = order ? order[i0] : i0;  // Morton order: a workgroup's 256 points share a handful of voxels -> the LDS stage absorbs them
     const float4 p = pts[i];
     // fp64 coordinate, as the CPU reference (fast_vgicp_voxel.hpp:158-160)
-    const int cx = (int)floor((double)p.x / res - 0.5), cy = (int)floor((double)p.y / res - 0.5), cz = (int)floor((double)p.z / res - 0.5);
-    if (!coord_in_range(cx, cy, cz)) {
-      atomicAdd(dropped, 1);
+    const double fx = floor((double)p.x / res - 0.5), fy = floor((double)p.y / res - 0.5), fz = floor((double)p.z / res - 0.5);
+    const bool ok = voxel_index_ok(fx, fy, fz);
+    const int cx = ok ? (int)fx : 0, cy = ok ? (int)fy : 0, cz = ok ? (int)fz : 0;
+    if (!ok) {
+      // non-finite or absurdly far point: it belongs to no voxel. Counted apart from `dropped` (table overflow, which the
+      // host answers with a rebuild at the safe size) so that one lidar NaN cannot fail an align.
+      atomicAdd(dropped + 1, 1);
     } else {
       const unsigned long long key = pack_key(cx, cy, cz);
       double v[VM_ACC_STRIDE];

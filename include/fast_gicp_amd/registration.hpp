@@ -134,8 +134,11 @@ inline Isometry3d se3_exp(const Vector6d& a) {
 }
 
 namespace detail {
+// A pivot with |d| <= DBL_MIN is handled like Eigen::LDLT (column left unscaled, pseudo-inverse of D in the solve): an
+// all-zero system (no correspondences) gives d = 0 and the optimiser returns the guess, converged, as the reference does.
 inline void ldlt6_solve(const Matrix6d& A, const Vector6d& rhs, Vector6d& x) {
   double L[36] = {0}, D[6], y[6];
+  constexpr double tiny = 2.2250738585072014e-308;
   for (int j = 0; j < 6; j++) {
     double d = A[j * 6 + j];
     for (int k = 0; k < j; k++) d -= L[j * 6 + k] * L[j * 6 + k] * D[k];
@@ -144,11 +147,11 @@ inline void ldlt6_solve(const Matrix6d& A, const Vector6d& rhs, Vector6d& x) {
     for (int i = j + 1; i < 6; i++) {
       double s = A[i * 6 + j];
       for (int k = 0; k < j; k++) s -= L[i * 6 + k] * L[j * 6 + k] * D[k];
-      L[i * 6 + j] = s / d;
+      L[i * 6 + j] = std::fabs(d) > tiny ? s / d : s;
     }
   }
   for (int i = 0; i < 6; i++) { double s = rhs[i]; for (int k = 0; k < i; k++) s -= L[i * 6 + k] * y[k]; y[i] = s; }
-  for (int i = 0; i < 6; i++) y[i] /= D[i];
+  for (int i = 0; i < 6; i++) y[i] = std::fabs(D[i]) > tiny ? y[i] / D[i] : 0.0;
   for (int i = 5; i >= 0; i--) { double s = y[i]; for (int k = i + 1; k < 6; k++) s -= L[k * 6 + i] * x[k]; x[i] = s; }
 }
 template <typename PointT>
@@ -431,7 +434,12 @@ protected:
     std::vector<int> neighbors((size_t)n * k);
     const int threads = host::omp_threads_for(n);  // hundreds of threads on a 17k-point loop only add contention
 #pragma omp parallel for schedule(guided, 8) num_threads(threads)
-    for (int i = 0; i < n; i++) tree.knn(&xyz[3 * (size_t)i], k, &neighbors[(size_t)i * k]);
+    for (int i = 0; i < n; i++) {
+      int* row = &neighbors[(size_t)i * k];
+      tree.knn(&xyz[3 * (size_t)i], k, row);
+      // a cloud with fewer than k points: the reference's zero-initialised vector keeps index 0 in the unfilled entries (:155,162)
+      for (int j = 0; j < k; j++) if (row[j] < 0) row[j] = 0;
+    }
     return neighbors;
   }
   void call(int rc, const char* what) const { detail::check(rc, what, fvh_vgicp_last_error(core_)); }

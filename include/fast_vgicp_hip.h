@@ -157,6 +157,7 @@ int fvh_vgicp_synchronize(fvh_vgicp* h);
  * hint must only cost a rebuild at the safe size (2 x N_t), never points. */
 int fvh_vgicp_debug_set_voxel_hint(fvh_vgicp* h, int num_voxels);
 int fvh_vgicp_debug_get_table_capacity(fvh_vgicp* h, int* capacity);
+int fvh_vgicp_debug_get_skipped_points(fvh_vgicp* h, int* n);  /* target points of the current voxel map that belong to no voxel: non-finite or |coord| >= 2^20 voxels (they are skipped, never fatal) */
 int fvh_vgicp_debug_get_persist_aborts(fvh_vgicp* h, int* n);  /* persistent-LM launches whose barrier watchdog fired (each was redone with one launch per LM transition) */
 
 /* new: multi-GPU (one process per GPU).  Every rank holds a spatial-tile shard of the source

@@ -221,7 +221,9 @@ inline Iso3 se3_exp(const double a[6]) {
 }
 
 // Solve (A) x = rhs for symmetric 6x6 A via LDL^T (no pivoting). Stands in for
-// Eigen::LDLT<Matrix6d>::solve (lsq_registration_impl.hpp:111,134).
+// Eigen::LDLT<Matrix6d>::solve (lsq_registration_impl.hpp:111,134). Zero pivots as Eigen treats them: the column is not
+// scaled (ldlt_inplace: "if (rs > 0 && pivot_is_valid) A21 /= realAkk") and the solve applies the pseudo-inverse of D
+// (|D_ii| <= numeric_limits::min() -> 0), so H = 0 (no correspondences) yields d = 0, delta = I: guess returned, converged.
 inline void ldlt6_solve(const double A_in[36], const double rhs[6], double x[6]) {
   double L[36] = {0}, D[6];
   for (int j = 0; j < 6; j++) {
@@ -232,12 +234,12 @@ inline void ldlt6_solve(const double A_in[36], const double rhs[6], double x[6])
     for (int i = j + 1; i < 6; i++) {
       double s = A_in[i * 6 + j];
       for (int k = 0; k < j; k++) s -= L[i * 6 + k] * L[j * 6 + k] * D[k];
-      L[i * 6 + j] = (lm_arith_variant() & 1) ? s * (1.0 / d) : s / d;
+      L[i * 6 + j] = !(std::fabs(d) > 2.2250738585072014e-308) ? s : ((lm_arith_variant() & 1) ? s * (1.0 / d) : s / d);
     }
   }
   double y[6];
   for (int i = 0; i < 6; i++) { double s = rhs[i]; for (int k = 0; k < i; k++) s -= L[i * 6 + k] * y[k]; y[i] = s; }
-  for (int i = 0; i < 6; i++) y[i] = (lm_arith_variant() & 1) ? y[i] * (1.0 / D[i]) : y[i] / D[i];
+  for (int i = 0; i < 6; i++) y[i] = !(std::fabs(D[i]) > 2.2250738585072014e-308) ? 0.0 : ((lm_arith_variant() & 1) ? y[i] * (1.0 / D[i]) : y[i] / D[i]);
   for (int i = 5; i >= 0; i--) { double s = y[i]; for (int k = i + 1; k < 6; k++) s -= L[k * 6 + i] * x[k]; x[i] = s; }
 }
 

@@ -1,0 +1,204 @@
+"""GPU tests for the state-machine / degenerate-input corners of the C ABI that round 1's advisor flagged:
+stale correspondence kinds, an all-zero normal system (no overlap), neighbour indices outside the cloud,
+non-finite points, and voxel getters after a table overflow. Every expectation is the REFERENCE's behaviour
+(cited) or a clean error -- never a NaN pose, an out-of-bounds read or a silently truncated map."""
+import numpy as np
+import pytest
+
+from tests import util
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def O():
+    from oracle import oracle
+    return oracle
+
+
+@pytest.fixture(scope="module")
+def small_pair():
+    return util.synthetic_pair(4000, 3500, seed=3, extent=12.0)
+
+
+def _core():
+    from fast_gicp_amd import capi
+    return capi.VGICPCore(0)
+
+
+def _prepared(tgt, src, search=1):
+    c = _core()
+    c.set_neighbor_search_method(search)
+    c.set_target_cloud(tgt); c.find_target_neighbors(20); c.calculate_target_covariances(3); c.create_target_voxelmap()
+    c.set_source_cloud(src); c.find_source_neighbors(20); c.calculate_source_covariances(3)
+    return c
+
+
+def test_no_overlap_returns_the_guess_converged(O):
+    """No correspondences -> H = 0, lambda = 0. Eigen::LDLT solves a zero system to d = 0 (pseudo-inverse of D), so
+    LsqRegistration (lsq_registration_impl.hpp:123-168) accepts delta = I and reports the guess as converged. The engine's
+    device LM, the host-side LM and the oracle must do the same -- not a NaN pose flagged converged."""
+    rng = np.random.default_rng(0)
+    tgt = rng.uniform(-5, 5, size=(2000, 3)).astype(np.float32)
+    src = (rng.uniform(-5, 5, size=(1500, 3)) + np.array([500.0, 0, 0])).astype(np.float32)
+    guess = util.random_pose(np.random.default_rng(1), 1.0, 0.2)
+    c = _prepared(tgt, src)
+    r = c.align(guess)
+    assert np.all(np.isfinite(r["T"])) and np.all(np.isfinite(r["H"]))
+    assert r["converged"] and not r["lm_failed"]
+    assert np.array_equal(r["T"], guess)
+    assert r["num_linearize"] == 1 and r["num_error_evals"] == 1
+    g = O.FastVGICP(search=O.DIRECT7)
+    g.set_target(tgt); g.set_source(src)
+    ro = g.align(guess)
+    assert ro["converged"] and np.array_equal(ro["T"], guess)
+    assert ro["num_linearize"] == r["num_linearize"] and ro["num_error_evals"] == r["num_error_evals"]
+    e, H, b = c.linearize(guess)
+    assert e == 0.0 and not H.any() and not b.any() and c.get_num_correspondences() == 0
+    c.close()
+
+
+def test_host_lm_no_overlap(O):
+    """The same degenerate case through the C++ host classes (registration.hpp, host-driven LM path of pygicp)."""
+    import pygicp
+    rng = np.random.default_rng(0)
+    tgt = rng.uniform(-5, 5, size=(2000, 3)).astype(np.float32)
+    src = (rng.uniform(-5, 5, size=(1500, 3)) + np.array([500.0, 0, 0])).astype(np.float32)
+    for device_lm in (False, True):
+        reg = pygicp.FastVGICPCuda()
+        reg.set_use_device_lm(device_lm)
+        reg.set_input_target(tgt); reg.set_input_source(src)
+        T = reg.align()
+        assert np.all(np.isfinite(T)) and np.array_equal(T, np.eye(4, dtype=T.dtype)) and reg.has_converged()
+
+
+def test_neighbor_indices_are_validated():
+    """A -1 pad (k-NN on fewer than k points) or any index outside [0, n) must be refused: cov_from_neighbors gathers pts[idx]."""
+    from fast_gicp_amd import capi
+    pts = np.random.default_rng(2).normal(size=(30, 3)).astype(np.float32)
+    c = _core()
+    c.set_source_cloud(pts)
+    good = np.tile(np.arange(5, dtype=np.int32), (30, 1))
+    c.set_source_neighbors(5, good)
+    c.calculate_source_covariances(0)
+    for bad_value in (-1, 30, 2**31 - 1):
+        bad = good.copy()
+        bad[17, 3] = bad_value
+        with pytest.raises(capi.FvhError, match="outside"):
+            c.set_source_neighbors(5, bad)
+    c.close()
+
+
+def test_small_cloud_through_the_host_kdtree_path():
+    """FastVGICPCuda's default CPU_PARALLEL_KDTREE mode on a cloud with fewer than k points: the reference's zero-initialised
+    index vector pads with index 0 (fast_vgicp_cuda_impl.hpp:155,162); the result must be finite."""
+    import pygicp
+    rng = np.random.default_rng(5)
+    tgt = rng.uniform(-2, 2, size=(12, 3)).astype(np.float32)
+    src = (tgt + 0.01).astype(np.float32)
+    reg = pygicp.FastVGICPCuda()
+    reg.set_resolution(4.0)
+    reg.set_input_target(tgt); reg.set_input_source(src)
+    T = reg.align()
+    assert np.all(np.isfinite(T))
+
+
+def test_non_finite_and_far_points_are_skipped_not_fatal(O, small_pair):
+    """A lidar NaN / inf / 1e9 outlier belongs to no voxel: skipped and counted apart from table overflow, so the align
+    works and equals the align of the cleaned cloud."""
+    tgt, src, _ = small_pair
+    junk = np.array([[np.nan, 0, 0], [np.inf, 1, 1], [1e9, 0, 0], [0, -3e7, 0]], np.float32)
+    pos = [5, 1000, 2500, 3999]
+    dirty = tgt.copy()
+    cov = O.covariances_knn(tgt, 20, O.PLANE)
+    cov_s = O.covariances_knn(src, 20, O.PLANE)
+    dirty[pos] = junk
+    keep = np.ones(len(tgt), bool); keep[pos] = False
+    res = []
+    for cloud, covs in ((dirty, cov), (tgt[keep], cov[keep])):
+        c = _core()
+        c.set_neighbor_search_method(1)
+        c.set_target_cloud(cloud); c.set_target_covariances(covs); c.create_target_voxelmap()
+        c.set_source_cloud(src); c.set_source_covariances(cov_s)
+        r = c.align()
+        coords, num, _, _ = c.get_voxelmap()
+        res.append((r, c.debug_skipped_points(), int(num.sum()), set(map(tuple, coords))))
+        c.close()
+    (rd, skipped_d, n_d, set_d), (rc, skipped_c, n_c, set_c) = res
+    assert skipped_d == 4 and skipped_c == 0
+    assert n_d == n_c == len(tgt) - 4 and set_d == set_c
+    assert rd["converged"] and np.all(np.isfinite(rd["T"]))
+    assert util.rel_err(rd["T"], rc["T"]) < 1e-12
+    # non-finite SOURCE points find no voxel and contribute nothing
+    c = _prepared(tgt, src)
+    e0, H0, b0 = c.linearize(np.eye(4))
+    n0 = c.get_num_correspondences()
+    src2 = np.concatenate([src, junk])
+    cov2 = np.concatenate([c.get_covariances("source").astype(np.float64), np.tile(np.eye(3), (4, 1, 1))])
+    c.set_source_cloud(src2); c.set_source_covariances(cov2)
+    e1, H1, b1 = c.linearize(np.eye(4))
+    assert c.get_num_correspondences() == n0 and np.isfinite(e1)
+    assert abs(e1 - e0) <= 1e-12 * abs(e0) and util.rel_err(H1, H0) < 1e-12
+    c.close()
+
+
+def test_correspondence_kind_follows_the_last_producer(small_pair):
+    """gicp_update_correspondences leaves nearest-POINT ids, align()/update_correspondences leave voxel-BUCKET ids in the
+    same buffer; each compute_error flavour must only accept its own kind (bucket ids index a table of capacity >= 2N,
+    the GICP records only hold N_t entries)."""
+    from fast_gicp_amd import capi
+    tgt, src, T = small_pair
+    c = _prepared(tgt, src)
+    c.gicp_update_correspondences(np.eye(4))
+    e_g = c.gicp_compute_error(np.eye(4), derivatives=False)
+    with pytest.raises(capi.FvhError):
+        c.compute_error(np.eye(4))                   # nearest-point ids are not voxel ids
+    r = c.align()                                    # leaves voxel correspondences of the last linearisation
+    e_v = c.compute_error(r["T"], derivatives=False)  # ... so this is legal again
+    assert np.isfinite(e_v) and e_v > 0
+    with pytest.raises(capi.FvhError):
+        c.gicp_compute_error(np.eye(4))              # and the GICP flavour must refuse them
+    with pytest.raises(capi.FvhError):
+        c.gicp_get_correspondences()
+    c.gicp_update_correspondences(np.eye(4))
+    assert abs(c.gicp_compute_error(np.eye(4), derivatives=False) - e_g) <= 1e-12 * abs(e_g)
+    c.close()
+
+
+def test_replacing_the_target_invalidates_correspondences(small_pair):
+    from fast_gicp_amd import capi
+    tgt, src, _ = small_pair
+    c = _prepared(tgt, src)
+    c.update_correspondences(np.eye(4))
+    c.compute_error(np.eye(4))
+    c.set_target_cloud(tgt[:1000])                   # voxel map gone
+    with pytest.raises(capi.FvhError):
+        c.compute_error(np.eye(4))
+    with pytest.raises(capi.FvhError):
+        c.update_correspondences(np.eye(4))
+    c.close()
+    c = _prepared(tgt, src)
+    c.gicp_update_correspondences(np.eye(4))
+    c.set_target_cloud(tgt[:1000])                   # GICP records gone as well
+    with pytest.raises(capi.FvhError):
+        c.gicp_compute_error(np.eye(4))
+    c.close()
+
+
+def test_voxel_getters_rebuild_an_overflowed_table(O, small_pair):
+    """create_target_voxelmap with a stale, far too small capacity hint: the getters must notice the overflow counter and
+    rebuild at the safe size (as align/compute_error do) instead of returning a truncated map."""
+    tgt, _, _ = small_pair
+    cov = O.covariances_knn(tgt, 20, O.PLANE)
+    c = _core()
+    c.set_resolution(0.25)
+    c.set_target_cloud(tgt); c.set_target_covariances(cov)
+    c.debug_set_voxel_hint(1)                        # 1,024 buckets for a few thousand voxels
+    c.create_target_voxelmap()
+    assert c.debug_table_capacity() == 1024
+    coords, num, means, _ = c.get_voxelmap()
+    oc, on, om, _ = O.voxelmap_vgicp(tgt, cov, 0.25)
+    assert len(oc) > 1024
+    assert c.debug_table_capacity() > 1024
+    assert util.voxel_dict(coords, num) == util.voxel_dict(oc, on) and int(num.sum()) == len(tgt)
+    c.close()

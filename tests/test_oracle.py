@@ -198,3 +198,17 @@ def test_product_preprocessing_matches_oracle(O):
     assert np.array_equal(t, ot) and np.array_equal(s, os_)
     t2, s2 = P.bundled_pair(util.DATA, origin_filter=False)
     assert (len(t2), len(s2)) == (17249, 17518)
+
+
+def test_no_overlap_returns_guess_converged(O):
+    """H = 0 / lambda = 0 (no correspondences): Eigen::LDLT's pseudo-inverse gives d = 0, the reference accepts delta = I
+    and reports the guess as converged (lsq_registration_impl.hpp:111-168). The restated solver must not produce NaN."""
+    rng = np.random.default_rng(0)
+    tgt = rng.uniform(-5, 5, size=(1500, 3)).astype(np.float32)
+    src = (rng.uniform(-5, 5, size=(1200, 3)) + np.array([500.0, 0, 0])).astype(np.float32)
+    guess = util.random_pose(np.random.default_rng(1), 1.0, 0.2)
+    for g in (O.FastVGICP(search=O.DIRECT7), O.NDT()):
+        g.set_target(tgt); g.set_source(src)
+        r = g.align(guess)
+        assert r["converged"] and np.array_equal(r["T"], guess)
+        assert r["num_linearize"] == 1 and r["num_error_evals"] == 1
