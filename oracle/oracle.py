@@ -259,6 +259,11 @@ class FastVGICP(_Reg):
         self._call("get_covs", 1 if which == "target" else 0, _p(out))
         return out
 
+    def set_voxelmap(self, coords, num, means, covs):
+        """Test leg: the target voxel map becomes exactly these records (e.g. the engine's own fp32-stored ones)."""
+        c, n, m, v = np.ascontiguousarray(coords, np.int32), np.ascontiguousarray(num, np.int32), _f64(means), _f64(covs)
+        self._call("set_voxelmap", len(n), _p(c), _p(n), _p(m), _p(v))
+
     def get_voxelmap(self):
         coords, num, means, vc = _voxel_out(self.nt)
         nv = self._call("get_voxelmap", _p(coords), _p(num), _p(means), _p(vc))
@@ -276,9 +281,16 @@ class NDT(_Reg):
     """fp64 restatement of NDTCuda's formulas (ndt_cuda.cu, ndt_compute_derivatives.cu)."""
     _prefix = "orc_ndt_"
 
-    def __init__(self, threads=0, resolution=1.0, mode=D2D, search=DIRECT7, radius=0.0):
+    def __init__(self, threads=0, resolution=1.0, mode=D2D, search=DIRECT7, radius=0.0, round_fp32=False):
         self.h = lib().orc_ndt_create()
         self._call("set_params", threads, C.c_double(resolution), mode, search, C.c_double(radius))
+        if round_fp32:
+            self._call("set_round_fp32", 1)
+
+    def set_voxelmap(self, which, coords, num, means, covs):
+        """Test leg: a voxel map becomes exactly these records (source order = the D2D iteration order)."""
+        c, n, m, v = np.ascontiguousarray(coords, np.int32), np.ascontiguousarray(num, np.int32), _f64(means), _f64(covs)
+        self._call("set_voxelmap", 1 if which == "target" else 0, len(n), _p(c), _p(n), _p(m), _p(v))
 
     def get_voxelmap(self, which):
         n = self.nt if which == "target" else self.ns

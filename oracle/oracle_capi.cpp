@@ -25,6 +25,20 @@ int dump_voxelmap(const VoxelMap& vm, int* coords, int* num, double* means, doub
   }
   return (int)vm.voxels.size();
 }
+// test leg "oracle fed the engine's own fp32 voxel data": replaces a voxel map by the given records (insertion order = given order)
+void load_voxelmap(VoxelMap& vm, int nv, const int* coords, const int* num, const double* means, const double* covs) {
+  vm.index.clear(); vm.coords.clear(); vm.voxels.clear();
+  for (int i = 0; i < nv; i++) {
+    VoxelKey k{coords[3 * i], coords[3 * i + 1], coords[3 * i + 2]};
+    Voxel v;
+    v.num_points = num[i];
+    for (int a = 0; a < 3; a++) v.mean[a] = means[3 * i + a];
+    std::memcpy(v.cov.m, covs + 9 * i, 9 * sizeof(double));
+    vm.index[k] = (int)vm.voxels.size();
+    vm.coords.push_back(k);
+    vm.voxels.push_back(v);
+  }
+}
 }  // namespace
 
 extern "C" {
@@ -156,6 +170,11 @@ int orc_vgicp_num_correspondences(void* h) { return (int)((FastVGICP*)h)->voxel_
 int orc_vgicp_num_voxels(void* h) { auto* g = (FastVGICP*)h; return g->voxelmap ? (int)g->voxelmap->voxels.size() : -1; }
 void orc_vgicp_get_covs(void* h, int which, double* out) { auto* g = (FastVGICP*)h; copy_m3(which ? g->target_covs : g->source_covs, out); }
 int orc_vgicp_get_voxelmap(void* h, int* coords, int* num, double* means, double* covs) { return dump_voxelmap(*((FastVGICP*)h)->voxelmap, coords, num, means, covs); }
+void orc_vgicp_set_voxelmap(void* h, int nv, const int* coords, const int* num, const double* means, const double* covs) {
+  auto* g = (FastVGICP*)h;
+  g->voxelmap.reset(new VoxelMap(g->voxel_resolution));  // (align() resets it again: this is for linearize / compute_error at fixed poses)
+  load_voxelmap(*g->voxelmap, nv, coords, num, means, covs);
+}
 void orc_vgicp_align(void* h, const double* guess16, orc_result* r) {
   auto* g = (FastVGICP*)h;
   g->align(iso_from_rowmajor16(guess16));
@@ -198,6 +217,13 @@ void orc_ndt_set_params(void* h, int threads, double res, int mode, int search, 
   if (threads > 0) g->num_threads = threads;
   g->resolution = res; g->distance_mode = (NDTDistanceMode)mode; g->search_method = (NeighborSearchMethod)search; g->search_radius = radius;
 }
+void orc_ndt_set_voxelmap(void* h, int which, int nv, const int* coords, const int* num, const double* means, const double* covs) {
+  auto* g = (NDT*)h;
+  auto& slot = which ? g->target_voxelmap : g->source_voxelmap;
+  slot.reset(new VoxelMap(g->resolution));
+  load_voxelmap(*slot, nv, coords, num, means, covs);
+}
+void orc_ndt_set_round_fp32(void* h, int on) { ((NDT*)h)->round_storage_fp32 = on != 0; }
 void orc_ndt_set_lm(void* h, int max_iter, double rot_eps, double trans_eps, int lm_max_iter, double init_lambda_factor) {
   auto* g = (NDT*)h;
   g->max_iterations = max_iter; g->rotation_epsilon = rot_eps; g->transformation_epsilon = trans_eps;

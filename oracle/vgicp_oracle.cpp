@@ -712,8 +712,14 @@ void NDT::swapSourceAndTarget() {
   input.swap(target);
 }
 void NDT::create_voxelmaps() {
-  if (!source_voxelmap && distance_mode != P2D) { source_voxelmap.reset(new VoxelMap(resolution)); source_voxelmap->create_ndt(*input); }
-  if (!target_voxelmap) { target_voxelmap.reset(new VoxelMap(resolution)); target_voxelmap->create_ndt(*target); }
+  // round_storage_fp32: the voxel means / covariances go through float like the device tables (the reference's are float
+  // too: gaussian_voxelmap.cuh:30-32) -- the parity leg that isolates the cost arithmetic from the storage rounding
+  auto round_map = [&](VoxelMap& m) {
+    if (!round_storage_fp32) return;
+    for (auto& v : m.voxels) { for (int a = 0; a < 3; a++) v.mean[a] = (double)(float)v.mean[a]; for (int i = 0; i < 9; i++) v.cov.m[i] = (double)(float)v.cov.m[i]; }
+  };
+  if (!source_voxelmap && distance_mode != P2D) { source_voxelmap.reset(new VoxelMap(resolution)); source_voxelmap->create_ndt(*input); round_map(*source_voxelmap); }
+  if (!target_voxelmap) { target_voxelmap.reset(new VoxelMap(resolution)); target_voxelmap->create_ndt(*target); round_map(*target_voxelmap); }
 }
 void NDT::align(const Iso3& guess) {
   if (target_cloud_updated) { pcl_tree.reset(new KdTree(*target)); target_cloud_updated = false; }

@@ -159,6 +159,7 @@ struct NDT : LsqBase {
   NDTDistanceMode distance_mode = D2D;          // :21
   NeighborSearchMethod search_method = DIRECT7; // :22
   double search_radius = 0.0;
+  bool round_storage_fp32 = false;              // test leg: voxel means/covs rounded to float as the device stores them
   CloudPtr input, target;
   std::shared_ptr<KdTree> pcl_tree;
   std::unique_ptr<VoxelMap> source_voxelmap, target_voxelmap;

@@ -128,11 +128,16 @@ def test_covariances_knn_match_oracle(O, pair, reg):
     c.calculate_source_covariances(reg)
     got = c.get_covariances("source").astype(np.float64)
     ref = O.covariances_knn(src, 20, reg)
-    scale = np.abs(ref).max(axis=(1, 2), keepdims=True)
-    err = np.abs(got - ref) / np.maximum(scale, 1e-12)
-    # eigen-based methods are ill-conditioned where two eigenvalues (nearly) coincide: allow a small tail
-    assert np.quantile(err.max(axis=(1, 2)), 0.999) < 2e-5
-    assert np.median(err.max(axis=(1, 2))) < 1e-6
+    if reg in (0, 4):  # NONE / FROBENIUS: no eigenvectors involved -> plain fp32 storage rounding on every point
+        scale = np.abs(ref).max(axis=(1, 2))
+        assert (np.abs(got - ref).max(axis=(1, 2)) <= 2e-7 * scale + 1e-12).all()
+    else:
+        # eigen-based: every point against its conditioning-aware bound (fp64 centred sums on both sides: input error 1e-13);
+        # points whose eigenvectors are undefined at that precision (exact ties) may only be a handful
+        raw = O.covariances_knn(src, 20, O.NONE)
+        err, bound, degenerate = util.cov_error_bound(got, ref, raw, input_rel=1e-13, gaps="01" if reg == 3 else "min")
+        assert degenerate.sum() <= 5
+        assert np.all(err[~degenerate] <= bound[~degenerate]), float((err / bound)[~degenerate].max())
     c.close()
 
 
@@ -151,8 +156,12 @@ def test_covariances_rbf_match_oracle(O, pair):
     c.calculate_source_covariances_rbf(3)
     got = c.get_covariances("source").astype(np.float64)
     ref = O.covariances_rbf(src, 0.5, 2.5, 3)
-    err = np.abs(got - ref).max(axis=(1, 2))
-    assert np.quantile(err, 0.99) < 1e-3
+    # PLANE depends on the eigenvector of the smallest eigenvalue only: the 5e-5 input error of the fp32 sums is amplified by
+    # lambda_max / (lambda_1 - lambda_0); every point is held to that bound, near-degenerate ones are counted
+    rawo = O.covariances_rbf(src, 0.5, 2.5, 0)
+    err, bound, degenerate = util.cov_error_bound(got, ref, rawo, input_rel=5e-5)
+    assert degenerate.sum() <= 5
+    assert np.all(err[~degenerate] <= bound[~degenerate]), float((err / bound)[~degenerate].max())
     c.close()
 
 
