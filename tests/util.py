@@ -55,8 +55,22 @@ def cov_error_bound(got, ref, raw, input_rel, gaps="01", storage_rel=1.2e-7, fac
     w = np.linalg.eigvalsh(raw)
     lam = np.maximum(np.abs(w).max(axis=1), 1e-300)
     gap = (w[:, 1] - w[:, 0]) if gaps == "01" else np.minimum(w[:, 1] - w[:, 0], w[:, 2] - w[:, 1])
-    amp = factor * input_rel * lam / np.maximum(gap, 1e-300)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        amp = np.where(gap > 1e-14 * lam, factor * input_rel * lam / gap, np.inf)  # zero matrix (isolated point) / exact tie: undefined
     scale = np.abs(ref).max(axis=(1, 2))
     err = np.abs(got - ref).max(axis=(1, 2))
     bound = (storage_rel + amp) * scale
     return err, bound, amp >= 0.5
+
+
+def sums_close(e, H, b, eo, Ho, bo, tol):
+    """err / H / b of one evaluation against a reference at relative tolerance `tol`. b = sum w J^T M e is a sum of
+    CANCELLING terms near the optimum (it is the gradient), so it is held to tol x its Cauchy-Schwarz scale
+    sqrt(H_ii * err) >= |b_i| rather than to tol x |b|: an input rounding of relative size tol moves every term by that
+    much, not the (arbitrarily small) total."""
+    H, Ho, b, bo = (np.asarray(a, np.float64) for a in (H, Ho, b, bo))
+    ok_e = abs(e - eo) <= tol * abs(eo)
+    ok_H = rel_err(H, Ho) <= tol
+    scale_b = np.sqrt(np.abs(np.diag(Ho)) * abs(eo))
+    ok_b = bool(np.all(np.abs(b - bo) <= tol * np.maximum(scale_b, 1e-300)))
+    return ok_e and ok_H and ok_b
