@@ -7,6 +7,10 @@ LIB_DIR = os.path.join(_HERE, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libfast_vgicp_hip.so")
 SOURCES = [os.path.join(_HERE, "csrc", f) for f in ("fvh_capi.hip", "kernels_cost.hpp", "kernels_cov.hpp", "kernels_voxelmap.hpp", "kernels_sort.hpp", "kernels_downsample.hpp", "dev_math.hpp")]
 HEADER = os.path.join(os.path.dirname(_HERE), "include", "fast_vgicp_hip.h")
+# -disable-machine-licm: the persistent LM kernel is one big loop over LM transitions; machine LICM hoists ~25 constant
+# materialisations and thread-index-derived addresses of its epilogue into the kernel prologue, where they stay live across
+# the main loop (187 instead of 162 VGPRs = 2 instead of 3 workgroups per CU). tools/kernel_resources.py reports the effect.
+HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-munsafe-fp-atomics", "-mllvm", "-disable-machine-licm"]
 
 
 def is_stale():
@@ -22,7 +26,7 @@ def build_lib(force=False, verbose=False):
         return LIB_PATH
     os.makedirs(LIB_DIR, exist_ok=True)
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-munsafe-fp-atomics", "-o", LIB_PATH, SOURCES[0], "-ldl"] + os.environ.get("FVH_EXTRA_HIPCC_FLAGS", "").split()
+    cmd = [hipcc] + HIPCC_FLAGS + ["-o", LIB_PATH, SOURCES[0], "-ldl"] + os.environ.get("FVH_EXTRA_HIPCC_FLAGS", "").split()
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)

@@ -663,11 +663,15 @@ int launch_cost(Engine* e, const CostSource& src, const VoxelMapDev& vm, int hos
   }
   const long long items = (long long)src.n_upper * P.groups_per_src;
   int blocks = (int)std::max<long long>(1, std::min<long long>(max_blocks, (items + 255) / 256));
-  if (persistent) {
-    // every workgroup must be resident at once: clamp the grid to what the device can hold (the kernel is grid-stride)
+  {
+    // The persistent kernel needs every workgroup resident at once: its grid is clamped to what the device can hold (the
+    // kernel is grid-stride). The per-transition launches take the SAME grid, so that both routes partition the items --
+    // and therefore order the sums -- identically (bit-identical results whichever route an align takes).
     const int cap = persistent_capacity<MODE>(e);
-    if (cap <= 0) return e->fail(FVH_ERR_HIP, "persistent cost kernel: occupancy query failed");
+    if (cap <= 0) return e->fail(FVH_ERR_HIP, "cost kernel: occupancy query failed");
     blocks = std::min(blocks, cap);
+  }
+  if (persistent) {
     { const char* v = getenv("FVH_PERSIST_WATCHDOG_TICKS"); P.watchdog_ticks = v ? strtoull(v, nullptr, 10) : PERSIST_WATCHDOG_TICKS; }  // test hook: 0 forces the abort + fallback path
     static const int zc = [] { const char* v = getenv("FVH_ZEROCOPY_RESULT"); return v ? atoi(v) : 1; }();
     P.result_host = (zc && !e->prof.on) ? e->result_dev : nullptr;  // (event profiling needs the stream drained anyway)

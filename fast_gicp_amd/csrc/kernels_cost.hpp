@@ -30,7 +30,7 @@ namespace fvh {
 
 constexpr int NSUM = 28;       // err(1) b(6) Hrr(6) Hrt(9) Htt(6)
 constexpr int PART_STRIDE = 32;
-constexpr int MAX_PARTIAL_ROWS = 512;  // workgroup rows; 8 group rows follow
+constexpr int MAX_PARTIAL_ROWS = 1024;  // workgroup rows (4 workgroups per CU x 256 CUs); the group rows follow
 
 enum CostMode { MODE_VGICP = 0, MODE_NDT_P2D = 1, MODE_NDT_D2D = 2 };
 enum Phase { PH_LINEARIZE = 0, PH_TRIAL = 1, PH_DONE = 2, PH_FIND_ONLY = 3, PH_EVAL_DERIV = 4, PH_EVAL_ERROR = 5 };
@@ -278,6 +278,166 @@ __device__ inline void dev_lm_step(LmState* st, const double* sums) {
   dev_lm_propose(st);
 }
 
+// value of lane `src` (compile-time constant) on every lane: two v_readlane_b32, no LDS crossbar round trip
+__device__ __forceinline__ double readlane_f64(double x, int src) {
+  const unsigned long long u = (unsigned long long)__double_as_longlong(x);
+  const unsigned lo = __builtin_amdgcn_readlane((unsigned)u, src), hi = __builtin_amdgcn_readlane((unsigned)(u >> 32), src);
+  return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+
+// ------------------------------------------------------------------------------------------------
+// The same transition, executed by ONE FULL WAVE (all 64 lanes call it; every branch below is wave-uniform).
+// Round 1 ran dev_lm_step on a single lane against the LDS copy of the state: ~300 dependent LDS round trips, 4.4 us of
+// every 20 us trip of the persistent kernel. Here the 6x6 system lives one element per lane (lanes 0..35), the LDL^T
+// factorisation is a right-looking sweep with lane shuffles (the same multiply/subtract sequence per element as
+// dev_ldlt6_solve), the small sequential parts (triangular solves, se3_exp, pose product, rho test) run redundantly on all
+// lanes in registers, and the state is read once at the top and written once at the bottom. `st` and `sums` must be LDS.
+// ------------------------------------------------------------------------------------------------
+__device__ inline void dev_lm_step_wave(LmState* st, const double* sums, const int lane) {
+  const int li = lane / 6, lj = lane - li * 6;
+  const bool in36 = lane < 36, in12 = lane < 12, in6 = lane < 6;
+  double* x0p = reinterpret_cast<double*>(&st->x0);
+  double* xip = reinterpret_cast<double*>(&st->xi);
+  double* xlp = reinterpret_cast<double*>(&st->x_lin);
+  int phase = st->phase;
+  double lambda = st->lambda, nu = st->nu, y0 = st->y0;
+  int outer_iter = st->outer_iter, inner_iter = st->inner_iter, converged = st->converged, lm_failed = st->lm_failed;
+  int num_linearize = st->num_linearize, num_error_evals = st->num_error_evals, nr_iterations = st->nr_iterations, corr_cur = st->corr_cur;
+  const int max_iterations = st->max_iterations, lm_max_iterations = st->lm_max_iterations;
+  auto commit = [&]() {
+    if (lane == 0) {
+      st->phase = phase; st->lambda = lambda; st->nu = nu; st->y0 = y0;
+      st->outer_iter = outer_iter; st->inner_iter = inner_iter; st->converged = converged; st->lm_failed = lm_failed;
+      st->num_linearize = num_linearize; st->num_error_evals = num_error_evals; st->nr_iterations = nr_iterations; st->corr_cur = corr_cur;
+    }
+  };
+  bool consume = false;
+  if (phase == PH_LINEARIZE) {
+    if (in12) xlp[lane] = x0p[lane];  // x_lin = x0
+    consume = true;
+  } else {  // PH_TRIAL (fused): trial error of this launch at sums[28]
+    const double yi = sums[28];
+    num_error_evals++;
+    double denom = 0;
+#pragma unroll
+    for (int j = 0; j < 6; j++) denom += st->d[j] * (lambda * st->d[j] - st->b[j]);
+    const double rho = (y0 - yi) / denom;
+    const bool conv = dev_is_converged(st, st->delta);
+    if (rho < 0) {
+      if (conv) {  // step_lm returns true with x0 unchanged -> converged_ = true
+        converged = 1; outer_iter++; phase = PH_DONE;
+        commit();
+        return;
+      }
+      lambda = nu * lambda;
+      nu = 2 * nu;
+      inner_iter++;
+      if (inner_iter >= lm_max_iterations) { lm_failed = 1; phase = PH_DONE; commit(); return; }  // "lm not converged!!"
+      // new trial from the SAME (H, b); the speculative linearisation of this launch is discarded
+    } else {  // accepted
+      if (in12) x0p[lane] = xip[lane];  // x0 = xi
+      { const double u = 2 * rho - 1; lambda = lambda * fmax(1.0 / 3.0, 1 - u * u * u); }
+      if (in36) st->final_H[lane] = st->H[lane];
+      converged = conv ? 1 : 0;
+      outer_iter++;
+      if (converged || outer_iter >= max_iterations) { phase = PH_DONE; commit(); return; }
+      // the speculative linearisation at xi (== the new x0) is exactly the next step_lm's linearize()
+      corr_cur ^= 1;
+      if (in12) xlp[lane] = x0p[lane];
+      consume = true;
+    }
+  }
+  double h, bv;  // lane (li, lj) < 36: H element; lane < 6: b element
+  if (consume) {  // dev_lm_consume_linearization
+    y0 = sums[0];
+    int hidx;
+    {  // unpack_sums: rr at 7 (xx xy xz yy yz zz), rt at 13 (3x3 row-major), tt at 22
+      const int a = li < 3 ? li : li - 3, c = lj < 3 ? lj : lj - 3;
+      const int lo = a < c ? a : c, hi = a < c ? c : a;
+      const int sym = lo * 3 - (lo * (lo - 1)) / 2 + (hi - lo);
+      if (li < 3 && lj < 3) hidx = 7 + sym;
+      else if (li >= 3 && lj >= 3) hidx = 22 + sym;
+      else if (li < 3) hidx = 13 + li * 3 + (lj - 3);
+      else hidx = 13 + lj * 3 + (li - 3);
+    }
+    h = in36 ? sums[hidx] : 0.0;
+    bv = in6 ? sums[1 + lane] : 0.0;
+    if (in36) st->H[lane] = h;
+    if (in6) st->b[lane] = bv;
+    num_linearize++;
+    nr_iterations = outer_iter;
+    if (lambda < 0.0) {
+      double mx = 0;
+#pragma unroll
+      for (int i = 0; i < 6; i++) mx = fmax(mx, fabs(readlane_f64(h, i * 7)));
+      lambda = st->lm_init_lambda_factor * mx;
+    }
+    nu = 2.0;
+    inner_iter = 0;
+    if (phase == PH_LINEARIZE) {
+      if (lm_max_iterations <= 0) { lm_failed = 1; phase = PH_DONE; commit(); return; }
+      phase = PH_TRIAL;
+    }
+  } else {
+    h = in36 ? st->H[lane] : 0.0;
+    bv = in6 ? st->b[lane] : 0.0;
+  }
+  // ---- dev_lm_propose: d = (H + lambda I)^-1 (-b); xi = exp(d) * x0 ----
+  double a = h + ((in36 && li == lj) ? lambda : 0.0);
+  double Dinv[6];
+#pragma unroll
+  for (int k = 0; k < 6; k++) {  // column k of L becomes final, then the trailing lower triangle is updated (same operations, same order per element as dev_ldlt6_solve)
+    // the UNSCALED column entries travel while the pivot's reciprocal is computed (the shuffles do not wait for the division);
+    // every lane then scales its two operands itself -- the same s * Dinv[k] products as the column's own lanes
+    const double uik = __shfl(a, in36 ? li * 6 + k : 0), ujk = __shfl(a, in36 ? lj * 6 + k : 0);
+    const double dk = readlane_f64(a, k * 7);
+    const bool pivot_ok = fabs(dk) > 2.2250738585072014e-308;
+    Dinv[k] = pivot_ok ? 1.0 / dk : 0.0;
+    const double lik = pivot_ok ? uik * Dinv[k] : uik, ljk = pivot_ok ? ujk * Dinv[k] : ujk;
+    if (in36 && lj == k && li > k) a = lik;
+    if (in36 && lj > k && li >= lj) a -= lik * ljk * dk;
+  }
+  double L[15], nb[6], y[6], d[6];  // strictly lower part, row by row: (1,0) (2,0) (2,1) (3,0) ...
+  {
+    int t = 0;
+#pragma unroll
+    for (int i = 1; i < 6; i++)
+#pragma unroll
+      for (int j = 0; j < i; j++) L[t++] = readlane_f64(a, i * 6 + j);
+  }
+#pragma unroll
+  for (int i = 0; i < 6; i++) nb[i] = -readlane_f64(bv, i);
+#pragma unroll
+  for (int i = 0; i < 6; i++) { double sacc = nb[i]; for (int k = 0; k < i; k++) sacc -= L[i * (i - 1) / 2 + k] * y[k]; y[i] = sacc; }
+#pragma unroll
+  for (int i = 0; i < 6; i++) y[i] *= Dinv[i];
+#pragma unroll
+  for (int i = 5; i >= 0; i--) { double sacc = y[i]; for (int k = i + 1; k < 6; k++) sacc -= L[k * (k - 1) / 2 + i] * d[k]; d[i] = sacc; }
+  PoseD delta;
+  dev_se3_exp(d, delta);
+  if (lane == 0) {
+#pragma unroll
+    for (int j = 0; j < 6; j++) st->d[j] = d[j];
+    st->delta = delta;
+  }
+  // xi = delta * x0 (dev_pose_mul), one element per lane: lane p < 9 -> r[p / 3][p % 3], lanes 9..11 -> t[p - 9]; each lane reads
+  // its three x0 operands straight from the LDS copy of the state (no uniform 12 + 12 doubles in registers)
+  if (in12) {
+    const int i = lane < 9 ? lane / 3 : lane - 9;
+    const int col = lane < 9 ? lane - 3 * i : 9;  // first operand: x0.r[0][j] ... or x0.t[0]
+    const int stride = lane < 9 ? 3 : 1;
+    const double b0 = x0p[col], b1 = x0p[col + stride], b2 = x0p[col + 2 * stride];
+    const double a0 = i == 0 ? delta.r[0] : (i == 1 ? delta.r[3] : delta.r[6]);
+    const double a1 = i == 0 ? delta.r[1] : (i == 1 ? delta.r[4] : delta.r[7]);
+    const double a2 = i == 0 ? delta.r[2] : (i == 1 ? delta.r[5] : delta.r[8]);
+    const double ti = i == 0 ? delta.t[0] : (i == 1 ? delta.t[1] : delta.t[2]);
+    double val = a0 * b0 + a1 * b1 + a2 * b2;
+    if (lane >= 9) val = a0 * b0 + a1 * b1 + a2 * b2 + ti;
+    xip[lane] = val;
+  }
+  commit();
+}
+
 // tiny kernels for the multi-GPU path and for (re)initialising the state
 __global__ void lm_init_kernel(LmState* st, PoseD guess, double rot_eps, double trans_eps, double lambda_factor, int max_iter, int lm_max_iter, unsigned* ticket) {
   if (blockIdx.x == 0 && threadIdx.x <= 8) ticket[threadIdx.x] = 0;
@@ -291,37 +451,61 @@ __global__ void lm_init_kernel(LmState* st, PoseD guess, double rot_eps, double 
   st->outer_iter = 0; st->inner_iter = 0; st->converged = 0; st->lm_failed = 0; st->num_linearize = 0; st->num_error_evals = 0; st->nr_iterations = 0;
   for (int i = 0; i < 36; i++) st->final_H[i] = (i % 7 == 0) ? 1.0 : 0.0;
 }
-__global__ void lm_update_kernel(LmState* st) {
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
-  if (st->phase == PH_DONE) return;
-  dev_lm_step(st, st->sums);
+__global__ __launch_bounds__(64) void lm_update_kernel(LmState* st) {  // <<<1, 64>>>: one wave, state staged through LDS
+  __shared__ LmState s;
+  constexpr int WORDS = sizeof(LmState) / 8 - 1;  // without the barrier word
+  unsigned long long* g = reinterpret_cast<unsigned long long*>(st);
+  unsigned long long* l = reinterpret_cast<unsigned long long*>(&s);
+  for (int i = threadIdx.x; i < WORDS; i += 64) l[i] = g[i];
+  __syncthreads();
+  if (s.phase == PH_DONE) return;
+  dev_lm_step_wave(&s, s.sums, threadIdx.x);
+  __syncthreads();
+  for (int i = threadIdx.x; i < WORDS; i += 64) g[i] = l[i];
 }
 
 // ------------------------------------------------------------------------------------------------
 // per-correspondence terms
 // ------------------------------------------------------------------------------------------------
+// All correspondences of ONE source element share its transformed point q, and the Jacobian J = [skew(q), -I] depends on q
+// only (fast_vgicp_impl.hpp:152-160, compute_derivatives.cu:80-91). So per hit only
+//     S += w M  (6),   g += w M e  (3),   err += w e^T M e
+// is accumulated, and the 27 derivative sums of the element follow ONCE from  b = J^T g,  H = J^T S J  (item_sums below) --
+// instead of ~100 fp64 operations per hit.
 template <typename Real>
-__device__ __forceinline__ void accumulate_term(double* acc, const Vec3<Real>& q, const Vec3<Real>& mu, const Sym3<Real>& M, Real w, bool deriv) {
+struct ItemAcc {
+  Sym3<Real> S;
+  Vec3<Real> g;
+  Real err;
+};
+template <typename Real>
+__device__ __forceinline__ void hit_term(ItemAcc<Real>& it, const Vec3<Real>& q, const Vec3<Real>& mu, const Sym3<Real>& M, Real w, bool deriv) {
   const Vec3<Real> e = {mu.x - q.x, mu.y - q.y, mu.z - q.z};
   const Vec3<Real> Me = mul(M, e);
-  acc[0] += (double)(w * (e.x * Me.x + e.y * Me.y + e.z * Me.z));
+  it.err += w * (e.x * Me.x + e.y * Me.y + e.z * Me.z);
   if (!deriv) return;
-  // J = [skew(q), -I]:  b = w J^T M e = w [Me x q ; -Me]
-  const Vec3<Real> bq = cross(Me, q);
-  acc[1] += (double)(w * bq.x); acc[2] += (double)(w * bq.y); acc[3] += (double)(w * bq.z);
-  acc[4] -= (double)(w * Me.x); acc[5] -= (double)(w * Me.y); acc[6] -= (double)(w * Me.z);
-  // P = skew(q) M (columns q x M_col) ; H = w [[P S^T, P], [P^T, M]]
-  const Vec3<Real> c0 = {M.xx, M.xy, M.xz}, c1 = {M.xy, M.yy, M.yz}, c2 = {M.xz, M.yz, M.zz};
+  it.g.x += w * Me.x; it.g.y += w * Me.y; it.g.z += w * Me.z;
+  it.S.xx += w * M.xx; it.S.xy += w * M.xy; it.S.xz += w * M.xz; it.S.yy += w * M.yy; it.S.yz += w * M.yz; it.S.zz += w * M.zz;
+}
+// v[0] = err, v[1..6] = b, v[7..12] = H_rr (xx xy xz yy yz zz), v[13..21] = H_rt (row-major), v[22..27] = H_tt
+template <typename Real>
+__device__ __forceinline__ void item_sums(double* v, const ItemAcc<Real>& it, const Vec3<Real>& q) {
+  v[0] = (double)it.err;
+  // b = J^T g = [g x q ; -g]
+  const Vec3<Real> bq = cross(it.g, q);
+  v[1] = (double)bq.x; v[2] = (double)bq.y; v[3] = (double)bq.z;
+  v[4] = -(double)it.g.x; v[5] = -(double)it.g.y; v[6] = -(double)it.g.z;
+  // P = skew(q) S (columns q x S_col) ; H = [[P skew(q)^T, P], [P^T, S]]
+  const Sym3<Real>& S = it.S;
+  const Vec3<Real> c0 = {S.xx, S.xy, S.xz}, c1 = {S.xy, S.yy, S.yz}, c2 = {S.xz, S.yz, S.zz};
   const Vec3<Real> p0 = cross(q, c0), p1 = cross(q, c1), p2 = cross(q, c2);  // P_ij = p_j[i]
   const Vec3<Real> r0 = {p0.x, p1.x, p2.x}, r1 = {p0.y, p1.y, p2.y}, r2 = {p0.z, p1.z, p2.z};  // rows of P
   const Vec3<Real> h0 = cross(q, r0), h1 = cross(q, r1), h2 = cross(q, r2);  // rows of H_rr
-  acc[7] += (double)(w * h0.x); acc[8] += (double)(w * h0.y); acc[9] += (double)(w * h0.z);
-  acc[10] += (double)(w * h1.y); acc[11] += (double)(w * h1.z); acc[12] += (double)(w * h2.z);
-  acc[13] += (double)(w * r0.x); acc[14] += (double)(w * r0.y); acc[15] += (double)(w * r0.z);
-  acc[16] += (double)(w * r1.x); acc[17] += (double)(w * r1.y); acc[18] += (double)(w * r1.z);
-  acc[19] += (double)(w * r2.x); acc[20] += (double)(w * r2.y); acc[21] += (double)(w * r2.z);
-  acc[22] += (double)(w * M.xx); acc[23] += (double)(w * M.xy); acc[24] += (double)(w * M.xz);
-  acc[25] += (double)(w * M.yy); acc[26] += (double)(w * M.yz); acc[27] += (double)(w * M.zz);
+  v[7] = (double)h0.x; v[8] = (double)h0.y; v[9] = (double)h0.z; v[10] = (double)h1.y; v[11] = (double)h1.z; v[12] = (double)h2.z;
+  v[13] = (double)r0.x; v[14] = (double)r0.y; v[15] = (double)r0.z;
+  v[16] = (double)r1.x; v[17] = (double)r1.y; v[18] = (double)r1.z;
+  v[19] = (double)r2.x; v[20] = (double)r2.y; v[21] = (double)r2.z;
+  v[22] = (double)S.xx; v[23] = (double)S.xy; v[24] = (double)S.xz; v[25] = (double)S.yy; v[26] = (double)S.yz; v[27] = (double)S.zz;
 }
 
 // Continue a linear probe from `slot` (the first bucket has already been inspected).
@@ -354,6 +538,27 @@ __device__ __forceinline__ double uniform_f64(double x) {  // wave-uniform value
   return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
 }
 
+// gfx950 v_permlane{32,16}_swap on a double (both dwords): afterwards the lanes whose bit W is clear hold (own a, partner's a)
+// and the lanes whose bit W is set hold (partner's b, own b) in (a, b) -- partner = lane ^ W -- so that a + b is the pair
+// sum of `a` on the lower lane and of `b` on the upper lane.
+template <int W>
+__device__ __forceinline__ void swap_halves(double& a, double& b) {
+  static_assert(W == 32 || W == 16, "v_permlane32_swap / v_permlane16_swap");
+  const unsigned long long ua = (unsigned long long)__double_as_longlong(a), ub = (unsigned long long)__double_as_longlong(b);
+  unsigned alo = (unsigned)ua, ahi = (unsigned)(ua >> 32), blo = (unsigned)ub, bhi = (unsigned)(ub >> 32);
+  if constexpr (W == 32) {
+    const auto r0 = __builtin_amdgcn_permlane32_swap(alo, blo, false, false);
+    const auto r1 = __builtin_amdgcn_permlane32_swap(ahi, bhi, false, false);
+    alo = r0[0]; blo = r0[1]; ahi = r1[0]; bhi = r1[1];
+  } else {
+    const auto r0 = __builtin_amdgcn_permlane16_swap(alo, blo, false, false);
+    const auto r1 = __builtin_amdgcn_permlane16_swap(ahi, bhi, false, false);
+    alo = r0[0]; blo = r0[1]; ahi = r1[0]; bhi = r1[1];
+  }
+  a = __longlong_as_double((long long)(((unsigned long long)ahi << 32) | alo));
+  b = __longlong_as_double((long long)(((unsigned long long)bhi << 32) | blo));
+}
+
 #ifdef FVH_COST_TIMING
 // Debug build only (-DFVH_COST_TIMING): 100 MHz wall-clock stamps of the LAST workgroup's walk through the epilogue
 // (slot 0 = earliest workgroup start of the launch, slot 9 = the last workgroup's own start). Read with
@@ -369,9 +574,12 @@ __device__ unsigned long long g_ptime[16][512][12];  // persistent kernel, per t
 #define FVH_PT_MAX(trip, k) do { } while (0)
 #endif
 
-// 2 workgroups per CU are part of the design (the persistent grid must be co-resident, 66 KB of LDS each): tell the
-// register allocator, which otherwise drifts over 256 VGPRs + AGPRs with small code changes and halves the grid.
-#define FVH_COST_BOUNDS __launch_bounds__(256, 2)
+// Workgroups per CU the register allocator must make room for (the persistent grid has to be co-resident, so this is part
+// of the design, not a hint): 3 -> at most 168 VGPRs. LDS (5 KB) no longer limits it.
+#ifndef FVH_COST_WG_PER_CU
+#define FVH_COST_WG_PER_CU 3
+#endif
+#define FVH_COST_BOUNDS __launch_bounds__(256, FVH_COST_WG_PER_CU)
 template <typename Real, int MODE, bool PERSIST>
 __global__ FVH_COST_BOUNDS void cost_kernel(CostParams P) {
 #ifdef FVH_COST_TIMING
@@ -428,15 +636,24 @@ __global__ FVH_COST_BOUNDS void cost_kernel(CostParams P) {
   int* corr_old = P.corr + (size_t)corr_sel * P.corr_stride;                      // read (stored ids)
   int* corr_new = fused ? P.corr + (size_t)(corr_sel ^ 1) * P.corr_stride : corr_old;  // written by the find
 
-  double acc[NSUM];
-#pragma unroll
-  for (int v = 0; v < NSUM; v++) acc[v] = 0.0;
-  double acc_y = 0.0;  // fused: trial error with the old ids
+  // Lane-distributed wave accumulator: after every work item the wave reduces the 29 sums of its 64 items with a
+  // transposing butterfly (below) that leaves the wave total of slot L >> 1 in lane L -- so the running sums of the whole
+  // main loop live in ONE fp64 register per lane instead of 29 (58 VGPRs of a kernel that sat at the 256-VGPR limit).
+  // At 17k points a thread has a single item per trip, i.e. the butterfly runs once, exactly like a reduction after the loop.
+  double wacc = 0.0;
+  const int lane = threadIdx.x & 63;
 
   const float4* tf = reinterpret_cast<const float4*>(P.table);
   // (consecutive threads take consecutive items on purpose: spreading a workgroup's items over the cloud made the launch
   // 24 % slower -- the loop is sensitive to how many distinct cache lines a wave touches)
-  for (int w = blockIdx.x * 256 + threadIdx.x; w < n_items; w += gridDim.x * 256) {
+  // The loop bound is wave-uniform (the butterfly needs all 64 lanes); lanes past the end contribute zeros.
+  for (int wbase = blockIdx.x * 256 + (threadIdx.x & 192); wbase < n_items; wbase += gridDim.x * 256) {
+    const int w = wbase + lane;
+    ItemAcc<Real> it = {{0, 0, 0, 0, 0, 0}, {0, 0, 0}, 0};
+    Real acc_y = 0;  // fused: trial error with the old ids
+    Vec3<Real> q = {0, 0, 0};
+    bool any_hit = false;  // an element without correspondences contributes exact zeros (its q may be non-finite: 0 * NaN)
+    if (w < n_items) {
     const int i0 = w / P.groups_per_src;
     const int g = w - i0 * P.groups_per_src;
     const int i = P.order ? P.order[i0] : i0;
@@ -455,7 +672,7 @@ __global__ FVH_COST_BOUNDS void cost_kernel(CostParams P) {
       RCR = rotate_cov(fused ? ev.r : lin.r, CA);
       if (fused) RCR_old = rotate_cov(lin.r, CA);
     }
-    const Vec3<Real> q = transform(ev, a);
+    q = transform(ev, a);
     int cx = 0, cy = 0, cz = 0;
     bool coord_ok = true;  // false: non-finite / out-of-range source point -> no correspondences (and no (int)floor(NaN))
     if (do_find) {
@@ -474,28 +691,35 @@ __global__ FVH_COST_BOUNDS void cost_kernel(CostParams P) {
 #pragma unroll
         for (int c = 0; c < COST_CH; c++) bo[c] = (oc + c < o_end) ? corr_old[(size_t)i * P.n_off + oc + c] : -1;
       }
+      float4 q1[COST_CH], q2[COST_CH];
+      float2 q3[COST_CH];  // voxel records (q3 = {c_yz, c_zz}: only 8 of its 16 bytes are data): of the old ids first (fused), then of the ids of this evaluation
       if (do_find) {
         unsigned long long key[COST_CH];
         unsigned slot[COST_CH];
         unsigned long long k0[COST_CH];
-        bool live[COST_CH];
+        constexpr unsigned long long DEAD_KEY = FVH_EMPTY_KEY - 1;  // no voxel has it (keys use 63 bits): "this lookup does not exist" without a flag register
 #pragma unroll
         for (int c = 0; c < COST_CH; c++) {
           const int o = min(oc + c, o_end - 1);
           const int x = cx + P.offsets[3 * o], y = cy + P.offsets[3 * o + 1], z = cz + P.offsets[3 * o + 2];
-          live[c] = (oc + c < o_end) && coord_ok && coord_in_range(x, y, z);
-          key[c] = pack_key(x, y, z);
+          const bool live = (oc + c < o_end) && coord_ok && coord_in_range(x, y, z);
+          key[c] = live ? pack_key(x, y, z) : DEAD_KEY;
           slot[c] = hash_key(key[c]) & P.mask;
           k0[c] = P.keys[slot[c]];
+        }
+        if (fused) {  // the old ids' records, in flight together with the probes
+#pragma unroll
+          for (int c = 0; c < COST_CH; c++) {
+            const size_t base = (size_t)max(bo[c], 0) * 4;
+            q1[c] = tf[base + 1]; q2[c] = tf[base + 2]; q3[c] = *reinterpret_cast<const float2*>(tf + base + 3);
+          }
         }
 #pragma unroll
         for (int c = 0; c < COST_CH; c++) {
           const unsigned long long k = k0[c];
           int r = -1;
-          if (live[c]) {
-            if (k == key[c]) r = (int)slot[c];
-            else if (k != FVH_EMPTY_KEY) r = probe_continue(P.keys, P.mask, key[c], slot[c]);  // rare at load <= 0.25
-          }
+          if (k == key[c]) r = (int)slot[c];
+          else if (k != FVH_EMPTY_KEY && key[c] != DEAD_KEY) r = probe_continue(P.keys, P.mask, key[c], slot[c]);  // rare at load <= 0.25
           b[c] = r;
           if (oc + c < o_end) corr_new[(size_t)i * P.n_off + oc + c] = r;
         }
@@ -505,18 +729,16 @@ __global__ FVH_COST_BOUNDS void cost_kernel(CostParams P) {
       }
       if (!do_cost) continue;
       // ---- round trip 3: the voxel records of all hits, unconditional loads (bucket 0 for misses) ----
-      float4 q1[COST_CH], q2[COST_CH], q3[COST_CH];
-#pragma unroll
-      for (int c = 0; c < COST_CH; c++) {
-        const size_t base = (size_t)max(b[c], 0) * 4;
-        q1[c] = tf[base + 1]; q2[c] = tf[base + 2]; q3[c] = tf[base + 3];
-      }
-      if (fused) {  // trial error with the OLD ids (usually the same buckets -> the lines are already on their way)
+      // Fused trip: the records of the OLD ids were requested above, together with the key probes (they only need the stored
+      // ids, not the probe results), and near convergence the new id of a slot IS its old id -- then the record is already in
+      // registers and the third dependent round trip disappears; only slots whose voxel changed load again, after the trial
+      // error of the old ids has consumed the old record.
+      if (fused) {  // trial error with the OLD ids
 #pragma unroll
         for (int c = 0; c < COST_CH; c++) {
           if (bo[c] < 0) continue;
-          const size_t base = (size_t)bo[c] * 4;
-          const float4 o1 = tf[base + 1], o2 = tf[base + 2], o3 = tf[base + 3];
+          const float4 o1 = q1[c], o2 = q2[c];
+          const float2 o3 = q3[c];
           const int npts = (int)o1.w;
           const Vec3<Real> mu = {(Real)o1.x, (Real)o1.y, (Real)o1.z};
           const Sym3<Real> A = {(Real)o2.x + RCR_old.xx, (Real)o2.y + RCR_old.xy, (Real)o2.z + RCR_old.xz, (Real)o2.w + RCR_old.yy, (Real)o3.x + RCR_old.yz, (Real)o3.y + RCR_old.zz};
@@ -532,7 +754,20 @@ __global__ FVH_COST_BOUNDS void cost_kernel(CostParams P) {
           }
           const Sym3<Real> M = inverse(A);
           const Vec3<Real> Me = mul(M, e);
-          acc_y += (double)(wgt * (e.x * Me.x + e.y * Me.y + e.z * Me.z));
+          acc_y += wgt * (e.x * Me.x + e.y * Me.y + e.z * Me.z);
+        }
+#pragma unroll
+        for (int c = 0; c < COST_CH; c++) {
+          if (b[c] >= 0 && b[c] != bo[c]) {  // the voxel of this slot changed: fetch its record now
+            const size_t base = (size_t)b[c] * 4;
+            q1[c] = tf[base + 1]; q2[c] = tf[base + 2]; q3[c] = *reinterpret_cast<const float2*>(tf + base + 3);
+          }
+        }
+      } else {
+#pragma unroll
+        for (int c = 0; c < COST_CH; c++) {
+          const size_t base = (size_t)max(b[c], 0) * 4;
+          q1[c] = tf[base + 1]; q2[c] = tf[base + 2]; q3[c] = *reinterpret_cast<const float2*>(tf + base + 3);
         }
       }
 #pragma unroll
@@ -552,45 +787,73 @@ __global__ FVH_COST_BOUNDS void cost_kernel(CostParams P) {
           wgt = ksq / (ksq + (ex * ex + ey * ey + ez * ez));  // cauchy(resolution, |e|) :15-18
         }
         const Sym3<Real> M = inverse(A);
-        accumulate_term<Real>(acc, q, mu, M, wgt, do_deriv);
+        hit_term<Real>(it, q, mu, M, wgt, do_deriv);
+        any_hit = true;
       }
+    }
+    }  // w < n_items
+    if (!do_cost) continue;  // host-mode PH_FIND_ONLY
+
+    // ---- per-item wave reduction: transposing butterfly over 32 slots (28 sums, the fused trial error, 3 zeros) ----
+    // Step m = 32, 16, 8, 4, 2: the lane pair (L, L ^ m) splits its current slots in halves, each lane keeps one half and
+    // receives the partner's values of that half -- 16 + 8 + 4 + 2 + 1 exchanges instead of 29 x 6 for a per-value tree --
+    // and after the last step (m = 1) lane L holds the WAVE total of slot L >> 1. The two big steps use gfx950's
+    // v_permlane32_swap / v_permlane16_swap, which exchange "my upper half" against "your lower half" in place: no select,
+    // no LDS crossbar, 2 instructions per double. (Round 1 reduced through a 61 KB tile[29][264] LDS transpose, which
+    // together with 256 VGPRs pinned the kernel at two workgroups per CU.) Every slot takes the same summation tree: the
+    // trial error is the same number whether it travels in slot 28 (fused) or in slot 0 (host-mode error evaluation).
+    {
+      double v[32];
+      if (do_deriv) {
+        const Vec3<Real> qz = {any_hit ? q.x : (Real)0, any_hit ? q.y : (Real)0, any_hit ? q.z : (Real)0};
+        item_sums<Real>(v, it, qz);
+      } else {
+        v[0] = (double)it.err;
+#pragma unroll
+        for (int j = 1; j < NSUM; j++) v[j] = 0.0;
+      }
+      v[28] = (double)acc_y;
+      v[29] = v[30] = v[31] = 0.0;
+#pragma unroll
+      for (int j = 0; j < 16; j++) { double a = v[j], b = v[j + 16]; swap_halves<32>(a, b); v[j] = a + b; }
+#pragma unroll
+      for (int j = 0; j < 8; j++) { double a = v[j], b = v[j + 8]; swap_halves<16>(a, b); v[j] = a + b; }
+#pragma unroll
+      for (int m = 8; m >= 2; m >>= 1) {
+        const bool up = (lane & m) != 0;
+        const int half = m >> 1;  // slots kept: 4, 2, 1
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+          if (j < half) {
+            const double lo = v[j], hi = v[j + half];
+            const double recv = __shfl_xor(up ? lo : hi, m);
+            v[j] = (up ? hi : lo) + recv;
+          }
+        }
+      }
+      v[0] += __shfl_xor(v[0], 1);
+      wacc += v[0];
     }
   }
 
-  // ---- workgroup reduction through an LDS transpose ------------------------------------------
-  // Every thread stores its values to tile[v][thread] (row stride 264 doubles: conflict-free for
-  // both phases), then thread (v = t/8, part = t%8) sums the 32 entries part, part+8, ... of row v
-  // and 3 shuffle steps combine the 8 parts. ~66 LDS operations per thread instead of the 336
-  // ds_bpermute of a per-value wave-shuffle tree (measured: the (H,b) launch cost 7 us more than
-  // the error-only launch, almost all of it crossbar traffic).
+  // ---- workgroup reduction: 4 waves x 32 slots through 1 KB of LDS ----------------------------------------
   if (!do_cost) return;  // host-mode PH_FIND_ONLY (never persistent)
+  // Everything from here to the end of the trip is written in terms of `tid`, an OPAQUE copy of threadIdx.x made per trip:
+  // in the persistent instantiation the epilogue sits inside the trip loop, and the optimiser otherwise hoists its ~30
+  // thread-index-derived addresses and flags into the kernel prologue, where they stay live across the main loop
+  // (213 instead of 163 VGPRs).
+  int tid = threadIdx.x;
+  asm volatile("" : "+v"(tid));
   FVH_STAMP(1);
   if (PERSIST) FVH_PT_MAX(gen, 1);
-  constexpr int RED_ROWS = NSUM + 1, RED_STRIDE = 264;
-  __shared__ double tile[RED_ROWS * RED_STRIDE];
-  const int nsum = do_deriv ? NSUM : 1;
-  const int t = threadIdx.x;
-#pragma unroll
-  for (int v = 0; v < NSUM; v++)
-    if (v < nsum) tile[v * RED_STRIDE + t] = acc[v];  // static indexing keeps acc[] in VGPRs
-  if (fused) tile[NSUM * RED_STRIDE + t] = acc_y;
+  if ((tid & 1) == 0) red[tid >> 6][(tid & 63) >> 1] = wacc;  // lane L (even) publishes slot L >> 1 of its wave
   __syncthreads();
-  {
-    const int v = t >> 3, part = t & 7;
-    const bool live = (v < nsum) || (fused && v == NSUM);
-    double x = 0.0;
-    if (v < RED_ROWS && live) {
-      const double* row = tile + v * RED_STRIDE + part;
-#pragma unroll 8
-      for (int j = 0; j < 32; j++) x += row[8 * j];
-    }
-#pragma unroll
-    for (int off = 4; off > 0; off >>= 1) x += __shfl_xor(x, off);
+  if (tid < PART_STRIDE) {
+    const int vv = tid;
+    const double x = (red[0][vv] + red[1][vv]) + (red[2][vv] + red[3][vv]);
     // write-through (sc1) so another workgroup can read it from L2 without a release fence;
     // row slot v: sums 0..27, fused trial error at 28 (== NSUM), 29..31 zero
-    if (part == 0 && v < PART_STRIDE) {
-      __hip_atomic_store(&P.partials[(size_t)blockIdx.x * PART_STRIDE + v], (v < RED_ROWS && live) ? x : 0.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
+    __hip_atomic_store(&P.partials[(size_t)blockIdx.x * PART_STRIDE + vv], x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
@@ -608,7 +871,7 @@ __global__ FVH_COST_BOUNDS void cost_kernel(CostParams P) {
   // sum of this group's partial rows -> fin[chunk][v] -> one group row (fixed order: deterministic)
   auto reduce_group_rows = [&](size_t out_row) {
     {
-      const int v = threadIdx.x & 31, chunk = threadIdx.x >> 5;  // 8 chunks x 32 values
+      const int v = tid & 31, chunk = tid >> 5;  // 8 chunks x 32 values
       double s = 0.0;
       for (unsigned j0 = chunk; j0 < gsize; j0 += 8 * 8) {
         double t[8];
@@ -623,8 +886,8 @@ __global__ FVH_COST_BOUNDS void cost_kernel(CostParams P) {
       fin[chunk][v] = s;
     }
     __syncthreads();
-    if (threadIdx.x < PART_STRIDE) {
-      const int v = threadIdx.x;
+    if (tid < PART_STRIDE) {
+      const int v = tid;
       double s = 0.0;
 #pragma unroll
       for (int c = 0; c < 8; c++) s += fin[c][v];
@@ -636,13 +899,13 @@ __global__ FVH_COST_BOUNDS void cost_kernel(CostParams P) {
   // sum of the <= 8 group rows in group order -> red[0][v]
   auto reduce_final = [&](size_t first_row) {
     {
-      const int v = threadIdx.x & 31;
-      const unsigned g = threadIdx.x >> 5;
+      const int v = tid & 31;
+      const unsigned g = tid >> 5;
       fin[g][v] = (g < ngroups) ? __hip_atomic_load(&P.partials[(first_row + g) * PART_STRIDE + v], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
     }
     __syncthreads();
-    if (threadIdx.x < PART_STRIDE) {
-      const int v = threadIdx.x;
+    if (tid < PART_STRIDE) {
+      const int v = tid;
       double s = 0.0;
 #pragma unroll
       for (int c = 0; c < 8; c++) s += fin[c][v];
@@ -667,42 +930,43 @@ __global__ FVH_COST_BOUNDS void cost_kernel(CostParams P) {
     // thread, fixed order), publishes one group row and arrives at the top counter; the last group
     // sums the <= 8 group rows and runs the LM step. No address sees more than gridDim/8 + 8 atomics
     // and no thread walks a long chain of dependent L2 round trips.
-    if (threadIdx.x == 0) s_last = (atomicAdd(&P.ticket[grp], 1u) == gsize - 1);
+    if (tid == 0) s_last = (atomicAdd(&P.ticket[grp], 1u) == gsize - 1);
     __syncthreads();
     if (!s_last) return;
     FVH_STAMP(3);
     reduce_group_rows((size_t)MAX_PARTIAL_ROWS + grp);
-    if (threadIdx.x == 0) s_last = (atomicAdd(&P.ticket[TICKET_GROUPS], 1u) == ngroups - 1);
+    if (tid == 0) s_last = (atomicAdd(&P.ticket[TICKET_GROUPS], 1u) == ngroups - 1);
     __syncthreads();
     if (!s_last) return;
     FVH_STAMP(4);
 
     // ---- the very last workgroup: sum the group rows in group order (deterministic), LM step ----
     reduce_final((size_t)MAX_PARTIAL_ROWS);
-    if (threadIdx.x <= TICKET_GROUPS) P.ticket[threadIdx.x] = 0;  // re-arm for the next launch
+    if (tid <= TICKET_GROUPS) P.ticket[tid] = 0;  // re-arm for the next launch
     // The LM step is one thread of dependent fp64 math; run it on an LDS copy of the state (a global
     // round trip per st-> access would cost more than the arithmetic) and write the state back with all lanes.
-    for (int i = threadIdx.x; i < ST_WORDS; i += 256) reinterpret_cast<unsigned long long*>(&s_st)[i] = st_words[i];
+    for (int i = tid; i < ST_WORDS; i += 256) reinterpret_cast<unsigned long long*>(&s_st)[i] = st_words[i];
     int vm_nv = 0, vm_dr = 0;
-    if (threadIdx.x == 0) {
+    if (tid == 0) {
       vm_nv = P.vm_counters[0];
       vm_dr = P.vm_counters[1] + (P.vm_counters2 ? P.vm_counters2[1] : 0);
     }
     __syncthreads();
     FVH_STAMP(5);
-    if (threadIdx.x == 0) {
+    if (tid == 0) {
       for (int v = 0; v < PART_STRIDE; v++) s_st.sums[v] = red[0][v];
       s_st.vm_num_voxels = vm_nv;
       s_st.vm_dropped = vm_dr;
       if (P.host_phase < 0 && P.init) init_state();
-      if (P.host_phase < 0 && !P.defer_lm) dev_lm_step(&s_st, red[0]);
     }
+    __syncthreads();
+    if (P.host_phase < 0 && !P.defer_lm && tid < 64) dev_lm_step_wave(&s_st, red[0], tid);
     FVH_STAMP(6);
     __syncthreads();
-    for (int i = threadIdx.x; i < ST_WORDS; i += 256) st_words[i] = reinterpret_cast<const unsigned long long*>(&s_st)[i];
+    for (int i = tid; i < ST_WORDS; i += 256) st_words[i] = reinterpret_cast<const unsigned long long*>(&s_st)[i];
 #ifdef FVH_COST_TIMING
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if (threadIdx.x == 0) {
+    if (tid == 0) {
       stamp[7] = wall_clock64();
       for (int i = 1; i <= 7; i++) g_cost_timing[i] = stamp[i];
       g_cost_timing[8] = gridDim.x;
@@ -728,19 +992,21 @@ __global__ FVH_COST_BOUNDS void cost_kernel(CostParams P) {
     // Group rows alternate by trip parity; only the opener reads them, and trip t + 1's rows are written after every
     // workgroup -- the opener included -- has arrived at trip t + 1.
     const unsigned trip = gen;
-    const double want_tag = (double)(P.launch_tag * 4096ull + trip + 1);
-    const double abort_tag = -(double)(P.launch_tag * 4096ull);  // launch-specific: a poisoned row of an older launch means nothing
+    unsigned long long ltag = P.launch_tag;
+    asm volatile("" : "+s"(ltag));  // opaque per trip: otherwise the two conversions below are hoisted out of the trip loop and held in 4 VGPRs across the main loop
+    const double want_tag = (double)(ltag * 4096ull + trip + 1);
+    const double abort_tag = -(double)(ltag * 4096ull);  // launch-specific: a poisoned row of an older launch means nothing
     const size_t grow0 = (size_t)MAX_PARTIAL_ROWS + (size_t)(trip & 1u) * TICKET_GROUPS;
     __shared__ double bc[BCAST_SLOTS];  // payload of the broadcast row as seen by this workgroup
     static_assert(TICKET_GROUPS == 8, "tb0..tb7");
     const unsigned tb = grp == 0 ? P.tb0 : grp == 1 ? P.tb1 : grp == 2 ? P.tb2 : grp == 3 ? P.tb3 : grp == 4 ? P.tb4 : grp == 5 ? P.tb5 : grp == 6 ? P.tb6 : P.tb7;
-    if (threadIdx.x == 0) s_last = (atomicAdd(&P.ticket[grp * 32], 1u) == tb + gsize * (trip + 1) - 1);
+    if (tid == 0) s_last = (atomicAdd(&P.ticket[grp * 32], 1u) == tb + gsize * (trip + 1) - 1);
     FVH_PT_MAX(trip, 2);
     __syncthreads();
     if (s_last) {
       reduce_group_rows(grow0 + grp);
       FVH_PT_MAX(trip, 5);
-      if (threadIdx.x == 0) atomicAdd(&P.ticket[TICKET_GROUPS * 32], 1u);
+      if (tid == 0) atomicAdd(&P.ticket[TICKET_GROUPS * 32], 1u);
       __syncthreads();
     }
     // The opener is always workgroup 0 (not whoever arrives last): the LM step is ~20 KB of code that runs once per
@@ -748,7 +1014,7 @@ __global__ FVH_COST_BOUNDS void cost_kernel(CostParams P) {
     // state stays in this workgroup's LDS for the whole launch instead of travelling through memory each trip.
     const bool opener = (blockIdx.x == 0);
     if (opener) {
-      if (threadIdx.x == 0) {  // wait for the last group (its own arrival included)
+      if (tid == 0) {  // wait for the last group (its own arrival included)
         const unsigned want = P.tb_top + ngroups * (trip + 1);
         const unsigned long long t0 = wall_clock64();
         int ok = 1;
@@ -760,29 +1026,29 @@ __global__ FVH_COST_BOUNDS void cost_kernel(CostParams P) {
       }
       __syncthreads();
       if (!s_last) {  // not every workgroup is resident / something is stuck: never hang the GPU -- poison every tag and leave
-        for (int idx = threadIdx.x; idx < PERSIST_REPLICAS * BCAST_SLOTS / 8; idx += 256) __hip_atomic_store(&P.bcast[idx * 8 + 7], abort_tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (threadIdx.x == 0) __hip_atomic_store(&st->aborted, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (int idx = tid; idx < PERSIST_REPLICAS * BCAST_SLOTS / 8; idx += 256) __hip_atomic_store(&P.bcast[idx * 8 + 7], abort_tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (tid == 0) __hip_atomic_store(&st->aborted, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         return;
       }
       FVH_PT_MAX(trip, 6);
       reduce_final(grow0);
       __syncthreads();
       FVH_PT_MAX(trip, 7);
-      if (trip == 0 && threadIdx.x == 0) {
+      if (trip == 0 && tid == 0) {
         init_state();
         s_st.vm_num_voxels = P.vm_counters[0];
         s_st.vm_dropped = P.vm_counters[1] + (P.vm_counters2 ? P.vm_counters2[1] : 0);
       }
-      if (threadIdx.x >= 64 && threadIdx.x < 64 + PART_STRIDE) s_st.sums[threadIdx.x - 64] = red[0][threadIdx.x - 64];  // (a lane each, not 32 round trips of lane 0)
+      if (tid >= 64 && tid < 64 + PART_STRIDE) s_st.sums[tid - 64] = red[0][tid - 64];  // (a lane each, not 32 round trips of lane 0)
       __syncthreads();
       FVH_PT_MAX(trip, 8);
-      if (threadIdx.x == 0) dev_lm_step(&s_st, red[0]);
+      if (tid < 64) dev_lm_step_wave(&s_st, red[0], tid);
       FVH_PT_MAX(trip, 9);
       __syncthreads();
-      if (threadIdx.x < 26) {  // payload: phase, correspondence buffer, x_lin, evaluation pose of the next trip
+      if (tid < 26) {  // payload: phase, correspondence buffer, x_lin, evaluation pose of the next trip
         const int ph = s_st.phase;
         const PoseD& pe = (ph == PH_LINEARIZE) ? s_st.x0 : s_st.xi;
-        const int d = threadIdx.x;
+        const int d = tid;
         double v;
         if (d == 0) v = (double)ph;
         else if (d == 1) v = (double)s_st.corr_cur;
@@ -794,29 +1060,29 @@ __global__ FVH_COST_BOUNDS void cost_kernel(CostParams P) {
       }
       __syncthreads();
       FVH_PT_MAX(trip, 10);
-      for (int idx = threadIdx.x; idx < PERSIST_REPLICAS * BCAST_SLOTS; idx += 256) {
+      for (int idx = tid; idx < PERSIST_REPLICAS * BCAST_SLOTS; idx += 256) {
         const int slot = idx % BCAST_SLOTS, seg = slot >> 3, k = slot & 7, d = seg * 7 + k;
         const double val = (k == 7) ? want_tag : (d < 26 ? bc[d] : 0.0);
         __hip_atomic_store(&P.bcast[idx], val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
       FVH_PT_MAX(trip, 3);
       if (s_st.phase == PH_DONE) {  // the state leaves the LDS once, at the end (the kernel boundary makes it visible)
-        for (int i = threadIdx.x; i < ST_WORDS; i += 256) st_words[i] = reinterpret_cast<const unsigned long long*>(&s_st)[i];
+        for (int i = tid; i < ST_WORDS; i += 256) st_words[i] = reinterpret_cast<const unsigned long long*>(&s_st)[i];
         if (P.result_host) {
           // ... and goes straight to the host through mapped pinned memory: the caller spins on the sequence word instead of
           // paying a device-to-host copy kernel and a stream synchronisation (~8 us of a 300 us registration)
-          for (int i = threadIdx.x; i < ST_WORDS; i += 256)
+          for (int i = tid; i < ST_WORDS; i += 256)
             __hip_atomic_store(&P.result_host[i], reinterpret_cast<const unsigned long long*>(&s_st)[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
           asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
           __syncthreads();
-          if (threadIdx.x == 0) __hip_atomic_store(&P.result_host[ST_WORDS + 1], P.launch_tag, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+          if (tid == 0) __hip_atomic_store(&P.result_host[ST_WORDS + 1], P.launch_tag, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
         }
       }
     }
     if (!opener) {
-      if (threadIdx.x < 64) {  // wave 0 polls this workgroup's copy
+      if (tid < 64) {  // wave 0 polls this workgroup's copy
         const double* rep = P.bcast + (size_t)(blockIdx.x % PERSIST_REPLICAS) * BCAST_SLOTS;
-        const int lane = threadIdx.x;
+        const int lane = tid;
         const bool is_slot = lane < BCAST_SLOTS, is_tag = is_slot && ((lane & 7) == 7);
         const unsigned long long t0 = wall_clock64();
         int ok = 0;
@@ -851,9 +1117,9 @@ __global__ FVH_COST_BOUNDS void cost_kernel(CostParams P) {
     corr_sel = (int)uniform_f64(bc[1]);
     // payload 2..13 = x_lin (r[9], t[3]), 14..25 = evaluation pose -> s_pose[0], s_pose[1] (every reader of the previous
     // poses is past the barrier above)
-    if (threadIdx.x < 24) {
-      const int which = threadIdx.x / 12, k = threadIdx.x % 12;
-      const Real v = (Real)bc[2 + threadIdx.x];
+    if (tid < 24) {
+      const int which = tid / 12, k = tid % 12;
+      const Real v = (Real)bc[2 + tid];
       if (k < 9) s_pose[which].r[k] = v; else s_pose[which].t[k - 9] = v;
     }
     __syncthreads();  // bc[] is rewritten after the next barrier; s_pose is read by the next trip

@@ -54,9 +54,9 @@ def test_product_does_not_import_oracle():
 
 
 def test_kernels_stay_on_the_right_side_of_the_register_cliff():
-    """hipcc's resource-usage remarks for gfx950 (cross-compiled, no GPU): the persistent LM kernel needs two workgroups per
-    CU (256 VGPRs, <= 80 KB LDS) -- one more live register halves its occupancy and doubled its run time when that happened
-    during round 1; the one-query-per-wave kernels rely on full occupancy. tools/kernel_resources.py prints the table."""
+    """hipcc's resource-usage remarks for gfx950 (cross-compiled, no GPU): every instantiation of the LM kernel must fit THREE
+    workgroups per CU (<= 168 VGPRs, no VGPR spill, LDS far below 160 KB / 3) -- round 1 sat at 256 VGPRs + 66 KB LDS = two; the
+    one-query-per-wave kernels rely on full occupancy. tools/kernel_resources.py prints the table."""
     import importlib.util
     spec = importlib.util.spec_from_file_location("kernel_resources", os.path.join(util.ROOT, "tools", "kernel_resources.py"))
     mod = importlib.util.module_from_spec(spec)
@@ -65,8 +65,9 @@ def test_kernels_stay_on_the_right_side_of_the_register_cliff():
     cost = {k: v for k, v in res.items() if "cost_kernel<" in k}
     assert len(cost) == 12, sorted(cost)  # {double, float} x {VGICP, NDT P2D, NDT D2D} x {per-transition, persistent}
     for k, v in cost.items():
-        assert v["occupancy"] >= 2 and v["vgprs"] <= 256 and v["lds"] <= 80 * 1024, (k, v)
-        assert v["vgpr_spill"] <= 8 and v["scratch"] <= 64, (k, v)  # today: 6 spilled VGPRs in the fp64 persistent VGICP / D2D variants, none elsewhere
+        assert v["occupancy"] >= 3 and v["vgprs"] <= 168 and v["lds"] <= 8 * 1024, (k, v)
+        assert v["vgpr_spill"] == 0 and v["scratch"] == 0, (k, v)
+    assert res["fvh::lm_update_kernel(fvh::LmState*)"]["vgprs"] <= 168  # the wave-parallel LM step is inlined into every cost kernel
     for name, occ in (("knn_tiled1_kernel", 8), ("nn1_corr_kernel", 8), ("cov_rbf1_kernel", 8), ("cov_from_neighbors_kernel<5>", 6), ("vm_accumulate_kernel<0>", 3),
                       ("sort_coop_kernel", 4)):
         hit = [v for k, v in res.items() if name in k]

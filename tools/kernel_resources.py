@@ -30,8 +30,9 @@ def kernel_resources():
     src = os.path.join(ROOT, "fast_gicp_amd", "csrc", "fvh_capi.hip")
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     with tempfile.TemporaryDirectory() as tmp:
-        cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-munsafe-fp-atomics", "-Rpass-analysis=kernel-resource-usage",
-               "-o", os.path.join(tmp, "t.so"), src, "-ldl"]
+        sys.path.insert(0, ROOT)
+        from fast_gicp_amd import build as _build
+        cmd = [hipcc] + _build.HIPCC_FLAGS + ["-Rpass-analysis=kernel-resource-usage", "-o", os.path.join(tmp, "t.so"), src, "-ldl"] + os.environ.get("FVH_EXTRA_HIPCC_FLAGS", "").split()
         err = subprocess.run(cmd, capture_output=True, text=True, check=True, cwd=tmp).stderr
     res, cur = {}, None
     for line in err.splitlines():
