@@ -1,17 +1,25 @@
 #!/usr/bin/env python
-"""Benchmark of the VGICP hot path on MI355X -- the reference's `100times_reuse` loop (src/align.cpp:87-101).
+"""Benchmark of the VGICP / NDT hot path on MI355X -- the reference's `100times_reuse` loop (src/align.cpp:87-101).
 
 One "step" = one registration of the steady-state odometry pattern
     swapSourceAndTarget(); clearSource(); setInputTarget(same ptr -> no-op); setInputSource(next scan); align()
 i.e. per step: 1 target voxel-map build (from the reused covariances) + covariance estimation of ONE cloud
-(brute-force k-NN k=20 + PLANE) + one full LM solve.  Inputs are resident in HBM before the timed region.
+(brute-force k-NN k=20 + PLANE) + one full LM solve.
 
-N = 1 workload (BASELINE.json configs[1]): bundled 251370668/251371071 pair (HEAD preprocessing, 17,047 / 17,334 pts),
-VGICP, DIRECT27, k_correspondences = 20, voxel resolution 1.0.
+`value` (the contract's number): inputs resident in HBM before the timed region (fvh_vgicp_set_source_cloud_device).
+`host_clouds_in`: the SAME loop fed the way src/align.cpp:94-96 feeds it -- a host cloud per registration through
+fvh_vgicp_set_source_cloud (one H2D inside the timed region): the PCIe-inclusive, reference-exact rate, measured in the same run.
+
+N = 1 headline workload (BASELINE.json configs[1]): bundled 251370668/251371071 pair (HEAD preprocessing, 17,047 / 17,334 pts),
+VGICP, DIRECT27, k_correspondences = 20, voxel resolution 1.0.  The default invocation also measures, time-boxed, the other
+single-GPU configurations of BASELINE.json and reports them under "configs", each with its own roofline and cpu_baseline:
+    synth100k_rbf  configs[2]  synthetic 100k <-> 100k, res 0.5, RBF covariances 0.5/2.5, DIRECT27
+    synth1m        configs[4]  synthetic 1M-point map <-> 100k-point scan, res 0.5, DIRECT7 (1-GPU form of the sharded config)
+    lidar_stream   configs[3]  frame-by-frame NDT D2D on ~118k-point simulated LiDAR frames incl. on-device downsampling
 N > 1: every rank registers its own copy of the stream of scan pairs (registrations are independent units -> weak
 scaling, no data-path collective); value = registrations of all ranks / max-over-ranks time.  The spatially sharded
-single-registration path (RCCL all-reduce of the 28-value normal equations per evaluation) is measured separately and
-reported under "sharded" when --gpus > 1.
+single-registration path (all-reduce of the normal equations per evaluation) is measured separately and reported under
+"sharded" together with the 1-GPU time of the same registration.
 
 Prints ONE JSON line on rank 0.
 """
@@ -26,6 +34,9 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+T_START = time.perf_counter()
+PMC_FILE = os.path.join(ROOT, "profiles", "r02_pmc_cost_kernel.json")
+
 
 def parse():
     ap = argparse.ArgumentParser()
@@ -36,24 +47,28 @@ def parse():
     ap.add_argument("--search", default=None, choices=["DIRECT1", "DIRECT7", "DIRECT27"])
     ap.add_argument("--cov", default="knn", choices=["knn", "rbf"])
     ap.add_argument("--precision", default="fp64", choices=["fp64", "fp32"])
+    ap.add_argument("--configs", default=None, help="comma list of extra configurations measured after the headline (default: all three when the headline is the default "
+                    "bundled17k run on one GPU; 'none' to skip): synth100k_rbf,synth1m,lidar_stream")
+    ap.add_argument("--time-box", type=float, default=170.0, help="seconds after which no further extra configuration is started")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-host-leg", action="store_true", help="skip the host-clouds-in (PCIe-inclusive) repetition of the timed loop")
     ap.add_argument("--no-profile", action="store_true", help="do not bracket the cost kernel with HIP events in the timed region")
     ap.add_argument("--sharded-deadline", type=int, default=240, help="--gpus > 1: seconds the extra spatially-sharded leg may take before it is abandoned")
     ap.add_argument("--streams", type=int, default=4, help="extra leg: S independent engine handles (own HIP streams, host threads) running the same loop concurrently on this GPU")
-    ap.add_argument("--cpu-loops", type=int, default=0, help="oracle registrations to time (0 = auto-bound to ~15 s)")
+    ap.add_argument("--cpu-loops", type=int, default=0, help="oracle registrations to time (0 = auto-bound)")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU budget of the headline's cpu_baseline leg (thread sweep included)")
     return ap.parse_args()
 
 
 def make_workload(name):
-    from fast_gicp_amd import preprocess
+    from fast_gicp_amd import preprocess, workloads
     if name == "bundled17k":
         tgt, src = preprocess.bundled_pair(os.path.join(ROOT, "data"))
         return tgt, src, 1.0, "bundled 251370668<->251371071, ApproximateVoxelGrid 0.1 + origin filter (17,047/17,334 pts)"
-    from tests import util
     if name == "synth100k":
-        tgt, src, _ = util.synthetic_pair(100_000, 100_000, seed=42)
+        tgt, src, _ = workloads.synthetic_pair(100_000, 100_000, seed=42)
         return tgt, src, 0.5, "synthetic 100k<->100k LiDAR-like scene, seed 42"
-    tgt, src, _ = util.synthetic_pair(1_000_000, 100_000, seed=44, extent=150.0)
+    tgt, src, _ = workloads.synthetic_pair(1_000_000, 100_000, seed=44, extent=150.0)
     return tgt, src, 0.5, "synthetic 1M map <-> 100k scan, seed 44"
 
 
@@ -75,15 +90,75 @@ def finish(dist, hung):
         dist.destroy_process_group()
 
 
+def pmc_traffic(key):
+    """HBM bytes per launch of the cost kernel from the committed PMC pass of this round (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in
+    separate runs, FETCH doubled per the gfx950 note of MI355X_MICROARCH.md; tools/pmc_traffic.py)."""
+    try:
+        return json.load(open(PMC_FILE)).get(key, {}).get("hbm_bytes_per_launch")
+    except Exception:
+        return None
+
+
+def thread_counts():
+    n = os.cpu_count() or 1
+    return sorted(set(t for t in (1, 8, 16, 32, n) if 1 <= t <= n))
+
+
+def cpu_baseline_vgicp(tgt, src, res, search, cov, budget_s, mode="reuse", counts=None):
+    """The oracle (fp64 OpenMP restatement of FastVGICP) on this box's host cores: the loop of the workload, thread counts
+    {1, 8, 16, 32, nproc} swept on a short sample, the best one timed on the rest of the budget and reported."""
+    from oracle import oracle as O
+    osearch = {"DIRECT27": O.DIRECT27, "DIRECT7": O.DIRECT7, "DIRECT1": O.DIRECT1}[search]
+
+    def make(threads):
+        g = O.FastVGICP(threads=threads, search=osearch, resolution=res, cov_mode=1 if cov == "rbf" else 0, kernel_width=0.5, kernel_max_dist=2.5)
+        return g
+
+    def time_loops(g, loops):
+        if mode == "reuse":  # align.cpp:87-101
+            ms, _ = g.bench(tgt, src, 2, loops)
+            return ms * 1e-3
+        t0 = time.perf_counter()  # scan-to-map localisation: the map stays the target, a fresh scan is registered every step
+        for _ in range(loops):
+            g.clear_source(); g.set_source(src); g.align()
+        return time.perf_counter() - t0
+
+    t_begin = time.perf_counter()
+    sweep = {}
+    best = None
+    counts = counts or thread_counts()
+    for th in reversed(counts):
+        g = make(th)
+        if mode == "reuse":
+            g.bench(tgt, src, 0, 1)  # "single": primes both clouds (covariances, kd-trees)
+        else:
+            g.set_target(tgt); g.set_source(src); g.align()
+        t = time_loops(g, 1)
+        loops = int(max(1, min(10, (budget_s / (3 * len(counts))) / max(t, 1e-3))))
+        t = time_loops(g, loops) / loops
+        sweep[th] = round(1.0 / t, 3)
+        if best is None or t < best[1]:
+            best = (th, t, g)
+        if time.perf_counter() - t_begin > budget_s * 0.7:
+            break
+    th, t, g = best
+    left = budget_s - (time.perf_counter() - t_begin)
+    loops = int(max(2, min(100, left / max(t, 1e-3))))
+    el = time_loops(g, loops)
+    return {"value": round(loops / el, 3), "unit": "registrations/sec", "cores": th, "kind": "port",
+            "sample": "%d iterations of the %s on the same pair/config (oracle/liboracle.so, OpenMP, %d threads = best of the sweep)" % (
+                loops, "100times_reuse loop" if mode == "reuse" else "scan-to-map loop (map prepared once)", th),
+            "thread_sweep_registrations_per_sec": sweep, "host_cores": os.cpu_count()}
+
+
 def sharded_leg(args, dist, rank, world, local_rank, dev):
     """BASELINE.json configs[4]: 1M-point map <-> 100k-point scan, DIRECT7, res 0.5; the scan is sharded by spatial tile
-    over the ranks, the 32-double normal-equation block is all-reduced by RCCL inside the device LM loop."""
+    over the ranks, the normal-equation block is all-reduced inside the device LM loop."""
     import torch
-    from fast_gicp_amd import capi, distributed as D
-    from tests import util
+    from fast_gicp_amd import capi, distributed as D, workloads
     try:
         torch.cuda.set_device(local_rank)  # this leg runs on a worker thread (run_with_deadline): the current device is per thread
-        tgt, src, _ = util.synthetic_pair(1_000_000, 100_000, seed=44, extent=150.0)
+        tgt, src, _ = workloads.synthetic_pair(1_000_000, 100_000, seed=44, extent=150.0)
         core = capi.VGICPCore(local_rank)
         core.set_resolution(0.5)
         core.set_neighbor_search_method(capi.DIRECT7)
@@ -110,7 +185,7 @@ def sharded_leg(args, dist, rank, world, local_rank, dev):
         return {"workload": "synthetic 1M-point map <-> 100k-point scan, DIRECT7, res 0.5, source tiles over %d GPUs, replicated target map" % world,
                 "aligns_per_sec": round(steps / float(el.item()), 3), "ms_per_align": round(float(el.item()) / steps * 1e3, 4), "evaluations_per_align": evals,
                 "us_per_evaluation_incl_allreduce": round(float(el.item()) / steps / max(evals, 1) * 1e6, 2), "map_build_ms": round(map_ms, 2), "converged": bool(r["converged"]),
-                "collective": "ncclAllReduce(32 x f64) on the engine stream, once per cost evaluation"}
+                "collective": sh.collective_description()}
     except Exception as e:  # the headline number must not depend on this leg
         return {"error": repr(e)}
 
@@ -158,18 +233,15 @@ def concurrent_leg(args, local_rank, d_clouds, n_pts, res, search, K):
     return {"streams": S, "steps_per_stream": steps, "registrations_per_sec": round(S * steps / el, 3), "note": "independent registrations, not the sequential reference loop"}
 
 
-def stream_main(args):
+def run_stream(args, steps, warmup, cpu_loops=15, frames_n=10):
     """BASELINE.json configs[3] (KITTI-style streaming, NDT D2D): the loop of src/kitti.cpp:95-128 with every stage on the
     device -- raw ~118k-point frame (resident in HBM) -> ApproximateVoxelGrid 0.25 (kitti.cpp:80-82) -> setInputSource ->
     align (NDTCuda defaults: D2D, DIRECT7, resolution 1.0) -> swapSourceAndTarget.  KITTI is not available offline: frames
-    come from the 64-ring LiDAR simulator in tests/util.py (1 m ego-motion per frame); the sequence is walked back and
-    forth so consecutive frames are always neighbours.  Single GPU only (a stream of dependent frames does not shard)."""
+    come from the 64-ring LiDAR simulator in fast_gicp_amd/workloads.py (1 m ego-motion per frame); the sequence is walked back
+    and forth so consecutive frames are always neighbours.  Single GPU only (a stream of dependent frames does not shard)."""
     import torch
-    from fast_gicp_amd import capi
-    from tests import util
-    if int(os.environ.get("WORLD_SIZE", "1")) != 1:
-        raise SystemExit("lidar_stream is a single-GPU workload")
-    F = 10
+    from fast_gicp_amd import capi, workloads
+    F = frames_n
     kitti_dir = os.environ.get("FVH_KITTI_DIR")  # e.g. .../sequences/00/velodyne: the real frames instead of the simulator (kitti.cpp:22-69 format)
     if kitti_dir:
         frames = []
@@ -182,7 +254,7 @@ def stream_main(args):
             raise SystemExit("FVH_KITTI_DIR holds fewer than two %06d.bin frames")
         F = len(frames)
     else:
-        frames = [util.lidar_frame(i) for i in range(F)]
+        frames = [workloads.lidar_frame(i) for i in range(F)]
     gpu = torch.device("cuda", 0)
     d_frames = [torch.from_numpy(f).to(gpu).contiguous() for f in frames]
     vg, ndt = capi.VoxelGrid(0), capi.NDTCore(0)
@@ -203,7 +275,7 @@ def stream_main(args):
         ndt.swap_source_and_target()
         state["n_ds"] += n
 
-    for _ in range(args.warmup):
+    for _ in range(warmup):
         step()
     # accuracy on the first lap (not timed): per-frame relative pose vs the simulator's ground truth
     errs = []
@@ -213,8 +285,8 @@ def stream_main(args):
     for i in range(1, F):
         step()
         if not kitti_dir:  # ground truth exists for the simulator only
-            gt = np.linalg.inv(util.lidar_pose(i - 1)) @ util.lidar_pose(i)
-            errs.append(util.pose_error(gt, state["last"]["T"])[0])
+            gt = np.linalg.inv(workloads.lidar_pose(i - 1)) @ workloads.lidar_pose(i)
+            errs.append(workloads.pose_error(gt, state["last"]["T"])[0])
     state["k"] = F - 1
     profile = not args.no_profile
     ndt.profile_reset(); vg.profile_reset()
@@ -222,18 +294,19 @@ def stream_main(args):
     state["n_ds"] = 0
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    n_eval = 0
-    for it in range(args.steps):
+    n_eval = n_launch = 0
+    for it in range(steps):
         if profile:
             ndt.profile_enable(it % 9 == 0); vg.profile_enable(it % 9 == 0)
         step()
         n_eval += state["last"]["num_linearize"] + state["last"]["num_error_evals"]
+        n_launch += state["last"]["num_launches"]
     ndt.synchronize(); torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     ndt.profile_enable(False); vg.profile_enable(False)
     stage_ms, roofline = {}, None
     n_raw = int(np.mean([len(f) for f in frames]))
-    n_ds = state["n_ds"] // max(args.steps, 1)
+    n_ds = state["n_ds"] // max(steps, 1)
     if profile:
         for cls in ("cost", "voxelmap"):
             ms, n = ndt.profile_get(cls)
@@ -242,49 +315,254 @@ def stream_main(args):
         ms, n = vg.profile_get()
         if n:
             stage_ms["downsample"] = {"total_ms": round(ms, 3), "launches": n, "avg_us": round(ms / n * 1e3, 3)}
-            # dominant stage of this loop: the filter. Algorithmic bytes: read N x 12 B, write M x 12 B
+            # the stage with real bytes in this loop: the filter. Algorithmic bytes: read N x 12 B, write M x 12 B
             b = n_raw * 12 + n_ds * 12
             ach = b / (ms / n * 1e-3) / 1e9
-            roofline = {"kernel": "voxel-grid filter (9 launches: keys, 1 radix pass, mark, scan, emit)", "bound": "hbm", "achieved": round(ach, 2), "peak": 8000.0, "unit": "GB/s",
-                        "frac": round(ach / 8000.0, 5), "traffic": None, "algorithmic_bytes_per_launch": b, "avg_launch_us": round(ms / n * 1e3, 3), "launches": n,
-                        "note": "1.4 MB of input per frame: launch/latency bound (a chain of 9 dependent small kernels + one D2H count), not HBM bound"}
+            roofline = {"kernel": "voxel-grid filter (ApproximateVoxelGrid chain: keys, 1 radix pass, mark, scan, emit)", "bound": "hbm", "achieved": round(ach, 2), "peak": 8000.0,
+                        "unit": "GB/s", "frac": round(ach / 8000.0, 5), "traffic": pmc_traffic("lidar_stream_downsample"), "algorithmic_bytes_per_launch": b,
+                        "avg_launch_us": round(ms / n * 1e3, 3), "launches": n,
+                        "note": "1.4 MB of input per frame: launch/latency bound (a chain of dependent small kernels), not HBM bound"}
     cpu = None
     if not args.no_cpu_baseline:
         from oracle import oracle as O
-        cores = min(os.cpu_count() or 1, 64)
-        g = O.NDT(threads=cores, mode=O.D2D, search=O.DIRECT7)
-        loops = args.cpu_loops or 40
-        g.set_target(O.approx_voxelgrid(frames[0], 0.25))
+        best = None
+        sweep = {}
+        for th in reversed(thread_counts()):
+            g = O.NDT(threads=th, mode=O.D2D, search=O.DIRECT7)
+            loops = max(4, cpu_loops // 3)
+            g.set_target(O.approx_voxelgrid(frames[0], 0.25))
+            t1 = time.perf_counter()
+            for k in range(1, loops + 1):
+                g.set_source(O.approx_voxelgrid(frames[seq[k % len(seq)]], 0.25))
+                g.align()
+                g.swap()
+            rate = loops / (time.perf_counter() - t1)
+            sweep[th] = round(rate, 3)
+            if best is None or rate > best[1]:
+                best = (th, rate)
+        cpu = {"value": best[1] if best else None, "unit": "registrations/sec", "cores": best[0], "kind": "port",
+               "sample": "%d frames of the same loop per thread count: oracle ApproximateVoxelGrid (1 thread, as PCL) + oracle NDT D2D (OpenMP); best of the sweep reported" % max(4, cpu_loops // 3),
+               "thread_sweep_registrations_per_sec": sweep, "host_cores": os.cpu_count()}
+        cpu["value"] = round(cpu["value"], 3)
+    vg.close(); ndt.close()
+    return {"metric": "registrations/sec (frame-by-frame odometry, kitti.cpp loop incl. downsampling)", "value": round(steps / elapsed, 3), "unit": "registrations/sec", "n_gpus": 1,
+            "steps": steps, "warmup": warmup, "ms_per_step": round(elapsed / steps * 1e3, 5), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f64" if args.precision == "fp64" else "f32", "data": "KITTI" if kitti_dir else "synthetic",
+            "config": {"workload": "%s, %d raw pts/frame -> ApproximateVoxelGrid 0.25 -> %d pts; NDT D2D, DIRECT7, res 1.0; %d-frame sequence walked back and forth" % (
+                "KITTI frames from FVH_KITTI_DIR" if kitti_dir else "simulated 64-ring LiDAR", n_raw, n_ds, F),
+                "method": "NDT_D2D", "neighbor_search": "DIRECT7", "voxel_resolution": 1.0, "parallelism": "single GPU"},
+            "per_registration": {"cost_evaluations": n_eval / steps, "kernel_launches_lm": n_launch / steps, "converged": bool(state["last"]["converged"])},
+            "accuracy": ({"max_frame_translation_error_m": round(float(max(errs)), 4), "mean_frame_translation_error_m": round(float(np.mean(errs)), 4)} if errs else None),
+            "roofline": roofline, "cpu_baseline": cpu, "stages": stage_ms}
+
+
+def run_registration(args, workload, cov, search_name, steps, warmup, local_rank=0, dist=None, dev=None, world=1, rank=0, headline=False, cpu_budget=12.0, cpu=True):
+    """The VGICP loop of one workload on this rank's GPU; returns the result dictionary (rank 0) or None."""
+    import torch
+    from fast_gicp_amd import capi
+    tgt, src, res, desc = make_workload(workload)
+    search = {"DIRECT27": capi.DIRECT27, "DIRECT7": capi.DIRECT7, "DIRECT1": capi.DIRECT1}[search_name]
+    K = 20
+    gpu = torch.device("cuda", local_rank)
+    d_clouds = [torch.from_numpy(tgt).to(gpu).contiguous(), torch.from_numpy(src).to(gpu).contiguous()]  # inputs resident in HBM
+    h_clouds = [tgt, src]
+    n_pts = [len(tgt), len(src)]
+
+    core = capi.VGICPCore(local_rank)
+    core.set_resolution(res)
+    core.set_neighbor_search_method(search)
+    core.set_kernel_params(0.5, 2.5)  # align.cpp:210 setKernelWidth(0.5) -> max_dist 2.5
+    core.set_precision(capi.COMPUTE_FP32 if args.precision == "fp32" else capi.COMPUTE_FP64)
+
+    def estimate_cov(which):
+        if cov == "knn":
+            getattr(core, "find_%s_neighbors" % which)(K)
+            getattr(core, "calculate_%s_covariances" % which)(capi.REG_PLANE)
+        else:
+            getattr(core, "calculate_%s_covariances_rbf" % which)(capi.REG_PLANE)
+
+    # "single" (align.cpp:58-68): both clouds from scratch
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    core.set_target_cloud_device(d_clouds[0].data_ptr(), n_pts[0], 3)
+    estimate_cov("target")
+    core.create_target_voxelmap()
+    core.set_source_cloud_device(d_clouds[1].data_ptr(), n_pts[1], 3)
+    estimate_cov("source")
+    first = core.align()
+    single_ms = (time.perf_counter() - t0) * 1e3
+    fitness = core.fitness_score(first["T"].astype(np.float32).astype(np.float64))
+
+    state = {"next": 0, "last": first, "host": False}  # after "single": target = cloud 0, source = cloud 1
+
+    def set_source(i):
+        if state["host"]:
+            core.set_source_cloud(h_clouds[i])  # align.cpp:94-96: a host cloud per registration (H2D inside)
+        else:
+            core.set_source_cloud_device(d_clouds[i].data_ptr(), n_pts[i], 3)
+
+    if workload == "synth1m":
+        # map-vs-scan localisation (BASELINE configs[4] shape): the 1M-point map stays the target, every step registers a scan
+        def step():
+            set_source(1)
+            estimate_cov("source")
+            state["last"] = core.align()
+            state["next"] = 0
+    else:
+        def step():
+            # reg.swapSourceAndTarget(); reg.clearSource(); reg.setInputTarget(target_) [no-op]; reg.setInputSource(source_); reg.align()
+            core.swap_source_and_target()
+            i = state["next"]
+            set_source(i)
+            estimate_cov("source")
+            state["last"] = core.align()
+            state["next"] = 1 - i
+
+    for _ in range(warmup):
+        step()
+
+    profile = not args.no_profile
+    # HIP-event bracketing costs ~20 % on a registration it is applied to: sample every 9th registration of the timed region
+    # (odd on purpose: the loop alternates between the two directions of the pair, which need 6 and 8 LM transitions)
+    PROFILE_EVERY = 9
+    core.profile_reset()
+    core.profile_enable(False)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    barrier()
+    t0 = time.perf_counter()
+    n_lin = n_err = n_launch = 0
+    for it in range(steps):
+        if profile:
+            core.profile_enable(it % PROFILE_EVERY == 0)
+        step()
+        n_lin += state["last"]["num_linearize"]
+        n_err += state["last"]["num_error_evals"]
+        n_launch += state["last"]["num_launches"]
+    barrier()
+    elapsed = time.perf_counter() - t0
+    core.profile_enable(False)
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # ---- the same loop, host clouds in (PCIe-inclusive; never `value`) ----
+    host_leg = None
+    if not args.no_host_leg and world == 1:
+        state["host"] = True
+        for _ in range(2):
+            step()
+        core.synchronize()
         t1 = time.perf_counter()
-        for k in range(1, loops + 1):
-            g.set_source(O.approx_voxelgrid(frames[seq[k % len(seq)]], 0.25))
-            g.align()
-            g.swap()
-        cpu = {"value": round(loops / (time.perf_counter() - t1), 3), "unit": "registrations/sec", "cores": cores, "kind": "port",
-               "sample": "%d frames of the same loop: oracle ApproximateVoxelGrid (1 thread, as PCL) + oracle NDT D2D (OpenMP, %d threads)" % (loops, cores)}
-    out = {"metric": "registrations/sec (frame-by-frame odometry, kitti.cpp loop incl. downsampling)", "value": round(args.steps / elapsed, 3), "unit": "registrations/sec", "n_gpus": 1,
-           "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 5), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-           "dtype": "f64" if args.precision == "fp64" else "f32", "data": "KITTI" if kitti_dir else "synthetic",
-           "config": {"workload": "%s, %d raw pts/frame -> ApproximateVoxelGrid 0.25 -> %d pts; NDT D2D, DIRECT7, res 1.0; %d-frame sequence walked back and forth" % ("KITTI frames from FVH_KITTI_DIR" if kitti_dir else "simulated 64-ring LiDAR", n_raw, n_ds, F),
-                      "method": "NDT_D2D", "neighbor_search": "DIRECT7", "voxel_resolution": 1.0, "parallelism": "single GPU"},
-           "per_registration": {"cost_evaluations": n_eval / args.steps, "converged": bool(state["last"]["converged"])},
-           "accuracy": ({"max_frame_translation_error_m": round(float(max(errs)), 4), "mean_frame_translation_error_m": round(float(np.mean(errs)), 4)} if errs else None),
-           "roofline": roofline, "cpu_baseline": cpu, "stages": stage_ms}
-    print(json.dumps(out))
+        for _ in range(steps):
+            step()
+        core.synchronize()
+        el_h = time.perf_counter() - t1
+        state["host"] = False
+        host_leg = {"value": round(steps / el_h, 3), "unit": "registrations/sec", "ms_per_step": round(el_h / steps * 1e3, 5),
+                    "note": "same loop, source cloud handed over as a HOST buffer every registration (fvh_vgicp_set_source_cloud: one %d-byte H2D + stream sync inside the step), as src/align.cpp:94-96 does"
+                            % (n_pts[1] * 12)}
+    if rank != 0:
+        core.close()
+        return None
+
+    # ---- roofline of the dominant kernel class of the LM loop (cost evaluation) ----
+    n_off = {"DIRECT27": 27, "DIRECT7": 7, "DIRECT1": 1}[search_name]
+    n_c = core.get_num_correspondences()  # valid (source, voxel) pairs of the last linearisation
+    n_src = n_pts[1 - state["next"]]
+    # SURVEY 8(d): B_eval = N_s*48 + N_s*N_off*16 + N_c*52 (+172 B out)
+    bytes_eval = n_src * 48 + n_src * n_off * 16 + n_c * 52 + 172
+    roofline = None
+    stage_ms = {}
+    if profile:
+        cost_ms, cost_n = core.profile_get("cost")
+        for cls in ("cost", "knn", "cov", "rbf", "voxelmap", "sort"):
+            ms, n = core.profile_get(cls)
+            if n:
+                stage_ms[cls] = {"total_ms": round(ms, 3), "launches": n, "avg_us": round(ms / n * 1e3, 3)}
+        if cost_n:
+            avg_s = cost_ms / cost_n * 1e-3
+            # SURVEY 8(d): a registration's cost evaluations move (n_lin + n_err) * B_eval algorithmic bytes. One launch of the
+            # persistent LM kernel runs ALL of them (kernel_launches_lm == 1); the multi-launch path spreads them over its launches.
+            evals_per_launch = (n_lin + n_err) / max(n_launch, 1)
+            bytes_launch = bytes_eval * evals_per_launch
+            achieved = bytes_launch / avg_s / 1e9
+            persistent = n_launch == steps
+            key = workload + ("_rbf" if cov == "rbf" else "") + ("_persistent" if persistent else "")
+            kname = "cost_kernel<%s,VGICP,%s>" % ("double" if args.precision == "fp64" else "float", "persistent" if persistent else "per-transition")
+            roofline = {"kernel": kname, "bound": "hbm", "achieved": round(achieved, 2),
+                        "peak": 8000.0, "unit": "GB/s", "frac": round(achieved / 8000.0, 5), "traffic": pmc_traffic(key), "algorithmic_bytes_per_launch": int(bytes_launch),
+                        "algorithmic_bytes_per_evaluation": bytes_eval, "evaluations_per_launch": round(evals_per_launch, 3),
+                        "avg_launch_us": round(avg_s * 1e6, 3), "launches": cost_n,
+                        "note": ("17k-point working set (~3 MB) is L2/Infinity-Cache resident and the fused trips share their loads between the trial evaluation and the next "
+                                 "linearisation: this kernel is bound by the latency chain of its %d barrier-separated trips, not by HBM; `traffic` (PMC) is what actually reaches HBM"
+                                 % round((n_err / steps) + 1) if workload == "bundled17k"
+                                 else "launch average over the LM launches of the timed region; `traffic` (PMC, profiles/r02_pmc_cost_kernel.json) is what reached HBM")}
+    if cov == "knn" and "knn" in stage_ms:
+        n = n_src
+        flops = 8.0 * n * n
+        # the k-NN is culled (it evaluates ~10 tiles x 64 pairs per query, not N pairs): this is the rate a full
+        # 8*N^2-flop brute-force sweep would need to match it, not a VALU utilisation figure
+        stage_ms["knn"]["bruteforce_equivalent_tflops"] = round(flops / (stage_ms["knn"]["avg_us"] * 1e-6) / 1e12, 3)
+
+    cpu_res = None
+    if cpu and not args.no_cpu_baseline and world == 1:
+        # (the 100k / 1M configurations prepare their clouds once per thread count: only the two largest counts are swept there)
+        counts = thread_counts() if workload == "bundled17k" else thread_counts()[-2:]
+        cpu_res = cpu_baseline_vgicp(tgt, src, res, search_name, cov, cpu_budget, mode="map" if workload == "synth1m" else "reuse", counts=counts)
+
+    conc = None
+    if headline and args.streams > 1 and world == 1 and cov == "knn" and workload != "synth1m":
+        try:
+            conc = concurrent_leg(args, local_rank, d_clouds, n_pts, res, search, K)
+        except Exception as ex:
+            conc = {"error": repr(ex)}
+    total_regs = steps * world
+    out = {
+        "metric": "registrations/sec (100-iter reuse) + final fitness_score; achieved HBM GB/s",
+        "value": round(total_regs / elapsed, 3), "unit": "registrations/sec", "n_gpus": world, "steps": steps, "warmup": warmup, "ms_per_step": round(elapsed / steps * 1e3, 5),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64" if args.precision == "fp64" else "f32",
+        "data": "bundled scans (real LiDAR)" if workload == "bundled17k" else "synthetic",
+        "config": {"workload": desc, "method": "VGICP", "neighbor_search": search_name, "k_correspondences": K, "covariance": cov, "regularization": "PLANE",
+                   "voxel_resolution": res, "parallelism": "1 registration stream per GPU" if world > 1 else "single GPU",
+                   "loop": "scan-to-map (map stays the target)" if workload == "synth1m" else "100times_reuse (align.cpp:87-101)", "inputs": "resident in HBM before the timed region"},
+        "fitness_score": round(fitness, 6), "single_ms": round(single_ms, 3),
+        "per_registration": {"linearize": n_lin / steps, "error_evals": n_err / steps, "kernel_launches_lm": n_launch / steps, "converged": bool(state["last"]["converged"]),
+                             "persistent_launches_aborted_by_watchdog": core.debug_persist_aborts()},
+        "host_clouds_in": host_leg,
+        "roofline": roofline, "cpu_baseline": cpu_res, "stages": stage_ms, "profiled_timed_region": ("every %dth registration" % PROFILE_EVERY) if profile else False,
+    }
+    if conc is not None:
+        out["concurrent_streams"] = conc
+    core.close()
+    return out
+
+
+EXTRA_CONFIGS = {
+    # name: (workload, cov, search, steps, warmup, cpu seconds)
+    "synth100k_rbf": ("synth100k", "rbf", "DIRECT27", 40, 5, 10.0),
+    "synth1m": ("synth1m", "knn", "DIRECT7", 40, 5, 12.0),
+}
 
 
 def main():
     args = parse()
-    if args.workload == "lidar_stream":
-        return stream_main(args)
     import torch
-    from fast_gicp_amd import capi
-
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the product path has no CPU fallback)")
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU (the product path has no CPU fallback)")
+    if args.workload == "lidar_stream":
+        if world != 1:
+            raise SystemExit("lidar_stream is a single-GPU workload")
+        print(json.dumps(run_stream(args, args.steps, args.warmup)), flush=True)
+        return
     # test-only knobs to walk the N > 1 control flow on a single-GPU box: all ranks on device 0, gloo for the barrier
     share_gpu = os.environ.get("FVH_BENCH_SHARE_GPU") == "1"
     backend = os.environ.get("FVH_BENCH_BACKEND", "nccl")
@@ -303,91 +581,10 @@ def main():
             dist.init_process_group(backend)
     dev = torch.device("cuda", local_rank) if backend == "nccl" else torch.device("cpu")
 
-    tgt, src, res, desc = make_workload(args.workload)
     if args.search is None:
         args.search = "DIRECT7" if args.workload == "synth1m" else "DIRECT27"
-    search = {"DIRECT27": capi.DIRECT27, "DIRECT7": capi.DIRECT7, "DIRECT1": capi.DIRECT1}[args.search]
-    K = 20
-    gpu = torch.device("cuda", local_rank)
-    d_clouds = [torch.from_numpy(tgt).to(gpu).contiguous(), torch.from_numpy(src).to(gpu).contiguous()]  # inputs resident in HBM
-    n_pts = [len(tgt), len(src)]
+    out = run_registration(args, args.workload, args.cov, args.search, args.steps, args.warmup, local_rank, dist, dev, world, rank, headline=True, cpu_budget=args.cpu_seconds)
 
-    core = capi.VGICPCore(local_rank)
-    core.set_resolution(res)
-    core.set_neighbor_search_method(search)
-    core.set_kernel_params(0.5, 2.5)  # align.cpp:210 setKernelWidth(0.5) -> max_dist 2.5
-    core.set_precision(capi.COMPUTE_FP32 if args.precision == "fp32" else capi.COMPUTE_FP64)
-
-    def estimate_cov(which):
-        if args.cov == "knn":
-            getattr(core, "find_%s_neighbors" % which)(K)
-            getattr(core, "calculate_%s_covariances" % which)(capi.REG_PLANE)
-        else:
-            getattr(core, "calculate_%s_covariances_rbf" % which)(capi.REG_PLANE)
-
-    # "single" (align.cpp:58-68): both clouds from scratch
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    core.set_target_cloud_device(d_clouds[0].data_ptr(), n_pts[0], 3)
-    estimate_cov("target")
-    core.create_target_voxelmap()
-    core.set_source_cloud_device(d_clouds[1].data_ptr(), n_pts[1], 3)
-    estimate_cov("source")
-    first = core.align()
-    single_ms = (time.perf_counter() - t0) * 1e3
-    fitness = core.fitness_score(first["T"].astype(np.float32).astype(np.float64))
-
-    state = {"next": 0, "last": first}  # after "single": target = cloud 0, source = cloud 1
-
-    if args.workload == "synth1m":
-        # map-vs-scan localisation (BASELINE configs[4] shape): the 1M-point map stays the target, every step registers a scan
-        def step():
-            core.set_source_cloud_device(d_clouds[1].data_ptr(), n_pts[1], 3)
-            estimate_cov("source")
-            state["last"] = core.align()
-            state["next"] = 0
-    else:
-        def step():
-            # reg.swapSourceAndTarget(); reg.clearSource(); reg.setInputTarget(target_) [no-op]; reg.setInputSource(source_); reg.align()
-            core.swap_source_and_target()
-            i = state["next"]
-            core.set_source_cloud_device(d_clouds[i].data_ptr(), n_pts[i], 3)
-            estimate_cov("source")
-            state["last"] = core.align()
-            state["next"] = 1 - i
-
-    for _ in range(args.warmup):
-        step()
-
-    profile = not args.no_profile
-    # HIP-event bracketing costs ~20 % on a registration it is applied to: sample every 9th registration of the timed region
-    # (odd on purpose: the loop alternates between the two directions of the pair, which need 6 and 8 LM transitions)
-    PROFILE_EVERY = 9
-    core.profile_reset()
-    core.profile_enable(False)
-
-    def barrier():
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    barrier()
-    t0 = time.perf_counter()
-    n_lin = n_err = n_launch = 0
-    for it in range(args.steps):
-        if profile:
-            core.profile_enable(it % PROFILE_EVERY == 0)
-        step()
-        n_lin += state["last"]["num_linearize"]
-        n_err += state["last"]["num_error_evals"]
-        n_launch += state["last"]["num_launches"]
-    barrier()
-    elapsed = time.perf_counter() - t0
-    core.profile_enable(False)
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
     sharded, sharded_hung = None, False
     if world > 1 and not share_gpu:
         # the headline number is already measured: a stuck collective in this extra leg must not take the JSON line with it
@@ -397,97 +594,28 @@ def main():
     if rank != 0:
         finish(dist, sharded_hung)
         return
-
-    total_regs = args.steps * world
-    value = total_regs / elapsed
-    ms_per_step = elapsed / args.steps * 1e3
-
-    # ---- roofline of the dominant kernel class of the LM loop (cost evaluation) ----
-    n_off = {"DIRECT27": 27, "DIRECT7": 7, "DIRECT1": 1}[args.search]
-    n_c = core.get_num_correspondences()  # valid (source, voxel) pairs of the last linearisation
-    n_src = n_pts[1 - state["next"]]
-    # B_eval = N_s*48 + N_s*N_off*16 + N_c*52 (+172 B out)
-    bytes_eval = n_src * 48 + n_src * n_off * 16 + n_c * 52 + 172
-    roofline = None
-    stage_ms = {}
-    if profile:
-        cost_ms, cost_n = core.profile_get("cost")
-        for cls in ("cost", "knn", "cov", "rbf", "voxelmap"):
-            ms, n = core.profile_get(cls)
-            if n:
-                stage_ms[cls] = {"total_ms": round(ms, 3), "launches": n, "avg_us": round(ms / n * 1e3, 3)}
-        if cost_n:
-            avg_s = cost_ms / cost_n * 1e-3
-            # a registration's cost evaluations move (n_lin + n_err) * B_eval algorithmic bytes. One launch of the
-            # persistent LM kernel runs ALL of them (kernel_launches_lm == 1); the multi-launch path spreads them over its launches.
-            evals_per_launch = (n_lin + n_err) / max(n_launch, 1)
-            bytes_launch = bytes_eval * evals_per_launch
-            achieved = bytes_launch / avg_s / 1e9
-            traffic = None
-            try:  # HBM bytes per launch from the committed PMC pass (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate runs; FETCH doubled per the gfx950 note)
-                pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_cost_kernel.json")))
-                traffic = pmc.get(args.workload + ("_persistent" if n_launch == args.steps else ""), {}).get("hbm_bytes_per_launch")
-            except Exception:
-                pass
-            kname = "cost_kernel<%s,VGICP,%s>" % ("double" if args.precision == "fp64" else "float", "persistent" if n_launch == args.steps else "per-transition")
-            roofline = {"kernel": kname, "bound": "hbm", "achieved": round(achieved, 2),
-                        "peak": 8000.0, "unit": "GB/s", "frac": round(achieved / 8000.0, 5), "traffic": traffic, "algorithmic_bytes_per_launch": int(bytes_launch),
-                        "algorithmic_bytes_per_evaluation": bytes_eval, "evaluations_per_launch": round(evals_per_launch, 3),
-                        "avg_launch_us": round(avg_s * 1e6, 3), "launches": cost_n,
-                        "note": ("17k-point working set (~3 MB) is L2/Infinity-Cache resident and the fused trips share their loads between the trial evaluation and the next "
-                                 "linearisation: this kernel is bound by the latency chain of its %d barrier-separated trips, not by HBM; `traffic` (PMC) is what actually reaches HBM"
-                                 % round((n_err / args.steps) + 1) if args.workload == "bundled17k"
-                                 else "launch average over the LM launches of the timed region")}
-    if args.cov == "knn" and "knn" in stage_ms:
-        n = n_src
-        flops = 8.0 * n * n
-        # the k-NN is culled (it evaluates ~10 tiles x 64 pairs per query, not N pairs): this is the rate a full
-        # 8*N^2-flop brute-force sweep would need to match it, not a VALU utilisation figure
-        stage_ms["knn"]["bruteforce_equivalent_tflops"] = round(flops / (stage_ms["knn"]["avg_us"] * 1e-6) / 1e12, 3)
-
-    # ---- CPU baseline: the oracle (fp64 OpenMP restatement of FastVGICP) on this box's host cores ----
-    cpu = None
-    if not args.no_cpu_baseline and world == 1:
-        from oracle import oracle as O
-        cores = min(os.cpu_count() or 1, 64)
-        g = O.FastVGICP(threads=cores, search={"DIRECT27": O.DIRECT27, "DIRECT7": O.DIRECT7, "DIRECT1": O.DIRECT1}[args.search], resolution=res,
-                        cov_mode=1 if args.cov == "rbf" else 0, kernel_width=0.5, kernel_max_dist=2.5)
-        g.bench(tgt, src, 0, 1)  # "single": primes both clouds
-        t1 = time.perf_counter()
-        g.bench(tgt, src, 2, 2)
-        per = (time.perf_counter() - t1) / 2
-        loops = args.cpu_loops or int(max(4, min(100, 15.0 / max(per, 1e-3))))
-        ms, _ = g.bench(tgt, src, 2, loops)
-        cpu = {"value": round(loops / (ms * 1e-3), 3), "unit": "registrations/sec", "cores": cores, "kind": "port",
-               "sample": "%d iterations of the 100times_reuse loop on the same pair/config (oracle/liboracle.so, OpenMP, %d threads)" % (loops, cores)}
-        if args.workload == "bundled17k":  # OMP_NUM_THREADS in {1, nproc}
-            g1 = O.FastVGICP(threads=1, search={"DIRECT27": O.DIRECT27, "DIRECT7": O.DIRECT7, "DIRECT1": O.DIRECT1}[args.search], resolution=res,
-                             cov_mode=1 if args.cov == "rbf" else 0, kernel_width=0.5, kernel_max_dist=2.5)
-            g1.bench(tgt, src, 0, 1)
-            ms1, _ = g1.bench(tgt, src, 2, 5)
-            cpu["single_thread"] = {"value": round(5 / (ms1 * 1e-3), 3), "unit": "registrations/sec", "cores": 1, "sample": "5 iterations of the same loop, 1 thread"}
-
-    conc = None
-    if args.streams > 1 and world == 1 and args.cov == "knn" and args.workload != "synth1m":
-        try:
-            conc = concurrent_leg(args, local_rank, d_clouds, n_pts, res, search, K)
-        except Exception as ex:
-            conc = {"error": repr(ex)}
-    out = {
-        "metric": "registrations/sec (100-iter reuse) + final fitness_score; achieved HBM GB/s",
-        "value": round(value, 3), "unit": "registrations/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 5),
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64" if args.precision == "fp64" else "f32", "data": "bundled scans (real LiDAR)" if args.workload == "bundled17k" else "synthetic",
-        "config": {"workload": desc, "method": "VGICP", "neighbor_search": args.search, "k_correspondences": K, "covariance": args.cov, "regularization": "PLANE",
-                   "voxel_resolution": res, "parallelism": "1 registration stream per GPU" if world > 1 else "single GPU"},
-        "fitness_score": round(fitness, 6), "single_ms": round(single_ms, 3),
-        "per_registration": {"linearize": n_lin / args.steps, "error_evals": n_err / args.steps, "kernel_launches_lm": n_launch / args.steps, "converged": bool(state["last"]["converged"]),
-                             "persistent_launches_aborted_by_watchdog": core.debug_persist_aborts()},
-        "roofline": roofline, "cpu_baseline": cpu, "stages": stage_ms, "profiled_timed_region": ("every %dth registration" % PROFILE_EVERY) if profile else False,
-    }
     if sharded is not None:
         out["sharded"] = sharded
-    if conc is not None:
-        out["concurrent_streams"] = conc
+
+    # ---- the other single-GPU configurations of BASELINE.json, time-boxed ----
+    default_headline = args.workload == "bundled17k" and args.cov == "knn" and world == 1
+    names = [] if args.configs == "none" else (args.configs.split(",") if args.configs else (["synth100k_rbf", "synth1m", "lidar_stream"] if default_headline else []))
+    if names:
+        configs = {}
+        for name in names:
+            if time.perf_counter() - T_START > args.time_box:
+                configs[name] = {"skipped": "time box of %.0f s reached before this configuration started" % args.time_box}
+                continue
+            try:
+                if name == "lidar_stream":
+                    configs[name] = run_stream(args, 60, 5)
+                else:
+                    wl, cov, search, steps, warmup, cpu_s = EXTRA_CONFIGS[name]
+                    configs[name] = run_registration(args, wl, cov, search, steps, warmup, local_rank, cpu_budget=cpu_s)
+            except Exception as ex:  # the headline must not depend on an extra configuration
+                configs[name] = {"error": repr(ex)}
+        out["configs"] = configs
+    out["bench_wall_s"] = round(time.perf_counter() - T_START, 1)
     print(json.dumps(out), flush=True)
     finish(dist, sharded_hung)
 

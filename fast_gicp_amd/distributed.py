@@ -149,6 +149,9 @@ class ShardedVGICP:
         self.core.comm_init(unique_id_bytes, self.world_size, self.rank)
         self._comm_ready = True
 
+    def collective_description(self):
+        return "ncclAllReduce(32 x f64) on the engine stream, once per cost evaluation" if self.device_collective else "host all-reduce (torch.distributed) of 43 doubles per evaluation"
+
     def set_target(self, xyz, k=20, regularization=3):
         self.core.set_target_cloud(xyz)
         self.core.find_target_neighbors(k)
