@@ -101,7 +101,7 @@ def pmc_traffic(key):
 
 def thread_counts():
     n = os.cpu_count() or 1
-    return sorted(set(t for t in (1, 8, 16, 32, n) if 1 <= t <= n))
+    return sorted(set(t for t in (1, 8, 16, 32, 64, n) if 1 <= t <= n))
 
 
 def cpu_baseline_vgicp(tgt, src, res, search, cov, budget_s, mode="reuse", counts=None):
@@ -127,7 +127,7 @@ def cpu_baseline_vgicp(tgt, src, res, search, cov, budget_s, mode="reuse", count
     sweep = {}
     best = None
     counts = counts or thread_counts()
-    for th in reversed(counts):
+    for th in counts:  # ascending: the sweep stops once more threads stop paying (a 256-thread OpenMP team on 17k-item loops is 40x slower than 64)
         g = make(th)
         if mode == "reuse":
             g.bench(tgt, src, 0, 1)  # "single": primes both clouds (covariances, kd-trees)
@@ -135,11 +135,13 @@ def cpu_baseline_vgicp(tgt, src, res, search, cov, budget_s, mode="reuse", count
             g.set_target(tgt); g.set_source(src); g.align()
         t = time_loops(g, 1)
         loops = int(max(1, min(10, (budget_s / (3 * len(counts))) / max(t, 1e-3))))
-        t = time_loops(g, loops) / loops
+        t = min(t, time_loops(g, loops) / loops)
         sweep[th] = round(1.0 / t, 3)
         if best is None or t < best[1]:
             best = (th, t, g)
-        if time.perf_counter() - t_begin > budget_s * 0.7:
+        elif t > 1.5 * best[1]:
+            break
+        if time.perf_counter() - t_begin > budget_s * 0.75:
             break
     th, t, g = best
     left = budget_s - (time.perf_counter() - t_begin)
@@ -327,7 +329,7 @@ def run_stream(args, steps, warmup, cpu_loops=15, frames_n=10):
         from oracle import oracle as O
         best = None
         sweep = {}
-        for th in reversed(thread_counts()):
+        for th in thread_counts():
             g = O.NDT(threads=th, mode=O.D2D, search=O.DIRECT7)
             loops = max(4, cpu_loops // 3)
             g.set_target(O.approx_voxelgrid(frames[0], 0.25))
@@ -512,8 +514,8 @@ def run_registration(args, workload, cov, search_name, steps, warmup, local_rank
 
     cpu_res = None
     if cpu and not args.no_cpu_baseline and world == 1:
-        # (the 100k / 1M configurations prepare their clouds once per thread count: only the two largest counts are swept there)
-        counts = thread_counts() if workload == "bundled17k" else thread_counts()[-2:]
+        # (the 100k / 1M configurations prepare their clouds once per thread count: only 16 and 64 threads are tried there)
+        counts = thread_counts() if workload == "bundled17k" else [t for t in thread_counts() if t in (16, 64)] or thread_counts()[-1:]
         cpu_res = cpu_baseline_vgicp(tgt, src, res, search_name, cov, cpu_budget, mode="map" if workload == "synth1m" else "reuse", counts=counts)
 
     conc = None
