@@ -15,6 +15,7 @@ REG_NONE, REG_MIN_EIG, REG_NORMALIZED_MIN_EIG, REG_PLANE, REG_FROBENIUS = range(
 DIRECT27, DIRECT7, DIRECT1, DIRECT_RADIUS = range(4)
 NDT_P2D, NDT_D2D = 0, 1
 COMPUTE_FP64, COMPUTE_FP32 = 0, 1
+VOXEL_ADDITIVE, VOXEL_ADDITIVE_WEIGHTED, VOXEL_MULTIPLICATIVE = range(3)
 
 EXPORTED_SYMBOLS = None  # filled by _declared_symbols()
 
@@ -216,6 +217,9 @@ def device_count():
 class VGICPCore(_Core):
     """fast_gicp::cuda::FastVGICPCudaCore on the HIP engine (same method names, snake_case as in the .cuh)."""
     _prefix = "fvh_vgicp_"
+
+    def set_voxel_accumulation_mode(self, mode):
+        self._call("set_voxel_accumulation_mode", int(mode))
 
     def set_kernel_params(self, kernel_width, kernel_max_dist):
         self._call("set_kernel_params", C.c_double(kernel_width), C.c_double(kernel_max_dist))

@@ -502,7 +502,7 @@ int get_nbr_host(Engine* e, CloudDev& c, int* k, int* out) {
 template <int MODE>
 int build_voxelmap(Engine* e, const CloudDev& c, VoxelMapDev& vm, double res, bool want_compact, bool force_safe = false) {
   if (!c.has_pts) return e->fail(FVH_ERR_BAD_STATE, "create_voxelmap: cloud not set");
-  if (MODE == 0 && !c.has_cov) return e->fail(FVH_ERR_BAD_STATE, "create_voxelmap: covariances not computed");
+  if (MODE != 1 && !c.has_cov) return e->fail(FVH_ERR_BAD_STATE, "create_voxelmap: covariances not computed");
   if (!(res > 0)) return e->fail(FVH_ERR_INVALID_ARGUMENT, "create_voxelmap: resolution must be > 0");
   unsigned safe = 1024;
   while (safe < 2u * (unsigned)std::max(c.n, 1)) safe <<= 1;
@@ -1120,7 +1120,11 @@ struct fvh_vgicp {
   double gicp_max_dist = 3.4028234663852886e38;
   CostSource cost_source() const { return CostSource{source.pts.as<float4>(), source.cov.as<float4>(), nullptr, source.n, nullptr, coherent_order(source)}; }
   CostSource gicp_cost_source() const { CostSource c{source.pts.as<float4>(), source.cov.as<float4>(), nullptr, source.n, nullptr, nullptr}; c.n_off_override = 1; return c; }
-  Rebuild rebuild_safe() { return [this] { return build_voxelmap<0>(&e, target, voxelmap, voxelmap.res, false, true); }; }
+  int voxel_mode = 0;        // VoxelAccumulationMode ordinal: 0 ADDITIVE, 1 ADDITIVE_WEIGHTED (same voxel type in the reference), 2 MULTIPLICATIVE
+  int build_map(double res, bool force_safe = false) {
+    return voxel_mode == 2 ? build_voxelmap<2>(&e, target, voxelmap, res, false, force_safe) : build_voxelmap<0>(&e, target, voxelmap, res, false, force_safe);
+  }
+  Rebuild rebuild_safe() { return [this] { return build_map(voxelmap.res, true); }; }
 };
 
 struct fvh_ndt {
@@ -1188,13 +1192,20 @@ int fvh_vgicp_set_kernel_params(fvh_vgicp* h, double w, double d) { CHECK_HANDLE
 int fvh_vgicp_set_neighbor_search_method(fvh_vgicp* h, int m, double radius) { CHECK_HANDLE(h); return h->e.set_offsets(m, radius); }
 int fvh_vgicp_set_precision(fvh_vgicp* h, int p) { CHECK_HANDLE(h); if (p != FVH_COMPUTE_FP64 && p != FVH_COMPUTE_FP32) return h->e.fail(FVH_ERR_INVALID_ARGUMENT, "bad precision"); h->e.precision = p; return FVH_OK; }
 
-int fvh_vgicp_create_target_voxelmap(fvh_vgicp* h) { CHECK_HANDLE(h); return build_voxelmap<0>(&h->e, h->target, h->voxelmap, h->resolution, false); }
+int fvh_vgicp_create_target_voxelmap(fvh_vgicp* h) { CHECK_HANDLE(h); return h->build_map(h->resolution); }
+int fvh_vgicp_set_voxel_accumulation_mode(fvh_vgicp* h, int mode) {
+  CHECK_HANDLE(h);
+  if (mode < 0 || mode > 2) return h->e.fail(FVH_ERR_INVALID_ARGUMENT, "unknown voxel accumulation mode");
+  if (mode != h->voxel_mode) { h->voxelmap.invalidate(); h->e.has_corr = false; }
+  h->voxel_mode = mode;
+  return FVH_OK;
+}
 int fvh_vgicp_swap_source_and_target(fvh_vgicp* h) {
   CHECK_HANDLE(h);
   h->source.swap(h->target);
   h->e.has_corr = false;
   if (!h->target.has_pts || !h->target.has_cov) { h->voxelmap.invalidate(); return FVH_OK; }  // fast_vgicp_cuda.cu:102-104
-  return build_voxelmap<0>(&h->e, h->target, h->voxelmap, h->resolution, false);
+  return h->build_map(h->resolution);
 }
 int fvh_vgicp_gicp_swap_source_and_target(fvh_vgicp* h) {  // FastGICP::swapSourceAndTarget (fast_gicp_impl.hpp:56-62): no voxel map to rebuild
   CHECK_HANDLE(h);

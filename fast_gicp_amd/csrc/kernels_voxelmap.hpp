@@ -62,7 +62,8 @@ __global__ __launch_bounds__(256) void vm_clear_kernel(unsigned long long* __res
   if (i < 16) counters[i] = 0;
 }
 
-// MODE 0: VGICP (sum of points and of point covariances); MODE 1: NDT (sum of points and p p^T)
+// MODE 0: VGICP additive (sum of points and of point covariances); MODE 1: NDT (sum of points and p p^T);
+// MODE 2: VGICP multiplicative (MultiplicativeGaussianVoxel::append, fast_vgicp_voxel.hpp:86-94: sum of C^-1 p and of C^-1)
 template <int MODE>
 __global__ __launch_bounds__(256) void vm_accumulate_kernel(const float4* __restrict__ pts, const float4* __restrict__ cov, int n, double res,
                                                             unsigned long long* __restrict__ table_keys, unsigned mask, double* __restrict__ acc,
@@ -93,6 +94,12 @@ __global__ __launch_bounds__(256) void vm_accumulate_kernel(const float4* __rest
       if (MODE == 0) {
         const float4 c0 = cov[2 * i], c1 = cov[2 * i + 1];
         v[3] = c0.x; v[4] = c0.y; v[5] = c0.z; v[6] = c0.w; v[7] = c1.x; v[8] = c1.y;
+      } else if (MODE == 2) {
+        const float4 c0 = cov[2 * i], c1 = cov[2 * i + 1];
+        const Sym3<double> Ci = inverse(Sym3<double>{(double)c0.x, (double)c0.y, (double)c0.z, (double)c0.w, (double)c1.x, (double)c1.y});
+        const Vec3<double> cp = mul(Ci, Vec3<double>{(double)p.x, (double)p.y, (double)p.z});
+        v[0] = cp.x; v[1] = cp.y; v[2] = cp.z;
+        v[3] = Ci.xx; v[4] = Ci.xy; v[5] = Ci.xz; v[6] = Ci.yy; v[7] = Ci.yz; v[8] = Ci.zz;
       } else {
         const double x = p.x, y = p.y, z = p.z;
         v[3] = x * x; v[4] = x * y; v[5] = x * z; v[6] = y * y; v[7] = y * z; v[8] = z * z;
@@ -173,10 +180,14 @@ __global__ __launch_bounds__(256) void vm_finalize_kernel(const unsigned long lo
   }
   const double cnt = a[9];
   const double inv = 1.0 / cnt;
-  const double mx = a[0] * inv, my = a[1] * inv, mz = a[2] * inv;
+  double mx = a[0] * inv, my = a[1] * inv, mz = a[2] * inv;
   Sym3<double> C;
   if (MODE == 0) {
     C.xx = a[3] * inv; C.xy = a[4] * inv; C.xz = a[5] * inv; C.yy = a[6] * inv; C.yz = a[7] * inv; C.zz = a[8] * inv;
+  } else if (MODE == 2) {  // MultiplicativeGaussianVoxel::finalize (fast_vgicp_voxel.hpp:96-102): cov = (sum C^-1)^-1, mean = cov * sum C^-1 p
+    C = inverse(Sym3<double>{a[3], a[4], a[5], a[6], a[7], a[8]});
+    const Vec3<double> m = mul(C, Vec3<double>{a[0], a[1], a[2]});
+    mx = m.x; my = m.y; mz = m.z;
   } else {
     C.xx = (a[3] - mx * a[0]) * inv; C.xy = (a[4] - mx * a[1]) * inv; C.xz = (a[5] - mx * a[2]) * inv;
     C.yy = (a[6] - my * a[1]) * inv; C.yz = (a[7] - my * a[2]) * inv; C.zz = (a[8] - mz * a[2]) * inv;

@@ -211,6 +211,12 @@ PYBIND11_MODULE(pygicp, m) {
   py::class_<VGICPCuda, Lsq, std::shared_ptr<VGICPCuda>>(m, "FastVGICPCuda")
       .def(py::init([](int device) { return std::make_shared<VGICPCuda>(device); }), py::arg("device") = 0)
       .def("set_resolution", &VGICPCuda::setResolution)
+      .def("set_voxel_accumulation_mode", [](VGICPCuda& v, const std::string& mode) {  // FastVGICP::setVoxelAccumulationMode (fast_vgicp_impl.hpp:41-43)
+        if (mode == "ADDITIVE") v.setVoxelAccumulationMode(fast_gicp::VoxelAccumulationMode::ADDITIVE);
+        else if (mode == "ADDITIVE_WEIGHTED") v.setVoxelAccumulationMode(fast_gicp::VoxelAccumulationMode::ADDITIVE_WEIGHTED);
+        else if (mode == "MULTIPLICATIVE") v.setVoxelAccumulationMode(fast_gicp::VoxelAccumulationMode::MULTIPLICATIVE);
+        else throw std::invalid_argument("unknown voxel accumulation mode: " + mode);
+      })
       .def("set_neighbor_search_method", [](VGICPCuda& v, const std::string& method, double radius) { v.setNeighborSearchMethod(search_method(method), radius); },
            py::arg("method") = "DIRECT1", py::arg("radius") = 1.5)
       .def("set_correspondence_randomness", &VGICPCuda::setCorrespondenceRandomness)

@@ -333,6 +333,12 @@ public:
 
   void setCorrespondenceRandomness(int) {}  // empty in the reference too (:38): k stays 20
   void setResolution(double resolution) { call(fvh_vgicp_set_resolution(core_, resolution), "set_resolution"); }
+  /// FastVGICP::setVoxelAccumulationMode (fast_vgicp_impl.hpp:41-43; CPU class only in the reference -- the CUDA core has the
+  /// additive voxel alone): takes effect when the target voxel map is next built (setInputTarget / swapSourceAndTarget)
+  void setVoxelAccumulationMode(VoxelAccumulationMode mode) {
+    call(fvh_vgicp_set_voxel_accumulation_mode(core_, static_cast<int>(mode)), "set_voxel_accumulation_mode");
+    if (this->target_) call(fvh_vgicp_create_target_voxelmap(core_), "create_target_voxelmap");  // (setInputTarget left cloud + covariances on the device)
+  }
   void setKernelWidth(double kernel_width, double max_dist = -1.0) {  // :45-51
     if (max_dist <= 0.0) max_dist = kernel_width * 5.0;
     call(fvh_vgicp_set_kernel_params(core_, kernel_width, max_dist), "set_kernel_params");

@@ -83,6 +83,11 @@ int fvh_vgicp_set_resolution(fvh_vgicp* h, double resolution);                  
 int fvh_vgicp_set_kernel_params(fvh_vgicp* h, double kernel_width, double kernel_max_dist);  /* [VC]:41 */
 int fvh_vgicp_set_neighbor_search_method(fvh_vgicp* h, int method, double radius);           /* [VC]:42, [VCU]:41-94 */
 int fvh_vgicp_set_precision(fvh_vgicp* h, int precision);                                    /* new */
+/* fast_gicp::VoxelAccumulationMode (gicp_settings.hpp:10) of the CPU FastVGICP (setVoxelAccumulationMode, fast_vgicp_impl.hpp:41-43;
+ * the CUDA core only has the additive voxel): ADDITIVE / ADDITIVE_WEIGHTED -> AdditiveGaussianVoxel (fast_vgicp_voxel.hpp:105-122),
+ * MULTIPLICATIVE -> MultiplicativeGaussianVoxel (:79-103: sum of C^-1 and C^-1 p, inverted at finalize). Takes effect at the next map build. */
+enum fvh_voxel_accumulation_mode { FVH_VOXEL_ADDITIVE = 0, FVH_VOXEL_ADDITIVE_WEIGHTED = 1, FVH_VOXEL_MULTIPLICATIVE = 2 };
+int fvh_vgicp_set_voxel_accumulation_mode(fvh_vgicp* h, int mode);
 
 int fvh_vgicp_swap_source_and_target(fvh_vgicp* h);                                          /* [VC]:44, [VCU]:97-107 */
 int fvh_vgicp_set_source_cloud(fvh_vgicp* h, const float* xyz, int n);                       /* [VC]:45 */

@@ -45,7 +45,7 @@ def lib():
         L.orc_fitness.restype = dbl
         L.orc_vgicp_create.restype = vp
         L.orc_ndt_create.restype = vp
-        for f in ("orc_vgicp_linearize", "orc_vgicp_compute_error", "orc_vgicp_fitness", "orc_vgicp_bench", "orc_ndt_linearize", "orc_ndt_compute_error", "orc_ndt_fitness"):
+        for f in ("orc_vgicp_cuda_compat_sums", "orc_vgicp_linearize", "orc_vgicp_compute_error", "orc_vgicp_fitness", "orc_vgicp_bench", "orc_ndt_linearize", "orc_ndt_compute_error", "orc_ndt_fitness"):
             getattr(L, f).restype = dbl
         _LIB = L
     return _LIB
@@ -136,10 +136,13 @@ def _voxel_out(n):
     return (np.empty((n, 3), np.int32), np.empty(n, np.int32), np.empty((n, 3), np.float64), np.empty((n, 3, 3), np.float64))
 
 
-def voxelmap_vgicp(xyz, covs, res):
+ADDITIVE, ADDITIVE_WEIGHTED, MULTIPLICATIVE = range(3)  # VoxelAccumulationMode (gicp_settings.hpp:10)
+
+
+def voxelmap_vgicp(xyz, covs, res, mode=ADDITIVE):
     a, c = _f32(xyz), _f64(covs)
     coords, num, means, vc = _voxel_out(len(a))
-    nv = lib().orc_voxelmap_vgicp(_p(a), _p(c), len(a), C.c_double(res), _p(coords), _p(num), _p(means), _p(vc))
+    nv = lib().orc_voxelmap_vgicp_mode(_p(a), _p(c), len(a), C.c_double(res), int(mode), _p(coords), _p(num), _p(means), _p(vc))
     return coords[:nv].copy(), num[:nv].copy(), means[:nv].copy(), vc[:nv].copy()
 
 
@@ -238,6 +241,20 @@ class FastVGICP(_Reg):
     def set_gicp_mode(self, on=True, max_correspondence_distance=3.4028234663852886e38):
         """FastGICP (fast_gicp_impl.hpp:118-240): nearest-target-point correspondences instead of voxels."""
         self._call("set_gicp_mode", int(on), C.c_double(max_correspondence_distance))
+
+    def set_voxel_accumulation_mode(self, mode):
+        """FastVGICP::setVoxelAccumulationMode (fast_vgicp_impl.hpp:41-43)."""
+        self._call("set_voxel_mode", int(mode))
+
+    def cuda_compat_sums(self, T, derivatives=True):
+        """compute_derivatives.cu:50-103 arithmetic in float over the correspondences / linearisation pose of the last linearize()."""
+        T = _f64(T)
+        if not derivatives:
+            return self._call("cuda_compat_sums", _p(T), None, None)
+        H = np.empty((6, 6), np.float64)
+        b = np.empty(6, np.float64)
+        e = self._call("cuda_compat_sums", _p(T), _p(H), _p(b))
+        return e, H, b
 
     def set_target_covs(self, covs):
         c = _f64(covs)

@@ -108,7 +108,7 @@ void orc_regularize(const double* cov9, int reg, double* out9) {
 int orc_voxelmap_vgicp(const float* xyz, const double* covs9, int n, double res, int* coords, int* num, double* means, double* covs) {
   Cloud c; c.xyz.assign(xyz, xyz + (size_t)3 * n);
   VoxelMap vm(res);
-  vm.create_vgicp(c, load_m3(covs9, n));
+  vm.create_vgicp(c, load_m3(covs9, n), 0);
   return dump_voxelmap(vm, coords, num, means, covs);
 }
 int orc_voxelmap_ndt(const float* xyz, int n, double res, int* coords, int* num, double* means, double* covs) {
@@ -170,6 +170,14 @@ int orc_vgicp_num_correspondences(void* h) { return (int)((FastVGICP*)h)->voxel_
 int orc_vgicp_num_voxels(void* h) { auto* g = (FastVGICP*)h; return g->voxelmap ? (int)g->voxelmap->voxels.size() : -1; }
 void orc_vgicp_get_covs(void* h, int which, double* out) { auto* g = (FastVGICP*)h; copy_m3(which ? g->target_covs : g->source_covs, out); }
 int orc_vgicp_get_voxelmap(void* h, int* coords, int* num, double* means, double* covs) { return dump_voxelmap(*((FastVGICP*)h)->voxelmap, coords, num, means, covs); }
+int orc_voxelmap_vgicp_mode(const float* xyz, const double* covs9, int n, double res, int mode, int* coords, int* num, double* means, double* covs) {
+  Cloud c; c.xyz.assign(xyz, xyz + (size_t)3 * n);
+  VoxelMap vm(res);
+  vm.create_vgicp(c, load_m3(covs9, n), mode);
+  return dump_voxelmap(vm, coords, num, means, covs);
+}
+double orc_vgicp_cuda_compat_sums(void* h, const double* T16, double* H36, double* b6) { return ((FastVGICP*)h)->cuda_compat_sums(iso_from_rowmajor16(T16), H36, b6); }
+void orc_vgicp_set_voxel_mode(void* h, int mode) { auto* g = (FastVGICP*)h; g->voxel_mode = mode; g->voxelmap.reset(); }
 void orc_vgicp_set_voxelmap(void* h, int nv, const int* coords, const int* num, const double* means, const double* covs) {
   auto* g = (FastVGICP*)h;
   g->voxelmap.reset(new VoxelMap(g->voxel_resolution));  // (align() resets it again: this is for linearize / compute_error at fixed poses)

@@ -360,7 +360,10 @@ int VoxelMap::lookup(const VoxelKey& k) const {
   return it == index.end() ? -1 : it->second;
 }
 
-void VoxelMap::create_vgicp(const Cloud& c, const std::vector<M3>& covs) {
+void VoxelMap::create_vgicp(const Cloud& c, const std::vector<M3>& covs, int mode) {
+  // mode: VoxelAccumulationMode ordinal (gicp_settings.hpp:10). ADDITIVE (0) and ADDITIVE_WEIGHTED (1) both create an
+  // AdditiveGaussianVoxel (fast_vgicp_voxel.hpp:137-141); MULTIPLICATIVE (2) a MultiplicativeGaussianVoxel (:142-144).
+  const bool multiplicative = (mode == 2);
   index.clear(); coords.clear(); voxels.clear();
   for (size_t i = 0; i < c.size(); i++) {
     V3 p = {{(double)c.pt(i)[0], (double)c.pt(i)[1], (double)c.pt(i)[2]}};
@@ -372,13 +375,25 @@ void VoxelMap::create_vgicp(const Cloud& c, const std::vector<M3>& covs) {
       voxels.emplace_back();
     }
     Voxel& v = voxels[it->second];
-    v.num_points++;                                   // AdditiveGaussianVoxel::append :112-116
-    for (int a = 0; a < 3; a++) v.mean[a] += p[a];
-    v.cov = m3_add(v.cov, covs[i]);
+    v.num_points++;
+    if (!multiplicative) {                            // AdditiveGaussianVoxel::append :112-116
+      for (int a = 0; a < 3; a++) v.mean[a] += p[a];
+      v.cov = m3_add(v.cov, covs[i]);
+    } else {                                          // MultiplicativeGaussianVoxel::append :86-94 (the 4x4 with (3,3) = 1 is block diagonal)
+      const M3 ci = m3_inverse(covs[i]);
+      v.cov = m3_add(v.cov, ci);
+      const V3 cp = m3_mulv(ci, p);
+      for (int a = 0; a < 3; a++) v.mean[a] += cp[a];
+    }
   }
-  for (auto& v : voxels) {                            // finalize :118-121
-    for (int a = 0; a < 3; a++) v.mean[a] /= v.num_points;
-    v.cov = m3_scale(v.cov, 1.0 / v.num_points);
+  for (auto& v : voxels) {
+    if (!multiplicative) {                            // finalize :118-121
+      for (int a = 0; a < 3; a++) v.mean[a] /= v.num_points;
+      v.cov = m3_scale(v.cov, 1.0 / v.num_points);
+    } else {                                          // finalize :96-102: cov = (sum C^-1)^-1, mean = cov * sum C^-1 p
+      v.cov = m3_inverse(v.cov);
+      v.mean = m3_mulv(v.cov, v.mean);
+    }
   }
 }
 
@@ -575,6 +590,7 @@ double FastVGICP::getFitnessScore() const {
 }
 
 void FastVGICP::update_correspondences(const Iso3& T) {
+  lin_pose = T;  // (kept for the cuda-compat leg, which re-forms R_eval C_A R_eval^T in float)
   voxel_correspondences.clear();
   if (gicp_mode) {
     // FastGICP::update_correspondences (fast_gicp_impl.hpp:118-156): query = trans.cast<float>() * point (fp32), exact 1-NN
@@ -632,7 +648,7 @@ void FastVGICP::update_correspondences(const Iso3& T) {
 double FastVGICP::linearize(const Iso3& T, double* H, double* b) {
   if (!gicp_mode && !voxelmap) {
     voxelmap.reset(new VoxelMap(voxel_resolution));
-    voxelmap->create_vgicp(*target, target_covs);
+    voxelmap->create_vgicp(*target, target_covs, voxel_mode);
     if (round_storage_fp32)
       for (auto& v : voxelmap->voxels) { for (int a = 0; a < 3; a++) v.mean[a] = (double)(float)v.mean[a]; for (int i = 0; i < 9; i++) v.cov.m[i] = (double)(float)v.cov.m[i]; }
   }
@@ -689,6 +705,53 @@ double FastVGICP::compute_error(const Iso3& T) {
     sum_errors += w * (e[0] * Me[0] + e[1] * Me[1] + e[2] * Me[2]);
   }
   return sum_errors;
+}
+
+// "cuda-compat" leg: the per-correspondence arithmetic of the reference's DEVICE path in float, term by term as
+// compute_derivatives.cu:50-103 writes it (pose cast to Isometry3f, float covariances and voxel records,
+// RCR = (R_eval C_A) R_eval^T, cofactor inverse, w = sqrtf(n), H = ((w J^T) M) J, b = ((w J^T) M) e, err = ((w e^T) M) e),
+// over the correspondences and the linearisation pose of the last linearize(). The reference reduces the float terms with a
+// Thrust tree of unspecified order; here (and in the engine's FVH_COMPUTE_FP32 mode) the terms are summed in double.
+double FastVGICP::cuda_compat_sums(const Iso3& T, double* H, double* b) const {
+  float Re[9], R[9], t[3];
+  for (int i = 0; i < 9; i++) { Re[i] = (float)lin_pose.R[i]; R[i] = (float)T.R[i]; }
+  for (int i = 0; i < 3; i++) t[i] = (float)T.t[i];
+  double sum_e = 0.0, Hs[36] = {0}, bs[6] = {0};
+  for (size_t n = 0; n < voxel_correspondences.size(); n++) {
+    const auto& corr = voxel_correspondences[n];
+    const Voxel& vox = voxelmap->voxels[corr.second];
+    if (vox.num_points <= 0) continue;
+    float a[3], mu[3], CA[9], CB[9];
+    for (int i = 0; i < 3; i++) { a[i] = input->pt(corr.first)[i]; mu[i] = (float)vox.mean[i]; }
+    for (int i = 0; i < 9; i++) { CA[i] = (float)source_covs[corr.first].m[i]; CB[i] = (float)vox.cov.m[i]; }
+    float q[3];
+    for (int i = 0; i < 3; i++) q[i] = (R[i * 3] * a[0] + R[i * 3 + 1] * a[1] + R[i * 3 + 2] * a[2]) + t[i];
+    float RC[9], A[9];
+    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) RC[i * 3 + j] = Re[i * 3] * CA[j] + Re[i * 3 + 1] * CA[3 + j] + Re[i * 3 + 2] * CA[6 + j];
+    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) A[i * 3 + j] = CB[i * 3 + j] + (RC[i * 3] * Re[j * 3] + RC[i * 3 + 1] * Re[j * 3 + 1] + RC[i * 3 + 2] * Re[j * 3 + 2]);
+    float c[9];
+    c[0] = A[4] * A[8] - A[5] * A[7]; c[1] = A[2] * A[7] - A[1] * A[8]; c[2] = A[1] * A[5] - A[2] * A[4];
+    c[3] = A[5] * A[6] - A[3] * A[8]; c[4] = A[0] * A[8] - A[2] * A[6]; c[5] = A[2] * A[3] - A[0] * A[5];
+    c[6] = A[3] * A[7] - A[4] * A[6]; c[7] = A[1] * A[6] - A[0] * A[7]; c[8] = A[0] * A[4] - A[1] * A[3];
+    const float det = A[0] * c[0] + A[1] * c[3] + A[2] * c[6], inv = 1.0f / det;
+    float M[9];
+    for (int i = 0; i < 9; i++) M[i] = c[i] * inv;
+    const float w = std::sqrt((float)vox.num_points);
+    const float e[3] = {mu[0] - q[0], mu[1] - q[1], mu[2] - q[2]};
+    float J[3][6] = {{0, -q[2], q[1], -1, 0, 0}, {q[2], 0, -q[0], 0, -1, 0}, {-q[1], q[0], 0, 0, 0, -1}};
+    float wJtM[6][3];  // (w J^T) M
+    for (int r = 0; r < 6; r++) for (int k = 0; k < 3; k++) wJtM[r][k] = (w * J[0][r]) * M[k] + (w * J[1][r]) * M[3 + k] + (w * J[2][r]) * M[6 + k];
+    float weM[3];
+    for (int k = 0; k < 3; k++) weM[k] = (w * e[0]) * M[k] + (w * e[1]) * M[3 + k] + (w * e[2]) * M[6 + k];
+    sum_e += (double)(weM[0] * e[0] + weM[1] * e[1] + weM[2] * e[2]);
+    if (!H || !b) continue;
+    for (int r = 0; r < 6; r++) {
+      for (int cc = 0; cc < 6; cc++) Hs[r * 6 + cc] += (double)(wJtM[r][0] * J[0][cc] + wJtM[r][1] * J[1][cc] + wJtM[r][2] * J[2][cc]);
+      bs[r] += (double)(wJtM[r][0] * e[0] + wJtM[r][1] * e[1] + wJtM[r][2] * e[2]);
+    }
+  }
+  if (H && b) { std::memcpy(H, Hs, sizeof(Hs)); std::memcpy(b, bs, sizeof(bs)); }
+  return sum_e;
 }
 
 // =====================================================================================

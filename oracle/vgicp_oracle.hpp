@@ -82,7 +82,7 @@ struct VoxelMap {
   std::vector<Voxel> voxels;
   explicit VoxelMap(double res) : resolution(res) {}
   VoxelKey coord(const V3& x) const;                                               // fast_vgicp_voxel.hpp:158-160
-  void create_vgicp(const Cloud& c, const std::vector<M3>& covs);                  // :129-156, AdditiveGaussianVoxel :105-122
+  void create_vgicp(const Cloud& c, const std::vector<M3>& covs, int mode = 0);    // :129-156, AdditiveGaussianVoxel :105-122, MultiplicativeGaussianVoxel :79-103
   void create_ndt(const Cloud& c);                                                 // gaussian_voxelmap.cu:122-148,178-198 + ndt_cuda.cu:128,139
   int lookup(const VoxelKey& k) const;                                             // :167-174
 };
@@ -120,6 +120,7 @@ struct FastVGICP : LsqBase {
   NeighborSearchMethod search_method = DIRECT1;       // :23
   // covariance source: 0 = kd-tree k-NN (CPU reference), 1 = RBF kernel (CUDA formula)
   int cov_mode = 0;
+  int voxel_mode = 0;                                 // VoxelAccumulationMode ordinal (fast_vgicp_impl.hpp:24 ADDITIVE; 2 = MULTIPLICATIVE)
   double kernel_width = 0.5, kernel_max_dist = 3.0;   // fast_vgicp_cuda_impl.hpp:31
   // when true, regularised covariances / voxel means+covs are rounded to fp32 before use,
   // mirroring the fp32 HBM storage of the HIP engine (diagnostic only).
@@ -135,6 +136,7 @@ struct FastVGICP : LsqBase {
   std::unique_ptr<VoxelMap> voxelmap;
   std::vector<std::pair<int, int>> voxel_correspondences;
   std::vector<M3> voxel_mahalanobis;
+  Iso3 lin_pose = iso_identity();  // pose of the last update_correspondences()
   bool target_cloud_updated = false;
 
   FastVGICP();
@@ -150,6 +152,7 @@ struct FastVGICP : LsqBase {
   void update_correspondences(const Iso3& T);                    // fast_vgicp_impl.hpp:73-116
   double linearize(const Iso3& T, double* H, double* b) override;  // :119-178
   double compute_error(const Iso3& T) override;                    // :181-204
+  double cuda_compat_sums(const Iso3& T, double* H, double* b) const;  // compute_derivatives.cu:50-103 in float over the current correspondences
 };
 
 // ---- NDT (ndt_cuda.cu, ndt_compute_derivatives.cu, ndt_cuda_impl.hpp), fp64 restatement ----

@@ -293,3 +293,49 @@ def test_cooperative_sort_and_its_fallback_give_the_same_knn(O, pair, monkeypatc
     monkeypatch.delenv("FVH_SORT_COOP_WATCHDOG_TICKS")
     assert np.array_equal(got, ref) and np.array_equal(got_fb, ref)
     c.close()
+
+
+def test_multiplicative_voxel_accumulation_matches_oracle(O, pair, oracle_covs):
+    """VoxelAccumulationMode::MULTIPLICATIVE (SURVEY 8 f4; fast_vgicp_voxel.hpp:79-103, CPU-only in the reference): voxel sets
+    and counts exact, means / covariances fp32 rounding, err / H / b 1e-9 against the oracle fed the same fp32-rounded data,
+    final transform 1e-4 with equal iteration counts; ADDITIVE_WEIGHTED == ADDITIVE as in the reference."""
+    from fast_gicp_amd import capi
+    tgt, src = pair
+    cov_t, cov_s = oracle_covs
+    c = _core()
+    c.set_neighbor_search_method(1)
+    c.set_voxel_accumulation_mode(capi.VOXEL_MULTIPLICATIVE)
+    c.set_target_cloud(tgt); c.set_source_cloud(src)
+    c.set_target_covariances(cov_t); c.set_source_covariances(cov_s)
+    c.create_target_voxelmap()
+    coords, num, means, covs = c.get_voxelmap()
+    oc, on, om, ocv = O.voxelmap_vgicp(tgt, cov_t.astype(np.float32).astype(np.float64), 1.0, O.MULTIPLICATIVE)
+    og, oo = np.lexsort(coords.T), np.lexsort(oc.T)
+    assert len(coords) == len(oc) and np.array_equal(coords[og], oc[oo]) and np.array_equal(num[og], on[oo])
+    np.testing.assert_allclose(means[og], om[oo], rtol=0, atol=4e-6 * np.abs(om).max())
+    np.testing.assert_allclose(covs[og], ocv[oo], rtol=2e-6, atol=1e-9)
+    g = O.FastVGICP(search=O.DIRECT7, round_fp32=True)
+    g.set_voxel_accumulation_mode(O.MULTIPLICATIVE)
+    g.set_target(tgt); g.set_source(src)
+    g.set_target_covs(cov_t.astype(np.float32).astype(np.float64)); g.set_source_covs(cov_s.astype(np.float32).astype(np.float64))
+    g.prepare()
+    for T in (np.eye(4), util.relative_pose()):
+        e, H, b = c.linearize(T)
+        eo, Ho, bo = g.linearize(T)
+        assert c.get_num_correspondences() == g.num_correspondences()
+        assert util.sums_close(e, H, b, eo, Ho, bo, 1e-9), (e, eo, util.rel_err(H, Ho))
+    r = c.align()
+    ro = g.align()
+    assert r["converged"] and ro["converged"] and r["num_linearize"] == ro["num_linearize"] and r["num_error_evals"] == ro["num_error_evals"]
+    assert util.rel_err(r["T"], ro["T"]) < 1e-4
+    te, re_ = util.pose_error(util.relative_pose(), r["T"])
+    assert te < 0.05 and re_ < np.radians(1.0)
+    # the mode is part of the map: switching back rebuilds an additive map equal to a fresh handle's
+    c.set_voxel_accumulation_mode(capi.VOXEL_ADDITIVE_WEIGHTED)
+    c.create_target_voxelmap()
+    _, _, m1, v1 = c.get_voxelmap()
+    d = _core()
+    d.set_target_cloud(tgt); d.set_target_covariances(cov_t); d.create_target_voxelmap()
+    _, _, m0, v0 = d.get_voxelmap()
+    assert np.array_equal(np.sort(m1, axis=0), np.sort(m0, axis=0)) and np.array_equal(np.sort(v1.reshape(len(v1), -1), axis=0), np.sort(v0.reshape(len(v0), -1), axis=0))
+    c.close(); d.close()

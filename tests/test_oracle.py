@@ -212,3 +212,25 @@ def test_no_overlap_returns_guess_converged(O):
         r = g.align(guess)
         assert r["converged"] and np.array_equal(r["T"], guess)
         assert r["num_linearize"] == 1 and r["num_error_evals"] == 1
+
+
+def test_multiplicative_voxels_against_numpy(O):
+    """MultiplicativeGaussianVoxel (fast_vgicp_voxel.hpp:79-103): cov = (sum C_i^-1)^-1, mean = cov * sum C_i^-1 p_i, num_points
+    counted as usual -- the oracle's restatement against plain numpy on a small cloud, and the additive mode untouched."""
+    tgt, _, _ = util.synthetic_pair(3000, 10, seed=5, extent=10.0)
+    covs = O.covariances_knn(tgt, 20, O.PLANE)
+    coords, num, means, vc = O.voxelmap_vgicp(tgt, covs, 1.0, O.MULTIPLICATIVE)
+    keys = np.floor(tgt.astype(np.float64) / 1.0 - 0.5).astype(np.int64)
+    assert int(num.sum()) == len(tgt) and len(np.unique(keys, axis=0)) == len(coords)
+    for s in np.random.default_rng(0).integers(0, len(coords), 60):
+        m = (keys == coords[s]).all(1)
+        ci = np.linalg.inv(covs[m])
+        cov = np.linalg.inv(ci.sum(0))
+        mean = cov @ np.einsum("nij,nj->i", ci, tgt[m].astype(np.float64))
+        assert num[s] == m.sum()
+        np.testing.assert_allclose(vc[s], cov, rtol=1e-9, atol=1e-12)
+        np.testing.assert_allclose(means[s], mean, rtol=1e-9, atol=1e-9)
+    ca, na, ma, va = O.voxelmap_vgicp(tgt, covs, 1.0, O.ADDITIVE)
+    cw, nw, mw, vw = O.voxelmap_vgicp(tgt, covs, 1.0, O.ADDITIVE_WEIGHTED)  # same voxel type in the reference (:137-141)
+    assert np.array_equal(ca, cw) and np.array_equal(ma, mw) and np.array_equal(va, vw)
+    assert not np.allclose(va, vc)
