@@ -428,7 +428,7 @@ int calc_cov_knn(Engine* e, CloudDev& c, int method) {
     const int blocks = (int)(((long long)c.n * COV_LANES + 255) / 256);
     if (c.k <= 20) cov_from_neighbors_kernel<5><<<blocks, 256, 0, e->stream>>>(c.pts.as<float4>(), c.n, c.k, c.nbr.as<int>(), method, c.cov.as<float4>());
     else if (c.k <= 32) cov_from_neighbors_kernel<8><<<blocks, 256, 0, e->stream>>>(c.pts.as<float4>(), c.n, c.k, c.nbr.as<int>(), method, c.cov.as<float4>());
-    else cov_from_neighbors_kernel<16><<<blocks, 256, 0, e->stream>>>(c.pts.as<float4>(), c.n, c.k, c.nbr.as<int>(), method, c.cov.as<float4>());
+    else cov_from_neighbors_regather_kernel<<<blocks, 256, 0, e->stream>>>(c.pts.as<float4>(), c.n, c.k, c.nbr.as<int>(), method, c.cov.as<float4>());
   }
   HIP_OR_FAIL(e, hipGetLastError());
   c.has_cov = true;

@@ -408,6 +408,41 @@ __global__ __launch_bounds__(256) void cov_from_neighbors_kernel(const float4* _
   if (sub == 0 && gt / COV_LANES < n) store_cov(cov, i, R);
 }
 
+// k > 32 (up to 64): the same four-lanes-per-point scheme, but the neighbours are gathered again for the centred pass instead
+// of being held in registers (the 16-per-lane instantiation of the kernel above needed 252 VGPRs + 928 spilled ones); the
+// second gather hits the lines the first one just brought in.
+__global__ __launch_bounds__(256) void cov_from_neighbors_regather_kernel(const float4* __restrict__ pts, int n, int k, const int* __restrict__ nbr, int method,
+                                                                          float4* __restrict__ cov) {
+  const int gt = blockIdx.x * 256 + threadIdx.x;
+  const int i = min(gt / COV_LANES, n - 1), sub = gt % COV_LANES;
+  const int* nb = nbr + (size_t)i * k;
+  double mx = 0, my = 0, mz = 0;
+#pragma unroll 4
+  for (int j = sub; j < k; j += COV_LANES) {
+    const float4 p = pts[nb[j]];
+    mx += (double)p.x; my += (double)p.y; mz += (double)p.z;
+  }
+#pragma unroll
+  for (int off = 1; off < COV_LANES; off <<= 1) { mx += __shfl_xor(mx, off); my += __shfl_xor(my, off); mz += __shfl_xor(mz, off); }
+  mx /= k; my /= k; mz /= k;
+  Sym3<double> C = {0, 0, 0, 0, 0, 0};
+#pragma unroll 4
+  for (int j = sub; j < k; j += COV_LANES) {
+    const float4 p = pts[nb[j]];
+    const double dx = (double)p.x - mx, dy = (double)p.y - my, dz = (double)p.z - mz;
+    C.xx += dx * dx; C.xy += dx * dy; C.xz += dx * dz; C.yy += dy * dy; C.yz += dy * dz; C.zz += dz * dz;
+  }
+#pragma unroll
+  for (int off = 1; off < COV_LANES; off <<= 1) {
+    C.xx += __shfl_xor(C.xx, off); C.xy += __shfl_xor(C.xy, off); C.xz += __shfl_xor(C.xz, off);
+    C.yy += __shfl_xor(C.yy, off); C.yz += __shfl_xor(C.yz, off); C.zz += __shfl_xor(C.zz, off);
+  }
+  const double inv = 1.0 / k;
+  C.xx *= inv; C.xy *= inv; C.xz *= inv; C.yy *= inv; C.yz *= inv; C.zz *= inv;
+  const Sym3<double> R = regularize_cov(C, method);
+  if (sub == 0 && gt / COV_LANES < n) store_cov(cov, i, R);
+}
+
 __global__ __launch_bounds__(256) void regularize_kernel(float4* __restrict__ cov, int n, int method) {
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;

@@ -369,3 +369,24 @@ def test_fp32_compute_mode_against_the_cuda_compat_oracle(O):
     te, re_ = util.pose_error(util.relative_pose(), r32["T"])
     assert te < 0.05 and re_ < np.radians(1.0)
     c.close()
+
+
+@pytest.mark.parametrize("k", [21, 32, 33, 40, 64])
+def test_covariances_for_large_k_match_oracle(O, k):
+    """k_correspondences beyond the reference default: 21..32 take the 8-per-lane register kernel, 33..64 the re-gathering
+    kernel (round 1's 16-per-lane instantiation spilled 928 VGPRs and was untested). Exact neighbour lists, covariances to
+    fp32 storage rounding (NONE) / the conditioning-aware bound (PLANE)."""
+    tgt, _, _ = util.synthetic_pair(6000, 10, seed=11, extent=15.0)
+    c = _core()
+    c.set_source_cloud(tgt); c.find_source_neighbors(k)
+    idx = O.knn(tgt, k)
+    assert np.array_equal(c.get_neighbors("source"), idx)
+    raw = O.covariances_knn(tgt, k, O.NONE, idx=idx)
+    c.calculate_source_covariances(0)
+    got = c.get_covariances("source").astype(np.float64)
+    assert np.all(np.abs(got - raw).max(axis=(1, 2)) <= 2e-7 * np.abs(raw).max(axis=(1, 2)) + 1e-12)
+    c.calculate_source_covariances(3)
+    got = c.get_covariances("source").astype(np.float64)
+    err, bound, degenerate = util.cov_error_bound(got, O.covariances_knn(tgt, k, O.PLANE, idx=idx), raw, input_rel=1e-13)
+    assert degenerate.sum() <= 5 and np.all(err[~degenerate] <= bound[~degenerate])
+    c.close()
