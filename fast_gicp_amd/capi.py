@@ -218,6 +218,26 @@ class VGICPCore(_Core):
     """fast_gicp::cuda::FastVGICPCudaCore on the HIP engine (same method names, snake_case as in the .cuh)."""
     _prefix = "fvh_vgicp_"
 
+    # ---- multi-GPU through peer-mapped exchange regions (no RCCL) ----
+    def peer_export(self, max_points):
+        """-> (64-byte IPC handle, raw device pointer of the region)"""
+        buf = (C.c_char * 64)()
+        ptr = C.c_ulonglong(0)
+        self._call("peer_export", int(max_points), buf, C.byref(ptr))
+        return bytes(buf), ptr.value
+
+    def peer_attach(self, nranks, rank, ranks_on_this_device, ipc_handles, process_local_ptrs=None):
+        blob = b"".join(bytes(h) for h in ipc_handles)
+        assert len(blob) == 64 * nranks
+        hbuf = (C.c_char * len(blob)).from_buffer_copy(blob)
+        pbuf = None
+        if process_local_ptrs is not None:
+            pbuf = (C.c_ulonglong * nranks)(*[int(p) for p in process_local_ptrs])
+        self._call("peer_attach", int(nranks), int(rank), int(ranks_on_this_device), hbuf, pbuf)
+
+    def peer_detach(self):
+        self._call("peer_detach")
+
     def set_voxel_accumulation_mode(self, mode):
         self._call("set_voxel_accumulation_mode", int(mode))
 

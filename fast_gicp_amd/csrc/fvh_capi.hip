@@ -20,6 +20,7 @@
 #include "kernels_cost.hpp"
 #include "kernels_cov.hpp"
 #include "kernels_downsample.hpp"
+#include "kernels_peer.hpp"
 #include "kernels_sort.hpp"
 #include "kernels_voxelmap.hpp"
 
@@ -51,6 +52,7 @@ struct CloudDev {
   DevBuf order;                        // Morton permutation: order[j] = original index of the j-th point along the curve
   DevBuf pts, cov, nbr, bbox, sorted;  // sorted: Morton-ordered copy, .w = original index; bbox: boxes of its 64-point tiles
   bool has_pts = false, has_cov = false, has_nbr = false, has_sorted = false;
+  bool nbr_tile_only = false;          // multi-GPU: the neighbour lists exist for this rank's tile only
   bool has_box = false;                // box holds the bounding cube of the CURRENT points (uploads that skip it: NDT, downsampler)
   bool box_dirty = false;              // box holds the cube of a cloud (cleared again by the cooperative sort that consumes it)
   void swap(CloudDev& o) { std::swap(*this, o); }
@@ -167,6 +169,24 @@ struct Engine {
   Profiler prof;
   void* comm = nullptr;
   int nranks = 1, rank = 0;
+  // peer-mapped exchange (kernels_peer.hpp): replaces RCCL for the two exchanges of a sharded registration
+  struct PeerComm {
+    int n = 1, rank = 0, ranks_on_device = 1;
+    char* region = nullptr;            // this handle's exchange region (fine-grained device memory, exported to the peers)
+    size_t region_bytes = 0, stage_half_bytes = 0;
+    char* peer_region[FVH_MAX_PEERS] = {nullptr};
+    bool ipc_opened[FVH_MAX_PEERS] = {false};
+    unsigned long long x = 2;          // exchange counter: the next sums exchange uses tag x / parity x & 1 (same on every rank: collective call discipline)
+    unsigned long long stage_gen = 0;  // covariance all-gathers so far
+    DevBuf err;                        // gather watchdog flag
+    bool attached() const { return n > 1; }
+    PeerView view(unsigned long long xbase) const {
+      PeerView v;
+      v.n = n; v.rank = rank; v.xbase = xbase;
+      for (int i = 0; i < FVH_MAX_PEERS; i++) v.region[i] = peer_region[i];
+      return v;
+    }
+  } peer;
 
   int fail(int code, const std::string& m) { err = m; return code; }
   int hipfail(hipError_t e, const char* what) { err = std::string(what) + ": " + hipGetErrorString(e); return FVH_ERR_HIP; }
@@ -209,11 +229,21 @@ struct Engine {
     if (stream) (void)hipStreamSynchronize(stream);
     if (comm && g_rccl.CommDestroy) g_rccl.CommDestroy(comm);
     comm = nullptr;
+    peer_detach();
+    if (peer.region) { (void)hipFree(peer.region); peer.region = nullptr; }
+    peer.err.release();
     prof.destroy();
     fit_best.release(); sort_coop.release(); pticket.release(); bcast.release(); offsets_dev.release(); state.release(); partials.release(); ticket.release(); corr.release(); misc.release(); fit.release(); staging.release(); sort_keys.release(); sort_idx.release(); sort_hist.release();
     if (pinned) (void)hipHostFree(pinned);
     if (result_host) (void)hipHostFree(result_host);
     if (stream) (void)hipStreamDestroy(stream);
+  }
+  void peer_detach() {
+    for (int i = 0; i < FVH_MAX_PEERS; i++) {
+      if (peer.ipc_opened[i] && peer.peer_region[i]) (void)hipIpcCloseMemHandle(peer.peer_region[i]);
+      peer.peer_region[i] = nullptr; peer.ipc_opened[i] = false;
+    }
+    peer.n = 1; peer.rank = 0; peer.ranks_on_device = 1;
   }
   int upload_offsets() {
     hipError_t e = offsets_dev.ensure(offsets_host.size() * sizeof(int));
@@ -396,6 +426,40 @@ int ensure_sorted(Engine* e, CloudDev& c) {
   return FVH_OK;
 }
 
+// ---- multi-GPU: this rank's tile of a cloud = the range [lo, hi) of its Morton order (chunks of equal size, rank order) ----
+struct Tile { int lo, hi, chunk; };
+inline Tile peer_tile(const Engine* e, int n) {
+  if (!e->peer.attached()) return Tile{0, n, n};
+  const int chunk = ((n + e->peer.n - 1) / e->peer.n + 63) & ~63;  // whole 64-point tiles of the sorted order
+  const int lo = std::min(n, e->peer.rank * chunk);
+  return Tile{lo, std::min(n, lo + chunk), std::max(chunk, 1)};
+}
+constexpr unsigned long long PEER_WATCHDOG_TICKS = 200'000'000ull;  // 2 s of the 100 MHz clock: a peer may still be uploading / sorting its copy
+
+// After a sharded covariance estimation every rank holds its tile only: pack it into this rank's staging half, publish the
+// generation to all peers, and read the other tiles straight out of the peers' staging areas (kernels_peer.hpp).
+int peer_allgather_cov(Engine* e, CloudDev& c) {
+  Engine::PeerComm& pc = e->peer;
+  const Tile t = peer_tile(e, c.n);
+  if ((size_t)t.chunk * 32 > pc.stage_half_bytes) return e->fail(FVH_ERR_INVALID_ARGUMENT, "peer exchange: cloud larger than the max_points given to peer_export");
+  const unsigned long long gen = ++pc.stage_gen;
+  const size_t off = PEER_STAGE_OFFSET + (size_t)(gen & 1ull) * pc.stage_half_bytes;
+  const PeerView pv = pc.view(0);
+  ProfScope ps(e, "peer_gather");
+  if (t.hi > t.lo)
+    peer_pack_cov_kernel<<<(t.hi - t.lo + 255) / 256, 256, 0, e->stream>>>(c.cov.as<float4>(), c.order.as<int>(), t.lo, t.hi, reinterpret_cast<float4*>(pc.region + off));
+  peer_signal_kernel<<<1, 64, 0, e->stream>>>(pv, gen);
+  HIP_OR_FAIL(e, pc.err.ensure(64));
+  HIP_OR_FAIL(e, hipMemsetAsync(pc.err.p, 0, 4, e->stream));
+  peer_gather_cov_kernel<<<(c.n + 255) / 256, 256, 0, e->stream>>>(pv, gen, off, c.cov.as<float4>(), c.order.as<int>(), c.n, t.chunk, PEER_WATCHDOG_TICKS, pc.err.as<int>());
+  HIP_OR_FAIL(e, hipGetLastError());
+  int* h_err = reinterpret_cast<int*>(e->pinned);
+  HIP_OR_FAIL(e, hipMemcpyAsync(h_err, pc.err.p, 4, hipMemcpyDeviceToHost, e->stream));
+  HIP_OR_FAIL(e, hipStreamSynchronize(e->stream));
+  if (*h_err) return e->fail(FVH_ERR_COMM, "peer exchange: a rank did not publish its covariance tile in time (every rank must make the same sequence of calls)");
+  return FVH_OK;
+}
+
 int find_neighbors(Engine* e, CloudDev& c, int k) {
   if (!c.has_pts) return e->fail(FVH_ERR_BAD_STATE, "find_neighbors: cloud not set");
   if (k <= 0 || k > 64) return e->fail(FVH_ERR_INVALID_ARGUMENT, "find_neighbors: k must be in [1, 64]");
@@ -403,18 +467,21 @@ int find_neighbors(Engine* e, CloudDev& c, int k) {
   HIP_OR_FAIL(e, c.nbr.ensure(sizeof(int) * (size_t)c.n * k));
   static const int knn_mode = [] { const char* v = getenv("FVH_KNN_MODE"); return v ? atoi(v) : 1; }();  // 0: full LDS-tiled sweep, 1: Morton order + tile culling
   const int waves = (c.n + KNN_Q - 1) / KNN_Q;
-  if (knn_mode == 0) {
+  if (knn_mode == 0 && !e->peer.attached()) {
     ProfScope ps(e, "knn");
     knn_bruteforce_kernel<<<(waves + 3) / 4, 256, 0, e->stream>>>(c.pts.as<float4>(), c.n, k, c.nbr.as<int>());
   } else {
     int rc = ensure_sorted(e, c);
     if (rc) return rc;
+    const Tile t = peer_tile(e, c.n);  // multi-GPU: the queries of this rank's tile only (the whole sorted cloud is the candidate set: an exact, implicit halo)
     ProfScope ps(e, "knn");
-    knn_tiled1_kernel<<<(c.n + 3) / 4, 256, 0, e->stream>>>(c.sorted.as<float4>(), c.bbox.as<float4>(), c.bbox2.as<float4>(), c.n, k, c.nbr.as<int>());
+    if (t.hi > t.lo)
+      knn_tiled1_kernel<<<(t.hi - t.lo + 3) / 4, 256, 0, e->stream>>>(c.sorted.as<float4>(), c.bbox.as<float4>(), c.bbox2.as<float4>(), c.n, k, c.nbr.as<int>(), t.lo, t.hi);
   }
   HIP_OR_FAIL(e, hipGetLastError());
   c.k = k;
   c.has_nbr = true;
+  c.nbr_tile_only = e->peer.attached();
   return FVH_OK;
 }
 
@@ -423,14 +490,22 @@ int calc_cov_knn(Engine* e, CloudDev& c, int method) {
   if (method < 0 || method > 4) return e->fail(FVH_ERR_INVALID_ARGUMENT, "unknown regularization method");
   if (c.k > COV_LANES * COV_MAX_PER_LANE) return e->fail(FVH_ERR_UNSUPPORTED, "calculate_covariances: more than 64 neighbours per point");
   HIP_OR_FAIL(e, c.cov.ensure(sizeof(float4) * 2 * (size_t)std::max(c.n, 1)));
+  const bool sharded = e->peer.attached();
+  if (sharded) { int rc = ensure_sorted(e, c); if (rc) return rc; }
   if (c.n) {
+    const Tile t = peer_tile(e, c.n);
+    const int m = sharded ? (t.hi - t.lo) : c.n;                      // points this rank computes
+    const int* subset = sharded ? c.order.as<int>() + t.lo : nullptr;  // ... its tile of the Morton order
     ProfScope ps(e, "cov");
-    const int blocks = (int)(((long long)c.n * COV_LANES + 255) / 256);
-    if (c.k <= 20) cov_from_neighbors_kernel<5><<<blocks, 256, 0, e->stream>>>(c.pts.as<float4>(), c.n, c.k, c.nbr.as<int>(), method, c.cov.as<float4>());
-    else if (c.k <= 32) cov_from_neighbors_kernel<8><<<blocks, 256, 0, e->stream>>>(c.pts.as<float4>(), c.n, c.k, c.nbr.as<int>(), method, c.cov.as<float4>());
-    else cov_from_neighbors_regather_kernel<<<blocks, 256, 0, e->stream>>>(c.pts.as<float4>(), c.n, c.k, c.nbr.as<int>(), method, c.cov.as<float4>());
+    const int blocks = (int)(((long long)m * COV_LANES + 255) / 256);
+    if (m > 0) {
+      if (c.k <= 20) cov_from_neighbors_kernel<5><<<blocks, 256, 0, e->stream>>>(c.pts.as<float4>(), m, c.k, c.nbr.as<int>(), method, c.cov.as<float4>(), subset);
+      else if (c.k <= 32) cov_from_neighbors_kernel<8><<<blocks, 256, 0, e->stream>>>(c.pts.as<float4>(), m, c.k, c.nbr.as<int>(), method, c.cov.as<float4>(), subset);
+      else cov_from_neighbors_regather_kernel<<<blocks, 256, 0, e->stream>>>(c.pts.as<float4>(), m, c.k, c.nbr.as<int>(), method, c.cov.as<float4>(), subset);
+    }
   }
   HIP_OR_FAIL(e, hipGetLastError());
+  if (sharded && c.n) { int rc = peer_allgather_cov(e, c); if (rc) return rc; }
   c.has_cov = true;
   return FVH_OK;
 }
@@ -439,22 +514,25 @@ int calc_cov_rbf(Engine* e, CloudDev& c, double kernel_width, double max_dist, i
   if (!c.has_pts) return e->fail(FVH_ERR_BAD_STATE, "calculate_covariances_rbf: cloud not set");
   if (method < 0 || method > 4) return e->fail(FVH_ERR_INVALID_ARGUMENT, "unknown regularization method");
   HIP_OR_FAIL(e, c.cov.ensure(sizeof(float4) * 2 * (size_t)std::max(c.n, 1)));
+  const bool sharded = e->peer.attached();
   if (c.n) {
     static const int rbf_mode = [] { const char* v = getenv("FVH_RBF_MODE"); return v ? atoi(v) : 1; }();  // 0: full sweep, 1: Morton order + tile culling
     const int waves = (c.n + RBF_Q - 1) / RBF_Q;
     const float md = (float)max_dist;
-    if (rbf_mode == 0) {
+    if (rbf_mode == 0 && !sharded) {
       ProfScope ps(e, "rbf");
       cov_rbf_kernel<<<(waves + 3) / 4, 256, 0, e->stream>>>(c.pts.as<float4>(), c.n, (float)kernel_width, md * md, method, c.cov.as<float4>());
     } else {
       int rc = ensure_sorted(e, c);
       if (rc) return rc;
+      const Tile t = peer_tile(e, c.n);
       ProfScope ps(e, "rbf");
-      if (rbf_mode == 2) cov_rbf_tiled_kernel<<<(waves + 3) / 4, 256, 0, e->stream>>>(c.sorted.as<float4>(), c.bbox.as<float4>(), c.n, (float)kernel_width, md * md, method, c.cov.as<float4>());
-      else cov_rbf1_kernel<<<(c.n + 3) / 4, 256, 0, e->stream>>>(c.sorted.as<float4>(), c.bbox.as<float4>(), c.bbox2.as<float4>(), c.n, (float)kernel_width, md * md, method, c.cov.as<float4>());
+      if (rbf_mode == 2 && !sharded) cov_rbf_tiled_kernel<<<(waves + 3) / 4, 256, 0, e->stream>>>(c.sorted.as<float4>(), c.bbox.as<float4>(), c.n, (float)kernel_width, md * md, method, c.cov.as<float4>());
+      else if (t.hi > t.lo) cov_rbf1_kernel<<<(t.hi - t.lo + 3) / 4, 256, 0, e->stream>>>(c.sorted.as<float4>(), c.bbox.as<float4>(), c.bbox2.as<float4>(), c.n, (float)kernel_width, md * md, method, c.cov.as<float4>(), t.lo, t.hi);
     }
   }
   HIP_OR_FAIL(e, hipGetLastError());
+  if (sharded && c.n) { int rc = peer_allgather_cov(e, c); if (rc) return rc; }
   c.has_cov = true;
   return FVH_OK;
 }
@@ -608,6 +686,7 @@ struct CostSource {
   const int* counters2;  // source voxel map counters (D2D) or null
   const int* order;      // Morton permutation of the source (large clouds) or null
   int n_off_override = 0;  // > 0: correspondences per source element regardless of the handle's offset list (GICP: 1)
+  bool shardable = false;  // the source elements are the points of a cloud with a Morton order: with peers attached each rank walks its tile
 };
 
 // Persistent LM kernel (kernels_cost.hpp, PERSIST): co-resident workgroup capacity of the device for this instantiation.
@@ -629,7 +708,7 @@ int persistent_capacity(Engine* e) {
 
 template <int MODE>
 int launch_cost(Engine* e, const CostSource& src, const VoxelMapDev& vm, int host_phase, const PoseD* lin, const PoseD* ev, const fvh_lm_params* init = nullptr,
-                bool persistent = false) {
+                bool persistent = false, unsigned long long peer_xbase = 0 /* multi-GPU: exchange counter of this launch's first sums exchange */) {
   CostParams P;
   std::memset(&P, 0, sizeof(P));
   P.src_pts = src.pts; P.src_cov = src.cov; P.d_n_src = src.d_n; P.n_src = src.n_upper; P.order = src.order;
@@ -661,15 +740,34 @@ int launch_cost(Engine* e, const CostSource& src, const VoxelMapDev& vm, int hos
     P.max_iterations = init->max_iterations; P.lm_max_iterations = init->lm_max_iterations;
     P.rotation_epsilon = init->rotation_epsilon; P.transformation_epsilon = init->transformation_epsilon; P.lm_init_lambda_factor = init->lm_init_lambda_factor;
   }
-  const long long items = (long long)src.n_upper * P.groups_per_src;
+  long long n_walk = src.n_upper;
+  P.item_lo = 0; P.item_hi = 0;
+  P.peer.n = 1; P.peer.rank = 0; P.peer.xbase = 0;
+  for (int i = 0; i < FVH_MAX_PEERS; i++) P.peer.region[i] = nullptr;
+  if (MODE == MODE_VGICP && e->peer.attached() && src.shardable) {
+    // multi-GPU: this rank's spatial tile of the source (a range of its Morton order) and the mailboxes of all ranks
+    const Tile t = peer_tile(e, src.n_upper);
+    P.item_lo = t.lo; P.item_hi = std::max(t.hi, 1);  // (item_hi == 0 means "everything")
+    if (t.hi <= t.lo) { P.item_lo = 0; P.item_hi = 1; n_walk = 0; P.n_src = 0; } else n_walk = t.hi - t.lo;
+    P.peer = e->peer.view(peer_xbase);
+    static const unsigned long long wd = [] { const char* v = getenv("FVH_PEER_WATCHDOG_TICKS"); return v ? strtoull(v, nullptr, 10) : PEER_WATCHDOG_TICKS; }();
+    P.peer_watchdog_ticks = wd;
+  }
+  const long long items = n_walk * P.groups_per_src;
   int blocks = (int)std::max<long long>(1, std::min<long long>(max_blocks, (items + 255) / 256));
   {
     // The persistent kernel needs every workgroup resident at once: its grid is clamped to what the device can hold (the
     // kernel is grid-stride). The per-transition launches take the SAME grid, so that both routes partition the items --
     // and therefore order the sums -- identically (bit-identical results whichever route an align takes).
-    const int cap = persistent_capacity<MODE>(e);
+    int cap = persistent_capacity<MODE>(e);
     if (cap <= 0) return e->fail(FVH_ERR_HIP, "cost kernel: occupancy query failed");
+    if (e->peer.attached()) cap = std::max(1, cap / std::max(1, e->peer.ranks_on_device));  // ranks sharing one GPU share its co-resident slots
     blocks = std::min(blocks, cap);
+  }
+  // abort word = 0 (the last 8 bytes of the state; never covered by the state write-back)
+  if (e->abort_word_dirty) {
+    HIP_OR_FAIL(e, hipMemsetAsync(reinterpret_cast<char*>(e->state.p) + sizeof(LmState) - 8, 0, 8, e->stream));
+    e->abort_word_dirty = false;
   }
   if (persistent) {
     { const char* v = getenv("FVH_PERSIST_WATCHDOG_TICKS"); P.watchdog_ticks = v ? strtoull(v, nullptr, 10) : PERSIST_WATCHDOG_TICKS; }  // test hook: 0 forces the abort + fallback path
@@ -678,11 +776,6 @@ int launch_cost(Engine* e, const CostSource& src, const VoxelMapDev& vm, int hos
     e->zero_copy_armed = P.result_host != nullptr;
     P.bcast = e->bcast.as<double>();
     P.launch_tag = ++e->persist_seq;
-    // abort word = 0 (the last 8 bytes of the state; never covered by the state write-back); arrival counters = 0
-    if (e->abort_word_dirty) {
-      HIP_OR_FAIL(e, hipMemsetAsync(reinterpret_cast<char*>(e->state.p) + sizeof(LmState) - 8, 0, 8, e->stream));
-      e->abort_word_dirty = false;
-    }
     if (e->pticket_dirty || e->pticket_base[TICKET_GROUPS] > 0x70000000u) {
       HIP_OR_FAIL(e, hipMemsetAsync(e->pticket.p, 0, PERSIST_TICKET_BYTES, e->stream));
       std::memset(e->pticket_base, 0, sizeof(e->pticket_base));
@@ -735,11 +828,18 @@ int do_compute_error(Engine* e, const CostSource& src, VoxelMapDev& vm, const do
   PoseD ev = pose_from_colmajor16(T16);
   LmState* h = reinterpret_cast<LmState*>(e->pinned);
   for (int attempt = 0; attempt < 2; attempt++) {
-    int rc = launch_cost<MODE>(e, src, vm, deriv ? PH_EVAL_DERIV : PH_EVAL_ERROR, &e->lin, &ev);
+    const bool sharded = MODE == MODE_VGICP && e->peer.attached() && src.shardable;
+    int rc = launch_cost<MODE>(e, src, vm, deriv ? PH_EVAL_DERIV : PH_EVAL_ERROR, &e->lin, &ev, nullptr, false, e->peer.x);
     if (rc) return rc;
+    if (sharded) e->peer.x++;  // one sums exchange per evaluation, on every rank
     if (e->comm) { rc = allreduce_sums(e); if (rc) return rc; }
     HIP_OR_FAIL(e, hipMemcpyAsync(h, e->state.p, sizeof(LmState), hipMemcpyDeviceToHost, e->stream));
     HIP_OR_FAIL(e, hipStreamSynchronize(e->stream));
+    if (h->aborted) {
+      e->abort_word_dirty = true;
+      e->peer.x = (e->peer.x + 8192) & ~1ull;
+      return e->fail(FVH_ERR_COMM, "compute_error: a peer rank did not deliver its sums (every rank must make the same sequence of calls)");
+    }
     vm.nv_hint = h->vm_num_voxels;
     if (h->vm_dropped == 0 || attempt == 1) break;
     // the hint-sized table overflowed: rebuild at the safe size, redo the correspondences, evaluate again
@@ -784,9 +884,10 @@ int do_align(Engine* e, const CostSource& src, VoxelMapDev& vm, const double* gu
   static const int persist_env = [] { const char* v = getenv("FVH_PERSISTENT"); return v ? atoi(v) : 1; }();
   const int active_before = g_active_aligns.fetch_add(1);
   struct Leave { ~Leave() { g_active_aligns.fetch_sub(1); } } leave;
+  const bool sharded = MODE == MODE_VGICP && e->peer.attached() && src.shardable;
   bool persistent = persist_env != 0 && !degenerate && !e->comm && !no_persist && active_before == 0 && budget < 4000 && (long long)src.n_upper * e->n_off <= PERSIST_MAX_ITEMS;
   if (persistent) {
-    int rc = launch_cost<MODE>(e, src, vm, -1, &guess, nullptr, &p, true);
+    int rc = launch_cost<MODE>(e, src, vm, -1, &guess, nullptr, &p, true, e->peer.x);
     if (rc) return rc;
     bool have_result = false;
     if (e->result_dev && e->zero_copy_armed) {
@@ -811,9 +912,13 @@ int do_align(Engine* e, const CostSource& src, VoxelMapDev& vm, const double* gu
       e->persist_aborts++;
       e->pticket_dirty = true;
       e->abort_word_dirty = true;
+      // multi-GPU: an abort on ANY rank reaches every rank within a watchdog period (its mailbox stays empty), so all ranks
+      // arrive here and restart together; the exchange counter jumps past whatever this launch may have used
+      if (sharded) e->peer.x = (e->peer.x + 8192) & ~1ull;
       return do_align<MODE>(e, src, vm, guess16, params, result, rebuild_safe, retried, true);
     }
     launched = 1;
+    if (sharded) e->peer.x += 1ull + (unsigned long long)h->num_error_evals;  // one exchange per trip
     {  // where the arrival counters stand now: every workgroup arrived once per trip, every group's last arriver bumped the top counter
       const unsigned trips = 1u + (unsigned)h->num_error_evals, B = (unsigned)e->last_persist_blocks;
       for (unsigned g = 0; g < (unsigned)TICKET_GROUPS; g++) e->pticket_base[g] += (g < B ? (B - g + TICKET_GROUPS - 1) / TICKET_GROUPS : 0u) * trips;
@@ -824,7 +929,7 @@ int do_align(Engine* e, const CostSource& src, VoxelMapDev& vm, const double* gu
     for (int s = 0; s < batch; s++) {
       // the first launch carries the initial guess and the LM parameters and (re)initialises the device state
       const bool first = (launched == 0 && s == 0 && !degenerate);
-      int rc = launch_cost<MODE>(e, src, vm, -1, first ? &guess : nullptr, nullptr, first ? &p : nullptr);
+      int rc = launch_cost<MODE>(e, src, vm, -1, first ? &guess : nullptr, nullptr, first ? &p : nullptr, false, e->peer.x + (unsigned long long)(launched + s));
       if (rc) return rc;
       if (e->comm) {
         rc = allreduce_sums(e);
@@ -835,9 +940,15 @@ int do_align(Engine* e, const CostSource& src, VoxelMapDev& vm, const double* gu
     launched += batch;
     HIP_OR_FAIL(e, hipMemcpyAsync(h, st, sizeof(LmState), hipMemcpyDeviceToHost, e->stream));
     HIP_OR_FAIL(e, hipStreamSynchronize(e->stream));
+    if (h->aborted) {  // (only the peer exchange raises it on this route)
+      e->abort_word_dirty = true;
+      e->peer.x = (e->peer.x + 8192) & ~1ull;
+      return e->fail(FVH_ERR_COMM, "align: a peer rank did not deliver its sums (every rank must make the same sequence of calls)");
+    }
     if (h->phase == PH_DONE || launched >= budget) break;
     batch = 3;
   }
+  if (!persistent && sharded && h->num_linearize > 0) e->peer.x += 1ull + (unsigned long long)h->num_error_evals;  // launches after PH_DONE leave before the exchange
   vm.nv_hint = h->vm_num_voxels;
   if (h->vm_dropped > 0) {  // hint-sized table overflowed: rebuild at the safe size and run again (rare)
     if (retried) return e->fail(FVH_ERR_BAD_STATE, "voxel map overflow persists after safe rebuild");
@@ -1118,7 +1229,13 @@ struct fvh_vgicp {
   VoxelMapDev voxelmap;
   VoxelMapDev gicp_records;  // per-target-point records for the nearest-point (GICP) cost
   double gicp_max_dist = 3.4028234663852886e38;
-  CostSource cost_source() const { return CostSource{source.pts.as<float4>(), source.cov.as<float4>(), nullptr, source.n, nullptr, coherent_order(source)}; }
+  CostSource cost_source() const {
+    // multi-GPU: the tiles are ranges of the Morton order whatever the size of the cloud (spatially compact shards)
+    const int* order = e.peer.attached() ? (source.has_sorted ? source.order.as<int>() : nullptr) : coherent_order(source);
+    CostSource c{source.pts.as<float4>(), source.cov.as<float4>(), nullptr, source.n, nullptr, order};
+    c.shardable = true;
+    return c;
+  }
   CostSource gicp_cost_source() const { CostSource c{source.pts.as<float4>(), source.cov.as<float4>(), nullptr, source.n, nullptr, nullptr}; c.n_off_override = 1; return c; }
   int voxel_mode = 0;        // VoxelAccumulationMode ordinal: 0 ADDITIVE, 1 ADDITIVE_WEIGHTED (same voxel type in the reference), 2 MULTIPLICATIVE
   int build_map(double res, bool force_safe = false) {
@@ -1257,7 +1374,18 @@ int fvh_vgicp_get_num_correspondences(fvh_vgicp* h, int* n) {
   int rc = fetch_corr(&h->e, h->e.corr_n_src, corr);
   if (rc) return rc;
   int c = 0;
-  for (int v : corr) c += (v >= 0);
+  if (h->e.peer.attached() && h->e.corr_kind == 0 && h->source.has_sorted && h->e.corr_n_src == h->source.n) {
+    // multi-GPU: only this rank's tile of the source was evaluated (the other rows of the buffer were never written)
+    const Tile t = peer_tile(&h->e, h->source.n);
+    std::vector<int> order((size_t)std::max(t.hi - t.lo, 0));
+    if (!order.empty()) {
+      HIP_OR_FAIL(&h->e, hipMemcpyAsync(order.data(), h->source.order.as<int>() + t.lo, sizeof(int) * order.size(), hipMemcpyDeviceToHost, h->e.stream));
+      HIP_OR_FAIL(&h->e, hipStreamSynchronize(h->e.stream));
+    }
+    for (int i : order) for (int o = 0; o < h->e.n_off; o++) c += (corr[(size_t)i * h->e.n_off + o] >= 0);
+  } else {
+    for (int v : corr) c += (v >= 0);
+  }
   *n = c;
   return FVH_OK;
 }
@@ -1287,6 +1415,7 @@ int fvh_vgicp_get_voxel_correspondences(fvh_vgicp* h, int* pairs) {
 int fvh_vgicp_update_correspondences(fvh_vgicp* h, const double* T) {
   CHECK_HANDLE(h);
   if (!h->source.has_pts || !h->source.has_cov) return h->e.fail(FVH_ERR_BAD_STATE, "update_correspondences: source cloud/covariances not set");
+  if (h->e.peer.attached() && h->source.n) { int rc = ensure_sorted(&h->e, h->source); if (rc) return rc; }
   h->e.corr_kind = 0;
   return do_update_correspondences<MODE_VGICP>(&h->e, h->cost_source(), h->voxelmap, T);
 }
@@ -1324,6 +1453,7 @@ int fvh_vgicp_compute_error(fvh_vgicp* h, const double* T, double* H, double* b,
 int fvh_vgicp_align(fvh_vgicp* h, const double* guess, const fvh_lm_params* p, fvh_lm_result* r) {
   CHECK_HANDLE(h);
   if (!h->source.has_pts || !h->source.has_cov) return h->e.fail(FVH_ERR_BAD_STATE, "align: source cloud/covariances not set");
+  if (h->e.peer.attached() && h->source.n) { int rc = ensure_sorted(&h->e, h->source); if (rc) return rc; }
   return do_align<MODE_VGICP>(&h->e, h->cost_source(), h->voxelmap, guess, p, r, h->rebuild_safe());
 }
 int fvh_vgicp_fitness_score(fvh_vgicp* h, const double* T, double max_range, double* score) { CHECK_HANDLE(h); return do_fitness(&h->e, h->source, h->target, T, max_range, score); }
@@ -1369,6 +1499,55 @@ int fvh_comm_unique_id(void* id128) {
   return g_rccl.GetUniqueId(id128) == 0 ? FVH_OK : FVH_ERR_COMM;
 }
 int fvh_vgicp_comm_init(fvh_vgicp* h, const void* id, int nranks, int rank) { CHECK_HANDLE(h); return comm_init(&h->e, id, nranks, rank); }
+// ---- peer-mapped exchange (kernels_peer.hpp) ----
+int fvh_vgicp_peer_export(fvh_vgicp* h, int max_points, void* ipc_handle64, unsigned long long* process_local_ptr) {
+  CHECK_HANDLE(h);
+  Engine* e = &h->e;
+  if (max_points <= 0 || !ipc_handle64) return e->fail(FVH_ERR_INVALID_ARGUMENT, "peer_export: bad arguments");
+  static_assert(sizeof(hipIpcMemHandle_t) == 64, "the C ABI hands the IPC handle over as 64 opaque bytes");
+  if (e->peer.attached()) return e->fail(FVH_ERR_BAD_STATE, "peer_export: detach first");
+  const size_t half = (((size_t)max_points + 63) & ~(size_t)63) * 32;  // two float4 per point; a single-rank "tile" is the whole cloud
+  const size_t bytes = PEER_STAGE_OFFSET + 2 * half;
+  if (!e->peer.region || e->peer.region_bytes < bytes) {
+    if (e->peer.region) { HIP_OR_FAIL(e, hipFree(e->peer.region)); e->peer.region = nullptr; }
+    HIP_OR_FAIL(e, hipExtMallocWithFlags(reinterpret_cast<void**>(&e->peer.region), bytes, hipDeviceMallocFinegrained));
+    e->peer.region_bytes = bytes;
+  }
+  e->peer.stage_half_bytes = half;
+  HIP_OR_FAIL(e, hipMemsetAsync(e->peer.region, 0, PEER_STAGE_OFFSET, e->stream));
+  HIP_OR_FAIL(e, hipStreamSynchronize(e->stream));
+  e->peer.x = 2; e->peer.stage_gen = 0;
+  hipIpcMemHandle_t hm;
+  HIP_OR_FAIL(e, hipIpcGetMemHandle(&hm, e->peer.region));
+  std::memcpy(ipc_handle64, &hm, 64);
+  if (process_local_ptr) *process_local_ptr = (unsigned long long)(uintptr_t)e->peer.region;
+  return FVH_OK;
+}
+int fvh_vgicp_peer_attach(fvh_vgicp* h, int nranks, int rank, int ranks_on_this_device, const void* ipc_handles, const unsigned long long* process_local_ptrs) {
+  CHECK_HANDLE(h);
+  Engine* e = &h->e;
+  if (nranks < 1 || nranks > FVH_MAX_PEERS || rank < 0 || rank >= nranks || ranks_on_this_device < 1 || (!ipc_handles && !process_local_ptrs))
+    return e->fail(FVH_ERR_INVALID_ARGUMENT, "peer_attach: bad arguments (at most 8 ranks)");
+  if (!e->peer.region) return e->fail(FVH_ERR_BAD_STATE, "peer_attach: call peer_export first");
+  if (e->comm) return e->fail(FVH_ERR_BAD_STATE, "peer_attach: an RCCL communicator is attached (use one or the other)");
+  e->peer_detach();
+  for (int p = 0; p < nranks; p++) {
+    if (p == rank) { e->peer.peer_region[p] = e->peer.region; continue; }
+    if (process_local_ptrs && process_local_ptrs[p]) { e->peer.peer_region[p] = reinterpret_cast<char*>((uintptr_t)process_local_ptrs[p]); continue; }  // a handle of THIS process
+    if (!ipc_handles) { e->peer_detach(); return e->fail(FVH_ERR_INVALID_ARGUMENT, "peer_attach: no IPC handle for a peer of another process"); }
+    hipIpcMemHandle_t hm;
+    std::memcpy(&hm, static_cast<const char*>(ipc_handles) + 64 * (size_t)p, 64);
+    void* ptr = nullptr;
+    hipError_t rc = hipIpcOpenMemHandle(&ptr, hm, hipIpcMemLazyEnablePeerAccess);
+    if (rc != hipSuccess) { e->peer_detach(); return e->hipfail(rc, "hipIpcOpenMemHandle (peer exchange region)"); }
+    e->peer.peer_region[p] = static_cast<char*>(ptr);
+    e->peer.ipc_opened[p] = true;
+  }
+  e->peer.n = nranks; e->peer.rank = rank; e->peer.ranks_on_device = ranks_on_this_device;
+  e->has_corr = false;
+  return FVH_OK;
+}
+int fvh_vgicp_peer_detach(fvh_vgicp* h) { CHECK_HANDLE(h); h->e.peer_detach(); h->e.has_corr = false; return FVH_OK; }
 int fvh_vgicp_comm_destroy(fvh_vgicp* h) { CHECK_HANDLE(h); if (h->e.comm) { g_rccl.CommDestroy(h->e.comm); h->e.comm = nullptr; } h->e.nranks = 1; h->e.rank = 0; return FVH_OK; }
 
 // ---- NDT ---------------------------------------------------------------------------------------

@@ -20,6 +20,7 @@
 #include <cstddef>
 
 #include "dev_math.hpp"
+#include "kernels_peer.hpp"
 
 // Contraction only inside one source expression (not across statements, which is hipcc's default "fast"): whether a
 // multiply and an add fuse must not depend on what the optimiser happens to see around them -- the persistent and the
@@ -95,6 +96,11 @@ struct CostParams {
   unsigned long long watchdog_ticks;  // persistent kernel: 100 MHz ticks a workgroup may wait at the barrier before it aborts the launch
   int max_iterations, lm_max_iterations;
   double rotation_epsilon, transformation_epsilon, lm_init_lambda_factor;
+  // multi-GPU (kernels_peer.hpp): this rank walks the source elements [item_lo, item_hi) of the (Morton) order -- its spatial
+  // tile -- and the reduced sums are exchanged with the peers inside the kernel; peer.n <= 1: single GPU, whole cloud
+  int item_lo, item_hi;
+  PeerView peer;
+  unsigned long long peer_watchdog_ticks;
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -632,7 +638,8 @@ __global__ FVH_COST_BOUNDS void cost_kernel(CostParams P) {
   // linearisation pose of the NEW ids; filled before the first trip and by the barrier code of every persistent trip)
   const Real res = (Real)P.res;
   const int n_src = P.d_n_src ? *P.d_n_src : P.n_src;
-  const int n_items = n_src * P.groups_per_src;
+  const int w_lo = (P.item_hi > 0 ? min(P.item_lo, n_src) : 0) * P.groups_per_src;           // this rank's tile of the item list
+  const int n_items = (P.item_hi > 0 ? min(P.item_hi, n_src) : n_src) * P.groups_per_src;     // (end of the range)
   int* corr_old = P.corr + (size_t)corr_sel * P.corr_stride;                      // read (stored ids)
   int* corr_new = fused ? P.corr + (size_t)(corr_sel ^ 1) * P.corr_stride : corr_old;  // written by the find
 
@@ -647,7 +654,7 @@ __global__ FVH_COST_BOUNDS void cost_kernel(CostParams P) {
   // (consecutive threads take consecutive items on purpose: spreading a workgroup's items over the cloud made the launch
   // 24 % slower -- the loop is sensitive to how many distinct cache lines a wave touches)
   // The loop bound is wave-uniform (the butterfly needs all 64 lanes); lanes past the end contribute zeros.
-  for (int wbase = blockIdx.x * 256 + (threadIdx.x & 192); wbase < n_items; wbase += gridDim.x * 256) {
+  for (int wbase = w_lo + blockIdx.x * 256 + (threadIdx.x & 192); wbase < n_items; wbase += gridDim.x * 256) {
     const int w = wbase + lane;
     ItemAcc<Real> it = {{0, 0, 0, 0, 0, 0}, {0, 0, 0}, 0};
     Real acc_y = 0;  // fused: trial error with the old ids
@@ -943,6 +950,13 @@ __global__ FVH_COST_BOUNDS void cost_kernel(CostParams P) {
     // ---- the very last workgroup: sum the group rows in group order (deterministic), LM step ----
     reduce_final((size_t)MAX_PARTIAL_ROWS);
     if (tid <= TICKET_GROUPS) P.ticket[tid] = 0;  // re-arm for the next launch
+    if (MODE == MODE_VGICP && P.peer.n > 1) {  // multi-GPU: sum the blocks of all ranks (rank order -> bit-identical on every rank); one workgroup per rank is in here
+      __syncthreads();
+      if (!peer_exchange_sums(P.peer, red[0], P.peer.xbase, P.peer_watchdog_ticks, tid, 256, &s_last)) {
+        if (tid == 0) __hip_atomic_store(&st->aborted, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // a peer did not deliver: the host reports FVH_ERR_COMM
+        return;
+      }
+    }
     // The LM step is one thread of dependent fp64 math; run it on an LDS copy of the state (a global
     // round trip per st-> access would cost more than the arithmetic) and write the state back with all lanes.
     for (int i = tid; i < ST_WORDS; i += 256) reinterpret_cast<unsigned long long*>(&s_st)[i] = st_words[i];
@@ -1025,14 +1039,21 @@ __global__ FVH_COST_BOUNDS void cost_kernel(CostParams P) {
         s_last = ok;
       }
       __syncthreads();
-      if (!s_last) {  // not every workgroup is resident / something is stuck: never hang the GPU -- poison every tag and leave
+      unsigned abort_code = s_last ? 0u : 1u;  // 1: not every workgroup is resident / something is stuck
+      if (!abort_code) {
+        FVH_PT_MAX(trip, 6);
+        reduce_final(grow0);
+        __syncthreads();
+        // multi-GPU: the openers of all ranks meet in each other's mailboxes (kernels_peer.hpp); every rank then runs the same LM step
+        // (VGICP handles only: the NDT handles shard through RCCL between launches, and their D2D instantiation has no register to spare)
+        if constexpr (MODE == MODE_VGICP)
+          if (P.peer.n > 1 && !peer_exchange_sums(P.peer, red[0], P.peer.xbase + trip, P.peer_watchdog_ticks, tid, 256, &s_last)) abort_code = 2u;  // 2: a peer did not deliver
+      }
+      if (abort_code) {  // never hang the GPU -- poison every tag of this launch and leave; the host takes it from `aborted`
         for (int idx = tid; idx < PERSIST_REPLICAS * BCAST_SLOTS / 8; idx += 256) __hip_atomic_store(&P.bcast[idx * 8 + 7], abort_tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (tid == 0) __hip_atomic_store(&st->aborted, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (tid == 0) __hip_atomic_store(&st->aborted, abort_code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         return;
       }
-      FVH_PT_MAX(trip, 6);
-      reduce_final(grow0);
-      __syncthreads();
       FVH_PT_MAX(trip, 7);
       if (trip == 0 && tid == 0) {
         init_state();

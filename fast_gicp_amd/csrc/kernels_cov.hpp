@@ -273,10 +273,10 @@ __device__ unsigned long long g_knn_time[32768][8];  // debug build: per query {
 #define KNN_STAMP(i) do { } while (0)
 #endif
 __global__ __launch_bounds__(256) void knn_tiled1_kernel(const float4* __restrict__ spts, const float4* __restrict__ bbox1, const float4* __restrict__ bbox2, int n, int k,
-                                                         int* __restrict__ out_idx) {
+                                                         int* __restrict__ out_idx, int q_begin = 0, int q_end = 0x7fffffff /* queries = this range of the Morton order (a rank's tile) */) {
   const int lane = threadIdx.x & 63;
-  const int q = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (q >= n) return;
+  const int q = q_begin + blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (q >= min(n, q_end)) return;
   KNN_STAMP(0);
   int dbg_tiles = 0, dbg_ins = 0;
   const int ntiles = (n + 63) >> 6, nsuper = (ntiles + 63) >> 6;
@@ -370,9 +370,10 @@ __device__ __forceinline__ void store_cov(float4* __restrict__ cov, int i, const
 constexpr int COV_LANES = 4, COV_MAX_PER_LANE = 16;  // k <= 64
 template <int PER_LANE>  // neighbours a lane holds: k <= 4 * PER_LANE (5 for the reference's k = 20)
 __global__ __launch_bounds__(256) void cov_from_neighbors_kernel(const float4* __restrict__ pts, int n, int k, const int* __restrict__ nbr, int method,
-                                                                 float4* __restrict__ cov) {
+                                                                 float4* __restrict__ cov, const int* __restrict__ subset = nullptr /* n point indices (a rank's tile), or all */) {
   const int gt = blockIdx.x * 256 + threadIdx.x;
-  const int i = min(gt / COV_LANES, n - 1), sub = gt % COV_LANES;
+  const int sub = gt % COV_LANES;
+  const int i = subset ? subset[min(gt / COV_LANES, n - 1)] : min(gt / COV_LANES, n - 1);
   const int* nb = nbr + (size_t)i * k;
   float px[PER_LANE], py[PER_LANE], pz[PER_LANE];
   double mx = 0, my = 0, mz = 0;
@@ -412,9 +413,10 @@ __global__ __launch_bounds__(256) void cov_from_neighbors_kernel(const float4* _
 // of being held in registers (the 16-per-lane instantiation of the kernel above needed 252 VGPRs + 928 spilled ones); the
 // second gather hits the lines the first one just brought in.
 __global__ __launch_bounds__(256) void cov_from_neighbors_regather_kernel(const float4* __restrict__ pts, int n, int k, const int* __restrict__ nbr, int method,
-                                                                          float4* __restrict__ cov) {
+                                                                          float4* __restrict__ cov, const int* __restrict__ subset = nullptr) {
   const int gt = blockIdx.x * 256 + threadIdx.x;
-  const int i = min(gt / COV_LANES, n - 1), sub = gt % COV_LANES;
+  const int sub = gt % COV_LANES;
+  const int i = subset ? subset[min(gt / COV_LANES, n - 1)] : min(gt / COV_LANES, n - 1);
   const int* nb = nbr + (size_t)i * k;
   double mx = 0, my = 0, mz = 0;
 #pragma unroll 4
@@ -608,10 +610,10 @@ __global__ __launch_bounds__(256) void cov_rbf_tiled_kernel(const float4* __rest
 // covariance). Lane l accumulates the candidates it sees at position l of every tile within max_dist, in ascending
 // tile order -- the arithmetic of cov_rbf_tiled_kernel, term by term (tiles it skips would have contributed weight 0).
 __global__ __launch_bounds__(256) void cov_rbf1_kernel(const float4* __restrict__ spts, const float4* __restrict__ bbox1, const float4* __restrict__ bbox2, int n, float kernel_width,
-                                                       float max_dist_sq, int method, float4* __restrict__ cov) {
+                                                       float max_dist_sq, int method, float4* __restrict__ cov, int q_begin = 0, int q_end = 0x7fffffff) {
   const int lane = threadIdx.x & 63;
-  const int q = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (q >= n) return;
+  const int q = q_begin + blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (q >= min(n, q_end)) return;
   const int ntiles = (n + 63) >> 6, nsuper = (ntiles + 63) >> 6;
   const float4 qv = spts[q];
   const float qx = read_lane(qv.x, 0), qy = read_lane(qv.y, 0), qz = read_lane(qv.z, 0);

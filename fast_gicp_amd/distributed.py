@@ -1,21 +1,24 @@
-"""Multi-GPU registration: one process per GPU, source cloud sharded by spatial tile, the 28-value
-normal-equation block {err, b(6), upper H(21)} all-reduced once per cost evaluation.
+"""Multi-GPU registration: one process per GPU, clouds sharded by spatial tile (= a range of the Morton order), the
+32-double normal-equation block {err, b(6), H(21), ...} summed over the ranks once per cost evaluation.
 
-The reference has no multi-GPU path ("Collectives: none"); this follows BASELINE.json's
-north_star.  Every correspondence contributes independently to (err, H, b), so the only coupling
-between shards is the sum:
+The reference has no multi-GPU path ("Collectives: none"); this follows BASELINE.json's north_star.
+Every correspondence contributes independently to (err, H, b), so the only coupling between shards is the sum.
 
-  * partition : contiguous ranges of the Morton order of the SOURCE cloud = spatial tiles
-                (`spatial_tile_partition`); the target Gaussian voxel map is replicated on every GPU
-                (64 B per bucket -- a 1M-point map is ~100 MB of a 288 GB HBM), so no halo exchange
-                is needed for DIRECT7/27 lookups;
-  * exchange  : one all-reduce (sum) of 32 doubles per linearize() / compute_error(); 256 B, pure
-                latency.  On GPUs it runs inside libfast_vgicp_hip.so as ncclAllReduce on the handle's
-                own stream (RCCL over xGMI, no host sync), and the LM step is then computed redundantly
-                on every rank from bit-identical sums, so no broadcast is needed;
-  * the host-driven variant below (`ShardedLsq`) does the same through a caller-supplied all-reduce
-    (torch.distributed gloo on CPU in the tests, NCCL/RCCL tensors on GPUs) and is what the
-    world_size=2 CPU tests exercise.
+Three ways to run it (ShardedVGICP(collective=...)):
+
+  "peer" (default on GPUs)  the engine shards INTERNALLY (include/fast_vgicp_hip.h, fvh_vgicp_peer_*): every rank makes the
+            same calls on the same full clouds; k-NN / covariance estimation run on the rank's tile and are all-gathered
+            through peer-mapped staging areas; the cost evaluation walks the rank's tile and the sums meet in peer-mapped
+            mailboxes INSIDE the cost kernel (one xGMI hop, 1.4 us measured) -- a sharded align stays ONE persistent
+            launch per rank, no RCCL, no numpy round trip.  This module only carries the 64-byte IPC handles between
+            the ranks (torch.distributed all_gather_object) -- see attach_peers().
+  "rccl"    round 1's path: the rank uploads its tile of the source; ncclAllReduce(32 x f64) on the engine stream between
+            the launches of the multi-launch LM route.
+  "host"    the host-driven `ShardedLsq` below through a caller-supplied all-reduce (torch.distributed gloo on CPU in the
+            tests): what the world_size = 2 CPU tests exercise.
+
+The target Gaussian voxel map is replicated on every GPU (64 B per bucket + 16 B of keys -- a 1M-point map is ~130 MB of
+288 GB), so DIRECT7/27 lookups need no halo exchange.
 """
 import numpy as np
 
@@ -132,36 +135,66 @@ class ShardedLsq:
 
 
 class ShardedVGICP:
-    """VGICP with the source cloud sharded over the ranks of a torch.distributed process group (one GPU each).
+    """VGICP over the ranks of a torch.distributed process group (one GPU each); see the module docstring for the three
+    collectives. `device_collective` (bool) is round 1's spelling: True = "rccl", False = "host"."""
 
-    Every rank: replicated target (covariances + voxel map), its own spatial tile of the source.  With
-    `device_collective=True` (GPUs) the all-reduce runs inside the engine as RCCL on the handle's stream and the
-    whole LM loop stays on the device (fvh_vgicp_align); otherwise the host-driven `ShardedLsq` is used with
-    `torch.distributed.all_reduce`."""
-
-    def __init__(self, core, rank, world_size, dist=None, device_collective=True):
+    def __init__(self, core, rank, world_size, dist=None, device_collective=None, collective=None):
         self.core, self.rank, self.world_size, self.dist = core, rank, world_size, dist
-        self.device_collective = device_collective and world_size >= 1
+        if collective is None:
+            collective = "rccl" if (device_collective is None or device_collective) else "host"
+        assert collective in ("peer", "rccl", "host")
+        self.collective = collective
+        self.device_collective = collective != "host"
         self._comm_ready = False
 
     def init_device_collective(self, unique_id_bytes):
-        """unique_id_bytes: the 128-byte RCCL id created on rank 0 (capi.comm_unique_id()) and broadcast to all ranks."""
+        """collective "rccl": the 128-byte RCCL id created on rank 0 (capi.comm_unique_id()) and broadcast to all ranks."""
+        assert self.collective == "rccl"
         self.core.comm_init(unique_id_bytes, self.world_size, self.rank)
         self._comm_ready = True
 
+    def attach_peers(self, max_points, device_index=0):
+        """collective "peer": export this rank's exchange region, swap the IPC handles with all ranks, map theirs.
+        `device_index`: the GPU this rank runs on (ranks sharing a GPU share its co-resident workgroup slots)."""
+        import os
+        assert self.collective == "peer"
+        handle, ptr = self.core.peer_export(int(max_points))
+        mine = (handle, ptr, os.getpid(), int(device_index))
+        if self.world_size > 1:
+            if self.dist is None:
+                raise RuntimeError("attach_peers needs a torch.distributed process group to carry the IPC handles")
+            allv = [None] * self.world_size
+            self.dist.all_gather_object(allv, mine)
+        else:
+            allv = [mine]
+        same_dev = sum(1 for v in allv if v[3] == int(device_index))
+        local = [v[1] if (v[2] == os.getpid()) else 0 for v in allv]
+        self.core.peer_attach(self.world_size, self.rank, same_dev, [v[0] for v in allv], local)
+        if self.dist is not None and self.world_size > 1:
+            self.dist.barrier()  # every rank has mapped every region before anybody writes into one
+        self._comm_ready = True
+
     def collective_description(self):
-        return "ncclAllReduce(32 x f64) on the engine stream, once per cost evaluation" if self.device_collective else "host all-reduce (torch.distributed) of 43 doubles per evaluation"
+        return {"peer": "peer-mapped mailboxes inside the persistent LM kernel (32 x f64 + tag per rank and evaluation, rank-order sum); covariances all-gathered through peer-mapped staging",
+                "rccl": "ncclAllReduce(32 x f64) on the engine stream, once per cost evaluation",
+                "host": "host all-reduce (torch.distributed) of 43 doubles per evaluation"}[self.collective]
 
     def set_target(self, xyz, k=20, regularization=3):
         self.core.set_target_cloud(xyz)
-        self.core.find_target_neighbors(k)
+        self.core.find_target_neighbors(k)          # collective "peer": this rank's tile, then the all-gather inside calculate_*
         self.core.calculate_target_covariances(regularization)
         self.core.create_target_voxelmap()
 
     def set_source(self, full_xyz, k=20, regularization=3):
-        """Covariances need neighbours across tile borders, so they are computed on the full cloud (cheap: culled
-        k-NN) and the rank then keeps only its tile for the cost evaluations."""
         full_xyz = np.ascontiguousarray(full_xyz, np.float32)
+        if self.collective == "peer":  # the engine shards internally: same calls on every rank, no host round trip
+            self.core.set_source_cloud(full_xyz)
+            self.core.find_source_neighbors(k)
+            self.core.calculate_source_covariances(regularization)
+            self.tile = None
+            return
+        # "rccl" / "host": covariances need neighbours across tile borders, so they are computed on the full cloud and the
+        # rank then keeps only its tile for the cost evaluations
         tile = spatial_tile_partition(full_xyz, self.world_size)[self.rank]
         self.core.set_source_cloud(full_xyz)
         self.core.find_source_neighbors(k)
@@ -174,7 +207,7 @@ class ShardedVGICP:
     def align(self, guess=None, **lm):
         if self.device_collective:
             if not self._comm_ready:
-                raise RuntimeError("call init_device_collective() first")
+                raise RuntimeError("call attach_peers() / init_device_collective() first")
             return self.core.align(guess, **lm)
         import torch
 

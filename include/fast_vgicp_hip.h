@@ -172,6 +172,28 @@ int fvh_comm_unique_id(void* id128 /* 128 bytes out */);
 int fvh_vgicp_comm_init(fvh_vgicp* h, const void* id128, int nranks, int rank);
 int fvh_vgicp_comm_destroy(fvh_vgicp* h);
 
+/* new: multi-GPU without RCCL -- peer-mapped exchange regions (one process per GPU on one node; also handles of one process).
+ * north_star: "large scans shard by spatial tile across up to 8 GPUs ... all-reduce of the 6x6/6x1 normal equations per
+ * iteration".  With peers attached, every rank makes the SAME sequence of calls on the SAME full clouds and the engine shards
+ * internally by spatial tile (= a range of the cloud's Morton order):
+ *   find_*_neighbors / calculate_*_covariances[_rbf]: each rank computes its tile (the whole sorted cloud is the candidate set:
+ *     an exact, implicit halo), then the tiles are all-gathered through the peers' staging areas -> every rank holds exactly
+ *     the covariances one GPU would have computed (voxel map: built from them on every rank, replicated);
+ *   update_correspondences / compute_error / align: each rank walks its tile of the source; the 32-double block {err, b, H} is
+ *     exchanged through the peers' mailboxes INSIDE the cost kernel (every rank writes its block into every peer's mailbox over
+ *     xGMI and sums in rank order -> bit-identical sums, the LM step runs redundantly, no broadcast): a sharded align is still
+ *     ONE persistent launch per rank.  Measured mailbox round trip (two processes, one MI355X): 1.4 us.
+ * peer_export: allocates the region (fine-grained device memory; staging for clouds of up to max_points) and returns its
+ *   hipIpcMemHandle_t as 64 opaque bytes (+ the raw device pointer for peers living in the same process).
+ * peer_attach: handles of all ranks in rank order (the own entry is ignored); process_local_ptrs[p] != 0 marks a peer of THIS
+ *   process (its pointer is used directly, IPC cannot map one's own allocation); ranks_on_this_device: how many of the ranks
+ *   share this GPU (their persistent grids share its co-resident workgroup slots).
+ * A rank that does not arrive within the watchdog (2 s, FVH_PEER_WATCHDOG_TICKS) fails the call with FVH_ERR_COMM on every rank. */
+int fvh_vgicp_peer_export(fvh_vgicp* h, int max_points, void* ipc_handle64 /* out */, unsigned long long* process_local_ptr /* out, may be NULL */);
+int fvh_vgicp_peer_attach(fvh_vgicp* h, int nranks, int rank, int ranks_on_this_device, const void* ipc_handles /* nranks x 64 B, may be NULL if all peers are local */,
+                          const unsigned long long* process_local_ptrs /* nranks entries or NULL */);
+int fvh_vgicp_peer_detach(fvh_vgicp* h);
+
 /* ---------------------------------------------------------------------------------------------
  * NDTCudaCore
  * ------------------------------------------------------------------------------------------- */
