@@ -451,7 +451,8 @@ int peer_allgather_cov(Engine* e, CloudDev& c) {
   peer_signal_kernel<<<1, 64, 0, e->stream>>>(pv, gen);
   HIP_OR_FAIL(e, pc.err.ensure(64));
   HIP_OR_FAIL(e, hipMemsetAsync(pc.err.p, 0, 4, e->stream));
-  peer_gather_cov_kernel<<<(c.n + 255) / 256, 256, 0, e->stream>>>(pv, gen, off, c.cov.as<float4>(), c.order.as<int>(), c.n, t.chunk, PEER_WATCHDOG_TICKS, pc.err.as<int>());
+  peer_wait_kernel<<<1, 64, 0, e->stream>>>(pv, gen, PEER_WATCHDOG_TICKS, pc.err.as<int>());
+  peer_gather_cov_kernel<<<(c.n + 255) / 256, 256, 0, e->stream>>>(pv, off, c.cov.as<float4>(), c.order.as<int>(), c.n, t.chunk, pc.err.as<int>());
   HIP_OR_FAIL(e, hipGetLastError());
   int* h_err = reinterpret_cast<int*>(e->pinned);
   HIP_OR_FAIL(e, hipMemcpyAsync(h_err, pc.err.p, 4, hipMemcpyDeviceToHost, e->stream));
@@ -771,6 +772,9 @@ int launch_cost(Engine* e, const CostSource& src, const VoxelMapDev& vm, int hos
   }
   if (persistent) {
     { const char* v = getenv("FVH_PERSIST_WATCHDOG_TICKS"); P.watchdog_ticks = v ? strtoull(v, nullptr, 10) : PERSIST_WATCHDOG_TICKS; }  // test hook: 0 forces the abort + fallback path
+    // multi-GPU: the opener may legitimately wait for a late peer (up to the peer watchdog); the workgroups waiting for the
+    // opener's broadcast must outlast that, or a 50 ms skew between ranks would look like a stuck local barrier
+    if (P.peer.n > 1 && P.watchdog_ticks) P.watchdog_ticks = std::max(P.watchdog_ticks, 2 * P.peer_watchdog_ticks);
     static const int zc = [] { const char* v = getenv("FVH_ZEROCOPY_RESULT"); return v ? atoi(v) : 1; }();
     P.result_host = (zc && !e->prof.on) ? e->result_dev : nullptr;  // (event profiling needs the stream drained anyway)
     e->zero_copy_armed = P.result_host != nullptr;

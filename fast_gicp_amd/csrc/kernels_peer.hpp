@@ -79,22 +79,23 @@ __global__ void peer_signal_kernel(PeerView pv, unsigned long long gen) {
   if ((int)threadIdx.x < pv.n)
     __hip_atomic_store(reinterpret_cast<unsigned long long*>(pv.region[threadIdx.x] + PEER_SIG_OFFSET) + pv.rank, gen, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
-// every point outside this rank's tile: cov[order[j]] <- the owner's staging (read over xGMI / the local fabric)
-__global__ __launch_bounds__(256) void peer_gather_cov_kernel(PeerView pv, unsigned long long gen, size_t stage_offset, float4* __restrict__ cov, const int* __restrict__ order, int n,
-                                                              int chunk, unsigned long long watchdog, int* __restrict__ err) {
-  __shared__ int s_ok;
-  if (threadIdx.x == 0) s_ok = 1;
-  __syncthreads();
-  if ((int)threadIdx.x < pv.n) {  // all owners must have published generation `gen`
+// ONE workgroup waits until every owner has published generation `gen` (a kernel of its own, in stream order before the
+// gather: if the thousands of gather workgroups polled themselves they would fill the GPU with spinning waves and starve the
+// kernels of a slower rank that shares it -- measured: 2 ranks on one GPU, 1M points, the late rank never got a CU)
+__global__ void peer_wait_kernel(PeerView pv, unsigned long long gen, unsigned long long watchdog, int* __restrict__ err) {
+  if ((int)threadIdx.x < pv.n) {
     const unsigned long long* sig = reinterpret_cast<const unsigned long long*>(pv.region[pv.rank] + PEER_SIG_OFFSET) + threadIdx.x;
     const unsigned long long t0 = wall_clock64();
     while (__hip_atomic_load(sig, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < gen) {
-      if (wall_clock64() - t0 > watchdog) { s_ok = 0; break; }
-      __builtin_amdgcn_s_sleep(2);
+      if (wall_clock64() - t0 > watchdog) { atomicAdd(err, 1); break; }
+      __builtin_amdgcn_s_sleep(8);
     }
   }
-  __syncthreads();
-  if (!s_ok) { if (threadIdx.x == 0) atomicAdd(err, 1); return; }
+}
+// every point outside this rank's tile: cov[order[j]] <- the owner's staging (read over xGMI / the local fabric)
+__global__ __launch_bounds__(256) void peer_gather_cov_kernel(PeerView pv, size_t stage_offset, float4* __restrict__ cov, const int* __restrict__ order, int n, int chunk,
+                                                              const int* __restrict__ err) {
+  if (*err) return;  // a peer never published: the host reports it
   const int j = blockIdx.x * 256 + threadIdx.x;
   if (j >= n) return;
   const int owner = j / chunk;
