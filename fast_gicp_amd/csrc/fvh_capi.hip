@@ -12,6 +12,7 @@
 #include <cstring>
 #include <functional>
 #include <map>
+#include <mutex>
 #include <string>
 #include <unordered_map>
 #include <vector>
@@ -136,7 +137,36 @@ struct Rccl {
 };
 Rccl g_rccl;
 std::atomic<int> g_live_engines{0};    // engine handles alive in this process that can launch gang kernels (registration handles)
-std::atomic<int> g_active_aligns{0};  // aligns in flight in this process (persistent kernels want the device to themselves)
+
+// Co-resident workgroup slots of a device, shared by the persistent LM launches of this process. A persistent grid must be
+// resident as a whole, so concurrent aligns (several handles driven by several host threads) SPLIT the slots instead of
+// one taking the device and the others falling back to one launch per LM transition: a launch is granted
+// min(what it wants, slots / recent concurrency, what is free). Other PROCESSES on the same GPU are invisible here: that
+// case is caught by the barrier watchdog and answered with a back-off (Engine::persist_backoff).
+struct SlotPool {
+  std::mutex mu;
+  int reserved[16] = {0}, active[16] = {0}, recent[16] = {0};
+  int acquire(int dev, int cap, int want) {  // -> granted workgroups (0: use the multi-launch route)
+    std::lock_guard<std::mutex> lk(mu);
+    dev &= 15;
+    active[dev]++;
+    recent[dev] = std::max(recent[dev], active[dev]);
+    static const int max_split = [] { const char* v = getenv("FVH_SLOT_MAX_SPLIT"); return v ? std::max(1, atoi(v)) : 4; }();
+    const int share = std::max(1, cap / std::max(1, std::min(recent[dev], max_split)));
+    const int grant = std::min(std::min(want, share), cap - reserved[dev]);
+    if (grant < std::min(want, 32)) return 0;  // too little left to be worth a gang launch
+    reserved[dev] += grant;
+    return grant;
+  }
+  void release(int dev, int grant) {
+    std::lock_guard<std::mutex> lk(mu);
+    dev &= 15;
+    reserved[dev] -= grant;
+    active[dev]--;
+    if (recent[dev] > active[dev] + 1) recent[dev]--;  // the estimate of the concurrency decays one align at a time
+  }
+};
+SlotPool g_slots;
 
 struct Engine {
   int device = 0;
@@ -166,6 +196,7 @@ struct Engine {
   int corr_sel = 0;        // which of the two correspondence buffers the host-mode calls use
   int last_steps = 0, prev_steps = 0;  // launches the last two aligns needed (odometry loops alternate directions)
   int persist_aborts = 0;               // persistent launches the watchdog turned into multi-launch retries
+  int persist_backoff = 0, persist_skip = 0;  // after an abort: aligns to run on the multi-launch route before the next persistent attempt (doubles per consecutive abort)
   Profiler prof;
   void* comm = nullptr;
   int nranks = 1, rank = 0;
@@ -695,37 +726,53 @@ constexpr unsigned long long PERSIST_WATCHDOG_TICKS = 5'000'000ull;  // 50 ms of
 constexpr long long PERSIST_MAX_ITEMS = 4'000'000;                   // beyond this a trip is no longer latency-bound: multi-launch path
 template <int MODE>
 int persistent_capacity(Engine* e) {
-  static int cap[2] = {-1, -1};
-  const int pi = e->precision == FVH_COMPUTE_FP32 ? 1 : 0;
-  if (cap[pi] < 0) {
+  static std::mutex mu;
+  static int cap[16][2];  // [device][precision]; 0 = not queried yet
+  std::lock_guard<std::mutex> lk(mu);
+  const int pi = e->precision == FVH_COMPUTE_FP32 ? 1 : 0, dev = e->device & 15;
+  if (cap[dev][pi] <= 0) {
     int per_cu = 0, cus = 0;
     hipError_t r = pi ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, cost_kernel<float, MODE, true>, 256, 0)
                       : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, cost_kernel<double, MODE, true>, 256, 0);
     if (r != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, e->device) != hipSuccess) return 0;
-    cap[pi] = per_cu * cus;
+    cap[dev][pi] = per_cu * cus;
   }
-  return cap[pi];
+  return cap[dev][pi];
+}
+
+// A work item is (source element, group of offsets). Small clouds: enough items to cover the chip (target_items). Large
+// clouds: still at most COST_CH..group_max offsets per item -- one thread walking all 27 offsets of its point left 24 %
+// of the resident threads without work at 100k points and made the launch 18 % slower than 4 offsets per item
+// (measured at 100k x DIRECT27: group 27: 423 us, 14: 426, 9: 361, 7: 386, 6: 368, 5: 423, 4: 358, 3: 355, 2: 459, 1: 615).
+struct CostShape { int group, groups_per_src; long long n_walk; int blocks; };
+inline CostShape cost_shape(const Engine* e, const CostSource& src) {
+  static const long long target_items = [] { const char* v = getenv("FVH_COST_TARGET_ITEMS"); return v ? atoll(v) : 256LL * 256 * 2; }();
+  static const int max_blocks = [] { const char* v = getenv("FVH_COST_MAX_BLOCKS"); int b = v ? atoi(v) : MAX_COST_BLOCKS; return b < 1 ? 1 : (b > MAX_COST_BLOCKS ? MAX_COST_BLOCKS : b); }();
+  static const int group_max = [] { const char* v = getenv("FVH_COST_GROUP_MAX"); return v ? std::max(1, atoi(v)) : COST_CH; }();
+  const int n_off = src.n_off_override > 0 ? src.n_off_override : e->n_off;
+  CostShape s;
+  const int groups = (int)std::min<long long>(n_off, std::max<long long>((n_off + group_max - 1) / group_max, target_items / std::max(src.n_upper, 1)));
+  s.group = (n_off + groups - 1) / groups;
+  s.groups_per_src = (n_off + s.group - 1) / s.group;
+  s.n_walk = src.n_upper;
+  if (e->peer.attached() && src.shardable) { const Tile t = peer_tile(e, src.n_upper); s.n_walk = std::max(t.hi - t.lo, 0); }  // multi-GPU: this rank's tile
+  s.blocks = (int)std::max<long long>(1, std::min<long long>(max_blocks, (s.n_walk * s.groups_per_src + 255) / 256));
+  return s;
 }
 
 template <int MODE>
 int launch_cost(Engine* e, const CostSource& src, const VoxelMapDev& vm, int host_phase, const PoseD* lin, const PoseD* ev, const fvh_lm_params* init = nullptr,
-                bool persistent = false, unsigned long long peer_xbase = 0 /* multi-GPU: exchange counter of this launch's first sums exchange */) {
+                bool persistent = false, unsigned long long peer_xbase = 0 /* multi-GPU: exchange counter of this launch's first sums exchange */,
+                int grid_limit = 0 /* > 0: at most this many workgroups (the slots granted to a persistent launch) */) {
   CostParams P;
   std::memset(&P, 0, sizeof(P));
   P.src_pts = src.pts; P.src_cov = src.cov; P.d_n_src = src.d_n; P.n_src = src.n_upper; P.order = src.order;
   P.table = vm.table.as<uint4>(); P.keys = vm.keys_cur(); P.mask = vm.capacity - 1; P.res = vm.res;
   const int n_off = src.n_off_override > 0 ? src.n_off_override : e->n_off;
   P.offsets = e->offsets_dev.as<int>(); P.n_off = n_off;
-  static const long long target_items = [] { const char* v = getenv("FVH_COST_TARGET_ITEMS"); return v ? atoll(v) : 256LL * 256 * 2; }();
-  static const int max_blocks = [] { const char* v = getenv("FVH_COST_MAX_BLOCKS"); int b = v ? atoi(v) : MAX_COST_BLOCKS; return b < 1 ? 1 : (b > MAX_COST_BLOCKS ? MAX_COST_BLOCKS : b); }();
-  // A work item is (source element, group of offsets). Small clouds: enough items to cover the chip (target_items). Large
-  // clouds: still at most COST_CH..group_max offsets per item -- one thread walking all 27 offsets of its point left 24 %
-  // of the resident threads without work at 100k points and made the launch 18 % slower than 4 offsets per item
-  // (measured at 100k x DIRECT27: group 27: 423 us, 14: 426, 9: 361, 7: 386, 6: 368, 5: 423, 4: 358, 3: 355, 2: 459, 1: 615).
-  static const int group_max = [] { const char* v = getenv("FVH_COST_GROUP_MAX"); return v ? std::max(1, atoi(v)) : COST_CH; }();
-  int groups = (int)std::min<long long>(n_off, std::max<long long>((n_off + group_max - 1) / group_max, target_items / std::max(src.n_upper, 1)));
-  P.group = (n_off + groups - 1) / groups;
-  P.groups_per_src = (n_off + P.group - 1) / P.group;
+  const CostShape shape = cost_shape(e, src);
+  P.group = shape.group;
+  P.groups_per_src = shape.groups_per_src;
   P.corr = e->corr.as<int>();
   P.corr_stride = (size_t)std::max(src.n_upper, 1) * n_off;
   P.host_corr_sel = e->corr_sel;
@@ -754,8 +801,8 @@ int launch_cost(Engine* e, const CostSource& src, const VoxelMapDev& vm, int hos
     static const unsigned long long wd = [] { const char* v = getenv("FVH_PEER_WATCHDOG_TICKS"); return v ? strtoull(v, nullptr, 10) : PEER_WATCHDOG_TICKS; }();
     P.peer_watchdog_ticks = wd;
   }
-  const long long items = n_walk * P.groups_per_src;
-  int blocks = (int)std::max<long long>(1, std::min<long long>(max_blocks, (items + 255) / 256));
+  int blocks = shape.blocks;
+  (void)n_walk;
   {
     // The persistent kernel needs every workgroup resident at once: its grid is clamped to what the device can hold (the
     // kernel is grid-stride). The per-transition launches take the SAME grid, so that both routes partition the items --
@@ -764,6 +811,7 @@ int launch_cost(Engine* e, const CostSource& src, const VoxelMapDev& vm, int hos
     if (cap <= 0) return e->fail(FVH_ERR_HIP, "cost kernel: occupancy query failed");
     if (e->peer.attached()) cap = std::max(1, cap / std::max(1, e->peer.ranks_on_device));  // ranks sharing one GPU share its co-resident slots
     blocks = std::min(blocks, cap);
+    if (grid_limit > 0) blocks = std::min(blocks, grid_limit);
   }
   // abort word = 0 (the last 8 bytes of the state; never covered by the state write-back)
   if (e->abort_word_dirty) {
@@ -882,22 +930,37 @@ int do_align(Engine* e, const CostSource& src, VoxelMapDev& vm, const double* gu
   long long launched = 0;
   int batch = e->last_steps > 0 ? std::max(e->last_steps, e->prev_steps) + 1 : 8;
   LmState* h = reinterpret_cast<LmState*>(e->pinned);
-  // One persistent launch for the whole LM loop when the problem is in the latency-bound regime, this handle is the only
-  // one aligning in the process right now (two persistent grids could starve each other of CU slots; the watchdog
-  // would catch it, but slowly) and there is no collective between evaluations.
+  // One persistent launch for the whole LM loop when the problem is in the latency-bound regime and there is no RCCL
+  // collective between evaluations. Concurrent aligns of this process (several handles, several host threads) split the
+  // device's co-resident workgroup slots (SlotPool); after a watchdog abort -- typically ANOTHER PROCESS on the same GPU, which
+  // the pool cannot see -- the handle backs off: it skips the persistent route for 1, 2, 4, ... 64 aligns before trying again,
+  // so a shared GPU costs one 50 ms stall now and then instead of one per registration.
   static const int persist_env = [] { const char* v = getenv("FVH_PERSISTENT"); return v ? atoi(v) : 1; }();
-  const int active_before = g_active_aligns.fetch_add(1);
-  struct Leave { ~Leave() { g_active_aligns.fetch_sub(1); } } leave;
   const bool sharded = MODE == MODE_VGICP && e->peer.attached() && src.shardable;
-  bool persistent = persist_env != 0 && !degenerate && !e->comm && !no_persist && active_before == 0 && budget < 4000 && (long long)src.n_upper * e->n_off <= PERSIST_MAX_ITEMS;
+  bool persistent = persist_env != 0 && !degenerate && !e->comm && !no_persist && budget < 4000 && (long long)src.n_upper * e->n_off <= PERSIST_MAX_ITEMS;
+  if (persistent && !sharded && e->persist_skip > 0) { e->persist_skip--; persistent = false; }  // backing off (a sharded align must take the same route on every rank)
+  int granted = 0;
+  struct Slots { int dev, grant; ~Slots() { if (grant > 0) g_slots.release(dev, grant); } } slots{e->device, 0};
   if (persistent) {
-    int rc = launch_cost<MODE>(e, src, vm, -1, &guess, nullptr, &p, true, e->peer.x);
+    int cap = persistent_capacity<MODE>(e);
+    if (e->peer.attached()) cap = std::max(1, cap / std::max(1, e->peer.ranks_on_device));
+    const int want = std::min(cost_shape(e, src).blocks, std::max(cap, 1));
+    granted = slots.grant = g_slots.acquire(e->device, std::max(cap, 1), want);
+    if (granted <= 0) {
+      if (sharded) granted = want;  // ranks must not diverge: take the slots anyway (the watchdog covers the rare collision)
+      else persistent = false;
+    }
+  }
+  if (persistent) {
+    int rc = launch_cost<MODE>(e, src, vm, -1, &guess, nullptr, &p, true, e->peer.x, granted);
     if (rc) return rc;
     bool have_result = false;
     if (e->result_dev && e->zero_copy_armed) {
       // spin on the sequence word the kernel writes after the state (mapped pinned memory); if the stream drains without it
       // (watchdog abort) fall through to the copy
       volatile unsigned long long* seq = reinterpret_cast<volatile unsigned long long*>(e->result_host) + sizeof(LmState) / 8;
+      static const bool block = [] { const char* v = getenv("FVH_HOST_WAIT"); return v && std::string(v) == "block"; }();  // FVH_HOST_WAIT=block: sleep in hipStreamSynchronize instead of spinning a core on the result word
+      if (block) (void)hipStreamSynchronize(e->stream);
       for (unsigned long long spins = 0;; spins++) {
         if (*seq == e->persist_seq) { have_result = true; break; }
         if ((spins & 0x3ff) == 0x3ff && hipStreamQuery(e->stream) != hipErrorNotReady) { have_result = (*seq == e->persist_seq); break; }  // drained (or failed: the copy below reports it)
@@ -916,12 +979,15 @@ int do_align(Engine* e, const CostSource& src, VoxelMapDev& vm, const double* gu
       e->persist_aborts++;
       e->pticket_dirty = true;
       e->abort_word_dirty = true;
+      e->persist_backoff = std::min(std::max(2 * e->persist_backoff, 1), 64);
+      e->persist_skip = e->persist_backoff;
       // multi-GPU: an abort on ANY rank reaches every rank within a watchdog period (its mailbox stays empty), so all ranks
       // arrive here and restart together; the exchange counter jumps past whatever this launch may have used
       if (sharded) e->peer.x = (e->peer.x + 8192) & ~1ull;
       return do_align<MODE>(e, src, vm, guess16, params, result, rebuild_safe, retried, true);
     }
     launched = 1;
+    e->persist_backoff = 0;  // a clean persistent run: the device is ours again
     if (sharded) e->peer.x += 1ull + (unsigned long long)h->num_error_evals;  // one exchange per trip
     {  // where the arrival counters stand now: every workgroup arrived once per trip, every group's last arriver bumped the top counter
       const unsigned trips = 1u + (unsigned)h->num_error_evals, B = (unsigned)e->last_persist_blocks;

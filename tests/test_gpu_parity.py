@@ -267,9 +267,11 @@ def test_persistent_and_multi_launch_paths_agree(O, pair, monkeypatch):
     r1 = c.align()
     assert c.debug_persist_aborts() == 1 and r1["num_launches"] > 1
     monkeypatch.delenv("FVH_PERSIST_WATCHDOG_TICKS")
-    r2 = c.align()
+    rb = c.align()  # back-off: the align right after an abort stays on the multi-launch route (another process may own the GPU)...
+    assert c.debug_persist_aborts() == 1 and rb["num_launches"] > 1
+    r2 = c.align()  # ... the next one tries the persistent kernel again
     assert c.debug_persist_aborts() == 1 and r2["num_launches"] == 1
-    for r in (r1, r2):
+    for r in (r1, rb, r2):
         assert r["converged"] and r["num_linearize"] == r0["num_linearize"] and r["num_error_evals"] == r0["num_error_evals"]
         assert np.array_equal(r["T"], r0["T"]) and np.array_equal(r["H"], r0["H"])
     c.close()
