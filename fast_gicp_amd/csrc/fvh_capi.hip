@@ -1204,14 +1204,83 @@ inline float host_ordered_to_float(unsigned u) {
   return f;
 }
 
+// pcl::ApproximateVoxelGrid: the fused six-launch chain of kernels_downsample.hpp (no memset, no key / index arrays; the count
+// comes back through mapped host memory instead of a copy kernel + stream synchronisation)
+int downsample_approx(Engine* e, DownsampleDev& d, const float* xyz, int n, int stride, bool on_device, float leaf, int* out_n) {
+  if (n < 0 || (n > 0 && !xyz)) return e->fail(FVH_ERR_INVALID_ARGUMENT, "voxelgrid: null points");
+  if (stride != 3 && stride != 4) return e->fail(FVH_ERR_INVALID_ARGUMENT, "voxelgrid: stride must be 3 or 4 floats");
+  if (n == 0) return FVH_OK;
+  const float* d_xyz = xyz;
+  if (!on_device) {
+    HIP_OR_FAIL(e, e->staging.ensure(sizeof(float) * stride * (size_t)n));
+    HIP_OR_FAIL(e, hipMemcpyAsync(e->staging.p, xyz, sizeof(float) * stride * (size_t)n, hipMemcpyHostToDevice, e->stream));
+    d_xyz = e->staging.as<float>();
+  }
+  const int nwaves = (n + AVG_ITEMS - 1) / AVG_ITEMS, nwords = (n + 31) / 32, nblocks = (nwords + 31) / 32;
+  HIP_OR_FAIL(e, d.keys.ensure(sizeof(unsigned) * ((size_t)AVG_SLOTS * nwaves + AVG_SLOTS)));  // slot x wave histogram + slot totals
+  HIP_OR_FAIL(e, d.idx.ensure(sizeof(float4) * (size_t)n));                                     // the points in slot order
+  HIP_OR_FAIL(e, d.head.ensure((size_t)n));                                                     // run heads (bytes)
+  HIP_OR_FAIL(e, d.trig.ensure(sizeof(unsigned) * (size_t)nwords));                             // trigger bits by original index
+  HIP_OR_FAIL(e, d.scan.ensure(sizeof(unsigned) * (size_t)(nblocks + 1)));                      // trigger prefix per 1024 indices
+  HIP_OR_FAIL(e, d.out.ensure(sizeof(float) * 3 * (size_t)n));
+  const bool fresh = d.slots.p == nullptr;
+  HIP_OR_FAIL(e, d.slots.ensure(sizeof(AvgState)));
+  if (fresh) HIP_OR_FAIL(e, hipMemsetAsync(d.slots.p, 0, sizeof(AvgState), e->stream));  // (the ticket re-arms itself afterwards)
+  unsigned* hist = d.keys.as<unsigned>();
+  unsigned* totals = hist + (size_t)AVG_SLOTS * nwaves;
+  float4* sorted = d.idx.as<float4>();
+  unsigned char* head = d.head.as<unsigned char>();
+  AvgState* st = d.slots.as<AvgState>();
+  const float inv = 1.0f / leaf;
+  const unsigned long long seq = ++e->persist_seq;
+  volatile unsigned long long* hres = reinterpret_cast<volatile unsigned long long*>(e->result_host);
+  {
+    ProfScope ps(e, "downsample");
+    const int wblocks = (nwaves + 3) / 4, pblocks = (n + 255) / 256;
+    avg_keys_hist_kernel<<<wblocks, 256, 0, e->stream>>>(d_xyz, n, stride, inv, nwaves, hist, d.trig.as<unsigned>(), nwords, st);
+    avg_binscan_kernel<<<AVG_SLOTS / 4, 256, 0, e->stream>>>(hist, nwaves, totals, st);
+    avg_scatter_kernel<<<wblocks, 256, 0, e->stream>>>(d_xyz, n, stride, inv, nwaves, hist, st, sorted);
+    avg_mark_kernel<<<pblocks, 256, 0, e->stream>>>(sorted, n, inv, head, d.trig.as<unsigned>(), st);
+    avg_scan_kernel<<<1, 1024, 0, e->stream>>>(d.trig.as<unsigned>(), nwords, d.scan.as<unsigned>(), st);
+    avg_emit_kernel<<<pblocks, 256, 0, e->stream>>>(sorted, head, n, inv, d.trig.as<unsigned>(), d.scan.as<unsigned>(), st, d.out.as<float>(), e->prof.on ? nullptr : e->result_dev, seq);
+  }
+  HIP_OR_FAIL(e, hipGetLastError());
+  unsigned long long count = 0, bad = 0;
+  bool have = false;
+  if (e->result_dev && !e->prof.on) {  // spin on the sequence word the scan kernel writes after the count (mapped pinned memory)
+    for (unsigned long long spins = 0;; spins++) {
+      if (hres[2] == seq) { have = true; break; }
+      if ((spins & 0x3ff) == 0x3ff && hipStreamQuery(e->stream) != hipErrorNotReady) { have = (hres[2] == seq); break; }
+    }
+    if (have) { std::atomic_thread_fence(std::memory_order_acquire); count = hres[0]; bad = hres[1]; }
+  }
+  if (!have) {
+    unsigned h[2] = {0, 0};
+    HIP_OR_FAIL(e, hipMemcpyAsync(h, &st->trig_total, 2 * sizeof(unsigned), hipMemcpyDeviceToHost, e->stream));  // trig_total, used_slots are adjacent
+    unsigned hb = 0;
+    HIP_OR_FAIL(e, hipMemcpyAsync(&hb, &st->bad, sizeof(unsigned), hipMemcpyDeviceToHost, e->stream));
+    HIP_OR_FAIL(e, hipStreamSynchronize(e->stream));
+    count = (unsigned long long)h[0] + h[1];
+    bad = hb;
+  } else if (!on_device) {
+    HIP_OR_FAIL(e, hipStreamSynchronize(e->stream));  // the caller may free its host buffer on return; (the staging copy is long done, this only drains the emit kernel)
+  }
+  if (bad) { d.out_n = 0; return e->fail(FVH_ERR_INVALID_ARGUMENT, "voxelgrid: non-finite coordinates in the input"); }
+  d.out_n = (int)count;
+  *out_n = d.out_n;
+  return FVH_OK;
+}
+
 int downsample(Engine* e, DownsampleDev& d, int method, const float* xyz, int n, int stride, bool on_device, float leaf, int* out_n) {
   if (!out_n) return e->fail(FVH_ERR_INVALID_ARGUMENT, "voxelgrid: null out_n");
   if (method != FVH_VOXELGRID_EXACT && method != FVH_VOXELGRID_APPROXIMATE) return e->fail(FVH_ERR_INVALID_ARGUMENT, "voxelgrid: unknown method");
   if (!(leaf > 0.f)) return e->fail(FVH_ERR_INVALID_ARGUMENT, "voxelgrid: leaf size must be > 0");
-  int rc = upload_cloud(e, d.cloud, xyz, n, stride, on_device, false);
-  if (rc) return rc;
+  int rc = FVH_OK;
   d.out_n = 0;
   *out_n = 0;
+  if (method == FVH_VOXELGRID_APPROXIMATE) return downsample_approx(e, d, xyz, n, stride, on_device, leaf, out_n);
+  rc = upload_cloud(e, d.cloud, xyz, n, stride, on_device, false);
+  if (rc) return rc;
   if (n == 0) return FVH_OK;
   ProfScope ps(e, "downsample");
   const float inv = 1.0f / leaf;

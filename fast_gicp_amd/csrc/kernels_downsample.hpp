@@ -164,4 +164,262 @@ __global__ __launch_bounds__(256) void vg_emit_kernel(const unsigned* __restrict
   out[3 * (size_t)pos + 2] = cz / cnt;
 }
 
+// =====================================================================================================================
+// pcl::ApproximateVoxelGrid, fused chain (round 2): SIX launches, no memset, no key / index arrays, the count goes to the
+// host through mapped memory. Round 1 ran the same decomposition as 9 kernels + 2 memsets + a D2H copy (87 us per 118k-point
+// frame, a third of the LiDAR-stream step):
+//   avg_keys_hist    slot of every point (straight from the caller's xyz, any stride) + per-wave slot histograms; clears the
+//                    small state of the later kernels
+//   avg_binscan      per-slot prefix over the waves; the last workgroup also scans the 512 slot totals
+//   avg_scatter      stable counting sort by slot: writes the POINTS in slot order (.w = original index) -- nothing else
+//   avg_mark         run heads inside a slot (voxel of a point != voxel of its predecessor); a head that is not a slot start is
+//                    the point whose arrival flushes the previous run: one bit in `trigbits` at its ORIGINAL index
+//   avg_scan         one workgroup: prefix of the trigger bits per 1024 indices, rank of the used slots, the output count
+//   avg_emit         one thread per run: centroid (fp32 sums in input order, as PCL), output position = rank of the flushing
+//                    point among all triggers (block prefix + popcounts), or behind them in slot order for the final flushes
+// Output points and order are bit-identical to the oracle's restatement of the PCL filter (tests/test_gpu_downsample.py).
+// =====================================================================================================================
+constexpr int AVG_ITEMS = 256;  // points per wave in the counting sort
+
+struct AvgState {            // small device state, cleared by avg_keys_hist for the NEXT stages of the same call
+  unsigned slot_used[AVG_SLOTS];
+  unsigned slot_rank[AVG_SLOTS + 1];
+  unsigned bin_base[AVG_SLOTS];
+  unsigned ticket, bad, trig_total, used_slots, emit_ticket;
+};
+
+__device__ __forceinline__ unsigned avg_slot(int ix, int iy, int iz) { return ((unsigned)ix * 7171u + (unsigned)iy * 3079u + (unsigned)iz * 4231u) & (AVG_SLOTS - 1); }
+__device__ __forceinline__ float4 load_xyz(const float* __restrict__ xyz, int i, int stride) {
+  const float* q = xyz + (size_t)i * stride;
+  return make_float4(q[0], q[1], q[2], 0.f);
+}
+
+__global__ __launch_bounds__(256) void avg_keys_hist_kernel(const float* __restrict__ xyz, int n, int stride, float inv, int nwaves, unsigned* __restrict__ hist /* [slots][nwaves] */,
+                                                            unsigned* __restrict__ trigbits, int nwords, AvgState* __restrict__ st) {
+  __shared__ unsigned h[4][AVG_SLOTS];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int wave = blockIdx.x * 4 + wv;
+  for (int w = blockIdx.x * 256 + threadIdx.x; w < nwords; w += gridDim.x * 256) trigbits[w] = 0u;
+  if (blockIdx.x == 0) {
+    for (int s = threadIdx.x; s < AVG_SLOTS; s += 256) st->slot_used[s] = 0u;
+    if (threadIdx.x == 0) { st->bad = 0u; }
+  }
+  for (int b = lane; b < AVG_SLOTS; b += 64) h[wv][b] = 0;
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  if (wave >= nwaves) return;
+  const int begin = wave * AVG_ITEMS, end = min(n, begin + AVG_ITEMS);
+  bool bad = false;
+  for (int i = begin + lane; i < end; i += 64) {
+    const float4 p = load_xyz(xyz, i, stride);
+    bad |= !finite3(p);
+    int ix, iy, iz;
+    avg_voxel(p, inv, ix, iy, iz);
+    atomicAdd(&h[wv][avg_slot(ix, iy, iz)], 1u);
+  }
+  if (__any(bad) && lane == 0) atomicOr(&st->bad, 1u);
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  for (int b = lane; b < AVG_SLOTS; b += 64) hist[(size_t)b * nwaves + wave] = h[wv][b];
+}
+
+// one wave per slot: exclusive prefix over the waves (radix_binscan_kernel), slot total; the LAST workgroup scans the totals
+__global__ __launch_bounds__(256) void avg_binscan_kernel(unsigned* __restrict__ hist, int nwaves, unsigned* __restrict__ totals /* [slots] scratch */, AvgState* __restrict__ st) {
+  __shared__ int s_last;
+  __shared__ unsigned s_tot[AVG_SLOTS];
+  const int lane = threadIdx.x & 63;
+  const int bin = blockIdx.x * 4 + (threadIdx.x >> 6);
+  {
+    unsigned* row = hist + (size_t)bin * nwaves;
+    unsigned run = 0;
+    for (int base = 0; base < nwaves; base += 64) {
+      const int w = base + lane;
+      const unsigned v = (w < nwaves) ? row[w] : 0u;
+      unsigned x = v;
+#pragma unroll
+      for (int off = 1; off < 64; off <<= 1) { const unsigned y = __shfl_up(x, off); if (lane >= off) x += y; }
+      if (w < nwaves) row[w] = run + x - v;
+      run += __shfl(x, 63);
+    }
+    if (lane == 0) __hip_atomic_store(&totals[bin], run, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  __threadfence();
+  __syncthreads();
+  if (threadIdx.x == 0) s_last = (atomicAdd(&st->ticket, 1u) == gridDim.x - 1);
+  __syncthreads();
+  if (!s_last) return;
+  for (int b = threadIdx.x; b < AVG_SLOTS; b += 256) s_tot[b] = __hip_atomic_load(&totals[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __syncthreads();
+  if (threadIdx.x < 64) {  // 512 totals: 8 per lane
+    unsigned v[8], sum = 0;
+#pragma unroll
+    for (int u = 0; u < 8; u++) { v[u] = s_tot[threadIdx.x * 8 + u]; sum += v[u]; }
+    unsigned x = sum;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) { const unsigned y = __shfl_up(x, off); if (lane >= off) x += y; }
+    unsigned run = x - sum;
+#pragma unroll
+    for (int u = 0; u < 8; u++) { st->bin_base[threadIdx.x * 8 + u] = run; run += v[u]; }
+    if (threadIdx.x == 0) st->ticket = 0u;  // re-armed for the next call
+  }
+}
+
+// stable scatter by slot: the points themselves, in slot order, original index in .w
+__global__ __launch_bounds__(256) void avg_scatter_kernel(const float* __restrict__ xyz, int n, int stride, float inv, int nwaves, const unsigned* __restrict__ offsets,
+                                                          const AvgState* __restrict__ st, float4* __restrict__ sorted_pts) {
+  __shared__ unsigned cur[4][AVG_SLOTS];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int wave = blockIdx.x * 4 + wv;
+  if (wave >= nwaves) return;
+  for (int b = lane; b < AVG_SLOTS; b += 64) cur[wv][b] = offsets[(size_t)b * nwaves + wave] + st->bin_base[b];
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  const int begin = wave * AVG_ITEMS, end = min(n, begin + AVG_ITEMS);
+  const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+  for (int base = begin; base < end; base += 64) {
+    const int i = base + lane;
+    const bool valid = i < end;
+    float4 p = valid ? load_xyz(xyz, i, stride) : make_float4(0, 0, 0, 0);
+    int ix, iy, iz;
+    avg_voxel(p, inv, ix, iy, iz);
+    const unsigned d = avg_slot(ix, iy, iz);
+    unsigned long long peers = __ballot(valid);
+#pragma unroll
+    for (int bit = 0; bit < 9; bit++) {
+      const unsigned long long m = __ballot((d >> bit) & 1);
+      peers &= ((d >> bit) & 1) ? m : ~m;
+    }
+    const int rank = __popcll(peers & lt_mask);
+    const int cnt = __popcll(peers);
+    const int leader = __ffsll((long long)peers) - 1;
+    unsigned dst_base = 0;
+    if (valid && lane == leader) { dst_base = cur[wv][d]; cur[wv][d] = dst_base + cnt; }
+    dst_base = __shfl(dst_base, leader);
+    if (valid) {
+      p.w = __int_as_float(i);
+      sorted_pts[dst_base + rank] = p;
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void avg_mark_kernel(const float4* __restrict__ sorted_pts, int n, float inv, unsigned char* __restrict__ head, unsigned* __restrict__ trigbits,
+                                                       AvgState* __restrict__ st) {
+  const int j = blockIdx.x * 256 + threadIdx.x;
+  if (j >= n) return;
+  const float4 p = sorted_pts[j];
+  int ax, ay, az;
+  avg_voxel(p, inv, ax, ay, az);
+  const unsigned slot = avg_slot(ax, ay, az);
+  bool slot_start = (j == 0), h = true;
+  if (j > 0) {
+    int bx, by, bz;
+    avg_voxel(sorted_pts[j - 1], inv, bx, by, bz);
+    slot_start = avg_slot(bx, by, bz) != slot;
+    h = slot_start || (ax != bx) || (ay != by) || (az != bz);
+  }
+  if (slot_start) st->slot_used[slot] = 1u;
+  else if (h) { const int id = __float_as_int(p.w); atomicOr(&trigbits[id >> 5], 1u << (id & 31)); }
+  head[j] = h ? 1 : 0;
+}
+
+// ONE workgroup of 1024 threads: block_base[b] = triggers with original index < 1024 b; slot_rank = exclusive scan of slot_used;
+// the count of output points goes to the device state (avg_emit hands it to the host).
+__global__ __launch_bounds__(1024) void avg_scan_kernel(const unsigned* __restrict__ trigbits, int nwords, unsigned* __restrict__ block_base /* [nblocks + 1] */, AvgState* __restrict__ st) {
+  __shared__ unsigned wsum[16];
+  __shared__ unsigned carry;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int nblocks = (nwords + 31) / 32;
+  if (tid == 0) carry = 0;
+  __syncthreads();
+  for (int base = 0; base < nblocks; base += 1024) {  // exclusive scan of the per-block popcounts, 1024 blocks (= 1M indices) per round
+    const int b = base + tid;
+    unsigned c = 0;
+    if (b < nblocks) {
+      const int w0 = b * 32, w1 = min(nwords, w0 + 32);
+      for (int w = w0; w < w1; w++) c += __popc(trigbits[w]);
+    }
+    unsigned x = c;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) { const unsigned y = __shfl_up(x, off); if (lane >= off) x += y; }
+    if (lane == 63) wsum[wv] = x;
+    __syncthreads();
+    unsigned pre = carry;
+    for (int w = 0; w < wv; w++) pre += wsum[w];
+    if (b < nblocks) block_base[b] = pre + x - c;
+    __syncthreads();
+    if (tid == 1023) carry = pre + x;
+    __syncthreads();
+  }
+  if (tid == 0) block_base[nblocks] = carry;
+  // slot ranks (512 flags: first 8 waves, one flag per lane)
+  unsigned f = 0, x = 0;
+  if (tid < AVG_SLOTS) { f = st->slot_used[tid]; x = f; }
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) { const unsigned y = __shfl_up(x, off); if (lane >= off) x += y; }
+  __syncthreads();
+  if (lane == 63 && wv < 8) wsum[wv] = x;
+  __syncthreads();
+  if (tid < AVG_SLOTS) {
+    unsigned pre = 0;
+    for (int w = 0; w < wv; w++) pre += wsum[w];
+    st->slot_rank[tid] = pre + x - f;
+    if (tid == AVG_SLOTS - 1) {
+      const unsigned used = pre + x, trig = carry;
+      st->slot_rank[AVG_SLOTS] = used;
+      st->used_slots = used;
+      st->trig_total = trig;
+    }
+  }
+}
+
+__device__ __forceinline__ void avg_emit_points(const float4* __restrict__ sorted_pts, const unsigned char* __restrict__ head, int n, float inv, const unsigned* __restrict__ trigbits,
+                                                const unsigned* __restrict__ block_base, const AvgState* __restrict__ st, float* __restrict__ out) {
+  const int j = blockIdx.x * 256 + threadIdx.x;
+  if (j >= n || !head[j]) return;
+  float4 p = sorted_pts[j];
+  int ix, iy, iz;
+  avg_voxel(p, inv, ix, iy, iz);
+  const unsigned slot = avg_slot(ix, iy, iz);
+  float cx = 0.f, cy = 0.f, cz = 0.f;
+  int e = j;
+  for (;;) {
+    cx += p.x; cy += p.y; cz += p.z;
+    e++;
+    if (e >= n || head[e]) break;
+    p = sorted_pts[e];
+  }
+  const float cnt = (float)(e - j);
+  unsigned pos = st->trig_total + st->slot_rank[slot];  // last run of its slot: flushed at the end, in slot order
+  if (e < n) {
+    const float4 q = sorted_pts[e];
+    int qx, qy, qz;
+    avg_voxel(q, inv, qx, qy, qz);
+    if (avg_slot(qx, qy, qz) == slot) {  // flushed by the arrival of point q: its rank among all flush-triggering points (by original index)
+      const int id = __float_as_int(q.w);
+      const int w = id >> 5;
+      unsigned r = block_base[id >> 10] + __popc(trigbits[w] & ((1u << (id & 31)) - 1u));
+      for (int k = (id >> 10) * 32; k < w; k++) r += __popc(trigbits[k]);
+      pos = r;
+    }
+  }
+  out[3 * (size_t)pos] = cx / cnt;
+  out[3 * (size_t)pos + 1] = cy / cnt;
+  out[3 * (size_t)pos + 2] = cz / cnt;
+}
+
+// The LAST workgroup to finish writes {count, bad flag, sequence} to mapped host memory: when the host sees the sequence
+// word, every centroid is in `out` (no copy kernel, no stream synchronisation on the way to the next stage).
+__global__ __launch_bounds__(256) void avg_emit_kernel(const float4* __restrict__ sorted_pts, const unsigned char* __restrict__ head, int n, float inv, const unsigned* __restrict__ trigbits,
+                                                       const unsigned* __restrict__ block_base, AvgState* __restrict__ st, float* __restrict__ out,
+                                                       unsigned long long* __restrict__ host_result /* {count, bad, seq} mapped, or null */, unsigned long long seq) {
+  avg_emit_points(sorted_pts, head, n, inv, trigbits, block_base, st, out);
+  if (!host_result) return;
+  __threadfence();
+  __syncthreads();
+  if (threadIdx.x == 0 && atomicAdd(&st->emit_ticket, 1u) == gridDim.x - 1) {
+    st->emit_ticket = 0u;
+    __hip_atomic_store(&host_result[0], (unsigned long long)(st->trig_total + st->used_slots), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(&host_result[1], (unsigned long long)st->bad, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __threadfence_system();
+    __hip_atomic_store(&host_result[2], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+}
+
 }  // namespace fvh
