@@ -348,6 +348,13 @@ class VGICPCore(_Core):
         self.gicp_update_correspondences(T)
         return self.gicp_compute_error(T, True)
 
+    def gicp_align(self, guess=None, **lm):
+        g = _colmajor16(np.eye(4) if guess is None else guess)
+        p = _lm_params(**lm)
+        r = LmResult()
+        self._call("gicp_align", _p(g), C.byref(p), C.byref(r))
+        return _result_dict(r)
+
     def gicp_get_correspondences(self):
         out = np.empty(self.num_points("source"), np.int32)
         self._call("gicp_get_correspondences", _p(out))

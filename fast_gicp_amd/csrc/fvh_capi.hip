@@ -719,6 +719,7 @@ struct CostSource {
   const int* order;      // Morton permutation of the source (large clouds) or null
   int n_off_override = 0;  // > 0: correspondences per source element regardless of the handle's offset list (GICP: 1)
   bool shardable = false;  // the source elements are the points of a cloud with a Morton order: with peers attached each rank walks its tile
+  bool external_find = false;  // FastGICP device LM: nn1_corr_kernel fills the correspondence buffers between the cost launches
 };
 
 // Persistent LM kernel (kernels_cost.hpp, PERSIST): co-resident workgroup capacity of the device for this instantiation.
@@ -780,6 +781,7 @@ int launch_cost(Engine* e, const CostSource& src, const VoxelMapDev& vm, int hos
   P.vm_counters = vm.counters_cur();
   P.vm_counters2 = src.counters2;
   P.host_phase = host_phase;
+  P.external_find = src.external_find ? 1 : 0;
   P.defer_lm = (e->comm != nullptr) ? 1 : 0;
   if (lin) P.lin = *lin;
   if (ev) P.ev = *ev;
@@ -1113,21 +1115,92 @@ int profile_get(Engine* e, const char* cls, double* total_ms, int* launches) {
 // ---------------------------------------------------------------------------------------------
 // FastGICP on the device: nearest-target-point correspondences + the VGICP cost kernel on per-point records
 // ---------------------------------------------------------------------------------------------
-int gicp_update_correspondences(Engine* e, CloudDev& src, CloudDev& tgt, VoxelMapDev& records, const double* T16, double max_dist) {
-  if (!T16) return e->fail(FVH_ERR_INVALID_ARGUMENT, "gicp_update_correspondences: null pose");
-  if (!src.has_pts || !tgt.has_pts || src.n == 0 || tgt.n == 0) return e->fail(FVH_ERR_BAD_STATE, "gicp_update_correspondences: clouds not set");
-  if (!src.has_cov || !tgt.has_cov) return e->fail(FVH_ERR_BAD_STATE, "gicp_update_correspondences: covariances not set");
-  if (!(max_dist > 0)) return e->fail(FVH_ERR_INVALID_ARGUMENT, "gicp_update_correspondences: max correspondence distance must be > 0");
+// sorted clouds + per-target-point records in the voxel-bucket layout (1 MB at 17k points: rebuilt every time rather than tracked)
+int gicp_prepare(Engine* e, CloudDev& src, CloudDev& tgt, VoxelMapDev& records, double max_dist, const char* who) {
+  if (!src.has_pts || !tgt.has_pts || src.n == 0 || tgt.n == 0) return e->fail(FVH_ERR_BAD_STATE, std::string(who) + ": clouds not set");
+  if (!src.has_cov || !tgt.has_cov) return e->fail(FVH_ERR_BAD_STATE, std::string(who) + ": covariances not set");
+  if (!(max_dist > 0)) return e->fail(FVH_ERR_INVALID_ARGUMENT, std::string(who) + ": max correspondence distance must be > 0");
   int rc = ensure_sorted(e, src);
   if (!rc) rc = ensure_sorted(e, tgt);
   if (rc) return rc;
-  // per-target-point records in the voxel-bucket layout (1 MB at 17k points: rebuilt every time rather than tracked)
   HIP_OR_FAIL(e, records.table.ensure(sizeof(float4) * 4 * (size_t)tgt.n));
-  HIP_OR_FAIL(e, records.counters.ensure(4 * sizeof(int)));
-  HIP_OR_FAIL(e, hipMemsetAsync(records.counters.p, 0, 4 * sizeof(int), e->stream));
+  HIP_OR_FAIL(e, records.counters.ensure(2 * 16 * sizeof(int)));
+  HIP_OR_FAIL(e, hipMemsetAsync(records.counters.p, 0, 2 * 16 * sizeof(int), e->stream));
   gicp_records_kernel<<<(tgt.n + 255) / 256, 256, 0, e->stream>>>(tgt.pts.as<float4>(), tgt.cov.as<float4>(), tgt.n, records.table.as<float4>());
   records.capacity = 1; records.res = 1.0; records.valid = true;
   HIP_OR_FAIL(e, e->corr.ensure(2 * sizeof(int) * (size_t)src.n));
+  return FVH_OK;
+}
+
+// FastGICP::computeTransformation with the whole LM loop on the device (fast_gicp_impl.hpp:118-240 driven by
+// lsq_registration_impl.hpp:53-168). Per LM transition TWO launches and no host round trip: nn1_corr_kernel searches the
+// nearest target point of every source point at the pose the LM state on the device says comes next (x0 for a linearisation,
+// the trial pose for the fused trial + speculative linearisation) and the cost kernel consumes those ids (external_find).
+// Round 1 drove this from the host: two blocking round trips per iteration.
+int gicp_align(Engine* e, CloudDev& src, CloudDev& tgt, VoxelMapDev& records, const CostSource& cs, double max_dist, const double* guess16, const fvh_lm_params* params,
+               fvh_lm_result* result) {
+  if (!guess16 || !result) return e->fail(FVH_ERR_INVALID_ARGUMENT, "gicp_align: null argument");
+  int rc = gicp_prepare(e, src, tgt, records, max_dist, "gicp_align");
+  if (rc) return rc;
+  fvh_lm_params p;
+  if (params) p = *params; else fvh_default_lm_params(&p);
+  LmState* st = e->state.as<LmState>();
+  const PoseD guess = pose_from_colmajor16(guess16);
+  float T12[12];
+  for (int i = 0; i < 3; i++) { for (int j = 0; j < 3; j++) T12[i * 4 + j] = (float)guess16[j * 4 + i]; T12[i * 4 + 3] = (float)guess16[12 + i]; }
+  char* base = (char*)e->fit.p;
+  HIP_OR_FAIL(e, hipMemcpyAsync(base + 16, T12, sizeof(T12), hipMemcpyHostToDevice, e->stream));
+  const double thr = std::min(max_dist, 1.8446743e19);
+  const LmLink link{&st->phase, &st->corr_cur, st->x0.r, st->xi.r, (size_t)src.n};
+  const long long budget = (long long)std::max(p.max_iterations, 0) * (1 + (long long)std::max(p.lm_max_iterations, 0)) + 1;
+  LmState* h = reinterpret_cast<LmState*>(e->pinned);
+  if (p.max_iterations <= 0) {
+    lm_init_kernel<<<1, 64, 0, e->stream>>>(st, guess, p.rotation_epsilon, p.transformation_epsilon, p.lm_init_lambda_factor, p.max_iterations, p.lm_max_iterations, e->ticket.as<unsigned>());
+    HIP_OR_FAIL(e, hipGetLastError());
+  }
+  long long launched = 0;
+  int batch = e->last_steps > 0 ? std::max(e->last_steps, e->prev_steps) + 1 : 8;
+  for (;;) {
+    for (int s = 0; s < batch && p.max_iterations > 0; s++) {
+      const bool first = (launched == 0 && s == 0);
+      {
+        ProfScope ps(e, "gicp_nn");
+        nn1_corr_kernel<<<(src.n + 3) / 4, 256, 0, e->stream>>>(src.sorted.as<float4>(), src.n, tgt.sorted.as<float4>(), tgt.bbox.as<float4>(), tgt.bbox2.as<float4>(), tgt.n,
+                                                                reinterpret_cast<const float*>(base + 16), thr * thr, e->corr.as<int>(), nullptr,
+                                                                first ? LmLink{nullptr, nullptr, nullptr, nullptr, 0} : link);
+      }
+      rc = launch_cost<MODE_VGICP>(e, cs, records, -1, first ? &guess : nullptr, nullptr, first ? &p : nullptr);
+      if (rc) return rc;
+    }
+    launched += batch;
+    HIP_OR_FAIL(e, hipMemcpyAsync(h, st, sizeof(LmState), hipMemcpyDeviceToHost, e->stream));
+    HIP_OR_FAIL(e, hipStreamSynchronize(e->stream));
+    if (h->phase == PH_DONE || launched >= budget || p.max_iterations <= 0) break;
+    batch = 3;
+  }
+  e->prev_steps = e->last_steps;
+  e->last_steps = 1 + h->num_error_evals;
+  e->lin = h->x_lin;
+  e->corr_sel = h->corr_cur;
+  e->has_corr = true;
+  e->corr_kind = 1;
+  e->corr_n_src = src.n;
+  pose_to_colmajor16(h->x0, result->T);
+  for (int i = 0; i < 6; i++) for (int j = 0; j < 6; j++) result->H[j * 6 + i] = h->final_H[i * 6 + j];
+  result->final_error = h->y0;
+  result->converged = h->converged;
+  result->nr_iterations = h->nr_iterations;
+  result->num_linearize = h->num_linearize;
+  result->num_error_evals = h->num_error_evals;
+  result->lm_failed = h->lm_failed;
+  result->num_launches = (int)(2 * launched);
+  return FVH_OK;
+}
+
+int gicp_update_correspondences(Engine* e, CloudDev& src, CloudDev& tgt, VoxelMapDev& records, const double* T16, double max_dist) {
+  if (!T16) return e->fail(FVH_ERR_INVALID_ARGUMENT, "gicp_update_correspondences: null pose");
+  int rc = gicp_prepare(e, src, tgt, records, max_dist, "gicp_update_correspondences");
+  if (rc) return rc;
   float T12[12];
   for (int i = 0; i < 3; i++) { for (int j = 0; j < 3; j++) T12[i * 4 + j] = (float)T16[j * 4 + i]; T12[i * 4 + 3] = (float)T16[12 + i]; }  // trans.cast<float>()
   char* base = (char*)e->fit.p;
@@ -1375,7 +1448,12 @@ struct fvh_vgicp {
     c.shardable = true;
     return c;
   }
-  CostSource gicp_cost_source() const { CostSource c{source.pts.as<float4>(), source.cov.as<float4>(), nullptr, source.n, nullptr, nullptr}; c.n_off_override = 1; return c; }
+  CostSource gicp_cost_source(bool external_find = false) const {
+    CostSource c{source.pts.as<float4>(), source.cov.as<float4>(), nullptr, source.n, nullptr, nullptr};
+    c.n_off_override = 1;
+    c.external_find = external_find;
+    return c;
+  }
   int voxel_mode = 0;        // VoxelAccumulationMode ordinal: 0 ADDITIVE, 1 ADDITIVE_WEIGHTED (same voxel type in the reference), 2 MULTIPLICATIVE
   int build_map(double res, bool force_safe = false) {
     return voxel_mode == 2 ? build_voxelmap<2>(&e, target, voxelmap, res, false, force_safe) : build_voxelmap<0>(&e, target, voxelmap, res, false, force_safe);
@@ -1568,6 +1646,10 @@ int fvh_vgicp_gicp_set_max_correspondence_distance(fvh_vgicp* h, double d) {
 int fvh_vgicp_gicp_update_correspondences(fvh_vgicp* h, const double* T) {
   CHECK_HANDLE(h);
   return gicp_update_correspondences(&h->e, h->source, h->target, h->gicp_records, T, h->gicp_max_dist);
+}
+int fvh_vgicp_gicp_align(fvh_vgicp* h, const double* guess, const fvh_lm_params* p, fvh_lm_result* r) {
+  CHECK_HANDLE(h);
+  return gicp_align(&h->e, h->source, h->target, h->gicp_records, h->gicp_cost_source(true), h->gicp_max_dist, guess, p, r);
 }
 int fvh_vgicp_gicp_compute_error(fvh_vgicp* h, const double* T, double* H, double* b, double* err) {
   CHECK_HANDLE(h);

@@ -99,6 +99,7 @@ struct CostParams {
   // multi-GPU (kernels_peer.hpp): this rank walks the source elements [item_lo, item_hi) of the (Morton) order -- its spatial
   // tile -- and the reduced sums are exchanged with the peers inside the kernel; peer.n <= 1: single GPU, whole cloud
   int item_lo, item_hi;
+  int external_find;  // FastGICP on the device: the correspondences of every linearisation were found by nn1_corr_kernel right before this launch (nothing to probe here)
   PeerView peer;
   unsigned long long peer_watchdog_ticks;
 };
@@ -627,7 +628,10 @@ __global__ FVH_COST_BOUNDS void cost_kernel(CostParams P) {
   for (;;) {  // PERSIST: one trip per LM transition; otherwise exactly one trip
   if (PERSIST) FVH_PT_MIN(gen, 0);
   const bool fused = (P.host_phase < 0) && (phase == PH_TRIAL);  // trial error (old ids) + speculative linearisation at xi (new ids)
-  const bool do_find = (phase == PH_LINEARIZE) || (phase == PH_FIND_ONLY) || fused;
+  // (external find -- FastGICP's device LM -- exists in the per-transition VGICP instantiation only: it is never persistent)
+  constexpr bool EXT_OK = !PERSIST && MODE == MODE_VGICP;
+  const bool external = EXT_OK && P.external_find != 0;
+  const bool do_find = !external && ((phase == PH_LINEARIZE) || (phase == PH_FIND_ONLY) || fused);
   const bool do_cost = (phase != PH_FIND_ONLY);
   const bool do_deriv = (phase == PH_LINEARIZE) || (phase == PH_EVAL_DERIV) || fused;
   // The two poses are wave-uniform: as scalars they cost 48 SGPRs for the whole main loop, and this kernel already
@@ -729,6 +733,13 @@ __global__ FVH_COST_BOUNDS void cost_kernel(CostParams P) {
           else if (k != FVH_EMPTY_KEY && key[c] != DEAD_KEY) r = probe_continue(P.keys, P.mask, key[c], slot[c]);  // rare at load <= 0.25
           b[c] = r;
           if (oc + c < o_end) corr_new[(size_t)i * P.n_off + oc + c] = r;
+        }
+      } else if (EXT_OK && fused) {  // external find (FastGICP): the new ids are already in the other buffer; the old ids' records first, as above
+#pragma unroll
+        for (int c = 0; c < COST_CH; c++) {
+          b[c] = (oc + c < o_end) ? corr_new[(size_t)i * P.n_off + oc + c] : -1;
+          const size_t base = (size_t)max(bo[c], 0) * 4;
+          q1[c] = tf[base + 1]; q2[c] = tf[base + 2]; q3[c] = *reinterpret_cast<const float2*>(tf + base + 3);
         }
       } else {
 #pragma unroll

@@ -17,6 +17,16 @@
 
 namespace fvh {
 
+// where nn1_corr_kernel finds the pose / the output buffer when it runs inside the device-resident LM loop of FastGICP
+// (raw pointers into the LmState on the device: r[9] t[3] doubles per pose)
+struct LmLink {
+  const int* phase;
+  const int* corr_cur;
+  const double* x0;
+  const double* xi;
+  size_t corr_stride;
+};
+
 // fp32 squared distance with a fixed association and NO fma contraction (hipcc's __fmul_rn is a
 // plain '*' that -ffp-contract=fast would fuse): bit-identical to the oracle's sqdist_f32.
 __device__ __forceinline__ float sqdist_nofma(const float4& p, float qx, float qy, float qz) {
@@ -832,13 +842,31 @@ __global__ __launch_bounds__(256) void nn_corr_tiled_kernel(const float4* __rest
 // least as near (ties resolve to the lower original index).
 __global__ __launch_bounds__(256) void nn1_corr_kernel(const float4* __restrict__ ssrc, int ns, const float4* __restrict__ stgt, const float4* __restrict__ bbox1,
                                                        const float4* __restrict__ bbox2, int nt, const float* __restrict__ T12, double thr_sq, int* __restrict__ corr,
-                                                       float* __restrict__ best_out = nullptr /* getFitnessScore: squared NN distance per query, in the order of ssrc */) {
+                                                       float* __restrict__ best_out = nullptr /* getFitnessScore: squared NN distance per query, in the order of ssrc */,
+                                                       LmLink lm = LmLink{nullptr, nullptr, nullptr, nullptr, 0} /* device LM (FastGICP): pose and output buffer follow the LM state on the device */) {
   const int lane = threadIdx.x & 63;
   const int q = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (q >= ns) return;
   const int ntiles = (nt + 63) >> 6, nsuper = (ntiles + 63) >> 6;
   const float4 qv = ssrc[q];
-  const float qx = transform_row_nofma(qv, T12 + 0), qy = transform_row_nofma(qv, T12 + 4), qz = transform_row_nofma(qv, T12 + 8);
+  float Tl[12];
+  if (lm.phase) {
+    // device-resident LM loop: this search belongs to the linearisation the NEXT cost launch will run -- at x0 into the current
+    // correspondence buffer (PH_LINEARIZE), or speculatively at the trial pose xi into the other one (fused PH_TRIAL)
+    const int phase = *lm.phase;
+    if (phase == 2 /* PH_DONE */) return;
+    const double* pose = (phase == 0 /* PH_LINEARIZE */) ? lm.x0 : lm.xi;
+    const int sel = (phase == 1 /* PH_TRIAL */) ? (*lm.corr_cur ^ 1) : *lm.corr_cur;
+    corr += (size_t)sel * lm.corr_stride;
+#pragma unroll
+    for (int r = 0; r < 3; r++) {  // trans.cast<float>() (fast_gicp_impl.hpp:121)
+      Tl[4 * r] = (float)pose[3 * r]; Tl[4 * r + 1] = (float)pose[3 * r + 1]; Tl[4 * r + 2] = (float)pose[3 * r + 2]; Tl[4 * r + 3] = (float)pose[9 + r];
+    }
+  } else {
+#pragma unroll
+    for (int j = 0; j < 12; j++) Tl[j] = T12[j];
+  }
+  const float qx = transform_row_nofma(qv, Tl + 0), qy = transform_row_nofma(qv, Tl + 4), qz = transform_row_nofma(qv, Tl + 8);
   float best = __builtin_inff();
   int besti = 0x7fffffff;
   auto sweep = [&](const float4& p, int base) __attribute__((always_inline)) {

@@ -460,7 +460,7 @@ private:
 
 /// FastGICP (gicp/fast_gicp.hpp:24-98, impl/fast_gicp_impl.hpp) on the HIP engine: the reference class is CPU/OpenMP only;
 /// here the covariances (exact k-NN + regularisation), the nearest-target-point correspondences and the cost sums run on
-/// the device, the LM recursion is the reference's host loop (LsqRegistration::step_lm).
+/// the device; the LM recursion runs on the device too (setUseDeviceLM(false): the reference's host loop, LsqRegistration::step_lm).
 template <typename PointSource, typename PointTarget>
 class FastGICP : public LsqRegistration<PointSource, PointTarget> {
   using Base = LsqRegistration<PointSource, PointTarget>;
@@ -474,7 +474,6 @@ public:
 
   explicit FastGICP(int device = 0) {  // fast_gicp_impl.hpp:9-23
     detail::check(fvh_vgicp_create(device, &core_), "fvh_vgicp_create", "cannot create the HIP engine (no GPU? there is no CPU fallback)");
-    this->use_device_lm_ = false;
   }
   ~FastGICP() override { if (core_) fvh_vgicp_destroy(core_); }
   FastGICP(const FastGICP&) = delete;
@@ -537,6 +536,20 @@ protected:
     Covariances out(n);
     for (size_t i = 0; i < n; i++) for (int j = 0; j < 9; j++) out[i][j] = f[9 * i + j];
     return out;
+  }
+  /// the whole LM loop on the device (fvh_vgicp_gicp_align): one nearest-point search + one cost launch per LM transition, no host round trip
+  bool device_align(Isometry3d& x0) override {
+    double g16[16];
+    x0.to_colmajor16(g16);
+    fvh_lm_params p{this->max_iterations_, this->rotation_epsilon_, this->transformation_epsilon_, this->lm_max_iterations_, this->lm_init_lambda_factor_};
+    fvh_lm_result r;
+    call(fvh_vgicp_gicp_align(core_, g16, &p, &r), "gicp_align");
+    x0 = Isometry3d::from_colmajor16(r.T);
+    this->converged_ = r.converged != 0;
+    this->nr_iterations_ = r.nr_iterations;
+    for (int i = 0; i < 6; i++) for (int j = 0; j < 6; j++) this->final_hessian_[i * 6 + j] = r.H[j * 6 + i];
+    if (r.lm_failed) std::fprintf(stderr, "lm not converged!!\n");
+    return true;
   }
   double linearize(const Isometry3d& trans, Matrix6d* H, Vector6d* b) override {  // :159-213
     double T16[16], err = 0, Hc[36];

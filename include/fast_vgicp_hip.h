@@ -150,6 +150,9 @@ int fvh_vgicp_gicp_set_max_correspondence_distance(fvh_vgicp* h, double max_dist
 int fvh_vgicp_gicp_swap_source_and_target(fvh_vgicp* h);                                    /* fast_gicp_impl.hpp:56-62: swaps clouds, neighbours, covariances; no voxel map */
 int fvh_vgicp_gicp_update_correspondences(fvh_vgicp* h, const double* T16);
 int fvh_vgicp_gicp_compute_error(fvh_vgicp* h, const double* T16, double* H36, double* b6, double* error);
+/* the whole FastGICP LM loop on the device: per LM transition one nearest-point search + one cost launch, no host round trip
+ * (the search reads the pose of the next linearisation from the LM state on the device); same result struct as fvh_vgicp_align */
+int fvh_vgicp_gicp_align(fvh_vgicp* h, const double* guess16, const fvh_lm_params* params, fvh_lm_result* result);
 int fvh_vgicp_gicp_get_correspondences(fvh_vgicp* h, int* target_index_per_source_point /* num_source_points ints, -1 = none */);
 
 /* new: per-kernel-class HIP-event timing on the handle's stream (for bench.py's roofline leg) */

@@ -114,3 +114,37 @@ def test_downsample_device_binding(O):
     b = pygicp.downsample_device(raw, 0.1)
     assert a.shape == b.shape == (17249, 3) and np.array_equal(a, b)
     assert np.array_equal(pygicp.downsample_device(raw, 0.2, exact=True).astype(np.float32), O.voxelgrid(raw, 0.2))
+
+
+@pytest.mark.parametrize("max_dist", [None, 1.0])
+def test_device_lm_align_matches_oracle_and_the_host_loop(O, pair, max_dist):
+    """fvh_vgicp_gicp_align: the whole FastGICP LM loop on the device (one nearest-point search + one cost launch per LM
+    transition, the search reading the next pose from the LM state on the device). Against the oracle's FastGICP: final
+    transform / Hessian / fitness 1e-4 with EQUAL linearisation and error-evaluation counts; against the host-driven loop over
+    the same device kernels: 1e-9; and the correspondences it leaves behind are those of its last linearisation."""
+    from fast_gicp_amd import distributed as D
+    tgt, src = pair
+    c = _prepared(tgt, src, max_dist)
+    r = c.gicp_align()
+    g = O.FastVGICP(k=20)
+    g.set_gicp_mode(True, 3.4028234663852886e38 if max_dist is None else max_dist)
+    g.set_target(tgt); g.set_source(src)
+    ro = g.align()
+    assert r["converged"] and ro["converged"]
+    assert r["num_linearize"] == ro["num_linearize"] and r["num_error_evals"] == ro["num_error_evals"]
+    assert util.rel_err(r["T"], ro["T"]) < 1e-4 and util.rel_err(r["H"], ro["H"]) < 1e-4
+    f = c.fitness_score(r["T"].astype(np.float32).astype(np.float64))
+    assert abs(f - g.fitness()) <= 1e-4 * g.fitness()
+    te, re_ = util.pose_error(util.relative_pose(), r["T"])
+    assert te < 0.05 and re_ < np.radians(1.0)  # gicp_test.cpp:148-149
+    corr_after = c.gicp_get_correspondences()
+    assert int((corr_after >= 0).sum()) > 0.8 * len(src)
+    e_after = c.gicp_compute_error(r["T"], derivatives=False)   # legal: nearest-point ids of the last linearisation
+    assert np.isfinite(e_after) and e_after > 0
+    lsq = D.ShardedLsq(lambda T: c.gicp_linearize(T), lambda T: c.gicp_compute_error(T, derivatives=False), lambda v: v)
+    rh = lsq.align()
+    assert util.rel_err(r["T"], rh["T"]) < 1e-9
+    # a guess near the solution: still the same answer
+    r2 = c.gicp_align(util.relative_pose())
+    assert r2["converged"] and util.rel_err(r2["T"], r["T"]) < 1e-3
+    c.close()
