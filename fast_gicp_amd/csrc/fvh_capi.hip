@@ -649,7 +649,7 @@ int build_voxelmap(Engine* e, const CloudDev& c, VoxelMapDev& vm, double res, bo
     if (c.n) {
       vm_accumulate_kernel<MODE><<<(c.n + 255) / 256, 256, 0, e->stream>>>(c.pts.as<float4>(), c.cov.as<float4>(), c.n, res, keys, cap - 1, vm.acc.as<double>(), counters + 1,
                                                                            coherent_order(c));
-      vm_finalize_kernel<MODE><<<(cap + 255) / 256, 256, 0, e->stream>>>(keys, vm.table.as<uint4>(), cap, vm.acc.as<double>(), counters, vm.occupied.as<int>(),
+      vm_finalize_kernel<MODE><<<(cap + VM_FIN_THREADS - 1) / VM_FIN_THREADS, VM_FIN_THREADS, 0, e->stream>>>(keys, vm.table.as<uint4>(), cap, vm.acc.as<double>(), counters, vm.occupied.as<int>(),
                                                                         want_compact ? vm.compact_pts.as<float4>() : nullptr, want_compact ? vm.compact_cov.as<float4>() : nullptr,
                                                                         vm.keys[vm.cur].as<unsigned long long>(), vm.counters.as<int>() + 16 * vm.cur);
       vm.clean_cap = cap;

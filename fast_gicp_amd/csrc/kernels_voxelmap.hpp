@@ -156,16 +156,23 @@ __global__ __launch_bounds__(256) void vm_accumulate_kernel(const float4* __rest
 // One thread per bucket. MODE 0: AdditiveGaussianVoxel::finalize (fast_vgicp_voxel.hpp:118-121,
 // gaussian_voxelmap.cu:164-171). MODE 1: ndt_finalize_voxels_kernel (gaussian_voxelmap.cu:184-193)
 // + MIN_EIG regularisation (ndt_cuda.cu:128,139).
+constexpr int VM_FIN_THREADS = 1024;  // buckets per workgroup = counter atomics saved
 template <int MODE>
-__global__ __launch_bounds__(256) void vm_finalize_kernel(const unsigned long long* __restrict__ keys, uint4* __restrict__ table, unsigned capacity, double* __restrict__ acc,
+__global__ __launch_bounds__(VM_FIN_THREADS) void vm_finalize_kernel(const unsigned long long* __restrict__ keys, uint4* __restrict__ table, unsigned capacity, double* __restrict__ acc,
                                                           int* __restrict__ num_voxels, int* __restrict__ occupied, float4* __restrict__ compact_pts, float4* __restrict__ compact_cov,
                                                           unsigned long long* __restrict__ next_keys, int* __restrict__ next_counters) {
-  const unsigned b = blockIdx.x * 256 + threadIdx.x;
-  if (b >= capacity) return;
-  next_keys[b] = FVH_EMPTY_KEY;  // the buffers of the NEXT build (the map before this one is dead)
-  if (b < 16) next_counters[b] = 0;
-  const unsigned long long key = keys[b];
-  if (key == FVH_EMPTY_KEY) return;
+  const unsigned b = blockIdx.x * VM_FIN_THREADS + threadIdx.x;
+  bool live = false;
+  int slot_in_wave = 0;
+  float mxf = 0.f, myf = 0.f, mzf = 0.f;
+  float4 q2 = make_float4(0, 0, 0, 0), q3 = q2;
+  unsigned long long key = FVH_EMPTY_KEY;
+  if (b < capacity) {
+    next_keys[b] = FVH_EMPTY_KEY;  // the buffers of the NEXT build (the map before this one is dead)
+    if (b < 16) next_counters[b] = 0;
+    key = keys[b];
+  }
+  if (key != FVH_EMPTY_KEY) {
   uint4 q0 = make_uint4((unsigned)key, (unsigned)(key >> 32), 0u, 0u);
   double a[VM_ACC_STRIDE];
   {
@@ -197,22 +204,37 @@ __global__ __launch_bounds__(256) void vm_finalize_kernel(const unsigned long lo
   q0.z = (unsigned)n;
   q0.w = 0;
   const float4 q1 = make_float4((float)mx, (float)my, (float)mz, (float)n);
-  const float4 q2 = make_float4((float)C.xx, (float)C.xy, (float)C.xz, (float)C.yy);
-  const float4 q3 = make_float4((float)C.yz, (float)C.zz, 0.f, 0.f);
+  q2 = make_float4((float)C.xx, (float)C.xy, (float)C.xz, (float)C.yy);
+  q3 = make_float4((float)C.yz, (float)C.zz, 0.f, 0.f);
+  mxf = (float)mx; myf = (float)my; mzf = (float)mz;
   float4* tf = reinterpret_cast<float4*>(table);
   table[(size_t)b * 4] = q0;
   tf[(size_t)b * 4 + 1] = q1;
   tf[(size_t)b * 4 + 2] = q2;
   tf[(size_t)b * 4 + 3] = q3;
-  // one atomic per wave, not per voxel: 60k same-address atomics made this kernel 50 us on a 100k-point scene
-  const unsigned long long live = __ballot(1);
-  const int lane = threadIdx.x & 63, leader = __ffsll((long long)live) - 1;
-  int base = 0;
-  if (lane == leader) base = atomicAdd(num_voxels, __popcll(live));
-  const int id = __shfl(base, leader) + __popcll(live & ((1ull << lane) - 1ull));
+  live = true;
+  }  // occupied bucket
+  // Compact list of the occupied buckets: ONE atomic per 1024-bucket WORKGROUP on the voxel counter. (Round 1 had one per wave: 4,096
+  // same-address atomics at 100k points / 262k buckets -- the memory-side atomic unit retires them one after the other, ~12 ns
+  // each, which was the 50 us this kernel took; per voxel it had been 60k of them.)
+  __shared__ int s_wave_cnt[VM_FIN_THREADS / 64], s_base;
+  const int wv = threadIdx.x >> 6;
+  const unsigned long long mask = __ballot(live);
+  slot_in_wave = __popcll(mask & ((1ull << (threadIdx.x & 63)) - 1ull));
+  if ((threadIdx.x & 63) == 0) s_wave_cnt[wv] = __popcll(mask);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int total = 0;
+    for (int w = 0; w < VM_FIN_THREADS / 64; w++) total += s_wave_cnt[w];
+    s_base = total ? atomicAdd(num_voxels, total) : 0;
+  }
+  __syncthreads();
+  if (!live) return;
+  int id = s_base + slot_in_wave;
+  for (int w = 0; w < wv; w++) id += s_wave_cnt[w];
   occupied[id] = (int)b;
   if (compact_pts) {  // D2D NDT: the source voxels are the "source cloud"
-    compact_pts[id] = make_float4((float)mx, (float)my, (float)mz, 0.f);
+    compact_pts[id] = make_float4(mxf, myf, mzf, 0.f);
     compact_cov[2 * id] = q2;
     compact_cov[2 * id + 1] = q3;
   }
