@@ -1,0 +1,2 @@
+#pragma once
+#include "../../core_decls_after_edit.hpp"
