@@ -175,6 +175,18 @@ class _Core:
     def synchronize(self):
         self._call("synchronize")
 
+    def set_lm_trace(self, on=True):
+        self._call("set_lm_trace", int(on))
+
+    def get_lm_trace(self):
+        """Rows {i, y0, yi, rho, lambda, |d|} of the last align (one per trial step), as LsqRegistration's debug print."""
+        n = C.c_int(0)
+        self._call("get_lm_trace", C.byref(n), None)
+        out = np.empty((n.value, 6), np.float64)
+        if n.value:
+            self._call("get_lm_trace", C.byref(n), _p(out))
+        return out
+
     def profile_enable(self, on=True):
         self._call("profile_enable", int(on))
 

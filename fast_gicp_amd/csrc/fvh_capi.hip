@@ -198,6 +198,9 @@ struct Engine {
   int persist_aborts = 0;               // persistent launches the watchdog turned into multi-launch retries
   int persist_backoff = 0, persist_skip = 0;  // after an abort: aligns to run on the multi-launch route before the next persistent attempt (doubles per consecutive abort)
   Profiler prof;
+  bool lm_trace_on = false;  // setDebugPrint: the device LM records one row per trial step
+  DevBuf lm_trace;
+  int lm_trace_rows = 0;
   void* comm = nullptr;
   int nranks = 1, rank = 0;
   // peer-mapped exchange (kernels_peer.hpp): replaces RCCL for the two exchanges of a sharded registration
@@ -264,7 +267,7 @@ struct Engine {
     if (peer.region) { (void)hipFree(peer.region); peer.region = nullptr; }
     peer.err.release();
     prof.destroy();
-    fit_best.release(); sort_coop.release(); pticket.release(); bcast.release(); offsets_dev.release(); state.release(); partials.release(); ticket.release(); corr.release(); misc.release(); fit.release(); staging.release(); sort_keys.release(); sort_idx.release(); sort_hist.release();
+    lm_trace.release(); fit_best.release(); sort_coop.release(); pticket.release(); bcast.release(); offsets_dev.release(); state.release(); partials.release(); ticket.release(); corr.release(); misc.release(); fit.release(); staging.release(); sort_keys.release(); sort_idx.release(); sort_hist.release();
     if (pinned) (void)hipHostFree(pinned);
     if (result_host) (void)hipHostFree(result_host);
     if (stream) (void)hipStreamDestroy(stream);
@@ -782,6 +785,7 @@ int launch_cost(Engine* e, const CostSource& src, const VoxelMapDev& vm, int hos
   P.vm_counters2 = src.counters2;
   P.host_phase = host_phase;
   P.external_find = src.external_find ? 1 : 0;
+  P.lm_trace = (e->lm_trace_on && host_phase < 0) ? e->lm_trace.as<double>() : nullptr;
   P.defer_lm = (e->comm != nullptr) ? 1 : 0;
   if (lin) P.lin = *lin;
   if (ev) P.ev = *ev;
@@ -929,6 +933,8 @@ int do_align(Engine* e, const CostSource& src, VoxelMapDev& vm, const double* gu
     HIP_OR_FAIL(e, hipGetLastError());
   }
   const long long budget = (long long)std::max(p.max_iterations, 0) * (1 + (long long)std::max(p.lm_max_iterations, 0)) + 1;
+  if (e->lm_trace_on) HIP_OR_FAIL(e, e->lm_trace.ensure(sizeof(double) * 6 * (size_t)std::max<long long>(budget, 1)));
+  e->lm_trace_rows = 0;
   long long launched = 0;
   int batch = e->last_steps > 0 ? std::max(e->last_steps, e->prev_steps) + 1 : 8;
   LmState* h = reinterpret_cast<LmState*>(e->pinned);
@@ -1044,6 +1050,7 @@ int do_align(Engine* e, const CostSource& src, VoxelMapDev& vm, const double* gu
   result->num_error_evals = h->num_error_evals;
   result->lm_failed = h->lm_failed;
   result->num_launches = (int)launched;
+  e->lm_trace_rows = e->lm_trace_on ? h->num_error_evals : 0;
   return FVH_OK;
 }
 
@@ -1153,6 +1160,8 @@ int gicp_align(Engine* e, CloudDev& src, CloudDev& tgt, VoxelMapDev& records, co
   const double thr = std::min(max_dist, 1.8446743e19);
   const LmLink link{&st->phase, &st->corr_cur, st->x0.r, st->xi.r, (size_t)src.n};
   const long long budget = (long long)std::max(p.max_iterations, 0) * (1 + (long long)std::max(p.lm_max_iterations, 0)) + 1;
+  if (e->lm_trace_on) HIP_OR_FAIL(e, e->lm_trace.ensure(sizeof(double) * 6 * (size_t)std::max<long long>(budget, 1)));
+  e->lm_trace_rows = 0;
   LmState* h = reinterpret_cast<LmState*>(e->pinned);
   if (p.max_iterations <= 0) {
     lm_init_kernel<<<1, 64, 0, e->stream>>>(st, guess, p.rotation_epsilon, p.transformation_epsilon, p.lm_init_lambda_factor, p.max_iterations, p.lm_max_iterations, e->ticket.as<unsigned>());
@@ -1194,6 +1203,7 @@ int gicp_align(Engine* e, CloudDev& src, CloudDev& tgt, VoxelMapDev& records, co
   result->num_error_evals = h->num_error_evals;
   result->lm_failed = h->lm_failed;
   result->num_launches = (int)(2 * launched);
+  e->lm_trace_rows = e->lm_trace_on ? h->num_error_evals : 0;
   return FVH_OK;
 }
 
@@ -1677,6 +1687,17 @@ int fvh_vgicp_align(fvh_vgicp* h, const double* guess, const fvh_lm_params* p, f
   if (h->e.peer.attached() && h->source.n) { int rc = ensure_sorted(&h->e, h->source); if (rc) return rc; }
   return do_align<MODE_VGICP>(&h->e, h->cost_source(), h->voxelmap, guess, p, r, h->rebuild_safe());
 }
+static int get_lm_trace(Engine* e, int* n, double* rows6) {
+  if (!n) return e->fail(FVH_ERR_INVALID_ARGUMENT, "get_lm_trace: null count");
+  *n = e->lm_trace_rows;
+  if (rows6 && e->lm_trace_rows > 0) {
+    HIP_OR_FAIL(e, hipMemcpyAsync(rows6, e->lm_trace.p, sizeof(double) * 6 * (size_t)e->lm_trace_rows, hipMemcpyDeviceToHost, e->stream));
+    HIP_OR_FAIL(e, hipStreamSynchronize(e->stream));
+  }
+  return FVH_OK;
+}
+int fvh_vgicp_set_lm_trace(fvh_vgicp* h, int on) { CHECK_HANDLE(h); h->e.lm_trace_on = on != 0; return FVH_OK; }
+int fvh_vgicp_get_lm_trace(fvh_vgicp* h, int* n, double* rows6) { CHECK_HANDLE(h); return get_lm_trace(&h->e, n, rows6); }
 int fvh_vgicp_fitness_score(fvh_vgicp* h, const double* T, double max_range, double* score) { CHECK_HANDLE(h); return do_fitness(&h->e, h->source, h->target, T, max_range, score); }
 int fvh_vgicp_profile_enable(fvh_vgicp* h, int on) { CHECK_HANDLE(h); h->e.prof.on = on != 0; return FVH_OK; }
 int fvh_vgicp_profile_reset(fvh_vgicp* h) { CHECK_HANDLE(h); HIP_OR_FAIL(&h->e, hipStreamSynchronize(h->e.stream)); h->e.prof.reset(); return FVH_OK; }
@@ -1847,6 +1868,8 @@ int fvh_ndt_align(fvh_ndt* h, const double* guess, const fvh_lm_params* p, fvh_l
   if (h->distance_mode == FVH_NDT_P2D) return do_align<MODE_NDT_P2D>(&h->e, h->cost_source(), h->target_vm, guess, p, r, h->rebuild_safe());
   return do_align<MODE_NDT_D2D>(&h->e, h->cost_source(), h->target_vm, guess, p, r, h->rebuild_safe());
 }
+int fvh_ndt_set_lm_trace(fvh_ndt* h, int on) { CHECK_HANDLE(h); h->e.lm_trace_on = on != 0; return FVH_OK; }
+int fvh_ndt_get_lm_trace(fvh_ndt* h, int* n, double* rows6) { CHECK_HANDLE(h); return get_lm_trace(&h->e, n, rows6); }
 int fvh_ndt_fitness_score(fvh_ndt* h, const double* T, double max_range, double* score) { CHECK_HANDLE(h); return do_fitness(&h->e, h->source, h->target, T, max_range, score); }
 int fvh_ndt_get_num_voxels(fvh_ndt* h, int which, int* n) {
   CHECK_HANDLE(h);

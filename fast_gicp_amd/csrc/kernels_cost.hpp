@@ -99,6 +99,7 @@ struct CostParams {
   // multi-GPU (kernels_peer.hpp): this rank walks the source elements [item_lo, item_hi) of the (Morton) order -- its spatial
   // tile -- and the reduced sums are exchanged with the peers inside the kernel; peer.n <= 1: single GPU, whole cloud
   int item_lo, item_hi;
+  double* lm_trace;   // setDebugPrint on the device LM: 6 doubles per trial {i, y0, yi, rho, lambda, |d|} (lsq_registration_impl.hpp:143-149), or null
   int external_find;  // FastGICP on the device: the correspondences of every linearisation were found by nn1_corr_kernel right before this launch (nothing to probe here)
   PeerView peer;
   unsigned long long peer_watchdog_ticks;
@@ -300,7 +301,7 @@ __device__ __forceinline__ double readlane_f64(double x, int src) {
 // dev_ldlt6_solve), the small sequential parts (triangular solves, se3_exp, pose product, rho test) run redundantly on all
 // lanes in registers, and the state is read once at the top and written once at the bottom. `st` and `sums` must be LDS.
 // ------------------------------------------------------------------------------------------------
-__device__ inline void dev_lm_step_wave(LmState* st, const double* sums, const int lane) {
+__device__ inline void dev_lm_step_wave(LmState* st, const double* sums, const int lane, double* trace = nullptr) {
   const int li = lane / 6, lj = lane - li * 6;
   const bool in36 = lane < 36, in12 = lane < 12, in6 = lane < 6;
   double* x0p = reinterpret_cast<double*>(&st->x0);
@@ -329,6 +330,13 @@ __device__ inline void dev_lm_step_wave(LmState* st, const double* sums, const i
 #pragma unroll
     for (int j = 0; j < 6; j++) denom += st->d[j] * (lambda * st->d[j] - st->b[j]);
     const double rho = (y0 - yi) / denom;
+    if (trace && lane == 0) {  // the line LsqRegistration prints per trial when setDebugPrint(true) (lsq_registration_impl.hpp:143-149)
+      double dn = 0;
+#pragma unroll
+      for (int j = 0; j < 6; j++) dn += st->d[j] * st->d[j];
+      double* row = trace + 6 * (size_t)(num_error_evals - 1);
+      row[0] = (double)inner_iter; row[1] = y0; row[2] = yi; row[3] = rho; row[4] = lambda; row[5] = sqrt(dn);
+    }
     const bool conv = dev_is_converged(st, st->delta);
     if (rho < 0) {
       if (conv) {  // step_lm returns true with x0 unchanged -> converged_ = true
@@ -985,7 +993,7 @@ __global__ FVH_COST_BOUNDS void cost_kernel(CostParams P) {
       if (P.host_phase < 0 && P.init) init_state();
     }
     __syncthreads();
-    if (P.host_phase < 0 && !P.defer_lm && tid < 64) dev_lm_step_wave(&s_st, red[0], tid);
+    if (P.host_phase < 0 && !P.defer_lm && tid < 64) dev_lm_step_wave(&s_st, red[0], tid, P.lm_trace);
     FVH_STAMP(6);
     __syncthreads();
     for (int i = tid; i < ST_WORDS; i += 256) st_words[i] = reinterpret_cast<const unsigned long long*>(&s_st)[i];
@@ -1074,7 +1082,7 @@ __global__ FVH_COST_BOUNDS void cost_kernel(CostParams P) {
       if (tid >= 64 && tid < 64 + PART_STRIDE) s_st.sums[tid - 64] = red[0][tid - 64];  // (a lane each, not 32 round trips of lane 0)
       __syncthreads();
       FVH_PT_MAX(trip, 8);
-      if (tid < 64) dev_lm_step_wave(&s_st, red[0], tid);
+      if (tid < 64) dev_lm_step_wave(&s_st, red[0], tid, P.lm_trace);
       FVH_PT_MAX(trip, 9);
       __syncthreads();
       if (tid < 26) {  // payload: phase, correspondence buffer, x_lin, evaluation pose of the next trip

@@ -154,6 +154,14 @@ inline void ldlt6_solve(const Matrix6d& A, const Vector6d& rhs, Vector6d& x) {
   for (int i = 0; i < 6; i++) y[i] = std::fabs(D[i]) > tiny ? y[i] / D[i] : 0.0;
   for (int i = 5; i >= 0; i--) { double s = y[i]; for (int k = i + 1; k < 6; k++) s -= L[k * 6 + i] * x[k]; x[i] = s; }
 }
+/// the table LsqRegistration::step_lm prints with setDebugPrint(true) (lsq_registration_impl.hpp:143-149), from the rows the
+/// device LM recorded ({i, y0, yi, rho, lambda, |delta|} per trial step)
+inline void print_lm_trace(const std::vector<double>& rows) {
+  for (size_t r = 0; r + 5 < rows.size(); r += 6) {
+    if ((int)rows[r] == 0) std::printf("--- LM optimization ---\n%5s %15s %15s %15s %15s %15s %5s\n", "i", "y0", "yi", "rho", "lambda", "|delta|", "dec");
+    std::printf("%5d %15g %15g %15g %15g %15g %5c\n", (int)rows[r], rows[r + 1], rows[r + 2], rows[r + 3], rows[r + 4], rows[r + 5], rows[r + 3] > 0.0 ? 'x' : ' ');
+  }
+}
 template <typename PointT>
 inline std::vector<float> pack_xyz(const PointCloud<PointT>& c) {
   std::vector<float> xyz(c.size() * 3);
@@ -425,7 +433,15 @@ protected:
     x0.to_colmajor16(g16);
     fvh_lm_params p{this->max_iterations_, this->rotation_epsilon_, this->transformation_epsilon_, this->lm_max_iterations_, this->lm_init_lambda_factor_};
     fvh_lm_result r;
+    call(fvh_vgicp_set_lm_trace(core_, this->lm_debug_print_ ? 1 : 0), "set_lm_trace");
     call(fvh_vgicp_align(core_, g16, &p, &r), "align");
+    if (this->lm_debug_print_) {
+      int n = 0;
+      call(fvh_vgicp_get_lm_trace(core_, &n, nullptr), "get_lm_trace");
+      std::vector<double> rows(6 * (size_t)n);
+      if (n) call(fvh_vgicp_get_lm_trace(core_, &n, rows.data()), "get_lm_trace");
+      detail::print_lm_trace(rows);
+    }
     x0 = Isometry3d::from_colmajor16(r.T);
     this->converged_ = r.converged != 0;
     this->nr_iterations_ = r.nr_iterations;
@@ -543,7 +559,15 @@ protected:
     x0.to_colmajor16(g16);
     fvh_lm_params p{this->max_iterations_, this->rotation_epsilon_, this->transformation_epsilon_, this->lm_max_iterations_, this->lm_init_lambda_factor_};
     fvh_lm_result r;
+    call(fvh_vgicp_set_lm_trace(core_, this->lm_debug_print_ ? 1 : 0), "set_lm_trace");
     call(fvh_vgicp_gicp_align(core_, g16, &p, &r), "gicp_align");
+    if (this->lm_debug_print_) {
+      int n = 0;
+      call(fvh_vgicp_get_lm_trace(core_, &n, nullptr), "get_lm_trace");
+      std::vector<double> rows(6 * (size_t)n);
+      if (n) call(fvh_vgicp_get_lm_trace(core_, &n, rows.data()), "get_lm_trace");
+      detail::print_lm_trace(rows);
+    }
     x0 = Isometry3d::from_colmajor16(r.T);
     this->converged_ = r.converged != 0;
     this->nr_iterations_ = r.nr_iterations;
@@ -640,7 +664,15 @@ protected:
     x0.to_colmajor16(g16);
     fvh_lm_params p{this->max_iterations_, this->rotation_epsilon_, this->transformation_epsilon_, this->lm_max_iterations_, this->lm_init_lambda_factor_};
     fvh_lm_result r;
+    call(fvh_ndt_set_lm_trace(core_, this->lm_debug_print_ ? 1 : 0), "set_lm_trace");
     call(fvh_ndt_align(core_, g16, &p, &r), "align");
+    if (this->lm_debug_print_) {
+      int n = 0;
+      call(fvh_ndt_get_lm_trace(core_, &n, nullptr), "get_lm_trace");
+      std::vector<double> rows(6 * (size_t)n);
+      if (n) call(fvh_ndt_get_lm_trace(core_, &n, rows.data()), "get_lm_trace");
+      detail::print_lm_trace(rows);
+    }
     x0 = Isometry3d::from_colmajor16(r.T);
     this->converged_ = r.converged != 0;
     this->nr_iterations_ = r.nr_iterations;

@@ -136,6 +136,11 @@ int fvh_vgicp_compute_error(fvh_vgicp* h, const double* T16, double* H36, double
  * lookups per evaluation, or after the barrier watchdog aborted a persistent launch (FVH_PERSISTENT=0 forces it).
  * All routes produce bit-identical results. */
 int fvh_vgicp_align(fvh_vgicp* h, const double* guess16, const fvh_lm_params* params, fvh_lm_result* result);
+/* setDebugPrint(true) on the device LM: with the trace on, an align records one row per trial step -- {inner iteration i, y0,
+ * yi, rho, lambda, |d|}, the columns LsqRegistration prints (lsq_registration_impl.hpp:143-149) -- fetched afterwards
+ * (rows6 may be NULL to query the count). */
+int fvh_vgicp_set_lm_trace(fvh_vgicp* h, int on);
+int fvh_vgicp_get_lm_trace(fvh_vgicp* h, int* num_rows, double* rows6);
 /* new: pcl::Registration::getFitnessScore(max_range) -- mean squared exact-NN distance of
  * (float)T * source to the target cloud (exact tile-culled 1-NN on device, fixed-order fp64 sum: bit-reproducible). */
 int fvh_vgicp_fitness_score(fvh_vgicp* h, const double* T16, double max_range, double* score);
@@ -219,6 +224,8 @@ int fvh_ndt_update_correspondences(fvh_ndt* h, const double* T16);              
 int fvh_ndt_compute_error(fvh_ndt* h, const double* T16, double* H36, double* b6, double* error); /* [NC]:50 */
 int fvh_ndt_align(fvh_ndt* h, const double* guess16, const fvh_lm_params* params, fvh_lm_result* result);
 int fvh_ndt_fitness_score(fvh_ndt* h, const double* T16, double max_range, double* score);
+int fvh_ndt_set_lm_trace(fvh_ndt* h, int on);
+int fvh_ndt_get_lm_trace(fvh_ndt* h, int* num_rows, double* rows6);
 int fvh_ndt_get_num_voxels(fvh_ndt* h, int which /* 0 source, 1 target */, int* num_voxels);
 int fvh_ndt_get_voxels(fvh_ndt* h, int which, int* coords3, int* num_points, float* means3, float* covs9);
 int fvh_ndt_get_num_correspondences(fvh_ndt* h, int* n);

@@ -120,3 +120,47 @@ def test_fast_gicp_covariance_accessors(pygicp, data):
     assert util.rel_err(T2, T0) > 1e-6
     with pytest.raises(Exception):
         reg2.set_source_covariances(cs[:10])
+
+
+def test_debug_print_table_from_the_device_lm(pygicp, data, capfd):
+    """setDebugPrint(true): the reference prints one line per trial step (lsq_registration_impl.hpp:143-149). The device-resident
+    LM records those rows on the GPU and the host prints the same table afterwards; it must equal, value for value, the table the
+    host-driven loop prints while it runs, and the oracle's."""
+    from oracle import oracle as O
+    target, source, _ = data
+    tables = {}
+    for dev in (True, False):
+        reg = pygicp.FastVGICPCuda()
+        reg.set_nearest_neighbor_search_method("GPU_BRUTEFORCE")
+        reg.set_use_device_lm(dev)
+        reg.set_debug_print(True)
+        reg.set_input_target(target); reg.set_input_source(source)
+        capfd.readouterr()
+        reg.align()
+        import sys
+        sys.stdout.flush()
+        out = capfd.readouterr().out
+        rows = [l.split() for l in out.splitlines() if l.strip() and l.split()[0].isdigit()]
+        assert out.count("--- LM optimization ---") >= 3 and len(rows) >= 3
+        tables[dev] = np.array([[float(v) for v in r[:6]] for r in rows])
+        assert all((len(r) == 7 and r[6] == "x") == (float(r[3]) > 0) for r in rows)
+    assert tables[True].shape == tables[False].shape
+    np.testing.assert_allclose(tables[True], tables[False], rtol=1e-5, atol=1e-12)  # (%g prints 6 significant digits)
+
+
+def test_lm_trace_rows_through_the_abi(data):
+    from fast_gicp_amd import capi
+    target, source, _ = data
+    c = capi.VGICPCore(0)
+    c.set_target_cloud(target); c.find_target_neighbors(20); c.calculate_target_covariances(); c.create_target_voxelmap()
+    c.set_source_cloud(source); c.find_source_neighbors(20); c.calculate_source_covariances()
+    r0 = c.align()
+    assert len(c.get_lm_trace()) == 0          # off by default
+    c.set_lm_trace(True)
+    r = c.align()
+    t = c.get_lm_trace()
+    assert t.shape == (r["num_error_evals"], 6) and np.array_equal(r["T"], r0["T"])
+    assert np.all(t[:, 3][t[:, 0] == 0] == t[:, 3][t[:, 0] == 0])
+    assert t[-1, 1] <= t[0, 1] and np.all(t[:, 4] > 0) and np.all(t[:, 5] > 0)   # y0 decreases over the run; lambda, |d| positive
+    assert np.all((t[:, 2] < t[:, 1]) == (t[:, 3] > 0))                            # rho > 0  <=>  the trial lowered the error (denominator > 0)
+    c.close()
