@@ -161,6 +161,7 @@ inline void print_lm_trace(const std::vector<double>& rows) {
     if ((int)rows[r] == 0) std::printf("--- LM optimization ---\n%5s %15s %15s %15s %15s %15s %5s\n", "i", "y0", "yi", "rho", "lambda", "|delta|", "dec");
     std::printf("%5d %15g %15g %15g %15g %15g %5c\n", (int)rows[r], rows[r + 1], rows[r + 2], rows[r + 3], rows[r + 4], rows[r + 5], rows[r + 3] > 0.0 ? 'x' : ' ');
   }
+  std::fflush(stdout);  // (std::endl in the reference)
 }
 template <typename PointT>
 inline std::vector<float> pack_xyz(const PointCloud<PointT>& c) {
@@ -279,6 +280,7 @@ protected:
         for (int j = 0; j < 6; j++) dn += d[j] * d[j];
         if (i == 0) std::printf("--- LM optimization ---\n%5s %15s %15s %15s %15s %15s %5s\n", "i", "y0", "yi", "rho", "lambda", "|delta|", "dec");
         std::printf("%5d %15g %15g %15g %15g %15g %5c\n", i, y0, yi, rho, lm_lambda_, std::sqrt(dn), rho > 0.0 ? 'x' : ' ');
+        std::fflush(stdout);
       }
       if (rho < 0) {
         if (is_converged(delta)) return true;
