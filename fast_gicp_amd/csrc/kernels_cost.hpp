@@ -301,7 +301,12 @@ __device__ __forceinline__ double readlane_f64(double x, int src) {
 // dev_ldlt6_solve), the small sequential parts (triangular solves, se3_exp, pose product, rho test) run redundantly on all
 // lanes in registers, and the state is read once at the top and written once at the bottom. `st` and `sums` must be LDS.
 // ------------------------------------------------------------------------------------------------
-__device__ inline void dev_lm_step_wave(LmState* st, const double* sums, const int lane, double* trace = nullptr) {
+#ifdef FVH_LM_STEP_NOINLINE  // A/B switch: a real function (called once per trip through generic pointers) instead of inlined code on LDS
+#define FVH_LM_STEP_ATTR __noinline__
+#else
+#define FVH_LM_STEP_ATTR __forceinline__
+#endif
+__device__ FVH_LM_STEP_ATTR void dev_lm_step_wave(LmState* st, const double* sums, const int lane, double* trace = nullptr) {
   const int li = lane / 6, lj = lane - li * 6;
   const bool in36 = lane < 36, in12 = lane < 12, in6 = lane < 6;
   double* x0p = reinterpret_cast<double*>(&st->x0);
@@ -423,11 +428,21 @@ __device__ inline void dev_lm_step_wave(LmState* st, const double* sums, const i
 #pragma unroll
   for (int i = 0; i < 6; i++) nb[i] = -readlane_f64(bv, i);
 #pragma unroll
-  for (int i = 0; i < 6; i++) { double sacc = nb[i]; for (int k = 0; k < i; k++) sacc -= L[i * (i - 1) / 2 + k] * y[k]; y[i] = sacc; }
+  for (int i = 0; i < 6; i++) {
+    double sacc = nb[i];
+#pragma unroll
+    for (int k = 0; k < 6; k++) if (k < i) sacc -= L[i * (i - 1) / 2 + k] * y[k];
+    y[i] = sacc;
+  }
 #pragma unroll
   for (int i = 0; i < 6; i++) y[i] *= Dinv[i];
 #pragma unroll
-  for (int i = 5; i >= 0; i--) { double sacc = y[i]; for (int k = i + 1; k < 6; k++) sacc -= L[k * (k - 1) / 2 + i] * d[k]; d[i] = sacc; }
+  for (int i = 5; i >= 0; i--) {
+    double sacc = y[i];
+#pragma unroll
+    for (int k = 0; k < 6; k++) if (k > i) sacc -= L[k * (k - 1) / 2 + i] * d[k];
+    d[i] = sacc;
+  }
   PoseD delta;
   dev_se3_exp(d, delta);
   if (lane == 0) {
@@ -1027,8 +1042,9 @@ __global__ FVH_COST_BOUNDS void cost_kernel(CostParams P) {
     const unsigned trip = gen;
     unsigned long long ltag = P.launch_tag;
     asm volatile("" : "+s"(ltag));  // opaque per trip: otherwise the two conversions below are hoisted out of the trip loop and held in 4 VGPRs across the main loop
-    const double want_tag = (double)(ltag * 4096ull + trip + 1);
-    const double abort_tag = -(double)(ltag * 4096ull);  // launch-specific: a poisoned row of an older launch means nothing
+    // (formed where they are used, from scalars: held as doubles they were four VGPRs live across the inlined LM step)
+    auto want_tag_of = [&]() { unsigned long long t = ltag * 4096ull + trip + 1; asm volatile("" : "+s"(t)); return (double)t; };
+    auto abort_tag_of = [&]() { unsigned long long t = ltag * 4096ull; asm volatile("" : "+s"(t)); return -(double)t; };  // launch-specific: a poisoned row of an older launch means nothing
     const size_t grow0 = (size_t)MAX_PARTIAL_ROWS + (size_t)(trip & 1u) * TICKET_GROUPS;
     __shared__ double bc[BCAST_SLOTS];  // payload of the broadcast row as seen by this workgroup
     static_assert(TICKET_GROUPS == 8, "tb0..tb7");
@@ -1069,6 +1085,7 @@ __global__ FVH_COST_BOUNDS void cost_kernel(CostParams P) {
           if (P.peer.n > 1 && !peer_exchange_sums(P.peer, red[0], P.peer.xbase + trip, P.peer_watchdog_ticks, tid, 256, &s_last)) abort_code = 2u;  // 2: a peer did not deliver
       }
       if (abort_code) {  // never hang the GPU -- poison every tag of this launch and leave; the host takes it from `aborted`
+        const double abort_tag = abort_tag_of();
         for (int idx = tid; idx < PERSIST_REPLICAS * BCAST_SLOTS / 8; idx += 256) __hip_atomic_store(&P.bcast[idx * 8 + 7], abort_tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (tid == 0) __hip_atomic_store(&st->aborted, abort_code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         return;
@@ -1102,7 +1119,7 @@ __global__ FVH_COST_BOUNDS void cost_kernel(CostParams P) {
       FVH_PT_MAX(trip, 10);
       for (int idx = tid; idx < PERSIST_REPLICAS * BCAST_SLOTS; idx += 256) {
         const int slot = idx % BCAST_SLOTS, seg = slot >> 3, k = slot & 7, d = seg * 7 + k;
-        const double val = (k == 7) ? want_tag : (d < 26 ? bc[d] : 0.0);
+        const double val = (k == 7) ? want_tag_of() : (d < 26 ? bc[d] : 0.0);
         __hip_atomic_store(&P.bcast[idx], val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
       FVH_PT_MAX(trip, 3);
@@ -1125,6 +1142,7 @@ __global__ FVH_COST_BOUNDS void cost_kernel(CostParams P) {
         const int lane = tid;
         const bool is_slot = lane < BCAST_SLOTS, is_tag = is_slot && ((lane & 7) == 7);
         const unsigned long long t0 = wall_clock64();
+        const double want_tag = want_tag_of(), abort_tag = abort_tag_of();
         int ok = 0;
         for (;;) {
           const double v = is_slot ? __hip_atomic_load(&rep[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;

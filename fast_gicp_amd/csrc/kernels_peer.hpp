@@ -28,6 +28,14 @@ struct PeerView {  // kernel argument (by value)
   char* region[FVH_MAX_PEERS];
 };
 
+// region pointer of rank p WITHOUT indexing the by-value struct dynamically (an indexed kernel-argument array is copied to
+// scratch memory: 8 selects instead)
+__device__ __forceinline__ char* peer_region(const PeerView& pv, int p) {
+  char* r = pv.region[0];
+#pragma unroll
+  for (int i = 1; i < FVH_MAX_PEERS; i++) r = (p == i) ? pv.region[i] : r;
+  return r;
+}
 __device__ __forceinline__ double* peer_mail(char* region, unsigned parity, int src_rank) {
   return reinterpret_cast<double*>(region) + ((size_t)parity * FVH_MAX_PEERS + src_rank) * MAIL_SLOT;
 }
@@ -39,14 +47,14 @@ __device__ inline bool peer_exchange_sums(const PeerView& pv, double* row, unsig
   const double tag = (double)x;
   for (int idx = tid; idx < pv.n * 32; idx += nthreads) {
     const int p = idx >> 5, v = idx & 31;
-    __hip_atomic_store(&peer_mail(pv.region[p], parity, pv.rank)[v], row[v], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(&peer_mail(peer_region(pv, p), parity, pv.rank)[v], row[v], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   }
   __threadfence_system();
   if (tid == 0) *s_flag = 1;
   __syncthreads();
   if (tid < pv.n) {
-    __hip_atomic_store(&peer_mail(pv.region[tid], parity, pv.rank)[32], tag, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-    const double* mine = peer_mail(pv.region[pv.rank], parity, tid);
+    __hip_atomic_store(&peer_mail(peer_region(pv, tid), parity, pv.rank)[32], tag, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    const double* mine = peer_mail(peer_region(pv, pv.rank), parity, tid);
     const unsigned long long t0 = wall_clock64();
     while (__hip_atomic_load(&mine[32], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) != tag) {
       if (wall_clock64() - t0 > watchdog) { *s_flag = 0; break; }
@@ -57,7 +65,8 @@ __device__ inline bool peer_exchange_sums(const PeerView& pv, double* row, unsig
   const bool ok = *s_flag != 0;
   if (ok && tid < 32) {
     double s = 0.0;
-    for (int r = 0; r < pv.n; r++) s += __hip_atomic_load(&peer_mail(pv.region[pv.rank], parity, r)[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    char* own = peer_region(pv, pv.rank);
+    for (int r = 0; r < pv.n; r++) s += __hip_atomic_load(&peer_mail(own, parity, r)[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     row[tid] = s;
   }
   __syncthreads();
@@ -77,14 +86,14 @@ __global__ __launch_bounds__(256) void peer_pack_cov_kernel(const float4* __rest
 __global__ void peer_signal_kernel(PeerView pv, unsigned long long gen) {
   __threadfence_system();
   if ((int)threadIdx.x < pv.n)
-    __hip_atomic_store(reinterpret_cast<unsigned long long*>(pv.region[threadIdx.x] + PEER_SIG_OFFSET) + pv.rank, gen, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(reinterpret_cast<unsigned long long*>(peer_region(pv, threadIdx.x) + PEER_SIG_OFFSET) + pv.rank, gen, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 // ONE workgroup waits until every owner has published generation `gen` (a kernel of its own, in stream order before the
 // gather: if the thousands of gather workgroups polled themselves they would fill the GPU with spinning waves and starve the
 // kernels of a slower rank that shares it -- measured: 2 ranks on one GPU, 1M points, the late rank never got a CU)
 __global__ void peer_wait_kernel(PeerView pv, unsigned long long gen, unsigned long long watchdog, int* __restrict__ err) {
   if ((int)threadIdx.x < pv.n) {
-    const unsigned long long* sig = reinterpret_cast<const unsigned long long*>(pv.region[pv.rank] + PEER_SIG_OFFSET) + threadIdx.x;
+    const unsigned long long* sig = reinterpret_cast<const unsigned long long*>(peer_region(pv, pv.rank) + PEER_SIG_OFFSET) + threadIdx.x;
     const unsigned long long t0 = wall_clock64();
     while (__hip_atomic_load(sig, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < gen) {
       if (wall_clock64() - t0 > watchdog) { atomicAdd(err, 1); break; }
@@ -100,7 +109,7 @@ __global__ __launch_bounds__(256) void peer_gather_cov_kernel(PeerView pv, size_
   if (j >= n) return;
   const int owner = j / chunk;
   if (owner == pv.rank) return;
-  const float4* stage = reinterpret_cast<const float4*>(pv.region[owner] + stage_offset);
+  const float4* stage = reinterpret_cast<const float4*>(peer_region(pv, owner) + stage_offset);
   const size_t k = (size_t)(j - owner * chunk);
   const int i = order[j];
   cov[2 * (size_t)i] = stage[2 * k];
