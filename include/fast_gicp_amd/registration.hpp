@@ -18,6 +18,7 @@
 #pragma once
 #include <array>
 #include <cmath>
+#include <cstddef>
 #include <cstdio>
 #include <cstring>
 #include <limits>
@@ -163,6 +164,26 @@ inline void print_lm_trace(const std::vector<double>& rows) {
   }
   std::fflush(stdout);  // (std::endl in the reference)
 }
+/// xyz of a cloud as the C ABI wants it: when the point type starts with three packed floats and is 12 or 16 bytes (PointXYZ
+/// here, pcl::PointXYZ upstream) the cloud's own storage is handed over with its stride -- no 200 KB repack per setInputSource;
+/// any other point type is packed into `scratch` (stride 3)
+template <typename PointT>
+struct XyzView {
+  const float* data;
+  int stride;
+  XyzView(const PointCloud<PointT>& c, std::vector<float>& scratch) {
+    constexpr bool direct = (sizeof(PointT) == 12 || sizeof(PointT) == 16) && offsetof(PointT, x) == 0 && offsetof(PointT, y) == 4 && offsetof(PointT, z) == 8;
+    if (direct) {
+      data = c.size() ? &c.points[0].x : nullptr;
+      stride = (int)(sizeof(PointT) / sizeof(float));
+    } else {
+      scratch.resize(c.size() * 3);
+      for (size_t i = 0; i < c.size(); i++) { scratch[3 * i] = c.points[i].x; scratch[3 * i + 1] = c.points[i].y; scratch[3 * i + 2] = c.points[i].z; }
+      data = scratch.data();
+      stride = 3;
+    }
+  }
+};
 template <typename PointT>
 inline std::vector<float> pack_xyz(const PointCloud<PointT>& c) {
   std::vector<float> xyz(c.size() * 3);
@@ -368,10 +389,11 @@ public:
   void setInputSource(const PointCloudSourceConstPtr& cloud) override {  // :85-111
     if (cloud == input_) return;
     input_ = cloud;
-    const std::vector<float> xyz = detail::pack_xyz(*cloud);
-    call(fvh_vgicp_set_source_cloud(core_, xyz.data(), (int)cloud->size()), "set_source_cloud");
+    const detail::XyzView<PointSource> view(*cloud, scratch_xyz_);
+    call(fvh_vgicp_set_source_cloud_strided(core_, view.data, (int)cloud->size(), view.stride), "set_source_cloud");
     switch (neighbor_search_method_) {
       case NearestNeighborMethod::CPU_PARALLEL_KDTREE: {
+        const std::vector<float> xyz = detail::pack_xyz(*cloud);
         const std::vector<int> nb = find_neighbors_parallel_kdtree(k_correspondences_, xyz);
         call(fvh_vgicp_set_source_neighbors(core_, k_correspondences_, nb.data()), "set_source_neighbors");
         call(fvh_vgicp_calculate_source_covariances(core_, (int)regularization_method_), "calculate_source_covariances");
@@ -388,10 +410,11 @@ public:
   void setInputTarget(const PointCloudTargetConstPtr& cloud) override {  // :114-141
     if (cloud == target_) return;
     target_ = cloud;
-    const std::vector<float> xyz = detail::pack_xyz(*cloud);
-    call(fvh_vgicp_set_target_cloud(core_, xyz.data(), (int)cloud->size()), "set_target_cloud");
+    const detail::XyzView<PointTarget> view(*cloud, scratch_xyz_);
+    call(fvh_vgicp_set_target_cloud_strided(core_, view.data, (int)cloud->size(), view.stride), "set_target_cloud");
     switch (neighbor_search_method_) {
       case NearestNeighborMethod::CPU_PARALLEL_KDTREE: {
+        const std::vector<float> xyz = detail::pack_xyz(*cloud);
         const std::vector<int> nb = find_neighbors_parallel_kdtree(k_correspondences_, xyz);
         call(fvh_vgicp_set_target_neighbors(core_, k_correspondences_, nb.data()), "set_target_neighbors");
         call(fvh_vgicp_calculate_target_covariances(core_, (int)regularization_method_), "calculate_target_covariances");
@@ -474,6 +497,7 @@ private:
   RegularizationMethod regularization_method_ = RegularizationMethod::PLANE;                     // :26
   NearestNeighborMethod neighbor_search_method_ = NearestNeighborMethod::CPU_PARALLEL_KDTREE;    // :27
   fvh_vgicp* core_ = nullptr;
+  std::vector<float> scratch_xyz_;  // only used for point types that are not 12 / 16 bytes of packed xyz
 };
 
 /// FastGICP (gicp/fast_gicp.hpp:24-98, impl/fast_gicp_impl.hpp) on the HIP engine: the reference class is CPU/OpenMP only;
@@ -512,16 +536,16 @@ public:
   void setInputSource(const PointCloudSourceConstPtr& cloud) override {  // :77-85 (covariances: :103-112, computed eagerly here)
     if (cloud == input_) return;
     input_ = cloud;
-    const std::vector<float> xyz = detail::pack_xyz(*cloud);
-    call(fvh_vgicp_set_source_cloud(core_, xyz.data(), (int)cloud->size()), "set_source_cloud");
+    const detail::XyzView<PointSource> view(*cloud, scratch_xyz_);
+    call(fvh_vgicp_set_source_cloud_strided(core_, view.data, (int)cloud->size(), view.stride), "set_source_cloud");
     call(fvh_vgicp_find_source_neighbors(core_, k_correspondences_), "find_source_neighbors");
     call(fvh_vgicp_calculate_source_covariances(core_, (int)regularization_method_), "calculate_source_covariances");
   }
   void setInputTarget(const PointCloudTargetConstPtr& cloud) override {  // :88-95
     if (cloud == target_) return;
     target_ = cloud;
-    const std::vector<float> xyz = detail::pack_xyz(*cloud);
-    call(fvh_vgicp_set_target_cloud(core_, xyz.data(), (int)cloud->size()), "set_target_cloud");
+    const detail::XyzView<PointTarget> view(*cloud, scratch_xyz_);
+    call(fvh_vgicp_set_target_cloud_strided(core_, view.data, (int)cloud->size(), view.stride), "set_target_cloud");
     call(fvh_vgicp_find_target_neighbors(core_, k_correspondences_), "find_target_neighbors");
     call(fvh_vgicp_calculate_target_covariances(core_, (int)regularization_method_), "calculate_target_covariances");
   }
@@ -597,6 +621,7 @@ private:
   int k_correspondences_ = 20;                                                // :17
   RegularizationMethod regularization_method_ = RegularizationMethod::PLANE;  // :21
   fvh_vgicp* core_ = nullptr;
+  std::vector<float> scratch_xyz_;  // only used for point types that are not 12 / 16 bytes of packed xyz
 };
 
 /// NDTCuda (ndt_cuda.hpp:23-69, impl/ndt_cuda_impl.hpp)
@@ -625,14 +650,14 @@ public:
   void setInputSource(const PointCloudSourceConstPtr& cloud) override {  // ndt_cuda_impl.hpp:52-60
     if (cloud == input_) return;
     input_ = cloud;
-    const std::vector<float> xyz = detail::pack_xyz(*cloud);
-    call(fvh_ndt_set_source_cloud(core_, xyz.data(), (int)cloud->size()), "set_source_cloud");
+    const detail::XyzView<PointSource> view(*cloud, scratch_xyz_);
+    call(fvh_ndt_set_source_cloud_strided(core_, view.data, (int)cloud->size(), view.stride), "set_source_cloud");
   }
   void setInputTarget(const PointCloudTargetConstPtr& cloud) override {  // :63-73
     if (cloud == target_) return;
     target_ = cloud;
-    const std::vector<float> xyz = detail::pack_xyz(*cloud);
-    call(fvh_ndt_set_target_cloud(core_, xyz.data(), (int)cloud->size()), "set_target_cloud");
+    const detail::XyzView<PointTarget> view(*cloud, scratch_xyz_);
+    call(fvh_ndt_set_target_cloud_strided(core_, view.data, (int)cloud->size(), view.stride), "set_target_cloud");
   }
   double getFitnessScore(double max_range = std::numeric_limits<double>::max()) override {
     double T16[16], score = 0;
@@ -686,6 +711,7 @@ protected:
 
 private:
   fvh_ndt* core_ = nullptr;
+  std::vector<float> scratch_xyz_;
 };
 
 }  // namespace fast_gicp

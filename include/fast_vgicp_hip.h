@@ -92,6 +92,10 @@ int fvh_vgicp_set_voxel_accumulation_mode(fvh_vgicp* h, int mode);
 int fvh_vgicp_swap_source_and_target(fvh_vgicp* h);                                          /* [VC]:44, [VCU]:97-107 */
 int fvh_vgicp_set_source_cloud(fvh_vgicp* h, const float* xyz, int n);                       /* [VC]:45 */
 int fvh_vgicp_set_target_cloud(fvh_vgicp* h, const float* xyz, int n);                       /* [VC]:46 */
+/* same from a HOST array of points `stride_floats` (3 or 4) floats apart -- e.g. &cloud->points[0].x of a pcl::PointCloud<pcl::PointXYZ>
+ * (16-byte points): the PointT -> Vector3f repack of fast_vgicp_cuda_impl.hpp:87-90,116-119 disappears */
+int fvh_vgicp_set_source_cloud_strided(fvh_vgicp* h, const float* xyz, int n, int stride_floats);
+int fvh_vgicp_set_target_cloud_strided(fvh_vgicp* h, const float* xyz, int n, int stride_floats);
 /* same, but the cloud is already in device memory (stride_floats = 3 or 4); D2D copy on the handle's stream */
 int fvh_vgicp_set_source_cloud_device(fvh_vgicp* h, const float* d_xyz, int n, int stride_floats);
 int fvh_vgicp_set_target_cloud_device(fvh_vgicp* h, const float* d_xyz, int n, int stride_floats);
@@ -215,6 +219,8 @@ int fvh_ndt_set_precision(fvh_ndt* h, int precision);
 int fvh_ndt_swap_source_and_target(fvh_ndt* h);                                              /* [NC]:41, [NCU]:90-93 */
 int fvh_ndt_set_source_cloud(fvh_ndt* h, const float* xyz, int n);                           /* [NC]:42 (invalidates the source voxel map) */
 int fvh_ndt_set_target_cloud(fvh_ndt* h, const float* xyz, int n);                           /* [NC]:43 */
+int fvh_ndt_set_source_cloud_strided(fvh_ndt* h, const float* xyz, int n, int stride_floats);
+int fvh_ndt_set_target_cloud_strided(fvh_ndt* h, const float* xyz, int n, int stride_floats);
 int fvh_ndt_set_source_cloud_device(fvh_ndt* h, const float* d_xyz, int n, int stride_floats);
 int fvh_ndt_set_target_cloud_device(fvh_ndt* h, const float* d_xyz, int n, int stride_floats);
 int fvh_ndt_create_voxelmaps(fvh_ndt* h);                                                    /* [NC]:45 (lazy; source skipped in P2D) */
