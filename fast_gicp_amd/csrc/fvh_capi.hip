@@ -296,9 +296,16 @@ struct Engine {
     peer.n = 1; peer.rank = 0; peer.ranks_on_device = 1;
   }
   int upload_offsets() {
-    hipError_t e = offsets_dev.ensure(offsets_host.size() * sizeof(int));
+    // device layout: n_off x {dx, dy, dz}, then n_off packed triples (10 bits each, biased by 512): one register per offset in the cost kernel
+    std::vector<int> dev(offsets_host);
+    for (int o = 0; o < n_off; o++) {
+      for (int a = 0; a < 3; a++)
+        if (std::abs(offsets_host[3 * o + a]) > 511) return fail(FVH_ERR_INVALID_ARGUMENT, "neighbor offsets beyond +-511 voxels are not supported");
+      dev.push_back((offsets_host[3 * o] + 512) | ((offsets_host[3 * o + 1] + 512) << 10) | ((offsets_host[3 * o + 2] + 512) << 20));
+    }
+    hipError_t e = offsets_dev.ensure(dev.size() * sizeof(int));
     if (e != hipSuccess) return hipfail(e, "hipMalloc");
-    e = hipMemcpyAsync(offsets_dev.p, offsets_host.data(), offsets_host.size() * sizeof(int), hipMemcpyHostToDevice, stream);
+    e = hipMemcpyAsync(offsets_dev.p, dev.data(), dev.size() * sizeof(int), hipMemcpyHostToDevice, stream);
     if (e != hipSuccess) return hipfail(e, "hipMemcpyAsync");
     e = hipStreamSynchronize(stream);  // offsets_host may be reassigned by the caller right after
     if (e != hipSuccess) return hipfail(e, "hipStreamSynchronize");
@@ -783,7 +790,7 @@ struct CostShape { int group, groups_per_src; long long n_walk; int blocks; };
 inline CostShape cost_shape(const Engine* e, const CostSource& src) {
   static const long long target_items = [] { const char* v = getenv("FVH_COST_TARGET_ITEMS"); return v ? atoll(v) : 256LL * 256 * 2; }();
   static const int max_blocks = [] { const char* v = getenv("FVH_COST_MAX_BLOCKS"); int b = v ? atoi(v) : MAX_COST_BLOCKS; return b < 1 ? 1 : (b > MAX_COST_BLOCKS ? MAX_COST_BLOCKS : b); }();
-  static const int group_max = [] { const char* v = getenv("FVH_COST_GROUP_MAX"); return v ? std::max(1, atoi(v)) : COST_CH; }();
+  static const int group_max = [] { const char* v = getenv("FVH_COST_GROUP_MAX"); return v ? std::min(std::max(1, atoi(v)), COST_CH) : COST_CH; }();  // the kernel keeps one item's lookups in flight together: at most COST_CH
   const int n_off = src.n_off_override > 0 ? src.n_off_override : e->n_off;
   CostShape s;
   const int groups = (int)std::min<long long>(n_off, std::max<long long>((n_off + group_max - 1) / group_max, target_items / std::max(src.n_upper, 1)));
@@ -804,7 +811,7 @@ int launch_cost(Engine* e, const CostSource& src, const VoxelMapDev& vm, int hos
   P.src_pts = src.pts; P.src_cov = src.cov; P.d_n_src = src.d_n; P.n_src = src.n_upper; P.order = src.order;
   P.table = vm.table.as<uint4>(); P.keys = vm.keys_cur(); P.mask = vm.capacity - 1; P.res = vm.res;
   const int n_off = src.n_off_override > 0 ? src.n_off_override : e->n_off;
-  P.offsets = e->offsets_dev.as<int>(); P.n_off = n_off;
+  P.offsets = e->offsets_dev.as<int>(); P.offsets_packed = e->offsets_dev.as<int>() + 3 * (size_t)e->n_off; P.n_off = n_off;
   const CostShape shape = cost_shape(e, src);
   P.group = shape.group;
   P.groups_per_src = shape.groups_per_src;
@@ -1759,6 +1766,15 @@ int fvh_debug_persist_timing(unsigned long long* out, int reset) {  // out: [16]
   if (reset) {
     void* p = nullptr;
     if (hipGetSymbolAddress(&p, HIP_SYMBOL(g_ptime)) != hipSuccess || hipMemset(p, 0, bytes) != hipSuccess) return FVH_ERR_HIP;
+  }
+  return FVH_OK;
+}
+int fvh_debug_main_timing(unsigned long long* out, int reset) {  // out: [16][512][12]
+  const size_t bytes = sizeof(unsigned long long) * 16 * 512 * 12;
+  if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(g_mtime), bytes) != hipSuccess) return FVH_ERR_HIP;
+  if (reset) {
+    void* p = nullptr;
+    if (hipGetSymbolAddress(&p, HIP_SYMBOL(g_mtime)) != hipSuccess || hipMemset(p, 0, bytes) != hipSuccess) return FVH_ERR_HIP;
   }
   return FVH_OK;
 }

@@ -72,6 +72,7 @@ struct CostParams {
   unsigned mask;
   double res;
   const int* offsets;         // n_off x 3
+  const int* offsets_packed;  // n_off x (dx + 512) | (dy + 512) << 10 | (dz + 512) << 20
   int n_off;
   int group;                  // offsets per work item
   int groups_per_src;         // ceil(n_off / group)
@@ -598,10 +599,19 @@ __device__ unsigned long long g_ptime[16][512][12];  // persistent kernel, per t
 #define FVH_STAMP(i) do { if (threadIdx.x == 0) stamp[i] = wall_clock64(); } while (0)
 #define FVH_PT_MIN(trip, k) do { if (threadIdx.x == 0 && (trip) < 16 && blockIdx.x < 512) g_ptime[trip][blockIdx.x][k] = wall_clock64(); } while (0)
 #define FVH_PT_MAX(trip, k) FVH_PT_MIN(trip, k)
+// main-loop timeline of wave 0 (tools/main_timing.py): waits for everything in flight, then stamps -- it serialises what the
+// scheduler would overlap, so the segments are upper bounds
+__device__ unsigned long long g_mtime[16][512][12];
+#define FVH_MT(trip, k) do { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); if (threadIdx.x == 0 && (trip) < 16 && blockIdx.x < 512) g_mtime[trip][blockIdx.x][k] = wall_clock64(); } while (0)
 #else
 #define FVH_STAMP(i) do { } while (0)
 #define FVH_PT_MIN(trip, k) do { } while (0)
 #define FVH_PT_MAX(trip, k) do { } while (0)
+#ifdef FVH_ASM_MARKS  // static instruction counts per section: hipcc -S -DFVH_ASM_MARKS, then tools/count_isa.py
+#define FVH_MT(trip, k) asm volatile("; FVH_MARK " #k)
+#else
+#define FVH_MT(trip, k) do { } while (0)
+#endif
 #endif
 
 // Workgroups per CU the register allocator must make room for (the persistent grid has to be co-resident, so this is part
@@ -687,94 +697,106 @@ __global__ FVH_COST_BOUNDS void cost_kernel(CostParams P) {
     Real acc_y = 0;  // fused: trial error with the old ids
     Vec3<Real> q = {0, 0, 0};
     bool any_hit = false;  // an element without correspondences contributes exact zeros (its q may be non-finite: 0 * NaN)
+    if (PERSIST) FVH_MT(gen, 0);
     if (w < n_items) {
     const int i0 = w / P.groups_per_src;
     const int g = w - i0 * P.groups_per_src;
     const int i = P.order ? P.order[i0] : i0;
-    // ---- round trip 1: the source element ----
+    const int o_begin = g * P.group, o_end = min(P.n_off, o_begin + P.group);
+    // The loop is a chain of dependent memory round trips (0.3 us each when coalesced, 0.5-0.8 us when scattered; measured
+    // with tools/main_timing.py) with ~4 us of fp64 arithmetic between them, on 2 waves per SIMD -- nothing hides a round trip
+    // unless the SAME wave has independent work for it. So every load is issued as soon as its address is known:
+    //   round trip 1: the source element, and -- their addresses depend on (i, g) only -- the stored ids and the neighbour
+    //                 offsets of the first chunk;
+    //   round trip 2: the records of the stored ids (fused trip), in flight during q, the voxel coordinate and R_lin C R_lin^T;
+    //   round trip 3: the first key probes, in flight during the trial error of the stored ids;
+    //   round trip 4: only for slots whose voxel changed (and rare probe continuations), in flight during R_ev C R_ev^T.
+    // The order of the arithmetic is chosen for registers as much as for latency: 40 VGPRs of records are live from round
+    // trip 2 on, so the two rotations of C_A are never live together (a first version that was, spilled 100 registers and ran
+    // 40 % slower). Measured effect of the early issue at 17k points: none (8.3 us per trip before and after) -- with two
+    // waves per SIMD the loop is bound by VALU issue (~1,650 VALU instructions per wave and trip, ~4.25 cycles each, PMC), and
+    // the other wave already filled the round trips; the younger workgroup of a CU is the one that finishes late.
+    // ---- round trip 1 ----
     const float4 a4 = P.src_pts[i];
     float4 c0 = make_float4(0, 0, 0, 0), c1 = c0;
     if (MODE != MODE_NDT_P2D && do_cost) { c0 = P.src_cov[2 * i]; c1 = P.src_cov[2 * i + 1]; }
+    const bool ext_fused = EXT_OK && external && fused;
+    int b[COST_CH], bo[COST_CH];
+    int ofp[COST_CH];  // packed neighbour offsets
+    float4 q1[COST_CH], q2[COST_CH];
+    float2 q3[COST_CH];  // voxel records (q3 = {c_yz, c_zz}: only 8 of its 16 bytes are data): of the old ids first (fused), then of the ids of this evaluation
+    // (a work item is at most COST_CH offsets -- cost_shape() -- so this is the whole item: no chunk loop)
+#pragma unroll
+    for (int c = 0; c < COST_CH; c++) {
+      const bool in = o_begin + c < o_end;
+      bo[c] = -1; b[c] = -1; ofp[c] = 0;
+      if (fused) bo[c] = in ? corr_old[(size_t)i * P.n_off + o_begin + c] : -1;
+      if (do_find) {
+        ofp[c] = P.offsets_packed[min(o_begin + c, o_end - 1)];
+      } else if (ext_fused) {
+        b[c] = in ? corr_new[(size_t)i * P.n_off + o_begin + c] : -1;
+      } else {
+        b[c] = in ? corr_old[(size_t)i * P.n_off + o_begin + c] : -1;
+      }
+    }
+    if (PERSIST) FVH_MT(gen, 1);
+    // ---- round trip 2 (fused): issued before the arithmetic below, which does not need it ----
+    if (fused) {  // the records of the stored ids (bucket 0 for "none")
+#pragma unroll
+      for (int c = 0; c < COST_CH; c++) {
+        const size_t base = (size_t)max(bo[c], 0) * 4;
+        q1[c] = tf[base + 1]; q2[c] = tf[base + 2]; q3[c] = *reinterpret_cast<const float2*>(tf + base + 3);
+      }
+    }
     const Vec3<Real> a = {(Real)a4.x, (Real)a4.y, (Real)a4.z};
     const Pose<Real>* pose_ptr = s_pose;
-    asm volatile("" : "+v"(pose_ptr));  // opaque: the loads below stay inside the iteration instead of becoming 48 loop-invariant registers
-    const Pose<Real> lin = pose_ptr[0], ev = pose_ptr[1];
+    asm volatile("" : "+v"(pose_ptr));  // opaque: the pose loads stay inside the iteration instead of becoming 48 loop-invariant registers
     Sym3<Real> RCR = {0, 0, 0, 0, 0, 0}, RCR_old = {0, 0, 0, 0, 0, 0};
-    if (MODE != MODE_NDT_P2D && do_cost) {
-      const Sym3<Real> CA = {(Real)c0.x, (Real)c0.y, (Real)c0.z, (Real)c0.w, (Real)c1.x, (Real)c1.y};
-      // the ids found by THIS launch are linearised at `ev` when fused, at `lin` otherwise
-      RCR = rotate_cov(fused ? ev.r : lin.r, CA);
-      if (fused) RCR_old = rotate_cov(lin.r, CA);
-    }
-    q = transform(ev, a);
     int cx = 0, cy = 0, cz = 0;
     bool coord_ok = true;  // false: non-finite / out-of-range source point -> no correspondences (and no (int)floor(NaN))
-    if (do_find) {
-      const Vec3<Real> ql = fused ? q : transform(lin, a);
-      const Real fx = floor(ql.x / res - (Real)0.5), fy = floor(ql.y / res - (Real)0.5), fz = floor(ql.z / res - (Real)0.5);
-      coord_ok = voxel_index_ok(fx, fy, fz);
-      cx = coord_ok ? (int)fx : 0;
-      cy = coord_ok ? (int)fy : 0;
-      cz = coord_ok ? (int)fz : 0;
-    }
-    const int o_begin = g * P.group, o_end = min(P.n_off, o_begin + P.group);
-    for (int oc = o_begin; oc < o_end; oc += COST_CH) {
-      int b[COST_CH], bo[COST_CH];
-      // ---- round trip 2: COST_CH independent lookups in flight (first probe of each, and/or the stored ids) ----
-      if (fused) {
-#pragma unroll
-        for (int c = 0; c < COST_CH; c++) bo[c] = (oc + c < o_end) ? corr_old[(size_t)i * P.n_off + oc + c] : -1;
-      }
-      float4 q1[COST_CH], q2[COST_CH];
-      float2 q3[COST_CH];  // voxel records (q3 = {c_yz, c_zz}: only 8 of its 16 bytes are data): of the old ids first (fused), then of the ids of this evaluation
+    {
+      const Pose<Real> ev = pose_ptr[1];
+      q = transform(ev, a);
       if (do_find) {
-        unsigned long long key[COST_CH];
-        unsigned slot[COST_CH];
-        unsigned long long k0[COST_CH];
-        constexpr unsigned long long DEAD_KEY = FVH_EMPTY_KEY - 1;  // no voxel has it (keys use 63 bits): "this lookup does not exist" without a flag register
+        Vec3<Real> ql = q;
+        if (!fused) { const Pose<Real> lin = pose_ptr[0]; ql = transform(lin, a); }
+        const Real fx = floor(ql.x / res - (Real)0.5), fy = floor(ql.y / res - (Real)0.5), fz = floor(ql.z / res - (Real)0.5);
+        coord_ok = voxel_index_ok(fx, fy, fz);
+        cx = coord_ok ? (int)fx : 0;
+        cy = coord_ok ? (int)fy : 0;
+        cz = coord_ok ? (int)fz : 0;
+      }
+    }
+    // the ids found by THIS launch are linearised at `ev` when fused (R_ev C R_ev^T is formed after the probes, below), at
+    // `lin` otherwise; the stored ids of a fused trip use `lin`
+    if (MODE != MODE_NDT_P2D && do_cost) {
+      const Sym3<Real> CA = {(Real)c0.x, (Real)c0.y, (Real)c0.z, (Real)c0.w, (Real)c1.x, (Real)c1.y};
+      const Pose<Real>& lin = pose_ptr[0];
+      Real Rl[9];
+#pragma unroll
+      for (int k = 0; k < 9; k++) Rl[k] = lin.r[k];
+      if (fused) RCR_old = rotate_cov(Rl, CA); else RCR = rotate_cov(Rl, CA);
+    }
+    if (PERSIST) FVH_MT(gen, 2);
+    {
+      unsigned long long key[COST_CH];
+      unsigned slot[COST_CH];
+      unsigned long long k0[COST_CH];
+      constexpr unsigned long long DEAD_KEY = FVH_EMPTY_KEY - 1;  // no voxel has it (keys use 63 bits): "this lookup does not exist" without a flag register
+      // ---- round trip 3: COST_CH independent first probes in flight ----
+      if (do_find) {
 #pragma unroll
         for (int c = 0; c < COST_CH; c++) {
-          const int o = min(oc + c, o_end - 1);
-          const int x = cx + P.offsets[3 * o], y = cy + P.offsets[3 * o + 1], z = cz + P.offsets[3 * o + 2];
-          const bool live = (oc + c < o_end) && coord_ok && coord_in_range(x, y, z);
+          const int x = cx + (int)(ofp[c] & 1023) - 512, y = cy + (int)((ofp[c] >> 10) & 1023) - 512, z = cz + (int)((ofp[c] >> 20) & 1023) - 512;
+          const bool live = (o_begin + c < o_end) && coord_ok && coord_in_range(x, y, z);
           key[c] = live ? pack_key(x, y, z) : DEAD_KEY;
           slot[c] = hash_key(key[c]) & P.mask;
           k0[c] = P.keys[slot[c]];
         }
-        if (fused) {  // the old ids' records, in flight together with the probes
-#pragma unroll
-          for (int c = 0; c < COST_CH; c++) {
-            const size_t base = (size_t)max(bo[c], 0) * 4;
-            q1[c] = tf[base + 1]; q2[c] = tf[base + 2]; q3[c] = *reinterpret_cast<const float2*>(tf + base + 3);
-          }
-        }
-#pragma unroll
-        for (int c = 0; c < COST_CH; c++) {
-          const unsigned long long k = k0[c];
-          int r = -1;
-          if (k == key[c]) r = (int)slot[c];
-          else if (k != FVH_EMPTY_KEY && key[c] != DEAD_KEY) r = probe_continue(P.keys, P.mask, key[c], slot[c]);  // rare at load <= 0.25
-          b[c] = r;
-          if (oc + c < o_end) corr_new[(size_t)i * P.n_off + oc + c] = r;
-        }
-      } else if (EXT_OK && fused) {  // external find (FastGICP): the new ids are already in the other buffer; the old ids' records first, as above
-#pragma unroll
-        for (int c = 0; c < COST_CH; c++) {
-          b[c] = (oc + c < o_end) ? corr_new[(size_t)i * P.n_off + oc + c] : -1;
-          const size_t base = (size_t)max(bo[c], 0) * 4;
-          q1[c] = tf[base + 1]; q2[c] = tf[base + 2]; q3[c] = *reinterpret_cast<const float2*>(tf + base + 3);
-        }
-      } else {
-#pragma unroll
-        for (int c = 0; c < COST_CH; c++) b[c] = (oc + c < o_end) ? corr_old[(size_t)i * P.n_off + oc + c] : -1;
       }
-      if (!do_cost) continue;
-      // ---- round trip 3: the voxel records of all hits, unconditional loads (bucket 0 for misses) ----
-      // Fused trip: the records of the OLD ids were requested above, together with the key probes (they only need the stored
-      // ids, not the probe results), and near convergence the new id of a slot IS its old id -- then the record is already in
-      // registers and the third dependent round trip disappears; only slots whose voxel changed load again, after the trial
-      // error of the old ids has consumed the old record.
-      if (fused) {  // trial error with the OLD ids
+      if (PERSIST) FVH_MT(gen, 3);
+      // ---- fused trip: trial error with the OLD ids while the probes are in flight ----
+      if (fused && do_cost) {
 #pragma unroll
         for (int c = 0; c < COST_CH; c++) {
           if (bo[c] < 0) continue;
@@ -797,6 +819,24 @@ __global__ FVH_COST_BOUNDS void cost_kernel(CostParams P) {
           const Vec3<Real> Me = mul(M, e);
           acc_y += wgt * (e.x * Me.x + e.y * Me.y + e.z * Me.z);
         }
+      }
+      if (PERSIST) FVH_MT(gen, 4);
+      if (do_find) {
+#pragma unroll
+        for (int c = 0; c < COST_CH; c++) {
+          const unsigned long long k = k0[c];
+          int r = -1;
+          if (k == key[c]) r = (int)slot[c];
+          else if (k != FVH_EMPTY_KEY && key[c] != DEAD_KEY) r = probe_continue(P.keys, P.mask, key[c], slot[c]);  // rare at load <= 0.25
+          b[c] = r;
+          if (o_begin + c < o_end) corr_new[(size_t)i * P.n_off + o_begin + c] = r;
+        }
+      }
+      if (do_cost) {
+      if (PERSIST) FVH_MT(gen, 5);
+      // ---- round trip 4: the voxel records of the ids of this evaluation (bucket 0 for misses). Fused trip: near convergence
+      // the new id of a slot IS its old id -- then the record is already in registers; only slots whose voxel changed load.
+      if (fused) {
 #pragma unroll
         for (int c = 0; c < COST_CH; c++) {
           if (b[c] >= 0 && b[c] != bo[c]) {  // the voxel of this slot changed: fetch its record now
@@ -811,6 +851,16 @@ __global__ FVH_COST_BOUNDS void cost_kernel(CostParams P) {
           q1[c] = tf[base + 1]; q2[c] = tf[base + 2]; q3[c] = *reinterpret_cast<const float2*>(tf + base + 3);
         }
       }
+      if (fused && MODE != MODE_NDT_P2D) {  // R_ev C_A R_ev^T, while the records of changed ids are in flight
+        const Pose<Real>* pose_ptr2 = s_pose;
+        asm volatile("" : "+v"(pose_ptr2) : : "memory");  // not before this point (see the register note above)
+        const Sym3<Real> CA = {(Real)c0.x, (Real)c0.y, (Real)c0.z, (Real)c0.w, (Real)c1.x, (Real)c1.y};
+        Real Re[9];
+#pragma unroll
+        for (int k = 0; k < 9; k++) Re[k] = pose_ptr2[1].r[k];
+        RCR = rotate_cov(Re, CA);
+      }
+      if (PERSIST) FVH_MT(gen, 6);
 #pragma unroll
       for (int c = 0; c < COST_CH; c++) {
         if (b[c] < 0) continue;
@@ -831,9 +881,11 @@ __global__ FVH_COST_BOUNDS void cost_kernel(CostParams P) {
         hit_term<Real>(it, q, mu, M, wgt, do_deriv);
         any_hit = true;
       }
+      }  // do_cost
     }
     }  // w < n_items
     if (!do_cost) continue;  // host-mode PH_FIND_ONLY
+    if (PERSIST) FVH_MT(gen, 7);
 
     // ---- per-item wave reduction: transposing butterfly over 32 slots (28 sums, the fused trial error, 3 zeros) ----
     // Step m = 32, 16, 8, 4, 2: the lane pair (L, L ^ m) splits its current slots in halves, each lane keeps one half and
@@ -875,6 +927,7 @@ __global__ FVH_COST_BOUNDS void cost_kernel(CostParams P) {
       v[0] += __shfl_xor(v[0], 1);
       wacc += v[0];
     }
+    if (PERSIST) FVH_MT(gen, 8);
   }
 
   // ---- workgroup reduction: 4 waves x 32 slots through 1 KB of LDS ----------------------------------------
