@@ -69,6 +69,38 @@ __device__ __forceinline__ Sym3<T> rotate_cov(const T* R, const Sym3<T>& C) {
   return S;
 }
 
+// adjugate (transposed cofactors) and determinant of a symmetric 3x3: A^-1 = adj(A) / det
+template <typename T>
+__device__ __forceinline__ Sym3<T> adjugate(const Sym3<T>& A, T& det) {
+  Sym3<T> C;
+  C.xx = A.yy * A.zz - A.yz * A.yz;
+  C.xy = A.xz * A.yz - A.xy * A.zz;
+  C.xz = A.xy * A.yz - A.xz * A.yy;
+  C.yy = A.xx * A.zz - A.xz * A.xz;
+  C.yz = A.xy * A.xz - A.xx * A.yz;
+  C.zz = A.xx * A.yy - A.xy * A.xy;
+  det = A.xx * C.xx + A.xy * C.xy + A.xz * C.xz;
+  return C;
+}
+
+// w / d without the range handling of an IEEE division (v_div_scale / v_div_fmas / v_div_fixup: 12 instructions): hardware
+// reciprocal seed + two Newton steps, ~1 ulp. For determinants of covariance sums -- normal, far from the exponent limits; a
+// zero determinant gives NaN instead of inf, and both poison the sums the same way.
+__device__ __forceinline__ double fast_div(double w, double d) {
+  double r = __builtin_amdgcn_rcp(d);
+  r = fma(r, fma(-d, r, 1.0), r);
+  r = fma(r, fma(-d, r, 1.0), r);
+  return w * r;
+}
+__device__ __forceinline__ float fast_div(float w, float d) { return w / d; }
+// a / b, correctly rounded, from the correctly rounded y = 1 / b (Markstein: q0 = RN(a y), r = a - b q0 exact in the fma,
+// RN(q0 + r y) is the rounded quotient) -- three instructions per quotient for a divisor shared by the whole launch
+__device__ __forceinline__ double div_by(double a, double b, double y) {
+  const double q0 = a * y;
+  return fma(fma(-q0, b, a), y, q0);
+}
+__device__ __forceinline__ float div_by(float a, float b, float) { return a / b; }
+
 // inverse of a symmetric 3x3 by cofactors (what Eigen's fixed-size inverse does)
 template <typename T>
 __device__ __forceinline__ Sym3<T> inverse(const Sym3<T>& A) {
@@ -210,13 +242,15 @@ __device__ __forceinline__ bool voxel_index_ok(T fx, T fy, T fz) {
   return fabs(fx) < lim && fabs(fy) < lim && fabs(fz) < lim;  // false for NaN
 }
 // 64-bit mix (murmur3 finaliser); the bucket layout is private so the hash is ours to choose
+// Multiplicative (Fibonacci) hash of the packed voxel key: two 32-bit multiplies. The GOOD bits are the high ones -- every
+// input bit reaches them -- so tables index with hash_slot() (top log2(capacity) bits), never with the low bits.
+// (Round 1 used the 64-bit murmur finaliser: two 64-bit multiplies = eight quarter-rate 32-bit multiplies per lookup, ~5 % of
+// the VALU time of the LM kernel's main loop, for a table whose keys are small consecutive integers.)
 __device__ __forceinline__ unsigned hash_key(unsigned long long k) {
-  k ^= k >> 33;
-  k *= 0xff51afd7ed558ccdull;
-  k ^= k >> 33;
-  k *= 0xc4ceb9fe1a85ec53ull;
-  k ^= k >> 33;
-  return (unsigned)k;
+  return (unsigned)k * 0x9E3779B1u + (unsigned)(k >> 32) * 0x85EBCA77u;
+}
+__device__ __forceinline__ unsigned hash_slot(unsigned long long k, unsigned mask /* capacity - 1, capacity a power of two */) {
+  return mask ? hash_key(k) >> __builtin_clz(mask) : 0u;
 }
 
 // order-preserving float <-> uint mapping for atomicMin/Max

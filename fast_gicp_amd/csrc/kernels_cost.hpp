@@ -18,6 +18,7 @@
 // pose in HBM. No host round trip inside the loop.
 #pragma once
 #include <cstddef>
+#include <type_traits>
 
 #include "dev_math.hpp"
 #include "kernels_peer.hpp"
@@ -70,7 +71,7 @@ struct CostParams {
   const uint4* table;                // voxel records (64 B per bucket)
   const unsigned long long* keys;    // voxel keys of the same buckets, dense (kernels_voxelmap.hpp)
   unsigned mask;
-  double res;
+  double res, inv_res;        // voxel resolution and its correctly rounded reciprocal (host)
   const int* offsets;         // n_off x 3
   const int* offsets_packed;  // n_off x (dx + 512) | (dy + 512) << 10 | (dz + 512) << 20
   int n_off;
@@ -509,15 +510,25 @@ struct ItemAcc {
   Vec3<Real> g;
   Real err;
 };
+// One correspondence with combined covariance A = C_B + R C_A R^T and weight w: the Mahalanobis matrix w A^-1 is applied as
+// (w / det A) adj(A) -- one division, and the adjugate is never scaled on its own.
 template <typename Real>
-__device__ __forceinline__ void hit_term(ItemAcc<Real>& it, const Vec3<Real>& q, const Vec3<Real>& mu, const Sym3<Real>& M, Real w, bool deriv) {
+__device__ __forceinline__ void hit_term(ItemAcc<Real>& it, const Vec3<Real>& q, const Vec3<Real>& mu, const Sym3<Real>& A, Real w, bool deriv) {
   const Vec3<Real> e = {mu.x - q.x, mu.y - q.y, mu.z - q.z};
-  const Vec3<Real> Me = mul(M, e);
-  it.err += w * (e.x * Me.x + e.y * Me.y + e.z * Me.z);
+  Real det;
+  const Sym3<Real> C = adjugate(A, det);
+  const Real s = fast_div(w, det);
+  const Vec3<Real> Ce = mul(C, e);
+  it.err += s * (e.x * Ce.x + e.y * Ce.y + e.z * Ce.z);
   if (!deriv) return;
-  it.g.x += w * Me.x; it.g.y += w * Me.y; it.g.z += w * Me.z;
-  it.S.xx += w * M.xx; it.S.xy += w * M.xy; it.S.xz += w * M.xz; it.S.yy += w * M.yy; it.S.yz += w * M.yz; it.S.zz += w * M.zz;
+  it.g.x += s * Ce.x; it.g.y += s * Ce.y; it.g.z += s * Ce.z;
+  it.S.xx += s * C.xx; it.S.xy += s * C.xy; it.S.xz += s * C.xz; it.S.yy += s * C.yy; it.S.yz += s * C.yz; it.S.zz += s * C.zz;
 }
+// the weight sqrt(n) stored with a voxel record (vm_finalize_kernel / gicp_records_kernel): a double in q3.zw
+template <typename Real>
+__device__ __forceinline__ Real record_weight(const float4& q3) { return (Real)__hiloint2double(__float_as_int(q3.w), __float_as_int(q3.z)); }
+template <typename Real>
+__device__ __forceinline__ Real record_weight(const float2&) { return (Real)1; }  // (NDT records carry none: never called)
 // v[0] = err, v[1..6] = b, v[7..12] = H_rr (xx xy xz yy yz zz), v[13..21] = H_rt (row-major), v[22..27] = H_tt
 template <typename Real>
 __device__ __forceinline__ void item_sums(double* v, const ItemAcc<Real>& it, const Vec3<Real>& q) {
@@ -673,7 +684,7 @@ __global__ FVH_COST_BOUNDS void cost_kernel(CostParams P) {
   // before the lookups start.
   // (s_pose[0] = lin: rotation used by the cached Mahalanobis of the OLD ids; s_pose[1] = ev: evaluation pose, also the
   // linearisation pose of the NEW ids; filled before the first trip and by the barrier code of every persistent trip)
-  const Real res = (Real)P.res;
+  const Real res = (Real)P.res, inv_res = (Real)P.inv_res;
   const int n_src = P.d_n_src ? *P.d_n_src : P.n_src;
   const int w_lo = (P.item_hi > 0 ? min(P.item_lo, n_src) : 0) * P.groups_per_src;           // this rank's tile of the item list
   const int n_items = (P.item_hi > 0 ? min(P.item_hi, n_src) : n_src) * P.groups_per_src;     // (end of the range)
@@ -724,7 +735,10 @@ __global__ FVH_COST_BOUNDS void cost_kernel(CostParams P) {
     int b[COST_CH], bo[COST_CH];
     int ofp[COST_CH];  // packed neighbour offsets
     float4 q1[COST_CH], q2[COST_CH];
-    float2 q3[COST_CH];  // voxel records (q3 = {c_yz, c_zz}: only 8 of its 16 bytes are data): of the old ids first (fused), then of the ids of this evaluation
+    // voxel records: of the old ids first (fused), then of the ids of this evaluation. q3 = {c_yz, c_zz, weight sqrt(n) as a double};
+    // NDT does not use the weight and loads 8 bytes only
+    using Q3 = typename std::conditional<MODE == MODE_VGICP, float4, float2>::type;
+    Q3 q3[COST_CH];
     // (a work item is at most COST_CH offsets -- cost_shape() -- so this is the whole item: no chunk loop)
 #pragma unroll
     for (int c = 0; c < COST_CH; c++) {
@@ -745,7 +759,7 @@ __global__ FVH_COST_BOUNDS void cost_kernel(CostParams P) {
 #pragma unroll
       for (int c = 0; c < COST_CH; c++) {
         const size_t base = (size_t)max(bo[c], 0) * 4;
-        q1[c] = tf[base + 1]; q2[c] = tf[base + 2]; q3[c] = *reinterpret_cast<const float2*>(tf + base + 3);
+        q1[c] = tf[base + 1]; q2[c] = tf[base + 2]; q3[c] = *reinterpret_cast<const Q3*>(tf + base + 3);
       }
     }
     const Vec3<Real> a = {(Real)a4.x, (Real)a4.y, (Real)a4.z};
@@ -760,7 +774,7 @@ __global__ FVH_COST_BOUNDS void cost_kernel(CostParams P) {
       if (do_find) {
         Vec3<Real> ql = q;
         if (!fused) { const Pose<Real> lin = pose_ptr[0]; ql = transform(lin, a); }
-        const Real fx = floor(ql.x / res - (Real)0.5), fy = floor(ql.y / res - (Real)0.5), fz = floor(ql.z / res - (Real)0.5);
+        const Real fx = floor(div_by(ql.x, res, inv_res) - (Real)0.5), fy = floor(div_by(ql.y, res, inv_res) - (Real)0.5), fz = floor(div_by(ql.z, res, inv_res) - (Real)0.5);
         coord_ok = voxel_index_ok(fx, fy, fz);
         cx = coord_ok ? (int)fx : 0;
         cy = coord_ok ? (int)fy : 0;
@@ -790,7 +804,7 @@ __global__ FVH_COST_BOUNDS void cost_kernel(CostParams P) {
           const int x = cx + (int)(ofp[c] & 1023) - 512, y = cy + (int)((ofp[c] >> 10) & 1023) - 512, z = cz + (int)((ofp[c] >> 20) & 1023) - 512;
           const bool live = (o_begin + c < o_end) && coord_ok && coord_in_range(x, y, z);
           key[c] = live ? pack_key(x, y, z) : DEAD_KEY;
-          slot[c] = hash_key(key[c]) & P.mask;
+          slot[c] = hash_slot(key[c], P.mask);
           k0[c] = P.keys[slot[c]];
         }
       }
@@ -801,23 +815,25 @@ __global__ FVH_COST_BOUNDS void cost_kernel(CostParams P) {
         for (int c = 0; c < COST_CH; c++) {
           if (bo[c] < 0) continue;
           const float4 o1 = q1[c], o2 = q2[c];
-          const float2 o3 = q3[c];
+          const Q3 o3 = q3[c];
           const int npts = (int)o1.w;
           const Vec3<Real> mu = {(Real)o1.x, (Real)o1.y, (Real)o1.z};
           const Sym3<Real> A = {(Real)o2.x + RCR_old.xx, (Real)o2.y + RCR_old.xy, (Real)o2.z + RCR_old.xz, (Real)o2.w + RCR_old.yy, (Real)o3.x + RCR_old.yz, (Real)o3.y + RCR_old.zz};
           const Vec3<Real> e = {mu.x - q.x, mu.y - q.y, mu.z - q.z};
           Real wgt;
-          if (MODE == MODE_VGICP) {
+          if constexpr (MODE == MODE_VGICP) {
             if (npts <= 0) continue;
-            wgt = sqrt((Real)npts);
+            wgt = record_weight<Real>(o3);
           } else {
             if (npts <= 6) continue;
             const Real ksq = res * res;
             wgt = ksq / (ksq + (e.x * e.x + e.y * e.y + e.z * e.z));
           }
-          const Sym3<Real> M = inverse(A);
-          const Vec3<Real> Me = mul(M, e);
-          acc_y += wgt * (e.x * Me.x + e.y * Me.y + e.z * Me.z);
+          // w e^T A^-1 e = (w / det A) e^T adj(A) e: the adjugate is never scaled
+          Real det;
+          const Sym3<Real> Adj = adjugate(A, det);
+          const Vec3<Real> Ce = mul(Adj, e);
+          acc_y += fast_div(wgt, det) * (e.x * Ce.x + e.y * Ce.y + e.z * Ce.z);
         }
       }
       if (PERSIST) FVH_MT(gen, 4);
@@ -841,14 +857,14 @@ __global__ FVH_COST_BOUNDS void cost_kernel(CostParams P) {
         for (int c = 0; c < COST_CH; c++) {
           if (b[c] >= 0 && b[c] != bo[c]) {  // the voxel of this slot changed: fetch its record now
             const size_t base = (size_t)b[c] * 4;
-            q1[c] = tf[base + 1]; q2[c] = tf[base + 2]; q3[c] = *reinterpret_cast<const float2*>(tf + base + 3);
+            q1[c] = tf[base + 1]; q2[c] = tf[base + 2]; q3[c] = *reinterpret_cast<const Q3*>(tf + base + 3);
           }
         }
       } else {
 #pragma unroll
         for (int c = 0; c < COST_CH; c++) {
           const size_t base = (size_t)max(b[c], 0) * 4;
-          q1[c] = tf[base + 1]; q2[c] = tf[base + 2]; q3[c] = *reinterpret_cast<const float2*>(tf + base + 3);
+          q1[c] = tf[base + 1]; q2[c] = tf[base + 2]; q3[c] = *reinterpret_cast<const Q3*>(tf + base + 3);
         }
       }
       if (fused && MODE != MODE_NDT_P2D) {  // R_ev C_A R_ev^T, while the records of changed ids are in flight
@@ -868,17 +884,16 @@ __global__ FVH_COST_BOUNDS void cost_kernel(CostParams P) {
         const Vec3<Real> mu = {(Real)q1[c].x, (Real)q1[c].y, (Real)q1[c].z};
         const Sym3<Real> A = {(Real)q2[c].x + RCR.xx, (Real)q2[c].y + RCR.xy, (Real)q2[c].z + RCR.xz, (Real)q2[c].w + RCR.yy, (Real)q3[c].x + RCR.yz, (Real)q3[c].y + RCR.zz};
         Real wgt;
-        if (MODE == MODE_VGICP) {
+        if constexpr (MODE == MODE_VGICP) {
           if (npts <= 0) continue;
-          wgt = sqrt((Real)npts);  // fast_vgicp_impl.hpp:149, compute_derivatives.cu:78
+          wgt = record_weight<Real>(q3[c]);  // sqrt(n): fast_vgicp_impl.hpp:149, compute_derivatives.cu:78 (stored with the voxel)
         } else {
           if (npts <= 6) continue;  // ndt_compute_derivatives.cu:61,133
           const Real ex = mu.x - q.x, ey = mu.y - q.y, ez = mu.z - q.z;
           const Real ksq = res * res;
           wgt = ksq / (ksq + (ex * ex + ey * ey + ez * ez));  // cauchy(resolution, |e|) :15-18
         }
-        const Sym3<Real> M = inverse(A);
-        hit_term<Real>(it, q, mu, M, wgt, do_deriv);
+        hit_term<Real>(it, q, mu, A, wgt, do_deriv);
         any_hit = true;
       }
       }  // do_cost

@@ -976,7 +976,8 @@ __global__ __launch_bounds__(256) void gicp_records_kernel(const float4* __restr
   table[4 * (size_t)i + 0] = make_float4(0.f, 0.f, __int_as_float(1), 0.f);
   table[4 * (size_t)i + 1] = make_float4(p.x, p.y, p.z, 1.0f);
   table[4 * (size_t)i + 2] = cov[2 * (size_t)i];
-  table[4 * (size_t)i + 3] = cov[2 * (size_t)i + 1];
+  const float4 c1 = cov[2 * (size_t)i + 1];
+  table[4 * (size_t)i + 3] = make_float4(c1.x, c1.y, __int_as_float(__double2loint(1.0)), __int_as_float(__double2hiint(1.0)));  // .zw = weight sqrt(1) as a double
 }
 
 // float xyz (stride 3 or 4) -> float4 (w = 0); optionally reduces the cloud's bounding cube into box[0..2] = ~ordered(min),

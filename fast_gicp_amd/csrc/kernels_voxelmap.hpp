@@ -51,7 +51,7 @@ __device__ __forceinline__ unsigned global_claim_from(unsigned long long* keys, 
   return 0xFFFFFFFFu;  // probe budget exhausted: the caller counts it in `dropped` and the host rebuilds at the safe size
 }
 __device__ __forceinline__ unsigned global_claim(unsigned long long* keys, unsigned mask, unsigned long long key) {
-  return global_claim_from(keys, mask, key, hash_key(key) & mask, 0);
+  return global_claim_from(keys, mask, key, hash_slot(key, mask), 0);
 }
 
 // first build at a capacity (afterwards vm_finalize_kernel leaves everything clean): keys -> EMPTY, accumulators and counters -> 0
@@ -106,7 +106,7 @@ __global__ __launch_bounds__(256) void vm_accumulate_kernel(const float4* __rest
       }
       v[9] = 1.0;
       // stage in the workgroup's LDS mini table
-      unsigned slot = (hash_key(key) >> 16) & (VM_LDS_SLOTS - 1);
+      unsigned slot = hash_slot(key, VM_LDS_SLOTS - 1);
       bool staged = false;
 #pragma unroll 1
       for (int pr = 0; pr < VM_LDS_PROBES; pr++) {
@@ -137,7 +137,7 @@ __global__ __launch_bounds__(256) void vm_accumulate_kernel(const float4* __rest
 #pragma unroll
   for (int u = 0; u < 2; u++) {
     fk[u] = lkey[tid + 256 * u];
-    fslot[u] = hash_key(fk[u]) & mask;
+    fslot[u] = hash_slot(fk[u], mask);
     fold[u] = FVH_EMPTY_KEY;
     if (fk[u] != FVH_EMPTY_KEY) fold[u] = atomicCAS(table_keys + fslot[u], FVH_EMPTY_KEY, fk[u]);
   }
@@ -205,7 +205,10 @@ __global__ __launch_bounds__(VM_FIN_THREADS) void vm_finalize_kernel(const unsig
   q0.w = 0;
   const float4 q1 = make_float4((float)mx, (float)my, (float)mz, (float)n);
   q2 = make_float4((float)C.xx, (float)C.xy, (float)C.xz, (float)C.yy);
-  q3 = make_float4((float)C.yz, (float)C.zz, 0.f, 0.f);
+  // .zw: the GICP weight sqrt(n) of the voxel as a double (fast_vgicp_impl.hpp:149) -- once per voxel here instead of once per
+  // correspondence and evaluation in the LM kernel
+  const double wn = sqrt((double)n);
+  q3 = make_float4((float)C.yz, (float)C.zz, __int_as_float(__double2loint(wn)), __int_as_float(__double2hiint(wn)));
   mxf = (float)mx; myf = (float)my; mzf = (float)mz;
   float4* tf = reinterpret_cast<float4*>(table);
   table[(size_t)b * 4] = q0;

@@ -68,9 +68,9 @@ def test_kernels_stay_on_the_right_side_of_the_register_cliff():
         assert v["occupancy"] >= 3 and v["vgprs"] <= 168 and v["lds"] <= 8 * 1024, (k, v)
         if ", true>" in k:
             # persistent instantiations: the LM step is inlined into the opener's once-per-trip path (7 us per launch faster than a
-            # call through generic pointers); a few values live across it are spilled THERE (4 scratch instructions in the whole
-            # kernel, none in the main loop -- checked by hand in the ISA, tools/kernel_resources.py shows the counts)
-            assert v["vgpr_spill"] <= 16 and v["scratch"] <= 64, (k, v)
+            # call through generic pointers); a few values live across it are spilled THERE (8 scratch instructions in the whole
+            # kernel, none in the main loop -- tools/count_isa.py lists them per section, tools/kernel_resources.py shows the counts)
+            assert v["vgpr_spill"] <= 24 and v["scratch"] <= 64, (k, v)
         else:
             assert v["vgpr_spill"] == 0 and v["scratch"] == 0, (k, v)
     assert res["fvh::lm_update_kernel(fvh::LmState*)"]["vgprs"] <= 168  # the wave-parallel LM step is inlined into every cost kernel

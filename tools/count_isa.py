@@ -29,7 +29,9 @@ for l in body:
             kind = "valu_trans64"
     elif op.startswith("s_"):
         kind = "salu"
-    elif op.startswith(("global_", "flat_", "buffer_", "scratch_")):
+    elif op.startswith("scratch_"):
+        kind = "scratch"
+    elif op.startswith(("global_", "flat_", "buffer_")):
         kind = "vmem"
     elif op.startswith("ds_"):
         kind = "lds"
@@ -37,6 +39,6 @@ for l in body:
         kind = "other"
     c[kind] += 1
     c["all"] += 1
-print("%-16s %6s %8s %8s %10s %6s %5s %5s" % ("section", "all", "valu_f64", "trans64", "valu_other", "salu", "vmem", "lds"))
+print("%-16s %6s %8s %8s %10s %6s %5s %5s %7s" % ("section", "all", "valu_f64", "trans64", "valu_other", "salu", "vmem", "lds", "scratch"))
 for k, c in counts.items():
-    print("%-16s %6d %8d %8d %10d %6d %5d %5d" % (k, c["all"], c["valu_f64"], c["valu_trans64"], c["valu_other"] + c["valu_trans"], c["salu"], c["vmem"], c["lds"]))
+    print("%-16s %6d %8d %8d %10d %6d %5d %5d %7d" % (k, c["all"], c["valu_f64"], c["valu_trans64"], c["valu_other"] + c["valu_trans"], c["salu"], c["vmem"], c["lds"], c["scratch"]))
