@@ -252,11 +252,12 @@ struct Engine {
     }
     (void)hipGetLastError();  // zero-copy results are optional
     if ((e = state.ensure(sizeof(LmState))) != hipSuccess) return hipfail(e, "hipMalloc");
-    if ((e = partials.ensure(sizeof(double) * PART_STRIDE * (MAX_COST_BLOCKS + 2 * TICKET_GROUPS))) != hipSuccess) return hipfail(e, "hipMalloc");
+    if ((e = partials.ensure(sizeof(double) * (PART_STRIDE * (MAX_COST_BLOCKS + 2 * TICKET_GROUPS) + TAGGED_ROWS_DOUBLES))) != hipSuccess) return hipfail(e, "hipMalloc");
     if ((e = ticket.ensure(64)) != hipSuccess) return hipfail(e, "hipMalloc");
     if ((e = pticket.ensure(PERSIST_TICKET_BYTES)) != hipSuccess) return hipfail(e, "hipMalloc");
     if ((e = bcast.ensure(sizeof(double) * PERSIST_REPLICAS * BCAST_SLOTS)) != hipSuccess) return hipfail(e, "hipMalloc");
     if ((e = hipMemsetAsync(bcast.p, 0, sizeof(double) * PERSIST_REPLICAS * BCAST_SLOTS, stream)) != hipSuccess) return hipfail(e, "hipMemsetAsync");
+    if ((e = hipMemsetAsync(partials.as<double>() + TAGGED_ROWS_OFFSET, 0, sizeof(double) * TAGGED_ROWS_DOUBLES, stream)) != hipSuccess) return hipfail(e, "hipMemsetAsync");  // tags of no launch
     if ((e = misc.ensure(256)) != hipSuccess) return hipfail(e, "hipMalloc");
     if ((e = fit.ensure(64)) != hipSuccess) return hipfail(e, "hipMalloc");
     if ((e = hipMemsetAsync(state.p, 0, sizeof(LmState), stream)) != hipSuccess) return hipfail(e, "hipMemsetAsync");
@@ -815,6 +816,10 @@ int launch_cost(Engine* e, const CostSource& src, const VoxelMapDev& vm, int hos
   const CostShape shape = cost_shape(e, src);
   P.group = shape.group;
   P.groups_per_src = shape.groups_per_src;
+  {  // w / d == mulhi(w, ceil(2^32 / d)) for all w with w * d < 2^32 (d = 1: no shift-free magic, plain division is free there)
+    const unsigned long long d = (unsigned long long)shape.groups_per_src, items = (unsigned long long)std::max(src.n_upper, 1) * d;
+    P.gps_magic = (d > 1 && items * d < (1ull << 32)) ? (unsigned)(((1ull << 32) + d - 1) / d) : 0u;
+  }
   P.corr = e->corr.as<int>();
   P.corr_stride = (size_t)std::max(src.n_upper, 1) * n_off;
   P.host_corr_sel = e->corr_sel;

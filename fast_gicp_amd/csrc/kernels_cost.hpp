@@ -77,6 +77,7 @@ struct CostParams {
   int n_off;
   int group;                  // offsets per work item
   int groups_per_src;         // ceil(n_off / group)
+  unsigned gps_magic;         // ceil(2^32 / groups_per_src) when item / groups_per_src == mulhi(item, magic) for every item of this launch, else 0
   int* corr;                  // 2 x [n_src][n_off] bucket index or -1 (double buffered for the speculative linearisation)
   size_t corr_stride;         // elements per buffer
   int host_corr_sel;          // host-mode launches: buffer to use
@@ -566,6 +567,18 @@ constexpr int PERSIST_TICKET_BYTES = 9 * 128;  // persistent kernel: 8 group cou
 constexpr int PERSIST_REPLICAS = 32;           // copies of the broadcast row; workgroup b polls copy b % PERSIST_REPLICAS
 constexpr int BCAST_SLOTS = 40;                // 5 segments of 64 B = 7 sums + 1 tag each (35 >= 29 sums)
 constexpr int TICKET_GROUPS = 8;  // hierarchical arrival counters (one per XCD-sized group of workgroups) + 1 top counter
+// Persistent kernel: the group rows travel as {sum, tag} PAIRS, one 16-byte agent-scope store per lane, and the opener polls
+// them with 16-byte loads -- the row is its own arrival signal: no "wait for the store, bump the top counter, poll the
+// counter, then load the rows" (three dependent memory-side round trips shorter per trip).
+typedef double pair_t __attribute__((ext_vector_type(2)));
+constexpr size_t TAGGED_ROWS_OFFSET = (size_t)PART_STRIDE * (MAX_PARTIAL_ROWS + 2 * TICKET_GROUPS);  // doubles into CostParams::partials
+constexpr size_t TAGGED_ROWS_DOUBLES = 2 * TICKET_GROUPS * PART_STRIDE * 2;                        // [parity][group][32] pairs
+__device__ __forceinline__ void store_pair_agent(pair_t* p, pair_t v) { asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory"); }
+__device__ __forceinline__ pair_t load_pair_agent(const pair_t* p) {
+  pair_t v;
+  asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(v) : "v"(p) : "memory");
+  return v;
+}
 
 // PERSIST = true: ONE launch runs the whole LM loop. Every trip of the outer loop is what one launch of the
 // non-persistent kernel does; instead of exiting, the workgroups wait at a barrier (monotonic arrival counters polled
@@ -710,7 +723,7 @@ __global__ FVH_COST_BOUNDS void cost_kernel(CostParams P) {
     bool any_hit = false;  // an element without correspondences contributes exact zeros (its q may be non-finite: 0 * NaN)
     if (PERSIST) FVH_MT(gen, 0);
     if (w < n_items) {
-    const int i0 = w / P.groups_per_src;
+    const int i0 = P.gps_magic ? (int)__umulhi((unsigned)w, P.gps_magic) : w / P.groups_per_src;  // (a 32-bit division is ~30 instructions)
     const int g = w - i0 * P.groups_per_src;
     const int i = P.order ? P.order[i0] : i0;
     const int o_begin = g * P.group, o_end = min(P.n_off, o_begin + P.group);
@@ -1113,39 +1126,75 @@ __global__ FVH_COST_BOUNDS void cost_kernel(CostParams P) {
     // (formed where they are used, from scalars: held as doubles they were four VGPRs live across the inlined LM step)
     auto want_tag_of = [&]() { unsigned long long t = ltag * 4096ull + trip + 1; asm volatile("" : "+s"(t)); return (double)t; };
     auto abort_tag_of = [&]() { unsigned long long t = ltag * 4096ull; asm volatile("" : "+s"(t)); return -(double)t; };  // launch-specific: a poisoned row of an older launch means nothing
-    const size_t grow0 = (size_t)MAX_PARTIAL_ROWS + (size_t)(trip & 1u) * TICKET_GROUPS;
     __shared__ double bc[BCAST_SLOTS];  // payload of the broadcast row as seen by this workgroup
     static_assert(TICKET_GROUPS == 8, "tb0..tb7");
     const unsigned tb = grp == 0 ? P.tb0 : grp == 1 ? P.tb1 : grp == 2 ? P.tb2 : grp == 3 ? P.tb3 : grp == 4 ? P.tb4 : grp == 5 ? P.tb5 : grp == 6 ? P.tb6 : P.tb7;
     if (tid == 0) s_last = (atomicAdd(&P.ticket[grp * 32], 1u) == tb + gsize * (trip + 1) - 1);
     FVH_PT_MAX(trip, 2);
     __syncthreads();
-    if (s_last) {
-      reduce_group_rows(grow0 + grp);
-      FVH_PT_MAX(trip, 5);
-      if (tid == 0) atomicAdd(&P.ticket[TICKET_GROUPS * 32], 1u);
+    pair_t* trows = reinterpret_cast<pair_t*>(P.partials + TAGGED_ROWS_OFFSET) + (size_t)(trip & 1u) * TICKET_GROUPS * PART_STRIDE;
+    if (s_last) {  // the group's last arriver: sum of the group's rows (the order of reduce_group_rows) -> one tagged row
+      {
+        const int v = tid & 31, chunk = tid >> 5;
+        double s = 0.0;
+        for (unsigned j0 = chunk; j0 < gsize; j0 += 8 * 8) {
+          double t[8];
+#pragma unroll
+          for (int u = 0; u < 8; u++) {
+            const unsigned j = j0 + 8 * u;
+            t[u] = (j < gsize) ? __hip_atomic_load(&P.partials[(size_t)(grp + j * TICKET_GROUPS) * PART_STRIDE + v], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
+          }
+#pragma unroll
+          for (int u = 0; u < 8; u++) s += t[u];
+        }
+        fin[chunk][v] = s;
+      }
       __syncthreads();
+      if (tid < PART_STRIDE) {
+        double s = 0.0;
+#pragma unroll
+        for (int c = 0; c < 8; c++) s += fin[c][tid];
+        pair_t pv;
+        pv.x = s; pv.y = want_tag_of();
+        store_pair_agent(trows + (size_t)grp * PART_STRIDE + tid, pv);
+      }
+      FVH_PT_MAX(trip, 5);
+      __syncthreads();  // fin[] is reused by the opener below
     }
     // The opener is always workgroup 0 (not whoever arrives last): the LM step is ~20 KB of code that runs once per
     // trip -- on a random CU it is fetched cold every time; on a fixed CU it stays in the instruction cache, and the LM
     // state stays in this workgroup's LDS for the whole launch instead of travelling through memory each trip.
     const bool opener = (blockIdx.x == 0);
     if (opener) {
-      if (tid == 0) {  // wait for the last group (its own arrival included)
-        const unsigned want = P.tb_top + ngroups * (trip + 1);
-        const unsigned long long t0 = wall_clock64();
-        int ok = 1;
-        while (__hip_atomic_load(&P.ticket[TICKET_GROUPS * 32], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {
-          if (wall_clock64() - t0 > P.watchdog_ticks) { ok = 0; break; }
-          __builtin_amdgcn_s_sleep(1);
+      if (tid == 0) s_last = 1;
+      __syncthreads();
+      {  // thread (value v, group g) polls ITS pair of group g's tagged row; the sum over the groups keeps reduce_final's order
+        const int v = tid & 31;
+        const unsigned g = tid >> 5;
+        double val = 0.0;
+        if (g < ngroups) {
+          const pair_t* src = trows + (size_t)g * PART_STRIDE + v;
+          const double want = want_tag_of();
+          const unsigned long long t0 = wall_clock64();
+          for (;;) {
+            const pair_t pv = load_pair_agent(src);
+            if (pv.y == want) { val = pv.x; break; }
+            if (wall_clock64() - t0 > P.watchdog_ticks) { s_last = 0; break; }
+            __builtin_amdgcn_s_sleep(1);
+          }
         }
-        s_last = ok;
+        fin[g][v] = val;
       }
       __syncthreads();
       unsigned abort_code = s_last ? 0u : 1u;  // 1: not every workgroup is resident / something is stuck
       if (!abort_code) {
         FVH_PT_MAX(trip, 6);
-        reduce_final(grow0);
+        if (tid < PART_STRIDE) {
+          double s = 0.0;
+#pragma unroll
+          for (int c = 0; c < 8; c++) s += fin[c][tid];
+          red[0][tid] = s;
+        }
         __syncthreads();
         // multi-GPU: the openers of all ranks meet in each other's mailboxes (kernels_peer.hpp); every rank then runs the same LM step
         // (VGICP handles only: the NDT handles shard through RCCL between launches, and their D2D instantiation has no register to spare)
