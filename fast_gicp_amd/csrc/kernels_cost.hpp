@@ -35,7 +35,10 @@ constexpr int PART_STRIDE = 32;
 constexpr int MAX_PARTIAL_ROWS = 1024;  // workgroup rows (4 workgroups per CU x 256 CUs); the group rows follow
 
 enum CostMode { MODE_VGICP = 0, MODE_NDT_P2D = 1, MODE_NDT_D2D = 2 };
-enum Phase { PH_LINEARIZE = 0, PH_TRIAL = 1, PH_DONE = 2, PH_FIND_ONLY = 3, PH_EVAL_DERIV = 4, PH_EVAL_ERROR = 5 };
+enum Phase { PH_LINEARIZE = 0, PH_TRIAL = 1, PH_DONE = 2, PH_FIND_ONLY = 3, PH_EVAL_DERIV = 4, PH_EVAL_ERROR = 5,
+             // a trial whose speculative linearisation can never be used -- the proposed step is already below the convergence
+             // thresholds, or an accepted step ends the outer loop: the trip evaluates the trial error of the stored ids only
+             PH_TRIAL_FINAL = 6 };
 // PH_TRIAL in device-LM mode is the FUSED launch: trial error with the old correspondences + speculative linearisation at the trial pose
 
 struct LmState {
@@ -331,8 +334,8 @@ __device__ FVH_LM_STEP_ATTR void dev_lm_step_wave(LmState* st, const double* sum
   if (phase == PH_LINEARIZE) {
     if (in12) xlp[lane] = x0p[lane];  // x_lin = x0
     consume = true;
-  } else {  // PH_TRIAL (fused): trial error of this launch at sums[28]
-    const double yi = sums[28];
+  } else {  // PH_TRIAL (fused): trial error of this launch at sums[28]; PH_TRIAL_FINAL (error only): at sums[0]
+    const double yi = sums[phase == PH_TRIAL_FINAL ? 0 : 28];
     num_error_evals++;
     double denom = 0;
 #pragma unroll
@@ -468,6 +471,10 @@ __device__ FVH_LM_STEP_ATTR void dev_lm_step_wave(LmState* st, const double* sum
     if (lane >= 9) val = a0 * b0 + a1 * b1 + a2 * b2 + ti;
     xip[lane] = val;
   }
+  // the trial of this proposal is the last evaluation of the align if the step is already converged (then accepted or not, the
+  // loop ends: lsq_registration_impl.hpp:57-66,150-165) or if accepting it exhausts max_iterations -- its speculative
+  // linearisation would be thrown away
+  if (phase == PH_TRIAL || phase == PH_TRIAL_FINAL) phase = (dev_is_converged(st, delta) || outer_iter + 1 >= max_iterations) ? PH_TRIAL_FINAL : PH_TRIAL;
   commit();
 }
 
