@@ -134,6 +134,7 @@ __global__ __launch_bounds__(256) void vg_mark_approx_kernel(const unsigned* __r
 // ---- centroids ----
 // One thread per run head: fp32 sums in input order (adds only, so nothing for the compiler to contract), then the
 // correctly rounded division by the count -- the arithmetic of the PCL filters.
+constexpr int EMIT_BATCH = 8;
 template <bool APPROX>
 __global__ __launch_bounds__(256) void vg_emit_kernel(const unsigned* __restrict__ keys, const int* __restrict__ idx, const float4* __restrict__ pts, int n,
                                                       const unsigned* __restrict__ head, const unsigned* __restrict__ pos_scan /* exact: scan(head) by j; approx: scan(trig) by original index */,
@@ -143,13 +144,30 @@ __global__ __launch_bounds__(256) void vg_emit_kernel(const unsigned* __restrict
   if (APPROX && result && blockIdx.x == 0 && threadIdx.x == 0) { result[0] = *trig_total; result[1] = slot_rank[AVG_SLOTS]; result[2] = *bad; }
   const int j = blockIdx.x * 256 + threadIdx.x;
   if (j >= n || !head[j]) return;
+  // The sum is sequential by definition (fp32, input order: the arithmetic of the PCL filter) but its LOADS are not: the next
+  // EMIT_BATCH indices, head flags and points are requested together, then consumed in order -- a run of r points costs
+  // ~2 r / EMIT_BATCH dependent round trips instead of 2 r (runs of 15-100 points made this the longest kernel of the filter).
   float cx = 0.f, cy = 0.f, cz = 0.f;
   int e = j;
-  do {
-    const float4 p = pts[idx[e]];
-    cx += p.x; cy += p.y; cz += p.z;
-    e++;
-  } while (e < n && !head[e]);
+  float4 p = pts[idx[j]];
+  bool more = true;
+  while (more) {
+    int ib[EMIT_BATCH];
+    unsigned hb[EMIT_BATCH];
+    float4 pb[EMIT_BATCH];
+#pragma unroll
+    for (int u = 0; u < EMIT_BATCH; u++) { const int k = e + 1 + u; hb[u] = (k < n) ? head[k] : 1u; ib[u] = idx[min(k, n - 1)]; }
+#pragma unroll
+    for (int u = 0; u < EMIT_BATCH; u++) pb[u] = pts[ib[u]];
+#pragma unroll
+    for (int u = 0; u < EMIT_BATCH; u++) {
+      if (more) {
+        cx += p.x; cy += p.y; cz += p.z;
+        e++;
+        if (hb[u]) more = false; else p = pb[u];
+      }
+    }
+  }
   const float cnt = (float)(e - j);
   unsigned pos;
   if (APPROX) {
@@ -241,7 +259,10 @@ __global__ __launch_bounds__(256) void avg_binscan_kernel(unsigned* __restrict__
     }
     if (lane == 0) __hip_atomic_store(&totals[bin], run, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
-  __threadfence();
+  // (no __threadfence(): an agent-scope release writes back the whole L2 of the XCD, once per WORKGROUP -- that was 12 of this
+  // kernel's 17 us. The only values another workgroup of this launch reads are the totals, stored write-through above; waiting
+  // for the store is all the release they need.)
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   if (threadIdx.x == 0) s_last = (atomicAdd(&st->ticket, 1u) == gridDim.x - 1);
   __syncthreads();
@@ -379,16 +400,25 @@ __device__ __forceinline__ void avg_emit_points(const float4* __restrict__ sorte
   const unsigned slot = avg_slot(ix, iy, iz);
   float cx = 0.f, cy = 0.f, cz = 0.f;
   int e = j;
-  for (;;) {
-    cx += p.x; cy += p.y; cz += p.z;
-    e++;
-    if (e >= n || head[e]) break;
-    p = sorted_pts[e];
+  float4 q = p;  // the first point of the NEXT run (it flushes this one)
+  bool more = true;
+  while (more) {  // batched loads, sequential sum (see vg_emit_kernel)
+    unsigned char hb[EMIT_BATCH];
+    float4 pb[EMIT_BATCH];
+#pragma unroll
+    for (int u = 0; u < EMIT_BATCH; u++) { const int k = e + 1 + u; hb[u] = (k < n) ? head[k] : (unsigned char)1; pb[u] = sorted_pts[min(k, n - 1)]; }
+#pragma unroll
+    for (int u = 0; u < EMIT_BATCH; u++) {
+      if (more) {
+        cx += p.x; cy += p.y; cz += p.z;
+        e++;
+        if (hb[u]) { more = false; q = pb[u]; } else p = pb[u];
+      }
+    }
   }
   const float cnt = (float)(e - j);
   unsigned pos = st->trig_total + st->slot_rank[slot];  // last run of its slot: flushed at the end, in slot order
   if (e < n) {
-    const float4 q = sorted_pts[e];
     int qx, qy, qz;
     avg_voxel(q, inv, qx, qy, qz);
     if (avg_slot(qx, qy, qz) == slot) {  // flushed by the arrival of point q: its rank among all flush-triggering points (by original index)
@@ -399,9 +429,11 @@ __device__ __forceinline__ void avg_emit_points(const float4* __restrict__ sorte
       pos = r;
     }
   }
-  out[3 * (size_t)pos] = cx / cnt;
-  out[3 * (size_t)pos + 1] = cy / cnt;
-  out[3 * (size_t)pos + 2] = cz / cnt;
+  // write-through: the host may hand `out` to a kernel on ANOTHER stream as soon as it sees the sequence word of the last
+  // workgroup (below), i.e. before this kernel's end-of-kernel release
+  __hip_atomic_store(&out[3 * (size_t)pos], cx / cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __hip_atomic_store(&out[3 * (size_t)pos + 1], cy / cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __hip_atomic_store(&out[3 * (size_t)pos + 2], cz / cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // The LAST workgroup to finish writes {count, bad flag, sequence} to mapped host memory: when the host sees the sequence
@@ -411,7 +443,7 @@ __global__ __launch_bounds__(256) void avg_emit_kernel(const float4* __restrict_
                                                        unsigned long long* __restrict__ host_result /* {count, bad, seq} mapped, or null */, unsigned long long seq) {
   avg_emit_points(sorted_pts, head, n, inv, trigbits, block_base, st, out);
   if (!host_result) return;
-  __threadfence();
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this workgroup's centroids are in memory (write-through stores); no L2 write-back (see avg_binscan_kernel)
   __syncthreads();
   if (threadIdx.x == 0 && atomicAdd(&st->emit_ticket, 1u) == gridDim.x - 1) {
     st->emit_ticket = 0u;
