@@ -177,6 +177,7 @@ struct Engine {
   int n_off = 1;
   DevBuf fit_best;   // squared nearest-neighbour distance per source point (fitness score)
   DevBuf sort_coop;  // SortCoopState + histograms of the cooperative small sort
+  DevBuf rbf_sums;   // [10][n] wave totals of the RBF covariance sweep
   DevBuf pticket;  // arrival counters of the persistent LM kernel: monotonic, the host tracks their values in pticket_base
   unsigned pticket_base[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};  // where the 8 group counters + the top counter stand
   bool pticket_dirty = true;   // unknown counter values (first use / after an aborted launch): clear them
@@ -282,7 +283,7 @@ struct Engine {
     if (peer.region) { (void)hipFree(peer.region); peer.region = nullptr; }
     peer.err.release();
     prof.destroy();
-    lm_trace.release(); fit_best.release(); sort_coop.release(); pticket.release(); bcast.release(); offsets_dev.release(); state.release(); partials.release(); ticket.release(); corr.release(); misc.release(); fit.release(); staging.release(); sort_keys.release(); sort_idx.release(); sort_hist.release();
+    lm_trace.release(); fit_best.release(); sort_coop.release(); rbf_sums.release(); pticket.release(); bcast.release(); offsets_dev.release(); state.release(); partials.release(); ticket.release(); corr.release(); misc.release(); fit.release(); staging.release(); sort_keys.release(); sort_idx.release(); sort_hist.release();
     if (pinned) (void)hipHostFree(pinned);
     if (upload_pinned) (void)hipHostFree(upload_pinned);
     if (upload_done) (void)hipEventDestroy(upload_done);
@@ -602,7 +603,13 @@ int calc_cov_rbf(Engine* e, CloudDev& c, double kernel_width, double max_dist, i
       const Tile t = peer_tile(e, c.n);
       ProfScope ps(e, "rbf");
       if (rbf_mode == 2 && !sharded) cov_rbf_tiled_kernel<<<(waves + 3) / 4, 256, 0, e->stream>>>(c.sorted.as<float4>(), c.bbox.as<float4>(), c.n, (float)kernel_width, md * md, method, c.cov.as<float4>());
-      else if (t.hi > t.lo) cov_rbf1_kernel<<<(t.hi - t.lo + 3) / 4, 256, 0, e->stream>>>(c.sorted.as<float4>(), c.bbox.as<float4>(), c.bbox2.as<float4>(), c.n, (float)kernel_width, md * md, method, c.cov.as<float4>(), t.lo, t.hi);
+      else if (t.hi > t.lo) {
+        // sweep (one query per wave) -> ten totals per query; regularisation with one thread per query
+        HIP_OR_FAIL(e, e->rbf_sums.ensure(sizeof(double) * 10 * (size_t)c.n));
+        cov_rbf1_kernel<<<(t.hi - t.lo + 3) / 4, 256, 0, e->stream>>>(c.sorted.as<float4>(), c.bbox.as<float4>(), c.bbox2.as<float4>(), c.n, (float)kernel_width, md * md, method, c.cov.as<float4>(), t.lo, t.hi,
+                                                                      e->rbf_sums.as<double>());
+        cov_rbf_finish_kernel<<<(t.hi - t.lo + 255) / 256, 256, 0, e->stream>>>(e->rbf_sums.as<double>(), c.sorted.as<float4>(), c.n, method, c.cov.as<float4>(), t.lo, t.hi);
+      }
     }
   }
   HIP_OR_FAIL(e, hipGetLastError());

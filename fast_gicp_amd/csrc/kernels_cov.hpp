@@ -619,8 +619,29 @@ __global__ __launch_bounds__(256) void cov_rbf_tiled_kernel(const float4* __rest
 // tile box against the group's box and ends with 80 wave reductions: 420 us at 100k points against 190 us for k-NN +
 // covariance). Lane l accumulates the candidates it sees at position l of every tile within max_dist, in ascending
 // tile order -- the arithmetic of cov_rbf_tiled_kernel, term by term (tiles it skips would have contributed weight 0).
+// The wave of a query ends with ten wave totals {W, X, Y, Z, XX, ..., ZZ}. They go to `sums` (SoA: sums[k * n + q]) and
+// cov_rbf_finish_kernel turns them into the regularised covariance with one THREAD per query: the eigen-decomposition of the
+// PLANE regularisation is ~1,000 dependent fp64 instructions, and run by lane 0 of a one-query wave it cost a full wave's issue
+// slots per query -- 180 of this kernel's 300 us at 100k points.
+__device__ __forceinline__ void rbf_cov_from_sums(double W, double X, double Y, double Z, double XX, double XY, double XZ, double YY, double YZ, double ZZ, int method,
+                                                  float4* __restrict__ cov, int index) {
+  const double iw = 1.0 / W;
+  const double mx = X * iw, my = Y * iw, mz = Z * iw;
+  Sym3<double> C;
+  C.xx = XX * iw - mx * mx; C.xy = XY * iw - mx * my; C.xz = XZ * iw - mx * mz;
+  C.yy = YY * iw - my * my; C.yz = YZ * iw - my * mz; C.zz = ZZ * iw - mz * mz;
+  store_cov(cov, index, regularize_cov(C, method));
+}
+__global__ __launch_bounds__(256) void cov_rbf_finish_kernel(const double* __restrict__ sums, const float4* __restrict__ spts, int n, int method, float4* __restrict__ cov, int q_begin, int q_end) {
+  const int q = q_begin + blockIdx.x * 256 + threadIdx.x;
+  if (q >= min(n, q_end)) return;
+  const size_t N = (size_t)n;
+  rbf_cov_from_sums(sums[q], sums[N + q], sums[2 * N + q], sums[3 * N + q], sums[4 * N + q], sums[5 * N + q], sums[6 * N + q], sums[7 * N + q], sums[8 * N + q], sums[9 * N + q], method,
+                    cov, __float_as_int(spts[q].w));
+}
 __global__ __launch_bounds__(256) void cov_rbf1_kernel(const float4* __restrict__ spts, const float4* __restrict__ bbox1, const float4* __restrict__ bbox2, int n, float kernel_width,
-                                                       float max_dist_sq, int method, float4* __restrict__ cov, int q_begin = 0, int q_end = 0x7fffffff) {
+                                                       float max_dist_sq, int method, float4* __restrict__ cov, int q_begin = 0, int q_end = 0x7fffffff,
+                                                       double* __restrict__ sums = nullptr /* [10][n]: leave the regularisation to cov_rbf_finish_kernel */) {
   const int lane = threadIdx.x & 63;
   const int q = q_begin + blockIdx.x * 4 + (threadIdx.x >> 6);
   if (q >= min(n, q_end)) return;
@@ -669,14 +690,16 @@ __global__ __launch_bounds__(256) void cov_rbf1_kernel(const float4* __restrict_
   const double X = wave_sum((double)sx), Y = wave_sum((double)sy), Z = wave_sum((double)sz);
   const double XX = wave_sum((double)sxx), XY = wave_sum((double)sxy), XZ = wave_sum((double)sxz);
   const double YY = wave_sum((double)syy), YZ = wave_sum((double)syz), ZZ = wave_sum((double)szz);
-  if (lane == 0) {
-    const double iw = 1.0 / W;
-    const double mx = X * iw, my = Y * iw, mz = Z * iw;
-    Sym3<double> C;
-    C.xx = XX * iw - mx * mx; C.xy = XY * iw - mx * my; C.xz = XZ * iw - mx * mz;
-    C.yy = YY * iw - my * my; C.yz = YZ * iw - my * mz; C.zz = ZZ * iw - mz * mz;
-    store_cov(cov, __float_as_int(qv.w), regularize_cov(C, method));
+  if (sums) {
+    if (lane < 10) {  // every lane holds all ten totals: lane k stores total k
+      double v = W;
+      v = lane == 1 ? X : v; v = lane == 2 ? Y : v; v = lane == 3 ? Z : v; v = lane == 4 ? XX : v; v = lane == 5 ? XY : v;
+      v = lane == 6 ? XZ : v; v = lane == 7 ? YY : v; v = lane == 8 ? YZ : v; v = lane == 9 ? ZZ : v;
+      sums[(size_t)lane * n + q] = v;
+    }
+    return;
   }
+  if (lane == 0) rbf_cov_from_sums(W, X, Y, Z, XX, XY, XZ, YY, YZ, ZZ, method, cov, __float_as_int(qv.w));
 }
 
 // getFitnessScore on the Morton-sorted clouds: the wave first sweeps the target tile whose box is
