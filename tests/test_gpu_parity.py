@@ -277,6 +277,47 @@ def test_persistent_and_multi_launch_paths_agree(O, pair, monkeypatch):
     c.close()
 
 
+@pytest.mark.parametrize("lm", [
+    dict(max_iterations=1),                                              # the first accepted trial ends the outer loop
+    dict(max_iterations=3),                                              # ... the third one does
+    dict(rotation_epsilon=1e-7, transformation_epsilon=1e-7, max_iterations=6),  # not converged by the thresholds when the iterations
+                                                                         # run out (tighter ones only compare rounding noise: rho = 0/0)
+    dict(rotation_epsilon=1.0, transformation_epsilon=10.0),             # converged by the first proposal
+    dict(lm_max_iterations=1),                                           # a rejected trial ends the align ("lm not converged")
+    dict(lm_init_lambda_factor=1e3),                                     # heavy damping: many small steps
+])
+def test_every_way_the_lm_loop_ends_matches_the_oracle(O, pair, monkeypatch, lm):
+    """lsq_registration_impl.hpp:53-168. The device loop evaluates a trial whose speculative linearisation can never be used (the
+    proposed step is already below the thresholds, or accepting it exhausts max_iterations) on the stored correspondences only
+    (PH_TRIAL_FINAL): whatever ends the loop, the bookkeeping (linearisations, error evaluations, iterations, converged) must be
+    the oracle's, the transform within 1e-4, and the one-launch and one-launch-per-transition routes bit-identical."""
+    tgt, src = pair
+    c = _core()
+    c.set_neighbor_search_method(1)
+    c.set_target_cloud(tgt); c.find_target_neighbors(20); c.calculate_target_covariances(3); c.create_target_voxelmap()
+    c.set_source_cloud(src); c.find_source_neighbors(20); c.calculate_source_covariances(3)
+    r = c.align(**lm)
+    g = O.FastVGICP(search=1)
+    okw = dict(lm)
+    if "lm_init_lambda_factor" in okw: okw["init_lambda_factor"] = okw.pop("lm_init_lambda_factor")
+    g.set_lm(**okw)
+    g.set_target(tgt); g.set_source(src)
+    ro = g.align()
+    assert r["converged"] == ro["converged"]
+    assert r["num_linearize"] == ro["num_linearize"] and r["num_error_evals"] == ro["num_error_evals"] and r["iterations"] == ro["iterations"]
+    assert util.rel_err(r["T"], ro["T"]) < 1e-4
+    assert r["num_launches"] == 1
+    monkeypatch.setenv("FVH_PERSISTENT", "0")  # (read once per process -- if it already was, the watchdog hook below still forces the other route)
+    monkeypatch.setenv("FVH_PERSIST_WATCHDOG_TICKS", "0")
+    r1 = c.align(**lm)
+    monkeypatch.delenv("FVH_PERSIST_WATCHDOG_TICKS")
+    monkeypatch.delenv("FVH_PERSISTENT")
+    assert r1["num_launches"] > 1 or r["num_error_evals"] == 0
+    assert np.array_equal(r1["T"], r["T"]) and np.array_equal(r1["H"], r["H"]) and r1["num_error_evals"] == r["num_error_evals"]
+    c.align()  # (leave the handle's back-off state as the next test expects it)
+    c.close()
+
+
 @pytest.mark.parametrize("n", [17334, 4099, 64, 20])
 def test_cooperative_sort_and_its_fallback_give_the_same_knn(O, pair, monkeypatch, n):
     """Small clouds are Morton-sorted by a cooperative kernel (32 workgroups meeting at grid barriers) with a
