@@ -161,11 +161,19 @@ template <int MODE>
 __global__ __launch_bounds__(VM_FIN_THREADS) void vm_finalize_kernel(const unsigned long long* __restrict__ keys, uint4* __restrict__ table, unsigned capacity, double* __restrict__ acc,
                                                           int* __restrict__ num_voxels, int* __restrict__ occupied, float4* __restrict__ compact_pts, float4* __restrict__ compact_cov,
                                                           unsigned long long* __restrict__ next_keys, int* __restrict__ next_counters) {
+  // NDT (MODE 1) regularises every voxel covariance through an eigen-decomposition (~1,000 dependent fp64 instructions). At a
+  // load factor of 0.25 a wave of buckets holds ~16 voxels, i.e. it would pay the decomposition for a quarter-full wave: the
+  // workgroup's voxels are compacted through LDS first and regularised by the first ceil(count / 64) waves, one voxel per lane.
+  constexpr bool DENSE = (MODE == 1);
+  __shared__ int s_wave_cnt[VM_FIN_THREADS / 64], s_base;
+  __shared__ double s_cov[DENSE ? VM_FIN_THREADS : 1][7];  // raw covariance + the weight sqrt(n)
+  __shared__ unsigned s_bucket[DENSE ? VM_FIN_THREADS : 1];
   const unsigned b = blockIdx.x * VM_FIN_THREADS + threadIdx.x;
   bool live = false;
-  int slot_in_wave = 0;
   float mxf = 0.f, myf = 0.f, mzf = 0.f;
   float4 q2 = make_float4(0, 0, 0, 0), q3 = q2;
+  Sym3<double> C = {0, 0, 0, 0, 0, 0};
+  double wn = 0.0;
   unsigned long long key = FVH_EMPTY_KEY;
   if (b < capacity) {
     next_keys[b] = FVH_EMPTY_KEY;  // the buffers of the NEXT build (the map before this one is dead)
@@ -173,70 +181,90 @@ __global__ __launch_bounds__(VM_FIN_THREADS) void vm_finalize_kernel(const unsig
     key = keys[b];
   }
   if (key != FVH_EMPTY_KEY) {
-  uint4 q0 = make_uint4((unsigned)key, (unsigned)(key >> 32), 0u, 0u);
-  double a[VM_ACC_STRIDE];
-  {
-    uint4* aq = reinterpret_cast<uint4*>(acc + (size_t)b * VM_ACC_STRIDE);  // 80 B per bucket, 16-B aligned
+    uint4 q0 = make_uint4((unsigned)key, (unsigned)(key >> 32), 0u, 0u);
+    double a[VM_ACC_STRIDE];
+    {
+      uint4* aq = reinterpret_cast<uint4*>(acc + (size_t)b * VM_ACC_STRIDE);  // 80 B per bucket, 16-B aligned
 #pragma unroll
-    for (int j = 0; j < VM_ACC_STRIDE / 2; j++) {
-      const uint4 v = aq[j];
-      a[2 * j] = __hiloint2double((int)v.y, (int)v.x);
-      a[2 * j + 1] = __hiloint2double((int)v.w, (int)v.z);
-      aq[j] = make_uint4(0, 0, 0, 0);  // consumed: clean for the next build
+      for (int j = 0; j < VM_ACC_STRIDE / 2; j++) {
+        const uint4 v = aq[j];
+        a[2 * j] = __hiloint2double((int)v.y, (int)v.x);
+        a[2 * j + 1] = __hiloint2double((int)v.w, (int)v.z);
+        aq[j] = make_uint4(0, 0, 0, 0);  // consumed: clean for the next build
+      }
     }
-  }
-  const double cnt = a[9];
-  const double inv = 1.0 / cnt;
-  double mx = a[0] * inv, my = a[1] * inv, mz = a[2] * inv;
-  Sym3<double> C;
-  if (MODE == 0) {
-    C.xx = a[3] * inv; C.xy = a[4] * inv; C.xz = a[5] * inv; C.yy = a[6] * inv; C.yz = a[7] * inv; C.zz = a[8] * inv;
-  } else if (MODE == 2) {  // MultiplicativeGaussianVoxel::finalize (fast_vgicp_voxel.hpp:96-102): cov = (sum C^-1)^-1, mean = cov * sum C^-1 p
-    C = inverse(Sym3<double>{a[3], a[4], a[5], a[6], a[7], a[8]});
-    const Vec3<double> m = mul(C, Vec3<double>{a[0], a[1], a[2]});
-    mx = m.x; my = m.y; mz = m.z;
-  } else {
-    C.xx = (a[3] - mx * a[0]) * inv; C.xy = (a[4] - mx * a[1]) * inv; C.xz = (a[5] - mx * a[2]) * inv;
-    C.yy = (a[6] - my * a[1]) * inv; C.yz = (a[7] - my * a[2]) * inv; C.zz = (a[8] - mz * a[2]) * inv;
-    C = regularize_cov(C, 1 /* MIN_EIG */);
-  }
-  const int n = (int)cnt;
-  q0.z = (unsigned)n;
-  q0.w = 0;
-  const float4 q1 = make_float4((float)mx, (float)my, (float)mz, (float)n);
-  q2 = make_float4((float)C.xx, (float)C.xy, (float)C.xz, (float)C.yy);
-  // .zw: the GICP weight sqrt(n) of the voxel as a double (fast_vgicp_impl.hpp:149) -- once per voxel here instead of once per
-  // correspondence and evaluation in the LM kernel
-  const double wn = sqrt((double)n);
-  q3 = make_float4((float)C.yz, (float)C.zz, __int_as_float(__double2loint(wn)), __int_as_float(__double2hiint(wn)));
-  mxf = (float)mx; myf = (float)my; mzf = (float)mz;
-  float4* tf = reinterpret_cast<float4*>(table);
-  table[(size_t)b * 4] = q0;
-  tf[(size_t)b * 4 + 1] = q1;
-  tf[(size_t)b * 4 + 2] = q2;
-  tf[(size_t)b * 4 + 3] = q3;
-  live = true;
+    const double cnt = a[9];
+    const double inv = 1.0 / cnt;
+    double mx = a[0] * inv, my = a[1] * inv, mz = a[2] * inv;
+    if (MODE == 0) {
+      C.xx = a[3] * inv; C.xy = a[4] * inv; C.xz = a[5] * inv; C.yy = a[6] * inv; C.yz = a[7] * inv; C.zz = a[8] * inv;
+    } else if (MODE == 2) {  // MultiplicativeGaussianVoxel::finalize (fast_vgicp_voxel.hpp:96-102): cov = (sum C^-1)^-1, mean = cov * sum C^-1 p
+      C = inverse(Sym3<double>{a[3], a[4], a[5], a[6], a[7], a[8]});
+      const Vec3<double> m = mul(C, Vec3<double>{a[0], a[1], a[2]});
+      mx = m.x; my = m.y; mz = m.z;
+    } else {  // (regularised below, on dense waves)
+      C.xx = (a[3] - mx * a[0]) * inv; C.xy = (a[4] - mx * a[1]) * inv; C.xz = (a[5] - mx * a[2]) * inv;
+      C.yy = (a[6] - my * a[1]) * inv; C.yz = (a[7] - my * a[2]) * inv; C.zz = (a[8] - mz * a[2]) * inv;
+    }
+    const int n = (int)cnt;
+    q0.z = (unsigned)n;
+    q0.w = 0;
+    // q3.zw: the GICP weight sqrt(n) of the voxel as a double (fast_vgicp_impl.hpp:149) -- once per voxel here instead of once per
+    // correspondence and evaluation in the LM kernel
+    wn = sqrt((double)n);
+    mxf = (float)mx; myf = (float)my; mzf = (float)mz;
+    table[(size_t)b * 4] = q0;
+    reinterpret_cast<float4*>(table)[(size_t)b * 4 + 1] = make_float4(mxf, myf, mzf, (float)n);
+    live = true;
   }  // occupied bucket
   // Compact list of the occupied buckets: ONE atomic per 1024-bucket WORKGROUP on the voxel counter. (Round 1 had one per wave: 4,096
   // same-address atomics at 100k points / 262k buckets -- the memory-side atomic unit retires them one after the other, ~12 ns
   // each, which was the 50 us this kernel took; per voxel it had been 60k of them.)
-  __shared__ int s_wave_cnt[VM_FIN_THREADS / 64], s_base;
   const int wv = threadIdx.x >> 6;
   const unsigned long long mask = __ballot(live);
-  slot_in_wave = __popcll(mask & ((1ull << (threadIdx.x & 63)) - 1ull));
+  const int slot_in_wave = __popcll(mask & ((1ull << (threadIdx.x & 63)) - 1ull));
   if ((threadIdx.x & 63) == 0) s_wave_cnt[wv] = __popcll(mask);
   __syncthreads();
-  if (threadIdx.x == 0) {
-    int total = 0;
-    for (int w = 0; w < VM_FIN_THREADS / 64; w++) total += s_wave_cnt[w];
-    s_base = total ? atomicAdd(num_voxels, total) : 0;
+  int total = 0, local = slot_in_wave;  // voxels of this workgroup; this voxel's position among them
+  for (int w = 0; w < VM_FIN_THREADS / 64; w++) { const int c = s_wave_cnt[w]; total += c; local += (w < wv) ? c : 0; }
+  if (threadIdx.x == 0) s_base = total ? atomicAdd(num_voxels, total) : 0;
+  if (DENSE && live) {
+    s_cov[local][0] = C.xx; s_cov[local][1] = C.xy; s_cov[local][2] = C.xz; s_cov[local][3] = C.yy; s_cov[local][4] = C.yz; s_cov[local][5] = C.zz; s_cov[local][6] = wn;
+    s_bucket[local] = b;
   }
   __syncthreads();
+  float4* tf = reinterpret_cast<float4*>(table);
+  if (DENSE) {
+    // one voxel per lane of the first waves: regularise (ndt_cuda.cu:128,139: MIN_EIG), write the covariance half of the record
+    if ((int)threadIdx.x < total) {
+      const int t = threadIdx.x;
+      const Sym3<double> R = regularize_cov(Sym3<double>{s_cov[t][0], s_cov[t][1], s_cov[t][2], s_cov[t][3], s_cov[t][4], s_cov[t][5]}, 1 /* MIN_EIG */);
+      const unsigned bt = s_bucket[t];
+      const float4 r2 = make_float4((float)R.xx, (float)R.xy, (float)R.xz, (float)R.yy);
+      const double w = s_cov[t][6];
+      const float4 r3 = make_float4((float)R.yz, (float)R.zz, __int_as_float(__double2loint(w)), __int_as_float(__double2hiint(w)));
+      tf[(size_t)bt * 4 + 2] = r2;
+      tf[(size_t)bt * 4 + 3] = r3;
+      if (compact_pts) {  // D2D NDT: the source voxels are the "source cloud"
+        const int id = s_base + t;
+        compact_cov[2 * id] = r2;
+        compact_cov[2 * id + 1] = r3;
+      }
+    }
+    if (!live) return;
+    const int id = s_base + local;
+    occupied[id] = (int)b;
+    if (compact_pts) compact_pts[id] = make_float4(mxf, myf, mzf, 0.f);
+    return;
+  }
   if (!live) return;
-  int id = s_base + slot_in_wave;
-  for (int w = 0; w < wv; w++) id += s_wave_cnt[w];
+  q2 = make_float4((float)C.xx, (float)C.xy, (float)C.xz, (float)C.yy);
+  q3 = make_float4((float)C.yz, (float)C.zz, __int_as_float(__double2loint(wn)), __int_as_float(__double2hiint(wn)));
+  tf[(size_t)b * 4 + 2] = q2;
+  tf[(size_t)b * 4 + 3] = q3;
+  const int id = s_base + local;
   occupied[id] = (int)b;
-  if (compact_pts) {  // D2D NDT: the source voxels are the "source cloud"
+  if (compact_pts) {
     compact_pts[id] = make_float4(mxf, myf, mzf, 0.f);
     compact_cov[2 * id] = q2;
     compact_cov[2 * id + 1] = q3;
