@@ -378,6 +378,23 @@ __device__ __forceinline__ void store_cov(float4* __restrict__ cov, int i, const
 // each walking 2 x 20 dependent gathers (21 us); here a lane gathers k/4 neighbours once, keeps them in registers for
 // the second (centred) pass, and the partial sums meet through two xor-shuffles in a fixed order.
 constexpr int COV_LANES = 4, COV_MAX_PER_LANE = 16;  // k <= 64
+// The 64 points of a 256-thread workgroup (4 lanes each) hand their raw covariances to the FIRST wave through LDS, which
+// regularises one point per lane: the eigen-decomposition (~1,000 dependent fp64 instructions) runs once per workgroup instead of
+// once per wave with every value replicated four times. Called by all 256 threads.
+__device__ __forceinline__ void cov_regularize_dense(const Sym3<double>& C, int method, float4* __restrict__ cov, int i, bool owner /* one lane per valid point */) {
+  __shared__ double s_c[64][6];
+  __shared__ int s_i[64];
+  const int p = threadIdx.x / COV_LANES;
+  if ((threadIdx.x % COV_LANES) == 0) {
+    s_c[p][0] = C.xx; s_c[p][1] = C.xy; s_c[p][2] = C.xz; s_c[p][3] = C.yy; s_c[p][4] = C.yz; s_c[p][5] = C.zz;
+    s_i[p] = owner ? i : -1;
+  }
+  __syncthreads();
+  if (threadIdx.x < 64 && s_i[threadIdx.x] >= 0) {
+    const int t = threadIdx.x;
+    store_cov(cov, s_i[t], regularize_cov(Sym3<double>{s_c[t][0], s_c[t][1], s_c[t][2], s_c[t][3], s_c[t][4], s_c[t][5]}, method));
+  }
+}
 template <int PER_LANE>  // neighbours a lane holds: k <= 4 * PER_LANE (5 for the reference's k = 20)
 __global__ __launch_bounds__(256) void cov_from_neighbors_kernel(const float4* __restrict__ pts, int n, int k, const int* __restrict__ nbr, int method,
                                                                  float4* __restrict__ cov, const int* __restrict__ subset = nullptr /* n point indices (a rank's tile), or all */) {
@@ -415,8 +432,7 @@ __global__ __launch_bounds__(256) void cov_from_neighbors_kernel(const float4* _
   }
   const double inv = 1.0 / k;
   C.xx *= inv; C.xy *= inv; C.xz *= inv; C.yy *= inv; C.yz *= inv; C.zz *= inv;
-  const Sym3<double> R = regularize_cov(C, method);  // all four lanes hold the same C: no divergence, lane 0 stores
-  if (sub == 0 && gt / COV_LANES < n) store_cov(cov, i, R);
+  cov_regularize_dense(C, method, cov, i, sub == 0 && gt / COV_LANES < n);
 }
 
 // k > 32 (up to 64): the same four-lanes-per-point scheme, but the neighbours are gathered again for the centred pass instead
@@ -451,8 +467,7 @@ __global__ __launch_bounds__(256) void cov_from_neighbors_regather_kernel(const 
   }
   const double inv = 1.0 / k;
   C.xx *= inv; C.xy *= inv; C.xz *= inv; C.yy *= inv; C.yz *= inv; C.zz *= inv;
-  const Sym3<double> R = regularize_cov(C, method);
-  if (sub == 0 && gt / COV_LANES < n) store_cov(cov, i, R);
+  cov_regularize_dense(C, method, cov, i, sub == 0 && gt / COV_LANES < n);
 }
 
 __global__ __launch_bounds__(256) void regularize_kernel(float4* __restrict__ cov, int n, int method) {
