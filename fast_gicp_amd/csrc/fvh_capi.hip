@@ -324,6 +324,7 @@ struct Engine {
         for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) for (int k = 0; k < 3; k++) { o.push_back(i - 1); o.push_back(j - 1); o.push_back(k - 1); }
         break;
       case FVH_DIRECT_RADIUS: {
+        if (!(radius >= 0.0) || radius > 511.0) return fail(FVH_ERR_INVALID_ARGUMENT, "DIRECT_RADIUS: radius must be within [0, 511] voxels");  // (NaN too; offsets travel packed, 10 bits per axis)
         int range = (int)std::ceil(radius);
         for (int i = -range; i <= range; i++) for (int j = -range; j <= range; j++) for (int k = -range; k <= range; k++)
           if (std::sqrt((double)(i * i + j * j + k * k)) <= radius + 1e-3) { o.push_back(i); o.push_back(j); o.push_back(k); }

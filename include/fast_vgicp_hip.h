@@ -81,6 +81,7 @@ const char* fvh_vgicp_last_error(const fvh_vgicp* h);
 
 int fvh_vgicp_set_resolution(fvh_vgicp* h, double resolution);                               /* [VC]:40 */
 int fvh_vgicp_set_kernel_params(fvh_vgicp* h, double kernel_width, double kernel_max_dist);  /* [VC]:41 */
+/* DIRECT_RADIUS: offsets up to +-511 voxels per axis (they travel packed, 10 bits each); a larger radius is FVH_ERR_INVALID_ARGUMENT */
 int fvh_vgicp_set_neighbor_search_method(fvh_vgicp* h, int method, double radius);           /* [VC]:42, [VCU]:41-94 */
 int fvh_vgicp_set_precision(fvh_vgicp* h, int precision);                                    /* new */
 /* fast_gicp::VoxelAccumulationMode (gicp_settings.hpp:10) of the CPU FastVGICP (setVoxelAccumulationMode, fast_vgicp_impl.hpp:41-43;

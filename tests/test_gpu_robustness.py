@@ -89,6 +89,18 @@ def test_neighbor_indices_are_validated():
     c.close()
 
 
+def test_direct_radius_is_range_checked():
+    """DIRECT_RADIUS enumerates (2 ceil(r) + 1)^3 candidate offsets on the host and ships them packed (10 bits per axis): a NaN, a
+    negative or an absurd radius must be refused up front instead of looping for minutes / overflowing the packing."""
+    from fast_gicp_amd import capi
+    c = _core()
+    for bad in (float("nan"), -1.0, 512.0, 1e9):
+        with pytest.raises(capi.FvhError, match="radius"):
+            c.set_neighbor_search_method(3, bad)
+    c.set_neighbor_search_method(3, 1.5)  # 19 offsets
+    c.close()
+
+
 def test_small_cloud_through_the_host_kdtree_path():
     """FastVGICPCuda's default CPU_PARALLEL_KDTREE mode on a cloud with fewer than k points: the reference's zero-initialised
     index vector pads with index 0 (fast_vgicp_cuda_impl.hpp:155,162); the result must be finite."""
