@@ -177,6 +177,64 @@ __global__ __launch_bounds__(256) void tile_bbox_kernel(const float4* __restrict
   }
 }
 
+// Both box levels in ONE launch (a dependent stage less than tile boxes -> boxes of 64 tile boxes): the first `tile_wgs`
+// workgroups box the 64-point tiles (one wave each), the others box 4,096 consecutive points each -- the same min / max as the
+// box of the 64 tile boxes, without waiting for them.
+__global__ __launch_bounds__(256) void tile_super_bbox_kernel(const float4* __restrict__ pts, int n, float4* __restrict__ bbox1, float4* __restrict__ bbox2, int tile_wgs,
+                                                              unsigned* __restrict__ clear_box /* the cloud's bounding cube, consumed earlier in the chain: left zeroed for the next upload */) {
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  if (clear_box && blockIdx.x == 0 && threadIdx.x < 6) clear_box[threadIdx.x] = 0u;
+  float lo[3], hi[3];
+  if ((int)blockIdx.x < tile_wgs) {
+    const int t = blockIdx.x * 4 + wv;
+    if (t * 64 >= n) return;
+    const float4 p = pts[min(t * 64 + lane, n - 1)];
+    lo[0] = hi[0] = p.x; lo[1] = hi[1] = p.y; lo[2] = hi[2] = p.z;
+#pragma unroll
+    for (int a = 0; a < 3; a++)
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) {
+        lo[a] = fminf(lo[a], __shfl_xor(lo[a], off));
+        hi[a] = fmaxf(hi[a], __shfl_xor(hi[a], off));
+      }
+    if (lane == 0) {
+      bbox1[2 * t] = make_float4(lo[0], lo[1], lo[2], 0.f);
+      bbox1[2 * t + 1] = make_float4(hi[0], hi[1], hi[2], 0.f);
+    }
+    return;
+  }
+  __shared__ float s_lo[4][3], s_hi[4][3];
+  const int s = blockIdx.x - tile_wgs;
+  const int first = s * 4096, last = min(n, first + 4096) - 1;  // (a partial tile pads with its last point, like the tile boxes: no effect on min / max)
+  lo[0] = lo[1] = lo[2] = 3e38f; hi[0] = hi[1] = hi[2] = -3e38f;
+#pragma unroll 4
+  for (int u = 0; u < 16; u++) {
+    const float4 p = pts[min(first + u * 256 + (int)threadIdx.x, last)];
+    lo[0] = fminf(lo[0], p.x); lo[1] = fminf(lo[1], p.y); lo[2] = fminf(lo[2], p.z);
+    hi[0] = fmaxf(hi[0], p.x); hi[1] = fmaxf(hi[1], p.y); hi[2] = fmaxf(hi[2], p.z);
+  }
+#pragma unroll
+  for (int a = 0; a < 3; a++) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      lo[a] = fminf(lo[a], __shfl_xor(lo[a], off));
+      hi[a] = fmaxf(hi[a], __shfl_xor(hi[a], off));
+    }
+    if (lane == 0) { s_lo[wv][a] = lo[a]; s_hi[wv][a] = hi[a]; }
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float l[3], h[3];
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+      l[a] = fminf(fminf(s_lo[0][a], s_lo[1][a]), fminf(s_lo[2][a], s_lo[3][a]));
+      h[a] = fmaxf(fmaxf(s_hi[0][a], s_hi[1][a]), fmaxf(s_hi[2][a], s_hi[3][a]));
+    }
+    bbox2[2 * s] = make_float4(l[0], l[1], l[2], 0.f);
+    bbox2[2 * s + 1] = make_float4(h[0], h[1], h[2], 0.f);
+  }
+}
+
 // Wave-wide bitonic sort of one (distance, index) pair per lane, ascending in the total order
 // (distance, index): 21 compare-exchange stages. Seeds a query's top-k list from a whole 64-point tile
 // at once -- ~250 instructions instead of ~43 serial insertions of ~50 dependent instructions each.

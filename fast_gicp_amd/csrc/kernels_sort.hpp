@@ -57,38 +57,59 @@ __device__ __forceinline__ unsigned spread3_9(unsigned v) {  // 9 bits -> every 
   return v;
 }
 
+// 27-bit Morton key of a point inside the cloud's bounding cube (cubic cells: the key is isotropic).
 // min_inverted: the box comes from pack_points_kernel (box[0..2] = ~ordered(min)), not from cloud_bbox_kernel
+struct MortonFrame { float lx, ly, lz, scale; };
+__device__ __forceinline__ MortonFrame morton_frame(const unsigned* __restrict__ box, int min_inverted) {
+  const unsigned flip = min_inverted ? 0xFFFFFFFFu : 0u;
+  MortonFrame f;
+  f.lx = ordered_to_float(box[0] ^ flip); f.ly = ordered_to_float(box[1] ^ flip); f.lz = ordered_to_float(box[2] ^ flip);
+  const float ex = ordered_to_float(box[3]) - f.lx, ey = ordered_to_float(box[4]) - f.ly, ez = ordered_to_float(box[5]) - f.lz;
+  f.scale = 511.999f / fmaxf(fmaxf(ex, ey), fmaxf(ez, 1e-6f));
+  return f;
+}
+__device__ __forceinline__ unsigned morton27(const MortonFrame& f, const float4& p) {
+  const unsigned ix = (unsigned)fminf(511.f, fmaxf(0.f, (p.x - f.lx) * f.scale));
+  const unsigned iy = (unsigned)fminf(511.f, fmaxf(0.f, (p.y - f.ly) * f.scale));
+  const unsigned iz = (unsigned)fminf(511.f, fmaxf(0.f, (p.z - f.lz) * f.scale));
+  return spread3_9(ix) | (spread3_9(iy) << 1) | (spread3_9(iz) << 2);
+}
 __global__ __launch_bounds__(256) void morton_keys_kernel(const float4* __restrict__ pts, int n, const unsigned* __restrict__ box, unsigned* __restrict__ keys,
                                                           int* __restrict__ idx, int min_inverted) {
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
-  const unsigned flip = min_inverted ? 0xFFFFFFFFu : 0u;
-  const float lx = ordered_to_float(box[0] ^ flip), ly = ordered_to_float(box[1] ^ flip), lz = ordered_to_float(box[2] ^ flip);
-  const float ex = ordered_to_float(box[3]) - lx, ey = ordered_to_float(box[4]) - ly, ez = ordered_to_float(box[5]) - lz;
-  const float extent = fmaxf(fmaxf(ex, ey), fmaxf(ez, 1e-6f));
-  const float scale = 511.999f / extent;  // cubic cells so the key is isotropic
-  const float4 p = pts[i];
-  const unsigned ix = (unsigned)fminf(511.f, fmaxf(0.f, (p.x - lx) * scale));
-  const unsigned iy = (unsigned)fminf(511.f, fmaxf(0.f, (p.y - ly) * scale));
-  const unsigned iz = (unsigned)fminf(511.f, fmaxf(0.f, (p.z - lz) * scale));
-  keys[i] = spread3_9(ix) | (spread3_9(iy) << 1) | (spread3_9(iz) << 2);
+  keys[i] = morton27(morton_frame(box, min_inverted), pts[i]);
   idx[i] = i;
 }
 
-// hist[bin * nwaves + wave]
-__global__ __launch_bounds__(256) void radix_hist_kernel(const unsigned* __restrict__ keys, int n, int shift, int nwaves, int items, unsigned* __restrict__ hist) {
-  __shared__ unsigned h[4][RADIX_BINS];
+// hist[bin * nwaves + wave]. With `pts` the keys do not exist yet: this first stage of the sort computes them on the way
+// (and stores them for its scatter) -- one dependent stage less than a key kernel in front of it (a stage of this chain is ~5 us
+// whatever it does).
+template <int BITS>
+__global__ __launch_bounds__(256) void radix_hist_kernel(unsigned* __restrict__ keys, int n, int shift, int nwaves, int items, unsigned* __restrict__ hist,
+                                                         const float4* __restrict__ pts = nullptr, const unsigned* __restrict__ box = nullptr, int min_inverted = 0) {
+  constexpr int BINS = 1 << BITS;
+  __shared__ unsigned h[4][BINS];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int wave = blockIdx.x * 4 + wv;
-  for (int b = lane; b < RADIX_BINS; b += 64) h[wv][b] = 0;
+  for (int b = lane; b < BINS; b += 64) h[wv][b] = 0;
   __syncthreads();
   if (wave < nwaves) {
     const int begin = wave * items, end = min(n, begin + items);
-    for (int i = begin + lane; i < end; i += 64) atomicAdd(&h[wv][(keys[i] >> shift) & (RADIX_BINS - 1)], 1u);
+    if (pts) {
+      const MortonFrame f = morton_frame(box, min_inverted);
+      for (int i = begin + lane; i < end; i += 64) {
+        const unsigned k = morton27(f, pts[i]);
+        keys[i] = k;
+        atomicAdd(&h[wv][(k >> shift) & (BINS - 1)], 1u);
+      }
+    } else {
+      for (int i = begin + lane; i < end; i += 64) atomicAdd(&h[wv][(keys[i] >> shift) & (BINS - 1)], 1u);
+    }
   }
   __syncthreads();
   if (wave < nwaves)
-    for (int b = lane; b < RADIX_BINS; b += 64) hist[(size_t)b * nwaves + wave] = h[wv][b];
+    for (int b = lane; b < BINS; b += 64) hist[(size_t)b * nwaves + wave] = h[wv][b];
 }
 
 // exclusive scan of `count` unsigned values in place, one workgroup of 1024 threads
@@ -125,10 +146,10 @@ __global__ __launch_bounds__(1024) void radix_scan_kernel(unsigned* __restrict__
 // was 32 us at 118k keys and ~300 us at 1M -- more than the rest of the pass): one wave per bin turns the bin's row of
 // per-wave counts into exclusive prefixes and emits the bin total; radix_scan_kernel then scans the 512 totals, and
 // the scatter adds bin_base[bin] to the in-bin prefix.
-__global__ __launch_bounds__(256) void radix_binscan_kernel(unsigned* __restrict__ hist /* [bins][nwaves] */, int nwaves, unsigned* __restrict__ totals /* [bins] */) {
+__global__ __launch_bounds__(256) void radix_binscan_kernel(unsigned* __restrict__ hist /* [bins][nwaves] */, int nwaves, unsigned* __restrict__ totals /* [bins] */, int bins = RADIX_BINS) {
   const int lane = threadIdx.x & 63;
   const int bin = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (bin >= RADIX_BINS) return;
+  if (bin >= bins) return;
   unsigned* row = hist + (size_t)bin * nwaves;
   unsigned run = 0;
   for (int base = 0; base < nwaves; base += 64) {
@@ -148,15 +169,17 @@ __global__ __launch_bounds__(256) void radix_binscan_kernel(unsigned* __restrict
 
 // stable scatter of (key, idx); on the last pass also gathers the point into the sorted cloud with
 // its original index in .w
-__global__ __launch_bounds__(256) void radix_scatter_kernel(const unsigned* __restrict__ keys_in, const int* __restrict__ idx_in, int n, int shift, int nwaves, int items,
+template <int BITS>
+__global__ __launch_bounds__(256) void radix_scatter_kernel(const unsigned* __restrict__ keys_in, const int* __restrict__ idx_in /* null: the identity (first pass) */, int n, int shift, int nwaves, int items,
                                                             const unsigned* __restrict__ offsets /* in-bin prefixes */, const unsigned* __restrict__ bin_base /* scanned bin totals */,
                                                             unsigned* __restrict__ keys_out, int* __restrict__ idx_out,
                                                             const float4* __restrict__ pts, float4* __restrict__ sorted_pts) {
-  __shared__ unsigned cur[4][RADIX_BINS];
+  constexpr int BINS = 1 << BITS;
+  __shared__ unsigned cur[4][BINS];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int wave = blockIdx.x * 4 + wv;
   if (wave >= nwaves) return;
-  for (int b = lane; b < RADIX_BINS; b += 64) cur[wv][b] = offsets[(size_t)b * nwaves + wave] + bin_base[b];
+  for (int b = lane; b < BINS; b += 64) cur[wv][b] = offsets[(size_t)b * nwaves + wave] + bin_base[b];
   // the cursors are private to this wave: wave-level ordering is enough (no workgroup barrier)
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   const int begin = wave * items, end = min(n, begin + items);
@@ -165,12 +188,12 @@ __global__ __launch_bounds__(256) void radix_scatter_kernel(const unsigned* __re
     const int i = base + lane;
     const bool valid = i < end;
     const unsigned key = valid ? keys_in[i] : 0xFFFFFFFFu;
-    const int id = valid ? idx_in[i] : -1;
-    const unsigned d = (key >> shift) & (RADIX_BINS - 1);
+    const int id = valid ? (idx_in ? idx_in[i] : i) : -1;
+    const unsigned d = (key >> shift) & (BINS - 1);
     // lanes holding the same digit
     unsigned long long peers = __ballot(valid);
 #pragma unroll
-    for (int bit = 0; bit < RADIX_BITS; bit++) {
+    for (int bit = 0; bit < BITS; bit++) {
       const unsigned long long m = __ballot((d >> bit) & 1);
       peers &= ((d >> bit) & 1) ? m : ~m;
     }
