@@ -381,7 +381,7 @@ int upload_cloud(Engine* e, CloudDev& c, const float* xyz, int n, int stride, bo
     boxp = c.box.as<unsigned>();
   }
   if (on_device) {
-    pack_points_kernel<<<(n + 255) / 256, 256, 0, e->stream>>>(xyz, n, stride, c.pts.as<float4>(), boxp);
+    pack_points_kernel<<<pack_grid(n, boxp != nullptr), 256, 0, e->stream>>>(xyz, n, stride, c.pts.as<float4>(), boxp);
     HIP_OR_FAIL(e, hipGetLastError());
   } else {
     // H2D the xyz (stride 3) / xyzi (stride 4, e.g. a KITTI .bin buffer) array into a staging buffer, then widen to float4 on device
@@ -397,11 +397,11 @@ int upload_cloud(Engine* e, CloudDev& c, const float* xyz, int n, int stride, bo
       HIP_OR_FAIL(e, hipMemcpyAsync(e->staging.p, e->upload_pinned, bytes, hipMemcpyHostToDevice, e->stream));
       HIP_OR_FAIL(e, hipEventRecord(e->upload_done, e->stream));
       e->upload_busy = true;
-      pack_points_kernel<<<(n + 255) / 256, 256, 0, e->stream>>>(e->staging.as<float>(), n, stride, c.pts.as<float4>(), boxp);
+      pack_points_kernel<<<pack_grid(n, boxp != nullptr), 256, 0, e->stream>>>(e->staging.as<float>(), n, stride, c.pts.as<float4>(), boxp);
       HIP_OR_FAIL(e, hipGetLastError());
     } else {
       HIP_OR_FAIL(e, hipMemcpyAsync(e->staging.p, xyz, bytes, hipMemcpyHostToDevice, e->stream));
-      pack_points_kernel<<<(n + 255) / 256, 256, 0, e->stream>>>(e->staging.as<float>(), n, stride, c.pts.as<float4>(), boxp);
+      pack_points_kernel<<<pack_grid(n, boxp != nullptr), 256, 0, e->stream>>>(e->staging.as<float>(), n, stride, c.pts.as<float4>(), boxp);
       HIP_OR_FAIL(e, hipGetLastError());
       HIP_OR_FAIL(e, hipStreamSynchronize(e->stream));  // caller may free xyz on return (reference copies too)
     }

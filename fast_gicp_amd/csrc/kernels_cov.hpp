@@ -1078,14 +1078,17 @@ __global__ __launch_bounds__(256) void gicp_records_kernel(const float4* __restr
 
 // float xyz (stride 3 or 4) -> float4 (w = 0); optionally reduces the cloud's bounding cube into box[0..2] = ~ordered(min),
 // box[3..5] = ordered(max) (zero-initialised by the host; both are atomicMax) for the cooperative sort
+inline int pack_grid(int n, bool with_box) { const int b = (n + 255) / 256; return with_box ? (b < 128 ? b : 128) : b; }
 __global__ __launch_bounds__(256) void pack_points_kernel(const float* __restrict__ xyz, int n, int stride, float4* __restrict__ out, unsigned* __restrict__ box) {
   __shared__ float s_lo[4][3], s_hi[4][3];
-  const int i = blockIdx.x * 256 + threadIdx.x;
   float lo[3] = {3e38f, 3e38f, 3e38f}, hi[3] = {-3e38f, -3e38f, -3e38f};
-  if (i < n) {
+  // grid-stride: with a bounding cube to reduce the grid is capped (pack_grid()) -- every workgroup ends with six atomics on the
+  // same six words, ~12 ns apart at the memory-side atomic unit: 391 workgroups of a 100k-point cloud spent 5 of 11 us queueing there
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
     const float x = xyz[(size_t)i * stride], y = xyz[(size_t)i * stride + 1], z = xyz[(size_t)i * stride + 2];
     out[i] = make_float4(x, y, z, 0.f);
-    lo[0] = hi[0] = x; lo[1] = hi[1] = y; lo[2] = hi[2] = z;
+    lo[0] = fminf(lo[0], x); lo[1] = fminf(lo[1], y); lo[2] = fminf(lo[2], z);
+    hi[0] = fmaxf(hi[0], x); hi[1] = fmaxf(hi[1], y); hi[2] = fmaxf(hi[2], z);
   }
   if (!box) return;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
