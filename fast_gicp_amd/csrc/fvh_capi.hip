@@ -695,7 +695,7 @@ int build_voxelmap(Engine* e, const CloudDev& c, VoxelMapDev& vm, double res, bo
     HIP_OR_FAIL(e, vm.table.ensure((size_t)cap * 64));
     HIP_OR_FAIL(e, vm.keys[0].ensure((size_t)cap * 8));
     HIP_OR_FAIL(e, vm.keys[1].ensure((size_t)cap * 8));
-    HIP_OR_FAIL(e, vm.acc.ensure((size_t)cap * VM_ACC_STRIDE * sizeof(double)));
+    HIP_OR_FAIL(e, vm.acc.ensure((size_t)cap * VM_ACC_BUCKET * sizeof(double)));
     HIP_OR_FAIL(e, vm.counters.ensure(2 * 16 * sizeof(int)));
     if (before[0] != vm.keys[0].p || before[1] != vm.keys[1].p || before[2] != vm.acc.p || before[3] != vm.counters.p) vm.clean_cap = 0;
   }
@@ -709,7 +709,7 @@ int build_voxelmap(Engine* e, const CloudDev& c, VoxelMapDev& vm, double res, bo
     const int fill = vm.cur ^ 1;
     unsigned long long* keys = vm.keys[fill].as<unsigned long long>();
     int* counters = vm.counters.as<int>() + 16 * fill;
-    if (vm.clean_cap != cap) vm_clear_kernel<<<(cap * 5 + 255) / 256, 256, 0, e->stream>>>(keys, vm.acc.as<double>(), cap, counters);
+    if (vm.clean_cap != cap) vm_clear_kernel<<<(cap * 10 + 255) / 256, 256, 0, e->stream>>>(keys, vm.acc.as<double>(), cap, counters);
     vm.clean_cap = 0;  // keys[fill] is in use from here on; the finalize pass below makes the OTHER pair clean
     if (c.n) {
       vm_accumulate_kernel<MODE><<<(c.n + 255) / 256, 256, 0, e->stream>>>(c.pts.as<float4>(), c.cov.as<float4>(), c.n, res, keys, cap - 1, vm.acc.as<double>(), counters + 1,

@@ -37,28 +37,37 @@ namespace fvh {
 constexpr int VM_LDS_SLOTS = 512;
 constexpr int VM_LDS_PROBES = 8;
 constexpr int VM_ACC_STRIDE = 10;
+// Two accumulator sets per bucket: the workgroup whose CAS CREATED the bucket is its owner and writes its partial sums with
+// plain stores; every other contributor adds into the visitor set with memory-side fp64 atomics. In Morton order nearly every
+// voxel has one contributing workgroup, so most of the ~10 atomics per (workgroup, voxel) -- 21 of this pass's 33 us at 100k
+// points -- become stores. vm_finalize_kernel adds the two sets.
+constexpr int VM_ACC_BUCKET = 2 * VM_ACC_STRIDE;
 constexpr unsigned VM_MAX_PROBE = 255;
 
 // Claim (or find) the bucket of `key`, linear probing from `slot`. CAS first: an atomic goes to the memory side (the
 // XCDs' L2s are not coherent), ~2 us per round trip, and the CAS alone answers both "free" and "already this key".
-__device__ __forceinline__ unsigned global_claim_from(unsigned long long* keys, unsigned mask, unsigned long long key, unsigned slot, unsigned probes_done) {
+// `created`: this call's CAS turned an empty bucket into the key's (exactly one caller per bucket and build sees that).
+__device__ __forceinline__ unsigned global_claim_from(unsigned long long* keys, unsigned mask, unsigned long long key, unsigned slot, unsigned probes_done, bool& created) {
   const unsigned max_probe = mask < VM_MAX_PROBE ? mask : VM_MAX_PROBE;
+  created = false;
   for (unsigned it = probes_done; it <= max_probe; it++) {
     const unsigned long long old = atomicCAS(keys + slot, FVH_EMPTY_KEY, key);
-    if (old == FVH_EMPTY_KEY || old == key) return slot;
+    if (old == FVH_EMPTY_KEY) { created = true; return slot; }
+    if (old == key) return slot;
     slot = (slot + 1) & mask;
   }
   return 0xFFFFFFFFu;  // probe budget exhausted: the caller counts it in `dropped` and the host rebuilds at the safe size
 }
 __device__ __forceinline__ unsigned global_claim(unsigned long long* keys, unsigned mask, unsigned long long key) {
-  return global_claim_from(keys, mask, key, hash_slot(key, mask), 0);
+  bool created;
+  return global_claim_from(keys, mask, key, hash_slot(key, mask), 0, created);
 }
 
 // first build at a capacity (afterwards vm_finalize_kernel leaves everything clean): keys -> EMPTY, accumulators and counters -> 0
 __global__ __launch_bounds__(256) void vm_clear_kernel(unsigned long long* __restrict__ keys, double* __restrict__ acc, unsigned capacity, int* __restrict__ counters) {
   const unsigned i = blockIdx.x * 256 + threadIdx.x;
   if (i < capacity) keys[i] = FVH_EMPTY_KEY;
-  if (i < capacity * 5) reinterpret_cast<uint4*>(acc)[i] = make_uint4(0, 0, 0, 0);  // 10 doubles = 5 quads per bucket
+  if (i < capacity * 10) reinterpret_cast<uint4*>(acc)[i] = make_uint4(0, 0, 0, 0);  // 2 x 10 doubles = 10 quads per bucket
   if (i < 16) counters[i] = 0;
 }
 
@@ -121,7 +130,7 @@ __global__ __launch_bounds__(256) void vm_accumulate_kernel(const float4* __rest
         unsigned b = global_claim(table_keys, mask, key);
         if (b != 0xFFFFFFFFu) {
 #pragma unroll
-          for (int j = 0; j < VM_ACC_STRIDE; j++) atomicAdd(&acc[(size_t)b * VM_ACC_STRIDE + j], v[j]);
+          for (int j = 0; j < VM_ACC_STRIDE; j++) atomicAdd(&acc[(size_t)b * VM_ACC_BUCKET + VM_ACC_STRIDE + j], v[j]);  // (a lone point: always a visitor)
         } else {
           atomicAdd(dropped, 1);
         }
@@ -146,10 +155,20 @@ __global__ __launch_bounds__(256) void vm_accumulate_kernel(const float4* __rest
     if (fk[u] == FVH_EMPTY_KEY) continue;
     const int s = tid + 256 * u;
     unsigned b = fslot[u];
-    if (fold[u] != FVH_EMPTY_KEY && fold[u] != fk[u]) b = global_claim_from(table_keys, mask, fk[u], (fslot[u] + 1) & mask, 1);
+    bool created = fold[u] == FVH_EMPTY_KEY;
+    if (fold[u] != FVH_EMPTY_KEY && fold[u] != fk[u]) b = global_claim_from(table_keys, mask, fk[u], (fslot[u] + 1) & mask, 1, created);
     if (b == 0xFFFFFFFFu) { atomicAdd(dropped, 1); continue; }
+    if (created) {  // owner: nobody else writes this half
+      uint4* dst = reinterpret_cast<uint4*>(acc + (size_t)b * VM_ACC_BUCKET);
 #pragma unroll
-    for (int j = 0; j < VM_ACC_STRIDE; j++) atomicAdd(&acc[(size_t)b * VM_ACC_STRIDE + j], lacc[s * VM_ACC_STRIDE + j]);
+      for (int j = 0; j < VM_ACC_STRIDE / 2; j++) {
+        const double lo = lacc[s * VM_ACC_STRIDE + 2 * j], hi = lacc[s * VM_ACC_STRIDE + 2 * j + 1];
+        dst[j] = make_uint4((unsigned)__double2loint(lo), (unsigned)__double2hiint(lo), (unsigned)__double2loint(hi), (unsigned)__double2hiint(hi));
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < VM_ACC_STRIDE; j++) atomicAdd(&acc[(size_t)b * VM_ACC_BUCKET + VM_ACC_STRIDE + j], lacc[s * VM_ACC_STRIDE + j]);
+    }
   }
 }
 
@@ -184,13 +203,14 @@ __global__ __launch_bounds__(VM_FIN_THREADS) void vm_finalize_kernel(const unsig
     uint4 q0 = make_uint4((unsigned)key, (unsigned)(key >> 32), 0u, 0u);
     double a[VM_ACC_STRIDE];
     {
-      uint4* aq = reinterpret_cast<uint4*>(acc + (size_t)b * VM_ACC_STRIDE);  // 80 B per bucket, 16-B aligned
+      uint4* aq = reinterpret_cast<uint4*>(acc + (size_t)b * VM_ACC_BUCKET);  // 2 x 80 B per bucket (owner sums, visitor sums), 16-B aligned
 #pragma unroll
       for (int j = 0; j < VM_ACC_STRIDE / 2; j++) {
-        const uint4 v = aq[j];
-        a[2 * j] = __hiloint2double((int)v.y, (int)v.x);
-        a[2 * j + 1] = __hiloint2double((int)v.w, (int)v.z);
+        const uint4 v = aq[j], w = aq[VM_ACC_STRIDE / 2 + j];
+        a[2 * j] = __hiloint2double((int)v.y, (int)v.x) + __hiloint2double((int)w.y, (int)w.x);
+        a[2 * j + 1] = __hiloint2double((int)v.w, (int)v.z) + __hiloint2double((int)w.w, (int)w.z);
         aq[j] = make_uint4(0, 0, 0, 0);  // consumed: clean for the next build
+        aq[VM_ACC_STRIDE / 2 + j] = make_uint4(0, 0, 0, 0);
       }
     }
     const double cnt = a[9];
