@@ -1,0 +1,27 @@
+"""bench.py's N > 1 control flow (barrier, max over ranks, one JSON line from rank 0) walked on a single-GPU box: both ranks on
+device 0, gloo for the barrier (FVH_BENCH_SHARE_GPU / FVH_BENCH_BACKEND, test-only knobs). The sharded leg (peer-mapped exchange)
+is covered by tests/test_gpu_peer.py; real xGMI scaling is the driver's to measure."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+from tests import util
+
+pytestmark = pytest.mark.gpu
+
+
+def test_two_rank_bench_prints_one_aggregate_line():
+    env = dict(os.environ, FVH_BENCH_SHARE_GPU="1", FVH_BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29531",
+           os.path.join(util.ROOT, "bench.py"), "--gpus", "2", "--steps", "10", "--warmup", "2", "--no-cpu-baseline", "--configs", "none"]
+    p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300, cwd=util.ROOT)
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert p.returncode == 0 and len(lines) == 1, (p.returncode, p.stdout[-400:], p.stderr[-800:])
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 10 and d["warmup"] == 2 and d["scaling"] == "weak" and d["higher_is_better"] is True
+    assert d["value"] > 0 and abs(d["value"] - 2 * 1e3 / d["ms_per_step"]) <= 1e-3 * d["value"]  # whole-job aggregate = ranks x steps / max time
+    assert abs(d["fitness_score"] - 0.198792) < 1e-5
+    assert "roofline" in d and d["roofline"]["bound"] in ("hbm", "mfma")
