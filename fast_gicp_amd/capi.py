@@ -90,6 +90,7 @@ class _Core:
 
     def __init__(self, device=0):
         self._lib = load()
+        self.device = int(device)
         self.h = C.c_void_p()
         rc = getattr(self._lib, self._prefix + "create")(int(device), C.byref(self.h))
         if rc != 0:
@@ -218,6 +219,13 @@ def comm_unique_id():
     if rc != 0:
         raise FvhError("fvh_comm_unique_id failed: %d" % rc)
     return bytes(buf)
+
+
+def debug_slot_pool(device=0):
+    """(reserved, active, recent) of the process-wide pool that splits a device's co-resident workgroup slots between concurrent aligns."""
+    r, a, c = C.c_int(0), C.c_int(0), C.c_int(0)
+    load().fvh_debug_slot_pool(int(device), C.byref(r), C.byref(a), C.byref(c))
+    return r.value, a.value, c.value
 
 
 def device_count():
@@ -376,6 +384,11 @@ class VGICPCore(_Core):
         n = C.c_int(0)
         self._call("debug_get_persist_aborts", C.byref(n))
         return n.value
+
+    def debug_persist_grid(self):
+        b, c = C.c_int(0), C.c_int(0)
+        self._call("debug_get_persist_grid", C.byref(b), C.byref(c))
+        return b.value, c.value
 
     def debug_table_capacity(self):
         n = C.c_int(0)

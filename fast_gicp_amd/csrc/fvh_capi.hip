@@ -149,14 +149,26 @@ struct SlotPool {
   int acquire(int dev, int cap, int want) {  // -> granted workgroups (0: use the multi-launch route)
     std::lock_guard<std::mutex> lk(mu);
     dev &= 15;
+    const int recent_before = recent[dev];
     active[dev]++;
     recent[dev] = std::max(recent[dev], active[dev]);
     static const int max_split = [] { const char* v = getenv("FVH_SLOT_MAX_SPLIT"); return v ? std::max(1, atoi(v)) : 4; }();
     const int share = std::max(1, cap / std::max(1, std::min(recent[dev], max_split)));
     const int grant = std::min(std::min(want, share), cap - reserved[dev]);
-    if (grant < std::min(want, 32)) return 0;  // too little left to be worth a gang launch
+    if (grant < std::min(want, 32)) {  // too little left to be worth a gang launch
+      // a refused request holds nothing and is never released: it must not stay counted (round 2 leaked `active` here, and every
+      // later persistent launch of the process got cap / min(recent, 4) workgroups for good)
+      active[dev]--;
+      recent[dev] = recent_before;
+      return 0;
+    }
     reserved[dev] += grant;
     return grant;
+  }
+  void snapshot(int dev, int* res, int* act, int* rec) {
+    std::lock_guard<std::mutex> lk(mu);
+    dev &= 15;
+    *res = reserved[dev]; *act = active[dev]; *rec = recent[dev];
   }
   void release(int dev, int grant) {
     std::lock_guard<std::mutex> lk(mu);
@@ -985,7 +997,7 @@ int do_compute_error(Engine* e, const CostSource& src, VoxelMapDev& vm, const do
 
 template <int MODE>
 int do_align(Engine* e, const CostSource& src, VoxelMapDev& vm, const double* guess16, const fvh_lm_params* params, fvh_lm_result* result, const Rebuild& rebuild_safe,
-             bool retried = false, bool no_persist = false) {
+             bool retried = false, bool no_persist = false, int forced_grid = 0 /* multi-launch retry of an aborted persistent launch: its grid */) {
   if (!guess16 || !result) return e->fail(FVH_ERR_INVALID_ARGUMENT, "align: null argument");
   if (!vm.valid) return e->fail(FVH_ERR_BAD_STATE, "align: target voxel map not built");
   fvh_lm_params p;
@@ -1058,7 +1070,7 @@ int do_align(Engine* e, const CostSource& src, VoxelMapDev& vm, const double* gu
       // multi-GPU: an abort on ANY rank reaches every rank within a watchdog period (its mailbox stays empty), so all ranks
       // arrive here and restart together; the exchange counter jumps past whatever this launch may have used
       if (sharded) e->peer.x = (e->peer.x + 8192) & ~1ull;
-      return do_align<MODE>(e, src, vm, guess16, params, result, rebuild_safe, retried, true);
+      return do_align<MODE>(e, src, vm, guess16, params, result, rebuild_safe, retried, true, granted);  // the same grid: the same partition of the items, the same sums
     }
     launched = 1;
     e->persist_backoff = 0;  // a clean persistent run: the device is ours again
@@ -1073,7 +1085,7 @@ int do_align(Engine* e, const CostSource& src, VoxelMapDev& vm, const double* gu
     for (int s = 0; s < batch; s++) {
       // the first launch carries the initial guess and the LM parameters and (re)initialises the device state
       const bool first = (launched == 0 && s == 0 && !degenerate);
-      int rc = launch_cost<MODE>(e, src, vm, -1, first ? &guess : nullptr, nullptr, first ? &p : nullptr, false, e->peer.x + (unsigned long long)(launched + s));
+      int rc = launch_cost<MODE>(e, src, vm, -1, first ? &guess : nullptr, nullptr, first ? &p : nullptr, false, e->peer.x + (unsigned long long)(launched + s), forced_grid);
       if (rc) return rc;
       if (e->comm) {
         rc = allreduce_sums(e);
@@ -1098,7 +1110,7 @@ int do_align(Engine* e, const CostSource& src, VoxelMapDev& vm, const double* gu
     if (retried) return e->fail(FVH_ERR_BAD_STATE, "voxel map overflow persists after safe rebuild");
     int rc = rebuild_safe();
     if (rc) return rc;
-    return do_align<MODE>(e, src, vm, guess16, params, result, rebuild_safe, true, no_persist);
+    return do_align<MODE>(e, src, vm, guess16, params, result, rebuild_safe, true, no_persist, forced_grid);
   }
   e->prev_steps = e->last_steps;
   e->last_steps = 1 + h->num_error_evals;  // launches this align needed: the first linearize + one fused launch per trial
@@ -1411,6 +1423,7 @@ int downsample_approx(Engine* e, DownsampleDev& d, const float* xyz, int n, int 
     HIP_OR_FAIL(e, hipStreamSynchronize(e->stream));
     count = (unsigned long long)h[0] + h[1];
     bad = hb;
+    if (!(e->result_dev && !e->prof.on) || hb) HIP_OR_FAIL(e, hipMemsetAsync(&st->bad, 0, sizeof(unsigned), e->stream));  // the emit kernel only re-arms the flag when it reports through mapped memory
   } else if (!on_device) {
     HIP_OR_FAIL(e, hipStreamSynchronize(e->stream));  // the caller may free its host buffer on return; (the staging copy is long done, this only drains the emit kernel)
   }
@@ -1772,6 +1785,20 @@ int fvh_vgicp_profile_reset(fvh_vgicp* h) { CHECK_HANDLE(h); HIP_OR_FAIL(&h->e, 
 int fvh_vgicp_profile_get(fvh_vgicp* h, const char* cls, double* ms, int* n) { CHECK_HANDLE(h); return profile_get(&h->e, cls, ms, n); }
 int fvh_vgicp_debug_set_voxel_hint(fvh_vgicp* h, int num_voxels) { CHECK_HANDLE(h); h->voxelmap.nv_hint = num_voxels; return FVH_OK; }
 int fvh_vgicp_debug_get_persist_aborts(fvh_vgicp* h, int* n) { CHECK_HANDLE(h); if (!n) return FVH_ERR_INVALID_ARGUMENT; *n = h->e.persist_aborts; return FVH_OK; }
+int fvh_vgicp_debug_get_persist_grid(fvh_vgicp* h, int* blocks, int* capacity) {
+  CHECK_HANDLE(h);
+  if (blocks) *blocks = h->e.last_persist_blocks;
+  if (capacity) *capacity = persistent_capacity<MODE_VGICP>(&h->e);
+  return FVH_OK;
+}
+int fvh_debug_slot_pool(int device, int* reserved, int* active, int* recent) {
+  int r = 0, a = 0, c = 0;
+  g_slots.snapshot(device, &r, &a, &c);
+  if (reserved) *reserved = r;
+  if (active) *active = a;
+  if (recent) *recent = c;
+  return FVH_OK;
+}
 int fvh_vgicp_debug_get_table_capacity(fvh_vgicp* h, int* capacity) { CHECK_HANDLE(h); if (!capacity) return FVH_ERR_INVALID_ARGUMENT; *capacity = (int)h->voxelmap.capacity; return FVH_OK; }
 int fvh_vgicp_debug_get_skipped_points(fvh_vgicp* h, int* n) {
   CHECK_HANDLE(h);

@@ -220,7 +220,8 @@ __global__ __launch_bounds__(256) void avg_keys_hist_kernel(const float* __restr
   for (int w = blockIdx.x * 256 + threadIdx.x; w < nwords; w += gridDim.x * 256) trigbits[w] = 0u;
   if (blockIdx.x == 0) {
     for (int s = threadIdx.x; s < AVG_SLOTS; s += 256) st->slot_used[s] = 0u;
-    if (threadIdx.x == 0) { st->bad = 0u; }
+    // (st->bad is NOT reset here: other workgroups of this very launch raise it with an atomic, and nothing orders a plain store
+    // of workgroup 0 against them -- the flag is cleared by whoever consumed it: the last workgroup of avg_emit_kernel, or the host)
   }
   for (int b = lane; b < AVG_SLOTS; b += 64) h[wv][b] = 0;
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -470,6 +471,7 @@ __global__ __launch_bounds__(256) void avg_emit_kernel(const float4* __restrict_
     st->emit_ticket = 0u;
     __hip_atomic_store(&host_result[0], (unsigned long long)(st->trig_total + st->used_slots), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     __hip_atomic_store(&host_result[1], (unsigned long long)st->bad, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    st->bad = 0u;  // consumed: re-armed for the next call (like the ticket), long after every setter of this call has finished
     __threadfence_system();
     __hip_atomic_store(&host_result[2], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
   }

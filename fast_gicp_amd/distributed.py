@@ -6,14 +6,15 @@ Every correspondence contributes independently to (err, H, b), so the only coupl
 
 Three ways to run it (ShardedVGICP(collective=...)):
 
-  "peer" (default on GPUs)  the engine shards INTERNALLY (include/fast_vgicp_hip.h, fvh_vgicp_peer_*): every rank makes the
+  "peer"    the engine shards INTERNALLY (include/fast_vgicp_hip.h, fvh_vgicp_peer_*): every rank makes the
             same calls on the same full clouds; k-NN / covariance estimation run on the rank's tile and are all-gathered
             through peer-mapped staging areas; the cost evaluation walks the rank's tile and the sums meet in peer-mapped
             mailboxes INSIDE the cost kernel (one xGMI hop, 1.4 us measured) -- a sharded align stays ONE persistent
             launch per rank, no RCCL, no numpy round trip.  This module only carries the 64-byte IPC handles between
             the ranks (torch.distributed all_gather_object) -- see attach_peers().
-  "rccl"    round 1's path: the rank uploads its tile of the source; ncclAllReduce(32 x f64) on the engine stream between
-            the launches of the multi-launch LM route.
+  "rccl"    (the DEFAULT: `collective=None`) the rank uploads its tile of the source; ncclAllReduce(32 x f64) on the engine
+            stream between the launches of the multi-launch LM route. It stays the default until the peer path has run on
+            distinct GPUs over xGMI (so far it was only exercised with all ranks on one device).
   "host"    the host-driven `ShardedLsq` below through a caller-supplied all-reduce (torch.distributed gloo on CPU in the
             tests): what the world_size = 2 CPU tests exercise.
 
@@ -153,11 +154,16 @@ class ShardedVGICP:
         self.core.comm_init(unique_id_bytes, self.world_size, self.rank)
         self._comm_ready = True
 
-    def attach_peers(self, max_points, device_index=0):
+    def attach_peers(self, max_points, device_index=None):
         """collective "peer": export this rank's exchange region, swap the IPC handles with all ranks, map theirs.
-        `device_index`: the GPU this rank runs on (ranks sharing a GPU share its co-resident workgroup slots)."""
+        `device_index`: the GPU this rank runs on (ranks sharing a GPU share its co-resident workgroup slots); by default the
+        device the handle was created on."""
         import os
         assert self.collective == "peer"
+        if device_index is None:
+            device_index = getattr(self.core, "device", None)
+            if device_index is None:
+                raise ValueError("attach_peers: pass device_index (the GPU this rank's handle lives on)")
         handle, ptr = self.core.peer_export(int(max_points))
         mine = (handle, ptr, os.getpid(), int(device_index))
         if self.world_size > 1:

@@ -177,6 +177,8 @@ int fvh_vgicp_debug_set_voxel_hint(fvh_vgicp* h, int num_voxels);
 int fvh_vgicp_debug_get_table_capacity(fvh_vgicp* h, int* capacity);
 int fvh_vgicp_debug_get_skipped_points(fvh_vgicp* h, int* n);  /* target points of the current voxel map that belong to no voxel: non-finite or |coord| >= 2^20 voxels (they are skipped, never fatal) */
 int fvh_vgicp_debug_get_persist_aborts(fvh_vgicp* h, int* n);  /* persistent-LM launches whose barrier watchdog fired (each was redone with one launch per LM transition) */
+int fvh_vgicp_debug_get_persist_grid(fvh_vgicp* h, int* blocks, int* capacity);  /* workgroups of the last persistent-LM launch / co-resident workgroup capacity of the device for that kernel */
+int fvh_debug_slot_pool(int device, int* reserved, int* active, int* recent);    /* the process-wide pool that splits those workgroup slots between concurrent aligns: all zero when nothing is in flight */
 
 /* new: multi-GPU (one process per GPU).  Every rank holds a spatial-tile shard of the source
  * cloud and the target voxel map; the 28-value normal-equation block (err, b, upper H) is

@@ -260,7 +260,72 @@ def test_concurrent_handles_share_the_coresident_slots():
         assert util.rel_err(T, ref["T"]) < 1e-9  # a different grid orders the sums differently: not bit-identical, but the same registration
     print("aligns/s: one handle %.0f, four concurrent handles %.0f (x%.2f), one-launch fraction %.2f" % (single, multi, multi / single, one_launch))
     assert multi > 0.9 * single  # (the aligns are latency chains sharing the same CUs: measured x1.2-1.4 at four handles; the point here is that nobody aborts or falls back)
+    # Round 2 leaked a concurrency count per REFUSED grant: afterwards every lone align of the process got
+    # cap / 4 workgroups. Whatever happened above, the pool must be empty now and a lone align must get its whole grid again.
+    assert capi.debug_slot_pool(0)[:2] == (0, 0), capi.debug_slot_pool(0)
+    for _ in range(6):  # (the concurrency ESTIMATE decays one align at a time by design)
+        r = cores[0].align()
+    blocks, cap = cores[0].debug_persist_grid()
+    assert r["num_launches"] == 1 and capi.debug_slot_pool(0) == (0, 0, 1), capi.debug_slot_pool(0)
+    lone = capi.VGICPCore(0)
+    lone.set_neighbor_search_method(0)
+    lone.set_target_cloud(tgt); lone.find_target_neighbors(20); lone.calculate_target_covariances(3); lone.create_target_voxelmap()
+    lone.set_source_cloud(src); lone.find_source_neighbors(20); lone.calculate_source_covariances(3)
+    lone.align()
+    assert lone.debug_persist_grid()[0] == blocks, (lone.debug_persist_grid(), blocks)  # a fresh handle and the veteran get the same grid
+    assert np.array_equal(lone.align()["T"], ref["T"])                                  # ... hence bit-identical sums with the very first align
+    lone.close()
     for c in cores:
+        c.close()
+
+
+def test_refused_slot_requests_do_not_throttle_later_aligns():
+    """The refusal path itself, deterministically: while one thread HOLDS most of the device's slots (a long align at 100k
+    points x DIRECT27 keeps its grant for ~0.3 ms per align, repeated), small aligns on other handles are refused or
+    squeezed; when everything has drained a lone handle must see the full grid and an empty pool."""
+    import threading
+    from fast_gicp_amd import capi
+    tgt, src = util.bundled_pair()
+    big_t, big_s, _ = util.synthetic_pair(100000, 100000, seed=5, extent=60.0)
+    big = capi.VGICPCore(0)
+    big.set_resolution(0.5); big.set_neighbor_search_method(2)
+    big.set_target_cloud(big_t); big.calculate_target_covariances_rbf(3); big.create_target_voxelmap()
+    big.set_source_cloud(big_s); big.calculate_source_covariances_rbf(3)
+    small = []
+    for _ in range(3):
+        c = capi.VGICPCore(0)
+        c.set_neighbor_search_method(2)
+        c.set_target_cloud(tgt); c.find_target_neighbors(20); c.calculate_target_covariances(3); c.create_target_voxelmap()
+        c.set_source_cloud(src); c.find_source_neighbors(20); c.calculate_source_covariances(3)
+        small.append(c)
+    ref = small[0].align()
+    full_blocks = small[0].debug_persist_grid()[0]
+    stop = threading.Event()
+    fallbacks = [0]
+
+    def hog():
+        while not stop.is_set():
+            big.align()
+
+    def nag(c):
+        for _ in range(40):
+            if c.align()["num_launches"] != 1:
+                fallbacks[0] += 1
+
+    th = [threading.Thread(target=hog)] + [threading.Thread(target=nag, args=(c,)) for c in small]
+    for t in th:
+        t.start()
+    for t in th[1:]:
+        t.join()
+    stop.set()
+    th[0].join()
+    assert capi.debug_slot_pool(0)[:2] == (0, 0), capi.debug_slot_pool(0)
+    for _ in range(6):
+        r = small[0].align()
+    assert r["num_launches"] == 1 and small[0].debug_persist_grid()[0] == full_blocks, (small[0].debug_persist_grid(), full_blocks)
+    assert np.array_equal(r["T"], ref["T"])
+    print("refused / squeezed small aligns that took the multi-launch route: %d of 120" % fallbacks[0])
+    for c in small + [big]:
         c.close()
 
 
