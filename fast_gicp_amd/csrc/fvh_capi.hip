@@ -145,21 +145,22 @@ std::atomic<int> g_live_engines{0};    // engine handles alive in this process t
 // case is caught by the barrier watchdog and answered with a back-off (Engine::persist_backoff).
 struct SlotPool {
   std::mutex mu;
-  int reserved[16] = {0}, active[16] = {0}, recent[16] = {0};
+  int reserved[16] = {0}, active[16] = {0}, recent[16] = {0}, calm[16] = {0};
+  static constexpr int DECAY_AFTER = 32;  // releases in a row that saw less concurrency than the estimate before the estimate drops by one
   int acquire(int dev, int cap, int want) {  // -> granted workgroups (0: use the multi-launch route)
     std::lock_guard<std::mutex> lk(mu);
     dev &= 15;
-    const int recent_before = recent[dev];
     active[dev]++;
     recent[dev] = std::max(recent[dev], active[dev]);
     static const int max_split = [] { const char* v = getenv("FVH_SLOT_MAX_SPLIT"); return v ? std::max(1, atoi(v)) : 4; }();
     const int share = std::max(1, cap / std::max(1, std::min(recent[dev], max_split)));
     const int grant = std::min(std::min(want, share), cap - reserved[dev]);
     if (grant < std::min(want, 32)) {  // too little left to be worth a gang launch
-      // a refused request holds nothing and is never released: it must not stay counted (round 2 leaked `active` here, and every
-      // later persistent launch of the process got cap / min(recent, 4) workgroups for good)
+      // a refused request holds nothing and is never released: it must not stay counted in `active` (round 2 leaked it here, and
+      // every later persistent launch of the process got cap / min(recent, 4) workgroups for good). The concurrency ESTIMATE keeps
+      // the bump: the next grants shrink so that this caller gets its share on the retry; it decays slowly in release().
       active[dev]--;
-      recent[dev] = recent_before;
+      calm[dev] = 0;
       return 0;
     }
     reserved[dev] += grant;
@@ -175,7 +176,15 @@ struct SlotPool {
     dev &= 15;
     reserved[dev] -= grant;
     active[dev]--;
-    if (recent[dev] > active[dev] + 1) recent[dev]--;  // the estimate of the concurrency decays one align at a time
+    // The estimate of the concurrency decays slowly: host threads spend half their time between aligns, so `active` at a release
+    // under-reads the contention. (Dropping it at every calm release made four 474-workgroup aligns oscillate: shares grew back to
+    // cap / 2, the third thread was refused, and 40 % of its aligns took the multi-launch route.) A lone handle is back at the
+    // full grid after 3 x DECAY_AFTER aligns -- ~30 ms -- instead of never (round 2).
+    if (recent[dev] > active[dev] + 1) {
+      if (++calm[dev] >= DECAY_AFTER) { recent[dev]--; calm[dev] = 0; }
+    } else {
+      calm[dev] = 0;
+    }
   }
 };
 SlotPool g_slots;
@@ -190,9 +199,6 @@ struct Engine {
   DevBuf fit_best;   // squared nearest-neighbour distance per source point (fitness score)
   DevBuf sort_coop;  // SortCoopState + histograms of the cooperative small sort
   DevBuf rbf_sums;   // [10][n] wave totals of the RBF covariance sweep
-  DevBuf pticket;  // arrival counters of the persistent LM kernel: monotonic, the host tracks their values in pticket_base
-  unsigned pticket_base[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};  // where the 8 group counters + the top counter stand
-  bool pticket_dirty = true;   // unknown counter values (first use / after an aborted launch): clear them
   bool abort_word_dirty = false;
   int last_persist_blocks = 0;
   bool zero_copy_armed = false;  // the last persistent launch writes its result to result_host
@@ -265,12 +271,11 @@ struct Engine {
     }
     (void)hipGetLastError();  // zero-copy results are optional
     if ((e = state.ensure(sizeof(LmState))) != hipSuccess) return hipfail(e, "hipMalloc");
-    if ((e = partials.ensure(sizeof(double) * (PART_STRIDE * (MAX_COST_BLOCKS + 2 * TICKET_GROUPS) + TAGGED_ROWS_DOUBLES))) != hipSuccess) return hipfail(e, "hipMalloc");
+    if ((e = partials.ensure(sizeof(double) * PARTIALS_DOUBLES)) != hipSuccess) return hipfail(e, "hipMalloc");
     if ((e = ticket.ensure(64)) != hipSuccess) return hipfail(e, "hipMalloc");
-    if ((e = pticket.ensure(PERSIST_TICKET_BYTES)) != hipSuccess) return hipfail(e, "hipMalloc");
-    if ((e = bcast.ensure(sizeof(double) * PERSIST_REPLICAS * BCAST_SLOTS)) != hipSuccess) return hipfail(e, "hipMalloc");
-    if ((e = hipMemsetAsync(bcast.p, 0, sizeof(double) * PERSIST_REPLICAS * BCAST_SLOTS, stream)) != hipSuccess) return hipfail(e, "hipMemsetAsync");
-    if ((e = hipMemsetAsync(partials.as<double>() + TAGGED_ROWS_OFFSET, 0, sizeof(double) * TAGGED_ROWS_DOUBLES, stream)) != hipSuccess) return hipfail(e, "hipMemsetAsync");  // tags of no launch
+    if ((e = bcast.ensure(sizeof(pair_t) * PERSIST_REPLICAS * BCAST_PAIRS)) != hipSuccess) return hipfail(e, "hipMalloc");
+    if ((e = hipMemsetAsync(bcast.p, 0, sizeof(pair_t) * PERSIST_REPLICAS * BCAST_PAIRS, stream)) != hipSuccess) return hipfail(e, "hipMemsetAsync");
+    if ((e = hipMemsetAsync(partials.p, 0, sizeof(double) * PARTIALS_DOUBLES, stream)) != hipSuccess) return hipfail(e, "hipMemsetAsync");  // tagged rows: tags of no launch
     if ((e = misc.ensure(256)) != hipSuccess) return hipfail(e, "hipMalloc");
     if ((e = fit.ensure(64)) != hipSuccess) return hipfail(e, "hipMalloc");
     if ((e = hipMemsetAsync(state.p, 0, sizeof(LmState), stream)) != hipSuccess) return hipfail(e, "hipMemsetAsync");
@@ -295,7 +300,7 @@ struct Engine {
     if (peer.region) { (void)hipFree(peer.region); peer.region = nullptr; }
     peer.err.release();
     prof.destroy();
-    lm_trace.release(); fit_best.release(); sort_coop.release(); rbf_sums.release(); pticket.release(); bcast.release(); offsets_dev.release(); state.release(); partials.release(); ticket.release(); corr.release(); misc.release(); fit.release(); staging.release(); sort_keys.release(); sort_idx.release(); sort_hist.release();
+    lm_trace.release(); fit_best.release(); sort_coop.release(); rbf_sums.release(); bcast.release(); offsets_dev.release(); state.release(); partials.release(); ticket.release(); corr.release(); misc.release(); fit.release(); staging.release(); sort_keys.release(); sort_idx.release(); sort_hist.release();
     if (pinned) (void)hipHostFree(pinned);
     if (upload_pinned) (void)hipHostFree(upload_pinned);
     if (upload_done) (void)hipEventDestroy(upload_done);
@@ -797,6 +802,9 @@ struct CostSource {
   int n_off_override = 0;  // > 0: correspondences per source element regardless of the handle's offset list (GICP: 1)
   bool shardable = false;  // the source elements are the points of a cloud with a Morton order: with peers attached each rank walks its tile
   bool external_find = false;  // FastGICP device LM: nn1_corr_kernel fills the correspondence buffers between the cost launches
+  int n_shape = 0;             // > 0: expected number of source elements when the exact one lives on the device (NDT D2D: source voxels, from the
+                               // last build of that map): shapes the grid and the offsets per item; the kernel is grid-stride, any value is correct
+  VoxelMapDev* source_map = nullptr;  // NDT D2D: where align() leaves the source voxel count it saw
 };
 
 // Persistent LM kernel (kernels_cost.hpp, PERSIST): co-resident workgroup capacity of the device for this instantiation.
@@ -829,10 +837,11 @@ inline CostShape cost_shape(const Engine* e, const CostSource& src) {
   static const int group_max = [] { const char* v = getenv("FVH_COST_GROUP_MAX"); return v ? std::min(std::max(1, atoi(v)), COST_CH) : COST_CH; }();  // the kernel keeps one item's lookups in flight together: at most COST_CH
   const int n_off = src.n_off_override > 0 ? src.n_off_override : e->n_off;
   CostShape s;
-  const int groups = (int)std::min<long long>(n_off, std::max<long long>((n_off + group_max - 1) / group_max, target_items / std::max(src.n_upper, 1)));
+  const int n_expected = src.n_shape > 0 ? std::min(src.n_shape, src.n_upper) : src.n_upper;
+  const int groups = (int)std::min<long long>(n_off, std::max<long long>((n_off + group_max - 1) / group_max, target_items / std::max(n_expected, 1)));
   s.group = (n_off + groups - 1) / groups;
   s.groups_per_src = (n_off + s.group - 1) / s.group;
-  s.n_walk = src.n_upper;
+  s.n_walk = n_expected;
   if (e->peer.attached() && src.shardable) { const Tile t = peer_tile(e, src.n_upper); s.n_walk = std::max(t.hi - t.lo, 0); }  // multi-GPU: this rank's tile
   s.blocks = (int)std::max<long long>(1, std::min<long long>(max_blocks, (s.n_walk * s.groups_per_src + 255) / 256));
   return s;
@@ -912,15 +921,7 @@ int launch_cost(Engine* e, const CostSource& src, const VoxelMapDev& vm, int hos
     e->zero_copy_armed = P.result_host != nullptr;
     P.bcast = e->bcast.as<double>();
     P.launch_tag = ++e->persist_seq;
-    if (e->pticket_dirty || e->pticket_base[TICKET_GROUPS] > 0x70000000u) {
-      HIP_OR_FAIL(e, hipMemsetAsync(e->pticket.p, 0, PERSIST_TICKET_BYTES, e->stream));
-      std::memset(e->pticket_base, 0, sizeof(e->pticket_base));
-      e->pticket_dirty = false;
-    }
-    P.tb0 = e->pticket_base[0]; P.tb1 = e->pticket_base[1]; P.tb2 = e->pticket_base[2]; P.tb3 = e->pticket_base[3]; P.tb4 = e->pticket_base[4];
-    P.tb5 = e->pticket_base[5]; P.tb6 = e->pticket_base[6]; P.tb7 = e->pticket_base[7]; P.tb_top = e->pticket_base[8];
     e->last_persist_blocks = blocks;
-    P.ticket = e->pticket.as<unsigned>();
     ProfScope ps(e, "cost");
     if (e->precision == FVH_COMPUTE_FP32) cost_kernel<float, MODE, true><<<blocks, 256, 0, e->stream>>>(P);
     else cost_kernel<double, MODE, true><<<blocks, 256, 0, e->stream>>>(P);
@@ -1063,7 +1064,6 @@ int do_align(Engine* e, const CostSource& src, VoxelMapDev& vm, const double* gu
     }
     if (h->aborted || h->phase != PH_DONE) {  // the barrier watchdog fired (workgroups not co-resident): redo with one launch per transition
       e->persist_aborts++;
-      e->pticket_dirty = true;
       e->abort_word_dirty = true;
       e->persist_backoff = std::min(std::max(2 * e->persist_backoff, 1), 64);
       e->persist_skip = e->persist_backoff;
@@ -1075,11 +1075,6 @@ int do_align(Engine* e, const CostSource& src, VoxelMapDev& vm, const double* gu
     launched = 1;
     e->persist_backoff = 0;  // a clean persistent run: the device is ours again
     if (sharded) e->peer.x += 1ull + (unsigned long long)h->num_error_evals;  // one exchange per trip
-    {  // where the arrival counters stand now: every workgroup arrived once per trip, every group's last arriver bumped the top counter
-      const unsigned trips = 1u + (unsigned)h->num_error_evals, B = (unsigned)e->last_persist_blocks;
-      for (unsigned g = 0; g < (unsigned)TICKET_GROUPS; g++) e->pticket_base[g] += (g < B ? (B - g + TICKET_GROUPS - 1) / TICKET_GROUPS : 0u) * trips;
-      e->pticket_base[TICKET_GROUPS] += std::min((unsigned)TICKET_GROUPS, B) * trips;
-    }
   }
   while (!persistent) {
     for (int s = 0; s < batch; s++) {
@@ -1106,6 +1101,7 @@ int do_align(Engine* e, const CostSource& src, VoxelMapDev& vm, const double* gu
   }
   if (!persistent && sharded && h->num_linearize > 0) e->peer.x += 1ull + (unsigned long long)h->num_error_evals;  // launches after PH_DONE leave before the exchange
   vm.nv_hint = h->vm_num_voxels;
+  if (src.source_map) src.source_map->nv_hint = h->vm_num_voxels2;
   if (h->vm_dropped > 0) {  // hint-sized table overflowed: rebuild at the safe size and run again (rare)
     if (retried) return e->fail(FVH_ERR_BAD_STATE, "voxel map overflow persists after safe rebuild");
     int rc = rebuild_safe();
@@ -1558,7 +1554,14 @@ struct fvh_ndt {
   VoxelMapDev source_vm, target_vm;
   CostSource cost_source() const {
     if (distance_mode == FVH_NDT_P2D) return CostSource{source.pts.as<float4>(), nullptr, nullptr, source.n, nullptr, coherent_order(source)};
-    return CostSource{source_vm.compact_pts.as<float4>(), source_vm.compact_cov.as<float4>(), source_vm.counters_cur(), source.n, source_vm.counters_cur(), nullptr};
+    CostSource cs{source_vm.compact_pts.as<float4>(), source_vm.compact_cov.as<float4>(), source_vm.counters_cur(), source.n, source_vm.counters_cur(), nullptr};
+    // the source elements are the voxels of the source map; their number is on the device. A frame stream rebuilds that map per
+    // frame with nearly the same voxel count: the count the last align saw (+ 25 %) sizes the grid -- a few thousand voxels instead
+    // of the cloud's ~25k points: 7 one-offset items per voxel instead of 3 of <= 3 offsets (a shorter chain per trip), a smaller
+    // grid at the barrier (<= 128 workgroups reduce in one level)
+    if (source_vm.nv_hint > 0) cs.n_shape = (int)std::min<long long>(source.n, (long long)source_vm.nv_hint + source_vm.nv_hint / 4 + 256);
+    cs.source_map = const_cast<VoxelMapDev*>(&source_vm);
+    return cs;
   }
   Rebuild rebuild_safe() {
     return [this] {
@@ -1815,6 +1818,16 @@ int fvh_debug_knn_timing(unsigned long long* out) { return hipMemcpyFromSymbol(o
 #endif
 #ifdef FVH_COST_TIMING
 // debug build only (not declared in the public header): out[0] = earliest workgroup start, out[1..7] = epilogue stamps of the last workgroup, 100 MHz ticks
+int fvh_debug_lm_timing(unsigned long long* out /* [16][8] shader-cycle stamps of the last 16 LM steps since the reset */, int reset) {
+  if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(g_lmtime), sizeof(unsigned long long) * 16 * 8) != hipSuccess) return FVH_ERR_HIP;
+  if (reset) {
+    unsigned zero = 0;
+    void* p = nullptr;
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_lmcall), &zero, sizeof(zero)) != hipSuccess) return FVH_ERR_HIP;
+    if (hipGetSymbolAddress(&p, HIP_SYMBOL(g_lmtime)) != hipSuccess || hipMemset(p, 0, sizeof(unsigned long long) * 16 * 8) != hipSuccess) return FVH_ERR_HIP;
+  }
+  return FVH_OK;
+}
 int fvh_debug_persist_timing(unsigned long long* out, int reset) {  // out: [16][512][12]
   const size_t bytes = sizeof(unsigned long long) * 16 * 512 * 12;
   if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(g_ptime), bytes) != hipSuccess) return FVH_ERR_HIP;

@@ -44,7 +44,7 @@ enum Phase { PH_LINEARIZE = 0, PH_TRIAL = 1, PH_DONE = 2, PH_FIND_ONLY = 3, PH_E
 struct LmState {
   PoseD x0;        // current estimate == linearisation pose
   PoseD xi;        // trial pose
-  PoseD delta;     // se3_exp(d) of the last step
+  PoseD delta;     // (unused since round 3: the convergence test of a proposed step travels as delta_converged)
   PoseD x_lin;     // pose at which the CURRENT correspondence buffer was computed (reference: linearized_x)
   double H[36], b[6], d[6];
   double y0, lambda, nu;
@@ -58,7 +58,9 @@ struct LmState {
   int corr_cur;       // which of the two correspondence buffers is current (device-LM mode flips it on accept)
   int vm_num_voxels;  // copied from the voxel map's counters by the last workgroup: capacity hint for the next build
   int vm_dropped;     // > 0: the hint-sized table overflowed -> host rebuilds at the safe size and re-runs
-  int pad_;
+  int vm_num_voxels2; // the same for the source voxel map (NDT D2D): shapes the grid of the next align of a frame stream
+  int delta_converged;  // is_converged(delta) of the step proposed last (computed when the step is proposed, consumed by the next trial)
+  int pad2_;
   // LAST 8 bytes are never covered by the state write-back: `aborted` is raised by the persistent kernel's barrier
   // watchdog (the host zeroes the word before the launch and falls back to one launch per transition if it is set)
   unsigned gen, aborted;
@@ -93,10 +95,7 @@ struct CostParams {
   int defer_lm;               // 1: multi-GPU -- only publish st->sums, LM step runs after the all-reduce
   PoseD lin, ev;              // host mode poses; device-LM first launch (init = 1): lin = initial guess
   int init;                   // 1: this is the first launch of an align -- start from P.lin and (re)initialise the LM state
-  // persistent kernel: values of the 8 group counters + the top counter when this launch starts (they are not cleared between
-  // launches). Separate scalars, not an array: an indexed kernel-argument array is copied to scratch memory.
-  unsigned tb0, tb1, tb2, tb3, tb4, tb5, tb6, tb7, tb_top;
-  double* bcast;              // persistent kernel: [PERSIST_REPLICAS][BCAST_SLOTS] broadcast rows
+  double* bcast;              // persistent kernel: [PERSIST_REPLICAS][BCAST_PAIRS] {value, tag} pairs
   unsigned long long launch_tag;  // persistent kernel: sequence number of this launch (tags of older launches never match)
   unsigned long long* result_host;  // persistent kernel: mapped pinned host memory, [sizeof(LmState)/8 words of state][sequence word] (null: not used)
   unsigned long long watchdog_ticks;  // persistent kernel: 100 MHz ticks a workgroup may wait at the barrier before it aborts the launch
@@ -112,11 +111,45 @@ struct CostParams {
 };
 
 // ------------------------------------------------------------------------------------------------
-// LM step on one thread (lsq_registration_impl.hpp:82-91,123-168; so3.hpp:58-104)
+// LM step (lsq_registration_impl.hpp:82-91,123-168; so3.hpp:58-104)
 // ------------------------------------------------------------------------------------------------
+// This code runs on ONE wave between two evaluations of the cost while every other SIMD of the chip waits for its result:
+// its dependent-instruction chain is latency on the critical path of every LM transition. Round 2's version (6x6 one element
+// per lane, pivots through lane shuffles, IEEE divisions, libm sincos) was a chain of ~6,500 cycles = 2.8 us of every ~17 us
+// trip: ten fp64 divisions (~300 dependent cycles each: v_div_scale / v_rcp / Newton / v_div_fmas / v_div_fixup) and twelve
+// LDS-crossbar shuffles sat on it. Here every lane runs the WHOLE step redundantly in registers (wave-uniform values, no
+// shuffles), reciprocals are a hardware seed + two Newton steps (fast_rcp: ~1 ulp, operands are pivots / norms far from the
+// exponent limits; the exact-zero pivot keeps Eigen's pseudo-inverse semantics), and the half-angle sine / cosine of a
+// step below one radian come from their Taylor polynomials.
+__device__ __forceinline__ double fast_rcp(double d) {
+  double r = __builtin_amdgcn_rcp(d);
+  r = fma(r, fma(-d, r, 1.0), r);
+  r = fma(r, fma(-d, r, 1.0), r);
+  return r;
+}
+// sin(x), cos(x) for |x| <= 0.5: Taylor to x^17 / x^18 (truncation < 4e-23 relative), Horner in x^2
+__device__ __forceinline__ void sincos_small(double x, double* sn, double* cs) {
+  const double z = x * x;
+  double ps = 1.0 / 355687428096000.0;
+  ps = fma(ps, z, -1.0 / 1307674368000.0);
+  ps = fma(ps, z, 1.0 / 6227020800.0);
+  ps = fma(ps, z, -1.0 / 39916800.0);
+  ps = fma(ps, z, 1.0 / 362880.0);
+  ps = fma(ps, z, -1.0 / 5040.0);
+  ps = fma(ps, z, 1.0 / 120.0);
+  ps = fma(ps, z, -1.0 / 6.0);
+  *sn = fma(x * z, ps, x);
+  double pc = -1.0 / 6402373705728000.0;
+  pc = fma(pc, z, 1.0 / 20922789888000.0);
+  pc = fma(pc, z, -1.0 / 87178291200.0);
+  pc = fma(pc, z, 1.0 / 479001600.0);
+  pc = fma(pc, z, -1.0 / 3628800.0);
+  pc = fma(pc, z, 1.0 / 40320.0);
+  pc = fma(pc, z, -1.0 / 720.0);
+  pc = fma(pc, z, 1.0 / 24.0);
+  *cs = fma(z * z, pc, fma(z, -0.5, 1.0));
+}
 __device__ inline void dev_se3_exp(const double a[6], PoseD& T) {
-  // This runs on ONE lane between two evaluations of the cost, so its instruction count is latency on the critical path
-  // of every LM transition (measured: four libm calls + 21 divisions made the persistent kernel 36 us slower per align).
   // One sincos of the half angle; the full-angle terms of the V matrix follow from the double-angle identities
   //   1 - cos(t) = 2 sin^2(t/2),   sin(t) = 2 sin(t/2) cos(t/2)
   // (so3.hpp:58-104 calls sin/cos four times; oracle probe ORC_LM_ARITH_VARIANT=2: converged poses agree to 5e-15).
@@ -124,14 +157,17 @@ __device__ inline void dev_se3_exp(const double a[6], PoseD& T) {
   const double theta_sq = ox * ox + oy * oy + oz * oz;
   const double theta = sqrt(theta_sq);
   double sh = 0.0, ch = 1.0;
-  if (theta >= 1e-10) sincos(0.5 * theta, &sh, &ch);  // needed by the V matrix even when the quaternion takes its Taylor branch
+  if (theta >= 1e-10) {  // needed by the V matrix even when the quaternion takes its Taylor branch
+    if (__builtin_amdgcn_ballot_w64(theta > 1.0) == 0ull) sincos_small(0.5 * theta, &sh, &ch); else sincos(0.5 * theta, &sh, &ch);  // (wave-uniform callers: a scalar branch)
+  }
+  const double inv_theta = theta >= 1e-10 ? fast_rcp(theta) : 0.0;
   double imag, real;
   if (theta_sq < 1e-10) {
     const double tq = theta_sq * theta_sq;
     imag = 0.5 - 1.0 / 48.0 * theta_sq + 1.0 / 3840.0 * tq;
     real = 1.0 - 1.0 / 8.0 * theta_sq + 1.0 / 384.0 * tq;
   } else {
-    imag = sh / theta;
+    imag = sh * inv_theta;
     real = ch;
   }
   const double qw = real, qx = imag * ox, qy = imag * oy, qz = imag * oz;
@@ -140,66 +176,42 @@ __device__ inline void dev_se3_exp(const double a[6], PoseD& T) {
   T.r[0] = 1 - (tyy + tzz); T.r[1] = txy - twz;       T.r[2] = txz + twy;
   T.r[3] = txy + twz;       T.r[4] = 1 - (txx + tzz); T.r[5] = tyz - twx;
   T.r[6] = txz - twy;       T.r[7] = tyz + twx;       T.r[8] = 1 - (txx + tyy);
-  double V[9];
-  if (theta < 1e-10) {
-#pragma unroll
-    for (int i = 0; i < 9; i++) V[i] = T.r[i];
+  // t = V v,  V = I + A Omega + B Omega^2 (so3.hpp:91-101; V = R below 1e-10): Omega v = omega x v and
+  // Omega^2 v = omega (omega . v) - theta^2 v, so the 3x3 products are never formed
+  const double vx = a[3], vy = a[4], vz = a[5];
+  if (__builtin_amdgcn_ballot_w64(theta < 1e-10) != 0ull) {
+    T.t[0] = T.r[0] * vx + T.r[1] * vy + T.r[2] * vz;
+    T.t[1] = T.r[3] * vx + T.r[4] * vy + T.r[5] * vz;
+    T.t[2] = T.r[6] * vx + T.r[7] * vy + T.r[8] * vz;
   } else {
-    const double inv_tsq = 1.0 / theta_sq;
-    const double A = 2.0 * sh * sh * inv_tsq, B = (theta - 2.0 * sh * ch) * inv_tsq / theta;
-    // Omega = skew(omega), Omega^2
-    const double O[9] = {0, -oz, oy, oz, 0, -ox, -oy, ox, 0};
-    double O2[9];
-#pragma unroll
-    for (int i = 0; i < 3; i++)
-#pragma unroll
-      for (int j = 0; j < 3; j++) O2[i * 3 + j] = O[i * 3 + 0] * O[0 * 3 + j] + O[i * 3 + 1] * O[1 * 3 + j] + O[i * 3 + 2] * O[2 * 3 + j];
-#pragma unroll
-    for (int i = 0; i < 9; i++) V[i] = ((i % 4 == 0) ? 1.0 : 0.0) + A * O[i] + B * O2[i];
-  }
-#pragma unroll
-  for (int i = 0; i < 3; i++) T.t[i] = V[i * 3 + 0] * a[3] + V[i * 3 + 1] * a[4] + V[i * 3 + 2] * a[5];
-}
-
-__device__ inline void dev_pose_mul(const PoseD& A, const PoseD& B, PoseD& C) {  // C = A * B
-#pragma unroll
-  for (int i = 0; i < 3; i++) {
-#pragma unroll
-    for (int j = 0; j < 3; j++) C.r[i * 3 + j] = A.r[i * 3 + 0] * B.r[0 * 3 + j] + A.r[i * 3 + 1] * B.r[1 * 3 + j] + A.r[i * 3 + 2] * B.r[2 * 3 + j];
-    C.t[i] = A.r[i * 3 + 0] * B.t[0] + A.r[i * 3 + 1] * B.t[1] + A.r[i * 3 + 2] * B.t[2] + A.t[i];
+    const double inv_tsq = inv_theta * inv_theta;
+    const double A = 2.0 * sh * sh * inv_tsq, B = (theta - 2.0 * sh * ch) * inv_tsq * inv_theta;
+    const double cx = oy * vz - oz * vy, cy = oz * vx - ox * vz, cz = ox * vy - oy * vx;
+    const double ov = ox * vx + oy * vy + oz * vz;
+    T.t[0] = vx + A * cx + B * (ox * ov - theta_sq * vx);
+    T.t[1] = vy + A * cy + B * (oy * ov - theta_sq * vy);
+    T.t[2] = vz + A * cz + B * (oz * ov - theta_sq * vz);
   }
 }
 
-__device__ inline void dev_ldlt6_solve(const double* A, const double* rhs, double* x) {
-  // one reciprocal per pivot (6 divisions instead of 21: each fp64 division is ~12 dependent instructions on the one
-  // lane that runs this; oracle probe ORC_LM_ARITH_VARIANT=1: converged poses agree to 2e-17); only the strictly
-  // lower part of L is used. A pivot with |d| <= DBL_MIN is treated the way Eigen::LDLT does (the column stays unscaled,
-  // the solve uses the pseudo-inverse of D): with no correspondences at all H = 0, lambda = 0 and the step is d = 0, so the
-  // reference returns the initial guess flagged converged (lsq_registration_impl.hpp:111-168) instead of a NaN pose.
-  double L[36], D[6], Dinv[6], y[6];
-  for (int j = 0; j < 6; j++) {
-    double dj = A[j * 6 + j];
-    for (int k = 0; k < j; k++) dj -= L[j * 6 + k] * L[j * 6 + k] * D[k];
-    D[j] = dj;
-    const bool pivot_ok = fabs(dj) > 2.2250738585072014e-308;
-    Dinv[j] = pivot_ok ? 1.0 / dj : 0.0;
-    for (int i = j + 1; i < 6; i++) {
-      double s = A[i * 6 + j];
-      for (int k = 0; k < j; k++) s -= L[i * 6 + k] * L[j * 6 + k] * D[k];
-      L[i * 6 + j] = pivot_ok ? s * Dinv[j] : s;
-    }
+// lsq_registration_impl.hpp:82-91: (|R - I|.max / rot_eps, |t|.max / trans_eps).max < 1. For positive thresholds x / eps < 1 is
+// exactly x < eps in IEEE arithmetic (a quotient of x < eps never rounds up to 1), so the two divisions are only formed for the
+// nonsensical thresholds (zero, negative, NaN) where the comparison form would answer differently.
+__device__ __forceinline__ bool dev_is_converged(double rot_eps, double trans_eps, const PoseD& delta) {
+  if (__builtin_amdgcn_ballot_w64(rot_eps > 0 && trans_eps > 0) != 0ull) {  // max_i x_i < eps  <=>  every x_i < eps: twelve compares, no max chain
+    bool ok = true;
+#pragma unroll
+    for (int i = 0; i < 9; i++) ok &= (fabs(delta.r[i] - ((i % 4 == 0) ? 1.0 : 0.0)) < rot_eps);  // (&=, not &&: no short-circuit branches)
+#pragma unroll
+    for (int i = 0; i < 3; i++) ok &= (fabs(delta.t[i]) < trans_eps);
+    return ok;
   }
-  for (int i = 0; i < 6; i++) { double s = rhs[i]; for (int k = 0; k < i; k++) s -= L[i * 6 + k] * y[k]; y[i] = s; }
-  for (int i = 0; i < 6; i++) y[i] *= Dinv[i];
-  for (int i = 5; i >= 0; i--) { double s = y[i]; for (int k = i + 1; k < 6; k++) s -= L[k * 6 + i] * x[k]; x[i] = s; }
-}
-
-__device__ inline bool dev_is_converged(const LmState* st, const PoseD& delta) {
-  // lsq_registration_impl.hpp:82-91: (|R - I|.max / rot_eps, |t|.max / trans_eps).max < 1 -- the max first, two divisions
   double rmax = 0, tmax = 0;
+#pragma unroll
   for (int i = 0; i < 9; i++) rmax = fmax(rmax, fabs(delta.r[i] - ((i % 4 == 0) ? 1.0 : 0.0)));
+#pragma unroll
   for (int i = 0; i < 3; i++) tmax = fmax(tmax, fabs(delta.t[i]));
-  return fmax(rmax / st->rotation_epsilon, tmax / st->transformation_epsilon) < 1;
+  return fmax(rmax / rot_eps, tmax / trans_eps) < 1;
 }
 
 // sums -> symmetric 6x6 H (row-major) and b
@@ -217,265 +229,254 @@ __device__ __host__ inline void unpack_sums(const double* s, double* H, double* 
       H[(3 + i) * 6 + 3 + j] = tt[sym[i][j]];
     }
 }
-
-__device__ inline void dev_lm_propose(LmState* st) {  // d = (H + lambda I)^-1 (-b); xi = exp(d) * x0
-  double A[36], nb[6];
-  for (int i = 0; i < 36; i++) A[i] = st->H[i];
-  for (int j = 0; j < 6; j++) { A[j * 6 + j] += st->lambda; nb[j] = -st->b[j]; }
-  double d[6];
-  dev_ldlt6_solve(A, nb, d);
-  for (int j = 0; j < 6; j++) st->d[j] = d[j];
-  PoseD delta;
-  dev_se3_exp(d, delta);
-  st->delta = delta;
-  dev_pose_mul(delta, st->x0, st->xi);
-}
-
-// One transition of the {linearize -> trial* -> accept} machine; exactly the control flow of
-// LsqRegistration::computeTransformation + step_lm.  sums[0..27] = {err, b, H} of the linearisation this
-// launch computed (at x0 for PH_LINEARIZE, speculatively at xi for the fused PH_TRIAL launch), sums[28] =
-// trial error y_i at xi with the OLD correspondences (fused launch only).
-__device__ inline void dev_lm_consume_linearization(LmState* st, const double* sums) {
-  st->y0 = sums[0];
-  unpack_sums(sums, st->H, st->b);
-  st->num_linearize++;
-  st->nr_iterations = st->outer_iter;
-  if (st->lambda < 0.0) {
-    double mx = 0;
-    for (int i = 0; i < 6; i++) mx = fmax(mx, fabs(st->H[i * 6 + i]));
-    st->lambda = st->lm_init_lambda_factor * mx;
-  }
-  st->nu = 2.0;
-  st->inner_iter = 0;
-}
-
-__device__ inline void dev_lm_step(LmState* st, const double* sums) {
-  if (st->phase == PH_LINEARIZE) {
-    st->x_lin = st->x0;
-    dev_lm_consume_linearization(st, sums);
-    if (st->lm_max_iterations <= 0) { st->lm_failed = 1; st->phase = PH_DONE; return; }
-    dev_lm_propose(st);
-    st->phase = PH_TRIAL;
-    return;
-  }
-  // PH_TRIAL (fused)
-  const double yi = sums[28];
-  st->num_error_evals++;
-  double denom = 0;
-  for (int j = 0; j < 6; j++) denom += st->d[j] * (st->lambda * st->d[j] - st->b[j]);
-  const double rho = (st->y0 - yi) / denom;
-  if (rho < 0) {
-    if (dev_is_converged(st, st->delta)) {  // step_lm returns true with x0 unchanged -> converged_ = true
-      st->converged = 1;
-      st->outer_iter++;
-      st->phase = PH_DONE;
-      return;
-    }
-    st->lambda = st->nu * st->lambda;
-    st->nu = 2 * st->nu;
-    st->inner_iter++;
-    if (st->inner_iter >= st->lm_max_iterations) { st->lm_failed = 1; st->phase = PH_DONE; return; }  // "lm not converged!!"
-    dev_lm_propose(st);  // new trial from the SAME (H, b); the speculative linearisation of this launch is discarded
-    return;
-  }
-  // accepted
-  st->x0 = st->xi;
-  { const double u = 2 * rho - 1; st->lambda = st->lambda * fmax(1.0 / 3.0, 1 - u * u * u); }
-  for (int i = 0; i < 36; i++) st->final_H[i] = st->H[i];
-  st->converged = dev_is_converged(st, st->delta) ? 1 : 0;
-  st->outer_iter++;
-  if (st->converged || st->outer_iter >= st->max_iterations) { st->phase = PH_DONE; return; }
-  // the speculative linearisation at xi (== the new x0) is exactly the next step_lm's linearize()
-  st->corr_cur ^= 1;
-  st->x_lin = st->x0;
-  dev_lm_consume_linearization(st, sums);
-  dev_lm_propose(st);
-}
-
-// value of lane `src` (compile-time constant) on every lane: two v_readlane_b32, no LDS crossbar round trip
-__device__ __forceinline__ double readlane_f64(double x, int src) {
-  const unsigned long long u = (unsigned long long)__double_as_longlong(x);
-  const unsigned lo = __builtin_amdgcn_readlane((unsigned)u, src), hi = __builtin_amdgcn_readlane((unsigned)(u >> 32), src);
-  return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+// where element (i, j) of H sits in the sums (the layout unpack_sums spells out)
+__device__ __host__ constexpr int sums_index_of_H(int i, int j) {
+  const int a = i < 3 ? i : i - 3, c = j < 3 ? j : j - 3;
+  const int lo = a < c ? a : c, hi = a < c ? c : a;
+  const int sym = lo * 3 - (lo * (lo - 1)) / 2 + (hi - lo);
+  return (i < 3 && j < 3) ? 7 + sym : (i >= 3 && j >= 3) ? 22 + sym : (i < 3) ? 13 + i * 3 + (j - 3) : 13 + j * 3 + (i - 3);
 }
 
 // ------------------------------------------------------------------------------------------------
-// The same transition, executed by ONE FULL WAVE (all 64 lanes call it; every branch below is wave-uniform).
-// Round 1 ran dev_lm_step on a single lane against the LDS copy of the state: ~300 dependent LDS round trips, 4.4 us of
-// every 20 us trip of the persistent kernel. Here the 6x6 system lives one element per lane (lanes 0..35), the LDL^T
-// factorisation is a right-looking sweep with lane shuffles (the same multiply/subtract sequence per element as
-// dev_ldlt6_solve), the small sequential parts (triangular solves, se3_exp, pose product, rho test) run redundantly on all
-// lanes in registers, and the state is read once at the top and written once at the bottom. `st` and `sums` must be LDS.
+// One transition of the {linearize -> trial* -> accept} machine; exactly the control flow of LsqRegistration::
+// computeTransformation + step_lm. sums[0..27] = {err, b, H} of the linearisation this evaluation computed (at x0 for
+// PH_LINEARIZE, speculatively at xi for the fused PH_TRIAL evaluation), sums[28] = trial error y_i at xi with the OLD
+// correspondences (fused evaluation only; PH_TRIAL_FINAL: y_i at sums[0]).
+// Executed by ONE FULL WAVE, every lane running the same instruction stream on the same (wave-uniform) values: the state is
+// read from LDS once at the top, the 6x6 LDL^T, the triangular solves, se3_exp and the tests live in registers, lanes 0..35 /
+// 0..11 / 0 write the results back. `st` and `sums` must be LDS.
 // ------------------------------------------------------------------------------------------------
 #ifdef FVH_LM_STEP_NOINLINE  // A/B switch: a real function (called once per trip through generic pointers) instead of inlined code on LDS
 #define FVH_LM_STEP_ATTR __noinline__
 #else
 #define FVH_LM_STEP_ATTR __forceinline__
 #endif
+// Every value below is wave-uniform, but the compiler cannot know (the state comes out of LDS, i.e. out of VGPRs): written
+// naively every `if` becomes exec-mask bookkeeping (s_and_saveexec / s_cbranch_execz, ~70 of them) and every merge a
+// v_cndmask. A condition that went through a ballot IS uniform to the compiler: plain scalar branches, no selects.
+#define FVH_UNI(c) (__builtin_amdgcn_ballot_w64(c) != 0ull)
+#ifdef FVH_COST_TIMING  // shader-cycle stamps inside the LM step (tools/persist_timing.py): [call][stage]; intrusive (every stamp drains the
+__device__ unsigned long long g_lmtime[16][8];  // memory pipeline, the previous stamp's store included): only with -DFVH_LM_STAGES
+__device__ unsigned g_lmcall;
+#endif
+#if defined(FVH_COST_TIMING) && defined(FVH_LM_STAGES)
+#define FVH_LM_T(k) do { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); if (lane == 0 && lm_call < 16) g_lmtime[lm_call][k] = __builtin_readcyclecounter(); } while (0)
+#else
+#define FVH_LM_T(k) do { } while (0)
+#endif
 __device__ FVH_LM_STEP_ATTR void dev_lm_step_wave(LmState* st, const double* sums, const int lane, double* trace = nullptr) {
-  const int li = lane / 6, lj = lane - li * 6;
   const bool in36 = lane < 36, in12 = lane < 12, in6 = lane < 6;
   double* x0p = reinterpret_cast<double*>(&st->x0);
   double* xip = reinterpret_cast<double*>(&st->xi);
   double* xlp = reinterpret_cast<double*>(&st->x_lin);
-  int phase = st->phase;
+#if defined(FVH_COST_TIMING) && defined(FVH_LM_STAGES)
+  const unsigned lm_call = __builtin_amdgcn_readfirstlane(g_lmcall);
+  if (lane == 0) g_lmcall = lm_call + 1;
+#endif
+  FVH_LM_T(0);
+  // ---- everything the decision needs, requested together (one LDS round trip) ----
+  const int phase0 = __builtin_amdgcn_readfirstlane(st->phase);
+  int phase = phase0;
   double lambda = st->lambda, nu = st->nu, y0 = st->y0;
-  int outer_iter = st->outer_iter, inner_iter = st->inner_iter, converged = st->converged, lm_failed = st->lm_failed;
-  int num_linearize = st->num_linearize, num_error_evals = st->num_error_evals, nr_iterations = st->nr_iterations, corr_cur = st->corr_cur;
-  const int max_iterations = st->max_iterations, lm_max_iterations = st->lm_max_iterations;
-  auto commit = [&]() {
-    if (lane == 0) {
-      st->phase = phase; st->lambda = lambda; st->nu = nu; st->y0 = y0;
-      st->outer_iter = outer_iter; st->inner_iter = inner_iter; st->converged = converged; st->lm_failed = lm_failed;
-      st->num_linearize = num_linearize; st->num_error_evals = num_error_evals; st->nr_iterations = nr_iterations; st->corr_cur = corr_cur;
-    }
-  };
-  bool consume = false;
-  if (phase == PH_LINEARIZE) {
-    if (in12) xlp[lane] = x0p[lane];  // x_lin = x0
+  int outer_iter = __builtin_amdgcn_readfirstlane(st->outer_iter), inner_iter = __builtin_amdgcn_readfirstlane(st->inner_iter);
+  int converged = __builtin_amdgcn_readfirstlane(st->converged), lm_failed = __builtin_amdgcn_readfirstlane(st->lm_failed);
+  int num_linearize = __builtin_amdgcn_readfirstlane(st->num_linearize), num_error_evals = __builtin_amdgcn_readfirstlane(st->num_error_evals);
+  int nr_iterations = __builtin_amdgcn_readfirstlane(st->nr_iterations), corr_cur = __builtin_amdgcn_readfirstlane(st->corr_cur);
+  const int max_iterations = __builtin_amdgcn_readfirstlane(st->max_iterations), lm_max_iterations = __builtin_amdgcn_readfirstlane(st->lm_max_iterations);
+  const double rot_eps = st->rotation_epsilon, trans_eps = st->transformation_epsilon, lambda_factor = st->lm_init_lambda_factor;
+  double dprev[6], bprev[6];
+#pragma unroll
+  for (int j = 0; j < 6; j++) { dprev[j] = st->d[j]; bprev[j] = st->b[j]; }
+  const int delta_conv_prev = __builtin_amdgcn_readfirstlane(st->delta_converged);
+
+  const double s0 = sums[0], s28 = sums[28];
+
+  bool accepted = false, consume = false, done = false;
+  if (phase0 == PH_LINEARIZE) {
     consume = true;
-  } else {  // PH_TRIAL (fused): trial error of this launch at sums[28]; PH_TRIAL_FINAL (error only): at sums[0]
-    const double yi = sums[phase == PH_TRIAL_FINAL ? 0 : 28];
+  } else {  // PH_TRIAL (fused): trial error of this evaluation at sums[28]; PH_TRIAL_FINAL (error only): at sums[0]
+    const double yi = phase0 == PH_TRIAL_FINAL ? s0 : s28;
     num_error_evals++;
     double denom = 0;
 #pragma unroll
-    for (int j = 0; j < 6; j++) denom += st->d[j] * (lambda * st->d[j] - st->b[j]);
-    const double rho = (y0 - yi) / denom;
-    if (trace && lane == 0) {  // the line LsqRegistration prints per trial when setDebugPrint(true) (lsq_registration_impl.hpp:143-149)
+    for (int j = 0; j < 6; j++) denom += dprev[j] * (lambda * dprev[j] - bprev[j]);
+    // rho = (y0 - yi) / denom: a degenerate denominator (zero / subnormal: d = 0, no correspondences) keeps the IEEE quotient
+    double rho;
+    if (FVH_UNI(fabs(denom) > 1e-290)) rho = (y0 - yi) * fast_rcp(denom); else rho = (y0 - yi) / denom;
+    if (trace) {  // the line LsqRegistration prints per trial when setDebugPrint(true) (lsq_registration_impl.hpp:143-149)
       double dn = 0;
 #pragma unroll
-      for (int j = 0; j < 6; j++) dn += st->d[j] * st->d[j];
-      double* row = trace + 6 * (size_t)(num_error_evals - 1);
-      row[0] = (double)inner_iter; row[1] = y0; row[2] = yi; row[3] = rho; row[4] = lambda; row[5] = sqrt(dn);
-    }
-    const bool conv = dev_is_converged(st, st->delta);
-    if (rho < 0) {
-      if (conv) {  // step_lm returns true with x0 unchanged -> converged_ = true
-        converged = 1; outer_iter++; phase = PH_DONE;
-        commit();
-        return;
+      for (int j = 0; j < 6; j++) dn += dprev[j] * dprev[j];
+      if (lane == 0) {
+        double* row = trace + 6 * (size_t)(num_error_evals - 1);
+        row[0] = (double)inner_iter; row[1] = y0; row[2] = yi; row[3] = rho; row[4] = lambda; row[5] = sqrt(dn);
       }
-      lambda = nu * lambda;
-      nu = 2 * nu;
-      inner_iter++;
-      if (inner_iter >= lm_max_iterations) { lm_failed = 1; phase = PH_DONE; commit(); return; }  // "lm not converged!!"
-      // new trial from the SAME (H, b); the speculative linearisation of this launch is discarded
-    } else {  // accepted
-      if (in12) x0p[lane] = xip[lane];  // x0 = xi
+    }
+    const bool conv = delta_conv_prev != 0;  // is_converged(delta) of the step whose trial this is (lsq_registration_impl.hpp:151,160)
+    if (FVH_UNI(rho < 0)) {
+      if (conv) {  // step_lm returns true with x0 unchanged -> converged_ = true
+        converged = 1; outer_iter++; phase = PH_DONE; done = true;
+      } else {
+        lambda = nu * lambda;
+        nu = 2 * nu;
+        inner_iter++;
+        if (inner_iter >= lm_max_iterations) { lm_failed = 1; phase = PH_DONE; done = true; }  // "lm not converged!!"
+        // otherwise: a new trial from the SAME (H, b); the speculative linearisation of this evaluation is discarded
+      }
+    } else {  // accepted: x0 = xi, final_H = H (both done in the tail below)
+      accepted = true;
       { const double u = 2 * rho - 1; lambda = lambda * fmax(1.0 / 3.0, 1 - u * u * u); }
-      if (in36) st->final_H[lane] = st->H[lane];
       converged = conv ? 1 : 0;
       outer_iter++;
-      if (converged || outer_iter >= max_iterations) { phase = PH_DONE; commit(); return; }
-      // the speculative linearisation at xi (== the new x0) is exactly the next step_lm's linearize()
-      corr_cur ^= 1;
-      if (in12) xlp[lane] = x0p[lane];
-      consume = true;
+      if (converged || outer_iter >= max_iterations) {
+        phase = PH_DONE; done = true;
+      } else {  // the speculative linearisation at xi (== the new x0) is exactly the next step_lm's linearize()
+        corr_cur ^= 1;
+        consume = true;
+      }
     }
   }
-  double h, bv;  // lane (li, lj) < 36: H element; lane < 6: b element
-  if (consume) {  // dev_lm_consume_linearization
-    y0 = sums[0];
-    int hidx;
-    {  // unpack_sums: rr at 7 (xx xy xz yy yz zz), rt at 13 (3x3 row-major), tt at 22
-      const int a = li < 3 ? li : li - 3, c = lj < 3 ? lj : lj - 3;
-      const int lo = a < c ? a : c, hi = a < c ? c : a;
-      const int sym = lo * 3 - (lo * (lo - 1)) / 2 + (hi - lo);
-      if (li < 3 && lj < 3) hidx = 7 + sym;
-      else if (li >= 3 && lj >= 3) hidx = 22 + sym;
-      else if (li < 3) hidx = 13 + li * 3 + (lj - 3);
-      else hidx = 13 + lj * 3 + (li - 3);
+  FVH_LM_T(1);
+  // (H, b) in registers on every lane: lower triangle row by row -- Hl[i (i + 1) / 2 + j], j <= i
+  double Hl[21], bv[6];
+  if (!done) {
+    if (consume) {  // dev_lm_consume_linearization: y0, H, b of the evaluation just reduced
+      y0 = s0;
+#pragma unroll
+      for (int i = 0; i < 6; i++) {
+        bv[i] = sums[1 + i];
+#pragma unroll
+        for (int j = 0; j <= i; j++) Hl[i * (i + 1) / 2 + j] = sums[sums_index_of_H(i, j)];
+      }
+      num_linearize++;
+      nr_iterations = outer_iter;
+      if (FVH_UNI(lambda < 0.0)) {
+        double mx = 0;
+#pragma unroll
+        for (int i = 0; i < 6; i++) mx = fmax(mx, fabs(Hl[i * (i + 1) / 2 + i]));
+        lambda = lambda_factor * mx;
+      }
+      nu = 2.0;
+      inner_iter = 0;
+      if (phase0 == PH_LINEARIZE) {
+        if (lm_max_iterations <= 0) { lm_failed = 1; phase = PH_DONE; done = true; } else phase = PH_TRIAL;
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 6; i++) {
+        bv[i] = bprev[i];
+#pragma unroll
+        for (int j = 0; j <= i; j++) Hl[i * (i + 1) / 2 + j] = st->H[i * 6 + j];
+      }
     }
-    h = in36 ? sums[hidx] : 0.0;
-    bv = in6 ? sums[1 + lane] : 0.0;
-    if (in36) st->H[lane] = h;
-    if (in6) st->b[lane] = bv;
-    num_linearize++;
-    nr_iterations = outer_iter;
-    if (lambda < 0.0) {
-      double mx = 0;
-#pragma unroll
-      for (int i = 0; i < 6; i++) mx = fmax(mx, fabs(readlane_f64(h, i * 7)));
-      lambda = st->lm_init_lambda_factor * mx;
-    }
-    nu = 2.0;
-    inner_iter = 0;
-    if (phase == PH_LINEARIZE) {
-      if (lm_max_iterations <= 0) { lm_failed = 1; phase = PH_DONE; commit(); return; }
-      phase = PH_TRIAL;
-    }
-  } else {
-    h = in36 ? st->H[lane] : 0.0;
-    bv = in6 ? st->b[lane] : 0.0;
   }
-  // ---- dev_lm_propose: d = (H + lambda I)^-1 (-b); xi = exp(d) * x0 ----
-  double a = h + ((in36 && li == lj) ? lambda : 0.0);
-  double Dinv[6];
-#pragma unroll
-  for (int k = 0; k < 6; k++) {  // column k of L becomes final, then the trailing lower triangle is updated (same operations, same order per element as dev_ldlt6_solve)
-    // the UNSCALED column entries travel while the pivot's reciprocal is computed (the shuffles do not wait for the division);
-    // every lane then scales its two operands itself -- the same s * Dinv[k] products as the column's own lanes
-    const double uik = __shfl(a, in36 ? li * 6 + k : 0), ujk = __shfl(a, in36 ? lj * 6 + k : 0);
-    const double dk = readlane_f64(a, k * 7);
-    const bool pivot_ok = fabs(dk) > 2.2250738585072014e-308;
-    Dinv[k] = pivot_ok ? 1.0 / dk : 0.0;
-    const double lik = pivot_ok ? uik * Dinv[k] : uik, ljk = pivot_ok ? ujk * Dinv[k] : ujk;
-    if (in36 && lj == k && li > k) a = lik;
-    if (in36 && lj > k && li >= lj) a -= lik * ljk * dk;
-  }
-  double L[15], nb[6], y[6], d[6];  // strictly lower part, row by row: (1,0) (2,0) (2,1) (3,0) ...
-  {
-    int t = 0;
-#pragma unroll
-    for (int i = 1; i < 6; i++)
-#pragma unroll
-      for (int j = 0; j < i; j++) L[t++] = readlane_f64(a, i * 6 + j);
-  }
-#pragma unroll
-  for (int i = 0; i < 6; i++) nb[i] = -readlane_f64(bv, i);
-#pragma unroll
-  for (int i = 0; i < 6; i++) {
-    double sacc = nb[i];
-#pragma unroll
-    for (int k = 0; k < 6; k++) if (k < i) sacc -= L[i * (i - 1) / 2 + k] * y[k];
-    y[i] = sacc;
-  }
-#pragma unroll
-  for (int i = 0; i < 6; i++) y[i] *= Dinv[i];
-#pragma unroll
-  for (int i = 5; i >= 0; i--) {
-    double sacc = y[i];
-#pragma unroll
-    for (int k = 0; k < 6; k++) if (k > i) sacc -= L[k * (k - 1) / 2 + i] * d[k];
-    d[i] = sacc;
-  }
+  if (lane == 0) { st->lambda = lambda; st->nu = nu; st->y0 = y0; }  // final from here on (stored now: not held in registers across the solve)
+  FVH_LM_T(2);
   PoseD delta;
-  dev_se3_exp(d, delta);
-  if (lane == 0) {
+  double d[6];
+  int delta_conv = delta_conv_prev;
+  if (!done) {
+    // ---- d = (H + lambda I)^-1 (-b): LDL^T in registers (Eigen::LDLT semantics for a vanishing pivot: the column stays
+    // unscaled and the solve uses the pseudo-inverse of D -- with no correspondences at all H = 0, lambda = 0, d = 0 and the
+    // reference returns the initial guess flagged converged instead of a NaN pose, lsq_registration_impl.hpp:111-168) ----
+    double L[15], D[6], Dinv[6];  // strictly lower part row by row: L[i (i - 1) / 2 + j], j < i
 #pragma unroll
-    for (int j = 0; j < 6; j++) st->d[j] = d[j];
-    st->delta = delta;
+    for (int j = 0; j < 6; j++) {
+      double dj = Hl[j * (j + 1) / 2 + j] + lambda;
+#pragma unroll
+      for (int k = 0; k < j; k++) dj -= L[j * (j - 1) / 2 + k] * L[j * (j - 1) / 2 + k] * D[k];
+      D[j] = dj;
+      const double r = fast_rcp(dj);
+      const bool pivot_ok = fabs(dj) > 2.2250738585072014e-308;
+      Dinv[j] = pivot_ok ? r : 0.0;
+      const double scale = pivot_ok ? r : 1.0;
+#pragma unroll
+      for (int i = j + 1; i < 6; i++) {
+        double sacc = Hl[i * (i + 1) / 2 + j];
+#pragma unroll
+        for (int k = 0; k < j; k++) sacc -= L[i * (i - 1) / 2 + k] * L[j * (j - 1) / 2 + k] * D[k];
+        L[i * (i - 1) / 2 + j] = sacc * scale;
+      }
+    }
+    double y[6];
+#pragma unroll
+    for (int i = 0; i < 6; i++) {
+      double sacc = -bv[i];
+#pragma unroll
+      for (int k = 0; k < i; k++) sacc -= L[i * (i - 1) / 2 + k] * y[k];
+      y[i] = sacc;
+    }
+#pragma unroll
+    for (int i = 0; i < 6; i++) y[i] *= Dinv[i];
+#pragma unroll
+    for (int i = 5; i >= 0; i--) {
+      double sacc = y[i];
+#pragma unroll
+      for (int k = i + 1; k < 6; k++) sacc -= L[k * (k - 1) / 2 + i] * d[k];
+      d[i] = sacc;
+    }
+    FVH_LM_T(3);
+    dev_se3_exp(d, delta);
+    FVH_LM_T(4);
+    // the trial of this proposal is the last evaluation of the align if the step is already converged (then accepted or not, the
+    // loop ends: lsq_registration_impl.hpp:57-66,150-165) or if accepting it exhausts max_iterations -- its speculative
+    // linearisation would be thrown away
+    delta_conv = FVH_UNI(dev_is_converged(rot_eps, trans_eps, delta)) ? 1 : 0;
+    phase = (delta_conv || outer_iter + 1 >= max_iterations) ? PH_TRIAL_FINAL : PH_TRIAL;
   }
-  // xi = delta * x0 (dev_pose_mul), one element per lane: lane p < 9 -> r[p / 3][p % 3], lanes 9..11 -> t[p - 9]; each lane reads
-  // its three x0 operands straight from the LDS copy of the state (no uniform 12 + 12 doubles in registers)
-  if (in12) {
-    const int i = lane < 9 ? lane / 3 : lane - 9;
-    const int col = lane < 9 ? lane - 3 * i : 9;  // first operand: x0.r[0][j] ... or x0.t[0]
-    const int stride = lane < 9 ? 3 : 1;
-    const double b0 = x0p[col], b1 = x0p[col + stride], b2 = x0p[col + 2 * stride];
-    const double a0 = i == 0 ? delta.r[0] : (i == 1 ? delta.r[3] : delta.r[6]);
-    const double a1 = i == 0 ? delta.r[1] : (i == 1 ? delta.r[4] : delta.r[7]);
-    const double a2 = i == 0 ? delta.r[2] : (i == 1 ? delta.r[5] : delta.r[8]);
-    const double ti = i == 0 ? delta.t[0] : (i == 1 ? delta.t[1] : delta.t[2]);
-    double val = a0 * b0 + a1 * b1 + a2 * b2;
-    if (lane >= 9) val = a0 * b0 + a1 * b1 + a2 * b2 + ti;
-    xip[lane] = val;
+  FVH_LM_T(5);
+  // ---- tail: the state in LDS. Everything comes out of registers (lane 0 stores the poses, the step and the scalars as 16-byte
+  // writes; the 6x6 copies go one element per lane): no LDS read-modify-write chains between the stages ----
+  double x0r[12], xir[12];  // the (new) current estimate: x0 = xi when the trial was accepted; read here, not at the top (24 doubles held across the
+  {                         // solve spilled); one LDS round trip
+    const double* src = accepted ? xip : x0p;
+#pragma unroll
+    for (int k = 0; k < 12; k++) x0r[k] = src[k];
   }
-  // the trial of this proposal is the last evaluation of the align if the step is already converged (then accepted or not, the
-  // loop ends: lsq_registration_impl.hpp:57-66,150-165) or if accepting it exhausts max_iterations -- its speculative
-  // linearisation would be thrown away
-  if (phase == PH_TRIAL || phase == PH_TRIAL_FINAL) phase = (dev_is_converged(st, delta) || outer_iter + 1 >= max_iterations) ? PH_TRIAL_FINAL : PH_TRIAL;
-  commit();
+  if (accepted && in36) st->final_H[lane] = st->H[lane];  // final_hessian_ = H (before H is replaced below)
+  if (consume) {
+    // the state's full row-major copy of H (the next trials' source, final_H, the host's getFinalHessian): one element per lane
+    const int li = lane / 6, lj = lane - li * 6;
+    const int a = li < 3 ? li : li - 3, c = lj < 3 ? lj : lj - 3;
+    const int lo = a < c ? a : c, hi = a < c ? c : a;
+    const int sym = lo * 3 - (lo * (lo - 1)) / 2 + (hi - lo);
+    int hidx;
+    if (li < 3 && lj < 3) hidx = 7 + sym;
+    else if (li >= 3 && lj >= 3) hidx = 22 + sym;
+    else if (li < 3) hidx = 13 + li * 3 + (lj - 3);
+    else hidx = 13 + lj * 3 + (li - 3);
+    if (in36) st->H[lane] = sums[hidx];
+    if (in6) st->b[lane] = sums[1 + lane];
+  }
+  if (!done) {  // xi = delta * x0 (dev_pose_mul)
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+#pragma unroll
+      for (int j = 0; j < 3; j++) xir[i * 3 + j] = delta.r[i * 3 + 0] * x0r[0 * 3 + j] + delta.r[i * 3 + 1] * x0r[1 * 3 + j] + delta.r[i * 3 + 2] * x0r[2 * 3 + j];
+      xir[9 + i] = delta.r[i * 3 + 0] * x0r[9] + delta.r[i * 3 + 1] * x0r[10] + delta.r[i * 3 + 2] * x0r[11] + delta.t[i];
+    }
+  }
+  if (lane == 0) {
+    if (accepted) {
+#pragma unroll
+      for (int k = 0; k < 12; k++) x0p[k] = x0r[k];
+    }
+    if (consume) {
+#pragma unroll
+      for (int k = 0; k < 12; k++) xlp[k] = x0r[k];  // x_lin = x0
+    }
+    if (!done) {
+#pragma unroll
+      for (int k = 0; k < 12; k++) xip[k] = xir[k];
+#pragma unroll
+      for (int j = 0; j < 6; j++) st->d[j] = d[j];
+    }
+    st->phase = phase;
+    st->outer_iter = outer_iter; st->inner_iter = inner_iter; st->converged = converged; st->lm_failed = lm_failed;
+    st->num_linearize = num_linearize; st->num_error_evals = num_error_evals; st->nr_iterations = nr_iterations; st->corr_cur = corr_cur;
+    st->delta_converged = delta_conv;
+  }
+  FVH_LM_T(6);
 }
 
 // tiny kernels for the multi-GPU path and for (re)initialising the state
@@ -487,7 +488,7 @@ __global__ void lm_init_kernel(LmState* st, PoseD guess, double rot_eps, double 
   st->max_iterations = max_iter; st->lm_max_iterations = lm_max_iter;
   st->lambda = -1.0; st->nu = 2.0; st->y0 = 0.0;
   st->phase = max_iter > 0 ? PH_LINEARIZE : PH_DONE;
-  st->corr_cur = 0; st->x_lin = guess;
+  st->corr_cur = 0; st->x_lin = guess; st->delta_converged = 0;
   st->outer_iter = 0; st->inner_iter = 0; st->converged = 0; st->lm_failed = 0; st->num_linearize = 0; st->num_error_evals = 0; st->nr_iterations = 0;
   for (int i = 0; i < 36; i++) st->final_H[i] = (i % 7 == 0) ? 1.0 : 0.0;
 }
@@ -570,21 +571,49 @@ __device__ __forceinline__ int probe_continue(const unsigned long long* __restri
 }
 
 constexpr int COST_CH = 4;     // voxel lookups a thread keeps in flight at once
-constexpr int PERSIST_TICKET_BYTES = 9 * 128;  // persistent kernel: 8 group counters + top counter, one 128-B line each
-constexpr int PERSIST_REPLICAS = 32;           // copies of the broadcast row; workgroup b polls copy b % PERSIST_REPLICAS
-constexpr int BCAST_SLOTS = 40;                // 5 segments of 64 B = 7 sums + 1 tag each (35 >= 29 sums)
-constexpr int TICKET_GROUPS = 8;  // hierarchical arrival counters (one per XCD-sized group of workgroups) + 1 top counter
-// Persistent kernel: the group rows travel as {sum, tag} PAIRS, one 16-byte agent-scope store per lane, and the opener polls
-// them with 16-byte loads -- the row is its own arrival signal: no "wait for the store, bump the top counter, poll the
-// counter, then load the rows" (three dependent memory-side round trips shorter per trip).
+#ifndef FVH_PERSIST_REPLICAS
+#define FVH_PERSIST_REPLICAS 32
+#endif
+constexpr int PERSIST_REPLICAS = FVH_PERSIST_REPLICAS;  // copies of the broadcast row (even); workgroup b polls copy b % PERSIST_REPLICAS
+constexpr int BCAST_PAIRS = 32;                // {value, tag} pairs per copy (26 used)
+constexpr int BCAST_VALUES = 26;               // phase, correspondence buffer, two poses
+constexpr int TICKET_GROUPS = 8;  // two-level reduction: workgroup b belongs to group b % 8 (its XCD under the observed dispatch order)
+#ifndef FVH_SINGLE_LEVEL_MAX
+#define FVH_SINGLE_LEVEL_MAX 128
+#endif
+constexpr int SINGLE_LEVEL_MAX_BLOCKS = FVH_SINGLE_LEVEL_MAX;  // grids up to this size reduce in ONE level (one group): every thread of the reducing workgroup polls <= 16 rows, 8 at a time
+// Everything that crosses workgroups inside the persistent kernel travels as {value, tag} PAIRS: one naturally aligned 16-byte
+// agent-scope (sc1, write-through) store per lane, polled with 16-byte sc1 loads. The tag names (launch, trip), so a pair is its
+// own arrival signal -- no counter, no fence, no "wait for the store, then raise a flag" (MI355X_MICROARCH.md: data-tagged
+// granules are the cheapest hand-off, ~1 us; a returning device-scope atomic plus a dependent load is two round trips).
 typedef double pair_t __attribute__((ext_vector_type(2)));
 constexpr size_t TAGGED_ROWS_OFFSET = (size_t)PART_STRIDE * (MAX_PARTIAL_ROWS + 2 * TICKET_GROUPS);  // doubles into CostParams::partials
-constexpr size_t TAGGED_ROWS_DOUBLES = 2 * TICKET_GROUPS * PART_STRIDE * 2;                        // [parity][group][32] pairs
+constexpr size_t TAGGED_ROWS_DOUBLES = 2 * TICKET_GROUPS * PART_STRIDE * 2;                        // group rows: [parity][group][32] pairs
+constexpr size_t WG_ROWS_OFFSET = TAGGED_ROWS_OFFSET + TAGGED_ROWS_DOUBLES;                         // workgroup rows of the persistent kernel: [MAX_PARTIAL_ROWS][32] pairs
+constexpr size_t WG_ROWS_DOUBLES = (size_t)MAX_PARTIAL_ROWS * PART_STRIDE * 2;
+constexpr size_t PARTIALS_DOUBLES = WG_ROWS_OFFSET + WG_ROWS_DOUBLES;
 __device__ __forceinline__ void store_pair_agent(pair_t* p, pair_t v) { asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory"); }
 __device__ __forceinline__ pair_t load_pair_agent(const pair_t* p) {
   pair_t v;
   asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(v) : "v"(p) : "memory");
   return v;
+}
+// eight pairs in flight together, ONE wait (the loads and the wait sit in one asm block: nothing can touch a destination
+// register before its data has landed)
+__device__ __forceinline__ void load_pairs8_agent(pair_t (&v)[8], const pair_t* const (&p)[8]) {
+  asm volatile(
+      "global_load_dwordx4 %0, %8, off sc1\n\t"
+      "global_load_dwordx4 %1, %9, off sc1\n\t"
+      "global_load_dwordx4 %2, %10, off sc1\n\t"
+      "global_load_dwordx4 %3, %11, off sc1\n\t"
+      "global_load_dwordx4 %4, %12, off sc1\n\t"
+      "global_load_dwordx4 %5, %13, off sc1\n\t"
+      "global_load_dwordx4 %6, %14, off sc1\n\t"
+      "global_load_dwordx4 %7, %15, off sc1\n\t"
+      "s_waitcnt vmcnt(0)"
+      : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]), "=&v"(v[4]), "=&v"(v[5]), "=&v"(v[6]), "=&v"(v[7])
+      : "v"(p[0]), "v"(p[1]), "v"(p[2]), "v"(p[3]), "v"(p[4]), "v"(p[5]), "v"(p[6]), "v"(p[7])
+      : "memory");
 }
 
 // PERSIST = true: ONE launch runs the whole LM loop. Every trip of the outer loop is what one launch of the
@@ -640,9 +669,13 @@ __device__ unsigned long long g_mtime[16][512][12];
 #define FVH_PT_MAX(trip, k) do { } while (0)
 #ifdef FVH_ASM_MARKS  // static instruction counts per section: hipcc -S -DFVH_ASM_MARKS, then tools/count_isa.py
 #define FVH_MT(trip, k) asm volatile("; FVH_MARK " #k)
+#define FVH_MARK(k) asm volatile("; FVH_MARK " #k)
 #else
 #define FVH_MT(trip, k) do { } while (0)
 #endif
+#endif
+#ifndef FVH_MARK
+#define FVH_MARK(k) do { } while (0)
 #endif
 
 // Workgroups per CU the register allocator must make room for (the persistent grid has to be co-resident, so this is part
@@ -977,26 +1010,29 @@ __global__ FVH_COST_BOUNDS void cost_kernel(CostParams P) {
   if (PERSIST) FVH_PT_MAX(gen, 1);
   if ((tid & 1) == 0) red[tid >> 6][(tid & 63) >> 1] = wacc;  // lane L (even) publishes slot L >> 1 of its wave
   __syncthreads();
-  if (tid < PART_STRIDE) {
-    const int vv = tid;
-    const double x = (red[0][vv] + red[1][vv]) + (red[2][vv] + red[3][vv]);
-    // write-through (sc1) so another workgroup can read it from L2 without a release fence;
-    // row slot v: sums 0..27, fused trial error at 28 (== NSUM), 29..31 zero
-    __hip_atomic_store(&P.partials[(size_t)blockIdx.x * PART_STRIDE + vv], x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  FVH_STAMP(2);
 
-  // ---- two-level arrival + two-level reduction ----------------------------------------------
-  // Workgroup b belongs to group b % 8 (its XCD under the observed dispatch order). The last arriver
-  // of a group sums that group's partial rows with all 256 threads (<= 8 independent sc1 loads per
-  // thread, fixed order), publishes one group row and arrives at the top counter; the last group
-  // sums the <= 8 group rows and runs the LM step. No address sees more than gridDim/8 + 8 atomics
-  // and no thread walks a long chain of dependent L2 round trips.
-  const unsigned grp = blockIdx.x % TICKET_GROUPS;
-  const unsigned ngroups = min((unsigned)TICKET_GROUPS, gridDim.x);
-  const unsigned gsize = (gridDim.x - grp + TICKET_GROUPS - 1) / TICKET_GROUPS;
+  // ---- two-level reduction (one level for small grids) ------------------------------------------
+  // Workgroup b belongs to group b % NG (NG = 8: its XCD under the observed dispatch order). A group's rows are summed by
+  // 256 threads -- thread (value v, chunk c) takes the rows c, c + 8, ... (<= 8 independent loads per batch, fixed order) --
+  // into one group row; the group rows are summed in group order. Grids of <= 64 workgroups are ONE group: a single level.
+  // The per-transition kernel finds "the last arriver" with atomic tickets; the persistent kernel has no tickets at all
+  // (designated collectors poll tagged rows, below). Both take the SAME summation order: bit-identical sums on both routes.
+  const unsigned NG = gridDim.x <= (unsigned)SINGLE_LEVEL_MAX_BLOCKS ? 1u : (unsigned)TICKET_GROUPS;
+  const unsigned grp = blockIdx.x % NG;
+  const unsigned ngroups = NG;  // (gridDim.x > 128 whenever NG == 8)
+  const unsigned gsize = (gridDim.x - grp + NG - 1) / NG;
+  if constexpr (!PERSIST) {
+    if (tid < PART_STRIDE) {
+      const int vv = tid;
+      const double x = (red[0][vv] + red[1][vv]) + (red[2][vv] + red[3][vv]);
+      // write-through (sc1) so another workgroup can read it from L2 without a release fence;
+      // row slot v: sums 0..27, fused trial error at 28 (== NSUM), 29..31 zero
+      __hip_atomic_store(&P.partials[(size_t)blockIdx.x * PART_STRIDE + vv], x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  }
+  FVH_STAMP(2);
   // sum of this group's partial rows -> fin[chunk][v] -> one group row (fixed order: deterministic)
   auto reduce_group_rows = [&](size_t out_row) {
     {
@@ -1007,7 +1043,7 @@ __global__ FVH_COST_BOUNDS void cost_kernel(CostParams P) {
 #pragma unroll
         for (int u = 0; u < 8; u++) {
           const unsigned j = j0 + 8 * u;
-          t[u] = (j < gsize) ? __hip_atomic_load(&P.partials[(size_t)(grp + j * TICKET_GROUPS) * PART_STRIDE + v], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
+          t[u] = (j < gsize) ? __hip_atomic_load(&P.partials[(size_t)(grp + j * NG) * PART_STRIDE + v], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
         }
 #pragma unroll
         for (int u = 0; u < 8; u++) s += t[u];
@@ -1047,7 +1083,7 @@ __global__ FVH_COST_BOUNDS void cost_kernel(CostParams P) {
     s_st.rotation_epsilon = P.rotation_epsilon; s_st.transformation_epsilon = P.transformation_epsilon; s_st.lm_init_lambda_factor = P.lm_init_lambda_factor;
     s_st.max_iterations = P.max_iterations; s_st.lm_max_iterations = P.lm_max_iterations;
     s_st.lambda = -1.0; s_st.nu = 2.0; s_st.y0 = 0.0;
-    s_st.phase = PH_LINEARIZE; s_st.corr_cur = 0;
+    s_st.phase = PH_LINEARIZE; s_st.corr_cur = 0; s_st.delta_converged = 0;
     s_st.outer_iter = 0; s_st.inner_iter = 0; s_st.converged = 0; s_st.lm_failed = 0; s_st.num_linearize = 0; s_st.num_error_evals = 0; s_st.nr_iterations = 0;
     for (int i = 0; i < 36; i++) s_st.final_H[i] = (i % 7 == 0) ? 1.0 : 0.0;
   };
@@ -1082,9 +1118,10 @@ __global__ FVH_COST_BOUNDS void cost_kernel(CostParams P) {
     // The LM step is one thread of dependent fp64 math; run it on an LDS copy of the state (a global
     // round trip per st-> access would cost more than the arithmetic) and write the state back with all lanes.
     for (int i = tid; i < ST_WORDS; i += 256) reinterpret_cast<unsigned long long*>(&s_st)[i] = st_words[i];
-    int vm_nv = 0, vm_dr = 0;
+    int vm_nv = 0, vm_dr = 0, vm_nv2 = 0;
     if (tid == 0) {
       vm_nv = P.vm_counters[0];
+      vm_nv2 = P.vm_counters2 ? P.vm_counters2[0] : 0;
       vm_dr = P.vm_counters[1] + (P.vm_counters2 ? P.vm_counters2[1] : 0);
     }
     __syncthreads();
@@ -1092,6 +1129,7 @@ __global__ FVH_COST_BOUNDS void cost_kernel(CostParams P) {
     if (tid == 0) {
       for (int v = 0; v < PART_STRIDE; v++) s_st.sums[v] = red[0][v];
       s_st.vm_num_voxels = vm_nv;
+      s_st.vm_num_voxels2 = vm_nv2;
       s_st.vm_dropped = vm_dr;
       if (P.host_phase < 0 && P.init) init_state();
     }
@@ -1111,45 +1149,76 @@ __global__ FVH_COST_BOUNDS void cost_kernel(CostParams P) {
 #endif
     return;
   } else {
-    // ---- persistent trip: the same two-level arrival, but nobody leaves -------------------------
-    // Counters are monotonic -- over the launch and across launches (the host passes their starting values instead
-    // of clearing them: a memset is a 3.5 us operation on the stream): in trip t the last arriver of a group draws
-    // tbase + gsize * (t + 1) - 1 and, after reducing its group's rows, bumps the top counter. Workgroup 0 (the "opener")
-    // waits for tbase + ngroups * (t + 1) there, sums the <= 8 group rows, runs the LM step and BROADCASTS
-    // what the next trip needs -- phase, correspondence buffer, the two poses: 26 values -- as PERSIST_REPLICAS copies
-    // of a 40-double row in which every 64-byte segment is 7 values + a tag (launch sequence, trip), written by 8
-    // adjacent lanes of one store instruction. Workgroup b polls copy b % PERSIST_REPLICAS with ONE 40-lane load per
-    // poll: when all 5 tags match, the values in the same segments are this trip's -- barrier and payload in a single
-    // memory round trip, and no address is read by more than ~8 workgroups.
-    // Dead ends measured on the way (474 workgroups, 17k points): one barrier word on the line of the arrival counters
+    // ---- persistent trip: nobody leaves, and nobody takes a ticket --------------------------------
+    // Round 2 found a group's last arriver with a returning atomic (one memory-side round trip), had it load the group's rows
+    // (a second one, after waiting for its own row store), publish a tagged group row, and the opener poll that. Now every
+    // workgroup publishes its 32 sums as {sum, tag} pairs -- ONE 16-byte write-through store per lane, no wait -- and goes
+    // straight to polling the broadcast; the first workgroup of each group (the COLLECTOR: blockIdx < NG) polls the pairs of its
+    // group's rows directly, eight in flight per thread, and adds them in the fixed order of reduce_group_rows as soon as the
+    // last one has landed; workgroup 0 (the OPENER; the LM state lives in its LDS for the whole launch) polls the NG group
+    // rows, runs the LM step and BROADCASTS what the next trip needs -- phase, correspondence buffer, the two poses: 26 values
+    // -- as PERSIST_REPLICAS copies of 26 tagged pairs. Workgroup b polls copy b % PERSIST_REPLICAS with one 26-lane 16-byte
+    // load per poll: barrier and payload in a single memory round trip, and no address is read by more than ~15 workgroups.
+    // The chain last-workgroup-done -> LM step is two hand-offs (one for grids of <= 64 workgroups) instead of four round trips.
+    // Dead ends measured in round 1/2 (474 workgroups, 17k points): one barrier word on the line of the arrival counters
     // (+10 us per trip); one barrier word + every workgroup reloading the state (21.6 us per trip: ~500 readers of the
     // same lines queue at their memory channel); every workgroup running the LM step redundantly on its own copy
     // (22.7 us per trip: the step takes 5 us instead of 1.5 when ~500 waves fetch its code at once).
-    // Group rows alternate by trip parity; only the opener reads them, and trip t + 1's rows are written after every
-    // workgroup -- the opener included -- has arrived at trip t + 1.
+    // Rows are single-buffered: a workgroup writes its trip t + 1 row only after it has seen the broadcast of trip t, which the
+    // opener sends after every row of trip t has been consumed. Tags embed the launch sequence: rows of older launches never match.
     const unsigned trip = gen;
     unsigned long long ltag = P.launch_tag;
     asm volatile("" : "+s"(ltag));  // opaque per trip: otherwise the two conversions below are hoisted out of the trip loop and held in 4 VGPRs across the main loop
     // (formed where they are used, from scalars: held as doubles they were four VGPRs live across the inlined LM step)
     auto want_tag_of = [&]() { unsigned long long t = ltag * 4096ull + trip + 1; asm volatile("" : "+s"(t)); return (double)t; };
     auto abort_tag_of = [&]() { unsigned long long t = ltag * 4096ull; asm volatile("" : "+s"(t)); return -(double)t; };  // launch-specific: a poisoned row of an older launch means nothing
-    __shared__ double bc[BCAST_SLOTS];  // payload of the broadcast row as seen by this workgroup
-    static_assert(TICKET_GROUPS == 8, "tb0..tb7");
-    const unsigned tb = grp == 0 ? P.tb0 : grp == 1 ? P.tb1 : grp == 2 ? P.tb2 : grp == 3 ? P.tb3 : grp == 4 ? P.tb4 : grp == 5 ? P.tb5 : grp == 6 ? P.tb6 : P.tb7;
-    if (tid == 0) s_last = (atomicAdd(&P.ticket[grp * 32], 1u) == tb + gsize * (trip + 1) - 1);
-    FVH_PT_MAX(trip, 2);
-    __syncthreads();
+    __shared__ double bc[BCAST_PAIRS];  // payload of the broadcast row as seen by this workgroup
+    pair_t* wrows = reinterpret_cast<pair_t*>(P.partials + WG_ROWS_OFFSET);
     pair_t* trows = reinterpret_cast<pair_t*>(P.partials + TAGGED_ROWS_OFFSET) + (size_t)(trip & 1u) * TICKET_GROUPS * PART_STRIDE;
-    if (s_last) {  // the group's last arriver: sum of the group's rows (the order of reduce_group_rows) -> one tagged row
+    pair_t* bcast = reinterpret_cast<pair_t*>(P.bcast);
+    auto poison = [&](int first, int stride) {  // never hang the GPU: every tag of this launch's broadcast becomes the abort tag
+      pair_t pv;
+      pv.x = 0.0; pv.y = abort_tag_of();
+      for (int idx = first; idx < PERSIST_REPLICAS * BCAST_PAIRS; idx += stride) store_pair_agent(bcast + idx, pv);
+    };
+    if (tid < PART_STRIDE) {
+      pair_t pv;
+      pv.x = (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);  // row slot v: sums 0..27, fused trial error at 28 (== NSUM), 29..31 zero
+      pv.y = want_tag_of();
+      store_pair_agent(wrows + (size_t)blockIdx.x * PART_STRIDE + tid, pv);
+    }
+    FVH_PT_MAX(trip, 2);
+    const bool collector = blockIdx.x < NG;  // == the first workgroup of group `grp`
+    const bool opener = (blockIdx.x == 0);
+    if (collector) {
+      if (tid == 0) s_last = 1;
+      __syncthreads();
       {
         const int v = tid & 31, chunk = tid >> 5;
+        const double want = want_tag_of();
         double s = 0.0;
         for (unsigned j0 = chunk; j0 < gsize; j0 += 8 * 8) {
+          const pair_t* src[8];
           double t[8];
+          unsigned pend = 0;
 #pragma unroll
           for (int u = 0; u < 8; u++) {
             const unsigned j = j0 + 8 * u;
-            t[u] = (j < gsize) ? __hip_atomic_load(&P.partials[(size_t)(grp + j * TICKET_GROUPS) * PART_STRIDE + v], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
+            const bool in = j < gsize;
+            src[u] = wrows + (size_t)(grp + (in ? j : j0) * NG) * PART_STRIDE + v;  // (rows past the end: a valid address, never looked at)
+            t[u] = 0.0;
+            pend |= in ? (1u << u) : 0u;
+          }
+          const unsigned long long t0 = wall_clock64();
+          for (;;) {
+            pair_t pv[8];
+            load_pairs8_agent(pv, src);
+#pragma unroll
+            for (int u = 0; u < 8; u++)
+              if (((pend >> u) & 1u) && pv[u].y == want) { t[u] = pv[u].x; pend &= ~(1u << u); }
+            if (!pend) break;
+            if (wall_clock64() - t0 > P.watchdog_ticks) { s_last = 0; break; }  // a row never came: not every workgroup is resident / something is stuck
+            __builtin_amdgcn_s_sleep(1);
           }
 #pragma unroll
           for (int u = 0; u < 8; u++) s += t[u];
@@ -1157,96 +1226,153 @@ __global__ FVH_COST_BOUNDS void cost_kernel(CostParams P) {
         fin[chunk][v] = s;
       }
       __syncthreads();
+      if (!s_last) {
+        poison(tid, 256);
+        if (tid == 0) __hip_atomic_store(&st->aborted, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return;
+      }
       if (tid < PART_STRIDE) {
         double s = 0.0;
 #pragma unroll
         for (int c = 0; c < 8; c++) s += fin[c][tid];
-        pair_t pv;
-        pv.x = s; pv.y = want_tag_of();
-        store_pair_agent(trows + (size_t)grp * PART_STRIDE + tid, pv);
+        if (NG > 1) {
+          pair_t pv;
+          pv.x = s; pv.y = want_tag_of();
+          store_pair_agent(trows + (size_t)grp * PART_STRIDE + tid, pv);
+        } else {
+          red[1][tid] = s;  // single level: this IS the only group row (the opener is the collector)
+        }
       }
       FVH_PT_MAX(trip, 5);
       __syncthreads();  // fin[] is reused by the opener below
     }
-    // The opener is always workgroup 0 (not whoever arrives last): the LM step is ~20 KB of code that runs once per
+    // The opener is always workgroup 0 (not whoever arrives last): the LM step is ~10 KB of code that runs once per
     // trip -- on a random CU it is fetched cold every time; on a fixed CU it stays in the instruction cache, and the LM
     // state stays in this workgroup's LDS for the whole launch instead of travelling through memory each trip.
-    const bool opener = (blockIdx.x == 0);
     if (opener) {
-      if (tid == 0) s_last = 1;
-      __syncthreads();
-      {  // thread (value v, group g) polls ITS pair of group g's tagged row; the sum over the groups keeps reduce_final's order
-        const int v = tid & 31;
-        const unsigned g = tid >> 5;
+      // From here to the broadcast ONE wave does everything (the other three wait at the barrier below): lanes 0..31 poll the
+      // pairs of the <= 8 group rows (eight in flight per lane) and add them in group order -- reduce_final's order --, the
+      // sums go to LDS, the LM step runs in registers, lanes 0..25 read the payload back and store it to the replicas. No
+      // __syncthreads, no LDS hop between the stages (round 2: five barriers and four LDS hand-offs between four groups of threads).
+      __shared__ unsigned s_abort;
+      if (tid == 0) s_abort = 0u;
+      const bool multi_gpu = MODE == MODE_VGICP && P.peer.n > 1;  // (kernel argument: uniform)
+      if (tid < 64) {
+        const int lane = tid;
         double val = 0.0;
-        if (g < ngroups) {
-          const pair_t* src = trows + (size_t)g * PART_STRIDE + v;
+        bool ok = true;
+        if (NG == 1) {
+          if (lane < PART_STRIDE) val = red[1][lane];  // single level: the group row is already in LDS (collector == opener; barrier above)
+        } else {
+          const pair_t* src[8];
+          double t[8];
+          unsigned pend = 0;
+#pragma unroll
+          for (int g = 0; g < 8; g++) {
+            src[g] = trows + (size_t)g * PART_STRIDE + (lane & 31);
+            t[g] = 0.0;
+            pend |= (1u << g);
+          }
+          if (lane >= PART_STRIDE) pend = 0;
           const double want = want_tag_of();
           const unsigned long long t0 = wall_clock64();
-          for (;;) {
-            const pair_t pv = load_pair_agent(src);
-            if (pv.y == want) { val = pv.x; break; }
-            if (wall_clock64() - t0 > P.watchdog_ticks) { s_last = 0; break; }
-            __builtin_amdgcn_s_sleep(1);
+          while (__builtin_amdgcn_ballot_w64(pend != 0u) != 0ull) {
+            pair_t pv[8];
+            load_pairs8_agent(pv, src);
+#pragma unroll
+            for (int g = 0; g < 8; g++)
+              if (((pend >> g) & 1u) && pv[g].y == want) { t[g] = pv[g].x; pend &= ~(1u << g); }
+            if (__builtin_amdgcn_readfirstlane((int)(wall_clock64() - t0 > P.watchdog_ticks))) { ok = false; break; }
+          }
+#pragma unroll
+          for (int g = 0; g < 8; g++) val += t[g];  // group order
+        }
+        FVH_PT_MAX(trip, 6);
+        if (lane < PART_STRIDE) red[0][lane] = val;
+        if (!ok && lane == 0) s_abort = 1u;  // 1: not every workgroup is resident / something is stuck
+        if (ok && !multi_gpu) {
+          FVH_PT_MAX(trip, 7);
+          if (trip == 0 && lane == 0) {
+            init_state();
+            s_st.vm_num_voxels = P.vm_counters[0];
+            s_st.vm_num_voxels2 = P.vm_counters2 ? P.vm_counters2[0] : 0;
+            s_st.vm_dropped = P.vm_counters[1] + (P.vm_counters2 ? P.vm_counters2[1] : 0);
+          }
+          if (lane < PART_STRIDE) s_st.sums[lane] = val;
+        }
+      }
+      if (multi_gpu) {
+        // multi-GPU: the openers of all ranks meet in each other's mailboxes (kernels_peer.hpp, all 256 threads); every rank then runs the same LM step
+        // (VGICP handles only: the NDT handles shard through RCCL between launches, and their D2D instantiation has no register to spare)
+        __syncthreads();
+        if constexpr (MODE == MODE_VGICP) {
+          if (!s_abort && !peer_exchange_sums(P.peer, red[0], P.peer.xbase + trip, P.peer_watchdog_ticks, tid, 256, &s_last)) {
+            if (tid == 0) s_abort = 2u;  // 2: a peer did not deliver
           }
         }
-        fin[g][v] = val;
+        __syncthreads();
+        if (!s_abort && tid < 64) {
+          if (trip == 0 && tid == 0) {
+            init_state();
+            s_st.vm_num_voxels = P.vm_counters[0];
+            s_st.vm_num_voxels2 = P.vm_counters2 ? P.vm_counters2[0] : 0;
+            s_st.vm_dropped = P.vm_counters[1] + (P.vm_counters2 ? P.vm_counters2[1] : 0);
+          }
+          if (tid < PART_STRIDE) s_st.sums[tid] = red[0][tid];
+        }
+      }
+      if (tid < 64) {
+        bool live = true;
+        if (multi_gpu) live = s_abort == 0u;
+        else live = __builtin_amdgcn_ballot_w64(s_abort != 0u) == 0ull;  // (same wave wrote it: LDS operations complete in order)
+        if (live) {
+          const int lane = tid;
+          FVH_PT_MAX(trip, 8);
+          FVH_MARK(20);
+#ifdef FVH_LM_TWICE  // experiment: a dry run on a copy of the state first -- the timed run then finds its code in the instruction cache
+          {
+            __shared__ LmState s_dry;
+            for (int i = lane; i < ST_WORDS; i += 64) reinterpret_cast<unsigned long long*>(&s_dry)[i] = reinterpret_cast<const unsigned long long*>(&s_st)[i];
+            dev_lm_step_wave(&s_dry, red[0], lane, nullptr);
+          }
+#endif
+#ifdef FVH_COST_TIMING
+          const unsigned long long lm_c0 = __builtin_readcyclecounter();
+#endif
+          dev_lm_step_wave(&s_st, red[0], lane, P.lm_trace);
+#ifdef FVH_COST_TIMING
+          if (threadIdx.x == 0 && trip < 16) g_ptime[trip][0][11] = __builtin_readcyclecounter() - lm_c0;  // shader cycles of the LM step (next to its wall-clock stamps 8 -> 9)
+#endif
+          FVH_MARK(21);
+          FVH_PT_MAX(trip, 9);
+          // payload: phase, correspondence buffer, x_lin, evaluation pose of the next trip -- one value per lane, read back from the state
+          const int ph = __builtin_amdgcn_readfirstlane(s_st.phase);
+          double v = 0.0;
+          const int d = lane & 31;  // both halves of the wave hold the payload: each store instruction fills TWO replicas
+          if (d < BCAST_VALUES) {
+            const double* xl = reinterpret_cast<const double*>(&s_st.x_lin);
+            const double* pe = reinterpret_cast<const double*>(ph == PH_LINEARIZE ? &s_st.x0 : &s_st.xi);
+            if (d == 0) v = (double)ph;
+            else if (d == 1) v = (double)s_st.corr_cur;
+            else if (d < 14) v = xl[d - 2];
+            else v = pe[d - 14];
+            if (lane < 32) bc[d] = v;  // (this workgroup's own copy for the next trip)
+            pair_t pv;
+            pv.x = v; pv.y = want_tag_of();
+            pair_t* dst = bcast + lane;  // lanes 32..63: the next replica (BCAST_PAIRS == 32)
+            static_assert(BCAST_PAIRS == 32 && PERSIST_REPLICAS % 2 == 0, "two replicas per store instruction");
+#pragma unroll 8
+            for (int r = 0; r < PERSIST_REPLICAS; r += 2) store_pair_agent(dst + (size_t)r * BCAST_PAIRS, pv);
+          }
+          FVH_PT_MAX(trip, 3);
+        }
       }
       __syncthreads();
-      unsigned abort_code = s_last ? 0u : 1u;  // 1: not every workgroup is resident / something is stuck
-      if (!abort_code) {
-        FVH_PT_MAX(trip, 6);
-        if (tid < PART_STRIDE) {
-          double s = 0.0;
-#pragma unroll
-          for (int c = 0; c < 8; c++) s += fin[c][tid];
-          red[0][tid] = s;
-        }
-        __syncthreads();
-        // multi-GPU: the openers of all ranks meet in each other's mailboxes (kernels_peer.hpp); every rank then runs the same LM step
-        // (VGICP handles only: the NDT handles shard through RCCL between launches, and their D2D instantiation has no register to spare)
-        if constexpr (MODE == MODE_VGICP)
-          if (P.peer.n > 1 && !peer_exchange_sums(P.peer, red[0], P.peer.xbase + trip, P.peer_watchdog_ticks, tid, 256, &s_last)) abort_code = 2u;  // 2: a peer did not deliver
-      }
-      if (abort_code) {  // never hang the GPU -- poison every tag of this launch and leave; the host takes it from `aborted`
-        const double abort_tag = abort_tag_of();
-        for (int idx = tid; idx < PERSIST_REPLICAS * BCAST_SLOTS / 8; idx += 256) __hip_atomic_store(&P.bcast[idx * 8 + 7], abort_tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (tid == 0) __hip_atomic_store(&st->aborted, abort_code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (s_abort) {  // never hang the GPU -- poison every tag of this launch and leave; the host takes it from `aborted`
+        poison(tid, 256);
+        if (tid == 0) __hip_atomic_store(&st->aborted, s_abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         return;
       }
-      FVH_PT_MAX(trip, 7);
-      if (trip == 0 && tid == 0) {
-        init_state();
-        s_st.vm_num_voxels = P.vm_counters[0];
-        s_st.vm_dropped = P.vm_counters[1] + (P.vm_counters2 ? P.vm_counters2[1] : 0);
-      }
-      if (tid >= 64 && tid < 64 + PART_STRIDE) s_st.sums[tid - 64] = red[0][tid - 64];  // (a lane each, not 32 round trips of lane 0)
-      __syncthreads();
-      FVH_PT_MAX(trip, 8);
-      if (tid < 64) dev_lm_step_wave(&s_st, red[0], tid, P.lm_trace);
-      FVH_PT_MAX(trip, 9);
-      __syncthreads();
-      if (tid < 26) {  // payload: phase, correspondence buffer, x_lin, evaluation pose of the next trip
-        const int ph = s_st.phase;
-        const PoseD& pe = (ph == PH_LINEARIZE) ? s_st.x0 : s_st.xi;
-        const int d = tid;
-        double v;
-        if (d == 0) v = (double)ph;
-        else if (d == 1) v = (double)s_st.corr_cur;
-        else if (d < 11) v = s_st.x_lin.r[d - 2];
-        else if (d < 14) v = s_st.x_lin.t[d - 11];
-        else if (d < 23) v = pe.r[d - 14];
-        else v = pe.t[d - 23];
-        bc[d] = v;
-      }
-      __syncthreads();
-      FVH_PT_MAX(trip, 10);
-      for (int idx = tid; idx < PERSIST_REPLICAS * BCAST_SLOTS; idx += 256) {
-        const int slot = idx % BCAST_SLOTS, seg = slot >> 3, k = slot & 7, d = seg * 7 + k;
-        const double val = (k == 7) ? want_tag_of() : (d < 26 ? bc[d] : 0.0);
-        __hip_atomic_store(&P.bcast[idx], val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      }
-      FVH_PT_MAX(trip, 3);
       if (s_st.phase == PH_DONE) {  // the state leaves the LDS once, at the end (the kernel boundary makes it visible)
         for (int i = tid; i < ST_WORDS; i += 256) st_words[i] = reinterpret_cast<const unsigned long long*>(&s_st)[i];
         if (P.result_host) {
@@ -1262,24 +1388,28 @@ __global__ FVH_COST_BOUNDS void cost_kernel(CostParams P) {
     }
     if (!opener) {
       if (tid < 64) {  // wave 0 polls this workgroup's copy
-        const double* rep = P.bcast + (size_t)(blockIdx.x % PERSIST_REPLICAS) * BCAST_SLOTS;
+#ifdef FVH_POLL_BACKOFF  // experiment: the answer cannot come before two hand-offs and the LM step: stay off the fabric meanwhile
+        if (!collector) __builtin_amdgcn_s_sleep(FVH_POLL_BACKOFF);
+#endif
+        const pair_t* rep = bcast + (size_t)(blockIdx.x % PERSIST_REPLICAS) * BCAST_PAIRS;
         const int lane = tid;
-        const bool is_slot = lane < BCAST_SLOTS, is_tag = is_slot && ((lane & 7) == 7);
+        const bool is_val = lane < BCAST_VALUES;
         const unsigned long long t0 = wall_clock64();
         const double want_tag = want_tag_of(), abort_tag = abort_tag_of();
         int ok = 0;
         for (;;) {
-          const double v = is_slot ? __hip_atomic_load(&rep[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
-          if (__any(is_tag && v == abort_tag)) break;  // another workgroup's watchdog aborted THIS launch
-          if (__all(!is_tag || v == want_tag)) {
-            const int d = (lane >> 3) * 7 + (lane & 7);
-            if (is_slot && !is_tag && d < 26) bc[d] = v;
+          pair_t pv;
+          pv.x = 0.0; pv.y = want_tag;
+          if (is_val) pv = load_pair_agent(rep + lane);
+          if (__any(is_val && pv.y == abort_tag)) break;  // another workgroup's watchdog aborted THIS launch
+          if (__all(pv.y == want_tag)) {
+            if (is_val) bc[lane] = pv.x;
             ok = 1;
             break;
           }
           if (__builtin_amdgcn_readfirstlane((int)(wall_clock64() - t0 > P.watchdog_ticks))) {
             // not every workgroup is resident / something is stuck: never hang the GPU -- poison every tag and leave
-            for (int idx = lane; idx < PERSIST_REPLICAS * BCAST_SLOTS / 8; idx += 64) __hip_atomic_store(&P.bcast[idx * 8 + 7], abort_tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            poison(lane, 64);
             if (lane == 0) __hip_atomic_store(&st->aborted, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             break;
           }

@@ -263,8 +263,11 @@ def test_concurrent_handles_share_the_coresident_slots():
     # Round 2 leaked a concurrency count per REFUSED grant: afterwards every lone align of the process got
     # cap / 4 workgroups. Whatever happened above, the pool must be empty now and a lone align must get its whole grid again.
     assert capi.debug_slot_pool(0)[:2] == (0, 0), capi.debug_slot_pool(0)
-    for _ in range(6):  # (the concurrency ESTIMATE decays one align at a time by design)
+    for _ in range(200):  # (the concurrency ESTIMATE decays slowly by design: one step per 32 calm aligns)
         r = cores[0].align()
+        if capi.debug_slot_pool(0)[2] <= 1:
+            break
+    r = cores[0].align()
     blocks, cap = cores[0].debug_persist_grid()
     assert r["num_launches"] == 1 and capi.debug_slot_pool(0) == (0, 0, 1), capi.debug_slot_pool(0)
     lone = capi.VGICPCore(0)
@@ -273,7 +276,7 @@ def test_concurrent_handles_share_the_coresident_slots():
     lone.set_source_cloud(src); lone.find_source_neighbors(20); lone.calculate_source_covariances(3)
     lone.align()
     assert lone.debug_persist_grid()[0] == blocks, (lone.debug_persist_grid(), blocks)  # a fresh handle and the veteran get the same grid
-    assert np.array_equal(lone.align()["T"], ref["T"])                                  # ... hence bit-identical sums with the very first align
+    assert util.rel_err(lone.align()["T"], ref["T"]) < 1e-9  # (not bit-identical: another BUILD of the voxel map -- its fp64 atomics land in another order, the fp32 records may differ in the last bit)
     lone.close()
     for c in cores:
         c.close()
@@ -320,10 +323,14 @@ def test_refused_slot_requests_do_not_throttle_later_aligns():
     stop.set()
     th[0].join()
     assert capi.debug_slot_pool(0)[:2] == (0, 0), capi.debug_slot_pool(0)
-    for _ in range(6):
+    for _ in range(200):
         r = small[0].align()
+        if capi.debug_slot_pool(0)[2] <= 1:
+            break
+    r = small[0].align()
+    assert capi.debug_slot_pool(0) == (0, 0, 1), capi.debug_slot_pool(0)
     assert r["num_launches"] == 1 and small[0].debug_persist_grid()[0] == full_blocks, (small[0].debug_persist_grid(), full_blocks)
-    assert np.array_equal(r["T"], ref["T"])
+    assert np.array_equal(r["T"], ref["T"])  # same handle, same map, same grid as its first align: the same bits
     print("refused / squeezed small aligns that took the multi-launch route: %d of 120" % fallbacks[0])
     for c in small + [big]:
         c.close()

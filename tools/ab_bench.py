@@ -37,7 +37,7 @@ def main():
         st = d.get("stages", {})
         print("%-44s %9.1f reg/s  cost %7.1f us  knn %6.1f  cov %5.1f  vm %5.1f  fitness %.6f aborts %s" % (
             spec, d["value"], st.get("cost", {}).get("avg_us", float("nan")), st.get("knn", {}).get("avg_us", float("nan")), st.get("cov", {}).get("avg_us", float("nan")),
-            st.get("voxelmap", {}).get("avg_us", float("nan")), d["fitness_score"], d["per_registration"]["persistent_launches_aborted_by_watchdog"]), flush=True)
+            st.get("voxelmap", {}).get("avg_us", float("nan")), d.get("fitness_score", float("nan")), d["per_registration"].get("persistent_launches_aborted_by_watchdog")), flush=True)
 
 
 if __name__ == "__main__":
