@@ -70,7 +70,7 @@ def test_kernels_stay_on_the_right_side_of_the_register_cliff():
             # persistent instantiations: the LM step is inlined into the opener's once-per-trip path (7 us per launch faster than a
             # call through generic pointers); a few values live across it are spilled THERE (8 scratch instructions in the whole
             # kernel, none in the main loop -- tools/count_isa.py lists them per section, tools/kernel_resources.py shows the counts)
-            assert v["vgpr_spill"] <= 24 and v["scratch"] <= 64, (k, v)
+            assert v["vgpr_spill"] <= 32 and v["scratch"] <= 96, (k, v)
         else:
             assert v["vgpr_spill"] == 0 and v["scratch"] == 0, (k, v)
     assert res["fvh::lm_update_kernel(fvh::LmState*)"]["vgprs"] <= 168  # the wave-parallel LM step is inlined into every cost kernel
@@ -79,3 +79,32 @@ def test_kernels_stay_on_the_right_side_of_the_register_cliff():
         hit = [v for k, v in res.items() if name in k]
         assert hit, name
         assert all(v["occupancy"] >= occ and v["vgpr_spill"] == 0 for v in hit), (name, hit)
+
+
+def test_the_lm_kernels_main_loop_has_no_scratch_access(tmp_path):
+    """What the spill budget above is really about: the once-per-trip epilogue of the persistent LM kernel may park a few values in
+    scratch, its MAIN LOOP (the sections between the FVH_MARK comments of a -DFVH_ASM_MARKS build) must not touch scratch at all,
+    in any persistent instantiation. tools/count_isa.py prints the same table."""
+    import re
+    import subprocess
+    from fast_gicp_amd import build as B
+    out = tmp_path / "fvh.s"
+    subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-mllvm", "-disable-machine-licm", "--cuda-device-only", "-S", "-DFVH_ASM_MARKS",
+                           "-o", str(out), B.SOURCES[0]], stderr=subprocess.DEVNULL)
+    text = out.read_text()
+    for real in "df":
+        for mode in "012":
+            name = "_ZN3fvh11cost_kernelI%sLi%sELb1EEEvNS_10CostParamsE" % (real, mode)
+            i = text.index(name + ":")
+            body = text[i:text.index(".Lfunc_end", i)].split("\n")
+            sec, scratch = "pre", {}
+            for line in body:
+                line = line.strip()
+                m = re.match(r"; FVH_MARK (\d+)", line)
+                if m:
+                    sec = int(m.group(1))
+                elif line.startswith("scratch_"):
+                    scratch[sec] = scratch.get(sec, 0) + 1
+            main_loop = {k: v for k, v in scratch.items() if k != "pre" and k not in (7, 20, 21)}  # marks 0..6 and 8 bracket the main loop; 7 = epilogue, 20/21 = LM step
+            assert not main_loop, (name, scratch)
+            assert sum(scratch.values()) <= 24, (name, scratch)
