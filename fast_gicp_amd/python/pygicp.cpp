@@ -17,6 +17,7 @@ using namespace fast_gicp;
 using Cloud = PointCloud<PointXYZ>;
 using Lsq = LsqRegistration<PointXYZ, PointXYZ>;
 using VGICPCuda = FastVGICPCuda<PointXYZ, PointXYZ>;
+using VGICP = FastVGICP<PointXYZ, PointXYZ>;
 using GICP = FastGICP<PointXYZ, PointXYZ>;
 using NDT = NDTCuda<PointXYZ, PointXYZ>;
 using Points = py::array_t<double, py::array::c_style | py::array::forcecast>;
@@ -107,9 +108,9 @@ static py::array_t<double> downsample_device(const Points& points, double resolu
   return res;
 }
 
-// align_points, main.cpp:64-150. "VGICP" (the CPU FastVGICP in the reference) runs on the same GPU
-// engine in its fp64 CPU-parity arithmetic with k_correspondences honoured; "GICP" (nearest-point
-// correspondences, no voxels) runs its correspondence search and cost sums on the device too.
+// align_points, main.cpp:64-150. "VGICP" (the CPU FastVGICP in the reference, main.cpp:102-108) runs on the same GPU engine in
+// its fp64 arithmetic WITH k_correspondences honoured (class FastVGICP of registration.hpp; "VGICP_CUDA" ignores it like the
+// reference's FastVGICPCuda: k = 20); "GICP" (nearest-point correspondences, no voxels) runs on the device too.
 static py::array_t<double> align_points(const Points& target, const Points& source, const std::string& method, double downsample_resolution, int k_correspondences,
                                         double max_correspondence_distance, double voxel_resolution, int /*num_threads*/, const std::string& neighbor_search_method,
                                         double neighbor_search_radius, const Mat4& initial_guess) {
@@ -121,7 +122,18 @@ static py::array_t<double> align_points(const Points& target, const Points& sour
     target_cloud = ft; source_cloud = fs;
   }
   std::shared_ptr<Lsq> reg;
-  if (method == "VGICP_CUDA" || method == "VGICP") {
+  if (method == "VGICP") {  // main.cpp:102-108
+    auto vgicp = std::make_shared<VGICP>();
+    vgicp->setCorrespondenceRandomness(k_correspondences);
+    vgicp->setResolution(voxel_resolution);
+    if (search_method(neighbor_search_method) == fast_gicp::NeighborSearchMethod::DIRECT_RADIUS) {
+      std::cerr << "error: FastVGICP has no DIRECT_RADIUS neighbor search (use VGICP_CUDA)" << std::endl;
+      return identity4();
+    }
+    vgicp->setNeighborSearchMethod(search_method(neighbor_search_method));
+    vgicp->setNumThreads(0);
+    reg = vgicp;
+  } else if (method == "VGICP_CUDA") {
     auto vgicp = std::make_shared<VGICPCuda>();
     vgicp->setCorrespondenceRandomness(k_correspondences);  // a no-op, as in the reference (k = 20)
     vgicp->setNeighborSearchMethod(search_method(neighbor_search_method), neighbor_search_radius);
@@ -236,8 +248,15 @@ PYBIND11_MODULE(pygicp, m) {
       .def("set_source_covariances", [](GICP& g, const py::array_t<double, py::array::c_style | py::array::forcecast>& c) { g.setSourceCovariances(numpy_to_covs(c)); })
       .def("set_target_covariances", [](GICP& g, const py::array_t<double, py::array::c_style | py::array::forcecast>& c) { g.setTargetCovariances(numpy_to_covs(c)); });
 
-  // The reference's CPU class name, served by the GPU engine in its fp64 CPU-parity arithmetic.
-  m.attr("FastVGICP") = m.attr("FastVGICPCuda");
+  // The reference's CPU class (main.cpp:192-196; there it derives from FastGICP: set_num_threads, set_correspondence_randomness,
+  // set_max_correspondence_distance), served by the GPU engine in its fp64 arithmetic; k IS honoured here (registration.hpp, FastVGICP).
+  py::class_<VGICP, VGICPCuda, std::shared_ptr<VGICP>>(m, "FastVGICP")
+      .def(py::init([](int device) { return std::make_shared<VGICP>(device); }), py::arg("device") = 0)
+      .def("set_num_threads", &VGICP::setNumThreads)
+      .def("set_correspondence_randomness", &VGICP::setCorrespondenceRandomness)
+      .def("set_max_correspondence_distance", &VGICP::setMaxCorrespondenceDistance)
+      .def("set_resolution", &VGICP::setResolution)
+      .def("set_neighbor_search_method", [](VGICP& v, const std::string& method) { v.setNeighborSearchMethod(search_method(method)); }, py::arg("method") = "DIRECT1");
 
   py::class_<NDT, Lsq, std::shared_ptr<NDT>>(m, "NDTCuda")
       .def(py::init([](int device) { return std::make_shared<NDT>(device); }), py::arg("device") = 0)

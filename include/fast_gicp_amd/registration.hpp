@@ -491,13 +491,36 @@ protected:
   }
   void call(int rc, const char* what) const { detail::check(rc, what, fvh_vgicp_last_error(core_)); }
 
-private:
+protected:
   int k_correspondences_ = 20;                                                                   // :24
+private:
   double voxel_resolution_ = 1.0;                                                                // :25
   RegularizationMethod regularization_method_ = RegularizationMethod::PLANE;                     // :26
+protected:
   NearestNeighborMethod neighbor_search_method_ = NearestNeighborMethod::CPU_PARALLEL_KDTREE;    // :27
+private:
   fvh_vgicp* core_ = nullptr;
   std::vector<float> scratch_xyz_;  // only used for point types that are not 12 / 16 bytes of packed xyz
+};
+
+/// FastVGICP -- the reference's CPU / OpenMP class (gicp/fast_vgicp.hpp:28-78, impl/fast_vgicp_impl.hpp) -- served by the same HIP
+/// engine in its fp64 arithmetic. What distinguishes it from FastVGICPCuda in the reference is kept: `setCorrespondenceRandomness(k)`
+/// IS honoured (FastGICP::k_correspondences_, fast_gicp_impl.hpp:41-43,253-265; the CUDA class ignores it, fast_vgicp_cuda_impl.hpp:38),
+/// the covariances come from EXACT k nearest neighbours (the reference's kd-tree; here the device's exact search: identical lists),
+/// `setNumThreads` exists (a no-op: there is no OpenMP team to size) and the neighbour search takes no radius (DIRECT1 / 7 / 27 only).
+template <typename PointSource, typename PointTarget>
+class FastVGICP : public FastVGICPCuda<PointSource, PointTarget> {
+  using Base = FastVGICPCuda<PointSource, PointTarget>;
+
+public:
+  explicit FastVGICP(int device = 0) : Base(device) { this->neighbor_search_method_ = NearestNeighborMethod::GPU_BRUTEFORCE; }
+  void setNumThreads(int) {}                                                      // fast_gicp_impl.hpp:36-38
+  void setCorrespondenceRandomness(int k) { this->k_correspondences_ = k; }       // fast_gicp_impl.hpp:41-43 (takes effect at the next setInputSource / setInputTarget)
+  void setMaxCorrespondenceDistance(double) {}                                    // inherited from pcl::Registration; FastVGICP never reads it (voxel correspondences)
+  void setNeighborSearchMethod(NeighborSearchMethod method) {                     // fast_vgicp_impl.hpp:46-48
+    if (method == NeighborSearchMethod::DIRECT_RADIUS) detail::check(FVH_ERR_INVALID_ARGUMENT, "setNeighborSearchMethod", "FastVGICP has no DIRECT_RADIUS (fast_vgicp_voxel.hpp:16-43): use FastVGICPCuda");
+    Base::setNeighborSearchMethod(method, -1.0);
+  }
 };
 
 /// FastGICP (gicp/fast_gicp.hpp:24-98, impl/fast_gicp_impl.hpp) on the HIP engine: the reference class is CPU/OpenMP only;

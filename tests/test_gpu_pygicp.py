@@ -164,3 +164,31 @@ def test_lm_trace_rows_through_the_abi(data):
     assert t[-1, 1] <= t[0, 1] and np.all(t[:, 4] > 0) and np.all(t[:, 5] > 0)   # y0 decreases over the run; lambda, |d| positive
     assert np.all((t[:, 2] < t[:, 1]) == (t[:, 3] > 0))                            # rho > 0  <=>  the trial lowered the error (denominator > 0)
     c.close()
+
+
+@pytest.mark.parametrize("k", [10, 15, 32])
+def test_vgicp_honours_k_correspondences_like_the_cpu_class(pygicp, k):
+    """main.cpp:102-108: align_points(method="VGICP") builds the CPU FastVGICP, whose setCorrespondenceRandomness(k) is real
+    (k_correspondences defaults to 15 in align_points, main.cpp:155-167), while FastVGICPCuda's is empty (k stays 20,
+    fast_vgicp_cuda_impl.hpp:38). Round 2 aliased "VGICP" to the CUDA class and ran k = 20 whatever the caller asked: here the
+    result must equal the ORACLE's FastVGICP with the same k (1e-4, north_star), and differ from the k = 20 result."""
+    from oracle import oracle as O
+    tgt, src = util.bundled_pair()
+    T = pygicp.align_points(tgt.astype(np.float64), src.astype(np.float64), method="VGICP", k_correspondences=k, voxel_resolution=1.0, neighbor_search_method="DIRECT7")
+    g = O.FastVGICP(k=k, search=O.DIRECT7)
+    g.set_target(tgt); g.set_source(src)
+    ro = g.align()
+    assert ro["converged"]
+    assert util.rel_err(T, ro["T"].astype(np.float32)) < 1e-4, (k, util.rel_err(T, ro["T"]))
+    T20 = pygicp.align_points(tgt.astype(np.float64), src.astype(np.float64), method="VGICP_CUDA", k_correspondences=k, voxel_resolution=1.0, neighbor_search_method="DIRECT7")
+    g20 = O.FastVGICP(k=20, search=O.DIRECT7)
+    g20.set_target(tgt); g20.set_source(src)
+    assert util.rel_err(T20, g20.align()["T"].astype(np.float32)) < 1e-4  # the CUDA class: k = 20 whatever was asked, as in the reference
+    assert not np.array_equal(T, T20)
+    # the class itself (main.cpp:192-196 + the FastGICP methods it inherits there)
+    reg = pygicp.FastVGICP()
+    reg.set_num_threads(4); reg.set_correspondence_randomness(k); reg.set_max_correspondence_distance(1.0)
+    reg.set_resolution(1.0); reg.set_neighbor_search_method("DIRECT7")
+    reg.set_input_target(tgt.astype(np.float64)); reg.set_input_source(src.astype(np.float64))
+    assert np.array_equal(reg.align(), T) and reg.has_converged()
+    assert isinstance(reg, pygicp.FastVGICPCuda) and isinstance(reg, pygicp.LsqRegistration)
