@@ -33,5 +33,26 @@ def build_lib(force=False, verbose=False):
     return LIB_PATH
 
 
+TEST_LIB_PATH = os.path.join(LIB_DIR, "variants", "test_kernels", "libfast_vgicp_hip.so")
+
+
+def build_test_kernels_lib(force=False, verbose=False):
+    """The same library with -DFVH_TEST_KERNELS: the superseded full-sweep / eight-queries-per-wave kernels and the FVH_*_MODE
+    switches that select them -- cross-checks of the culled kernels, used by tests/test_gpu_edge_and_properties.py only
+    (FVH_LIB_PATH points a test subprocess at it). The product library does not contain them."""
+    if not force and os.path.exists(TEST_LIB_PATH):
+        t = os.path.getmtime(TEST_LIB_PATH)
+        if not any(os.path.exists(s) and os.path.getmtime(s) > t for s in SOURCES + [HEADER]):
+            return TEST_LIB_PATH
+    os.makedirs(os.path.dirname(TEST_LIB_PATH), exist_ok=True)
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    cmd = [hipcc] + HIPCC_FLAGS + ["-DFVH_TEST_KERNELS", "-o", TEST_LIB_PATH, SOURCES[0], "-ldl"]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return TEST_LIB_PATH
+
+
 if __name__ == "__main__":
     print(build_lib(force=True, verbose=True))
+    print(build_test_kernels_lib(force=True, verbose=True))

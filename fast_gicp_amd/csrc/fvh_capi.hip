@@ -573,12 +573,15 @@ int find_neighbors(Engine* e, CloudDev& c, int k) {
   if (k <= 0 || k > 64) return e->fail(FVH_ERR_INVALID_ARGUMENT, "find_neighbors: k must be in [1, 64]");
   if (c.n < k) return e->fail(FVH_ERR_INVALID_ARGUMENT, "find_neighbors: fewer points than k");
   HIP_OR_FAIL(e, c.nbr.ensure(sizeof(int) * (size_t)c.n * k));
-  static const int knn_mode = [] { const char* v = getenv("FVH_KNN_MODE"); return v ? atoi(v) : 1; }();  // 0: full LDS-tiled sweep, 1: Morton order + tile culling
-  const int waves = (c.n + KNN_Q - 1) / KNN_Q;
+#ifdef FVH_TEST_KERNELS  // test build only: FVH_KNN_MODE=0 selects the superseded full LDS-tiled sweep as a cross-check of the culled search
+  static const int knn_mode = [] { const char* v = getenv("FVH_KNN_MODE"); return v ? atoi(v) : 1; }();
   if (knn_mode == 0 && !e->peer.attached()) {
+    const int waves = (c.n + KNN_Q - 1) / KNN_Q;
     ProfScope ps(e, "knn");
     knn_bruteforce_kernel<<<(waves + 3) / 4, 256, 0, e->stream>>>(c.pts.as<float4>(), c.n, k, c.nbr.as<int>());
-  } else {
+  } else
+#endif
+  {
     int rc = ensure_sorted(e, c);
     if (rc) return rc;
     const Tile t = peer_tile(e, c.n);  // multi-GPU: the queries of this rank's tile only (the whole sorted cloud is the candidate set: an exact, implicit halo)
@@ -624,19 +627,25 @@ int calc_cov_rbf(Engine* e, CloudDev& c, double kernel_width, double max_dist, i
   HIP_OR_FAIL(e, c.cov.ensure(sizeof(float4) * 2 * (size_t)std::max(c.n, 1)));
   const bool sharded = e->peer.attached();
   if (c.n) {
-    static const int rbf_mode = [] { const char* v = getenv("FVH_RBF_MODE"); return v ? atoi(v) : 1; }();  // 0: full sweep, 1: Morton order + tile culling
-    const int waves = (c.n + RBF_Q - 1) / RBF_Q;
     const float md = (float)max_dist;
+#ifdef FVH_TEST_KERNELS  // test build only: FVH_RBF_MODE=0 full sweep, 2: eight queries per wave (both superseded by the one-query-per-wave sweep)
+    static const int rbf_mode = [] { const char* v = getenv("FVH_RBF_MODE"); return v ? atoi(v) : 1; }();
+    const int waves = (c.n + RBF_Q - 1) / RBF_Q;
     if (rbf_mode == 0 && !sharded) {
       ProfScope ps(e, "rbf");
       cov_rbf_kernel<<<(waves + 3) / 4, 256, 0, e->stream>>>(c.pts.as<float4>(), c.n, (float)kernel_width, md * md, method, c.cov.as<float4>());
-    } else {
+    } else
+#endif
+    {
       int rc = ensure_sorted(e, c);
       if (rc) return rc;
       const Tile t = peer_tile(e, c.n);
       ProfScope ps(e, "rbf");
+#ifdef FVH_TEST_KERNELS
       if (rbf_mode == 2 && !sharded) cov_rbf_tiled_kernel<<<(waves + 3) / 4, 256, 0, e->stream>>>(c.sorted.as<float4>(), c.bbox.as<float4>(), c.n, (float)kernel_width, md * md, method, c.cov.as<float4>());
-      else if (t.hi > t.lo) {
+      else
+#endif
+      if (t.hi > t.lo) {
         // sweep (one query per wave) -> ten totals per query; regularisation with one thread per query
         HIP_OR_FAIL(e, e->rbf_sums.ensure(sizeof(double) * 10 * (size_t)c.n));
         cov_rbf1_kernel<<<(t.hi - t.lo + 3) / 4, 256, 0, e->stream>>>(c.sorted.as<float4>(), c.bbox.as<float4>(), c.bbox2.as<float4>(), c.n, (float)kernel_width, md * md, method, c.cov.as<float4>(), t.lo, t.hi,
@@ -1136,7 +1145,11 @@ int do_fitness(Engine* e, CloudDev& src, CloudDev& tgt, const double* T16, doubl
   char* base = (char*)e->fit.p;
   HIP_OR_FAIL(e, hipMemsetAsync(base, 0, 16, e->stream));
   HIP_OR_FAIL(e, hipMemcpyAsync(base + 16, T12, sizeof(T12), hipMemcpyHostToDevice, e->stream));
+#ifdef FVH_TEST_KERNELS  // test build only: FVH_FIT_MODE=0 full sweep, 2: eight queries per wave
   static const int fit_mode = [] { const char* v = getenv("FVH_FIT_MODE"); return v ? atoi(v) : 1; }();
+#else
+  constexpr int fit_mode = 1;
+#endif
   if (fit_mode != 0) {
     int rc = ensure_sorted(e, src);
     if (!rc) rc = ensure_sorted(e, tgt);
@@ -1144,13 +1157,16 @@ int do_fitness(Engine* e, CloudDev& src, CloudDev& tgt, const double* T16, doubl
   }
   {
     ProfScope ps(e, "fitness");
+#ifdef FVH_TEST_KERNELS
     const int waves = (src.n + FIT_Q - 1) / FIT_Q;
     if (fit_mode == 0) {
       fitness_kernel<<<(waves + 3) / 4, 256, 0, e->stream>>>(src.pts.as<float4>(), src.n, tgt.pts.as<float4>(), tgt.n, (const float*)(base + 16), max_range, (double*)base);
     } else if (fit_mode == 2) {
       fitness_tiled_kernel<<<(waves + 3) / 4, 256, 0, e->stream>>>(src.sorted.as<float4>(), src.n, tgt.sorted.as<float4>(), tgt.bbox.as<float4>(), tgt.n, (const float*)(base + 16), max_range,
                                                                     (double*)base);
-    } else {  // one query per wave (the k = 1 search of the GICP path), then a fixed-order reduction
+    } else
+#endif
+    {  // one query per wave (the k = 1 search of the GICP path), then a fixed-order reduction
       HIP_OR_FAIL(e, e->fit_best.ensure(sizeof(float) * (size_t)src.n));
       nn1_corr_kernel<<<(src.n + 3) / 4, 256, 0, e->stream>>>(src.sorted.as<float4>(), src.n, tgt.sorted.as<float4>(), tgt.bbox.as<float4>(), tgt.bbox2.as<float4>(), tgt.n,
                                                               (const float*)(base + 16), 0.0, nullptr, e->fit_best.as<float>());
@@ -1292,14 +1308,17 @@ int gicp_update_correspondences(Engine* e, CloudDev& src, CloudDev& tgt, VoxelMa
   const double thr = std::min(max_dist, 1.8446743e19);  // threshold^2 must stay finite in fp64 (reference default: float max)
   {
     ProfScope ps(e, "gicp_nn");
-    static const int nn_mode = [] { const char* v = getenv("FVH_GICP_NN_MODE"); return v ? atoi(v) : 1; }();  // 1: one query per wave, 0: 8 queries per wave
-    if (nn_mode == 1) {
-      nn1_corr_kernel<<<(src.n + 3) / 4, 256, 0, e->stream>>>(src.sorted.as<float4>(), src.n, tgt.sorted.as<float4>(), tgt.bbox.as<float4>(), tgt.bbox2.as<float4>(), tgt.n,
-                                                              reinterpret_cast<const float*>(base + 16), thr * thr, e->corr.as<int>());
-    } else {
+#ifdef FVH_TEST_KERNELS  // test build only: FVH_GICP_NN_MODE=0 selects the superseded eight-queries-per-wave search
+    static const int nn_mode = [] { const char* v = getenv("FVH_GICP_NN_MODE"); return v ? atoi(v) : 1; }();
+    if (nn_mode != 1) {
       const int waves = (src.n + FIT_Q - 1) / FIT_Q;
       nn_corr_tiled_kernel<<<(waves + 3) / 4, 256, 0, e->stream>>>(src.sorted.as<float4>(), src.n, tgt.sorted.as<float4>(), tgt.bbox.as<float4>(), tgt.n, reinterpret_cast<const float*>(base + 16), thr * thr,
                                                                    e->corr.as<int>());
+    } else
+#endif
+    {
+      nn1_corr_kernel<<<(src.n + 3) / 4, 256, 0, e->stream>>>(src.sorted.as<float4>(), src.n, tgt.sorted.as<float4>(), tgt.bbox.as<float4>(), tgt.bbox2.as<float4>(), tgt.n,
+                                                              reinterpret_cast<const float*>(base + 16), thr * thr, e->corr.as<int>());
     }
   }
   HIP_OR_FAIL(e, hipGetLastError());

@@ -107,6 +107,7 @@ __device__ __forceinline__ void sweep_candidates(const float4* __restrict__ pts,
 // out_idx: [n][k] neighbour indices, ascending (distance, index); k <= 64.
 // The running top-k list is ordered by the total order (distance, index), so the result does not
 // depend on the visiting order of the tiles.
+#ifdef FVH_TEST_KERNELS  // superseded kernel kept as a cross-check of the culled one: only in the test build (fast_gicp_amd/build.py: build_test_kernels_lib)
 __global__ __launch_bounds__(256) void knn_bruteforce_kernel(const float4* __restrict__ pts, int n, int k, int* __restrict__ out_idx) {
   __shared__ float4 tile[2][SWEEP_TILE];
   const int lane = threadIdx.x & 63;
@@ -148,6 +149,7 @@ __global__ __launch_bounds__(256) void knn_bruteforce_kernel(const float4* __res
   for (int j = 0; j < KNN_Q; j++)
     if (q_base + j < n && lane < k) out_idx[(size_t)(q_base + j) * k + lane] = li[j];
 }
+#endif
 
 // ------------------------------------------------------------------------------------------------
 // Tile-culled exact k-NN. Points are taken in the order given (LiDAR clouds are scan-ordered, so 64
@@ -548,6 +550,7 @@ constexpr int RBF_Q = 8;
 // (covariance_estimation_rbf.cu:67-85), weighted mean/cov (:40-52), evaluated centred on the query
 // (identical maths, fp32-safe), wave-reduced in fp64, regularised. The reference's unmasked
 // zero-padding of the last 512-block (:127-129) is NOT replicated.
+#ifdef FVH_TEST_KERNELS  // superseded kernel kept as a cross-check of the culled one: only in the test build (fast_gicp_amd/build.py: build_test_kernels_lib)
 __global__ __launch_bounds__(256) void cov_rbf_kernel(const float4* __restrict__ pts, int n, float kernel_width, float max_dist_sq, int method,
                                                       float4* __restrict__ cov) {
   __shared__ float4 tile[2][SWEEP_TILE];
@@ -590,12 +593,14 @@ __global__ __launch_bounds__(256) void cov_rbf_kernel(const float4* __restrict__
     }
   }
 }
+#endif
 
 constexpr int FIT_Q = 8;
 
 // pcl::Registration::getFitnessScore restated for the device: transform the source by the FLOAT
 // pose (final_transformation_ is float), exact 1-NN by tiled brute force, sum d^2 <= max_range.
 // out[0] += sum, out[1] += count (fp64 atomics).
+#ifdef FVH_TEST_KERNELS  // superseded kernel kept as a cross-check of the culled one: only in the test build (fast_gicp_amd/build.py: build_test_kernels_lib)
 __global__ __launch_bounds__(256) void fitness_kernel(const float4* __restrict__ src, int ns, const float4* __restrict__ tgt, int nt, const float* __restrict__ T12 /* row-major 3x4 */,
                                                       double max_range, double* __restrict__ out) {
   __shared__ float4 tile[2][SWEEP_TILE];
@@ -630,9 +635,11 @@ __global__ __launch_bounds__(256) void fitness_kernel(const float4* __restrict__
     atomicAdd(&out[1], cnt);
   }
 }
+#endif
 
 // RBF covariances on the Morton-sorted cloud: only tiles whose box is within max_dist of the wave's
 // query box are swept (fixed-radius culling). cov is indexed by ORIGINAL point index.
+#ifdef FVH_TEST_KERNELS  // superseded kernel kept as a cross-check of the culled one: only in the test build (fast_gicp_amd/build.py: build_test_kernels_lib)
 __global__ __launch_bounds__(256) void cov_rbf_tiled_kernel(const float4* __restrict__ spts, const float4* __restrict__ bbox, int n, float kernel_width, float max_dist_sq,
                                                             int method, float4* __restrict__ cov) {
   const int lane = threadIdx.x & 63;
@@ -687,6 +694,7 @@ __global__ __launch_bounds__(256) void cov_rbf_tiled_kernel(const float4* __rest
     }
   }
 }
+#endif
 
 // Same sums, ONE query per wave with the two box levels of the k-NN kernel (the 8-queries-per-wave version tests every
 // tile box against the group's box and ends with 80 wave reductions: 420 us at 100k points against 190 us for k-NN +
@@ -777,6 +785,7 @@ __global__ __launch_bounds__(256) void cov_rbf1_kernel(const float4* __restrict_
 
 // getFitnessScore on the Morton-sorted clouds: the wave first sweeps the target tile whose box is
 // nearest to its (transformed) query box, then every tile that can still beat the current minima.
+#ifdef FVH_TEST_KERNELS  // superseded kernel kept as a cross-check of the culled one: only in the test build (fast_gicp_amd/build.py: build_test_kernels_lib)
 __global__ __launch_bounds__(256) void fitness_tiled_kernel(const float4* __restrict__ ssrc, int ns, const float4* __restrict__ stgt, const float4* __restrict__ tbox, int nt,
                                                             const float* __restrict__ T12, double max_range, double* __restrict__ out) {
   const int lane = threadIdx.x & 63;
@@ -848,6 +857,7 @@ __global__ __launch_bounds__(256) void fitness_tiled_kernel(const float4* __rest
     atomicAdd(&out[1], cnt);
   }
 }
+#endif
 
 // ------------------------------------------------------------------------------------------------
 // FastGICP correspondences (fast_gicp_impl.hpp:118-156): for every source point the exact nearest
@@ -856,6 +866,7 @@ __global__ __launch_bounds__(256) void fitness_tiled_kernel(const float4* __rest
 // winner's ORIGINAL index; equal distances -> lower index (the oracle's kd-tree order). corr[original source index] =
 // original target index or -1.
 // ------------------------------------------------------------------------------------------------
+#ifdef FVH_TEST_KERNELS  // superseded kernel kept as a cross-check of the culled one: only in the test build (fast_gicp_amd/build.py: build_test_kernels_lib)
 __global__ __launch_bounds__(256) void nn_corr_tiled_kernel(const float4* __restrict__ ssrc, int ns, const float4* __restrict__ stgt, const float4* __restrict__ tbox, int nt,
                                                             const float* __restrict__ T12, double thr_sq, int* __restrict__ corr) {
   const int lane = threadIdx.x & 63;
@@ -931,6 +942,7 @@ __global__ __launch_bounds__(256) void nn_corr_tiled_kernel(const float4* __rest
       if (q_base + j < ns) corr[qid[j]] = ((double)best[j] < thr_sq) ? besti[j] : -1;
   }
 }
+#endif
 
 // Same search, ONE query per wave (like knn_tiled1_kernel: the regime is a latency chain per query, so 17k short waves
 // beat 2k long ones -- the 8-queries-per-wave sweep above took 430 us per search at 17k x 17k, 4 per GICP registration).

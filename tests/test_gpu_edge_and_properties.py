@@ -208,7 +208,8 @@ def test_registration_recovers_ground_truth_1m_map(big):
 
 
 def test_full_sweep_modes_agree_with_culled_modes():
-    """The un-culled LDS-tiled sweeps (FVH_KNN_MODE/FVH_RBF_MODE/FVH_FIT_MODE=0) ship as selectable modes: same results."""
+    """The un-culled LDS-tiled sweeps (FVH_KNN_MODE/FVH_RBF_MODE/FVH_FIT_MODE=0) of the TEST build of the library
+    (-DFVH_TEST_KERNELS, fast_gicp_amd/build.py: the product library no longer carries them) give the culled kernels' results."""
     import os
     import subprocess
     import sys
@@ -229,7 +230,11 @@ np.savez(sys.argv[1], nb=nb, cov=cov, f=f)
 ''' % util.ROOT
     out = []
     for mode in ("1", "0"):
+        from fast_gicp_amd import build as B
+        assert os.path.exists(B.TEST_LIB_PATH), "run __graft_entry__.build() (it builds the -DFVH_TEST_KERNELS library too)"
         env = dict(os.environ, FVH_KNN_MODE=mode, FVH_RBF_MODE=mode, FVH_FIT_MODE=mode)
+        if mode == "0":
+            env["FVH_LIB_PATH"] = B.TEST_LIB_PATH  # mode 1 = the product library
         path = os.path.join(util.ROOT, "gpurun_out", "modes_%s.npz" % mode)
         os.makedirs(os.path.dirname(path), exist_ok=True)
         subprocess.check_call([sys.executable, "-c", code, path], env=env)
