@@ -1,0 +1,550 @@
+// ORACLE (test infrastructure, NOT product code).  Only tests/, __graft_entry__.smoke() and bench.py's
+// cpu_baseline leg may use anything under oracle/.
+//
+// "cuda-compat" leg: an fp32 CPU restatement of the reference's DEVICE path end to end -- FastVGICPCuda
+// (gicp/impl/fast_vgicp_cuda_impl.hpp + cuda/fast_vgicp_cuda.cu) and NDTCuda (ndt/impl/ndt_cuda_impl.hpp +
+// cuda/ndt_cuda.cu) -- next to the fp64 restatement of the CPU class in vgicp_oracle.cpp. Where the two reference paths
+// differ, this file follows the .cu files:
+//   * k-NN covariances UNCENTRED in float: mean = sum p / k, C = sum p p^T / k - mean mean^T     covariance_estimation.cu:26-34
+//   * PLANE / MIN_EIG through SelfAdjointEigenSolver<Matrix3f>::computeDirect (closed form, eigenvalues ascending) and
+//     C <- V diag(.) V^-1 with the 3x3 cofactor inverse                                           covariance_regularization.cu:15-52,84-101
+//   * FROBENIUS in float                                                                          covariance_regularization.cu:74-82
+//   * RBF covariances in float, accumulated per block of 512 points, blocks added in order         covariance_estimation_rbf.cu:40-109
+//     (WITHOUT the reference's padding points at the origin, :130-133 -- a bug there)
+//   * voxel coordinates floor(x / res - 0.5) in FLOAT                                             vector3_hash.cuh:35-38
+//   * voxel sums in float (atomicAdd per component; here: point order), mean = sum / n, cov = sum C / n (VGICP) or
+//     (sum p p^T - mean (sum p)^T) / n (NDT), NDT voxels then MIN_EIG-regularised                  gaussian_voxelmap.cu:89-148,158-198; ndt_cuda.cu:128,139
+//   * correspondences: (R p + t) in float -> coordinate + offset -> lookup, offset-major list     find_voxel_correspondences.cu:32-111
+//   * cost terms in float: RCR = R_lin C_A R_lin^T, M = (C_B + RCR)^-1 (cofactors), w = sqrtf(n), H = w J^T M J, b = w J^T M e
+//                                                                                                 compute_derivatives.cu:50-135
+//     NDT: n <= 6 skipped, w = cauchy(resolution, |e|), P2D M = C_B^-1, D2D as above               ndt_compute_derivatives.cu:10-163
+//   * the float terms are REDUCED in float by thrust::transform_reduce, whose tree is unspecified: here a pairwise (binary
+//     tree) float sum over the correspondence list; H, b are widened to double afterwards          compute_derivatives.cu:167-183
+//   * the optimiser itself is the host's fp64 LsqRegistration (shared LsqBase of vgicp_oracle.cpp), poses are cast to float at
+//     the boundary (fast_vgicp_cuda.cu:256-258,270-275)
+// Third-party arithmetic restated from its published form: Eigen (unvendored submodule) SelfAdjointEigenSolver.h,
+// direct_selfadjoint_eigenvalues<SolverType, 3, false> (Eigen 3.3 / 3.4: shift by the mean, scale by the largest entry,
+// trigonometric roots, eigenvector of the most separated eigenvalue by the larger of two cross products); fixed-size
+// 3x3 inverse by cofactors. nvcc contracts a * b + c into FMAs at its discretion; this file is built with
+// -ffp-contract=off: last-bit differences against the real device code are expected, nothing larger.
+//
+// Pins (tests/test_oracle.py): SURVEY 8c(4)'s recorded fp32 twin -- bundled pair, HEAD preprocessing, resolution 1.0:
+// DIRECT1 fitness 0.204998 with correspondence counts 14,990 -> 16,124 -> 16,108 -> 16,104, DIRECT27 fitness 0.198996.
+#include <omp.h>
+
+#include <cmath>
+#include <cstring>
+#include <unordered_map>
+#include <vector>
+
+#include "vgicp_oracle.hpp"
+
+namespace orc {
+namespace cc {
+
+struct M3f { float m[9]; float& operator()(int r, int c) { return m[r * 3 + c]; } float operator()(int r, int c) const { return m[r * 3 + c]; } };
+struct V3f { float v[3]; float& operator[](int i) { return v[i]; } float operator[](int i) const { return v[i]; } };
+
+static inline M3f zero3() { M3f a; std::memset(a.m, 0, sizeof(a.m)); return a; }
+static inline M3f mul(const M3f& a, const M3f& b) {
+  M3f c;
+  for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) c(i, j) = a(i, 0) * b(0, j) + a(i, 1) * b(1, j) + a(i, 2) * b(2, j);
+  return c;
+}
+static inline M3f transpose(const M3f& a) { M3f c; for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) c(i, j) = a(j, i); return c; }
+// Eigen's fixed-size 3x3 inverse: cofactors / determinant (compute_inverse_size3_helper), float
+static inline M3f inverse(const M3f& a) {
+  M3f c;
+  c(0, 0) = a(1, 1) * a(2, 2) - a(1, 2) * a(2, 1);
+  c(0, 1) = a(0, 2) * a(2, 1) - a(0, 1) * a(2, 2);
+  c(0, 2) = a(0, 1) * a(1, 2) - a(0, 2) * a(1, 1);
+  c(1, 0) = a(1, 2) * a(2, 0) - a(1, 0) * a(2, 2);
+  c(1, 1) = a(0, 0) * a(2, 2) - a(0, 2) * a(2, 0);
+  c(1, 2) = a(0, 2) * a(1, 0) - a(0, 0) * a(1, 2);
+  c(2, 0) = a(1, 0) * a(2, 1) - a(1, 1) * a(2, 0);
+  c(2, 1) = a(0, 1) * a(2, 0) - a(0, 0) * a(2, 1);
+  c(2, 2) = a(0, 0) * a(1, 1) - a(0, 1) * a(1, 0);
+  const float det = a(0, 0) * c(0, 0) + a(0, 1) * c(1, 0) + a(0, 2) * c(2, 0);
+  const float inv = 1.0f / det;
+  for (int i = 0; i < 9; i++) c.m[i] *= inv;
+  return c;
+}
+static inline V3f cross(const V3f& a, const V3f& b) { return V3f{{a[1] * b[2] - a[2] * b[1], a[2] * b[0] - a[0] * b[2], a[0] * b[1] - a[1] * b[0]}}; }
+static inline float dot(const V3f& a, const V3f& b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
+static inline V3f col(const M3f& a, int j) { return V3f{{a(0, j), a(1, j), a(2, j)}}; }
+static inline void set_col(M3f& a, int j, const V3f& v) { a(0, j) = v[0]; a(1, j) = v[1]; a(2, j) = v[2]; }
+
+// Eigen::SelfAdjointEigenSolver<Matrix3f>::computeDirect (SelfAdjointEigenSolver.h, direct_selfadjoint_eigenvalues<..., 3, false>).
+// vals ascending, eigenvectors in the COLUMNS of vecs. Reads the lower triangle like Eigen.
+static void extract_kernel(M3f& mat, V3f& res, V3f& representative) {
+  int i0 = 0;  // the largest |diagonal| entry
+  for (int i = 1; i < 3; i++) if (std::fabs(mat(i, i)) > std::fabs(mat(i0, i0))) i0 = i;
+  representative = col(mat, i0);
+  const V3f c0 = cross(representative, col(mat, (i0 + 1) % 3)), c1 = cross(representative, col(mat, (i0 + 2) % 3));
+  const float n0 = dot(c0, c0), n1 = dot(c1, c1);
+  if (n0 > n1) { const float s = std::sqrt(n0); res = V3f{{c0[0] / s, c0[1] / s, c0[2] / s}}; }
+  else { const float s = std::sqrt(n1); res = V3f{{c1[0] / s, c1[1] / s, c1[2] / s}}; }
+}
+static void eig3_direct(const M3f& A, float vals[3], M3f& vecs) {
+  const float shift = (A(0, 0) + A(1, 1) + A(2, 2)) / 3.0f;
+  M3f S;  // selfadjointView<Lower>
+  for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) S(i, j) = i >= j ? A(i, j) : A(j, i);
+  for (int i = 0; i < 3; i++) S(i, i) -= shift;
+  float scale = 0.0f;
+  for (int i = 0; i < 9; i++) scale = std::max(scale, std::fabs(S.m[i]));
+  if (scale > 0.0f) for (int i = 0; i < 9; i++) S.m[i] /= scale;
+  {  // computeRoots: x^3 - c2 x^2 + c1 x - c0 = 0
+    const float s_inv3 = 1.0f / 3.0f, s_sqrt3 = std::sqrt(3.0f);
+    const float c0 = S(0, 0) * S(1, 1) * S(2, 2) + 2.0f * S(1, 0) * S(2, 0) * S(2, 1) - S(0, 0) * S(2, 1) * S(2, 1) - S(1, 1) * S(2, 0) * S(2, 0) - S(2, 2) * S(1, 0) * S(1, 0);
+    const float c1 = S(0, 0) * S(1, 1) - S(1, 0) * S(1, 0) + S(0, 0) * S(2, 2) - S(2, 0) * S(2, 0) + S(1, 1) * S(2, 2) - S(2, 1) * S(2, 1);
+    const float c2 = S(0, 0) + S(1, 1) + S(2, 2);
+    const float c2_over_3 = c2 * s_inv3;
+    float a_over_3 = (c2 * c2_over_3 - c1) * s_inv3;
+    a_over_3 = std::max(a_over_3, 0.0f);
+    const float half_b = 0.5f * (c0 + c2_over_3 * (2.0f * c2_over_3 * c2_over_3 - c1));
+    float q = a_over_3 * a_over_3 * a_over_3 - half_b * half_b;
+    q = std::max(q, 0.0f);
+    const float rho = std::sqrt(a_over_3);
+    const float theta = std::atan2(std::sqrt(q), half_b) * s_inv3;
+    const float cos_theta = std::cos(theta), sin_theta = std::sin(theta);
+    vals[0] = c2_over_3 - rho * (cos_theta + s_sqrt3 * sin_theta);
+    vals[1] = c2_over_3 - rho * (cos_theta - s_sqrt3 * sin_theta);
+    vals[2] = c2_over_3 + 2.0f * rho * cos_theta;
+  }
+  const float eps = 1.1920929e-07f;  // NumTraits<float>::epsilon()
+  if ((vals[2] - vals[0]) <= eps) {
+    vecs = zero3(); vecs(0, 0) = vecs(1, 1) = vecs(2, 2) = 1.0f;
+  } else {
+    M3f tmp = S;
+    float d0 = vals[2] - vals[1];
+    const float d1 = vals[1] - vals[0];
+    int k = 0, l = 2;
+    if (d0 > d1) { std::swap(k, l); d0 = d1; }
+    V3f vk, vl;
+    for (int i = 0; i < 3; i++) tmp(i, i) -= vals[k];
+    extract_kernel(tmp, vk, vl);  // vl = the saved representative column (nearly orthogonal to vk)
+    if (d0 <= 2.0f * eps * d1) {
+      const float p = dot(vk, vl);
+      for (int i = 0; i < 3; i++) vl[i] -= p * vl[i];  // (as written in Eigen: col(l) -= col(k).dot(col(l)) * col(l))
+      const float n = std::sqrt(dot(vl, vl));
+      for (int i = 0; i < 3; i++) vl[i] /= n;
+    } else {
+      tmp = S;
+      for (int i = 0; i < 3; i++) tmp(i, i) -= vals[l];
+      V3f dummy;
+      extract_kernel(tmp, vl, dummy);
+    }
+    set_col(vecs, k, vk);
+    set_col(vecs, l, vl);
+    V3f v1 = cross(col(vecs, 2), col(vecs, 0));
+    const float n = std::sqrt(dot(v1, v1));
+    for (int i = 0; i < 3; i++) v1[i] /= n;
+    set_col(vecs, 1, v1);
+  }
+  for (int i = 0; i < 3; i++) vals[i] = vals[i] * scale + shift;
+}
+
+// covariance_regularization.cu:15-125
+static M3f regularize(const M3f& cov, RegularizationMethod m) {
+  if (m == FROBENIUS) {  // :74-82
+    M3f C = cov;
+    for (int i = 0; i < 3; i++) C(i, i) += 1e-3f;
+    M3f Ci = inverse(C);
+    float nrm = 0.0f;
+    for (int i = 0; i < 9; i++) nrm += Ci.m[i] * Ci.m[i];
+    nrm = std::sqrt(nrm);
+    for (int i = 0; i < 9; i++) Ci.m[i] /= nrm;
+    return inverse(Ci);
+  }
+  if (m != PLANE && m != MIN_EIG) return cov;  // (:122-124 prints "unimplemented" and leaves the matrix alone)
+  float vals[3];
+  M3f V;
+  eig3_direct(cov, vals, V);
+  M3f D = zero3();
+  if (m == PLANE) { D(0, 0) = 1e-3f; D(1, 1) = 1.0f; D(2, 2) = 1.0f; }                        // :34-52,112
+  else for (int i = 0; i < 3; i++) D(i, i) = std::fmax(1e-3f, vals[i]);                       // :84-101
+  return mul(mul(V, D), inverse(V));
+}
+
+// covariance_estimation.cu:20-35
+static void covariances_knn(const Cloud& c, int k, const std::vector<int>& idx, std::vector<M3f>& covs, int threads) {
+  const int n = (int)c.size();
+  covs.resize(n);
+#pragma omp parallel for num_threads(threads) schedule(guided, 8)
+  for (int i = 0; i < n; i++) {
+    float mean[3] = {0, 0, 0};
+    M3f C = zero3();
+    for (int j = 0; j < k; j++) {
+      const float* p = c.pt(idx[(size_t)i * k + j]);
+      for (int a = 0; a < 3; a++) mean[a] += p[a];
+      for (int a = 0; a < 3; a++) for (int b = 0; b < 3; b++) C(a, b) += p[a] * p[b];
+    }
+    for (int a = 0; a < 3; a++) mean[a] /= (float)k;
+    for (int a = 0; a < 3; a++) for (int b = 0; b < 3; b++) C(a, b) = C(a, b) / (float)k - mean[a] * mean[b];
+    covs[i] = C;
+  }
+}
+
+// covariance_estimation_rbf.cu:40-109,120-150 (blocks of 512 candidate points, block partials added in block order; no padding points)
+static void covariances_rbf(const Cloud& c, float exp_factor, float max_dist, std::vector<M3f>& covs, int threads) {
+  const int n = (int)c.size(), BLOCK = 512;
+  const float max_dist_sq = max_dist * max_dist;
+  covs.resize(n);
+#pragma omp parallel for num_threads(threads) schedule(guided, 8)
+  for (int i = 0; i < n; i++) {
+    const float* x = c.pt(i);
+    float sw = 0.0f, sm[3] = {0, 0, 0};
+    M3f sc = zero3();
+    for (int b0 = 0; b0 < n; b0 += BLOCK) {
+      float w_ = 0.0f, m_[3] = {0, 0, 0};
+      M3f c_ = zero3();
+      for (int j = b0; j < std::min(n, b0 + BLOCK); j++) {
+        const float* p = c.pt(j);
+        const float dx = x[0] - p[0], dy = x[1] - p[1], dz = x[2] - p[2];
+        const float sq = dx * dx + dy * dy + dz * dz;
+        if (sq > max_dist_sq) continue;
+        const float w = std::exp(-exp_factor * sq);  // expf
+        w_ += w;
+        for (int a = 0; a < 3; a++) m_[a] += w * p[a];
+        for (int a = 0; a < 3; a++) for (int bb = 0; bb < 3; bb++) c_(a, bb) += (w * p[a]) * p[bb];  // w * x * x^T, left to right
+      }
+      if (b0 == 0) { sw = w_; for (int a = 0; a < 3; a++) sm[a] = m_[a]; sc = c_; }
+      else { sw += w_; for (int a = 0; a < 3; a++) sm[a] += m_[a]; for (int q = 0; q < 9; q++) sc.m[q] += c_.m[q]; }
+    }
+    float mean[3];
+    for (int a = 0; a < 3; a++) mean[a] = sm[a] / sw;                                           // finalize(): :47-52
+    for (int a = 0; a < 3; a++) for (int b = 0; b < 3; b++) sc(a, b) = (sc(a, b) - mean[a] * sm[b]) / sw;
+    covs[i] = sc;
+  }
+}
+
+// GaussianVoxelMap (gaussian_voxelmap.cu). The bucket table (hash, linear scan, retry loop :208-257) only decides WHERE a voxel is
+// stored; the set of voxels and their sums do not depend on it: a coordinate -> slot map in first-touch order stands in.
+struct VoxelMapF {
+  float resolution;
+  std::unordered_map<VoxelKey, int, VoxelKeyHash> index;
+  std::vector<VoxelKey> coords;
+  std::vector<int> num_points;
+  std::vector<V3f> means;
+  std::vector<M3f> covs;
+  explicit VoxelMapF(float res) : resolution(res) {}
+  VoxelKey coord(const float x[3]) const {  // vector3_hash.cuh:35-38: (x.array() / resolution - 0.5).floor().cast<int>() in float
+    return VoxelKey{(int)std::floor(x[0] / resolution - 0.5f), (int)std::floor(x[1] / resolution - 0.5f), (int)std::floor(x[2] / resolution - 0.5f)};
+  }
+  int slot(const VoxelKey& k) {
+    auto it = index.find(k);
+    if (it != index.end()) return it->second;
+    const int s = (int)coords.size();
+    index[k] = s; coords.push_back(k); num_points.push_back(0); means.push_back(V3f{{0, 0, 0}}); covs.push_back(zero3());
+    return s;
+  }
+  int lookup(const VoxelKey& k) const { auto it = index.find(k); return it == index.end() ? -1 : it->second; }
+  void create_vgicp(const Cloud& c, const std::vector<M3f>& pc) {  // accumulate_points_kernel :89-120 + finalize_voxels_kernel :158-171
+    for (size_t i = 0; i < c.size(); i++) {
+      const int s = slot(coord(c.pt(i)));
+      num_points[s]++;
+      for (int a = 0; a < 3; a++) means[s][a] += c.pt(i)[a];
+      for (int q = 0; q < 9; q++) covs[s].m[q] += pc[i].m[q];
+    }
+    for (size_t s = 0; s < coords.size(); s++) {
+      for (int a = 0; a < 3; a++) means[s][a] /= (float)num_points[s];
+      for (int q = 0; q < 9; q++) covs[s].m[q] /= (float)num_points[s];
+    }
+  }
+  void create_ndt(const Cloud& c) {  // :122-148 + ndt_finalize_voxels_kernel :178-198 + ndt_cuda.cu:128,139 (MIN_EIG)
+    for (size_t i = 0; i < c.size(); i++) {
+      const float* p = c.pt(i);
+      const int s = slot(coord(p));
+      num_points[s]++;
+      for (int a = 0; a < 3; a++) means[s][a] += p[a];
+      for (int a = 0; a < 3; a++) for (int b = 0; b < 3; b++) covs[s](a, b) += p[a] * p[b];
+    }
+    for (size_t s = 0; s < coords.size(); s++) {
+      const V3f sum = means[s];
+      const float n = (float)num_points[s];
+      for (int a = 0; a < 3; a++) means[s][a] /= n;
+      for (int a = 0; a < 3; a++) for (int b = 0; b < 3; b++) covs[s](a, b) = (covs[s](a, b) - means[s][a] * sum[b]) / n;
+      covs[s] = regularize(covs[s], MIN_EIG);
+    }
+  }
+};
+
+struct Term { float e; float H[36]; float b[6]; };
+// thrust::transform_reduce over float tuples: a tree of unspecified shape on the device; pairwise (binary tree) float sums here
+static Term reduce_terms(std::vector<Term>& t) {
+  if (t.empty()) { Term z; std::memset(&z, 0, sizeof(z)); return z; }
+  for (size_t stride = 1; stride < t.size(); stride *= 2) {
+#pragma omp parallel for schedule(static)
+    for (long long i = 0; i < (long long)t.size(); i += 2 * (long long)stride) {
+      if ((size_t)i + stride >= t.size()) continue;
+      Term& a = t[(size_t)i];
+      const Term& b = t[(size_t)i + stride];
+      a.e += b.e;
+      for (int q = 0; q < 36; q++) a.H[q] += b.H[q];
+      for (int q = 0; q < 6; q++) a.b[q] += b.b[q];
+    }
+  }
+  return t[0];
+}
+
+// one correspondence: compute_derivatives.cu:50-103 / ndt_compute_derivatives.cu:57-90,128-162. mode: 0 VGICP, 1 NDT P2D, 2 NDT D2D
+static inline void cost_term(int mode, const float a[3], const M3f* CA, int num_points, const V3f& mu, const M3f& CB, const float Re[9], const float R[9], const float t[3],
+                             float resolution, bool deriv, Term& out) {
+  std::memset(&out, 0, sizeof(out));
+  if (mode == 0 ? num_points <= 0 : num_points <= 6) return;
+  float q[3];
+  for (int i = 0; i < 3; i++) q[i] = (R[i * 3] * a[0] + R[i * 3 + 1] * a[1] + R[i * 3 + 2] * a[2]) + t[i];
+  M3f M;
+  if (mode == 1) {
+    M = inverse(CB);
+  } else {
+    M3f Rm, RC, A;
+    std::memcpy(Rm.m, Re, sizeof(Rm.m));
+    RC = mul(mul(Rm, *CA), transpose(Rm));
+    for (int i = 0; i < 9; i++) A.m[i] = CB.m[i] + RC.m[i];
+    M = inverse(A);
+  }
+  const float e[3] = {mu[0] - q[0], mu[1] - q[1], mu[2] - q[2]};
+  float w;
+  if (mode == 0) w = std::sqrt((float)num_points);
+  else { const float k_sq = resolution * resolution, x = std::sqrt(e[0] * e[0] + e[1] * e[1] + e[2] * e[2]); w = k_sq / (k_sq + x * x); }  // cauchy(k, |e|) :15-18
+  float weM[3];
+  for (int k = 0; k < 3; k++) weM[k] = (w * e[0]) * M.m[k] + (w * e[1]) * M.m[3 + k] + (w * e[2]) * M.m[6 + k];
+  out.e = weM[0] * e[0] + weM[1] * e[1] + weM[2] * e[2];  // w * e^T * M * e, left to right
+  if (!deriv) return;
+  const float J[3][6] = {{0, -q[2], q[1], -1, 0, 0}, {q[2], 0, -q[0], 0, -1, 0}, {-q[1], q[0], 0, 0, 0, -1}};
+  float wJtM[6][3];  // (w J^T) M
+  for (int r = 0; r < 6; r++) for (int k = 0; k < 3; k++) wJtM[r][k] = (w * J[0][r]) * M.m[k] + (w * J[1][r]) * M.m[3 + k] + (w * J[2][r]) * M.m[6 + k];
+  for (int r = 0; r < 6; r++) {
+    for (int c = 0; c < 6; c++) out.H[r * 6 + c] = wJtM[r][0] * J[0][c] + wJtM[r][1] * J[1][c] + wJtM[r][2] * J[2][c];
+    out.b[r] = wJtM[r][0] * e[0] + wJtM[r][1] * e[1] + wJtM[r][2] * e[2];
+  }
+}
+
+struct CompatBase : LsqBase {
+  int num_threads = omp_get_max_threads();
+  NeighborSearchMethod search_method = DIRECT1;
+  double search_radius = 0.0;
+  float resolution = 1.0f;
+  CloudPtr input, target;
+  std::shared_ptr<KdTree> pcl_tree;
+  bool target_cloud_updated = false;
+  std::vector<std::pair<int, int>> correspondences;  // (source element, target voxel), offset-major
+  std::vector<int> corr_history;                      // size of the list after every update_correspondences() of the last align()
+  float lin_R[9], lin_t[3];
+  CompatBase() { for (int i = 0; i < 36; i++) final_hessian[i] = (i % 7 == 0) ? 1.0 : 0.0; }
+  // find_voxel_correspondences.cu:84-111: one pass per offset over all source elements, invalid ones removed (order kept)
+  void find(const std::vector<V3f>& src, const VoxelMapF& vm, const Iso3& T) {
+    for (int i = 0; i < 9; i++) lin_R[i] = (float)T.R[i];
+    for (int i = 0; i < 3; i++) lin_t[i] = (float)T.t[i];
+    const auto offsets = neighbor_offsets(search_method, search_radius);
+    correspondences.clear();
+    for (const auto& o : offsets)
+      for (size_t i = 0; i < src.size(); i++) {
+        float q[3];
+        for (int a = 0; a < 3; a++) q[a] = (lin_R[a * 3] * src[i][0] + lin_R[a * 3 + 1] * src[i][1] + lin_R[a * 3 + 2] * src[i][2]) + lin_t[a];
+        VoxelKey k = vm.coord(q);
+        k.x += o.x; k.y += o.y; k.z += o.z;
+        const int v = vm.lookup(k);
+        if (v >= 0) correspondences.push_back({(int)i, v});
+      }
+    corr_history.push_back((int)correspondences.size());
+  }
+  double getFitnessScore() const { return fitness_score(*input, *pcl_tree, final_transformation); }
+};
+
+// FastVGICPCuda (fast_vgicp_cuda_impl.hpp) on FastVGICPCudaCore (fast_vgicp_cuda.cu)
+struct VGICPCuda : CompatBase {
+  int k_correspondences = 20;                 // fast_vgicp_cuda_impl.hpp:24 (setCorrespondenceRandomness is empty, :38)
+  RegularizationMethod regularization = PLANE;  // :26
+  int cov_mode = 0;                           // 0: exact k-NN (CPU_PARALLEL_KDTREE / GPU_BRUTEFORCE), 1: GPU_RBF_KERNEL
+  float kernel_width = 0.5f, kernel_max_dist = 3.0f;  // :31
+  std::vector<M3f> source_covs, target_covs;
+  std::unique_ptr<VoxelMapF> voxelmap;
+  void covs_of(const Cloud& c, std::vector<M3f>& out) {  // :85-141: neighbours -> covariance_estimation -> covariance_regularization
+    if (cov_mode == 1) covariances_rbf(c, kernel_width, kernel_max_dist, out, num_threads);
+    else { std::vector<int> idx; knn_all(c, k_correspondences, num_threads, idx); covariances_knn(c, k_correspondences, idx, out, num_threads); }
+#pragma omp parallel for num_threads(num_threads) schedule(guided, 8)
+    for (long long i = 0; i < (long long)out.size(); i++) out[(size_t)i] = regularize(out[(size_t)i], regularization);
+  }
+  void setInputSource(const CloudPtr& c) { if (c == input) return; input = c; covs_of(*c, source_covs); }
+  void setInputTarget(const CloudPtr& c) {  // :114-141: covariances, then create_target_voxelmap()
+    if (c == target) return;
+    target = c; target_cloud_updated = true;
+    covs_of(*c, target_covs);
+    voxelmap.reset(new VoxelMapF(resolution));
+    voxelmap->create_vgicp(*c, target_covs);
+  }
+  void swapSourceAndTarget() {  // :69-72 + fast_vgicp_cuda.cu:97-107
+    input.swap(target); source_covs.swap(target_covs);
+    if (target) { target_cloud_updated = true; voxelmap.reset(new VoxelMapF(resolution)); voxelmap->create_vgicp(*target, target_covs); }
+  }
+  void align(const Iso3& guess) {
+    if (target_cloud_updated) { pcl_tree.reset(new KdTree(*target)); target_cloud_updated = false; }
+    corr_history.clear();
+    optimize(guess);
+  }
+  double cost(const Iso3& T, double* H, double* b) {  // fast_vgicp_cuda.cu:264-284 -> compute_derivatives.cu:147-184
+    float R[9], t[3];
+    for (int i = 0; i < 9; i++) R[i] = (float)T.R[i];
+    for (int i = 0; i < 3; i++) t[i] = (float)T.t[i];
+    const bool deriv = H && b;
+    std::vector<Term> terms(correspondences.size());
+#pragma omp parallel for num_threads(num_threads) schedule(static)
+    for (long long n = 0; n < (long long)correspondences.size(); n++) {
+      const auto& c = correspondences[(size_t)n];
+      cost_term(0, input->pt(c.first), &source_covs[c.first], voxelmap->num_points[c.second], voxelmap->means[c.second], voxelmap->covs[c.second], lin_R, R, t, resolution, deriv,
+                terms[(size_t)n]);
+    }
+    const Term s = reduce_terms(terms);
+    if (deriv) { for (int i = 0; i < 36; i++) H[i] = (double)s.H[i]; for (int i = 0; i < 6; i++) b[i] = (double)s.b[i]; }
+    return (double)s.e;
+  }
+  double linearize(const Iso3& T, double* H, double* b) override {  // fast_vgicp_cuda_impl.hpp:170-173
+    num_linearize++;
+    std::vector<V3f> src(input->size());
+    for (size_t i = 0; i < src.size(); i++) src[i] = V3f{{input->pt(i)[0], input->pt(i)[1], input->pt(i)[2]}};
+    find(src, *voxelmap, T);
+    return cost(T, H, b);
+  }
+  double compute_error(const Iso3& T) override { num_error_evals++; return cost(T, nullptr, nullptr); }  // :176-178
+};
+
+// NDTCuda (ndt_cuda_impl.hpp) on NDTCudaCore (ndt_cuda.cu)
+struct NDTCuda : CompatBase {
+  NDTDistanceMode distance_mode = D2D;  // ndt_cuda.cu:21
+  std::unique_ptr<VoxelMapF> source_voxelmap, target_voxelmap;
+  NDTCuda() { search_method = DIRECT7; }  // :22
+  void setInputSource(const CloudPtr& c) { if (c == input) return; input = c; source_voxelmap.reset(); }
+  void setInputTarget(const CloudPtr& c) { if (c == target) return; target = c; target_cloud_updated = true; target_voxelmap.reset(); }
+  void swapSourceAndTarget() { input.swap(target); source_voxelmap.swap(target_voxelmap); target_cloud_updated = true; }
+  void create_voxelmaps() {  // ndt_cuda.cu:115-140
+    if (!source_voxelmap && distance_mode != P2D) { source_voxelmap.reset(new VoxelMapF(resolution)); source_voxelmap->create_ndt(*input); }
+    if (!target_voxelmap) { target_voxelmap.reset(new VoxelMapF(resolution)); target_voxelmap->create_ndt(*target); }
+  }
+  void align(const Iso3& guess) {  // ndt_cuda_impl.hpp:76-79
+    if (target_cloud_updated) { pcl_tree.reset(new KdTree(*target)); target_cloud_updated = false; }
+    create_voxelmaps();
+    corr_history.clear();
+    optimize(guess);
+  }
+  double cost(const Iso3& T, double* H, double* b) {  // ndt_cuda.cu:161-177
+    float R[9], t[3];
+    for (int i = 0; i < 9; i++) R[i] = (float)T.R[i];
+    for (int i = 0; i < 3; i++) t[i] = (float)T.t[i];
+    const bool d2d = distance_mode == D2D;
+    std::vector<Term> terms(correspondences.size());
+#pragma omp parallel for num_threads(num_threads) schedule(static)
+    for (long long n = 0; n < (long long)correspondences.size(); n++) {
+      const auto& c = correspondences[(size_t)n];
+      const float* a = d2d ? source_voxelmap->means[c.first].v : input->pt(c.first);
+      cost_term(d2d ? 2 : 1, a, d2d ? &source_voxelmap->covs[c.first] : nullptr, target_voxelmap->num_points[c.second], target_voxelmap->means[c.second], target_voxelmap->covs[c.second],
+                lin_R, R, t, resolution, true, terms[(size_t)n]);  // (the NDT kernels always form H and b: ndt_compute_derivatives.cu:191-231)
+    }
+    const Term s = reduce_terms(terms);
+    if (H && b) { for (int i = 0; i < 36; i++) H[i] = (double)s.H[i]; for (int i = 0; i < 6; i++) b[i] = (double)s.b[i]; }
+    return (double)s.e;
+  }
+  double linearize(const Iso3& T, double* H, double* b) override {  // ndt_cuda_impl.hpp:82-85 + ndt_cuda.cu:142-159
+    num_linearize++;
+    std::vector<V3f> src;
+    if (distance_mode == D2D) src = source_voxelmap->means;
+    else { src.resize(input->size()); for (size_t i = 0; i < src.size(); i++) src[i] = V3f{{input->pt(i)[0], input->pt(i)[1], input->pt(i)[2]}}; }
+    find(src, *target_voxelmap, T);
+    return cost(T, H, b);
+  }
+  double compute_error(const Iso3& T) override { num_error_evals++; return cost(T, nullptr, nullptr); }
+};
+
+}  // namespace cc
+}  // namespace orc
+
+// ---- C ABI for ctypes (oracle/oracle.py: CudaCompatVGICP / CudaCompatNDT) ----
+using namespace orc;
+namespace {
+std::shared_ptr<Cloud> cc_cloud(const float* xyz, int n) { auto c = std::make_shared<Cloud>(); c->xyz.assign(xyz, xyz + (size_t)3 * n); return c; }
+struct cc_result { double T[16]; double H[36]; int converged, nr_iterations, num_linearize, num_error_evals; };
+template <typename Reg>
+void cc_fill(Reg* g, cc_result* r) {
+  iso_to_rowmajor16(g->final_transformation, r->T);
+  std::memcpy(r->H, g->final_hessian, sizeof(r->H));
+  r->converged = g->converged; r->nr_iterations = g->nr_iterations; r->num_linearize = g->num_linearize; r->num_error_evals = g->num_error_evals;
+}
+void cc_dump_covs(const std::vector<cc::M3f>& v, double* out) { for (size_t i = 0; i < v.size(); i++) for (int q = 0; q < 9; q++) out[9 * i + q] = (double)v[i].m[q]; }
+int cc_dump_map(const cc::VoxelMapF& vm, int* coords, int* num, double* means, double* covs) {
+  for (size_t i = 0; i < vm.coords.size(); i++) {
+    coords[3 * i] = vm.coords[i].x; coords[3 * i + 1] = vm.coords[i].y; coords[3 * i + 2] = vm.coords[i].z;
+    num[i] = vm.num_points[i];
+    for (int a = 0; a < 3; a++) means[3 * i + a] = (double)vm.means[i][a];
+    for (int q = 0; q < 9; q++) covs[9 * i + q] = (double)vm.covs[i].m[q];
+  }
+  return (int)vm.coords.size();
+}
+}  // namespace
+
+extern "C" {
+void* orc_ccv_create() { return new cc::VGICPCuda(); }
+void orc_ccv_destroy(void* h) { delete (cc::VGICPCuda*)h; }
+void orc_ccv_set_params(void* h, int threads, int reg, double res, int search, double radius, int cov_mode, double kw, double kmax) {
+  auto* g = (cc::VGICPCuda*)h;
+  if (threads > 0) g->num_threads = threads;
+  g->regularization = (RegularizationMethod)reg; g->resolution = (float)res; g->search_method = (NeighborSearchMethod)search; g->search_radius = radius;
+  g->cov_mode = cov_mode; g->kernel_width = (float)kw; g->kernel_max_dist = (float)kmax;
+}
+void orc_ccv_set_lm(void* h, int max_iter, double rot_eps, double trans_eps, int lm_max_iter, double init_lambda_factor) {
+  auto* g = (cc::VGICPCuda*)h;
+  g->max_iterations = max_iter; g->rotation_epsilon = rot_eps; g->transformation_epsilon = trans_eps; g->lm_max_iterations = lm_max_iter; g->lm_init_lambda_factor = init_lambda_factor;
+}
+void orc_ccv_set_target(void* h, const float* xyz, int n) { ((cc::VGICPCuda*)h)->setInputTarget(cc_cloud(xyz, n)); }
+void orc_ccv_set_source(void* h, const float* xyz, int n) { ((cc::VGICPCuda*)h)->setInputSource(cc_cloud(xyz, n)); }
+void orc_ccv_swap(void* h) { ((cc::VGICPCuda*)h)->swapSourceAndTarget(); }
+void orc_ccv_prepare(void* h) { auto* g = (cc::VGICPCuda*)h; if (g->target_cloud_updated) { g->pcl_tree.reset(new KdTree(*g->target)); g->target_cloud_updated = false; } }
+double orc_ccv_linearize(void* h, const double* T16, double* H36, double* b6) { return ((cc::VGICPCuda*)h)->linearize(iso_from_rowmajor16(T16), H36, b6); }
+double orc_ccv_compute_error(void* h, const double* T16) { return ((cc::VGICPCuda*)h)->compute_error(iso_from_rowmajor16(T16)); }
+int orc_ccv_num_correspondences(void* h) { return (int)((cc::VGICPCuda*)h)->correspondences.size(); }
+int orc_ccv_corr_history(void* h, int* out, int max_n) { auto& v = ((cc::VGICPCuda*)h)->corr_history; for (size_t i = 0; i < v.size() && (int)i < max_n; i++) out[i] = v[i]; return (int)v.size(); }
+void orc_ccv_get_covs(void* h, int which, double* out) { auto* g = (cc::VGICPCuda*)h; cc_dump_covs(which ? g->target_covs : g->source_covs, out); }
+int orc_ccv_get_voxelmap(void* h, int* coords, int* num, double* means, double* covs) { return cc_dump_map(*((cc::VGICPCuda*)h)->voxelmap, coords, num, means, covs); }
+void orc_ccv_align(void* h, const double* guess16, cc_result* r) { auto* g = (cc::VGICPCuda*)h; g->align(iso_from_rowmajor16(guess16)); cc_fill(g, r); }
+double orc_ccv_fitness(void* h) { return ((cc::VGICPCuda*)h)->getFitnessScore(); }
+
+void* orc_ccn_create() { return new cc::NDTCuda(); }
+void orc_ccn_destroy(void* h) { delete (cc::NDTCuda*)h; }
+void orc_ccn_set_params(void* h, int threads, double res, int mode, int search, double radius) {
+  auto* g = (cc::NDTCuda*)h;
+  if (threads > 0) g->num_threads = threads;
+  g->resolution = (float)res; g->distance_mode = (NDTDistanceMode)mode; g->search_method = (NeighborSearchMethod)search; g->search_radius = radius;
+}
+void orc_ccn_set_lm(void* h, int max_iter, double rot_eps, double trans_eps, int lm_max_iter, double init_lambda_factor) {
+  auto* g = (cc::NDTCuda*)h;
+  g->max_iterations = max_iter; g->rotation_epsilon = rot_eps; g->transformation_epsilon = trans_eps; g->lm_max_iterations = lm_max_iter; g->lm_init_lambda_factor = init_lambda_factor;
+}
+void orc_ccn_set_target(void* h, const float* xyz, int n) { ((cc::NDTCuda*)h)->setInputTarget(cc_cloud(xyz, n)); }
+void orc_ccn_set_source(void* h, const float* xyz, int n) { ((cc::NDTCuda*)h)->setInputSource(cc_cloud(xyz, n)); }
+void orc_ccn_swap(void* h) { ((cc::NDTCuda*)h)->swapSourceAndTarget(); }
+void orc_ccn_prepare(void* h) { auto* g = (cc::NDTCuda*)h; if (g->target_cloud_updated) { g->pcl_tree.reset(new KdTree(*g->target)); g->target_cloud_updated = false; } g->create_voxelmaps(); }
+double orc_ccn_linearize(void* h, const double* T16, double* H36, double* b6) { return ((cc::NDTCuda*)h)->linearize(iso_from_rowmajor16(T16), H36, b6); }
+double orc_ccn_compute_error(void* h, const double* T16) { return ((cc::NDTCuda*)h)->compute_error(iso_from_rowmajor16(T16)); }
+int orc_ccn_num_correspondences(void* h) { return (int)((cc::NDTCuda*)h)->correspondences.size(); }
+int orc_ccn_corr_history(void* h, int* out, int max_n) { auto& v = ((cc::NDTCuda*)h)->corr_history; for (size_t i = 0; i < v.size() && (int)i < max_n; i++) out[i] = v[i]; return (int)v.size(); }
+int orc_ccn_get_voxelmap(void* h, int which, int* coords, int* num, double* means, double* covs) {
+  auto* g = (cc::NDTCuda*)h;
+  return cc_dump_map(which ? *g->target_voxelmap : *g->source_voxelmap, coords, num, means, covs);
+}
+void orc_ccn_align(void* h, const double* guess16, cc_result* r) { auto* g = (cc::NDTCuda*)h; g->align(iso_from_rowmajor16(guess16)); cc_fill(g, r); }
+double orc_ccn_fitness(void* h) { return ((cc::NDTCuda*)h)->getFitnessScore(); }
+// the two float building blocks on their own (tests compare them with numpy)
+void orc_cc_eig3(const double* A9, double* vals3, double* vecs9) {
+  cc::M3f A, V; float w[3];
+  for (int i = 0; i < 9; i++) A.m[i] = (float)A9[i];
+  cc::eig3_direct(A, w, V);
+  for (int i = 0; i < 3; i++) vals3[i] = (double)w[i];
+  for (int i = 0; i < 9; i++) vecs9[i] = (double)V.m[i];
+}
+void orc_cc_regularize(const double* A9, int reg, double* out9) {
+  cc::M3f A;
+  for (int i = 0; i < 9; i++) A.m[i] = (float)A9[i];
+  const cc::M3f R = cc::regularize(A, (RegularizationMethod)reg);
+  for (int i = 0; i < 9; i++) out9[i] = (double)R.m[i];
+}
+}  // extern "C"

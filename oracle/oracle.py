@@ -27,7 +27,7 @@ class Result(C.Structure):
 
 def build(force=False):
     so = os.path.join(_HERE, "liboracle.so")
-    srcs = [os.path.join(_HERE, f) for f in ("vgicp_oracle.cpp", "oracle_capi.cpp", "vgicp_oracle.hpp", "oracle_math.hpp", "oracle_align.cpp")]
+    srcs = [os.path.join(_HERE, f) for f in ("vgicp_oracle.cpp", "oracle_capi.cpp", "cuda_compat.cpp", "vgicp_oracle.hpp", "oracle_math.hpp", "oracle_align.cpp")]
     if force or not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
         subprocess.check_call(["make", "-C", _HERE, "-s", "all"])
     return so
@@ -45,7 +45,10 @@ def lib():
         L.orc_fitness.restype = dbl
         L.orc_vgicp_create.restype = vp
         L.orc_ndt_create.restype = vp
-        for f in ("orc_vgicp_cuda_compat_sums", "orc_vgicp_linearize", "orc_vgicp_compute_error", "orc_vgicp_fitness", "orc_vgicp_bench", "orc_ndt_linearize", "orc_ndt_compute_error", "orc_ndt_fitness"):
+        L.orc_ccv_create.restype = vp
+        L.orc_ccn_create.restype = vp
+        for f in ("orc_vgicp_cuda_compat_sums", "orc_vgicp_linearize", "orc_vgicp_compute_error", "orc_vgicp_fitness", "orc_vgicp_bench", "orc_ndt_linearize", "orc_ndt_compute_error", "orc_ndt_fitness",
+                  "orc_ccv_linearize", "orc_ccv_compute_error", "orc_ccv_fitness", "orc_ccn_linearize", "orc_ccn_compute_error", "orc_ccn_fitness"):
             getattr(L, f).restype = dbl
         _LIB = L
     return _LIB
@@ -314,3 +317,68 @@ class NDT(_Reg):
         coords, num, means, vc = _voxel_out(n)
         nv = self._call("get_voxelmap", 1 if which == "target" else 0, _p(coords), _p(num), _p(means), _p(vc))
         return coords[:nv].copy(), num[:nv].copy(), means[:nv].copy(), vc[:nv].copy()
+
+
+# ---------------------------------------------------------------------------------------------------
+# "cuda-compat" leg (oracle/cuda_compat.cpp): fp32 restatement of the reference's DEVICE path end to end
+# ---------------------------------------------------------------------------------------------------
+class _Compat(_Reg):
+    def set_lm(self, max_iterations=64, rotation_epsilon=2e-3, transformation_epsilon=5e-4, lm_max_iterations=10, init_lambda_factor=1e-9):
+        self._call("set_lm", max_iterations, C.c_double(rotation_epsilon), C.c_double(transformation_epsilon), lm_max_iterations, C.c_double(init_lambda_factor))
+
+    def corr_history(self):
+        """Correspondence-list length after every update_correspondences() of the last align()."""
+        out = np.empty(4096, np.int32)
+        n = self._call("corr_history", _p(out), 4096)
+        return out[:n].tolist()
+
+
+class CudaCompatVGICP(_Compat):
+    """FastVGICPCuda + FastVGICPCudaCore in float (covariance_estimation.cu, covariance_regularization.cu, gaussian_voxelmap.cu,
+    find_voxel_correspondences.cu, compute_derivatives.cu); k = 20 always, like the reference's CUDA class."""
+    _prefix = "orc_ccv_"
+
+    def __init__(self, threads=0, reg=PLANE, resolution=1.0, search=DIRECT1, radius=0.0, cov_mode=0, kernel_width=0.5, kernel_max_dist=3.0):
+        self.h = lib().orc_ccv_create()
+        self._call("set_params", threads, reg, C.c_double(resolution), search, C.c_double(radius), cov_mode, C.c_double(kernel_width), C.c_double(kernel_max_dist))
+
+    def get_covs(self, which):
+        n = self.nt if which == "target" else self.ns
+        out = np.empty((n, 3, 3), np.float64)
+        self._call("get_covs", 1 if which == "target" else 0, _p(out))
+        return out
+
+    def get_voxelmap(self):
+        coords, num, means, vc = _voxel_out(self.nt)
+        nv = self._call("get_voxelmap", _p(coords), _p(num), _p(means), _p(vc))
+        return coords[:nv].copy(), num[:nv].copy(), means[:nv].copy(), vc[:nv].copy()
+
+
+class CudaCompatNDT(_Compat):
+    """NDTCuda + NDTCudaCore in float (gaussian_voxelmap.cu NDT branch + MIN_EIG, ndt_compute_derivatives.cu)."""
+    _prefix = "orc_ccn_"
+
+    def __init__(self, threads=0, resolution=1.0, mode=D2D, search=DIRECT7, radius=0.0):
+        self.h = lib().orc_ccn_create()
+        self._call("set_params", threads, C.c_double(resolution), mode, search, C.c_double(radius))
+
+    def get_voxelmap(self, which):
+        n = self.nt if which == "target" else self.ns
+        coords, num, means, vc = _voxel_out(n)
+        nv = self._call("get_voxelmap", 1 if which == "target" else 0, _p(coords), _p(num), _p(means), _p(vc))
+        return coords[:nv].copy(), num[:nv].copy(), means[:nv].copy(), vc[:nv].copy()
+
+
+def cc_eig3(A):
+    """Eigen::SelfAdjointEigenSolver<Matrix3f>::computeDirect as restated in cuda_compat.cpp: (values ascending, vectors in columns)."""
+    a = _f64(A).reshape(3, 3)
+    w, V = np.empty(3, np.float64), np.empty((3, 3), np.float64)
+    lib().orc_cc_eig3(_p(a), _p(w), _p(V))
+    return w, V
+
+
+def cc_regularize(A, reg):
+    a = _f64(A).reshape(3, 3)
+    out = np.empty((3, 3), np.float64)
+    lib().orc_cc_regularize(_p(a), reg, _p(out))
+    return out

@@ -1,0 +1,112 @@
+"""GPU tests: the engine's FVH_COMPUTE_FP32 mode END TO END against the oracle's "cuda-compat" leg -- the float restatement of
+the reference's device path (oracle/cuda_compat.cpp: FastVGICPCuda / NDTCuda as the .cu files compute them).
+
+north_star asks for parity with FastVGICP *and* FastVGICPCuda. The two reference paths differ from EACH OTHER by 1e-4..3e-4 of
+the pose on the bundled pair (tests/test_oracle.py::test_cuda_compat_recorded_values): fp64 centred covariances + fp64 voxel sums
++ fp64 cost on the CPU, float uncentred covariances + float voxel sums + float cost on the device. The engine's fp32 mode keeps
+fp64 for everything that is computed ONCE per cloud (covariances, voxel sums, voxel coordinates) and runs the per-correspondence
+cost in float with fp64 sums -- it sits between the two reference paths. Tolerances below are stated against that spread:
+pose 5e-4 relative, fitness 1e-3 relative, equal iteration counts; cost sums at a FIXED pose and FIXED correspondences 2e-3
+(float cost terms on both sides, different covariance arithmetic upstream)."""
+import numpy as np
+import pytest
+
+from tests import util
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def O():
+    from oracle import oracle
+    return oracle
+
+
+def _engine(tgt, src, search, precision):
+    from fast_gicp_amd import capi
+    c = capi.VGICPCore(0)
+    c.set_precision(precision)
+    c.set_neighbor_search_method(search)
+    c.set_target_cloud(tgt); c.find_target_neighbors(20); c.calculate_target_covariances(capi.REG_PLANE); c.create_target_voxelmap()
+    c.set_source_cloud(src); c.find_source_neighbors(20); c.calculate_source_covariances(capi.REG_PLANE)
+    return c
+
+
+@pytest.mark.parametrize("search", ["DIRECT1", "DIRECT7", "DIRECT27"])
+def test_vgicp_fp32_mode_end_to_end_vs_cuda_compat(O, search):
+    from fast_gicp_amd import capi
+    tgt, src = util.bundled_pair()
+    cs, os_ = {"DIRECT1": (capi.DIRECT1, O.DIRECT1), "DIRECT7": (capi.DIRECT7, O.DIRECT7), "DIRECT27": (capi.DIRECT27, O.DIRECT27)}[search]
+    g = O.CudaCompatVGICP(search=os_)
+    g.set_target(tgt); g.set_source(src)
+    ro = g.align()
+    fo = g.fitness()
+    c = _engine(tgt, src, cs, capi.COMPUTE_FP32)
+    r = c.align()
+    f = c.fitness_score(r["T"].astype(np.float32).astype(np.float64))
+    assert r["converged"] and ro["converged"]
+    assert r["num_linearize"] == ro["num_linearize"] and r["num_error_evals"] == ro["num_error_evals"], (r, ro)
+    dT = util.rel_err(r["T"], ro["T"])
+    print("%s: fp32 engine vs cuda-compat oracle: pose rel %.2e, fitness %.6f vs %.6f" % (search, dT, f, fo))
+    assert dT < 5e-4, dT
+    assert abs(f - fo) < 1e-3 * fo, (f, fo)
+    # the voxel sets are the same whichever arithmetic builds them, and the first correspondence list (identity pose) has the same length
+    coords, num, _, _ = g.get_voxelmap()
+    ec, en, _, _ = c.get_voxelmap()
+    assert util.voxel_dict(ec, en) == util.voxel_dict(coords, num)
+    c.update_correspondences(np.eye(4))
+    assert c.get_num_correspondences() == g.corr_history()[0]
+    # the engine's two precisions against each other: float cost terms move the pose by less than the reference's own CPU / GPU spread
+    c64 = _engine(tgt, src, cs, capi.COMPUTE_FP64)
+    r64 = c64.align()
+    assert util.rel_err(r["T"], r64["T"]) < 2e-4
+    c.close(); c64.close()
+
+
+def test_vgicp_fp32_cost_sums_at_a_fixed_pose_vs_cuda_compat(O):
+    """err / H / b at the ground-truth pose of the bundled pair: the engine's float cost on its own (fp64-built) covariances and voxels
+    against the all-float device restatement. What differs is upstream of the cost (uncentred float covariances, float voxel sums):
+    2e-3 relative on err and H, b on its Cauchy-Schwarz scale."""
+    from fast_gicp_amd import capi
+    tgt, src = util.bundled_pair()
+    T = util.relative_pose()
+    g = O.CudaCompatVGICP(search=O.DIRECT7)
+    g.set_target(tgt); g.set_source(src); g.prepare()
+    eo, Ho, bo = g.linearize(T)
+    c = _engine(tgt, src, capi.DIRECT7, capi.COMPUTE_FP32)
+    e, H, b = c.linearize(T)
+    assert c.get_num_correspondences() == g.num_correspondences()
+    assert util.sums_close(e, H, b, eo, Ho, bo, 2e-3), (e, eo, util.rel_err(H, Ho))
+    c.close()
+
+
+@pytest.mark.parametrize("mode", ["D2D", "P2D"])
+def test_ndt_fp32_mode_end_to_end_vs_cuda_compat(O, mode):
+    """NDTCuda (ndt_cuda.cu, ndt_compute_derivatives.cu) on the gicp_test.cpp input (exact VoxelGrid 0.2) and on a pair of simulated
+    LiDAR frames: the engine's fp32 mode against the float restatement -- same voxel sets, same iteration counts, pose 1e-3
+    (the NDT cost is flatter than VGICP's: float noise in H moves the optimum further), fitness 2e-3."""
+    from fast_gicp_amd import capi, workloads
+    om, cm = {"D2D": (O.D2D, capi.NDT_D2D), "P2D": (O.P2D, capi.NDT_P2D)}[mode]
+    t, s = util.bundled_pair(origin_filter=False, leaf=0.2, exact_voxelgrid=True)
+    f0 = O.approx_voxelgrid(workloads.lidar_frame(2), 0.25)
+    f1 = O.approx_voxelgrid(workloads.lidar_frame(3), 0.25)
+    for name, tgt, src in (("gicp_test pair", t, s), ("lidar frames", f0, f1)):
+        g = O.CudaCompatNDT(mode=om, search=O.DIRECT7)
+        g.set_target(tgt); g.set_source(src)
+        ro = g.align()
+        d = capi.NDTCore(0)
+        d.set_precision(capi.COMPUTE_FP32)
+        d.set_distance_mode(cm); d.set_neighbor_search_method(capi.DIRECT7); d.set_resolution(1.0)
+        d.set_target_cloud(tgt); d.set_source_cloud(src)
+        r = d.align()
+        assert r["converged"] and ro["converged"], name
+        assert r["num_linearize"] == ro["num_linearize"], (name, r["num_linearize"], ro["num_linearize"])
+        dT = util.rel_err(r["T"], ro["T"])
+        fit, fo = d.fitness_score(r["T"].astype(np.float32).astype(np.float64)), g.fitness()
+        print("NDT %s, %s: fp32 engine vs cuda-compat oracle: pose rel %.2e, fitness %.6f vs %.6f" % (mode, name, dT, fit, fo))
+        assert dT < 1e-3, (name, dT)
+        assert abs(fit - fo) < 2e-3 * fo, (name, fit, fo)
+        cc, cn, _, _ = g.get_voxelmap("target")
+        ec, en, _, _ = d.get_voxelmap("target")
+        assert util.voxel_dict(cc, cn) == util.voxel_dict(ec, en), name
+        d.close()
