@@ -258,6 +258,12 @@ class VGICPCore(_Core):
     def peer_detach(self):
         self._call("peer_detach")
 
+    def peer_selfcheck(self, timeout_seconds=5.0):
+        """Collective: a store of every rank reaches every rank (FvhError with the missing ranks otherwise)."""
+        m = C.c_int(0)
+        self._call("peer_selfcheck", C.c_double(timeout_seconds), C.byref(m))
+        return m.value
+
     def set_voxel_accumulation_mode(self, mode):
         self._call("set_voxel_accumulation_mode", int(mode))
 

@@ -243,6 +243,8 @@ struct Engine {
     size_t region_bytes = 0, stage_half_bytes = 0;
     char* peer_region[FVH_MAX_PEERS] = {nullptr};
     bool ipc_opened[FVH_MAX_PEERS] = {false};
+    unsigned long long check_gen = 0;  // self-checks so far (fvh_vgicp_peer_selfcheck: collective, same count on every rank)
+    int peer_device[FVH_MAX_PEERS] = {-1, -1, -1, -1, -1, -1, -1, -1};  // device an attached region lives on (hipPointerGetAttributes), -1 unknown
     unsigned long long x = 2;          // exchange counter: the next sums exchange uses tag x / parity x & 1 (same on every rank: collective call discipline)
     unsigned long long stage_gen = 0;  // covariance all-gathers so far
     DevBuf err;                        // gather watchdog flag
@@ -1921,8 +1923,53 @@ int fvh_vgicp_peer_attach(fvh_vgicp* h, int nranks, int rank, int ranks_on_this_
     e->peer.peer_region[p] = static_cast<char*>(ptr);
     e->peer.ipc_opened[p] = true;
   }
+  // where does every region live, and can this device reach it? (a clear error now instead of a 2 s exchange time-out later)
+  for (int p = 0; p < nranks; p++) {
+    e->peer.peer_device[p] = -1;
+    hipPointerAttribute_t attr;
+    if (hipPointerGetAttributes(&attr, e->peer.peer_region[p]) == hipSuccess) e->peer.peer_device[p] = attr.device;
+    else (void)hipGetLastError();
+    const int pd = e->peer.peer_device[p];
+    if (pd >= 0 && pd != e->device) {
+      int can = 0;
+      if (hipDeviceCanAccessPeer(&can, e->device, pd) == hipSuccess && !can) {
+        e->peer_detach();
+        return e->fail(FVH_ERR_COMM, "peer_attach: device " + std::to_string(e->device) + " cannot access device " + std::to_string(pd) + " (rank " + std::to_string(p) +
+                                       "): no peer-to-peer path between them (hipDeviceCanAccessPeer); use the RCCL route (fvh_vgicp_comm_init)");
+      }
+    }
+  }
   e->peer.n = nranks; e->peer.rank = rank; e->peer.ranks_on_device = ranks_on_this_device;
   e->has_corr = false;
+  return FVH_OK;
+}
+// Collective (every rank calls it, in the same order with respect to other collective calls): every rank stores a nonce into every
+// region and waits for everybody's nonce in its own -- the path the in-kernel mailboxes take, checked once up front.
+int fvh_vgicp_peer_selfcheck(fvh_vgicp* h, double timeout_seconds, int* missing_rank_mask) {
+  CHECK_HANDLE(h);
+  Engine* e = &h->e;
+  if (missing_rank_mask) *missing_rank_mask = 0;
+  if (!e->peer.attached()) return e->fail(FVH_ERR_BAD_STATE, "peer_selfcheck: no peers attached");
+  if (!(timeout_seconds > 0)) timeout_seconds = 5.0;
+  const unsigned long long nonce = 0x5e1fc4ec00000000ull + (++e->peer.check_gen);
+  const PeerView pv = e->peer.view(0);
+  HIP_OR_FAIL(e, e->peer.err.ensure(64));
+  HIP_OR_FAIL(e, hipMemsetAsync(e->peer.err.p, 0, 4, e->stream));
+  peer_check_write_kernel<<<1, 64, 0, e->stream>>>(pv, nonce);
+  peer_check_wait_kernel<<<1, 64, 0, e->stream>>>(pv, nonce, (unsigned long long)(timeout_seconds * 1e8), e->peer.err.as<unsigned>());
+  HIP_OR_FAIL(e, hipGetLastError());
+  unsigned* h_missing = reinterpret_cast<unsigned*>(e->pinned);
+  HIP_OR_FAIL(e, hipMemcpyAsync(h_missing, e->peer.err.p, 4, hipMemcpyDeviceToHost, e->stream));
+  HIP_OR_FAIL(e, hipStreamSynchronize(e->stream));
+  if (*h_missing) {
+    if (missing_rank_mask) *missing_rank_mask = (int)*h_missing;
+    std::string who;
+    for (int p = 0; p < e->peer.n; p++)
+      if (*h_missing & (1u << p)) who += (who.empty() ? "" : ", ") + std::to_string(p) + " (device " + std::to_string(e->peer.peer_device[p]) + ")";
+    return e->fail(FVH_ERR_COMM, "peer_selfcheck: rank " + std::to_string(e->peer.rank) + " (device " + std::to_string(e->device) + ") never saw the store of rank(s) " + who +
+                                   " within " + std::to_string(timeout_seconds) + " s -- that rank did not call the self-check, or its stores do not reach this device's memory "
+                                   "(IPC mapping / xGMI peer access); use the RCCL route (fvh_vgicp_comm_init)");
+  }
   return FVH_OK;
 }
 int fvh_vgicp_peer_detach(fvh_vgicp* h) { CHECK_HANDLE(h); h->e.peer_detach(); h->e.has_corr = false; return FVH_OK; }

@@ -20,7 +20,9 @@ constexpr int FVH_MAX_PEERS = 8;
 constexpr int MAIL_SLOT = 40;  // doubles
 constexpr size_t PEER_MAIL_BYTES = 2 * FVH_MAX_PEERS * MAIL_SLOT * sizeof(double);
 constexpr size_t PEER_SIG_OFFSET = PEER_MAIL_BYTES;
+constexpr size_t PEER_CHECK_OFFSET = PEER_SIG_OFFSET + 64;  // self-check nonce per source rank (u64 x 8), see peer_check_*_kernel
 constexpr size_t PEER_STAGE_OFFSET = 8192;
+static_assert(PEER_CHECK_OFFSET + 64 <= PEER_STAGE_OFFSET, "exchange region header");
 
 struct PeerView {  // kernel argument (by value)
   int n, rank;
@@ -71,6 +73,26 @@ __device__ inline bool peer_exchange_sums(const PeerView& pv, double* row, unsig
   }
   __syncthreads();
   return ok;
+}
+
+// ---- self-check: does a store of every rank reach every rank? (run once after attaching, before anything depends on it) ----
+// every rank writes `nonce` into slot [its rank] of EVERY region (its own included) ...
+__global__ void peer_check_write_kernel(PeerView pv, unsigned long long nonce) {
+  if ((int)threadIdx.x < pv.n) {
+    __hip_atomic_store(reinterpret_cast<unsigned long long*>(peer_region(pv, threadIdx.x) + PEER_CHECK_OFFSET) + pv.rank, nonce, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __threadfence_system();
+  }
+}
+// ... and waits until all n slots of its OWN region hold it; missing[0] = bit mask of the ranks whose store never came
+__global__ void peer_check_wait_kernel(PeerView pv, unsigned long long nonce, unsigned long long watchdog, unsigned* __restrict__ missing) {
+  if ((int)threadIdx.x < pv.n) {
+    const unsigned long long* slot = reinterpret_cast<const unsigned long long*>(peer_region(pv, pv.rank) + PEER_CHECK_OFFSET) + threadIdx.x;
+    const unsigned long long t0 = wall_clock64();
+    while (__hip_atomic_load(slot, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) != nonce) {
+      if (wall_clock64() - t0 > watchdog) { atomicOr(missing, 1u << threadIdx.x); break; }
+      __builtin_amdgcn_s_sleep(8);
+    }
+  }
 }
 
 // ---- covariance all-gather --------------------------------------------------------------------------------------------

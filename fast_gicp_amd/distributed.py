@@ -154,7 +154,7 @@ class ShardedVGICP:
         self.core.comm_init(unique_id_bytes, self.world_size, self.rank)
         self._comm_ready = True
 
-    def attach_peers(self, max_points, device_index=None):
+    def attach_peers(self, max_points, device_index=None, selfcheck_timeout=5.0):
         """collective "peer": export this rank's exchange region, swap the IPC handles with all ranks, map theirs.
         `device_index`: the GPU this rank runs on (ranks sharing a GPU share its co-resident workgroup slots); by default the
         device the handle was created on."""
@@ -178,6 +178,8 @@ class ShardedVGICP:
         self.core.peer_attach(self.world_size, self.rank, same_dev, [v[0] for v in allv], local)
         if self.dist is not None and self.world_size > 1:
             self.dist.barrier()  # every rank has mapped every region before anybody writes into one
+        if self.world_size > 1:
+            self.core.peer_selfcheck(selfcheck_timeout)  # a store of every rank reaches every rank (xGMI / IPC): a clear error now, not a time-out inside a registration
         self._comm_ready = True
 
     def collective_description(self):

@@ -208,6 +208,11 @@ int fvh_vgicp_peer_export(fvh_vgicp* h, int max_points, void* ipc_handle64 /* ou
 int fvh_vgicp_peer_attach(fvh_vgicp* h, int nranks, int rank, int ranks_on_this_device, const void* ipc_handles /* nranks x 64 B, may be NULL if all peers are local */,
                           const unsigned long long* process_local_ptrs /* nranks entries or NULL */);
 int fvh_vgicp_peer_detach(fvh_vgicp* h);
+/* peer_attach refuses (FVH_ERR_COMM) a peer region on a device this one cannot reach (hipDeviceCanAccessPeer).
+ * peer_selfcheck: COLLECTIVE -- every rank stores a nonce into every attached region and waits until every rank's nonce has arrived
+ *   in its own (the path the in-kernel mailboxes take, over xGMI between devices); FVH_ERR_COMM + the bit mask of the ranks whose
+ *   store never came after timeout_seconds (<= 0: 5 s). Call it once after attaching, before the first sharded registration. */
+int fvh_vgicp_peer_selfcheck(fvh_vgicp* h, double timeout_seconds, int* missing_rank_mask /* out, may be NULL */);
 
 /* ---------------------------------------------------------------------------------------------
  * NDTCudaCore

@@ -151,3 +151,41 @@ def test_peer_errors():
     assert c.align()["converged"]
     c.peer_detach()
     c.close()
+
+
+def test_peer_selfcheck():
+    """fvh_vgicp_peer_selfcheck: a store of every rank reaches every rank's region (the in-kernel mailboxes' path), checked once
+    after attaching. Two handles of one process: both call it -> ok; only one calls it -> FVH_ERR_COMM naming the silent rank,
+    and the next (complete) check works again."""
+    from fast_gicp_amd import capi
+    cores = [capi.VGICPCore(0) for _ in range(2)]
+    exports = [c.peer_export(1000) for c in cores]
+    for rank, c in enumerate(cores):
+        c.peer_attach(2, rank, 2, [h for h, _ in exports], [p for _, p in exports])
+    out = [None, None]
+
+    def check(rank, timeout):
+        try:
+            out[rank] = cores[rank].peer_selfcheck(timeout)
+        except capi.FvhError as ex:
+            out[rank] = ex
+
+    th = [threading.Thread(target=check, args=(r, 5.0)) for r in range(2)]
+    [t.start() for t in th]
+    [t.join(30) for t in th]
+    assert out == [0, 0], out
+    check(0, 0.2)  # rank 1 stays silent
+    assert isinstance(out[0], capi.FvhError) and "rank(s) 1" in str(out[0]), out[0]
+    # rank 1 catches up with the missed round (its counter must match rank 0's), then a complete round passes
+    out[1] = None
+    check(1, 0.2)
+    th = [threading.Thread(target=check, args=(r, 5.0)) for r in range(2)]
+    [t.start() for t in th]
+    [t.join(30) for t in th]
+    assert out == [0, 0], out
+    solo = capi.VGICPCore(0)
+    with pytest.raises(capi.FvhError):
+        solo.peer_selfcheck()  # nothing attached
+    solo.close()
+    for c in cores:
+        c.peer_detach(); c.close()

@@ -1,0 +1,80 @@
+#!/usr/bin/env python
+"""Folds the rocprofv3 --pmc passes of one round into ONE json that bench.py reads (profiles/rNN_pmc.json):
+    python tools/pmc_collect.py out.json entry:kernel_substr:fetch_csv:write_csv:sq_csv [...]
+(any csv may be '-'). Per entry: HBM bytes per launch (FETCH_SIZE / WRITE_SIZE, separate passes as MI355X_MICROARCH.md prescribes:
+both in KiB, FETCH_SIZE doubled on gfx950), and from the SQ pass: VALU instructions per wave, VALU-busy / waiting fractions of the
+wave cycles, and the chip-level VALU pipe utilisation  SQ_ACTIVE_INST_VALU * 4 / (GRBM_GUI_ACTIVE * #SIMDs)  (quad-cycle counter;
+one SIMD runs one VALU instruction at a time, so the sum over waves is the pipe's busy time).
+The file is stamped with the git commit and a hash of fast_gicp_amd/csrc/: bench.py refuses to quote it once the kernels changed."""
+import csv
+import hashlib
+import json
+import os
+import subprocess
+import sys
+from collections import defaultdict
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SIMDS = 256 * 4
+
+
+def csrc_sha():
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "fast_gicp_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        h.update(f.encode())
+        h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def per_launch(path, kern, min_ns=8000):
+    acc, n, dur = defaultdict(float), defaultdict(int), []
+    seen = set()
+    for r in csv.DictReader(open(path)):
+        if kern in r["Kernel_Name"]:
+            d = int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
+            if d >= min_ns:
+                acc[r["Counter_Name"]] += float(r["Counter_Value"])
+                n[r["Counter_Name"]] += 1
+                key = (r.get("Dispatch_Id"), r["Start_Timestamp"])
+                if key not in seen:
+                    seen.add(key)
+                    dur.append(d)
+    return {k: acc[k] / n[k] for k in acc}, (max(n.values()) if n else 0), (sum(dur) / len(dur) if dur else None)
+
+
+def main(out, *specs):
+    try:
+        commit = subprocess.check_output(["git", "-C", ROOT, "rev-parse", "--short=12", "HEAD"], stderr=subprocess.DEVNULL).decode().strip()
+    except Exception:
+        commit = os.environ.get("FVH_COMMIT", "unknown")  # (the GPU box has no .git: the artifacts script passes the commit in)
+    res = {"_meta": {"commit": commit, "csrc_sha": csrc_sha(),
+                     "method": "rocprofv3 --kernel-trace --pmc <one counter group per pass>; launches >= 8 us; hbm_bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024 "
+                               "(gfx950: FETCH_SIZE reports half of wide coalesced reads); profiled passes run at lower clocks than un-profiled ones"}}
+    for spec in specs:
+        name, kern, fcsv, wcsv, scsv = spec.split(":")
+        e = {"kernel": kern}
+        if fcsv != "-" and wcsv != "-" and os.path.exists(fcsv) and os.path.exists(wcsv):
+            f, nf, _ = per_launch(fcsv, kern)
+            w, nw, _ = per_launch(wcsv, kern)
+            if "FETCH_SIZE" in f and "WRITE_SIZE" in w:
+                e.update(fetch_size_kib_raw=round(f["FETCH_SIZE"], 1), write_size_kib_raw=round(w["WRITE_SIZE"], 1), launches_fetch_pass=nf, launches_write_pass=nw,
+                         hbm_bytes_per_launch=int((2 * f["FETCH_SIZE"] + w["WRITE_SIZE"]) * 1024))
+        if scsv != "-" and os.path.exists(scsv):
+            m, ns, dur = per_launch(scsv, kern)
+            wc = m.get("SQ_WAVE_CYCLES") or float("nan")
+            e["sq"] = {"launches": ns, "avg_launch_us_in_this_pass": None if dur is None else round(dur / 1e3, 2), "counters_per_launch": {k: round(v, 1) for k, v in m.items()},
+                       "valu_insts_per_wave": round(m.get("SQ_INSTS_VALU", float("nan")) / max(m.get("SQ_WAVES", 1), 1), 1),
+                       "valu_busy_frac_of_wave_cycles": round(m.get("SQ_ACTIVE_INST_VALU", float("nan")) / wc, 4),
+                       "waiting_frac_of_wave_cycles": round(m.get("SQ_WAIT_ANY", float("nan")) / wc, 4),
+                       "issue_stall_frac_of_wave_cycles": round(m.get("SQ_WAIT_INST_ANY", float("nan")) / wc, 4)}
+            if m.get("GRBM_GUI_ACTIVE"):
+                e["sq"]["valu_pipe_utilisation_of_chip"] = round(m.get("SQ_ACTIVE_INST_VALU", float("nan")) * 4.0 / (m["GRBM_GUI_ACTIVE"] * SIMDS), 4)
+                e["sq"]["effective_clock_ghz"] = None if not dur else round(m["GRBM_GUI_ACTIVE"] / dur, 3)
+        res[name] = e
+    json.dump(res, open(out, "w"), indent=1)
+    print(json.dumps(res, indent=1))
+
+
+if __name__ == "__main__":
+    main(*sys.argv[1:])
