@@ -35,7 +35,10 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 T_START = time.perf_counter()
-PMC_FILE = os.path.join(ROOT, "profiles", "r02_pmc_cost_kernel.json")
+PMC_FILE = os.path.join(ROOT, "profiles", "r03_pmc.json")
+# the cpu_baseline legs (oracle, OpenMP): threads next to each other -- they share the voxel map and the kd-tree through the caches
+os.environ.setdefault("OMP_PROC_BIND", "close")
+os.environ.setdefault("OMP_PLACES", "cores")
 
 
 def parse():
@@ -90,13 +93,55 @@ def finish(dist, hung):
         dist.destroy_process_group()
 
 
+def csrc_sha():
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "fast_gicp_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        h.update(f.encode())
+        h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+_PMC = {}
+
+
+def pmc_entry(key):
+    """(entry, source) of the committed PMC passes of this round (profiles/r03_pmc.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE / SQ group
+    in separate runs of THIS command, tools/r03_artifacts.sh + tools/pmc_collect.py; FETCH doubled per the gfx950 note of
+    MI355X_MICROARCH.md). PMC counters cannot be collected inside a timed run, so the numbers are a committed measurement -- stamped
+    with the commit and a hash of fast_gicp_amd/csrc/ they were taken at, and NOT quoted once the kernels have changed."""
+    if not _PMC:
+        try:
+            _PMC.update(json.load(open(PMC_FILE)))
+        except Exception:
+            _PMC["_meta"] = {}
+        _PMC["_stale"] = _PMC.get("_meta", {}).get("csrc_sha") != csrc_sha()
+    meta = _PMC.get("_meta", {})
+    if not meta:
+        return None, "no PMC pass committed for this round (profiles/r03_pmc.json)"
+    if _PMC["_stale"]:
+        return None, "PMC pass of commit %s is older than fast_gicp_amd/csrc/ (hash %s != %s): not quoted" % (meta.get("commit"), meta.get("csrc_sha"), csrc_sha())
+    return _PMC.get(key), "committed PMC pass of commit %s (profiles/r03_pmc.json, csrc hash %s == this tree)" % (meta.get("commit"), meta.get("csrc_sha"))
+
+
 def pmc_traffic(key):
-    """HBM bytes per launch of the cost kernel from the committed PMC pass of this round (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in
-    separate runs, FETCH doubled per the gfx950 note of MI355X_MICROARCH.md; tools/pmc_traffic.py)."""
-    try:
-        return json.load(open(PMC_FILE)).get(key, {}).get("hbm_bytes_per_launch")
-    except Exception:
-        return None
+    e, src = pmc_entry(key)
+    return (e or {}).get("hbm_bytes_per_launch"), src
+
+
+def valu_roofline(key, kernel, avg_us, n_queries, n_candidates):
+    """the O(N^2)-class kernels (exact k-NN, RBF sweep) are fp32-VALU bound, not HBM bound: VALU pipe utilisation from
+    the SQ pass + the pair-evaluation rate a full N x N sweep would need to match the culled search."""
+    e, src = pmc_entry(key)
+    sq = (e or {}).get("sq") or {}
+    util = sq.get("valu_pipe_utilisation_of_chip")
+    return {"kernel": kernel, "bound": "valu", "achieved": None if util is None else round(util * 78.6, 3), "peak": 78.6, "unit": "T lane-op/s (256 CUs x 4 SIMD-32 x 2.4 GHz)",
+            "frac": util, "valu_busy_frac_of_wave_cycles": sq.get("valu_busy_frac_of_wave_cycles"), "waiting_frac_of_wave_cycles": sq.get("waiting_frac_of_wave_cycles"),
+            "valu_insts_per_query": sq.get("valu_insts_per_wave"), "counters_source": src,
+            "pair_evaluations_per_sec_full_sweep_equivalent": round(float(n_queries) * n_candidates / (avg_us * 1e-6), 1),
+            "note": "one query per wave, culled by two levels of tile boxes: the sweep visits ~10 tiles x 64 candidates per query, so the full-sweep-equivalent rate is what a "
+                    "brute-force N x N kernel would have to sustain (8 flop per pair), not arithmetic this kernel performs"}
 
 
 def thread_counts():
@@ -145,68 +190,126 @@ def cpu_baseline_vgicp(tgt, src, res, search, cov, budget_s, mode="reuse", count
             break
     th, t, g = best
     left = budget_s - (time.perf_counter() - t_begin)
-    loops = int(max(2, min(100, left / max(t, 1e-3))))
+    loops = int(max(10, min(100, left / max(t, 1e-3))))  # (never fewer than 10 iterations, whatever the budget says)
     el = time_loops(g, loops)
     return {"value": round(loops / el, 3), "unit": "registrations/sec", "cores": th, "kind": "port",
             "sample": "%d iterations of the %s on the same pair/config (oracle/liboracle.so, OpenMP, %d threads = best of the sweep)" % (
                 loops, "100times_reuse loop" if mode == "reuse" else "scan-to-map loop (map prepared once)", th),
-            "thread_sweep_registrations_per_sec": sweep, "host_cores": os.cpu_count()}
+            "thread_sweep_registrations_per_sec": sweep, "host_cores": os.cpu_count(), "omp_proc_bind": os.environ.get("OMP_PROC_BIND")}
+
+
+def cpu_config0(budget_s=8.0):
+    """BASELINE.json configs[0]: the reference's OWN CPU benchmark -- FastVGICP (OpenMP), bundled pair, voxel resolution 1.0, DIRECT1, k = 20,
+    100times_reuse loop (README.md:126-128: 4408 ms on one thread = 22.7 registrations/s, 806.53 ms on the 16 threads of an i9-9900K = 124.0).
+    Timed here on the oracle (the fp64 restatement of that class) on THIS box's host cores: the one published CPU number the oracle's speed
+    can be held against."""
+    from fast_gicp_amd import preprocess
+    tgt, src = preprocess.bundled_pair(os.path.join(ROOT, "data"))
+    n = os.cpu_count() or 1
+    counts = sorted(set(t for t in (1, 8, 16, 32, 64) if t <= n))
+    r = cpu_baseline_vgicp(tgt, src, 1.0, "DIRECT1", "knn", budget_s, mode="reuse", counts=counts)
+    sweep = r["thread_sweep_registrations_per_sec"]
+    r.update({"config": "BASELINE.json configs[0]: FastVGICP (CPU/OpenMP) on the bundled pair, voxel_res 1.0, DIRECT1, 100times_reuse (oracle = fp64 restatement of the reference class)",
+              "published_reference": {"registrations_per_sec_16_threads": 124.0, "registrations_per_sec_1_thread": 22.7, "hardware": "Core i9-9900K (8C/16T)", "source": "README.md:126-128"},
+              "this_box_at_16_threads": sweep.get(16), "this_box_at_1_thread": sweep.get(1)})
+    return r
 
 
 def sharded_leg(args, dist, rank, world, local_rank, dev):
-    """BASELINE.json configs[4]: 1M-point map <-> 100k-point scan, DIRECT7, res 0.5, ONE registration spread over the ranks:
-    every rank holds the full clouds, the engine shards k-NN / covariances / cost evaluation by spatial tile internally and
-    exchanges through peer-mapped regions (fvh_vgicp_peer_*: mailboxes inside the persistent LM kernel, no RCCL).
-    Timed: the scan-to-map step (set_source + k-NN + covariances + align) sharded, and the same step on one GPU."""
+    """north_star: "large scans shard by spatial tile across up to 8 GPUs with an RCCL all-reduce of the 6x6 / 6x1 normal equations per
+    iteration ... 100 k / 1 M synthetic clouds at 1 / 2 / 4 / 8 GPUs". ONE registration spread over the ranks, for both large configurations
+    (BASELINE configs[4]: 1M-point map <-> 100k-point scan, DIRECT7; configs[2]-sized 100k <-> 100k, DIRECT27) and BOTH exchange routes:
+      "peer"  the engine shards k-NN / covariances / cost evaluation by Morton tile internally, sums meet in peer-mapped mailboxes INSIDE the
+              persistent LM kernel (fvh_vgicp_peer_*; a self-check of the mailboxes runs at attach time);
+      "rccl"  every rank uploads its spatial tile of the source, ncclAllReduce(32 x f64) on the engine stream after every cost launch.
+    Timed per route: the scan-to-map step (source in, k-NN, covariances, align) as two stages, next to the same step on one GPU."""
     import torch
     from fast_gicp_amd import capi, distributed as D, workloads
-    try:
-        torch.cuda.set_device(local_rank)  # this leg runs on a worker thread (run_with_deadline): the current device is per thread
-        tgt, src, _ = workloads.synthetic_pair(1_000_000, 100_000, seed=44, extent=150.0)
-        core = capi.VGICPCore(local_rank)
-        core.set_resolution(0.5)
-        core.set_neighbor_search_method(capi.DIRECT7)
-        steps = 20
+    torch.cuda.set_device(local_rank)  # this leg runs on a worker thread (run_with_deadline): the current device is per thread
+    steps = 20
+    out = {"world_size": world, "note": "no scaling curve has been measured on distinct GPUs before this run: the 8-GPU node is the driver's"}
 
-        def step():
-            core.set_source_cloud(src); core.find_source_neighbors(20); core.calculate_source_covariances(capi.REG_PLANE)
-            return core.align()
+    def barrier():
+        dist.barrier(); torch.cuda.synchronize()
 
-        def timed():
-            step()
-            dist.barrier(); torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            for _ in range(steps):
-                r = step()
-            core.synchronize()
-            dist.barrier()
-            el = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
-            dist.all_reduce(el, op=dist.ReduceOp.MAX)
-            return float(el.item()) / steps, r
+    def max_over_ranks(x):
+        t = torch.tensor([x], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
 
-        # one GPU (every rank does the same, unsharded)
-        core.set_target_cloud(tgt); core.find_target_neighbors(20); core.calculate_target_covariances(capi.REG_PLANE); core.create_target_voxelmap()
-        single_s, r1 = timed()
-        # sharded over the ranks
-        sh = D.ShardedVGICP(core, rank, world, dist, collective="peer")
-        sh.attach_peers(len(tgt), device_index=local_rank)
+    def timed(prepare_source, align, sync):
+        """(ms per step, ms of the source stage, ms of the align stage, last result) -- max over the ranks"""
+        prepare_source(); r = align(); sync()
+        barrier()
+        t_src = t_al = 0.0
         t0 = time.perf_counter()
-        sh.set_target(tgt)
-        core.synchronize()
-        map_ms = (time.perf_counter() - t0) * 1e3
-        shard_s, r = timed()
-        evals = r["num_linearize"] + r["num_error_evals"]
+        for _ in range(steps):
+            ta = time.perf_counter()
+            prepare_source(); sync()
+            tb = time.perf_counter()
+            r = align(); sync()
+            t_src += tb - ta
+            t_al += time.perf_counter() - tb
         dist.barrier()
-        core.peer_detach()
-        core.close()
-        return {"workload": "synthetic 1M-point map <-> 100k-point scan, DIRECT7, res 0.5: scan-to-map step (host scan in, k-NN, covariances, align) over %d GPUs, replicated target map" % world,
-                "registrations_per_sec": round(1.0 / shard_s, 3), "ms_per_registration": round(shard_s * 1e3, 4),
-                "single_gpu_ms_per_registration": round(single_s * 1e3, 4), "speedup_vs_single_gpu": round(single_s / shard_s, 3),
-                "evaluations_per_align": evals, "kernel_launches_lm": r["num_launches"], "sharded_map_preparation_ms": round(map_ms, 2),
-                "converged": bool(r["converged"]) and bool(r1["converged"]), "pose_equals_single_gpu": bool(np.abs(r["T"] - r1["T"]).max() < 1e-9),
-                "collective": sh.collective_description()}
-    except Exception as e:  # the headline number must not depend on this leg
-        return {"error": repr(e)}
+        el = max_over_ranks(time.perf_counter() - t0)
+        return el / steps * 1e3, max_over_ranks(t_src) / steps * 1e3, max_over_ranks(t_al) / steps * 1e3, r
+
+    cases = [("map1m_scan100k", (1_000_000, 100_000, 44, 150.0), capi.DIRECT7, "synthetic 1M-point map <-> 100k-point scan, DIRECT7, res 0.5 (BASELINE configs[4])"),
+             ("synth100k", (100_000, 100_000, 42, 60.0), capi.DIRECT27, "synthetic 100k <-> 100k, DIRECT27, res 0.5")]
+    for name, (n_t, n_s, seed, extent), search, desc in cases:
+        res = {"workload": desc + ": scan-to-map step (host scan in, k-NN k = 20, PLANE covariances, align) over %d GPUs, replicated target voxel map" % world}
+        try:
+            tgt, src, _ = workloads.synthetic_pair(n_t, n_s, seed=seed, extent=extent)
+
+            def fresh():
+                c = capi.VGICPCore(local_rank)
+                c.set_resolution(0.5); c.set_neighbor_search_method(search)
+                return c
+
+            # ---- one GPU (every rank does the same, unsharded) ----
+            c1 = fresh()
+            c1.set_target_cloud(tgt); c1.find_target_neighbors(20); c1.calculate_target_covariances(capi.REG_PLANE); c1.create_target_voxelmap()
+
+            def src1():
+                c1.set_source_cloud(src); c1.find_source_neighbors(20); c1.calculate_source_covariances(capi.REG_PLANE)
+            ms1, ms1_src, ms1_al, r1 = timed(src1, c1.align, c1.synchronize)
+            c1.close()
+            res["single_gpu"] = {"ms_per_registration": round(ms1, 4), "source_stage_ms": round(ms1_src, 4), "align_ms": round(ms1_al, 4), "converged": bool(r1["converged"])}
+            for coll in ("peer", "rccl"):
+                try:
+                    c = fresh()
+                    sh = D.ShardedVGICP(c, rank, world, dist, collective=coll)
+                    t0 = time.perf_counter()
+                    if coll == "peer":
+                        sh.attach_peers(max(n_t, n_s), device_index=local_rank)   # (runs the mailbox self-check across the devices)
+                    else:
+                        uid = [capi.comm_unique_id() if rank == 0 else None]
+                        dist.broadcast_object_list(uid, src=0)
+                        sh.init_device_collective(uid[0])
+                    attach_ms = (time.perf_counter() - t0) * 1e3
+                    t0 = time.perf_counter()
+                    sh.set_target(tgt)
+                    c.synchronize()
+                    map_ms = (time.perf_counter() - t0) * 1e3
+                    ms, ms_src, ms_al, r = timed(lambda: sh.set_source(src), sh.align, c.synchronize)
+                    res[coll] = {"registrations_per_sec": round(1e3 / ms, 3), "ms_per_registration": round(ms, 4), "source_stage_ms": round(ms_src, 4), "align_ms": round(ms_al, 4),
+                                 "speedup_vs_single_gpu": round(ms1 / ms, 3), "align_speedup_vs_single_gpu": round(ms1_al / ms_al, 3),
+                                 "evaluations_per_align": r["num_linearize"] + r["num_error_evals"], "kernel_launches_lm": r["num_launches"],
+                                 "attach_ms": round(attach_ms, 2), "sharded_map_preparation_ms": round(map_ms, 2), "converged": bool(r["converged"]),
+                                 "pose_equals_single_gpu": bool(np.abs(r["T"] - r1["T"]).max() < 1e-9), "max_abs_pose_difference": float(np.abs(r["T"] - r1["T"]).max()),
+                                 "collective": sh.collective_description()}
+                    dist.barrier()
+                    if coll == "peer":
+                        c.peer_detach()
+                    else:
+                        c.comm_destroy()
+                    c.close()
+                except Exception as e:  # one route failing must not hide the other
+                    res[coll] = {"error": repr(e)}
+        except Exception as e:  # the headline number must not depend on this leg
+            res["error"] = repr(e)
+        out[name] = res
+    return out
 
 
 def concurrent_leg(args, local_rank, d_clouds, n_pts, res, search, K):
@@ -323,24 +426,45 @@ def run_stream(args, steps, warmup, cpu_loops=15, frames_n=10):
     ndt.synchronize(); torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     ndt.profile_enable(False); vg.profile_enable(False)
-    stage_ms, roofline = {}, None
+    stage_ms, roofline, roofline_ds = {}, None, None
     n_raw = int(np.mean([len(f) for f in frames]))
     n_ds = state["n_ds"] // max(steps, 1)
+    # sizes of the last registration for the byte model: after the swap at the end of a step its SOURCE voxel map is the target map
+    n_c = ndt.get_num_correspondences()
+    n_sv = ndt.get_num_voxels("target")
+    n_tv = ndt.get_num_voxels("source")
     if profile:
         for cls in ("cost", "voxelmap"):
             ms, n = ndt.profile_get(cls)
             if n:
                 stage_ms[cls] = {"total_ms": round(ms, 3), "launches": n, "avg_us": round(ms / n * 1e3, 3)}
+        if "cost" in stage_ms:
+            # the DOMINANT kernel of this loop: the LM kernel's NDT D2D instantiation. SURVEY 8(d) with the source voxels as the source
+            # elements: B_eval = N_sv * 48 + N_sv * N_off * 16 + N_c * 52 + 172 per evaluation; one persistent launch runs them all
+            ms, n = ndt.profile_get("cost")
+            evals = n_eval / max(n_launch, 1)
+            bytes_eval = n_sv * 48 + n_sv * 7 * 16 + n_c * 52 + 172
+            b = bytes_eval * evals
+            ach = b / (ms / n * 1e-3) / 1e9
+            traffic, traffic_src = pmc_traffic("lidar_stream_cost") if args.precision == "fp64" else (None, "PMC passes exist for the fp64 kernel only")
+            sq = ((pmc_entry("lidar_stream_cost")[0] or {}).get("sq") or {}) if traffic is not None else {}
+            roofline = {"kernel": "cost_kernel<%s,NDT_D2D,persistent>" % ("double" if args.precision == "fp64" else "float"), "bound": "hbm", "achieved": round(ach, 2), "peak": 8000.0,
+                        "unit": "GB/s", "frac": round(ach / 8000.0, 5), "traffic": traffic, "traffic_source": traffic_src,
+                        "valu_busy_frac_of_wave_cycles": sq.get("valu_busy_frac_of_wave_cycles"), "valu_pipe_utilisation_of_chip": sq.get("valu_pipe_utilisation_of_chip"),
+                        "algorithmic_bytes_per_launch": int(b), "algorithmic_bytes_per_evaluation": int(bytes_eval), "evaluations_per_launch": round(evals, 3),
+                        "source_voxels": n_sv, "target_voxels": n_tv, "correspondences": n_c, "avg_launch_us": round(ms / n * 1e3, 3), "launches": n,
+                        "note": "a few thousand source voxels x 7 offsets: ~%d trips of a barrier-separated latency chain (per trip ~5 us of one-item-per-thread main loop "
+                                "+ ~6 us of hand-offs and LM step, tools/persist_timing.py --ndt); the working set (~1 MB) never leaves the caches" % round(evals / 2 + 1)}
         ms, n = vg.profile_get()
         if n:
             stage_ms["downsample"] = {"total_ms": round(ms, 3), "launches": n, "avg_us": round(ms / n * 1e3, 3)}
-            # the stage with real bytes in this loop: the filter. Algorithmic bytes: read N x 12 B, write M x 12 B
+            # second entry: the stage with real bytes in this loop, the filter. Algorithmic bytes: read N x 12 B, write M x 12 B
             b = n_raw * 12 + n_ds * 12
             ach = b / (ms / n * 1e-3) / 1e9
-            roofline = {"kernel": "voxel-grid filter (ApproximateVoxelGrid, 6 fused launches: slot histogram, slot scan, scatter, mark, trigger scan, emit)", "bound": "hbm", "achieved": round(ach, 2), "peak": 8000.0,
-                        "unit": "GB/s", "frac": round(ach / 8000.0, 5), "traffic": pmc_traffic("lidar_stream_downsample"), "algorithmic_bytes_per_launch": b,
-                        "avg_launch_us": round(ms / n * 1e3, 3), "launches": n,
-                        "note": "1.4 MB of input per frame: launch/latency bound (a chain of dependent small kernels), not HBM bound"}
+            roofline_ds = {"kernel": "voxel-grid filter (ApproximateVoxelGrid, 6 fused launches: slot histogram, slot scan, scatter, mark, trigger scan, emit)", "bound": "hbm", "achieved": round(ach, 2),
+                           "peak": 8000.0, "unit": "GB/s", "frac": round(ach / 8000.0, 5), "traffic": None, "algorithmic_bytes_per_launch": b,
+                           "avg_launch_us": round(ms / n * 1e3, 3), "launches": n,
+                           "note": "1.4 MB of input per frame: launch/latency bound (a chain of six dependent small kernels), not HBM bound; `traffic`: a per-chain PMC figure is not collected"}
     cpu = None
     if not args.no_cpu_baseline:
         from oracle import oracle as O
@@ -415,7 +539,7 @@ def run_stream(args, steps, warmup, cpu_loops=15, frames_n=10):
                 "method": "NDT_D2D", "neighbor_search": "DIRECT7", "voxel_resolution": 1.0, "parallelism": "single GPU"},
             "per_registration": {"cost_evaluations": n_eval / steps, "kernel_launches_lm": n_launch / steps, "converged": bool(state["last"]["converged"])},
             "accuracy": ({"max_frame_translation_error_m": round(float(max(errs)), 4), "mean_frame_translation_error_m": round(float(np.mean(errs)), 4)} if errs else None),
-            "roofline": roofline, "cpu_baseline": cpu, "stages": stage_ms}
+            "roofline": roofline, "roofline_downsample": roofline_ds, "cpu_baseline": cpu, "stages": stage_ms}
 
 
 def run_registration(args, workload, cov, search_name, steps, warmup, local_rank=0, dist=None, dev=None, world=1, rank=0, headline=False, cpu_budget=12.0, cpu=True):
@@ -555,22 +679,24 @@ def run_registration(args, workload, cov, search_name, steps, warmup, local_rank
             bytes_launch = bytes_eval * evals_per_launch
             achieved = bytes_launch / avg_s / 1e9
             persistent = n_launch == steps
-            key = workload + ("_rbf" if cov == "rbf" else "") + ("_persistent" if persistent else "")
+            key = workload + ("_rbf" if cov == "rbf" else "") + "_cost"
             kname = "cost_kernel<%s,VGICP,%s>" % ("double" if args.precision == "fp64" else "float", "persistent" if persistent else "per-transition")
+            traffic, traffic_src = pmc_traffic(key) if (persistent and args.precision == "fp64") else (None, "PMC passes exist for the persistent fp64 kernel only")
+            sq = ((pmc_entry(key)[0] or {}).get("sq") or {}) if traffic is not None else {}
             roofline = {"kernel": kname, "bound": "hbm", "achieved": round(achieved, 2),
-                        "peak": 8000.0, "unit": "GB/s", "frac": round(achieved / 8000.0, 5), "traffic": pmc_traffic(key), "algorithmic_bytes_per_launch": int(bytes_launch),
+                        "peak": 8000.0, "unit": "GB/s", "frac": round(achieved / 8000.0, 5), "traffic": traffic, "traffic_source": traffic_src,
+                        "valu_busy_frac_of_wave_cycles": sq.get("valu_busy_frac_of_wave_cycles"), "valu_pipe_utilisation_of_chip": sq.get("valu_pipe_utilisation_of_chip"),
+                        "algorithmic_bytes_per_launch": int(bytes_launch),
                         "algorithmic_bytes_per_evaluation": bytes_eval, "evaluations_per_launch": round(evals_per_launch, 3),
                         "avg_launch_us": round(avg_s * 1e6, 3), "launches": cost_n,
                         "note": ("17k-point working set (~3 MB) is L2/Infinity-Cache resident and the fused trips share their loads between the trial evaluation and the next "
                                  "linearisation: this kernel is bound by the latency chain of its %d barrier-separated trips, not by HBM; `traffic` (PMC) is what actually reaches HBM"
                                  % round((n_err / steps) + 1) if workload == "bundled17k"
-                                 else "launch average over the LM launches of the timed region; `traffic` (PMC, profiles/r02_pmc_cost_kernel.json) is what reached HBM")}
-    if cov == "knn" and "knn" in stage_ms:
-        n = n_src
-        flops = 8.0 * n * n
-        # the k-NN is culled (it evaluates ~10 tiles x 64 pairs per query, not N pairs): this is the rate a full
-        # 8*N^2-flop brute-force sweep would need to match it, not a VALU utilisation figure
-        stage_ms["knn"]["bruteforce_equivalent_tflops"] = round(flops / (stage_ms["knn"]["avg_us"] * 1e-6) / 1e12, 3)
+                                 else "launch average over the LM launches of the timed region; `traffic` (PMC) is what reached HBM")}
+    if cov == "knn" and "knn" in stage_ms:  # VALU-bound stage -> VALU utilisation (PMC) + pair-evaluation rate
+        stage_ms["knn"]["roofline"] = valu_roofline(workload + "_knn", "knn_tiled1_kernel", stage_ms["knn"]["avg_us"], n_src, n_src)
+    if cov == "rbf" and "rbf" in stage_ms:
+        stage_ms["rbf"]["roofline"] = valu_roofline(workload + "_rbf_rbf", "cov_rbf1_kernel (+ cov_rbf_finish_kernel)", stage_ms["rbf"]["avg_us"], n_src, n_src)
 
     cpu_res = None
     if cpu and not args.no_cpu_baseline and world == 1:
@@ -656,8 +782,8 @@ def main():
     if rank != 0:
         finish(dist, sharded_hung)
         return
-    if sharded is not None:
-        out["sharded"] = sharded
+    if sharded is not None:  # (leads the line: with N > 1 `value` is N independent registration streams -- weak scaling by construction; THIS is the exchange path)
+        out = {"metric": out["metric"], "value": out["value"], "unit": out["unit"], "n_gpus": out["n_gpus"], "sharded": sharded, **{k: v for k, v in out.items() if k not in ("metric", "value", "unit", "n_gpus")}}
 
     # ---- the other single-GPU configurations of BASELINE.json, time-boxed ----
     default_headline = args.workload == "bundled17k" and args.cov == "knn" and world == 1
@@ -676,6 +802,11 @@ def main():
                     configs[name] = run_registration(args, wl, cov, search, steps, warmup, local_rank, cpu_budget=cpu_s)
             except Exception as ex:  # the headline must not depend on an extra configuration
                 configs[name] = {"error": repr(ex)}
+        if default_headline and not args.no_cpu_baseline and time.perf_counter() - T_START <= args.time_box + 30:
+            try:
+                configs["cpu_fastvgicp_direct1"] = cpu_config0()
+            except Exception as ex:
+                configs["cpu_fastvgicp_direct1"] = {"error": repr(ex)}
         out["configs"] = configs
     out["bench_wall_s"] = round(time.perf_counter() - T_START, 1)
     print(json.dumps(out), flush=True)

@@ -489,6 +489,11 @@ class NDTCore(_Core):
     def create_source_voxelmap(self):
         self._call("create_source_voxelmap")
 
+    def get_num_voxels(self, which):
+        n = C.c_int(0)
+        self._call("get_num_voxels", 0 if which == "source" else 1, C.byref(n))
+        return n.value
+
     def get_voxelmap(self, which):
         w = 1 if which == "target" else 0
         n = C.c_int(0)
