@@ -429,10 +429,16 @@ def run_stream(args, steps, warmup, cpu_loops=15, frames_n=10):
     stage_ms, roofline, roofline_ds = {}, None, None
     n_raw = int(np.mean([len(f) for f in frames]))
     n_ds = state["n_ds"] // max(steps, 1)
-    # sizes of the last registration for the byte model: after the swap at the end of a step its SOURCE voxel map is the target map
+    # sizes of one registration for the byte model (outside the timed region: one more frame, no swap afterwards)
+    i = seq[(state["k"] + 1) % len(seq)]
+    ptr, n = vg.filter_device(d_frames[i].data_ptr(), len(frames[i]), 0.25, vg.APPROXIMATE)
+    ndt.set_source_cloud_device(ptr, n, 3)
+    ndt.align()
     n_c = ndt.get_num_correspondences()
-    n_sv = ndt.get_num_voxels("target")
-    n_tv = ndt.get_num_voxels("source")
+    n_sv = ndt.get_num_voxels("source")
+    n_tv = ndt.get_num_voxels("target")
+    ndt.swap_source_and_target()
+    state["k"] += 1
     if profile:
         for cls in ("cost", "voxelmap"):
             ms, n = ndt.profile_get(cls)

@@ -9,6 +9,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <atomic>
+#include <chrono>
 #include <cstring>
 #include <functional>
 #include <map>
@@ -146,11 +147,19 @@ std::atomic<int> g_live_engines{0};    // engine handles alive in this process t
 struct SlotPool {
   std::mutex mu;
   int reserved[16] = {0}, active[16] = {0}, recent[16] = {0}, calm[16] = {0};
-  static constexpr int DECAY_AFTER = 32;  // releases in a row that saw less concurrency than the estimate before the estimate drops by one
+  std::chrono::steady_clock::time_point last_contention[16];
+  static constexpr int DECAY_AFTER = 32;       // releases in a row that saw less concurrency than the estimate before the estimate drops by one
+  static constexpr int QUIET_RESET_MS = 20;    // no overlapping align / refusal for this long: the burst is over, the estimate starts again from what is active now
   int acquire(int dev, int cap, int want) {  // -> granted workgroups (0: use the multi-launch route)
     std::lock_guard<std::mutex> lk(mu);
     dev &= 15;
+    const auto now = std::chrono::steady_clock::now();
     active[dev]++;
+    // A burst of concurrent aligns (a 4-stream leg of a benchmark, a batch of parallel requests) must not throttle the lone aligns that
+    // follow it: once nothing has overlapped for QUIET_RESET_MS the estimate is what is active right now. (Round 2 never forgot --
+    // a leak; decaying only per calm release kept a lone handle at cap / 4 for its next ~100 aligns.)
+    if (active[dev] > 1) last_contention[dev] = now;
+    else if (recent[dev] > 1 && now - last_contention[dev] > std::chrono::milliseconds(QUIET_RESET_MS)) { recent[dev] = 1; calm[dev] = 0; }
     recent[dev] = std::max(recent[dev], active[dev]);
     static const int max_split = [] { const char* v = getenv("FVH_SLOT_MAX_SPLIT"); return v ? std::max(1, atoi(v)) : 4; }();
     const int share = std::max(1, cap / std::max(1, std::min(recent[dev], max_split)));
@@ -161,6 +170,7 @@ struct SlotPool {
       // the bump: the next grants shrink so that this caller gets its share on the retry; it decays slowly in release().
       active[dev]--;
       calm[dev] = 0;
+      last_contention[dev] = now;
       return 0;
     }
     reserved[dev] += grant;
@@ -178,8 +188,8 @@ struct SlotPool {
     active[dev]--;
     // The estimate of the concurrency decays slowly: host threads spend half their time between aligns, so `active` at a release
     // under-reads the contention. (Dropping it at every calm release made four 474-workgroup aligns oscillate: shares grew back to
-    // cap / 2, the third thread was refused, and 40 % of its aligns took the multi-launch route.) A lone handle is back at the
-    // full grid after 3 x DECAY_AFTER aligns -- ~30 ms -- instead of never (round 2).
+    // cap / 2, the third thread was refused, and 40 % of its aligns took the multi-launch route.) Under SUSTAINED but lower concurrency
+    // the estimate comes down one step per DECAY_AFTER calm releases; once nothing overlaps at all, acquire() resets it (QUIET_RESET_MS).
     if (recent[dev] > active[dev] + 1) {
       if (++calm[dev] >= DECAY_AFTER) { recent[dev]--; calm[dev] = 0; }
     } else {

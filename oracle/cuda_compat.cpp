@@ -401,13 +401,12 @@ struct VGICPCuda : CompatBase {
     return (double)s.e;
   }
   double linearize(const Iso3& T, double* H, double* b) override {  // fast_vgicp_cuda_impl.hpp:170-173
-    num_linearize++;
     std::vector<V3f> src(input->size());
     for (size_t i = 0; i < src.size(); i++) src[i] = V3f{{input->pt(i)[0], input->pt(i)[1], input->pt(i)[2]}};
     find(src, *voxelmap, T);
     return cost(T, H, b);
   }
-  double compute_error(const Iso3& T) override { num_error_evals++; return cost(T, nullptr, nullptr); }  // :176-178
+  double compute_error(const Iso3& T) override { return cost(T, nullptr, nullptr); }  // :176-178
 };
 
 // NDTCuda (ndt_cuda_impl.hpp) on NDTCudaCore (ndt_cuda.cu)
@@ -446,14 +445,13 @@ struct NDTCuda : CompatBase {
     return (double)s.e;
   }
   double linearize(const Iso3& T, double* H, double* b) override {  // ndt_cuda_impl.hpp:82-85 + ndt_cuda.cu:142-159
-    num_linearize++;
     std::vector<V3f> src;
     if (distance_mode == D2D) src = source_voxelmap->means;
     else { src.resize(input->size()); for (size_t i = 0; i < src.size(); i++) src[i] = V3f{{input->pt(i)[0], input->pt(i)[1], input->pt(i)[2]}}; }
     find(src, *target_voxelmap, T);
     return cost(T, H, b);
   }
-  double compute_error(const Iso3& T) override { num_error_evals++; return cost(T, nullptr, nullptr); }
+  double compute_error(const Iso3& T) override { return cost(T, nullptr, nullptr); }
 };
 
 }  // namespace cc

