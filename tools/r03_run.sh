@@ -1,15 +1,14 @@
 set -x
-O=gpurun_out/r03j
+O=gpurun_out/r03l
 mkdir -p $O
-timeout 900 python -m pytest tests -m gpu -q 2>&1 | tail -40 > $O/pytest.txt
-timeout 600 python bench.py > $O/bench.json 2> $O/bench.err
-tail -30 $O/pytest.txt; tail -3 $O/bench.err; python - <<PY
+timeout 300 python -m pytest tests/test_gpu_cuda_compat.py tests/test_gpu_robustness.py -m gpu -q 2>&1 | tail -15 > $O/pytest.txt
+timeout 200 python bench.py --precision fp32 --configs none --no-cpu-baseline --streams 1 > $O/bench_fp32.json 2> $O/bench_fp32.err
+timeout 200 python bench.py --configs none --no-cpu-baseline --streams 1 > $O/bench_fp64.json 2> $O/bench_fp64.err
+timeout 200 python bench.py --workload lidar_stream --precision fp32 --no-cpu-baseline > $O/stream_fp32.json 2> $O/stream_fp32.err
+tail -8 $O/pytest.txt
+python - <<PY
 import json
-d = json.load(open("$O/bench.json"))
-print("headline", d["value"], d["ms_per_step"], "roofline", d["roofline"]["frac"], d["roofline"]["avg_launch_us"], "traffic", d["roofline"]["traffic"], d["roofline"].get("traffic_source"), "cpu", d["cpu_baseline"]["value"], d["cpu_baseline"]["cores"], "wall", d.get("bench_wall_s"))
-for k, v in (d.get("configs") or {}).items():
-    if "value" in v:
-        print(k, v["value"], v.get("ms_per_step"), "roofline", (v.get("roofline") or {}).get("frac"), (v.get("roofline") or {}).get("avg_launch_us"), "cpu", (v.get("cpu_baseline") or {}).get("value"), (v.get("cpu_baseline") or {}).get("cores"), v.get("this_box_at_16_threads"))
-    else:
-        print(k, v)
+for n in ("bench_fp32", "bench_fp64", "stream_fp32"):
+    d = json.load(open("$O/%s.json" % n))
+    print(n, d["value"], d["dtype"], (d.get("roofline") or {}).get("avg_launch_us"), d.get("fitness_score"), (d.get("stages") or {}).get("cost"))
 PY
