@@ -3,7 +3,7 @@
     python tools/pmc_collect.py out.json entry:kernel_substr:fetch_csv:write_csv:sq_csv [...]
 (any csv may be '-'). Per entry: HBM bytes per launch (FETCH_SIZE / WRITE_SIZE, separate passes as MI355X_MICROARCH.md prescribes:
 both in KiB, FETCH_SIZE doubled on gfx950), and from the SQ pass: VALU instructions per wave, VALU-busy / waiting fractions of the
-wave cycles, and the chip-level VALU pipe utilisation  SQ_ACTIVE_INST_VALU * 4 / (GRBM_GUI_ACTIVE * #SIMDs)  (quad-cycle counter;
+wave cycles, and the chip-level VALU pipe utilisation  SQ_ACTIVE_INST_VALU * 4 / (GRBM_GUI_ACTIVE / 8 XCDs * #SIMDs)  (quad-cycle counter;
 one SIMD runs one VALU instruction at a time, so the sum over waves is the pipe's busy time).
 The file is stamped with the git commit and a hash of fast_gicp_amd/csrc/: bench.py refuses to quote it once the kernels changed."""
 import csv
@@ -16,6 +16,7 @@ from collections import defaultdict
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SIMDS = 256 * 4
+XCDS = 8  # GRBM_GUI_ACTIVE comes back SUMMED over the 8 XCDs (2.6 M "cycles" for a 135 us kernel = 8 x 2.44 GHz): one XCD's count is the chip's clock
 
 
 def csrc_sha():
@@ -69,8 +70,9 @@ def main(out, *specs):
                        "waiting_frac_of_wave_cycles": round(m.get("SQ_WAIT_ANY", float("nan")) / wc, 4),
                        "issue_stall_frac_of_wave_cycles": round(m.get("SQ_WAIT_INST_ANY", float("nan")) / wc, 4)}
             if m.get("GRBM_GUI_ACTIVE"):
-                e["sq"]["valu_pipe_utilisation_of_chip"] = round(m.get("SQ_ACTIVE_INST_VALU", float("nan")) * 4.0 / (m["GRBM_GUI_ACTIVE"] * SIMDS), 4)
-                e["sq"]["effective_clock_ghz"] = None if not dur else round(m["GRBM_GUI_ACTIVE"] / dur, 3)
+                e["sq"]["valu_pipe_utilisation_of_chip"] = round(m.get("SQ_ACTIVE_INST_VALU", float("nan")) * 4.0 / (m["GRBM_GUI_ACTIVE"] / XCDS * SIMDS), 4)
+                e["sq"]["effective_clock_ghz"] = None if not dur else round(m["GRBM_GUI_ACTIVE"] / XCDS / dur, 3)
+                e["sq"]["cycles_per_valu_instruction"] = round(m.get("SQ_ACTIVE_INST_VALU", float("nan")) * 4.0 / max(m.get("SQ_INSTS_VALU", 1), 1), 2)
         res[name] = e
     json.dump(res, open(out, "w"), indent=1)
     print(json.dumps(res, indent=1))
