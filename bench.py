@@ -136,8 +136,13 @@ def valu_roofline(key, kernel, avg_us, n_queries, n_candidates):
     e, src = pmc_entry(key)
     sq = (e or {}).get("sq") or {}
     util = sq.get("valu_pipe_utilisation_of_chip")
-    return {"kernel": kernel, "bound": "valu", "achieved": None if util is None else round(util * 78.6, 3), "peak": 78.6, "unit": "T lane-op/s (256 CUs x 4 SIMD-32 x 2.4 GHz)",
-            "frac": util, "valu_busy_frac_of_wave_cycles": sq.get("valu_busy_frac_of_wave_cycles"), "waiting_frac_of_wave_cycles": sq.get("waiting_frac_of_wave_cycles"),
+    insts, t_us = (sq.get("counters_per_launch") or {}).get("SQ_INSTS_VALU"), sq.get("avg_launch_us_in_this_pass")
+    rate = None if not insts or not t_us else round(insts * 64 / (t_us * 1e-6) / 1e12, 3)
+    return {"kernel": kernel, "bound": "valu", "achieved": rate, "peak": 78.6, "unit": "T lane-op/s (VALU instructions x 64 lanes per second; peak = 256 CUs x 4 SIMD-32 x 2.4 GHz)",
+            "frac": util, "frac_definition": "VALU pipe busy: SQ_ACTIVE_INST_VALU x 4 / (GRBM_GUI_ACTIVE / 8 XCDs x 1024 SIMDs) -- the share of all SIMD cycles of the launch in which a VALU "
+                                             "instruction occupied the pipe (%s cycles per instruction in this mix: transcendental, 64-bit and compare instructions take more than the 2 of a plain fp32 op)"
+                                             % sq.get("cycles_per_valu_instruction"),
+            "valu_busy_frac_of_wave_cycles": sq.get("valu_busy_frac_of_wave_cycles"), "waiting_frac_of_wave_cycles": sq.get("waiting_frac_of_wave_cycles"),
             "valu_insts_per_query": sq.get("valu_insts_per_wave"), "counters_source": src,
             "pair_evaluations_per_sec_full_sweep_equivalent": round(float(n_queries) * n_candidates / (avg_us * 1e-6), 1),
             "note": "one query per wave, culled by two levels of tile boxes: the sweep visits ~10 tiles x 64 candidates per query, so the full-sweep-equivalent rate is what a "

@@ -73,6 +73,8 @@ struct VoxelMapDev {
   double res = 1.0;
   unsigned capacity = 0;
   DevBuf table, acc, occupied, compact_pts, compact_cov;
+  DevBuf bitmap, grid;    // occupancy bitmap of a large map + its VmGrid (kernels_voxelmap.hpp); has_bitmap: built for the live map
+  bool has_bitmap = false;
   DevBuf keys[2];   // voxel keys, double buffered: keys[cur] belongs to the live map, the other one is what the next build fills
   DevBuf counters;  // 2 sets of 16 ints, [0] num_voxels [1] dropped; set `cur` belongs to the live map
   int cur = 0;
@@ -87,8 +89,8 @@ struct VoxelMapDev {
   std::vector<uint4> h_table;
   std::vector<int> h_occupied;
   std::unordered_map<int, int> bucket_to_index;
-  void invalidate() { valid = false; host_valid = false; }
-  void release() { table.release(); acc.release(); occupied.release(); compact_pts.release(); compact_cov.release(); counters.release(); keys[0].release(); keys[1].release(); clean_cap = 0; }
+  void invalidate() { valid = false; host_valid = false; has_bitmap = false; }
+  void release() { table.release(); acc.release(); occupied.release(); compact_pts.release(); compact_cov.release(); counters.release(); keys[0].release(); keys[1].release(); bitmap.release(); grid.release(); clean_cap = 0; has_bitmap = false; }
 };
 
 struct Profiler {
@@ -756,6 +758,22 @@ int build_voxelmap(Engine* e, const CloudDev& c, VoxelMapDev& vm, double res, bo
                                                                         want_compact ? vm.compact_pts.as<float4>() : nullptr, want_compact ? vm.compact_cov.as<float4>() : nullptr,
                                                                         vm.keys[vm.cur].as<unsigned long long>(), vm.counters.as<int>() + 16 * vm.cur);
       vm.clean_cap = cap;
+      // large map: occupancy bitmap over the bounding box of its voxels (kernels_voxelmap.hpp) -- the LM kernel answers its misses
+      // from these cache-resident bits instead of a 64-byte HBM sector per probe. Four small launches after the finalize pass; maps
+      // of this size are built once per localisation run, not once per registration.
+      static const int bitmap_min = [] { const char* v = getenv("FVH_BITMAP_MIN_POINTS"); return v ? atoi(v) : 300000; }();
+      static const size_t bitmap_bytes = [] { const char* v = getenv("FVH_BITMAP_MAX_BYTES"); return v ? (size_t)atoll(v) : (size_t)(32u << 20); }();
+      if (c.n >= bitmap_min && bitmap_bytes >= 8) {
+        HIP_OR_FAIL(e, vm.bitmap.ensure(bitmap_bytes));
+        HIP_OR_FAIL(e, vm.grid.ensure(sizeof(VmGrid)));
+        VmGrid* g = vm.grid.as<VmGrid>();
+        vm_grid_init_kernel<<<1, 64, 0, e->stream>>>(g);
+        vm_grid_bounds_kernel<<<64, 256, 0, e->stream>>>(keys, vm.occupied.as<int>(), counters, g);
+        vm_grid_setup_kernel<<<1, 64, 0, e->stream>>>(g, (unsigned long long)(bitmap_bytes / 8));
+        vm_grid_clear_kernel<<<512, 256, 0, e->stream>>>(vm.bitmap.as<unsigned long long>(), g);
+        vm_grid_set_kernel<<<256, 256, 0, e->stream>>>(keys, vm.occupied.as<int>(), counters, g, vm.bitmap.as<unsigned long long>());
+        vm.has_bitmap = true;
+      }
     }
     vm.cur = fill;
   }
@@ -876,6 +894,8 @@ int launch_cost(Engine* e, const CostSource& src, const VoxelMapDev& vm, int hos
   std::memset(&P, 0, sizeof(P));
   P.src_pts = src.pts; P.src_cov = src.cov; P.d_n_src = src.d_n; P.n_src = src.n_upper; P.order = src.order;
   P.table = vm.table.as<uint4>(); P.keys = vm.keys_cur(); P.mask = vm.capacity - 1; P.res = vm.res; P.inv_res = 1.0 / vm.res;
+  P.bitmap = vm.has_bitmap ? vm.bitmap.as<unsigned long long>() : nullptr;
+  P.grid = vm.has_bitmap ? vm.grid.as<VmGrid>() : nullptr;
   const int n_off = src.n_off_override > 0 ? src.n_off_override : e->n_off;
   P.offsets = e->offsets_dev.as<int>(); P.offsets_packed = e->offsets_dev.as<int>() + 3 * (size_t)e->n_off; P.n_off = n_off;
   const CostShape shape = cost_shape(e, src);

@@ -22,6 +22,7 @@
 
 #include "dev_math.hpp"
 #include "kernels_peer.hpp"
+#include "kernels_voxelmap.hpp"
 
 // Contraction only inside one source expression (not across statements, which is hipcc's default "fast"): whether a
 // multiply and an add fuse must not depend on what the optimiser happens to see around them -- the persistent and the
@@ -76,6 +77,8 @@ struct CostParams {
   const uint4* table;                // voxel records (64 B per bucket)
   const unsigned long long* keys;    // voxel keys of the same buckets, dense (kernels_voxelmap.hpp)
   unsigned mask;
+  const unsigned long long* bitmap;  // occupancy bitmap of a large map (kernels_voxelmap.hpp: VmGrid) or null: misses answered without touching the key table
+  const VmGrid* grid;
   double res, inv_res;        // voxel resolution and its correctly rounded reciprocal (host)
   const int* offsets;         // n_off x 3
   const int* offsets_packed;  // n_off x (dx + 512) | (dy + 512) << 10 | (dz + 512) << 20
@@ -852,13 +855,40 @@ __global__ FVH_COST_BOUNDS void cost_kernel(CostParams P) {
       constexpr unsigned long long DEAD_KEY = FVH_EMPTY_KEY - 1;  // no voxel has it (keys use 63 bits): "this lookup does not exist" without a flag register
       // ---- round trip 3: COST_CH independent first probes in flight ----
       if (do_find) {
+        bool live[COST_CH];
 #pragma unroll
         for (int c = 0; c < COST_CH; c++) {
           const int x = cx + (int)(ofp[c] & 1023) - 512, y = cy + (int)((ofp[c] >> 10) & 1023) - 512, z = cz + (int)((ofp[c] >> 20) & 1023) - 512;
-          const bool live = (o_begin + c < o_end) && coord_ok && coord_in_range(x, y, z);
-          key[c] = live ? pack_key(x, y, z) : DEAD_KEY;
+          live[c] = (o_begin + c < o_end) && coord_ok && coord_in_range(x, y, z);
+          key[c] = live[c] ? pack_key(x, y, z) : DEAD_KEY;
+        }
+        bool filtered = false;
+        if (P.bitmap) {  // (kernel argument: uniform) large map: the cache-resident occupancy bits answer the misses -- only guaranteed hits go to the table
+          const VmGrid* gptr = P.grid;
+          asm volatile("" : "+s"(gptr));  // re-read per item: nine scalars must not live across the main loop
+          const VmGrid g = *gptr;
+          if (g.enabled) {  // (0: the map's box did not fit the bitmap budget -- every lookup goes to the table as before)
+            filtered = true;
+            unsigned long long w[COST_CH];
+            unsigned bit[COST_CH];
+#pragma unroll
+            for (int c = 0; c < COST_CH; c++) {
+              unsigned long long word = 0;
+              bit[c] = 0;
+              live[c] = live[c] && vm_grid_locate(g, (unsigned)(key[c] & 0x1FFFFF), (unsigned)((key[c] >> 21) & 0x1FFFFF), (unsigned)((key[c] >> 42) & 0x1FFFFF), word, bit[c]);
+              w[c] = live[c] ? P.bitmap[word] : 0ull;
+            }
+#pragma unroll
+            for (int c = 0; c < COST_CH; c++) {
+              live[c] = live[c] && ((w[c] >> bit[c]) & 1ull);
+              if (!live[c]) key[c] = DEAD_KEY;
+            }
+          }
+        }
+#pragma unroll
+        for (int c = 0; c < COST_CH; c++) {
           slot[c] = hash_slot(key[c], P.mask);
-          k0[c] = P.keys[slot[c]];
+          k0[c] = (filtered && !live[c]) ? FVH_EMPTY_KEY : P.keys[slot[c]];  // (filtered: no load at all; unfiltered: the rare dead lookup reads a valid slot, no branch)
         }
       }
       if (PERSIST) FVH_MT(gen, 3);

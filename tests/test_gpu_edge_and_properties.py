@@ -397,3 +397,51 @@ def test_covariances_for_large_k_match_oracle(O, k):
     err, bound, degenerate = util.cov_error_bound(got, O.covariances_knn(tgt, k, O.PLANE, idx=idx), raw, input_rel=1e-13)
     assert degenerate.sum() <= 5 and np.all(err[~degenerate] <= bound[~degenerate])
     c.close()
+
+
+def test_occupancy_bitmap_changes_nothing_but_the_traffic(tmp_path):
+    """Large maps answer the misses of their DIRECT7 / DIRECT27 probes from a cache-resident occupancy bitmap (one bit per voxel
+    over the map's bounding box) instead of a key-table sector per probe. Forced on for a small map here (FVH_BITMAP_MIN_POINTS=1),
+    and with a budget too small for the box (the grid disables itself and every lookup goes to the table): correspondences, sums
+    and the registration must equal the plain lookups' (counts exactly, sums to rounding) in all three cases, for VGICP and NDT."""
+    import os
+    import subprocess
+    import sys
+    code = r"""
+import sys, numpy as np
+sys.path.insert(0, %r)
+from tests import util
+from fast_gicp_amd import capi
+tgt, src, T = util.synthetic_pair(60000, 20000, seed=11, extent=40.0)
+src = np.vstack([src, [[500.0, 0.0, 0.0], [np.nan, 0.0, 0.0]]]).astype(np.float32)   # far outside the map's box / not finite
+out = {}
+for search in (capi.DIRECT7, capi.DIRECT27):
+    c = capi.VGICPCore(0)
+    c.set_resolution(0.5); c.set_neighbor_search_method(search)
+    c.set_target_cloud(tgt); c.find_target_neighbors(20); c.calculate_target_covariances(3); c.create_target_voxelmap()
+    c.set_source_cloud(src); c.set_source_covariances(np.tile(np.eye(3) * 0.01, (len(src), 1, 1)))
+    e, H, b = c.linearize(T)
+    r = c.align()
+    out["v%%d" %% search] = np.concatenate([[e, c.get_num_correspondences()], H.ravel(), b, r["T"].ravel(), [r["num_error_evals"]]])
+    c.close()
+d = capi.NDTCore(0)
+d.set_resolution(1.0); d.set_neighbor_search_method(capi.DIRECT7); d.set_distance_mode(capi.NDT_D2D)
+d.set_target_cloud(tgt); d.set_source_cloud(src[:-2])
+d.align(); r = d.align()
+out["ndt"] = np.concatenate([r["T"].ravel(), [r["num_error_evals"], d.get_num_correspondences()]])
+np.savez(sys.argv[1], **out)
+""" % util.ROOT
+    res = []
+    for name, env in (("plain", {"FVH_BITMAP_MIN_POINTS": "100000000"}), ("bitmap", {"FVH_BITMAP_MIN_POINTS": "1"}), ("over_budget", {"FVH_BITMAP_MIN_POINTS": "1", "FVH_BITMAP_MAX_BYTES": "64"})):
+        path = str(tmp_path / (name + ".npz"))
+        subprocess.check_call([sys.executable, "-c", code, path], env=dict(os.environ, **env))
+        res.append(np.load(path))
+    # (three processes = three BUILDS of the maps: their fp64 atomics land in another order, and NDT D2D walks its source voxels in
+    # arrival order -- sums agree to rounding, not to the bit; every COUNT must be exact)
+    for k in res[0].files:
+        for other, name in ((res[1], "bitmap"), (res[2], "over budget")):
+            a, b = res[0][k], other[k]
+            assert util.rel_err(a, b) < 1e-9, (k, name, util.rel_err(a, b))
+            counts = [1, -1] if k.startswith("v") else [-2, -1]   # correspondences / error evaluations
+            assert all(a[i] == b[i] for i in counts), (k, name)
+    assert res[0]["v1"][1] > 10000  # (the comparison is not vacuous: tens of thousands of correspondences)

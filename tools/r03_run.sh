@@ -1,14 +1,8 @@
 set -x
-O=gpurun_out/r03l
+O=gpurun_out/r03m
 mkdir -p $O
-timeout 300 python -m pytest tests/test_gpu_cuda_compat.py tests/test_gpu_robustness.py -m gpu -q 2>&1 | tail -15 > $O/pytest.txt
-timeout 200 python bench.py --precision fp32 --configs none --no-cpu-baseline --streams 1 > $O/bench_fp32.json 2> $O/bench_fp32.err
-timeout 200 python bench.py --configs none --no-cpu-baseline --streams 1 > $O/bench_fp64.json 2> $O/bench_fp64.err
-timeout 200 python bench.py --workload lidar_stream --precision fp32 --no-cpu-baseline > $O/stream_fp32.json 2> $O/stream_fp32.err
-tail -8 $O/pytest.txt
-python - <<PY
-import json
-for n in ("bench_fp32", "bench_fp64", "stream_fp32"):
-    d = json.load(open("$O/%s.json" % n))
-    print(n, d["value"], d["dtype"], (d.get("roofline") or {}).get("avg_launch_us"), d.get("fitness_score"), (d.get("stages") or {}).get("cost"))
-PY
+timeout 900 python -m pytest tests -m gpu -q -x 2>&1 | tail -15 > $O/pytest.txt
+timeout 300 python tools/ab_bench.py --workload synth1m --steps 50 default:FVH_BITMAP_MIN_POINTS=100000000 default default:FVH_BITMAP_MIN_POINTS=100000000 default > $O/ab1m.txt 2>&1
+timeout 300 python tools/ab_bench.py --workload synth100k --steps 50 default default:FVH_BITMAP_MIN_POINTS=1 default default:FVH_BITMAP_MIN_POINTS=1 > $O/ab100k.txt 2>&1
+timeout 300 python tools/ab_bench.py --steps 200 default default:FVH_BITMAP_MIN_POINTS=1 default default:FVH_BITMAP_MIN_POINTS=1 > $O/ab17k.txt 2>&1
+tail -6 $O/pytest.txt; cat $O/ab1m.txt $O/ab100k.txt $O/ab17k.txt
