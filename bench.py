@@ -220,7 +220,7 @@ def cpu_config0(budget_s=8.0):
     return r
 
 
-def sharded_leg(args, dist, rank, world, local_rank, dev):
+def sharded_leg(args, dist, rank, world, local_rank, dev, small=False):
     """north_star: "large scans shard by spatial tile across up to 8 GPUs with an RCCL all-reduce of the 6x6 / 6x1 normal equations per
     iteration ... 100 k / 1 M synthetic clouds at 1 / 2 / 4 / 8 GPUs". ONE registration spread over the ranks, for both large configurations
     (BASELINE configs[4]: 1M-point map <-> 100k-point scan, DIRECT7; configs[2]-sized 100k <-> 100k, DIRECT27) and BOTH exchange routes:
@@ -261,6 +261,10 @@ def sharded_leg(args, dist, rank, world, local_rank, dev):
 
     cases = [("map1m_scan100k", (1_000_000, 100_000, 44, 150.0), capi.DIRECT7, "synthetic 1M-point map <-> 100k-point scan, DIRECT7, res 0.5 (BASELINE configs[4])"),
              ("synth100k", (100_000, 100_000, 42, 60.0), capi.DIRECT27, "synthetic 100k <-> 100k, DIRECT27, res 0.5")]
+    routes = ("peer", "rccl")
+    if small:  # test-only (tests/test_gpu_bench_flow.py): the leg's control flow with all ranks on ONE GPU -- small clouds, and no RCCL (it needs a GPU per rank)
+        cases = [("small", (40_000, 20_000, 21, 40.0), capi.DIRECT7, "synthetic 40k <-> 20k, DIRECT7, res 0.5 (control-flow test)")]
+        routes, steps = ("peer",), 3
     for name, (n_t, n_s, seed, extent), search, desc in cases:
         res = {"workload": desc + ": scan-to-map step (host scan in, k-NN k = 20, PLANE covariances, align) over %d GPUs, replicated target voxel map" % world}
         try:
@@ -280,7 +284,7 @@ def sharded_leg(args, dist, rank, world, local_rank, dev):
             ms1, ms1_src, ms1_al, r1 = timed(src1, c1.align, c1.synchronize)
             c1.close()
             res["single_gpu"] = {"ms_per_registration": round(ms1, 4), "source_stage_ms": round(ms1_src, 4), "align_ms": round(ms1_al, 4), "converged": bool(r1["converged"])}
-            for coll in ("peer", "rccl"):
+            for coll in routes:
                 try:
                     c = fresh()
                     sh = D.ShardedVGICP(c, rank, world, dist, collective=coll)
@@ -785,9 +789,9 @@ def main():
     out = run_registration(args, args.workload, args.cov, args.search, args.steps, args.warmup, local_rank, dist, dev, world, rank, headline=True, cpu_budget=args.cpu_seconds)
 
     sharded, sharded_hung = None, False
-    if world > 1 and not share_gpu:
+    if world > 1 and (not share_gpu or os.environ.get("FVH_BENCH_SHARDED_TEST") == "1"):
         # the headline number is already measured: a stuck collective in this extra leg must not take the JSON line with it
-        sharded, sharded_hung = run_with_deadline(lambda: sharded_leg(args, dist, rank, world, local_rank, dev), args.sharded_deadline)
+        sharded, sharded_hung = run_with_deadline(lambda: sharded_leg(args, dist, rank, world, local_rank, dev, small=share_gpu), args.sharded_deadline)
         if sharded_hung:
             sharded = {"error": "sharded leg did not finish within %d s on rank %d" % (args.sharded_deadline, rank)}
     if rank != 0:

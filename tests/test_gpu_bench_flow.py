@@ -1,6 +1,7 @@
 """bench.py's N > 1 control flow (barrier, max over ranks, one JSON line from rank 0) walked on a single-GPU box: both ranks on
-device 0, gloo for the barrier (FVH_BENCH_SHARE_GPU / FVH_BENCH_BACKEND, test-only knobs). The sharded leg (peer-mapped exchange)
-is covered by tests/test_gpu_peer.py; real xGMI scaling is the driver's to measure."""
+device 0, gloo for the barrier (FVH_BENCH_SHARE_GPU / FVH_BENCH_BACKEND, test-only knobs). The sharded leg runs too, in its small
+form (FVH_BENCH_SHARDED_TEST: peer route only -- RCCL needs a GPU per rank): the object must lead the line, carry the single-GPU time
+next to the sharded one, and the sharded pose must equal the single-GPU pose. Real xGMI scaling is the driver's to measure."""
 import json
 import os
 import subprocess
@@ -14,7 +15,7 @@ pytestmark = pytest.mark.gpu
 
 
 def test_two_rank_bench_prints_one_aggregate_line():
-    env = dict(os.environ, FVH_BENCH_SHARE_GPU="1", FVH_BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
+    env = dict(os.environ, FVH_BENCH_SHARE_GPU="1", FVH_BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1", FVH_BENCH_SHARDED_TEST="1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29531",
            os.path.join(util.ROOT, "bench.py"), "--gpus", "2", "--steps", "10", "--warmup", "2", "--no-cpu-baseline", "--configs", "none"]
     p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300, cwd=util.ROOT)
@@ -25,3 +26,9 @@ def test_two_rank_bench_prints_one_aggregate_line():
     assert d["value"] > 0 and abs(d["value"] - 2 * 1e3 / d["ms_per_step"]) <= 1e-3 * d["value"]  # whole-job aggregate = ranks x steps / max time
     assert abs(d["fitness_score"] - 0.198792) < 1e-5
     assert "roofline" in d and d["roofline"]["bound"] in ("hbm", "mfma")
+    assert list(d)[:5] == ["metric", "value", "unit", "n_gpus", "sharded"]  # the exchange path leads the N > 1 line
+    sh = d["sharded"]["small"]
+    assert "error" not in sh and "error" not in sh["peer"], sh
+    assert sh["single_gpu"]["converged"] and sh["peer"]["converged"] and sh["peer"]["pose_equals_single_gpu"], sh
+    assert sh["peer"]["ms_per_registration"] > 0 and sh["peer"]["source_stage_ms"] > 0 and sh["peer"]["align_ms"] > 0
+    assert "rccl" not in sh  # (one GPU: not runnable here)

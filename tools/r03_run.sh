@@ -1,6 +1,7 @@
 set -x
-O=gpurun_out/r03n
+O=gpurun_out/r03o
 mkdir -p $O
-timeout 900 python -m pytest tests -m gpu -q -x 2>&1 | tail -15 > $O/pytest.txt
-timeout 300 python tools/ab_bench.py --workload synth1m --steps 50 default:FVH_COST_CHUNKED_ITEMS=0 default default:FVH_COST_CHUNKED_ITEMS=0 default > $O/ab1m.txt 2>&1
-tail -6 $O/pytest.txt; cat $O/ab1m.txt
+timeout 300 python tools/ab_bench.py --workload synth1m --steps 50 default wg4 default wg4 > $O/ab1m.txt 2>&1
+timeout 300 python tools/ab_bench.py --workload synth100k --steps 50 default wg4 > $O/ab100k.txt 2>&1
+timeout 300 python tools/ab_bench.py --steps 100 default wg4 > $O/ab17k.txt 2>&1
+cat $O/ab1m.txt $O/ab100k.txt $O/ab17k.txt
