@@ -269,6 +269,61 @@ struct Engine {
     }
   } peer;
 
+  // Side stream: swap_source_and_target() rebuilds the target map from a cloud whose data is complete when the stream is known
+  // drained (`quiet`: the last call was an align that returned). The two build kernels are then independent of what the caller
+  // does next -- upload the new source, sort it, search its neighbours, compute its covariances -- and run beside that chain on
+  // `side`; the first call that is not part of that chain (align above all) makes the main stream wait for `side_done`.
+  hipStream_t side = nullptr;
+  hipEvent_t side_done = nullptr;
+  bool side_pending = false;       // a build on `side` the main stream has not been ordered after yet
+  const void* side_reads = nullptr;  // the CloudDev that build reads
+  bool quiet = false, was_quiet = false;  // the main stream had drained when the current API call began (set by align on return)
+  hipStream_t side_stream() {
+    static const bool on = [] { const char* v = getenv("FVH_SIDE_STREAM"); return !v || atoi(v) != 0; }();
+    if (!on || prof.on || comm || peer.attached()) return nullptr;
+    if (!side) {
+      if (hipStreamCreateWithFlags(&side, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); side = nullptr; return nullptr; }
+      if (hipEventCreateWithFlags(&side_done, hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); (void)hipStreamDestroy(side); side = nullptr; return nullptr; }
+    }
+    return side;
+  }
+  int join_side() {
+    if (!side_pending) return FVH_OK;
+    side_pending = false; side_reads = nullptr;
+    // As a rule the build ends long before the source chain on the main stream does, and the host -- which runs ahead of the
+    // GPU here -- can watch for that at no cost: a wait packet on the main stream instead puts ~6 us of queue processing in
+    // front of the LM kernel (kernel trace, profiles/r03_side_stream_knn.md). Bounded: then the packet after all.
+    for (int spins = 0; spins < 400; spins++) {
+      const hipError_t q = hipEventQuery(side_done);
+      if (q == hipSuccess) return FVH_OK;  // (kernels launched from here on see the finished map)
+      if (q != hipErrorNotReady) break;
+    }
+    (void)hipGetLastError();
+    hipError_t e = hipStreamWaitEvent(stream, side_done, 0);
+    return e == hipSuccess ? FVH_OK : hipfail(e, "hipStreamWaitEvent");
+  }
+  // The build is not queued by swap itself, nor behind the upload of the next source: at that point of a registration the GPU is
+  // waiting for the host (kernel trace: 12 us of idle main stream while the host queued the side work). It is kept here and
+  // queued behind the launches of the neighbour search or the covariance pass (after_source_chain_call), which give the host
+  // ~100 us of slack; any call outside the source chain runs it on the main stream, in order (settle).
+  std::function<int(hipStream_t)> deferred;
+  int settle() {
+    if (deferred) {
+      auto f = std::move(deferred);
+      deferred = nullptr;
+      const int rc = f(nullptr);
+      if (rc) return rc;
+    }
+    return join_side();
+  }
+  int after_source_chain_call(int rc) {
+    if (!deferred) return rc;
+    auto f = std::move(deferred);
+    deferred = nullptr;
+    const int rc2 = f(rc == FVH_OK ? side_stream() : nullptr);
+    return rc ? rc : rc2;
+  }
+
   int fail(int code, const std::string& m) { err = m; return code; }
   int hipfail(hipError_t e, const char* what) { err = std::string(what) + ": " + hipGetErrorString(e); return FVH_ERR_HIP; }
 
@@ -307,6 +362,7 @@ struct Engine {
   void shutdown() {
     if (counted) { g_live_engines.fetch_sub(1); counted = false; }
     (void)hipSetDevice(device);
+    if (side) (void)hipStreamSynchronize(side);
     if (stream) (void)hipStreamSynchronize(stream);
     if (comm && g_rccl.CommDestroy) g_rccl.CommDestroy(comm);
     comm = nullptr;
@@ -320,6 +376,8 @@ struct Engine {
     if (upload_done) (void)hipEventDestroy(upload_done);
     if (result_host) (void)hipHostFree(result_host);
     if (stream) (void)hipStreamDestroy(stream);
+    if (side_done) (void)hipEventDestroy(side_done);
+    if (side) (void)hipStreamDestroy(side);
   }
   void peer_detach() {
     for (int i = 0; i < FVH_MAX_PEERS; i++) {
@@ -600,8 +658,15 @@ int find_neighbors(Engine* e, CloudDev& c, int k) {
     if (rc) return rc;
     const Tile t = peer_tile(e, c.n);  // multi-GPU: the queries of this rank's tile only (the whole sorted cloud is the candidate set: an exact, implicit halo)
     ProfScope ps(e, "knn");
-    if (t.hi > t.lo)
-      knn_tiled1_kernel<<<(t.hi - t.lo + 3) / 4, 256, 0, e->stream>>>(c.sorted.as<float4>(), c.bbox.as<float4>(), c.bbox2.as<float4>(), c.n, k, c.nbr.as<int>(), t.lo, t.hi);
+    // small clouds: the kernel lasts as long as its slowest queries, and those are the ones the nearest-first walk shortens;
+    // the throughput-bound sizes hide them behind the other queries and keep the cheaper index-order walk (kernels_cov.hpp)
+    static const int nf_max = [] { const char* v = getenv("FVH_KNN_NEAREST_FIRST_MAX_POINTS"); return v ? atoi(v) : 65536; }();
+    if (t.hi > t.lo) {
+      if (c.n <= nf_max)
+        knn_tiled1_kernel<true><<<(t.hi - t.lo + 3) / 4, 256, 0, e->stream>>>(c.sorted.as<float4>(), c.bbox.as<float4>(), c.bbox2.as<float4>(), c.n, k, c.nbr.as<int>(), t.lo, t.hi);
+      else
+        knn_tiled1_kernel<false><<<(t.hi - t.lo + 3) / 4, 256, 0, e->stream>>>(c.sorted.as<float4>(), c.bbox.as<float4>(), c.bbox2.as<float4>(), c.n, k, c.nbr.as<int>(), t.lo, t.hi);
+    }
   }
   HIP_OR_FAIL(e, hipGetLastError());
   c.k = k;
@@ -715,7 +780,8 @@ int get_nbr_host(Engine* e, CloudDev& c, int* k, int* out) {
 
 // GaussianVoxelMap::create_voxelmap (gaussian_voxelmap.cu:208-257) -- two kernels, no retry loop
 template <int MODE>
-int build_voxelmap(Engine* e, const CloudDev& c, VoxelMapDev& vm, double res, bool want_compact, bool force_safe = false) {
+int build_voxelmap(Engine* e, const CloudDev& c, VoxelMapDev& vm, double res, bool want_compact, bool force_safe = false, hipStream_t on_side = nullptr) {
+  hipStream_t const st = on_side ? on_side : e->stream;
   if (!c.has_pts) return e->fail(FVH_ERR_BAD_STATE, "create_voxelmap: cloud not set");
   if (MODE != 1 && !c.has_cov) return e->fail(FVH_ERR_BAD_STATE, "create_voxelmap: covariances not computed");
   if (!(res > 0)) return e->fail(FVH_ERR_INVALID_ARGUMENT, "create_voxelmap: resolution must be > 0");
@@ -745,16 +811,16 @@ int build_voxelmap(Engine* e, const CloudDev& c, VoxelMapDev& vm, double res, bo
     HIP_OR_FAIL(e, vm.compact_cov.ensure(sizeof(float4) * 2 * (size_t)std::max(c.n, 1)));
   }
   {
-    ProfScope ps(e, "voxelmap");
+    ProfScope ps(e, "voxelmap");  // (never on the side stream: side_stream() is off while profiling)
     const int fill = vm.cur ^ 1;
     unsigned long long* keys = vm.keys[fill].as<unsigned long long>();
     int* counters = vm.counters.as<int>() + 16 * fill;
-    if (vm.clean_cap != cap) vm_clear_kernel<<<(cap * 10 + 255) / 256, 256, 0, e->stream>>>(keys, vm.acc.as<double>(), cap, counters);
+    if (vm.clean_cap != cap) vm_clear_kernel<<<(cap * 10 + 255) / 256, 256, 0, st>>>(keys, vm.acc.as<double>(), cap, counters);
     vm.clean_cap = 0;  // keys[fill] is in use from here on; the finalize pass below makes the OTHER pair clean
     if (c.n) {
-      vm_accumulate_kernel<MODE><<<(c.n + 255) / 256, 256, 0, e->stream>>>(c.pts.as<float4>(), c.cov.as<float4>(), c.n, res, keys, cap - 1, vm.acc.as<double>(), counters + 1,
+      vm_accumulate_kernel<MODE><<<(c.n + 255) / 256, 256, 0, st>>>(c.pts.as<float4>(), c.cov.as<float4>(), c.n, res, keys, cap - 1, vm.acc.as<double>(), counters + 1,
                                                                            coherent_order(c));
-      vm_finalize_kernel<MODE><<<(cap + VM_FIN_THREADS - 1) / VM_FIN_THREADS, VM_FIN_THREADS, 0, e->stream>>>(keys, vm.table.as<uint4>(), cap, vm.acc.as<double>(), counters, vm.occupied.as<int>(),
+      vm_finalize_kernel<MODE><<<(cap + VM_FIN_THREADS - 1) / VM_FIN_THREADS, VM_FIN_THREADS, 0, st>>>(keys, vm.table.as<uint4>(), cap, vm.acc.as<double>(), counters, vm.occupied.as<int>(),
                                                                         want_compact ? vm.compact_pts.as<float4>() : nullptr, want_compact ? vm.compact_cov.as<float4>() : nullptr,
                                                                         vm.keys[vm.cur].as<unsigned long long>(), vm.counters.as<int>() + 16 * vm.cur);
       vm.clean_cap = cap;
@@ -767,17 +833,22 @@ int build_voxelmap(Engine* e, const CloudDev& c, VoxelMapDev& vm, double res, bo
         HIP_OR_FAIL(e, vm.bitmap.ensure(bitmap_bytes));
         HIP_OR_FAIL(e, vm.grid.ensure(sizeof(VmGrid)));
         VmGrid* g = vm.grid.as<VmGrid>();
-        vm_grid_init_kernel<<<1, 64, 0, e->stream>>>(g);
-        vm_grid_bounds_kernel<<<64, 256, 0, e->stream>>>(keys, vm.occupied.as<int>(), counters, g);
-        vm_grid_setup_kernel<<<1, 64, 0, e->stream>>>(g, (unsigned long long)(bitmap_bytes / 8));
-        vm_grid_clear_kernel<<<512, 256, 0, e->stream>>>(vm.bitmap.as<unsigned long long>(), g);
-        vm_grid_set_kernel<<<256, 256, 0, e->stream>>>(keys, vm.occupied.as<int>(), counters, g, vm.bitmap.as<unsigned long long>());
+        vm_grid_init_kernel<<<1, 64, 0, st>>>(g);
+        vm_grid_bounds_kernel<<<64, 256, 0, st>>>(keys, vm.occupied.as<int>(), counters, g);
+        vm_grid_setup_kernel<<<1, 64, 0, st>>>(g, (unsigned long long)(bitmap_bytes / 8));
+        vm_grid_clear_kernel<<<512, 256, 0, st>>>(vm.bitmap.as<unsigned long long>(), g);
+        vm_grid_set_kernel<<<256, 256, 0, st>>>(keys, vm.occupied.as<int>(), counters, g, vm.bitmap.as<unsigned long long>());
         vm.has_bitmap = true;
       }
     }
     vm.cur = fill;
   }
   HIP_OR_FAIL(e, hipGetLastError());
+  if (on_side) {
+    HIP_OR_FAIL(e, hipEventRecord(e->side_done, on_side));
+    e->side_pending = true;
+    e->side_reads = &c;
+  }
   vm.valid = true;
   e->has_corr = false;
   return FVH_OK;
@@ -1591,8 +1662,8 @@ struct fvh_vgicp {
     return c;
   }
   int voxel_mode = 0;        // VoxelAccumulationMode ordinal: 0 ADDITIVE, 1 ADDITIVE_WEIGHTED (same voxel type in the reference), 2 MULTIPLICATIVE
-  int build_map(double res, bool force_safe = false) {
-    return voxel_mode == 2 ? build_voxelmap<2>(&e, target, voxelmap, res, false, force_safe) : build_voxelmap<0>(&e, target, voxelmap, res, false, force_safe);
+  int build_map(double res, bool force_safe = false, hipStream_t on_side = nullptr) {
+    return voxel_mode == 2 ? build_voxelmap<2>(&e, target, voxelmap, res, false, force_safe, on_side) : build_voxelmap<0>(&e, target, voxelmap, res, false, force_safe, on_side);
   }
   Rebuild rebuild_safe() { return [this] { return build_map(voxelmap.res, true); }; }
 };
@@ -1628,9 +1699,19 @@ struct fvh_voxelgrid {
   DownsampleDev d;
 };
 
-#define CHECK_HANDLE(h) \
+// CHECK_HANDLE_SOURCE_CHAIN: the calls that only touch the SOURCE cloud -- they may run beside a target-map build on the side
+// stream (Engine::side); every other call orders the main stream after that build first.
+#define CHECK_HANDLE_SOURCE_CHAIN(h) \
+  if (!(h)) return FVH_ERR_INVALID_ARGUMENT; \
+  { hipError_t _e = hipSetDevice((h)->e.device); if (_e != hipSuccess) return (h)->e.hipfail(_e, "hipSetDevice"); } \
+  (h)->e.was_quiet = (h)->e.quiet; (h)->e.quiet = false;
+// CHECK_HANDLE_HOST_ONLY: plain host-side setters that queue nothing: they leave the engine's stream bookkeeping alone.
+#define CHECK_HANDLE_HOST_ONLY(h) \
   if (!(h)) return FVH_ERR_INVALID_ARGUMENT; \
   { hipError_t _e = hipSetDevice((h)->e.device); if (_e != hipSuccess) return (h)->e.hipfail(_e, "hipSetDevice"); }
+#define CHECK_HANDLE(h) \
+  CHECK_HANDLE_SOURCE_CHAIN(h) \
+  { int _j = (h)->e.settle(); if (_j) return _j; }
 
 extern "C" {
 
@@ -1657,6 +1738,8 @@ int fvh_vgicp_create(int device, fvh_vgicp** out) {
 int fvh_vgicp_destroy(fvh_vgicp* h) {
   if (!h) return FVH_ERR_INVALID_ARGUMENT;
   (void)hipSetDevice(h->e.device);
+  h->e.deferred = nullptr;
+  if (h->e.side) (void)hipStreamSynchronize(h->e.side);
   if (h->e.stream) (void)hipStreamSynchronize(h->e.stream);
   h->source.release(); h->target.release(); h->voxelmap.release(); h->gicp_records.release();
   h->e.shutdown();
@@ -1664,10 +1747,10 @@ int fvh_vgicp_destroy(fvh_vgicp* h) {
   return FVH_OK;
 }
 const char* fvh_vgicp_last_error(const fvh_vgicp* h) { return h ? h->e.err.c_str() : "null handle"; }
-int fvh_vgicp_set_resolution(fvh_vgicp* h, double r) { CHECK_HANDLE(h); if (!(r > 0)) return h->e.fail(FVH_ERR_INVALID_ARGUMENT, "resolution must be > 0"); h->resolution = r; return FVH_OK; }
-int fvh_vgicp_set_kernel_params(fvh_vgicp* h, double w, double d) { CHECK_HANDLE(h); h->kernel_width = w; h->kernel_max_dist = d; return FVH_OK; }
+int fvh_vgicp_set_resolution(fvh_vgicp* h, double r) { CHECK_HANDLE_HOST_ONLY(h); if (!(r > 0)) return h->e.fail(FVH_ERR_INVALID_ARGUMENT, "resolution must be > 0"); h->resolution = r; return FVH_OK; }
+int fvh_vgicp_set_kernel_params(fvh_vgicp* h, double w, double d) { CHECK_HANDLE_HOST_ONLY(h); h->kernel_width = w; h->kernel_max_dist = d; return FVH_OK; }
 int fvh_vgicp_set_neighbor_search_method(fvh_vgicp* h, int m, double radius) { CHECK_HANDLE(h); return h->e.set_offsets(m, radius); }
-int fvh_vgicp_set_precision(fvh_vgicp* h, int p) { CHECK_HANDLE(h); if (p != FVH_COMPUTE_FP64 && p != FVH_COMPUTE_FP32) return h->e.fail(FVH_ERR_INVALID_ARGUMENT, "bad precision"); h->e.precision = p; return FVH_OK; }
+int fvh_vgicp_set_precision(fvh_vgicp* h, int p) { CHECK_HANDLE_HOST_ONLY(h); if (p != FVH_COMPUTE_FP64 && p != FVH_COMPUTE_FP32) return h->e.fail(FVH_ERR_INVALID_ARGUMENT, "bad precision"); h->e.precision = p; return FVH_OK; }
 
 int fvh_vgicp_create_target_voxelmap(fvh_vgicp* h) { CHECK_HANDLE(h); return h->build_map(h->resolution); }
 int fvh_vgicp_set_voxel_accumulation_mode(fvh_vgicp* h, int mode) {
@@ -1682,6 +1765,14 @@ int fvh_vgicp_swap_source_and_target(fvh_vgicp* h) {
   h->source.swap(h->target);
   h->e.has_corr = false;
   if (!h->target.has_pts || !h->target.has_cov) { h->voxelmap.invalidate(); return FVH_OK; }  // fast_vgicp_cuda.cu:102-104
+  // the stream had drained (the caller holds the result of an align): the new target's points and covariances are complete, and
+  // the build can run on the side stream while the caller prepares the next source cloud on the main one
+  if (h->e.was_quiet && h->e.side_stream()) {
+    const double res = h->resolution;
+    h->voxelmap.invalidate();
+    h->e.deferred = [h, res](hipStream_t on_side) { return h->build_map(res, false, on_side); };
+    return FVH_OK;
+  }
   return h->build_map(h->resolution);
 }
 int fvh_vgicp_gicp_swap_source_and_target(fvh_vgicp* h) {  // FastGICP::swapSourceAndTarget (fast_gicp_impl.hpp:56-62): no voxel map to rebuild
@@ -1692,19 +1783,19 @@ int fvh_vgicp_gicp_swap_source_and_target(fvh_vgicp* h) {  // FastGICP::swapSour
   return FVH_OK;
 }
 static void cloud_replaced(CloudDev& c) { c.has_cov = false; c.has_nbr = false; }
-int fvh_vgicp_set_source_cloud(fvh_vgicp* h, const float* xyz, int n) { CHECK_HANDLE(h); h->e.has_corr = false; cloud_replaced(h->source); return upload_cloud(&h->e, h->source, xyz, n, 3, false); }
+int fvh_vgicp_set_source_cloud(fvh_vgicp* h, const float* xyz, int n) { CHECK_HANDLE_SOURCE_CHAIN(h); h->e.has_corr = false; cloud_replaced(h->source); return (upload_cloud(&h->e, h->source, xyz, n, 3, false)); }
 int fvh_vgicp_set_target_cloud(fvh_vgicp* h, const float* xyz, int n) { CHECK_HANDLE(h); h->e.has_corr = false; h->voxelmap.invalidate(); h->gicp_records.invalidate(); cloud_replaced(h->target); return upload_cloud(&h->e, h->target, xyz, n, 3, false); }
-int fvh_vgicp_set_source_cloud_strided(fvh_vgicp* h, const float* xyz, int n, int stride) { CHECK_HANDLE(h); h->e.has_corr = false; cloud_replaced(h->source); return upload_cloud(&h->e, h->source, xyz, n, stride, false); }
+int fvh_vgicp_set_source_cloud_strided(fvh_vgicp* h, const float* xyz, int n, int stride) { CHECK_HANDLE_SOURCE_CHAIN(h); h->e.has_corr = false; cloud_replaced(h->source); return (upload_cloud(&h->e, h->source, xyz, n, stride, false)); }
 int fvh_vgicp_set_target_cloud_strided(fvh_vgicp* h, const float* xyz, int n, int stride) { CHECK_HANDLE(h); h->e.has_corr = false; h->voxelmap.invalidate(); h->gicp_records.invalidate(); cloud_replaced(h->target); return upload_cloud(&h->e, h->target, xyz, n, stride, false); }
-int fvh_vgicp_set_source_cloud_device(fvh_vgicp* h, const float* d, int n, int stride) { CHECK_HANDLE(h); h->e.has_corr = false; cloud_replaced(h->source); return upload_cloud(&h->e, h->source, d, n, stride, true); }
+int fvh_vgicp_set_source_cloud_device(fvh_vgicp* h, const float* d, int n, int stride) { CHECK_HANDLE_SOURCE_CHAIN(h); h->e.has_corr = false; cloud_replaced(h->source); return (upload_cloud(&h->e, h->source, d, n, stride, true)); }
 int fvh_vgicp_set_target_cloud_device(fvh_vgicp* h, const float* d, int n, int stride) { CHECK_HANDLE(h); h->e.has_corr = false; h->voxelmap.invalidate(); h->gicp_records.invalidate(); cloud_replaced(h->target); return upload_cloud(&h->e, h->target, d, n, stride, true); }
 int fvh_vgicp_set_source_neighbors(fvh_vgicp* h, int k, const int* idx) { CHECK_HANDLE(h); return set_neighbors(&h->e, h->source, k, idx); }
 int fvh_vgicp_set_target_neighbors(fvh_vgicp* h, int k, const int* idx) { CHECK_HANDLE(h); return set_neighbors(&h->e, h->target, k, idx); }
-int fvh_vgicp_find_source_neighbors(fvh_vgicp* h, int k) { CHECK_HANDLE(h); return find_neighbors(&h->e, h->source, k); }
+int fvh_vgicp_find_source_neighbors(fvh_vgicp* h, int k) { CHECK_HANDLE_SOURCE_CHAIN(h); return h->e.after_source_chain_call(find_neighbors(&h->e, h->source, k)); }
 int fvh_vgicp_find_target_neighbors(fvh_vgicp* h, int k) { CHECK_HANDLE(h); return find_neighbors(&h->e, h->target, k); }
-int fvh_vgicp_calculate_source_covariances(fvh_vgicp* h, int m) { CHECK_HANDLE(h); return calc_cov_knn(&h->e, h->source, m); }
+int fvh_vgicp_calculate_source_covariances(fvh_vgicp* h, int m) { CHECK_HANDLE_SOURCE_CHAIN(h); return h->e.after_source_chain_call(calc_cov_knn(&h->e, h->source, m)); }
 int fvh_vgicp_calculate_target_covariances(fvh_vgicp* h, int m) { CHECK_HANDLE(h); return calc_cov_knn(&h->e, h->target, m); }
-int fvh_vgicp_calculate_source_covariances_rbf(fvh_vgicp* h, int m) { CHECK_HANDLE(h); return calc_cov_rbf(&h->e, h->source, h->kernel_width, h->kernel_max_dist, m); }
+int fvh_vgicp_calculate_source_covariances_rbf(fvh_vgicp* h, int m) { CHECK_HANDLE_SOURCE_CHAIN(h); return h->e.after_source_chain_call(calc_cov_rbf(&h->e, h->source, h->kernel_width, h->kernel_max_dist, m)); }
 int fvh_vgicp_calculate_target_covariances_rbf(fvh_vgicp* h, int m) { CHECK_HANDLE(h); return calc_cov_rbf(&h->e, h->target, h->kernel_width, h->kernel_max_dist, m); }
 int fvh_vgicp_set_source_covariances(fvh_vgicp* h, const double* c) { CHECK_HANDLE(h); return set_cov_host(&h->e, h->source, c); }
 int fvh_vgicp_set_target_covariances(fvh_vgicp* h, const double* c) { CHECK_HANDLE(h); return set_cov_host(&h->e, h->target, c); }
@@ -1820,7 +1911,11 @@ int fvh_vgicp_align(fvh_vgicp* h, const double* guess, const fvh_lm_params* p, f
   CHECK_HANDLE(h);
   if (!h->source.has_pts || !h->source.has_cov) return h->e.fail(FVH_ERR_BAD_STATE, "align: source cloud/covariances not set");
   if (h->e.peer.attached() && h->source.n) { int rc = ensure_sorted(&h->e, h->source); if (rc) return rc; }
-  return do_align<MODE_VGICP>(&h->e, h->cost_source(), h->voxelmap, guess, p, r, h->rebuild_safe());
+  const int rc = do_align<MODE_VGICP>(&h->e, h->cost_source(), h->voxelmap, guess, p, r, h->rebuild_safe());
+  // the result is on the host: everything this handle queued has run (of a persistent launch only the workgroups' exit remains,
+  // and they touch neither clouds nor the map any more)
+  if (rc == FVH_OK) h->e.quiet = true;
+  return rc;
 }
 static int get_lm_trace(Engine* e, int* n, double* rows6) {
   if (!n) return e->fail(FVH_ERR_INVALID_ARGUMENT, "get_lm_trace: null count");
@@ -1834,7 +1929,7 @@ static int get_lm_trace(Engine* e, int* n, double* rows6) {
 int fvh_vgicp_set_lm_trace(fvh_vgicp* h, int on) { CHECK_HANDLE(h); h->e.lm_trace_on = on != 0; return FVH_OK; }
 int fvh_vgicp_get_lm_trace(fvh_vgicp* h, int* n, double* rows6) { CHECK_HANDLE(h); return get_lm_trace(&h->e, n, rows6); }
 int fvh_vgicp_fitness_score(fvh_vgicp* h, const double* T, double max_range, double* score) { CHECK_HANDLE(h); return do_fitness(&h->e, h->source, h->target, T, max_range, score); }
-int fvh_vgicp_profile_enable(fvh_vgicp* h, int on) { CHECK_HANDLE(h); h->e.prof.on = on != 0; return FVH_OK; }
+int fvh_vgicp_profile_enable(fvh_vgicp* h, int on) { CHECK_HANDLE_HOST_ONLY(h); h->e.prof.on = on != 0; return FVH_OK; }
 int fvh_vgicp_profile_reset(fvh_vgicp* h) { CHECK_HANDLE(h); HIP_OR_FAIL(&h->e, hipStreamSynchronize(h->e.stream)); h->e.prof.reset(); return FVH_OK; }
 int fvh_vgicp_profile_get(fvh_vgicp* h, const char* cls, double* ms, int* n) { CHECK_HANDLE(h); return profile_get(&h->e, cls, ms, n); }
 int fvh_vgicp_debug_set_voxel_hint(fvh_vgicp* h, int num_voxels) { CHECK_HANDLE(h); h->voxelmap.nv_hint = num_voxels; return FVH_OK; }

@@ -332,6 +332,23 @@ __device__ __forceinline__ void wave_bitonic_sort64(unsigned long long& key, int
   }
 }
 
+// Minimum of a u32 over the wave (every lane gets it): an inclusive min-scan inside the rows of 16 lanes (DPP row shifts; lanes
+// without a source keep the identity), the row results passed on with the two row broadcasts, the total read from lane 63.
+// Six dependent VALU ops and one readlane -- no trip through the LDS crossbar.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ unsigned dpp_min_step(unsigned x) {
+  return min(x, (unsigned)__builtin_amdgcn_update_dpp(-1, (int)x, CTRL, ROW_MASK, 0xF, false));
+}
+__device__ __forceinline__ unsigned wave_min_u32(unsigned v) {
+  v = dpp_min_step<0x111, 0xF>(v);  // row_shr:1
+  v = dpp_min_step<0x112, 0xF>(v);  // row_shr:2
+  v = dpp_min_step<0x114, 0xF>(v);  // row_shr:4
+  v = dpp_min_step<0x118, 0xF>(v);  // row_shr:8 -> lane 15 of a row: the row's minimum
+  v = dpp_min_step<0x142, 0xA>(v);  // row_bcast:15 into rows 1, 3
+  v = dpp_min_step<0x143, 0xC>(v);  // row_bcast:31 into rows 2, 3
+  return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
+}
+
 // ONE query per wave (the regime is latency-chain bound, not throughput bound: measured time was
 // proportional to the queries per wave). Seed = bitonic sort of the own tile; two-level box culling
 // (super tiles of 64 tiles, then tiles); the next surviving tile is prefetched while the current one
@@ -342,6 +359,7 @@ __device__ unsigned long long g_knn_time[32768][8];  // debug build: per query {
 #else
 #define KNN_STAMP(i) do { } while (0)
 #endif
+template <bool NEAREST_FIRST>
 __global__ __launch_bounds__(256) void knn_tiled1_kernel(const float4* __restrict__ spts, const float4* __restrict__ bbox1, const float4* __restrict__ bbox2, int n, int k,
                                                          int* __restrict__ out_idx, int q_begin = 0, int q_end = 0x7fffffff /* queries = this range of the Morton order (a rank's tile) */) {
   const int lane = threadIdx.x & 63;
@@ -389,34 +407,82 @@ __global__ __launch_bounds__(256) void knn_tiled1_kernel(const float4* __restric
   if (t0 > 0) merge_tile(pb);
   KNN_STAMP(3);
 
-  for (int sc = 0; sc < nsuper; sc += 64) {
-    const int s = sc + lane;
-    const float lb2 = (s < nsuper) ? point_box_sq(bbox2[2 * s], bbox2[2 * s + 1], qx, qy, qz) : __builtin_inff();
-    unsigned long long smask = __ballot(lb2 <= td);
-    while (smask) {
-      const int ssrc = __ffsll((long long)smask) - 1;
-      smask &= smask - 1;
-      if (read_lane(lb2, ssrc) > td) continue;
-      const int t = ((sc + ssrc) << 6) + lane;
-      const float lb = (t < ntiles) ? point_box_sq(bbox1[2 * t], bbox1[2 * t + 1], qx, qy, qz) : __builtin_inff();
-      unsigned long long tmask = __ballot(lb <= td && (t < t0 - 1 || t > t0 + 1));
-      if (!tmask) continue;
-      // software pipeline: the load of the next surviving tile is in flight while this one is merged
-      int cur = __ffsll((long long)tmask) - 1;
-      tmask &= tmask - 1;
-      float4 pcur = load_candidate(spts, ((((sc + ssrc) << 6) + cur) << 6) + lane, n);
-      while (true) {
-        int nxt = -1;
-        float4 pnxt = pcur;
-        if (tmask) {
-          nxt = __ffsll((long long)tmask) - 1;
-          tmask &= tmask - 1;
-          pnxt = load_candidate(spts, ((((sc + ssrc) << 6) + nxt) << 6) + lane, n);
+  if constexpr (!NEAREST_FIRST) {
+    // boxes in index order: scalar mask arithmetic, a find-first-set per box -- the cheapest walk per box
+    for (int sc = 0; sc < nsuper; sc += 64) {
+      const int s = sc + lane;
+      const float lb2 = (s < nsuper) ? point_box_sq(bbox2[2 * s], bbox2[2 * s + 1], qx, qy, qz) : __builtin_inff();
+      unsigned long long smask = __ballot(lb2 <= td);
+      while (smask) {
+        const int ssrc = __ffsll((long long)smask) - 1;
+        smask &= smask - 1;
+        if (read_lane(lb2, ssrc) > td) continue;
+        const int t = ((sc + ssrc) << 6) + lane;
+        const float lb = (t < ntiles) ? point_box_sq(bbox1[2 * t], bbox1[2 * t + 1], qx, qy, qz) : __builtin_inff();
+        unsigned long long tmask = __ballot(lb <= td && (t < t0 - 1 || t > t0 + 1));
+        if (!tmask) continue;
+        // software pipeline: the load of the next surviving tile is in flight while this one is merged
+        int cur = __ffsll((long long)tmask) - 1;
+        tmask &= tmask - 1;
+        float4 pcur = load_candidate(spts, ((((sc + ssrc) << 6) + cur) << 6) + lane, n);
+        while (true) {
+          int nxt = -1;
+          float4 pnxt = pcur;
+          if (tmask) {
+            nxt = __ffsll((long long)tmask) - 1;
+            tmask &= tmask - 1;
+            pnxt = load_candidate(spts, ((((sc + ssrc) << 6) + nxt) << 6) + lane, n);
+          }
+          if (read_lane(lb, cur) <= td) merge_tile(pcur);
+          if (nxt < 0) break;
+          cur = nxt;
+          pcur = pnxt;
         }
-        if (read_lane(lb, cur) <= td) merge_tile(pcur);
-        if (nxt < 0) break;
-        cur = nxt;
-        pcur = pnxt;
+      }
+    }
+  } else {
+    // Nearest box first, at both levels (wave_min_u32 per box, the keys in a VGPR: ~35 more instructions per box). The order does
+    // not change the result -- the k smallest keys of a total order -- only how many candidates pass the threshold on the way. A
+    // query whose own tile straddles a jump of the Morton curve meets its true neighbours late in index order: 7 such queries of
+    // the bundled target cloud took 400 insertions / 43 us each and alone stretched the kernel from 34 to 58 us
+    // (tools/knn_timing.py). Ascending boxes also end the walk at the first one beyond the threshold (it only shrinks). Small
+    // clouds take this walk: their kernel lasts as long as its slowest queries (17k points: 49 -> 39 us on average over the two
+    // bundled clouds). The throughput-bound sizes hide a slow query behind the others and pay for the extra instructions
+    // instead (100k points: 159 -> 169 us), so they keep the index order. (One kernel that switches per query after N
+    // insertions was measured too: its index-order part compiled 10-17 % slower than the plain one.)
+    for (int sc = 0; sc < nsuper; sc += 64) {
+      const int s = sc + lane;
+      const float lb2 = (s < nsuper) ? point_box_sq(bbox2[2 * s], bbox2[2 * s + 1], qx, qy, qz) : __builtin_inff();
+      unsigned k2 = (lb2 <= td) ? ((s == (t0 >> 6)) ? 0u : __float_as_uint(lb2) + 1u) : ~0u;  // (the own super tile before all others)
+      while (true) {
+        const unsigned m2 = wave_min_u32(k2);
+        if (m2 == ~0u) break;
+        const int ssrc = __ffsll((long long)__ballot(k2 == m2)) - 1;
+        k2 = (lane == ssrc) ? ~0u : k2;
+        if (read_lane(lb2, ssrc) > td) break;  // ascending: none of the remaining super tiles can qualify either
+        const int t = ((sc + ssrc) << 6) + lane;
+        const float lb = (t < ntiles) ? point_box_sq(bbox1[2 * t], bbox1[2 * t + 1], qx, qy, qz) : __builtin_inff();
+        unsigned k1 = (lb <= td && (t < t0 - 1 || t > t0 + 1)) ? __float_as_uint(lb) : ~0u;
+        unsigned m1 = wave_min_u32(k1);
+        if (m1 == ~0u) continue;
+        // software pipeline: the load of the next surviving tile is in flight while this one is merged
+        int cur = __ffsll((long long)__ballot(k1 == m1)) - 1;
+        k1 = (lane == cur) ? ~0u : k1;
+        float4 pcur = load_candidate(spts, ((((sc + ssrc) << 6) + cur) << 6) + lane, n);
+        while (true) {
+          int nxt = -1;
+          float4 pnxt = pcur;
+          m1 = wave_min_u32(k1);
+          if (m1 != ~0u && __uint_as_float(m1) <= td) {
+            nxt = __ffsll((long long)__ballot(k1 == m1)) - 1;
+            k1 = (lane == nxt) ? ~0u : k1;
+            pnxt = load_candidate(spts, ((((sc + ssrc) << 6) + nxt) << 6) + lane, n);
+          }
+          if (read_lane(lb, cur) <= td) merge_tile(pcur);
+          if (nxt < 0) break;
+          cur = nxt;
+          pcur = pnxt;
+        }
       }
     }
   }

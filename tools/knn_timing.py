@@ -11,6 +11,8 @@ from fast_gicp_amd import capi, preprocess  # noqa: E402
 
 L = capi.load()
 tgt, src = preprocess.bundled_pair(os.path.join(ROOT, "data"))
+if len(sys.argv) > 1 and sys.argv[1] == "target":  # the other cloud of the pair (its search takes 60 us against 33)
+    src = tgt
 c = capi.VGICPCore(0)
 c.set_source_cloud(src)
 for _ in range(3):
@@ -27,3 +29,11 @@ print("per query [us] median / p90:  seed loads %.2f / %.2f   bitonic sort %.2f 
 print("tiles merged per query: mean %.1f  insertions: mean %.1f p90 %.0f" % (v[:, 5].mean(), v[:, 6].mean(), np.percentile(v[:, 6], 90)))
 start = np.sort(t[:, 0] - t[:, 0].min()) / 100.0
 print("wave starts [us]: 10%% %.1f  50%% %.1f  90%% %.1f  last %.1f" % (start[len(start) // 10], start[len(start) // 2], start[9 * len(start) // 10], start[-1]))
+dur = (t[:, 4] - t[:, 0]) / 100.0
+end = (t[:, 4] - t[:, 0].min()) / 100.0
+o = np.argsort(-end)[:12]
+print("last finishers: query(sorted pos) start end dur tiles insertions")
+for i in o:
+    print("  %6d  %6.1f %6.1f %6.1f  %4d %5d" % (i, (t[i, 0] - t[:, 0].min()) / 100.0, end[i], dur[i], v[i, 5], v[i, 6]))
+print("duration percentiles [us]: 50 %.1f 90 %.1f 99 %.1f 99.9 %.1f max %.1f" % tuple(np.percentile(dur, [50, 90, 99, 99.9, 100])))
+print("tiles percentiles: 50 %d 90 %d 99 %d max %d;  insertions: 50 %d 90 %d 99 %d max %d" % (tuple(np.percentile(v[:, 5], [50, 90, 99, 100])) + tuple(np.percentile(v[:, 6], [50, 90, 99, 100]))))
