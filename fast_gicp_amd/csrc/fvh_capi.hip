@@ -209,7 +209,8 @@ struct Engine {
   std::vector<int> offsets_host{0, 0, 0};
   int n_off = 1;
   DevBuf fit_best;   // squared nearest-neighbour distance per source point (fitness score)
-  DevBuf sort_coop;  // SortCoopState + histograms of the cooperative small sort
+  DevBuf sort_coop;  // SortCoopState + tagged histograms / elements / final order of the cooperative small sort (kernels_sort.hpp)
+  unsigned sort_seq = 0;  // its launch sequence number: the tag of everything one launch hands between workgroups
   DevBuf rbf_sums;   // [10][n] wave totals of the RBF covariance sweep
   bool abort_word_dirty = false;
   int last_persist_blocks = 0;
@@ -536,14 +537,18 @@ int ensure_sorted(Engine* e, CloudDev& c) {
     const bool coop = c.has_box && ((sort_mode == 2 && g_live_engines.load() == 1) || sort_mode == 3);
     if (coop) {
       const bool fresh = e->sort_coop.p == nullptr;
-      HIP_OR_FAIL(e, e->sort_coop.ensure(sizeof(SortCoopState) + sizeof(unsigned) * 2 * SMALL_BINS * COOP_WGS));
+      HIP_OR_FAIL(e, e->sort_coop.ensure(COOP_STATE_BYTES));
       SortCoopState* cs = e->sort_coop.as<SortCoopState>();
+      char* base = reinterpret_cast<char*>(cs);
       unsigned* chist = reinterpret_cast<unsigned*>(cs + 1);
-      if (fresh) HIP_OR_FAIL(e, hipMemsetAsync(cs, 0, sizeof(SortCoopState), e->stream));  // afterwards the finish kernel leaves it zeroed for the next sort
+      // once: tags of no launch everywhere (afterwards the finish kernel leaves the state zeroed and every launch rewrites the tagged words)
+      if (fresh) HIP_OR_FAIL(e, hipMemsetAsync(cs, 0, COOP_STATE_BYTES, e->stream));
+      if ((++e->sort_seq & 0x7FFFu) == 0) ++e->sort_seq;  // (a 16-bit tag of 0 is what fresh memory holds)
       unsigned long long wd = 2'000'000ull;  // 20 ms
       { const char* v = getenv("FVH_SORT_COOP_WATCHDOG_TICKS"); if (v) wd = strtoull(v, nullptr, 10); }  // test hook: 0 forces the fallback
-      sort_coop_kernel<<<COOP_WGS, COOP_THREADS, 0, e->stream>>>(c.pts.as<float4>(), n, e->sort_keys.as<unsigned>() + n, e->sort_idx.as<int>(), c.order.as<int>(), c.sorted.as<float4>(),
-                                                                 c.bbox.as<float4>(), c.box.as<unsigned>(), chist, cs, wd);
+      sort_coop_kernel<<<COOP_WGS, COOP_THREADS, 0, e->stream>>>(c.pts.as<float4>(), n, c.order.as<int>(), c.sorted.as<float4>(), c.bbox.as<float4>(), c.box.as<unsigned>(), chist,
+                                                                 reinterpret_cast<unsigned long long*>(base + COOP_ELEM_OFFSET), reinterpret_cast<unsigned long long*>(base + COOP_FIN_OFFSET), cs,
+                                                                 e->sort_seq, wd);
       // normally the super boxes only; when the cooperative kernel did not finish, one workgroup redoes everything
       sort_coop_finish_kernel<<<1, 1024, 0, e->stream>>>(c.pts.as<float4>(), n, e->sort_keys.as<unsigned>(), c.order.as<int>(), e->sort_keys.as<unsigned>() + n, e->sort_idx.as<int>(),
                                                          c.sorted.as<float4>(), c.bbox.as<float4>(), c.bbox2.as<float4>(), cs, c.box.as<unsigned>());

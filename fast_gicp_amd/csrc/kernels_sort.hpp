@@ -433,21 +433,21 @@ __global__ __launch_bounds__(1024) void sort_small_kernel(const float4* __restri
 
 // ------------------------------------------------------------------------------------------------
 // Small clouds, cooperative version: the same 18-bit Morton order as sort_small_kernel (identical output), but on
-// COOP_WGS workgroups that meet at grid barriers instead of one workgroup doing everything (62 us at 17k points on
-// one CU, + 10 us for the tile / super boxes). Phases: keys + digit-0 histograms | scatter 0 | digit-1 histograms |
-// scatter 1 + gather | tile boxes (bounding cube: pack_points_kernel before; super boxes: the finish kernel after); between phases every wave waits for its
-// (write-through) stores, the workgroup arrives at a monotonic counter and waits for all COOP_WGS arrivals.
+// COOP_WGS co-resident workgroups instead of one workgroup doing everything (62 us at 17k points on one CU, + 10 us for the
+// tile / super boxes). Phases: keys + digit-0 histograms | scatter 0 | digit-1 histograms | scatter 1 + gather | tile boxes
+// (bounding cube: pack_points_kernel before; super boxes: the finish kernel after). What one phase hands to the next crosses
+// workgroups through tagged words the consumer polls (see sort_coop_kernel) -- no grid barrier.
 // Each wave owns a contiguous chunk of <= 128 keys (2 steps of 64), so stable order = (workgroup, wave, step, lane).
 // The per-pass scan is done redundantly by every workgroup from the 512 x COOP_WGS matrix of workgroup totals.
-// A stuck barrier (workgroups not co-resident) trips a watchdog: fewer than COOP_WGS workgroups finish and
+// A poll that never succeeds (workgroups not co-resident) trips a watchdog: fewer than COOP_WGS workgroups finish and
 // sort_coop_finish_kernel, launched right behind, does the whole job on one workgroup instead.
 // ------------------------------------------------------------------------------------------------
 constexpr int COOP_WGS = 32, COOP_THREADS = 512, COOP_WAVES = COOP_THREADS / 64, COOP_STEPS = 2;
 static_assert(COOP_WGS * COOP_WAVES * COOP_STEPS * 64 >= SORT_SMALL_MAX, "every key needs a slot");
 static_assert(COOP_THREADS == SMALL_BINS, "one thread per bin in the scans");
 
-struct SortCoopState {     // zeroed by the host before every launch
-  unsigned arrivals;        // monotonic barrier counter
+struct SortCoopState {     // zeroed by the host before the first launch, by sort_coop_finish_kernel after every launch
+  unsigned arrivals;        // (unused since the hand-offs carry tags)
   unsigned abort;
   unsigned finished;        // workgroups that ran to the end; COOP_WGS = the cooperative kernel did the whole job
   unsigned pad[13];
@@ -456,42 +456,51 @@ struct SortCoopState {     // zeroed by the host before every launch
 template <typename T> __device__ __forceinline__ void st_agent(T* p, T v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }  // write-through (sc1)
 template <typename T> __device__ __forceinline__ T ld_agent(const T* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }     // bypasses the non-coherent L2
 
-__device__ __forceinline__ bool coop_barrier(SortCoopState* st, unsigned phase, unsigned long long watchdog_ticks, int* s_flag) {
-  // no __threadfence(): a release/acquire pair at agent scope writes back and invalidates the whole L2 of the XCD at
-  // every barrier (measured: the kernel took ~100 us). Everything that crosses workgroups is stored write-through and
-  // loaded L2-bypassing instead (st_agent / ld_agent), so waiting for this wave's stores is all the release needed.
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    int ok = 1;
-    atomicAdd(&st->arrivals, 1u);
-    const unsigned want = (phase + 1) * COOP_WGS;
-    const unsigned long long t0 = wall_clock64();
-    while (__hip_atomic_load(&st->arrivals, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {
-      if (__hip_atomic_load(&st->abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) || wall_clock64() - t0 > watchdog_ticks) {
-        __hip_atomic_store(&st->abort, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        ok = 0;
-        break;
-      }
-      __builtin_amdgcn_s_sleep(1);
-    }
-    *s_flag = ok;
+// Hand-offs between workgroups carry their own arrival signal (round 3, as in the LM kernel): a histogram entry is
+// {count:16, tag:16}, a scattered element {tag:31, key:18, index:15} in ONE 64-bit word, an entry of the final order {tag:32,
+// index:32} -- tag = this launch's sequence number (+ the pass). A consumer polls the words it needs with L2-bypassing loads
+// until their tags are current; nobody waits for anybody else: no arrival counter, no "wait for my stores, add 1, poll the
+// counter" (four grid barriers of ~3 us each in the first version of this kernel). Buffers are zeroed
+// when allocated, sequence numbers start at 1 and every complete launch rewrites every word it will poll next time.
+// A failed poll is the expensive case -- 16k lanes re-reading 2 MB past the caches while the stores they wait for are still on
+// their way: polling at once made the registration 9 us SLOWER than the barriers (4,145 -> 3,995 reg/s); a first look after
+// ~0.9 us (s_sleep 32) and then every ~0.2 us makes it 5 us faster (4,190 -> 4,265; 16 / 32 / 48 measure the same).
+#ifndef FVH_COOP_POLL_SLEEP
+#define FVH_COOP_POLL_SLEEP 8
+#endif
+#ifndef FVH_COOP_FIRST_SLEEP
+#define FVH_COOP_FIRST_SLEEP 32
+#endif
+constexpr int COOP_MATRIX_WORDS = 2 * SMALL_BINS * COOP_WGS;                                    // u32 {count, tag}
+constexpr size_t COOP_ELEM_OFFSET = sizeof(SortCoopState) + sizeof(unsigned) * COOP_MATRIX_WORDS;  // u64 x SORT_SMALL_MAX: pass-0 output
+constexpr size_t COOP_FIN_OFFSET = COOP_ELEM_OFFSET + sizeof(unsigned long long) * SORT_SMALL_MAX;  // u64 x SORT_SMALL_MAX: final order
+constexpr size_t COOP_STATE_BYTES = COOP_FIN_OFFSET + sizeof(unsigned long long) * SORT_SMALL_MAX;
+static_assert(SORT_SMALL_MAX <= (1 << 15) && SMALL_BITS * SMALL_PASSES <= 18, "element packing: 15 index bits, 18 key bits");
+
+__device__ __forceinline__ bool coop_timed_out(SortCoopState* st, unsigned long long t0, unsigned long long watchdog_ticks) {
+  if (__hip_atomic_load(&st->abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) || wall_clock64() - t0 > watchdog_ticks) {
+    __hip_atomic_store(&st->abort, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return true;
   }
-  __syncthreads();
-  return *s_flag != 0;
+  return false;
 }
 
-__global__ __launch_bounds__(COOP_THREADS) void sort_coop_kernel(const float4* __restrict__ pts, int n, unsigned* keysB, int* idxB, int* order, float4* sorted, float4* bbox1,
+__global__ __launch_bounds__(COOP_THREADS) void sort_coop_kernel(const float4* __restrict__ pts, int n, int* order, float4* sorted, float4* bbox1,
                                                                 const unsigned* __restrict__ box /* {~ordered(min) x3, ordered(max) x3} */, unsigned* hist /* [2][SMALL_BINS][COOP_WGS] */,
-                                                                SortCoopState* st, unsigned long long watchdog_ticks) {
+                                                                unsigned long long* elem, unsigned long long* fin, SortCoopState* st, unsigned seq, unsigned long long watchdog_ticks) {
   __shared__ unsigned wh[COOP_WAVES][SMALL_BINS];  // per-wave digit counts -> exclusive prefix over the waves of this workgroup -> scatter cursors
   __shared__ unsigned wsum[COOP_WAVES];
-  __shared__ int s_flag;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, wg = blockIdx.x;
   const int gw = wg * COOP_WAVES + wv;  // global wave index
   const int chunk = ((((n + COOP_WGS * COOP_WAVES - 1) / (COOP_WGS * COOP_WAVES)) + 63) & ~63);
   const int begin = gw * chunk, end = min(n, begin + chunk);
   const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+  const unsigned long long t_start = wall_clock64();
+  const unsigned long long etag = (unsigned long long)(seq & 0x7fffffffu);
+  if (watchdog_ticks == 0) {  // test hook: the fallback does the whole job
+    if (tid == 0) __hip_atomic_store(&st->abort, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return;
+  }
 
   // ---- keys (the arithmetic of sort_small_kernel); the bounding cube was reduced by pack_points_kernel when the cloud was set ----
   float4 p[COOP_STEPS];
@@ -520,12 +529,24 @@ __global__ __launch_bounds__(COOP_THREADS) void sort_coop_kernel(const float4* _
   for (int pass = 0; pass < SMALL_PASSES; pass++) {
     const int shift = pass * SMALL_BITS;
     unsigned* gh = hist + (size_t)pass * SMALL_BINS * COOP_WGS;
-    if (pass > 0) {  // reload this wave's chunk in the order pass 0 produced
+    const unsigned htag = ((seq << 1) | (unsigned)pass) & 0xFFFFu;
+    int failed = 0;
+    if (pass > 0) {  // this wave's chunk in the order pass 0 produced: poll until every element of the chunk has landed
+      if (FVH_COOP_FIRST_SLEEP) __builtin_amdgcn_s_sleep(FVH_COOP_FIRST_SLEEP);
 #pragma unroll
       for (int u = 0; u < COOP_STEPS; u++) {
         const int i = begin + u * 64 + lane;
-        key[u] = (i < end) ? ld_agent(&keysB[i]) : 0xFFFFFFFFu;
-        id[u] = (i < end) ? ld_agent(&idxB[i]) : -1;
+        unsigned long long v = 0;
+        if (i < end) {
+          while (true) {
+            v = ld_agent(&elem[i]);
+            if ((v >> 33) == etag) break;
+            if (coop_timed_out(st, t_start, watchdog_ticks)) { failed = 1; break; }
+            __builtin_amdgcn_s_sleep(FVH_COOP_POLL_SLEEP);
+          }
+        }
+        key[u] = (i < end) ? (unsigned)(v >> 15) & 0x3FFFFu : 0xFFFFFFFFu;
+        id[u] = (i < end) ? (int)(v & 0x7FFFu) : -1;
       }
     }
     // per-wave digit histogram
@@ -533,23 +554,31 @@ __global__ __launch_bounds__(COOP_THREADS) void sort_coop_kernel(const float4* _
 #pragma unroll
     for (int u = 0; u < COOP_STEPS; u++)
       if (begin + u * 64 + lane < end) atomicAdd(&wh[wv][(key[u] >> shift) & (SMALL_BINS - 1)], 1u);
-    __syncthreads();
-    {  // thread = bin: exclusive prefix over this workgroup's waves; workgroup total -> global
+    if (__syncthreads_or(failed)) return;
+    {  // thread = bin: exclusive prefix over this workgroup's waves; workgroup total -> global, tagged
       unsigned run = 0;
 #pragma unroll
       for (int w = 0; w < COOP_WAVES; w++) { const unsigned c = wh[w][tid]; wh[w][tid] = run; run += c; }
-      st_agent(&gh[(size_t)tid * COOP_WGS + wg], run);
+      st_agent(&gh[(size_t)tid * COOP_WGS + wg], (run << 16) | htag);
     }
-    if (!coop_barrier(st, 2 * pass, watchdog_ticks, &s_flag)) return;
-    {  // thread = bin: total over all workgroups and the part before this workgroup; then the bins are scanned
+    {  // thread = bin: total over all workgroups and the part before this workgroup (polled until all 32 entries are current); then the bins are scanned
       const unsigned long long* row = reinterpret_cast<const unsigned long long*>(gh + (size_t)tid * COOP_WGS);
       unsigned long long v[COOP_WGS / 2];
+      if (FVH_COOP_FIRST_SLEEP) __builtin_amdgcn_s_sleep(FVH_COOP_FIRST_SLEEP);
+      while (true) {
 #pragma unroll
-      for (int j = 0; j < COOP_WGS / 2; j++) v[j] = ld_agent(&row[j]);  // independent loads, one round trip
+        for (int j = 0; j < COOP_WGS / 2; j++) v[j] = ld_agent(&row[j]);  // independent loads, one round trip
+        unsigned bad = 0;
+#pragma unroll
+        for (int j = 0; j < COOP_WGS / 2; j++) bad |= (((unsigned)v[j] & 0xFFFFu) ^ htag) | (((unsigned)(v[j] >> 32) & 0xFFFFu) ^ htag);
+        if (!bad) break;
+        if (coop_timed_out(st, t_start, watchdog_ticks)) { failed = 1; break; }
+        __builtin_amdgcn_s_sleep(FVH_COOP_POLL_SLEEP);
+      }
       unsigned total = 0, before = 0;
 #pragma unroll
       for (int j = 0; j < COOP_WGS / 2; j++) {
-        const unsigned a = (unsigned)v[j], b = (unsigned)(v[j] >> 32);
+        const unsigned a = (unsigned)v[j] >> 16, b = (unsigned)(v[j] >> 48);
         total += a + b;
         before += ((2 * j < wg) ? a : 0u) + ((2 * j + 1 < wg) ? b : 0u);
       }
@@ -557,7 +586,7 @@ __global__ __launch_bounds__(COOP_THREADS) void sort_coop_kernel(const float4* _
 #pragma unroll
       for (int off = 1; off < 64; off <<= 1) { const unsigned y = __shfl_up(x, off); if (lane >= off) x += y; }
       if (lane == 63) wsum[wv] = x;
-      __syncthreads();
+      if (__syncthreads_or(failed)) return;
       unsigned base = x - total + before;
       for (int w = 0; w < wv; w++) base += wsum[w];
 #pragma unroll
@@ -588,23 +617,34 @@ __global__ __launch_bounds__(COOP_THREADS) void sort_coop_kernel(const float4* _
       if (valid) {
         const unsigned dst = dst_base + rank;
         if (!last) {
-          st_agent(&keysB[dst], key[u]);
-          st_agent(&idxB[dst], id[u]);
+          st_agent(&elem[dst], (etag << 33) | ((unsigned long long)key[u] << 15) | (unsigned long long)(unsigned)id[u]);
         } else {
-          st_agent(&order[dst], id[u]);
+          st_agent(&fin[dst], ((unsigned long long)seq << 32) | (unsigned long long)(unsigned)id[u]);
+          order[dst] = id[u];
           float4 q = pts[id[u]];
           q.w = __int_as_float(id[u]);
           sorted[dst] = q;
         }
       }
     }
-    if (!coop_barrier(st, 2 * pass + 1, watchdog_ticks, &s_flag)) return;
   }
 
-  // ---- boxes of the 64-point tiles, then of 64 tiles ----
-  const int ntiles = (n + 63) >> 6, nsuper = (ntiles + 63) >> 6;
-  for (int t = gw; t < ntiles; t += COOP_WGS * COOP_WAVES) {
-    const float4 q = pts[ld_agent(&order[min(t * 64 + lane, n - 1)])];  // (the sorted copy was written by other workgroups with plain stores)
+  // ---- boxes of the 64-point tiles (the boxes of 64 tiles are left to sort_coop_finish_kernel: a kernel boundary is the cheapest barrier) ----
+  const int ntiles = (n + 63) >> 6;
+  int failed = 0;
+  if (FVH_COOP_FIRST_SLEEP) __builtin_amdgcn_s_sleep(FVH_COOP_FIRST_SLEEP);
+  for (int t = gw; t < ntiles && !failed; t += COOP_WGS * COOP_WAVES) {
+    const int j = min(t * 64 + lane, n - 1);
+    unsigned long long v;
+    while (true) {
+      v = ld_agent(&fin[j]);
+      if (!__ballot((unsigned)(v >> 32) != seq)) break;  // (wave-uniform: all 64 entries of the tile)
+      if (coop_timed_out(st, t_start, watchdog_ticks)) { failed = 1; break; }
+      __builtin_amdgcn_s_sleep(FVH_COOP_POLL_SLEEP);
+    }
+    failed = __ballot(failed) != 0;
+    if (failed) break;
+    const float4 q = pts[(int)(unsigned)v];
     float l3[3] = {q.x, q.y, q.z}, h3[3] = {q.x, q.y, q.z};
 #pragma unroll
     for (int a = 0; a < 3; a++)
@@ -613,17 +653,16 @@ __global__ __launch_bounds__(COOP_THREADS) void sort_coop_kernel(const float4* _
         l3[a] = fminf(l3[a], __shfl_xor(l3[a], off));
         h3[a] = fmaxf(h3[a], __shfl_xor(h3[a], off));
       }
-    if (lane < 8) {  // 2 x float4 = 8 floats, one write-through store per lane
+    if (lane < 8) {  // 2 x float4 = 8 floats, one store per lane
       const float v8[8] = {l3[0], l3[1], l3[2], 0.f, h3[0], h3[1], h3[2], 0.f};
       float out = v8[0];
 #pragma unroll
       for (int c = 1; c < 8; c++) out = (lane == c) ? v8[c] : out;
-      st_agent(reinterpret_cast<float*>(bbox1 + 2 * t) + lane, out);
+      reinterpret_cast<float*>(bbox1 + 2 * t)[lane] = out;
     }
   }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  if (tid == 0) atomicAdd(&st->finished, 1u);  // the boxes of 64 tiles are left to sort_coop_finish_kernel (a kernel boundary is the cheapest barrier)
+  if (__syncthreads_or(failed)) return;
+  if (tid == 0) atomicAdd(&st->finished, 1u);
 }
 
 // Runs right behind sort_coop_kernel on one workgroup: normally just the <= 8 super boxes; when the cooperative kernel

@@ -35,8 +35,8 @@ def main():
             continue
         d = json.loads(line[-1])
         st = d.get("stages", {})
-        print("%-44s %9.1f reg/s  cost %7.1f us  knn %6.1f  cov %5.1f  vm %5.1f  fitness %.6f aborts %s" % (
-            spec, d["value"], st.get("cost", {}).get("avg_us", float("nan")), st.get("knn", {}).get("avg_us", float("nan")), st.get("cov", {}).get("avg_us", float("nan")),
+        print("%-44s %9.1f reg/s  cost %7.1f us  sort %5.1f  knn %6.1f  cov %5.1f  vm %5.1f  fitness %.6f aborts %s" % (
+            spec, d["value"], st.get("cost", {}).get("avg_us", float("nan")), st.get("sort", {}).get("avg_us", float("nan")), st.get("knn", {}).get("avg_us", float("nan")), st.get("cov", {}).get("avg_us", float("nan")),
             st.get("voxelmap", {}).get("avg_us", float("nan")), d.get("fitness_score", float("nan")), d["per_registration"].get("persistent_launches_aborted_by_watchdog")), flush=True)
 
 
