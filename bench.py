@@ -427,7 +427,7 @@ def run_stream(args, steps, warmup, cpu_loops=15, frames_n=10):
     t0 = time.perf_counter()
     n_eval = n_launch = 0
     for it in range(steps):
-        if profile:
+        if profile and it % 9 <= 1:
             ndt.profile_enable(it % 9 == 0); vg.profile_enable(it % 9 == 0)
         step()
         n_eval += state["last"]["num_linearize"] + state["last"]["num_error_evals"]
@@ -638,7 +638,7 @@ def run_registration(args, workload, cov, search_name, steps, warmup, local_rank
     t0 = time.perf_counter()
     n_lin = n_err = n_launch = 0
     for it in range(steps):
-        if profile:
+        if profile and it % PROFILE_EVERY <= 1:  # (on at 0, off again at 1: a call per step would sit between an align and the next launch, with the GPU idle)
             core.profile_enable(it % PROFILE_EVERY == 0)
         step()
         n_lin += state["last"]["num_linearize"]

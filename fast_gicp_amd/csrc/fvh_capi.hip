@@ -281,7 +281,7 @@ struct Engine {
   bool quiet = false, was_quiet = false;  // the main stream had drained when the current API call began (set by align on return)
   hipStream_t side_stream() {
     static const bool on = [] { const char* v = getenv("FVH_SIDE_STREAM"); return !v || atoi(v) != 0; }();
-    if (!on || prof.on || comm || peer.attached()) return nullptr;
+    if (!on || comm || peer.attached()) return nullptr;
     if (!side) {
       if (hipStreamCreateWithFlags(&side, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); side = nullptr; return nullptr; }
       if (hipEventCreateWithFlags(&side_done, hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); (void)hipStreamDestroy(side); side = nullptr; return nullptr; }
@@ -435,9 +435,9 @@ struct Engine {
   } while (0)
 
 struct ProfScope {
-  Engine* e; hipEvent_t stop = nullptr;
-  ProfScope(Engine* e_, const char* cls) : e(e_) { if (e->prof.on) e->prof.begin(cls, e->stream, &stop); }
-  ~ProfScope() { if (stop) (void)hipEventRecord(stop, e->stream); }
+  Engine* e; hipEvent_t stop = nullptr; hipStream_t st;
+  ProfScope(Engine* e_, const char* cls, hipStream_t on = nullptr) : e(e_), st(on ? on : e_->stream) { if (e->prof.on) e->prof.begin(cls, st, &stop); }
+  ~ProfScope() { if (stop) (void)hipEventRecord(stop, st); }
 };
 
 inline PoseD pose_from_colmajor16(const double* T) {
@@ -816,7 +816,7 @@ int build_voxelmap(Engine* e, const CloudDev& c, VoxelMapDev& vm, double res, bo
     HIP_OR_FAIL(e, vm.compact_cov.ensure(sizeof(float4) * 2 * (size_t)std::max(c.n, 1)));
   }
   {
-    ProfScope ps(e, "voxelmap");  // (never on the side stream: side_stream() is off while profiling)
+    ProfScope ps(e, "voxelmap", st);
     const int fill = vm.cur ^ 1;
     unsigned long long* keys = vm.keys[fill].as<unsigned long long>();
     int* counters = vm.counters.as<int>() + 16 * fill;
@@ -1304,6 +1304,7 @@ int comm_init(Engine* e, const void* id128, int nranks, int rank) {
 
 int profile_get(Engine* e, const char* cls, double* total_ms, int* launches) {
   if (!cls) return e->fail(FVH_ERR_INVALID_ARGUMENT, "profile_get: null class");
+  if (e->side) HIP_OR_FAIL(e, hipStreamSynchronize(e->side));  // (the map build's events may live there)
   HIP_OR_FAIL(e, hipStreamSynchronize(e->stream));
   double tot = 0; int n = 0;
   auto it = e->prof.recs.find(cls);
