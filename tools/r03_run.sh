@@ -1,4 +1,5 @@
 #!/bin/bash
-for i in 1 2; do
-python tools/ab_bench.py --steps 300 default default:FVH_COST_TARGET_ITEMS=70000 default:FVH_COST_TARGET_ITEMS=52000 default:FVH_COST_TARGET_ITEMS=90000 default:FVH_COST_TARGET_ITEMS=200000
-done
+mkdir -p gpurun_out/r03s
+python -m pytest tests -m gpu -x -q 2>&1 | grep -vE "^RCCL|^HIP version|^ROCm|^Hostname|^Librccl|amdgpu.ids" | tail -6 > gpurun_out/r03s/pytest_full.txt
+cat gpurun_out/r03s/pytest_full.txt
+FVH_COMMIT=05f4b179e1e1 bash tools/r03_artifacts.sh all
