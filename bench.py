@@ -397,10 +397,16 @@ def run_stream(args, steps, warmup, cpu_loops=15, frames_n=10):
     ndt.set_target_cloud_device(ptr, n, 3)
     state = {"k": 0, "last": None, "n_ds": 0}
 
+    # the filter runs on the registration handle's stream and reports its count one kernel early (fvh_voxelgrid_filter_device_async):
+    # upload, map build and LM kernel are queued behind its last kernel while that kernel runs
+    shared = os.environ.get("FVH_BENCH_STREAM_SYNC", "0") != "1"  # (A/B knob: 1 = the filter on its own stream, synchronous count)
+    if shared:
+        vg.share_stream(ndt)
+
     def step():
         state["k"] += 1
         i = seq[state["k"] % len(seq)]
-        ptr, n = vg.filter_device(d_frames[i].data_ptr(), len(frames[i]), 0.25, vg.APPROXIMATE)
+        ptr, n = vg.filter_device(d_frames[i].data_ptr(), len(frames[i]), 0.25, vg.APPROXIMATE, asynchronous=shared)
         ndt.set_source_cloud_device(ptr, n, 3)
         state["last"] = ndt.align()
         ndt.swap_source_and_target()
@@ -507,6 +513,7 @@ def run_stream(args, steps, warmup, cpu_loops=15, frames_n=10):
     pipelined = None
     try:
         import threading
+        vg.share_stream(None)  # (two filter handles with their own streams and a host thread from here on)
         vgs = [vg, capi.VoxelGrid(0)]
         slots = [None, None]
         ready = [threading.Event(), threading.Event()]

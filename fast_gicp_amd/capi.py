@@ -456,13 +456,32 @@ class VoxelGrid:
         self._check(self._lib.fvh_voxelgrid_get_points(self._h, _p(out)), "fvh_voxelgrid_get_points")
         return out
 
-    def filter_device(self, d_ptr, n, leaf, method=APPROXIMATE, stride=3):
-        """Device pointer in (n points, `stride` floats apart); returns (device pointer to packed xyz, count) valid until the next filter call."""
+    def share_stream(self, core):
+        """Run this filter on the stream of a registration handle (NDTCore / VGICPCore; None: back to its own): its output is then
+        ordered before whatever that handle queues next, and filter_device(..., asynchronous=True) may return while the last kernel
+        of the filter is still running. The registration handle must outlive the sharing."""
+        if core is None:
+            self._check(self._lib.fvh_voxelgrid_share_stream_with_ndt(self._h, None), "fvh_voxelgrid_share_stream_with_ndt")
+        elif isinstance(core, NDTCore):
+            self._check(self._lib.fvh_voxelgrid_share_stream_with_ndt(self._h, core.h), "fvh_voxelgrid_share_stream_with_ndt")
+        else:
+            self._check(self._lib.fvh_voxelgrid_share_stream_with_vgicp(self._h, core.h), "fvh_voxelgrid_share_stream_with_vgicp")
+
+    def filter_device(self, d_ptr, n, leaf, method=APPROXIMATE, stride=3, asynchronous=False):
+        """Device pointer in (n points, `stride` floats apart); returns (device pointer to packed xyz, count) valid until the next filter call.
+        asynchronous (after share_stream): the count is final on return, the points are complete in the shared stream's order only."""
         m = C.c_int(0)
-        self._check(self._lib.fvh_voxelgrid_filter_device(self._h, int(method), C.c_void_p(d_ptr), int(n), int(stride), C.c_float(leaf), C.byref(m)), "fvh_voxelgrid_filter_device")
+        fn = self._lib.fvh_voxelgrid_filter_device_async if asynchronous else self._lib.fvh_voxelgrid_filter_device
+        self._check(fn(self._h, int(method), C.c_void_p(d_ptr), int(n), int(stride), C.c_float(leaf), C.byref(m)), "fvh_voxelgrid_filter_device")
         ptr = C.c_void_p()
         self._check(self._lib.fvh_voxelgrid_device_points(self._h, C.byref(ptr), C.byref(m)), "fvh_voxelgrid_device_points")
         return ptr.value or 0, m.value
+
+    def get_points(self, n):
+        """Host copy of the last filter_device() result (n = the count it returned); ordered after the filter on its stream."""
+        out = np.empty((int(n), 3), np.float32)
+        self._check(self._lib.fvh_voxelgrid_get_points(self._h, _p(out)), "fvh_voxelgrid_get_points")
+        return out
 
     def profile_enable(self, on=True):
         self._check(self._lib.fvh_voxelgrid_profile_enable(self._h, int(on)), "profile_enable")

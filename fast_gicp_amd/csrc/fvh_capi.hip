@@ -296,7 +296,10 @@ struct Engine {
     // front of the LM kernel (kernel trace, profiles/r03_side_stream_knn.md). Bounded: then the packet after all.
     for (int spins = 0; spins < 400; spins++) {
       const hipError_t q = hipEventQuery(side_done);
-      if (q == hipSuccess) return FVH_OK;  // (kernels launched from here on see the finished map)
+      if (q == hipSuccess) {  // (kernels launched from here on see the finished map)
+        if (spins) (void)hipGetLastError();  // "not ready" must not be what the next launch check reads
+        return FVH_OK;
+      }
       if (q != hipErrorNotReady) break;
     }
     (void)hipGetLastError();
@@ -333,6 +336,7 @@ struct Engine {
     hipError_t e = hipSetDevice(dev);
     if (e != hipSuccess) return hipfail(e, "hipSetDevice");
     if ((e = hipStreamCreateWithFlags(&stream, hipStreamNonBlocking)) != hipSuccess) return hipfail(e, "hipStreamCreate");
+    owned_stream = stream;
     if ((e = hipHostMalloc(&pinned, sizeof(LmState) + 1024, hipHostMallocDefault)) != hipSuccess) return hipfail(e, "hipHostMalloc");
     if (hipHostMalloc(&result_host, sizeof(LmState) + 64, hipHostMallocMapped | hipHostMallocCoherent) == hipSuccess) {
       std::memset(result_host, 0, sizeof(LmState) + 64);
@@ -360,7 +364,9 @@ struct Engine {
     return FVH_OK;
   }
   bool counted = false;
+  hipStream_t owned_stream = nullptr;  // the stream init() made; `stream` may be another handle's (fvh_voxelgrid_share_stream_*)
   void shutdown() {
+    if (stream != owned_stream) stream = owned_stream;  // a borrowed stream is its owner's to drain and destroy
     if (counted) { g_live_engines.fetch_sub(1); counted = false; }
     (void)hipSetDevice(device);
     if (side) (void)hipStreamSynchronize(side);
@@ -1491,7 +1497,7 @@ inline float host_ordered_to_float(unsigned u) {
 
 // pcl::ApproximateVoxelGrid: the fused six-launch chain of kernels_downsample.hpp (no memset, no key / index arrays; the count
 // comes back through mapped host memory instead of a copy kernel + stream synchronisation)
-int downsample_approx(Engine* e, DownsampleDev& d, const float* xyz, int n, int stride, bool on_device, float leaf, int* out_n) {
+int downsample_approx(Engine* e, DownsampleDev& d, const float* xyz, int n, int stride, bool on_device, float leaf, int* out_n, bool early = false) {
   if (n < 0 || (n > 0 && !xyz)) return e->fail(FVH_ERR_INVALID_ARGUMENT, "voxelgrid: null points");
   if (stride != 3 && stride != 4) return e->fail(FVH_ERR_INVALID_ARGUMENT, "voxelgrid: stride must be 3 or 4 floats");
   if (n == 0) return FVH_OK;
@@ -1526,8 +1532,10 @@ int downsample_approx(Engine* e, DownsampleDev& d, const float* xyz, int n, int 
     avg_binscan_kernel<<<AVG_SLOTS / 4, 256, 0, e->stream>>>(hist, nwaves, totals, st);
     avg_scatter_kernel<<<wblocks, 256, 0, e->stream>>>(d_xyz, n, stride, inv, nwaves, hist, st, sorted);
     avg_mark_kernel<<<pblocks, 256, 0, e->stream>>>(sorted, n, inv, head, d.trig.as<unsigned>(), st);
-    avg_scan_kernel<<<1, 1024, 0, e->stream>>>(d.trig.as<unsigned>(), nwords, d.scan.as<unsigned>(), st);
-    avg_emit_kernel<<<pblocks, 256, 0, e->stream>>>(sorted, head, n, inv, d.trig.as<unsigned>(), d.scan.as<unsigned>(), st, d.out.as<float>(), e->prof.on ? nullptr : e->result_dev, seq);
+    // early: the count travels to the host from the scan kernel and the call returns while the emit kernel runs (same-stream consumers only)
+    early = early && on_device && e->result_dev && !e->prof.on;
+    avg_scan_kernel<<<1, 1024, 0, e->stream>>>(d.trig.as<unsigned>(), nwords, d.scan.as<unsigned>(), st, early ? e->result_dev : nullptr, seq);
+    avg_emit_kernel<<<pblocks, 256, 0, e->stream>>>(sorted, head, n, inv, d.trig.as<unsigned>(), d.scan.as<unsigned>(), st, d.out.as<float>(), (e->prof.on || early) ? nullptr : e->result_dev, seq);
   }
   HIP_OR_FAIL(e, hipGetLastError());
   unsigned long long count = 0, bad = 0;
@@ -1557,14 +1565,14 @@ int downsample_approx(Engine* e, DownsampleDev& d, const float* xyz, int n, int 
   return FVH_OK;
 }
 
-int downsample(Engine* e, DownsampleDev& d, int method, const float* xyz, int n, int stride, bool on_device, float leaf, int* out_n) {
+int downsample(Engine* e, DownsampleDev& d, int method, const float* xyz, int n, int stride, bool on_device, float leaf, int* out_n, bool early = false) {
   if (!out_n) return e->fail(FVH_ERR_INVALID_ARGUMENT, "voxelgrid: null out_n");
   if (method != FVH_VOXELGRID_EXACT && method != FVH_VOXELGRID_APPROXIMATE) return e->fail(FVH_ERR_INVALID_ARGUMENT, "voxelgrid: unknown method");
   if (!(leaf > 0.f)) return e->fail(FVH_ERR_INVALID_ARGUMENT, "voxelgrid: leaf size must be > 0");
   int rc = FVH_OK;
   d.out_n = 0;
   *out_n = 0;
-  if (method == FVH_VOXELGRID_APPROXIMATE) return downsample_approx(e, d, xyz, n, stride, on_device, leaf, out_n);
+  if (method == FVH_VOXELGRID_APPROXIMATE) return downsample_approx(e, d, xyz, n, stride, on_device, leaf, out_n, early);
   rc = upload_cloud(e, d.cloud, xyz, n, stride, on_device, false);
   if (rc) return rc;
   if (n == 0) return FVH_OK;
@@ -2249,6 +2257,29 @@ const char* fvh_voxelgrid_last_error(const fvh_voxelgrid* h) { return h ? h->e.e
 int fvh_voxelgrid_filter(fvh_voxelgrid* h, int method, const float* xyz, int n, float leaf, int* out_n) { CHECK_HANDLE(h); return downsample(&h->e, h->d, method, xyz, n, 3, false, leaf, out_n); }
 int fvh_voxelgrid_filter_strided(fvh_voxelgrid* h, int method, const float* xyz, int n, int stride, float leaf, int* out_n) { CHECK_HANDLE(h); return downsample(&h->e, h->d, method, xyz, n, stride, false, leaf, out_n); }
 int fvh_voxelgrid_filter_device(fvh_voxelgrid* h, int method, const float* d_xyz, int n, int stride, float leaf, int* out_n) { CHECK_HANDLE(h); return downsample(&h->e, h->d, method, d_xyz, n, stride, true, leaf, out_n); }
+// Extension for a device-resident pipeline (no PCL counterpart): the filter runs on the registration handle's stream, so what it
+// writes is ordered before whatever that handle queues next, and the _async call returns as soon as the COUNT is known (it comes
+// from the scan kernel, one kernel before the centroids exist): set_*_cloud_device + align are queued behind the emit kernel
+// while it runs -- no idle stream between the filter and the registration. The output buffer is complete in stream order only:
+// without a shared stream the call is the synchronous one.
+int fvh_voxelgrid_share_stream_with_ndt(fvh_voxelgrid* h, fvh_ndt* other) {
+  CHECK_HANDLE(h);
+  HIP_OR_FAIL(&h->e, hipStreamSynchronize(h->e.stream));
+  if (other && other->e.device != h->e.device) return h->e.fail(FVH_ERR_INVALID_ARGUMENT, "share_stream: the two handles live on different devices");
+  h->e.stream = other ? other->e.stream : h->e.owned_stream;  // null: back to the filter's own stream
+  return FVH_OK;
+}
+int fvh_voxelgrid_share_stream_with_vgicp(fvh_voxelgrid* h, fvh_vgicp* other) {
+  CHECK_HANDLE(h);
+  HIP_OR_FAIL(&h->e, hipStreamSynchronize(h->e.stream));
+  if (other && other->e.device != h->e.device) return h->e.fail(FVH_ERR_INVALID_ARGUMENT, "share_stream: the two handles live on different devices");
+  h->e.stream = other ? other->e.stream : h->e.owned_stream;
+  return FVH_OK;
+}
+int fvh_voxelgrid_filter_device_async(fvh_voxelgrid* h, int method, const float* d_xyz, int n, int stride, float leaf, int* out_n) {
+  CHECK_HANDLE(h);
+  return downsample(&h->e, h->d, method, d_xyz, n, stride, true, leaf, out_n, /*early=*/h->e.stream != h->e.owned_stream);
+}
 int fvh_voxelgrid_get_points(fvh_voxelgrid* h, float* out_xyz) {
   CHECK_HANDLE(h);
   if (h->d.out_n == 0) return FVH_OK;

@@ -343,7 +343,11 @@ __global__ __launch_bounds__(256) void avg_mark_kernel(const float4* __restrict_
 
 // ONE workgroup of 1024 threads: block_base[b] = triggers with original index < 1024 b; slot_rank = exclusive scan of slot_used;
 // the count of output points goes to the device state (avg_emit hands it to the host).
-__global__ __launch_bounds__(1024) void avg_scan_kernel(const unsigned* __restrict__ trigbits, int nwords, unsigned* __restrict__ block_base /* [nblocks + 1] */, AvgState* __restrict__ st) {
+// `early_result` (mapped host memory, or null): the count is known HERE, one kernel before the centroids exist -- a caller that
+// consumes the output on the same stream (fvh_voxelgrid_filter_device_async) gets it now and queues its next stage behind the emit
+// kernel while that kernel runs; the emit kernel then reports nothing.
+__global__ __launch_bounds__(1024) void avg_scan_kernel(const unsigned* __restrict__ trigbits, int nwords, unsigned* __restrict__ block_base /* [nblocks + 1] */, AvgState* __restrict__ st,
+                                                        unsigned long long* __restrict__ early_result = nullptr /* {count, bad, seq} */, unsigned long long seq = 0) {
   __shared__ unsigned wsum[16];
   __shared__ unsigned carry;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -387,6 +391,13 @@ __global__ __launch_bounds__(1024) void avg_scan_kernel(const unsigned* __restri
       st->slot_rank[AVG_SLOTS] = used;
       st->used_slots = used;
       st->trig_total = trig;
+      if (early_result) {  // (every setter of `bad` ran in the first kernel of the chain)
+        __hip_atomic_store(&early_result[0], (unsigned long long)(trig + used), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(&early_result[1], (unsigned long long)st->bad, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        st->bad = 0u;  // consumed: re-armed for the next call
+        __threadfence_system();
+        __hip_atomic_store(&early_result[2], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+      }
     }
   }
 }

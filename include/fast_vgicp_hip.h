@@ -267,6 +267,14 @@ const char* fvh_voxelgrid_last_error(const fvh_voxelgrid* h);
 int fvh_voxelgrid_filter(fvh_voxelgrid* h, int method, const float* xyz, int n, float leaf, int* out_n);                       /* setLeafSize(l,l,l); setInputCloud; filter */
 int fvh_voxelgrid_filter_strided(fvh_voxelgrid* h, int method, const float* xyz, int n, int stride_floats /* 3, or 4 for xyzi (KITTI .bin, kitti.cpp:48-60) */, float leaf, int* out_n);
 int fvh_voxelgrid_filter_device(fvh_voxelgrid* h, int method, const float* d_xyz, int n, int stride_floats, float leaf, int* out_n);
+/* Device-resident pipeline (no PCL counterpart; kitti.cpp:95-128 with every stage on the GPU): run the filter on the registration
+ * handle's stream (null: back to its own) -- its output is then ordered before whatever that handle queues next -- and let
+ * _async return as soon as the output COUNT is known, while the last kernel of the filter still runs: the caller hands
+ * fvh_voxelgrid_device_points() to fvh_*_set_*_cloud_device() of THAT handle. Without a shared stream _async is the synchronous call.
+ * The registration handle must outlive the sharing (un-share or destroy the filter first). */
+int fvh_voxelgrid_share_stream_with_ndt(fvh_voxelgrid* h, fvh_ndt* registration);
+int fvh_voxelgrid_share_stream_with_vgicp(fvh_voxelgrid* h, fvh_vgicp* registration);
+int fvh_voxelgrid_filter_device_async(fvh_voxelgrid* h, int method, const float* d_xyz, int n, int stride_floats, float leaf, int* out_n);
 int fvh_voxelgrid_get_points(fvh_voxelgrid* h, float* out_xyz /* host or device, 3*out_n floats */);
 int fvh_voxelgrid_device_points(fvh_voxelgrid* h, const float** d_xyz, int* n);
 int fvh_voxelgrid_profile_enable(fvh_voxelgrid* h, int on);

@@ -137,3 +137,52 @@ def test_strided_host_input_equals_packed(O, vg):
     xyzi = np.column_stack([f, np.random.default_rng(1).uniform(0, 1, len(f)).astype(np.float32)])
     for m, ref in ((vg.APPROXIMATE, O.approx_voxelgrid), (vg.EXACT, O.voxelgrid)):
         _same(vg.filter_strided(xyzi, 4, 0.25, m), ref(f, 0.25))
+
+
+def test_shared_stream_async_filter_feeds_the_registration(O):
+    """fvh_voxelgrid_share_stream_with_ndt + fvh_voxelgrid_filter_device_async: the count comes back one kernel early and the points
+    are complete in the registration handle's stream order only -- read back in that order they must be the filtered cloud
+    (bit-exact against the oracle, in order), frame after frame on the same buffers, and the odometry that consumes them on the
+    device must equal the synchronous pipeline's. A non-finite input is still refused; without a shared stream the call is the synchronous one."""
+    import torch
+    from fast_gicp_amd import capi
+    frames = [util.lidar_frame(i) for i in range(4)]
+    d_frames = [torch.from_numpy(f).cuda() for f in frames]
+    torch.cuda.synchronize()
+
+    def run(asynchronous):
+        vg, ndt = capi.VoxelGrid(0), capi.NDTCore(0)
+        ndt.set_distance_mode(capi.NDT_D2D); ndt.set_neighbor_search_method(capi.DIRECT7); ndt.set_resolution(1.0)
+        if asynchronous:
+            vg.share_stream(ndt)
+        ptr, n = vg.filter_device(d_frames[0].data_ptr(), len(frames[0]), 0.25, vg.APPROXIMATE, asynchronous=asynchronous)
+        ndt.set_target_cloud_device(ptr, n, 3)
+        clouds, poses = [vg.get_points(n)], []
+        for i in range(1, 4):
+            ptr, n = vg.filter_device(d_frames[i].data_ptr(), len(frames[i]), 0.25, vg.APPROXIMATE, asynchronous=asynchronous)
+            ndt.set_source_cloud_device(ptr, n, 3)
+            poses.append(ndt.align()["T"].copy())
+            clouds.append(vg.get_points(n))
+            ndt.swap_source_and_target()
+        if asynchronous:  # a bad frame is reported by the early result too, and the handle keeps working
+            bad = frames[1].copy(); bad[7, 1] = np.nan
+            t = torch.from_numpy(bad).cuda(); torch.cuda.synchronize()
+            with pytest.raises(capi.FvhError):
+                vg.filter_device(t.data_ptr(), len(bad), 0.25, vg.APPROXIMATE, asynchronous=True)
+            ptr, n = vg.filter_device(d_frames[1].data_ptr(), len(frames[1]), 0.25, vg.APPROXIMATE, asynchronous=True)
+            assert n == len(clouds[1])
+            vg.share_stream(None)
+            ptr, n = vg.filter_device(d_frames[2].data_ptr(), len(frames[2]), 0.25, vg.APPROXIMATE, asynchronous=True)  # = synchronous now
+            assert n == len(clouds[2])
+            _same(vg.get_points(n), clouds[2])
+        vg.close(); ndt.close()
+        return clouds, poses
+
+    sync_clouds, sync_poses = run(False)
+    async_clouds, async_poses = run(True)
+    for i in range(4):
+        ref = O.approx_voxelgrid(frames[i], 0.25)
+        _same(sync_clouds[i], ref)
+        _same(async_clouds[i], ref)
+    for a, b in zip(sync_poses, async_poses):
+        assert util.rel_err(a, b) < 1e-9  # (two builds of each map: fp64 atomics in arrival order)

@@ -445,3 +445,36 @@ np.savez(sys.argv[1], **out)
             counts = [1, -1] if k.startswith("v") else [-2, -1]   # correspondences / error evaluations
             assert all(a[i] == b[i] for i in counts), (k, name)
     assert res[0]["v1"][1] > 10000  # (the comparison is not vacuous: tens of thousands of correspondences)
+
+
+def test_both_knn_walks_give_the_same_lists(tmp_path):
+    """knn_tiled1_kernel<true> (boxes nearest first: clouds up to 65,536 points) and <false> (index order: larger clouds) differ in
+    the order candidates are met, never in the result -- the k smallest (distance, index) keys. Each walk is forced onto the size
+    the other one normally serves (FVH_KNN_NEAREST_FIRST_MAX_POINTS, read once per process); the lists must be equal element by
+    element, for a small cloud with far outliers (the case the nearest-first walk exists for) and for a 100k one."""
+    import os
+    import subprocess
+    import sys
+    code = r"""
+import sys, numpy as np
+sys.path.insert(0, %r)
+from fast_gicp_amd import capi
+rng = np.random.default_rng(4)
+small = rng.uniform(-20, 20, size=(12000, 3)).astype(np.float32); small[:, 2] *= 0.1
+small = np.vstack([small, rng.uniform(-400, 400, size=(37, 3)).astype(np.float32)])   # stragglers: their neighbours are far from their tile
+big = rng.uniform(-60, 60, size=(100000, 3)).astype(np.float32); big[:, 2] *= 0.05
+out = {}
+for name, cloud, k in (("small", small, 20), ("small_k64", small[:3000], 64), ("big", big, 20)):
+    c = capi.VGICPCore(0)
+    c.set_source_cloud(cloud); c.find_source_neighbors(k)
+    out[name] = c.get_neighbors("source")
+    c.close()
+np.savez(sys.argv[1], **out)
+""" % util.ROOT
+    res = []
+    for name, limit in (("index_order", "0"), ("nearest_first", "100000000")):
+        path = str(tmp_path / (name + ".npz"))
+        subprocess.check_call([sys.executable, "-c", code, path], env=dict(os.environ, FVH_KNN_NEAREST_FIRST_MAX_POINTS=limit))
+        res.append(np.load(path))
+    for key in res[0].files:
+        assert np.array_equal(res[0][key], res[1][key]), key
