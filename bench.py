@@ -175,6 +175,7 @@ def cpu_baseline_vgicp(tgt, src, res, search, cov, budget_s, mode="reuse", count
 
     t_begin = time.perf_counter()
     sweep = {}
+    swept = []
     best = None
     counts = counts or thread_counts()
     for th in counts:  # ascending: the sweep stops once more threads stop paying (a 256-thread OpenMP team on 17k-item loops is 40x slower than 64)
@@ -187,19 +188,27 @@ def cpu_baseline_vgicp(tgt, src, res, search, cov, budget_s, mode="reuse", count
         loops = int(max(1, min(10, (budget_s / (3 * len(counts))) / max(t, 1e-3))))
         t = min(t, time_loops(g, loops) / loops)
         sweep[th] = round(1.0 / t, 3)
+        swept.append((t, th, g))
         if best is None or t < best[1]:
             best = (th, t, g)
         elif t > 1.5 * best[1]:
             break
         if time.perf_counter() - t_begin > budget_s * 0.75:
             break
-    th, t, g = best
+    # the two best thread counts of the (short, noisy) sweep are both timed on the rest of the budget; the faster one is reported
+    # -- a lucky sweep sample at one count must not decide which configuration stands for the host
+    swept.sort(key=lambda x: x[0])
     left = budget_s - (time.perf_counter() - t_begin)
-    loops = int(max(10, min(100, left / max(t, 1e-3))))  # (never fewer than 10 iterations, whatever the budget says)
-    el = time_loops(g, loops)
-    return {"value": round(loops / el, 3), "unit": "registrations/sec", "cores": th, "kind": "port",
-            "sample": "%d iterations of the %s on the same pair/config (oracle/liboracle.so, OpenMP, %d threads = best of the sweep)" % (
+    finals = []
+    for t, th, g in swept[:2]:
+        loops = int(max(10, min(100, (left / len(swept[:2])) / max(t, 1e-3))))  # (never fewer than 10 iterations, whatever the budget says)
+        el = time_loops(g, loops)
+        finals.append((loops / el, th, loops))
+    rate, th, loops = max(finals)
+    return {"value": round(rate, 3), "unit": "registrations/sec", "cores": th, "kind": "port",
+            "sample": "%d iterations of the %s on the same pair/config (oracle/liboracle.so, OpenMP, %d threads = the faster of the sweep's two best thread counts, both re-timed)" % (
                 loops, "100times_reuse loop" if mode == "reuse" else "scan-to-map loop (map prepared once)", th),
+            "confirmed_registrations_per_sec": {str(c): round(r, 3) for r, c, _ in finals},
             "thread_sweep_registrations_per_sec": sweep, "host_cores": os.cpu_count(), "omp_proc_bind": os.environ.get("OMP_PROC_BIND")}
 
 
