@@ -95,6 +95,7 @@ struct VoxelMapDev {
 
 struct Profiler {
   bool on = false;
+  bool cost_only = false;  // level 2: only the LM / cost launches are bracketed (two events per registration instead of twelve)
   struct Rec { std::vector<std::pair<hipEvent_t, hipEvent_t>> ev; size_t used = 0; };
   std::map<std::string, Rec> recs;
   hipEvent_t begin(const char* cls, hipStream_t s, hipEvent_t* stop_out) {
@@ -442,7 +443,9 @@ struct Engine {
 
 struct ProfScope {
   Engine* e; hipEvent_t stop = nullptr; hipStream_t st;
-  ProfScope(Engine* e_, const char* cls, hipStream_t on = nullptr) : e(e_), st(on ? on : e_->stream) { if (e->prof.on) e->prof.begin(cls, st, &stop); }
+  ProfScope(Engine* e_, const char* cls, hipStream_t on = nullptr) : e(e_), st(on ? on : e_->stream) {
+    if (e->prof.on && (!e->prof.cost_only || std::strcmp(cls, "cost") == 0)) e->prof.begin(cls, st, &stop);
+  }
   ~ProfScope() { if (stop) (void)hipEventRecord(stop, st); }
 };
 
@@ -1040,7 +1043,7 @@ int launch_cost(Engine* e, const CostSource& src, const VoxelMapDev& vm, int hos
     // opener's broadcast must outlast that, or a 50 ms skew between ranks would look like a stuck local barrier
     if (P.peer.n > 1 && P.watchdog_ticks) P.watchdog_ticks = std::max(P.watchdog_ticks, 2 * P.peer_watchdog_ticks);
     static const int zc = [] { const char* v = getenv("FVH_ZEROCOPY_RESULT"); return v ? atoi(v) : 1; }();
-    P.result_host = (zc && !e->prof.on) ? e->result_dev : nullptr;  // (event profiling needs the stream drained anyway)
+    P.result_host = (zc && (!e->prof.on || e->prof.cost_only)) ? e->result_dev : nullptr;  // (full stage profiling drains the stream per call anyway; the two events of level 2 do not need it)
     e->zero_copy_armed = P.result_host != nullptr;
     P.bcast = e->bcast.as<double>();
     P.launch_tag = ++e->persist_seq;
@@ -1943,7 +1946,7 @@ static int get_lm_trace(Engine* e, int* n, double* rows6) {
 int fvh_vgicp_set_lm_trace(fvh_vgicp* h, int on) { CHECK_HANDLE(h); h->e.lm_trace_on = on != 0; return FVH_OK; }
 int fvh_vgicp_get_lm_trace(fvh_vgicp* h, int* n, double* rows6) { CHECK_HANDLE(h); return get_lm_trace(&h->e, n, rows6); }
 int fvh_vgicp_fitness_score(fvh_vgicp* h, const double* T, double max_range, double* score) { CHECK_HANDLE(h); return do_fitness(&h->e, h->source, h->target, T, max_range, score); }
-int fvh_vgicp_profile_enable(fvh_vgicp* h, int on) { CHECK_HANDLE_HOST_ONLY(h); h->e.prof.on = on != 0; return FVH_OK; }
+int fvh_vgicp_profile_enable(fvh_vgicp* h, int on) { CHECK_HANDLE_HOST_ONLY(h); h->e.prof.on = on != 0; h->e.prof.cost_only = on == 2; return FVH_OK; }
 int fvh_vgicp_profile_reset(fvh_vgicp* h) { CHECK_HANDLE(h); HIP_OR_FAIL(&h->e, hipStreamSynchronize(h->e.stream)); h->e.prof.reset(); return FVH_OK; }
 int fvh_vgicp_profile_get(fvh_vgicp* h, const char* cls, double* ms, int* n) { CHECK_HANDLE(h); return profile_get(&h->e, cls, ms, n); }
 int fvh_vgicp_debug_set_voxel_hint(fvh_vgicp* h, int num_voxels) { CHECK_HANDLE(h); h->voxelmap.nv_hint = num_voxels; return FVH_OK; }
@@ -2226,7 +2229,7 @@ int fvh_ndt_get_num_correspondences(fvh_ndt* h, int* n) {
   *n = c;
   return FVH_OK;
 }
-int fvh_ndt_profile_enable(fvh_ndt* h, int on) { CHECK_HANDLE(h); h->e.prof.on = on != 0; return FVH_OK; }
+int fvh_ndt_profile_enable(fvh_ndt* h, int on) { CHECK_HANDLE(h); h->e.prof.on = on != 0; h->e.prof.cost_only = on == 2; return FVH_OK; }
 int fvh_ndt_profile_reset(fvh_ndt* h) { CHECK_HANDLE(h); HIP_OR_FAIL(&h->e, hipStreamSynchronize(h->e.stream)); h->e.prof.reset(); return FVH_OK; }
 int fvh_ndt_profile_get(fvh_ndt* h, const char* cls, double* ms, int* n) { CHECK_HANDLE(h); return profile_get(&h->e, cls, ms, n); }
 int fvh_ndt_synchronize(fvh_ndt* h) { CHECK_HANDLE(h); HIP_OR_FAIL(&h->e, hipStreamSynchronize(h->e.stream)); return FVH_OK; }
@@ -2295,7 +2298,7 @@ int fvh_voxelgrid_device_points(fvh_voxelgrid* h, const float** d_xyz, int* n) {
   *n = h->d.out_n;
   return FVH_OK;
 }
-int fvh_voxelgrid_profile_enable(fvh_voxelgrid* h, int on) { CHECK_HANDLE(h); h->e.prof.on = on != 0; return FVH_OK; }
+int fvh_voxelgrid_profile_enable(fvh_voxelgrid* h, int on) { CHECK_HANDLE(h); h->e.prof.on = on != 0; h->e.prof.cost_only = on == 2; return FVH_OK; }
 int fvh_voxelgrid_profile_reset(fvh_voxelgrid* h) { CHECK_HANDLE(h); HIP_OR_FAIL(&h->e, hipStreamSynchronize(h->e.stream)); h->e.prof.reset(); return FVH_OK; }
 int fvh_voxelgrid_profile_get(fvh_voxelgrid* h, double* ms, int* n) { CHECK_HANDLE(h); return profile_get(&h->e, "downsample", ms, n); }
 

@@ -166,7 +166,7 @@ int fvh_vgicp_gicp_align(fvh_vgicp* h, const double* guess16, const fvh_lm_param
 int fvh_vgicp_gicp_get_correspondences(fvh_vgicp* h, int* target_index_per_source_point /* num_source_points ints, -1 = none */);
 
 /* new: per-kernel-class HIP-event timing on the handle's stream (for bench.py's roofline leg) */
-int fvh_vgicp_profile_enable(fvh_vgicp* h, int on);
+int fvh_vgicp_profile_enable(fvh_vgicp* h, int on /* 0 off; 1 every kernel class; 2 the "cost" class only: two events per registration, the result still travels through mapped memory */);
 int fvh_vgicp_profile_reset(fvh_vgicp* h);
 /* kernel_class in {"cost", "knn", "cov", "rbf", "voxelmap", "fitness"}; sums over launches since reset */
 int fvh_vgicp_profile_get(fvh_vgicp* h, const char* kernel_class, double* total_ms, int* launches);
