@@ -675,11 +675,16 @@ int find_neighbors(Engine* e, CloudDev& c, int k) {
     // small clouds: the kernel lasts as long as its slowest queries, and those are the ones the nearest-first walk shortens;
     // the throughput-bound sizes hide them behind the other queries and keep the cheaper index-order walk (kernels_cov.hpp)
     static const int nf_max = [] { const char* v = getenv("FVH_KNN_NEAREST_FIRST_MAX_POINTS"); return v ? atoi(v) : 65536; }();
+    // one query = one wave = one WORKGROUP: a 4-wave workgroup holds its four slots until its slowest query is done (queries take
+    // 8 us on average, 12.6 at the 90th percentile), single-wave workgroups hand each slot back at once: 39.7 -> 37 us at 17k points,
+    // 161 -> 154 us at 100k (FVH_KNN_BLOCK=256 / 128: the old shapes, for A/B runs)
+    static const int knn_block = [] { const char* v = getenv("FVH_KNN_BLOCK"); const int b = v ? atoi(v) : 64; return (b == 256 || b == 128) ? b : 64; }();
+    const int per_block = knn_block / 64;
     if (t.hi > t.lo) {
       if (c.n <= nf_max)
-        knn_tiled1_kernel<true><<<(t.hi - t.lo + 3) / 4, 256, 0, e->stream>>>(c.sorted.as<float4>(), c.bbox.as<float4>(), c.bbox2.as<float4>(), c.n, k, c.nbr.as<int>(), t.lo, t.hi);
+        knn_tiled1_kernel<true><<<(t.hi - t.lo + per_block - 1) / per_block, knn_block, 0, e->stream>>>(c.sorted.as<float4>(), c.bbox.as<float4>(), c.bbox2.as<float4>(), c.n, k, c.nbr.as<int>(), t.lo, t.hi);
       else
-        knn_tiled1_kernel<false><<<(t.hi - t.lo + 3) / 4, 256, 0, e->stream>>>(c.sorted.as<float4>(), c.bbox.as<float4>(), c.bbox2.as<float4>(), c.n, k, c.nbr.as<int>(), t.lo, t.hi);
+        knn_tiled1_kernel<false><<<(t.hi - t.lo + per_block - 1) / per_block, knn_block, 0, e->stream>>>(c.sorted.as<float4>(), c.bbox.as<float4>(), c.bbox2.as<float4>(), c.n, k, c.nbr.as<int>(), t.lo, t.hi);
     }
   }
   HIP_OR_FAIL(e, hipGetLastError());

@@ -363,7 +363,7 @@ template <bool NEAREST_FIRST>
 __global__ __launch_bounds__(256) void knn_tiled1_kernel(const float4* __restrict__ spts, const float4* __restrict__ bbox1, const float4* __restrict__ bbox2, int n, int k,
                                                          int* __restrict__ out_idx, int q_begin = 0, int q_end = 0x7fffffff /* queries = this range of the Morton order (a rank's tile) */) {
   const int lane = threadIdx.x & 63;
-  const int q = q_begin + blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int q = q_begin + blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);  // (launched with 64, 128 or 256 threads: 1, 2 or 4 queries per workgroup)
   if (q >= min(n, q_end)) return;
   KNN_STAMP(0);
   int dbg_tiles = 0, dbg_ins = 0;
