@@ -278,7 +278,6 @@ struct Engine {
   hipStream_t side = nullptr;
   hipEvent_t side_done = nullptr;
   bool side_pending = false;       // a build on `side` the main stream has not been ordered after yet
-  const void* side_reads = nullptr;  // the CloudDev that build reads
   bool quiet = false, was_quiet = false;  // the main stream had drained when the current API call began (set by align on return)
   hipStream_t side_stream() {
     static const bool on = [] { const char* v = getenv("FVH_SIDE_STREAM"); return !v || atoi(v) != 0; }();
@@ -291,7 +290,7 @@ struct Engine {
   }
   int join_side() {
     if (!side_pending) return FVH_OK;
-    side_pending = false; side_reads = nullptr;
+    side_pending = false;
     // As a rule the build ends long before the source chain on the main stream does, and the host -- which runs ahead of the
     // GPU here -- can watch for that at no cost: a wait packet on the main stream instead puts ~6 us of queue processing in
     // front of the LM kernel (kernel trace, profiles/r03_side_stream_knn.md). Bounded: then the packet after all.
@@ -746,6 +745,7 @@ int calc_cov_rbf(Engine* e, CloudDev& c, double kernel_width, double max_dist, i
       if (t.hi > t.lo) {
         // sweep (one query per wave) -> ten totals per query; regularisation with one thread per query
         HIP_OR_FAIL(e, e->rbf_sums.ensure(sizeof(double) * 10 * (size_t)c.n));
+        // (single-wave workgroups, which shortened the k-NN kernel, change nothing here: 152 us either way -- this sweep keeps the VALU pipes 95 % busy)
         cov_rbf1_kernel<<<(t.hi - t.lo + 3) / 4, 256, 0, e->stream>>>(c.sorted.as<float4>(), c.bbox.as<float4>(), c.bbox2.as<float4>(), c.n, (float)kernel_width, md * md, method, c.cov.as<float4>(), t.lo, t.hi,
                                                                       e->rbf_sums.as<double>());
         cov_rbf_finish_kernel<<<(t.hi - t.lo + 255) / 256, 256, 0, e->stream>>>(e->rbf_sums.as<double>(), c.sorted.as<float4>(), c.n, method, c.cov.as<float4>(), t.lo, t.hi);
@@ -866,7 +866,6 @@ int build_voxelmap(Engine* e, const CloudDev& c, VoxelMapDev& vm, double res, bo
   if (on_side) {
     HIP_OR_FAIL(e, hipEventRecord(e->side_done, on_side));
     e->side_pending = true;
-    e->side_reads = &c;
   }
   vm.valid = true;
   e->has_corr = false;
@@ -1290,7 +1289,7 @@ int do_fitness(Engine* e, CloudDev& src, CloudDev& tgt, const double* T16, doubl
 #endif
     {  // one query per wave (the k = 1 search of the GICP path), then a fixed-order reduction
       HIP_OR_FAIL(e, e->fit_best.ensure(sizeof(float) * (size_t)src.n));
-      nn1_corr_kernel<<<(src.n + 3) / 4, 256, 0, e->stream>>>(src.sorted.as<float4>(), src.n, tgt.sorted.as<float4>(), tgt.bbox.as<float4>(), tgt.bbox2.as<float4>(), tgt.n,
+      nn1_corr_kernel<<<src.n, 64, 0, e->stream>>>(src.sorted.as<float4>(), src.n, tgt.sorted.as<float4>(), tgt.bbox.as<float4>(), tgt.bbox2.as<float4>(), tgt.n,
                                                               (const float*)(base + 16), 0.0, nullptr, e->fit_best.as<float>());
       fitness_reduce_kernel<<<1, 1024, 0, e->stream>>>(e->fit_best.as<float>(), src.n, max_range, (double*)base);
     }
@@ -1387,7 +1386,7 @@ int gicp_align(Engine* e, CloudDev& src, CloudDev& tgt, VoxelMapDev& records, co
       const bool first = (launched == 0 && s == 0);
       {
         ProfScope ps(e, "gicp_nn");
-        nn1_corr_kernel<<<(src.n + 3) / 4, 256, 0, e->stream>>>(src.sorted.as<float4>(), src.n, tgt.sorted.as<float4>(), tgt.bbox.as<float4>(), tgt.bbox2.as<float4>(), tgt.n,
+        nn1_corr_kernel<<<src.n, 64, 0, e->stream>>>(src.sorted.as<float4>(), src.n, tgt.sorted.as<float4>(), tgt.bbox.as<float4>(), tgt.bbox2.as<float4>(), tgt.n,
                                                                 reinterpret_cast<const float*>(base + 16), thr * thr, e->corr.as<int>(), nullptr,
                                                                 first ? LmLink{nullptr, nullptr, nullptr, nullptr, 0} : link);
       }
@@ -1440,7 +1439,7 @@ int gicp_update_correspondences(Engine* e, CloudDev& src, CloudDev& tgt, VoxelMa
     } else
 #endif
     {
-      nn1_corr_kernel<<<(src.n + 3) / 4, 256, 0, e->stream>>>(src.sorted.as<float4>(), src.n, tgt.sorted.as<float4>(), tgt.bbox.as<float4>(), tgt.bbox2.as<float4>(), tgt.n,
+      nn1_corr_kernel<<<src.n, 64, 0, e->stream>>>(src.sorted.as<float4>(), src.n, tgt.sorted.as<float4>(), tgt.bbox.as<float4>(), tgt.bbox2.as<float4>(), tgt.n,
                                                               reinterpret_cast<const float*>(base + 16), thr * thr, e->corr.as<int>());
     }
   }

@@ -790,7 +790,7 @@ __global__ __launch_bounds__(256) void cov_rbf1_kernel(const float4* __restrict_
                                                        float max_dist_sq, int method, float4* __restrict__ cov, int q_begin = 0, int q_end = 0x7fffffff,
                                                        double* __restrict__ sums = nullptr /* [10][n]: leave the regularisation to cov_rbf_finish_kernel */) {
   const int lane = threadIdx.x & 63;
-  const int q = q_begin + blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int q = q_begin + blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   if (q >= min(n, q_end)) return;
   const int ntiles = (n + 63) >> 6, nsuper = (ntiles + 63) >> 6;
   const float4 qv = spts[q];
@@ -1019,7 +1019,7 @@ __global__ __launch_bounds__(256) void nn1_corr_kernel(const float4* __restrict_
                                                        float* __restrict__ best_out = nullptr /* getFitnessScore: squared NN distance per query, in the order of ssrc */,
                                                        LmLink lm = LmLink{nullptr, nullptr, nullptr, nullptr, 0} /* device LM (FastGICP): pose and output buffer follow the LM state on the device */) {
   const int lane = threadIdx.x & 63;
-  const int q = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int q = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);  // (one query per wave; launched with one wave per workgroup, see find_neighbors)
   if (q >= ns) return;
   const int ntiles = (nt + 63) >> 6, nsuper = (ntiles + 63) >> 6;
   const float4 qv = ssrc[q];
