@@ -607,6 +607,7 @@ def run_registration(args, workload, cov, search_name, steps, warmup, local_rank
             getattr(core, "calculate_%s_covariances_rbf" % which)(capi.REG_PLANE)
 
     # "single" (align.cpp:58-68): both clouds from scratch
+    d_ptrs = [t.data_ptr() for t in d_clouds]  # (Tensor.data_ptr() is a microsecond of Python on the path between an align and the next launch)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     core.set_target_cloud_device(d_clouds[0].data_ptr(), n_pts[0], 3)
@@ -624,7 +625,7 @@ def run_registration(args, workload, cov, search_name, steps, warmup, local_rank
         if state["host"]:
             core.set_source_cloud(h_clouds[i])  # align.cpp:94-96: a host cloud per registration (H2D inside)
         else:
-            core.set_source_cloud_device(d_clouds[i].data_ptr(), n_pts[i], 3)
+            core.set_source_cloud_device(d_ptrs[i], n_pts[i], 3)
 
     if workload == "synth1m":
         # map-vs-scan localisation (BASELINE configs[4] shape): the 1M-point map stays the target, every step registers a scan

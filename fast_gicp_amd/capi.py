@@ -93,6 +93,8 @@ class _Core:
 
     def __init__(self, device=0):
         self._lib = load()
+        if "_fns" not in type(self).__dict__:
+            type(self)._fns = {}  # per class (VGICPCore / NDTCore have different prefixes)
         self.device = int(device)
         self.h = C.c_void_p()
         rc = getattr(self._lib, self._prefix + "create")(int(device), C.byref(self.h))
@@ -111,7 +113,10 @@ class _Core:
             pass
 
     def _call(self, name, *args):
-        rc = getattr(self._lib, self._prefix + name)(self.h, *args)
+        fn = self._fns.get(name)
+        if fn is None:  # (bound once per class: the attribute lookup on the CDLL sits between an align and the next launch)
+            fn = self._fns[name] = getattr(self._lib, self._prefix + name)
+        rc = fn(self.h, *args)
         if rc != 0:
             msg = getattr(self._lib, self._prefix + "last_error")(self.h)
             raise FvhError("%s%s: status %d: %s" % (self._prefix, name, rc, msg.decode() if msg else ""))
