@@ -31,7 +31,8 @@ if [ "$WHAT" = "pmc" ] || [ "$WHAT" = "all" ]; then
     S=$(find $O/pmc_${w}_SQ -name "*counter_collection.csv" | head -1); S=${S:--}
     SPECS="$SPECS ${w}_cost:cost_kernel:$F:$W:$S"
     case $w in
-      bundled17k|synth1m) SPECS="$SPECS ${w}_knn:knn_tiled1_kernel:$F:$W:$S" ;;
+      bundled17k) SPECS="$SPECS ${w}_knn:knn_tiled1_kernel:$F:$W:$S ${w}_sort:sort_coop_kernel:$F:$W:$S" ;;
+      synth1m) SPECS="$SPECS ${w}_knn:knn_tiled1_kernel:$F:$W:$S" ;;
       synth100k_rbf) SPECS="$SPECS ${w}_rbf:cov_rbf1_kernel:$F:$W:$S" ;;
       lidar_stream) SPECS="$SPECS ${w}_downsample_emit:avg_emit_kernel:$F:$W:$S" ;;
     esac
