@@ -69,3 +69,20 @@ def test_bench_deadline_helper_abandons_a_stuck_leg():
     t0 = time.perf_counter()
     res, hung = bench.run_with_deadline(lambda: time.sleep(30), 0.2)
     assert res is None and hung and time.perf_counter() - t0 < 5
+
+
+def test_bench_cpu_baseline_reports_a_confirmed_thread_count():
+    """bench.py's cpu_baseline leg: the thread sweep is a short, noisy sample, so the two best counts are both re-timed on the rest
+    of the budget and the faster one is what the line reports -- `value` must be one of the confirmed rates, `cores` its thread
+    count, and the sample must say how many iterations were timed (never fewer than 10)."""
+    import importlib
+    import sys
+    sys.path.insert(0, util.ROOT)
+    bench = importlib.import_module("bench")
+    tgt, src, _ = util.synthetic_pair(3000, 2500, seed=5, extent=10.0)
+    r = bench.cpu_baseline_vgicp(tgt, src, 1.0, "DIRECT7", "knn", 1.5, counts=[1, 2])
+    conf = r["confirmed_registrations_per_sec"]
+    assert set(conf) <= {"1", "2"} and len(conf) >= 1
+    assert r["value"] == max(conf.values()) and str(r["cores"]) in conf and conf[str(r["cores"])] == r["value"]
+    assert r["kind"] == "port" and r["unit"] == "registrations/sec"
+    assert int(r["sample"].split()[0]) >= 10
