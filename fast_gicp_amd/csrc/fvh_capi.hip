@@ -1804,12 +1804,19 @@ int fvh_vgicp_gicp_swap_source_and_target(fvh_vgicp* h) {  // FastGICP::swapSour
   return FVH_OK;
 }
 static void cloud_replaced(CloudDev& c) { c.has_cov = false; c.has_nbr = false; }
-int fvh_vgicp_set_source_cloud(fvh_vgicp* h, const float* xyz, int n) { CHECK_HANDLE_SOURCE_CHAIN(h); h->e.has_corr = false; cloud_replaced(h->source); return (upload_cloud(&h->e, h->source, xyz, n, 3, false)); }
-int fvh_vgicp_set_target_cloud(fvh_vgicp* h, const float* xyz, int n) { CHECK_HANDLE(h); h->e.has_corr = false; h->voxelmap.invalidate(); h->gicp_records.invalidate(); cloud_replaced(h->target); return upload_cloud(&h->e, h->target, xyz, n, 3, false); }
-int fvh_vgicp_set_source_cloud_strided(fvh_vgicp* h, const float* xyz, int n, int stride) { CHECK_HANDLE_SOURCE_CHAIN(h); h->e.has_corr = false; cloud_replaced(h->source); return (upload_cloud(&h->e, h->source, xyz, n, stride, false)); }
-int fvh_vgicp_set_target_cloud_strided(fvh_vgicp* h, const float* xyz, int n, int stride) { CHECK_HANDLE(h); h->e.has_corr = false; h->voxelmap.invalidate(); h->gicp_records.invalidate(); cloud_replaced(h->target); return upload_cloud(&h->e, h->target, xyz, n, stride, false); }
-int fvh_vgicp_set_source_cloud_device(fvh_vgicp* h, const float* d, int n, int stride) { CHECK_HANDLE_SOURCE_CHAIN(h); h->e.has_corr = false; cloud_replaced(h->source); return (upload_cloud(&h->e, h->source, d, n, stride, true)); }
-int fvh_vgicp_set_target_cloud_device(fvh_vgicp* h, const float* d, int n, int stride) { CHECK_HANDLE(h); h->e.has_corr = false; h->voxelmap.invalidate(); h->gicp_records.invalidate(); cloud_replaced(h->target); return upload_cloud(&h->e, h->target, d, n, stride, true); }
+// The Morton order of a VGICP cloud is queued right behind its upload: every neighbour search needs it (and large clouds walk the LM
+// loop in it), and the caller's next call -- find_*_neighbors as a rule -- would launch it a few microseconds of host time later
+// with the stream idle in between (kernel trace: 4 us between the pack kernel and the sort).
+static int uploaded(Engine* e, CloudDev& c, int rc) {
+  if (rc || c.n == 0) return rc;
+  return ensure_sorted(e, c);
+}
+int fvh_vgicp_set_source_cloud(fvh_vgicp* h, const float* xyz, int n) { CHECK_HANDLE_SOURCE_CHAIN(h); h->e.has_corr = false; cloud_replaced(h->source); return uploaded(&h->e, h->source, upload_cloud(&h->e, h->source, xyz, n, 3, false)); }
+int fvh_vgicp_set_target_cloud(fvh_vgicp* h, const float* xyz, int n) { CHECK_HANDLE(h); h->e.has_corr = false; h->voxelmap.invalidate(); h->gicp_records.invalidate(); cloud_replaced(h->target); return uploaded(&h->e, h->target, upload_cloud(&h->e, h->target, xyz, n, 3, false)); }
+int fvh_vgicp_set_source_cloud_strided(fvh_vgicp* h, const float* xyz, int n, int stride) { CHECK_HANDLE_SOURCE_CHAIN(h); h->e.has_corr = false; cloud_replaced(h->source); return uploaded(&h->e, h->source, upload_cloud(&h->e, h->source, xyz, n, stride, false)); }
+int fvh_vgicp_set_target_cloud_strided(fvh_vgicp* h, const float* xyz, int n, int stride) { CHECK_HANDLE(h); h->e.has_corr = false; h->voxelmap.invalidate(); h->gicp_records.invalidate(); cloud_replaced(h->target); return uploaded(&h->e, h->target, upload_cloud(&h->e, h->target, xyz, n, stride, false)); }
+int fvh_vgicp_set_source_cloud_device(fvh_vgicp* h, const float* d, int n, int stride) { CHECK_HANDLE_SOURCE_CHAIN(h); h->e.has_corr = false; cloud_replaced(h->source); return uploaded(&h->e, h->source, upload_cloud(&h->e, h->source, d, n, stride, true)); }
+int fvh_vgicp_set_target_cloud_device(fvh_vgicp* h, const float* d, int n, int stride) { CHECK_HANDLE(h); h->e.has_corr = false; h->voxelmap.invalidate(); h->gicp_records.invalidate(); cloud_replaced(h->target); return uploaded(&h->e, h->target, upload_cloud(&h->e, h->target, d, n, stride, true)); }
 int fvh_vgicp_set_source_neighbors(fvh_vgicp* h, int k, const int* idx) { CHECK_HANDLE(h); return set_neighbors(&h->e, h->source, k, idx); }
 int fvh_vgicp_set_target_neighbors(fvh_vgicp* h, int k, const int* idx) { CHECK_HANDLE(h); return set_neighbors(&h->e, h->target, k, idx); }
 int fvh_vgicp_find_source_neighbors(fvh_vgicp* h, int k) { CHECK_HANDLE_SOURCE_CHAIN(h); return h->e.after_source_chain_call(find_neighbors(&h->e, h->source, k)); }
