@@ -72,8 +72,8 @@ def test_bench_deadline_helper_abandons_a_stuck_leg():
 
 
 def test_bench_cpu_baseline_reports_a_confirmed_thread_count():
-    """bench.py's cpu_baseline leg: the thread sweep is a short, noisy sample, so the two best counts are both re-timed on the rest
-    of the budget and the faster one is what the line reports -- `value` must be one of the confirmed rates, `cores` its thread
+    """bench.py's cpu_baseline leg: the thread sweep is a short, noisy sample, so the three best counts are all re-timed on the rest
+    of the budget and the fastest one is what the line reports -- `value` must be one of the confirmed rates, `cores` its thread
     count, and the sample must say how many iterations were timed (never fewer than 10)."""
     import importlib
     import sys
