@@ -16,6 +16,9 @@
 //     linearize() / compute_error() -> fvh_*_update_correspondences / fvh_*_compute_error,
 //     i.e. exactly the reference's call sequence. Both give the same result to fp64 rounding.
 #pragma once
+#if defined(__SSE2__)
+#include <immintrin.h>
+#endif
 #include <array>
 #include <cmath>
 #include <cstddef>
@@ -184,6 +187,74 @@ struct XyzView {
     }
   }
 };
+// out[i] = in[i] with (x, y, z) <- M (x, y, z, 1): pcl::transformPointCloud for the output cloud of align(). It runs between the
+// end of one registration and the first launch of the next with the GPU idle, so packed xyz / xyzw points (12- or 16-byte structs)
+// go four at a time through SSE (the scalar loop: 50 us for 17k points, ~15 % of a registration). Every lane evaluates
+// ((m0 x + m1 y) + m2 z) + m3 in that order without fusing: bit for bit the scalar loop's result.
+template <typename PointT>
+inline void transform_points_scalar(const PointT* in, PointT* out, size_t begin, size_t n, const float* m) {
+  for (size_t i = begin; i < n; i++) {
+    PointT q = in[i];
+    const float x = q.x, y = q.y, z = q.z;
+    q.x = m[0] * x + m[1] * y + m[2] * z + m[3];
+    q.y = m[4] * x + m[5] * y + m[6] * z + m[7];
+    q.z = m[8] * x + m[9] * y + m[10] * z + m[11];
+    out[i] = q;
+  }
+}
+#if defined(__SSE2__)
+inline void fvh_sse_rows(const float* m, __m128 X, __m128 Y, __m128 Z, __m128& ox, __m128& oy, __m128& oz) {
+  auto row = [&](int r) {
+    const __m128 a = _mm_mul_ps(_mm_set1_ps(m[4 * r]), X), b = _mm_mul_ps(_mm_set1_ps(m[4 * r + 1]), Y), c = _mm_mul_ps(_mm_set1_ps(m[4 * r + 2]), Z);
+    return _mm_add_ps(_mm_add_ps(_mm_add_ps(a, b), c), _mm_set1_ps(m[4 * r + 3]));
+  };
+  ox = row(0); oy = row(1); oz = row(2);
+}
+#endif
+template <typename PointT>
+inline void transform_points(const PointT* in, PointT* out, size_t n, const float* m) {
+  size_t done = 0;
+#if defined(__SSE2__)
+  constexpr bool xyz_first = offsetof(PointT, x) == 0 && offsetof(PointT, y) == 4 && offsetof(PointT, z) == 8;
+  if constexpr (xyz_first && sizeof(PointT) == 16) {  // x y z w: a 4 x 4 transpose each way
+    const float* src = reinterpret_cast<const float*>(in);
+    float* dst = reinterpret_cast<float*>(out);
+    for (; done + 4 <= n; done += 4) {
+      __m128 p0 = _mm_loadu_ps(src + 4 * done), p1 = _mm_loadu_ps(src + 4 * done + 4), p2 = _mm_loadu_ps(src + 4 * done + 8), p3 = _mm_loadu_ps(src + 4 * done + 12);
+      _MM_TRANSPOSE4_PS(p0, p1, p2, p3);  // p0 = x's, p1 = y's, p2 = z's, p3 = w's
+      __m128 ox, oy, oz;
+      fvh_sse_rows(m, p0, p1, p2, ox, oy, oz);
+      _MM_TRANSPOSE4_PS(ox, oy, oz, p3);
+      _mm_storeu_ps(dst + 4 * done, ox); _mm_storeu_ps(dst + 4 * done + 4, oy); _mm_storeu_ps(dst + 4 * done + 8, oz); _mm_storeu_ps(dst + 4 * done + 12, p3);
+    }
+  } else if constexpr (xyz_first && sizeof(PointT) == 12) {  // x y z packed: 4 points = 3 vectors
+    const float* src = reinterpret_cast<const float*>(in);
+    float* dst = reinterpret_cast<float*>(out);
+    for (; done + 4 <= n; done += 4) {
+      const __m128 a = _mm_loadu_ps(src + 3 * done);      // x0 y0 z0 x1
+      const __m128 b = _mm_loadu_ps(src + 3 * done + 4);  // y1 z1 x2 y2
+      const __m128 c = _mm_loadu_ps(src + 3 * done + 8);  // z2 x3 y3 z3
+      const __m128 x2y2x3y3 = _mm_shuffle_ps(b, c, _MM_SHUFFLE(2, 1, 3, 2));
+      const __m128 y0z0y1z1 = _mm_shuffle_ps(a, b, _MM_SHUFFLE(1, 0, 2, 1));
+      const __m128 X = _mm_shuffle_ps(a, x2y2x3y3, _MM_SHUFFLE(2, 0, 3, 0));         // x0 x1 x2 x3
+      const __m128 Y = _mm_shuffle_ps(y0z0y1z1, x2y2x3y3, _MM_SHUFFLE(3, 1, 2, 0));  // y0 y1 y2 y3
+      const __m128 Z = _mm_shuffle_ps(y0z0y1z1, c, _MM_SHUFFLE(3, 0, 3, 1));         // z0 z1 z2 z3
+      __m128 ox, oy, oz;
+      fvh_sse_rows(m, X, Y, Z, ox, oy, oz);
+      // back to x0 y0 z0 x1 | y1 z1 x2 y2 | z2 x3 y3 z3
+      const __m128 x0x2y0y2 = _mm_shuffle_ps(ox, oy, _MM_SHUFFLE(2, 0, 2, 0));
+      const __m128 y1y3z1z3 = _mm_shuffle_ps(oy, oz, _MM_SHUFFLE(3, 1, 3, 1));
+      const __m128 z0z2x1x3 = _mm_shuffle_ps(oz, ox, _MM_SHUFFLE(3, 1, 2, 0));
+      const __m128 ra = _mm_shuffle_ps(x0x2y0y2, z0z2x1x3, _MM_SHUFFLE(2, 0, 2, 0));  // x0 y0 z0 x1
+      const __m128 rb = _mm_shuffle_ps(y1y3z1z3, x0x2y0y2, _MM_SHUFFLE(3, 1, 2, 0));  // y1 z1 x2 y2
+      const __m128 rc = _mm_shuffle_ps(z0z2x1x3, y1y3z1z3, _MM_SHUFFLE(3, 1, 3, 1));  // z2 x3 y3 z3
+      _mm_storeu_ps(dst + 3 * done, ra); _mm_storeu_ps(dst + 3 * done + 4, rb); _mm_storeu_ps(dst + 3 * done + 8, rc);
+    }
+  }
+#endif
+  transform_points_scalar(in, out, done, n, m);
+}
+
 template <typename PointT>
 inline std::vector<float> pack_xyz(const PointCloud<PointT>& c) {
   std::vector<float> xyz(c.size() * 3);
@@ -253,14 +324,7 @@ protected:
     }
     final_transformation_ = x0.cast_float();
     output.points.resize(input_->size());  // pcl::transformPointCloud(*input_, output, final_transformation_)
-    for (size_t i = 0; i < input_->size(); i++) {
-      const auto& p = input_->points[i];
-      const float* m = final_transformation_.m;
-      output.points[i] = p;
-      output.points[i].x = m[0] * p.x + m[1] * p.y + m[2] * p.z + m[3];
-      output.points[i].y = m[4] * p.x + m[5] * p.y + m[6] * p.z + m[7];
-      output.points[i].z = m[8] * p.x + m[9] * p.y + m[10] * p.z + m[11];
-    }
+    detail::transform_points(input_->points.data(), output.points.data(), input_->size(), final_transformation_.m);
   }
 
   bool is_converged(const Isometry3d& delta) const {  // :82-91

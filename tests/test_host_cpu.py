@@ -86,3 +86,16 @@ def test_bench_cpu_baseline_reports_a_confirmed_thread_count():
     assert r["value"] == max(conf.values()) and str(r["cores"]) in conf and conf[str(r["cores"])] == r["value"]
     assert r["kind"] == "port" and r["unit"] == "registrations/sec"
     assert int(r["sample"].split()[0]) >= 10
+
+
+def test_vectorised_output_cloud_transform_is_bit_identical(tmp_path):
+    """align(output) fills the transformed source cloud on the host (pcl::transformPointCloud) between two registrations, with the GPU
+    idle: packed xyz / xyzw points go through SSE four at a time. Same bits as the scalar loop for every tail length."""
+    import os
+    import subprocess
+    exe = str(tmp_path / "transform_points_check")
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-ffp-contract=off", "-I", os.path.join(util.ROOT, "include"),
+                           os.path.join(util.ROOT, "tests", "cpp", "transform_points_check.cpp"), "-o", exe])
+    out = subprocess.run([exe], capture_output=True, text=True)
+    assert out.returncode == 0 and "MISMATCH" not in out.stdout, out.stdout
+    assert out.stdout.count("bit-identical") == 17
