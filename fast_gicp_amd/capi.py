@@ -521,6 +521,14 @@ class NDTCore(_Core):
         self._call("get_num_voxels", 0 if which == "source" else 1, C.byref(n))
         return n.value
 
+    def get_voxel_correspondences(self):
+        """(n, 2): (source element, target voxel index of get_voxelmap("target")); the source element is a point index (P2D) or an
+        index into get_voxelmap("source") (D2D)."""
+        n = self.get_num_correspondences()
+        out = np.empty((max(n, 1), 2), np.int32)
+        self._call("get_voxel_correspondences", _p(out))
+        return out[:n]
+
     def get_voxelmap(self, which):
         w = 1 if which == "target" else 0
         n = C.c_int(0)

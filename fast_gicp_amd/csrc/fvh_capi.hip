@@ -2240,6 +2240,33 @@ int fvh_ndt_get_num_correspondences(fvh_ndt* h, int* n) {
   *n = c;
   return FVH_OK;
 }
+// offset-major then source element, invalid pairs removed (ndt_cuda.cu:142-161 builds the list with the functor of find_voxel_correspondences.cu:84-111)
+int fvh_ndt_get_voxel_correspondences(fvh_ndt* h, int* pairs) {
+  CHECK_HANDLE(h);
+  if (!pairs) return FVH_ERR_INVALID_ARGUMENT;
+  const Rebuild rb = h->rebuild_safe();
+  int rc = fetch_voxelmap_host(&h->e, h->target_vm, &rb);
+  if (rc) return rc;
+  std::vector<int> corr;
+  rc = fetch_corr(&h->e, h->e.corr_n_src, corr);
+  if (rc) return rc;
+  int nsrc = h->e.corr_n_src;
+  if (h->distance_mode == FVH_NDT_D2D) {  // only the first num_source_voxels rows are live; row i = source voxel i of the getter
+    rc = fetch_voxelmap_host(&h->e, h->source_vm);
+    if (rc) return rc;
+    nsrc = (int)h->source_vm.h_occupied.size();
+  }
+  size_t w = 0;
+  for (int o = 0; o < h->e.n_off; o++)
+    for (int i = 0; i < nsrc; i++) {
+      const int b = corr[(size_t)i * h->e.n_off + o];
+      if (b < 0) continue;
+      pairs[2 * w] = i;
+      pairs[2 * w + 1] = h->target_vm.bucket_to_index[b];
+      w++;
+    }
+  return FVH_OK;
+}
 int fvh_ndt_profile_enable(fvh_ndt* h, int on) { CHECK_HANDLE(h); h->e.prof.on = on != 0; h->e.prof.cost_only = on == 2; return FVH_OK; }
 int fvh_ndt_profile_reset(fvh_ndt* h) { CHECK_HANDLE(h); HIP_OR_FAIL(&h->e, hipStreamSynchronize(h->e.stream)); h->e.prof.reset(); return FVH_OK; }
 int fvh_ndt_profile_get(fvh_ndt* h, const char* cls, double* ms, int* n) { CHECK_HANDLE(h); return profile_get(&h->e, cls, ms, n); }

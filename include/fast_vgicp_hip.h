@@ -243,6 +243,10 @@ int fvh_ndt_get_lm_trace(fvh_ndt* h, int* num_rows, double* rows6);
 int fvh_ndt_get_num_voxels(fvh_ndt* h, int which /* 0 source, 1 target */, int* num_voxels);
 int fvh_ndt_get_voxels(fvh_ndt* h, int which, int* coords3, int* num_points, float* means3, float* covs9);
 int fvh_ndt_get_num_correspondences(fvh_ndt* h, int* n);
+/* debug getter of the list behind [NC]:67 (`correspondences`, ndt_cuda.cu:142-161), offset-major, invalid pairs removed:
+ * (source element, target voxel) -- the source element is a point index (P2D) or an index into fvh_ndt_get_voxels(h, 0, ...)
+ * (D2D), the target voxel an index into fvh_ndt_get_voxels(h, 1, ...). 2 * fvh_ndt_get_num_correspondences ints. */
+int fvh_ndt_get_voxel_correspondences(fvh_ndt* h, int* pairs);
 int fvh_ndt_profile_enable(fvh_ndt* h, int on);                                              /* HIP-event timing per kernel class, as fvh_vgicp_profile_* */
 int fvh_ndt_profile_reset(fvh_ndt* h);
 int fvh_ndt_profile_get(fvh_ndt* h, const char* kernel_class, double* total_ms, int* launches);

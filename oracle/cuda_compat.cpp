@@ -500,6 +500,16 @@ void orc_ccv_prepare(void* h) { auto* g = (cc::VGICPCuda*)h; if (g->target_cloud
 double orc_ccv_linearize(void* h, const double* T16, double* H36, double* b6) { return ((cc::VGICPCuda*)h)->linearize(iso_from_rowmajor16(T16), H36, b6); }
 double orc_ccv_compute_error(void* h, const double* T16) { return ((cc::VGICPCuda*)h)->compute_error(iso_from_rowmajor16(T16)); }
 int orc_ccv_num_correspondences(void* h) { return (int)((cc::VGICPCuda*)h)->correspondences.size(); }
+int orc_ccv_get_correspondences(void* h, int* out7) {  // {source index, 0, 0, 0, target voxel x, y, z}, offset-major like find_voxel_correspondences.cu:84-111
+  auto* g = (cc::VGICPCuda*)h;
+  for (size_t n = 0; n < g->correspondences.size(); n++) {
+    const auto& c = g->correspondences[n];
+    int* o = out7 + 7 * n;
+    const VoxelKey& k = g->voxelmap->coords[c.second];
+    o[0] = c.first; o[1] = o[2] = o[3] = 0; o[4] = k.x; o[5] = k.y; o[6] = k.z;
+  }
+  return (int)g->correspondences.size();
+}
 int orc_ccv_corr_history(void* h, int* out, int max_n) { auto& v = ((cc::VGICPCuda*)h)->corr_history; for (size_t i = 0; i < v.size() && (int)i < max_n; i++) out[i] = v[i]; return (int)v.size(); }
 void orc_ccv_get_covs(void* h, int which, double* out) { auto* g = (cc::VGICPCuda*)h; cc_dump_covs(which ? g->target_covs : g->source_covs, out); }
 int orc_ccv_get_voxelmap(void* h, int* coords, int* num, double* means, double* covs) { return cc_dump_map(*((cc::VGICPCuda*)h)->voxelmap, coords, num, means, covs); }
@@ -524,6 +534,18 @@ void orc_ccn_prepare(void* h) { auto* g = (cc::NDTCuda*)h; if (g->target_cloud_u
 double orc_ccn_linearize(void* h, const double* T16, double* H36, double* b6) { return ((cc::NDTCuda*)h)->linearize(iso_from_rowmajor16(T16), H36, b6); }
 double orc_ccn_compute_error(void* h, const double* T16) { return ((cc::NDTCuda*)h)->compute_error(iso_from_rowmajor16(T16)); }
 int orc_ccn_num_correspondences(void* h) { return (int)((cc::NDTCuda*)h)->correspondences.size(); }
+int orc_ccn_get_correspondences(void* h, int* out7) {  // {source element, source voxel x, y, z (D2D), target voxel x, y, z}
+  auto* g = (cc::NDTCuda*)h;
+  for (size_t n = 0; n < g->correspondences.size(); n++) {
+    const auto& c = g->correspondences[n];
+    int* o = out7 + 7 * n;
+    o[0] = c.first; o[1] = o[2] = o[3] = 0;
+    if (g->distance_mode == D2D) { const VoxelKey& s = g->source_voxelmap->coords[c.first]; o[1] = s.x; o[2] = s.y; o[3] = s.z; }
+    const VoxelKey& k = g->target_voxelmap->coords[c.second];
+    o[4] = k.x; o[5] = k.y; o[6] = k.z;
+  }
+  return (int)g->correspondences.size();
+}
 int orc_ccn_corr_history(void* h, int* out, int max_n) { auto& v = ((cc::NDTCuda*)h)->corr_history; for (size_t i = 0; i < v.size() && (int)i < max_n; i++) out[i] = v[i]; return (int)v.size(); }
 int orc_ccn_get_voxelmap(void* h, int which, int* coords, int* num, double* means, double* covs) {
   auto* g = (cc::NDTCuda*)h;

@@ -222,6 +222,13 @@ class _Reg:
     def num_correspondences(self):
         return self._call("num_correspondences")
 
+    def correspondences(self):
+        """Every correspondence of the last linearize() as a row {source element, source voxel x y z (NDT D2D, else 0), target voxel x y z
+        (FastGICP mode: target point index, 0, 0)}, in the oracle's list order (index-level parity tests compare them as sets)."""
+        out = np.empty((max(self.num_correspondences(), 1), 7), np.int32)
+        n = self._call("get_correspondences", _p(out))
+        return out[:n].copy()
+
     def align(self, guess=None):
         g = _f64(np.eye(4) if guess is None else guess)
         r = Result()

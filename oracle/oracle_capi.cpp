@@ -167,6 +167,19 @@ void orc_vgicp_prepare(void* h) {
 double orc_vgicp_linearize(void* h, const double* T16, double* H36, double* b6) { return ((FastVGICP*)h)->linearize(iso_from_rowmajor16(T16), H36, b6); }
 double orc_vgicp_compute_error(void* h, const double* T16) { return ((FastVGICP*)h)->compute_error(iso_from_rowmajor16(T16)); }
 int orc_vgicp_num_correspondences(void* h) { return (int)((FastVGICP*)h)->voxel_correspondences.size(); }
+// index-level parity (tests): every correspondence as {source index, 0, 0, 0, target voxel x, y, z} -- voxels by COORDINATE, so that
+// the list does not depend on anybody's voxel numbering; FastGICP mode: {source index, 0, 0, 0, target point index, 0, 0}
+int orc_vgicp_get_correspondences(void* h, int* out7) {
+  auto* g = (FastVGICP*)h;
+  for (size_t n = 0; n < g->voxel_correspondences.size(); n++) {
+    const auto& c = g->voxel_correspondences[n];
+    int* o = out7 + 7 * n;
+    o[0] = c.first; o[1] = o[2] = o[3] = 0;
+    if (g->gicp_mode) { o[4] = c.second; o[5] = o[6] = 0; }
+    else { const VoxelKey& k = g->voxelmap->coords[c.second]; o[4] = k.x; o[5] = k.y; o[6] = k.z; }
+  }
+  return (int)g->voxel_correspondences.size();
+}
 int orc_vgicp_num_voxels(void* h) { auto* g = (FastVGICP*)h; return g->voxelmap ? (int)g->voxelmap->voxels.size() : -1; }
 void orc_vgicp_get_covs(void* h, int which, double* out) { auto* g = (FastVGICP*)h; copy_m3(which ? g->target_covs : g->source_covs, out); }
 int orc_vgicp_get_voxelmap(void* h, int* coords, int* num, double* means, double* covs) { return dump_voxelmap(*((FastVGICP*)h)->voxelmap, coords, num, means, covs); }
@@ -244,6 +257,19 @@ void orc_ndt_prepare(void* h) { auto* g = (NDT*)h; if (g->target_cloud_updated) 
 double orc_ndt_linearize(void* h, const double* T16, double* H36, double* b6) { return ((NDT*)h)->linearize(iso_from_rowmajor16(T16), H36, b6); }
 double orc_ndt_compute_error(void* h, const double* T16) { return ((NDT*)h)->compute_error(iso_from_rowmajor16(T16)); }
 int orc_ndt_num_correspondences(void* h) { return (int)((NDT*)h)->correspondences.size(); }
+// {source element, source voxel x, y, z (D2D; P2D: zeros), target voxel x, y, z}
+int orc_ndt_get_correspondences(void* h, int* out7) {
+  auto* g = (NDT*)h;
+  for (size_t n = 0; n < g->correspondences.size(); n++) {
+    const auto& c = g->correspondences[n];
+    int* o = out7 + 7 * n;
+    o[0] = c.first; o[1] = o[2] = o[3] = 0;
+    if (g->distance_mode == D2D) { const VoxelKey& s = g->source_voxelmap->coords[c.first]; o[1] = s.x; o[2] = s.y; o[3] = s.z; }
+    const VoxelKey& k = g->target_voxelmap->coords[c.second];
+    o[4] = k.x; o[5] = k.y; o[6] = k.z;
+  }
+  return (int)g->correspondences.size();
+}
 int orc_ndt_get_voxelmap(void* h, int which, int* coords, int* num, double* means, double* covs) {
   auto* g = (NDT*)h;
   return dump_voxelmap(which ? *g->target_voxelmap : *g->source_voxelmap, coords, num, means, covs);

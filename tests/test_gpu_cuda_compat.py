@@ -65,6 +65,49 @@ def test_vgicp_fp32_mode_end_to_end_vs_cuda_compat(O, search):
     c.close(); c64.close()
 
 
+@pytest.mark.parametrize("search", ["DIRECT1", "DIRECT7", "DIRECT27"])
+def test_vgicp_fp32_mode_on_the_cuda_compat_legs_own_covariances(O, search):
+    """Which part of the 5e-4 above is covariance noise and which is cost arithmetic: the engine's fp32 mode is fed the cuda-compat leg's OWN
+    float covariances (fvh_vgicp_set_*_covariances), so that everything upstream of the voxel map is identical -- what is left is the voxel
+    sums (fp64 here, float there: gaussian_voxelmap.cu:164-193), the float voxel coordinate (vector3_hash.cuh:35-38), the float cost terms
+    (compute_derivatives.cu:50-135: a different but equivalent order of float operations) and their summation (fp64 here, a float tree
+    there). Held to north_star's 1e-4 END TO END with equal iteration counts, identical correspondence lists at every step, and the sums
+    at a fixed pose to 1e-4 of their scale. The covariance ESTIMATION (fp64 centred here, float uncentred there) is what the other
+    4e-4 of the test above are."""
+    from fast_gicp_amd import capi
+    tgt, src = util.bundled_pair()
+    cs, os_ = {"DIRECT1": (capi.DIRECT1, O.DIRECT1), "DIRECT7": (capi.DIRECT7, O.DIRECT7), "DIRECT27": (capi.DIRECT27, O.DIRECT27)}[search]
+    g = O.CudaCompatVGICP(search=os_)
+    g.set_target(tgt); g.set_source(src); g.prepare()
+    T0 = util.relative_pose()
+    eo, Ho, bo = g.linearize(T0)  # (estimates the covariances and builds the voxel map on first use)
+    c = capi.VGICPCore(0)
+    c.set_precision(capi.COMPUTE_FP32)
+    c.set_neighbor_search_method(cs)
+    c.set_target_cloud(tgt); c.set_source_cloud(src)
+    c.set_target_covariances(g.get_covs("target")); c.set_source_covariances(g.get_covs("source"))
+    c.create_target_voxelmap()
+    e, H, b = c.linearize(T0)
+    util.assert_same_correspondences(c, g, ordered=True)
+    de, dH = abs(e - eo) / abs(eo), util.rel_err(H, Ho)
+    db = float(np.max(np.abs(b - bo) / np.sqrt(np.abs(np.diag(Ho)) * abs(eo))))
+    print("%s fixed pose, same float covariances: err %.2e H %.2e b %.2e (Cauchy-Schwarz scale)" % (search, de, dH, db))
+    assert de < 1e-4 and dH < 1e-4 and db < 1e-4, (de, dH, db)
+    ro = g.align()
+    fo = g.fitness()
+    r = c.align()
+    f = c.fitness_score(r["T"].astype(np.float32).astype(np.float64))
+    assert r["converged"] and ro["converged"]
+    assert r["num_linearize"] == ro["num_linearize"] and r["num_error_evals"] == ro["num_error_evals"], (r, ro)
+    util.assert_same_correspondences(c, g, ordered=True)  # the lists of the last linearisation of either align
+    dT = util.rel_err(r["T"], ro["T"])
+    print("%s end to end, same float covariances: pose rel %.2e, fitness %.6f vs %.6f, final H %.2e" % (search, dT, f, fo, util.rel_err(r["H"], ro["H"])))
+    assert dT < 1e-4, dT
+    assert abs(f - fo) < 1e-4 * fo, (f, fo)
+    assert util.rel_err(r["H"], ro["H"]) < 1e-3
+    c.close()
+
+
 def test_vgicp_fp32_cost_sums_at_a_fixed_pose_vs_cuda_compat(O):
     """err / H / b at the ground-truth pose of the bundled pair: the engine's float cost on its own (fp64-built) covariances and voxels
     against the all-float device restatement. What differs is upstream of the cost (uncentred float covariances, float voxel sums):

@@ -54,6 +54,8 @@ def test_correspondences_and_sums_match_oracle(O, pair, max_dist):
         thr = np.inf if max_dist is None else float(max_dist) ** 2
         expect = np.where(sq[:, 0].astype(np.float64) < thr, idx[:, 0], -1)
         assert np.array_equal(corr, expect)
+        # ... and the oracle's own (source point, target point) list (fast_gicp_impl.hpp:118-156), pair by pair
+        assert np.array_equal(np.stack([np.nonzero(corr >= 0)[0], corr[corr >= 0]], axis=1), util.sort_rows(g.correspondences()[:, [0, 4]]))
         assert abs(e - eo) <= 1e-9 * abs(eo)
         assert util.rel_err(H, Ho) <= 1e-9 and util.rel_err(b, bo) <= 1e-9
         T2 = util.random_pose(np.random.default_rng(3), 0.2, 0.05) @ T

@@ -43,11 +43,14 @@ def _poses(T_gt, seed):
     return [np.eye(4), T_gt, util.random_pose(np.random.default_rng(seed), 1.0, 0.3) @ T_gt]
 
 
-def _check_sums(c, refs_tols, poses, seed):
-    """linearize + trial-step error of the engine `c` against oracle objects [(oracle, tol), ...] at each pose."""
+def _check_sums(c, refs_tols, poses, seed, d2d=False):
+    """linearize + trial-step error of the engine `c` against oracle objects [(oracle, tol), ...] at each pose; the correspondence
+    PAIRS (source element, voxel coordinate) equal the first oracle's exactly (index-level parity, tests/test_gpu_correspondences.py)."""
     for T in poses:
         e, H, b = c.linearize(T)
         n_corr = c.get_num_correspondences()
+        refs_tols[0][0].linearize(T)
+        util.assert_same_correspondences(c, refs_tols[0][0], d2d=d2d)
         T2 = util.random_pose(np.random.default_rng(seed), 0.2, 0.05) @ T
         e2 = c.compute_error(T2, derivatives=False)
         for g, tol in refs_tols:
@@ -283,7 +286,7 @@ def test_c4_ndt_frame_pair(O, c4, mode):
     for which, rec in maps.items():
         g32.set_voxelmap(which, *rec)
     gt = np.linalg.inv(util.lidar_pose(3)) @ util.lidar_pose(4)
-    _check_sums(c, [(g32, 1e-9), (g64, 2e-5)], _poses(gt, 23), 29)
+    _check_sums(c, [(g32, 1e-9), (g64, 2e-5)], _poses(gt, 23), 29, d2d=(mode == 1))
     r = c.align()
     go = O.NDT(mode=mode, search=D7)
     go.set_target(tgt); go.set_source(src)

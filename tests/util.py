@@ -74,3 +74,49 @@ def sums_close(e, H, b, eo, Ho, bo, tol):
     scale_b = np.sqrt(np.abs(np.diag(Ho)) * abs(eo))
     ok_b = bool(np.all(np.abs(b - bo) <= tol * np.maximum(scale_b, 1e-300)))
     return ok_e and ok_H and ok_b
+
+
+def engine_corr_rows(c, d2d=False):
+    """The engine's correspondence list (fvh_*_get_voxel_correspondences: (source element, voxel index in getter order), offset-major)
+    resolved to rows {source element, source voxel x y z, target voxel x y z} -- voxels by COORDINATE, so the rows do not depend on
+    anybody's voxel numbering. VGICP / NDT P2D: the source element is the point index (source voxel columns 0); NDT D2D: the source
+    element IS a source voxel, numbered differently by the engine and the oracle -> column 0 is zeroed, its coordinate identifies it."""
+    from fast_gicp_amd import capi
+    pairs = np.asarray(c.get_voxel_correspondences(), np.int64).reshape(-1, 2)
+    rows = np.zeros((len(pairs), 7), np.int64)
+    if isinstance(c, capi.NDTCore):
+        tcoords = np.asarray(c.get_voxelmap("target")[0], np.int64)
+        if d2d:
+            rows[:, 1:4] = np.asarray(c.get_voxelmap("source")[0], np.int64)[pairs[:, 0]]
+        else:
+            rows[:, 0] = pairs[:, 0]
+    else:
+        tcoords = np.asarray(c.get_voxelmap()[0], np.int64)
+        rows[:, 0] = pairs[:, 0]
+    rows[:, 4:7] = tcoords[pairs[:, 1]]
+    return rows
+
+
+def oracle_corr_rows(g, d2d=False):
+    rows = np.asarray(g.correspondences(), np.int64)
+    if d2d:
+        rows = rows.copy()
+        rows[:, 0] = 0
+    return rows
+
+
+def sort_rows(rows):
+    rows = np.asarray(rows)
+    return rows[np.lexsort(rows.T[::-1])] if len(rows) else rows
+
+
+def assert_same_correspondences(c, g, d2d=False, ordered=False):
+    """Index-level parity: the engine's (source element, voxel) pairs EQUAL the oracle's -- as a set, or (ordered=True: the cuda-compat
+    leg, whose list is offset-major like find_voxel_correspondences.cu:84-111 and like the engine's getter) as a list."""
+    got, ref = engine_corr_rows(c, d2d), oracle_corr_rows(g, d2d)
+    assert len(got) == len(ref), (len(got), len(ref))
+    assert len(np.unique(got, axis=0)) == len(got), "duplicate pairs in the engine's list"
+    if ordered and not d2d:
+        assert np.array_equal(got, ref), "correspondence lists differ (order included)"
+    else:
+        assert np.array_equal(sort_rows(got), sort_rows(ref)), "correspondence pair sets differ"
