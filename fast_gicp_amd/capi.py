@@ -236,6 +236,13 @@ def debug_slot_pool(device=0):
     return r.value, a.value, c.value
 
 
+def debug_xcd_local():
+    """(wanted, placement_aborts): whether persistent launches still use XCD-local hand-offs, and how many launches the placement check ended."""
+    w, a = C.c_int(0), C.c_int(0)
+    load().fvh_debug_xcd_local(C.byref(w), C.byref(a))
+    return w.value, a.value
+
+
 def device_count():
     n = C.c_int(0)
     rc = load().fvh_device_count(C.byref(n))

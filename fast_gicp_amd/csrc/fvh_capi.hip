@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 #include <dlfcn.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -150,10 +151,16 @@ std::atomic<int> g_live_engines{0};    // engine handles alive in this process t
 struct SlotPool {
   std::mutex mu;
   int reserved[16] = {0}, active[16] = {0}, recent[16] = {0}, calm[16] = {0};
+  int used[16][8] = {{0}};  // slots held per XCD (a spread grid of n workgroups holds ceil(n / 8) on each: block b runs on XCD b % 8)
   std::chrono::steady_clock::time_point last_contention[16];
   static constexpr int DECAY_AFTER = 32;       // releases in a row that saw less concurrency than the estimate before the estimate drops by one
   static constexpr int QUIET_RESET_MS = 20;    // no overlapping align / refusal for this long: the burst is over, the estimate starts again from what is active now
-  int acquire(int dev, int cap, int want) {  // -> granted workgroups (0: use the multi-launch route)
+  struct Grant { int n = 0; unsigned mask = 0; };  // n workgroups; mask != 0: all of them on these XCDs, ceil(n / popcount) each (a launch confined by CostParams::xcd_mask)
+  // `confine_ok`: the caller can run on a SUBSET of the XCDs (its persistent launch is dispatched 8 x too wide and keeps the workgroups
+  // that land there). Taken when other aligns are in flight -- K aligns then share the chip XCD by XCD (8 / K each, the least loaded
+  // ones), each with XCD-local hand-offs, instead of K chip-wide grids of polling waves fighting for the same SIMDs -- or when the
+  // caller prefers ONE XCD for a small grid (`prefer_single`).
+  Grant acquire(int dev, int cap, int want, bool confine_ok, bool prefer_single) {  // -> n == 0: use the multi-launch route
     std::lock_guard<std::mutex> lk(mu);
     dev &= 15;
     const auto now = std::chrono::steady_clock::now();
@@ -165,29 +172,52 @@ struct SlotPool {
     else if (recent[dev] > 1 && now - last_contention[dev] > std::chrono::milliseconds(QUIET_RESET_MS)) { recent[dev] = 1; calm[dev] = 0; }
     recent[dev] = std::max(recent[dev], active[dev]);
     static const int max_split = [] { const char* v = getenv("FVH_SLOT_MAX_SPLIT"); return v ? std::max(1, atoi(v)) : 4; }();
-    const int share = std::max(1, cap / std::max(1, std::min(recent[dev], max_split)));
-    const int grant = std::min(std::min(want, share), cap - reserved[dev]);
-    if (grant < std::min(want, 32)) {  // too little left to be worth a gang launch
+    static const int share_by_xcd = [] { const char* v = getenv("FVH_SHARE_BY_XCD"); return v ? atoi(v) : 1; }();  // 0: round 3's behaviour (chip-wide grids of cap / concurrency workgroups)
+    const int per_xcd = std::max(1, cap / 8);
+    Grant g;
+    const bool contended = recent[dev] > 1;
+    if (confine_ok && ((contended && share_by_xcd) || (prefer_single && want <= per_xcd))) {
+      const int k_max = contended ? std::max(1, 8 / std::max(1, std::min(recent[dev], max_split))) : 1;
+      const int k = std::max(1, std::min(k_max, (want + per_xcd - 1) / per_xcd));
+      int order[8] = {0, 1, 2, 3, 4, 5, 6, 7};
+      std::stable_sort(order, order + 8, [&](int a, int b) { return used[dev][a] < used[dev][b]; });
+      int worst = 0;
+      for (int i = 0; i < k; i++) { g.mask |= 1u << order[i]; worst = std::max(worst, used[dev][order[i]]); }
+      g.n = std::min(want, k * (per_xcd - worst));
+    } else {
+      int worst = 0;
+      for (int x = 0; x < 8; x++) worst = std::max(worst, used[dev][x]);
+      const int share = std::max(1, cap / std::max(1, std::min(recent[dev], max_split)));
+      g.n = std::min(std::min(want, share), 8 * (per_xcd - worst));
+    }
+    if (g.n < std::min(want, 32)) {  // too little left to be worth a gang launch
       // a refused request holds nothing and is never released: it must not stay counted in `active` (round 2 leaked it here, and
       // every later persistent launch of the process got cap / min(recent, 4) workgroups for good). The concurrency ESTIMATE keeps
       // the bump: the next grants shrink so that this caller gets its share on the retry; it decays slowly in release().
       active[dev]--;
       calm[dev] = 0;
       last_contention[dev] = now;
-      return 0;
+      return Grant{};
     }
-    reserved[dev] += grant;
-    return grant;
+    reserved[dev] += g.n;
+    charge(dev, g, +1);
+    return g;
+  }
+  void charge(int dev, const Grant& g, int sign) {
+    const unsigned m = g.mask ? g.mask : 0xFFu;
+    const int k = __builtin_popcount(m), each = (g.n + k - 1) / k;
+    for (int x = 0; x < 8; x++) if ((m >> x) & 1u) used[dev][x] += sign * each;
   }
   void snapshot(int dev, int* res, int* act, int* rec) {
     std::lock_guard<std::mutex> lk(mu);
     dev &= 15;
     *res = reserved[dev]; *act = active[dev]; *rec = recent[dev];
   }
-  void release(int dev, int grant) {
+  void release(int dev, const Grant& g) {
     std::lock_guard<std::mutex> lk(mu);
     dev &= 15;
-    reserved[dev] -= grant;
+    reserved[dev] -= g.n;
+    charge(dev, g, -1);
     active[dev]--;
     // The estimate of the concurrency decays slowly: host threads spend half their time between aligns, so `active` at a release
     // under-reads the contention. (Dropping it at every calm release made four 474-workgroup aligns oscillate: shares grew back to
@@ -201,6 +231,30 @@ struct SlotPool {
   }
 };
 SlotPool g_slots;
+// XCD-local hand-offs of the persistent LM kernel (kernels_cost.hpp: xcd_local). On by default; every launch checks that the
+// dispatcher placed the members of each group on one XCD (abort code 3 otherwise: the block -> XCD mapping is an observation, not a
+// contract), and after XCD_LOCAL_MAX_STRIKES such aborts the process stops asking for it. FVH_XCD_LOCAL=0 never asks for it.
+constexpr int XCD_LOCAL_MAX_STRIKES = 3;
+std::atomic<int> g_xcd_local_strikes{0};
+inline bool xcd_local_wanted() {
+  static const bool env_on = [] { const char* v = getenv("FVH_XCD_LOCAL"); return !v || atoi(v) != 0; }();
+  return env_on && g_xcd_local_strikes.load() < XCD_LOCAL_MAX_STRIKES;
+}
+// the layout of one cost launch: both routes of an align take the same (nb, ng), i.e. the same partition and summation order
+struct GridPlan { int nb = 0; int ng = 0; unsigned mask = 0; int local = 0; };
+// Grids of up to SINGLE_LEVEL_MAX_BLOCKS workgroups (NDT D2D over a few thousand source voxels, DIRECT1 at 17k points):
+//   FVH_SMALL_GRID_LAYOUT=0  chip-wide, ONE group: rows -> workgroup 0 -> broadcast, write-through hand-offs (round 3);
+//                        =1  confined to ONE XCD when they fit (<= a sixth of the co-resident slots): every hand-off is XCD-local;
+//                        =2  chip-wide in EIGHT groups like the large grids (XCD-local rows and broadcast, one cross-XCD hand-off).
+// The group count is a function of the grid size alone, so that every route of an align adds the sums in the same order.
+inline int small_grid_layout() {
+  static const int v = [] { const char* e = getenv("FVH_SMALL_GRID_LAYOUT"); return e ? atoi(e) : 2; }();
+  return v;
+}
+inline int default_groups(int nb) {
+  if (nb > SINGLE_LEVEL_MAX_BLOCKS) return TICKET_GROUPS;
+  return (small_grid_layout() == 2 && nb >= 2 * TICKET_GROUPS) ? TICKET_GROUPS : 1;
+}
 
 struct Engine {
   int device = 0;
@@ -978,7 +1032,7 @@ inline CostShape cost_shape(const Engine* e, const CostSource& src) {
 template <int MODE>
 int launch_cost(Engine* e, const CostSource& src, const VoxelMapDev& vm, int host_phase, const PoseD* lin, const PoseD* ev, const fvh_lm_params* init = nullptr,
                 bool persistent = false, unsigned long long peer_xbase = 0 /* multi-GPU: exchange counter of this launch's first sums exchange */,
-                int grid_limit = 0 /* > 0: at most this many workgroups (the slots granted to a persistent launch) */) {
+                const GridPlan* plan = nullptr /* align(): the layout both routes take (workgroups granted, groups, XCD confinement) */) {
   CostParams P;
   std::memset(&P, 0, sizeof(P));
   P.src_pts = src.pts; P.src_cov = src.cov; P.d_n_src = src.d_n; P.n_src = src.n_upper; P.order = src.order;
@@ -1034,7 +1088,21 @@ int launch_cost(Engine* e, const CostSource& src, const VoxelMapDev& vm, int hos
     if (cap <= 0) return e->fail(FVH_ERR_HIP, "cost kernel: occupancy query failed");
     if (e->peer.attached()) cap = std::max(1, cap / std::max(1, e->peer.ranks_on_device));  // ranks sharing one GPU share its co-resident slots
     blocks = std::min(blocks, cap);
-    if (grid_limit > 0) blocks = std::min(blocks, grid_limit);
+    if (plan && plan->nb > 0) blocks = std::min(blocks, plan->nb);
+  }
+  P.ng = (plan && plan->ng > 0) ? plan->ng : default_groups(blocks);
+  if (P.ng > blocks) P.ng = 1;  // (every group needs its first workgroup)
+  P.nb = blocks;
+  P.xcd_mask = 0; P.xcd_local = 0;
+  int launch_blocks = blocks;
+  if (persistent && plan) {
+    P.xcd_mask = plan->mask & 0xFFu;
+    P.xcd_local = plan->local;
+    if (P.xcd_mask) {  // dispatched 8 x too wide: only the workgroups that land on the chosen XCDs stay (kernels_cost.hpp)
+      const int m = __builtin_popcount(P.xcd_mask);
+      launch_blocks = 8 * ((blocks + m - 1) / m);
+      if (P.ng != m) P.xcd_local = 0;  // (a group would span XCDs: write-through hand-offs)
+    }
   }
   // abort word = 0 (the last 8 bytes of the state; never covered by the state write-back)
   if (e->abort_word_dirty) {
@@ -1053,8 +1121,8 @@ int launch_cost(Engine* e, const CostSource& src, const VoxelMapDev& vm, int hos
     P.launch_tag = ++e->persist_seq;
     e->last_persist_blocks = blocks;
     ProfScope ps(e, "cost");
-    if (e->precision == FVH_COMPUTE_FP32) cost_kernel<float, MODE, true><<<blocks, 256, 0, e->stream>>>(P);
-    else cost_kernel<double, MODE, true><<<blocks, 256, 0, e->stream>>>(P);
+    if (e->precision == FVH_COMPUTE_FP32) cost_kernel<float, MODE, true><<<launch_blocks, 256, 0, e->stream>>>(P);
+    else cost_kernel<double, MODE, true><<<launch_blocks, 256, 0, e->stream>>>(P);
   } else {
     ProfScope ps(e, "cost");
     if (e->precision == FVH_COMPUTE_FP32) cost_kernel<float, MODE, false><<<blocks, 256, 0, e->stream>>>(P);
@@ -1128,7 +1196,7 @@ int do_compute_error(Engine* e, const CostSource& src, VoxelMapDev& vm, const do
 
 template <int MODE>
 int do_align(Engine* e, const CostSource& src, VoxelMapDev& vm, const double* guess16, const fvh_lm_params* params, fvh_lm_result* result, const Rebuild& rebuild_safe,
-             bool retried = false, bool no_persist = false, int forced_grid = 0 /* multi-launch retry of an aborted persistent launch: its grid */) {
+             bool retried = false, bool no_persist = false, const GridPlan* forced_plan = nullptr /* multi-launch retry of an aborted persistent launch: its layout */) {
   if (!guess16 || !result) return e->fail(FVH_ERR_INVALID_ARGUMENT, "align: null argument");
   if (!vm.valid) return e->fail(FVH_ERR_BAD_STATE, "align: target voxel map not built");
   fvh_lm_params p;
@@ -1156,20 +1224,31 @@ int do_align(Engine* e, const CostSource& src, VoxelMapDev& vm, const double* gu
   const bool sharded = MODE == MODE_VGICP && e->peer.attached() && src.shardable;
   bool persistent = persist_env != 0 && !degenerate && !e->comm && !no_persist && budget < 4000 && (long long)src.n_upper * e->n_off <= PERSIST_MAX_ITEMS;
   if (persistent && !sharded && e->persist_skip > 0) { e->persist_skip--; persistent = false; }  // backing off (a sharded align must take the same route on every rank)
-  int granted = 0;
-  struct Slots { int dev, grant; ~Slots() { if (grant > 0) g_slots.release(dev, grant); } } slots{e->device, 0};
+  GridPlan plan;
+  if (forced_plan) plan = *forced_plan;
+  struct Slots { int dev; SlotPool::Grant g; ~Slots() { if (g.n > 0) g_slots.release(dev, g); } } slots{e->device, {}};
   if (persistent) {
     int cap = persistent_capacity<MODE>(e);
     if (e->peer.attached()) cap = std::max(1, cap / std::max(1, e->peer.ranks_on_device));
     const int want = std::min(cost_shape(e, src).blocks, std::max(cap, 1));
-    granted = slots.grant = g_slots.acquire(e->device, std::max(cap, 1), want);
+    // Layouts (kernels_cost.hpp): chip-wide grids reduce per XCD (ng = 8; small ones: default_groups()); concurrent aligns -- and small
+    // grids under FVH_SMALL_GRID_LAYOUT=1 -- are confined to one XCD each (ng = 1, every hand-off XCD-local).
+    const int small_layout = small_grid_layout();
+    const bool local_ok = xcd_local_wanted();
+    const bool confine_ok = local_ok && !sharded;  // (a confined launch only pays with XCD-local hand-offs; ranks of a sharded align must agree on the layout)
+    slots.g = g_slots.acquire(e->device, std::max(cap, 1), want, confine_ok, small_layout == 1);
+    int granted = slots.g.n;
     if (granted <= 0) {
       if (sharded) granted = want;  // ranks must not diverge: take the slots anyway (the watchdog covers the rare collision)
       else persistent = false;
     }
+    plan = GridPlan{};
+    plan.nb = granted;
+    if (slots.g.mask) { plan.mask = slots.g.mask; plan.ng = __builtin_popcount(slots.g.mask); plan.local = 1; }  // one group per XCD
+    else { plan.ng = default_groups(granted); plan.local = (plan.ng == TICKET_GROUPS && local_ok) ? 1 : 0; }  // (one chip-wide group spans XCDs: write-through)
   }
   if (persistent) {
-    int rc = launch_cost<MODE>(e, src, vm, -1, &guess, nullptr, &p, true, e->peer.x, granted);
+    int rc = launch_cost<MODE>(e, src, vm, -1, &guess, nullptr, &p, true, e->peer.x, &plan);
     if (rc) return rc;
     bool have_result = false;
     if (e->result_dev && e->zero_copy_armed) {
@@ -1200,7 +1279,8 @@ int do_align(Engine* e, const CostSource& src, VoxelMapDev& vm, const double* gu
       // multi-GPU: an abort on ANY rank reaches every rank within a watchdog period (its mailbox stays empty), so all ranks
       // arrive here and restart together; the exchange counter jumps past whatever this launch may have used
       if (sharded) e->peer.x = (e->peer.x + 8192) & ~1ull;
-      return do_align<MODE>(e, src, vm, guess16, params, result, rebuild_safe, retried, true, granted);  // the same grid: the same partition of the items, the same sums
+      if (h->aborted == 3u) g_xcd_local_strikes.fetch_add(1);  // the members of a group did not share an XCD: a few of these and the XCD-local flavour is off for good
+      return do_align<MODE>(e, src, vm, guess16, params, result, rebuild_safe, retried, true, &plan);  // the same layout: the same partition of the items, the same sums
     }
     launched = 1;
     e->persist_backoff = 0;  // a clean persistent run: the device is ours again
@@ -1210,7 +1290,7 @@ int do_align(Engine* e, const CostSource& src, VoxelMapDev& vm, const double* gu
     for (int s = 0; s < batch; s++) {
       // the first launch carries the initial guess and the LM parameters and (re)initialises the device state
       const bool first = (launched == 0 && s == 0 && !degenerate);
-      int rc = launch_cost<MODE>(e, src, vm, -1, first ? &guess : nullptr, nullptr, first ? &p : nullptr, false, e->peer.x + (unsigned long long)(launched + s), forced_grid);
+      int rc = launch_cost<MODE>(e, src, vm, -1, first ? &guess : nullptr, nullptr, first ? &p : nullptr, false, e->peer.x + (unsigned long long)(launched + s), forced_plan ? &plan : nullptr);
       if (rc) return rc;
       if (e->comm) {
         rc = allreduce_sums(e);
@@ -1236,7 +1316,7 @@ int do_align(Engine* e, const CostSource& src, VoxelMapDev& vm, const double* gu
     if (retried) return e->fail(FVH_ERR_BAD_STATE, "voxel map overflow persists after safe rebuild");
     int rc = rebuild_safe();
     if (rc) return rc;
-    return do_align<MODE>(e, src, vm, guess16, params, result, rebuild_safe, true, no_persist, forced_grid);
+    return do_align<MODE>(e, src, vm, guess16, params, result, rebuild_safe, true, no_persist, forced_plan);
   }
   e->prev_steps = e->last_steps;
   e->last_steps = 1 + h->num_error_evals;  // launches this align needed: the first linearize + one fused launch per trial
@@ -1966,6 +2046,11 @@ int fvh_vgicp_debug_get_persist_grid(fvh_vgicp* h, int* blocks, int* capacity) {
   CHECK_HANDLE(h);
   if (blocks) *blocks = h->e.last_persist_blocks;
   if (capacity) *capacity = persistent_capacity<MODE_VGICP>(&h->e);
+  return FVH_OK;
+}
+int fvh_debug_xcd_local(int* wanted, int* placement_aborts) {
+  if (wanted) *wanted = xcd_local_wanted() ? 1 : 0;
+  if (placement_aborts) *placement_aborts = g_xcd_local_strikes.load();
   return FVH_OK;
 }
 int fvh_debug_slot_pool(int device, int* reserved, int* active, int* recent) {

@@ -1,21 +1,35 @@
-// The GN/LM hot loop for gfx950: ONE kernel per linearize() / compute_error().
+// The GN/LM hot loop for gfx950: ONE kernel for the whole LsqRegistration::computeTransformation loop (PERSIST = true: one
+// launch per align(), one "trip" per LM transition), or one launch per linearize() / compute_error() (PERSIST = false: the
+// host-driven calls of the C ABI and the fallback route of align()).
 //
 // Replaces SURVEY 2.2 K18-K23 + X2: find_voxel_correspondences (N_off launches + remove_if,
 // find_voxel_correspondences.cu:16-111), compute_derivatives (transform_reduce of 43-float tuples,
-// compute_derivatives.cu:18-184), the NDT variants (ndt_compute_derivatives.cu:33-231), the three
-// tiny H2D copies and the blocking D2H per evaluation, and -- in device-LM mode -- the host side
-// of LsqRegistration::step_lm (lsq_registration_impl.hpp:123-168).
+// compute_derivatives.cu:18-184), the NDT variants (ndt_compute_derivatives.cu:33-231), the three tiny H2D copies and the
+// blocking D2H per evaluation, and the host side of LsqRegistration::step_lm (lsq_registration_impl.hpp:123-168).
 //
-// Work item = (source element i, offset group g). Adjacent lanes share the source element
-// (broadcast loads). Per item: transform, voxel coordinate (fp64 like the CPU reference or fp32 like
-// the CUDA one), probe the 64-B bucket table, Mahalanobis M = (C_B + R C_A R^T)^-1 with R of the
-// LINEARISATION pose (fast_vgicp_impl.hpp:101-115 caches it; compute_derivatives.cu:71-72), residual
-// and the 28 unique values {err, b(6), H_rr(6), H_rt(9), H_tt(6)} accumulated per thread in fp64
-// registers. 3x3/6x6 math stays in VGPRs (no MFMA). Reduction: wave shuffles -> LDS across the 4
-// waves -> one 28-double partial per workgroup written through to L2 (sc1) -> the LAST workgroup
-// (atomic ticket) sums the partials in a fixed order and, in device-LM mode, runs the LM step
-// (6x6 LDL^T, se3_exp, rho test, lambda schedule, convergence) so the next launch finds the new
-// pose in HBM. No host round trip inside the loop.
+// Work item = (source element i, offset group g). Adjacent lanes share the source element (broadcast loads). Per item:
+// transform, voxel coordinate (fp64 like the CPU reference or fp32 like the CUDA one), probe the dense key table, Mahalanobis
+// M = (C_B + R C_A R^T)^-1 with R of the LINEARISATION pose (fast_vgicp_impl.hpp:101-115 caches it; compute_derivatives.cu:71-72),
+// residual; per hit only S += w M, g += w M e, err are accumulated -- b = J^T g and H = J^T S J follow once per item (J depends
+// on the element alone). 3x3 / 6x6 math stays in VGPRs (no MFMA).
+//
+// Reduction and hand-offs. Per item the wave reduces its 64 items' 29 sums with a transposing butterfly (v_permlane32/16_swap)
+// into ONE fp64 accumulator per lane; after the main loop 4 waves x 32 slots meet in 1 KB of LDS -> one row of 32 sums per
+// workgroup. Workgroup b belongs to group b % ng (ng = 1 for small grids, else 8: the group IS the workgroup's XCD).
+//   * PERSIST = false: rows are written through (sc1), the last arriver of a group (atomic ticket) adds the group's rows in a fixed
+//     order into a group row, the last group adds the <= 8 group rows in group order and runs the LM step; the state goes to HBM.
+//   * PERSIST = true: nothing takes a ticket and nothing waits for a store. Everything that crosses workgroups travels as
+//     {value, tag} PAIRS (one aligned 16-byte store per lane; tag = (launch sequence, trip): a pair is its own arrival signal,
+//     nothing is ever cleared). The first workgroup of each group (the COLLECTOR) polls the pairs of its group's rows, adds
+//     them in the ticket route's order and publishes a tagged group row; EVERY collector then polls all group rows, adds them in
+//     group order and runs the LM step redundantly on its own LDS copy of the state (identical inputs, identical arithmetic:
+//     bit-identical on all eight) and broadcasts the 26 values the next trip needs (phase, correspondence buffer, two poses) to
+//     the workgroups of ITS OWN group only. Of the three hand-offs per trip only the group rows cross XCDs: rows and broadcast
+//     stay inside one XCD, where a plain store is visible to an L1-bypassing (sc1) load through the XCD's own L2 in ~0.2 us
+//     instead of a ~1 us memory-side round trip (`xcd_local`; every workgroup checks HW_REG_XCC_ID against the XCD its group
+//     stands for before it relies on that, and a launch can be confined to a subset of the XCDs -- `xcd_mask` -- so that small
+//     grids need no cross-XCD hop at all and several aligns can share the chip XCD by XCD). Both routes add the same numbers in
+//     the same order: bit-identical results.
 #pragma once
 #include <cstddef>
 #include <type_traits>
@@ -45,7 +59,6 @@ enum Phase { PH_LINEARIZE = 0, PH_TRIAL = 1, PH_DONE = 2, PH_FIND_ONLY = 3, PH_E
 struct LmState {
   PoseD x0;        // current estimate == linearisation pose
   PoseD xi;        // trial pose
-  PoseD delta;     // (unused since round 3: the convergence test of a proposed step travels as delta_converged)
   PoseD x_lin;     // pose at which the CURRENT correspondence buffer was computed (reference: linearized_x)
   double H[36], b[6], d[6];
   double y0, lambda, nu;
@@ -111,6 +124,12 @@ struct CostParams {
   int external_find;  // FastGICP on the device: the correspondences of every linearisation were found by nn1_corr_kernel right before this launch (nothing to probe here)
   PeerView peer;
   unsigned long long peer_watchdog_ticks;
+  // grid layout (both routes take the same (nb, ng): the same partition of the items and the same order of the sums)
+  int ng;              // reduction groups: workgroup b belongs to group b % ng (1: single level; 8: one group per XCD)
+  int nb;              // persistent kernel with xcd_mask != 0: logical workgroups (the launch is 8 x ceil(nb / popcount(mask)))
+  unsigned xcd_mask;   // persistent kernel: != 0 -> only workgroups dispatched to these XCDs (blockIdx & 7) stay; the others exit at once
+  int xcd_local;       // persistent kernel: every member of a group sits on the group's XCD (checked per workgroup): rows and broadcast
+                       // travel through that XCD's L2 (plain stores) instead of write-through + memory-side polls
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -591,11 +610,20 @@ constexpr int SINGLE_LEVEL_MAX_BLOCKS = FVH_SINGLE_LEVEL_MAX;  // grids up to th
 // granules are the cheapest hand-off, ~1 us; a returning device-scope atomic plus a dependent load is two round trips).
 typedef double pair_t __attribute__((ext_vector_type(2)));
 constexpr size_t TAGGED_ROWS_OFFSET = (size_t)PART_STRIDE * (MAX_PARTIAL_ROWS + 2 * TICKET_GROUPS);  // doubles into CostParams::partials
-constexpr size_t TAGGED_ROWS_DOUBLES = 2 * TICKET_GROUPS * PART_STRIDE * 2;                        // group rows: [parity][group][32] pairs
+constexpr int GLOBAL_ROW = TICKET_GROUPS;                                                          // multi-GPU: the all-reduced sums, published by workgroup 0 to the other collectors
+constexpr size_t TAGGED_ROWS_DOUBLES = 2 * (TICKET_GROUPS + 1) * PART_STRIDE * 2;                  // group rows: [parity][group | global][32] pairs
 constexpr size_t WG_ROWS_OFFSET = TAGGED_ROWS_OFFSET + TAGGED_ROWS_DOUBLES;                         // workgroup rows of the persistent kernel: [MAX_PARTIAL_ROWS][32] pairs
 constexpr size_t WG_ROWS_DOUBLES = (size_t)MAX_PARTIAL_ROWS * PART_STRIDE * 2;
 constexpr size_t PARTIALS_DOUBLES = WG_ROWS_OFFSET + WG_ROWS_DOUBLES;
 __device__ __forceinline__ void store_pair_agent(pair_t* p, pair_t v) { asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory"); }
+// XCD-local flavour: a plain store stays in (and is served from) the L2 of the writer's XCD; readers ON THAT XCD see it with the same
+// L1-bypassing sc1 loads, as an L2 hit (MI355X_MICROARCH.md: same-XCD hand-off with plain producer stores). Not visible to other XCDs.
+__device__ __forceinline__ void store_pair_xcd(pair_t* p, pair_t v) { asm volatile("global_store_dwordx4 %0, %1, off" ::"v"(p), "v"(v) : "memory"); }
+__device__ __forceinline__ unsigned xcc_id() {  // the XCD this wave runs on (HW_REG_XCC_ID, bits 3:0)
+  unsigned v;
+  asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID, 0, 4)" : "=s"(v));
+  return v;
+}
 __device__ __forceinline__ pair_t load_pair_agent(const pair_t* p) {
   pair_t v;
   asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(v) : "v"(p) : "memory");
@@ -619,13 +647,12 @@ __device__ __forceinline__ void load_pairs8_agent(pair_t (&v)[8], const pair_t* 
       : "memory");
 }
 
-// PERSIST = true: ONE launch runs the whole LM loop. Every trip of the outer loop is what one launch of the
-// non-persistent kernel does; instead of exiting, the workgroups wait at a barrier (monotonic arrival counters polled
-// with agent-scope loads), then every workgroup finishes the reduction and runs the LM step itself on its own LDS
-// copy of the state, and goes again until the state says PH_DONE. This removes the per-launch
-// dispatch + ramp (~4.5 us of an 18 us launch at 17k points, FVH_COST_TIMING) and the speculative no-op launches.
-// All workgroups must be co-resident (the host clamps the grid to the occupancy limit); a watchdog turns a stuck
-// barrier into an abort flag + fallback to the multi-launch path instead of a hang.
+// PERSIST = true: ONE launch runs the whole LM loop. Every trip of the outer loop is what one launch of the non-persistent
+// kernel does; instead of exiting, the workgroups hand their sums to their group's collector and poll its broadcast (the
+// protocol is described where it is implemented, at the end of the kernel). This removes the per-launch dispatch + ramp
+// (~4.5 us of an 18 us launch at 17k points, FVH_COST_TIMING) and the speculative no-op launches. All workgroups must be
+// co-resident (the host clamps the grid to the occupancy limit); a watchdog on every poll turns a stuck hand-off into an abort
+// flag + fallback to the multi-launch path instead of a hang.
 __device__ __forceinline__ double uniform_f64(double x) {  // wave-uniform value -> SGPR pair
   const unsigned long long u = (unsigned long long)__double_as_longlong(x);
   const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)u), hi = __builtin_amdgcn_readfirstlane((unsigned)(u >> 32));
@@ -660,12 +687,12 @@ __device__ __forceinline__ void swap_halves(double& a, double& b) {
 __device__ unsigned long long g_cost_timing[16];
 __device__ unsigned long long g_ptime[16][512][12];  // persistent kernel, per trip and workgroup: {start, main end, arrival, open (opener only), seen, LM done}; plain stores, no shared address
 #define FVH_STAMP(i) do { if (threadIdx.x == 0) stamp[i] = wall_clock64(); } while (0)
-#define FVH_PT_MIN(trip, k) do { if (threadIdx.x == 0 && (trip) < 16 && blockIdx.x < 512) g_ptime[trip][blockIdx.x][k] = wall_clock64(); } while (0)
+#define FVH_PT_MIN(trip, k) do { if (threadIdx.x == 0 && (trip) < 16 && lb < 512) g_ptime[trip][lb][k] = wall_clock64(); } while (0)
 #define FVH_PT_MAX(trip, k) FVH_PT_MIN(trip, k)
 // main-loop timeline of wave 0 (tools/main_timing.py): waits for everything in flight, then stamps -- it serialises what the
 // scheduler would overlap, so the segments are upper bounds
 __device__ unsigned long long g_mtime[16][512][12];
-#define FVH_MT(trip, k) do { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); if (threadIdx.x == 0 && (trip) < 16 && blockIdx.x < 512) g_mtime[trip][blockIdx.x][k] = wall_clock64(); } while (0)
+#define FVH_MT(trip, k) do { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); if (threadIdx.x == 0 && (trip) < 16 && lb < 512) g_mtime[trip][lb][k] = wall_clock64(); } while (0)
 #else
 #define FVH_STAMP(i) do { } while (0)
 #define FVH_PT_MIN(trip, k) do { } while (0)
@@ -702,6 +729,21 @@ __global__ FVH_COST_BOUNDS void cost_kernel(CostParams P) {
   static_assert(ST_WORDS <= 256, "one state word per thread after the barrier");
   LmState* st = P.st;
   unsigned long long* st_words = reinterpret_cast<unsigned long long*>(st);
+  // Logical workgroup id / count. A persistent launch confined to some XCDs (xcd_mask) is dispatched 8 x too wide: the workgroups
+  // that find themselves on another XCD (HW_REG_XCC_ID) leave at once, the rest number themselves densely -- the dispatcher hands
+  // consecutive blocks to consecutive XCDs (block b runs on XCD (b + c) % 8 with one c per launch: tools/probes/probe_xcc.hip), so every
+  // row of 8 blocks holds each XCD once. That is an observation, not a contract: every workgroup publishes the c it sees with its sums
+  // and the collectors end the launch if they ever differ (`xcd_local` below).
+  unsigned lb = blockIdx.x, nb = gridDim.x;
+  if constexpr (PERSIST) {
+    if (P.xcd_mask) {
+      const unsigned phys = __builtin_amdgcn_readfirstlane(xcc_id()) & 7u;
+      if (!((P.xcd_mask >> phys) & 1u)) return;
+      lb = (blockIdx.x >> 3) * (unsigned)__popc(P.xcd_mask) + (unsigned)__popc(P.xcd_mask & ((1u << phys) - 1u));
+      nb = (unsigned)P.nb;
+      if (lb >= nb) return;
+    }
+  }
   unsigned gen = 0;  // PERSIST: barrier generations this workgroup has passed
   int phase, corr_sel;
   PoseD lin_d, ev_d;
@@ -758,7 +800,7 @@ __global__ FVH_COST_BOUNDS void cost_kernel(CostParams P) {
   // (consecutive threads take consecutive items on purpose: spreading a workgroup's items over the cloud made the launch
   // 24 % slower -- the loop is sensitive to how many distinct cache lines a wave touches)
   // The loop bound is wave-uniform (the butterfly needs all 64 lanes); lanes past the end contribute zeros.
-  for (int wbase = w_lo + blockIdx.x * 256 + (threadIdx.x & 192); wbase < n_items; wbase += gridDim.x * 256) {
+  for (int wbase = w_lo + (int)lb * 256 + (threadIdx.x & 192); wbase < n_items; wbase += (int)nb * 256) {
     const int w = wbase + lane;
     ItemAcc<Real> it = {{0, 0, 0, 0, 0, 0}, {0, 0, 0}, 0};
     Real acc_y = 0;  // fused: trial error with the old ids
@@ -1047,17 +1089,17 @@ __global__ FVH_COST_BOUNDS void cost_kernel(CostParams P) {
   // into one group row; the group rows are summed in group order. Grids of <= 64 workgroups are ONE group: a single level.
   // The per-transition kernel finds "the last arriver" with atomic tickets; the persistent kernel has no tickets at all
   // (designated collectors poll tagged rows, below). Both take the SAME summation order: bit-identical sums on both routes.
-  const unsigned NG = gridDim.x <= (unsigned)SINGLE_LEVEL_MAX_BLOCKS ? 1u : (unsigned)TICKET_GROUPS;
-  const unsigned grp = blockIdx.x % NG;
-  const unsigned ngroups = NG;  // (gridDim.x > 128 whenever NG == 8)
-  const unsigned gsize = (gridDim.x - grp + NG - 1) / NG;
+  const unsigned NG = (unsigned)P.ng;  // (host: 1 for grids of <= SINGLE_LEVEL_MAX_BLOCKS workgroups and for single-XCD launches, else 8)
+  const unsigned grp = lb % NG;
+  const unsigned ngroups = NG;
+  const unsigned gsize = (nb - grp + NG - 1) / NG;
   if constexpr (!PERSIST) {
     if (tid < PART_STRIDE) {
       const int vv = tid;
       const double x = (red[0][vv] + red[1][vv]) + (red[2][vv] + red[3][vv]);
       // write-through (sc1) so another workgroup can read it from L2 without a release fence;
       // row slot v: sums 0..27, fused trial error at 28 (== NSUM), 29..31 zero
-      __hip_atomic_store(&P.partials[(size_t)blockIdx.x * PART_STRIDE + vv], x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(&P.partials[(size_t)lb * PART_STRIDE + vv], x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -1173,29 +1215,33 @@ __global__ FVH_COST_BOUNDS void cost_kernel(CostParams P) {
     if (tid == 0) {
       stamp[7] = wall_clock64();
       for (int i = 1; i <= 7; i++) g_cost_timing[i] = stamp[i];
-      g_cost_timing[8] = gridDim.x;
+      g_cost_timing[8] = nb;
       g_cost_timing[9] = stamp[0];
     }
 #endif
     return;
   } else {
     // ---- persistent trip: nobody leaves, and nobody takes a ticket --------------------------------
-    // Round 2 found a group's last arriver with a returning atomic (one memory-side round trip), had it load the group's rows
-    // (a second one, after waiting for its own row store), publish a tagged group row, and the opener poll that. Now every
-    // workgroup publishes its 32 sums as {sum, tag} pairs -- ONE 16-byte write-through store per lane, no wait -- and goes
-    // straight to polling the broadcast; the first workgroup of each group (the COLLECTOR: blockIdx < NG) polls the pairs of its
-    // group's rows directly, eight in flight per thread, and adds them in the fixed order of reduce_group_rows as soon as the
-    // last one has landed; workgroup 0 (the OPENER; the LM state lives in its LDS for the whole launch) polls the NG group
-    // rows, runs the LM step and BROADCASTS what the next trip needs -- phase, correspondence buffer, the two poses: 26 values
-    // -- as PERSIST_REPLICAS copies of 26 tagged pairs. Workgroup b polls copy b % PERSIST_REPLICAS with one 26-lane 16-byte
-    // load per poll: barrier and payload in a single memory round trip, and no address is read by more than ~15 workgroups.
-    // The chain last-workgroup-done -> LM step is two hand-offs (one for grids of <= 64 workgroups) instead of four round trips.
+    // Every workgroup publishes its 32 sums as {sum, tag} pairs -- ONE 16-byte store per lane, no wait -- and goes straight to
+    // polling the broadcast of its group. The first workgroup of each group (the COLLECTOR, lb < NG) polls the pairs of its
+    // group's rows, eight in flight per thread, adds them in the fixed order of reduce_group_rows as soon as the last one has
+    // landed, and publishes a tagged group row (write-through: this is the one hand-off that crosses XCDs). Then EVERY collector
+    // polls all NG group rows on one wave, adds them in group order -- reduce_final's order --, runs the LM step in registers
+    // on ITS OWN LDS copy of the state (the eight copies see identical sums and stay bit-identical; round 2 measured ~500
+    // redundant steps, which thrash the instruction caches: eight do not) and broadcasts what the next trip needs -- phase,
+    // correspondence buffer, two poses: 26 values -- as `reps` copies of 26 tagged pairs to the workgroups of its own group.
+    // Round 3 had ONE workgroup run the step and broadcast to the whole chip: rows -> collector, group rows -> opener, broadcast ->
+    // everybody were three memory-side round trips of ~1 us each. Now rows and broadcast stay inside the group = inside one XCD
+    // (xcd_local: plain stores, served to the polling sc1 loads by that XCD's L2), and only the group rows pay the ~1 us.
+    // Multi-GPU: workgroup 0 alone meets the peers (kernels_peer.hpp) and hands the all-reduced sums to the other collectors as
+    // one more tagged row. Workgroup 0 also owns what leaves the launch: the LM trace, the final state, the result word.
     // Dead ends measured in round 1/2 (474 workgroups, 17k points): one barrier word on the line of the arrival counters
     // (+10 us per trip); one barrier word + every workgroup reloading the state (21.6 us per trip: ~500 readers of the
-    // same lines queue at their memory channel); every workgroup running the LM step redundantly on its own copy
-    // (22.7 us per trip: the step takes 5 us instead of 1.5 when ~500 waves fetch its code at once).
-    // Rows are single-buffered: a workgroup writes its trip t + 1 row only after it has seen the broadcast of trip t, which the
-    // opener sends after every row of trip t has been consumed. Tags embed the launch sequence: rows of older launches never match.
+    // same lines queue at their memory channel); EVERY workgroup running the LM step (22.7 us per trip).
+    // Rows are single-buffered: a workgroup writes its trip t + 1 row only after it has seen its group's broadcast of trip t, which
+    // the collector sends after every row of trip t has been consumed; group rows alternate between two parities (a collector can
+    // be at most one trip ahead of the slowest one: it needs that one's next group row). Tags embed the launch sequence: rows of
+    // older launches never match.
     const unsigned trip = gen;
     unsigned long long ltag = P.launch_tag;
     asm volatile("" : "+s"(ltag));  // opaque per trip: otherwise the two conversions below are hoisted out of the trip loop and held in 4 VGPRs across the main loop
@@ -1203,25 +1249,39 @@ __global__ FVH_COST_BOUNDS void cost_kernel(CostParams P) {
     auto want_tag_of = [&]() { unsigned long long t = ltag * 4096ull + trip + 1; asm volatile("" : "+s"(t)); return (double)t; };
     auto abort_tag_of = [&]() { unsigned long long t = ltag * 4096ull; asm volatile("" : "+s"(t)); return -(double)t; };  // launch-specific: a poisoned row of an older launch means nothing
     __shared__ double bc[BCAST_PAIRS];  // payload of the broadcast row as seen by this workgroup
+    __shared__ unsigned s_abort;
     pair_t* wrows = reinterpret_cast<pair_t*>(P.partials + WG_ROWS_OFFSET);
-    pair_t* trows = reinterpret_cast<pair_t*>(P.partials + TAGGED_ROWS_OFFSET) + (size_t)(trip & 1u) * TICKET_GROUPS * PART_STRIDE;
+    pair_t* trows = reinterpret_cast<pair_t*>(P.partials + TAGGED_ROWS_OFFSET) + (size_t)(trip & 1u) * (TICKET_GROUPS + 1) * PART_STRIDE;
     pair_t* bcast = reinterpret_cast<pair_t*>(P.bcast);
-    auto poison = [&](int first, int stride) {  // never hang the GPU: every tag of this launch's broadcast becomes the abort tag
+    const bool local = P.xcd_local != 0;  // (kernel argument: uniform)
+    // copies of the broadcast row a group owns: all of them for a single group, PERSIST_REPLICAS / 8 each otherwise; workgroup lb
+    // polls copy (lb / NG) % reps of its group -- no address is read by more than ~15 workgroups
+    const unsigned reps = NG == 1 ? (unsigned)PERSIST_REPLICAS : (unsigned)(PERSIST_REPLICAS / TICKET_GROUPS);
+    static_assert(PERSIST_REPLICAS % (2 * TICKET_GROUPS) == 0, "an even number of broadcast copies per group");
+    pair_t* my_bcast = bcast + (size_t)(NG == 1 ? 0u : grp * reps) * BCAST_PAIRS;
+    auto poison = [&](int first, int stride) {  // never hang the GPU: every tag of this launch's broadcast becomes the abort tag (write-through: best effort across XCDs, every poll also has its own watchdog)
       pair_t pv;
       pv.x = 0.0; pv.y = abort_tag_of();
       for (int idx = first; idx < PERSIST_REPLICAS * BCAST_PAIRS; idx += stride) store_pair_agent(bcast + idx, pv);
     };
+    // The XCD-local flavour is only sound if every member of a group really runs on ONE XCD (HIP promises no placement). Members of a
+    // group share blockIdx % 8 (or, in a confined launch, the XCD itself), so it is enough that the dispatcher's rotation
+    // c = (XCC_ID - blockIdx) mod 8 is the same for every workgroup of the launch: each workgroup publishes the c it sees in the unused
+    // slot 31 of its row, the collectors compare (rows against their own, then the group rows among each other) and end the launch
+    // with code 3 if anything differs -- the host redoes the align with one launch per transition and, after a few of those, stops
+    // asking for the local flavour.
+    const double my_rot = local ? (double)((__builtin_amdgcn_readfirstlane(xcc_id()) - blockIdx.x) & 7u) : 0.0;
     if (tid < PART_STRIDE) {
       pair_t pv;
-      pv.x = (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);  // row slot v: sums 0..27, fused trial error at 28 (== NSUM), 29..31 zero
+      pv.x = (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);  // row slot v: sums 0..27, fused trial error at 28 (== NSUM), 29..30 zero
+      if (tid == PART_STRIDE - 1) pv.x = my_rot;                         // slot 31: the dispatcher's rotation as this workgroup sees it
       pv.y = want_tag_of();
-      store_pair_agent(wrows + (size_t)blockIdx.x * PART_STRIDE + tid, pv);
+      if (local) store_pair_xcd(wrows + (size_t)lb * PART_STRIDE + tid, pv); else store_pair_agent(wrows + (size_t)lb * PART_STRIDE + tid, pv);
     }
     FVH_PT_MAX(trip, 2);
-    const bool collector = blockIdx.x < NG;  // == the first workgroup of group `grp`
-    const bool opener = (blockIdx.x == 0);
+    const bool collector = lb < NG;  // == the first workgroup of group `grp`
     if (collector) {
-      if (tid == 0) s_last = 1;
+      if (tid == 0) { s_last = 1; s_abort = 0u; }
       __syncthreads();
       {
         const int v = tid & 31, chunk = tid >> 5;
@@ -1250,6 +1310,10 @@ __global__ FVH_COST_BOUNDS void cost_kernel(CostParams P) {
             if (wall_clock64() - t0 > P.watchdog_ticks) { s_last = 0; break; }  // a row never came: not every workgroup is resident / something is stuck
             __builtin_amdgcn_s_sleep(1);
           }
+          if (v == PART_STRIDE - 1) {  // slot 31 is not a sum: count the rows whose rotation is not ours
+#pragma unroll
+            for (int u = 0; u < 8; u++) t[u] = (((j0 + 8 * u) < gsize) && t[u] != my_rot) ? 1.0 : 0.0;
+          }
 #pragma unroll
           for (int u = 0; u < 8; u++) s += t[u];
         }
@@ -1265,43 +1329,36 @@ __global__ FVH_COST_BOUNDS void cost_kernel(CostParams P) {
         double s = 0.0;
 #pragma unroll
         for (int c = 0; c < 8; c++) s += fin[c][tid];
+        if (tid == PART_STRIDE - 1) s = (s == 0.0) ? my_rot : -1.0;  // this group's verdict: its rotation, or "members disagree"
         if (NG > 1) {
           pair_t pv;
           pv.x = s; pv.y = want_tag_of();
-          store_pair_agent(trows + (size_t)grp * PART_STRIDE + tid, pv);
-        } else {
-          red[1][tid] = s;  // single level: this IS the only group row (the opener is the collector)
+          store_pair_agent(trows + (size_t)grp * PART_STRIDE + tid, pv);  // (crosses XCDs: always write-through)
         }
+        red[1][tid] = s;  // single level: this IS the only group row
       }
       FVH_PT_MAX(trip, 5);
-      __syncthreads();  // fin[] is reused by the opener below
-    }
-    // The opener is always workgroup 0 (not whoever arrives last): the LM step is ~10 KB of code that runs once per
-    // trip -- on a random CU it is fetched cold every time; on a fixed CU it stays in the instruction cache, and the LM
-    // state stays in this workgroup's LDS for the whole launch instead of travelling through memory each trip.
-    if (opener) {
       // From here to the broadcast ONE wave does everything (the other three wait at the barrier below): lanes 0..31 poll the
-      // pairs of the <= 8 group rows (eight in flight per lane) and add them in group order -- reduce_final's order --, the
-      // sums go to LDS, the LM step runs in registers, lanes 0..25 read the payload back and store it to the replicas. No
-      // __syncthreads, no LDS hop between the stages (round 2: five barriers and four LDS hand-offs between four groups of threads).
-      __shared__ unsigned s_abort;
-      if (tid == 0) s_abort = 0u;
+      // pairs of the <= 8 group rows (eight in flight per lane) and add them in group order, the sums go to LDS, the LM step runs
+      // in registers, lanes 0..25 read the payload back and store it to the group's copies. No __syncthreads, no LDS hop between
+      // the stages. (red[1] above was written by this same wave: LDS operations of a wave complete in order.)
       const bool multi_gpu = MODE == MODE_VGICP && P.peer.n > 1;  // (kernel argument: uniform)
       if (tid < 64) {
         const int lane = tid;
         double val = 0.0;
         bool ok = true;
         if (NG == 1) {
-          if (lane < PART_STRIDE) val = red[1][lane];  // single level: the group row is already in LDS (collector == opener; barrier above)
-        } else {
+          if (lane < PART_STRIDE) val = red[1][lane];
+        } else if (!multi_gpu || lb == 0) {
           const pair_t* src[8];
           double t[8];
           unsigned pend = 0;
 #pragma unroll
           for (int g = 0; g < 8; g++) {
-            src[g] = trows + (size_t)g * PART_STRIDE + (lane & 31);
+            const bool in = (unsigned)g < NG;
+            src[g] = trows + (size_t)(in ? g : 0) * PART_STRIDE + (lane & 31);
             t[g] = 0.0;
-            pend |= (1u << g);
+            pend |= in ? (1u << g) : 0u;
           }
           if (lane >= PART_STRIDE) pend = 0;
           const double want = want_tag_of();
@@ -1314,26 +1371,37 @@ __global__ FVH_COST_BOUNDS void cost_kernel(CostParams P) {
               if (((pend >> g) & 1u) && pv[g].y == want) { t[g] = pv[g].x; pend &= ~(1u << g); }
             if (__builtin_amdgcn_readfirstlane((int)(wall_clock64() - t0 > P.watchdog_ticks))) { ok = false; break; }
           }
+          if (lane == PART_STRIDE - 1) {  // slot 31: every group must have seen our rotation
+#pragma unroll
+            for (int g = 0; g < 8; g++) t[g] = ((unsigned)g < NG && t[g] != my_rot) ? 1.0 : 0.0;
+          }
 #pragma unroll
           for (int g = 0; g < 8; g++) val += t[g];  // group order
+        } else {  // multi-GPU, collectors 1..NG-1: the all-reduced sums come from workgroup 0
+          const pair_t* src = trows + (size_t)GLOBAL_ROW * PART_STRIDE + (lane & 31);
+          const double want = want_tag_of();
+          const unsigned long long t0 = wall_clock64();
+          bool pend = lane < PART_STRIDE;
+          while (__builtin_amdgcn_ballot_w64(pend) != 0ull) {
+            const pair_t pv = load_pair_agent(src);
+            if (pend && pv.y == want) { val = pv.x; pend = false; }
+            if (__builtin_amdgcn_readfirstlane((int)(wall_clock64() - t0 > P.watchdog_ticks))) { ok = false; break; }
+          }
         }
         FVH_PT_MAX(trip, 6);
+        // slot 31 now holds: single level -- our rotation or -1; two levels -- the number of groups that disagree with us (the
+        // multi-GPU collectors 1.. read workgroup 0's verdict instead, which is 0 or it would not have been published)
+        if (lane == PART_STRIDE - 1) {
+          const bool placement_ok = !local || (NG == 1 ? val == my_rot : val == 0.0);
+          if (ok && !placement_ok) s_abort = 3u;  // 3: the workgroups of a group do not share an XCD
+          val = 0.0;
+        }
         if (lane < PART_STRIDE) red[0][lane] = val;
         if (!ok && lane == 0) s_abort = 1u;  // 1: not every workgroup is resident / something is stuck
-        if (ok && !multi_gpu) {
-          FVH_PT_MAX(trip, 7);
-          if (trip == 0 && lane == 0) {
-            init_state();
-            s_st.vm_num_voxels = P.vm_counters[0];
-            s_st.vm_num_voxels2 = P.vm_counters2 ? P.vm_counters2[0] : 0;
-            s_st.vm_dropped = P.vm_counters[1] + (P.vm_counters2 ? P.vm_counters2[1] : 0);
-          }
-          if (lane < PART_STRIDE) s_st.sums[lane] = val;
-        }
       }
-      if (multi_gpu) {
-        // multi-GPU: the openers of all ranks meet in each other's mailboxes (kernels_peer.hpp, all 256 threads); every rank then runs the same LM step
-        // (VGICP handles only: the NDT handles shard through RCCL between launches, and their D2D instantiation has no register to spare)
+      if (multi_gpu && lb == 0) {
+        // multi-GPU: workgroup 0 of every rank meets the others in each other's mailboxes (kernels_peer.hpp, all 256 threads); every rank
+        // then runs the same LM step (VGICP handles only: the NDT handles shard through RCCL between launches)
         __syncthreads();
         if constexpr (MODE == MODE_VGICP) {
           if (!s_abort && !peer_exchange_sums(P.peer, red[0], P.peer.xbase + trip, P.peer_watchdog_ticks, tid, 256, &s_last)) {
@@ -1341,44 +1409,40 @@ __global__ FVH_COST_BOUNDS void cost_kernel(CostParams P) {
           }
         }
         __syncthreads();
-        if (!s_abort && tid < 64) {
-          if (trip == 0 && tid == 0) {
+        if (!s_abort && NG > 1 && tid < PART_STRIDE) {
+          pair_t pv;
+          pv.x = red[0][tid]; pv.y = want_tag_of();
+          store_pair_agent(trows + (size_t)GLOBAL_ROW * PART_STRIDE + tid, pv);
+        }
+      }
+      if (tid < 64) {
+        const int lane = tid;
+        if (__builtin_amdgcn_ballot_w64(s_abort != 0u) == 0ull) {  // (written by this wave, or behind the barriers of the peer exchange)
+          FVH_PT_MAX(trip, 7);
+          if (trip == 0 && lane == 0) {
             init_state();
             s_st.vm_num_voxels = P.vm_counters[0];
             s_st.vm_num_voxels2 = P.vm_counters2 ? P.vm_counters2[0] : 0;
             s_st.vm_dropped = P.vm_counters[1] + (P.vm_counters2 ? P.vm_counters2[1] : 0);
           }
-          if (tid < PART_STRIDE) s_st.sums[tid] = red[0][tid];
-        }
-      }
-      if (tid < 64) {
-        bool live = true;
-        if (multi_gpu) live = s_abort == 0u;
-        else live = __builtin_amdgcn_ballot_w64(s_abort != 0u) == 0ull;  // (same wave wrote it: LDS operations complete in order)
-        if (live) {
-          const int lane = tid;
+          if (lane < PART_STRIDE) s_st.sums[lane] = red[0][lane];
           FVH_PT_MAX(trip, 8);
           FVH_MARK(20);
-#ifdef FVH_LM_TWICE  // experiment: a dry run on a copy of the state first -- the timed run then finds its code in the instruction cache
-          {
-            __shared__ LmState s_dry;
-            for (int i = lane; i < ST_WORDS; i += 64) reinterpret_cast<unsigned long long*>(&s_dry)[i] = reinterpret_cast<const unsigned long long*>(&s_st)[i];
-            dev_lm_step_wave(&s_dry, red[0], lane, nullptr);
-          }
-#endif
 #ifdef FVH_COST_TIMING
           const unsigned long long lm_c0 = __builtin_readcyclecounter();
 #endif
-          dev_lm_step_wave(&s_st, red[0], lane, P.lm_trace);
+          // The step is ~10 KB of code that runs once per trip -- always on the same few CUs (the collectors), so it stays in their
+          // instruction caches, and the state stays in the collector's LDS for the whole launch instead of travelling through memory
+          dev_lm_step_wave(&s_st, red[0], lane, lb == 0 ? P.lm_trace : nullptr);
 #ifdef FVH_COST_TIMING
-          if (threadIdx.x == 0 && trip < 16) g_ptime[trip][0][11] = __builtin_readcyclecounter() - lm_c0;  // shader cycles of the LM step (next to its wall-clock stamps 8 -> 9)
+          if (threadIdx.x == 0 && trip < 16 && lb == 0) g_ptime[trip][0][11] = __builtin_readcyclecounter() - lm_c0;  // shader cycles of the LM step (next to its wall-clock stamps 8 -> 9)
 #endif
           FVH_MARK(21);
           FVH_PT_MAX(trip, 9);
           // payload: phase, correspondence buffer, x_lin, evaluation pose of the next trip -- one value per lane, read back from the state
           const int ph = __builtin_amdgcn_readfirstlane(s_st.phase);
           double v = 0.0;
-          const int d = lane & 31;  // both halves of the wave hold the payload: each store instruction fills TWO replicas
+          const int d = lane & 31;  // both halves of the wave hold the payload: each store instruction fills TWO copies
           if (d < BCAST_VALUES) {
             const double* xl = reinterpret_cast<const double*>(&s_st.x_lin);
             const double* pe = reinterpret_cast<const double*>(ph == PH_LINEARIZE ? &s_st.x0 : &s_st.xi);
@@ -1389,10 +1453,13 @@ __global__ FVH_COST_BOUNDS void cost_kernel(CostParams P) {
             if (lane < 32) bc[d] = v;  // (this workgroup's own copy for the next trip)
             pair_t pv;
             pv.x = v; pv.y = want_tag_of();
-            pair_t* dst = bcast + lane;  // lanes 32..63: the next replica (BCAST_PAIRS == 32)
-            static_assert(BCAST_PAIRS == 32 && PERSIST_REPLICAS % 2 == 0, "two replicas per store instruction");
-#pragma unroll 8
-            for (int r = 0; r < PERSIST_REPLICAS; r += 2) store_pair_agent(dst + (size_t)r * BCAST_PAIRS, pv);
+            pair_t* dst = my_bcast + lane;  // lanes 32..63: the next copy (BCAST_PAIRS == 32)
+            static_assert(BCAST_PAIRS == 32, "two copies per store instruction");
+            if (local) {
+              for (unsigned r = 0; r < reps; r += 2) store_pair_xcd(dst + (size_t)r * BCAST_PAIRS, pv);
+            } else {
+              for (unsigned r = 0; r < reps; r += 2) store_pair_agent(dst + (size_t)r * BCAST_PAIRS, pv);
+            }
           }
           FVH_PT_MAX(trip, 3);
         }
@@ -1403,7 +1470,7 @@ __global__ FVH_COST_BOUNDS void cost_kernel(CostParams P) {
         if (tid == 0) __hip_atomic_store(&st->aborted, s_abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         return;
       }
-      if (s_st.phase == PH_DONE) {  // the state leaves the LDS once, at the end (the kernel boundary makes it visible)
+      if (lb == 0 && s_st.phase == PH_DONE) {  // the state leaves the LDS once, at the end (the kernel boundary makes it visible)
         for (int i = tid; i < ST_WORDS; i += 256) st_words[i] = reinterpret_cast<const unsigned long long*>(&s_st)[i];
         if (P.result_host) {
           // ... and goes straight to the host through mapped pinned memory: the caller spins on the sequence word instead of
@@ -1415,13 +1482,9 @@ __global__ FVH_COST_BOUNDS void cost_kernel(CostParams P) {
           if (tid == 0) __hip_atomic_store(&P.result_host[ST_WORDS + 1], P.launch_tag, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
         }
       }
-    }
-    if (!opener) {
-      if (tid < 64) {  // wave 0 polls this workgroup's copy
-#ifdef FVH_POLL_BACKOFF  // experiment: the answer cannot come before two hand-offs and the LM step: stay off the fabric meanwhile
-        if (!collector) __builtin_amdgcn_s_sleep(FVH_POLL_BACKOFF);
-#endif
-        const pair_t* rep = bcast + (size_t)(blockIdx.x % PERSIST_REPLICAS) * BCAST_PAIRS;
+    } else {
+      if (tid < 64) {  // wave 0 polls this workgroup's copy of its group's broadcast
+        const pair_t* rep = my_bcast + (size_t)((lb / NG) % reps) * BCAST_PAIRS;
         const int lane = tid;
         const bool is_val = lane < BCAST_VALUES;
         const unsigned long long t0 = wall_clock64();

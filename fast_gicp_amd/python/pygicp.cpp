@@ -206,6 +206,11 @@ PYBIND11_MODULE(pygicp, m) {
       .def("set_initial_lambda_factor", &Lsq::setInitialLambdaFactor)
       .def("set_debug_print", &Lsq::setDebugPrint)
       .def("set_use_device_lm", &Lsq::setUseDeviceLM)
+      .def("set_lsq_type", [](Lsq& reg, const std::string& t) {  // lsq_optimizer_type_ (lsq_registration.hpp:13,78): "LM" (default) or "GN"
+        if (t == "LM" || t == "LevenbergMarquardt") reg.setLSQType(fast_gicp::LSQ_OPTIMIZER_TYPE::LevenbergMarquardt);
+        else if (t == "GN" || t == "GaussNewton") reg.setLSQType(fast_gicp::LSQ_OPTIMIZER_TYPE::GaussNewton);
+        else throw std::invalid_argument("unknown optimizer type " + t + " (LM, GN)");
+      })
       .def("evaluate_cost", [](Lsq& reg, const Mat4& pose) {
         Matrix6d H; Vector6d b;
         const double e = reg.evaluateCost(numpy2mat4(pose), &H, &b);
@@ -248,14 +253,18 @@ PYBIND11_MODULE(pygicp, m) {
       .def("set_source_covariances", [](GICP& g, const py::array_t<double, py::array::c_style | py::array::forcecast>& c) { g.setSourceCovariances(numpy_to_covs(c)); })
       .def("set_target_covariances", [](GICP& g, const py::array_t<double, py::array::c_style | py::array::forcecast>& c) { g.setTargetCovariances(numpy_to_covs(c)); });
 
-  // The reference's CPU class (main.cpp:192-196; there it derives from FastGICP: set_num_threads, set_correspondence_randomness,
-  // set_max_correspondence_distance), served by the GPU engine in its fp64 arithmetic; k IS honoured here (registration.hpp, FastVGICP).
-  py::class_<VGICP, VGICPCuda, std::shared_ptr<VGICP>>(m, "FastVGICP")
+  // The reference's CPU class (main.cpp:192-196; as there it derives from FastGICP: set_num_threads, set_correspondence_randomness,
+  // set_max_correspondence_distance, the covariance accessors), served by the GPU engine in its fp64 arithmetic; k IS honoured.
+  py::class_<VGICP, GICP, std::shared_ptr<VGICP>>(m, "FastVGICP")
       .def(py::init([](int device) { return std::make_shared<VGICP>(device); }), py::arg("device") = 0)
-      .def("set_num_threads", &VGICP::setNumThreads)
-      .def("set_correspondence_randomness", &VGICP::setCorrespondenceRandomness)
-      .def("set_max_correspondence_distance", &VGICP::setMaxCorrespondenceDistance)
+      .def("set_max_correspondence_distance", &VGICP::setMaxCorrespondenceDistance)  // (FastVGICP never reads it: voxel correspondences)
       .def("set_resolution", &VGICP::setResolution)
+      .def("set_voxel_accumulation_mode", [](VGICP& v, const std::string& mode) {  // FastVGICP::setVoxelAccumulationMode (fast_vgicp_impl.hpp:41-43)
+        if (mode == "ADDITIVE") v.setVoxelAccumulationMode(fast_gicp::VoxelAccumulationMode::ADDITIVE);
+        else if (mode == "ADDITIVE_WEIGHTED") v.setVoxelAccumulationMode(fast_gicp::VoxelAccumulationMode::ADDITIVE_WEIGHTED);
+        else if (mode == "MULTIPLICATIVE") v.setVoxelAccumulationMode(fast_gicp::VoxelAccumulationMode::MULTIPLICATIVE);
+        else throw std::invalid_argument("unknown voxel accumulation mode: " + mode);
+      })
       .def("set_neighbor_search_method", [](VGICP& v, const std::string& method) { v.setNeighborSearchMethod(search_method(method)); }, py::arg("method") = "DIRECT1");
 
   py::class_<NDT, Lsq, std::shared_ptr<NDT>>(m, "NDTCuda")

@@ -281,6 +281,9 @@ public:
   void setInitialLambdaFactor(double f) { lm_init_lambda_factor_ = f; }
   void setDebugPrint(bool p) { lm_debug_print_ = p; }
   void setUseDeviceLM(bool on) { use_device_lm_ = on; }
+  /// lsq_optimizer_type_ (lsq_registration.hpp:78: protected there, set by subclasses; LevenbergMarquardt by default, :15). Gauss-Newton
+  /// (step_gn, :108-121) runs the reference's host loop on the device's linearize(); the device-resident loop is Levenberg-Marquardt.
+  void setLSQType(LSQ_OPTIMIZER_TYPE type) { lsq_optimizer_type_ = type; }
   const Matrix6d& getFinalHessian() const { return final_hessian_; }
   const Matrix4f& getFinalTransformation() const { return final_transformation_; }
   bool hasConverged() const { return converged_; }
@@ -309,13 +312,13 @@ protected:
     Isometry3d x0 = Isometry3d::from(guess);
     lm_lambda_ = -1.0;
     converged_ = false;
-    if (use_device_lm_ && device_align(x0)) {
+    if (use_device_lm_ && lsq_optimizer_type_ == LSQ_OPTIMIZER_TYPE::LevenbergMarquardt && device_align(x0)) {
       // whole loop ran on the GPU
     } else {
       for (int i = 0; i < max_iterations_ && !converged_; i++) {
         nr_iterations_ = i;
         Isometry3d delta;
-        if (!step_lm(x0, delta)) {
+        if (!step_optimize(x0, delta)) {
           std::fprintf(stderr, "lm not converged!!\n");
           break;
         }
@@ -339,6 +342,20 @@ protected:
   /// subclasses with a device-resident LM return true after updating x0 / converged_ / nr_iterations_ / final_hessian_
   virtual bool device_align(Isometry3d& x0) { (void)x0; return false; }
 
+  bool step_optimize(Isometry3d& x0, Isometry3d& delta) {  // :94-104
+    return lsq_optimizer_type_ == LSQ_OPTIMIZER_TYPE::GaussNewton ? step_gn(x0, delta) : step_lm(x0, delta);
+  }
+  bool step_gn(Isometry3d& x0, Isometry3d& delta) {  // :108-121
+    Matrix6d H;
+    Vector6d b, nb, d;
+    linearize(x0, &H, &b);
+    for (int j = 0; j < 6; j++) nb[j] = -b[j];
+    detail::ldlt6_solve(H, nb, d);
+    delta = se3_exp(d);
+    x0 = delta * x0;
+    final_hessian_ = H;
+    return true;
+  }
   bool step_lm(Isometry3d& x0, Isometry3d& delta) {  // :123-168
     Matrix6d H;
     Vector6d b;
@@ -555,36 +572,13 @@ protected:
   }
   void call(int rc, const char* what) const { detail::check(rc, what, fvh_vgicp_last_error(core_)); }
 
-protected:
-  int k_correspondences_ = 20;                                                                   // :24
 private:
+  int k_correspondences_ = 20;                                                                   // :24
   double voxel_resolution_ = 1.0;                                                                // :25
   RegularizationMethod regularization_method_ = RegularizationMethod::PLANE;                     // :26
-protected:
   NearestNeighborMethod neighbor_search_method_ = NearestNeighborMethod::CPU_PARALLEL_KDTREE;    // :27
-private:
   fvh_vgicp* core_ = nullptr;
   std::vector<float> scratch_xyz_;  // only used for point types that are not 12 / 16 bytes of packed xyz
-};
-
-/// FastVGICP -- the reference's CPU / OpenMP class (gicp/fast_vgicp.hpp:28-78, impl/fast_vgicp_impl.hpp) -- served by the same HIP
-/// engine in its fp64 arithmetic. What distinguishes it from FastVGICPCuda in the reference is kept: `setCorrespondenceRandomness(k)`
-/// IS honoured (FastGICP::k_correspondences_, fast_gicp_impl.hpp:41-43,253-265; the CUDA class ignores it, fast_vgicp_cuda_impl.hpp:38),
-/// the covariances come from EXACT k nearest neighbours (the reference's kd-tree; here the device's exact search: identical lists),
-/// `setNumThreads` exists (a no-op: there is no OpenMP team to size) and the neighbour search takes no radius (DIRECT1 / 7 / 27 only).
-template <typename PointSource, typename PointTarget>
-class FastVGICP : public FastVGICPCuda<PointSource, PointTarget> {
-  using Base = FastVGICPCuda<PointSource, PointTarget>;
-
-public:
-  explicit FastVGICP(int device = 0) : Base(device) { this->neighbor_search_method_ = NearestNeighborMethod::GPU_BRUTEFORCE; }
-  void setNumThreads(int) {}                                                      // fast_gicp_impl.hpp:36-38
-  void setCorrespondenceRandomness(int k) { this->k_correspondences_ = k; }       // fast_gicp_impl.hpp:41-43 (takes effect at the next setInputSource / setInputTarget)
-  void setMaxCorrespondenceDistance(double) {}                                    // inherited from pcl::Registration; FastVGICP never reads it (voxel correspondences)
-  void setNeighborSearchMethod(NeighborSearchMethod method) {                     // fast_vgicp_impl.hpp:46-48
-    if (method == NeighborSearchMethod::DIRECT_RADIUS) detail::check(FVH_ERR_INVALID_ARGUMENT, "setNeighborSearchMethod", "FastVGICP has no DIRECT_RADIUS (fast_vgicp_voxel.hpp:16-43): use FastVGICPCuda");
-    Base::setNeighborSearchMethod(method, -1.0);
-  }
 };
 
 /// FastGICP (gicp/fast_gicp.hpp:24-98, impl/fast_gicp_impl.hpp) on the HIP engine: the reference class is CPU/OpenMP only;
@@ -593,6 +587,8 @@ public:
 template <typename PointSource, typename PointTarget>
 class FastGICP : public LsqRegistration<PointSource, PointTarget> {
   using Base = LsqRegistration<PointSource, PointTarget>;
+
+protected:
   using Base::input_;
   using Base::target_;
 
@@ -625,16 +621,14 @@ public:
     input_ = cloud;
     const detail::XyzView<PointSource> view(*cloud, scratch_xyz_);
     call(fvh_vgicp_set_source_cloud_strided(core_, view.data, (int)cloud->size(), view.stride), "set_source_cloud");
-    call(fvh_vgicp_find_source_neighbors(core_, k_correspondences_), "find_source_neighbors");
-    call(fvh_vgicp_calculate_source_covariances(core_, (int)regularization_method_), "calculate_source_covariances");
+    estimate_covariances(*cloud, true);
   }
   void setInputTarget(const PointCloudTargetConstPtr& cloud) override {  // :88-95
     if (cloud == target_) return;
     target_ = cloud;
     const detail::XyzView<PointTarget> view(*cloud, scratch_xyz_);
     call(fvh_vgicp_set_target_cloud_strided(core_, view.data, (int)cloud->size(), view.stride), "set_target_cloud");
-    call(fvh_vgicp_find_target_neighbors(core_, k_correspondences_), "find_target_neighbors");
-    call(fvh_vgicp_calculate_target_covariances(core_, (int)regularization_method_), "calculate_target_covariances");
+    estimate_covariances(*cloud, false);
   }
   /// gicp/fast_gicp.hpp:60-70: covariances computed elsewhere / read back. The reference carries them as 4x4 doubles with a
   /// zero last row and column; here a covariance is its 3x3 block, 9 doubles per point (symmetric, so any major).
@@ -704,11 +698,116 @@ protected:
   }
   void call(int rc, const char* what) const { detail::check(rc, what, fvh_vgicp_last_error(core_)); }
 
-private:
+  /// calculate_covariances (fast_gicp_impl.hpp:244-301): k nearest neighbours of every point + regularisation. The device's exact
+  /// search serves k <= 64 on clouds of at least k points; what the reference's kd-tree also accepts -- larger k, or fewer points than
+  /// k (nearestKSearch then returns them all; the unfilled entries of its index vector stay 0) -- goes through the host kd-tree.
+  template <typename CloudT>
+  void estimate_covariances(const CloudT& cloud, bool source) {
+    const int n = (int)cloud.size(), k = k_correspondences_;
+    if (k < 1) throw std::invalid_argument("setCorrespondenceRandomness: k must be >= 1");
+    if (n == 0) return;
+    if (k <= 64 && n >= k) {
+      call(source ? fvh_vgicp_find_source_neighbors(core_, k) : fvh_vgicp_find_target_neighbors(core_, k), "find_neighbors");
+    } else {
+      if (k > 64) throw std::invalid_argument("setCorrespondenceRandomness: more than 64 neighbours per point are not supported by the covariance kernel");
+      const std::vector<float> xyz = detail::pack_xyz(cloud);
+      host::KdTree tree(xyz.data(), n);
+      std::vector<int> nb((size_t)n * k);
+      for (int i = 0; i < n; i++) {
+        int* row = &nb[(size_t)i * k];
+        tree.knn(&xyz[3 * (size_t)i], k, row);
+        for (int j = 0; j < k; j++) if (row[j] < 0) row[j] = 0;
+      }
+      call(source ? fvh_vgicp_set_source_neighbors(core_, k, nb.data()) : fvh_vgicp_set_target_neighbors(core_, k, nb.data()), "set_neighbors");
+    }
+    call(source ? fvh_vgicp_calculate_source_covariances(core_, (int)regularization_method_) : fvh_vgicp_calculate_target_covariances(core_, (int)regularization_method_), "calculate_covariances");
+  }
+
+protected:
   int k_correspondences_ = 20;                                                // :17
   RegularizationMethod regularization_method_ = RegularizationMethod::PLANE;  // :21
   fvh_vgicp* core_ = nullptr;
   std::vector<float> scratch_xyz_;  // only used for point types that are not 12 / 16 bytes of packed xyz
+};
+
+/// FastVGICP -- the reference's CPU / OpenMP class (gicp/fast_vgicp.hpp:28-78, impl/fast_vgicp_impl.hpp) -- served by the same HIP
+/// engine in its fp64 arithmetic. As in the reference it EXTENDS FastGICP (fast_vgicp.hpp:28): the cloud / covariance side --
+/// `setCorrespondenceRandomness(k)` honoured (FastGICP::k_correspondences_, fast_gicp_impl.hpp:41-43,253-265; the CUDA class ignores
+/// it, fast_vgicp_cuda_impl.hpp:38), covariances from EXACT k nearest neighbours (the reference's kd-tree; here the device's exact
+/// search: identical lists), `setNumThreads` (a no-op: there is no OpenMP team to size), the covariance accessors -- is FastGICP's;
+/// what it replaces is the correspondence model: voxels of the target instead of its nearest points (fast_vgicp_impl.hpp:73-204).
+/// The neighbour search takes no radius (DIRECT1 / 7 / 27 only, fast_vgicp_voxel.hpp:16-43).
+template <typename PointSource, typename PointTarget>
+class FastVGICP : public FastGICP<PointSource, PointTarget> {
+  using Base = FastGICP<PointSource, PointTarget>;
+  using Base::core_;
+  using Base::input_;
+  using Base::target_;
+
+public:
+  using PointCloudTargetConstPtr = typename Base::PointCloudTargetConstPtr;
+
+  explicit FastVGICP(int device = 0) : Base(device) {  // fast_vgicp_impl.hpp:19-25
+    this->call(fvh_vgicp_set_resolution(core_, 1.0), "set_resolution");
+    this->call(fvh_vgicp_set_neighbor_search_method(core_, (int)NeighborSearchMethod::DIRECT1, -1.0), "set_neighbor_search_method");
+  }
+  void setResolution(double resolution) { this->call(fvh_vgicp_set_resolution(core_, resolution), "set_resolution"); }  // :36-38
+  void setNeighborSearchMethod(NeighborSearchMethod method) {  // :46-48
+    if (method == NeighborSearchMethod::DIRECT_RADIUS) detail::check(FVH_ERR_INVALID_ARGUMENT, "setNeighborSearchMethod", "FastVGICP has no DIRECT_RADIUS (fast_vgicp_voxel.hpp:16-43): use FastVGICPCuda");
+    this->call(fvh_vgicp_set_neighbor_search_method(core_, (int)method, -1.0), "set_neighbor_search_method");
+  }
+  void setVoxelAccumulationMode(VoxelAccumulationMode mode) {  // :41-43; takes effect when the target voxel map is next built
+    this->call(fvh_vgicp_set_voxel_accumulation_mode(core_, static_cast<int>(mode)), "set_voxel_accumulation_mode");
+    if (target_) this->call(fvh_vgicp_create_target_voxelmap(core_), "create_target_voxelmap");
+  }
+  void setMaxCorrespondenceDistance(double) {}  // inherited from pcl::Registration; FastVGICP never reads it (voxel correspondences)
+
+  void swapSourceAndTarget() override {  // fast_vgicp_impl.hpp:46-53: swaps clouds and covariances, drops the voxel map (rebuilt here, not lazily)
+    this->call(fvh_vgicp_swap_source_and_target(core_), "swap_source_and_target");
+    input_.swap(target_);
+  }
+  void setInputTarget(const PointCloudTargetConstPtr& cloud) override {  // :56-63
+    if (cloud == target_) return;
+    Base::setInputTarget(cloud);
+    this->call(fvh_vgicp_create_target_voxelmap(core_), "create_target_voxelmap");
+  }
+
+protected:
+  double linearize(const Isometry3d& trans, Matrix6d* H, Vector6d* b) override {  // :119-178
+    double T16[16], err = 0, Hc[36];
+    trans.to_colmajor16(T16);
+    this->call(fvh_vgicp_update_correspondences(core_, T16), "update_correspondences");
+    this->call(fvh_vgicp_compute_error(core_, T16, (H && b) ? Hc : nullptr, (H && b) ? b->data() : nullptr, &err), "compute_error");
+    if (H && b) for (int i = 0; i < 6; i++) for (int j = 0; j < 6; j++) (*H)[i * 6 + j] = Hc[j * 6 + i];
+    return err;
+  }
+  double compute_error(const Isometry3d& trans) override {  // :181-204
+    double T16[16], err = 0;
+    trans.to_colmajor16(T16);
+    this->call(fvh_vgicp_compute_error(core_, T16, nullptr, nullptr, &err), "compute_error");
+    return err;
+  }
+  bool device_align(Isometry3d& x0) override {
+    double g16[16];
+    x0.to_colmajor16(g16);
+    fvh_lm_params p{this->max_iterations_, this->rotation_epsilon_, this->transformation_epsilon_, this->lm_max_iterations_, this->lm_init_lambda_factor_};
+    fvh_lm_result r;
+    this->call(fvh_vgicp_set_lm_trace(core_, this->lm_debug_print_ ? 1 : 0), "set_lm_trace");
+    this->call(fvh_vgicp_align(core_, g16, &p, &r), "align");
+    if (this->lm_debug_print_) {
+      int n = 0;
+      this->call(fvh_vgicp_get_lm_trace(core_, &n, nullptr), "get_lm_trace");
+      std::vector<double> rows(6 * (size_t)n);
+      if (n) this->call(fvh_vgicp_get_lm_trace(core_, &n, rows.data()), "get_lm_trace");
+      detail::print_lm_trace(rows);
+    }
+    x0 = Isometry3d::from_colmajor16(r.T);
+    this->converged_ = r.converged != 0;
+    this->nr_iterations_ = r.nr_iterations;
+    for (int i = 0; i < 6; i++) for (int j = 0; j < 6; j++) this->final_hessian_[i * 6 + j] = r.H[j * 6 + i];
+    if (r.lm_failed) std::fprintf(stderr, "lm not converged!!\n");
+    return true;
+  }
 };
 
 /// NDTCuda (ndt_cuda.hpp:23-69, impl/ndt_cuda_impl.hpp)

@@ -179,6 +179,9 @@ int fvh_vgicp_debug_get_skipped_points(fvh_vgicp* h, int* n);  /* target points 
 int fvh_vgicp_debug_get_persist_aborts(fvh_vgicp* h, int* n);  /* persistent-LM launches whose barrier watchdog fired (each was redone with one launch per LM transition) */
 int fvh_vgicp_debug_get_persist_grid(fvh_vgicp* h, int* blocks, int* capacity);  /* workgroups of the last persistent-LM launch / co-resident workgroup capacity of the device for that kernel */
 int fvh_debug_slot_pool(int device, int* reserved, int* active, int* recent);    /* the process-wide pool that splits those workgroup slots between concurrent aligns: all zero when nothing is in flight */
+/* persistent LM kernel, XCD-local hand-offs (kernels_cost.hpp): *wanted = 1 while the process still asks for them, *placement_aborts =
+ * launches that ended because the dispatcher had not placed the workgroups of a group on one XCD (3 of those switch the flavour off) */
+int fvh_debug_xcd_local(int* wanted, int* placement_aborts);
 
 /* new: multi-GPU (one process per GPU).  Every rank holds a spatial-tile shard of the source
  * cloud and the target voxel map; the 28-value normal-equation block (err, b, upper H) is

@@ -191,6 +191,10 @@ class _Reg:
             args.append(int(debug))
         self._call("set_lm", *args)
 
+    def set_optimizer(self, name):
+        """lsq_optimizer_type_: "LM" (default, lsq_registration_impl.hpp:15) or "GN" (step_gn, :108-121)."""
+        self._call("set_optimizer", 1 if name == "GN" else 0)
+
     def set_target(self, xyz):
         a = _f32(xyz)
         self._call("set_target", _p(a), len(a))

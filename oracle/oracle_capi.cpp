@@ -149,6 +149,8 @@ void orc_vgicp_set_lm(void* h, int max_iter, double rot_eps, double trans_eps, i
   g->max_iterations = max_iter; g->rotation_epsilon = rot_eps; g->transformation_epsilon = trans_eps;
   g->lm_max_iterations = lm_max_iter; g->lm_init_lambda_factor = init_lambda_factor; g->lm_debug_print = debug != 0;
 }
+void orc_vgicp_set_optimizer(void* h, int gauss_newton) { ((FastVGICP*)h)->gauss_newton = gauss_newton != 0; }
+void orc_ndt_set_optimizer(void* h, int gauss_newton) { ((NDT*)h)->gauss_newton = gauss_newton != 0; }
 void orc_vgicp_set_target(void* h, const float* xyz, int n) { ((FastVGICP*)h)->setInputTarget(make_cloud(xyz, n)); }
 void orc_vgicp_set_source(void* h, const float* xyz, int n) { ((FastVGICP*)h)->setInputSource(make_cloud(xyz, n)); }
 void orc_vgicp_set_target_covs(void* h, const double* c9) { auto* g = (FastVGICP*)h; g->target_covs = load_m3(c9, g->target->size()); }

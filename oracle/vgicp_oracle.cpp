@@ -454,6 +454,19 @@ bool LsqBase::is_converged(const Iso3& delta) const {
   return std::max(rmax, tmax) < 1;
 }
 
+// lsq_registration_impl.hpp:108-121
+bool LsqBase::step_gn(Iso3& x0, Iso3& delta) {
+  double H[36], b[6], nb[6], d[6];
+  linearize(x0, H, b);
+  num_linearize++;
+  for (int j = 0; j < 6; j++) nb[j] = -b[j];
+  ldlt6_solve(H, nb, d);
+  delta = se3_exp(d);
+  x0 = iso_mul(delta, x0);
+  std::memcpy(final_hessian, H, sizeof(H));
+  return true;
+}
+
 bool LsqBase::step_lm(Iso3& x0, Iso3& delta) {
   double H[36], b[6];
   double y0 = linearize(x0, H, b);
@@ -502,7 +515,7 @@ void LsqBase::optimize(const Iso3& guess) {
   for (int i = 0; i < max_iterations && !converged; i++) {
     nr_iterations = i;
     Iso3 delta;
-    if (!step_lm(x0, delta)) {
+    if (!(gauss_newton ? step_gn(x0, delta) : step_lm(x0, delta))) {  // step_optimize, :94-104
       std::cerr << "lm not converged!!" << std::endl;
       break;
     }

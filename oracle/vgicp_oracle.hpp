@@ -107,6 +107,8 @@ struct LsqBase {
   virtual double linearize(const Iso3& T, double* H, double* b) = 0;
   virtual double compute_error(const Iso3& T) = 0;
   bool is_converged(const Iso3& delta) const;        // :82-91
+  bool gauss_newton = false;                         // lsq_optimizer_type_ == GaussNewton (:15 default: LevenbergMarquardt)
+  bool step_gn(Iso3& x0, Iso3& delta);               // :108-121
   bool step_lm(Iso3& x0, Iso3& delta);               // :123-168
   void optimize(const Iso3& guess);                  // :53-79 (computeTransformation minus the PCL cloud transform)
 };

@@ -63,6 +63,33 @@ def test_host_lm_equals_device_lm(pygicp, data, cls):
     assert out[0][3] == out[1][3]
 
 
+@pytest.mark.parametrize("cls", ["FastVGICPCuda", "FastVGICP", "FastGICP", "NDTCuda"])
+def test_gauss_newton_optimizer_matches_oracle(pygicp, data, cls):
+    """LSQ_OPTIMIZER_TYPE::GaussNewton (lsq_registration_impl.hpp:94-121) through the host classes: the reference's host loop on the
+    device's linearize(), against the oracle's step_gn at 1e-4 (north_star), Hessian included."""
+    from oracle import oracle as O
+    target, source, gt = data
+    reg = getattr(pygicp, cls)()
+    reg.set_lsq_type("GN")
+    reg.set_input_target(target); reg.set_input_source(source)
+    T = reg.align()
+    if cls == "NDTCuda":
+        g = O.NDT()
+    else:
+        g = O.FastVGICP(search=O.DIRECT1)
+        if cls == "FastGICP":
+            g.set_gicp_mode(True)
+    g.set_optimizer("GN")
+    g.set_target(target.astype(np.float32)); g.set_source(source.astype(np.float32))
+    ro = g.align()
+    assert reg.has_converged() and ro["converged"] and ro["num_error_evals"] == 0
+    assert util.rel_err(T, ro["T"].astype(np.float32)) < 1e-4
+    assert util.rel_err(reg.get_final_hessian(), ro["H"]) < 1e-4
+    _check(gt, T, True, cls + " Gauss-Newton")
+    with pytest.raises(Exception):
+        reg.set_lsq_type("Newton")
+
+
 def test_neighbor_methods_agree(pygicp, data):
     """CPU_PARALLEL_KDTREE (host kd-tree, reference default) and GPU_BRUTEFORCE give the same neighbours -> same result."""
     target, source, _ = data
@@ -191,4 +218,4 @@ def test_vgicp_honours_k_correspondences_like_the_cpu_class(pygicp, k):
     reg.set_resolution(1.0); reg.set_neighbor_search_method("DIRECT7")
     reg.set_input_target(tgt.astype(np.float64)); reg.set_input_source(src.astype(np.float64))
     assert np.array_equal(reg.align(), T) and reg.has_converged()
-    assert isinstance(reg, pygicp.FastVGICPCuda) and isinstance(reg, pygicp.LsqRegistration)
+    assert isinstance(reg, pygicp.FastGICP) and isinstance(reg, pygicp.LsqRegistration)  # main.cpp:192: FastVGICP derives from FastGICP

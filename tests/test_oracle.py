@@ -61,6 +61,28 @@ def test_gicp_test_scenarios(O, method):
     r = reg.align(); check(r["T"], r["converged"], "swap and set target")
 
 
+@pytest.mark.parametrize("method", ["VGICP", "NDT"])
+def test_gauss_newton_step(O, method):
+    """step_gn (lsq_registration_impl.hpp:108-121; selected by lsq_optimizer_type_, :94-104): plain Gauss-Newton -- linearize, H d = -b by LDLT,
+    x0 = exp(d) x0, no trial evaluation. On the gicp_test pair it meets the reference's tolerance like LM does, never evaluates the error
+    alone, and one GN iteration from a pose IS the numpy solve of that pose's normal equations."""
+    t, s = util.bundled_pair(origin_filter=False, leaf=0.2, exact_voxelgrid=True)
+    g = O.FastVGICP(search=O.DIRECT7) if method == "VGICP" else O.NDT()
+    g.set_optimizer("GN")
+    g.set_target(t); g.set_source(s)
+    r = g.align()
+    te, re_ = util.pose_error(util.relative_pose(), r["T"])
+    assert r["converged"] and te < 0.05 and re_ < np.radians(1.0)
+    assert r["num_error_evals"] == 0 and r["num_linearize"] == r["iterations"]
+    g.set_lm(max_iterations=1)
+    r1 = g.align()
+    g.prepare()
+    e, H, b = g.linearize(np.eye(4))
+    d = np.linalg.solve(H, -b)
+    assert util.rel_err(r1["T"], O.se3_exp(d)) < 1e-9
+    assert util.rel_err(r1["H"], H) < 1e-12
+
+
 def test_readme_fitness_band(O):
     """README.md:126-128 vgicp fitness 0.204067 (stale revision) -> +-1 % sanity band (SURVEY 6 caveat 3)."""
     t, s = util.bundled_pair(origin_filter=True)

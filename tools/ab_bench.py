@@ -12,13 +12,17 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def main():
     args = sys.argv[1:]
-    workload, steps = "bundled17k", "100"
+    workload, steps, streams, cov = "bundled17k", "100", "1", "knn"
     while args and args[0].startswith("--"):
         k = args.pop(0)
         if k == "--workload":
             workload = args.pop(0)
         elif k == "--steps":
             steps = args.pop(0)
+        elif k == "--cov":
+            cov = args.pop(0)
+        elif k == "--streams":  # > 1: also the concurrent-handles leg (S engine handles, S host threads)
+            streams = args.pop(0)
     for spec in args:
         name, _, envs = spec.partition(":")
         env = dict(os.environ)
@@ -27,7 +31,7 @@ def main():
         for kv in filter(None, envs.split(",")):
             k, _, v = kv.partition("=")
             env[k] = v
-        cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--workload", workload, "--steps", steps, "--warmup", "10", "--no-cpu-baseline", "--streams", "1"]
+        cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--workload", workload, "--steps", steps, "--warmup", "10", "--no-cpu-baseline", "--streams", streams, "--configs", "none", "--no-host-leg", "--cov", cov]
         p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
         line = [l for l in p.stdout.splitlines() if l.startswith("{")]
         if not line:
@@ -35,9 +39,12 @@ def main():
             continue
         d = json.loads(line[-1])
         st = d.get("stages", {})
-        print("%-44s %9.1f reg/s  cost %7.1f us  sort %5.1f  knn %6.1f  cov %5.1f  vm %5.1f  fitness %.6f aborts %s" % (
-            spec, d["value"], st.get("cost", {}).get("avg_us", float("nan")), st.get("sort", {}).get("avg_us", float("nan")), st.get("knn", {}).get("avg_us", float("nan")), st.get("cov", {}).get("avg_us", float("nan")),
-            st.get("voxelmap", {}).get("avg_us", float("nan")), d.get("fitness_score", float("nan")), d["per_registration"].get("persistent_launches_aborted_by_watchdog")), flush=True)
+        nan = float("nan")
+        cs = d.get("concurrent_streams") or {}
+        print("%-52s %9.1f reg/s  cost %7.1f us (roofline launch %7.1f)  sort %5.1f  knn %6.1f  cov %5.1f  vm %5.1f  fitness %.6f aborts %s%s" % (
+            spec, d["value"], st.get("cost", {}).get("avg_us", nan), (d.get("roofline") or {}).get("avg_launch_us", nan), st.get("sort", {}).get("avg_us", nan), st.get("knn", {}).get("avg_us", nan),
+            st.get("cov", {}).get("avg_us", nan), st.get("voxelmap", {}).get("avg_us", nan), d.get("fitness_score", nan), (d.get("per_registration") or {}).get("persistent_launches_aborted_by_watchdog"),
+            ("  | %s streams: %.1f reg/s" % (cs.get("streams"), cs.get("registrations_per_sec", nan))) if cs else ""), flush=True)
 
 
 if __name__ == "__main__":
