@@ -48,7 +48,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--workload", default="bundled17k", choices=["bundled17k", "synth100k", "synth1m", "lidar_stream"])
     ap.add_argument("--search", default=None, choices=["DIRECT1", "DIRECT7", "DIRECT27"])
-    ap.add_argument("--cov", default="knn", choices=["knn", "rbf"])
+    ap.add_argument("--cov", default="knn", choices=["knn", "rbf", "kdtree"])
     ap.add_argument("--precision", default="fp64", choices=["fp64", "fp32"])
     ap.add_argument("--configs", default=None, help="comma list of extra configurations measured after the headline (default: all three when the headline is the default "
                     "bundled17k run on one GPU; 'none' to skip): synth100k_rbf,synth1m,lidar_stream")
@@ -230,6 +230,105 @@ def cpu_config0(budget_s=8.0):
     return r
 
 
+def sharded_headline(args, dist, rank, world, local_rank, dev, small=False):
+    """--gpus N > 1: the line's `value`. ONE registration stream whose every registration is spread over the N GPUs -- BASELINE configs[4]:
+    1M-point map <-> 100k-point scan, DIRECT7, res 0.5, source sharded by spatial tile (Morton ranges), target voxel map replicated, the
+    32 x f64 normal-equation block summed over the ranks once per cost evaluation (north_star: RCCL all-reduce over xGMI; route "rccl",
+    FVH_BENCH_ROUTE=peer selects the in-kernel mailboxes). A step = scan in (host buffer, as a localisation loop receives it), k-NN k = 20,
+    PLANE covariances, align. Strong scaling: the work per registration is fixed, N grows. The same step on ONE GPU is timed first on every
+    rank (`n1_same_workload`), so that the speed-up can be read off this line alone."""
+    import torch
+    from fast_gicp_amd import capi, distributed as D, workloads
+    torch.cuda.set_device(local_rank)  # (worker thread of run_with_deadline: the current device is per thread)
+    route = os.environ.get("FVH_BENCH_ROUTE", "peer" if small else "rccl")
+    n_t, n_s, seed, extent, search_name = (40_000, 20_000, 21, 40.0, "DIRECT7") if small else (1_000_000, 100_000, 44, 150.0, "DIRECT7")
+    tgt, src, _ = workloads.synthetic_pair(n_t, n_s, seed=seed, extent=extent)
+    steps, warmup = args.steps, args.warmup
+
+    def barrier():
+        dist.barrier(); torch.cuda.synchronize()
+
+    def max_over_ranks(x):
+        t = torch.tensor([x], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def fresh():
+        c = capi.VGICPCore(local_rank)
+        c.set_resolution(0.5); c.set_neighbor_search_method(capi.DIRECT7)
+        return c
+
+    # ---- the same step on one GPU (every rank, unsharded) ----
+    c1 = fresh()
+    c1.set_target_cloud(tgt); c1.find_target_neighbors(20); c1.calculate_target_covariances(capi.REG_PLANE); c1.create_target_voxelmap()
+
+    def step1():
+        c1.set_source_cloud(src); c1.find_source_neighbors(20); c1.calculate_source_covariances(capi.REG_PLANE)
+        return c1.align()
+    for _ in range(min(warmup, 5)):
+        r1 = step1()
+    n1_steps = max(5, min(steps, 40))
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(n1_steps):
+        r1 = step1()
+    c1.synchronize()
+    ms1 = max_over_ranks(time.perf_counter() - t0) / n1_steps * 1e3
+    c1.close()
+
+    # ---- sharded over the ranks ----
+    c = fresh()
+    sh = D.ShardedVGICP(c, rank, world, dist, collective=route)
+    t0 = time.perf_counter()
+    if route == "peer":
+        sh.attach_peers(max(n_t, n_s), device_index=local_rank)
+    else:
+        uid = [capi.comm_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(uid, src=0)
+        sh.init_device_collective(uid[0])
+    attach_ms = (time.perf_counter() - t0) * 1e3
+    sh.set_target(tgt)
+    c.synchronize()
+
+    def step():
+        sh.set_source(src)
+        return sh.align()
+    for _ in range(warmup):
+        r = step()
+    barrier()
+    t0 = time.perf_counter()
+    n_eval = n_launch = 0
+    for _ in range(steps):
+        r = step()
+        n_eval += r["num_linearize"] + r["num_error_evals"]
+        n_launch += r["num_launches"]
+    barrier()
+    elapsed = max_over_ranks(time.perf_counter() - t0)
+    out = {
+        "metric": "registrations/sec (one registration stream, every registration sharded over the GPUs by spatial tile; BASELINE configs[4])",
+        "value": round(steps / elapsed, 3), "unit": "registrations/sec", "n_gpus": world, "steps": steps, "warmup": warmup, "ms_per_step": round(elapsed / steps * 1e3, 5),
+        "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": "synthetic %s-point map <-> %s-point scan, seed %d: scan-to-map step (host scan in, k-NN k = 20, PLANE covariances, align)" % (
+                       "{:,}".format(n_t), "{:,}".format(n_s), seed),
+                   "method": "VGICP", "neighbor_search": search_name, "k_correspondences": 20, "covariance": "knn", "regularization": "PLANE", "voxel_resolution": 0.5,
+                   "parallelism": "source sharded by spatial tile (Morton ranges) over %d GPUs, target voxel map replicated; %s" % (world, sh.collective_description()),
+                   "route": route},
+        "n1_same_workload": {"value": round(1e3 / ms1, 3), "unit": "registrations/sec", "ms_per_step": round(ms1, 5), "steps": n1_steps, "converged": bool(r1["converged"]),
+                             "note": "the same step, unsharded, on one GPU (max over the ranks, each on its own GPU): value / this = the strong-scaling speed-up"},
+        "speedup_vs_one_gpu": round(ms1 / (elapsed / steps * 1e3), 3),
+        "per_registration": {"cost_evaluations": n_eval / steps, "kernel_launches_lm": n_launch / steps, "converged": bool(r["converged"]),
+                             "pose_equals_single_gpu": bool(np.abs(r["T"] - r1["T"]).max() < 1e-9), "max_abs_pose_difference": float(np.abs(r["T"] - r1["T"]).max())},
+        "attach_ms": round(attach_ms, 2),
+    }
+    dist.barrier()
+    if route == "peer":
+        c.peer_detach()
+    else:
+        c.comm_destroy()
+    c.close()
+    return out
+
+
 def sharded_leg(args, dist, rank, world, local_rank, dev, small=False):
     """north_star: "large scans shard by spatial tile across up to 8 GPUs with an RCCL all-reduce of the 6x6 / 6x1 normal equations per
     iteration ... 100 k / 1 M synthetic clouds at 1 / 2 / 4 / 8 GPUs". ONE registration spread over the ranks, for both large configurations
@@ -369,9 +468,29 @@ def concurrent_leg(args, local_rank, d_clouds, n_pts, res, search, K):
     for c in cores:
         c.synchronize()
     el = time.perf_counter() - t0
+    # the LM loop alone (clouds, covariances and maps stay): what the persistent kernels of S handles make of the chip between them
+    def aligns(c, n):
+        for _ in range(n):
+            c.align()
+    na = max(40, steps)
+    aligns(cores[0], 5)
+    t0 = time.perf_counter()
+    aligns(cores[0], na)
+    one = na / (time.perf_counter() - t0)
+    time.sleep(0.05)
+    threads = [threading.Thread(target=aligns, args=(c, na)) for c in cores]
+    t0 = time.perf_counter()
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    many = S * na / (time.perf_counter() - t0)
     for c in cores:
         c.close()
-    return {"streams": S, "steps_per_stream": steps, "registrations_per_sec": round(S * steps / el, 3), "note": "independent registrations, not the sequential reference loop"}
+    return {"streams": S, "steps_per_stream": steps, "registrations_per_sec": round(S * steps / el, 3), "note": "independent registrations, not the sequential reference loop",
+            "align_only": {"one_handle_aligns_per_sec": round(one, 1), "all_handles_aligns_per_sec": round(many, 1), "ratio": round(many / one, 3),
+                           "note": "align() alone on prepared handles: the co-resident workgroup slots are split between the concurrent persistent LM kernels (SlotPool); the full loop "
+                                   "above adds each stream's sort / k-NN / covariance kernels, which wait for room beside the resident LM workgroups"}}
 
 
 def run_stream(args, steps, warmup, cpu_loops=15, frames_n=10):
@@ -600,9 +719,19 @@ def run_registration(args, workload, cov, search_name, steps, warmup, local_rank
     core.set_kernel_params(0.5, 2.5)  # align.cpp:210 setKernelWidth(0.5) -> max_dist 2.5
     core.set_precision(capi.COMPUTE_FP32 if args.precision == "fp32" else capi.COMPUTE_FP64)
 
+    kd = None
+    if cov == "kdtree":  # FastVGICPCuda's default, NearestNeighborMethod::CPU_PARALLEL_KDTREE (fast_vgicp_cuda_impl.hpp:152-167): neighbours from a host
+        import pygicp   # kd-tree (OpenMP), handed to the device, covariances there -- the "vgicp_cuda (parallel_kdtree)" row of align.cpp:190-196
+        kd = pygicp._kdtree_knn
+    cloud_of = {"target": 0, "source": 1}
+
     def estimate_cov(which):
         if cov == "knn":
             getattr(core, "find_%s_neighbors" % which)(K)
+            getattr(core, "calculate_%s_covariances" % which)(capi.REG_PLANE)
+        elif cov == "kdtree":
+            idx = kd(h_clouds[cloud_of[which]].astype(np.float64), K)
+            getattr(core, "set_%s_neighbors" % which)(K, np.ascontiguousarray(idx, np.int32))
             getattr(core, "calculate_%s_covariances" % which)(capi.REG_PLANE)
         else:
             getattr(core, "calculate_%s_covariances_rbf" % which)(capi.REG_PLANE)
@@ -632,6 +761,7 @@ def run_registration(args, workload, cov, search_name, steps, warmup, local_rank
         # map-vs-scan localisation (BASELINE configs[4] shape): the 1M-point map stays the target, every step registers a scan
         def step():
             set_source(1)
+            cloud_of["source"] = 1
             estimate_cov("source")
             state["last"] = core.align()
             state["next"] = 0
@@ -641,6 +771,7 @@ def run_registration(args, workload, cov, search_name, steps, warmup, local_rank
             core.swap_source_and_target()
             i = state["next"]
             set_source(i)
+            cloud_of["source"], cloud_of["target"] = i, 1 - i
             estimate_cov("source")
             state["last"] = core.align()
             state["next"] = 1 - i
@@ -782,6 +913,9 @@ def run_registration(args, workload, cov, search_name, steps, warmup, local_rank
 
 EXTRA_CONFIGS = {
     # name: (workload, cov, search, steps, warmup, cpu seconds)
+    # BASELINE configs[1] with the other two covariance modes of align.cpp:190-213: the headline is gpu_bruteforce
+    "bundled17k_rbf_kernel": ("bundled17k", "rbf", "DIRECT27", 100, 10, 0.0),
+    "bundled17k_parallel_kdtree": ("bundled17k", "kdtree", "DIRECT27", 20, 3, 0.0),
     "synth100k_rbf": ("synth100k", "rbf", "DIRECT27", 40, 5, 10.0),
     "synth1m": ("synth1m", "knn", "DIRECT7", 40, 5, 12.0),
 }
@@ -792,8 +926,18 @@ def main():
     import torch
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the product path has no CPU fallback)")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` on its own: become the launch the driver would have made (one rank per GPU over RCCL)
+        import socket
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        os.execvp(sys.executable, [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+                                   "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:])
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
+    if args.gpus != world and rank == 0:
+        print("bench.py: --gpus %d but WORLD_SIZE=%d: the process group decides (one rank per GPU)" % (args.gpus, world), file=sys.stderr)
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.workload == "lidar_stream":
         if world != 1:
@@ -820,23 +964,42 @@ def main():
 
     if args.search is None:
         args.search = "DIRECT7" if args.workload == "synth1m" else "DIRECT27"
-    out = run_registration(args, args.workload, args.cov, args.search, args.steps, args.warmup, local_rank, dist, dev, world, rank, headline=True, cpu_budget=args.cpu_seconds)
-
     sharded, sharded_hung = None, False
-    if world > 1 and (not share_gpu or os.environ.get("FVH_BENCH_SHARDED_TEST") == "1"):
-        # the headline number is already measured: a stuck collective in this extra leg must not take the JSON line with it
-        sharded, sharded_hung = run_with_deadline(lambda: sharded_leg(args, dist, rank, world, local_rank, dev, small=share_gpu), args.sharded_deadline)
-        if sharded_hung:
-            sharded = {"error": "sharded leg did not finish within %d s on rank %d" % (args.sharded_deadline, rank)}
-    if rank != 0:
-        finish(dist, sharded_hung)
-        return
-    if sharded is not None:  # (leads the line: with N > 1 `value` is N independent registration streams -- weak scaling by construction; THIS is the exchange path)
-        out = {"metric": out["metric"], "value": out["value"], "unit": out["unit"], "n_gpus": out["n_gpus"], "sharded": sharded, **{k: v for k, v in out.items() if k not in ("metric", "value", "unit", "n_gpus")}}
+    if world > 1:
+        # N > 1: `value` is the path north_star describes -- ONE registration sharded over the GPUs (BASELINE configs[4]), strong scaling. The N
+        # independent 17k streams the line used to lead with (no traffic between the GPUs: weak scaling by construction) follow as `replicas_17k`.
+        # Every collective leg runs on a worker thread under a deadline: a stuck exchange must not take the JSON line with it.
+        head, hung = run_with_deadline(lambda: sharded_headline(args, dist, rank, world, local_rank, dev, small=share_gpu), args.sharded_deadline)
+        if hung or head is None:
+            head = None
+            sharded_hung = hung
+        replicas = None
+        if not sharded_hung:
+            replicas = run_registration(args, args.workload, args.cov, args.search, min(args.steps, 100), min(args.warmup, 10), local_rank, dist, dev, world, rank, headline=False,
+                                        cpu_budget=args.cpu_seconds, cpu=False)
+            if os.environ.get("FVH_BENCH_SHARDED_DETAIL", "1") == "1" and (not share_gpu or os.environ.get("FVH_BENCH_SHARDED_TEST") == "1"):
+                sharded, sharded_hung = run_with_deadline(lambda: sharded_leg(args, dist, rank, world, local_rank, dev, small=share_gpu), args.sharded_deadline)
+                if sharded_hung:
+                    sharded = {"error": "sharded detail leg did not finish within %d s on rank %d" % (args.sharded_deadline, rank)}
+        if rank != 0:
+            finish(dist, sharded_hung)
+            return
+        if head is not None:
+            out = head
+            if replicas is not None:
+                out["replicas_17k"] = {k: replicas[k] for k in ("metric", "value", "unit", "steps", "warmup", "ms_per_step", "scaling", "config", "fitness_score", "per_registration", "roofline") if k in replicas}
+                out["replicas_17k"]["note"] = "N independent registration streams of the 17k pair, one per GPU (the N = 1 headline replicated): no data-path collective, weak scaling by construction"
+        else:  # the sharded step failed or hung: say so, and report what was measured
+            out = replicas if replicas is not None else {"metric": "registrations/sec", "value": None, "unit": "registrations/sec", "n_gpus": world}
+            out["sharded_headline_error"] = "the sharded registration did not finish within %d s: `value` is N independent 17k streams instead" % args.sharded_deadline
+        if sharded is not None:
+            out["sharded"] = sharded
+    else:
+        out = run_registration(args, args.workload, args.cov, args.search, args.steps, args.warmup, local_rank, dist, dev, world, rank, headline=True, cpu_budget=args.cpu_seconds)
 
     # ---- the other single-GPU configurations of BASELINE.json, time-boxed ----
     default_headline = args.workload == "bundled17k" and args.cov == "knn" and world == 1
-    names = [] if args.configs == "none" else (args.configs.split(",") if args.configs else (["synth100k_rbf", "synth1m", "lidar_stream"] if default_headline else []))
+    names = [] if args.configs == "none" else (args.configs.split(",") if args.configs else (["bundled17k_rbf_kernel", "bundled17k_parallel_kdtree", "synth100k_rbf", "synth1m", "lidar_stream"] if default_headline else []))
     if names:
         configs = {}
         for name in names:
@@ -848,7 +1011,7 @@ def main():
                     configs[name] = run_stream(args, 60, 5)
                 else:
                     wl, cov, search, steps, warmup, cpu_s = EXTRA_CONFIGS[name]
-                    configs[name] = run_registration(args, wl, cov, search, steps, warmup, local_rank, cpu_budget=cpu_s)
+                    configs[name] = run_registration(args, wl, cov, search, steps, warmup, local_rank, cpu_budget=cpu_s, cpu=cpu_s > 0)
             except Exception as ex:  # the headline must not depend on an extra configuration
                 configs[name] = {"error": repr(ex)}
         if default_headline and not args.no_cpu_baseline and time.perf_counter() - T_START <= args.time_box + 30:

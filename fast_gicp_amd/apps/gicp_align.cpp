@@ -3,6 +3,7 @@
 // "single / 100times / 100times_reuse / fitness_score" output line (README.md:118-134).
 #include <algorithm>
 #include <chrono>
+#include <cstdlib>
 #include <iostream>
 
 #include "fast_gicp_amd/pcd_io.hpp"
@@ -48,6 +49,28 @@ void test(Registration& reg, const Cloud::ConstPtr& target, const Cloud::ConstPt
   }
   t2 = std::chrono::high_resolution_clock::now();
   std::cout << "100times_reuse:" << std::chrono::duration_cast<std::chrono::nanoseconds>(t2 - t1).count() / 1e6 << "[msec] fitness_score:" << fitness_score << std::endl;
+
+  if (std::getenv("GICP_ALIGN_BREAKDOWN")) {  // where a registration of the reuse loop spends its host time (not part of the reference's output)
+    using clk = std::chrono::steady_clock;
+    double t_swap = 0, t_src = 0, t_align = 0;
+    for (int i = 0; i < 100; i++) {
+      auto a = clk::now();
+      reg.swapSourceAndTarget();
+      reg.clearSource();
+      reg.setInputTarget(target_);
+      auto b = clk::now();
+      reg.setInputSource(source_);
+      auto c = clk::now();
+      reg.align(aligned);
+      auto d = clk::now();
+      target_.swap(source_);
+      t_swap += std::chrono::duration<double, std::micro>(b - a).count();
+      t_src += std::chrono::duration<double, std::micro>(c - b).count();
+      t_align += std::chrono::duration<double, std::micro>(d - c).count();
+    }
+    std::cout << "  breakdown per registration [us]: swap + clearSource + setInputTarget " << t_swap / 100 << ", setInputSource (upload, k-NN / covariance launches) " << t_src / 100
+              << ", align (waits for the GPU, transforms the output cloud) " << t_align / 100 << std::endl;
+  }
 }
 
 int main(int argc, char** argv) {

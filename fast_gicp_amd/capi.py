@@ -270,6 +270,15 @@ class VGICPCore(_Core):
             pbuf = (C.c_ulonglong * nranks)(*[int(p) for p in process_local_ptrs])
         self._call("peer_attach", int(nranks), int(rank), int(ranks_on_this_device), hbuf, pbuf)
 
+    def set_target_map_sharding(self, on=True, margin_voxels=2):
+        """Multi-GPU: this rank's target voxel map holds the voxels around its tile of the source only (rebuilt per align)."""
+        self._call("set_target_map_sharding", 1 if on else 0, int(margin_voxels))
+
+    def debug_map_shard(self):
+        a, b = C.c_int(0), C.c_int(0)
+        self._call("debug_get_map_shard", C.byref(a), C.byref(b))
+        return bool(a.value), b.value
+
     def peer_detach(self):
         self._call("peer_detach")
 

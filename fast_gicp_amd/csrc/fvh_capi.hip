@@ -76,6 +76,8 @@ struct VoxelMapDev {
   DevBuf table, acc, occupied, compact_pts, compact_cov;
   DevBuf bitmap, grid;    // occupancy bitmap of a large map + its VmGrid (kernels_voxelmap.hpp); has_bitmap: built for the live map
   bool has_bitmap = false;
+  DevBuf region;          // VmRegion of a map that holds one rank's shard only (multi-GPU, fvh_vgicp_set_target_map_sharding)
+  bool is_shard = false;  // the live map was built through `region`
   DevBuf keys[2];   // voxel keys, double buffered: keys[cur] belongs to the live map, the other one is what the next build fills
   DevBuf counters;  // 2 sets of 16 ints, [0] num_voxels [1] dropped; set `cur` belongs to the live map
   int cur = 0;
@@ -90,8 +92,8 @@ struct VoxelMapDev {
   std::vector<uint4> h_table;
   std::vector<int> h_occupied;
   std::unordered_map<int, int> bucket_to_index;
-  void invalidate() { valid = false; host_valid = false; has_bitmap = false; }
-  void release() { table.release(); acc.release(); occupied.release(); compact_pts.release(); compact_cov.release(); counters.release(); keys[0].release(); keys[1].release(); bitmap.release(); grid.release(); clean_cap = 0; has_bitmap = false; }
+  void invalidate() { valid = false; host_valid = false; has_bitmap = false; is_shard = false; }
+  void release() { table.release(); acc.release(); occupied.release(); compact_pts.release(); compact_cov.release(); counters.release(); keys[0].release(); keys[1].release(); bitmap.release(); grid.release(); region.release(); clean_cap = 0; has_bitmap = false; is_shard = false; }
 };
 
 struct Profiler {
@@ -123,6 +125,7 @@ struct Rccl {
   int (*CommInitRank)(void**, int, UID, int) = nullptr;
   int (*CommDestroy)(void*) = nullptr;
   int (*AllReduce)(const void*, void*, size_t, int, int, void*, hipStream_t) = nullptr;
+  int (*AllGather)(const void*, void*, size_t, int, void*, hipStream_t) = nullptr;
   bool load() {
     if (lib) return true;
     // reuse the RCCL the process already has (e.g. the one torch.distributed loaded) before loading another copy
@@ -137,7 +140,8 @@ struct Rccl {
     CommInitRank = (decltype(CommInitRank))dlsym(lib, "ncclCommInitRank");
     CommDestroy = (decltype(CommDestroy))dlsym(lib, "ncclCommDestroy");
     AllReduce = (decltype(AllReduce))dlsym(lib, "ncclAllReduce");
-    return GetUniqueId && CommInitRank && CommDestroy && AllReduce;
+    AllGather = (decltype(AllGather))dlsym(lib, "ncclAllGather");
+    return GetUniqueId && CommInitRank && CommDestroy && AllReduce && AllGather;
   }
 };
 Rccl g_rccl;
@@ -172,22 +176,35 @@ struct SlotPool {
     else if (recent[dev] > 1 && now - last_contention[dev] > std::chrono::milliseconds(QUIET_RESET_MS)) { recent[dev] = 1; calm[dev] = 0; }
     recent[dev] = std::max(recent[dev], active[dev]);
     static const int max_split = [] { const char* v = getenv("FVH_SLOT_MAX_SPLIT"); return v ? std::max(1, atoi(v)) : 4; }();
-    static const int share_by_xcd = [] { const char* v = getenv("FVH_SHARE_BY_XCD"); return v ? atoi(v) : 1; }();  // 0: round 3's behaviour (chip-wide grids of cap / concurrency workgroups)
+    // FVH_SHARE_BY_XCD=1: concurrent aligns are confined to 8 / K XCDs each (below). Measured (tools/r04_conc.py, profiles/r04_concurrency.txt):
+    // no better than chip-wide grids of cap / K workgroups -- 4 handles 15.8k vs 16.9k aligns/s, 8 handles 16.0k vs 19.9k: a hand-off costs
+    // ~1 us whether or not it crosses XCDs, and a confined grid has to leave room for the blocks that only pass through. Off by default.
+    static const int share_by_xcd = [] { const char* v = getenv("FVH_SHARE_BY_XCD"); return v ? atoi(v) : 0; }();
     const int per_xcd = std::max(1, cap / 8);
+    // A confined launch is dispatched over ALL XCDs and keeps the workgroups that land on its own: the others must find a free slot on
+    // THEIR XCD to start and exit. XCDs filled to the brim by other aligns' resident workgroups would block them (and with them the
+    // launch, until the watchdog: measured, 4 streams at 96 of 96 slots per XCD ran ten times slower than unconfined) -- so a confined
+    // align takes at most two of the three workgroup slots of a CU; the third stays free for transients and the other streams' kernels.
+    static const int confined_pct = [] { const char* v = getenv("FVH_CONFINED_SLOT_PCT"); return v ? std::min(100, std::max(10, atoi(v))) : 67; }();
     Grant g;
     const bool contended = recent[dev] > 1;
+    const int per_xcd_confined = contended ? std::max(1, per_xcd * confined_pct / 100) : per_xcd;
     if (confine_ok && ((contended && share_by_xcd) || (prefer_single && want <= per_xcd))) {
       const int k_max = contended ? std::max(1, 8 / std::max(1, std::min(recent[dev], max_split))) : 1;
-      const int k = std::max(1, std::min(k_max, (want + per_xcd - 1) / per_xcd));
+      const int k = std::max(1, std::min(k_max, (want + per_xcd_confined - 1) / per_xcd_confined));
       int order[8] = {0, 1, 2, 3, 4, 5, 6, 7};
       std::stable_sort(order, order + 8, [&](int a, int b) { return used[dev][a] < used[dev][b]; });
       int worst = 0;
       for (int i = 0; i < k; i++) { g.mask |= 1u << order[i]; worst = std::max(worst, used[dev][order[i]]); }
-      g.n = std::min(want, k * (per_xcd - worst));
+      g.n = std::min(want, k * std::max(0, per_xcd_confined - worst));
     } else {
       int worst = 0;
       for (int x = 0; x < 8; x++) worst = std::max(worst, used[dev][x]);
-      const int share = std::max(1, cap / std::max(1, std::min(recent[dev], max_split)));
+      // (FVH_CONTENDED_SLOT_PCT: the part of the device the concurrent aligns may hold between them -- the rest stays free for the other
+      // streams' neighbour searches and sorts, which cannot start on a CU whose register file three resident LM workgroups fill)
+      static const int contended_pct = [] { const char* v = getenv("FVH_CONTENDED_SLOT_PCT"); return v ? std::min(100, std::max(10, atoi(v))) : 100; }();
+      const int pool = contended ? cap * contended_pct / 100 : cap;
+      const int share = std::max(1, pool / std::max(1, std::min(recent[dev], max_split)));
       g.n = std::min(std::min(want, share), 8 * (per_xcd - worst));
     }
     if (g.n < std::min(want, 32)) {  // too little left to be worth a gang launch
@@ -329,6 +346,12 @@ struct Engine {
   // drained (`quiet`: the last call was an align that returned). The two build kernels are then independent of what the caller
   // does next -- upload the new source, sort it, search its neighbours, compute its covariances -- and run beside that chain on
   // `side`; the first call that is not part of that chain (align above all) makes the main stream wait for `side_done`.
+  // multi-GPU, either exchange: the engine shards a VGICP cloud internally -- every rank makes the same calls on the same full clouds and
+  // works on its spatial tile (a range of the Morton order); the peer path exchanges inside the kernels, the RCCL path between them
+  bool sharded() const { return peer.attached() || comm != nullptr; }
+  int shard_ranks() const { return peer.attached() ? peer.n : (comm ? nranks : 1); }
+  int shard_rank() const { return peer.attached() ? peer.rank : (comm ? rank : 0); }
+  DevBuf gather_stage;  // RCCL route: covariances of the whole cloud in Morton order (ncclAllGather in place)
   hipStream_t side = nullptr;
   hipEvent_t side_done = nullptr;
   bool side_pending = false;       // a build on `side` the main stream has not been ordered after yet
@@ -431,7 +454,7 @@ struct Engine {
     if (peer.region) { (void)hipFree(peer.region); peer.region = nullptr; }
     peer.err.release();
     prof.destroy();
-    lm_trace.release(); fit_best.release(); sort_coop.release(); rbf_sums.release(); bcast.release(); offsets_dev.release(); state.release(); partials.release(); ticket.release(); corr.release(); misc.release(); fit.release(); staging.release(); sort_keys.release(); sort_idx.release(); sort_hist.release();
+    gather_stage.release(); lm_trace.release(); fit_best.release(); sort_coop.release(); rbf_sums.release(); bcast.release(); offsets_dev.release(); state.release(); partials.release(); ticket.release(); corr.release(); misc.release(); fit.release(); staging.release(); sort_keys.release(); sort_idx.release(); sort_hist.release();
     if (pinned) (void)hipHostFree(pinned);
     if (upload_pinned) (void)hipHostFree(upload_pinned);
     if (upload_done) (void)hipEventDestroy(upload_done);
@@ -675,9 +698,10 @@ int ensure_sorted(Engine* e, CloudDev& c) {
 // ---- multi-GPU: this rank's tile of a cloud = the range [lo, hi) of its Morton order (chunks of equal size, rank order) ----
 struct Tile { int lo, hi, chunk; };
 inline Tile peer_tile(const Engine* e, int n) {
-  if (!e->peer.attached()) return Tile{0, n, n};
-  const int chunk = ((n + e->peer.n - 1) / e->peer.n + 63) & ~63;  // whole 64-point tiles of the sorted order
-  const int lo = std::min(n, e->peer.rank * chunk);
+  if (!e->sharded()) return Tile{0, n, n};
+  const int nr = std::max(1, e->shard_ranks());
+  const int chunk = ((n + nr - 1) / nr + 63) & ~63;  // whole 64-point tiles of the sorted order
+  const int lo = std::min(n, e->shard_rank() * chunk);
   return Tile{lo, std::min(n, lo + chunk), std::max(chunk, 1)};
 }
 constexpr unsigned long long PEER_WATCHDOG_TICKS = 200'000'000ull;  // 2 s of the 100 MHz clock: a peer may still be uploading / sorting its copy
@@ -707,6 +731,33 @@ int peer_allgather_cov(Engine* e, CloudDev& c) {
   return FVH_OK;
 }
 
+// The same all-gather on the RCCL route (fvh_vgicp_comm_init): every rank packs the covariances of its tile into its slot of a buffer that
+// holds the whole cloud in Morton order -- tile r is the range [r chunk, (r + 1) chunk) of it --, ncclAllGather fills the other slots in
+// place (32 B per point over xGMI), and one kernel scatters the buffer back to the original point order.
+__global__ __launch_bounds__(256) void scatter_sorted_cov_kernel(const float4* __restrict__ stage, float4* __restrict__ cov, const int* __restrict__ order, int n, int lo, int hi) {
+  const int j = blockIdx.x * 256 + threadIdx.x;
+  if (j >= n || (j >= lo && j < hi)) return;  // (this rank's own tile is already in place)
+  const int i = order[j];
+  cov[2 * (size_t)i] = stage[2 * (size_t)j];
+  cov[2 * (size_t)i + 1] = stage[2 * (size_t)j + 1];
+}
+int rccl_allgather_cov(Engine* e, CloudDev& c) {
+  const Tile t = peer_tile(e, c.n);
+  const int nr = std::max(1, e->shard_ranks());
+  HIP_OR_FAIL(e, e->gather_stage.ensure(sizeof(float4) * 2 * (size_t)t.chunk * nr));
+  float4* stage = e->gather_stage.as<float4>();
+  ProfScope ps(e, "peer_gather");
+  if (t.hi > t.lo)
+    peer_pack_cov_kernel<<<(t.hi - t.lo + 255) / 256, 256, 0, e->stream>>>(c.cov.as<float4>(), c.order.as<int>(), t.lo, t.hi, stage + 2 * (size_t)t.lo);
+  HIP_OR_FAIL(e, hipGetLastError());
+  const int rc = g_rccl.AllGather(stage + 2 * (size_t)e->shard_rank() * t.chunk, stage, (size_t)t.chunk * 8, /*ncclFloat*/ 7, e->comm, e->stream);
+  if (rc != 0) return e->fail(FVH_ERR_COMM, "ncclAllGather failed with code " + std::to_string(rc));
+  scatter_sorted_cov_kernel<<<(c.n + 255) / 256, 256, 0, e->stream>>>(stage, c.cov.as<float4>(), c.order.as<int>(), c.n, t.lo, t.hi);
+  HIP_OR_FAIL(e, hipGetLastError());
+  return FVH_OK;
+}
+inline int allgather_cov(Engine* e, CloudDev& c) { return e->peer.attached() ? peer_allgather_cov(e, c) : rccl_allgather_cov(e, c); }
+
 int find_neighbors(Engine* e, CloudDev& c, int k) {
   if (!c.has_pts) return e->fail(FVH_ERR_BAD_STATE, "find_neighbors: cloud not set");
   if (k <= 0 || k > 64) return e->fail(FVH_ERR_INVALID_ARGUMENT, "find_neighbors: k must be in [1, 64]");
@@ -714,7 +765,7 @@ int find_neighbors(Engine* e, CloudDev& c, int k) {
   HIP_OR_FAIL(e, c.nbr.ensure(sizeof(int) * (size_t)c.n * k));
 #ifdef FVH_TEST_KERNELS  // test build only: FVH_KNN_MODE=0 selects the superseded full LDS-tiled sweep as a cross-check of the culled search
   static const int knn_mode = [] { const char* v = getenv("FVH_KNN_MODE"); return v ? atoi(v) : 1; }();
-  if (knn_mode == 0 && !e->peer.attached()) {
+  if (knn_mode == 0 && !e->sharded()) {
     const int waves = (c.n + KNN_Q - 1) / KNN_Q;
     ProfScope ps(e, "knn");
     knn_bruteforce_kernel<<<(waves + 3) / 4, 256, 0, e->stream>>>(c.pts.as<float4>(), c.n, k, c.nbr.as<int>());
@@ -743,7 +794,7 @@ int find_neighbors(Engine* e, CloudDev& c, int k) {
   HIP_OR_FAIL(e, hipGetLastError());
   c.k = k;
   c.has_nbr = true;
-  c.nbr_tile_only = e->peer.attached();
+  c.nbr_tile_only = e->sharded();
   return FVH_OK;
 }
 
@@ -752,7 +803,7 @@ int calc_cov_knn(Engine* e, CloudDev& c, int method) {
   if (method < 0 || method > 4) return e->fail(FVH_ERR_INVALID_ARGUMENT, "unknown regularization method");
   if (c.k > COV_LANES * COV_MAX_PER_LANE) return e->fail(FVH_ERR_UNSUPPORTED, "calculate_covariances: more than 64 neighbours per point");
   HIP_OR_FAIL(e, c.cov.ensure(sizeof(float4) * 2 * (size_t)std::max(c.n, 1)));
-  const bool sharded = e->peer.attached();
+  const bool sharded = e->sharded();
   if (sharded) { int rc = ensure_sorted(e, c); if (rc) return rc; }
   if (c.n) {
     const Tile t = peer_tile(e, c.n);
@@ -767,7 +818,7 @@ int calc_cov_knn(Engine* e, CloudDev& c, int method) {
     }
   }
   HIP_OR_FAIL(e, hipGetLastError());
-  if (sharded && c.n) { int rc = peer_allgather_cov(e, c); if (rc) return rc; }
+  if (sharded && c.n) { int rc = allgather_cov(e, c); if (rc) return rc; }
   c.has_cov = true;
   return FVH_OK;
 }
@@ -776,7 +827,7 @@ int calc_cov_rbf(Engine* e, CloudDev& c, double kernel_width, double max_dist, i
   if (!c.has_pts) return e->fail(FVH_ERR_BAD_STATE, "calculate_covariances_rbf: cloud not set");
   if (method < 0 || method > 4) return e->fail(FVH_ERR_INVALID_ARGUMENT, "unknown regularization method");
   HIP_OR_FAIL(e, c.cov.ensure(sizeof(float4) * 2 * (size_t)std::max(c.n, 1)));
-  const bool sharded = e->peer.attached();
+  const bool sharded = e->sharded();
   if (c.n) {
     const float md = (float)max_dist;
 #ifdef FVH_TEST_KERNELS  // test build only: FVH_RBF_MODE=0 full sweep, 2: eight queries per wave (both superseded by the one-query-per-wave sweep)
@@ -807,7 +858,7 @@ int calc_cov_rbf(Engine* e, CloudDev& c, double kernel_width, double max_dist, i
     }
   }
   HIP_OR_FAIL(e, hipGetLastError());
-  if (sharded && c.n) { int rc = peer_allgather_cov(e, c); if (rc) return rc; }
+  if (sharded && c.n) { int rc = allgather_cov(e, c); if (rc) return rc; }
   c.has_cov = true;
   return FVH_OK;
 }
@@ -853,7 +904,8 @@ int get_nbr_host(Engine* e, CloudDev& c, int* k, int* out) {
 
 // GaussianVoxelMap::create_voxelmap (gaussian_voxelmap.cu:208-257) -- two kernels, no retry loop
 template <int MODE>
-int build_voxelmap(Engine* e, const CloudDev& c, VoxelMapDev& vm, double res, bool want_compact, bool force_safe = false, hipStream_t on_side = nullptr) {
+int build_voxelmap(Engine* e, const CloudDev& c, VoxelMapDev& vm, double res, bool want_compact, bool force_safe = false, hipStream_t on_side = nullptr,
+                   bool shard = false /* only the voxels of vm.region (already computed on this stream) */) {
   hipStream_t const st = on_side ? on_side : e->stream;
   if (!c.has_pts) return e->fail(FVH_ERR_BAD_STATE, "create_voxelmap: cloud not set");
   if (MODE != 1 && !c.has_cov) return e->fail(FVH_ERR_BAD_STATE, "create_voxelmap: covariances not computed");
@@ -892,7 +944,7 @@ int build_voxelmap(Engine* e, const CloudDev& c, VoxelMapDev& vm, double res, bo
     vm.clean_cap = 0;  // keys[fill] is in use from here on; the finalize pass below makes the OTHER pair clean
     if (c.n) {
       vm_accumulate_kernel<MODE><<<(c.n + 255) / 256, 256, 0, st>>>(c.pts.as<float4>(), c.cov.as<float4>(), c.n, res, keys, cap - 1, vm.acc.as<double>(), counters + 1,
-                                                                           coherent_order(c));
+                                                                           coherent_order(c), shard ? vm.region.as<VmRegion>() : nullptr);
       vm_finalize_kernel<MODE><<<(cap + VM_FIN_THREADS - 1) / VM_FIN_THREADS, VM_FIN_THREADS, 0, st>>>(keys, vm.table.as<uint4>(), cap, vm.acc.as<double>(), counters, vm.occupied.as<int>(),
                                                                         want_compact ? vm.compact_pts.as<float4>() : nullptr, want_compact ? vm.compact_cov.as<float4>() : nullptr,
                                                                         vm.keys[vm.cur].as<unsigned long long>(), vm.counters.as<int>() + 16 * vm.cur);
@@ -902,7 +954,7 @@ int build_voxelmap(Engine* e, const CloudDev& c, VoxelMapDev& vm, double res, bo
       // of this size are built once per localisation run, not once per registration.
       static const int bitmap_min = [] { const char* v = getenv("FVH_BITMAP_MIN_POINTS"); return v ? atoi(v) : 300000; }();
       static const size_t bitmap_bytes = [] { const char* v = getenv("FVH_BITMAP_MAX_BYTES"); return v ? (size_t)atoll(v) : (size_t)(32u << 20); }();
-      if (c.n >= bitmap_min && bitmap_bytes >= 8) {
+      if (c.n >= bitmap_min && bitmap_bytes >= 8 && !shard) {  // (a shard is a fraction of the map: its keys stay cache-resident)
         HIP_OR_FAIL(e, vm.bitmap.ensure(bitmap_bytes));
         HIP_OR_FAIL(e, vm.grid.ensure(sizeof(VmGrid)));
         VmGrid* g = vm.grid.as<VmGrid>();
@@ -922,6 +974,7 @@ int build_voxelmap(Engine* e, const CloudDev& c, VoxelMapDev& vm, double res, bo
     e->side_pending = true;
   }
   vm.valid = true;
+  vm.is_shard = shard;
   e->has_corr = false;
   return FVH_OK;
 }
@@ -1024,7 +1077,7 @@ inline CostShape cost_shape(const Engine* e, const CostSource& src) {
   s.group = (n_off + groups - 1) / groups;
   s.groups_per_src = (n_off + s.group - 1) / s.group;
   s.n_walk = n_expected;
-  if (e->peer.attached() && src.shardable) { const Tile t = peer_tile(e, src.n_upper); s.n_walk = std::max(t.hi - t.lo, 0); }  // multi-GPU: this rank's tile
+  if (e->sharded() && src.shardable) { const Tile t = peer_tile(e, src.n_upper); s.n_walk = std::max(t.hi - t.lo, 0); }  // multi-GPU: this rank's tile
   s.blocks = (int)std::max<long long>(1, std::min<long long>(max_blocks, (s.n_walk * s.groups_per_src + 255) / 256));
   return s;
 }
@@ -1039,6 +1092,7 @@ int launch_cost(Engine* e, const CostSource& src, const VoxelMapDev& vm, int hos
   P.table = vm.table.as<uint4>(); P.keys = vm.keys_cur(); P.mask = vm.capacity - 1; P.res = vm.res; P.inv_res = 1.0 / vm.res;
   P.bitmap = vm.has_bitmap ? vm.bitmap.as<unsigned long long>() : nullptr;
   P.grid = vm.has_bitmap ? vm.grid.as<VmGrid>() : nullptr;
+  P.region = vm.is_shard ? vm.region.as<VmRegion>() : nullptr;
   const int n_off = src.n_off_override > 0 ? src.n_off_override : e->n_off;
   P.offsets = e->offsets_dev.as<int>(); P.offsets_packed = e->offsets_dev.as<int>() + 3 * (size_t)e->n_off; P.n_off = n_off;
   const CostShape shape = cost_shape(e, src);
@@ -1069,12 +1123,13 @@ int launch_cost(Engine* e, const CostSource& src, const VoxelMapDev& vm, int hos
   P.item_lo = 0; P.item_hi = 0;
   P.peer.n = 1; P.peer.rank = 0; P.peer.xbase = 0;
   for (int i = 0; i < FVH_MAX_PEERS; i++) P.peer.region[i] = nullptr;
-  if (MODE == MODE_VGICP && e->peer.attached() && src.shardable) {
-    // multi-GPU: this rank's spatial tile of the source (a range of its Morton order) and the mailboxes of all ranks
+  if (MODE == MODE_VGICP && e->sharded() && src.shardable) {
+    // multi-GPU: this rank's spatial tile of the source (a range of its Morton order) and -- peer route -- the mailboxes of all ranks
+    // (RCCL route: the sums meet between the launches, allreduce_sums)
     const Tile t = peer_tile(e, src.n_upper);
     P.item_lo = t.lo; P.item_hi = std::max(t.hi, 1);  // (item_hi == 0 means "everything")
     if (t.hi <= t.lo) { P.item_lo = 0; P.item_hi = 1; n_walk = 0; P.n_src = 0; } else n_walk = t.hi - t.lo;
-    P.peer = e->peer.view(peer_xbase);
+    if (e->peer.attached()) P.peer = e->peer.view(peer_xbase);
     static const unsigned long long wd = [] { const char* v = getenv("FVH_PEER_WATCHDOG_TICKS"); return v ? strtoull(v, nullptr, 10) : PEER_WATCHDOG_TICKS; }();
     P.peer_watchdog_ticks = wd;
   }
@@ -1094,6 +1149,18 @@ int launch_cost(Engine* e, const CostSource& src, const VoxelMapDev& vm, int hos
   if (P.ng > blocks) P.ng = 1;  // (every group needs its first workgroup)
   P.nb = blocks;
   P.xcd_mask = 0; P.xcd_local = 0;
+  {
+    // Grids of two workgroups per CU (257 .. 512 workgroups: the 17k-point headline has 474): the second workgroup of a CU loses VALU
+    // arbitration to the first (older waves win), finishes its main loop ~2 us later and keeps the whole trip waiting; s_setprio 1 for it
+    // makes the pair finish together: LM launch 136 -> 127 us (profiles/r04_priority_ab.txt). With three workgroups per CU the same
+    // priority costs 7 % (100k x 100k DIRECT27), for everybody at once it changes nothing: only this shape gets it.
+    static const int prio = [] { const char* v = getenv("FVH_COST_PRIO"); return v ? atoi(v) : -1; }();
+    int cus = 256;
+    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, e->device);
+    P.prio_from = cus;
+    const bool confined = plan && plan->mask;
+    P.prio_mode = prio >= 0 ? prio : ((persistent && !confined && blocks > cus && blocks <= 2 * cus) ? 1 : 0);
+  }
   int launch_blocks = blocks;
   if (persistent && plan) {
     P.xcd_mask = plan->mask & 0xFFu;
@@ -1751,7 +1818,7 @@ struct fvh_vgicp {
   double gicp_max_dist = 3.4028234663852886e38;
   CostSource cost_source() const {
     // multi-GPU: the tiles are ranges of the Morton order whatever the size of the cloud (spatially compact shards)
-    const int* order = e.peer.attached() ? (source.has_sorted ? source.order.as<int>() : nullptr) : coherent_order(source);
+    const int* order = e.sharded() ? (source.has_sorted ? source.order.as<int>() : nullptr) : coherent_order(source);
     CostSource c{source.pts.as<float4>(), source.cov.as<float4>(), nullptr, source.n, nullptr, order};
     c.shardable = true;
     return c;
@@ -1763,10 +1830,14 @@ struct fvh_vgicp {
     return c;
   }
   int voxel_mode = 0;        // VoxelAccumulationMode ordinal: 0 ADDITIVE, 1 ADDITIVE_WEIGHTED (same voxel type in the reference), 2 MULTIPLICATIVE
-  int build_map(double res, bool force_safe = false, hipStream_t on_side = nullptr) {
-    return voxel_mode == 2 ? build_voxelmap<2>(&e, target, voxelmap, res, false, force_safe, on_side) : build_voxelmap<0>(&e, target, voxelmap, res, false, force_safe, on_side);
+  // multi-GPU: the target map sharded by the ranks' spatial tiles + halo (fvh_vgicp_set_target_map_sharding)
+  bool shard_map = false;
+  int shard_margin = 2;      // voxels of pose motion the halo allows for on top of the reach of the neighbour offsets
+  int shard_fallbacks = 0;   // aligns redone on the full map because a source element left the shard's inner box
+  int build_map(double res, bool force_safe = false, hipStream_t on_side = nullptr, bool shard = false) {
+    return voxel_mode == 2 ? build_voxelmap<2>(&e, target, voxelmap, res, false, force_safe, on_side, shard) : build_voxelmap<0>(&e, target, voxelmap, res, false, force_safe, on_side, shard);
   }
-  Rebuild rebuild_safe() { return [this] { return build_map(voxelmap.res, true); }; }
+  Rebuild rebuild_safe() { return [this] { return build_map(voxelmap.res, true, nullptr, voxelmap.is_shard); }; }
 };
 
 struct fvh_ndt {
@@ -1861,6 +1932,21 @@ int fvh_vgicp_set_voxel_accumulation_mode(fvh_vgicp* h, int mode) {
   h->voxel_mode = mode;
   return FVH_OK;
 }
+// multi-GPU (with peers attached or a communicator): keep only this rank's shard of the target voxel map (see fvh_vgicp_align)
+int fvh_vgicp_set_target_map_sharding(fvh_vgicp* h, int on, int margin_voxels) {
+  CHECK_HANDLE(h);
+  if (margin_voxels < 0 || margin_voxels > 64) return h->e.fail(FVH_ERR_INVALID_ARGUMENT, "set_target_map_sharding: margin must be within [0, 64] voxels");
+  if ((on != 0) != h->shard_map || margin_voxels != h->shard_margin) { h->voxelmap.invalidate(); h->e.has_corr = false; }
+  h->shard_map = on != 0;
+  h->shard_margin = margin_voxels;
+  return FVH_OK;
+}
+int fvh_vgicp_debug_get_map_shard(fvh_vgicp* h, int* is_shard, int* fallbacks) {
+  CHECK_HANDLE(h);
+  if (is_shard) *is_shard = h->voxelmap.valid && h->voxelmap.is_shard ? 1 : 0;
+  if (fallbacks) *fallbacks = h->shard_fallbacks;
+  return FVH_OK;
+}
 int fvh_vgicp_swap_source_and_target(fvh_vgicp* h) {
   CHECK_HANDLE(h);
   h->source.swap(h->target);
@@ -1935,7 +2021,7 @@ int fvh_vgicp_get_num_correspondences(fvh_vgicp* h, int* n) {
   int rc = fetch_corr(&h->e, h->e.corr_n_src, corr);
   if (rc) return rc;
   int c = 0;
-  if (h->e.peer.attached() && h->e.corr_kind == 0 && h->source.has_sorted && h->e.corr_n_src == h->source.n) {
+  if (h->e.sharded() && h->e.corr_kind == 0 && h->source.has_sorted && h->e.corr_n_src == h->source.n) {
     // multi-GPU: only this rank's tile of the source was evaluated (the other rows of the buffer were never written)
     const Tile t = peer_tile(&h->e, h->source.n);
     std::vector<int> order((size_t)std::max(t.hi - t.lo, 0));
@@ -1976,8 +2062,9 @@ int fvh_vgicp_get_voxel_correspondences(fvh_vgicp* h, int* pairs) {
 int fvh_vgicp_update_correspondences(fvh_vgicp* h, const double* T) {
   CHECK_HANDLE(h);
   if (!h->source.has_pts || !h->source.has_cov) return h->e.fail(FVH_ERR_BAD_STATE, "update_correspondences: source cloud/covariances not set");
-  if (h->e.peer.attached() && h->source.n) { int rc = ensure_sorted(&h->e, h->source); if (rc) return rc; }
+  if (h->e.sharded() && h->source.n) { int rc = ensure_sorted(&h->e, h->source); if (rc) return rc; }
   h->e.corr_kind = 0;
+  if (h->voxelmap.valid && h->voxelmap.is_shard) { int rc = h->build_map(h->resolution); if (rc) return rc; }  // host-driven evaluations use the whole map (a sharded align left its shard behind)
   return do_update_correspondences<MODE_VGICP>(&h->e, h->cost_source(), h->voxelmap, T);
 }
 // ---- FastGICP (nearest target point) on the same handle: fast_gicp_impl.hpp:118-240 ----
@@ -2018,7 +2105,29 @@ int fvh_vgicp_compute_error(fvh_vgicp* h, const double* T, double* H, double* b,
 int fvh_vgicp_align(fvh_vgicp* h, const double* guess, const fvh_lm_params* p, fvh_lm_result* r) {
   CHECK_HANDLE(h);
   if (!h->source.has_pts || !h->source.has_cov) return h->e.fail(FVH_ERR_BAD_STATE, "align: source cloud/covariances not set");
-  if (h->e.peer.attached() && h->source.n) { int rc = ensure_sorted(&h->e, h->source); if (rc) return rc; }
+  if (h->e.sharded() && h->source.n) { int rc = ensure_sorted(&h->e, h->source); if (rc) return rc; }
+  if (h->shard_map && h->e.sharded() && h->e.shard_ranks() > 1 && guess) {
+    // Sharded target map: this rank's map holds the voxels around T_guess * (its tile of the source) only -- the tile's bounding box in
+    // voxel coordinates, widened by the reach of the neighbour offsets + shard_margin voxels of pose motion. Built per align (it depends
+    // on the guess); if a source element leaves the inner box during the LM loop the align is redone on the full map.
+    Engine* e = &h->e;
+    if (!h->target.has_pts || !h->target.has_cov) return e->fail(FVH_ERR_BAD_STATE, "align: target cloud / covariances not set");
+    HIP_OR_FAIL(e, h->voxelmap.region.ensure(sizeof(VmRegion)));
+    int reach = 0;
+    for (int v : e->offsets_host) reach = std::max(reach, std::abs(v));
+    const Tile t = peer_tile(e, h->source.n);
+    vm_region_kernel<<<1, 1024, 0, e->stream>>>(h->source.sorted.as<float4>(), t.lo, t.hi, pose_from_colmajor16(guess), h->resolution, reach + h->shard_margin, reach, h->voxelmap.region.as<VmRegion>());
+    HIP_OR_FAIL(e, hipGetLastError());
+    int rc = h->build_map(h->resolution, false, nullptr, true);
+    if (rc) return rc;
+    rc = do_align<MODE_VGICP>(e, h->cost_source(), h->voxelmap, guess, p, r, h->rebuild_safe());
+    if (rc) return rc;
+    // (the flag travelled with the sums of every evaluation: all ranks hold the same value and fall back together -- the redo is a collective align like any other)
+    if (!reinterpret_cast<const LmState*>(e->pinned)->halo_exceeded) { h->e.quiet = true; return FVH_OK; }
+    h->shard_fallbacks++;
+    rc = h->build_map(h->resolution);
+    if (rc) return rc;
+  }
   const int rc = do_align<MODE_VGICP>(&h->e, h->cost_source(), h->voxelmap, guess, p, r, h->rebuild_safe());
   // the result is on the host: everything this handle queued has run (of a persistent launch only the workgroups' exit remains,
   // and they touch neither clouds nor the map any more)

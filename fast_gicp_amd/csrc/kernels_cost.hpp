@@ -74,7 +74,7 @@ struct LmState {
   int vm_dropped;     // > 0: the hint-sized table overflowed -> host rebuilds at the safe size and re-runs
   int vm_num_voxels2; // the same for the source voxel map (NDT D2D): shapes the grid of the next align of a frame stream
   int delta_converged;  // is_converged(delta) of the step proposed last (computed when the step is proposed, consumed by the next trial)
-  int pad2_;
+  int halo_exceeded;    // sharded target map (VmRegion): some evaluation of this align had a source element outside the shard's inner box (summed over all ranks)
   // LAST 8 bytes are never covered by the state write-back: `aborted` is raised by the persistent kernel's barrier
   // watchdog (the host zeroes the word before the launch and falls back to one launch per transition if it is set)
   unsigned gen, aborted;
@@ -92,6 +92,7 @@ struct CostParams {
   unsigned mask;
   const unsigned long long* bitmap;  // occupancy bitmap of a large map (kernels_voxelmap.hpp: VmGrid) or null: misses answered without touching the key table
   const VmGrid* grid;
+  const VmRegion* region;            // the target map is a rank's shard (kernels_voxelmap.hpp: VmRegion) or null: source elements that leave its inner box raise `exceeded`
   double res, inv_res;        // voxel resolution and its correctly rounded reciprocal (host)
   const int* offsets;         // n_off x 3
   const int* offsets_packed;  // n_off x (dx + 512) | (dy + 512) << 10 | (dz + 512) << 20
@@ -128,6 +129,10 @@ struct CostParams {
   int ng;              // reduction groups: workgroup b belongs to group b % ng (1: single level; 8: one group per XCD)
   int nb;              // persistent kernel with xcd_mask != 0: logical workgroups (the launch is 8 x ceil(nb / popcount(mask)))
   unsigned xcd_mask;   // persistent kernel: != 0 -> only workgroups dispatched to these XCDs (blockIdx & 7) stay; the others exit at once
+  int prio_mode;       // wave priority in the main loop (FVH_COST_PRIO; VERDICT r3 #3a). 0: none; 1: s_setprio 1 for the SECOND workgroup of a CU
+                       // (lb >= 256); 2: the same for its first half only (up to the first probes); 3: for the FIRST workgroup of a CU instead;
+                       // 4: for every workgroup (computing waves outrank the waves that already poll the broadcast on the same SIMDs)
+  int prio_from;       // ... "second" = logical workgroups from this one on (the host passes the number of CUs)
   int xcd_local;       // persistent kernel: every member of a group sits on the group's XCD (checked per workgroup): rows and broadcast
                        // travel through that XCD's L2 (plain stores) instead of write-through + memory-side polls
 };
@@ -312,6 +317,7 @@ __device__ FVH_LM_STEP_ATTR void dev_lm_step_wave(LmState* st, const double* sum
   const int delta_conv_prev = __builtin_amdgcn_readfirstlane(st->delta_converged);
 
   const double s0 = sums[0], s28 = sums[28];
+  if (lane == 0 && sums[30] > 0.0) st->halo_exceeded = 1;  // (sharded target map: a source element left some rank's shard in this evaluation)
 
   bool accepted = false, consume = false, done = false;
   if (phase0 == PH_LINEARIZE) {
@@ -510,7 +516,7 @@ __global__ void lm_init_kernel(LmState* st, PoseD guess, double rot_eps, double 
   st->max_iterations = max_iter; st->lm_max_iterations = lm_max_iter;
   st->lambda = -1.0; st->nu = 2.0; st->y0 = 0.0;
   st->phase = max_iter > 0 ? PH_LINEARIZE : PH_DONE;
-  st->corr_cur = 0; st->x_lin = guess; st->delta_converged = 0;
+  st->corr_cur = 0; st->x_lin = guess; st->delta_converged = 0; st->halo_exceeded = 0;
   st->outer_iter = 0; st->inner_iter = 0; st->converged = 0; st->lm_failed = 0; st->num_linearize = 0; st->num_error_evals = 0; st->nr_iterations = 0;
   for (int i = 0; i < 36; i++) st->final_H[i] = (i % 7 == 0) ? 1.0 : 0.0;
 }
@@ -804,8 +810,13 @@ __global__ FVH_COST_BOUNDS void cost_kernel(CostParams P) {
     const int w = wbase + lane;
     ItemAcc<Real> it = {{0, 0, 0, 0, 0, 0}, {0, 0, 0}, 0};
     Real acc_y = 0;  // fused: trial error with the old ids
+    if (PERSIST && P.prio_mode) {
+      const bool second = lb >= (unsigned)P.prio_from;  // (the dispatcher fills the CUs once before any gets a second workgroup)
+      if (P.prio_mode == 4 || (P.prio_mode == 3 ? !second : second)) __builtin_amdgcn_s_setprio(1);
+    }
     Vec3<Real> q = {0, 0, 0};
     bool any_hit = false;  // an element without correspondences contributes exact zeros (its q may be non-finite: 0 * NaN)
+    bool left_shard = false;  // sharded target map: this element's neighbourhood is not wholly inside the rank's shard
     if (PERSIST) FVH_MT(gen, 0);
     if (w < n_items) {
     const int i0 = P.gps_magic ? (int)__umulhi((unsigned)w, P.gps_magic) : w / P.groups_per_src;  // (a 32-bit division is ~30 instructions)
@@ -877,6 +888,11 @@ __global__ FVH_COST_BOUNDS void cost_kernel(CostParams P) {
         cx = coord_ok ? (int)fx : 0;
         cy = coord_ok ? (int)fy : 0;
         cz = coord_ok ? (int)fz : 0;
+        if (P.region) {  // (kernel argument: uniform) sharded target map: is every voxel this element can reach in the shard?
+          const VmRegion* rg = P.region;
+          asm volatile("" : "+s"(rg));  // re-read per item: six scalars must not live across the main loop
+          left_shard = coord_ok && (cx < rg->inner_lo[0] || cx > rg->inner_hi[0] || cy < rg->inner_lo[1] || cy > rg->inner_hi[1] || cz < rg->inner_lo[2] || cz > rg->inner_hi[2]);
+        }
       }
     }
     // the ids found by THIS launch are linearised at `ev` when fused (R_ev C R_ev^T is formed after the probes, below), at
@@ -934,6 +950,7 @@ __global__ FVH_COST_BOUNDS void cost_kernel(CostParams P) {
         }
       }
       if (PERSIST) FVH_MT(gen, 3);
+      if (PERSIST && P.prio_mode == 2 && lb >= (unsigned)P.prio_from) __builtin_amdgcn_s_setprio(0);
       // ---- fused trip: trial error with the OLD ids while the probes are in flight ----
       if (fused && do_cost) {
 #pragma unroll
@@ -1024,6 +1041,7 @@ __global__ FVH_COST_BOUNDS void cost_kernel(CostParams P) {
       }  // do_cost
     }
     }  // w < n_items
+    if (PERSIST && P.prio_mode) __builtin_amdgcn_s_setprio(0);
     if (!do_cost) continue;  // host-mode PH_FIND_ONLY
     if (PERSIST) FVH_MT(gen, 7);
 
@@ -1046,7 +1064,8 @@ __global__ FVH_COST_BOUNDS void cost_kernel(CostParams P) {
         for (int j = 1; j < NSUM; j++) v[j] = 0.0;
       }
       v[28] = (double)acc_y;
-      v[29] = v[30] = v[31] = 0.0;
+      v[29] = v[31] = 0.0;
+      v[30] = left_shard ? 1.0 : 0.0;  // travels with the sums -- through the workgroup rows, the group rows and the exchange between the ranks -- so that every rank learns it
 #pragma unroll
       for (int j = 0; j < 16; j++) { double a = v[j], b = v[j + 16]; swap_halves<32>(a, b); v[j] = a + b; }
 #pragma unroll
@@ -1155,7 +1174,7 @@ __global__ FVH_COST_BOUNDS void cost_kernel(CostParams P) {
     s_st.rotation_epsilon = P.rotation_epsilon; s_st.transformation_epsilon = P.transformation_epsilon; s_st.lm_init_lambda_factor = P.lm_init_lambda_factor;
     s_st.max_iterations = P.max_iterations; s_st.lm_max_iterations = P.lm_max_iterations;
     s_st.lambda = -1.0; s_st.nu = 2.0; s_st.y0 = 0.0;
-    s_st.phase = PH_LINEARIZE; s_st.corr_cur = 0; s_st.delta_converged = 0;
+    s_st.phase = PH_LINEARIZE; s_st.corr_cur = 0; s_st.delta_converged = 0; s_st.halo_exceeded = 0;
     s_st.outer_iter = 0; s_st.inner_iter = 0; s_st.converged = 0; s_st.lm_failed = 0; s_st.num_linearize = 0; s_st.num_error_evals = 0; s_st.nr_iterations = 0;
     for (int i = 0; i < 36; i++) s_st.final_H[i] = (i % 7 == 0) ? 1.0 : 0.0;
   };

@@ -71,12 +71,53 @@ __global__ __launch_bounds__(256) void vm_clear_kernel(unsigned long long* __res
   if (i < 16) counters[i] = 0;
 }
 
+// ---- target map sharded by the ranks' spatial tiles (multi-GPU) --------------------------------------------------
+// A rank that walks one spatial tile of the source only ever looks up the voxels around T * tile: its map may hold just those -- the
+// voxels of the tile's bounding box (in voxel coordinates, at the initial guess) widened by a halo = the reach of the neighbour offsets +
+// a margin for the motion of the pose during the align. A voxel inside the box receives ALL its points (the box is voxel-aligned), so
+// its record is the replicated map's. The cost kernel reports (in a spare slot of its sums, so that every rank learns it) if a source
+// element ever leaves the inner box -- then some of its neighbours may be missing from the shard -- and the host redoes the align on the
+// full map.
+struct VmRegion {
+  int lo[3], hi[3];              // voxel coordinates this shard holds, inclusive; lo > hi: nothing
+  int inner_lo[3], inner_hi[3];  // base voxels whose whole neighbourhood lies inside
+  int pad[2];
+};
+__global__ __launch_bounds__(1024) void vm_region_kernel(const float4* __restrict__ sorted, int lo, int hi, PoseD T, double res, int halo, int reach, VmRegion* __restrict__ out) {
+  __shared__ int smin[3][16], smax[3][16];
+  int mn[3] = {0x7fffffff, 0x7fffffff, 0x7fffffff}, mx[3] = {-0x7fffffff - 1, -0x7fffffff - 1, -0x7fffffff - 1};
+  for (int j = lo + (int)threadIdx.x; j < hi; j += 1024) {
+    const float4 p = sorted[j];
+    const double q[3] = {T.r[0] * p.x + T.r[1] * p.y + T.r[2] * p.z + T.t[0], T.r[3] * p.x + T.r[4] * p.y + T.r[5] * p.z + T.t[1], T.r[6] * p.x + T.r[7] * p.y + T.r[8] * p.z + T.t[2]};
+    const double f[3] = {floor(q[0] / res - 0.5), floor(q[1] / res - 0.5), floor(q[2] / res - 0.5)};
+    if (!voxel_index_ok(f[0], f[1], f[2])) continue;
+#pragma unroll
+    for (int a = 0; a < 3; a++) { mn[a] = min(mn[a], (int)f[a]); mx[a] = max(mx[a], (int)f[a]); }
+  }
+#pragma unroll
+  for (int a = 0; a < 3; a++) {
+    for (int o = 32; o >= 1; o >>= 1) { mn[a] = min(mn[a], __shfl_xor(mn[a], o)); mx[a] = max(mx[a], __shfl_xor(mx[a], o)); }
+    if ((threadIdx.x & 63) == 0) { smin[a][threadIdx.x >> 6] = mn[a]; smax[a][threadIdx.x >> 6] = mx[a]; }
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int a = 0; a < 3; a++) {
+      int l = smin[a][0], h = smax[a][0];
+      for (int w = 1; w < 16; w++) { l = min(l, smin[a][w]); h = max(h, smax[a][w]); }
+      const bool any = l <= h;
+      out->lo[a] = any ? l - halo : 1; out->hi[a] = any ? h + halo : 0;
+      out->inner_lo[a] = any ? l - halo + reach : 1; out->inner_hi[a] = any ? h + halo - reach : 0;
+    }
+    out->pad[0] = out->pad[1] = 0;
+  }
+}
+
 // MODE 0: VGICP additive (sum of points and of point covariances); MODE 1: NDT (sum of points and p p^T);
 // MODE 2: VGICP multiplicative (MultiplicativeGaussianVoxel::append, fast_vgicp_voxel.hpp:86-94: sum of C^-1 p and of C^-1)
 template <int MODE>
 __global__ __launch_bounds__(256) void vm_accumulate_kernel(const float4* __restrict__ pts, const float4* __restrict__ cov, int n, double res,
                                                             unsigned long long* __restrict__ table_keys, unsigned mask, double* __restrict__ acc,
-                                                            int* __restrict__ dropped, const int* __restrict__ order) {
+                                                            int* __restrict__ dropped, const int* __restrict__ order, const VmRegion* __restrict__ region = nullptr) {
   __shared__ unsigned long long lkey[VM_LDS_SLOTS];
   __shared__ double lacc[VM_LDS_SLOTS * VM_ACC_STRIDE];
   const int tid = threadIdx.x;
@@ -92,7 +133,10 @@ __global__ __launch_bounds__(256) void vm_accumulate_kernel(const float4* __rest
     const double fx = floor((double)p.x / res - 0.5), fy = floor((double)p.y / res - 0.5), fz = floor((double)p.z / res - 0.5);
     const bool ok = voxel_index_ok(fx, fy, fz);
     const int cx = ok ? (int)fx : 0, cy = ok ? (int)fy : 0, cz = ok ? (int)fz : 0;
-    if (!ok) {
+    bool outside = false;  // a sharded map (VmRegion) holds the voxels of its box only: other points are somebody else's
+    if (region && ok) outside = cx < region->lo[0] || cx > region->hi[0] || cy < region->lo[1] || cy > region->hi[1] || cz < region->lo[2] || cz > region->hi[2];
+    if (outside) {
+    } else if (!ok) {
       // non-finite or absurdly far point: it belongs to no voxel. Counted apart from `dropped` (table overflow, which the
       // host answers with a rebuild at the safe size) so that one lidar NaN cannot fail an align.
       atomicAdd(dropped + 1, 1);

@@ -12,9 +12,10 @@ Three ways to run it (ShardedVGICP(collective=...)):
             mailboxes INSIDE the cost kernel (one xGMI hop, 1.4 us measured) -- a sharded align stays ONE persistent
             launch per rank, no RCCL, no numpy round trip.  This module only carries the 64-byte IPC handles between
             the ranks (torch.distributed all_gather_object) -- see attach_peers().
-  "rccl"    (the DEFAULT: `collective=None`) the rank uploads its tile of the source; ncclAllReduce(32 x f64) on the engine
-            stream between the launches of the multi-launch LM route. It stays the default until the peer path has run on
-            distinct GPUs over xGMI (so far it was only exercised with all ranks on one device).
+  "rccl"    (the DEFAULT: `collective=None`) the engine shards internally here too (fvh_vgicp_comm_init): k-NN / covariance estimation on
+            the rank's tile + ncclAllGather of the 32 B / point covariances, ncclAllReduce(32 x f64) on the engine stream between the
+            launches of the multi-launch LM route. It stays the default until the peer path has run on distinct GPUs over xGMI (so far
+            it was only exercised with all ranks on one device).
   "host"    the host-driven `ShardedLsq` below through a caller-supplied all-reduce (torch.distributed gloo on CPU in the
             tests): what the world_size = 2 CPU tests exercise.
 
@@ -195,14 +196,16 @@ class ShardedVGICP:
 
     def set_source(self, full_xyz, k=20, regularization=3):
         full_xyz = np.ascontiguousarray(full_xyz, np.float32)
-        if self.collective == "peer":  # the engine shards internally: same calls on every rank, no host round trip
+        if self.collective in ("peer", "rccl"):
+            # the engine shards internally on both device routes: same calls on the same full cloud on every rank, no host round trip -- k-NN
+            # and covariances on the rank's tile, all-gathered through peer-mapped staging ("peer") or ncclAllGather ("rccl")
             self.core.set_source_cloud(full_xyz)
             self.core.find_source_neighbors(k)
             self.core.calculate_source_covariances(regularization)
             self.tile = None
             return
-        # "rccl" / "host": covariances need neighbours across tile borders, so they are computed on the full cloud and the
-        # rank then keeps only its tile for the cost evaluations
+        # "host": covariances need neighbours across tile borders, so they are computed on the full cloud and the rank then keeps only
+        # its tile for the cost evaluations
         tile = spatial_tile_partition(full_xyz, self.world_size)[self.rank]
         self.core.set_source_cloud(full_xyz)
         self.core.find_source_neighbors(k)

@@ -183,9 +183,12 @@ int fvh_debug_slot_pool(int device, int* reserved, int* active, int* recent);   
  * launches that ended because the dispatcher had not placed the workgroups of a group on one XCD (3 of those switch the flavour off) */
 int fvh_debug_xcd_local(int* wanted, int* placement_aborts);
 
-/* new: multi-GPU (one process per GPU).  Every rank holds a spatial-tile shard of the source
- * cloud and the target voxel map; the 28-value normal-equation block (err, b, upper H) is
- * all-reduced over RCCL on the handle's stream after every cost evaluation. */
+/* new: multi-GPU over RCCL (one process per GPU). With a communicator attached a VGICP handle shards INTERNALLY, like the peer path below:
+ * every rank makes the same calls on the same FULL clouds; neighbour search and covariance estimation run on the rank's spatial tile (a
+ * range of the cloud's Morton order) and the 32 B / point covariances are all-gathered (ncclAllGather); every cost evaluation walks the
+ * rank's tile of the source and the 32-double normal-equation block (err, b, H, trial error) is all-reduced (ncclAllReduce) on the
+ * handle's stream; the LM step then runs redundantly on every rank. The target voxel map is replicated. (NDT handles: the caller hands
+ * each rank its shard of the source; only the all-reduce is the library's.) */
 int fvh_comm_unique_id(void* id128 /* 128 bytes out */);
 int fvh_vgicp_comm_init(fvh_vgicp* h, const void* id128, int nranks, int rank);
 int fvh_vgicp_comm_destroy(fvh_vgicp* h);
@@ -216,6 +219,15 @@ int fvh_vgicp_peer_detach(fvh_vgicp* h);
  *   in its own (the path the in-kernel mailboxes take, over xGMI between devices); FVH_ERR_COMM + the bit mask of the ranks whose
  *   store never came after timeout_seconds (<= 0: 5 s). Call it once after attaching, before the first sharded registration. */
 int fvh_vgicp_peer_selfcheck(fvh_vgicp* h, double timeout_seconds, int* missing_rank_mask /* out, may be NULL */);
+/* Multi-GPU, either exchange (peers attached or a communicator): shard the TARGET voxel map too ("sharded by the same tiles +
+ * halo"). With `on`, fvh_vgicp_align builds this rank's map from the target points around T_guess * (its spatial tile of the source) only:
+ * the tile's bounding box in voxel coordinates, widened by the reach of the neighbour offsets (1 voxel for DIRECT7 / 27, ceil(r) for
+ * DIRECT_RADIUS) + `margin_voxels` for the motion of the pose during the align. A voxel inside the box receives all its points: its record
+ * is the replicated map's. If a source element leaves the inner box during the LM loop (the pose moved further than the margin allows)
+ * the rank redoes that align on the full map. The map is rebuilt per align (it depends on the guess): meant for maps that should not be
+ * replicated, not for speed. The host-driven calls (update_correspondences / compute_error) keep using the replicated map. */
+int fvh_vgicp_set_target_map_sharding(fvh_vgicp* h, int on, int margin_voxels);
+int fvh_vgicp_debug_get_map_shard(fvh_vgicp* h, int* live_map_is_a_shard, int* aligns_redone_on_the_full_map);
 
 /* ---------------------------------------------------------------------------------------------
  * NDTCudaCore

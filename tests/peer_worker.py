@@ -13,6 +13,7 @@ import numpy as np  # noqa: E402
 def main():
     rank, world, port, out = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3]), sys.argv[4]
     n_t, n_s, search, cov = int(sys.argv[5]), int(sys.argv[6]), int(sys.argv[7]), sys.argv[8]
+    shard_map = len(sys.argv) > 9 and sys.argv[9] == "shardmap"
     import torch.distributed as dist
     from fast_gicp_amd import capi, distributed as D, workloads
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -33,9 +34,14 @@ def main():
     cov_t, cov_s = core.get_covariances("target"), core.get_covariances("source")
     e, H, b = core.linearize(np.eye(4))
     ncorr = core.get_num_correspondences()
+    nvox_full = len(core.get_voxelmap()[0])
+    if shard_map:  # the target map sharded by the ranks' tiles + halo (fvh_vgicp_set_target_map_sharding): built per align from here on
+        core.set_target_map_sharding(True, 2)
     r = core.align()
+    nvox = len(core.get_voxelmap()[0])
+    shard_state = core.debug_map_shard()
     r2 = core.align(T)  # a second collective align on the same handles (exchange counters carry on)
-    np.savez(out, cov_t=cov_t, cov_s=cov_s, e=e, H=H, b=b, T=r["T"], Hf=r["H"], converged=r["converged"], nlin=r["num_linearize"], nerr=r["num_error_evals"],
+    np.savez(out, nvox_full=nvox_full, nvox=nvox, is_shard=shard_state[0], fallbacks=core.debug_map_shard()[1], cov_t=cov_t, cov_s=cov_s, e=e, H=H, b=b, T=r["T"], Hf=r["H"], converged=r["converged"], nlin=r["num_linearize"], nerr=r["num_error_evals"],
              launches=r["num_launches"], aborts=core.debug_persist_aborts(), T2=r2["T"], launches2=r2["num_launches"], ncorr=ncorr)
     dist.barrier()
     core.peer_detach()

@@ -93,6 +93,34 @@ def test_sharded_registration_processes_sharing_the_gpu(tmp_path, world, n_t, n_
             assert int(r["launches"]) == 1 and int(r["launches2"]) == 1
 
 
+def test_target_map_sharded_by_tile_and_halo():
+    """"target voxel map sharded by the same tiles + 1-voxel halo". Two ranks (processes sharing the GPU), DIRECT7, each building
+    only the voxels around T_guess * (its tile of the source) + halo: the registration equals the one on the replicated map to 1e-11
+    with equal iteration counts, every rank's shard is smaller than the full map, and no align had to fall back to the full map."""
+    n_t, n_s, search, world = 60000, 40000, 1, 2
+    port = _free_port()
+    outs, procs = [], []
+    import tempfile
+    d = tempfile.mkdtemp()
+    for rank in range(world):
+        out = os.path.join(d, "rank%d.npz" % rank)
+        outs.append(out)
+        procs.append(subprocess.Popen([sys.executable, os.path.join(util.ROOT, "tests", "peer_worker.py"), str(rank), str(world), str(port), out, str(n_t), str(n_s), str(search), "knn", "shardmap"],
+                                      stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    logs = [p.communicate(timeout=240)[0] for p in procs]
+    assert all(p.returncode == 0 for p in procs), "\n".join(logs)
+    res = [np.load(o) for o in outs]
+    ref = _unsharded(n_t, n_s, search, "knn")
+    for r in res:
+        assert bool(r["is_shard"]) and int(r["fallbacks"]) == 0, (r["is_shard"], r["fallbacks"])
+        assert 0 < int(r["nvox"]) < int(r["nvox_full"]), (int(r["nvox"]), int(r["nvox_full"]))
+        assert bool(r["converged"]) and int(r["nlin"]) == ref["r"]["num_linearize"] and int(r["nerr"]) == ref["r"]["num_error_evals"]
+        assert util.rel_err(r["T"], ref["r"]["T"]) < 1e-11 and util.rel_err(r["Hf"], ref["r"]["H"]) < 1e-11
+        assert util.rel_err(r["T2"], ref["r2"]["T"]) < 1e-11
+    assert np.array_equal(res[0]["T"], res[1]["T"])
+    print("voxels per rank:", [int(r["nvox"]) for r in res], "of", int(res[0]["nvox_full"]))
+
+
 def test_sharded_registration_two_handles_one_process():
     """Two ranks as two handles of this process (two host threads): the regions are shared by pointer (IPC cannot map one's
     own allocation). Only one handle of a process may run the persistent kernel at a time, so one rank takes the

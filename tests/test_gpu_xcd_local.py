@@ -63,7 +63,9 @@ def test_local_and_write_through_handoffs_give_the_same_bits(tmp_path, layout):
     assert tuple(a["xcd_local"]) == (1, 0), a["xcd_local"]   # still wanted, no placement abort
     assert tuple(b["xcd_local"]) == (0, 0)
     for k in a.files:
-        if k != "xcd_local":
+        if k.startswith("ndt1"):  # NDT D2D walks the source voxels in the order of the compact list, i.e. of workgroup arrival in the map build:
+            assert util.rel_err(a[k], b[k]) < 1e-12, (layout, k)  # two PROCESSES (two builds) agree to rounding, not to the bit
+        elif k != "xcd_local":
             assert np.array_equal(a[k], b[k]), (layout, k)
     if layout == "2":  # the per-transition route: no persistent launch at all (the launch counts asserted in RUN do not apply -> its own script would be needed);
         return         # it is compared with the persistent route, bit for bit, in tests/test_gpu_parity.py and tests/test_gpu_edge_and_properties.py

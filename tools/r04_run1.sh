@@ -1,8 +1,8 @@
 #!/bin/bash
 # round 4, GPU call 1: the whole GPU suite on the replicated-collector LM kernel + A/B of the hand-off flavours and grid layouts
 export HSA_ENABLE_IPC_MODE_LEGACY=0
-O=gpurun_out/r04a; mkdir -p $O
-./tools/probes/probe_xcc > $O/probe_xcc.txt 2>&1; cat $O/probe_xcc.txt
+O=gpurun_out/r04b; mkdir -p $O
+
 timeout 1200 python -m pytest tests -m gpu -q --maxfail=12 2>&1 | tail -40 > $O/tests.txt
 timeout 300 python tools/ab_bench.py --workload bundled17k --steps 100 --streams 4 default default:FVH_XCD_LOCAL=0 default:FVH_SHARE_BY_XCD=0 > $O/ab17k.txt 2>&1
 timeout 300 python tools/ab_bench.py --workload lidar_stream --steps 60 default:FVH_SMALL_GRID_LAYOUT=0 default:FVH_SMALL_GRID_LAYOUT=1 default:FVH_SMALL_GRID_LAYOUT=2 default:FVH_SMALL_GRID_LAYOUT=2,FVH_XCD_LOCAL=0 > $O/ablidar.txt 2>&1
