@@ -35,7 +35,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 T_START = time.perf_counter()
-PMC_FILE = os.path.join(ROOT, "profiles", "r03_pmc.json")
+PMC_FILE = os.path.join(ROOT, "profiles", "r04_pmc.json")
 # the cpu_baseline legs (oracle, OpenMP): threads next to each other -- they share the voxel map and the kd-tree through the caches
 os.environ.setdefault("OMP_PROC_BIND", "close")
 os.environ.setdefault("OMP_PLACES", "cores")
@@ -107,7 +107,7 @@ _PMC = {}
 
 
 def pmc_entry(key):
-    """(entry, source) of the committed PMC passes of this round (profiles/r03_pmc.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE / SQ group
+    """(entry, source) of the committed PMC passes of this round (profiles/r04_pmc.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE / SQ group
     in separate runs of THIS command, tools/r03_artifacts.sh + tools/pmc_collect.py; FETCH doubled per the gfx950 note of
     MI355X_MICROARCH.md). PMC counters cannot be collected inside a timed run, so the numbers are a committed measurement -- stamped
     with the commit and a hash of fast_gicp_amd/csrc/ they were taken at, and NOT quoted once the kernels have changed."""
@@ -119,10 +119,10 @@ def pmc_entry(key):
         _PMC["_stale"] = _PMC.get("_meta", {}).get("csrc_sha") != csrc_sha()
     meta = _PMC.get("_meta", {})
     if not meta:
-        return None, "no PMC pass committed for this round (profiles/r03_pmc.json)"
+        return None, "no PMC pass committed for this round (profiles/r04_pmc.json)"
     if _PMC["_stale"]:
         return None, "PMC pass of commit %s is older than fast_gicp_amd/csrc/ (hash %s != %s): not quoted" % (meta.get("commit"), meta.get("csrc_sha"), csrc_sha())
-    return _PMC.get(key), "committed PMC pass of commit %s (profiles/r03_pmc.json, csrc hash %s == this tree)" % (meta.get("commit"), meta.get("csrc_sha"))
+    return _PMC.get(key), "committed PMC pass of commit %s (profiles/r04_pmc.json, csrc hash %s == this tree)" % (meta.get("commit"), meta.get("csrc_sha"))
 
 
 def pmc_traffic(key):
@@ -468,6 +468,7 @@ def concurrent_leg(args, local_rank, d_clouds, n_pts, res, search, K):
     for c in cores:
         c.synchronize()
     el = time.perf_counter() - t0
+    aborts_loop = sum(c.debug_persist_aborts() for c in cores)
     # the LM loop alone (clouds, covariances and maps stay): what the persistent kernels of S handles make of the chip between them
     def aligns(c, n):
         for _ in range(n):
@@ -485,10 +486,12 @@ def concurrent_leg(args, local_rank, d_clouds, n_pts, res, search, K):
     for t in threads:
         t.join()
     many = S * na / (time.perf_counter() - t0)
+    aborts = sum(c.debug_persist_aborts() for c in cores)
     for c in cores:
         c.close()
     return {"streams": S, "steps_per_stream": steps, "registrations_per_sec": round(S * steps / el, 3), "note": "independent registrations, not the sequential reference loop",
-            "align_only": {"one_handle_aligns_per_sec": round(one, 1), "all_handles_aligns_per_sec": round(many, 1), "ratio": round(many / one, 3),
+            "persistent_launches_aborted_by_watchdog": aborts_loop, "xcd_local_wanted_and_placement_aborts": list(capi.debug_xcd_local()),
+            "align_only": {"one_handle_aligns_per_sec": round(one, 1), "all_handles_aligns_per_sec": round(many, 1), "ratio": round(many / one, 3), "persistent_launches_aborted_by_watchdog": aborts - aborts_loop,
                            "note": "align() alone on prepared handles: the co-resident workgroup slots are split between the concurrent persistent LM kernels (SlotPool); the full loop "
                                    "above adds each stream's sort / k-NN / covariance kernels, which wait for room beside the resident LM workgroups"}}
 

@@ -401,9 +401,24 @@ struct Engine {
     if (!deferred) return rc;
     auto f = std::move(deferred);
     deferred = nullptr;
-    const int rc2 = f(rc == FVH_OK ? side_stream() : nullptr);
+    int rc2 = f(rc == FVH_OK ? side_stream() : nullptr);
+    if (rc2 != FVH_OK && rc == FVH_OK) {
+      // the build could not be queued beside the source chain (allocation / launch error): once more, in order on the main stream, so
+      // that a failure is at least the build's own and not a side effect of where it was queued; whatever remains is reported as what
+      // it is -- the map build swap_source_and_target() deferred -- by the call that had to run it
+      (void)hipGetLastError();
+      side_pending = false;
+      rc2 = f(nullptr);
+      if (rc2 != FVH_OK) err = "target voxel map build deferred by swap_source_and_target: " + err;
+    }
     return rc ? rc : rc2;
   }
+  // A voxel-grid filter that borrowed this engine's stream (fvh_voxelgrid_share_stream_with_*) queues work the engine does not see:
+  // the stream is then no longer known to be drained
+  Engine* stream_owner = nullptr;
+  // the caller has used this handle's DEVICE neighbour search / fitness / RBF covariances before: uploads queue the Morton sort at once
+  // (a caller that brings its own neighbour lists -- FastVGICPCuda's default host kd-tree -- never consumes it on small clouds)
+  bool device_search_seen = false;
 
   int fail(int code, const std::string& m) { err = m; return code; }
   int hipfail(hipError_t e, const char* what) { err = std::string(what) + ": " + hipGetErrorString(e); return FVH_ERR_HIP; }
@@ -600,6 +615,7 @@ int set_neighbors(Engine* e, CloudDev& c, int k, const int* idx) {
 
 // Morton-sort the cloud (kernels_sort.hpp) and box its 64-point tiles; cached until the cloud changes.
 int ensure_sorted(Engine* e, CloudDev& c) {
+  e->device_search_seen = true;
   if (c.has_sorted) return FVH_OK;
   const int n = c.n;
   static const int items_env = [] { const char* v = getenv("FVH_SORT_ITEMS"); return v ? atoi(v) : 0; }();
@@ -628,7 +644,7 @@ int ensure_sorted(Engine* e, CloudDev& c) {
       unsigned* chist = reinterpret_cast<unsigned*>(cs + 1);
       // once: tags of no launch everywhere (afterwards the finish kernel leaves the state zeroed and every launch rewrites the tagged words)
       if (fresh) HIP_OR_FAIL(e, hipMemsetAsync(cs, 0, COOP_STATE_BYTES, e->stream));
-      if ((++e->sort_seq & 0x7FFFu) == 0) ++e->sort_seq;  // (a 16-bit tag of 0 is what fresh memory holds)
+      if ((++e->sort_seq & (COOP_HTAG_MASK >> 1)) == 0) ++e->sort_seq;  // (a histogram tag of 0 is what fresh memory holds)
       unsigned long long wd = 2'000'000ull;  // 20 ms
       { const char* v = getenv("FVH_SORT_COOP_WATCHDOG_TICKS"); if (v) wd = strtoull(v, nullptr, 10); }  // test hook: 0 forces the fallback
       sort_coop_kernel<<<COOP_WGS, COOP_THREADS, 0, e->stream>>>(c.pts.as<float4>(), n, c.order.as<int>(), c.sorted.as<float4>(), c.bbox.as<float4>(), c.box.as<unsigned>(), chist,
@@ -1178,8 +1194,8 @@ int launch_cost(Engine* e, const CostSource& src, const VoxelMapDev& vm, int hos
   }
   if (persistent) {
     { const char* v = getenv("FVH_PERSIST_WATCHDOG_TICKS"); P.watchdog_ticks = v ? strtoull(v, nullptr, 10) : PERSIST_WATCHDOG_TICKS; }  // test hook: 0 forces the abort + fallback path
-    // multi-GPU: the opener may legitimately wait for a late peer (up to the peer watchdog); the workgroups waiting for the
-    // opener's broadcast must outlast that, or a 50 ms skew between ranks would look like a stuck local barrier
+    // multi-GPU: workgroup 0 may legitimately wait for a late peer (up to the peer watchdog); the collectors waiting for its all-reduced
+    // row and the workgroups waiting for their broadcast must outlast that, or a 50 ms skew between ranks would look like a stuck local barrier
     if (P.peer.n > 1 && P.watchdog_ticks) P.watchdog_ticks = std::max(P.watchdog_ticks, 2 * P.peer_watchdog_ticks);
     static const int zc = [] { const char* v = getenv("FVH_ZEROCOPY_RESULT"); return v ? atoi(v) : 1; }();
     P.result_host = (zc && (!e->prof.on || e->prof.cost_only)) ? e->result_dev : nullptr;  // (full stage profiling drains the stream per call anyway; the two events of level 2 do not need it)
@@ -1720,6 +1736,7 @@ int downsample_approx(Engine* e, DownsampleDev& d, const float* xyz, int n, int 
 }
 
 int downsample(Engine* e, DownsampleDev& d, int method, const float* xyz, int n, int stride, bool on_device, float leaf, int* out_n, bool early = false) {
+  if (e->stream_owner) e->stream_owner->quiet = false;  // work on a borrowed stream: its owner can no longer assume the stream has drained (Engine::quiet)
   if (!out_n) return e->fail(FVH_ERR_INVALID_ARGUMENT, "voxelgrid: null out_n");
   if (method != FVH_VOXELGRID_EXACT && method != FVH_VOXELGRID_APPROXIMATE) return e->fail(FVH_ERR_INVALID_ARGUMENT, "voxelgrid: unknown method");
   if (!(leaf > 0.f)) return e->fail(FVH_ERR_INVALID_ARGUMENT, "voxelgrid: leaf size must be > 0");
@@ -1975,6 +1992,7 @@ static void cloud_replaced(CloudDev& c) { c.has_cov = false; c.has_nbr = false; 
 // with the stream idle in between (kernel trace: 4 us between the pack kernel and the sort).
 static int uploaded(Engine* e, CloudDev& c, int rc) {
   if (rc || c.n == 0) return rc;
+  if (!e->device_search_seen && !e->sharded() && c.n < COHERENT_MIN_POINTS) return FVH_OK;  // nobody may ever need the order: it stays lazy (ensure_sorted where it is consumed)
   return ensure_sorted(e, c);
 }
 int fvh_vgicp_set_source_cloud(fvh_vgicp* h, const float* xyz, int n) { CHECK_HANDLE_SOURCE_CHAIN(h); h->e.has_corr = false; cloud_replaced(h->source); return uploaded(&h->e, h->source, upload_cloud(&h->e, h->source, xyz, n, 3, false)); }
@@ -2502,6 +2520,7 @@ int fvh_voxelgrid_share_stream_with_ndt(fvh_voxelgrid* h, fvh_ndt* other) {
   HIP_OR_FAIL(&h->e, hipStreamSynchronize(h->e.stream));
   if (other && other->e.device != h->e.device) return h->e.fail(FVH_ERR_INVALID_ARGUMENT, "share_stream: the two handles live on different devices");
   h->e.stream = other ? other->e.stream : h->e.owned_stream;  // null: back to the filter's own stream
+  h->e.stream_owner = other ? &other->e : nullptr;
   return FVH_OK;
 }
 int fvh_voxelgrid_share_stream_with_vgicp(fvh_voxelgrid* h, fvh_vgicp* other) {
@@ -2509,6 +2528,7 @@ int fvh_voxelgrid_share_stream_with_vgicp(fvh_voxelgrid* h, fvh_vgicp* other) {
   HIP_OR_FAIL(&h->e, hipStreamSynchronize(h->e.stream));
   if (other && other->e.device != h->e.device) return h->e.fail(FVH_ERR_INVALID_ARGUMENT, "share_stream: the two handles live on different devices");
   h->e.stream = other ? other->e.stream : h->e.owned_stream;
+  h->e.stream_owner = other ? &other->e : nullptr;
   return FVH_OK;
 }
 int fvh_voxelgrid_filter_device_async(fvh_voxelgrid* h, int method, const float* d_xyz, int n, int stride, float leaf, int* out_n) {

@@ -131,7 +131,8 @@ struct CostParams {
   unsigned xcd_mask;   // persistent kernel: != 0 -> only workgroups dispatched to these XCDs (blockIdx & 7) stay; the others exit at once
   int prio_mode;       // wave priority in the main loop (FVH_COST_PRIO; VERDICT r3 #3a). 0: none; 1: s_setprio 1 for the SECOND workgroup of a CU
                        // (lb >= 256); 2: the same for its first half only (up to the first probes); 3: for the FIRST workgroup of a CU instead;
-                       // 4: for every workgroup (computing waves outrank the waves that already poll the broadcast on the same SIMDs)
+                       // 4: for every workgroup (computing waves outrank the waves that already poll the broadcast on the same SIMDs);
+                       // 6: graded -- priority 1 for the second, 2 for the third workgroup of a CU
   int prio_from;       // ... "second" = logical workgroups from this one on (the host passes the number of CUs)
   int xcd_local;       // persistent kernel: every member of a group sits on the group's XCD (checked per workgroup): rows and broadcast
                        // travel through that XCD's L2 (plain stores) instead of write-through + memory-side polls
@@ -609,7 +610,7 @@ constexpr int TICKET_GROUPS = 8;  // two-level reduction: workgroup b belongs to
 #ifndef FVH_SINGLE_LEVEL_MAX
 #define FVH_SINGLE_LEVEL_MAX 128
 #endif
-constexpr int SINGLE_LEVEL_MAX_BLOCKS = FVH_SINGLE_LEVEL_MAX;  // grids up to this size reduce in ONE level (one group): every thread of the reducing workgroup polls <= 16 rows, 8 at a time
+constexpr int SINGLE_LEVEL_MAX_BLOCKS = FVH_SINGLE_LEVEL_MAX;  // grids up to this size MAY reduce in one level (one group: every thread of the reducing workgroup polls <= 16 rows, 8 at a time); the host picks (fvh_capi.hip: default_groups)
 // Everything that crosses workgroups inside the persistent kernel travels as {value, tag} PAIRS: one naturally aligned 16-byte
 // agent-scope (sc1, write-through) store per lane, polled with 16-byte sc1 loads. The tag names (launch, trip), so a pair is its
 // own arrival signal -- no counter, no fence, no "wait for the store, then raise a flag" (MI355X_MICROARCH.md: data-tagged
@@ -691,7 +692,7 @@ __device__ __forceinline__ void swap_halves(double& a, double& b) {
 // (slot 0 = earliest workgroup start of the launch, slot 9 = the last workgroup's own start). Read with
 // fvh_debug_cost_timing(); tools/cost_timing.py prints the breakdown.
 __device__ unsigned long long g_cost_timing[16];
-__device__ unsigned long long g_ptime[16][512][12];  // persistent kernel, per trip and workgroup: {start, main end, arrival, open (opener only), seen, LM done}; plain stores, no shared address
+__device__ unsigned long long g_ptime[16][512][12];  // persistent kernel, per trip and workgroup: {start, main end, row published, broadcast issued (collectors), broadcast seen, group row published, collector holds all sums, ... LM done}; plain stores, no shared address
 #define FVH_STAMP(i) do { if (threadIdx.x == 0) stamp[i] = wall_clock64(); } while (0)
 #define FVH_PT_MIN(trip, k) do { if (threadIdx.x == 0 && (trip) < 16 && lb < 512) g_ptime[trip][lb][k] = wall_clock64(); } while (0)
 #define FVH_PT_MAX(trip, k) FVH_PT_MIN(trip, k)
@@ -812,7 +813,9 @@ __global__ FVH_COST_BOUNDS void cost_kernel(CostParams P) {
     Real acc_y = 0;  // fused: trial error with the old ids
     if (PERSIST && P.prio_mode) {
       const bool second = lb >= (unsigned)P.prio_from;  // (the dispatcher fills the CUs once before any gets a second workgroup)
-      if (P.prio_mode == 4 || (P.prio_mode == 3 ? !second : second)) __builtin_amdgcn_s_setprio(1);
+      if (P.prio_mode == 6) {  // graded: the younger a workgroup of its CU, the higher its priority (three workgroups per CU)
+        if (lb >= 2u * (unsigned)P.prio_from) __builtin_amdgcn_s_setprio(2); else if (second) __builtin_amdgcn_s_setprio(1);
+      } else if (P.prio_mode == 4 || (P.prio_mode == 3 ? !second : second)) __builtin_amdgcn_s_setprio(1);
     }
     Vec3<Real> q = {0, 0, 0};
     bool any_hit = false;  // an element without correspondences contributes exact zeros (its q may be non-finite: 0 * NaN)
@@ -1108,7 +1111,7 @@ __global__ FVH_COST_BOUNDS void cost_kernel(CostParams P) {
   // into one group row; the group rows are summed in group order. Grids of <= 64 workgroups are ONE group: a single level.
   // The per-transition kernel finds "the last arriver" with atomic tickets; the persistent kernel has no tickets at all
   // (designated collectors poll tagged rows, below). Both take the SAME summation order: bit-identical sums on both routes.
-  const unsigned NG = (unsigned)P.ng;  // (host: 1 for grids of <= SINGLE_LEVEL_MAX_BLOCKS workgroups and for single-XCD launches, else 8)
+  const unsigned NG = (unsigned)P.ng;  // (host, default_groups(): 8 = one group per XCD, 1 for tiny grids and launches confined to one XCD)
   const unsigned grp = lb % NG;
   const unsigned ngroups = NG;
   const unsigned gsize = (nb - grp + NG - 1) / NG;

@@ -88,7 +88,11 @@ __global__ void peer_check_wait_kernel(PeerView pv, unsigned long long nonce, un
   if ((int)threadIdx.x < pv.n) {
     const unsigned long long* slot = reinterpret_cast<const unsigned long long*>(peer_region(pv, pv.rank) + PEER_CHECK_OFFSET) + threadIdx.x;
     const unsigned long long t0 = wall_clock64();
-    while (__hip_atomic_load(slot, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) != nonce) {
+    // the slot is a monotonic generation (a fixed prefix + the number of self-checks so far): a rank that is already one round ahead
+    // has overwritten it with a LARGER value of the same prefix -- that is still "its store reached us"
+    for (;;) {
+      const unsigned long long v = __hip_atomic_load(slot, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM);
+      if ((v >> 32) == (nonce >> 32) && v >= nonce) break;
       if (wall_clock64() - t0 > watchdog) { atomicOr(missing, 1u << threadIdx.x); break; }
       __builtin_amdgcn_s_sleep(8);
     }

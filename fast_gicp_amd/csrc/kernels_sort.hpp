@@ -457,7 +457,7 @@ template <typename T> __device__ __forceinline__ void st_agent(T* p, T v) { __hi
 template <typename T> __device__ __forceinline__ T ld_agent(const T* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }     // bypasses the non-coherent L2
 
 // Hand-offs between workgroups carry their own arrival signal (round 3, as in the LM kernel): a histogram entry is
-// {count:16, tag:16}, a scattered element {tag:31, key:18, index:15} in ONE 64-bit word, an entry of the final order {tag:32,
+// {count:11, tag:21}, a scattered element {tag:31, key:18, index:15} in ONE 64-bit word, an entry of the final order {tag:32,
 // index:32} -- tag = this launch's sequence number (+ the pass). A consumer polls the words it needs with L2-bypassing loads
 // until their tags are current; nobody waits for anybody else: no arrival counter, no "wait for my stores, add 1, poll the
 // counter" (four grid barriers of ~3 us each in the first version of this kernel). Buffers are zeroed
@@ -472,6 +472,9 @@ template <typename T> __device__ __forceinline__ T ld_agent(const T* p) { return
 #define FVH_COOP_FIRST_SLEEP 32
 #endif
 constexpr int COOP_MATRIX_WORDS = 2 * SMALL_BINS * COOP_WGS;                                    // u32 {count, tag}
+constexpr int COOP_HTAG_BITS = 21;
+constexpr unsigned COOP_HTAG_MASK = (1u << COOP_HTAG_BITS) - 1u;
+static_assert(COOP_THREADS * COOP_STEPS < (1 << (32 - COOP_HTAG_BITS)), "a workgroup's count of one bin must fit the bits above the tag");
 constexpr size_t COOP_ELEM_OFFSET = sizeof(SortCoopState) + sizeof(unsigned) * COOP_MATRIX_WORDS;  // u64 x SORT_SMALL_MAX: pass-0 output
 constexpr size_t COOP_FIN_OFFSET = COOP_ELEM_OFFSET + sizeof(unsigned long long) * SORT_SMALL_MAX;  // u64 x SORT_SMALL_MAX: final order
 constexpr size_t COOP_STATE_BYTES = COOP_FIN_OFFSET + sizeof(unsigned long long) * SORT_SMALL_MAX;
@@ -529,7 +532,9 @@ __global__ __launch_bounds__(COOP_THREADS) void sort_coop_kernel(const float4* _
   for (int pass = 0; pass < SMALL_PASSES; pass++) {
     const int shift = pass * SMALL_BITS;
     unsigned* gh = hist + (size_t)pass * SMALL_BINS * COOP_WGS;
-    const unsigned htag = ((seq << 1) | (unsigned)pass) & 0xFFFFu;
+    // {count:11, tag:21}: a workgroup holds at most 1,024 keys, so 11 bits carry its count and the tag wraps every 2^20 sorts of an engine
+    // (16 tag bits wrapped every 32,768: a word a watchdog-aborted launch never rewrote could have matched a later launch)
+    const unsigned htag = ((seq << 1) | (unsigned)pass) & COOP_HTAG_MASK;
     int failed = 0;
     if (pass > 0) {  // this wave's chunk in the order pass 0 produced: poll until every element of the chunk has landed
       if (FVH_COOP_FIRST_SLEEP) __builtin_amdgcn_s_sleep(FVH_COOP_FIRST_SLEEP);
@@ -559,7 +564,7 @@ __global__ __launch_bounds__(COOP_THREADS) void sort_coop_kernel(const float4* _
       unsigned run = 0;
 #pragma unroll
       for (int w = 0; w < COOP_WAVES; w++) { const unsigned c = wh[w][tid]; wh[w][tid] = run; run += c; }
-      st_agent(&gh[(size_t)tid * COOP_WGS + wg], (run << 16) | htag);
+      st_agent(&gh[(size_t)tid * COOP_WGS + wg], (run << COOP_HTAG_BITS) | htag);
     }
     {  // thread = bin: total over all workgroups and the part before this workgroup (polled until all 32 entries are current); then the bins are scanned
       const unsigned long long* row = reinterpret_cast<const unsigned long long*>(gh + (size_t)tid * COOP_WGS);
@@ -570,7 +575,7 @@ __global__ __launch_bounds__(COOP_THREADS) void sort_coop_kernel(const float4* _
         for (int j = 0; j < COOP_WGS / 2; j++) v[j] = ld_agent(&row[j]);  // independent loads, one round trip
         unsigned bad = 0;
 #pragma unroll
-        for (int j = 0; j < COOP_WGS / 2; j++) bad |= (((unsigned)v[j] & 0xFFFFu) ^ htag) | (((unsigned)(v[j] >> 32) & 0xFFFFu) ^ htag);
+        for (int j = 0; j < COOP_WGS / 2; j++) bad |= (((unsigned)v[j] & COOP_HTAG_MASK) ^ htag) | (((unsigned)(v[j] >> 32) & COOP_HTAG_MASK) ^ htag);
         if (!bad) break;
         if (coop_timed_out(st, t_start, watchdog_ticks)) { failed = 1; break; }
         __builtin_amdgcn_s_sleep(FVH_COOP_POLL_SLEEP);
@@ -578,7 +583,7 @@ __global__ __launch_bounds__(COOP_THREADS) void sort_coop_kernel(const float4* _
       unsigned total = 0, before = 0;
 #pragma unroll
       for (int j = 0; j < COOP_WGS / 2; j++) {
-        const unsigned a = (unsigned)v[j] >> 16, b = (unsigned)(v[j] >> 48);
+        const unsigned a = (unsigned)v[j] >> COOP_HTAG_BITS, b = (unsigned)(v[j] >> (32 + COOP_HTAG_BITS));
         total += a + b;
         before += ((2 * j < wg) ? a : 0u) + ((2 * j + 1 < wg) ? b : 0u);
       }
