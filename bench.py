@@ -436,6 +436,13 @@ def concurrent_leg(args, local_rank, d_clouds, n_pts, res, search, K):
     import threading
     from fast_gicp_amd import capi
     S, steps = args.streams, max(20, args.steps // 2)
+    # The oracle's OpenMP runtime (cpu_baseline, OMP_PROC_BIND=close) binds the thread that opened its parallel regions -- this one -- to
+    # its first place, and threads started from here inherit that mask: all S host threads would spin on ONE core (round 3's x1.03 at four
+    # streams was mostly this). Give the process its CPUs back before starting them.
+    try:
+        os.sched_setaffinity(0, range(os.cpu_count() or 1))
+    except (AttributeError, OSError):
+        pass
     cores = []
     for _ in range(S):
         c = capi.VGICPCore(local_rank)
