@@ -496,9 +496,18 @@ def concurrent_leg(args, local_rank, d_clouds, n_pts, res, search, K):
     aborts = sum(c.debug_persist_aborts() for c in cores)
     for c in cores:
         c.close()
+    # ... and the same align-only measurement in a process of its own (no torch context, fresh CPU mask): fast_gicp_amd/concurrency_probe.py
+    clean = None
+    try:
+        import subprocess
+        p = subprocess.run([sys.executable, "-m", "fast_gicp_amd.concurrency_probe", "1", str(S)], capture_output=True, text=True, timeout=120, cwd=ROOT)
+        line = [l for l in p.stdout.splitlines() if l.startswith("{")]
+        clean = json.loads(line[-1]) if line else {"error": p.stderr[-300:]}
+    except Exception as ex:  # noqa: BLE001
+        clean = {"error": repr(ex)}
     return {"streams": S, "steps_per_stream": steps, "registrations_per_sec": round(S * steps / el, 3), "note": "independent registrations, not the sequential reference loop",
             "persistent_launches_aborted_by_watchdog": aborts_loop, "xcd_local_wanted_and_placement_aborts": list(capi.debug_xcd_local()),
-            "align_only": {"one_handle_aligns_per_sec": round(one, 1), "all_handles_aligns_per_sec": round(many, 1), "ratio": round(many / one, 3), "persistent_launches_aborted_by_watchdog": aborts - aborts_loop,
+            "align_only": {"one_handle_aligns_per_sec": round(one, 1), "all_handles_aligns_per_sec": round(many, 1), "ratio": round(many / one, 3), "persistent_launches_aborted_by_watchdog": aborts - aborts_loop, "in_a_process_without_torch": clean,
                            "note": "align() alone on prepared handles: the co-resident workgroup slots are split between the concurrent persistent LM kernels (SlotPool); the full loop "
                                    "above adds each stream's sort / k-NN / covariance kernels, which wait for room beside the resident LM workgroups"}}
 

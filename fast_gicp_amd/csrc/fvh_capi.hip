@@ -1340,9 +1340,12 @@ int do_align(Engine* e, const CostSource& src, VoxelMapDev& vm, const double* gu
       volatile unsigned long long* seq = reinterpret_cast<volatile unsigned long long*>(e->result_host) + sizeof(LmState) / 8;
       static const bool block = [] { const char* v = getenv("FVH_HOST_WAIT"); return v && std::string(v) == "block"; }();  // FVH_HOST_WAIT=block: sleep in hipStreamSynchronize instead of spinning a core on the result word
       if (block) (void)hipStreamSynchronize(e->stream);
+      // (the stream is only asked now and then -- it answers "drained" when a launch ended without its result word, i.e. aborted: every query
+      // takes the runtime's lock, which concurrent aligns of other host threads also need for their launches)
+      static const unsigned long long query_mask = [] { const char* v = getenv("FVH_RESULT_QUERY_SPINS"); unsigned long long n = v ? strtoull(v, nullptr, 10) : 1024ull; unsigned long long m = 1; while (m < n) m <<= 1; return m - 1; }();
       for (unsigned long long spins = 0;; spins++) {
         if (*seq == e->persist_seq) { have_result = true; break; }
-        if ((spins & 0x3ff) == 0x3ff && hipStreamQuery(e->stream) != hipErrorNotReady) { have_result = (*seq == e->persist_seq); break; }  // drained (or failed: the copy below reports it)
+        if ((spins & query_mask) == query_mask && hipStreamQuery(e->stream) != hipErrorNotReady) { have_result = (*seq == e->persist_seq); break; }  // drained (or failed: the copy below reports it)
       }
       if (have_result) {
         std::atomic_thread_fence(std::memory_order_acquire);

@@ -15,6 +15,18 @@ sys.path.insert(0, ROOT)
 
 def child():
     import numpy as np
+    if os.environ.get("CONC_IMPORT_TORCH") == "1":  # does a process that also holds torch's HIP context behave differently? (bench.py does)
+        import torch
+        torch.cuda.init(); torch.zeros(1, device="cuda")
+    if os.environ.get("CONC_OMP_FIRST") == "1":     # ... or one whose main thread ran an OpenMP region of the oracle first (bench.py's cpu_baseline)?
+        os.environ.setdefault("OMP_PROC_BIND", "close"); os.environ.setdefault("OMP_PLACES", "cores")
+        from oracle import oracle as O
+        from fast_gicp_amd import preprocess as pp
+        t, s_ = pp.bundled_pair(os.path.join(ROOT, "data"))
+        O.covariances_knn(t, 20, O.PLANE, threads=16)
+        if os.environ.get("CONC_RESET_AFFINITY") == "1":
+            os.sched_setaffinity(0, range(os.cpu_count()))
+        print("  affinity of the main thread: %d CPUs" % len(os.sched_getaffinity(0)), flush=True)
     from fast_gicp_amd import capi, preprocess
     tgt, src = preprocess.bundled_pair(os.path.join(ROOT, "data"))
     S_max, steps = 8, 60
