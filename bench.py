@@ -304,6 +304,27 @@ def sharded_headline(args, dist, rank, world, local_rank, dev, small=False):
         n_launch += r["num_launches"]
     barrier()
     elapsed = max_over_ranks(time.perf_counter() - t0)
+    # roofline of the dominant kernel (this rank's cost launches, HIP events on the engine's stream), on a few more steps outside the timed region
+    roofline = None
+    try:
+        c.profile_reset(); c.profile_enable(2)
+        ne = 0
+        for _ in range(5):
+            rr = step()
+            ne += rr["num_linearize"] + rr["num_error_evals"]
+        c.profile_enable(0)
+        cost_ms, cost_n = c.profile_get("cost")
+        n_tile = -(-n_s // world)
+        n_c = c.get_num_correspondences()  # (sharded: the pairs of this rank's tile)
+        bytes_eval = n_tile * 48 + n_tile * 7 * 16 + n_c * 52 + 172
+        if cost_n:
+            achieved = ne * bytes_eval / (cost_ms * 1e-3) / 1e9
+            roofline = {"kernel": "cost_kernel<double,VGICP,%s> on this rank's tile (1 / %d of the scan)" % ("persistent" if cost_n == 5 else "per-transition", world), "bound": "hbm",
+                        "achieved": round(achieved, 2), "peak": 8000.0, "unit": "GB/s", "frac": round(achieved / 8000.0, 5), "traffic": None,
+                        "algorithmic_bytes_per_evaluation": bytes_eval, "evaluations": ne, "launches": cost_n, "avg_launch_us": round(cost_ms / cost_n * 1e3, 3),
+                        "note": "rank 0; SURVEY 8(d) B_eval over the tile; no PMC pass exists for the sharded launches (traffic null)"}
+    except Exception as ex:  # noqa: BLE001
+        roofline = {"error": repr(ex)}
     out = {
         "metric": "registrations/sec (one registration stream, every registration sharded over the GPUs by spatial tile; BASELINE configs[4])",
         "value": round(steps / elapsed, 3), "unit": "registrations/sec", "n_gpus": world, "steps": steps, "warmup": warmup, "ms_per_step": round(elapsed / steps * 1e3, 5),
@@ -318,7 +339,8 @@ def sharded_headline(args, dist, rank, world, local_rank, dev, small=False):
         "speedup_vs_one_gpu": round(ms1 / (elapsed / steps * 1e3), 3),
         "per_registration": {"cost_evaluations": n_eval / steps, "kernel_launches_lm": n_launch / steps, "converged": bool(r["converged"]),
                              "pose_equals_single_gpu": bool(np.abs(r["T"] - r1["T"]).max() < 1e-9), "max_abs_pose_difference": float(np.abs(r["T"] - r1["T"]).max())},
-        "attach_ms": round(attach_ms, 2),
+        "attach_ms": round(attach_ms, 2), "roofline": roofline,
+        "cpu_baseline": None,  # (N = 1 only: the N = 1 line carries it)
     }
     dist.barrier()
     if route == "peer":
