@@ -1681,10 +1681,11 @@ int downsample_approx(Engine* e, DownsampleDev& d, const float* xyz, int n, int 
     d_xyz = e->staging.as<float>();
   }
   const int nwaves = (n + AVG_ITEMS - 1) / AVG_ITEMS, nwords = (n + 31) / 32, nblocks = (nwords + 31) / 32;
-  HIP_OR_FAIL(e, d.keys.ensure(sizeof(unsigned) * ((size_t)AVG_SLOTS * nwaves + AVG_SLOTS)));  // slot x wave histogram + slot totals
+  const int wblocks = (nwaves + 3) / 4;
+  HIP_OR_FAIL(e, d.keys.ensure(sizeof(unsigned) * ((size_t)AVG_SLOTS * nwaves + AVG_SLOTS + (size_t)AVG_SLOTS * wblocks)));  // slot x wave histogram + slot totals + per-workgroup histograms (fused chain)
   HIP_OR_FAIL(e, d.idx.ensure(sizeof(float4) * (size_t)n));                                     // the points in slot order
   HIP_OR_FAIL(e, d.head.ensure((size_t)n));                                                     // run heads (bytes)
-  HIP_OR_FAIL(e, d.trig.ensure(sizeof(unsigned) * (size_t)nwords));                             // trigger bits by original index
+  HIP_OR_FAIL(e, d.trig.ensure(sizeof(unsigned) * (size_t)nblocks * 32));                       // trigger bits by original index (whole blocks of 32 words)
   HIP_OR_FAIL(e, d.scan.ensure(sizeof(unsigned) * (size_t)(nblocks + 1)));                      // trigger prefix per 1024 indices
   HIP_OR_FAIL(e, d.out.ensure(sizeof(float) * 3 * (size_t)n));
   const bool fresh = d.slots.p == nullptr;
@@ -1692,6 +1693,11 @@ int downsample_approx(Engine* e, DownsampleDev& d, const float* xyz, int n, int 
   if (fresh) HIP_OR_FAIL(e, hipMemsetAsync(d.slots.p, 0, sizeof(AvgState), e->stream));  // (the ticket re-arms itself afterwards)
   unsigned* hist = d.keys.as<unsigned>();
   unsigned* totals = hist + (size_t)AVG_SLOTS * nwaves;
+  unsigned* hist_wg = totals + AVG_SLOTS;
+  // up to AVG_FUSED_MAX_POINTS points: four launches -- the scatter and the emit kernel recompute the two small prefix sums themselves
+  // (kernels_downsample.hpp); FVH_AVG_FUSED=0 keeps round 2's six for A/B runs
+  static const bool fused_on = [] { const char* v = getenv("FVH_AVG_FUSED"); return !v || atoi(v) != 0; }();
+  const bool fused = fused_on && n <= AVG_FUSED_MAX_POINTS;
   float4* sorted = d.idx.as<float4>();
   unsigned char* head = d.head.as<unsigned char>();
   AvgState* st = d.slots.as<AvgState>();
@@ -1700,15 +1706,23 @@ int downsample_approx(Engine* e, DownsampleDev& d, const float* xyz, int n, int 
   volatile unsigned long long* hres = reinterpret_cast<volatile unsigned long long*>(e->result_host);
   {
     ProfScope ps(e, "downsample");
-    const int wblocks = (nwaves + 3) / 4, pblocks = (n + 255) / 256;
-    avg_keys_hist_kernel<<<wblocks, 256, 0, e->stream>>>(d_xyz, n, stride, inv, nwaves, hist, d.trig.as<unsigned>(), nwords, st);
-    avg_binscan_kernel<<<AVG_SLOTS / 4, 256, 0, e->stream>>>(hist, nwaves, totals, st);
-    avg_scatter_kernel<<<wblocks, 256, 0, e->stream>>>(d_xyz, n, stride, inv, nwaves, hist, st, sorted);
-    avg_mark_kernel<<<pblocks, 256, 0, e->stream>>>(sorted, n, inv, head, d.trig.as<unsigned>(), st);
-    // early: the count travels to the host from the scan kernel and the call returns while the emit kernel runs (same-stream consumers only)
+    const int pblocks = (n + 255) / 256;
+    // early: the count travels to the host before the centroids exist and the call returns while the emit kernel runs (same-stream consumers only)
     early = early && on_device && e->result_dev && !e->prof.on;
-    avg_scan_kernel<<<1, 1024, 0, e->stream>>>(d.trig.as<unsigned>(), nwords, d.scan.as<unsigned>(), st, early ? e->result_dev : nullptr, seq);
-    avg_emit_kernel<<<pblocks, 256, 0, e->stream>>>(sorted, head, n, inv, d.trig.as<unsigned>(), d.scan.as<unsigned>(), st, d.out.as<float>(), (e->prof.on || early) ? nullptr : e->result_dev, seq);
+    unsigned long long* final_result = (e->prof.on || early) ? nullptr : e->result_dev;
+    if (fused) {
+      avg_keys_hist_kernel<<<wblocks, 256, 0, e->stream>>>(d_xyz, n, stride, inv, nwaves, hist, d.trig.as<unsigned>(), nwords, st, hist_wg);
+      avg_scatter_kernel<<<wblocks, 256, 0, e->stream>>>(d_xyz, n, stride, inv, nwaves, hist, st, sorted, hist_wg);
+      avg_mark_kernel<<<pblocks, 256, 0, e->stream>>>(sorted, n, inv, head, d.trig.as<unsigned>(), st);
+      avg_emit_kernel<<<pblocks, 256, 0, e->stream>>>(sorted, head, n, inv, d.trig.as<unsigned>(), nullptr, st, d.out.as<float>(), final_result, seq, nwords, early ? e->result_dev : nullptr);
+    } else {
+      avg_keys_hist_kernel<<<wblocks, 256, 0, e->stream>>>(d_xyz, n, stride, inv, nwaves, hist, d.trig.as<unsigned>(), nwords, st);
+      avg_binscan_kernel<<<AVG_SLOTS / 4, 256, 0, e->stream>>>(hist, nwaves, totals, st);
+      avg_scatter_kernel<<<wblocks, 256, 0, e->stream>>>(d_xyz, n, stride, inv, nwaves, hist, st, sorted);
+      avg_mark_kernel<<<pblocks, 256, 0, e->stream>>>(sorted, n, inv, head, d.trig.as<unsigned>(), st);
+      avg_scan_kernel<<<1, 1024, 0, e->stream>>>(d.trig.as<unsigned>(), nwords, d.scan.as<unsigned>(), st, early ? e->result_dev : nullptr, seq);
+      avg_emit_kernel<<<pblocks, 256, 0, e->stream>>>(sorted, head, n, inv, d.trig.as<unsigned>(), d.scan.as<unsigned>(), st, d.out.as<float>(), final_result, seq);
+    }
   }
   HIP_OR_FAIL(e, hipGetLastError());
   unsigned long long count = 0, bad = 0;

@@ -197,7 +197,10 @@ __global__ __launch_bounds__(256) void vg_emit_kernel(const unsigned* __restrict
 //                    point among all triggers (block prefix + popcounts), or behind them in slot order for the final flushes
 // Output points and order are bit-identical to the oracle's restatement of the PCL filter (tests/test_gpu_downsample.py).
 // =====================================================================================================================
-constexpr int AVG_ITEMS = 256;  // points per wave in the counting sort
+#ifndef FVH_AVG_ITEMS
+#define FVH_AVG_ITEMS 512
+#endif
+constexpr int AVG_ITEMS = FVH_AVG_ITEMS;  // points per wave in the counting sort (512: the fused chain's scatter re-reads one histogram row per WORKGROUP of the sort -- 58 rows at 118k points instead of 116; measured 256 / 512 / 1024: chain 43.4 / 40.4 / 44.7 us)
 
 struct AvgState {            // small device state, cleared by avg_keys_hist for the NEXT stages of the same call
   unsigned slot_used[AVG_SLOTS];
@@ -212,32 +215,57 @@ __device__ __forceinline__ float4 load_xyz(const float* __restrict__ xyz, int i,
   return make_float4(q[0], q[1], q[2], 0.f);
 }
 
-__global__ __launch_bounds__(256) void avg_keys_hist_kernel(const float* __restrict__ xyz, int n, int stride, float inv, int nwaves, unsigned* __restrict__ hist /* [slots][nwaves] */,
-                                                            unsigned* __restrict__ trigbits, int nwords, AvgState* __restrict__ st) {
+// Frames of up to AVG_FUSED_MAX_POINTS points (a LiDAR frame is 118k) take a FOUR-launch chain: the slot x wave prefix of the counting sort
+// and the prefix of the trigger bits are small enough to be recomputed by every workgroup that needs them (from 237 KB of per-workgroup
+// histograms, 15 KB of trigger words), which removes the two scan launches -- each a global dependency of ~5-9 us for ~1 us of work --
+// without any in-kernel hand-off (round 2's six launches: 47 us per 118k-point frame). Larger inputs keep the scan kernels.
+constexpr int AVG_ROUNDS = AVG_ITEMS / 64;
+constexpr int AVG_FUSED_MAX_POINTS = 262144;
+constexpr int AVG_FUSED_MAX_WGS = AVG_FUSED_MAX_POINTS / (4 * AVG_ITEMS);      // workgroups of the counting sort (4 waves x 256 points)
+constexpr int AVG_FUSED_MAX_BLOCKS = AVG_FUSED_MAX_POINTS / 1024;              // trigger-bit blocks of 1,024 indices
+
+__global__ __launch_bounds__(256) void avg_keys_hist_kernel(const float* __restrict__ xyz, int n, int stride, float inv, int nwaves, unsigned* __restrict__ hist /* [slots][nwaves], or (fused) [nwaves][slots] */,
+                                                            unsigned* __restrict__ trigbits, int nwords, AvgState* __restrict__ st, unsigned* __restrict__ hist_wg = nullptr /* fused chain: [workgroups][slots] */) {
   __shared__ unsigned h[4][AVG_SLOTS];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int wave = blockIdx.x * 4 + wv;
-  for (int w = blockIdx.x * 256 + threadIdx.x; w < nwords; w += gridDim.x * 256) trigbits[w] = 0u;
+  for (int w = blockIdx.x * 256 + threadIdx.x; w < ((nwords + 31) & ~31); w += gridDim.x * 256) trigbits[w] = 0u;  // (whole blocks of 32 words: the buffer is sized so)
   if (blockIdx.x == 0) {
     for (int s = threadIdx.x; s < AVG_SLOTS; s += 256) st->slot_used[s] = 0u;
     // (st->bad is NOT reset here: other workgroups of this very launch raise it with an atomic, and nothing orders a plain store
     // of workgroup 0 against them -- the flag is cleared by whoever consumed it: the last workgroup of avg_emit_kernel, or the host)
   }
+  // (the launch is ~230 waves on 256 CUs: one wave's chain of load -> LDS round trips IS the kernel, so all of its points are fetched first)
+  float4 pts[AVG_ROUNDS];
+  const int begin = wave * AVG_ITEMS, end = min(n, begin + AVG_ITEMS);
+  if (wave < nwaves) {
+#pragma unroll
+    for (int u = 0; u < AVG_ROUNDS; u++) { const int i = begin + u * 64 + lane; pts[u] = load_xyz(xyz, min(i, end - 1), stride); }
+  }
   for (int b = lane; b < AVG_SLOTS; b += 64) h[wv][b] = 0;
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-  if (wave >= nwaves) return;
-  const int begin = wave * AVG_ITEMS, end = min(n, begin + AVG_ITEMS);
-  bool bad = false;
-  for (int i = begin + lane; i < end; i += 64) {
-    const float4 p = load_xyz(xyz, i, stride);
-    bad |= !finite3(p);
-    int ix, iy, iz;
-    avg_voxel(p, inv, ix, iy, iz);
-    atomicAdd(&h[wv][avg_slot(ix, iy, iz)], 1u);
+  if (wave < nwaves) {
+    bool bad = false;
+#pragma unroll
+    for (int u = 0; u < AVG_ROUNDS; u++) {
+      const int i = begin + u * 64 + lane;
+      if (i < end) {
+        const float4 p = pts[u];
+        bad |= !finite3(p);
+        int ix, iy, iz;
+        avg_voxel(p, inv, ix, iy, iz);
+        atomicAdd(&h[wv][avg_slot(ix, iy, iz)], 1u);
+      }
+    }
+    if (__any(bad) && lane == 0) atomicOr(&st->bad, 1u);
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    if (hist_wg) { for (int b = lane; b < AVG_SLOTS; b += 64) hist[(size_t)wave * AVG_SLOTS + b] = h[wv][b]; }
+    else { for (int b = lane; b < AVG_SLOTS; b += 64) hist[(size_t)b * nwaves + wave] = h[wv][b]; }
   }
-  if (__any(bad) && lane == 0) atomicOr(&st->bad, 1u);
-  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-  for (int b = lane; b < AVG_SLOTS; b += 64) hist[(size_t)b * nwaves + wave] = h[wv][b];
+  if (hist_wg) {  // this workgroup's row: the sum over its four waves
+    __syncthreads();
+    for (int b = threadIdx.x; b < AVG_SLOTS; b += 256) hist_wg[(size_t)blockIdx.x * AVG_SLOTS + b] = (h[0][b] + h[1][b]) + (h[2][b] + h[3][b]);
+  }
 }
 
 // one wave per slot: exclusive prefix over the waves (radix_binscan_kernel), slot total; the LAST workgroup scans the totals
@@ -285,20 +313,90 @@ __global__ __launch_bounds__(256) void avg_binscan_kernel(unsigned* __restrict__
 }
 
 // stable scatter by slot: the points themselves, in slot order, original index in .w
+// `hist_wg` != null: the fused chain -- offsets = per-wave counts [nwaves][slots]; this workgroup derives its scatter cursors itself:
+// slot base (exclusive scan of the slot totals) + the counts of all earlier workgroups + those of its own earlier waves.
 __global__ __launch_bounds__(256) void avg_scatter_kernel(const float* __restrict__ xyz, int n, int stride, float inv, int nwaves, const unsigned* __restrict__ offsets,
-                                                          const AvgState* __restrict__ st, float4* __restrict__ sorted_pts) {
+                                                          const AvgState* __restrict__ st, float4* __restrict__ sorted_pts, const unsigned* __restrict__ hist_wg = nullptr) {
   __shared__ unsigned cur[4][AVG_SLOTS];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int wave = blockIdx.x * 4 + wv;
-  if (wave >= nwaves) return;
-  for (int b = lane; b < AVG_SLOTS; b += 64) cur[wv][b] = offsets[(size_t)b * nwaves + wave] + st->bin_base[b];
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   const int begin = wave * AVG_ITEMS, end = min(n, begin + AVG_ITEMS);
+  float4 pts[AVG_ROUNDS];  // this wave's points, in flight while the cursors are derived (see avg_keys_hist_kernel)
+  if (wave < nwaves) {
+#pragma unroll
+    for (int u = 0; u < AVG_ROUNDS; u++) { const int i = begin + u * 64 + lane; pts[u] = load_xyz(xyz, min(i, end - 1), stride); }
+  }
+  if (hist_wg) {
+    __shared__ unsigned s_tot[AVG_SLOTS], s_base[AVG_SLOTS];
+    __shared__ unsigned s_pt[4][AVG_SLOTS], s_pb[4][AVG_SLOTS];
+    const int nwg = (int)gridDim.x, me = (int)blockIdx.x, t = threadIdx.x;
+    // the rows of all workgroups, dealt to the four waves; a lane takes eight consecutive slots of a row as two 16-byte loads
+    // (one 4-byte load per slot and row: 116 dependent-issue loads per thread, ~6 of this kernel's 14 us)
+    static_assert(AVG_SLOTS == 512, "a row is 64 lanes x 8 slots");
+    unsigned tot[8], bef[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) { tot[k] = 0; bef[k] = 0; }
+    for (int g0 = wv; g0 < nwg; g0 += 32) {
+      uint4 a[8], b[8];
+#pragma unroll
+      for (int u = 0; u < 8; u++) {
+        const int g = min(g0 + 4 * u, nwg - 1);
+        const uint4* row = reinterpret_cast<const uint4*>(hist_wg + (size_t)g * AVG_SLOTS) + lane * 2;
+        a[u] = row[0]; b[u] = row[1];
+      }
+#pragma unroll
+      for (int u = 0; u < 8; u++) {
+        const int g = g0 + 4 * u;
+        if (g < nwg) {
+          const unsigned v[8] = {a[u].x, a[u].y, a[u].z, a[u].w, b[u].x, b[u].y, b[u].z, b[u].w};
+          const bool before = g < me;
+#pragma unroll
+          for (int k = 0; k < 8; k++) { tot[k] += v[k]; bef[k] += before ? v[k] : 0u; }
+        }
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < 8; k++) { s_pt[wv][lane * 8 + k] = tot[k]; s_pb[wv][lane * 8 + k] = bef[k]; }
+    __syncthreads();
+    const unsigned tot0 = (s_pt[0][t] + s_pt[1][t]) + (s_pt[2][t] + s_pt[3][t]), tot1 = (s_pt[0][256 + t] + s_pt[1][256 + t]) + (s_pt[2][256 + t] + s_pt[3][256 + t]);
+    const unsigned bef0 = (s_pb[0][t] + s_pb[1][t]) + (s_pb[2][t] + s_pb[3][t]), bef1 = (s_pb[0][256 + t] + s_pb[1][256 + t]) + (s_pb[2][256 + t] + s_pb[3][256 + t]);
+    s_tot[t] = tot0; s_tot[256 + t] = tot1;
+    __syncthreads();
+    if (t < 64) {  // 512 totals: 8 per lane, exclusive scan
+      unsigned v[8], sum = 0;
+#pragma unroll
+      for (int u = 0; u < 8; u++) { v[u] = s_tot[t * 8 + u]; sum += v[u]; }
+      unsigned x = sum;
+#pragma unroll
+      for (int off = 1; off < 64; off <<= 1) { const unsigned y = __shfl_up(x, off); if (lane >= off) x += y; }
+      unsigned run = x - sum;
+#pragma unroll
+      for (int u = 0; u < 8; u++) { s_base[t * 8 + u] = run; run += v[u]; }
+    }
+    __syncthreads();
+    {
+      unsigned c0 = s_base[t] + bef0, c1 = s_base[256 + t] + bef1;
+#pragma unroll
+      for (int w = 0; w < 4; w++) {
+        cur[w][t] = c0; cur[w][256 + t] = c1;
+        const int gw = me * 4 + w;
+        if (gw < nwaves) { c0 += offsets[(size_t)gw * AVG_SLOTS + t]; c1 += offsets[(size_t)gw * AVG_SLOTS + 256 + t]; }
+      }
+    }
+    __syncthreads();
+    if (wave >= nwaves) return;
+  } else {
+    if (wave >= nwaves) return;
+    for (int b = lane; b < AVG_SLOTS; b += 64) cur[wv][b] = offsets[(size_t)b * nwaves + wave] + st->bin_base[b];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  }
   const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
-  for (int base = begin; base < end; base += 64) {
-    const int i = base + lane;
+#pragma unroll
+  for (int u = 0; u < AVG_ROUNDS; u++) {
+    if (begin + u * 64 >= end) break;
+    const int i = begin + u * 64 + lane;
     const bool valid = i < end;
-    float4 p = valid ? load_xyz(xyz, i, stride) : make_float4(0, 0, 0, 0);
+    float4 p = pts[u];
     int ix, iy, iz;
     avg_voxel(p, inv, ix, iy, iz);
     const unsigned d = avg_slot(ix, iy, iz);
@@ -408,10 +506,8 @@ __global__ __launch_bounds__(1024) void avg_scan_kernel(const unsigned* __restri
 // the 768 that follow, with their head flags) in LDS with coalesced loads; the walks read LDS (a batch is ~100 cycles instead of
 // ~1,500) and fall back to global batches only beyond the window.
 constexpr int AVG_WINDOW = 1024;
-__device__ __forceinline__ void avg_emit_points(const float4* __restrict__ sorted_pts, const unsigned char* __restrict__ head, int n, float inv, const unsigned* __restrict__ trigbits,
-                                                const unsigned* __restrict__ block_base, const AvgState* __restrict__ st, float* __restrict__ out) {
-  __shared__ float4 s_pts[AVG_WINDOW];
-  __shared__ unsigned char s_head[AVG_WINDOW];
+// the window into LDS (no barrier here: the caller's next __syncthreads() publishes it)
+__device__ __forceinline__ void avg_emit_stage(const float4* __restrict__ sorted_pts, const unsigned char* __restrict__ head, int n, float4* s_pts, unsigned char* s_head) {
   const int w0 = blockIdx.x * 256;
 #pragma unroll
   for (int u = 0; u < AVG_WINDOW / 256; u++) {
@@ -419,7 +515,11 @@ __device__ __forceinline__ void avg_emit_points(const float4* __restrict__ sorte
     s_pts[u * 256 + threadIdx.x] = sorted_pts[min(k, n - 1)];
     s_head[u * 256 + threadIdx.x] = (k < n) ? head[k] : (unsigned char)1;
   }
-  __syncthreads();
+}
+__device__ __forceinline__ void avg_emit_points(const float4* __restrict__ sorted_pts, const unsigned char* __restrict__ head, int n, float inv, const unsigned* __restrict__ trigbits,
+                                                const unsigned* block_base, const unsigned* slot_rank, unsigned trig_total, float* __restrict__ out,
+                                                const float4* s_pts, const unsigned char* s_head, const unsigned short* word_prefix = nullptr /* (LDS) triggers before each word, within its block */) {
+  const int w0 = blockIdx.x * 256;
   const int j = w0 + threadIdx.x;
   if (j >= n || !s_head[threadIdx.x]) return;
   float4 p = s_pts[threadIdx.x];
@@ -450,7 +550,7 @@ __device__ __forceinline__ void avg_emit_points(const float4* __restrict__ sorte
     }
   }
   const float cnt = (float)(e - j);
-  unsigned pos = st->trig_total + st->slot_rank[slot];  // last run of its slot: flushed at the end, in slot order
+  unsigned pos = trig_total + slot_rank[slot];  // last run of its slot: flushed at the end, in slot order
   if (e < n) {
     int qx, qy, qz;
     avg_voxel(q, inv, qx, qy, qz);
@@ -458,7 +558,8 @@ __device__ __forceinline__ void avg_emit_points(const float4* __restrict__ sorte
       const int id = __float_as_int(q.w);
       const int w = id >> 5;
       unsigned r = block_base[id >> 10] + __popc(trigbits[w] & ((1u << (id & 31)) - 1u));
-      for (int k = (id >> 10) * 32; k < w; k++) r += __popc(trigbits[k]);
+      if (word_prefix) r += word_prefix[w];
+      else for (int k = (id >> 10) * 32; k < w; k++) r += __popc(trigbits[k]);  // (up to 31 dependent L2 round trips)
       pos = r;
     }
   }
@@ -471,16 +572,83 @@ __device__ __forceinline__ void avg_emit_points(const float4* __restrict__ sorte
 
 // The LAST workgroup to finish writes {count, bad flag, sequence} to mapped host memory: when the host sees the sequence
 // word, every centroid is in `out` (no copy kernel, no stream synchronisation on the way to the next stage).
+// `block_base` == null: the fused chain (no avg_scan_kernel ran) -- every workgroup scans the trigger words and the slot flags itself
+// (AVG_FUSED_MAX_BLOCKS blocks of 32 words at most); workgroup 0 also leaves the totals in the device state and, for a caller that consumes
+// the output on the same stream (`early_result`), reports the count NOW, before the centroids exist.
 __global__ __launch_bounds__(256) void avg_emit_kernel(const float4* __restrict__ sorted_pts, const unsigned char* __restrict__ head, int n, float inv, const unsigned* __restrict__ trigbits,
                                                        const unsigned* __restrict__ block_base, AvgState* __restrict__ st, float* __restrict__ out,
-                                                       unsigned long long* __restrict__ host_result /* {count, bad, seq} mapped, or null */, unsigned long long seq) {
-  avg_emit_points(sorted_pts, head, n, inv, trigbits, block_base, st, out);
+                                                       unsigned long long* __restrict__ host_result /* {count, bad, seq} mapped, or null */, unsigned long long seq,
+                                                       int nwords = 0, unsigned long long* __restrict__ early_result = nullptr) {
+  __shared__ unsigned s_bb[AVG_FUSED_MAX_BLOCKS + 1], s_rank[AVG_SLOTS + 1], s_w[4];
+  __shared__ float4 s_pts[AVG_WINDOW];
+  __shared__ unsigned char s_head[AVG_WINDOW];
+  __shared__ unsigned short s_wp[AVG_FUSED_MAX_BLOCKS * 32];
+  unsigned trig_total, used_slots;
+  if (block_base) {
+    trig_total = st->trig_total; used_slots = st->used_slots;
+    avg_emit_stage(sorted_pts, head, n, s_pts, s_head);
+    __syncthreads();
+    avg_emit_points(sorted_pts, head, n, inv, trigbits, block_base, st->slot_rank, trig_total, out, s_pts, s_head);
+  } else {
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    const int nblocks = (nwords + 31) / 32;
+    // (counting the triggers per block with atomics in avg_mark_kernel instead: ~20k adds on ~116 addresses, that kernel 5.5 -> 29 us)
+    unsigned c = 0;
+    if (t < nblocks) {
+      const uint4* q = reinterpret_cast<const uint4*>(trigbits + t * 32);  // (whole blocks: zeroed to the block boundary by avg_keys_hist_kernel)
+#pragma unroll
+      for (int w = 0; w < 8; w++) {  // (and the triggers before each word of the block: a rank is then one LDS read, not a walk over up to 31 words)
+        const uint4 v = q[w];
+        unsigned short* wp = s_wp + t * 32 + w * 4;
+        wp[0] = (unsigned short)c; c += __popc(v.x);
+        wp[1] = (unsigned short)c; c += __popc(v.y);
+        wp[2] = (unsigned short)c; c += __popc(v.z);
+        wp[3] = (unsigned short)c; c += __popc(v.w);
+      }
+    }
+    const unsigned f0 = st->slot_used[2 * t], f1 = st->slot_used[2 * t + 1];
+    avg_emit_stage(sorted_pts, head, n, s_pts, s_head);  // (its loads fly with the ones above; the barriers below publish it)
+    unsigned x = c;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) { const unsigned y = __shfl_up(x, off); if (lane >= off) x += y; }
+    if (lane == 63) s_w[wv] = x;
+    __syncthreads();
+    unsigned pre = 0;
+    for (int w = 0; w < wv; w++) pre += s_w[w];
+    s_bb[t] = pre + x - c;  // (AVG_FUSED_MAX_BLOCKS == 256: one block per thread)
+    trig_total = s_w[0] + s_w[1] + s_w[2] + s_w[3];
+    if (t == 0) s_bb[AVG_FUSED_MAX_BLOCKS] = trig_total;
+    __syncthreads();
+    // slot ranks: exclusive scan of the 512 "slot used" flags, two per thread
+    unsigned y2 = f0 + f1, z = y2;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) { const unsigned y = __shfl_up(z, off); if (lane >= off) z += y; }
+    if (lane == 63) s_w[wv] = z;
+    __syncthreads();
+    unsigned pre2 = 0;
+    for (int w = 0; w < wv; w++) pre2 += s_w[w];
+    s_rank[2 * t] = pre2 + z - y2; s_rank[2 * t + 1] = pre2 + z - y2 + f0;
+    used_slots = s_w[0] + s_w[1] + s_w[2] + s_w[3];
+    if (t == 0) s_rank[AVG_SLOTS] = used_slots;
+    __syncthreads();
+    if (blockIdx.x == 0 && t == 0) {
+      st->trig_total = trig_total; st->used_slots = used_slots;
+      if (early_result) {  // (every setter of `bad` ran in the first kernel of the chain)
+        __hip_atomic_store(&early_result[0], (unsigned long long)(trig_total + used_slots), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(&early_result[1], (unsigned long long)st->bad, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        st->bad = 0u;  // consumed: re-armed for the next call
+        __threadfence_system();
+        __hip_atomic_store(&early_result[2], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+      }
+    }
+    avg_emit_points(sorted_pts, head, n, inv, trigbits, s_bb, s_rank, trig_total, out, s_pts, s_head, s_wp);
+  }
   if (!host_result) return;
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this workgroup's centroids are in memory (write-through stores); no L2 write-back (see avg_binscan_kernel)
   __syncthreads();
   if (threadIdx.x == 0 && atomicAdd(&st->emit_ticket, 1u) == gridDim.x - 1) {
     st->emit_ticket = 0u;
-    __hip_atomic_store(&host_result[0], (unsigned long long)(st->trig_total + st->used_slots), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(&host_result[0], (unsigned long long)(trig_total + used_slots), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     __hip_atomic_store(&host_result[1], (unsigned long long)st->bad, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     st->bad = 0u;  // consumed: re-armed for the next call (like the ticket), long after every setter of this call has finished
     __threadfence_system();
