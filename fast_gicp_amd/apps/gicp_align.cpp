@@ -53,6 +53,9 @@ void test(Registration& reg, const Cloud::ConstPtr& target, const Cloud::ConstPt
   if (std::getenv("GICP_ALIGN_BREAKDOWN")) {  // where a registration of the reuse loop spends its host time (not part of the reference's output)
     using clk = std::chrono::steady_clock;
     double t_swap = 0, t_src = 0, t_align = 0;
+    auto& ht = fast_gicp::detail::host_timing();
+    ht = {};
+    ht.on = true;
     for (int i = 0; i < 100; i++) {
       auto a = clk::now();
       reg.swapSourceAndTarget();
@@ -69,7 +72,8 @@ void test(Registration& reg, const Cloud::ConstPtr& target, const Cloud::ConstPt
       t_align += std::chrono::duration<double, std::micro>(d - c).count();
     }
     std::cout << "  breakdown per registration [us]: swap + clearSource + setInputTarget " << t_swap / 100 << ", setInputSource (upload, k-NN / covariance launches) " << t_src / 100
-              << ", align (waits for the GPU, transforms the output cloud) " << t_align / 100 << std::endl;
+              << ", align (waits for the GPU, transforms the output cloud) " << t_align / 100 << " (of it: optimisation " << ht.optimize_us / 100 << ", output cloud " << ht.transform_us / 100 << ")" << std::endl;
+    ht.on = false;
   }
 }
 

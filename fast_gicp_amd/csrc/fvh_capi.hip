@@ -146,6 +146,22 @@ struct Rccl {
 };
 Rccl g_rccl;
 std::atomic<int> g_live_engines{0};    // engine handles alive in this process that can launch gang kernels (registration handles)
+// When each of them last queued a gang kernel (cooperative sort, persistent LM kernel), by handle number mod 64. Two gang kernels from
+// two streams could starve each other of CU slots (the watchdogs + fall-backs recover, slowly): the cooperative sort is used while no
+// OTHER handle has been busy within the window -- a second handle that merely exists (the reference's align.cpp keeps its NDT object
+// alive while the VGICP rows run) no longer costs the VGICP handle 38 us per registration.
+std::atomic<long long> g_gang_stamp_ns[64];
+std::atomic<int> g_engine_numbers{0};
+inline long long steady_ns() { return std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+inline bool other_gang_recent(int me, long long window_ns) {
+  const long long now = steady_ns();
+  for (int i = 0; i < 64; i++) {
+    if (i == me) continue;
+    const long long t = g_gang_stamp_ns[i].load(std::memory_order_relaxed);
+    if (t && now - t < window_ns) return true;
+  }
+  return false;
+}
 
 // Co-resident workgroup slots of a device, shared by the persistent LM launches of this process. A persistent grid must be
 // resident as a whole, so concurrent aligns (several handles driven by several host threads) SPLIT the slots instead of
@@ -291,17 +307,22 @@ struct Engine {
   unsigned long long persist_seq = 0;
   DevBuf offsets_dev, state, partials, ticket, corr, misc, fit, staging, sort_keys, sort_idx, sort_hist;
   void* pinned = nullptr;  // sizeof(LmState) + slack
-  void* upload_pinned = nullptr;  // pinned staging of host clouds (upload_cloud)
-  size_t upload_pinned_cap = 0;
-  hipEvent_t upload_done = nullptr;
-  bool upload_busy = false;
+  // pinned staging of host clouds (upload_cloud): TWO slots used in turn, each with its own "consumed" event -- a target and a
+  // source handed over back to back do not wait for each other's consumer
+  void* upload_pinned = nullptr;
+  size_t upload_pinned_cap = 0;  // bytes per slot
+  hipEvent_t upload_done[2] = {nullptr, nullptr};
+  bool upload_busy[2] = {false, false};
+  int upload_slot = 0;
   bool ensure_upload_pinned(size_t bytes) {
     if (bytes <= upload_pinned_cap) return true;
-    if (upload_busy) { (void)hipEventSynchronize(upload_done); upload_busy = false; }
+    for (int s = 0; s < 2; s++) {
+      if (upload_busy[s]) { (void)hipEventSynchronize(upload_done[s]); upload_busy[s] = false; }
+      if (!upload_done[s] && hipEventCreateWithFlags(&upload_done[s], hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); return false; }
+    }
     if (upload_pinned) { (void)hipHostFree(upload_pinned); upload_pinned = nullptr; upload_pinned_cap = 0; }
-    if (!upload_done && hipEventCreateWithFlags(&upload_done, hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); return false; }
-    const size_t want = bytes + bytes / 4 + 4096;
-    if (hipHostMalloc(&upload_pinned, want, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); upload_pinned = nullptr; return false; }
+    const size_t want = (bytes + bytes / 4 + 4096 + 255) & ~(size_t)255;
+    if (hipHostMalloc(&upload_pinned, 2 * want, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); upload_pinned = nullptr; return false; }
     upload_pinned_cap = want;
     return true;
   }
@@ -452,10 +473,12 @@ struct Engine {
     int rc = upload_offsets();
     if (rc) return rc;
     if ((e = hipStreamSynchronize(stream)) != hipSuccess) return hipfail(e, "hipStreamSynchronize");  // "warming up GPU" (fast_vgicp_cuda.cu:19-20)
-    if (gang_kernels) { g_live_engines.fetch_add(1); counted = true; }
+    if (gang_kernels) { g_live_engines.fetch_add(1); counted = true; gang_id = g_engine_numbers.fetch_add(1) & 63; }
     return FVH_OK;
   }
   bool counted = false;
+  int gang_id = 0;
+  void gang_stamp() { if (counted) g_gang_stamp_ns[gang_id].store(steady_ns(), std::memory_order_relaxed); }
   hipStream_t owned_stream = nullptr;  // the stream init() made; `stream` may be another handle's (fvh_voxelgrid_share_stream_*)
   void shutdown() {
     if (stream != owned_stream) stream = owned_stream;  // a borrowed stream is its owner's to drain and destroy
@@ -472,7 +495,7 @@ struct Engine {
     gather_stage.release(); lm_trace.release(); fit_best.release(); sort_coop.release(); rbf_sums.release(); bcast.release(); offsets_dev.release(); state.release(); partials.release(); ticket.release(); corr.release(); misc.release(); fit.release(); staging.release(); sort_keys.release(); sort_idx.release(); sort_hist.release();
     if (pinned) (void)hipHostFree(pinned);
     if (upload_pinned) (void)hipHostFree(upload_pinned);
-    if (upload_done) (void)hipEventDestroy(upload_done);
+    for (int s = 0; s < 2; s++) if (upload_done[s]) (void)hipEventDestroy(upload_done[s]);
     if (result_host) (void)hipHostFree(result_host);
     if (stream) (void)hipStreamDestroy(stream);
     if (side_done) (void)hipEventDestroy(side_done);
@@ -582,13 +605,28 @@ int upload_cloud(Engine* e, CloudDev& c, const float* xyz, int n, int stride, bo
       // the caller's (pageable) buffer is consumed by a plain memcpy into pinned memory of the handle; the copy to the device and
       // everything after it is then truly asynchronous -- no stream synchronisation before returning (the reference's loop hands
       // over a host cloud per registration: this took the PCIe-inclusive rate from 3,220 to the rate below)
-      if (e->upload_busy) { HIP_OR_FAIL(e, hipEventSynchronize(e->upload_done)); e->upload_busy = false; }  // the previous upload still reading the pinned buffer (normally long finished)
-      std::memcpy(e->upload_pinned, xyz, bytes);
-      HIP_OR_FAIL(e, hipMemcpyAsync(e->staging.p, e->upload_pinned, bytes, hipMemcpyHostToDevice, e->stream));
-      HIP_OR_FAIL(e, hipEventRecord(e->upload_done, e->stream));
-      e->upload_busy = true;
-      pack_points_kernel<<<pack_grid(n, boxp != nullptr), 256, 0, e->stream>>>(e->staging.as<float>(), n, stride, c.pts.as<float4>(), boxp);
-      HIP_OR_FAIL(e, hipGetLastError());
+      const int us = (e->upload_slot ^= 1);
+      char* slot = static_cast<char*>(e->upload_pinned) + (size_t)us * e->upload_pinned_cap;
+      if (e->upload_busy[us]) { HIP_OR_FAIL(e, hipEventSynchronize(e->upload_done[us])); e->upload_busy[us] = false; }  // the upload before the last still reading this slot (normally long finished)
+      std::memcpy(slot, xyz, bytes);
+      // Small clouds: the widening kernel reads the pinned buffer itself, over PCIe (a 17k-point cloud is 0.2-0.3 MB: a few microseconds)
+      // -- a copy-engine transfer in front of it costs its own start-up plus a hand-over between the copy and the compute queue,
+      // ~20 us of a 250 us registration. Large clouds keep the copy engine (the kernel's PCIe reads would be the slower transfer).
+      static const size_t zero_copy_max = [] { const char* v = getenv("FVH_ZEROCOPY_UPLOAD_MAX"); return v ? (size_t)atoll(v) : (size_t)(1u << 20); }();
+      void* pinned_dev = nullptr;
+      if (bytes <= zero_copy_max && hipHostGetDevicePointer(&pinned_dev, slot, 0) == hipSuccess && pinned_dev) {
+        pack_points_kernel<<<pack_grid(n, boxp != nullptr), 256, 0, e->stream>>>(static_cast<const float*>(pinned_dev), n, stride, c.pts.as<float4>(), boxp);
+        HIP_OR_FAIL(e, hipGetLastError());
+        HIP_OR_FAIL(e, hipEventRecord(e->upload_done[us], e->stream));
+        e->upload_busy[us] = true;
+      } else {
+        (void)hipGetLastError();
+        HIP_OR_FAIL(e, hipMemcpyAsync(e->staging.p, slot, bytes, hipMemcpyHostToDevice, e->stream));
+        HIP_OR_FAIL(e, hipEventRecord(e->upload_done[us], e->stream));
+        e->upload_busy[us] = true;
+        pack_points_kernel<<<pack_grid(n, boxp != nullptr), 256, 0, e->stream>>>(e->staging.as<float>(), n, stride, c.pts.as<float4>(), boxp);
+        HIP_OR_FAIL(e, hipGetLastError());
+      }
     } else {
       HIP_OR_FAIL(e, hipMemcpyAsync(e->staging.p, xyz, bytes, hipMemcpyHostToDevice, e->stream));
       pack_points_kernel<<<pack_grid(n, boxp != nullptr), 256, 0, e->stream>>>(e->staging.as<float>(), n, stride, c.pts.as<float4>(), boxp);
@@ -635,7 +673,9 @@ int ensure_sorted(Engine* e, CloudDev& c) {
   if (sort_mode >= 1 && n <= SORT_SMALL_MAX) {
     // cooperative kernel (32 workgroups meeting at grid barriers) when this is the only engine of the process: two
     // gang kernels from two streams could starve each other of CU slots (the watchdog + fallback would recover, slowly)
-    const bool coop = c.has_box && ((sort_mode == 2 && g_live_engines.load() == 1) || sort_mode == 3);
+    static const long long gang_window_ns = [] { const char* v = getenv("FVH_GANG_WINDOW_MS"); return (long long)(v ? atof(v) : 20.0) * 1000000ll; }();
+    const bool coop = c.has_box && ((sort_mode == 2 && (g_live_engines.load() == 1 || !other_gang_recent(e->gang_id, gang_window_ns))) || sort_mode == 3);
+    e->gang_stamp();
     if (coop) {
       const bool fresh = e->sort_coop.p == nullptr;
       HIP_OR_FAIL(e, e->sort_coop.ensure(COOP_STATE_BYTES));
@@ -1204,6 +1244,7 @@ int launch_cost(Engine* e, const CostSource& src, const VoxelMapDev& vm, int hos
     P.launch_tag = ++e->persist_seq;
     e->last_persist_blocks = blocks;
     ProfScope ps(e, "cost");
+    e->gang_stamp();
     if (e->precision == FVH_COMPUTE_FP32) cost_kernel<float, MODE, true><<<launch_blocks, 256, 0, e->stream>>>(P);
     else cost_kernel<double, MODE, true><<<launch_blocks, 256, 0, e->stream>>>(P);
   } else {

@@ -20,6 +20,7 @@
 #include <immintrin.h>
 #endif
 #include <array>
+#include <chrono>
 #include <cmath>
 #include <cstddef>
 #include <cstdio>
@@ -261,6 +262,9 @@ inline std::vector<float> pack_xyz(const PointCloud<PointT>& c) {
   for (size_t i = 0; i < c.size(); i++) { xyz[3 * i] = c.points[i].x; xyz[3 * i + 1] = c.points[i].y; xyz[3 * i + 2] = c.points[i].z; }
   return xyz;
 }
+/// where align() spends its host time (apps/gicp_align, GICP_ALIGN_BREAKDOWN): off unless a caller switches it on
+struct HostTiming { bool on = false; double optimize_us = 0, transform_us = 0; };
+inline HostTiming& host_timing() { static HostTiming t; return t; }
 }  // namespace detail
 
 /// LsqRegistration (lsq_registration.hpp:14-83) minus the PCL base: the members of pcl::Registration its callers use.
@@ -312,6 +316,9 @@ protected:
     Isometry3d x0 = Isometry3d::from(guess);
     lm_lambda_ = -1.0;
     converged_ = false;
+    detail::HostTiming& ht = detail::host_timing();
+    std::chrono::steady_clock::time_point ht0, ht1;
+    if (ht.on) ht0 = std::chrono::steady_clock::now();
     if (use_device_lm_ && lsq_optimizer_type_ == LSQ_OPTIMIZER_TYPE::LevenbergMarquardt && device_align(x0)) {
       // whole loop ran on the GPU
     } else {
@@ -326,8 +333,13 @@ protected:
       }
     }
     final_transformation_ = x0.cast_float();
+    if (ht.on) ht1 = std::chrono::steady_clock::now();
     output.points.resize(input_->size());  // pcl::transformPointCloud(*input_, output, final_transformation_)
     detail::transform_points(input_->points.data(), output.points.data(), input_->size(), final_transformation_.m);
+    if (ht.on) {
+      ht.optimize_us += std::chrono::duration<double, std::micro>(ht1 - ht0).count();
+      ht.transform_us += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - ht1).count();
+    }
   }
 
   bool is_converged(const Isometry3d& delta) const {  // :82-91
