@@ -1204,7 +1204,7 @@ int launch_cost(Engine* e, const CostSource& src, const VoxelMapDev& vm, int hos
   P.ng = (plan && plan->ng > 0) ? plan->ng : default_groups(blocks);
   if (P.ng > blocks) P.ng = 1;  // (every group needs its first workgroup)
   P.nb = blocks;
-  P.xcd_mask = 0; P.xcd_local = 0;
+  P.xcd_mask = 0; P.xcd_local = 0; P.lm_everywhere = 0;
   {
     // Grids of two workgroups per CU (257 .. 512 workgroups: the 17k-point headline has 474): the second workgroup of a CU loses VALU
     // arbitration to the first (older waves win), finishes its main loop ~2 us later and keeps the whole trip waiting; s_setprio 1 for it
@@ -1216,6 +1216,12 @@ int launch_cost(Engine* e, const CostSource& src, const VoxelMapDev& vm, int hos
     P.prio_from = cus;
     const bool confined = plan && plan->mask;
     P.prio_mode = prio >= 0 ? prio : ((persistent && !confined && blocks > cus && blocks <= 2 * cus) ? 1 : 0);
+    // The LM step on EVERY workgroup (each polls the group rows itself: no broadcast hand-off) for grids of at most two workgroups per
+    // CU: 17k headline 126.1 -> 123.5 us, NDT LiDAR frames 81.8 -> 79.0 us. With three per CU (100k / 1M points: 768 workgroups) the
+    // redundant steps cost more than the hand-off they replace (210.5 -> 216 us, 223 -> 227 us): those keep the collectors' broadcast.
+    // FVH_LM_EVERYWHERE: 0 never, 1 (default) by this rule, 2 always. (profiles/r04_lm_everywhere.txt)
+    static const int everywhere = [] { const char* v = getenv("FVH_LM_EVERYWHERE"); return v ? atoi(v) : 1; }();
+    P.lm_everywhere = (persistent && P.ng > 1 && (everywhere == 2 || (everywhere == 1 && blocks <= 2 * cus))) ? 1 : 0;
   }
   int launch_blocks = blocks;
   if (persistent && plan) {

@@ -136,6 +136,8 @@ struct CostParams {
   int prio_from;       // ... "second" = logical workgroups from this one on (the host passes the number of CUs)
   int xcd_local;       // persistent kernel: every member of a group sits on the group's XCD (checked per workgroup): rows and broadcast
                        // travel through that XCD's L2 (plain stores) instead of write-through + memory-side polls
+  int lm_everywhere;   // persistent kernel, two levels: EVERY workgroup polls the group rows and runs the LM step on its own copy of the
+                       // state -- no broadcast hand-off (small grids: one workgroup per CU, the step's code stays in its instruction cache)
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -1255,11 +1257,16 @@ __global__ FVH_COST_BOUNDS void cost_kernel(CostParams P) {
     // Round 3 had ONE workgroup run the step and broadcast to the whole chip: rows -> collector, group rows -> opener, broadcast ->
     // everybody were three memory-side round trips of ~1 us each. Now rows and broadcast stay inside the group = inside one XCD
     // (xcd_local: plain stores, served to the polling sc1 loads by that XCD's L2), and only the group rows pay the ~1 us.
+    // lm_everywhere (grids of <= 2 workgroups per CU, single GPU): the group rows are polled by EVERY workgroup, each runs the step on
+    // its own LDS state and nobody broadcasts -- the third hand-off is gone (17k: 126.1 -> 123.5 us; NDT frames 81.8 -> 79.0). The
+    // step itself is ~0.3 us slower there (it shares its CU with computing or polling waves), so the gain is ~0.4 us per trip, and
+    // with three workgroups per CU it turns into a loss (768 workgroups: +4-6 us per launch).
     // Multi-GPU: workgroup 0 alone meets the peers (kernels_peer.hpp) and hands the all-reduced sums to the other collectors as
     // one more tagged row. Workgroup 0 also owns what leaves the launch: the LM trace, the final state, the result word.
     // Dead ends measured in round 1/2 (474 workgroups, 17k points): one barrier word on the line of the arrival counters
     // (+10 us per trip); one barrier word + every workgroup reloading the state (21.6 us per trip: ~500 readers of the
-    // same lines queue at their memory channel); EVERY workgroup running the LM step (22.7 us per trip).
+    // same lines queue at their memory channel); EVERY workgroup running the LM step on a state RELOADED from memory each trip (22.7 us per trip; with the state resident in LDS and
+    // the group rows as input it is the lm_everywhere flavour above).
     // Rows are single-buffered: a workgroup writes its trip t + 1 row only after it has seen its group's broadcast of trip t, which
     // the collector sends after every row of trip t has been consumed; group rows alternate between two parities (a collector can
     // be at most one trip ahead of the slowest one: it needs that one's next group row). Tags embed the launch sequence: rows of
@@ -1302,10 +1309,12 @@ __global__ FVH_COST_BOUNDS void cost_kernel(CostParams P) {
     }
     FVH_PT_MAX(trip, 2);
     const bool collector = lb < NG;  // == the first workgroup of group `grp`
-    if (collector) {
+    const bool multi_gpu = MODE == MODE_VGICP && P.peer.n > 1;  // (kernel argument: uniform)
+    const bool everywhere = P.lm_everywhere != 0 && NG > 1 && !multi_gpu;  // (kernel arguments: uniform)
+    if (collector || everywhere) {
       if (tid == 0) { s_last = 1; s_abort = 0u; }
       __syncthreads();
-      {
+      if (collector) {
         const int v = tid & 31, chunk = tid >> 5;
         const double want = want_tag_of();
         double s = 0.0;
@@ -1341,13 +1350,13 @@ __global__ FVH_COST_BOUNDS void cost_kernel(CostParams P) {
         }
         fin[chunk][v] = s;
       }
-      __syncthreads();
+      if (collector) __syncthreads();  // (uniform per workgroup)
       if (!s_last) {
         poison(tid, 256);
         if (tid == 0) __hip_atomic_store(&st->aborted, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         return;
       }
-      if (tid < PART_STRIDE) {
+      if (collector && tid < PART_STRIDE) {
         double s = 0.0;
 #pragma unroll
         for (int c = 0; c < 8; c++) s += fin[c][tid];
@@ -1364,7 +1373,6 @@ __global__ FVH_COST_BOUNDS void cost_kernel(CostParams P) {
       // pairs of the <= 8 group rows (eight in flight per lane) and add them in group order, the sums go to LDS, the LM step runs
       // in registers, lanes 0..25 read the payload back and store it to the group's copies. No __syncthreads, no LDS hop between
       // the stages. (red[1] above was written by this same wave: LDS operations of a wave complete in order.)
-      const bool multi_gpu = MODE == MODE_VGICP && P.peer.n > 1;  // (kernel argument: uniform)
       if (tid < 64) {
         const int lane = tid;
         double val = 0.0;
@@ -1392,6 +1400,10 @@ __global__ FVH_COST_BOUNDS void cost_kernel(CostParams P) {
             for (int g = 0; g < 8; g++)
               if (((pend >> g) & 1u) && pv[g].y == want) { t[g] = pv[g].x; pend &= ~(1u << g); }
             if (__builtin_amdgcn_readfirstlane((int)(wall_clock64() - t0 > P.watchdog_ticks))) { ok = false; break; }
+#ifndef FVH_EVERYWHERE_SLEEP
+#define FVH_EVERYWHERE_SLEEP 0  // (0 / 1 / 2 / 8 measured: 123.4 / 123.4 / 124.1 / 126.1 us at 17k)
+#endif
+            if (!collector && FVH_EVERYWHERE_SLEEP) __builtin_amdgcn_s_sleep(FVH_EVERYWHERE_SLEEP);  // (lm_everywhere: ~10x the pollers of the collectors-only protocol)
           }
           if (lane == PART_STRIDE - 1) {  // slot 31: every group must have seen our rotation
 #pragma unroll
@@ -1477,7 +1489,8 @@ __global__ FVH_COST_BOUNDS void cost_kernel(CostParams P) {
             pv.x = v; pv.y = want_tag_of();
             pair_t* dst = my_bcast + lane;  // lanes 32..63: the next copy (BCAST_PAIRS == 32)
             static_assert(BCAST_PAIRS == 32, "two copies per store instruction");
-            if (local) {
+            if (everywhere) {  // (nobody polls a broadcast: every workgroup has just computed the payload itself)
+            } else if (local) {
               for (unsigned r = 0; r < reps; r += 2) store_pair_xcd(dst + (size_t)r * BCAST_PAIRS, pv);
             } else {
               for (unsigned r = 0; r < reps; r += 2) store_pair_agent(dst + (size_t)r * BCAST_PAIRS, pv);

@@ -93,6 +93,21 @@ def test_edge_cases(O, vg):
     _same(vg.filter(one, 0.5), one)  # handle still usable after errors
 
 
+def test_approximate_voxelgrid_both_chains_around_the_fused_limit(O, vg):
+    """Frames of up to 262,144 points take the four-launch chain (prefixes recomputed per workgroup), larger ones the six-launch
+    chain with its scan kernels: both against the oracle, on sizes either side of the limit and around the 2,048-point workgroups
+    of the counting sort."""
+    rng = np.random.default_rng(5)
+    for n in (2047, 2049, 131072, 262143, 262144, 262145, 300001):
+        c = (rng.normal(size=(n, 3)) * np.array([10.0, 10.0, 1.5])).astype(np.float32)
+        # first half in voxel order (long runs, as a LiDAR sweep delivers them), second half in random order (a flush per point)
+        k = np.floor(c[: n // 2] / 0.7).astype(np.int64)
+        c[: n // 2] = c[: n // 2][np.lexsort((k[:, 2], k[:, 1], k[:, 0]))]
+        ref = O.approx_voxelgrid(c, 0.7)
+        assert 0.3 * n < len(ref) < 0.8 * n
+        _same(vg.filter(c, 0.7, vg.APPROXIMATE), ref)
+
+
 def test_properties_1m(vg):
     """Full-size properties (no oracle): every input point lands in exactly one output centroid's voxel; permutation
     of the input changes neither the exact filter's output set nor its order (order = voxel index)."""
