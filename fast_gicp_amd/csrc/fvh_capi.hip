@@ -1221,7 +1221,8 @@ int launch_cost(Engine* e, const CostSource& src, const VoxelMapDev& vm, int hos
     // redundant steps cost more than the hand-off they replace (210.5 -> 216 us, 223 -> 227 us): those keep the collectors' broadcast.
     // FVH_LM_EVERYWHERE: 0 never, 1 (default) by this rule, 2 always. (profiles/r04_lm_everywhere.txt)
     static const int everywhere = [] { const char* v = getenv("FVH_LM_EVERYWHERE"); return v ? atoi(v) : 1; }();
-    P.lm_everywhere = (persistent && P.ng > 1 && (everywhere == 2 || (everywhere == 1 && blocks <= 2 * cus))) ? 1 : 0;
+    static const int everywhere1 = [] { const char* v = getenv("FVH_LM_EVERYWHERE_SINGLE"); return v ? atoi(v) : 0; }();  // also on single-level grids: every workgroup adds all rows
+    P.lm_everywhere = (persistent && (P.ng > 1 || everywhere1) && (everywhere == 2 || (everywhere == 1 && blocks <= 2 * cus))) ? 1 : 0;
   }
   int launch_blocks = blocks;
   if (persistent && plan) {

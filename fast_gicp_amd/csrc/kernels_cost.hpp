@@ -1310,11 +1310,12 @@ __global__ FVH_COST_BOUNDS void cost_kernel(CostParams P) {
     FVH_PT_MAX(trip, 2);
     const bool collector = lb < NG;  // == the first workgroup of group `grp`
     const bool multi_gpu = MODE == MODE_VGICP && P.peer.n > 1;  // (kernel argument: uniform)
-    const bool everywhere = P.lm_everywhere != 0 && NG > 1 && !multi_gpu;  // (kernel arguments: uniform)
+    const bool everywhere = P.lm_everywhere != 0 && !multi_gpu;  // (kernel arguments: uniform)
+    const bool adds_rows = collector || (everywhere && NG == 1);  // single level + everywhere: every workgroup adds ALL rows itself (one hand-off per trip)
     if (collector || everywhere) {
       if (tid == 0) { s_last = 1; s_abort = 0u; }
       __syncthreads();
-      if (collector) {
+      if (adds_rows) {
         const int v = tid & 31, chunk = tid >> 5;
         const double want = want_tag_of();
         double s = 0.0;
@@ -1350,13 +1351,13 @@ __global__ FVH_COST_BOUNDS void cost_kernel(CostParams P) {
         }
         fin[chunk][v] = s;
       }
-      if (collector) __syncthreads();  // (uniform per workgroup)
+      if (adds_rows) __syncthreads();  // (uniform per workgroup)
       if (!s_last) {
         poison(tid, 256);
         if (tid == 0) __hip_atomic_store(&st->aborted, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         return;
       }
-      if (collector && tid < PART_STRIDE) {
+      if (adds_rows && tid < PART_STRIDE) {
         double s = 0.0;
 #pragma unroll
         for (int c = 0; c < 8; c++) s += fin[c][tid];
