@@ -660,10 +660,10 @@ def run_stream(args, steps, warmup, cpu_loops=15, frames_n=10):
             # second entry: the stage with real bytes in this loop, the filter. Algorithmic bytes: read N x 12 B, write M x 12 B
             b = n_raw * 12 + n_ds * 12
             ach = b / (ms / n * 1e-3) / 1e9
-            roofline_ds = {"kernel": "voxel-grid filter (ApproximateVoxelGrid, 6 fused launches: slot histogram, slot scan, scatter, mark, trigger scan, emit)", "bound": "hbm", "achieved": round(ach, 2),
+            roofline_ds = {"kernel": "voxel-grid filter (ApproximateVoxelGrid, 4 launches: slot histogram, scatter, mark, emit; the two scans are recomputed per workgroup)", "bound": "hbm", "achieved": round(ach, 2),
                            "peak": 8000.0, "unit": "GB/s", "frac": round(ach / 8000.0, 5), "traffic": None, "algorithmic_bytes_per_launch": b,
                            "avg_launch_us": round(ms / n * 1e3, 3), "launches": n,
-                           "note": "1.4 MB of input per frame: launch/latency bound (a chain of six dependent small kernels), not HBM bound; `traffic`: a per-chain PMC figure is not collected"}
+                           "note": "1.4 MB of input per frame: launch/latency bound (a chain of four dependent small kernels), not HBM bound; `traffic`: a per-chain PMC figure is not collected"}
     cpu = None
     if not args.no_cpu_baseline:
         from oracle import oracle as O
