@@ -274,6 +274,14 @@ class VGICPCore(_Core):
         """Multi-GPU: this rank's target voxel map holds the voxels around its tile of the source only (rebuilt per align)."""
         self._call("set_target_map_sharding", 1 if on else 0, int(margin_voxels))
 
+    def debug_spatial_order(self, which="source"):
+        """(order, tile_boxes): the Morton order of a cloud (original index per sorted position) and the boxes of its 64-point tiles"""
+        n = self.num_points(which)
+        order = np.empty(max(n, 1), np.int32)
+        boxes = np.empty(((max(n, 1) + 63) // 64, 8), np.float32)
+        self._call("debug_get_spatial_order", 0 if which == "source" else 1, _p(order), _p(boxes))
+        return order[:n], boxes[: (n + 63) // 64]
+
     def debug_map_shard(self):
         a, b = C.c_int(0), C.c_int(0)
         self._call("debug_get_map_shard", C.byref(a), C.byref(b))

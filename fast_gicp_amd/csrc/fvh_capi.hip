@@ -717,6 +717,40 @@ int ensure_sorted(Engine* e, CloudDev& c) {
     HIP_OR_FAIL(e, hipMemsetAsync(box + 3, 0, 12, e->stream));
     cloud_bbox_kernel<<<std::min(256, (n + 255) / 256), 256, 0, e->stream>>>(c.pts.as<float4>(), n, box);
   }
+  // Up to SORT_FUSED_MAX points: two launches per pass (kernels_sort.hpp: the scatter derives its cursors from per-workgroup digit counts),
+  // two passes over the top 2 x FVH_SORT_FUSED_BITS bits of the key. 100k points: 71 us in nine launches -> see profiles/r04_sort_fused.txt.
+  static const int fused_bits = [] { const char* v = getenv("FVH_SORT_FUSED_BITS"); const int b = v ? atoi(v) : 10; return (b == 9 || b == 10) ? b : 0; }();  // 0: the four-launch passes below. (9: the sort is 8 us shorter and the exact k-NN behind it 14 us longer -- coarser cells, looser tiles)
+  if (fused_bits && n <= SORT_FUSED_MAX) {
+    const int fwaves = (n + SORT_FUSED_ITEMS - 1) / SORT_FUSED_ITEMS, fwgs = (fwaves + 3) / 4, fbins = 1 << fused_bits;
+    HIP_OR_FAIL(e, e->sort_hist.ensure(sizeof(unsigned) * (size_t)fbins * (size_t)(fwaves + fwgs)));
+    unsigned* fhist = e->sort_hist.as<unsigned>();
+    unsigned* fhist_wg = fhist + (size_t)fbins * fwaves;
+    for (int pass = 0; pass < 2; pass++) {
+      const int in = pass & 1, out = in ^ 1;
+      const int shift = 27 - (2 - pass) * fused_bits;
+      const bool first = pass == 0, last = pass == 1;
+      const float4* kp = first ? c.pts.as<float4>() : nullptr;  // first stage: keys computed on the way
+      const int* iin = first ? nullptr : e->sort_idx.as<int>();              // (first pass: the identity)
+      int* iout = first ? e->sort_idx.as<int>() : c.order.as<int>();         // the final permutation lands in the cloud's own buffer
+      const float4* gp = last ? c.pts.as<float4>() : nullptr;
+      float4* sp = last ? c.sorted.as<float4>() : nullptr;
+      if (fused_bits == 9) {
+        radix_hist_fused_kernel<9><<<fwgs, 256, 0, e->stream>>>(keys[in], n, shift, fwaves, fhist, fhist_wg, kp, box, packed_box ? 1 : 0);
+        radix_scatter_fused_kernel<9><<<fwgs, 256, 0, e->stream>>>(keys[in], iin, n, shift, fwaves, fhist, fhist_wg, keys[out], iout, gp, sp);
+      } else {
+        radix_hist_fused_kernel<10><<<fwgs, 256, 0, e->stream>>>(keys[in], n, shift, fwaves, fhist, fhist_wg, kp, box, packed_box ? 1 : 0);
+        radix_scatter_fused_kernel<10><<<fwgs, 256, 0, e->stream>>>(keys[in], iin, n, shift, fwaves, fhist, fhist_wg, keys[out], iout, gp, sp);
+      }
+    }
+    const int nsuper = (ntiles + 63) / 64;
+    HIP_OR_FAIL(e, c.bbox2.ensure(sizeof(float4) * 2 * (size_t)nsuper));
+    const int tile_wgs = (ntiles + 3) / 4;
+    tile_super_bbox_kernel<<<tile_wgs + nsuper, 256, 0, e->stream>>>(c.sorted.as<float4>(), n, c.bbox.as<float4>(), c.bbox2.as<float4>(), tile_wgs, packed_box ? c.box.as<unsigned>() : nullptr);
+    HIP_OR_FAIL(e, hipGetLastError());
+    if (packed_box) { c.has_box = false; c.box_dirty = false; }
+    c.has_sorted = true;
+    return FVH_OK;
+  }
   static const int two_pass_max = [] { const char* v = getenv("FVH_SORT_TWO_PASS_MAX"); return v ? atoi(v) : 262144; }();
   const bool two_pass = n <= two_pass_max;
   const int passes = two_pass ? 2 : RADIX_PASSES, bits = two_pass ? 11 : RADIX_BITS, bins = 1 << bits;
@@ -2027,6 +2061,19 @@ int fvh_vgicp_debug_get_map_shard(fvh_vgicp* h, int* is_shard, int* fallbacks) {
   CHECK_HANDLE(h);
   if (is_shard) *is_shard = h->voxelmap.valid && h->voxelmap.is_shard ? 1 : 0;
   if (fallbacks) *fallbacks = h->shard_fallbacks;
+  return FVH_OK;
+}
+int fvh_vgicp_debug_get_spatial_order(fvh_vgicp* h, int which, int* order, float* tile_boxes) {
+  CHECK_HANDLE(h);
+  Engine* e = &h->e;
+  CloudDev& c = which ? h->target : h->source;
+  if (!c.has_pts) return e->fail(FVH_ERR_BAD_STATE, "debug_get_spatial_order: cloud not set");
+  int rc = ensure_sorted(e, c);
+  if (rc) return rc;
+  if (c.n == 0) return FVH_OK;
+  if (order) HIP_OR_FAIL(e, hipMemcpyAsync(order, c.order.p, sizeof(int) * (size_t)c.n, hipMemcpyDeviceToHost, e->stream));
+  if (tile_boxes) HIP_OR_FAIL(e, hipMemcpyAsync(tile_boxes, c.bbox.p, sizeof(float4) * 2 * (size_t)((c.n + 63) / 64), hipMemcpyDeviceToHost, e->stream));
+  HIP_OR_FAIL(e, hipStreamSynchronize(e->stream));
   return FVH_OK;
 }
 int fvh_vgicp_swap_source_and_target(fvh_vgicp* h) {

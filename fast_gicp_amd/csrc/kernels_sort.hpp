@@ -221,6 +221,178 @@ __global__ __launch_bounds__(256) void radix_scatter_kernel(const unsigned* __re
 
 
 // ------------------------------------------------------------------------------------------------
+// Mid-size clouds (SORT_SMALL_MAX < n <= SORT_FUSED_MAX, e.g. the 100k-point scans of configs[2] / [4]): TWO launches per pass.
+// The four-launch pass above spends two launches (radix_binscan, radix_scan: ~7 + ~5 us + their gaps) on a few microseconds of
+// prefix arithmetic whose input is small: with 2,048 points per workgroup a 100k-point cloud is 49 workgroups, i.e. 49 rows of
+// per-workgroup digit counts. The histogram kernel writes those rows ([workgroup][bin], next to the per-wave rows [wave][bin]) and
+// every workgroup of the scatter derives its own cursors from them -- bin totals -> exclusive scan in LDS, + the rows of the
+// earlier workgroups, + its own earlier waves -- exactly as the ApproximateVoxelGrid chain does (kernels_downsample.hpp, round 4).
+// No in-kernel hand-off, no co-residency requirement. Two passes over the top 2 x BITS bits of the 27-bit key.
+// ------------------------------------------------------------------------------------------------
+constexpr int SORT_FUSED_MAX = 262144;
+constexpr int SORT_FUSED_ITEMS = 512, SORT_FUSED_ROUNDS = SORT_FUSED_ITEMS / 64;  // points per wave (2,048 per workgroup)
+constexpr int SORT_FUSED_MAX_WGS = SORT_FUSED_MAX / (4 * SORT_FUSED_ITEMS);        // 128 rows at most
+
+template <int BITS>
+__global__ __launch_bounds__(256) void radix_hist_fused_kernel(unsigned* __restrict__ keys, int n, int shift, int nwaves, unsigned* __restrict__ hist /* [nwaves][BINS] */,
+                                                               unsigned* __restrict__ hist_wg /* [workgroups][BINS] */, const float4* __restrict__ pts = nullptr,
+                                                               const unsigned* __restrict__ box = nullptr, int min_inverted = 0) {
+  constexpr int BINS = 1 << BITS;
+  __shared__ unsigned h[4][BINS];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int wave = blockIdx.x * 4 + wv;
+  const int begin = wave * SORT_FUSED_ITEMS, end = min(n, begin + SORT_FUSED_ITEMS);
+  // (a launch of ~200 waves on 256 CUs: one wave's chain of load -> LDS round trips IS the kernel, so all of its keys are fetched first)
+  unsigned k[SORT_FUSED_ROUNDS];
+  if (wave < nwaves) {
+    if (pts) {
+      const MortonFrame f = morton_frame(box, min_inverted);
+      float4 p[SORT_FUSED_ROUNDS];
+#pragma unroll
+      for (int u = 0; u < SORT_FUSED_ROUNDS; u++) p[u] = pts[min(begin + u * 64 + lane, end - 1)];
+#pragma unroll
+      for (int u = 0; u < SORT_FUSED_ROUNDS; u++) {
+        k[u] = morton27(f, p[u]);
+        const int i = begin + u * 64 + lane;
+        if (i < end) keys[i] = k[u];
+      }
+    } else {
+#pragma unroll
+      for (int u = 0; u < SORT_FUSED_ROUNDS; u++) k[u] = keys[min(begin + u * 64 + lane, end - 1)];
+    }
+  }
+  for (int b = lane; b < BINS; b += 64) h[wv][b] = 0;
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  if (wave < nwaves) {
+#pragma unroll
+    for (int u = 0; u < SORT_FUSED_ROUNDS; u++)
+      if (begin + u * 64 + lane < end) atomicAdd(&h[wv][(k[u] >> shift) & (BINS - 1)], 1u);
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    for (int b = lane; b < BINS; b += 64) hist[(size_t)wave * BINS + b] = h[wv][b];
+  }
+  __syncthreads();
+  for (int b = threadIdx.x; b < BINS; b += 256) hist_wg[(size_t)blockIdx.x * BINS + b] = (h[0][b] + h[1][b]) + (h[2][b] + h[3][b]);
+}
+
+template <int BITS>
+__global__ __launch_bounds__(256) void radix_scatter_fused_kernel(const unsigned* __restrict__ keys_in, const int* __restrict__ idx_in /* null: the identity (first pass) */, int n, int shift, int nwaves,
+                                                                  const unsigned* __restrict__ hist /* [nwaves][BINS] */, const unsigned* __restrict__ hist_wg /* [workgroups][BINS] */,
+                                                                  unsigned* __restrict__ keys_out, int* __restrict__ idx_out, const float4* __restrict__ pts, float4* __restrict__ sorted_pts) {
+  constexpr int BINS = 1 << BITS;
+  constexpr int PER = BINS / 64;       // consecutive bins a lane takes of a row
+  constexpr int BATCH = 32 / PER;      // rows a wave keeps in flight (32 values per lane)
+  static_assert(PER % 4 == 0 && BATCH >= 1, "a lane reads whole 16-byte groups of a row");
+  __shared__ unsigned cur[4][BINS];
+  __shared__ unsigned s_pt[4][BINS], s_pb[4][BINS], s_tot[BINS], s_base[BINS], s_w[4];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, t = threadIdx.x;
+  const int wave = blockIdx.x * 4 + wv;
+  const int begin = wave * SORT_FUSED_ITEMS, end = min(n, begin + SORT_FUSED_ITEMS);
+  // this wave's keys and indices, in flight while the cursors are derived
+  unsigned key[SORT_FUSED_ROUNDS];
+  int id[SORT_FUSED_ROUNDS];
+  if (wave < nwaves) {
+#pragma unroll
+    for (int u = 0; u < SORT_FUSED_ROUNDS; u++) {
+      const int i = min(begin + u * 64 + lane, end - 1);
+      key[u] = keys_in[i];
+      id[u] = idx_in ? idx_in[i] : i;
+    }
+  }
+  {
+    const int nwg = (int)gridDim.x, me = (int)blockIdx.x;
+    unsigned tot[PER], bef[PER];
+#pragma unroll
+    for (int q = 0; q < PER; q++) { tot[q] = 0; bef[q] = 0; }
+    for (int g0 = wv; g0 < nwg; g0 += 4 * BATCH) {  // the rows of all workgroups, dealt to the four waves
+      uint4 a[BATCH][PER / 4];
+#pragma unroll
+      for (int u = 0; u < BATCH; u++) {
+        const int g = min(g0 + 4 * u, nwg - 1);
+        const uint4* row = reinterpret_cast<const uint4*>(hist_wg + (size_t)g * BINS) + lane * (PER / 4);
+#pragma unroll
+        for (int q = 0; q < PER / 4; q++) a[u][q] = row[q];
+      }
+#pragma unroll
+      for (int u = 0; u < BATCH; u++) {
+        const int g = g0 + 4 * u;
+        if (g < nwg) {
+          const bool before = g < me;
+#pragma unroll
+          for (int q = 0; q < PER / 4; q++) {
+            const unsigned v[4] = {a[u][q].x, a[u][q].y, a[u][q].z, a[u][q].w};
+#pragma unroll
+            for (int c = 0; c < 4; c++) { tot[4 * q + c] += v[c]; bef[4 * q + c] += before ? v[c] : 0u; }
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < PER; q++) { s_pt[wv][lane * PER + q] = tot[q]; s_pb[wv][lane * PER + q] = bef[q]; }
+    __syncthreads();
+    for (int b = t; b < BINS; b += 256) s_tot[b] = (s_pt[0][b] + s_pt[1][b]) + (s_pt[2][b] + s_pt[3][b]);
+    __syncthreads();
+    {  // exclusive scan of the BINS totals: every wave scans a quarter, the quarters meet through s_w
+      constexpr int QPER = BINS / 256;  // consecutive totals per thread
+      unsigned v[QPER], sum = 0;
+#pragma unroll
+      for (int q = 0; q < QPER; q++) { v[q] = s_tot[t * QPER + q]; sum += v[q]; }
+      unsigned x = sum;
+#pragma unroll
+      for (int off = 1; off < 64; off <<= 1) { const unsigned y = __shfl_up(x, off); if (lane >= off) x += y; }
+      if (lane == 63) s_w[wv] = x;
+      __syncthreads();
+      unsigned run = x - sum;
+      for (int w = 0; w < wv; w++) run += s_w[w];
+#pragma unroll
+      for (int q = 0; q < QPER; q++) { s_base[t * QPER + q] = run; run += v[q]; }
+    }
+    __syncthreads();
+    for (int b = t; b < BINS; b += 256) {
+      unsigned c = s_base[b] + ((s_pb[0][b] + s_pb[1][b]) + (s_pb[2][b] + s_pb[3][b]));
+#pragma unroll
+      for (int w = 0; w < 4; w++) {
+        cur[w][b] = c;
+        const int gw = me * 4 + w;
+        if (gw < nwaves) c += hist[(size_t)gw * BINS + b];
+      }
+    }
+    __syncthreads();
+  }
+  if (wave >= nwaves) return;
+  const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+#pragma unroll
+  for (int u = 0; u < SORT_FUSED_ROUNDS; u++) {
+    if (begin + u * 64 >= end) break;  // wave-uniform
+    const bool valid = begin + u * 64 + lane < end;
+    const unsigned d = (key[u] >> shift) & (BINS - 1);
+    unsigned long long peers = __ballot(valid);
+#pragma unroll
+    for (int bit = 0; bit < BITS; bit++) {
+      const unsigned long long m = __ballot((d >> bit) & 1);
+      peers &= ((d >> bit) & 1) ? m : ~m;
+    }
+    const int rank = __popcll(peers & lt_mask);
+    const int leader = __ffsll((long long)peers) - 1;
+    unsigned dst_base = 0;
+    if (valid && lane == leader) {
+      dst_base = cur[wv][d];
+      cur[wv][d] = dst_base + (unsigned)__popcll(peers);
+    }
+    dst_base = __shfl(dst_base, leader);
+    if (valid) {
+      const unsigned dst = dst_base + rank;
+      keys_out[dst] = key[u];
+      idx_out[dst] = id[u];
+      if (sorted_pts) {
+        float4 p = pts[id[u]];
+        p.w = __int_as_float(id[u]);
+        sorted_pts[dst] = p;
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // Small clouds (n <= SORT_SMALL_MAX): the whole ordering in ONE launch of ONE 1024-thread workgroup.
 // The multi-kernel path above costs ~105 us at 17k points -- nine dependent launches of a handful of
 // waves each, plus a 512 x n_waves histogram matrix to scan -- where the actual work is a few

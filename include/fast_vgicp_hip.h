@@ -228,6 +228,10 @@ int fvh_vgicp_peer_selfcheck(fvh_vgicp* h, double timeout_seconds, int* missing_
  * replicated, not for speed. The host-driven calls (update_correspondences / compute_error) keep using the replicated map. */
 int fvh_vgicp_set_target_map_sharding(fvh_vgicp* h, int on, int margin_voxels);
 int fvh_vgicp_debug_get_map_shard(fvh_vgicp* h, int* live_map_is_a_shard, int* aligns_redone_on_the_full_map);
+/* test hook: the spatial (Morton) order of a cloud -- order[j] = original index of the j-th point of the sorted cloud (n ints) -- and the
+ * boxes of its 64-point tiles (8 floats per tile: min xyz 0, max xyz 0). which: 0 source, 1 target. Sorts the cloud if it is not sorted yet.
+ * No reference counterpart (the order is this engine's own device for culling the exact searches and for the multi-GPU tiles). */
+int fvh_vgicp_debug_get_spatial_order(fvh_vgicp* h, int which, int* order, float* tile_boxes);
 
 /* ---------------------------------------------------------------------------------------------
  * NDTCudaCore

@@ -1,0 +1,57 @@
+"""The spatial (Morton) order every exact search of the engine is culled by, checked DIRECTLY (the k-NN tests only notice a broken order
+through wrong neighbour lists -- a valid but unsorted permutation would pass them, slowly): order[] is a permutation; the keys of the sorted
+cloud are non-decreasing in the bits the route sorts by, with ties in original-index order (stable LSD passes); the 64-point tile boxes are
+the min / max of their points. One case per route: cooperative kernel / its one-workgroup fall-back (n <= 32,768), the two-launch passes
+(<= 262,144), the four-launch passes above that."""
+import numpy as np
+import pytest
+
+from tests import util
+
+pytestmark = pytest.mark.gpu
+
+
+def _spread(v, bits):
+    out = np.zeros_like(v)
+    for b in range(bits):
+        out |= ((v >> b) & 1) << (3 * b)
+    return out
+
+
+def _keys(pts, axis_bits):
+    """kernels_sort.hpp: morton27 (9 bits per axis, large clouds) / the small sorts' 6 bits per axis, on the cloud's bounding cube"""
+    lo = pts.min(0)
+    extent = np.float32(max((pts.max(0) - lo).max(), np.float32(1e-6)))
+    qmax = np.float32((1 << axis_bits) - 1)
+    scale = np.float32(np.float32(511.999) / extent) if axis_bits == 9 else np.float32((qmax + np.float32(0.999)) / extent)
+    q = np.minimum(qmax, np.maximum(np.float32(0), (pts - lo) * scale)).astype(np.int64)
+    return _spread(q[:, 0], axis_bits) | (_spread(q[:, 1], axis_bits) << 1) | (_spread(q[:, 2], axis_bits) << 2)
+
+
+@pytest.mark.parametrize("n, key_bits, sorted_bits", [
+    (1000, 18, 18), (17334, 18, 18), (32768, 18, 18),          # one launch (cooperative) or one workgroup
+    (32769, 27, 20), (100000, 27, 20), (262144, 27, 20),       # two launches per pass, top 2 x 10 bits of the 27-bit key
+    (262145, 27, 27),                                          # four launches per pass, three 9-bit passes
+])
+def test_order_is_a_stable_morton_sort_and_tiles_are_boxed(n, key_bits, sorted_bits):
+    import os
+    from fast_gicp_amd import capi
+    if sorted_bits == 20 and os.environ.get("FVH_SORT_FUSED_BITS"):  # (A/B knob of the two-launch passes: 9 -> 18 bits, 0 -> the four-launch passes' 22)
+        sorted_bits = {"9": 18, "10": 20, "0": 22}[os.environ["FVH_SORT_FUSED_BITS"]]
+    rng = np.random.default_rng(n)
+    pts = (rng.normal(size=(n, 3)) * np.array([20.0, 20.0, 2.0])).astype(np.float32)
+    pts[: n // 8] = np.round(pts[: n // 8])  # many equal keys and equal points: stability is visible
+    c = capi.VGICPCore(0)
+    c.set_source_cloud(pts)
+    order, boxes = c.debug_spatial_order("source")
+    assert np.array_equal(np.sort(order), np.arange(n))
+    k = _keys(pts, key_bits // 3)[order] >> (key_bits - sorted_bits)
+    d = np.diff(k)
+    assert (d >= 0).all(), "keys of the sorted cloud decrease at %d positions" % int((d < 0).sum())
+    ties = d == 0
+    assert (np.diff(order.astype(np.int64))[ties] > 0).all(), "equal keys are not in original-index order"
+    sp = pts[order]
+    pad = (-n) % 64
+    full = np.concatenate([sp, np.repeat(sp[-1:], pad, 0)]).reshape(-1, 64, 3)
+    assert np.array_equal(boxes[:, 0:3], full.min(1)) and np.array_equal(boxes[:, 4:7], full.max(1))
+    c.close()
