@@ -280,10 +280,15 @@ __global__ __launch_bounds__(256) void radix_scatter_fused_kernel(const unsigned
                                                                   unsigned* __restrict__ keys_out, int* __restrict__ idx_out, const float4* __restrict__ pts, float4* __restrict__ sorted_pts) {
   constexpr int BINS = 1 << BITS;
   constexpr int PER = BINS / 64;       // consecutive bins a lane takes of a row
-  constexpr int BATCH = 32 / PER;      // rows a wave keeps in flight (32 values per lane)
+#ifndef FVH_SORT_FUSED_BATCH_VALUES
+#define FVH_SORT_FUSED_BATCH_VALUES 64  // (32 / 64 values per lane in flight: sort stage 47.0 / 44.4 us at 100k points)
+#endif
+  constexpr int BATCH = FVH_SORT_FUSED_BATCH_VALUES / PER;  // rows a wave keeps in flight
+  constexpr int PSTRIDE = 65;          // partial sums of (lane, q) live at q * 65 + lane: conflict-free for the lanes' writes AND the per-bin reads
+  auto pidx = [](int b) { return (b % PER) * PSTRIDE + b / PER; };
   static_assert(PER % 4 == 0 && BATCH >= 1, "a lane reads whole 16-byte groups of a row");
   __shared__ unsigned cur[4][BINS];
-  __shared__ unsigned s_pt[4][BINS], s_pb[4][BINS], s_tot[BINS], s_base[BINS], s_w[4];
+  __shared__ unsigned s_pt[4][PER * 65], s_pb[4][PER * 65], s_tot[BINS], s_base[BINS], s_w[4];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, t = threadIdx.x;
   const int wave = blockIdx.x * 4 + wv;
   const int begin = wave * SORT_FUSED_ITEMS, end = min(n, begin + SORT_FUSED_ITEMS);
@@ -297,6 +302,11 @@ __global__ __launch_bounds__(256) void radix_scatter_fused_kernel(const unsigned
       key[u] = keys_in[i];
       id[u] = idx_in ? idx_in[i] : i;
     }
+  }
+  float4 gp[SORT_FUSED_ROUNDS];  // last pass: the points themselves (scattered 16-byte reads), in flight beside the rows below
+  if (sorted_pts && wave < nwaves) {
+#pragma unroll
+    for (int u = 0; u < SORT_FUSED_ROUNDS; u++) { const float4 q = pts[id[u]]; gp[u] = make_float4(q.x, q.y, q.z, __int_as_float(id[u])); }  // (built whole: a later `.w =` pins the array in memory)
   }
   {
     const int nwg = (int)gridDim.x, me = (int)blockIdx.x;
@@ -327,9 +337,9 @@ __global__ __launch_bounds__(256) void radix_scatter_fused_kernel(const unsigned
       }
     }
 #pragma unroll
-    for (int q = 0; q < PER; q++) { s_pt[wv][lane * PER + q] = tot[q]; s_pb[wv][lane * PER + q] = bef[q]; }
+    for (int q = 0; q < PER; q++) { s_pt[wv][q * PSTRIDE + lane] = tot[q]; s_pb[wv][q * PSTRIDE + lane] = bef[q]; }
     __syncthreads();
-    for (int b = t; b < BINS; b += 256) s_tot[b] = (s_pt[0][b] + s_pt[1][b]) + (s_pt[2][b] + s_pt[3][b]);
+    for (int b = t; b < BINS; b += 256) { const int j = pidx(b); s_tot[b] = (s_pt[0][j] + s_pt[1][j]) + (s_pt[2][j] + s_pt[3][j]); }
     __syncthreads();
     {  // exclusive scan of the BINS totals: every wave scans a quarter, the quarters meet through s_w
       constexpr int QPER = BINS / 256;  // consecutive totals per thread
@@ -348,7 +358,8 @@ __global__ __launch_bounds__(256) void radix_scatter_fused_kernel(const unsigned
     }
     __syncthreads();
     for (int b = t; b < BINS; b += 256) {
-      unsigned c = s_base[b] + ((s_pb[0][b] + s_pb[1][b]) + (s_pb[2][b] + s_pb[3][b]));
+      const int j = pidx(b);
+      unsigned c = s_base[b] + ((s_pb[0][j] + s_pb[1][j]) + (s_pb[2][j] + s_pb[3][j]));
 #pragma unroll
       for (int w = 0; w < 4; w++) {
         cur[w][b] = c;
@@ -361,32 +372,29 @@ __global__ __launch_bounds__(256) void radix_scatter_fused_kernel(const unsigned
   if (wave >= nwaves) return;
   const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
 #pragma unroll
-  for (int u = 0; u < SORT_FUSED_ROUNDS; u++) {
-    if (begin + u * 64 >= end) break;  // wave-uniform
+  for (int u = 0; u < SORT_FUSED_ROUNDS; u++) {  // (no early exit: a `break` keeps the loop rolled and sends key / id / gp to memory)
     const bool valid = begin + u * 64 + lane < end;
     const unsigned d = (key[u] >> shift) & (BINS - 1);
     unsigned long long peers = __ballot(valid);
+    if (peers) {  // wave-uniform
 #pragma unroll
-    for (int bit = 0; bit < BITS; bit++) {
-      const unsigned long long m = __ballot((d >> bit) & 1);
-      peers &= ((d >> bit) & 1) ? m : ~m;
-    }
-    const int rank = __popcll(peers & lt_mask);
-    const int leader = __ffsll((long long)peers) - 1;
-    unsigned dst_base = 0;
-    if (valid && lane == leader) {
-      dst_base = cur[wv][d];
-      cur[wv][d] = dst_base + (unsigned)__popcll(peers);
-    }
-    dst_base = __shfl(dst_base, leader);
-    if (valid) {
-      const unsigned dst = dst_base + rank;
-      keys_out[dst] = key[u];
-      idx_out[dst] = id[u];
-      if (sorted_pts) {
-        float4 p = pts[id[u]];
-        p.w = __int_as_float(id[u]);
-        sorted_pts[dst] = p;
+      for (int bit = 0; bit < BITS; bit++) {
+        const unsigned long long m = __ballot((d >> bit) & 1);
+        peers &= ((d >> bit) & 1) ? m : ~m;
+      }
+      const int rank = __popcll(peers & lt_mask);
+      const int leader = __ffsll((long long)peers) - 1;
+      unsigned dst_base = 0;
+      if (valid && lane == leader) {
+        dst_base = cur[wv][d];
+        cur[wv][d] = dst_base + (unsigned)__popcll(peers);
+      }
+      dst_base = __shfl(dst_base, valid ? leader : 0);
+      if (valid) {
+        const unsigned dst = dst_base + rank;
+        keys_out[dst] = key[u];
+        idx_out[dst] = id[u];
+        if (sorted_pts) sorted_pts[dst] = gp[u];
       }
     }
   }
