@@ -1394,6 +1394,11 @@ __global__ FVH_COST_BOUNDS void cost_kernel(CostParams P) {
           if (lane >= PART_STRIDE) pend = 0;
           const double want = want_tag_of();
           const unsigned long long t0 = wall_clock64();
+#ifndef FVH_EVERYWHERE_FIRST_SLEEP
+#define FVH_EVERYWHERE_FIRST_SLEEP 0  // (0 / 16 / 32 / 48 / 64 measured: 122.2 - 123.1 us at 17k, 78.4 - 79.5 us NDT: the early polls cost nothing)
+#endif
+          // (lm_everywhere: a non-collector's group rows cannot be complete sooner than a collection + a hand-off after its own row)
+          if (!collector && FVH_EVERYWHERE_FIRST_SLEEP) __builtin_amdgcn_s_sleep(FVH_EVERYWHERE_FIRST_SLEEP);
           while (__builtin_amdgcn_ballot_w64(pend != 0u) != 0ull) {
             pair_t pv[8];
             load_pairs8_agent(pv, src);
