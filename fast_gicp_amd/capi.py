@@ -236,6 +236,15 @@ def debug_slot_pool(device=0):
     return r.value, a.value, c.value
 
 
+def debug_sort_routes():
+    """[cooperative, one workgroup, two-launch passes, four-launch passes]: Morton sorts queued by this process so far, per route"""
+    a = (C.c_int * 4)()
+    rc = load().fvh_debug_sort_routes(a)
+    if rc != 0:
+        raise FvhError("fvh_debug_sort_routes: status %d" % rc)
+    return list(a)
+
+
 def debug_xcd_local():
     """(wanted, placement_aborts): whether persistent launches still use XCD-local hand-offs, and how many launches the placement check ended."""
     w, a = C.c_int(0), C.c_int(0)

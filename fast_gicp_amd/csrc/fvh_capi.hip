@@ -148,9 +148,11 @@ Rccl g_rccl;
 std::atomic<int> g_live_engines{0};    // engine handles alive in this process that can launch gang kernels (registration handles)
 // When each of them last queued a gang kernel (cooperative sort, persistent LM kernel), by handle number mod 64. Two gang kernels from
 // two streams could starve each other of CU slots (the watchdogs + fall-backs recover, slowly): the cooperative sort is used while no
-// OTHER handle has been busy within the window -- a second handle that merely exists (the reference's align.cpp keeps its NDT object
-// alive while the VGICP rows run) no longer costs the VGICP handle 38 us per registration.
+// OTHER handle has a gang kernel in flight: queued within the window and not yet followed by an align that returned (which drains the
+// handle's stream and clears its stamp). A second handle that merely exists (the reference's align.cpp keeps its NDT object alive while
+// the VGICP rows run), or one that the same thread uses in turn, no longer costs the VGICP handle 38 us per registration.
 std::atomic<long long> g_gang_stamp_ns[64];
+std::atomic<int> g_sort_routes[4];  // sorts queued by this process: cooperative kernel, one workgroup, two-launch passes, four-launch passes (fvh_debug_sort_routes)
 std::atomic<int> g_engine_numbers{0};
 inline long long steady_ns() { return std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 inline bool other_gang_recent(int me, long long window_ns) {
@@ -479,6 +481,7 @@ struct Engine {
   bool counted = false;
   int gang_id = 0;
   void gang_stamp() { if (counted) g_gang_stamp_ns[gang_id].store(steady_ns(), std::memory_order_relaxed); }
+  void gang_clear() { if (counted) g_gang_stamp_ns[gang_id].store(0, std::memory_order_relaxed); }  // the caller holds the result of an align: nothing of this handle is in flight
   hipStream_t owned_stream = nullptr;  // the stream init() made; `stream` may be another handle's (fvh_voxelgrid_share_stream_*)
   void shutdown() {
     if (stream != owned_stream) stream = owned_stream;  // a borrowed stream is its owner's to drain and destroy
@@ -676,6 +679,7 @@ int ensure_sorted(Engine* e, CloudDev& c) {
     static const long long gang_window_ns = [] { const char* v = getenv("FVH_GANG_WINDOW_MS"); return (long long)(v ? atof(v) : 20.0) * 1000000ll; }();
     const bool coop = c.has_box && ((sort_mode == 2 && (g_live_engines.load() == 1 || !other_gang_recent(e->gang_id, gang_window_ns))) || sort_mode == 3);
     e->gang_stamp();
+    g_sort_routes[coop ? 0 : 1].fetch_add(1, std::memory_order_relaxed);
     if (coop) {
       const bool fresh = e->sort_coop.p == nullptr;
       HIP_OR_FAIL(e, e->sort_coop.ensure(COOP_STATE_BYTES));
@@ -720,6 +724,7 @@ int ensure_sorted(Engine* e, CloudDev& c) {
   // Up to SORT_FUSED_MAX points: two launches per pass (kernels_sort.hpp: the scatter derives its cursors from per-workgroup digit counts),
   // two passes over the top 2 x FVH_SORT_FUSED_BITS bits of the key. 100k points: 71 us in nine launches -> see profiles/r04_sort_fused.txt.
   static const int fused_bits = [] { const char* v = getenv("FVH_SORT_FUSED_BITS"); const int b = v ? atoi(v) : 10; return (b == 9 || b == 10) ? b : 0; }();  // 0: the four-launch passes below. (9: the sort is 8 us shorter and the exact k-NN behind it 14 us longer -- coarser cells, looser tiles)
+  g_sort_routes[(fused_bits && n <= SORT_FUSED_MAX) ? 2 : 3].fetch_add(1, std::memory_order_relaxed);
   if (fused_bits && n <= SORT_FUSED_MAX) {
     const int fwaves = (n + SORT_FUSED_ITEMS - 1) / SORT_FUSED_ITEMS, fwgs = (fwaves + 3) / 4, fbins = 1 << fused_bits;
     HIP_OR_FAIL(e, e->sort_hist.ensure(sizeof(unsigned) * (size_t)fbins * (size_t)(fwaves + fwgs)));
@@ -1486,6 +1491,7 @@ int do_align(Engine* e, const CostSource& src, VoxelMapDev& vm, const double* gu
     if (rc) return rc;
     return do_align<MODE>(e, src, vm, guess16, params, result, rebuild_safe, true, no_persist, forced_plan);
   }
+  e->gang_clear();
   e->prev_steps = e->last_steps;
   e->last_steps = 1 + h->num_error_evals;  // launches this align needed: the first linearize + one fused launch per trial
   e->lin = h->x_lin;
@@ -2210,7 +2216,9 @@ int fvh_vgicp_gicp_update_correspondences(fvh_vgicp* h, const double* T) {
 }
 int fvh_vgicp_gicp_align(fvh_vgicp* h, const double* guess, const fvh_lm_params* p, fvh_lm_result* r) {
   CHECK_HANDLE(h);
-  return gicp_align(&h->e, h->source, h->target, h->gicp_records, h->gicp_cost_source(true), h->gicp_max_dist, guess, p, r);
+  const int rc = gicp_align(&h->e, h->source, h->target, h->gicp_records, h->gicp_cost_source(true), h->gicp_max_dist, guess, p, r);
+  if (rc == FVH_OK) h->e.gang_clear();  // (the result came back through a stream synchronisation)
+  return rc;
 }
 int fvh_vgicp_gicp_compute_error(fvh_vgicp* h, const double* T, double* H, double* b, double* err) {
   CHECK_HANDLE(h);
@@ -2287,6 +2295,11 @@ int fvh_vgicp_debug_get_persist_grid(fvh_vgicp* h, int* blocks, int* capacity) {
   if (capacity) *capacity = persistent_capacity<MODE_VGICP>(&h->e);
   return FVH_OK;
 }
+int fvh_debug_sort_routes(int* counts4) {
+  if (!counts4) return FVH_ERR_INVALID_ARGUMENT;
+  for (int i = 0; i < 4; i++) counts4[i] = g_sort_routes[i].load();
+  return FVH_OK;
+}
 int fvh_debug_xcd_local(int* wanted, int* placement_aborts) {
   if (wanted) *wanted = xcd_local_wanted() ? 1 : 0;
   if (placement_aborts) *placement_aborts = g_xcd_local_strikes.load();
@@ -2309,7 +2322,7 @@ int fvh_vgicp_debug_get_skipped_points(fvh_vgicp* h, int* n) {
   HIP_OR_FAIL(&h->e, hipStreamSynchronize(h->e.stream));
   return FVH_OK;
 }
-int fvh_vgicp_synchronize(fvh_vgicp* h) { CHECK_HANDLE(h); HIP_OR_FAIL(&h->e, hipStreamSynchronize(h->e.stream)); return FVH_OK; }
+int fvh_vgicp_synchronize(fvh_vgicp* h) { CHECK_HANDLE(h); HIP_OR_FAIL(&h->e, hipStreamSynchronize(h->e.stream)); h->e.gang_clear(); return FVH_OK; }
 
 #ifdef FVH_KNN_TIMING
 int fvh_debug_knn_timing(unsigned long long* out) { return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_knn_time), sizeof(unsigned long long) * 32768 * 8) == hipSuccess ? FVH_OK : FVH_ERR_HIP; }
@@ -2594,7 +2607,7 @@ int fvh_ndt_get_voxel_correspondences(fvh_ndt* h, int* pairs) {
 int fvh_ndt_profile_enable(fvh_ndt* h, int on) { CHECK_HANDLE(h); h->e.prof.on = on != 0; h->e.prof.cost_only = on == 2; return FVH_OK; }
 int fvh_ndt_profile_reset(fvh_ndt* h) { CHECK_HANDLE(h); HIP_OR_FAIL(&h->e, hipStreamSynchronize(h->e.stream)); h->e.prof.reset(); return FVH_OK; }
 int fvh_ndt_profile_get(fvh_ndt* h, const char* cls, double* ms, int* n) { CHECK_HANDLE(h); return profile_get(&h->e, cls, ms, n); }
-int fvh_ndt_synchronize(fvh_ndt* h) { CHECK_HANDLE(h); HIP_OR_FAIL(&h->e, hipStreamSynchronize(h->e.stream)); return FVH_OK; }
+int fvh_ndt_synchronize(fvh_ndt* h) { CHECK_HANDLE(h); HIP_OR_FAIL(&h->e, hipStreamSynchronize(h->e.stream)); h->e.gang_clear(); return FVH_OK; }
 int fvh_ndt_comm_init(fvh_ndt* h, const void* id, int nranks, int rank) { CHECK_HANDLE(h); return comm_init(&h->e, id, nranks, rank); }
 int fvh_ndt_comm_destroy(fvh_ndt* h) { CHECK_HANDLE(h); if (h->e.comm) { g_rccl.CommDestroy(h->e.comm); h->e.comm = nullptr; } h->e.nranks = 1; h->e.rank = 0; return FVH_OK; }
 

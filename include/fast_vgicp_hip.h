@@ -182,6 +182,9 @@ int fvh_debug_slot_pool(int device, int* reserved, int* active, int* recent);   
 /* persistent LM kernel, XCD-local hand-offs (kernels_cost.hpp): *wanted = 1 while the process still asks for them, *placement_aborts =
  * launches that ended because the dispatcher had not placed the workgroups of a group on one XCD (3 of those switch the flavour off) */
 int fvh_debug_xcd_local(int* wanted, int* placement_aborts);
+/* test hook: how many Morton sorts this process has queued on each route -- {cooperative kernel, one workgroup, two-launch radix passes,
+ * four-launch radix passes}. (The cooperative kernel is a gang kernel: it is not used while ANOTHER registration handle has one in flight.) */
+int fvh_debug_sort_routes(int* counts4);
 
 /* new: multi-GPU over RCCL (one process per GPU). With a communicator attached a VGICP handle shards INTERNALLY, like the peer path below:
  * every rank makes the same calls on the same FULL clouds; neighbour search and covariance estimation run on the rank's spatial tile (a
