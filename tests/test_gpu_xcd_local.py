@@ -80,3 +80,24 @@ def test_layouts_agree_to_rounding(tmp_path):
                 assert util.rel_err(r[k], runs[0][k]) < 1e-9, k
     # the large grid (DIRECT27 at 17k points: eight groups in every layout) is the same launch in all three
     assert all(np.array_equal(r["vgicp0_T"], runs[0]["vgicp0_T"]) for r in runs[1:])
+
+
+def test_lm_step_on_every_workgroup_gives_the_collectors_bits(tmp_path):
+    """CostParams::lm_everywhere (default on grids of <= 2 workgroups per CU): every workgroup polls the group rows and runs the LM step on its
+    own copy of the state instead of waiting for a collector's broadcast. Same sums, same instructions: identical poses and Hessians to the
+    collectors-only protocol (FVH_LM_EVERYWHERE=0) and to the always-on flavour (=2), for VGICP (474 and 68 workgroups) and NDT P2D; NDT D2D
+    to rounding (two processes, two map builds: see above). The single-level flavour (every workgroup adds ALL rows) is held to the same."""
+    a = _run(tmp_path, "rule")
+    for name, env in (("never", dict(FVH_LM_EVERYWHERE="0")), ("always", dict(FVH_LM_EVERYWHERE="2")),
+                      ("single", dict(FVH_SMALL_GRID_LAYOUT="0", FVH_LM_EVERYWHERE_SINGLE="1"))):
+        b = _run(tmp_path, name, **env)
+        assert tuple(b["xcd_local"])[1] == 0
+        for k in a.files:
+            if k == "xcd_local" or k.endswith("_grid"):
+                continue
+            if name == "single" and not k.startswith("vgicp0"):  # another layout for the small grids: another order of the sums
+                assert util.rel_err(a[k], b[k]) < 1e-9, (name, k)
+            elif k.startswith("ndt1"):
+                assert util.rel_err(a[k], b[k]) < 1e-12, (name, k)
+            else:
+                assert np.array_equal(a[k], b[k]), (name, k)
