@@ -864,7 +864,7 @@ def run_registration(args, workload, cov, search_name, steps, warmup, local_rank
         el_h = time.perf_counter() - t1
         state["host"] = False
         host_leg = {"value": round(steps / el_h, 3), "unit": "registrations/sec", "ms_per_step": round(el_h / steps * 1e3, 5),
-                    "note": "same loop, source cloud handed over as a HOST buffer every registration (fvh_vgicp_set_source_cloud: one %d-byte H2D + stream sync inside the step), as src/align.cpp:94-96 does"
+                    "note": "same loop, source cloud handed over as a HOST buffer every registration (fvh_vgicp_set_source_cloud: %d bytes copied into the handle's pinned staging buffer and read from there by the widening kernel over PCIe), as src/align.cpp:94-96 does"
                             % (n_pts[1] * 12)}
     if rank != 0:
         core.close()
