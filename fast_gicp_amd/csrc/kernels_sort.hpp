@@ -230,7 +230,10 @@ __global__ __launch_bounds__(256) void radix_scatter_kernel(const unsigned* __re
 // No in-kernel hand-off, no co-residency requirement. Two passes over the top 2 x BITS bits of the 27-bit key.
 // ------------------------------------------------------------------------------------------------
 constexpr int SORT_FUSED_MAX = 262144;
-constexpr int SORT_FUSED_ITEMS = 512, SORT_FUSED_ROUNDS = SORT_FUSED_ITEMS / 64;  // points per wave (2,048 per workgroup)
+#ifndef FVH_SORT_FUSED_ITEMS
+#define FVH_SORT_FUSED_ITEMS 512  // (256 / 512 / 1024 measured: sort stage 47.7 / 44.5 / 51.5 us at 100k points)
+#endif
+constexpr int SORT_FUSED_ITEMS = FVH_SORT_FUSED_ITEMS, SORT_FUSED_ROUNDS = SORT_FUSED_ITEMS / 64;  // points per wave (2,048 per workgroup)
 constexpr int SORT_FUSED_MAX_WGS = SORT_FUSED_MAX / (4 * SORT_FUSED_ITEMS);        // 128 rows at most
 
 template <int BITS>
