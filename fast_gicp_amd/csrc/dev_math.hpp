@@ -135,16 +135,42 @@ __device__ __forceinline__ Vec3<T> cross(const Vec3<T>& a, const Vec3<T>& b) {
   return c;
 }
 
+// 1 / d, sqrt(x), 1 / sqrt(x) for NORMAL, finite arguments far from the exponent limits: hardware seed + two Newton steps (~1 ulp), without
+// the scaling / fix-up sequences of the IEEE operations (12-20 instructions each). The Jacobi rotations below are a chain of ~2,000
+// DEPENDENT fp64 instructions per matrix (each rotation: three divisions, two square roots); that chain IS the covariance kernel of a
+// 17k-point cloud (9.4 us) and the NDT voxel finalisation (10.7 us) -- these cut it by ~40 %.
+__device__ __forceinline__ double rcp_nr(double d) {
+  double r = __builtin_amdgcn_rcp(d);
+  r = fma(r, fma(-d, r, 1.0), r);
+  r = fma(r, fma(-d, r, 1.0), r);
+  return r;
+}
+__device__ __forceinline__ double rsq_nr(double x) {
+  double y = __builtin_amdgcn_rsq(x);
+  y = fma(0.5 * y, fma(-x * y, y, 1.0), y);
+  y = fma(0.5 * y, fma(-x * y, y, 1.0), y);
+  return y;
+}
+__device__ __forceinline__ double sqrt_nr(double x) {
+  const double y = rsq_nr(x);
+  const double s = x * y;
+  return fma(fma(-s, s, x), 0.5 * y, s);
+}
+
 // Symmetric 3x3 eigen-decomposition, cyclic Jacobi, fp64. Eigenvalues ascending in w,
 // eigenvectors in the COLUMNS of V (row-major V[r*3+c]).
+// A rotation is skipped for |apq| <= 1e-290 (physically zero; keeps the reciprocal seed finite); |theta| > 1e100 -- where
+// sqrt(theta^2 + 1) == |theta| exactly and theta^2 may overflow -- takes t = 1 / (2 theta) through an IEEE division (rare branch).
 __device__ inline void sym_eig3(const Sym3<double>& S, double w[3], double V[9]) {
   double a00 = S.xx, a01 = S.xy, a02 = S.xz, a11 = S.yy, a12 = S.yz, a22 = S.zz;
   double v[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
 #define FVH_JACOBI_ROT(app, aqq, apq, arp, arq, p, q)                                   \
-  if (apq != 0.0) {                                                                      \
-    double theta = (aqq - app) / (2.0 * apq);                                            \
-    double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));    \
-    double c = 1.0 / sqrt(t * t + 1.0), s = t * c;                                       \
+  if (fabs(apq) > 1e-290) {                                                              \
+    const double theta = (aqq - app) * rcp_nr(2.0 * apq);                                \
+    double t;                                                                            \
+    if (!(fabs(theta) <= 1e100)) t = 0.5 / theta;                                        \
+    else { const double rr = rcp_nr(fabs(theta) + sqrt_nr(fma(theta, theta, 1.0))); t = theta >= 0 ? rr : -rr; } \
+    const double c = rsq_nr(fma(t, t, 1.0)), s = t * c;                                  \
     app -= t * apq;                                                                      \
     aqq += t * apq;                                                                      \
     apq = 0.0;                                                                           \
