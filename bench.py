@@ -21,7 +21,11 @@ scaling, no data-path collective); value = registrations of all ranks / max-over
 single-registration path (all-reduce of the normal equations per evaluation) is measured separately and reported under
 "sharded" together with the 1-GPU time of the same registration.
 
-Prints ONE JSON line on rank 0.
+Output (rank 0): the LAST stdout line is ONE compact JSON object (< 4 KB: the contract's keys, `roofline`, `cpu_baseline`, one short
+entry per extra configuration -- compact_line()). The full detail (stages, thread sweeps, notes, per-route sharded detail) goes to
+bench_detail.json beside this script and to stderr, never to stdout.
+The timed region is run REPEATS times (each: exactly --steps steps between barrier + synchronize); `ms_per_step` / `value` are the median
+repeat, min / max are reported beside it.
 """
 import argparse
 import json
@@ -101,6 +105,153 @@ def csrc_sha():
         h.update(f.encode())
         h.update(open(os.path.join(d, f), "rb").read())
     return h.hexdigest()[:16]
+
+
+REPEATS = 5
+COMPACT_LIMIT = 4096
+DETAIL_FILE = os.path.join(ROOT, "bench_detail.json")
+
+_ROOFLINE_KEYS = ("kernel", "bound", "achieved", "peak", "unit", "frac", "traffic", "algorithmic_bytes_per_launch", "avg_launch_us", "flop_frac")
+
+
+def median_of(times):
+    """(median, min, max) of the repeat times; the median of an even count is the mean of the middle two."""
+    t = sorted(times)
+    n = len(t)
+    med = t[n // 2] if n % 2 else 0.5 * (t[n // 2 - 1] + t[n // 2])
+    return med, t[0], t[-1]
+
+
+def _short(s, n):
+    return s if not isinstance(s, str) or len(s) <= n else s[: n - 3] + "..."
+
+
+def _compact_roofline(r):
+    if not isinstance(r, dict):
+        return None
+    if "error" in r:
+        return {"error": _short(r["error"], 120)}
+    out = {k: r[k] for k in _ROOFLINE_KEYS if k in r}
+    if isinstance(out.get("unit"), str):
+        out["unit"] = out["unit"].split(" (")[0]
+    out["kernel"] = _short(out.get("kernel"), 80)
+    return out
+
+
+def _compact_cpu(c):
+    if not isinstance(c, dict):
+        return None
+    out = {k: c[k] for k in ("value", "unit", "cores", "kind") if k in c}
+    out["sample"] = _short(c.get("sample"), 150)
+    if "host_cores" in c:
+        out["host_cores"] = c["host_cores"]
+    return out
+
+
+def _compact_config(c):
+    """one extra configuration -> {value, ms_per_step, frac, avg_launch_us} (+ the pipelined rate of the LiDAR loop, + cores of a CPU-only entry)"""
+    if not isinstance(c, dict):
+        return None
+    if "error" in c or "skipped" in c:
+        return {k: _short(c[k], 100) for k in ("error", "skipped") if k in c}
+    out = {}
+    for k in ("value", "unit", "ms_per_step", "ms_per_step_min", "ms_per_step_max", "steps", "cores", "kind", "fitness_score"):
+        if k in c:
+            out[k] = c[k]
+    r = c.get("roofline")
+    if isinstance(r, dict) and "frac" in r:
+        out["frac"] = r["frac"]
+        out["avg_launch_us"] = r.get("avg_launch_us")
+        out["traffic"] = r.get("traffic")
+    cb = c.get("cpu_baseline")
+    if isinstance(cb, dict) and "value" in cb:
+        out["cpu_baseline"] = {"value": cb["value"], "cores": cb.get("cores"), "kind": cb.get("kind")}
+    p = c.get("pipelined")
+    if isinstance(p, dict):
+        out["pipelined"] = p.get("registrations_per_sec", _short(p.get("error"), 80))
+    return out
+
+
+def compact_line(detail):
+    """The line the driver parses: the contract's keys + roofline + cpu_baseline + one short entry per extra configuration, as ONE strict-JSON
+    line shorter than COMPACT_LIMIT bytes whatever the detail dictionary holds (optional parts are dropped, longest first, until it fits)."""
+    d = detail
+    cfg = d.get("config") or {}
+    out = {k: d.get(k) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data")}
+    out["metric"] = _short(out["metric"], 140)
+    for k in ("repeats", "ms_per_step_min", "ms_per_step_max", "fitness_score", "speedup_vs_one_gpu"):
+        if k in d:
+            out[k] = d[k]
+    out["config"] = {k: _short(v, 160) for k, v in cfg.items() if k in ("workload", "method", "neighbor_search", "k_correspondences", "covariance", "regularization", "voxel_resolution",
+                                                                         "parallelism", "loop", "inputs", "route")}
+    out["roofline"] = _compact_roofline(d.get("roofline"))
+    out["cpu_baseline"] = _compact_cpu(d.get("cpu_baseline"))
+    optional = []
+    if isinstance(d.get("host_clouds_in"), dict):
+        out["host_clouds_in"] = {k: d["host_clouds_in"].get(k) for k in ("value", "ms_per_step")}
+        optional.append("host_clouds_in")
+    if isinstance(d.get("n1_same_workload"), dict):
+        out["n1_same_workload"] = {k: d["n1_same_workload"].get(k) for k in ("value", "ms_per_step", "steps")}
+    if isinstance(d.get("replicas_17k"), dict):
+        out["replicas_17k"] = _compact_config(d["replicas_17k"])
+        optional.append("replicas_17k")
+    if isinstance(d.get("per_registration"), dict):
+        out["per_registration"] = {k: v for k, v in d["per_registration"].items() if not isinstance(v, (dict, list, str))}
+        optional.append("per_registration")
+    if isinstance(d.get("concurrent_streams"), dict) and "registrations_per_sec" in d["concurrent_streams"]:
+        out["concurrent_streams"] = {"streams": d["concurrent_streams"].get("streams"), "value": d["concurrent_streams"]["registrations_per_sec"]}
+        optional.append("concurrent_streams")
+    if isinstance(d.get("configs"), dict):
+        out["configs"] = {k: _compact_config(v) for k, v in d["configs"].items()}
+    if "sharded_headline_error" in d:
+        out["sharded_headline_error"] = _short(d["sharded_headline_error"], 160)
+    for k in ("bench_wall_s", "detail"):
+        if k in d:
+            out[k] = d[k]
+
+    def dumps(o):
+        return json.dumps(o, separators=(",", ":"), allow_nan=False)
+
+    def clean(o):  # strict JSON: NaN / Infinity -> null
+        if isinstance(o, float) and (o != o or o in (float("inf"), float("-inf"))):
+            return None
+        if isinstance(o, dict):
+            return {str(k): clean(v) for k, v in o.items()}
+        if isinstance(o, (list, tuple)):
+            return [clean(v) for v in o]
+        if isinstance(o, (np.floating, np.integer, np.bool_)):
+            return clean(o.item())
+        return o
+
+    out = clean(out)
+    line = dumps(out)
+    for k in optional[::-1] + ["configs"]:  # (never reached with the shapes this script builds; the bound must hold for ANY detail)
+        if len(line) < COMPACT_LIMIT:
+            break
+        if k == "configs" and isinstance(out.get("configs"), dict):
+            out["configs"] = {n: ({"value": c.get("value")} if isinstance(c, dict) else None) for n, c in out["configs"].items()}
+        else:
+            out.pop(k, None)
+        line = dumps(out)
+    if len(line) >= COMPACT_LIMIT:
+        out.pop("configs", None)
+        out["config"] = {"workload": _short((out.get("config") or {}).get("workload"), 100)}
+        line = dumps(out)
+    assert len(line) < COMPACT_LIMIT and "\n" not in line
+    return line
+
+
+def emit(detail):
+    """bench_detail.json + stderr get everything; stdout gets the compact line, last."""
+    detail["detail"] = "bench_detail.json (beside bench.py) + stderr"
+    try:
+        with open(DETAIL_FILE, "w") as f:
+            json.dump(detail, f)
+    except OSError as ex:
+        detail["detail"] = "stderr only (%r)" % ex
+    sys.stdout.flush()
+    print("bench_detail: " + json.dumps(detail), file=sys.stderr, flush=True)
+    print(compact_line(detail), flush=True)
 
 
 _PMC = {}
@@ -295,15 +446,19 @@ def sharded_headline(args, dist, rank, world, local_rank, dev, small=False):
         return sh.align()
     for _ in range(warmup):
         r = step()
-    barrier()
-    t0 = time.perf_counter()
     n_eval = n_launch = 0
-    for _ in range(steps):
-        r = step()
-        n_eval += r["num_linearize"] + r["num_error_evals"]
-        n_launch += r["num_launches"]
-    barrier()
-    elapsed = max_over_ranks(time.perf_counter() - t0)
+    rep_times = []
+    for _rep in range(REPEATS):
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            r = step()
+            n_eval += r["num_linearize"] + r["num_error_evals"]
+            n_launch += r["num_launches"]
+        barrier()
+        rep_times.append(max_over_ranks(time.perf_counter() - t0))
+    elapsed, el_min, el_max = median_of(rep_times)
+    n_regs = steps * REPEATS
     # roofline of the dominant kernel (this rank's cost launches, HIP events on the engine's stream), on a few more steps outside the timed region
     roofline = None
     try:
@@ -321,13 +476,14 @@ def sharded_headline(args, dist, rank, world, local_rank, dev, small=False):
             achieved = ne * bytes_eval / (cost_ms * 1e-3) / 1e9
             roofline = {"kernel": "cost_kernel<double,VGICP,%s> on this rank's tile (1 / %d of the scan)" % ("persistent" if cost_n == 5 else "per-transition", world), "bound": "hbm",
                         "achieved": round(achieved, 2), "peak": 8000.0, "unit": "GB/s", "frac": round(achieved / 8000.0, 5), "traffic": None,
-                        "algorithmic_bytes_per_evaluation": bytes_eval, "evaluations": ne, "launches": cost_n, "avg_launch_us": round(cost_ms / cost_n * 1e3, 3),
+                        "algorithmic_bytes_per_launch": int(bytes_eval * ne / cost_n), "algorithmic_bytes_per_evaluation": bytes_eval, "evaluations": ne, "launches": cost_n, "avg_launch_us": round(cost_ms / cost_n * 1e3, 3),
                         "note": "rank 0; SURVEY 8(d) B_eval over the tile; no PMC pass exists for the sharded launches (traffic null)"}
     except Exception as ex:  # noqa: BLE001
         roofline = {"error": repr(ex)}
     out = {
         "metric": "registrations/sec (one registration stream, every registration sharded over the GPUs by spatial tile; BASELINE configs[4])",
         "value": round(steps / elapsed, 3), "unit": "registrations/sec", "n_gpus": world, "steps": steps, "warmup": warmup, "ms_per_step": round(elapsed / steps * 1e3, 5),
+        "repeats": REPEATS, "ms_per_step_min": round(el_min / steps * 1e3, 5), "ms_per_step_max": round(el_max / steps * 1e3, 5),
         "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
         "config": {"workload": "synthetic %s-point map <-> %s-point scan, seed %d: scan-to-map step (host scan in, k-NN k = 20, PLANE covariances, align)" % (
                        "{:,}".format(n_t), "{:,}".format(n_s), seed),
@@ -337,7 +493,7 @@ def sharded_headline(args, dist, rank, world, local_rank, dev, small=False):
         "n1_same_workload": {"value": round(1e3 / ms1, 3), "unit": "registrations/sec", "ms_per_step": round(ms1, 5), "steps": n1_steps, "converged": bool(r1["converged"]),
                              "note": "the same step, unsharded, on one GPU (max over the ranks, each on its own GPU): value / this = the strong-scaling speed-up"},
         "speedup_vs_one_gpu": round(ms1 / (elapsed / steps * 1e3), 3),
-        "per_registration": {"cost_evaluations": n_eval / steps, "kernel_launches_lm": n_launch / steps, "converged": bool(r["converged"]),
+        "per_registration": {"cost_evaluations": n_eval / n_regs, "kernel_launches_lm": n_launch / n_regs, "converged": bool(r["converged"]),
                              "pose_equals_single_gpu": bool(np.abs(r["T"] - r1["T"]).max() < 1e-9), "max_abs_pose_difference": float(np.abs(r["T"] - r1["T"]).max())},
         "attach_ms": round(attach_ms, 2), "roofline": roofline,
         "cpu_baseline": None,  # (N = 1 only: the N = 1 line carries it)
@@ -599,21 +755,26 @@ def run_stream(args, steps, warmup, cpu_loops=15, frames_n=10):
     ndt.profile_reset(); vg.profile_reset()
     ndt.profile_enable(False); vg.profile_enable(False)
     state["n_ds"] = 0
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
     n_eval = n_launch = 0
-    for it in range(steps):
-        if profile and it % 9 <= 1:
-            ndt.profile_enable(2 if it % 9 == 0 else 0)  # the LM kernel only (two events per sampled frame); map build and filter are timed after the timed region
-        step()
-        n_eval += state["last"]["num_linearize"] + state["last"]["num_error_evals"]
-        n_launch += state["last"]["num_launches"]
-    ndt.synchronize(); torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
+    rep_times = []
+    for _rep in range(REPEATS):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for it in range(steps):
+            if profile and it % 9 <= 1:
+                ndt.profile_enable(2 if it % 9 == 0 else 0)  # the LM kernel only (two events per sampled frame); map build and filter are timed after the timed region
+            step()
+            n_eval += state["last"]["num_linearize"] + state["last"]["num_error_evals"]
+            n_launch += state["last"]["num_launches"]
+        ndt.synchronize(); torch.cuda.synchronize()
+        rep_times.append(time.perf_counter() - t0)
+        ndt.profile_enable(False)
+    elapsed, el_min, el_max = median_of(rep_times)
+    n_regs = steps * REPEATS
     ndt.profile_enable(False); vg.profile_enable(False)
     stage_ms, roofline, roofline_ds = {}, None, None
     cost_sample = ndt.profile_get("cost") if profile else (0.0, 0)
-    n_ds = state["n_ds"] // max(steps, 1)
+    n_ds = state["n_ds"] // max(n_regs, 1)
     if profile:  # the other stages: 18 more frames of the same loop, every kernel class bracketed, outside the timed region
         ndt.profile_reset(); vg.profile_reset()
         ndt.profile_enable(1); vg.profile_enable(True)
@@ -732,12 +893,13 @@ def run_stream(args, steps, warmup, cpu_loops=15, frames_n=10):
         pipelined = {"error": repr(ex)}
     vg.close(); ndt.close()
     return {"pipelined": pipelined, "metric": "registrations/sec (frame-by-frame odometry, kitti.cpp loop incl. downsampling)", "value": round(steps / elapsed, 3), "unit": "registrations/sec", "n_gpus": 1,
-            "steps": steps, "warmup": warmup, "ms_per_step": round(elapsed / steps * 1e3, 5), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "steps": steps, "warmup": warmup, "ms_per_step": round(elapsed / steps * 1e3, 5), "repeats": REPEATS, "ms_per_step_min": round(el_min / steps * 1e3, 5),
+            "ms_per_step_max": round(el_max / steps * 1e3, 5), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64" if args.precision == "fp64" else "f32", "data": "KITTI" if kitti_dir else "synthetic",
             "config": {"workload": "%s, %d raw pts/frame -> ApproximateVoxelGrid 0.25 -> %d pts; NDT D2D, DIRECT7, res 1.0; %d-frame sequence walked back and forth" % (
                 "KITTI frames from FVH_KITTI_DIR" if kitti_dir else "simulated 64-ring LiDAR", n_raw, n_ds, F),
                 "method": "NDT_D2D", "neighbor_search": "DIRECT7", "voxel_resolution": 1.0, "parallelism": "single GPU"},
-            "per_registration": {"cost_evaluations": n_eval / steps, "kernel_launches_lm": n_launch / steps, "converged": bool(state["last"]["converged"])},
+            "per_registration": {"cost_evaluations": n_eval / n_regs, "kernel_launches_lm": n_launch / n_regs, "converged": bool(state["last"]["converged"])},
             "accuracy": ({"max_frame_translation_error_m": round(float(max(errs)), 4), "mean_frame_translation_error_m": round(float(np.mean(errs)), 4)} if errs else None),
             "roofline": roofline, "roofline_downsample": roofline_ds, "cpu_baseline": cpu, "stages": stage_ms}
 
@@ -832,23 +994,28 @@ def run_registration(args, workload, cov, search_name, steps, warmup, local_rank
             dist.barrier()
         torch.cuda.synchronize()
 
-    barrier()
-    t0 = time.perf_counter()
     n_lin = n_err = n_launch = 0
-    for it in range(steps):
-        if profile and it % PROFILE_EVERY <= 1:  # (on at 0, off again at 1: a call per step would sit between an align and the next launch, with the GPU idle)
-            core.profile_enable(2 if it % PROFILE_EVERY == 0 else 0)  # level 2: the LM kernel only (the roofline's launch time); the other stages are timed after the timed region
-        step()
-        n_lin += state["last"]["num_linearize"]
-        n_err += state["last"]["num_error_evals"]
-        n_launch += state["last"]["num_launches"]
-    barrier()
-    elapsed = time.perf_counter() - t0
-    core.profile_enable(False)
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    rep_times = []
+    for _rep in range(REPEATS):  # the timed region, REPEATS times: exactly `steps` steps between barrier + synchronize on both sides, max over the ranks
+        barrier()
+        t0 = time.perf_counter()
+        for it in range(steps):
+            if profile and it % PROFILE_EVERY <= 1:  # (on at 0, off again at 1: a call per step would sit between an align and the next launch, with the GPU idle)
+                core.profile_enable(2 if it % PROFILE_EVERY == 0 else 0)  # level 2: the LM kernel only (the roofline's launch time); the other stages are timed after the timed region
+            step()
+            n_lin += state["last"]["num_linearize"]
+            n_err += state["last"]["num_error_evals"]
+            n_launch += state["last"]["num_launches"]
+        barrier()
+        el = time.perf_counter() - t0
+        core.profile_enable(False)
+        if dist is not None:
+            t = torch.tensor([el], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el = float(t.item())
+        rep_times.append(el)
+    elapsed, el_min, el_max = median_of(rep_times)
+    n_regs = steps * REPEATS  # registrations the per-registration counters were summed over
 
     # ---- the same loop, host clouds in (PCIe-inclusive; never `value`) ----
     host_leg = None
@@ -899,7 +1066,7 @@ def run_registration(args, workload, cov, search_name, steps, warmup, local_rank
             evals_per_launch = (n_lin + n_err) / max(n_launch, 1)
             bytes_launch = bytes_eval * evals_per_launch
             achieved = bytes_launch / avg_s / 1e9
-            persistent = n_launch == steps
+            persistent = n_launch == n_regs
             key = workload + ("_rbf" if cov == "rbf" else "") + "_cost"
             kname = "cost_kernel<%s,VGICP,%s>" % ("double" if args.precision == "fp64" else "float", "persistent" if persistent else "per-transition")
             traffic, traffic_src = pmc_traffic(key) if (persistent and args.precision == "fp64") else (None, "PMC passes exist for the persistent fp64 kernel only")
@@ -912,7 +1079,7 @@ def run_registration(args, workload, cov, search_name, steps, warmup, local_rank
                         "avg_launch_us": round(avg_s * 1e6, 3), "launches": cost_n,
                         "note": ("17k-point working set (~3 MB) is L2/Infinity-Cache resident and the fused trips share their loads between the trial evaluation and the next "
                                  "linearisation: this kernel is bound by the latency chain of its %d barrier-separated trips, not by HBM; `traffic` (PMC) is what actually reaches HBM"
-                                 % round((n_err / steps) + 1) if workload == "bundled17k"
+                                 % round((n_err / n_regs) + 1) if workload == "bundled17k"
                                  else "launch average over the LM launches of the timed region; `traffic` (PMC) is what reached HBM")}
     if cov == "knn" and "knn" in stage_ms:  # VALU-bound stage -> VALU utilisation (PMC) + pair-evaluation rate
         stage_ms["knn"]["roofline"] = valu_roofline(workload + "_knn", "knn_tiled1_kernel", stage_ms["knn"]["avg_us"], n_src, n_src)
@@ -935,13 +1102,14 @@ def run_registration(args, workload, cov, search_name, steps, warmup, local_rank
     out = {
         "metric": "registrations/sec (100-iter reuse) + final fitness_score; achieved HBM GB/s",
         "value": round(total_regs / elapsed, 3), "unit": "registrations/sec", "n_gpus": world, "steps": steps, "warmup": warmup, "ms_per_step": round(elapsed / steps * 1e3, 5),
+        "repeats": REPEATS, "ms_per_step_min": round(el_min / steps * 1e3, 5), "ms_per_step_max": round(el_max / steps * 1e3, 5),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64" if args.precision == "fp64" else "f32",
         "data": "bundled scans (real LiDAR)" if workload == "bundled17k" else "synthetic",
         "config": {"workload": desc, "method": "VGICP", "neighbor_search": search_name, "k_correspondences": K, "covariance": cov, "regularization": "PLANE",
                    "voxel_resolution": res, "parallelism": "1 registration stream per GPU" if world > 1 else "single GPU",
                    "loop": "scan-to-map (map stays the target)" if workload == "synth1m" else "100times_reuse (align.cpp:87-101)", "inputs": "resident in HBM before the timed region"},
         "fitness_score": round(fitness, 6), "single_ms": round(single_ms, 3),
-        "per_registration": {"linearize": n_lin / steps, "error_evals": n_err / steps, "kernel_launches_lm": n_launch / steps, "converged": bool(state["last"]["converged"]),
+        "per_registration": {"linearize": n_lin / n_regs, "error_evals": n_err / n_regs, "kernel_launches_lm": n_launch / n_regs, "converged": bool(state["last"]["converged"]),
                              "persistent_launches_aborted_by_watchdog": core.debug_persist_aborts()},
         "host_clouds_in": host_leg,
         "roofline": roofline, "cpu_baseline": cpu_res, "stages": stage_ms, "profiled_timed_region": ("every %dth registration" % PROFILE_EVERY) if profile else False,
@@ -983,7 +1151,7 @@ def main():
     if args.workload == "lidar_stream":
         if world != 1:
             raise SystemExit("lidar_stream is a single-GPU workload")
-        print(json.dumps(run_stream(args, args.steps, args.warmup)), flush=True)
+        emit(run_stream(args, args.steps, args.warmup))
         return
     # test-only knobs to walk the N > 1 control flow on a single-GPU box: all ranks on device 0, gloo for the barrier
     share_gpu = os.environ.get("FVH_BENCH_SHARE_GPU") == "1"
@@ -1062,7 +1230,7 @@ def main():
                 configs["cpu_fastvgicp_direct1"] = {"error": repr(ex)}
         out["configs"] = configs
     out["bench_wall_s"] = round(time.perf_counter() - T_START, 1)
-    print(json.dumps(out), flush=True)
+    emit(out)
     finish(dist, sharded_hung)
 
 
