@@ -847,48 +847,48 @@ def run_stream(args, steps, warmup, cpu_loops=15, frames_n=10):
                "sample": "%d frames of the same loop per thread count: oracle ApproximateVoxelGrid (1 thread, as PCL) + oracle NDT D2D (OpenMP); best of the sweep reported" % max(4, cpu_loops // 3),
                "thread_sweep_registrations_per_sec": sweep, "host_cores": os.cpu_count()}
         cpu["value"] = round(cpu["value"], 3)
-    # ---- side leg: the same loop as a two-stage pipeline (frame k+1 is downsampled on a second handle / stream / host thread
-    # while frame k is registered; the odometry chain itself stays sequential). Not `value`: kitti.cpp is a sequential loop.
+    # ---- side leg: the same loop as a two-stage pipeline on ONE host thread (fvh_ndt_align_async / _wait + the handle's prepared-source
+    # slot): while the LM kernel of frame k runs on the main stream, frame k+1 is filtered, widened and its voxel map built on the handle's
+    # second stream. The odometry chain itself stays sequential; poses are bit-identical to the plain loop (tests/test_gpu_streaming.py).
+    # Not `value`: kitti.cpp is a sequential loop.
     pipelined = None
     try:
-        import threading
-        vg.share_stream(None)  # (two filter handles with their own streams and a host thread from here on)
-        vgs = [vg, capi.VoxelGrid(0)]
-        slots = [None, None]
-        ready = [threading.Event(), threading.Event()]
-        free = [threading.Event(), threading.Event()]
-        for f in free:
-            f.set()
+        vg.share_stream(None)
+        vg.share_prepare_stream(ndt)
         P = max(steps, 20)
-        order = [seq[(k + 1) % len(seq)] for k in range(P)]
+        order = [seq[(k + 1) % len(seq)] for k in range(P + 1)]
+        ptrs = [t.data_ptr() for t in d_frames]
+        lens = [len(f) for f in frames]
 
-        def producer():
-            for k, i in enumerate(order):
-                b = k & 1
-                free[b].wait(); free[b].clear()
-                slots[b] = vgs[b].filter_device(d_frames[i].data_ptr(), len(frames[i]), 0.25, vg.APPROXIMATE)
-                ready[b].set()
+        def prepare(i):
+            ptr, n = vg.filter_device(ptrs[i], lens[i], 0.25, vg.APPROXIMATE, asynchronous=True)
+            ndt.prepare_source_device(ptr, n, 3)
 
-        ptr, n = vg.filter_device(d_frames[seq[0]].data_ptr(), len(frames[seq[0]]), 0.25, vg.APPROXIMATE)
+        def run(count):
+            r = None
+            for k in range(count):
+                ndt.adopt_prepared_source()
+                ndt.align_async()
+                prepare(order[k + 1])
+                r = ndt.align_wait()
+                ndt.swap_source_and_target()
+            return r
+
+        ptr, n = vg.filter_device(ptrs[seq[0]], lens[seq[0]], 0.25, vg.APPROXIMATE)
         ndt.set_target_cloud_device(ptr, n, 3)
-        th = threading.Thread(target=producer, daemon=True)
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        th.start()
-        for k in range(P):
-            b = k & 1
-            ready[b].wait(); ready[b].clear()
-            ptr, n = slots[b]
-            ndt.set_source_cloud_device(ptr, n, 3)
-            r = ndt.align()      # (synchronises the NDT stream: the copy out of the filter's buffer is done)
-            free[b].set()
-            ndt.swap_source_and_target()
-        ndt.synchronize()
-        el = time.perf_counter() - t0
-        th.join(5)
-        pipelined = {"registrations_per_sec": round(P / el, 3), "ms_per_step": round(el / P * 1e3, 5), "converged": bool(r["converged"]),
-                     "note": "downsampling of frame k+1 (second voxel-grid handle, own stream and host thread) overlapped with the registration of frame k"}
-        vgs[1].close()
+        prepare(order[0])
+        run(5)
+        times = []
+        for _rep in range(REPEATS):
+            ndt.synchronize(); torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            r = run(P)
+            ndt.synchronize(); torch.cuda.synchronize()
+            times.append(time.perf_counter() - t0)
+        el, el_lo, el_hi = median_of(times)
+        pipelined = {"registrations_per_sec": round(P / el, 3), "ms_per_step": round(el / P * 1e3, 5), "ms_per_step_min": round(el_lo / P * 1e3, 5), "ms_per_step_max": round(el_hi / P * 1e3, 5),
+                     "steps": P, "repeats": REPEATS, "converged": bool(r["converged"]), "kernel_launches_lm": r["num_launches"],
+                     "note": "one host thread: adopt_prepared_source, align_async, [filter + prepare_source_device of frame k+1 on the handle's second stream], align_wait, swap"}
     except Exception as ex:  # noqa: BLE001
         pipelined = {"error": repr(ex)}
     vg.close(); ndt.close()

@@ -505,6 +505,11 @@ class VoxelGrid:
         else:
             self._check(self._lib.fvh_voxelgrid_share_stream_with_vgicp(self._h, core.h), "fvh_voxelgrid_share_stream_with_vgicp")
 
+    def share_prepare_stream(self, ndt):
+        """Run this filter on the SECOND stream of an NDTCore (the one prepare_source_device works on): the next frame is filtered
+        beside the LM kernel of the current one."""
+        self._check(self._lib.fvh_voxelgrid_share_prepare_stream_with_ndt(self._h, ndt.h), "fvh_voxelgrid_share_prepare_stream_with_ndt")
+
     def filter_device(self, d_ptr, n, leaf, method=APPROXIMATE, stride=3, asynchronous=False):
         """Device pointer in (n points, `stride` floats apart); returns (device pointer to packed xyz, count) valid until the next filter call.
         asynchronous (after share_stream): the count is final on return, the points are complete in the shared stream's order only."""
@@ -548,6 +553,27 @@ class NDTCore(_Core):
 
     def create_source_voxelmap(self):
         self._call("create_source_voxelmap")
+
+    # ---- pipelined frame streams (include/fast_vgicp_hip.h: fvh_ndt_align_async ...) ----
+    def align_async(self, guess=None, **lm):
+        """Launch the LM kernel and return; align_wait() collects the result. In between only prepare_source_device() (and a VoxelGrid
+        that shares the prepare stream) may be used on this handle."""
+        self._g = _colmajor16(np.eye(4) if guess is None else guess)
+        self._lm = _lm_params(**lm)
+        self._call("align_async", _p(self._g), C.byref(self._lm))
+
+    def align_wait(self):
+        r = LmResult()
+        self._call("align_wait", C.byref(r))
+        return _result_dict(r)
+
+    def prepare_source_device(self, ptr, n, stride=3):
+        """The NEXT source cloud (device pointer) into the handle's prepared slot, on its second stream: widened and, for D2D, its
+        voxel map built, beside whatever runs on the main stream."""
+        self._call("prepare_source_device", C.c_void_p(ptr), int(n), int(stride))
+
+    def adopt_prepared_source(self):
+        self._call("adopt_prepared_source")
 
     def get_num_voxels(self, which):
         n = C.c_int(0)

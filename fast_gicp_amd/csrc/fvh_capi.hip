@@ -145,25 +145,20 @@ struct Rccl {
   }
 };
 Rccl g_rccl;
-std::atomic<int> g_live_engines{0};    // engine handles alive in this process that can launch gang kernels (registration handles)
-// When each of them last queued a gang kernel (cooperative sort, persistent LM kernel), by handle number mod 64. Two gang kernels from
-// two streams could starve each other of CU slots (the watchdogs + fall-backs recover, slowly): the cooperative sort is used while no
-// OTHER handle has a gang kernel in flight: queued within the window and not yet followed by an align that returned (which drains the
-// handle's stream and clears its stamp). A second handle that merely exists (the reference's align.cpp keeps its NDT object alive while
-// the VGICP rows run), or one that the same thread uses in turn, no longer costs the VGICP handle 38 us per registration.
-std::atomic<long long> g_gang_stamp_ns[64];
+// Gang kernels (the cooperative sort, the persistent LM kernel: grids whose workgroups wait for each other) of two handles could starve
+// each other of CU slots (the watchdogs + fall-backs recover, slowly). The persistent LM launches split the slots through the SlotPool
+// below; the cooperative sort is used only while no OTHER handle has a gang kernel IN FLIGHT. "In flight" is tracked, not guessed: a
+// handle marks itself under the registry's lock before it launches one (check and mark are one atomic step across host threads), records
+// an event behind it, and is in flight until that event has fired or the handle has seen its own result (align returned / synchronize).
+// A second handle that merely exists (the reference's align.cpp keeps its NDT object alive while the VGICP rows run), or one that the
+// same thread uses in turn, costs nothing. (Round 4 used a 20 ms wall-clock window over 64 hashed slots here.)
+struct Engine;
+struct GangRegistry {
+  std::mutex mu;
+  std::vector<Engine*> engines;  // registration handles alive in this process
+} g_gangs;
 std::atomic<int> g_sort_routes[4];  // sorts queued by this process: cooperative kernel, one workgroup, two-launch passes, four-launch passes (fvh_debug_sort_routes)
-std::atomic<int> g_engine_numbers{0};
 inline long long steady_ns() { return std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
-inline bool other_gang_recent(int me, long long window_ns) {
-  const long long now = steady_ns();
-  for (int i = 0; i < 64; i++) {
-    if (i == me) continue;
-    const long long t = g_gang_stamp_ns[i].load(std::memory_order_relaxed);
-    if (t && now - t < window_ns) return true;
-  }
-  return false;
-}
 
 // Co-resident workgroup slots of a device, shared by the persistent LM launches of this process. A persistent grid must be
 // resident as a whole, so concurrent aligns (several handles driven by several host threads) SPLIT the slots instead of
@@ -375,6 +370,7 @@ struct Engine {
   int shard_ranks() const { return peer.attached() ? peer.n : (comm ? nranks : 1); }
   int shard_rank() const { return peer.attached() ? peer.rank : (comm ? rank : 0); }
   DevBuf gather_stage;  // RCCL route: covariances of the whole cloud in Morton order (ncclAllGather in place)
+  int rccl_checked_n = -1;  // cloud size the ranks were last found to agree on (rccl_allgather_cov)
   hipStream_t side = nullptr;
   hipEvent_t side_done = nullptr;
   bool side_pending = false;       // a build on `side` the main stream has not been ordered after yet
@@ -475,17 +471,49 @@ struct Engine {
     int rc = upload_offsets();
     if (rc) return rc;
     if ((e = hipStreamSynchronize(stream)) != hipSuccess) return hipfail(e, "hipStreamSynchronize");  // "warming up GPU" (fast_vgicp_cuda.cu:19-20)
-    if (gang_kernels) { g_live_engines.fetch_add(1); counted = true; gang_id = g_engine_numbers.fetch_add(1) & 63; }
+    if (gang_kernels) {
+      if ((e = hipEventCreateWithFlags(&gang_done, hipEventDisableTiming)) != hipSuccess) return hipfail(e, "hipEventCreate");
+      std::lock_guard<std::mutex> lk(g_gangs.mu);
+      g_gangs.engines.push_back(this);
+      counted = true;
+    }
     return FVH_OK;
   }
-  bool counted = false;
-  int gang_id = 0;
-  void gang_stamp() { if (counted) g_gang_stamp_ns[gang_id].store(steady_ns(), std::memory_order_relaxed); }
-  void gang_clear() { if (counted) g_gang_stamp_ns[gang_id].store(0, std::memory_order_relaxed); }  // the caller holds the result of an align: nothing of this handle is in flight
+  bool counted = false;             // registered in g_gangs (registration handles; a voxel-grid filter never launches a gang kernel)
+  hipEvent_t gang_done = nullptr;   // recorded behind the last gang kernel this handle queued
+  std::atomic<int> gang_launching{0};  // > 0: between "marked" and "event recorded"
+  std::atomic<bool> gang_open{false};  // a gang kernel was queued and the handle has not seen its result yet (the event says whether it still runs)
+  bool gang_in_flight() const {  // (called by OTHER handles under g_gangs.mu)
+    if (gang_launching.load(std::memory_order_acquire) > 0) return true;
+    if (!gang_open.load(std::memory_order_acquire)) return false;
+    const hipError_t q = hipEventQuery(gang_done);
+    if (q == hipErrorNotReady) { (void)hipGetLastError(); return true; }
+    return false;
+  }
+  // mark this handle as launching a gang kernel; `exclusive`: only if no other handle has one in flight (false = refused, nothing marked)
+  bool gang_begin(bool exclusive) {
+    if (!counted) return !exclusive;
+    std::lock_guard<std::mutex> lk(g_gangs.mu);
+    if (exclusive)
+      for (Engine* o : g_gangs.engines) if (o != this && o->gang_in_flight()) return false;
+    gang_launching.fetch_add(1, std::memory_order_acq_rel);
+    return true;
+  }
+  void gang_end() {  // the gang kernel (and whatever must follow it) is queued
+    if (!counted) return;
+    (void)hipEventRecord(gang_done, stream);
+    gang_open.store(true, std::memory_order_release);
+    gang_launching.fetch_sub(1, std::memory_order_acq_rel);
+  }
+  void gang_clear() { if (counted) gang_open.store(false, std::memory_order_release); }  // the caller holds the result of an align / drained the stream: nothing of this handle is in flight
   hipStream_t owned_stream = nullptr;  // the stream init() made; `stream` may be another handle's (fvh_voxelgrid_share_stream_*)
   void shutdown() {
     if (stream != owned_stream) stream = owned_stream;  // a borrowed stream is its owner's to drain and destroy
-    if (counted) { g_live_engines.fetch_sub(1); counted = false; }
+    if (counted) {
+      std::lock_guard<std::mutex> lk(g_gangs.mu);
+      g_gangs.engines.erase(std::remove(g_gangs.engines.begin(), g_gangs.engines.end(), this), g_gangs.engines.end());
+      counted = false;
+    }
     (void)hipSetDevice(device);
     if (side) (void)hipStreamSynchronize(side);
     if (stream) (void)hipStreamSynchronize(stream);
@@ -501,6 +529,7 @@ struct Engine {
     for (int s = 0; s < 2; s++) if (upload_done[s]) (void)hipEventDestroy(upload_done[s]);
     if (result_host) (void)hipHostFree(result_host);
     if (stream) (void)hipStreamDestroy(stream);
+    if (gang_done) (void)hipEventDestroy(gang_done);
     if (side_done) (void)hipEventDestroy(side_done);
     if (side) (void)hipStreamDestroy(side);
   }
@@ -579,7 +608,9 @@ inline void pose_to_colmajor16(const PoseD& p, double* T) {
 // ---------------------------------------------------------------------------------------------
 // shared building blocks
 // ---------------------------------------------------------------------------------------------
-int upload_cloud(Engine* e, CloudDev& c, const float* xyz, int n, int stride, bool on_device, bool want_box = true /* the cooperative sort's bounding cube (VGICP clouds) */) {
+int upload_cloud(Engine* e, CloudDev& c, const float* xyz, int n, int stride, bool on_device, bool want_box = true /* the cooperative sort's bounding cube (VGICP clouds) */,
+                 hipStream_t on = nullptr /* another stream than the handle's (the prepared-source slot of an NDT handle) */) {
+  hipStream_t const st = on ? on : e->stream;
   if (n < 0 || (n > 0 && !xyz)) return e->fail(FVH_ERR_INVALID_ARGUMENT, "set_cloud: null points");
   if (stride != 3 && stride != 4) return e->fail(FVH_ERR_INVALID_ARGUMENT, "set_cloud: stride must be 3 or 4 floats");
   HIP_OR_FAIL(e, c.pts.ensure(sizeof(float4) * (size_t)std::max(n, 1)));
@@ -592,12 +623,12 @@ int upload_cloud(Engine* e, CloudDev& c, const float* xyz, int n, int stride, bo
   if (want_box) {
     const bool fresh_box = c.box.p == nullptr;
     HIP_OR_FAIL(e, c.box.ensure(64));
-    if (fresh_box || c.box_dirty) HIP_OR_FAIL(e, hipMemsetAsync(c.box.p, 0, 64, e->stream));  // (the cooperative sort's finish kernel leaves it cleared)
+    if (fresh_box || c.box_dirty) HIP_OR_FAIL(e, hipMemsetAsync(c.box.p, 0, 64, st));  // (the cooperative sort's finish kernel leaves it cleared)
     c.box_dirty = true;
     boxp = c.box.as<unsigned>();
   }
   if (on_device) {
-    pack_points_kernel<<<pack_grid(n, boxp != nullptr), 256, 0, e->stream>>>(xyz, n, stride, c.pts.as<float4>(), boxp);
+    pack_points_kernel<<<pack_grid(n, boxp != nullptr), 256, 0, st>>>(xyz, n, stride, c.pts.as<float4>(), boxp);
     HIP_OR_FAIL(e, hipGetLastError());
   } else {
     // H2D the xyz (stride 3) / xyzi (stride 4, e.g. a KITTI .bin buffer) array into a staging buffer, then widen to float4 on device
@@ -618,23 +649,23 @@ int upload_cloud(Engine* e, CloudDev& c, const float* xyz, int n, int stride, bo
       static const size_t zero_copy_max = [] { const char* v = getenv("FVH_ZEROCOPY_UPLOAD_MAX"); return v ? (size_t)atoll(v) : (size_t)(1u << 20); }();
       void* pinned_dev = nullptr;
       if (bytes <= zero_copy_max && hipHostGetDevicePointer(&pinned_dev, slot, 0) == hipSuccess && pinned_dev) {
-        pack_points_kernel<<<pack_grid(n, boxp != nullptr), 256, 0, e->stream>>>(static_cast<const float*>(pinned_dev), n, stride, c.pts.as<float4>(), boxp);
+        pack_points_kernel<<<pack_grid(n, boxp != nullptr), 256, 0, st>>>(static_cast<const float*>(pinned_dev), n, stride, c.pts.as<float4>(), boxp);
         HIP_OR_FAIL(e, hipGetLastError());
-        HIP_OR_FAIL(e, hipEventRecord(e->upload_done[us], e->stream));
+        HIP_OR_FAIL(e, hipEventRecord(e->upload_done[us], st));
         e->upload_busy[us] = true;
       } else {
         (void)hipGetLastError();
-        HIP_OR_FAIL(e, hipMemcpyAsync(e->staging.p, slot, bytes, hipMemcpyHostToDevice, e->stream));
-        HIP_OR_FAIL(e, hipEventRecord(e->upload_done[us], e->stream));
+        HIP_OR_FAIL(e, hipMemcpyAsync(e->staging.p, slot, bytes, hipMemcpyHostToDevice, st));
+        HIP_OR_FAIL(e, hipEventRecord(e->upload_done[us], st));
         e->upload_busy[us] = true;
-        pack_points_kernel<<<pack_grid(n, boxp != nullptr), 256, 0, e->stream>>>(e->staging.as<float>(), n, stride, c.pts.as<float4>(), boxp);
+        pack_points_kernel<<<pack_grid(n, boxp != nullptr), 256, 0, st>>>(e->staging.as<float>(), n, stride, c.pts.as<float4>(), boxp);
         HIP_OR_FAIL(e, hipGetLastError());
       }
     } else {
-      HIP_OR_FAIL(e, hipMemcpyAsync(e->staging.p, xyz, bytes, hipMemcpyHostToDevice, e->stream));
-      pack_points_kernel<<<pack_grid(n, boxp != nullptr), 256, 0, e->stream>>>(e->staging.as<float>(), n, stride, c.pts.as<float4>(), boxp);
+      HIP_OR_FAIL(e, hipMemcpyAsync(e->staging.p, xyz, bytes, hipMemcpyHostToDevice, st));
+      pack_points_kernel<<<pack_grid(n, boxp != nullptr), 256, 0, st>>>(e->staging.as<float>(), n, stride, c.pts.as<float4>(), boxp);
       HIP_OR_FAIL(e, hipGetLastError());
-      HIP_OR_FAIL(e, hipStreamSynchronize(e->stream));  // caller may free xyz on return (reference copies too)
+      HIP_OR_FAIL(e, hipStreamSynchronize(st));  // caller may free xyz on return (reference copies too)
     }
   }
   return FVH_OK;
@@ -674,11 +705,10 @@ int ensure_sorted(Engine* e, CloudDev& c) {
   ProfScope ps(e, "sort");
   static const int sort_mode = [] { const char* v = getenv("FVH_SORT_MODE"); return v ? atoi(v) : 2; }();  // 0: multi-kernel radix, 1: single workgroup, 2: cooperative (single-engine processes), 3: cooperative always
   if (sort_mode >= 1 && n <= SORT_SMALL_MAX) {
-    // cooperative kernel (32 workgroups meeting at grid barriers) when this is the only engine of the process: two
-    // gang kernels from two streams could starve each other of CU slots (the watchdog + fallback would recover, slowly)
-    static const long long gang_window_ns = [] { const char* v = getenv("FVH_GANG_WINDOW_MS"); return (long long)(v ? atof(v) : 20.0) * 1000000ll; }();
-    const bool coop = c.has_box && ((sort_mode == 2 && (g_live_engines.load() == 1 || !other_gang_recent(e->gang_id, gang_window_ns))) || sort_mode == 3);
-    e->gang_stamp();
+    // cooperative kernel (32 workgroups meeting at grid barriers) while no OTHER handle has a gang kernel in flight (GangRegistry above:
+    // two gang kernels from two streams could starve each other of CU slots; the watchdog + fallback would recover, slowly)
+    const bool coop = c.has_box && (sort_mode == 3 ? e->gang_begin(false) : e->gang_begin(true));
+    struct GangEnd { Engine* e; bool on; ~GangEnd() { if (on) e->gang_end(); } } gang_end{e, coop};  // (on every way out: the event behind whatever was queued)
     g_sort_routes[coop ? 0 : 1].fetch_add(1, std::memory_order_relaxed);
     if (coop) {
       const bool fresh = e->sort_coop.p == nullptr;
@@ -839,6 +869,23 @@ __global__ __launch_bounds__(256) void scatter_sorted_cov_kernel(const float4* _
 int rccl_allgather_cov(Engine* e, CloudDev& c) {
   const Tile t = peer_tile(e, c.n);
   const int nr = std::max(1, e->shard_ranks());
+  // With a communicator attached every rank uploads the SAME full cloud (the engine shards internally); a caller still handing each rank
+  // its own tile (the contract before round 4) would get mismatched all-gather counts -- a hang or a corrupted collective. Checked once
+  // per cloud size: max over the ranks of (n, -n) must be (n, -n) everywhere.
+  if (e->rccl_checked_n != c.n) {
+    int* d = e->misc.as<int>() + 32;
+    int* hh = reinterpret_cast<int*>(e->pinned) + 8;
+    hh[0] = c.n; hh[1] = -c.n;
+    HIP_OR_FAIL(e, hipMemcpyAsync(d, hh, 8, hipMemcpyHostToDevice, e->stream));
+    const int rc0 = g_rccl.AllReduce(d, d, 2, /*ncclInt32*/ 2, /*ncclMax*/ 2, e->comm, e->stream);
+    if (rc0 != 0) return e->fail(FVH_ERR_COMM, "ncclAllReduce failed with code " + std::to_string(rc0));
+    HIP_OR_FAIL(e, hipMemcpyAsync(hh, d, 8, hipMemcpyDeviceToHost, e->stream));
+    HIP_OR_FAIL(e, hipStreamSynchronize(e->stream));
+    if (hh[0] != c.n || hh[1] != -c.n)
+      return e->fail(FVH_ERR_COMM, "the ranks hold clouds of different sizes (" + std::to_string(-hh[1]) + " .. " + std::to_string(hh[0]) + " points): with a communicator attached every rank "
+                     "uploads the same FULL cloud and the engine shards it internally (include/fast_vgicp_hip.h: fvh_vgicp_comm_init)");
+    e->rccl_checked_n = c.n;
+  }
   HIP_OR_FAIL(e, e->gather_stage.ensure(sizeof(float4) * 2 * (size_t)t.chunk * nr));
   float4* stage = e->gather_stage.as<float4>();
   ProfScope ps(e, "peer_gather");
@@ -1000,7 +1047,8 @@ int get_nbr_host(Engine* e, CloudDev& c, int* k, int* out) {
 // GaussianVoxelMap::create_voxelmap (gaussian_voxelmap.cu:208-257) -- two kernels, no retry loop
 template <int MODE>
 int build_voxelmap(Engine* e, const CloudDev& c, VoxelMapDev& vm, double res, bool want_compact, bool force_safe = false, hipStream_t on_side = nullptr,
-                   bool shard = false /* only the voxels of vm.region (already computed on this stream) */) {
+                   bool shard = false /* only the voxels of vm.region (already computed on this stream) */,
+                   bool detached = false /* a map that is not the live one yet (prepared-source slot): the caller orders the main stream after `on_side` itself, correspondences stay valid */) {
   hipStream_t const st = on_side ? on_side : e->stream;
   if (!c.has_pts) return e->fail(FVH_ERR_BAD_STATE, "create_voxelmap: cloud not set");
   if (MODE != 1 && !c.has_cov) return e->fail(FVH_ERR_BAD_STATE, "create_voxelmap: covariances not computed");
@@ -1064,13 +1112,13 @@ int build_voxelmap(Engine* e, const CloudDev& c, VoxelMapDev& vm, double res, bo
     vm.cur = fill;
   }
   HIP_OR_FAIL(e, hipGetLastError());
-  if (on_side) {
+  if (on_side && !detached) {
     HIP_OR_FAIL(e, hipEventRecord(e->side_done, on_side));
     e->side_pending = true;
   }
   vm.valid = true;
   vm.is_shard = shard;
-  e->has_corr = false;
+  if (!detached) e->has_corr = false;
   return FVH_OK;
 }
 
@@ -1289,10 +1337,13 @@ int launch_cost(Engine* e, const CostSource& src, const VoxelMapDev& vm, int hos
     P.bcast = e->bcast.as<double>();
     P.launch_tag = ++e->persist_seq;
     e->last_persist_blocks = blocks;
-    ProfScope ps(e, "cost");
-    e->gang_stamp();
-    if (e->precision == FVH_COMPUTE_FP32) cost_kernel<float, MODE, true><<<launch_blocks, 256, 0, e->stream>>>(P);
-    else cost_kernel<double, MODE, true><<<launch_blocks, 256, 0, e->stream>>>(P);
+    (void)e->gang_begin(false);  // (the persistent launches share the chip through the SlotPool; other handles' cooperative sorts stay away while this runs)
+    {
+      ProfScope ps(e, "cost");
+      if (e->precision == FVH_COMPUTE_FP32) cost_kernel<float, MODE, true><<<launch_blocks, 256, 0, e->stream>>>(P);
+      else cost_kernel<double, MODE, true><<<launch_blocks, 256, 0, e->stream>>>(P);
+    }
+    e->gang_end();
   } else {
     ProfScope ps(e, "cost");
     if (e->precision == FVH_COMPUTE_FP32) cost_kernel<float, MODE, false><<<blocks, 256, 0, e->stream>>>(P);
@@ -1364,40 +1415,58 @@ int do_compute_error(Engine* e, const CostSource& src, VoxelMapDev& vm, const do
   return FVH_OK;
 }
 
+// What align_begin() leaves for align_finish(): an align is a launch (the persistent LM kernel) and a wait for its result; the C ABI
+// offers the two halves separately (fvh_ndt_align_async / _wait) so that the host can queue the NEXT frame's preparation on the
+// handle's second stream while the LM kernel runs.
+struct AlignCtx {
+  bool active = false;
+  fvh_lm_params p;
+  double guess16[16];
+  bool degenerate = false, persistent = false, sharded = false, no_persist = false, retried = false, forced = false;
+  long long budget = 0;
+  GridPlan plan;
+  int grant_dev = 0;
+  SlotPool::Grant grant;
+  void release_slots() { if (grant.n > 0) g_slots.release(grant_dev, grant); grant = SlotPool::Grant{}; }
+};
+
 template <int MODE>
 int do_align(Engine* e, const CostSource& src, VoxelMapDev& vm, const double* guess16, const fvh_lm_params* params, fvh_lm_result* result, const Rebuild& rebuild_safe,
-             bool retried = false, bool no_persist = false, const GridPlan* forced_plan = nullptr /* multi-launch retry of an aborted persistent launch: its layout */) {
-  if (!guess16 || !result) return e->fail(FVH_ERR_INVALID_ARGUMENT, "align: null argument");
+             bool retried = false, bool no_persist = false, const GridPlan* forced_plan = nullptr);
+
+// first half: validate, pick the route and the grid, launch the persistent LM kernel (the multi-launch route queues nothing here)
+template <int MODE>
+int align_begin(Engine* e, AlignCtx& c, const CostSource& src, VoxelMapDev& vm, const double* guess16, const fvh_lm_params* params,
+                bool retried = false, bool no_persist = false, const GridPlan* forced_plan = nullptr /* multi-launch retry of an aborted persistent launch: its layout */) {
+  if (!guess16) return e->fail(FVH_ERR_INVALID_ARGUMENT, "align: null argument");
   if (!vm.valid) return e->fail(FVH_ERR_BAD_STATE, "align: target voxel map not built");
-  fvh_lm_params p;
+  c = AlignCtx{};
+  fvh_lm_params& p = c.p;
   if (params) p = *params; else fvh_default_lm_params(&p);
+  std::memcpy(c.guess16, guess16, sizeof(c.guess16));
+  c.retried = retried; c.no_persist = no_persist; c.grant_dev = e->device;
   HIP_OR_FAIL(e, e->corr.ensure(2 * sizeof(int) * (size_t)std::max(src.n_upper, 1) * e->n_off));
   LmState* st = e->state.as<LmState>();
   const PoseD guess = pose_from_colmajor16(guess16);
-  const bool degenerate = p.max_iterations <= 0;  // nothing to launch: only the state has to say "done"
-  if (degenerate) {
+  c.degenerate = p.max_iterations <= 0;  // nothing to launch: only the state has to say "done"
+  if (c.degenerate) {
     lm_init_kernel<<<1, 64, 0, e->stream>>>(st, guess, p.rotation_epsilon, p.transformation_epsilon, p.lm_init_lambda_factor, p.max_iterations, p.lm_max_iterations, e->ticket.as<unsigned>());
     HIP_OR_FAIL(e, hipGetLastError());
   }
-  const long long budget = (long long)std::max(p.max_iterations, 0) * (1 + (long long)std::max(p.lm_max_iterations, 0)) + 1;
-  if (e->lm_trace_on) HIP_OR_FAIL(e, e->lm_trace.ensure(sizeof(double) * 6 * (size_t)std::max<long long>(budget, 1)));
+  c.budget = (long long)std::max(p.max_iterations, 0) * (1 + (long long)std::max(p.lm_max_iterations, 0)) + 1;
+  if (e->lm_trace_on) HIP_OR_FAIL(e, e->lm_trace.ensure(sizeof(double) * 6 * (size_t)std::max<long long>(c.budget, 1)));
   e->lm_trace_rows = 0;
-  long long launched = 0;
-  int batch = e->last_steps > 0 ? std::max(e->last_steps, e->prev_steps) + 1 : 8;
-  LmState* h = reinterpret_cast<LmState*>(e->pinned);
   // One persistent launch for the whole LM loop when the problem is in the latency-bound regime and there is no RCCL
   // collective between evaluations. Concurrent aligns of this process (several handles, several host threads) split the
   // device's co-resident workgroup slots (SlotPool); after a watchdog abort -- typically ANOTHER PROCESS on the same GPU, which
   // the pool cannot see -- the handle backs off: it skips the persistent route for 1, 2, 4, ... 64 aligns before trying again,
   // so a shared GPU costs one 50 ms stall now and then instead of one per registration.
   static const int persist_env = [] { const char* v = getenv("FVH_PERSISTENT"); return v ? atoi(v) : 1; }();
-  const bool sharded = MODE == MODE_VGICP && e->peer.attached() && src.shardable;
-  bool persistent = persist_env != 0 && !degenerate && !e->comm && !no_persist && budget < 4000 && (long long)src.n_upper * e->n_off <= PERSIST_MAX_ITEMS;
-  if (persistent && !sharded && e->persist_skip > 0) { e->persist_skip--; persistent = false; }  // backing off (a sharded align must take the same route on every rank)
-  GridPlan plan;
-  if (forced_plan) plan = *forced_plan;
-  struct Slots { int dev; SlotPool::Grant g; ~Slots() { if (g.n > 0) g_slots.release(dev, g); } } slots{e->device, {}};
-  if (persistent) {
+  c.sharded = MODE == MODE_VGICP && e->peer.attached() && src.shardable;
+  c.persistent = persist_env != 0 && !c.degenerate && !e->comm && !no_persist && c.budget < 4000 && (long long)src.n_upper * e->n_off <= PERSIST_MAX_ITEMS;
+  if (c.persistent && !c.sharded && e->persist_skip > 0) { e->persist_skip--; c.persistent = false; }  // backing off (a sharded align must take the same route on every rank)
+  if (forced_plan) { c.plan = *forced_plan; c.forced = true; }
+  if (c.persistent) {
     int cap = persistent_capacity<MODE>(e);
     if (e->peer.attached()) cap = std::max(1, cap / std::max(1, e->peer.ranks_on_device));
     const int want = std::min(cost_shape(e, src).blocks, std::max(cap, 1));
@@ -1405,21 +1474,41 @@ int do_align(Engine* e, const CostSource& src, VoxelMapDev& vm, const double* gu
     // grids under FVH_SMALL_GRID_LAYOUT=1 -- are confined to one XCD each (ng = 1, every hand-off XCD-local).
     const int small_layout = small_grid_layout();
     const bool local_ok = xcd_local_wanted();
-    const bool confine_ok = local_ok && !sharded;  // (a confined launch only pays with XCD-local hand-offs; ranks of a sharded align must agree on the layout)
-    slots.g = g_slots.acquire(e->device, std::max(cap, 1), want, confine_ok, small_layout == 1);
-    int granted = slots.g.n;
+    const bool confine_ok = local_ok && !c.sharded;  // (a confined launch only pays with XCD-local hand-offs; ranks of a sharded align must agree on the layout)
+    c.grant = g_slots.acquire(e->device, std::max(cap, 1), want, confine_ok, small_layout == 1);
+    int granted = c.grant.n;
     if (granted <= 0) {
-      if (sharded) granted = want;  // ranks must not diverge: take the slots anyway (the watchdog covers the rare collision)
-      else persistent = false;
+      if (c.sharded) granted = want;  // ranks must not diverge: take the slots anyway (the watchdog covers the rare collision)
+      else c.persistent = false;
     }
-    plan = GridPlan{};
-    plan.nb = granted;
-    if (slots.g.mask) { plan.mask = slots.g.mask; plan.ng = __builtin_popcount(slots.g.mask); plan.local = 1; }  // one group per XCD
-    else { plan.ng = default_groups(granted); plan.local = (plan.ng == TICKET_GROUPS && local_ok) ? 1 : 0; }  // (one chip-wide group spans XCDs: write-through)
+    c.plan = GridPlan{};
+    c.plan.nb = granted;
+    if (c.grant.mask) { c.plan.mask = c.grant.mask; c.plan.ng = __builtin_popcount(c.grant.mask); c.plan.local = 1; }  // one group per XCD
+    else { c.plan.ng = default_groups(granted); c.plan.local = (c.plan.ng == TICKET_GROUPS && local_ok) ? 1 : 0; }  // (one chip-wide group spans XCDs: write-through)
   }
+  if (c.persistent) {
+    int rc = launch_cost<MODE>(e, src, vm, -1, &guess, nullptr, &p, true, e->peer.x, &c.plan);
+    if (rc) { c.release_slots(); return rc; }
+  }
+  c.active = true;
+  return FVH_OK;
+}
+
+// second half: wait for the persistent kernel's result (or run the multi-launch loop), answer aborts and table overflows, fill `result`
+template <int MODE>
+int align_finish(Engine* e, AlignCtx& c, const CostSource& src, VoxelMapDev& vm, fvh_lm_result* result, const Rebuild& rebuild_safe) {
+  if (!c.active) return e->fail(FVH_ERR_BAD_STATE, "align: nothing in flight");
+  struct Done { AlignCtx& c; ~Done() { c.release_slots(); c.active = false; } } done{c};
+  if (!result) return e->fail(FVH_ERR_INVALID_ARGUMENT, "align: null argument");
+  const fvh_lm_params& p = c.p;
+  const bool persistent = c.persistent, sharded = c.sharded, degenerate = c.degenerate;
+  const long long budget = c.budget;
+  const PoseD guess = pose_from_colmajor16(c.guess16);
+  LmState* st = e->state.as<LmState>();
+  long long launched = 0;
+  int batch = e->last_steps > 0 ? std::max(e->last_steps, e->prev_steps) + 1 : 8;
+  LmState* h = reinterpret_cast<LmState*>(e->pinned);
   if (persistent) {
-    int rc = launch_cost<MODE>(e, src, vm, -1, &guess, nullptr, &p, true, e->peer.x, &plan);
-    if (rc) return rc;
     bool have_result = false;
     if (e->result_dev && e->zero_copy_armed) {
       // spin on the sequence word the kernel writes after the state (mapped pinned memory); if the stream drains without it
@@ -1453,7 +1542,10 @@ int do_align(Engine* e, const CostSource& src, VoxelMapDev& vm, const double* gu
       // arrive here and restart together; the exchange counter jumps past whatever this launch may have used
       if (sharded) e->peer.x = (e->peer.x + 8192) & ~1ull;
       if (h->aborted == 3u) g_xcd_local_strikes.fetch_add(1);  // the members of a group did not share an XCD: a few of these and the XCD-local flavour is off for good
-      return do_align<MODE>(e, src, vm, guess16, params, result, rebuild_safe, retried, true, &plan);  // the same layout: the same partition of the items, the same sums
+      const GridPlan plan = c.plan;
+      const bool retried = c.retried;
+      c.release_slots();
+      return do_align<MODE>(e, src, vm, c.guess16, &p, result, rebuild_safe, retried, true, &plan);  // the same layout: the same partition of the items, the same sums
     }
     launched = 1;
     e->persist_backoff = 0;  // a clean persistent run: the device is ours again
@@ -1463,7 +1555,7 @@ int do_align(Engine* e, const CostSource& src, VoxelMapDev& vm, const double* gu
     for (int s = 0; s < batch; s++) {
       // the first launch carries the initial guess and the LM parameters and (re)initialises the device state
       const bool first = (launched == 0 && s == 0 && !degenerate);
-      int rc = launch_cost<MODE>(e, src, vm, -1, first ? &guess : nullptr, nullptr, first ? &p : nullptr, false, e->peer.x + (unsigned long long)(launched + s), forced_plan ? &plan : nullptr);
+      int rc = launch_cost<MODE>(e, src, vm, -1, first ? &guess : nullptr, nullptr, first ? &p : nullptr, false, e->peer.x + (unsigned long long)(launched + s), c.forced ? &c.plan : nullptr);
       if (rc) return rc;
       if (e->comm) {
         rc = allreduce_sums(e);
@@ -1486,10 +1578,13 @@ int do_align(Engine* e, const CostSource& src, VoxelMapDev& vm, const double* gu
   vm.nv_hint = h->vm_num_voxels;
   if (src.source_map) src.source_map->nv_hint = h->vm_num_voxels2;
   if (h->vm_dropped > 0) {  // hint-sized table overflowed: rebuild at the safe size and run again (rare)
-    if (retried) return e->fail(FVH_ERR_BAD_STATE, "voxel map overflow persists after safe rebuild");
+    if (c.retried) return e->fail(FVH_ERR_BAD_STATE, "voxel map overflow persists after safe rebuild");
+    const bool no_persist = c.no_persist, forced = c.forced;
+    const GridPlan plan = c.plan;
+    c.release_slots();
     int rc = rebuild_safe();
     if (rc) return rc;
-    return do_align<MODE>(e, src, vm, guess16, params, result, rebuild_safe, true, no_persist, forced_plan);
+    return do_align<MODE>(e, src, vm, c.guess16, &p, result, rebuild_safe, true, no_persist, forced ? &plan : nullptr);
   }
   e->gang_clear();
   e->prev_steps = e->last_steps;
@@ -1510,6 +1605,16 @@ int do_align(Engine* e, const CostSource& src, VoxelMapDev& vm, const double* gu
   result->num_launches = (int)launched;
   e->lm_trace_rows = e->lm_trace_on ? h->num_error_evals : 0;
   return FVH_OK;
+}
+
+template <int MODE>
+int do_align(Engine* e, const CostSource& src, VoxelMapDev& vm, const double* guess16, const fvh_lm_params* params, fvh_lm_result* result, const Rebuild& rebuild_safe,
+             bool retried, bool no_persist, const GridPlan* forced_plan) {
+  if (!result) return e->fail(FVH_ERR_INVALID_ARGUMENT, "align: null argument");
+  AlignCtx c;
+  int rc = align_begin<MODE>(e, c, src, vm, guess16, params, retried, no_persist, forced_plan);
+  if (rc) return rc;
+  return align_finish<MODE>(e, c, src, vm, result, rebuild_safe);
 }
 
 int do_fitness(Engine* e, CloudDev& src, CloudDev& tgt, const double* T16, double max_range, double* score) {
@@ -1566,6 +1671,7 @@ int comm_init(Engine* e, const void* id128, int nranks, int rank) {
   int rc = g_rccl.CommInitRank(&e->comm, nranks, uid, rank);
   if (rc != 0) { e->comm = nullptr; return e->fail(FVH_ERR_COMM, "ncclCommInitRank failed with code " + std::to_string(rc)); }
   e->nranks = nranks; e->rank = rank;
+  e->rccl_checked_n = -1;
   return FVH_OK;
 }
 
@@ -1960,6 +2066,10 @@ struct fvh_vgicp {
     return voxel_mode == 2 ? build_voxelmap<2>(&e, target, voxelmap, res, false, force_safe, on_side, shard) : build_voxelmap<0>(&e, target, voxelmap, res, false, force_safe, on_side, shard);
   }
   Rebuild rebuild_safe() { return [this] { return build_map(voxelmap.res, true, nullptr, voxelmap.is_shard); }; }
+  // A sharded align leaves this rank's SHARD behind as the live map; everything host-driven (update_correspondences, compute_error,
+  // the voxel getters) works on the whole map: rebuilt here, at the resolution the live map was built with. (The correspondences of
+  // the shard die with it: compute_error then asks for update_correspondences instead of reading the wrong buckets.)
+  int whole_map() { return (voxelmap.valid && voxelmap.is_shard) ? build_map(voxelmap.res) : (int)FVH_OK; }
 };
 
 struct fvh_ndt {
@@ -1968,6 +2078,13 @@ struct fvh_ndt {
   int distance_mode = FVH_NDT_D2D;  // ndt_cuda.cu:21
   CloudDev source, target;
   VoxelMapDev source_vm, target_vm;
+  // Pipelined frame streams (fvh_ndt_prepare_source_device / _adopt_prepared_source): the NEXT source cloud and its voxel map are built
+  // in this slot on the handle's second stream (Engine::side) while the LM kernel of the current frame runs on the main one
+  CloudDev next_source;
+  VoxelMapDev next_vm;
+  bool next_ready = false;
+  hipEvent_t prep_done = nullptr;
+  AlignCtx pending;  // fvh_ndt_align_async .. fvh_ndt_align_wait
   CostSource cost_source() const {
     if (distance_mode == FVH_NDT_P2D) return CostSource{source.pts.as<float4>(), nullptr, nullptr, source.n, nullptr, coherent_order(source)};
     CostSource cs{source_vm.compact_pts.as<float4>(), source_vm.compact_cov.as<float4>(), source_vm.counters_cur(), source.n, source_vm.counters_cur(), nullptr};
@@ -2136,11 +2253,11 @@ int fvh_vgicp_get_source_neighbors(fvh_vgicp* h, int* k, int* out) { CHECK_HANDL
 int fvh_vgicp_get_target_neighbors(fvh_vgicp* h, int* k, int* out) { CHECK_HANDLE(h); return get_nbr_host(&h->e, h->target, k, out); }
 int fvh_vgicp_get_source_covariances(fvh_vgicp* h, float* c) { CHECK_HANDLE(h); return get_cov_host(&h->e, h->source, c); }
 int fvh_vgicp_get_target_covariances(fvh_vgicp* h, float* c) { CHECK_HANDLE(h); return get_cov_host(&h->e, h->target, c); }
-int fvh_vgicp_get_num_voxels(fvh_vgicp* h, int* n) { CHECK_HANDLE(h); if (!n) return FVH_ERR_INVALID_ARGUMENT; const Rebuild rb = h->rebuild_safe(); int rc = fetch_voxelmap_host(&h->e, h->voxelmap, &rb); if (rc) return rc; *n = (int)h->voxelmap.h_occupied.size(); return FVH_OK; }
-int fvh_vgicp_get_voxel_num_points(fvh_vgicp* h, int* o) { CHECK_HANDLE(h); const Rebuild rb = h->rebuild_safe(); return get_voxels_host(&h->e, h->voxelmap, nullptr, o, nullptr, nullptr, &rb); }
-int fvh_vgicp_get_voxel_means(fvh_vgicp* h, float* o) { CHECK_HANDLE(h); const Rebuild rb = h->rebuild_safe(); return get_voxels_host(&h->e, h->voxelmap, nullptr, nullptr, o, nullptr, &rb); }
-int fvh_vgicp_get_voxel_covs(fvh_vgicp* h, float* o) { CHECK_HANDLE(h); const Rebuild rb = h->rebuild_safe(); return get_voxels_host(&h->e, h->voxelmap, nullptr, nullptr, nullptr, o, &rb); }
-int fvh_vgicp_get_voxel_coords(fvh_vgicp* h, int* o) { CHECK_HANDLE(h); const Rebuild rb = h->rebuild_safe(); return get_voxels_host(&h->e, h->voxelmap, o, nullptr, nullptr, nullptr, &rb); }
+int fvh_vgicp_get_num_voxels(fvh_vgicp* h, int* n) { CHECK_HANDLE(h); { int _w = h->whole_map(); if (_w) return _w; } if (!n) return FVH_ERR_INVALID_ARGUMENT; const Rebuild rb = h->rebuild_safe(); int rc = fetch_voxelmap_host(&h->e, h->voxelmap, &rb); if (rc) return rc; *n = (int)h->voxelmap.h_occupied.size(); return FVH_OK; }
+int fvh_vgicp_get_voxel_num_points(fvh_vgicp* h, int* o) { CHECK_HANDLE(h); { int _w = h->whole_map(); if (_w) return _w; } const Rebuild rb = h->rebuild_safe(); return get_voxels_host(&h->e, h->voxelmap, nullptr, o, nullptr, nullptr, &rb); }
+int fvh_vgicp_get_voxel_means(fvh_vgicp* h, float* o) { CHECK_HANDLE(h); { int _w = h->whole_map(); if (_w) return _w; } const Rebuild rb = h->rebuild_safe(); return get_voxels_host(&h->e, h->voxelmap, nullptr, nullptr, o, nullptr, &rb); }
+int fvh_vgicp_get_voxel_covs(fvh_vgicp* h, float* o) { CHECK_HANDLE(h); { int _w = h->whole_map(); if (_w) return _w; } const Rebuild rb = h->rebuild_safe(); return get_voxels_host(&h->e, h->voxelmap, nullptr, nullptr, nullptr, o, &rb); }
+int fvh_vgicp_get_voxel_coords(fvh_vgicp* h, int* o) { CHECK_HANDLE(h); { int _w = h->whole_map(); if (_w) return _w; } const Rebuild rb = h->rebuild_safe(); return get_voxels_host(&h->e, h->voxelmap, o, nullptr, nullptr, nullptr, &rb); }
 
 static int fetch_corr(Engine* e, int n_src, std::vector<int>& corr) {
   if (!e->has_corr) return e->fail(FVH_ERR_BAD_STATE, "no correspondences: call update_correspondences first");
@@ -2200,7 +2317,7 @@ int fvh_vgicp_update_correspondences(fvh_vgicp* h, const double* T) {
   if (!h->source.has_pts || !h->source.has_cov) return h->e.fail(FVH_ERR_BAD_STATE, "update_correspondences: source cloud/covariances not set");
   if (h->e.sharded() && h->source.n) { int rc = ensure_sorted(&h->e, h->source); if (rc) return rc; }
   h->e.corr_kind = 0;
-  if (h->voxelmap.valid && h->voxelmap.is_shard) { int rc = h->build_map(h->resolution); if (rc) return rc; }  // host-driven evaluations use the whole map (a sharded align left its shard behind)
+  { int rc = h->whole_map(); if (rc) return rc; }  // host-driven evaluations use the whole map (a sharded align left its shard behind)
   return do_update_correspondences<MODE_VGICP>(&h->e, h->cost_source(), h->voxelmap, T);
 }
 // ---- FastGICP (nearest target point) on the same handle: fast_gicp_impl.hpp:118-240 ----
@@ -2238,6 +2355,7 @@ int fvh_vgicp_gicp_get_correspondences(fvh_vgicp* h, int* target_index_per_sourc
 int fvh_vgicp_compute_error(fvh_vgicp* h, const double* T, double* H, double* b, double* err) {
   CHECK_HANDLE(h);
   if (h->e.has_corr && h->e.corr_kind != 0) return h->e.fail(FVH_ERR_BAD_STATE, "compute_error: the stored correspondences are nearest-point (GICP) ones; call update_correspondences first");
+  { int rc = h->whole_map(); if (rc) return rc; }
   return do_compute_error<MODE_VGICP>(&h->e, h->cost_source(), h->voxelmap, T, H, b, err, h->rebuild_safe());
 }
 int fvh_vgicp_align(fvh_vgicp* h, const double* guess, const fvh_lm_params* p, fvh_lm_result* r) {
@@ -2466,6 +2584,8 @@ int fvh_vgicp_peer_detach(fvh_vgicp* h) { CHECK_HANDLE(h); h->e.peer_detach(); h
 int fvh_vgicp_comm_destroy(fvh_vgicp* h) { CHECK_HANDLE(h); if (h->e.comm) { g_rccl.CommDestroy(h->e.comm); h->e.comm = nullptr; } h->e.nranks = 1; h->e.rank = 0; return FVH_OK; }
 
 // ---- NDT ---------------------------------------------------------------------------------------
+// between fvh_ndt_align_async and fvh_ndt_align_wait the handle's clouds, maps and state belong to the running LM kernel
+#define NDT_NOT_PENDING(h) if ((h)->pending.active) return (h)->e.fail(FVH_ERR_BAD_STATE, "an align_async is in flight: call fvh_ndt_align_wait first");
 int fvh_ndt_create(int device, fvh_ndt** out) {
   if (!out) return FVH_ERR_INVALID_ARGUMENT;
   *out = nullptr;
@@ -2481,29 +2601,32 @@ int fvh_ndt_destroy(fvh_ndt* h) {
   if (!h) return FVH_ERR_INVALID_ARGUMENT;
   (void)hipSetDevice(h->e.device);
   if (h->e.stream) (void)hipStreamSynchronize(h->e.stream);
-  h->source.release(); h->target.release(); h->source_vm.release(); h->target_vm.release();
+  if (h->e.side) (void)hipStreamSynchronize(h->e.side);
+  if (h->pending.active) { h->pending.release_slots(); h->pending.active = false; }
+  h->source.release(); h->target.release(); h->source_vm.release(); h->target_vm.release(); h->next_source.release(); h->next_vm.release();
+  if (h->prep_done) (void)hipEventDestroy(h->prep_done);
   h->e.shutdown();
   delete h;
   return FVH_OK;
 }
 const char* fvh_ndt_last_error(const fvh_ndt* h) { return h ? h->e.err.c_str() : "null handle"; }
-int fvh_ndt_set_distance_mode(fvh_ndt* h, int m) { CHECK_HANDLE(h); if (m != FVH_NDT_P2D && m != FVH_NDT_D2D) return h->e.fail(FVH_ERR_INVALID_ARGUMENT, "bad distance mode"); h->distance_mode = m; h->e.has_corr = false; return FVH_OK; }
-int fvh_ndt_set_resolution(fvh_ndt* h, double r) { CHECK_HANDLE(h); if (!(r > 0)) return h->e.fail(FVH_ERR_INVALID_ARGUMENT, "resolution must be > 0"); h->resolution = r; return FVH_OK; }
-int fvh_ndt_set_neighbor_search_method(fvh_ndt* h, int m, double radius) { CHECK_HANDLE(h); return h->e.set_offsets(m, radius); }
-int fvh_ndt_set_precision(fvh_ndt* h, int p) { CHECK_HANDLE(h); if (p != FVH_COMPUTE_FP64 && p != FVH_COMPUTE_FP32) return h->e.fail(FVH_ERR_INVALID_ARGUMENT, "bad precision"); h->e.precision = p; return FVH_OK; }
+int fvh_ndt_set_distance_mode(fvh_ndt* h, int m) { CHECK_HANDLE(h); NDT_NOT_PENDING(h); if (m != FVH_NDT_P2D && m != FVH_NDT_D2D) return h->e.fail(FVH_ERR_INVALID_ARGUMENT, "bad distance mode"); h->distance_mode = m; h->e.has_corr = false; return FVH_OK; }
+int fvh_ndt_set_resolution(fvh_ndt* h, double r) { CHECK_HANDLE(h); NDT_NOT_PENDING(h); if (!(r > 0)) return h->e.fail(FVH_ERR_INVALID_ARGUMENT, "resolution must be > 0"); h->resolution = r; return FVH_OK; }
+int fvh_ndt_set_neighbor_search_method(fvh_ndt* h, int m, double radius) { CHECK_HANDLE(h); NDT_NOT_PENDING(h); return h->e.set_offsets(m, radius); }
+int fvh_ndt_set_precision(fvh_ndt* h, int p) { CHECK_HANDLE(h); NDT_NOT_PENDING(h); if (p != FVH_COMPUTE_FP64 && p != FVH_COMPUTE_FP32) return h->e.fail(FVH_ERR_INVALID_ARGUMENT, "bad precision"); h->e.precision = p; return FVH_OK; }
 int fvh_ndt_swap_source_and_target(fvh_ndt* h) {
-  CHECK_HANDLE(h);
+  CHECK_HANDLE(h); NDT_NOT_PENDING(h);
   h->source.swap(h->target);
   std::swap(h->source_vm, h->target_vm);
   h->e.has_corr = false;
   return FVH_OK;
 }
-int fvh_ndt_set_source_cloud(fvh_ndt* h, const float* xyz, int n) { CHECK_HANDLE(h); h->e.has_corr = false; h->source_vm.invalidate(); return upload_cloud(&h->e, h->source, xyz, n, 3, false, false); }
-int fvh_ndt_set_target_cloud(fvh_ndt* h, const float* xyz, int n) { CHECK_HANDLE(h); h->e.has_corr = false; h->target_vm.invalidate(); return upload_cloud(&h->e, h->target, xyz, n, 3, false, false); }
-int fvh_ndt_set_source_cloud_strided(fvh_ndt* h, const float* xyz, int n, int s) { CHECK_HANDLE(h); h->e.has_corr = false; h->source_vm.invalidate(); return upload_cloud(&h->e, h->source, xyz, n, s, false, false); }
-int fvh_ndt_set_target_cloud_strided(fvh_ndt* h, const float* xyz, int n, int s) { CHECK_HANDLE(h); h->e.has_corr = false; h->target_vm.invalidate(); return upload_cloud(&h->e, h->target, xyz, n, s, false, false); }
-int fvh_ndt_set_source_cloud_device(fvh_ndt* h, const float* d, int n, int s) { CHECK_HANDLE(h); h->e.has_corr = false; h->source_vm.invalidate(); return upload_cloud(&h->e, h->source, d, n, s, true, false); }
-int fvh_ndt_set_target_cloud_device(fvh_ndt* h, const float* d, int n, int s) { CHECK_HANDLE(h); h->e.has_corr = false; h->target_vm.invalidate(); return upload_cloud(&h->e, h->target, d, n, s, true, false); }
+int fvh_ndt_set_source_cloud(fvh_ndt* h, const float* xyz, int n) { CHECK_HANDLE(h); NDT_NOT_PENDING(h); h->e.has_corr = false; h->source_vm.invalidate(); return upload_cloud(&h->e, h->source, xyz, n, 3, false, false); }
+int fvh_ndt_set_target_cloud(fvh_ndt* h, const float* xyz, int n) { CHECK_HANDLE(h); NDT_NOT_PENDING(h); h->e.has_corr = false; h->target_vm.invalidate(); return upload_cloud(&h->e, h->target, xyz, n, 3, false, false); }
+int fvh_ndt_set_source_cloud_strided(fvh_ndt* h, const float* xyz, int n, int s) { CHECK_HANDLE(h); NDT_NOT_PENDING(h); h->e.has_corr = false; h->source_vm.invalidate(); return upload_cloud(&h->e, h->source, xyz, n, s, false, false); }
+int fvh_ndt_set_target_cloud_strided(fvh_ndt* h, const float* xyz, int n, int s) { CHECK_HANDLE(h); NDT_NOT_PENDING(h); h->e.has_corr = false; h->target_vm.invalidate(); return upload_cloud(&h->e, h->target, xyz, n, s, false, false); }
+int fvh_ndt_set_source_cloud_device(fvh_ndt* h, const float* d, int n, int s) { CHECK_HANDLE(h); NDT_NOT_PENDING(h); h->e.has_corr = false; h->source_vm.invalidate(); return upload_cloud(&h->e, h->source, d, n, s, true, false); }
+int fvh_ndt_set_target_cloud_device(fvh_ndt* h, const float* d, int n, int s) { CHECK_HANDLE(h); NDT_NOT_PENDING(h); h->e.has_corr = false; h->target_vm.invalidate(); return upload_cloud(&h->e, h->target, d, n, s, true, false); }
 int fvh_ndt_create_source_voxelmap(fvh_ndt* h) {
   CHECK_HANDLE(h);
   // a swapped-in target map has no compact arrays: rebuild in that case
@@ -2524,28 +2647,85 @@ static int ndt_ready(fvh_ndt* h) {
   return FVH_OK;
 }
 int fvh_ndt_update_correspondences(fvh_ndt* h, const double* T) {
-  CHECK_HANDLE(h);
+  CHECK_HANDLE(h); NDT_NOT_PENDING(h);
   int rc = ndt_ready(h); if (rc) return rc;
   if (h->distance_mode == FVH_NDT_P2D) return do_update_correspondences<MODE_NDT_P2D>(&h->e, h->cost_source(), h->target_vm, T);
   return do_update_correspondences<MODE_NDT_D2D>(&h->e, h->cost_source(), h->target_vm, T);
 }
 int fvh_ndt_compute_error(fvh_ndt* h, const double* T, double* H, double* b, double* err) {
-  CHECK_HANDLE(h);
+  CHECK_HANDLE(h); NDT_NOT_PENDING(h);
   int rc = ndt_ready(h); if (rc) return rc;
   if (h->distance_mode == FVH_NDT_P2D) return do_compute_error<MODE_NDT_P2D>(&h->e, h->cost_source(), h->target_vm, T, H, b, err, h->rebuild_safe());
   return do_compute_error<MODE_NDT_D2D>(&h->e, h->cost_source(), h->target_vm, T, H, b, err, h->rebuild_safe());
 }
 int fvh_ndt_align(fvh_ndt* h, const double* guess, const fvh_lm_params* p, fvh_lm_result* r) {
-  CHECK_HANDLE(h);
+  CHECK_HANDLE(h); NDT_NOT_PENDING(h);
   int rc = fvh_ndt_create_voxelmaps(h);  // NDTCuda::computeTransformation (ndt_cuda_impl.hpp:76-79)
   if (rc) return rc;
   rc = ndt_ready(h); if (rc) return rc;
   if (h->distance_mode == FVH_NDT_P2D) return do_align<MODE_NDT_P2D>(&h->e, h->cost_source(), h->target_vm, guess, p, r, h->rebuild_safe());
   return do_align<MODE_NDT_D2D>(&h->e, h->cost_source(), h->target_vm, guess, p, r, h->rebuild_safe());
 }
+// ---- pipelined frame streams: align = launch + wait; the next source is prepared beside the running LM kernel ----
+int fvh_ndt_align_async(fvh_ndt* h, const double* guess, const fvh_lm_params* p) {
+  CHECK_HANDLE(h);
+  if (h->pending.active) return h->e.fail(FVH_ERR_BAD_STATE, "align_async: the previous align_async has not been waited for");
+  int rc = fvh_ndt_create_voxelmaps(h);
+  if (rc) return rc;
+  rc = ndt_ready(h); if (rc) return rc;
+  if (h->distance_mode == FVH_NDT_P2D) return align_begin<MODE_NDT_P2D>(&h->e, h->pending, h->cost_source(), h->target_vm, guess, p);
+  return align_begin<MODE_NDT_D2D>(&h->e, h->pending, h->cost_source(), h->target_vm, guess, p);
+}
+int fvh_ndt_align_wait(fvh_ndt* h, fvh_lm_result* r) {
+  CHECK_HANDLE_HOST_ONLY(h);
+  if (!h->pending.active) return h->e.fail(FVH_ERR_BAD_STATE, "align_wait: no align_async in flight");
+  if (h->distance_mode == FVH_NDT_P2D) return align_finish<MODE_NDT_P2D>(&h->e, h->pending, h->cost_source(), h->target_vm, r, h->rebuild_safe());
+  return align_finish<MODE_NDT_D2D>(&h->e, h->pending, h->cost_source(), h->target_vm, r, h->rebuild_safe());
+}
+int fvh_ndt_prepare_source_device(fvh_ndt* h, const float* d_xyz, int n, int stride) {
+  CHECK_HANDLE_HOST_ONLY(h);  // (touches the prepared slot and the second stream only: legal between align_async and align_wait)
+  Engine* e = &h->e;
+  hipStream_t ps = e->side_stream();  // null (multi-GPU handle, FVH_SIDE_STREAM=0): in order on the main stream -- correct, nothing overlaps
+  if (ps == nullptr && h->pending.active) return e->fail(FVH_ERR_BAD_STATE, "prepare_source: this handle has no second stream; call it outside align_async .. align_wait");
+  if (!h->prep_done) HIP_OR_FAIL(e, hipEventCreateWithFlags(&h->prep_done, hipEventDisableTiming));
+  h->next_ready = false;
+  h->next_vm.invalidate();
+  int rc = upload_cloud(e, h->next_source, d_xyz, n, stride, true, false, ps);
+  if (rc) return rc;
+  {
+    // D2D registers the map itself; in both modes it is the TARGET map of the frame after (swap_source_and_target): built here it is
+    // hidden too. Its table is sized like the maps of the frames before it (the voxel count the last align saw).
+    if (h->next_vm.nv_hint < 0) h->next_vm.nv_hint = std::max(h->source_vm.nv_hint, h->target_vm.nv_hint);
+    rc = build_voxelmap<1>(e, h->next_source, h->next_vm, h->resolution, true, false, ps, false, /*detached=*/true);
+    if (rc) return rc;
+  }
+  HIP_OR_FAIL(e, hipEventRecord(h->prep_done, ps ? ps : e->stream));
+  h->next_ready = true;
+  return FVH_OK;
+}
+int fvh_ndt_adopt_prepared_source(fvh_ndt* h) {
+  CHECK_HANDLE(h);
+  Engine* e = &h->e;
+  if (h->pending.active) return e->fail(FVH_ERR_BAD_STATE, "adopt_prepared_source: an align_async is in flight");
+  if (!h->next_ready) return e->fail(FVH_ERR_BAD_STATE, "adopt_prepared_source: nothing prepared (fvh_ndt_prepare_source_device)");
+  h->next_ready = false;
+  h->source.swap(h->next_source);
+  std::swap(h->source_vm, h->next_vm);
+  e->has_corr = false;
+  // As a rule the preparation ended while the last align was still running: the host sees that at no cost. Otherwise the main stream waits.
+  if (e->side) {
+    hipError_t q = hipErrorNotReady;
+    for (int spins = 0; spins < 64 && q == hipErrorNotReady; spins++) q = hipEventQuery(h->prep_done);
+    if (q != hipSuccess) {
+      (void)hipGetLastError();
+      HIP_OR_FAIL(e, hipStreamWaitEvent(e->stream, h->prep_done, 0));
+    }
+  }
+  return FVH_OK;
+}
 int fvh_ndt_set_lm_trace(fvh_ndt* h, int on) { CHECK_HANDLE(h); h->e.lm_trace_on = on != 0; return FVH_OK; }
 int fvh_ndt_get_lm_trace(fvh_ndt* h, int* n, double* rows6) { CHECK_HANDLE(h); return get_lm_trace(&h->e, n, rows6); }
-int fvh_ndt_fitness_score(fvh_ndt* h, const double* T, double max_range, double* score) { CHECK_HANDLE(h); return do_fitness(&h->e, h->source, h->target, T, max_range, score); }
+int fvh_ndt_fitness_score(fvh_ndt* h, const double* T, double max_range, double* score) { CHECK_HANDLE(h); NDT_NOT_PENDING(h); return do_fitness(&h->e, h->source, h->target, T, max_range, score); }
 int fvh_ndt_get_num_voxels(fvh_ndt* h, int which, int* n) {
   CHECK_HANDLE(h);
   if (!n) return FVH_ERR_INVALID_ARGUMENT;
@@ -2608,8 +2788,8 @@ int fvh_ndt_profile_enable(fvh_ndt* h, int on) { CHECK_HANDLE(h); h->e.prof.on =
 int fvh_ndt_profile_reset(fvh_ndt* h) { CHECK_HANDLE(h); HIP_OR_FAIL(&h->e, hipStreamSynchronize(h->e.stream)); h->e.prof.reset(); return FVH_OK; }
 int fvh_ndt_profile_get(fvh_ndt* h, const char* cls, double* ms, int* n) { CHECK_HANDLE(h); return profile_get(&h->e, cls, ms, n); }
 int fvh_ndt_synchronize(fvh_ndt* h) { CHECK_HANDLE(h); HIP_OR_FAIL(&h->e, hipStreamSynchronize(h->e.stream)); h->e.gang_clear(); return FVH_OK; }
-int fvh_ndt_comm_init(fvh_ndt* h, const void* id, int nranks, int rank) { CHECK_HANDLE(h); return comm_init(&h->e, id, nranks, rank); }
-int fvh_ndt_comm_destroy(fvh_ndt* h) { CHECK_HANDLE(h); if (h->e.comm) { g_rccl.CommDestroy(h->e.comm); h->e.comm = nullptr; } h->e.nranks = 1; h->e.rank = 0; return FVH_OK; }
+int fvh_ndt_comm_init(fvh_ndt* h, const void* id, int nranks, int rank) { CHECK_HANDLE(h); NDT_NOT_PENDING(h); return comm_init(&h->e, id, nranks, rank); }
+int fvh_ndt_comm_destroy(fvh_ndt* h) { CHECK_HANDLE(h); NDT_NOT_PENDING(h); if (h->e.comm) { g_rccl.CommDestroy(h->e.comm); h->e.comm = nullptr; } h->e.nranks = 1; h->e.rank = 0; return FVH_OK; }
 
 // ---- voxel-grid downsampling ----
 int fvh_voxelgrid_create(int device, fvh_voxelgrid** out) {
@@ -2646,6 +2826,16 @@ int fvh_voxelgrid_share_stream_with_ndt(fvh_voxelgrid* h, fvh_ndt* other) {
   if (other && other->e.device != h->e.device) return h->e.fail(FVH_ERR_INVALID_ARGUMENT, "share_stream: the two handles live on different devices");
   h->e.stream = other ? other->e.stream : h->e.owned_stream;  // null: back to the filter's own stream
   h->e.stream_owner = other ? &other->e : nullptr;
+  return FVH_OK;
+}
+int fvh_voxelgrid_share_prepare_stream_with_ndt(fvh_voxelgrid* h, fvh_ndt* other) {
+  CHECK_HANDLE(h);
+  HIP_OR_FAIL(&h->e, hipStreamSynchronize(h->e.stream));
+  if (!other) return h->e.fail(FVH_ERR_INVALID_ARGUMENT, "share_prepare_stream: null registration handle");
+  if (other->e.device != h->e.device) return h->e.fail(FVH_ERR_INVALID_ARGUMENT, "share_stream: the two handles live on different devices");
+  hipStream_t ps = other->e.side_stream();
+  h->e.stream = ps ? ps : other->e.stream;
+  h->e.stream_owner = &other->e;
   return FVH_OK;
 }
 int fvh_voxelgrid_share_stream_with_vgicp(fvh_voxelgrid* h, fvh_vgicp* other) {

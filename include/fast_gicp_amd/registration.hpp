@@ -649,7 +649,7 @@ public:
     if (!input_ || covs.size() != input_->size()) throw std::invalid_argument("setSourceCovariances: one covariance per source point, after setInputSource");
     call(fvh_vgicp_set_source_covariances(core_, covs.empty() ? nullptr : covs[0].data()), "set_source_covariances");
   }
-  void setTargetCovariances(const Covariances& covs) {
+  virtual void setTargetCovariances(const Covariances& covs) {  // (virtual: FastVGICP's target voxel map is made of them)
     if (!target_ || covs.size() != target_->size()) throw std::invalid_argument("setTargetCovariances: one covariance per target point, after setInputTarget");
     call(fvh_vgicp_set_target_covariances(core_, covs.empty() ? nullptr : covs[0].data()), "set_target_covariances");
   }
@@ -763,7 +763,17 @@ public:
     this->call(fvh_vgicp_set_resolution(core_, 1.0), "set_resolution");
     this->call(fvh_vgicp_set_neighbor_search_method(core_, (int)NeighborSearchMethod::DIRECT1, -1.0), "set_neighbor_search_method");
   }
-  void setResolution(double resolution) { this->call(fvh_vgicp_set_resolution(core_, resolution), "set_resolution"); }  // :36-38
+  // The reference builds the voxel map lazily, inside the first linearisation of every align (fast_vgicp_impl.hpp:120-123), from
+  // whatever resolution and target covariances are current then; this class builds it eagerly -- so every setter the map depends on
+  // rebuilds it when a target is set (setResolution, setTargetCovariances, setVoxelAccumulationMode).
+  void setResolution(double resolution) {  // :36-38
+    this->call(fvh_vgicp_set_resolution(core_, resolution), "set_resolution");
+    if (target_) this->call(fvh_vgicp_create_target_voxelmap(core_), "create_target_voxelmap");
+  }
+  void setTargetCovariances(const typename Base::Covariances& covs) override {  // gicp/fast_gicp.hpp:66-68, consumed by :129-156 of the impl
+    Base::setTargetCovariances(covs);
+    this->call(fvh_vgicp_create_target_voxelmap(core_), "create_target_voxelmap");
+  }
   void setNeighborSearchMethod(NeighborSearchMethod method) {  // :46-48
     if (method == NeighborSearchMethod::DIRECT_RADIUS) detail::check(FVH_ERR_INVALID_ARGUMENT, "setNeighborSearchMethod", "FastVGICP has no DIRECT_RADIUS (fast_vgicp_voxel.hpp:16-43): use FastVGICPCuda");
     this->call(fvh_vgicp_set_neighbor_search_method(core_, (int)method, -1.0), "set_neighbor_search_method");

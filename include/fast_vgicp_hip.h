@@ -259,6 +259,20 @@ int fvh_ndt_create_source_voxelmap(fvh_ndt* h);                                 
 int fvh_ndt_update_correspondences(fvh_ndt* h, const double* T16);                           /* [NC]:49 */
 int fvh_ndt_compute_error(fvh_ndt* h, const double* T16, double* H36, double* b6, double* error); /* [NC]:50 */
 int fvh_ndt_align(fvh_ndt* h, const double* guess16, const fvh_lm_params* params, fvh_lm_result* result);
+/* new: a frame stream as a two-stage pipeline (src/kitti.cpp:95-128 with the preparation of frame k+1 hidden under the registration of
+ * frame k). The handle owns a SECOND stream and a prepared-source slot:
+ *   fvh_ndt_align_async          launches the LM kernel on the main stream and returns; fvh_ndt_align_wait collects its result
+ *                                (together they are fvh_ndt_align, bit for bit). Between the two, only fvh_ndt_prepare_source_device
+ *                                (and a voxel-grid filter sharing the prepare stream) may be called on this handle.
+ *   fvh_ndt_prepare_source_device widens a device cloud into the slot and (D2D) builds its voxel map there, all on the second stream;
+ *                                returns when everything is queued.
+ *   fvh_ndt_adopt_prepared_source the slot becomes the source (what set_source_cloud + the lazy map build of the next align would have
+ *                                made: same kernels, same data, bit-identical maps); the main stream is ordered after the preparation.
+ * The loop:  adopt; align_async; [filter next frame on the prepare stream; prepare_source_device]; align_wait; swap_source_and_target. */
+int fvh_ndt_align_async(fvh_ndt* h, const double* guess16, const fvh_lm_params* params);
+int fvh_ndt_align_wait(fvh_ndt* h, fvh_lm_result* result);
+int fvh_ndt_prepare_source_device(fvh_ndt* h, const float* d_xyz, int n, int stride_floats);
+int fvh_ndt_adopt_prepared_source(fvh_ndt* h);
 int fvh_ndt_fitness_score(fvh_ndt* h, const double* T16, double max_range, double* score);
 int fvh_ndt_set_lm_trace(fvh_ndt* h, int on);
 int fvh_ndt_get_lm_trace(fvh_ndt* h, int* num_rows, double* rows6);
@@ -300,6 +314,9 @@ int fvh_voxelgrid_filter_device(fvh_voxelgrid* h, int method, const float* d_xyz
  * The registration handle must outlive the sharing (un-share or destroy the filter first). */
 int fvh_voxelgrid_share_stream_with_ndt(fvh_voxelgrid* h, fvh_ndt* registration);
 int fvh_voxelgrid_share_stream_with_vgicp(fvh_voxelgrid* h, fvh_vgicp* registration);
+/* same, on the registration handle's SECOND stream (the one fvh_ndt_prepare_source_device works on): the filter of the next frame runs
+ * beside the LM kernel of the current one, its output is ordered before the preparation that consumes it */
+int fvh_voxelgrid_share_prepare_stream_with_ndt(fvh_voxelgrid* h, fvh_ndt* registration);
 int fvh_voxelgrid_filter_device_async(fvh_voxelgrid* h, int method, const float* d_xyz, int n, int stride_floats, float leaf, int* out_n);
 int fvh_voxelgrid_get_points(fvh_voxelgrid* h, float* out_xyz /* host or device, 3*out_n floats */);
 int fvh_voxelgrid_device_points(fvh_voxelgrid* h, const float** d_xyz, int* n);

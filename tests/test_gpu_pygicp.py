@@ -219,3 +219,44 @@ def test_vgicp_honours_k_correspondences_like_the_cpu_class(pygicp, k):
     reg.set_input_target(tgt.astype(np.float64)); reg.set_input_source(src.astype(np.float64))
     assert np.array_equal(reg.align(), T) and reg.has_converged()
     assert isinstance(reg, pygicp.FastGICP) and isinstance(reg, pygicp.LsqRegistration)  # main.cpp:192: FastVGICP derives from FastGICP
+
+
+def test_vgicp_uses_target_covariances_and_resolution_set_after_the_target(pygicp):
+    """fast_vgicp_impl.hpp:56-63,120-123: the CPU class builds its voxel map lazily, inside the first linearisation of an align, from the
+    target covariances and the resolution that are current THEN -- so set_target_covariances() and set_resolution() called after
+    set_input_target() take effect. The host class here builds the map eagerly: both setters must rebuild it (they did not,
+    and user covariances were silently ignored). Checked against the oracle driven with the same covariances / resolution."""
+    from oracle import oracle as O
+    tgt, src = util.bundled_pair(leaf=0.25)
+    rng = np.random.default_rng(5)
+    A = rng.normal(size=(len(tgt), 3, 3)) * 0.05
+    cov_t = A @ np.swapaxes(A, 1, 2) + np.eye(3) * 1e-3  # arbitrary SPD covariances, nothing like the k-NN PLANE ones
+
+    def oracle(res, covs):
+        g = O.FastVGICP(k=20, search=O.DIRECT7, resolution=res)
+        g.set_target(tgt); g.set_source(src)
+        if covs is not None:
+            g.set_target_covs(covs)
+        r = g.align()
+        assert r["converged"]
+        return r["T"].astype(np.float32)
+
+    def make(res):
+        reg = pygicp.FastVGICP()
+        reg.set_resolution(res); reg.set_neighbor_search_method("DIRECT7")
+        reg.set_input_target(tgt.astype(np.float64)); reg.set_input_source(src.astype(np.float64))
+        return reg
+
+    reg = make(1.0)
+    T_default = reg.align()
+    assert util.rel_err(T_default, oracle(1.0, None)) < 1e-4
+    reg.set_target_covariances(cov_t)  # AFTER the target (and its map) exist
+    T_user = reg.align()
+    assert reg.has_converged()
+    assert util.rel_err(T_user, oracle(1.0, cov_t)) < 1e-4
+    assert util.rel_err(T_user, T_default) > 1e-5  # (the user covariances do change the optimum: ignoring them cannot pass)
+    reg = make(1.0)
+    reg.set_resolution(2.0)  # AFTER the target
+    T_res = reg.align()
+    assert util.rel_err(T_res, oracle(2.0, None)) < 1e-4
+    assert util.rel_err(T_res, T_default) > 1e-6

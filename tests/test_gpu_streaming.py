@@ -96,3 +96,83 @@ def test_gicp_kitti_app_on_simulated_sequence(tmp_path, method):
     gt = np.linalg.inv(util.lidar_pose(0)) @ util.lidar_pose(n - 1)
     te, re_ = util.pose_error(gt, est)
     assert te < 0.12 and re_ < np.radians(1.0), (te, re_)
+
+
+def _sorted_map(vm):
+    coords, num, means, covs = vm
+    o = np.lexsort((coords[:, 2], coords[:, 1], coords[:, 0]))
+    return coords[o], num[o], means[o], covs[o]
+
+
+@pytest.mark.parametrize("mode", [1, 0])  # D2D (NDTCuda default), P2D
+def test_pipelined_frame_stream_equals_the_sequential_loop(mode):
+    """The two-stage pipeline of the C ABI (fvh_ndt_align_async / _wait, fvh_ndt_prepare_source_device / _adopt_prepared_source, the
+    voxel-grid filter on the handle's prepare stream): frame k+1 is filtered, widened and its voxel map built on the second stream while
+    the LM kernel of frame k runs (kitti.cpp:95-128: filter -> setInputSource -> align -> swapSourceAndTarget, one stage ahead).
+    Same kernels on the same data: the voxel maps it registers are the sequential loop's record for record (fp32 records, compared as
+    sets: the ORDER of a map's voxel list is decided by atomics in both loops and differs between two runs of either), iteration counts
+    are equal and the poses agree to the noise of that order (fp64 sums in another order: 1e-9 relative is 1e5 x looser than observed)."""
+    import torch
+    from fast_gicp_amd import capi
+    n_frames = 9
+    raw = [util.lidar_frame(i) for i in range(n_frames)]
+    dev = torch.device("cuda", 0)
+    d_raw = [torch.from_numpy(f).to(dev).contiguous() for f in raw]
+
+    def make():
+        c = capi.NDTCore(0)
+        c.set_distance_mode(mode); c.set_neighbor_search_method(1); c.set_resolution(1.0)
+        return c
+
+    # ---- sequential ----
+    vg, c = capi.VoxelGrid(0), make()
+    ptr, n = vg.filter_device(d_raw[0].data_ptr(), len(raw[0]), 0.25)
+    c.set_target_cloud_device(ptr, n, 3)
+    seq, seq_maps = [], []
+    for i in range(1, n_frames):
+        ptr, n = vg.filter_device(d_raw[i].data_ptr(), len(raw[i]), 0.25)
+        c.set_source_cloud_device(ptr, n, 3)
+        r = c.align()
+        assert r["converged"]
+        seq.append((r["T"].copy(), r["H"].copy(), r["final_error"], r["num_linearize"], r["num_error_evals"]))
+        seq_maps.append((_sorted_map(c.get_voxelmap("source")) if mode == 1 else None, _sorted_map(c.get_voxelmap("target"))))
+        c.swap_source_and_target()
+    vg.close(); c.close()
+
+    # ---- pipelined ----
+    vg, c = capi.VoxelGrid(0), make()
+    ptr, n = vg.filter_device(d_raw[0].data_ptr(), len(raw[0]), 0.25)
+    c.set_target_cloud_device(ptr, n, 3)
+    vg.share_prepare_stream(c)
+    ptr, n = vg.filter_device(d_raw[1].data_ptr(), len(raw[1]), 0.25, asynchronous=True)
+    c.prepare_source_device(ptr, n, 3)
+    for i in range(1, n_frames):
+        c.adopt_prepared_source()
+        c.align_async()
+        if i + 1 < n_frames:  # the next frame, beside the running LM kernel
+            ptr, n = vg.filter_device(d_raw[i + 1].data_ptr(), len(raw[i + 1]), 0.25, asynchronous=True)
+            c.prepare_source_device(ptr, n, 3)
+        r = c.align_wait()
+        T, H, err, nl, ne = seq[i - 1]
+        assert r["converged"] and r["num_launches"] == 1
+        assert (r["num_linearize"], r["num_error_evals"]) == (nl, ne), i
+        assert util.rel_err(r["T"], T) < 1e-9 and util.rel_err(r["H"], H) < 1e-9 and abs(r["final_error"] - err) <= 1e-9 * abs(err), i
+        src_map, tgt_map = seq_maps[i - 1]
+        for a, b in zip(_sorted_map(c.get_voxelmap("target")), tgt_map):
+            assert np.array_equal(a, b), i
+        if mode == 1:
+            for a, b in zip(_sorted_map(c.get_voxelmap("source")), src_map):
+                assert np.array_equal(a, b), i
+        c.swap_source_and_target()
+    # misuse is refused, not undefined
+    with pytest.raises(capi.FvhError):
+        c.adopt_prepared_source()  # nothing prepared
+    with pytest.raises(capi.FvhError):
+        c.align_wait()  # nothing in flight
+    c.align_async()
+    with pytest.raises(capi.FvhError):
+        c.align_async()  # one in flight already
+    with pytest.raises(capi.FvhError):
+        c.swap_source_and_target()
+    assert c.align_wait()["converged"] is not None
+    vg.close(); c.close()
