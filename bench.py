@@ -39,7 +39,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 T_START = time.perf_counter()
-PMC_FILE = os.path.join(ROOT, "profiles", "r04_pmc.json")
+PMC_FILE = os.path.join(ROOT, "profiles", "r05_pmc.json")
 # the cpu_baseline legs (oracle, OpenMP): threads next to each other -- they share the voxel map and the kd-tree through the caches
 os.environ.setdefault("OMP_PROC_BIND", "close")
 os.environ.setdefault("OMP_PLACES", "cores")
@@ -258,7 +258,7 @@ _PMC = {}
 
 
 def pmc_entry(key):
-    """(entry, source) of the committed PMC passes of this round (profiles/r04_pmc.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE / SQ group
+    """(entry, source) of the committed PMC passes of this round (profiles/r05_pmc.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE / SQ group
     in separate runs of THIS command, tools/r03_artifacts.sh + tools/pmc_collect.py; FETCH doubled per the gfx950 note of
     MI355X_MICROARCH.md). PMC counters cannot be collected inside a timed run, so the numbers are a committed measurement -- stamped
     with the commit and a hash of fast_gicp_amd/csrc/ they were taken at, and NOT quoted once the kernels have changed."""
@@ -270,10 +270,10 @@ def pmc_entry(key):
         _PMC["_stale"] = _PMC.get("_meta", {}).get("csrc_sha") != csrc_sha()
     meta = _PMC.get("_meta", {})
     if not meta:
-        return None, "no PMC pass committed for this round (profiles/r04_pmc.json)"
+        return None, "no PMC pass committed for this round (profiles/r05_pmc.json)"
     if _PMC["_stale"]:
         return None, "PMC pass of commit %s is older than fast_gicp_amd/csrc/ (hash %s != %s): not quoted" % (meta.get("commit"), meta.get("csrc_sha"), csrc_sha())
-    return _PMC.get(key), "committed PMC pass of commit %s (profiles/r04_pmc.json, csrc hash %s == this tree)" % (meta.get("commit"), meta.get("csrc_sha"))
+    return _PMC.get(key), "committed PMC pass of commit %s (profiles/r05_pmc.json, csrc hash %s == this tree)" % (meta.get("commit"), meta.get("csrc_sha"))
 
 
 def pmc_traffic(key):
@@ -281,23 +281,36 @@ def pmc_traffic(key):
     return (e or {}).get("hbm_bytes_per_launch"), src
 
 
+VALU_PEAK_LANE_OPS = 78.6e12   # 1024 SIMDs x 64 lanes / 2 cycles x 2.4 GHz: one wave64 VALU instruction per SIMD every 2 cycles (MI355X_MICROARCH.md)
+VALU_PEAK_FLOPS = 157.3e12     # the same, 2 flop per lane-op (fma): the guide's fp32 vector peak
+VALU_PROBE_LANE_OPS = 50.9e12  # what a pure v_fma_f32 stream of 8 waves per SIMD sustained on this chip (tools/probes/probe_valu_rate.hip, profiles/r05_valu_rate.txt)
+
+
 def valu_roofline(key, kernel, avg_us, n_queries, n_candidates):
-    """the O(N^2)-class kernels (exact k-NN, RBF sweep) are fp32-VALU bound, not HBM bound: VALU pipe utilisation from
-    the SQ pass + the pair-evaluation rate a full N x N sweep would need to match the culled search."""
+    """the O(N^2)-class kernels (exact k-NN, RBF sweep) are fp32-VALU bound, not HBM bound. `frac` = the share of the peak VALU
+    ISSUE rate (SQ_INSTS_VALU x 2 cycles / SIMD cycles of the launch, from the committed SQ pass: <= 1 by construction); `flop_frac` = the
+    useful arithmetic -- candidate distances and box tests the culled search actually evaluated (tools/pair_counts.py) x flop each / launch
+    time / 157.3 TFLOP/s: most issued instructions of these kernels are selection (64-bit key compares, DPP moves, ballots), not flops."""
     e, src = pmc_entry(key)
     sq = (e or {}).get("sq") or {}
-    util = sq.get("valu_pipe_utilisation_of_chip")
+    pairs = (e or {}).get("pairs") or {}
     insts, t_us = (sq.get("counters_per_launch") or {}).get("SQ_INSTS_VALU"), sq.get("avg_launch_us_in_this_pass")
-    rate = None if not insts or not t_us else round(insts * 64 / (t_us * 1e-6) / 1e12, 3)
-    return {"kernel": kernel, "bound": "valu", "achieved": rate, "peak": 78.6, "unit": "T lane-op/s (VALU instructions x 64 lanes per second; peak = 256 CUs x 4 SIMD-32 x 2.4 GHz)",
-            "frac": util, "frac_definition": "VALU pipe busy: SQ_ACTIVE_INST_VALU x 4 / (GRBM_GUI_ACTIVE / 8 XCDs x 1024 SIMDs) -- the share of all SIMD cycles of the launch in which a VALU "
-                                             "instruction occupied the pipe (%s cycles per instruction in this mix: transcendental, 64-bit and compare instructions take more than the 2 of a plain fp32 op)"
-                                             % sq.get("cycles_per_valu_instruction"),
+    rate = None if not insts or not t_us else insts * 64 / (t_us * 1e-6)
+    flop = pairs.get("flop_per_launch")
+    flop_rate = None if not flop or not avg_us else flop / (avg_us * 1e-6)
+    return {"kernel": kernel, "bound": "valu", "achieved": None if rate is None else round(rate / 1e12, 3), "peak": VALU_PEAK_LANE_OPS / 1e12, "unit": "T lane-op/s",
+            "frac": sq.get("valu_issue_utilisation"),
+            "frac_definition": "VALU issue utilisation: SQ_INSTS_VALU x 2 cycles / (GRBM_GUI_ACTIVE / 8 XCDs x 1024 SIMDs) of the PMC pass -- the share of the peak rate of one wave64 "
+                               "VALU instruction per SIMD every 2 cycles; <= 1 by construction (DPP, 64-bit and transcendental instructions take longer than 2 cycles)",
+            "frac_of_measured_fma_issue_rate": None if rate is None else round(rate / VALU_PROBE_LANE_OPS, 4),
+            "flop_frac": None if flop_rate is None else round(flop_rate / VALU_PEAK_FLOPS, 5),
+            "flop_per_launch": flop, "achieved_tflops": None if flop_rate is None else round(flop_rate / 1e12, 3), "peak_tflops": VALU_PEAK_FLOPS / 1e12,
+            "candidates_per_query": pairs.get("candidates_per_query"), "box_tests_per_launch": pairs.get("box_tests_per_launch"),
             "valu_busy_frac_of_wave_cycles": sq.get("valu_busy_frac_of_wave_cycles"), "waiting_frac_of_wave_cycles": sq.get("waiting_frac_of_wave_cycles"),
             "valu_insts_per_query": sq.get("valu_insts_per_wave"), "counters_source": src,
             "pair_evaluations_per_sec_full_sweep_equivalent": round(float(n_queries) * n_candidates / (avg_us * 1e-6), 1),
-            "note": "one query per wave, culled by two levels of tile boxes: the sweep visits ~10 tiles x 64 candidates per query, so the full-sweep-equivalent rate is what a "
-                    "brute-force N x N kernel would have to sustain (8 flop per pair), not arithmetic this kernel performs"}
+            "note": "one query per wave, culled by two levels of tile boxes: the full-sweep-equivalent rate is what a brute-force N x N kernel would have to sustain, "
+                    "not arithmetic this kernel performs; flop_frac counts the arithmetic it does perform"}
 
 
 def thread_counts():
@@ -810,7 +823,7 @@ def run_stream(args, steps, warmup, cpu_loops=15, frames_n=10):
             sq = ((pmc_entry("lidar_stream_cost")[0] or {}).get("sq") or {}) if traffic is not None else {}
             roofline = {"kernel": "cost_kernel<%s,NDT_D2D,persistent>" % ("double" if args.precision == "fp64" else "float"), "bound": "hbm", "achieved": round(ach, 2), "peak": 8000.0,
                         "unit": "GB/s", "frac": round(ach / 8000.0, 5), "traffic": traffic, "traffic_source": traffic_src,
-                        "valu_busy_frac_of_wave_cycles": sq.get("valu_busy_frac_of_wave_cycles"), "valu_pipe_utilisation_of_chip": sq.get("valu_pipe_utilisation_of_chip"),
+                        "valu_busy_frac_of_wave_cycles": sq.get("valu_busy_frac_of_wave_cycles"), "valu_issue_utilisation": sq.get("valu_issue_utilisation"),
                         "algorithmic_bytes_per_launch": int(b), "algorithmic_bytes_per_evaluation": int(bytes_eval), "evaluations_per_launch": round(evals, 3),
                         "source_voxels": n_sv, "target_voxels": n_tv, "correspondences": n_c, "avg_launch_us": round(ms / n * 1e3, 3), "launches": n,
                         "note": "a few thousand source voxels x 7 offsets: ~%d trips of a barrier-separated latency chain (per trip ~5 us of one-item-per-thread main loop "
@@ -821,10 +834,13 @@ def run_stream(args, steps, warmup, cpu_loops=15, frames_n=10):
             # second entry: the stage with real bytes in this loop, the filter. Algorithmic bytes: read N x 12 B, write M x 12 B
             b = n_raw * 12 + n_ds * 12
             ach = b / (ms / n * 1e-3) / 1e9
+            # PMC traffic of the chain = the sum over its four kernels (one FETCH_SIZE and one WRITE_SIZE pass of this command, profiles/r05_pmc.json)
+            parts = [pmc_traffic("lidar_stream_downsample_" + k)[0] for k in ("hist", "scatter", "mark", "emit")]
+            ds_traffic = int(sum(parts)) if all(p is not None for p in parts) else None
             roofline_ds = {"kernel": "voxel-grid filter (ApproximateVoxelGrid, 4 launches: slot histogram, scatter, mark, emit; the two scans are recomputed per workgroup)", "bound": "hbm", "achieved": round(ach, 2),
-                           "peak": 8000.0, "unit": "GB/s", "frac": round(ach / 8000.0, 5), "traffic": None, "algorithmic_bytes_per_launch": b,
+                           "peak": 8000.0, "unit": "GB/s", "frac": round(ach / 8000.0, 5), "traffic": ds_traffic, "traffic_per_kernel": dict(zip(("hist", "scatter", "mark", "emit"), parts)), "algorithmic_bytes_per_launch": b,
                            "avg_launch_us": round(ms / n * 1e3, 3), "launches": n,
-                           "note": "1.4 MB of input per frame: launch/latency bound (a chain of four dependent small kernels), not HBM bound; `traffic`: a per-chain PMC figure is not collected"}
+                           "note": "1.4 MB of input per frame: launch/latency bound (a chain of four dependent small kernels), not HBM bound; `traffic` = the four kernels' PMC bytes summed"}
     cpu = None
     if not args.no_cpu_baseline:
         from oracle import oracle as O
@@ -1000,8 +1016,9 @@ def run_registration(args, workload, cov, search_name, steps, warmup, local_rank
         barrier()
         t0 = time.perf_counter()
         for it in range(steps):
-            if profile and it % PROFILE_EVERY <= 1:  # (on at 0, off again at 1: a call per step would sit between an align and the next launch, with the GPU idle)
-                core.profile_enable(2 if it % PROFILE_EVERY == 0 else 0)  # level 2: the LM kernel only (the roofline's launch time); the other stages are timed after the timed region
+            g = _rep * steps + it  # (counted over all repeats: the samples then alternate between the two directions of the pair whatever `steps` is)
+            if profile and g % PROFILE_EVERY <= 1:  # (on at 0, off again at 1: a call per step would sit between an align and the next launch, with the GPU idle)
+                core.profile_enable(2 if g % PROFILE_EVERY == 0 else 0)  # level 2: the LM kernel only (the roofline's launch time); the other stages are timed after the timed region
             step()
             n_lin += state["last"]["num_linearize"]
             n_err += state["last"]["num_error_evals"]
@@ -1073,7 +1090,7 @@ def run_registration(args, workload, cov, search_name, steps, warmup, local_rank
             sq = ((pmc_entry(key)[0] or {}).get("sq") or {}) if traffic is not None else {}
             roofline = {"kernel": kname, "bound": "hbm", "achieved": round(achieved, 2),
                         "peak": 8000.0, "unit": "GB/s", "frac": round(achieved / 8000.0, 5), "traffic": traffic, "traffic_source": traffic_src,
-                        "valu_busy_frac_of_wave_cycles": sq.get("valu_busy_frac_of_wave_cycles"), "valu_pipe_utilisation_of_chip": sq.get("valu_pipe_utilisation_of_chip"),
+                        "valu_busy_frac_of_wave_cycles": sq.get("valu_busy_frac_of_wave_cycles"), "valu_issue_utilisation": sq.get("valu_issue_utilisation"),
                         "algorithmic_bytes_per_launch": int(bytes_launch),
                         "algorithmic_bytes_per_evaluation": bytes_eval, "evaluations_per_launch": round(evals_per_launch, 3),
                         "avg_launch_us": round(avg_s * 1e6, 3), "launches": cost_n,

@@ -14,7 +14,7 @@ from . import build as _build
 REG_NONE, REG_MIN_EIG, REG_NORMALIZED_MIN_EIG, REG_PLANE, REG_FROBENIUS = range(5)
 DIRECT27, DIRECT7, DIRECT1, DIRECT_RADIUS = range(4)
 NDT_P2D, NDT_D2D = 0, 1
-COMPUTE_FP64, COMPUTE_FP32 = 0, 1
+COMPUTE_FP64, COMPUTE_FP32, COMPUTE_CUDA_COMPAT = 0, 1, 2
 VOXEL_ADDITIVE, VOXEL_ADDITIVE_WEIGHTED, VOXEL_MULTIPLICATIVE = range(3)
 
 EXPORTED_SYMBOLS = None  # filled by _declared_symbols()
@@ -290,6 +290,11 @@ class VGICPCore(_Core):
         boxes = np.empty(((max(n, 1) + 63) // 64, 8), np.float32)
         self._call("debug_get_spatial_order", 0 if which == "source" else 1, _p(order), _p(boxes))
         return order[:n], boxes[: (n + 63) // 64]
+
+    def debug_live_map_voxels(self):
+        n = C.c_int(0)
+        self._call("debug_get_live_map_voxels", C.byref(n))
+        return n.value
 
     def debug_map_shard(self):
         a, b = C.c_int(0), C.c_int(0)

@@ -168,16 +168,15 @@ inline long long steady_ns() { return std::chrono::duration_cast<std::chrono::na
 struct SlotPool {
   std::mutex mu;
   int reserved[16] = {0}, active[16] = {0}, recent[16] = {0}, calm[16] = {0};
-  int used[16][8] = {{0}};  // slots held per XCD (a spread grid of n workgroups holds ceil(n / 8) on each: block b runs on XCD b % 8)
   std::chrono::steady_clock::time_point last_contention[16];
   static constexpr int DECAY_AFTER = 32;       // releases in a row that saw less concurrency than the estimate before the estimate drops by one
   static constexpr int QUIET_RESET_MS = 20;    // no overlapping align / refusal for this long: the burst is over, the estimate starts again from what is active now
-  struct Grant { int n = 0; unsigned mask = 0; };  // n workgroups; mask != 0: all of them on these XCDs, ceil(n / popcount) each (a launch confined by CostParams::xcd_mask)
-  // `confine_ok`: the caller can run on a SUBSET of the XCDs (its persistent launch is dispatched 8 x too wide and keeps the workgroups
-  // that land there). Taken when other aligns are in flight -- K aligns then share the chip XCD by XCD (8 / K each, the least loaded
-  // ones), each with XCD-local hand-offs, instead of K chip-wide grids of polling waves fighting for the same SIMDs -- or when the
-  // caller prefers ONE XCD for a small grid (`prefer_single`).
-  Grant acquire(int dev, int cap, int want, bool confine_ok, bool prefer_single) {  // -> n == 0: use the multi-launch route
+  struct Grant { int n = 0; };  // n workgroups, spread over the chip (block b runs on XCD b % 8)
+  // (Round 4 could also confine a grant to a subset of the XCDs -- K concurrent aligns sharing the chip XCD by XCD, or a small grid on ONE
+  // XCD. Measured, profiles/r04_concurrency.txt / r04_small_grid_layouts.txt: no better than chip-wide grids of cap / K workgroups -- a
+  // hand-off costs ~1 us whether or not it crosses XCDs, and a confined launch has to leave room for the blocks that only pass through.
+  // Removed from the pool and from the kernel.)
+  Grant acquire(int dev, int cap, int want) {  // -> n == 0: use the multi-launch route
     std::lock_guard<std::mutex> lk(mu);
     dev &= 15;
     const auto now = std::chrono::steady_clock::now();
@@ -189,37 +188,14 @@ struct SlotPool {
     else if (recent[dev] > 1 && now - last_contention[dev] > std::chrono::milliseconds(QUIET_RESET_MS)) { recent[dev] = 1; calm[dev] = 0; }
     recent[dev] = std::max(recent[dev], active[dev]);
     static const int max_split = [] { const char* v = getenv("FVH_SLOT_MAX_SPLIT"); return v ? std::max(1, atoi(v)) : 4; }();
-    // FVH_SHARE_BY_XCD=1: concurrent aligns are confined to 8 / K XCDs each (below). Measured (tools/r04_conc.py, profiles/r04_concurrency.txt):
-    // no better than chip-wide grids of cap / K workgroups -- 4 handles 15.8k vs 16.9k aligns/s, 8 handles 16.0k vs 19.9k: a hand-off costs
-    // ~1 us whether or not it crosses XCDs, and a confined grid has to leave room for the blocks that only pass through. Off by default.
-    static const int share_by_xcd = [] { const char* v = getenv("FVH_SHARE_BY_XCD"); return v ? atoi(v) : 0; }();
-    const int per_xcd = std::max(1, cap / 8);
-    // A confined launch is dispatched over ALL XCDs and keeps the workgroups that land on its own: the others must find a free slot on
-    // THEIR XCD to start and exit. XCDs filled to the brim by other aligns' resident workgroups would block them (and with them the
-    // launch, until the watchdog: measured, 4 streams at 96 of 96 slots per XCD ran ten times slower than unconfined) -- so a confined
-    // align takes at most two of the three workgroup slots of a CU; the third stays free for transients and the other streams' kernels.
-    static const int confined_pct = [] { const char* v = getenv("FVH_CONFINED_SLOT_PCT"); return v ? std::min(100, std::max(10, atoi(v))) : 67; }();
-    Grant g;
+    // (FVH_CONTENDED_SLOT_PCT: the part of the device the concurrent aligns may hold between them -- the rest stays free for the other
+    // streams' neighbour searches and sorts, which cannot start on a CU whose register file three resident LM workgroups fill)
+    static const int contended_pct = [] { const char* v = getenv("FVH_CONTENDED_SLOT_PCT"); return v ? std::min(100, std::max(10, atoi(v))) : 100; }();
     const bool contended = recent[dev] > 1;
-    const int per_xcd_confined = contended ? std::max(1, per_xcd * confined_pct / 100) : per_xcd;
-    if (confine_ok && ((contended && share_by_xcd) || (prefer_single && want <= per_xcd))) {
-      const int k_max = contended ? std::max(1, 8 / std::max(1, std::min(recent[dev], max_split))) : 1;
-      const int k = std::max(1, std::min(k_max, (want + per_xcd_confined - 1) / per_xcd_confined));
-      int order[8] = {0, 1, 2, 3, 4, 5, 6, 7};
-      std::stable_sort(order, order + 8, [&](int a, int b) { return used[dev][a] < used[dev][b]; });
-      int worst = 0;
-      for (int i = 0; i < k; i++) { g.mask |= 1u << order[i]; worst = std::max(worst, used[dev][order[i]]); }
-      g.n = std::min(want, k * std::max(0, per_xcd_confined - worst));
-    } else {
-      int worst = 0;
-      for (int x = 0; x < 8; x++) worst = std::max(worst, used[dev][x]);
-      // (FVH_CONTENDED_SLOT_PCT: the part of the device the concurrent aligns may hold between them -- the rest stays free for the other
-      // streams' neighbour searches and sorts, which cannot start on a CU whose register file three resident LM workgroups fill)
-      static const int contended_pct = [] { const char* v = getenv("FVH_CONTENDED_SLOT_PCT"); return v ? std::min(100, std::max(10, atoi(v))) : 100; }();
-      const int pool = contended ? cap * contended_pct / 100 : cap;
-      const int share = std::max(1, pool / std::max(1, std::min(recent[dev], max_split)));
-      g.n = std::min(std::min(want, share), 8 * (per_xcd - worst));
-    }
+    const int pool = contended ? cap * contended_pct / 100 : cap;
+    const int share = std::max(1, pool / std::max(1, std::min(recent[dev], max_split)));
+    Grant g;
+    g.n = std::min(std::min(want, share), std::max(0, cap - reserved[dev]));
     if (g.n < std::min(want, 32)) {  // too little left to be worth a gang launch
       // a refused request holds nothing and is never released: it must not stay counted in `active` (round 2 leaked it here, and
       // every later persistent launch of the process got cap / min(recent, 4) workgroups for good). The concurrency ESTIMATE keeps
@@ -230,13 +206,7 @@ struct SlotPool {
       return Grant{};
     }
     reserved[dev] += g.n;
-    charge(dev, g, +1);
     return g;
-  }
-  void charge(int dev, const Grant& g, int sign) {
-    const unsigned m = g.mask ? g.mask : 0xFFu;
-    const int k = __builtin_popcount(m), each = (g.n + k - 1) / k;
-    for (int x = 0; x < 8; x++) if ((m >> x) & 1u) used[dev][x] += sign * each;
   }
   void snapshot(int dev, int* res, int* act, int* rec) {
     std::lock_guard<std::mutex> lk(mu);
@@ -247,7 +217,6 @@ struct SlotPool {
     std::lock_guard<std::mutex> lk(mu);
     dev &= 15;
     reserved[dev] -= g.n;
-    charge(dev, g, -1);
     active[dev]--;
     // The estimate of the concurrency decays slowly: host threads spend half their time between aligns, so `active` at a release
     // under-reads the contention. (Dropping it at every calm release made four 474-workgroup aligns oscillate: shares grew back to
@@ -271,14 +240,14 @@ inline bool xcd_local_wanted() {
   return env_on && g_xcd_local_strikes.load() < XCD_LOCAL_MAX_STRIKES;
 }
 // the layout of one cost launch: both routes of an align take the same (nb, ng), i.e. the same partition and summation order
-struct GridPlan { int nb = 0; int ng = 0; unsigned mask = 0; int local = 0; };
+struct GridPlan { int nb = 0; int ng = 0; int local = 0; };
 // Grids of up to SINGLE_LEVEL_MAX_BLOCKS workgroups (NDT D2D over a few thousand source voxels, DIRECT1 at 17k points):
-//   FVH_SMALL_GRID_LAYOUT=0  chip-wide, ONE group: rows -> workgroup 0 -> broadcast, write-through hand-offs (round 3);
-//                        =1  confined to ONE XCD when they fit (<= a sixth of the co-resident slots): every hand-off is XCD-local;
-//                        =2  chip-wide in EIGHT groups like the large grids (XCD-local rows and broadcast, one cross-XCD hand-off).
+//   FVH_SMALL_GRID_LAYOUT=2 (default)  chip-wide in EIGHT groups like the large grids (XCD-local rows and broadcast, one cross-XCD hand-off);
+//                        =0            chip-wide, ONE group: rows -> workgroup 0 -> broadcast, write-through hand-offs (round 3; kept for A/B runs
+//                                      and as the second layout the bit-identity tests walk). (=1, one XCD only, was measured worse and is gone.)
 // The group count is a function of the grid size alone, so that every route of an align adds the sums in the same order.
 inline int small_grid_layout() {
-  static const int v = [] { const char* e = getenv("FVH_SMALL_GRID_LAYOUT"); return e ? atoi(e) : 2; }();
+  static const int v = [] { const char* e = getenv("FVH_SMALL_GRID_LAYOUT"); return (e && atoi(e) == 0) ? 0 : 2; }();
   return v;
 }
 inline int default_groups(int nb) {
@@ -291,6 +260,7 @@ struct Engine {
   hipStream_t stream = nullptr;
   std::string err;
   int precision = FVH_COMPUTE_FP64;
+  bool float_cost() const { return precision != FVH_COMPUTE_FP64; }  // FP32 and CUDA_COMPAT: the per-correspondence arithmetic in float (sums in fp64)
   std::vector<int> offsets_host{0, 0, 0};
   int n_off = 1;
   DevBuf fit_best;   // squared nearest-neighbour distance per source point (fitness score)
@@ -953,7 +923,10 @@ int calc_cov_knn(Engine* e, CloudDev& c, int method) {
     const int* subset = sharded ? c.order.as<int>() + t.lo : nullptr;  // ... its tile of the Morton order
     ProfScope ps(e, "cov");
     const int blocks = (int)(((long long)m * COV_LANES + 255) / 256);
-    if (m > 0) {
+    if (m > 0 && e->precision == FVH_COMPUTE_CUDA_COMPAT) {
+      // FastVGICPCuda's own arithmetic: uncentred float sums in list order + Eigen's closed-form float eigen solver (kernels_cov.hpp)
+      cov_from_neighbors_cuda_compat_kernel<<<(m + 255) / 256, 256, 0, e->stream>>>(c.pts.as<float4>(), m, c.k, c.nbr.as<int>(), method, c.cov.as<float4>(), subset);
+    } else if (m > 0) {
       if (c.k <= 20) cov_from_neighbors_kernel<5><<<blocks, 256, 0, e->stream>>>(c.pts.as<float4>(), m, c.k, c.nbr.as<int>(), method, c.cov.as<float4>(), subset);
       else if (c.k <= 32) cov_from_neighbors_kernel<8><<<blocks, 256, 0, e->stream>>>(c.pts.as<float4>(), m, c.k, c.nbr.as<int>(), method, c.cov.as<float4>(), subset);
       else cov_from_neighbors_regather_kernel<<<blocks, 256, 0, e->stream>>>(c.pts.as<float4>(), m, c.k, c.nbr.as<int>(), method, c.cov.as<float4>(), subset);
@@ -1193,7 +1166,7 @@ int persistent_capacity(Engine* e) {
   static std::mutex mu;
   static int cap[16][2];  // [device][precision]; 0 = not queried yet
   std::lock_guard<std::mutex> lk(mu);
-  const int pi = e->precision == FVH_COMPUTE_FP32 ? 1 : 0, dev = e->device & 15;
+  const int pi = e->float_cost() ? 1 : 0, dev = e->device & 15;
   if (cap[dev][pi] <= 0) {
     int per_cu = 0, cus = 0;
     hipError_t r = pi ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, cost_kernel<float, MODE, true>, 256, 0)
@@ -1290,37 +1263,26 @@ int launch_cost(Engine* e, const CostSource& src, const VoxelMapDev& vm, int hos
   }
   P.ng = (plan && plan->ng > 0) ? plan->ng : default_groups(blocks);
   if (P.ng > blocks) P.ng = 1;  // (every group needs its first workgroup)
-  P.nb = blocks;
-  P.xcd_mask = 0; P.xcd_local = 0; P.lm_everywhere = 0;
+  P.xcd_local = 0; P.lm_everywhere = 0;
   {
     // Grids of two workgroups per CU (257 .. 512 workgroups: the 17k-point headline has 474): the second workgroup of a CU loses VALU
     // arbitration to the first (older waves win), finishes its main loop ~2 us later and keeps the whole trip waiting; s_setprio 1 for it
     // makes the pair finish together: LM launch 136 -> 127 us (profiles/r04_priority_ab.txt). With three workgroups per CU the same
     // priority costs 7 % (100k x 100k DIRECT27), for everybody at once it changes nothing: only this shape gets it.
-    static const int prio = [] { const char* v = getenv("FVH_COST_PRIO"); return v ? atoi(v) : -1; }();
+    static const int prio = [] { const char* v = getenv("FVH_COST_PRIO"); return v ? (atoi(v) != 0 ? 1 : 0) : -1; }();  // A/B knob: 0 never, 1 always (default: by the rule below)
     int cus = 256;
     (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, e->device);
     P.prio_from = cus;
-    const bool confined = plan && plan->mask;
-    P.prio_mode = prio >= 0 ? prio : ((persistent && !confined && blocks > cus && blocks <= 2 * cus) ? 1 : 0);
+    P.prio_mode = prio >= 0 ? prio : ((persistent && blocks > cus && blocks <= 2 * cus) ? 1 : 0);
     // The LM step on EVERY workgroup (each polls the group rows itself: no broadcast hand-off) for grids of at most two workgroups per
     // CU: 17k headline 126.1 -> 123.5 us, NDT LiDAR frames 81.8 -> 79.0 us. With three per CU (100k / 1M points: 768 workgroups) the
     // redundant steps cost more than the hand-off they replace (210.5 -> 216 us, 223 -> 227 us): those keep the collectors' broadcast.
     // FVH_LM_EVERYWHERE: 0 never, 1 (default) by this rule, 2 always. (profiles/r04_lm_everywhere.txt)
     static const int everywhere = [] { const char* v = getenv("FVH_LM_EVERYWHERE"); return v ? atoi(v) : 1; }();
-    static const int everywhere1 = [] { const char* v = getenv("FVH_LM_EVERYWHERE_SINGLE"); return v ? atoi(v) : 0; }();  // also on single-level grids: every workgroup adds all rows
-    P.lm_everywhere = (persistent && (P.ng > 1 || everywhere1) && (everywhere == 2 || (everywhere == 1 && blocks <= 2 * cus))) ? 1 : 0;
+    P.lm_everywhere = (persistent && P.ng > 1 && (everywhere == 2 || (everywhere == 1 && blocks <= 2 * cus))) ? 1 : 0;
   }
-  int launch_blocks = blocks;
-  if (persistent && plan) {
-    P.xcd_mask = plan->mask & 0xFFu;
-    P.xcd_local = plan->local;
-    if (P.xcd_mask) {  // dispatched 8 x too wide: only the workgroups that land on the chosen XCDs stay (kernels_cost.hpp)
-      const int m = __builtin_popcount(P.xcd_mask);
-      launch_blocks = 8 * ((blocks + m - 1) / m);
-      if (P.ng != m) P.xcd_local = 0;  // (a group would span XCDs: write-through hand-offs)
-    }
-  }
+  const int launch_blocks = blocks;
+  if (persistent && plan) P.xcd_local = plan->local;
   // abort word = 0 (the last 8 bytes of the state; never covered by the state write-back)
   if (e->abort_word_dirty) {
     HIP_OR_FAIL(e, hipMemsetAsync(reinterpret_cast<char*>(e->state.p) + sizeof(LmState) - 8, 0, 8, e->stream));
@@ -1340,14 +1302,25 @@ int launch_cost(Engine* e, const CostSource& src, const VoxelMapDev& vm, int hos
     (void)e->gang_begin(false);  // (the persistent launches share the chip through the SlotPool; other handles' cooperative sorts stay away while this runs)
     {
       ProfScope ps(e, "cost");
-      if (e->precision == FVH_COMPUTE_FP32) cost_kernel<float, MODE, true><<<launch_blocks, 256, 0, e->stream>>>(P);
-      else cost_kernel<double, MODE, true><<<launch_blocks, 256, 0, e->stream>>>(P);
+      // (items of ONE offset take the instantiation unrolled for one lookup; both routes of an align pick by the same shape)
+      if (P.group == 1) {
+        if (e->float_cost()) cost_kernel<float, MODE, true, 1><<<launch_blocks, 256, 0, e->stream>>>(P);
+        else cost_kernel<double, MODE, true, 1><<<launch_blocks, 256, 0, e->stream>>>(P);
+      } else {
+        if (e->float_cost()) cost_kernel<float, MODE, true><<<launch_blocks, 256, 0, e->stream>>>(P);
+        else cost_kernel<double, MODE, true><<<launch_blocks, 256, 0, e->stream>>>(P);
+      }
     }
     e->gang_end();
   } else {
     ProfScope ps(e, "cost");
-    if (e->precision == FVH_COMPUTE_FP32) cost_kernel<float, MODE, false><<<blocks, 256, 0, e->stream>>>(P);
-    else cost_kernel<double, MODE, false><<<blocks, 256, 0, e->stream>>>(P);
+    if (P.group == 1) {
+      if (e->float_cost()) cost_kernel<float, MODE, false, 1><<<blocks, 256, 0, e->stream>>>(P);
+      else cost_kernel<double, MODE, false, 1><<<blocks, 256, 0, e->stream>>>(P);
+    } else {
+      if (e->float_cost()) cost_kernel<float, MODE, false><<<blocks, 256, 0, e->stream>>>(P);
+      else cost_kernel<double, MODE, false><<<blocks, 256, 0, e->stream>>>(P);
+    }
   }
   HIP_OR_FAIL(e, hipGetLastError());
   return FVH_OK;
@@ -1470,12 +1443,9 @@ int align_begin(Engine* e, AlignCtx& c, const CostSource& src, VoxelMapDev& vm, 
     int cap = persistent_capacity<MODE>(e);
     if (e->peer.attached()) cap = std::max(1, cap / std::max(1, e->peer.ranks_on_device));
     const int want = std::min(cost_shape(e, src).blocks, std::max(cap, 1));
-    // Layouts (kernels_cost.hpp): chip-wide grids reduce per XCD (ng = 8; small ones: default_groups()); concurrent aligns -- and small
-    // grids under FVH_SMALL_GRID_LAYOUT=1 -- are confined to one XCD each (ng = 1, every hand-off XCD-local).
-    const int small_layout = small_grid_layout();
+    // Layouts (kernels_cost.hpp): chip-wide grids reduce per XCD (ng = 8; small ones: default_groups())
     const bool local_ok = xcd_local_wanted();
-    const bool confine_ok = local_ok && !c.sharded;  // (a confined launch only pays with XCD-local hand-offs; ranks of a sharded align must agree on the layout)
-    c.grant = g_slots.acquire(e->device, std::max(cap, 1), want, confine_ok, small_layout == 1);
+    c.grant = g_slots.acquire(e->device, std::max(cap, 1), want);
     int granted = c.grant.n;
     if (granted <= 0) {
       if (c.sharded) granted = want;  // ranks must not diverge: take the slots anyway (the watchdog covers the rare collision)
@@ -1483,8 +1453,8 @@ int align_begin(Engine* e, AlignCtx& c, const CostSource& src, VoxelMapDev& vm, 
     }
     c.plan = GridPlan{};
     c.plan.nb = granted;
-    if (c.grant.mask) { c.plan.mask = c.grant.mask; c.plan.ng = __builtin_popcount(c.grant.mask); c.plan.local = 1; }  // one group per XCD
-    else { c.plan.ng = default_groups(granted); c.plan.local = (c.plan.ng == TICKET_GROUPS && local_ok) ? 1 : 0; }  // (one chip-wide group spans XCDs: write-through)
+    c.plan.ng = default_groups(granted);
+    c.plan.local = (c.plan.ng == TICKET_GROUPS && local_ok) ? 1 : 0;  // (one chip-wide group spans XCDs: write-through)
   }
   if (c.persistent) {
     int rc = launch_cost<MODE>(e, src, vm, -1, &guess, nullptr, &p, true, e->peer.x, &c.plan);
@@ -2161,7 +2131,7 @@ const char* fvh_vgicp_last_error(const fvh_vgicp* h) { return h ? h->e.err.c_str
 int fvh_vgicp_set_resolution(fvh_vgicp* h, double r) { CHECK_HANDLE_HOST_ONLY(h); if (!(r > 0)) return h->e.fail(FVH_ERR_INVALID_ARGUMENT, "resolution must be > 0"); h->resolution = r; return FVH_OK; }
 int fvh_vgicp_set_kernel_params(fvh_vgicp* h, double w, double d) { CHECK_HANDLE_HOST_ONLY(h); h->kernel_width = w; h->kernel_max_dist = d; return FVH_OK; }
 int fvh_vgicp_set_neighbor_search_method(fvh_vgicp* h, int m, double radius) { CHECK_HANDLE(h); return h->e.set_offsets(m, radius); }
-int fvh_vgicp_set_precision(fvh_vgicp* h, int p) { CHECK_HANDLE_HOST_ONLY(h); if (p != FVH_COMPUTE_FP64 && p != FVH_COMPUTE_FP32) return h->e.fail(FVH_ERR_INVALID_ARGUMENT, "bad precision"); h->e.precision = p; return FVH_OK; }
+int fvh_vgicp_set_precision(fvh_vgicp* h, int p) { CHECK_HANDLE_HOST_ONLY(h); if (p != FVH_COMPUTE_FP64 && p != FVH_COMPUTE_FP32 && p != FVH_COMPUTE_CUDA_COMPAT) return h->e.fail(FVH_ERR_INVALID_ARGUMENT, "bad precision"); h->e.precision = p; return FVH_OK; }
 
 int fvh_vgicp_create_target_voxelmap(fvh_vgicp* h) { CHECK_HANDLE(h); return h->build_map(h->resolution); }
 int fvh_vgicp_set_voxel_accumulation_mode(fvh_vgicp* h, int mode) {
@@ -2178,6 +2148,14 @@ int fvh_vgicp_set_target_map_sharding(fvh_vgicp* h, int on, int margin_voxels) {
   if ((on != 0) != h->shard_map || margin_voxels != h->shard_margin) { h->voxelmap.invalidate(); h->e.has_corr = false; }
   h->shard_map = on != 0;
   h->shard_margin = margin_voxels;
+  return FVH_OK;
+}
+int fvh_vgicp_debug_get_live_map_voxels(fvh_vgicp* h, int* n) {  // voxel count of the map the last align used, as it is (a shard stays a shard: no rebuild)
+  CHECK_HANDLE(h);
+  if (!n) return FVH_ERR_INVALID_ARGUMENT;
+  if (!h->voxelmap.valid) return h->e.fail(FVH_ERR_BAD_STATE, "voxel map not built");
+  HIP_OR_FAIL(&h->e, hipMemcpyAsync(n, h->voxelmap.counters_cur(), sizeof(int), hipMemcpyDeviceToHost, h->e.stream));
+  HIP_OR_FAIL(&h->e, hipStreamSynchronize(h->e.stream));
   return FVH_OK;
 }
 int fvh_vgicp_debug_get_map_shard(fvh_vgicp* h, int* is_shard, int* fallbacks) {
@@ -2443,6 +2421,11 @@ int fvh_vgicp_debug_get_skipped_points(fvh_vgicp* h, int* n) {
 int fvh_vgicp_synchronize(fvh_vgicp* h) { CHECK_HANDLE(h); HIP_OR_FAIL(&h->e, hipStreamSynchronize(h->e.stream)); h->e.gang_clear(); return FVH_OK; }
 
 #ifdef FVH_KNN_TIMING
+int fvh_debug_pair_counts(unsigned long long* out8, int reset) {  // candidate points / box tests the culled k-NN and RBF searches evaluated since the last reset
+  if (out8 && hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_pair_counts), sizeof(unsigned long long) * 8) != hipSuccess) return FVH_ERR_HIP;
+  if (reset) { unsigned long long z[8] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_pair_counts), z, sizeof(z)) != hipSuccess) return FVH_ERR_HIP; }
+  return FVH_OK;
+}
 int fvh_debug_knn_timing(unsigned long long* out) { return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_knn_time), sizeof(unsigned long long) * 32768 * 8) == hipSuccess ? FVH_OK : FVH_ERR_HIP; }
 #endif
 #ifdef FVH_COST_TIMING

@@ -27,9 +27,9 @@
 //     the workgroups of ITS OWN group only. Of the three hand-offs per trip only the group rows cross XCDs: rows and broadcast
 //     stay inside one XCD, where a plain store is visible to an L1-bypassing (sc1) load through the XCD's own L2 in ~0.2 us
 //     instead of a ~1 us memory-side round trip (`xcd_local`; every workgroup checks HW_REG_XCC_ID against the XCD its group
-//     stands for before it relies on that, and a launch can be confined to a subset of the XCDs -- `xcd_mask` -- so that small
-//     grids need no cross-XCD hop at all and several aligns can share the chip XCD by XCD). Both routes add the same numbers in
-//     the same order: bit-identical results.
+//     stands for before it relies on that). Both routes add the same numbers in the same order: bit-identical results.
+//     (Round 4 could also confine a launch to a subset of the XCDs; measured no better for small grids and worse for concurrent aligns,
+//     profiles/r04_small_grid_layouts.txt / r04_concurrency.txt: removed.)
 #pragma once
 #include <cstddef>
 #include <type_traits>
@@ -127,13 +127,10 @@ struct CostParams {
   unsigned long long peer_watchdog_ticks;
   // grid layout (both routes take the same (nb, ng): the same partition of the items and the same order of the sums)
   int ng;              // reduction groups: workgroup b belongs to group b % ng (1: single level; 8: one group per XCD)
-  int nb;              // persistent kernel with xcd_mask != 0: logical workgroups (the launch is 8 x ceil(nb / popcount(mask)))
-  unsigned xcd_mask;   // persistent kernel: != 0 -> only workgroups dispatched to these XCDs (blockIdx & 7) stay; the others exit at once
-  int prio_mode;       // wave priority in the main loop (FVH_COST_PRIO; VERDICT r3 #3a). 0: none; 1: s_setprio 1 for the SECOND workgroup of a CU
-                       // (lb >= 256); 2: the same for its first half only (up to the first probes); 3: for the FIRST workgroup of a CU instead;
-                       // 4: for every workgroup (computing waves outrank the waves that already poll the broadcast on the same SIMDs);
-                       // 6: graded -- priority 1 for the second, 2 for the third workgroup of a CU
-  int prio_from;       // ... "second" = logical workgroups from this one on (the host passes the number of CUs)
+  int prio_mode;       // wave priority in the main loop (FVH_COST_PRIO). 0: none; 1: s_setprio 1 for the SECOND workgroup of a CU (lb >= prio_from).
+                       // (Round 4 also measured: the first half of the loop only, the FIRST workgroup instead, every workgroup, graded by age --
+                       // all worse or equal, profiles/r04_priority_ab.txt; they are no longer in the kernel.)
+  int prio_from;       // ... "second" = workgroups from this one on (the host passes the number of CUs)
   int xcd_local;       // persistent kernel: every member of a group sits on the group's XCD (checked per workgroup): rows and broadcast
                        // travel through that XCD's L2 (plain stores) instead of write-through + memory-side polls
   int lm_everywhere;   // persistent kernel, two levels: EVERY workgroup polls the group rows and runs the LM step on its own copy of the
@@ -723,8 +720,12 @@ __device__ unsigned long long g_mtime[16][512][12];
 #define FVH_COST_WG_PER_CU 3
 #endif
 #define FVH_COST_BOUNDS __launch_bounds__(256, FVH_COST_WG_PER_CU)
-template <typename Real, int MODE, bool PERSIST>
+// CH: voxel lookups per work item the code is unrolled for -- COST_CH, or 1 for launches whose items hold a single offset (NDT D2D over a
+// few thousand source voxels, DIRECT1): the four-chunk code executed its three dead chunks masked, ~40 % of the main loop's instructions
+// on a grid with one wave per SIMD, where nothing hides an instruction (tools/count_isa.py: 2,200 -> see profiles/r05_isa_counts.txt).
+template <typename Real, int MODE, bool PERSIST, int CH = COST_CH>
 __global__ FVH_COST_BOUNDS void cost_kernel(CostParams P) {
+  static_assert(CH == 1 || CH == COST_CH, "one or COST_CH lookups per item");
 #ifdef FVH_COST_TIMING
   __shared__ unsigned long long stamp[12];  // LDS, not registers: must not change the kernel being measured
   if (threadIdx.x == 0) { stamp[0] = wall_clock64(); atomicMin(&g_cost_timing[0], stamp[0]); }
@@ -738,21 +739,10 @@ __global__ FVH_COST_BOUNDS void cost_kernel(CostParams P) {
   static_assert(ST_WORDS <= 256, "one state word per thread after the barrier");
   LmState* st = P.st;
   unsigned long long* st_words = reinterpret_cast<unsigned long long*>(st);
-  // Logical workgroup id / count. A persistent launch confined to some XCDs (xcd_mask) is dispatched 8 x too wide: the workgroups
-  // that find themselves on another XCD (HW_REG_XCC_ID) leave at once, the rest number themselves densely -- the dispatcher hands
-  // consecutive blocks to consecutive XCDs (block b runs on XCD (b + c) % 8 with one c per launch: tools/probes/probe_xcc.hip), so every
-  // row of 8 blocks holds each XCD once. That is an observation, not a contract: every workgroup publishes the c it sees with its sums
-  // and the collectors end the launch if they ever differ (`xcd_local` below).
-  unsigned lb = blockIdx.x, nb = gridDim.x;
-  if constexpr (PERSIST) {
-    if (P.xcd_mask) {
-      const unsigned phys = __builtin_amdgcn_readfirstlane(xcc_id()) & 7u;
-      if (!((P.xcd_mask >> phys) & 1u)) return;
-      lb = (blockIdx.x >> 3) * (unsigned)__popc(P.xcd_mask) + (unsigned)__popc(P.xcd_mask & ((1u << phys) - 1u));
-      nb = (unsigned)P.nb;
-      if (lb >= nb) return;
-    }
-  }
+  // Workgroup id / count. The dispatcher hands consecutive blocks to consecutive XCDs (block b runs on XCD (b + c) % 8 with one c per
+  // launch: tools/probes/probe_xcc.hip). That is an observation, not a contract: every workgroup publishes the c it sees with its sums and
+  // the collectors end the launch if they ever differ (`xcd_local` below).
+  const unsigned lb = blockIdx.x, nb = gridDim.x;
   unsigned gen = 0;  // PERSIST: barrier generations this workgroup has passed
   int phase, corr_sel;
   PoseD lin_d, ev_d;
@@ -776,6 +766,18 @@ __global__ FVH_COST_BOUNDS void cost_kernel(CostParams P) {
   __shared__ Pose<Real> s_pose[2];
   if (threadIdx.x == 0) { s_pose[0] = pose_cast<Real>(lin_d); s_pose[1] = pose_cast<Real>(ev_d); }
   __syncthreads();
+  // The number of source elements of an NDT D2D launch lives on the device (the source map's voxel counter) and does not change during the
+  // launch: read once here. (Read per trip it was a dependent global round trip in front of every trip's first loads.)
+  const int n_src_launch = P.d_n_src ? *P.d_n_src : P.n_src;
+  // Sticky items (persistent launches whose every thread has at most ONE item: the 17k headline, NDT frames, DIRECT1 / 7 on small clouds):
+  // a thread's item is the same on every trip, so what does not depend on the pose -- the element's index, point and covariance, and the
+  // voxel ids it found on earlier trips (both correspondence buffers) -- is kept in LDS after the first trip: the first round trip of
+  // every later trip (source element + stored ids, ~0.3 us from L2) becomes an LDS read. 12 + 1 + 2 CH KB per workgroup; each thread
+  // touches its own slots only (no barrier). The ids still go to the global buffers too (getters, the per-transition route after an abort).
+  constexpr int STICKY_T = PERSIST ? 256 : 1;
+  __shared__ float4 s_src[3][STICKY_T];
+  __shared__ int s_elem[STICKY_T];
+  __shared__ int s_ids[2][CH][STICKY_T];
   for (;;) {  // PERSIST: one trip per LM transition; otherwise exactly one trip
   if (PERSIST) FVH_PT_MIN(gen, 0);
   const bool fused = (P.host_phase < 0) && (phase == PH_TRIAL);  // trial error (old ids) + speculative linearisation at xi (new ids)
@@ -792,11 +794,14 @@ __global__ FVH_COST_BOUNDS void cost_kernel(CostParams P) {
   // (s_pose[0] = lin: rotation used by the cached Mahalanobis of the OLD ids; s_pose[1] = ev: evaluation pose, also the
   // linearisation pose of the NEW ids; filled before the first trip and by the barrier code of every persistent trip)
   const Real res = (Real)P.res, inv_res = (Real)P.inv_res;
-  const int n_src = P.d_n_src ? *P.d_n_src : P.n_src;
+  const int n_src = n_src_launch;
   const int w_lo = (P.item_hi > 0 ? min(P.item_lo, n_src) : 0) * P.groups_per_src;           // this rank's tile of the item list
   const int n_items = (P.item_hi > 0 ? min(P.item_hi, n_src) : n_src) * P.groups_per_src;     // (end of the range)
   int* corr_old = P.corr + (size_t)corr_sel * P.corr_stride;                      // read (stored ids)
   int* corr_new = fused ? P.corr + (size_t)(corr_sel ^ 1) * P.corr_stride : corr_old;  // written by the find
+  const bool sticky = PERSIST && ((long long)(n_items - w_lo) <= (long long)nb * 256);  // (uniform, the same on every trip of a launch)
+  const bool cached = sticky && gen > 0;
+  const int sel_new = fused ? (corr_sel ^ 1) : corr_sel;
 
   // Lane-distributed wave accumulator: after every work item the wave reduces the 29 sums of its 64 items with a
   // transposing butterfly (below) that leaves the wave total of slot L >> 1 in lane L -- so the running sums of the whole
@@ -813,12 +818,7 @@ __global__ FVH_COST_BOUNDS void cost_kernel(CostParams P) {
     const int w = wbase + lane;
     ItemAcc<Real> it = {{0, 0, 0, 0, 0, 0}, {0, 0, 0}, 0};
     Real acc_y = 0;  // fused: trial error with the old ids
-    if (PERSIST && P.prio_mode) {
-      const bool second = lb >= (unsigned)P.prio_from;  // (the dispatcher fills the CUs once before any gets a second workgroup)
-      if (P.prio_mode == 6) {  // graded: the younger a workgroup of its CU, the higher its priority (three workgroups per CU)
-        if (lb >= 2u * (unsigned)P.prio_from) __builtin_amdgcn_s_setprio(2); else if (second) __builtin_amdgcn_s_setprio(1);
-      } else if (P.prio_mode == 4 || (P.prio_mode == 3 ? !second : second)) __builtin_amdgcn_s_setprio(1);
-    }
+    if (PERSIST && P.prio_mode && lb >= (unsigned)P.prio_from) __builtin_amdgcn_s_setprio(1);  // (the dispatcher fills the CUs once before any gets a second workgroup)
     Vec3<Real> q = {0, 0, 0};
     bool any_hit = false;  // an element without correspondences contributes exact zeros (its q may be non-finite: 0 * NaN)
     bool left_shard = false;  // sharded target map: this element's neighbourhood is not wholly inside the rank's shard
@@ -826,7 +826,9 @@ __global__ FVH_COST_BOUNDS void cost_kernel(CostParams P) {
     if (w < n_items) {
     const int i0 = P.gps_magic ? (int)__umulhi((unsigned)w, P.gps_magic) : w / P.groups_per_src;  // (a 32-bit division is ~30 instructions)
     const int g = w - i0 * P.groups_per_src;
-    const int i = P.order ? P.order[i0] : i0;
+    const int st = PERSIST ? (int)threadIdx.x : 0;  // this thread's sticky slot
+    int i;
+    if (cached) i = s_elem[st]; else i = P.order ? P.order[i0] : i0;
     const int o_begin = g * P.group, o_end = min(P.n_off, o_begin + P.group);
     // The loop is a chain of dependent memory round trips (0.3 us each when coalesced, 0.5-0.8 us when scattered; measured
     // with tools/main_timing.py) with ~4 us of fp64 arithmetic between them, on 2 waves per SIMD -- nothing hides a round trip
@@ -842,36 +844,45 @@ __global__ FVH_COST_BOUNDS void cost_kernel(CostParams P) {
     // waves per SIMD the loop is bound by VALU issue (~1,650 VALU instructions per wave and trip, ~4.25 cycles each, PMC), and
     // the other wave already filled the round trips; the younger workgroup of a CU is the one that finishes late.
     // ---- round trip 1 ----
-    const float4 a4 = P.src_pts[i];
-    float4 c0 = make_float4(0, 0, 0, 0), c1 = c0;
-    if (MODE != MODE_NDT_P2D && do_cost) { c0 = P.src_cov[2 * i]; c1 = P.src_cov[2 * i + 1]; }
+    float4 a4, c0 = make_float4(0, 0, 0, 0), c1 = c0;
+    if (cached) {
+      a4 = s_src[0][st];
+      if (MODE != MODE_NDT_P2D) { c0 = s_src[1][st]; c1 = s_src[2][st]; }
+    } else {
+      a4 = P.src_pts[i];
+      if (MODE != MODE_NDT_P2D && do_cost) { c0 = P.src_cov[2 * i]; c1 = P.src_cov[2 * i + 1]; }
+      if (sticky) {  // (trip 0 of a persistent launch: a linearisation, do_cost holds)
+        s_elem[st] = i; s_src[0][st] = a4;
+        if (MODE != MODE_NDT_P2D) { s_src[1][st] = c0; s_src[2][st] = c1; }
+      }
+    }
     const bool ext_fused = EXT_OK && external && fused;
-    int b[COST_CH], bo[COST_CH];
-    int ofp[COST_CH];  // packed neighbour offsets
-    float4 q1[COST_CH], q2[COST_CH];
+    int b[CH], bo[CH];
+    int ofp[CH];  // packed neighbour offsets
+    float4 q1[CH], q2[CH];
     // voxel records: of the old ids first (fused), then of the ids of this evaluation. q3 = {c_yz, c_zz, weight sqrt(n) as a double};
     // NDT does not use the weight and loads 8 bytes only
     using Q3 = typename std::conditional<MODE == MODE_VGICP, float4, float2>::type;
-    Q3 q3[COST_CH];
-    // (a work item is at most COST_CH offsets -- cost_shape() -- so this is the whole item: no chunk loop)
+    Q3 q3[CH];
+    // (a work item is at most CH offsets -- cost_shape() -- so this is the whole item: no chunk loop)
 #pragma unroll
-    for (int c = 0; c < COST_CH; c++) {
+    for (int c = 0; c < CH; c++) {
       const bool in = o_begin + c < o_end;
       bo[c] = -1; b[c] = -1; ofp[c] = 0;
-      if (fused) bo[c] = in ? corr_old[(size_t)i * P.n_off + o_begin + c] : -1;
+      if (fused) bo[c] = cached ? s_ids[corr_sel][c][st] : (in ? corr_old[(size_t)i * P.n_off + o_begin + c] : -1);
       if (do_find) {
         ofp[c] = P.offsets_packed[min(o_begin + c, o_end - 1)];
       } else if (ext_fused) {
         b[c] = in ? corr_new[(size_t)i * P.n_off + o_begin + c] : -1;
       } else {
-        b[c] = in ? corr_old[(size_t)i * P.n_off + o_begin + c] : -1;
+        b[c] = cached ? s_ids[corr_sel][c][st] : (in ? corr_old[(size_t)i * P.n_off + o_begin + c] : -1);
       }
     }
     if (PERSIST) FVH_MT(gen, 1);
     // ---- round trip 2 (fused): issued before the arithmetic below, which does not need it ----
     if (fused) {  // the records of the stored ids (bucket 0 for "none")
 #pragma unroll
-      for (int c = 0; c < COST_CH; c++) {
+      for (int c = 0; c < CH; c++) {
         const size_t base = (size_t)max(bo[c], 0) * 4;
         q1[c] = tf[base + 1]; q2[c] = tf[base + 2]; q3[c] = *reinterpret_cast<const Q3*>(tf + base + 3);
       }
@@ -912,15 +923,15 @@ __global__ FVH_COST_BOUNDS void cost_kernel(CostParams P) {
     }
     if (PERSIST) FVH_MT(gen, 2);
     {
-      unsigned long long key[COST_CH];
-      unsigned slot[COST_CH];
-      unsigned long long k0[COST_CH];
+      unsigned long long key[CH];
+      unsigned slot[CH];
+      unsigned long long k0[CH];
       constexpr unsigned long long DEAD_KEY = FVH_EMPTY_KEY - 1;  // no voxel has it (keys use 63 bits): "this lookup does not exist" without a flag register
-      // ---- round trip 3: COST_CH independent first probes in flight ----
+      // ---- round trip 3: CH independent first probes in flight ----
       if (do_find) {
-        bool live[COST_CH];
+        bool live[CH];
 #pragma unroll
-        for (int c = 0; c < COST_CH; c++) {
+        for (int c = 0; c < CH; c++) {
           const int x = cx + (int)(ofp[c] & 1023) - 512, y = cy + (int)((ofp[c] >> 10) & 1023) - 512, z = cz + (int)((ofp[c] >> 20) & 1023) - 512;
           live[c] = (o_begin + c < o_end) && coord_ok && coord_in_range(x, y, z);
           key[c] = live[c] ? pack_key(x, y, z) : DEAD_KEY;
@@ -932,34 +943,33 @@ __global__ FVH_COST_BOUNDS void cost_kernel(CostParams P) {
           const VmGrid g = *gptr;
           if (g.enabled) {  // (0: the map's box did not fit the bitmap budget -- every lookup goes to the table as before)
             filtered = true;
-            unsigned long long w[COST_CH];
-            unsigned bit[COST_CH];
+            unsigned long long w[CH];
+            unsigned bit[CH];
 #pragma unroll
-            for (int c = 0; c < COST_CH; c++) {
+            for (int c = 0; c < CH; c++) {
               unsigned long long word = 0;
               bit[c] = 0;
               live[c] = live[c] && vm_grid_locate(g, (unsigned)(key[c] & 0x1FFFFF), (unsigned)((key[c] >> 21) & 0x1FFFFF), (unsigned)((key[c] >> 42) & 0x1FFFFF), word, bit[c]);
               w[c] = live[c] ? P.bitmap[word] : 0ull;
             }
 #pragma unroll
-            for (int c = 0; c < COST_CH; c++) {
+            for (int c = 0; c < CH; c++) {
               live[c] = live[c] && ((w[c] >> bit[c]) & 1ull);
               if (!live[c]) key[c] = DEAD_KEY;
             }
           }
         }
 #pragma unroll
-        for (int c = 0; c < COST_CH; c++) {
+        for (int c = 0; c < CH; c++) {
           slot[c] = hash_slot(key[c], P.mask);
           k0[c] = (filtered && !live[c]) ? FVH_EMPTY_KEY : P.keys[slot[c]];  // (filtered: no load at all; unfiltered: the rare dead lookup reads a valid slot, no branch)
         }
       }
       if (PERSIST) FVH_MT(gen, 3);
-      if (PERSIST && P.prio_mode == 2 && lb >= (unsigned)P.prio_from) __builtin_amdgcn_s_setprio(0);
       // ---- fused trip: trial error with the OLD ids while the probes are in flight ----
       if (fused && do_cost) {
 #pragma unroll
-        for (int c = 0; c < COST_CH; c++) {
+        for (int c = 0; c < CH; c++) {
           if (bo[c] < 0) continue;
           const float4 o1 = q1[c], o2 = q2[c];
           const Q3 o3 = q3[c];
@@ -986,13 +996,14 @@ __global__ FVH_COST_BOUNDS void cost_kernel(CostParams P) {
       if (PERSIST) FVH_MT(gen, 4);
       if (do_find) {
 #pragma unroll
-        for (int c = 0; c < COST_CH; c++) {
+        for (int c = 0; c < CH; c++) {
           const unsigned long long k = k0[c];
           int r = -1;
           if (k == key[c]) r = (int)slot[c];
           else if (k != FVH_EMPTY_KEY && key[c] != DEAD_KEY) r = probe_continue(P.keys, P.mask, key[c], slot[c]);  // rare at load <= 0.25
           b[c] = r;
           if (o_begin + c < o_end) corr_new[(size_t)i * P.n_off + o_begin + c] = r;
+          if (sticky) s_ids[sel_new][c][st] = (o_begin + c < o_end) ? r : -1;
         }
       }
       if (do_cost) {
@@ -1001,7 +1012,7 @@ __global__ FVH_COST_BOUNDS void cost_kernel(CostParams P) {
       // the new id of a slot IS its old id -- then the record is already in registers; only slots whose voxel changed load.
       if (fused) {
 #pragma unroll
-        for (int c = 0; c < COST_CH; c++) {
+        for (int c = 0; c < CH; c++) {
           if (b[c] >= 0 && b[c] != bo[c]) {  // the voxel of this slot changed: fetch its record now
             const size_t base = (size_t)b[c] * 4;
             q1[c] = tf[base + 1]; q2[c] = tf[base + 2]; q3[c] = *reinterpret_cast<const Q3*>(tf + base + 3);
@@ -1009,7 +1020,7 @@ __global__ FVH_COST_BOUNDS void cost_kernel(CostParams P) {
         }
       } else {
 #pragma unroll
-        for (int c = 0; c < COST_CH; c++) {
+        for (int c = 0; c < CH; c++) {
           const size_t base = (size_t)max(b[c], 0) * 4;
           q1[c] = tf[base + 1]; q2[c] = tf[base + 2]; q3[c] = *reinterpret_cast<const Q3*>(tf + base + 3);
         }
@@ -1025,7 +1036,7 @@ __global__ FVH_COST_BOUNDS void cost_kernel(CostParams P) {
       }
       if (PERSIST) FVH_MT(gen, 6);
 #pragma unroll
-      for (int c = 0; c < COST_CH; c++) {
+      for (int c = 0; c < CH; c++) {
         if (b[c] < 0) continue;
         const int npts = (int)q1[c].w;
         const Vec3<Real> mu = {(Real)q1[c].x, (Real)q1[c].y, (Real)q1[c].z};
@@ -1113,7 +1124,7 @@ __global__ FVH_COST_BOUNDS void cost_kernel(CostParams P) {
   // into one group row; the group rows are summed in group order. Grids of <= 64 workgroups are ONE group: a single level.
   // The per-transition kernel finds "the last arriver" with atomic tickets; the persistent kernel has no tickets at all
   // (designated collectors poll tagged rows, below). Both take the SAME summation order: bit-identical sums on both routes.
-  const unsigned NG = (unsigned)P.ng;  // (host, default_groups(): 8 = one group per XCD, 1 for tiny grids and launches confined to one XCD)
+  const unsigned NG = (unsigned)P.ng;  // (host, default_groups(): 8 = one group per XCD, 1 for tiny grids)
   const unsigned grp = lb % NG;
   const unsigned ngroups = NG;
   const unsigned gsize = (nb - grp + NG - 1) / NG;
@@ -1294,7 +1305,7 @@ __global__ FVH_COST_BOUNDS void cost_kernel(CostParams P) {
       for (int idx = first; idx < PERSIST_REPLICAS * BCAST_PAIRS; idx += stride) store_pair_agent(bcast + idx, pv);
     };
     // The XCD-local flavour is only sound if every member of a group really runs on ONE XCD (HIP promises no placement). Members of a
-    // group share blockIdx % 8 (or, in a confined launch, the XCD itself), so it is enough that the dispatcher's rotation
+    // group share blockIdx % 8, so it is enough that the dispatcher's rotation
     // c = (XCC_ID - blockIdx) mod 8 is the same for every workgroup of the launch: each workgroup publishes the c it sees in the unused
     // slot 31 of its row, the collectors compare (rows against their own, then the group rows among each other) and end the launch
     // with code 3 if anything differs -- the host redoes the align with one launch per transition and, after a few of those, stops
@@ -1311,7 +1322,7 @@ __global__ FVH_COST_BOUNDS void cost_kernel(CostParams P) {
     const bool collector = lb < NG;  // == the first workgroup of group `grp`
     const bool multi_gpu = MODE == MODE_VGICP && P.peer.n > 1;  // (kernel argument: uniform)
     const bool everywhere = P.lm_everywhere != 0 && !multi_gpu;  // (kernel arguments: uniform)
-    const bool adds_rows = collector || (everywhere && NG == 1);  // single level + everywhere: every workgroup adds ALL rows itself (one hand-off per trip)
+    const bool adds_rows = collector;  // (round 4 also let EVERY workgroup of a single-level grid add all rows itself: one hand-off fewer, paid back by the wider poll -- removed)
     if (collector || everywhere) {
       if (tid == 0) { s_last = 1; s_abort = 0u; }
       __syncthreads();
@@ -1394,11 +1405,8 @@ __global__ FVH_COST_BOUNDS void cost_kernel(CostParams P) {
           if (lane >= PART_STRIDE) pend = 0;
           const double want = want_tag_of();
           const unsigned long long t0 = wall_clock64();
-#ifndef FVH_EVERYWHERE_FIRST_SLEEP
-#define FVH_EVERYWHERE_FIRST_SLEEP 0  // (0 / 16 / 32 / 48 / 64 measured: 122.2 - 123.1 us at 17k, 78.4 - 79.5 us NDT: the early polls cost nothing)
-#endif
-          // (lm_everywhere: a non-collector's group rows cannot be complete sooner than a collection + a hand-off after its own row)
-          if (!collector && FVH_EVERYWHERE_FIRST_SLEEP) __builtin_amdgcn_s_sleep(FVH_EVERYWHERE_FIRST_SLEEP);
+          // (lm_everywhere: the non-collectors start polling at once; a delayed first look and spaced polls were measured and bought nothing,
+          // profiles/r04_lm_everywhere.txt)
           while (__builtin_amdgcn_ballot_w64(pend != 0u) != 0ull) {
             pair_t pv[8];
             load_pairs8_agent(pv, src);
@@ -1406,10 +1414,6 @@ __global__ FVH_COST_BOUNDS void cost_kernel(CostParams P) {
             for (int g = 0; g < 8; g++)
               if (((pend >> g) & 1u) && pv[g].y == want) { t[g] = pv[g].x; pend &= ~(1u << g); }
             if (__builtin_amdgcn_readfirstlane((int)(wall_clock64() - t0 > P.watchdog_ticks))) { ok = false; break; }
-#ifndef FVH_EVERYWHERE_SLEEP
-#define FVH_EVERYWHERE_SLEEP 0  // (0 / 1 / 2 / 8 measured: 123.4 / 123.4 / 124.1 / 126.1 us at 17k)
-#endif
-            if (!collector && FVH_EVERYWHERE_SLEEP) __builtin_amdgcn_s_sleep(FVH_EVERYWHERE_SLEEP);  // (lm_everywhere: ~10x the pollers of the collectors-only protocol)
           }
           if (lane == PART_STRIDE - 1) {  // slot 31: every group must have seen our rotation
 #pragma unroll

@@ -354,10 +354,16 @@ __device__ __forceinline__ unsigned wave_min_u32(unsigned v) {
 // (super tiles of 64 tiles, then tiles); the next surviving tile is prefetched while the current one
 // is merged, so the L2 round trips overlap with the insertion chain.
 #ifdef FVH_KNN_TIMING
+// debug build: what the culled searches actually evaluate, summed over every launch since the last reset -- [0] k-NN candidate points,
+// [1] k-NN box tests, [2] RBF candidate points, [3] RBF box tests, [4] k-NN queries, [5] RBF queries (tools/pair_counts.py: the flop
+// fraction of the VALU rooflines = these x 8 flop / launch time / 157.3 TFLOP/s)
+__device__ unsigned long long g_pair_counts[8];
+#define PAIR_COUNT(slot, n) do { if (lane == 0) atomicAdd(&g_pair_counts[slot], (unsigned long long)(n)); } while (0)
 __device__ unsigned long long g_knn_time[32768][8];  // debug build: per query {start, seeds loaded, sorted, neighbours merged, culled sweep done, #tiles swept, #insertions}
 #define KNN_STAMP(i) do { if (lane == 0 && q < 32768) g_knn_time[q][i] = wall_clock64(); } while (0)
 #else
 #define KNN_STAMP(i) do { } while (0)
+#define PAIR_COUNT(slot, n) do { } while (0)
 #endif
 template <bool NEAREST_FIRST>
 __global__ __launch_bounds__(256) void knn_tiled1_kernel(const float4* __restrict__ spts, const float4* __restrict__ bbox1, const float4* __restrict__ bbox2, int n, int k,
@@ -366,7 +372,7 @@ __global__ __launch_bounds__(256) void knn_tiled1_kernel(const float4* __restric
   const int q = q_begin + blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);  // (launched with 64, 128 or 256 threads: 1, 2 or 4 queries per workgroup)
   if (q >= min(n, q_end)) return;
   KNN_STAMP(0);
-  int dbg_tiles = 0, dbg_ins = 0;
+  int dbg_tiles = 0, dbg_ins = 0, dbg_boxes = 0;
   const int ntiles = (n + 63) >> 6, nsuper = (ntiles + 63) >> 6;
   const float4 qv = spts[q];
   const float qx = read_lane(qv.x, 0), qy = read_lane(qv.y, 0), qz = read_lane(qv.z, 0);
@@ -412,6 +418,7 @@ __global__ __launch_bounds__(256) void knn_tiled1_kernel(const float4* __restric
     for (int sc = 0; sc < nsuper; sc += 64) {
       const int s = sc + lane;
       const float lb2 = (s < nsuper) ? point_box_sq(bbox2[2 * s], bbox2[2 * s + 1], qx, qy, qz) : __builtin_inff();
+      dbg_boxes += 64;
       unsigned long long smask = __ballot(lb2 <= td);
       while (smask) {
         const int ssrc = __ffsll((long long)smask) - 1;
@@ -419,6 +426,7 @@ __global__ __launch_bounds__(256) void knn_tiled1_kernel(const float4* __restric
         if (read_lane(lb2, ssrc) > td) continue;
         const int t = ((sc + ssrc) << 6) + lane;
         const float lb = (t < ntiles) ? point_box_sq(bbox1[2 * t], bbox1[2 * t + 1], qx, qy, qz) : __builtin_inff();
+        dbg_boxes += 64;
         unsigned long long tmask = __ballot(lb <= td && (t < t0 - 1 || t > t0 + 1));
         if (!tmask) continue;
         // software pipeline: the load of the next surviving tile is in flight while this one is merged
@@ -453,6 +461,7 @@ __global__ __launch_bounds__(256) void knn_tiled1_kernel(const float4* __restric
     for (int sc = 0; sc < nsuper; sc += 64) {
       const int s = sc + lane;
       const float lb2 = (s < nsuper) ? point_box_sq(bbox2[2 * s], bbox2[2 * s + 1], qx, qy, qz) : __builtin_inff();
+      dbg_boxes += 64;
       unsigned k2 = (lb2 <= td) ? ((s == (t0 >> 6)) ? 0u : __float_as_uint(lb2) + 1u) : ~0u;  // (the own super tile before all others)
       while (true) {
         const unsigned m2 = wave_min_u32(k2);
@@ -462,6 +471,7 @@ __global__ __launch_bounds__(256) void knn_tiled1_kernel(const float4* __restric
         if (read_lane(lb2, ssrc) > td) break;  // ascending: none of the remaining super tiles can qualify either
         const int t = ((sc + ssrc) << 6) + lane;
         const float lb = (t < ntiles) ? point_box_sq(bbox1[2 * t], bbox1[2 * t + 1], qx, qy, qz) : __builtin_inff();
+        dbg_boxes += 64;
         unsigned k1 = (lb <= td && (t < t0 - 1 || t > t0 + 1)) ? __float_as_uint(lb) : ~0u;
         unsigned m1 = wave_min_u32(k1);
         if (m1 == ~0u) continue;
@@ -491,11 +501,203 @@ __global__ __launch_bounds__(256) void knn_tiled1_kernel(const float4* __restric
 #ifdef FVH_KNN_TIMING
   if (lane == 0 && q < 32768) { g_knn_time[q][5] = dbg_tiles; g_knn_time[q][6] = dbg_ins; }
 #endif
+  PAIR_COUNT(0, 64 * (1 + dbg_tiles)); PAIR_COUNT(1, dbg_boxes); PAIR_COUNT(4, 1);  // (the own tile + every merged tile: 64 candidate distances each)
 }
 
 __device__ __forceinline__ void store_cov(float4* __restrict__ cov, int i, const Sym3<double>& C) {
   cov[2 * i] = make_float4((float)C.xx, (float)C.xy, (float)C.xz, (float)C.yy);
   cov[2 * i + 1] = make_float4((float)C.yz, (float)C.zz, 0.f, 0.f);
+}
+
+// ------------------------------------------------------------------------------------------------
+// FastVGICPCuda arithmetic (fvh_vgicp_set_precision(FVH_COMPUTE_CUDA_COMPAT)): the covariance of a point as the reference's DEVICE
+// path computes it -- covariance_estimation.cu:20-35: UNCENTRED float sums over the k neighbours in list order, mean = sum / k,
+// C = sum p p^T / k - mean mean^T; covariance_regularization.cu:15-125: Eigen::SelfAdjointEigenSolver<Matrix3f>::computeDirect (closed
+// form, trigonometric roots, eigenvalues ascending), C <- V diag V^-1 with the cofactor inverse (PLANE: diag(1e-3, 1, 1); MIN_EIG:
+// max(lambda, 1e-3)), FROBENIUS through two cofactor inverses; NONE / NORMALIZED_MIN_EIG leave the matrix alone (:122-124).
+// At 50 m from the sensor the uncentred float sums carry |p|^2 x 6e-8 ~ 2e-4 m^2 of rounding noise -- the size of a plane's smallest
+// eigenvalue -- so the result depends on the ORDER of the float operations: every expression below has the association of the
+// statement it restates and NO fma contraction (as oracle/cuda_compat.cpp, the judge of this mode, which is built with
+// -ffp-contract=off; nvcc contracts at its discretion, so the real device code differs from both in the last bits).
+// One thread per point: 20 independent gathers, ~400 float operations; this mode is about parity, not speed.
+// ------------------------------------------------------------------------------------------------
+struct M3f { float m[9]; };
+__device__ __forceinline__ M3f m3f_mul(const M3f& a, const M3f& b) {
+#pragma clang fp contract(off)
+  M3f c;
+#pragma unroll
+  for (int i = 0; i < 3; i++)
+#pragma unroll
+    for (int j = 0; j < 3; j++) c.m[i * 3 + j] = a.m[i * 3] * b.m[j] + a.m[i * 3 + 1] * b.m[3 + j] + a.m[i * 3 + 2] * b.m[6 + j];
+  return c;
+}
+__device__ __forceinline__ M3f m3f_inverse(const M3f& a) {  // Eigen's fixed-size 3x3 inverse: cofactors / determinant
+#pragma clang fp contract(off)
+  M3f c;
+  c.m[0] = a.m[4] * a.m[8] - a.m[5] * a.m[7];
+  c.m[1] = a.m[2] * a.m[7] - a.m[1] * a.m[8];
+  c.m[2] = a.m[1] * a.m[5] - a.m[2] * a.m[4];
+  c.m[3] = a.m[5] * a.m[6] - a.m[3] * a.m[8];
+  c.m[4] = a.m[0] * a.m[8] - a.m[2] * a.m[6];
+  c.m[5] = a.m[2] * a.m[3] - a.m[0] * a.m[5];
+  c.m[6] = a.m[3] * a.m[7] - a.m[4] * a.m[6];
+  c.m[7] = a.m[1] * a.m[6] - a.m[0] * a.m[7];
+  c.m[8] = a.m[0] * a.m[4] - a.m[1] * a.m[3];
+  const float det = a.m[0] * c.m[0] + a.m[1] * c.m[3] + a.m[2] * c.m[6];
+  const float inv = 1.0f / det;
+#pragma unroll
+  for (int i = 0; i < 9; i++) c.m[i] *= inv;
+  return c;
+}
+struct V3f { float v[3]; };
+__device__ __forceinline__ V3f v3f_cross(const V3f& a, const V3f& b) {
+#pragma clang fp contract(off)
+  return V3f{{a.v[1] * b.v[2] - a.v[2] * b.v[1], a.v[2] * b.v[0] - a.v[0] * b.v[2], a.v[0] * b.v[1] - a.v[1] * b.v[0]}};
+}
+__device__ __forceinline__ float v3f_dot(const V3f& a, const V3f& b) {
+#pragma clang fp contract(off)
+  return a.v[0] * b.v[0] + a.v[1] * b.v[1] + a.v[2] * b.v[2];
+}
+__device__ __forceinline__ V3f m3f_col(const M3f& a, int j) { return V3f{{a.m[j], a.m[3 + j], a.m[6 + j]}}; }
+// direct_selfadjoint_eigenvalues<..., 3, false>::extractKernel
+__device__ __forceinline__ void eig3f_extract_kernel(const M3f& mat, V3f& res, V3f& representative) {
+#pragma clang fp contract(off)
+  int i0 = 0;
+  if (fabsf(mat.m[4]) > fabsf(mat.m[0])) i0 = 1;
+  if (fabsf(mat.m[8]) > fabsf(mat.m[i0 * 4])) i0 = 2;
+  representative = m3f_col(mat, i0);
+  const V3f c0 = v3f_cross(representative, m3f_col(mat, (i0 + 1) % 3)), c1 = v3f_cross(representative, m3f_col(mat, (i0 + 2) % 3));
+  const float n0 = v3f_dot(c0, c0), n1 = v3f_dot(c1, c1);
+  if (n0 > n1) { const float s = sqrtf(n0); res = V3f{{c0.v[0] / s, c0.v[1] / s, c0.v[2] / s}}; }
+  else { const float s = sqrtf(n1); res = V3f{{c1.v[0] / s, c1.v[1] / s, c1.v[2] / s}}; }
+}
+// SelfAdjointEigenSolver<Matrix3f>::computeDirect: vals ascending, eigenvectors in the COLUMNS of vecs; reads the lower triangle
+__device__ inline void eig3f_direct(const M3f& A, float vals[3], M3f& vecs) {
+#pragma clang fp contract(off)
+  const float shift = (A.m[0] + A.m[4] + A.m[8]) / 3.0f;
+  M3f S;
+#pragma unroll
+  for (int i = 0; i < 3; i++)
+#pragma unroll
+    for (int j = 0; j < 3; j++) S.m[i * 3 + j] = i >= j ? A.m[i * 3 + j] : A.m[j * 3 + i];
+  S.m[0] -= shift; S.m[4] -= shift; S.m[8] -= shift;
+  float scale = 0.0f;
+#pragma unroll
+  for (int i = 0; i < 9; i++) scale = fmaxf(scale, fabsf(S.m[i]));
+  if (scale > 0.0f) {
+#pragma unroll
+    for (int i = 0; i < 9; i++) S.m[i] /= scale;
+  }
+  {  // computeRoots: x^3 - c2 x^2 + c1 x - c0 = 0
+    const float s_inv3 = 1.0f / 3.0f, s_sqrt3 = sqrtf(3.0f);
+    const float c0 = S.m[0] * S.m[4] * S.m[8] + 2.0f * S.m[3] * S.m[6] * S.m[7] - S.m[0] * S.m[7] * S.m[7] - S.m[4] * S.m[6] * S.m[6] - S.m[8] * S.m[3] * S.m[3];
+    const float c1 = S.m[0] * S.m[4] - S.m[3] * S.m[3] + S.m[0] * S.m[8] - S.m[6] * S.m[6] + S.m[4] * S.m[8] - S.m[7] * S.m[7];
+    const float c2 = S.m[0] + S.m[4] + S.m[8];
+    const float c2_over_3 = c2 * s_inv3;
+    float a_over_3 = (c2 * c2_over_3 - c1) * s_inv3;
+    a_over_3 = fmaxf(a_over_3, 0.0f);
+    const float half_b = 0.5f * (c0 + c2_over_3 * (2.0f * c2_over_3 * c2_over_3 - c1));
+    float q = a_over_3 * a_over_3 * a_over_3 - half_b * half_b;
+    q = fmaxf(q, 0.0f);
+    const float rho = sqrtf(a_over_3);
+    const float theta = atan2f(sqrtf(q), half_b) * s_inv3;
+    const float cos_theta = cosf(theta), sin_theta = sinf(theta);
+    vals[0] = c2_over_3 - rho * (cos_theta + s_sqrt3 * sin_theta);
+    vals[1] = c2_over_3 - rho * (cos_theta - s_sqrt3 * sin_theta);
+    vals[2] = c2_over_3 + 2.0f * rho * cos_theta;
+  }
+  const float eps = 1.1920929e-07f;  // NumTraits<float>::epsilon()
+  V3f e0 = {{1.f, 0.f, 0.f}}, e1 = {{0.f, 1.f, 0.f}}, e2 = {{0.f, 0.f, 1.f}};
+  if (!((vals[2] - vals[0]) <= eps)) {
+    M3f tmp = S;
+    float d0 = vals[2] - vals[1];
+    const float d1 = vals[1] - vals[0];
+    int k = 0, l = 2;
+    if (d0 > d1) { k = 2; l = 0; d0 = d1; }
+    V3f vk, vl;
+    tmp.m[0] -= vals[k]; tmp.m[4] -= vals[k]; tmp.m[8] -= vals[k];
+    eig3f_extract_kernel(tmp, vk, vl);  // vl = the saved representative column (nearly orthogonal to vk)
+    if (d0 <= 2.0f * eps * d1) {
+      const float pr = v3f_dot(vk, vl);
+#pragma unroll
+      for (int i = 0; i < 3; i++) vl.v[i] -= pr * vl.v[i];  // (as written in Eigen: col(l) -= col(k).dot(col(l)) * col(l))
+      const float nn = sqrtf(v3f_dot(vl, vl));
+#pragma unroll
+      for (int i = 0; i < 3; i++) vl.v[i] /= nn;
+    } else {
+      tmp = S;
+      tmp.m[0] -= vals[l]; tmp.m[4] -= vals[l]; tmp.m[8] -= vals[l];
+      V3f dummy;
+      eig3f_extract_kernel(tmp, vl, dummy);
+    }
+    if (k == 0) { e0 = vk; e2 = vl; } else { e2 = vk; e0 = vl; }
+    V3f v1 = v3f_cross(e2, e0);
+    const float nn = sqrtf(v3f_dot(v1, v1));
+#pragma unroll
+    for (int i = 0; i < 3; i++) v1.v[i] /= nn;
+    e1 = v1;
+  }
+#pragma unroll
+  for (int i = 0; i < 3; i++) { vecs.m[i * 3] = e0.v[i]; vecs.m[i * 3 + 1] = e1.v[i]; vecs.m[i * 3 + 2] = e2.v[i]; }
+#pragma unroll
+  for (int i = 0; i < 3; i++) vals[i] = vals[i] * scale + shift;
+}
+__device__ inline M3f regularize_cov_cuda_compat(const M3f& cov, int method) {
+#pragma clang fp contract(off)
+  if (method == 4) {  // FROBENIUS (:74-82)
+    M3f C = cov;
+    C.m[0] += 1e-3f; C.m[4] += 1e-3f; C.m[8] += 1e-3f;
+    M3f Ci = m3f_inverse(C);
+    float nrm = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 9; i++) nrm += Ci.m[i] * Ci.m[i];
+    nrm = sqrtf(nrm);
+#pragma unroll
+    for (int i = 0; i < 9; i++) Ci.m[i] /= nrm;
+    return m3f_inverse(Ci);
+  }
+  if (method != 3 && method != 1) return cov;  // NONE / NORMALIZED_MIN_EIG: ":122-124 unimplemented", the matrix is left alone
+  float vals[3];
+  M3f V;
+  eig3f_direct(cov, vals, V);
+  M3f D;
+#pragma unroll
+  for (int i = 0; i < 9; i++) D.m[i] = 0.0f;
+  if (method == 3) { D.m[0] = 1e-3f; D.m[4] = 1.0f; D.m[8] = 1.0f; }  // PLANE (:34-52,112)
+  else { D.m[0] = fmaxf(1e-3f, vals[0]); D.m[4] = fmaxf(1e-3f, vals[1]); D.m[8] = fmaxf(1e-3f, vals[2]); }  // MIN_EIG (:84-101)
+  return m3f_mul(m3f_mul(V, D), m3f_inverse(V));
+}
+__global__ __launch_bounds__(256) void cov_from_neighbors_cuda_compat_kernel(const float4* __restrict__ pts, int n, int k, const int* __restrict__ nbr, int method,
+                                                                             float4* __restrict__ cov, const int* __restrict__ subset /* a rank's tile of the Morton order, or null */) {
+#pragma clang fp contract(off)
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  if (t >= n) return;
+  const int i = subset ? subset[t] : t;
+  float mean[3] = {0.f, 0.f, 0.f};
+  M3f C;
+#pragma unroll
+  for (int q = 0; q < 9; q++) C.m[q] = 0.f;
+  for (int j = 0; j < k; j++) {
+    const float4 p4 = pts[nbr[(size_t)i * k + j]];
+    const float p[3] = {p4.x, p4.y, p4.z};
+#pragma unroll
+    for (int a = 0; a < 3; a++) mean[a] += p[a];
+#pragma unroll
+    for (int a = 0; a < 3; a++)
+#pragma unroll
+      for (int b = 0; b < 3; b++) C.m[a * 3 + b] += p[a] * p[b];
+  }
+  const float kf = (float)k;
+#pragma unroll
+  for (int a = 0; a < 3; a++) mean[a] /= kf;
+#pragma unroll
+  for (int a = 0; a < 3; a++)
+#pragma unroll
+    for (int b = 0; b < 3; b++) C.m[a * 3 + b] = C.m[a * 3 + b] / kf - mean[a] * mean[b];
+  const M3f R = regularize_cov_cuda_compat(C, method);
+  // the engine stores a covariance as its upper triangle (fvh_vgicp_set_*_covariances reads the same six entries of a 3x3)
+  cov[2 * (size_t)i] = make_float4(R.m[0], R.m[1], R.m[2], R.m[4]);
+  cov[2 * (size_t)i + 1] = make_float4(R.m[5], R.m[8], 0.f, 0.f);
 }
 
 // K4 + K7/8/9 fused: centred fp64 covariance of the k neighbours (CPU semantics,
@@ -795,11 +997,13 @@ __global__ __launch_bounds__(256) void cov_rbf1_kernel(const float4* __restrict_
   const int ntiles = (n + 63) >> 6, nsuper = (ntiles + 63) >> 6;
   const float4 qv = spts[q];
   const float qx = read_lane(qv.x, 0), qy = read_lane(qv.y, 0), qz = read_lane(qv.z, 0);
+  int dbg_tiles = 0, dbg_boxes = 0;
   float sw = 0.f, sx = 0.f, sy = 0.f, sz = 0.f, sxx = 0.f, sxy = 0.f, sxz = 0.f, syy = 0.f, syz = 0.f, szz = 0.f;
   auto sweep = [&](const float4& p) __attribute__((always_inline)) {
     const float dx = p.x - qx, dy = p.y - qy, dz = p.z - qz;
     const float sq = sqdist_nofma(p, qx, qy, qz);
     const float w = (sq > max_dist_sq) ? 0.f : __expf(-kernel_width * sq);
+    dbg_tiles++;
     sw += w;
     const float wx = w * dx, wy = w * dy, wz = w * dz;
     sx += wx; sy += wy; sz += wz;
@@ -808,12 +1012,14 @@ __global__ __launch_bounds__(256) void cov_rbf1_kernel(const float4* __restrict_
   for (int sc = 0; sc < nsuper; sc += 64) {
     const int s = sc + lane;
     const float lb2 = (s < nsuper) ? point_box_sq(bbox2[2 * s], bbox2[2 * s + 1], qx, qy, qz) : __builtin_inff();
+    dbg_boxes += 64;
     unsigned long long smask = __ballot(lb2 <= max_dist_sq);
     while (smask) {
       const int ssrc = __ffsll((long long)smask) - 1;
       smask &= smask - 1;
       const int t = ((sc + ssrc) << 6) + lane;
       const float lb = (t < ntiles) ? point_box_sq(bbox1[2 * t], bbox1[2 * t + 1], qx, qy, qz) : __builtin_inff();
+      dbg_boxes += 64;
       unsigned long long tmask = __ballot(lb <= max_dist_sq);
       if (!tmask) continue;
       int cur = __ffsll((long long)tmask) - 1;
@@ -833,6 +1039,8 @@ __global__ __launch_bounds__(256) void cov_rbf1_kernel(const float4* __restrict_
       }
     }
   }
+  PAIR_COUNT(2, 64 * dbg_tiles); PAIR_COUNT(3, dbg_boxes); PAIR_COUNT(5, 1);
+  (void)dbg_tiles; (void)dbg_boxes;
   const double W = wave_sum((double)sw);
   const double X = wave_sum((double)sx), Y = wave_sum((double)sy), Z = wave_sum((double)sz);
   const double XX = wave_sum((double)sxx), XY = wave_sum((double)sxy), XZ = wave_sum((double)sxz);

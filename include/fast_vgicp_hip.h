@@ -43,9 +43,11 @@ enum fvh_regularization { FVH_REG_NONE = 0, FVH_REG_MIN_EIG = 1, FVH_REG_NORMALI
 enum fvh_neighbor_search { FVH_DIRECT27 = 0, FVH_DIRECT7 = 1, FVH_DIRECT1 = 2, FVH_DIRECT_RADIUS = 3 };
 /* fast_gicp::NDTDistanceMode (ndt_settings.hpp:6) */
 enum fvh_ndt_distance_mode { FVH_NDT_P2D = 0, FVH_NDT_D2D = 1 };
-/* arithmetic of the per-correspondence cost math: fp64 matches the CPU FastVGICP (default),
- * fp32 matches the CUDA path's float arithmetic (sums are still accumulated in fp64). */
-enum fvh_precision { FVH_COMPUTE_FP64 = 0, FVH_COMPUTE_FP32 = 1 };
+/* arithmetic: FP64 matches the CPU FastVGICP (default); FP32 runs the per-correspondence cost math in float like the CUDA path (sums are
+ * still accumulated in fp64) on the engine's fp64-centred covariances; CUDA_COMPAT is FastVGICPCuda's arithmetic end to end -- FP32's cost
+ * math + the k-NN covariances as covariance_estimation.cu:20-35 / covariance_regularization.cu:15-125 compute them (uncentred float sums
+ * in neighbour-list order, Eigen's closed-form float eigen solver). VGICP handles only; RBF covariances and the voxel sums stay fp64. */
+enum fvh_precision { FVH_COMPUTE_FP64 = 0, FVH_COMPUTE_FP32 = 1, FVH_COMPUTE_CUDA_COMPAT = 2 };
 
 /* LsqRegistration parameters (lsq_registration_impl.hpp:9-22 defaults) for the device-resident LM */
 typedef struct fvh_lm_params {
@@ -228,9 +230,13 @@ int fvh_vgicp_peer_selfcheck(fvh_vgicp* h, double timeout_seconds, int* missing_
  * DIRECT_RADIUS) + `margin_voxels` for the motion of the pose during the align. A voxel inside the box receives all its points: its record
  * is the replicated map's. If a source element leaves the inner box during the LM loop (the pose moved further than the margin allows)
  * the rank redoes that align on the full map. The map is rebuilt per align (it depends on the guess): meant for maps that should not be
- * replicated, not for speed. The host-driven calls (update_correspondences / compute_error) keep using the replicated map. */
+ * replicated, not for speed. The host-driven calls (update_correspondences / compute_error / the voxel getters) use the replicated map:
+ * after a sharded align they rebuild it (and the shard's correspondences die with it). */
 int fvh_vgicp_set_target_map_sharding(fvh_vgicp* h, int on, int margin_voxels);
 int fvh_vgicp_debug_get_map_shard(fvh_vgicp* h, int* live_map_is_a_shard, int* aligns_redone_on_the_full_map);
+/* voxel count of the live map as the last align left it (a shard stays a shard). The voxel GETTERS (fvh_vgicp_get_num_voxels, get_voxel_*),
+ * update_correspondences and compute_error always work on the WHOLE map: after a sharded align they rebuild it first. */
+int fvh_vgicp_debug_get_live_map_voxels(fvh_vgicp* h, int* num_voxels);
 /* test hook: the spatial (Morton) order of a cloud -- order[j] = original index of the j-th point of the sorted cloud (n ints) -- and the
  * boxes of its 64-point tiles (8 floats per tile: min xyz 0, max xyz 0). which: 0 source, 1 target. Sorts the cloud if it is not sorted yet.
  * No reference counterpart (the order is this engine's own device for culling the exact searches and for the multi-GPU tiles). */

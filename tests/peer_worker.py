@@ -38,8 +38,10 @@ def main():
     if shard_map:  # the target map sharded by the ranks' tiles + halo (fvh_vgicp_set_target_map_sharding): built per align from here on
         core.set_target_map_sharding(True, 2)
     r = core.align()
-    nvox = len(core.get_voxelmap()[0])
-    shard_state = core.debug_map_shard()
+    shard_state = core.debug_map_shard()      # (before any getter: the voxel getters rebuild the whole map after a sharded align)
+    nvox = core.debug_live_map_voxels()
+    if shard_map:
+        assert len(core.get_voxelmap()[0]) == nvox_full and not core.debug_map_shard()[0]  # ... as the header says
     r2 = core.align(T)  # a second collective align on the same handles (exchange counters carry on)
     np.savez(out, nvox_full=nvox_full, nvox=nvox, is_shard=shard_state[0], fallbacks=core.debug_map_shard()[1], cov_t=cov_t, cov_s=cov_s, e=e, H=H, b=b, T=r["T"], Hf=r["H"], converged=r["converged"], nlin=r["num_linearize"], nerr=r["num_error_evals"],
              launches=r["num_launches"], aborts=core.debug_persist_aborts(), T2=r2["T"], launches2=r2["num_launches"], ncorr=ncorr)

@@ -63,10 +63,12 @@ def test_kernels_stay_on_the_right_side_of_the_register_cliff():
     spec.loader.exec_module(mod)
     res = mod.kernel_resources()
     cost = {k: v for k, v in res.items() if "cost_kernel<" in k}
-    assert len(cost) == 12, sorted(cost)  # {double, float} x {VGICP, NDT P2D, NDT D2D} x {per-transition, persistent}
+    assert len(cost) == 24, sorted(cost)  # {double, float} x {VGICP, NDT P2D, NDT D2D} x {per-transition, persistent} x {4, 1 lookups per item}
     for k, v in cost.items():
-        assert v["occupancy"] >= 3 and v["vgprs"] <= 168 and v["lds"] <= 8 * 1024, (k, v)
-        if ", true>" in k:
+        # LDS: 5 KB of reduction scratch + LM state; the persistent instantiations add the sticky-item cache (12 + 1 + 2 CH KB): three
+        # (four for the one-lookup instantiations) workgroups per CU stay far below the CU's 160 KB
+        assert v["occupancy"] >= 3 and v["vgprs"] <= 168 and v["lds"] <= (27 * 1024 if ", true, " in k else 8 * 1024), (k, v)
+        if ", true, " in k:
             # persistent instantiations: the LM step is inlined into the opener's once-per-trip path (7 us per launch faster than a
             # call through generic pointers); a few values live across it are spilled THERE (8 scratch instructions in the whole
             # kernel, none in the main loop -- tools/count_isa.py lists them per section, tools/kernel_resources.py shows the counts)
@@ -93,8 +95,9 @@ def test_the_lm_kernels_main_loop_has_no_scratch_access(tmp_path):
                            "-o", str(out), B.SOURCES[0]], stderr=subprocess.DEVNULL)
     text = out.read_text()
     for real in "df":
+      for ch in "41":
         for mode in "012":
-            name = "_ZN3fvh11cost_kernelI%sLi%sELb1EEEvNS_10CostParamsE" % (real, mode)
+            name = "_ZN3fvh11cost_kernelI%sLi%sELb1ELi%sEEEvNS_10CostParamsE" % (real, mode, ch)
             i = text.index(name + ":")
             body = text[i:text.index(".Lfunc_end", i)].split("\n")
             sec, scratch = "pre", {}

@@ -59,7 +59,8 @@ def test_order_is_a_stable_morton_sort_and_tiles_are_boxed(n, key_bits, sorted_b
 
 def test_cooperative_sort_is_kept_unless_another_handle_has_a_gang_kernel_in_flight():
     """The one-launch cooperative sort is a gang kernel (32 co-resident workgroups): it is skipped while ANOTHER registration handle of the
-    process may have a gang kernel in flight -- queued within the last 20 ms and not yet followed by an align / synchronize that returned.
+    process has a gang kernel IN FLIGHT -- marked at launch under a process-wide lock, in flight until the event recorded behind it has
+    fired or that handle's align / synchronize has returned (fvh_capi.hip: GangRegistry; round 4 guessed with a 20 ms wall-clock window).
     A second handle that merely exists (the reference's align.cpp keeps its NDT object alive while the VGICP rows run) or that the same
     thread uses in turn must not cost the first one its fast sort (it did: +38 us per registration in apps/gicp_align)."""
     from fast_gicp_amd import capi, preprocess
@@ -81,14 +82,12 @@ def test_cooperative_sort_is_kept_unless_another_handle_has_a_gang_kernel_in_fli
     assert ra["converged"] and tuple(routes() - r0)[:2] == (2, 0)
     # used in turn by one thread: a's align has returned, so b's sorts are cooperative too
     b.set_target_cloud(tgt); b.find_target_neighbors(20); b.calculate_target_covariances(); b.create_target_voxelmap()
-    import time
-    t_b = time.perf_counter()
     b.set_source_cloud(src); b.find_source_neighbors(20); b.calculate_source_covariances()
     assert tuple(routes() - r0)[:2] == (4, 0)
-    # b's sorts are queued and b has not aligned yet (a gang kernel of b may be in flight): a falls back to the one-workgroup sort ...
+    # b's sort is queued and b has not aligned yet: if it is still running when a asks, a falls back to the one-workgroup sort (4, 1);
+    # if its event has fired already (it lasts ~30 us), a sorts cooperatively (5, 0) -- either way ...
     a.set_source_cloud(src); a.find_source_neighbors(20)
-    within_window = time.perf_counter() - t_b < 0.015  # (the rule's window is 20 ms: a stalled test process must not fail the test)
-    assert tuple(routes() - r0)[:2] == ((4, 1) if within_window else (5, 0)) or not within_window
+    assert tuple(routes() - r0)[:2] in ((4, 1), (5, 0))
     one_wg = int((routes() - r0)[1])
     rb = b.align()
     # ... which gives the same order: same neighbours, same registration

@@ -1,10 +1,14 @@
 #!/usr/bin/env python
 """Folds the rocprofv3 --pmc passes of one round into ONE json that bench.py reads (profiles/rNN_pmc.json):
-    python tools/pmc_collect.py out.json entry:kernel_substr:fetch_csv:write_csv:sq_csv [...]
+    python tools/pmc_collect.py out.json [--pairs pairs.json] entry:kernel_substr:fetch_csv:write_csv:sq_csv[:min_ns] [...]
 (any csv may be '-'). Per entry: HBM bytes per launch (FETCH_SIZE / WRITE_SIZE, separate passes as MI355X_MICROARCH.md prescribes:
 both in KiB, FETCH_SIZE doubled on gfx950), and from the SQ pass: VALU instructions per wave, VALU-busy / waiting fractions of the
-wave cycles, and the chip-level VALU pipe utilisation  SQ_ACTIVE_INST_VALU * 4 / (GRBM_GUI_ACTIVE / 8 XCDs * #SIMDs)  (quad-cycle counter;
-one SIMD runs one VALU instruction at a time, so the sum over waves is the pipe's busy time).
+wave cycles, and the chip-level VALU ISSUE utilisation  SQ_INSTS_VALU * 2 / (GRBM_GUI_ACTIVE / 8 XCDs * #SIMDs): the share of the peak issue
+rate of one wave64 VALU instruction per SIMD every 2 cycles (MI355X_MICROARCH.md: v_fma_f32 wave64 = 2 cycles on a SIMD-32; 157.3 TFLOP/s
+= 1024 SIMDs x 64 lanes x 2 flop / 2 cycles x 2.4 GHz). No instruction issues faster, so this is <= 1 by construction. (Round 4 divided
+SQ_ACTIVE_INST_VALU x 4 by the SIMD cycles: that counter is summed per WAVE in quad-cycles and waves of one SIMD overlap in the pipe -- it
+read 1.04 on the 1M-point k-NN. It is still recorded, as `valu_active_quadcycles_over_simd_cycles`, and not called a utilisation.)
+`--pairs file.json` (tools/pair_counts.py) adds what the culled searches actually evaluate, for the flop fraction of the VALU stages.
 The file is stamped with the git commit and a hash of fast_gicp_amd/csrc/: bench.py refuses to quote it once the kernels changed."""
 import csv
 import hashlib
@@ -45,6 +49,11 @@ def per_launch(path, kern, min_ns=8000):
 
 
 def main(out, *specs):
+    pairs = {}
+    if specs and specs[0] == "--pairs":
+        if os.path.exists(specs[1]):
+            pairs = json.load(open(specs[1]))
+        specs = specs[2:]
     try:
         commit = subprocess.check_output(["git", "-C", ROOT, "rev-parse", "--short=12", "HEAD"], stderr=subprocess.DEVNULL).decode().strip()
     except Exception:
@@ -53,16 +62,18 @@ def main(out, *specs):
                      "method": "rocprofv3 --kernel-trace --pmc <one counter group per pass>; launches >= 8 us; hbm_bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024 "
                                "(gfx950: FETCH_SIZE reports half of wide coalesced reads); profiled passes run at lower clocks than un-profiled ones"}}
     for spec in specs:
-        name, kern, fcsv, wcsv, scsv = spec.split(":")
+        parts = spec.split(":")
+        name, kern, fcsv, wcsv, scsv = parts[:5]
+        min_ns = int(parts[5]) if len(parts) > 5 else 8000  # (launches shorter than this are the early-exit / no-op ones of a multi-launch route)
         e = {"kernel": kern}
         if fcsv != "-" and wcsv != "-" and os.path.exists(fcsv) and os.path.exists(wcsv):
-            f, nf, _ = per_launch(fcsv, kern)
-            w, nw, _ = per_launch(wcsv, kern)
+            f, nf, _ = per_launch(fcsv, kern, min_ns)
+            w, nw, _ = per_launch(wcsv, kern, min_ns)
             if "FETCH_SIZE" in f and "WRITE_SIZE" in w:
                 e.update(fetch_size_kib_raw=round(f["FETCH_SIZE"], 1), write_size_kib_raw=round(w["WRITE_SIZE"], 1), launches_fetch_pass=nf, launches_write_pass=nw,
                          hbm_bytes_per_launch=int((2 * f["FETCH_SIZE"] + w["WRITE_SIZE"]) * 1024))
         if scsv != "-" and os.path.exists(scsv):
-            m, ns, dur = per_launch(scsv, kern)
+            m, ns, dur = per_launch(scsv, kern, min_ns)
             wc = m.get("SQ_WAVE_CYCLES") or float("nan")
             e["sq"] = {"launches": ns, "avg_launch_us_in_this_pass": None if dur is None else round(dur / 1e3, 2), "counters_per_launch": {k: round(v, 1) for k, v in m.items()},
                        "valu_insts_per_wave": round(m.get("SQ_INSTS_VALU", float("nan")) / max(m.get("SQ_WAVES", 1), 1), 1),
@@ -70,9 +81,16 @@ def main(out, *specs):
                        "waiting_frac_of_wave_cycles": round(m.get("SQ_WAIT_ANY", float("nan")) / wc, 4),
                        "issue_stall_frac_of_wave_cycles": round(m.get("SQ_WAIT_INST_ANY", float("nan")) / wc, 4)}
             if m.get("GRBM_GUI_ACTIVE"):
-                e["sq"]["valu_pipe_utilisation_of_chip"] = round(m.get("SQ_ACTIVE_INST_VALU", float("nan")) * 4.0 / (m["GRBM_GUI_ACTIVE"] / XCDS * SIMDS), 4)
+                simd_cycles = m["GRBM_GUI_ACTIVE"] / XCDS * SIMDS
+                util = m.get("SQ_INSTS_VALU", float("nan")) * 2.0 / simd_cycles
+                assert not util > 1.0, "a VALU issue utilisation above 1: the normalisation is wrong (%s: %r)" % (name, util)
+                e["sq"]["valu_issue_utilisation"] = round(util, 4)
+                e["sq"]["valu_active_quadcycles_over_simd_cycles"] = round(m.get("SQ_ACTIVE_INST_VALU", float("nan")) * 4.0 / simd_cycles, 4)  # (per-wave sum: NOT bounded by 1)
                 e["sq"]["effective_clock_ghz"] = None if not dur else round(m["GRBM_GUI_ACTIVE"] / XCDS / dur, 3)
-                e["sq"]["cycles_per_valu_instruction"] = round(m.get("SQ_ACTIVE_INST_VALU", float("nan")) * 4.0 / max(m.get("SQ_INSTS_VALU", 1), 1), 2)
+                if dur:
+                    e["sq"]["valu_wave_instructions_per_sec"] = round(m.get("SQ_INSTS_VALU", 0.0) / (dur * 1e-9), 1)
+        if name in pairs:
+            e["pairs"] = pairs[name]
         res[name] = e
     json.dump(res, open(out, "w"), indent=1)
     print(json.dumps(res, indent=1))
