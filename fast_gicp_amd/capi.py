@@ -580,6 +580,11 @@ class NDTCore(_Core):
     def adopt_prepared_source(self):
         self._call("adopt_prepared_source")
 
+    def set_source_tile(self, rank, nranks):
+        """Evaluate tile `rank` of `nranks` of the source only (P2D: points in Morton order, D2D: source voxels ranked by key): linearize /
+        compute_error return PARTIAL sums, to be added over the ranks; nranks = 1 switches it off."""
+        self._call("set_source_tile", int(rank), int(nranks))
+
     def get_num_voxels(self, which):
         n = C.c_int(0)
         self._call("get_num_voxels", 0 if which == "source" else 1, C.byref(n))

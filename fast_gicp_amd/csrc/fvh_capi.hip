@@ -76,6 +76,8 @@ struct VoxelMapDev {
   DevBuf table, acc, occupied, compact_pts, compact_cov;
   DevBuf bitmap, grid;    // occupancy bitmap of a large map + its VmGrid (kernels_voxelmap.hpp); has_bitmap: built for the live map
   bool has_bitmap = false;
+  DevBuf canon;           // canonical (key-sorted) order of the compact voxel list (multi-GPU NDT D2D: every rank cuts the same list); has_canon: of the live map
+  bool has_canon = false;
   DevBuf region;          // VmRegion of a map that holds one rank's shard only (multi-GPU, fvh_vgicp_set_target_map_sharding)
   bool is_shard = false;  // the live map was built through `region`
   DevBuf keys[2];   // voxel keys, double buffered: keys[cur] belongs to the live map, the other one is what the next build fills
@@ -92,8 +94,8 @@ struct VoxelMapDev {
   std::vector<uint4> h_table;
   std::vector<int> h_occupied;
   std::unordered_map<int, int> bucket_to_index;
-  void invalidate() { valid = false; host_valid = false; has_bitmap = false; is_shard = false; }
-  void release() { table.release(); acc.release(); occupied.release(); compact_pts.release(); compact_cov.release(); counters.release(); keys[0].release(); keys[1].release(); bitmap.release(); grid.release(); region.release(); clean_cap = 0; has_bitmap = false; is_shard = false; }
+  void invalidate() { valid = false; host_valid = false; has_bitmap = false; is_shard = false; has_canon = false; }
+  void release() { table.release(); acc.release(); occupied.release(); compact_pts.release(); compact_cov.release(); counters.release(); keys[0].release(); keys[1].release(); bitmap.release(); grid.release(); region.release(); canon.release(); clean_cap = 0; has_bitmap = false; is_shard = false; has_canon = false; }
 };
 
 struct Profiler {
@@ -336,9 +338,11 @@ struct Engine {
   // `side`; the first call that is not part of that chain (align above all) makes the main stream wait for `side_done`.
   // multi-GPU, either exchange: the engine shards a VGICP cloud internally -- every rank makes the same calls on the same full clouds and
   // works on its spatial tile (a range of the Morton order); the peer path exchanges inside the kernels, the RCCL path between them
-  bool sharded() const { return peer.attached() || comm != nullptr; }
-  int shard_ranks() const { return peer.attached() ? peer.n : (comm ? nranks : 1); }
-  int shard_rank() const { return peer.attached() ? peer.rank : (comm ? rank : 0); }
+  // (NDT handles: the caller names the tile itself -- fvh_ndt_set_source_tile -- with or without a communicator)
+  int tile_rank = 0, tile_n = 1;
+  bool sharded() const { return peer.attached() || comm != nullptr || tile_n > 1; }
+  int shard_ranks() const { return peer.attached() ? peer.n : (tile_n > 1 ? tile_n : (comm ? nranks : 1)); }
+  int shard_rank() const { return peer.attached() ? peer.rank : (tile_n > 1 ? tile_rank : (comm ? rank : 0)); }
   DevBuf gather_stage;  // RCCL route: covariances of the whole cloud in Morton order (ncclAllGather in place)
   int rccl_checked_n = -1;  // cloud size the ranks were last found to agree on (rccl_allgather_cov)
   hipStream_t side = nullptr;
@@ -1156,6 +1160,7 @@ struct CostSource {
   int n_shape = 0;             // > 0: expected number of source elements when the exact one lives on the device (NDT D2D: source voxels, from the
                                // last build of that map): shapes the grid and the offsets per item; the kernel is grid-stride, any value is correct
   VoxelMapDev* source_map = nullptr;  // NDT D2D: where align() leaves the source voxel count it saw
+  bool device_tile = false;           // NDT D2D with a tile set: the kernel cuts this rank's chunk of the (canonically ordered) element list from the device-side count
 };
 
 // Persistent LM kernel (kernels_cost.hpp, PERSIST): co-resident workgroup capacity of the device for this instantiation.
@@ -1194,6 +1199,7 @@ inline CostShape cost_shape(const Engine* e, const CostSource& src) {
   s.groups_per_src = (n_off + s.group - 1) / s.group;
   s.n_walk = n_expected;
   if (e->sharded() && src.shardable) { const Tile t = peer_tile(e, src.n_upper); s.n_walk = std::max(t.hi - t.lo, 0); }  // multi-GPU: this rank's tile
+  if (src.device_tile) s.n_walk = (n_expected + e->shard_ranks() - 1) / std::max(1, e->shard_ranks());
   s.blocks = (int)std::max<long long>(1, std::min<long long>(max_blocks, (s.n_walk * s.groups_per_src + 255) / 256));
   return s;
 }
@@ -1239,13 +1245,15 @@ int launch_cost(Engine* e, const CostSource& src, const VoxelMapDev& vm, int hos
   P.item_lo = 0; P.item_hi = 0;
   P.peer.n = 1; P.peer.rank = 0; P.peer.xbase = 0;
   for (int i = 0; i < FVH_MAX_PEERS; i++) P.peer.region[i] = nullptr;
-  if (MODE == MODE_VGICP && e->sharded() && src.shardable) {
+  P.tile_rank = 0; P.tile_n = 1;
+  if (MODE == MODE_NDT_D2D && src.device_tile) { P.tile_rank = e->shard_rank(); P.tile_n = e->shard_ranks(); }
+  if ((MODE == MODE_VGICP || MODE == MODE_NDT_P2D) && e->sharded() && src.shardable) {
     // multi-GPU: this rank's spatial tile of the source (a range of its Morton order) and -- peer route -- the mailboxes of all ranks
     // (RCCL route: the sums meet between the launches, allreduce_sums)
     const Tile t = peer_tile(e, src.n_upper);
     P.item_lo = t.lo; P.item_hi = std::max(t.hi, 1);  // (item_hi == 0 means "everything")
     if (t.hi <= t.lo) { P.item_lo = 0; P.item_hi = 1; n_walk = 0; P.n_src = 0; } else n_walk = t.hi - t.lo;
-    if (e->peer.attached()) P.peer = e->peer.view(peer_xbase);
+    if (MODE == MODE_VGICP && e->peer.attached()) P.peer = e->peer.view(peer_xbase);
     static const unsigned long long wd = [] { const char* v = getenv("FVH_PEER_WATCHDOG_TICKS"); return v ? strtoull(v, nullptr, 10) : PEER_WATCHDOG_TICKS; }();
     P.peer_watchdog_ticks = wd;
   }
@@ -2056,8 +2064,15 @@ struct fvh_ndt {
   hipEvent_t prep_done = nullptr;
   AlignCtx pending;  // fvh_ndt_align_async .. fvh_ndt_align_wait
   CostSource cost_source() const {
-    if (distance_mode == FVH_NDT_P2D) return CostSource{source.pts.as<float4>(), nullptr, nullptr, source.n, nullptr, coherent_order(source)};
+    const bool tiled = e.tile_n > 1;  // fvh_ndt_set_source_tile: this handle evaluates one spatial tile of the source
+    if (distance_mode == FVH_NDT_P2D) {
+      // P2D shards like VGICP: source POINTS by Morton tile (the order exists once the caller's align / update_correspondences sorted the cloud)
+      CostSource cs{source.pts.as<float4>(), nullptr, nullptr, source.n, nullptr, tiled ? (source.has_sorted ? source.order.as<int>() : nullptr) : coherent_order(source)};
+      cs.shardable = tiled;
+      return cs;
+    }
     CostSource cs{source_vm.compact_pts.as<float4>(), source_vm.compact_cov.as<float4>(), source_vm.counters_cur(), source.n, source_vm.counters_cur(), nullptr};
+    if (tiled) { cs.order = source_vm.has_canon ? source_vm.canon.as<int>() : nullptr; cs.device_tile = true; }  // D2D: source VOXELS in canonical order
     // the source elements are the voxels of the source map; their number is on the device. A frame stream rebuilds that map per
     // frame with nearly the same voxel count: the count the last align saw (+ 25 %) sizes the grid -- a few thousand voxels instead
     // of the cloud's ~25k points: 7 one-offset items per voxel instead of 3 of <= 3 offsets (a shorter chain per trip), a smaller
@@ -2627,6 +2642,34 @@ static int ndt_ready(fvh_ndt* h) {
   if (!h->source.has_pts) return h->e.fail(FVH_ERR_BAD_STATE, "source cloud not set");
   if (!h->target_vm.valid) return h->e.fail(FVH_ERR_BAD_STATE, "target voxel map not built (create_voxelmaps)");
   if (h->distance_mode == FVH_NDT_D2D && !(h->source_vm.valid && h->source_vm.compact_pts.p)) return h->e.fail(FVH_ERR_BAD_STATE, "source voxel map not built (create_voxelmaps)");
+  if (h->e.tile_n > 1) {  // a tiled handle walks a range of an ORDER every rank agrees on
+    Engine* e = &h->e;
+    if (h->distance_mode == FVH_NDT_P2D) {  // the points' Morton order (a function of the cloud alone)
+      if (h->source.n) { int rc = ensure_sorted(e, h->source); if (rc) return rc; }
+    } else if (!h->source_vm.has_canon) {   // the source voxels ranked by key (kernels_voxelmap.hpp: vm_canonical_order_kernel)
+      HIP_OR_FAIL(e, h->source_vm.canon.ensure(sizeof(int) * (size_t)std::max(h->source.n, 1)));
+      vm_canonical_order_kernel<<<(std::max(h->source.n, 1) + 255) / 256, 256, 0, e->stream>>>(h->source_vm.keys_cur(), h->source_vm.occupied.as<int>(), h->source_vm.counters_cur(),
+                                                                                            h->source_vm.canon.as<int>());
+      HIP_OR_FAIL(e, hipGetLastError());
+      h->source_vm.has_canon = true;
+    }
+  }
+  return FVH_OK;
+}
+// north_star: "large scans shard by spatial tile ... all-reduce of the normal equations per iteration", for NDT. A tiled handle holds the
+// FULL clouds (the target map is replicated) and evaluates ONE spatial tile of the source: P2D -- chunk `rank` of `nranks` equal chunks of
+// the source points' Morton order, exactly as a sharded VGICP handle; D2D -- the same chunk of the source map's voxels ranked by key
+// (the compact list of a map is ordered by atomics and differs between two builds of the same map: ndt_cuda.cu:142-161 walks it as it
+// comes; the canonical order makes every rank cut the same list). update_correspondences / compute_error then return the tile's PARTIAL
+// sums (err, H, b) -- the caller adds them over the ranks (fast_gicp_amd/distributed.py: ShardedNDT, host route); with a communicator
+// attached (fvh_ndt_comm_init with the same nranks) align() all-reduces them on the device between the launches of the LM loop.
+int fvh_ndt_set_source_tile(fvh_ndt* h, int rank, int nranks) {
+  CHECK_HANDLE(h); NDT_NOT_PENDING(h);
+  if (nranks < 1 || rank < 0 || rank >= nranks) return h->e.fail(FVH_ERR_INVALID_ARGUMENT, "set_source_tile: need 0 <= rank < nranks");
+  if (h->e.comm && nranks > 1 && (nranks != h->e.nranks || rank != h->e.rank)) return h->e.fail(FVH_ERR_INVALID_ARGUMENT, "set_source_tile: rank / nranks differ from the attached communicator's");
+  h->e.tile_rank = nranks > 1 ? rank : 0;
+  h->e.tile_n = nranks;
+  h->e.has_corr = false;
   return FVH_OK;
 }
 int fvh_ndt_update_correspondences(fvh_ndt* h, const double* T) {
@@ -2643,6 +2686,8 @@ int fvh_ndt_compute_error(fvh_ndt* h, const double* T, double* H, double* b, dou
 }
 int fvh_ndt_align(fvh_ndt* h, const double* guess, const fvh_lm_params* p, fvh_lm_result* r) {
   CHECK_HANDLE(h); NDT_NOT_PENDING(h);
+  if (h->e.tile_n > 1 && !h->e.comm) return h->e.fail(FVH_ERR_BAD_STATE, "align: this handle evaluates one tile of the source (fvh_ndt_set_source_tile) and has no communicator: its sums are "
+                                                                        "partial -- all-reduce update_correspondences / compute_error over the ranks, or attach one (fvh_ndt_comm_init)");
   int rc = fvh_ndt_create_voxelmaps(h);  // NDTCuda::computeTransformation (ndt_cuda_impl.hpp:76-79)
   if (rc) return rc;
   rc = ndt_ready(h); if (rc) return rc;
@@ -2652,6 +2697,7 @@ int fvh_ndt_align(fvh_ndt* h, const double* guess, const fvh_lm_params* p, fvh_l
 // ---- pipelined frame streams: align = launch + wait; the next source is prepared beside the running LM kernel ----
 int fvh_ndt_align_async(fvh_ndt* h, const double* guess, const fvh_lm_params* p) {
   CHECK_HANDLE(h);
+  if (h->e.tile_n > 1) return h->e.fail(FVH_ERR_UNSUPPORTED, "align_async: not on a tiled handle (fvh_ndt_set_source_tile)");
   if (h->pending.active) return h->e.fail(FVH_ERR_BAD_STATE, "align_async: the previous align_async has not been waited for");
   int rc = fvh_ndt_create_voxelmaps(h);
   if (rc) return rc;
@@ -2725,6 +2771,7 @@ int fvh_ndt_get_voxels(fvh_ndt* h, int which, int* coords3, int* num_points, flo
 }
 int fvh_ndt_get_num_correspondences(fvh_ndt* h, int* n) {
   CHECK_HANDLE(h);
+  if (h->e.tile_n > 1) return h->e.fail(FVH_ERR_UNSUPPORTED, "correspondence getters: not on a tiled handle (only its tile's rows of the list exist)");
   if (!n) return FVH_ERR_INVALID_ARGUMENT;
   std::vector<int> corr;
   int rc = fetch_corr(&h->e, h->e.corr_n_src, corr);
@@ -2743,6 +2790,7 @@ int fvh_ndt_get_num_correspondences(fvh_ndt* h, int* n) {
 // offset-major then source element, invalid pairs removed (ndt_cuda.cu:142-161 builds the list with the functor of find_voxel_correspondences.cu:84-111)
 int fvh_ndt_get_voxel_correspondences(fvh_ndt* h, int* pairs) {
   CHECK_HANDLE(h);
+  if (h->e.tile_n > 1) return h->e.fail(FVH_ERR_UNSUPPORTED, "correspondence getters: not on a tiled handle (only its tile's rows of the list exist)");
   if (!pairs) return FVH_ERR_INVALID_ARGUMENT;
   const Rebuild rb = h->rebuild_safe();
   int rc = fetch_voxelmap_host(&h->e, h->target_vm, &rb);
@@ -2771,7 +2819,11 @@ int fvh_ndt_profile_enable(fvh_ndt* h, int on) { CHECK_HANDLE(h); h->e.prof.on =
 int fvh_ndt_profile_reset(fvh_ndt* h) { CHECK_HANDLE(h); HIP_OR_FAIL(&h->e, hipStreamSynchronize(h->e.stream)); h->e.prof.reset(); return FVH_OK; }
 int fvh_ndt_profile_get(fvh_ndt* h, const char* cls, double* ms, int* n) { CHECK_HANDLE(h); return profile_get(&h->e, cls, ms, n); }
 int fvh_ndt_synchronize(fvh_ndt* h) { CHECK_HANDLE(h); HIP_OR_FAIL(&h->e, hipStreamSynchronize(h->e.stream)); h->e.gang_clear(); return FVH_OK; }
-int fvh_ndt_comm_init(fvh_ndt* h, const void* id, int nranks, int rank) { CHECK_HANDLE(h); NDT_NOT_PENDING(h); return comm_init(&h->e, id, nranks, rank); }
+int fvh_ndt_comm_init(fvh_ndt* h, const void* id, int nranks, int rank) {
+  CHECK_HANDLE(h); NDT_NOT_PENDING(h);
+  if (h->e.tile_n > 1 && (h->e.tile_n != nranks || h->e.tile_rank != rank)) return h->e.fail(FVH_ERR_INVALID_ARGUMENT, "comm_init: rank / nranks differ from fvh_ndt_set_source_tile's");
+  return comm_init(&h->e, id, nranks, rank);
+}
 int fvh_ndt_comm_destroy(fvh_ndt* h) { CHECK_HANDLE(h); NDT_NOT_PENDING(h); if (h->e.comm) { g_rccl.CommDestroy(h->e.comm); h->e.comm = nullptr; } h->e.nranks = 1; h->e.rank = 0; return FVH_OK; }
 
 // ---- voxel-grid downsampling ----

@@ -121,6 +121,9 @@ struct CostParams {
   // multi-GPU (kernels_peer.hpp): this rank walks the source elements [item_lo, item_hi) of the (Morton) order -- its spatial
   // tile -- and the reduced sums are exchanged with the peers inside the kernel; peer.n <= 1: single GPU, whole cloud
   int item_lo, item_hi;
+  // ... the same for a source whose element count lives on the device (NDT D2D: the voxels of the source map, walked in the canonical --
+  // key-sorted -- order `order` so that every rank cuts the same list): this rank takes chunk tile_rank of tile_n equal chunks (tile_n <= 1: everything)
+  int tile_rank, tile_n;
   double* lm_trace;   // setDebugPrint on the device LM: 6 doubles per trial {i, y0, yi, rho, lambda, |d|} (lsq_registration_impl.hpp:143-149), or null
   int external_find;  // FastGICP on the device: the correspondences of every linearisation were found by nn1_corr_kernel right before this launch (nothing to probe here)
   PeerView peer;
@@ -778,6 +781,7 @@ __global__ FVH_COST_BOUNDS void cost_kernel(CostParams P) {
   __shared__ float4 s_src[3][STICKY_T];
   __shared__ int s_elem[STICKY_T];
   __shared__ int s_ids[2][CH][STICKY_T];
+  __shared__ int s_ofp[CH][STICKY_T];  // the item's packed neighbour offsets
   for (;;) {  // PERSIST: one trip per LM transition; otherwise exactly one trip
   if (PERSIST) FVH_PT_MIN(gen, 0);
   const bool fused = (P.host_phase < 0) && (phase == PH_TRIAL);  // trial error (old ids) + speculative linearisation at xi (new ids)
@@ -795,8 +799,13 @@ __global__ FVH_COST_BOUNDS void cost_kernel(CostParams P) {
   // linearisation pose of the NEW ids; filled before the first trip and by the barrier code of every persistent trip)
   const Real res = (Real)P.res, inv_res = (Real)P.inv_res;
   const int n_src = n_src_launch;
-  const int w_lo = (P.item_hi > 0 ? min(P.item_lo, n_src) : 0) * P.groups_per_src;           // this rank's tile of the item list
-  const int n_items = (P.item_hi > 0 ? min(P.item_hi, n_src) : n_src) * P.groups_per_src;     // (end of the range)
+  int w_lo = (P.item_hi > 0 ? min(P.item_lo, n_src) : 0) * P.groups_per_src;           // this rank's tile of the item list
+  int n_items = (P.item_hi > 0 ? min(P.item_hi, n_src) : n_src) * P.groups_per_src;     // (end of the range)
+  if (P.tile_n > 1) {  // (kernel argument: uniform) device-side element count: the tile is cut here
+    const int chunk = (n_src + P.tile_n - 1) / P.tile_n, lo = min(P.tile_rank * chunk, n_src);
+    w_lo = lo * P.groups_per_src;
+    n_items = min(lo + chunk, n_src) * P.groups_per_src;
+  }
   int* corr_old = P.corr + (size_t)corr_sel * P.corr_stride;                      // read (stored ids)
   int* corr_new = fused ? P.corr + (size_t)(corr_sel ^ 1) * P.corr_stride : corr_old;  // written by the find
   const bool sticky = PERSIST && ((long long)(n_items - w_lo) <= (long long)nb * 256);  // (uniform, the same on every trip of a launch)
@@ -871,7 +880,8 @@ __global__ FVH_COST_BOUNDS void cost_kernel(CostParams P) {
       bo[c] = -1; b[c] = -1; ofp[c] = 0;
       if (fused) bo[c] = cached ? s_ids[corr_sel][c][st] : (in ? corr_old[(size_t)i * P.n_off + o_begin + c] : -1);
       if (do_find) {
-        ofp[c] = P.offsets_packed[min(o_begin + c, o_end - 1)];
+        if (cached) ofp[c] = s_ofp[c][st];
+        else { ofp[c] = P.offsets_packed[min(o_begin + c, o_end - 1)]; if (sticky) s_ofp[c][st] = ofp[c]; }
       } else if (ext_fused) {
         b[c] = in ? corr_new[(size_t)i * P.n_off + o_begin + c] : -1;
       } else {
@@ -926,6 +936,8 @@ __global__ FVH_COST_BOUNDS void cost_kernel(CostParams P) {
       unsigned long long key[CH];
       unsigned slot[CH];
       unsigned long long k0[CH];
+      float4 sq1 = make_float4(0, 0, 0, 0), sq2 = sq1;  // CH == 1: the speculatively loaded record of the home slot
+      Q3 sq3 = {};
       constexpr unsigned long long DEAD_KEY = FVH_EMPTY_KEY - 1;  // no voxel has it (keys use 63 bits): "this lookup does not exist" without a flag register
       // ---- round trip 3: CH independent first probes in flight ----
       if (do_find) {
@@ -963,6 +975,15 @@ __global__ FVH_COST_BOUNDS void cost_kernel(CostParams P) {
         for (int c = 0; c < CH; c++) {
           slot[c] = hash_slot(key[c], P.mask);
           k0[c] = (filtered && !live[c]) ? FVH_EMPTY_KEY : P.keys[slot[c]];  // (filtered: no load at all; unfiltered: the rare dead lookup reads a valid slot, no branch)
+        }
+        // One-lookup items (CH == 1: 122 VGPRs, far from the cliff): the RECORD of the home slot is requested together with its key. At a
+        // load factor <= 0.25 the home slot is the answer of nearly every hit, so the dependent round trip "key -> record" of a slot
+        // whose voxel changed (every slot of a plain linearisation) disappears; a miss or a continued probe simply does not use it.
+        if constexpr (CH == 1) {
+          if (do_cost && !(fused && (int)slot[0] == bo[0])) {  // (fused and unchanged: the old record in q1..q3 IS the record)
+            const size_t sb = (size_t)slot[0] * 4;
+            sq1 = tf[sb + 1]; sq2 = tf[sb + 2]; sq3 = *reinterpret_cast<const Q3*>(tf + sb + 3);
+          }
         }
       }
       if (PERSIST) FVH_MT(gen, 3);
@@ -1014,6 +1035,7 @@ __global__ FVH_COST_BOUNDS void cost_kernel(CostParams P) {
 #pragma unroll
         for (int c = 0; c < CH; c++) {
           if (b[c] >= 0 && b[c] != bo[c]) {  // the voxel of this slot changed: fetch its record now
+            if (CH == 1 && do_find && b[c] == (int)slot[c]) { q1[c] = sq1; q2[c] = sq2; q3[c] = sq3; continue; }  // ... unless it came with the key
             const size_t base = (size_t)b[c] * 4;
             q1[c] = tf[base + 1]; q2[c] = tf[base + 2]; q3[c] = *reinterpret_cast<const Q3*>(tf + base + 3);
           }
@@ -1021,6 +1043,7 @@ __global__ FVH_COST_BOUNDS void cost_kernel(CostParams P) {
       } else {
 #pragma unroll
         for (int c = 0; c < CH; c++) {
+          if (CH == 1 && do_find && b[c] == (int)slot[c]) { q1[c] = sq1; q2[c] = sq2; q3[c] = sq3; continue; }
           const size_t base = (size_t)max(b[c], 0) * 4;
           q1[c] = tf[base + 1]; q2[c] = tf[base + 2]; q3[c] = *reinterpret_cast<const Q3*>(tf + base + 3);
         }

@@ -335,6 +335,30 @@ __global__ __launch_bounds__(VM_FIN_THREADS) void vm_finalize_kernel(const unsig
   }
 }
 
+// ---- canonical order of a map's voxel list (multi-GPU NDT D2D) -----------------------------------------------------------------
+// The compact list of a map (`occupied`, compact_pts / compact_cov) is in the order in which the finalize pass's workgroups took their
+// ranges from an atomic counter, and a voxel's bucket depends on the order of the build's CAS races: two ranks that build the same map
+// hold the same voxels in different orders. Ranks that share a D2D registration must cut the SAME list (north_star: shard by spatial
+// tile), so the voxels are ranked by their key -- z-major, then y, then x: contiguous ranges are slabs of space -- and walked in that
+// order: order[rank of voxel i] = i. n_v^2 key compares out of LDS (a few thousand voxels: microseconds), one thread per voxel.
+__global__ __launch_bounds__(256) void vm_canonical_order_kernel(const unsigned long long* __restrict__ keys, const int* __restrict__ occupied, const int* __restrict__ counters,
+                                                                 int* __restrict__ order) {
+  __shared__ unsigned long long s_keys[1024];
+  const int nv = counters[0];
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (blockIdx.x * 256 >= nv) return;  // (whole workgroup: uniform)
+  const unsigned long long mine = i < nv ? keys[occupied[i]] : 0ull;
+  int rank = 0;
+  for (int base = 0; base < nv; base += 1024) {
+    __syncthreads();
+    for (int j = threadIdx.x; j < 1024; j += 256) s_keys[j] = (base + j < nv) ? keys[occupied[base + j]] : FVH_EMPTY_KEY;  // (EMPTY = ~0: never below a voxel key)
+    __syncthreads();
+    const int m = min(1024, nv - base);
+    for (int j = 0; j < m; j++) rank += (s_keys[j] < mine) ? 1 : 0;
+  }
+  if (i < nv) order[rank] = i;
+}
+
 // ---- occupancy bitmap of large maps ------------------------------------------------------------------------------------------
 // 65 % of the DIRECT7 / DIRECT27 probes of a registration MISS (the neighbour voxel does not exist), and on a map that no longer
 // fits the L2s every miss still pulls a 64-byte sector of the key table out of HBM for an 8-byte compare: at 1M points the LM

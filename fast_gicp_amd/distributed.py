@@ -138,7 +138,8 @@ class ShardedLsq:
 
 class ShardedVGICP:
     """VGICP over the ranks of a torch.distributed process group (one GPU each); see the module docstring for the three
-    collectives. `device_collective` (bool) is round 1's spelling: True = "rccl", False = "host"."""
+    collectives. `device_collective` (bool) is round 1's spelling: True = "rccl", False = "host". The target voxel map is replicated by
+    default; core.set_target_map_sharding(True, margin) shards it too, by the ranks' tiles + halo (peer and rccl routes)."""
 
     def __init__(self, core, rank, world_size, dist=None, device_collective=None, collective=None):
         self.core, self.rank, self.world_size, self.dist = core, rank, world_size, dist
@@ -221,6 +222,56 @@ class ShardedVGICP:
                 raise RuntimeError("call attach_peers() / init_device_collective() first")
             return self.core.align(guess, **lm)
         import torch
+
+        def allreduce(v):
+            t = torch.from_numpy(np.ascontiguousarray(v, np.float64))
+            if self.dist is not None and self.world_size > 1:
+                self.dist.all_reduce(t)
+            return t.numpy()
+
+        lsq = ShardedLsq(lambda T: self.core.linearize(T), lambda T: self.core.compute_error(T, derivatives=False), allreduce, **{
+            "max_iterations": lm.get("max_iterations", 64), "rotation_epsilon": lm.get("rotation_epsilon", 2e-3),
+            "transformation_epsilon": lm.get("transformation_epsilon", 5e-4), "lm_max_iterations": lm.get("lm_max_iterations", 10),
+            "lm_init_lambda_factor": lm.get("lm_init_lambda_factor", 1e-9)})
+        return lsq.align(guess)
+
+
+class ShardedNDT:
+    """NDT (P2D or D2D) over the ranks of a process group, sharded by spatial tile of the SOURCE (fvh_ndt_set_source_tile): every rank holds
+    the full clouds -- the target voxel map is replicated --, P2D walks the rank's chunk of the source points' Morton order, D2D the rank's
+    chunk of the source map's voxels ranked by voxel key (a canonical order: the map's own voxel list is ordered by atomics and differs
+    between two builds of the same map). Routes:
+      "rccl"  fvh_ndt_comm_init: ncclAllReduce(32 x f64) on the engine stream after every cost launch of the multi-launch LM loop;
+      "host"  the host-driven ShardedLsq above through torch.distributed (gloo on CPU in the tests): one all-reduce of 43 doubles per evaluation.
+    (There is no peer-mailbox route for NDT handles.)"""
+
+    def __init__(self, core, rank, world_size, dist=None, collective="rccl"):
+        assert collective in ("rccl", "host")
+        self.core, self.rank, self.world_size, self.dist, self.collective = core, rank, world_size, dist, collective
+        self._comm_ready = False
+        core.set_source_tile(rank, world_size)
+
+    def init_device_collective(self, unique_id_bytes):
+        assert self.collective == "rccl"
+        self.core.comm_init(unique_id_bytes, self.world_size, self.rank)
+        self._comm_ready = True
+
+    def collective_description(self):
+        return {"rccl": "ncclAllReduce(32 x f64) on the engine stream, once per cost evaluation", "host": "host all-reduce (torch.distributed) of 43 doubles per evaluation"}[self.collective]
+
+    def set_target(self, xyz):
+        self.core.set_target_cloud(xyz)
+
+    def set_source(self, full_xyz):
+        self.core.set_source_cloud(np.ascontiguousarray(full_xyz, np.float32))  # the FULL cloud on every rank: the engine cuts the tile
+
+    def align(self, guess=None, **lm):
+        if self.collective == "rccl":
+            if not self._comm_ready:
+                raise RuntimeError("call init_device_collective() first")
+            return self.core.align(guess, **lm)
+        import torch
+        self.core.create_voxelmaps()
 
         def allreduce(v):
             t = torch.from_numpy(np.ascontiguousarray(v, np.float64))

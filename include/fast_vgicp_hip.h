@@ -192,8 +192,9 @@ int fvh_debug_sort_routes(int* counts4);
  * every rank makes the same calls on the same FULL clouds; neighbour search and covariance estimation run on the rank's spatial tile (a
  * range of the cloud's Morton order) and the 32 B / point covariances are all-gathered (ncclAllGather); every cost evaluation walks the
  * rank's tile of the source and the 32-double normal-equation block (err, b, H, trial error) is all-reduced (ncclAllReduce) on the
- * handle's stream; the LM step then runs redundantly on every rank. The target voxel map is replicated. (NDT handles: the caller hands
- * each rank its shard of the source; only the all-reduce is the library's.) */
+ * handle's stream; the LM step then runs redundantly on every rank. The target voxel map is replicated. (NDT handles: either the caller
+ * hands each rank its shard of the source and only the all-reduce is the library's, or -- fvh_ndt_set_source_tile -- every rank holds the
+ * full source and the engine walks the rank's spatial tile.) */
 int fvh_comm_unique_id(void* id128 /* 128 bytes out */);
 int fvh_vgicp_comm_init(fvh_vgicp* h, const void* id128, int nranks, int rank);
 int fvh_vgicp_comm_destroy(fvh_vgicp* h);
@@ -294,6 +295,13 @@ int fvh_ndt_profile_reset(fvh_ndt* h);
 int fvh_ndt_profile_get(fvh_ndt* h, const char* kernel_class, double* total_ms, int* launches);
 int fvh_ndt_synchronize(fvh_ndt* h);
 int fvh_ndt_comm_init(fvh_ndt* h, const void* id128, int nranks, int rank);
+/* new: multi-GPU NDT by spatial tile. The handle keeps the FULL clouds (target map replicated) and evaluates tile `rank` of `nranks` of the
+ * source: P2D -- that chunk of the source points' Morton order (as a sharded VGICP handle); D2D -- that chunk of the source map's voxels
+ * ranked by voxel key (a canonical order: the compact list [NCU]:142-161 walks is ordered by atomics and differs between two builds).
+ * fvh_ndt_update_correspondences / fvh_ndt_compute_error then return the tile's PARTIAL err / H / b, to be added over the ranks by the
+ * caller; with a communicator of the same nranks attached fvh_ndt_align all-reduces them on the device (without one it refuses).
+ * nranks = 1 switches the tile off. The correspondence getters and fvh_ndt_align_async are not available on a tiled handle. */
+int fvh_ndt_set_source_tile(fvh_ndt* h, int rank, int nranks);
 int fvh_ndt_comm_destroy(fvh_ndt* h);
 
 /* ---------------------------------------------------------------------------------------------------

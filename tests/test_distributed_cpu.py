@@ -199,3 +199,65 @@ def test_rccl_route_host_logic_world2_gloo(tmp_path):
     g = O.FastVGICP(threads=2, search=O.DIRECT7)
     g.set_target(tgt[:6000]); g.set_source(src[:6000])
     assert util.rel_err(res[0]["T"], g.align()["T"]) < 1e-8
+
+
+class _FakeNdtCore:
+    """Stands in for capi.NDTCore (P2D) on a box without GPUs: what the ENGINE does with a source tile set (fvh_ndt_set_source_tile: full
+    clouds on every rank, the target voxel map replicated, the cost evaluated over the rank's chunk of the source points' Morton order) is
+    restated on the ORACLE's NDT, so that two gloo ranks can check ShardedNDT's host logic and that the decomposition equals the
+    unsharded registration."""
+
+    def __init__(self):
+        from oracle import oracle as O
+        self.O, self.tile_of, self.calls = O, None, []
+        self.tgt = self.src = None
+
+    def set_source_tile(self, rank, nranks): self.tile_of = (rank, nranks); self.calls.append(("set_source_tile", rank, nranks))
+    def set_target_cloud(self, xyz): self.tgt = np.asarray(xyz, np.float32); self.calls.append(("set_target_cloud", len(xyz)))
+    def set_source_cloud(self, xyz): self.src = np.asarray(xyz, np.float32); self.calls.append(("set_source_cloud", len(xyz)))
+
+    def create_voxelmaps(self):
+        from fast_gicp_amd import distributed as D
+        rank, nranks = self.tile_of
+        self.tile = D.spatial_tile_partition(self.src, nranks)[rank]
+        self.g = self.O.NDT(threads=2, mode=self.O.P2D, search=self.O.DIRECT7)
+        self.g.set_target(self.tgt); self.g.set_source(self.src[self.tile])  # the rank's tile of the source against the replicated target map
+        self.g.prepare()
+
+    def linearize(self, T): return self.g.linearize(T)
+    def compute_error(self, T, derivatives=True): return self.g.compute_error(T)
+
+
+def _ndt_worker(rank, world, port, out_dir):
+    import torch.distributed as dist
+    from fast_gicp_amd import distributed as D
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    tgt, src = util.bundled_pair(leaf=0.25)
+    core = _FakeNdtCore()
+    sh = D.ShardedNDT(core, rank, world, dist, collective="host")
+    sh.set_target(tgt); sh.set_source(src)
+    r = sh.align()
+    assert core.calls[0] == ("set_source_tile", rank, world) and [c[0] for c in core.calls[1:]] == ["set_target_cloud", "set_source_cloud"]  # full clouds on every rank
+    assert core.calls[2][1] == len(src)
+    np.savez(os.path.join(out_dir, "ndt_rank%d.npz" % rank), T=r["T"], converged=r["converged"], tile=core.tile)
+    dist.destroy_process_group()
+
+
+def test_sharded_ndt_host_route_world2_gloo(tmp_path):
+    """ShardedNDT(collective="host") on two gloo ranks: the source sharded by spatial tile (P2D: points in Morton order), the target map
+    replicated, one all-reduce of the normal equations per evaluation -- equals the unsharded NDT registration of the oracle."""
+    import torch.multiprocessing as mp
+    from oracle import oracle as O
+    world, port = 2, _free_port()
+    mp.spawn(_ndt_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    res = [np.load(os.path.join(str(tmp_path), "ndt_rank%d.npz" % r)) for r in range(world)]
+    tgt, src = util.bundled_pair(leaf=0.25)
+    tiles = [set(r["tile"].tolist()) for r in res]
+    assert not (tiles[0] & tiles[1]) and len(tiles[0] | tiles[1]) == len(src)
+    assert np.array_equal(res[0]["T"], res[1]["T"]) and bool(res[0]["converged"])  # identical sums on both ranks: lock-step without a broadcast
+    g = O.NDT(threads=2, mode=O.P2D, search=O.DIRECT7)
+    g.set_target(tgt); g.set_source(src)
+    r = g.align()
+    assert r["converged"] and util.rel_err(res[0]["T"], r["T"]) < 1e-8

@@ -118,3 +118,53 @@ def test_ndt_swap_reuses_voxelmaps(O, gicp_test_pair):
     te, re_ = util.pose_error(util.relative_pose(), np.linalg.inv(r2["T"]))
     assert te < 0.05 and re_ < np.radians(1.0)
     c.close(); d.close()
+
+
+@pytest.mark.parametrize("mode", [0, 1])  # P2D, D2D
+@pytest.mark.parametrize("nranks", [2, 3])
+def test_ndt_source_tiles_partition_the_cost(mode, nranks):
+    """fvh_ndt_set_source_tile (multi-GPU NDT by spatial tile): `nranks` handles on the same full clouds, each evaluating
+    its tile -- P2D: a chunk of the source points' Morton order; D2D: a chunk of the source voxels ranked by key (every handle builds its
+    own source map: the canonical order makes them cut the same list whatever order their builds left it in). The tiles' partial sums
+    must add up to the unsharded evaluation (err, H, b to 1e-11: the same terms in another order), at two poses; and the host-route
+    registration over the tiles (ShardedLsq: one all-reduce per evaluation, here a plain sum in this process) equals the unsharded align."""
+    from fast_gicp_amd import capi, distributed as D, workloads
+    vg = capi.VoxelGrid(0)
+    tgt, src = vg.filter(workloads.lidar_frame(3), 0.25), vg.filter(workloads.lidar_frame(4), 0.25)
+
+    def make():
+        c = capi.NDTCore(0)
+        c.set_distance_mode(mode); c.set_neighbor_search_method(capi.DIRECT7); c.set_resolution(1.0)
+        c.set_target_cloud(tgt); c.set_source_cloud(src); c.create_voxelmaps()
+        return c
+
+    ref = make()
+    tiles = [make() for _ in range(nranks)]
+    for r, c in enumerate(tiles):
+        c.set_source_tile(r, nranks)
+    T1 = util.random_pose(np.random.default_rng(7), max_angle_deg=1.0, max_trans=0.3)
+    for T in (np.eye(4), T1):
+        e0, H0, b0 = ref.linearize(T)
+        parts = [c.linearize(T) for c in tiles]
+        e, H, b = sum(p[0] for p in parts), sum(p[1] for p in parts), sum(p[2] for p in parts)
+        assert all(p[0] > 0 for p in parts)  # every tile holds part of the scene
+        assert abs(e - e0) <= 1e-11 * abs(e0) and util.rel_err(H, H0) < 1e-11 and util.rel_err(b, b0) < 1e-11, (mode, nranks)
+        ee = sum(c.compute_error(T1, derivatives=False) for c in tiles)  # error only, at another pose, on the stored correspondences
+        assert abs(ee - ref.compute_error(T1, derivatives=False)) <= 1e-11 * abs(ee)
+    # a tiled handle without a communicator must not run the LM loop on partial sums; its correspondence getters are not available
+    with pytest.raises(capi.FvhError):
+        tiles[0].align()
+    with pytest.raises(capi.FvhError):
+        tiles[0].get_num_correspondences()
+    # the host route: LM on the summed evaluations == the unsharded device LM (same algorithm, sums in another order)
+    r0 = ref.align()
+    lsq = D.ShardedLsq(lambda T: tuple(sum(x) for x in zip(*[c.linearize(T) for c in tiles])), lambda T: sum(c.compute_error(T, derivatives=False) for c in tiles), lambda v: v)
+    r = lsq.align()
+    assert r["converged"] and r0["converged"] and util.rel_err(r["T"], r0["T"]) < 1e-9
+    # switching the tile off gives the whole cloud back
+    tiles[0].set_source_tile(0, 1)
+    e1, _, _ = tiles[0].linearize(np.eye(4))
+    assert abs(e1 - ref.linearize(np.eye(4))[0]) <= 1e-11 * abs(e1)
+    for c in tiles + [ref]:
+        c.close()
+    vg.close()

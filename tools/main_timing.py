@@ -12,11 +12,19 @@ sys.path.insert(0, ROOT)
 from fast_gicp_amd import capi, preprocess  # noqa: E402
 
 L = capi.load()
-tgt, src = preprocess.bundled_pair(os.path.join(ROOT, "data"))
-c = capi.VGICPCore(0)
-c.set_neighbor_search_method(capi.DIRECT27)
-c.set_target_cloud(tgt); c.find_target_neighbors(20); c.calculate_target_covariances(); c.create_target_voxelmap()
-c.set_source_cloud(src); c.find_source_neighbors(20); c.calculate_source_covariances()
+if "--ndt" in sys.argv:  # the LiDAR-stream configuration: NDT D2D, DIRECT7, two consecutive simulated frames after ApproximateVoxelGrid 0.25
+    from fast_gicp_amd import workloads
+    vg = capi.VoxelGrid(0)
+    c = capi.NDTCore(0)
+    c.set_distance_mode(capi.NDT_D2D); c.set_neighbor_search_method(capi.DIRECT7); c.set_resolution(1.0)
+    c.set_target_cloud(vg.filter(workloads.lidar_frame(3), 0.25, vg.APPROXIMATE))
+    c.set_source_cloud(vg.filter(workloads.lidar_frame(4), 0.25, vg.APPROXIMATE))
+else:
+    tgt, src = preprocess.bundled_pair(os.path.join(ROOT, "data"))
+    c = capi.VGICPCore(0)
+    c.set_neighbor_search_method(capi.DIRECT27)
+    c.set_target_cloud(tgt); c.find_target_neighbors(20); c.calculate_target_covariances(); c.create_target_voxelmap()
+    c.set_source_cloud(src); c.find_source_neighbors(20); c.calculate_source_covariances()
 for rep in range(5):
     c.align()
 L.fvh_debug_main_timing(None, 1)
