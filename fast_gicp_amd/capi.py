@@ -22,7 +22,7 @@ EXPORTED_SYMBOLS = None  # filled by _declared_symbols()
 
 class LmParams(C.Structure):
     _fields_ = [("max_iterations", C.c_int), ("rotation_epsilon", C.c_double), ("transformation_epsilon", C.c_double), ("lm_max_iterations", C.c_int),
-                ("lm_init_lambda_factor", C.c_double)]
+                ("lm_init_lambda_factor", C.c_double), ("optimizer", C.c_int)]
 
 
 class LmResult(C.Structure):
@@ -75,8 +75,9 @@ def _colmajor16(T):
     return np.ascontiguousarray(np.asarray(T, dtype=np.float64).reshape(4, 4).T)
 
 
-def _lm_params(max_iterations=64, rotation_epsilon=2e-3, transformation_epsilon=5e-4, lm_max_iterations=10, lm_init_lambda_factor=1e-9):
-    return LmParams(max_iterations, rotation_epsilon, transformation_epsilon, lm_max_iterations, lm_init_lambda_factor)
+def _lm_params(max_iterations=64, rotation_epsilon=2e-3, transformation_epsilon=5e-4, lm_max_iterations=10, lm_init_lambda_factor=1e-9, optimizer=0):
+    """optimizer: 0 Levenberg-Marquardt (default), 1 Gauss-Newton (LSQ_OPTIMIZER_TYPE, lsq_registration.hpp:15)"""
+    return LmParams(max_iterations, rotation_epsilon, transformation_epsilon, lm_max_iterations, lm_init_lambda_factor, optimizer)
 
 
 def _result_dict(r):

@@ -261,6 +261,7 @@ struct Engine {
   int device = 0;
   hipStream_t stream = nullptr;
   std::string err;
+  int align_optimizer = 0;  // optimiser of the launches being queued: 0 LM (and every host-driven evaluation), 1 Gauss-Newton (fvh_lm_params::optimizer)
   int precision = FVH_COMPUTE_FP64;
   bool float_cost() const { return precision != FVH_COMPUTE_FP64; }  // FP32 and CUDA_COMPAT: the per-correspondence arithmetic in float (sums in fp64)
   std::vector<int> offsets_host{0, 0, 0};
@@ -1240,6 +1241,7 @@ int launch_cost(Engine* e, const CostSource& src, const VoxelMapDev& vm, int hos
     P.init = 1;
     P.max_iterations = init->max_iterations; P.lm_max_iterations = init->lm_max_iterations;
     P.rotation_epsilon = init->rotation_epsilon; P.transformation_epsilon = init->transformation_epsilon; P.lm_init_lambda_factor = init->lm_init_lambda_factor;
+    P.optimizer = init->optimizer != 0 ? 1 : 0;
   }
   long long n_walk = src.n_upper;
   P.item_lo = 0; P.item_hi = 0;
@@ -1310,25 +1312,25 @@ int launch_cost(Engine* e, const CostSource& src, const VoxelMapDev& vm, int hos
     (void)e->gang_begin(false);  // (the persistent launches share the chip through the SlotPool; other handles' cooperative sorts stay away while this runs)
     {
       ProfScope ps(e, "cost");
-      // (items of ONE offset take the instantiation unrolled for one lookup; both routes of an align pick by the same shape)
-      if (P.group == 1) {
-        if (e->float_cost()) cost_kernel<float, MODE, true, 1><<<launch_blocks, 256, 0, e->stream>>>(P);
-        else cost_kernel<double, MODE, true, 1><<<launch_blocks, 256, 0, e->stream>>>(P);
-      } else {
-        if (e->float_cost()) cost_kernel<float, MODE, true><<<launch_blocks, 256, 0, e->stream>>>(P);
-        else cost_kernel<double, MODE, true><<<launch_blocks, 256, 0, e->stream>>>(P);
-      }
+      // (items of ONE offset take the instantiation unrolled for one lookup; both routes of an align pick by the same shape.
+      // Gauss-Newton aligns take their own instantiations: the Levenberg-Marquardt ones do not carry the other optimiser's code)
+#define FVH_LAUNCH_COST(PERS, GRID)                                                                                                   \
+  do {                                                                                                                                \
+    const bool f32 = e->float_cost();                                                                                                 \
+    if ((host_phase < 0 ? e->align_optimizer : 0) == 0) {                                                                             \
+      if (P.group == 1) { if (f32) cost_kernel<float, MODE, PERS, 1><<<GRID, 256, 0, e->stream>>>(P); else cost_kernel<double, MODE, PERS, 1><<<GRID, 256, 0, e->stream>>>(P); } \
+      else { if (f32) cost_kernel<float, MODE, PERS><<<GRID, 256, 0, e->stream>>>(P); else cost_kernel<double, MODE, PERS><<<GRID, 256, 0, e->stream>>>(P); }                    \
+    } else {                                                                                                                          \
+      if (P.group == 1) { if (f32) cost_kernel<float, MODE, PERS, 1, true><<<GRID, 256, 0, e->stream>>>(P); else cost_kernel<double, MODE, PERS, 1, true><<<GRID, 256, 0, e->stream>>>(P); } \
+      else { if (f32) cost_kernel<float, MODE, PERS, COST_CH, true><<<GRID, 256, 0, e->stream>>>(P); else cost_kernel<double, MODE, PERS, COST_CH, true><<<GRID, 256, 0, e->stream>>>(P); } \
+    }                                                                                                                                 \
+  } while (0)
+      FVH_LAUNCH_COST(true, launch_blocks);
     }
     e->gang_end();
   } else {
     ProfScope ps(e, "cost");
-    if (P.group == 1) {
-      if (e->float_cost()) cost_kernel<float, MODE, false, 1><<<blocks, 256, 0, e->stream>>>(P);
-      else cost_kernel<double, MODE, false, 1><<<blocks, 256, 0, e->stream>>>(P);
-    } else {
-      if (e->float_cost()) cost_kernel<float, MODE, false><<<blocks, 256, 0, e->stream>>>(P);
-      else cost_kernel<double, MODE, false><<<blocks, 256, 0, e->stream>>>(P);
-    }
+    FVH_LAUNCH_COST(false, blocks);
   }
   HIP_OR_FAIL(e, hipGetLastError());
   return FVH_OK;
@@ -1425,13 +1427,14 @@ int align_begin(Engine* e, AlignCtx& c, const CostSource& src, VoxelMapDev& vm, 
   fvh_lm_params& p = c.p;
   if (params) p = *params; else fvh_default_lm_params(&p);
   std::memcpy(c.guess16, guess16, sizeof(c.guess16));
+  e->align_optimizer = p.optimizer != 0 ? 1 : 0;  // (every launch of this align -- begin, finish, fall-backs -- takes that optimiser's instantiation)
   c.retried = retried; c.no_persist = no_persist; c.grant_dev = e->device;
   HIP_OR_FAIL(e, e->corr.ensure(2 * sizeof(int) * (size_t)std::max(src.n_upper, 1) * e->n_off));
   LmState* st = e->state.as<LmState>();
   const PoseD guess = pose_from_colmajor16(guess16);
   c.degenerate = p.max_iterations <= 0;  // nothing to launch: only the state has to say "done"
   if (c.degenerate) {
-    lm_init_kernel<<<1, 64, 0, e->stream>>>(st, guess, p.rotation_epsilon, p.transformation_epsilon, p.lm_init_lambda_factor, p.max_iterations, p.lm_max_iterations, e->ticket.as<unsigned>());
+    lm_init_kernel<<<1, 64, 0, e->stream>>>(st, guess, p.rotation_epsilon, p.transformation_epsilon, p.lm_init_lambda_factor, p.max_iterations, p.lm_max_iterations, e->ticket.as<unsigned>(), p.optimizer != 0 ? 1 : 0);
     HIP_OR_FAIL(e, hipGetLastError());
   }
   c.budget = (long long)std::max(p.max_iterations, 0) * (1 + (long long)std::max(p.lm_max_iterations, 0)) + 1;
@@ -1479,6 +1482,7 @@ int align_finish(Engine* e, AlignCtx& c, const CostSource& src, VoxelMapDev& vm,
   struct Done { AlignCtx& c; ~Done() { c.release_slots(); c.active = false; } } done{c};
   if (!result) return e->fail(FVH_ERR_INVALID_ARGUMENT, "align: null argument");
   const fvh_lm_params& p = c.p;
+  e->align_optimizer = p.optimizer != 0 ? 1 : 0;
   const bool persistent = c.persistent, sharded = c.sharded, degenerate = c.degenerate;
   const long long budget = c.budget;
   const PoseD guess = pose_from_colmajor16(c.guess16);
@@ -1527,7 +1531,7 @@ int align_finish(Engine* e, AlignCtx& c, const CostSource& src, VoxelMapDev& vm,
     }
     launched = 1;
     e->persist_backoff = 0;  // a clean persistent run: the device is ours again
-    if (sharded) e->peer.x += 1ull + (unsigned long long)h->num_error_evals;  // one exchange per trip
+    if (sharded) e->peer.x += (unsigned long long)(p.optimizer ? h->num_linearize : 1 + h->num_error_evals);  // one exchange per trip
   }
   while (!persistent) {
     for (int s = 0; s < batch; s++) {
@@ -1538,7 +1542,7 @@ int align_finish(Engine* e, AlignCtx& c, const CostSource& src, VoxelMapDev& vm,
       if (e->comm) {
         rc = allreduce_sums(e);
         if (rc) return rc;
-        lm_update_kernel<<<1, 64, 0, e->stream>>>(st);
+        if (p.optimizer) lm_update_kernel<true><<<1, 64, 0, e->stream>>>(st); else lm_update_kernel<false><<<1, 64, 0, e->stream>>>(st);
       }
     }
     launched += batch;
@@ -1552,7 +1556,7 @@ int align_finish(Engine* e, AlignCtx& c, const CostSource& src, VoxelMapDev& vm,
     if (h->phase == PH_DONE || launched >= budget) break;
     batch = 3;
   }
-  if (!persistent && sharded && h->num_linearize > 0) e->peer.x += 1ull + (unsigned long long)h->num_error_evals;  // launches after PH_DONE leave before the exchange
+  if (!persistent && sharded && h->num_linearize > 0) e->peer.x += (unsigned long long)(p.optimizer ? h->num_linearize : 1 + h->num_error_evals);  // launches after PH_DONE leave before the exchange
   vm.nv_hint = h->vm_num_voxels;
   if (src.source_map) src.source_map->nv_hint = h->vm_num_voxels2;
   if (h->vm_dropped > 0) {  // hint-sized table overflowed: rebuild at the safe size and run again (rare)
@@ -1566,7 +1570,7 @@ int align_finish(Engine* e, AlignCtx& c, const CostSource& src, VoxelMapDev& vm,
   }
   e->gang_clear();
   e->prev_steps = e->last_steps;
-  e->last_steps = 1 + h->num_error_evals;  // launches this align needed: the first linearize + one fused launch per trial
+  e->last_steps = p.optimizer ? std::max(1, (int)h->num_linearize) : 1 + h->num_error_evals;  // launches this align needed: the first linearize + one fused launch per trial (Gauss-Newton: one per linearisation)
   e->lin = h->x_lin;
   e->corr_sel = h->corr_cur;
   e->has_corr = true;  // correspondences of the last consumed linearisation stay valid for compute_error()
@@ -1701,6 +1705,7 @@ int gicp_align(Engine* e, CloudDev& src, CloudDev& tgt, VoxelMapDev& records, co
   if (rc) return rc;
   fvh_lm_params p;
   if (params) p = *params; else fvh_default_lm_params(&p);
+  e->align_optimizer = p.optimizer != 0 ? 1 : 0;
   LmState* st = e->state.as<LmState>();
   const PoseD guess = pose_from_colmajor16(guess16);
   float T12[12];
@@ -1714,7 +1719,7 @@ int gicp_align(Engine* e, CloudDev& src, CloudDev& tgt, VoxelMapDev& records, co
   e->lm_trace_rows = 0;
   LmState* h = reinterpret_cast<LmState*>(e->pinned);
   if (p.max_iterations <= 0) {
-    lm_init_kernel<<<1, 64, 0, e->stream>>>(st, guess, p.rotation_epsilon, p.transformation_epsilon, p.lm_init_lambda_factor, p.max_iterations, p.lm_max_iterations, e->ticket.as<unsigned>());
+    lm_init_kernel<<<1, 64, 0, e->stream>>>(st, guess, p.rotation_epsilon, p.transformation_epsilon, p.lm_init_lambda_factor, p.max_iterations, p.lm_max_iterations, e->ticket.as<unsigned>(), p.optimizer != 0 ? 1 : 0);
     HIP_OR_FAIL(e, hipGetLastError());
   }
   long long launched = 0;
@@ -1738,7 +1743,7 @@ int gicp_align(Engine* e, CloudDev& src, CloudDev& tgt, VoxelMapDev& records, co
     batch = 3;
   }
   e->prev_steps = e->last_steps;
-  e->last_steps = 1 + h->num_error_evals;
+  e->last_steps = p.optimizer ? std::max(1, (int)h->num_linearize) : 1 + h->num_error_evals;
   e->lin = h->x_lin;
   e->corr_sel = h->corr_cur;
   e->has_corr = true;
@@ -2113,7 +2118,7 @@ extern "C" {
 
 void fvh_default_lm_params(fvh_lm_params* p) {
   if (!p) return;
-  p->max_iterations = 64; p->rotation_epsilon = 2e-3; p->transformation_epsilon = 5e-4; p->lm_max_iterations = 10; p->lm_init_lambda_factor = 1e-9;
+  p->max_iterations = 64; p->rotation_epsilon = 2e-3; p->transformation_epsilon = 5e-4; p->lm_max_iterations = 10; p->lm_init_lambda_factor = 1e-9; p->optimizer = 0;
 }
 int fvh_device_count(int* count) {
   if (!count) return FVH_ERR_INVALID_ARGUMENT;

@@ -67,6 +67,7 @@ struct LmState {
   // parameters
   double rotation_epsilon, transformation_epsilon, lm_init_lambda_factor;
   int max_iterations, lm_max_iterations;
+  int optimizer, pad_;  // 0 Levenberg-Marquardt (step_lm), 1 Gauss-Newton (step_gn, lsq_registration_impl.hpp:108-121: every transition is a linearisation, the step is always taken)
   // status
   int phase, outer_iter, inner_iter, converged, lm_failed, num_linearize, num_error_evals, nr_iterations;
   int corr_cur;       // which of the two correspondence buffers is current (device-LM mode flips it on accept)
@@ -117,6 +118,7 @@ struct CostParams {
   unsigned long long* result_host;  // persistent kernel: mapped pinned host memory, [sizeof(LmState)/8 words of state][sequence word] (null: not used)
   unsigned long long watchdog_ticks;  // persistent kernel: 100 MHz ticks a workgroup may wait at the barrier before it aborts the launch
   int max_iterations, lm_max_iterations;
+  int optimizer;       // fvh_lm_params::optimizer (first launch of an align)
   double rotation_epsilon, transformation_epsilon, lm_init_lambda_factor;
   // multi-GPU (kernels_peer.hpp): this rank walks the source elements [item_lo, item_hi) of the (Morton) order -- its spatial
   // tile -- and the reduced sums are exchanged with the peers inside the kernel; peer.n <= 1: single GPU, whole cloud
@@ -294,6 +296,9 @@ __device__ unsigned g_lmcall;
 #else
 #define FVH_LM_T(k) do { } while (0)
 #endif
+// GN (compile time): LsqRegistration::step_gn instead of step_lm. A template parameter, not a branch on the state: the Levenberg-Marquardt
+// instantiations of the LM kernel sit on a register cliff and must not pay for the other optimiser's code.
+template <bool GN = false>
 __device__ FVH_LM_STEP_ATTR void dev_lm_step_wave(LmState* st, const double* sums, const int lane, double* trace = nullptr) {
   const bool in36 = lane < 36, in12 = lane < 12, in6 = lane < 6;
   double* x0p = reinterpret_cast<double*>(&st->x0);
@@ -313,6 +318,7 @@ __device__ FVH_LM_STEP_ATTR void dev_lm_step_wave(LmState* st, const double* sum
   int num_linearize = __builtin_amdgcn_readfirstlane(st->num_linearize), num_error_evals = __builtin_amdgcn_readfirstlane(st->num_error_evals);
   int nr_iterations = __builtin_amdgcn_readfirstlane(st->nr_iterations), corr_cur = __builtin_amdgcn_readfirstlane(st->corr_cur);
   const int max_iterations = __builtin_amdgcn_readfirstlane(st->max_iterations), lm_max_iterations = __builtin_amdgcn_readfirstlane(st->lm_max_iterations);
+  constexpr bool gauss_newton = GN;  // step_gn: H d = -b undamped, x0 = exp(d) x0 at once (no trial evaluation)
   const double rot_eps = st->rotation_epsilon, trans_eps = st->transformation_epsilon, lambda_factor = st->lm_init_lambda_factor;
   double dprev[6], bprev[6];
 #pragma unroll
@@ -389,7 +395,7 @@ __device__ FVH_LM_STEP_ATTR void dev_lm_step_wave(LmState* st, const double* sum
       }
       nu = 2.0;
       inner_iter = 0;
-      if (phase0 == PH_LINEARIZE) {
+      if (phase0 == PH_LINEARIZE && !gauss_newton) {
         if (lm_max_iterations <= 0) { lm_failed = 1; phase = PH_DONE; done = true; } else phase = PH_TRIAL;
       }
     } else {
@@ -405,15 +411,17 @@ __device__ FVH_LM_STEP_ATTR void dev_lm_step_wave(LmState* st, const double* sum
   FVH_LM_T(2);
   PoseD delta;
   double d[6];
+  bool gn_step = false;
   int delta_conv = delta_conv_prev;
   if (!done) {
     // ---- d = (H + lambda I)^-1 (-b): LDL^T in registers (Eigen::LDLT semantics for a vanishing pivot: the column stays
     // unscaled and the solve uses the pseudo-inverse of D -- with no correspondences at all H = 0, lambda = 0, d = 0 and the
     // reference returns the initial guess flagged converged instead of a NaN pose, lsq_registration_impl.hpp:111-168) ----
     double L[15], D[6], Dinv[6];  // strictly lower part row by row: L[i (i - 1) / 2 + j], j < i
+    const double lam_solve = gauss_newton ? 0.0 : lambda;  // (H + 0 is H: Gauss-Newton factorises H itself, lsq_registration_impl.hpp:111)
 #pragma unroll
     for (int j = 0; j < 6; j++) {
-      double dj = Hl[j * (j + 1) / 2 + j] + lambda;
+      double dj = Hl[j * (j + 1) / 2 + j] + lam_solve;
 #pragma unroll
       for (int k = 0; k < j; k++) dj -= L[j * (j - 1) / 2 + k] * L[j * (j - 1) / 2 + k] * D[k];
       D[j] = dj;
@@ -453,7 +461,14 @@ __device__ FVH_LM_STEP_ATTR void dev_lm_step_wave(LmState* st, const double* sum
     // loop ends: lsq_registration_impl.hpp:57-66,150-165) or if accepting it exhausts max_iterations -- its speculative
     // linearisation would be thrown away
     delta_conv = FVH_UNI(dev_is_converged(rot_eps, trans_eps, delta)) ? 1 : 0;
-    phase = (delta_conv || outer_iter + 1 >= max_iterations) ? PH_TRIAL_FINAL : PH_TRIAL;
+    if (gauss_newton) {  // the step is taken: converged_ = is_converged(delta), next outer iteration (lsq_registration_impl.hpp:57-66)
+      gn_step = true;
+      converged = delta_conv;
+      outer_iter++;
+      phase = (converged || outer_iter >= max_iterations) ? PH_DONE : PH_LINEARIZE;
+    } else {
+      phase = (delta_conv || outer_iter + 1 >= max_iterations) ? PH_TRIAL_FINAL : PH_TRIAL;
+    }
   }
   FVH_LM_T(5);
   // ---- tail: the state in LDS. Everything comes out of registers (lane 0 stores the poses, the step and the scalars as 16-byte
@@ -478,6 +493,7 @@ __device__ FVH_LM_STEP_ATTR void dev_lm_step_wave(LmState* st, const double* sum
     else hidx = 13 + lj * 3 + (li - 3);
     if (in36) st->H[lane] = sums[hidx];
     if (in6) st->b[lane] = sums[1 + lane];
+    if (gn_step && in36) st->final_H[lane] = sums[hidx];  // step_gn: final_hessian_ = H
   }
   if (!done) {  // xi = delta * x0 (dev_pose_mul)
 #pragma unroll
@@ -494,7 +510,11 @@ __device__ FVH_LM_STEP_ATTR void dev_lm_step_wave(LmState* st, const double* sum
     }
     if (consume) {
 #pragma unroll
-      for (int k = 0; k < 12; k++) xlp[k] = x0r[k];  // x_lin = x0
+      for (int k = 0; k < 12; k++) xlp[k] = gn_step ? xir[k] : x0r[k];  // x_lin = x0 (Gauss-Newton: the NEW x0, where the next trip linearises)
+    }
+    if (gn_step) {
+#pragma unroll
+      for (int k = 0; k < 12; k++) x0p[k] = xir[k];  // x0 = delta * x0
     }
     if (!done) {
 #pragma unroll
@@ -511,18 +531,19 @@ __device__ FVH_LM_STEP_ATTR void dev_lm_step_wave(LmState* st, const double* sum
 }
 
 // tiny kernels for the multi-GPU path and for (re)initialising the state
-__global__ void lm_init_kernel(LmState* st, PoseD guess, double rot_eps, double trans_eps, double lambda_factor, int max_iter, int lm_max_iter, unsigned* ticket) {
+__global__ void lm_init_kernel(LmState* st, PoseD guess, double rot_eps, double trans_eps, double lambda_factor, int max_iter, int lm_max_iter, unsigned* ticket, int optimizer = 0) {
   if (blockIdx.x == 0 && threadIdx.x <= 8) ticket[threadIdx.x] = 0;
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
   st->x0 = guess; st->xi = guess;
   st->rotation_epsilon = rot_eps; st->transformation_epsilon = trans_eps; st->lm_init_lambda_factor = lambda_factor;
-  st->max_iterations = max_iter; st->lm_max_iterations = lm_max_iter;
+  st->max_iterations = max_iter; st->lm_max_iterations = lm_max_iter; st->optimizer = optimizer; st->pad_ = 0;
   st->lambda = -1.0; st->nu = 2.0; st->y0 = 0.0;
   st->phase = max_iter > 0 ? PH_LINEARIZE : PH_DONE;
   st->corr_cur = 0; st->x_lin = guess; st->delta_converged = 0; st->halo_exceeded = 0;
   st->outer_iter = 0; st->inner_iter = 0; st->converged = 0; st->lm_failed = 0; st->num_linearize = 0; st->num_error_evals = 0; st->nr_iterations = 0;
   for (int i = 0; i < 36; i++) st->final_H[i] = (i % 7 == 0) ? 1.0 : 0.0;
 }
+template <bool GN = false>
 __global__ __launch_bounds__(64) void lm_update_kernel(LmState* st) {  // <<<1, 64>>>: one wave, state staged through LDS
   __shared__ LmState s;
   constexpr int WORDS = sizeof(LmState) / 8 - 1;  // without the barrier word
@@ -531,7 +552,7 @@ __global__ __launch_bounds__(64) void lm_update_kernel(LmState* st) {  // <<<1, 
   for (int i = threadIdx.x; i < WORDS; i += 64) l[i] = g[i];
   __syncthreads();
   if (s.phase == PH_DONE) return;
-  dev_lm_step_wave(&s, s.sums, threadIdx.x);
+  dev_lm_step_wave<GN>(&s, s.sums, threadIdx.x);
   __syncthreads();
   for (int i = threadIdx.x; i < WORDS; i += 64) g[i] = l[i];
 }
@@ -726,7 +747,7 @@ __device__ unsigned long long g_mtime[16][512][12];
 // CH: voxel lookups per work item the code is unrolled for -- COST_CH, or 1 for launches whose items hold a single offset (NDT D2D over a
 // few thousand source voxels, DIRECT1): the four-chunk code executed its three dead chunks masked, ~40 % of the main loop's instructions
 // on a grid with one wave per SIMD, where nothing hides an instruction (tools/count_isa.py: 2,200 -> see profiles/r05_isa_counts.txt).
-template <typename Real, int MODE, bool PERSIST, int CH = COST_CH>
+template <typename Real, int MODE, bool PERSIST, int CH = COST_CH, bool GN = false>
 __global__ FVH_COST_BOUNDS void cost_kernel(CostParams P) {
   static_assert(CH == 1 || CH == COST_CH, "one or COST_CH lookups per item");
 #ifdef FVH_COST_TIMING
@@ -1211,7 +1232,7 @@ __global__ FVH_COST_BOUNDS void cost_kernel(CostParams P) {
   auto init_state = [&]() {
     s_st.x0 = P.lin; s_st.xi = P.lin; s_st.x_lin = P.lin;
     s_st.rotation_epsilon = P.rotation_epsilon; s_st.transformation_epsilon = P.transformation_epsilon; s_st.lm_init_lambda_factor = P.lm_init_lambda_factor;
-    s_st.max_iterations = P.max_iterations; s_st.lm_max_iterations = P.lm_max_iterations;
+    s_st.max_iterations = P.max_iterations; s_st.lm_max_iterations = P.lm_max_iterations; s_st.optimizer = P.optimizer; s_st.pad_ = 0;
     s_st.lambda = -1.0; s_st.nu = 2.0; s_st.y0 = 0.0;
     s_st.phase = PH_LINEARIZE; s_st.corr_cur = 0; s_st.delta_converged = 0; s_st.halo_exceeded = 0;
     s_st.outer_iter = 0; s_st.inner_iter = 0; s_st.converged = 0; s_st.lm_failed = 0; s_st.num_linearize = 0; s_st.num_error_evals = 0; s_st.nr_iterations = 0;
@@ -1264,7 +1285,7 @@ __global__ FVH_COST_BOUNDS void cost_kernel(CostParams P) {
       if (P.host_phase < 0 && P.init) init_state();
     }
     __syncthreads();
-    if (P.host_phase < 0 && !P.defer_lm && tid < 64) dev_lm_step_wave(&s_st, red[0], tid, P.lm_trace);
+    if (P.host_phase < 0 && !P.defer_lm && tid < 64) dev_lm_step_wave<GN>(&s_st, red[0], tid, P.lm_trace);
     FVH_STAMP(6);
     __syncthreads();
     for (int i = tid; i < ST_WORDS; i += 256) st_words[i] = reinterpret_cast<const unsigned long long*>(&s_st)[i];
@@ -1500,7 +1521,7 @@ __global__ FVH_COST_BOUNDS void cost_kernel(CostParams P) {
 #endif
           // The step is ~10 KB of code that runs once per trip -- always on the same few CUs (the collectors), so it stays in their
           // instruction caches, and the state stays in the collector's LDS for the whole launch instead of travelling through memory
-          dev_lm_step_wave(&s_st, red[0], lane, lb == 0 ? P.lm_trace : nullptr);
+          dev_lm_step_wave<GN>(&s_st, red[0], lane, lb == 0 ? P.lm_trace : nullptr);
 #ifdef FVH_COST_TIMING
           if (threadIdx.x == 0 && trip < 16 && lb == 0) g_ptime[trip][0][11] = __builtin_readcyclecounter() - lm_c0;  // shader cycles of the LM step (next to its wall-clock stamps 8 -> 9)
 #endif

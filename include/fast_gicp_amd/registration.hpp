@@ -286,7 +286,7 @@ public:
   void setDebugPrint(bool p) { lm_debug_print_ = p; }
   void setUseDeviceLM(bool on) { use_device_lm_ = on; }
   /// lsq_optimizer_type_ (lsq_registration.hpp:78: protected there, set by subclasses; LevenbergMarquardt by default, :15). Gauss-Newton
-  /// (step_gn, :108-121) runs the reference's host loop on the device's linearize(); the device-resident loop is Levenberg-Marquardt.
+  /// (step_gn, :108-121) is device-resident too (fvh_lm_params::optimizer); setUseDeviceLM(false) runs the reference's host loop on the device's linearize().
   void setLSQType(LSQ_OPTIMIZER_TYPE type) { lsq_optimizer_type_ = type; }
   const Matrix6d& getFinalHessian() const { return final_hessian_; }
   const Matrix4f& getFinalTransformation() const { return final_transformation_; }
@@ -319,7 +319,7 @@ protected:
     detail::HostTiming& ht = detail::host_timing();
     std::chrono::steady_clock::time_point ht0, ht1;
     if (ht.on) ht0 = std::chrono::steady_clock::now();
-    if (use_device_lm_ && lsq_optimizer_type_ == LSQ_OPTIMIZER_TYPE::LevenbergMarquardt && device_align(x0)) {
+    if (use_device_lm_ && device_align(x0)) {  // (both optimiser types: Levenberg-Marquardt and, since round 5, Gauss-Newton run inside the kernel)
       // whole loop ran on the GPU
     } else {
       for (int i = 0; i < max_iterations_ && !converged_; i++) {
@@ -549,7 +549,8 @@ protected:
   bool device_align(Isometry3d& x0) override {
     double g16[16];
     x0.to_colmajor16(g16);
-    fvh_lm_params p{this->max_iterations_, this->rotation_epsilon_, this->transformation_epsilon_, this->lm_max_iterations_, this->lm_init_lambda_factor_};
+    fvh_lm_params p{this->max_iterations_, this->rotation_epsilon_, this->transformation_epsilon_, this->lm_max_iterations_, this->lm_init_lambda_factor_,
+                    this->lsq_optimizer_type_ == LSQ_OPTIMIZER_TYPE::GaussNewton ? 1 : 0};
     fvh_lm_result r;
     call(fvh_vgicp_set_lm_trace(core_, this->lm_debug_print_ ? 1 : 0), "set_lm_trace");
     call(fvh_vgicp_align(core_, g16, &p, &r), "align");
@@ -676,7 +677,8 @@ protected:
   bool device_align(Isometry3d& x0) override {
     double g16[16];
     x0.to_colmajor16(g16);
-    fvh_lm_params p{this->max_iterations_, this->rotation_epsilon_, this->transformation_epsilon_, this->lm_max_iterations_, this->lm_init_lambda_factor_};
+    fvh_lm_params p{this->max_iterations_, this->rotation_epsilon_, this->transformation_epsilon_, this->lm_max_iterations_, this->lm_init_lambda_factor_,
+                    this->lsq_optimizer_type_ == LSQ_OPTIMIZER_TYPE::GaussNewton ? 1 : 0};
     fvh_lm_result r;
     call(fvh_vgicp_set_lm_trace(core_, this->lm_debug_print_ ? 1 : 0), "set_lm_trace");
     call(fvh_vgicp_gicp_align(core_, g16, &p, &r), "gicp_align");
@@ -812,7 +814,8 @@ protected:
   bool device_align(Isometry3d& x0) override {
     double g16[16];
     x0.to_colmajor16(g16);
-    fvh_lm_params p{this->max_iterations_, this->rotation_epsilon_, this->transformation_epsilon_, this->lm_max_iterations_, this->lm_init_lambda_factor_};
+    fvh_lm_params p{this->max_iterations_, this->rotation_epsilon_, this->transformation_epsilon_, this->lm_max_iterations_, this->lm_init_lambda_factor_,
+                    this->lsq_optimizer_type_ == LSQ_OPTIMIZER_TYPE::GaussNewton ? 1 : 0};
     fvh_lm_result r;
     this->call(fvh_vgicp_set_lm_trace(core_, this->lm_debug_print_ ? 1 : 0), "set_lm_trace");
     this->call(fvh_vgicp_align(core_, g16, &p, &r), "align");
@@ -897,7 +900,8 @@ protected:
   bool device_align(Isometry3d& x0) override {
     double g16[16];
     x0.to_colmajor16(g16);
-    fvh_lm_params p{this->max_iterations_, this->rotation_epsilon_, this->transformation_epsilon_, this->lm_max_iterations_, this->lm_init_lambda_factor_};
+    fvh_lm_params p{this->max_iterations_, this->rotation_epsilon_, this->transformation_epsilon_, this->lm_max_iterations_, this->lm_init_lambda_factor_,
+                    this->lsq_optimizer_type_ == LSQ_OPTIMIZER_TYPE::GaussNewton ? 1 : 0};
     fvh_lm_result r;
     call(fvh_ndt_set_lm_trace(core_, this->lm_debug_print_ ? 1 : 0), "set_lm_trace");
     call(fvh_ndt_align(core_, g16, &p, &r), "align");

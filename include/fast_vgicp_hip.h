@@ -49,13 +49,14 @@ enum fvh_ndt_distance_mode { FVH_NDT_P2D = 0, FVH_NDT_D2D = 1 };
  * in neighbour-list order, Eigen's closed-form float eigen solver). VGICP handles only; RBF covariances and the voxel sums stay fp64. */
 enum fvh_precision { FVH_COMPUTE_FP64 = 0, FVH_COMPUTE_FP32 = 1, FVH_COMPUTE_CUDA_COMPAT = 2 };
 
-/* LsqRegistration parameters (lsq_registration_impl.hpp:9-22 defaults) for the device-resident LM */
+/* LsqRegistration parameters (lsq_registration_impl.hpp:9-22 defaults) for the device-resident optimiser loop */
 typedef struct fvh_lm_params {
   int max_iterations;            /* 64   pcl max_iterations_ */
   double rotation_epsilon;       /* 2e-3 */
   double transformation_epsilon; /* 5e-4 */
   int lm_max_iterations;         /* 10 */
   double lm_init_lambda_factor;  /* 1e-9 */
+  int optimizer;                 /* 0 LSQ_OPTIMIZER_TYPE::LevenbergMarquardt (step_lm, default), 1 GaussNewton (step_gn, lsq_registration_impl.hpp:108-121) */
 } fvh_lm_params;
 
 typedef struct fvh_lm_result {

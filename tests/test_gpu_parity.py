@@ -382,3 +382,42 @@ def test_multiplicative_voxel_accumulation_matches_oracle(O, pair, oracle_covs):
     _, _, m0, v0 = d.get_voxelmap()
     assert np.array_equal(np.sort(m1, axis=0), np.sort(m0, axis=0)) and np.array_equal(np.sort(v1.reshape(len(v1), -1), axis=0), np.sort(v0.reshape(len(v0), -1), axis=0))
     c.close(); d.close()
+
+
+@pytest.mark.parametrize("search", ["DIRECT7", "DIRECT27"])
+def test_gauss_newton_on_the_device_matches_the_oracle_on_both_routes(O, pair, search):
+    """fvh_lm_params::optimizer = 1: LsqRegistration::step_gn (lsq_registration_impl.hpp:108-121) inside the kernel -- every transition a
+    linearisation, H d = -b undamped, x0 = exp(d) x0, final_hessian_ = H, converged_ = is_converged(delta). Against the oracle's step_gn
+    (pose 1e-4, equal iteration count, no error evaluations), and the persistent launch against one launch per transition: same bits."""
+    import os
+    import subprocess
+    import sys
+    from fast_gicp_amd import capi
+    tgt, src = pair
+    cs, os_ = {"DIRECT7": (capi.DIRECT7, O.DIRECT7), "DIRECT27": (capi.DIRECT27, O.DIRECT27)}[search]
+    g = O.FastVGICP(search=os_)
+    g.set_optimizer("GN")
+    g.set_target(tgt); g.set_source(src)
+    ro = g.align()
+    c = capi.VGICPCore(0)
+    c.set_neighbor_search_method(cs)
+    c.set_target_cloud(tgt); c.find_target_neighbors(20); c.calculate_target_covariances(capi.REG_PLANE); c.create_target_voxelmap()
+    c.set_source_cloud(src); c.find_source_neighbors(20); c.calculate_source_covariances(capi.REG_PLANE)
+    r = c.align(optimizer=1)
+    assert r["converged"] and ro["converged"] and r["num_launches"] == 1
+    assert r["num_error_evals"] == 0 == ro["num_error_evals"] and r["num_linearize"] == ro["num_linearize"] and r["nr_iterations"] == ro["nr_iterations"]
+    assert util.rel_err(r["T"], ro["T"]) < 1e-4 and util.rel_err(r["H"], ro["H"]) < 1e-4
+    rl = c.align()  # Levenberg-Marquardt on the same handle afterwards: the optimiser is a per-align parameter
+    assert rl["converged"] and rl["num_error_evals"] > 0
+    # one launch per transition (FVH_PERSISTENT=0, its own process: the knob is read once): bit-identical to the persistent launch
+    code = ("import sys, numpy as np; sys.path.insert(0, %r)\\n"
+            "from tests import util; from fast_gicp_amd import capi\\n"
+            "tgt, src = util.bundled_pair(); c = capi.VGICPCore(0); c.set_neighbor_search_method(%d)\\n"
+            "c.set_target_cloud(tgt); c.find_target_neighbors(20); c.calculate_target_covariances(3); c.create_target_voxelmap()\\n"
+            "c.set_source_cloud(src); c.find_source_neighbors(20); c.calculate_source_covariances(3)\\n"
+            "r = c.align(optimizer=1); assert r['num_launches'] > 1; np.save(sys.argv[1], np.concatenate([r['T'].ravel(), r['H'].ravel()]))\\n") % (util.ROOT, cs)
+    import tempfile
+    out = os.path.join(tempfile.mkdtemp(), "gn.npy")
+    subprocess.check_call([sys.executable, "-c", code, out], env=dict(os.environ, FVH_PERSISTENT="0"), cwd=util.ROOT)
+    assert np.array_equal(np.load(out), np.concatenate([r["T"].ravel(), r["H"].ravel()]))
+    c.close()

@@ -65,14 +65,22 @@ def test_host_lm_equals_device_lm(pygicp, data, cls):
 
 @pytest.mark.parametrize("cls", ["FastVGICPCuda", "FastVGICP", "FastGICP", "NDTCuda"])
 def test_gauss_newton_optimizer_matches_oracle(pygicp, data, cls):
-    """LSQ_OPTIMIZER_TYPE::GaussNewton (lsq_registration_impl.hpp:94-121) through the host classes: the reference's host loop on the
-    device's linearize(), against the oracle's step_gn at 1e-4 (north_star), Hessian included."""
+    """LSQ_OPTIMIZER_TYPE::GaussNewton (lsq_registration_impl.hpp:94-121) through the host classes, against the oracle's step_gn at 1e-4
+    (north_star), Hessian included. Since round 5 the Gauss-Newton loop is device-resident like Levenberg-Marquardt (fvh_lm_params::optimizer:
+    one linearisation per transition inside the kernel, the step always taken); the reference's host loop on the device's linearize()
+    (set_use_device_lm(False)) must give the same registration to fp64 rounding."""
     from oracle import oracle as O
     target, source, gt = data
     reg = getattr(pygicp, cls)()
     reg.set_lsq_type("GN")
     reg.set_input_target(target); reg.set_input_source(source)
     T = reg.align()
+    host = getattr(pygicp, cls)()
+    host.set_lsq_type("GN"); host.set_use_device_lm(False)
+    host.set_input_target(target); host.set_input_source(source)
+    Th = host.align()
+    assert np.array_equal(T, Th) and reg.has_converged() and host.has_converged()  # float32 final_transformation_
+    assert util.rel_err(reg.get_final_hessian(), host.get_final_hessian()) < 1e-10
     if cls == "NDTCuda":
         g = O.NDT()
     else:

@@ -7,7 +7,7 @@ import re
 import sys
 
 path = sys.argv[1]
-name = sys.argv[2] if len(sys.argv) > 2 else "_ZN3fvh11cost_kernelIdLi0ELb1ELi4EEEvNS_10CostParamsE"
+name = sys.argv[2] if len(sys.argv) > 2 else "_ZN3fvh11cost_kernelIdLi0ELb1ELi4ELb0EEEvNS_10CostParamsE"
 t = open(path).read()
 i = t.index(name + ":")
 body = t[i:t.index(".Lfunc_end", i)].split("\n")
