@@ -2,7 +2,9 @@
 // frames %06d.bin (x, y, z, intensity as float32, kitti.cpp:22-69) -> ApproximateVoxelGrid 0.25 ON THE DEVICE (the raw
 // xyzi buffer goes to the GPU as it is) -> setInputSource -> align -> swapSourceAndTarget -> pose accumulation; prints the
 // running frame rate and writes the trajectory in KITTI format (12 values per line, kitti.cpp:141-153).
-//   usage: gicp_kitti /path/to/sequences/00/velodyne [ndt|vgicp|gicp] [trajectory.txt]
+//   usage: gicp_kitti /path/to/sequences/00/velodyne [ndt|ndt_pipelined|vgicp|gicp] [trajectory.txt]
+// ndt_pipelined: the same loop as a two-stage pipeline -- while the LM kernel of frame k runs, frame k+1 is read, filtered on the handle's
+// second stream and its voxel map built there (NDTCuda::alignAsync / prepareNextSourceDevice / adoptPreparedSource / alignWait).
 #include <chrono>
 #include <cstdio>
 #include <deque>
@@ -56,9 +58,22 @@ static Cloud::Ptr downsample_on_device(fvh_voxelgrid* vg, const std::vector<floa
   return cloud;
 }
 
+static void write_trajectory(const std::string& traj_path, const std::vector<Isometry3d>& poses) {  // kitti.cpp:141-153
+  std::ofstream ofs(traj_path);
+  ofs.precision(9);
+  for (const auto& pose : poses) {
+    for (int i = 0; i < 3; i++)
+      for (int j = 0; j < 4; j++) {
+        if (i || j) ofs << " ";
+        ofs << (j < 3 ? pose.R[i * 3 + j] : pose.t[i]);
+      }
+    ofs << std::endl;
+  }
+}
+
 int main(int argc, char** argv) {
   if (argc < 2) {
-    std::cout << "usage: gicp_kitti /your/kitti/path/sequences/00/velodyne [ndt|vgicp|gicp] [trajectory.txt]" << std::endl;
+    std::cout << "usage: gicp_kitti /your/kitti/path/sequences/00/velodyne [ndt|ndt_pipelined|vgicp|gicp] [trajectory.txt]" << std::endl;
     return 0;
   }
   const std::string method = argc > 2 ? argv[2] : "gicp";  // the reference's default is FastGICP (kitti.cpp:85)
@@ -86,6 +101,40 @@ int main(int argc, char** argv) {
     reg = gicp;
   }
 
+  if (method == "ndt_pipelined") {
+    NDTCuda<PointXYZ, PointXYZ> ndt;
+    ndt.setResolution(1.0);
+    ndt.setInputTarget(downsample_on_device(vg, kitti.frame(0), downsample_resolution));
+    detail::check(fvh_voxelgrid_share_prepare_stream_with_ndt(vg, ndt.core()), "share_prepare_stream", fvh_voxelgrid_last_error(vg));
+    auto prepare = [&](size_t i) {  // read + filter + widen + voxel map of frame i, all on the handle's second stream
+      const std::vector<float> xyzi = kitti.frame(i);
+      int n = 0;
+      const float* d_xyz = nullptr;
+      detail::check(fvh_voxelgrid_filter_strided(vg, FVH_VOXELGRID_APPROXIMATE, xyzi.data(), (int)(xyzi.size() / 4), 4, downsample_resolution, &n), "fvh_voxelgrid_filter_strided", fvh_voxelgrid_last_error(vg));
+      detail::check(fvh_voxelgrid_device_points(vg, &d_xyz, &n), "fvh_voxelgrid_device_points", fvh_voxelgrid_last_error(vg));
+      ndt.prepareNextSourceDevice(d_xyz, n, 3);
+    };
+    std::vector<Isometry3d> poses(kitti.size());
+    poses[0] = Isometry3d::Identity();
+    std::deque<std::chrono::high_resolution_clock::time_point> stamps;
+    stamps.push_back(std::chrono::high_resolution_clock::now());
+    if (kitti.size() > 1) prepare(1);
+    for (size_t i = 1; i < kitti.size(); i++) {
+      ndt.adoptPreparedSource();
+      ndt.alignAsync();
+      if (i + 1 < kitti.size()) prepare(i + 1);  // beside the running LM kernel
+      poses[i] = poses[i - 1] * Isometry3d::from(ndt.alignWait());
+      ndt.swapSourceAndTarget();
+      stamps.push_back(std::chrono::high_resolution_clock::now());
+      if (stamps.size() > 30) stamps.pop_front();
+      std::cout << stamps.size() / (std::chrono::duration_cast<std::chrono::nanoseconds>(stamps.back() - stamps.front()).count() / 1e9) << "fps" << std::endl;
+    }
+    detail::check(fvh_voxelgrid_share_stream_with_ndt(vg, nullptr), "share_stream", fvh_voxelgrid_last_error(vg));
+    fvh_voxelgrid_destroy(vg);
+    write_trajectory(traj_path, poses);
+    return 0;
+  }
+
   // set initial frame as target (kitti.cpp:95-99)
   reg->setInputTarget(downsample_on_device(vg, kitti.frame(0), downsample_resolution));
   std::vector<Isometry3d> poses(kitti.size());
@@ -106,15 +155,6 @@ int main(int argc, char** argv) {
   }
   fvh_voxelgrid_destroy(vg);
 
-  std::ofstream ofs(traj_path);  // kitti.cpp:141-153
-  ofs.precision(9);
-  for (const auto& pose : poses) {
-    for (int i = 0; i < 3; i++)
-      for (int j = 0; j < 4; j++) {
-        if (i || j) ofs << " ";
-        ofs << (j < 3 ? pose.R[i * 3 + j] : pose.t[i]);
-      }
-    ofs << std::endl;
-  }
+  write_trajectory(traj_path, poses);
   return 0;
 }

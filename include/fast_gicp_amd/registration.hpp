@@ -878,6 +878,31 @@ public:
   }
   fvh_ndt* core() { return core_; }
 
+  // ---- frame streams as a two-stage pipeline (no reference counterpart; C ABI: fvh_ndt_align_async / _wait, fvh_ndt_prepare_source_device /
+  // _adopt_prepared_source). kitti.cpp:95-128 with the preparation of frame k+1 hidden under the registration of frame k:
+  //     adoptPreparedSource(); alignAsync(); [filter frame k+1 on the prepare stream; prepareNextSourceDevice()]; alignWait(); swapSourceAndTarget();
+  // The prepared source lives on the device only: getInputSource() is null for it and alignWait() returns the pose without
+  // transforming a host cloud. Same kernels on the same data as the sequential calls: same registration.
+  void prepareNextSourceDevice(const float* d_xyz, int n, int stride_floats = 3) { call(fvh_ndt_prepare_source_device(core_, d_xyz, n, stride_floats), "prepare_source_device"); }
+  void adoptPreparedSource() { call(fvh_ndt_adopt_prepared_source(core_), "adopt_prepared_source"); input_.reset(); }
+  void alignAsync(const Matrix4f& guess = Matrix4f::Identity()) {
+    double g16[16];
+    Isometry3d::from(guess).to_colmajor16(g16);
+    fvh_lm_params p{this->max_iterations_, this->rotation_epsilon_, this->transformation_epsilon_, this->lm_max_iterations_, this->lm_init_lambda_factor_,
+                    this->lsq_optimizer_type_ == LSQ_OPTIMIZER_TYPE::GaussNewton ? 1 : 0};
+    call(fvh_ndt_align_async(core_, g16, &p), "align_async");
+  }
+  const Matrix4f& alignWait() {
+    fvh_lm_result r;
+    call(fvh_ndt_align_wait(core_, &r), "align_wait");
+    this->final_transformation_ = Isometry3d::from_colmajor16(r.T).cast_float();
+    this->converged_ = r.converged != 0;
+    this->nr_iterations_ = r.nr_iterations;
+    for (int i = 0; i < 6; i++) for (int j = 0; j < 6; j++) this->final_hessian_[i * 6 + j] = r.H[j * 6 + i];
+    if (r.lm_failed) std::fprintf(stderr, "lm not converged!!\n");
+    return this->final_transformation_;
+  }
+
 protected:
   void computeTransformation(typename Base::PointCloudSource& output, const Matrix4f& guess) override {  // :76-79
     call(fvh_ndt_create_voxelmaps(core_), "create_voxelmaps");

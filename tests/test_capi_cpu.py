@@ -123,3 +123,18 @@ def test_the_lm_kernels_main_loop_has_no_scratch_access(tmp_path):
             main_loop = {k: v for k, v in scratch.items() if k != "pre" and k not in (7, 20, 21)}  # marks 0..6 and 8 bracket the main loop; 7 = epilogue, 20/21 = LM step
             assert not main_loop, (name, scratch)
             assert sum(scratch.values()) <= 24, (name, scratch)
+
+
+def test_every_environment_knob_is_documented():
+    """INTEGRATION.md lists EVERY FVH_* environment variable the library reads, with default and status: the set of
+    getenv("FVH_...") calls in fast_gicp_amd/csrc must equal the set named in its table (test-build-only switches apart)."""
+    src = ""
+    d = os.path.join(util.ROOT, "fast_gicp_amd", "csrc")
+    for f in os.listdir(d):
+        src += open(os.path.join(d, f)).read()
+    read = set(re.findall(r'getenv\("(FVH_[A-Z_0-9]+)"\)', src))
+    doc = open(os.path.join(util.ROOT, "INTEGRATION.md")).read()
+    table = doc[doc.index("the complete list"):doc.index("Removed in round 5")]
+    named = set(re.findall(r"`(FVH_[A-Z_0-9]+)`", table))
+    test_build_only = {"FVH_KNN_MODE", "FVH_RBF_MODE", "FVH_FIT_MODE", "FVH_GICP_NN_MODE"}
+    assert read - test_build_only == named - {"FVH_LIB_PATH"}, (sorted(read - test_build_only - named), sorted(named - read))

@@ -405,7 +405,7 @@ def test_gauss_newton_on_the_device_matches_the_oracle_on_both_routes(O, pair, s
     c.set_source_cloud(src); c.find_source_neighbors(20); c.calculate_source_covariances(capi.REG_PLANE)
     r = c.align(optimizer=1)
     assert r["converged"] and ro["converged"] and r["num_launches"] == 1
-    assert r["num_error_evals"] == 0 == ro["num_error_evals"] and r["num_linearize"] == ro["num_linearize"] and r["nr_iterations"] == ro["nr_iterations"]
+    assert r["num_error_evals"] == 0 == ro["num_error_evals"] and r["num_linearize"] == ro["num_linearize"] and r["iterations"] == ro["iterations"]
     assert util.rel_err(r["T"], ro["T"]) < 1e-4 and util.rel_err(r["H"], ro["H"]) < 1e-4
     rl = c.align()  # Levenberg-Marquardt on the same handle afterwards: the optimiser is a per-align parameter
     assert rl["converged"] and rl["num_error_evals"] > 0

@@ -74,7 +74,7 @@ def test_vgicp_odometry_matches_oracle(O, frames):
     c.close()
 
 
-@pytest.mark.parametrize("method", ["ndt", "vgicp", "gicp"])
+@pytest.mark.parametrize("method", ["ndt", "ndt_pipelined", "vgicp", "gicp"])
 def test_gicp_kitti_app_on_simulated_sequence(tmp_path, method):
     """apps/gicp_kitti (the reference's src/kitti.cpp driver): KITTI-format .bin frames (x, y, z, intensity) in, trajectory
     in KITTI format out; the raw xyzi buffers are downsampled on the device. 5 simulated frames, end pose vs ground truth."""
@@ -96,6 +96,11 @@ def test_gicp_kitti_app_on_simulated_sequence(tmp_path, method):
     gt = np.linalg.inv(util.lidar_pose(0)) @ util.lidar_pose(n - 1)
     te, re_ = util.pose_error(gt, est)
     assert te < 0.12 and re_ < np.radians(1.0), (te, re_)
+    if method == "ndt_pipelined":  # the C++ pipeline (NDTCuda::alignAsync / prepareNextSourceDevice / adoptPreparedSource / alignWait) == the sequential app
+        traj2 = str(tmp_path / "traj_seq.txt")
+        out2 = subprocess.run([exe, str(tmp_path), "ndt", traj2], capture_output=True, text=True, timeout=300)
+        assert out2.returncode == 0, out2.stderr
+        assert np.abs(np.loadtxt(traj2) - np.loadtxt(traj)).max() < 1e-6
 
 
 def _sorted_map(vm):
