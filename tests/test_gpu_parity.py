@@ -410,12 +410,20 @@ def test_gauss_newton_on_the_device_matches_the_oracle_on_both_routes(O, pair, s
     rl = c.align()  # Levenberg-Marquardt on the same handle afterwards: the optimiser is a per-align parameter
     assert rl["converged"] and rl["num_error_evals"] > 0
     # one launch per transition (FVH_PERSISTENT=0, its own process: the knob is read once): bit-identical to the persistent launch
-    code = ("import sys, numpy as np; sys.path.insert(0, %r)\\n"
-            "from tests import util; from fast_gicp_amd import capi\\n"
-            "tgt, src = util.bundled_pair(); c = capi.VGICPCore(0); c.set_neighbor_search_method(%d)\\n"
-            "c.set_target_cloud(tgt); c.find_target_neighbors(20); c.calculate_target_covariances(3); c.create_target_voxelmap()\\n"
-            "c.set_source_cloud(src); c.find_source_neighbors(20); c.calculate_source_covariances(3)\\n"
-            "r = c.align(optimizer=1); assert r['num_launches'] > 1; np.save(sys.argv[1], np.concatenate([r['T'].ravel(), r['H'].ravel()]))\\n") % (util.ROOT, cs)
+    code = """
+import sys, numpy as np
+sys.path.insert(0, %r)
+from tests import util
+from fast_gicp_amd import capi
+tgt, src = util.bundled_pair()
+c = capi.VGICPCore(0)
+c.set_neighbor_search_method(%d)
+c.set_target_cloud(tgt); c.find_target_neighbors(20); c.calculate_target_covariances(3); c.create_target_voxelmap()
+c.set_source_cloud(src); c.find_source_neighbors(20); c.calculate_source_covariances(3)
+r = c.align(optimizer=1)
+assert r["num_launches"] > 1
+np.save(sys.argv[1], np.concatenate([r["T"].ravel(), r["H"].ravel()]))
+""" % (util.ROOT, cs)
     import tempfile
     out = os.path.join(tempfile.mkdtemp(), "gn.npy")
     subprocess.check_call([sys.executable, "-c", code, out], env=dict(os.environ, FVH_PERSISTENT="0"), cwd=util.ROOT)
