@@ -1187,8 +1187,11 @@ int persistent_capacity(Engine* e) {
 // clouds: still at most COST_CH..group_max offsets per item -- one thread walking all 27 offsets of its point left 24 %
 // of the resident threads without work at 100k points and made the launch 18 % slower than 4 offsets per item
 // (measured at 100k x DIRECT27: group 27: 423 us, 14: 426, 9: 361, 7: 386, 6: 368, 5: 423, 4: 358, 3: 355, 2: 459, 1: 615).
-struct CostShape { int group, groups_per_src; long long n_walk; int blocks; };
-inline CostShape cost_shape(const Engine* e, const CostSource& src) {
+struct CostShape { int group, groups_per_src; long long n_walk; int blocks; int split; };
+// `mode`, `device_lm`: NDT launches of the device-resident optimiser loop whose items hold one offset and whose grid stays within one
+// workgroup per CU take the wave-role layout (kernels_cost.hpp: `split` -- 128 items per workgroup, waves 0-1 the trial error of the
+// stored ids, waves 2-3 the new linearisation). Both routes of an align call this with the same arguments: the same layout.
+inline CostShape cost_shape(const Engine* e, const CostSource& src, int mode = MODE_VGICP, bool device_lm = false) {
   static const long long target_items = [] { const char* v = getenv("FVH_COST_TARGET_ITEMS"); return v ? atoll(v) : 256LL * 256 * 2; }();
   static const int max_blocks = [] { const char* v = getenv("FVH_COST_MAX_BLOCKS"); int b = v ? atoi(v) : MAX_COST_BLOCKS; return b < 1 ? 1 : (b > MAX_COST_BLOCKS ? MAX_COST_BLOCKS : b); }();
   static const int group_max = [] { const char* v = getenv("FVH_COST_GROUP_MAX"); return v ? std::min(std::max(1, atoi(v)), COST_CH) : COST_CH; }();  // the kernel keeps one item's lookups in flight together: at most COST_CH
@@ -1202,6 +1205,15 @@ inline CostShape cost_shape(const Engine* e, const CostSource& src) {
   if (e->sharded() && src.shardable) { const Tile t = peer_tile(e, src.n_upper); s.n_walk = std::max(t.hi - t.lo, 0); }  // multi-GPU: this rank's tile
   if (src.device_tile) s.n_walk = (n_expected + e->shard_ranks() - 1) / std::max(1, e->shard_ranks());
   s.blocks = (int)std::max<long long>(1, std::min<long long>(max_blocks, (s.n_walk * s.groups_per_src + 255) / 256));
+  s.split = 0;
+  static const int split_on = [] { const char* v = getenv("FVH_COST_SPLIT"); return v ? atoi(v) : 1; }();
+  if (split_on && device_lm && mode != MODE_VGICP && s.group == 1) {
+    static int cus[16] = {0};
+    const int dev = e->device & 15;
+    if (cus[dev] <= 0 && hipDeviceGetAttribute(&cus[dev], hipDeviceAttributeMultiprocessorCount, e->device) != hipSuccess) cus[dev] = 0;
+    const long long wgs = (s.n_walk * s.groups_per_src + 127) / 128;
+    if (cus[dev] > 0 && wgs <= cus[dev]) { s.split = 1; s.blocks = (int)std::max<long long>(1, wgs); }
+  }
   return s;
 }
 
@@ -1218,8 +1230,9 @@ int launch_cost(Engine* e, const CostSource& src, const VoxelMapDev& vm, int hos
   P.region = vm.is_shard ? vm.region.as<VmRegion>() : nullptr;
   const int n_off = src.n_off_override > 0 ? src.n_off_override : e->n_off;
   P.offsets = e->offsets_dev.as<int>(); P.offsets_packed = e->offsets_dev.as<int>() + 3 * (size_t)e->n_off; P.n_off = n_off;
-  const CostShape shape = cost_shape(e, src);
+  const CostShape shape = cost_shape(e, src, MODE, host_phase < 0);
   P.group = shape.group;
+  P.split = shape.split;
   P.groups_per_src = shape.groups_per_src;
   {  // w / d == mulhi(w, ceil(2^32 / d)) for all w with w * d < 2^32 (d = 1: no shift-free magic, plain division is free there)
     const unsigned long long d = (unsigned long long)shape.groups_per_src, items = (unsigned long long)std::max(src.n_upper, 1) * d;
@@ -1453,7 +1466,7 @@ int align_begin(Engine* e, AlignCtx& c, const CostSource& src, VoxelMapDev& vm, 
   if (c.persistent) {
     int cap = persistent_capacity<MODE>(e);
     if (e->peer.attached()) cap = std::max(1, cap / std::max(1, e->peer.ranks_on_device));
-    const int want = std::min(cost_shape(e, src).blocks, std::max(cap, 1));
+    const int want = std::min(cost_shape(e, src, MODE, true).blocks, std::max(cap, 1));
     // Layouts (kernels_cost.hpp): chip-wide grids reduce per XCD (ng = 8; small ones: default_groups())
     const bool local_ok = xcd_local_wanted();
     c.grant = g_slots.acquire(e->device, std::max(cap, 1), want);

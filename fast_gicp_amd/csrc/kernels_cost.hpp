@@ -126,6 +126,9 @@ struct CostParams {
   // ... the same for a source whose element count lives on the device (NDT D2D: the voxels of the source map, walked in the canonical --
   // key-sorted -- order `order` so that every rank cuts the same list): this rank takes chunk tile_rank of tile_n equal chunks (tile_n <= 1: everything)
   int tile_rank, tile_n;
+  // NDT device LM on small grids: a workgroup takes 128 items, waves 0-1 evaluate the trial error of the stored ids, waves 2-3 find and
+  // linearise the new ones (see the main loop); 0: every wave does both for its own 64 items
+  int split;
   double* lm_trace;   // setDebugPrint on the device LM: 6 doubles per trial {i, y0, yi, rho, lambda, |d|} (lsq_registration_impl.hpp:143-149), or null
   int external_find;  // FastGICP on the device: the correspondences of every linearisation were found by nn1_corr_kernel right before this launch (nothing to probe here)
   PeerView peer;
@@ -803,6 +806,7 @@ __global__ FVH_COST_BOUNDS void cost_kernel(CostParams P) {
   __shared__ int s_elem[STICKY_T];
   __shared__ int s_ids[2][CH][STICKY_T];
   __shared__ int s_ofp[CH][STICKY_T];  // the item's packed neighbour offsets
+  bool a_primed = false;  // wave roles: waves 0-1 skip the plain linearisations, so they fill their sticky slots on their FIRST fused trip, whichever that is
   for (;;) {  // PERSIST: one trip per LM transition; otherwise exactly one trip
   if (PERSIST) FVH_PT_MIN(gen, 0);
   const bool fused = (P.host_phase < 0) && (phase == PH_TRIAL);  // trial error (old ids) + speculative linearisation at xi (new ids)
@@ -829,8 +833,21 @@ __global__ FVH_COST_BOUNDS void cost_kernel(CostParams P) {
   }
   int* corr_old = P.corr + (size_t)corr_sel * P.corr_stride;                      // read (stored ids)
   int* corr_new = fused ? P.corr + (size_t)(corr_sel ^ 1) * P.corr_stride : corr_old;  // written by the find
-  const bool sticky = PERSIST && ((long long)(n_items - w_lo) <= (long long)nb * 256);  // (uniform, the same on every trip of a launch)
-  const bool cached = sticky && gen > 0;
+  // Wave roles (NDT instantiations with one lookup per item, device LM, grids of at most one workgroup per CU -- `P.split`): a fused trip
+  // is two independent pieces of work per item -- (A) the trial error of the STORED id at the trial pose (old record, R_lin C R_lin^T,
+  // one Mahalanobis term) and (B) the new linearisation (voxel coordinate, probe, record, R_ev C R_ev^T, hit term, 28 item sums, the
+  // butterfly). With one wave per SIMD nothing overlaps them and every instruction is ~6 cycles of latency, while 3/4 of the chip's
+  // SIMDs hold no wave at all: so a workgroup takes 128 items instead of 256, waves 0-1 run (A) and waves 2-3 run (B) for the same
+  // items. Roles are wave-uniform (scalar branches). The critical wave's instruction stream shrinks to (B). (A)'s waves read the
+  // stored ids from (B)'s sticky slots (thread + 128) and contribute slot 28 (the trial error) only.
+  constexpr bool SPLIT_OK = (MODE != MODE_VGICP) && CH == 1;
+  const bool split = SPLIT_OK && P.split != 0;
+  const int wave_id = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const bool role_a = split && wave_id < 2;   // trial error of the stored ids only
+  const bool role_b = split && wave_id >= 2;  // everything else
+  const int wstride = split ? 128 : 256;
+  const bool sticky = PERSIST && ((long long)(n_items - w_lo) <= (long long)nb * wstride);  // (uniform, the same on every trip of a launch)
+  const bool cached = sticky && (role_a ? a_primed : gen > 0);
   const int sel_new = fused ? (corr_sel ^ 1) : corr_sel;
 
   // Lane-distributed wave accumulator: after every work item the wave reduces the 29 sums of its 64 items with a
@@ -844,7 +861,8 @@ __global__ FVH_COST_BOUNDS void cost_kernel(CostParams P) {
   // (consecutive threads take consecutive items on purpose: spreading a workgroup's items over the cloud made the launch
   // 24 % slower -- the loop is sensitive to how many distinct cache lines a wave touches)
   // The loop bound is wave-uniform (the butterfly needs all 64 lanes); lanes past the end contribute zeros.
-  for (int wbase = w_lo + (int)lb * 256 + (threadIdx.x & 192); wbase < n_items; wbase += (int)nb * 256) {
+  for (int wbase = w_lo + (int)lb * wstride + (split ? ((wave_id & 1) << 6) : (int)(threadIdx.x & 192)); wbase < n_items; wbase += (int)nb * wstride) {
+    if (role_a && !fused) continue;  // (a plain linearisation / an error-only evaluation has no second piece of work: waves 0-1 contribute zeros)
     const int w = wbase + lane;
     ItemAcc<Real> it = {{0, 0, 0, 0, 0, 0}, {0, 0, 0}, 0};
     Real acc_y = 0;  // fused: trial error with the old ids
@@ -899,8 +917,9 @@ __global__ FVH_COST_BOUNDS void cost_kernel(CostParams P) {
     for (int c = 0; c < CH; c++) {
       const bool in = o_begin + c < o_end;
       bo[c] = -1; b[c] = -1; ofp[c] = 0;
-      if (fused) bo[c] = cached ? s_ids[corr_sel][c][st] : (in ? corr_old[(size_t)i * P.n_off + o_begin + c] : -1);
-      if (do_find) {
+      if (fused && !role_b) bo[c] = cached ? s_ids[corr_sel][c][role_a ? st + 128 : st] : (in ? corr_old[(size_t)i * P.n_off + o_begin + c] : -1);
+      if (role_a) {
+      } else if (do_find) {
         if (cached) ofp[c] = s_ofp[c][st];
         else { ofp[c] = P.offsets_packed[min(o_begin + c, o_end - 1)]; if (sticky) s_ofp[c][st] = ofp[c]; }
       } else if (ext_fused) {
@@ -911,7 +930,7 @@ __global__ FVH_COST_BOUNDS void cost_kernel(CostParams P) {
     }
     if (PERSIST) FVH_MT(gen, 1);
     // ---- round trip 2 (fused): issued before the arithmetic below, which does not need it ----
-    if (fused) {  // the records of the stored ids (bucket 0 for "none")
+    if (fused && !role_b) {  // the records of the stored ids (bucket 0 for "none")
 #pragma unroll
       for (int c = 0; c < CH; c++) {
         const size_t base = (size_t)max(bo[c], 0) * 4;
@@ -927,7 +946,7 @@ __global__ FVH_COST_BOUNDS void cost_kernel(CostParams P) {
     {
       const Pose<Real> ev = pose_ptr[1];
       q = transform(ev, a);
-      if (do_find) {
+      if (do_find && !role_a) {
         Vec3<Real> ql = q;
         if (!fused) { const Pose<Real> lin = pose_ptr[0]; ql = transform(lin, a); }
         const Real fx = floor(div_by(ql.x, res, inv_res) - (Real)0.5), fy = floor(div_by(ql.y, res, inv_res) - (Real)0.5), fz = floor(div_by(ql.z, res, inv_res) - (Real)0.5);
@@ -950,7 +969,7 @@ __global__ FVH_COST_BOUNDS void cost_kernel(CostParams P) {
       Real Rl[9];
 #pragma unroll
       for (int k = 0; k < 9; k++) Rl[k] = lin.r[k];
-      if (fused) RCR_old = rotate_cov(Rl, CA); else RCR = rotate_cov(Rl, CA);
+      if (fused) { if (!role_b) RCR_old = rotate_cov(Rl, CA); } else RCR = rotate_cov(Rl, CA);
     }
     if (PERSIST) FVH_MT(gen, 2);
     {
@@ -961,7 +980,7 @@ __global__ FVH_COST_BOUNDS void cost_kernel(CostParams P) {
       Q3 sq3 = {};
       constexpr unsigned long long DEAD_KEY = FVH_EMPTY_KEY - 1;  // no voxel has it (keys use 63 bits): "this lookup does not exist" without a flag register
       // ---- round trip 3: CH independent first probes in flight ----
-      if (do_find) {
+      if (do_find && !role_a) {
         bool live[CH];
 #pragma unroll
         for (int c = 0; c < CH; c++) {
@@ -1009,7 +1028,7 @@ __global__ FVH_COST_BOUNDS void cost_kernel(CostParams P) {
       }
       if (PERSIST) FVH_MT(gen, 3);
       // ---- fused trip: trial error with the OLD ids while the probes are in flight ----
-      if (fused && do_cost) {
+      if (fused && do_cost && !role_b) {
 #pragma unroll
         for (int c = 0; c < CH; c++) {
           if (bo[c] < 0) continue;
@@ -1036,7 +1055,7 @@ __global__ FVH_COST_BOUNDS void cost_kernel(CostParams P) {
         }
       }
       if (PERSIST) FVH_MT(gen, 4);
-      if (do_find) {
+      if (do_find && !role_a) {
 #pragma unroll
         for (int c = 0; c < CH; c++) {
           const unsigned long long k = k0[c];
@@ -1048,7 +1067,7 @@ __global__ FVH_COST_BOUNDS void cost_kernel(CostParams P) {
           if (sticky) s_ids[sel_new][c][st] = (o_begin + c < o_end) ? r : -1;
         }
       }
-      if (do_cost) {
+      if (do_cost && !role_a) {
       if (PERSIST) FVH_MT(gen, 5);
       // ---- round trip 4: the voxel records of the ids of this evaluation (bucket 0 for misses). Fused trip: near convergence
       // the new id of a slot IS its old id -- then the record is already in registers; only slots whose voxel changed load.
@@ -1104,6 +1123,13 @@ __global__ FVH_COST_BOUNDS void cost_kernel(CostParams P) {
     if (PERSIST && P.prio_mode) __builtin_amdgcn_s_setprio(0);
     if (!do_cost) continue;  // host-mode PH_FIND_ONLY
     if (PERSIST) FVH_MT(gen, 7);
+    if (role_a) {  // one number per item: the wave's total goes where the butterfly would have left slot 28 (lanes 56, 57)
+      double tot = (double)acc_y;
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) tot += __shfl_xor(tot, off);
+      if ((lane >> 1) == NSUM) wacc += tot;
+      continue;
+    }
 
     // ---- per-item wave reduction: transposing butterfly over 32 slots (28 sums, the fused trial error, 3 zeros) ----
     // Step m = 32, 16, 8, 4, 2: the lane pair (L, L ^ m) splits its current slots in halves, each lane keeps one half and
@@ -1149,6 +1175,7 @@ __global__ FVH_COST_BOUNDS void cost_kernel(CostParams P) {
     if (PERSIST) FVH_MT(gen, 8);
   }
 
+  if (role_a && fused) a_primed = true;  // (their sticky slots are filled now)
   // ---- workgroup reduction: 4 waves x 32 slots through 1 KB of LDS ----------------------------------------
   if (!do_cost) return;  // host-mode PH_FIND_ONLY (never persistent)
   // Everything from here to the end of the trip is written in terms of `tid`, an OPAQUE copy of threadIdx.x made per trip:
