@@ -38,7 +38,8 @@ def test_two_rank_bench_prints_one_aggregate_line():
     assert d["value"] == c["value"]
     assert d["n1_same_workload"]["value"] > 0 and d["n1_same_workload"]["converged"]
     assert d["per_registration"]["converged"] and d["per_registration"]["pose_equals_single_gpu"], d["per_registration"]
-    assert abs(d["speedup_vs_one_gpu"] - d["value"] / d["n1_same_workload"]["value"]) <= 2e-3 * d["speedup_vs_one_gpu"]
+    # (both are rounded to three decimals; two processes sharing ONE GPU can be arbitrarily slow: absolute + relative tolerance)
+    assert abs(d["speedup_vs_one_gpu"] - d["value"] / d["n1_same_workload"]["value"]) <= 1e-3 + 2e-3 * d["speedup_vs_one_gpu"]
     rep = d["replicas_17k"]  # the N = 1 headline, replicated: whole-job aggregate = ranks x steps / max time
     assert rep["scaling"] == "weak" and rep["value"] > 0 and abs(rep["value"] - 2 * 1e3 / rep["ms_per_step"]) <= 1e-3 * rep["value"]
     assert abs(rep["fitness_score"] - 0.198792) < 1e-5
