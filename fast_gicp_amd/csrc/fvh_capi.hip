@@ -602,9 +602,16 @@ int upload_cloud(Engine* e, CloudDev& c, const float* xyz, int n, int stride, bo
     c.box_dirty = true;
     boxp = c.box.as<unsigned>();
   }
-  if (on_device) {
-    pack_points_kernel<<<pack_grid(n, boxp != nullptr), 256, 0, st>>>(xyz, n, stride, c.pts.as<float4>(), boxp);
+  // widen `srcp` to float4 (+ bounding cube); `slot`: the pinned upload slot that kernel reads (its "free again" event follows it)
+  auto pack = [&](const float* srcp, int slot) -> int {
+    pack_points_kernel<<<pack_grid(n, boxp != nullptr), 256, 0, st>>>(srcp, n, stride, c.pts.as<float4>(), boxp);
     HIP_OR_FAIL(e, hipGetLastError());
+    if (slot >= 0) { HIP_OR_FAIL(e, hipEventRecord(e->upload_done[slot], st)); e->upload_busy[slot] = true; }
+    return FVH_OK;
+  };
+  if (on_device) {
+    int rc = pack(xyz, -1);
+    if (rc) return rc;
   } else {
     // H2D the xyz (stride 3) / xyzi (stride 4, e.g. a KITTI .bin buffer) array into a staging buffer, then widen to float4 on device
     const size_t bytes = sizeof(float) * stride * (size_t)n;
@@ -624,17 +631,15 @@ int upload_cloud(Engine* e, CloudDev& c, const float* xyz, int n, int stride, bo
       static const size_t zero_copy_max = [] { const char* v = getenv("FVH_ZEROCOPY_UPLOAD_MAX"); return v ? (size_t)atoll(v) : (size_t)(1u << 20); }();
       void* pinned_dev = nullptr;
       if (bytes <= zero_copy_max && hipHostGetDevicePointer(&pinned_dev, slot, 0) == hipSuccess && pinned_dev) {
-        pack_points_kernel<<<pack_grid(n, boxp != nullptr), 256, 0, st>>>(static_cast<const float*>(pinned_dev), n, stride, c.pts.as<float4>(), boxp);
-        HIP_OR_FAIL(e, hipGetLastError());
-        HIP_OR_FAIL(e, hipEventRecord(e->upload_done[us], st));
-        e->upload_busy[us] = true;
+        int rc = pack(static_cast<const float*>(pinned_dev), us);
+        if (rc) return rc;
       } else {
         (void)hipGetLastError();
         HIP_OR_FAIL(e, hipMemcpyAsync(e->staging.p, slot, bytes, hipMemcpyHostToDevice, st));
         HIP_OR_FAIL(e, hipEventRecord(e->upload_done[us], st));
         e->upload_busy[us] = true;
-        pack_points_kernel<<<pack_grid(n, boxp != nullptr), 256, 0, st>>>(e->staging.as<float>(), n, stride, c.pts.as<float4>(), boxp);
-        HIP_OR_FAIL(e, hipGetLastError());
+        int rc = pack(e->staging.as<float>(), -1);
+        if (rc) return rc;
       }
     } else {
       HIP_OR_FAIL(e, hipMemcpyAsync(e->staging.p, xyz, bytes, hipMemcpyHostToDevice, st));
@@ -691,17 +696,18 @@ int ensure_sorted(Engine* e, CloudDev& c) {
       SortCoopState* cs = e->sort_coop.as<SortCoopState>();
       char* base = reinterpret_cast<char*>(cs);
       unsigned* chist = reinterpret_cast<unsigned*>(cs + 1);
-      // once: tags of no launch everywhere (afterwards the finish kernel leaves the state zeroed and every launch rewrites the tagged words)
+      // once: tags of no launch everywhere (afterwards every launch rewrites the tagged words, and the state words are compared with the launch's number)
       if (fresh) HIP_OR_FAIL(e, hipMemsetAsync(cs, 0, COOP_STATE_BYTES, e->stream));
       if ((++e->sort_seq & (COOP_HTAG_MASK >> 1)) == 0) ++e->sort_seq;  // (a histogram tag of 0 is what fresh memory holds)
       unsigned long long wd = 2'000'000ull;  // 20 ms
       { const char* v = getenv("FVH_SORT_COOP_WATCHDOG_TICKS"); if (v) wd = strtoull(v, nullptr, 10); }  // test hook: 0 forces the fallback
-      sort_coop_kernel<<<COOP_WGS, COOP_THREADS, 0, e->stream>>>(c.pts.as<float4>(), n, c.order.as<int>(), c.sorted.as<float4>(), c.bbox.as<float4>(), c.box.as<unsigned>(), chist,
-                                                                 reinterpret_cast<unsigned long long*>(base + COOP_ELEM_OFFSET), reinterpret_cast<unsigned long long*>(base + COOP_FIN_OFFSET), cs,
-                                                                 e->sort_seq, wd);
-      // normally the super boxes only; when the cooperative kernel did not finish, one workgroup redoes everything
-      sort_coop_finish_kernel<<<1, 1024, 0, e->stream>>>(c.pts.as<float4>(), n, e->sort_keys.as<unsigned>(), c.order.as<int>(), e->sort_keys.as<unsigned>() + n, e->sort_idx.as<int>(),
-                                                         c.sorted.as<float4>(), c.bbox.as<float4>(), c.bbox2.as<float4>(), cs, c.box.as<unsigned>());
+      unsigned long long* celem = reinterpret_cast<unsigned long long*>(base + COOP_ELEM_OFFSET);
+      sort_coop_kernel<<<COOP_WGS, COOP_THREADS, 0, e->stream>>>(c.pts.as<float4>(), n, c.order.as<int>(), c.sorted.as<float4>(), c.box.as<unsigned>(), chist, celem, cs, e->sort_seq, wd);
+      // tile boxes (one tile per wave) + super boxes (one workgroup each); when the cooperative kernel did not finish, workgroup 0 redoes everything
+      const int fin_tile_wgs = (ntiles + 15) / 16;
+      sort_coop_finish_kernel<<<fin_tile_wgs + nsuper_small, 1024, 0, e->stream>>>(c.pts.as<float4>(), n, e->sort_keys.as<unsigned>(), c.order.as<int>(), e->sort_keys.as<unsigned>() + n,
+                                                                                   e->sort_idx.as<int>(), c.sorted.as<float4>(), c.bbox.as<float4>(), c.bbox2.as<float4>(), cs, c.box.as<unsigned>(),
+                                                                                   e->sort_seq, fin_tile_wgs);
       c.box_dirty = false;  // consumed and cleared by the finish kernel
     } else {
       sort_small_kernel<<<1, 1024, 0, e->stream>>>(c.pts.as<float4>(), n, e->sort_keys.as<unsigned>(), c.order.as<int>(), e->sort_keys.as<unsigned>() + n, e->sort_idx.as<int>());
@@ -2460,6 +2466,9 @@ int fvh_debug_pair_counts(unsigned long long* out8, int reset) {  // candidate p
   return FVH_OK;
 }
 int fvh_debug_knn_timing(unsigned long long* out) { return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_knn_time), sizeof(unsigned long long) * 32768 * 8) == hipSuccess ? FVH_OK : FVH_ERR_HIP; }
+#endif
+#ifdef FVH_SORT_TIMING
+int fvh_debug_sort_timing(unsigned long long* out /* [COOP_WGS][16] */) { return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_sort_time), sizeof(unsigned long long) * COOP_WGS * 16) == hipSuccess ? FVH_OK : FVH_ERR_HIP; }
 #endif
 #ifdef FVH_COST_TIMING
 // debug build only (not declared in the public header): out[0] = earliest workgroup start, out[1..7] = epilogue stamps of the last workgroup, 100 MHz ticks

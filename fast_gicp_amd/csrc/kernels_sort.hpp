@@ -9,6 +9,7 @@
 // contiguous range 64 items at a time; same-digit lanes find each other with 9 ballots, the lowest
 // lane of a digit group advances the wave's cursor, rank = popcount of lower peers -> stable).
 #pragma once
+#include <cstddef>
 #include "dev_math.hpp"
 
 namespace fvh {
@@ -617,23 +618,26 @@ __global__ __launch_bounds__(1024) void sort_small_kernel(const float4* __restri
 // ------------------------------------------------------------------------------------------------
 // Small clouds, cooperative version: the same 18-bit Morton order as sort_small_kernel (identical output), but on
 // COOP_WGS co-resident workgroups instead of one workgroup doing everything (62 us at 17k points on one CU, + 10 us for the
-// tile / super boxes). Phases: keys + digit-0 histograms | scatter 0 | digit-1 histograms | scatter 1 + gather | tile boxes
-// (bounding cube: pack_points_kernel before; super boxes: the finish kernel after). What one phase hands to the next crosses
-// workgroups through tagged words the consumer polls (see sort_coop_kernel) -- no grid barrier.
+// tile / super boxes). Phases: keys + digit-0 histograms | scatter 0 | digit-1 histograms | scatter 1 + gather (bounding cube:
+// pack_points_kernel before; tile and super boxes: sort_coop_finish_kernel after -- a kernel boundary costs what a hand-off costs, ~3 us,
+// and that kernel exists anyway: it is the fallback). What one phase hands to the next crosses workgroups through tagged words the
+// consumer polls (see sort_coop_kernel) -- no grid barrier. (Round 5 also built the widening of the caller's array + the bounding cube
+// INTO this kernel, for one more hand-off: 22.4 us against pack 4.8 + sort 19.4, and the registration rate did not move. Not kept.)
 // Each wave owns a contiguous chunk of <= 128 keys (2 steps of 64), so stable order = (workgroup, wave, step, lane).
 // The per-pass scan is done redundantly by every workgroup from the 512 x COOP_WGS matrix of workgroup totals.
-// A poll that never succeeds (workgroups not co-resident) trips a watchdog: fewer than COOP_WGS workgroups finish and
+// A poll that never succeeds (workgroups not co-resident) trips a watchdog: not every workgroup reports "done" and
 // sort_coop_finish_kernel, launched right behind, does the whole job on one workgroup instead.
 // ------------------------------------------------------------------------------------------------
 constexpr int COOP_WGS = 32, COOP_THREADS = 512, COOP_WAVES = COOP_THREADS / 64, COOP_STEPS = 2;
 static_assert(COOP_WGS * COOP_WAVES * COOP_STEPS * 64 >= SORT_SMALL_MAX, "every key needs a slot");
 static_assert(COOP_THREADS == SMALL_BINS, "one thread per bin in the scans");
+static_assert(COOP_THREADS == COOP_WGS * 16 && SMALL_BINS == 16 * 32, "a thread polls 32 consecutive words of one row of the matrix");
 
-struct SortCoopState {     // zeroed by the host before the first launch, by sort_coop_finish_kernel after every launch
-  unsigned arrivals;        // (unused since the hand-offs carry tags)
-  unsigned abort;
-  unsigned finished;        // workgroups that ran to the end; COOP_WGS = the cooperative kernel did the whole job
-  unsigned pad[13];
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+struct SortCoopState {     // zeroed once, when allocated. Every word is compared with the launch's sequence number (>= 1): nothing is ever reset
+  unsigned abort_seq;              // == seq: a workgroup of launch `seq` gave up (watchdog, or the test hook)
+  unsigned pad[15];
+  unsigned done_seq[COOP_WGS];     // [w] == seq: workgroup w of launch `seq` ran to the end; all of them = the cooperative kernel did the whole job
 };
 
 template <typename T> __device__ __forceinline__ void st_agent(T* p, T v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }  // write-through (sc1)
@@ -645,58 +649,94 @@ template <typename T> __device__ __forceinline__ T ld_agent(const T* p) { return
 // until their tags are current; nobody waits for anybody else: no arrival counter, no "wait for my stores, add 1, poll the
 // counter" (four grid barriers of ~3 us each in the first version of this kernel). Buffers are zeroed
 // when allocated, sequence numbers start at 1 and every complete launch rewrites every word it will poll next time.
-// A failed poll is the expensive case -- 16k lanes re-reading 2 MB past the caches while the stores they wait for are still on
-// their way: polling at once made the registration 9 us SLOWER than the barriers (4,145 -> 3,995 reg/s); a first look after
-// ~0.9 us (s_sleep 32) and then every ~0.2 us makes it 5 us faster (4,190 -> 4,265; 16 / 32 / 48 measure the same).
+// What a hand-off costs (round 5, tools/sort_timing.py + rocprofv3 A/B, tools/ab_sort.sh): an sc1 load past the caches is ~1 us for one
+// word per lane and ~2 us for the 64 KB of a pass's histogram matrix per workgroup; a store is visible ~1 us after it was issued. Two things
+// were slower than that and are gone: (a) the matrix as [bin][workgroup] -- a workgroup published 512 scattered 4-byte words -- read by 32
+// separate agent-scope loads per thread, ten of which the compiler serialised behind their own s_waitcnt (now [workgroup][bin]: 2 KB of whole
+// lines per workgroup, read as eight 16-byte loads behind ONE wait and transposed through LDS); (b) a failed poll that consulted the watchdog
+// -- a clock read and another load past the caches -- before every retry (now every 16th). 27.5 -> 22.2 us at 17k points. With cheap
+// retries the delay before the first look no longer matters (0.1 ... 0.9 us measure the same; polling with no delay at all costs 3 us).
 #ifndef FVH_COOP_POLL_SLEEP
 #define FVH_COOP_POLL_SLEEP 8
 #endif
 #ifndef FVH_COOP_FIRST_SLEEP
-#define FVH_COOP_FIRST_SLEEP 32
+#define FVH_COOP_FIRST_SLEEP 8
 #endif
 constexpr int COOP_MATRIX_WORDS = 2 * SMALL_BINS * COOP_WGS;                                    // u32 {count, tag}
 constexpr int COOP_HTAG_BITS = 21;
 constexpr unsigned COOP_HTAG_MASK = (1u << COOP_HTAG_BITS) - 1u;
 static_assert(COOP_THREADS * COOP_STEPS < (1 << (32 - COOP_HTAG_BITS)), "a workgroup's count of one bin must fit the bits above the tag");
 constexpr size_t COOP_ELEM_OFFSET = sizeof(SortCoopState) + sizeof(unsigned) * COOP_MATRIX_WORDS;  // u64 x SORT_SMALL_MAX: pass-0 output
-constexpr size_t COOP_FIN_OFFSET = COOP_ELEM_OFFSET + sizeof(unsigned long long) * SORT_SMALL_MAX;  // u64 x SORT_SMALL_MAX: final order
-constexpr size_t COOP_STATE_BYTES = COOP_FIN_OFFSET + sizeof(unsigned long long) * SORT_SMALL_MAX;
+constexpr size_t COOP_STATE_BYTES = COOP_ELEM_OFFSET + sizeof(unsigned long long) * SORT_SMALL_MAX;
+static_assert(sizeof(SortCoopState) % 16 == 0, "the matrix behind it is read in 16-byte words");
 static_assert(SORT_SMALL_MAX <= (1 << 15) && SMALL_BITS * SMALL_PASSES <= 18, "element packing: 15 index bits, 18 key bits");
 
-__device__ __forceinline__ bool coop_timed_out(SortCoopState* st, unsigned long long t0, unsigned long long watchdog_ticks) {
-  if (__hip_atomic_load(&st->abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) || wall_clock64() - t0 > watchdog_ticks) {
-    __hip_atomic_store(&st->abort, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+// eight 16-byte agent-scope loads of 128 consecutive bytes in flight together, one wait (loads and wait in one asm block: nothing touches a
+// destination register before its data has landed)
+__device__ __forceinline__ void load8x16_agent(u32x4 (&v)[8], const u32x4* p) {
+  asm volatile(
+      "global_load_dwordx4 %0, %8, off sc1\n\t"
+      "global_load_dwordx4 %1, %8, off offset:16 sc1\n\t"
+      "global_load_dwordx4 %2, %8, off offset:32 sc1\n\t"
+      "global_load_dwordx4 %3, %8, off offset:48 sc1\n\t"
+      "global_load_dwordx4 %4, %8, off offset:64 sc1\n\t"
+      "global_load_dwordx4 %5, %8, off offset:80 sc1\n\t"
+      "global_load_dwordx4 %6, %8, off offset:96 sc1\n\t"
+      "global_load_dwordx4 %7, %8, off offset:112 sc1\n\t"
+      "s_waitcnt vmcnt(0)"
+      : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]), "=&v"(v[4]), "=&v"(v[5]), "=&v"(v[6]), "=&v"(v[7])
+      : "v"(p)
+      : "memory");
+}
+
+__device__ __forceinline__ bool coop_timed_out(SortCoopState* st, unsigned seq, unsigned long long t0, unsigned long long watchdog_ticks) {
+  if (__hip_atomic_load(&st->abort_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == seq || wall_clock64() - t0 > watchdog_ticks) {
+    __hip_atomic_store(&st->abort_seq, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     return true;
   }
   return false;
 }
+#ifdef FVH_SORT_TIMING  // debug build only (tools/sort_timing.py): 100 MHz wall-clock stamps of every workgroup's walk through the phases
+__device__ unsigned long long g_sort_time[COOP_WGS][16];
+#define FVH_ST(k) do { if (threadIdx.x == 0) g_sort_time[wg][k] = wall_clock64(); } while (0)
+#else
+#define FVH_ST(k) do { } while (0)
+#endif
 
-__global__ __launch_bounds__(COOP_THREADS) void sort_coop_kernel(const float4* __restrict__ pts, int n, int* order, float4* sorted, float4* bbox1,
-                                                                const unsigned* __restrict__ box /* {~ordered(min) x3, ordered(max) x3} */, unsigned* hist /* [2][SMALL_BINS][COOP_WGS] */,
-                                                                unsigned long long* elem, unsigned long long* fin, SortCoopState* st, unsigned seq, unsigned long long watchdog_ticks) {
+__global__ __launch_bounds__(COOP_THREADS) void sort_coop_kernel(const float4* __restrict__ pts, int n, int* order, float4* sorted,
+                                                                const unsigned* __restrict__ box /* {~ordered(min) x3, ordered(max) x3} */, unsigned* hist /* [2][COOP_WGS][SMALL_BINS] */,
+                                                                unsigned long long* elem, SortCoopState* st, unsigned seq, unsigned long long watchdog_ticks) {
   __shared__ unsigned wh[COOP_WAVES][SMALL_BINS];  // per-wave digit counts -> exclusive prefix over the waves of this workgroup -> scatter cursors
   __shared__ unsigned wsum[COOP_WAVES];
-  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, wg = blockIdx.x;
+  __shared__ unsigned short s_cnt[COOP_WGS][SMALL_BINS];  // the pass's matrix of workgroup totals (counts <= 1,024), on its way from "thread = 32 words of a row" to "thread = bin"
+  const int wg = blockIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int gw = wg * COOP_WAVES + wv;  // global wave index
   const int chunk = ((((n + COOP_WGS * COOP_WAVES - 1) / (COOP_WGS * COOP_WAVES)) + 63) & ~63);
   const int begin = gw * chunk, end = min(n, begin + chunk);
   const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
   const unsigned long long t_start = wall_clock64();
   const unsigned long long etag = (unsigned long long)(seq & 0x7fffffffu);
+  unsigned spins = 0;  // failed polls: the watchdog (a clock read + a load past the caches) is consulted every 16th
+  FVH_ST(0);
   if (watchdog_ticks == 0) {  // test hook: the fallback does the whole job
-    if (tid == 0) __hip_atomic_store(&st->abort, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (tid == 0) __hip_atomic_store(&st->abort_seq, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     return;
   }
 
-  // ---- keys (the arithmetic of sort_small_kernel); the bounding cube was reduced by pack_points_kernel when the cloud was set ----
   float4 p[COOP_STEPS];
 #pragma unroll
   for (int u = 0; u < COOP_STEPS; u++) {
     const int i = begin + u * 64 + lane;
     p[u] = (i < end) ? pts[i] : make_float4(0, 0, 0, 0);
   }
-  const float lx = ordered_to_float(~box[0]), ly = ordered_to_float(~box[1]), lz = ordered_to_float(~box[2]);
-  const float hx = ordered_to_float(box[3]), hy = ordered_to_float(box[4]), hz = ordered_to_float(box[5]);
+  unsigned bx[6];
+#pragma unroll
+  for (int a = 0; a < 6; a++) bx[a] = box[a];  // (the bounding cube was reduced by pack_points_kernel when the cloud was set)
+
+  // ---- keys (the arithmetic of sort_small_kernel) ----
+  const float lx = ordered_to_float(~bx[0]), ly = ordered_to_float(~bx[1]), lz = ordered_to_float(~bx[2]);
+  const float hx = ordered_to_float(bx[3]), hy = ordered_to_float(bx[4]), hz = ordered_to_float(bx[5]);
   const float extent = fmaxf(fmaxf(hx - lx, hy - ly), fmaxf(hz - lz, 1e-6f));
   const float qmax = (float)((1 << SMALL_AXIS_BITS) - 1);
   const float scale = (qmax + 0.999f) / extent;
@@ -712,6 +752,7 @@ __global__ __launch_bounds__(COOP_THREADS) void sort_coop_kernel(const float4* _
     id[u] = (i < end) ? i : -1;
   }
 
+  FVH_ST(1);  // keys computed
   for (int pass = 0; pass < SMALL_PASSES; pass++) {
     const int shift = pass * SMALL_BITS;
     unsigned* gh = hist + (size_t)pass * SMALL_BINS * COOP_WGS;
@@ -729,7 +770,7 @@ __global__ __launch_bounds__(COOP_THREADS) void sort_coop_kernel(const float4* _
           while (true) {
             v = ld_agent(&elem[i]);
             if ((v >> 33) == etag) break;
-            if (coop_timed_out(st, t_start, watchdog_ticks)) { failed = 1; break; }
+            if ((++spins & 15u) == 0u && coop_timed_out(st, seq, t_start, watchdog_ticks)) { failed = 1; break; }
             __builtin_amdgcn_s_sleep(FVH_COOP_POLL_SLEEP);
           }
         }
@@ -737,6 +778,7 @@ __global__ __launch_bounds__(COOP_THREADS) void sort_coop_kernel(const float4* _
         id[u] = (i < end) ? (int)(v & 0x7FFFu) : -1;
       }
     }
+    FVH_ST(2 + 5 * pass);  // (pass 1: this workgroup's elements of pass 0 have landed)
     // per-wave digit histogram
     for (int b = lane; b < SMALL_BINS; b += 64) wh[wv][b] = 0;
 #pragma unroll
@@ -747,28 +789,42 @@ __global__ __launch_bounds__(COOP_THREADS) void sort_coop_kernel(const float4* _
       unsigned run = 0;
 #pragma unroll
       for (int w = 0; w < COOP_WAVES; w++) { const unsigned c = wh[w][tid]; wh[w][tid] = run; run += c; }
-      st_agent(&gh[(size_t)tid * COOP_WGS + wg], (run << COOP_HTAG_BITS) | htag);
+      st_agent(&gh[(size_t)wg * SMALL_BINS + tid], (run << COOP_HTAG_BITS) | htag);  // [workgroup][bin]: a workgroup publishes 2 KB of whole lines
     }
+    FVH_ST(3 + 5 * pass);  // workgroup totals published
     {  // thread = bin: total over all workgroups and the part before this workgroup (polled until all 32 entries are current); then the bins are scanned
-      const unsigned long long* row = reinterpret_cast<const unsigned long long*>(gh + (size_t)tid * COOP_WGS);
-      unsigned long long v[COOP_WGS / 2];
+      // The matrix is [workgroup][bin]: thread t takes 32 consecutive words of row t / 16 -- eight 16-byte loads in flight together, ONE wait
+      // (32 separate agent-scope loads were compiled into 22 batched + 10 serialised round trips: 3.5 of this kernel's 26 us per pass) --
+      // checks their tags, and the counts cross to "thread = bin" through LDS.
+      const u32x4* src = reinterpret_cast<const u32x4*>(gh + (size_t)(tid >> 4) * SMALL_BINS + (size_t)(tid & 15) * 32);
+      u32x4 q[8];
       if (FVH_COOP_FIRST_SLEEP) __builtin_amdgcn_s_sleep(FVH_COOP_FIRST_SLEEP);
       while (true) {
-#pragma unroll
-        for (int j = 0; j < COOP_WGS / 2; j++) v[j] = ld_agent(&row[j]);  // independent loads, one round trip
+        load8x16_agent(q, src);
         unsigned bad = 0;
 #pragma unroll
-        for (int j = 0; j < COOP_WGS / 2; j++) bad |= (((unsigned)v[j] & COOP_HTAG_MASK) ^ htag) | (((unsigned)(v[j] >> 32) & COOP_HTAG_MASK) ^ htag);
+        for (int j = 0; j < 8; j++) bad |= ((q[j].x & COOP_HTAG_MASK) ^ htag) | ((q[j].y & COOP_HTAG_MASK) ^ htag) | ((q[j].z & COOP_HTAG_MASK) ^ htag) | ((q[j].w & COOP_HTAG_MASK) ^ htag);
         if (!bad) break;
-        if (coop_timed_out(st, t_start, watchdog_ticks)) { failed = 1; break; }
+        if ((++spins & 15u) == 0u && coop_timed_out(st, seq, t_start, watchdog_ticks)) { failed = 1; break; }
         __builtin_amdgcn_s_sleep(FVH_COOP_POLL_SLEEP);
       }
+      FVH_ST(4 + 5 * pass);  // this thread's part of the matrix is current
+      {
+        uint2* dst = reinterpret_cast<uint2*>(&s_cnt[tid >> 4][(tid & 15) * 32]);
+#pragma unroll
+        for (int j = 0; j < 8; j++)
+          dst[j] = make_uint2((q[j].x >> COOP_HTAG_BITS) | ((q[j].y >> COOP_HTAG_BITS) << 16), (q[j].z >> COOP_HTAG_BITS) | ((q[j].w >> COOP_HTAG_BITS) << 16));
+      }
+      if (__syncthreads_or(failed)) return;
+#ifdef FVH_SORT_TIMING
+      if (pass == 0) { FVH_ST(14); if (threadIdx.x == 0) g_sort_time[wg][15] = spins; }
+#endif
       unsigned total = 0, before = 0;
 #pragma unroll
-      for (int j = 0; j < COOP_WGS / 2; j++) {
-        const unsigned a = (unsigned)v[j] >> COOP_HTAG_BITS, b = (unsigned)(v[j] >> (32 + COOP_HTAG_BITS));
-        total += a + b;
-        before += ((2 * j < wg) ? a : 0u) + ((2 * j + 1 < wg) ? b : 0u);
+      for (int j = 0; j < COOP_WGS; j++) {
+        const unsigned a = s_cnt[j][tid];
+        total += a;
+        before += (j < wg) ? a : 0u;
       }
       unsigned x = total;
 #pragma unroll
@@ -781,6 +837,7 @@ __global__ __launch_bounds__(COOP_THREADS) void sort_coop_kernel(const float4* _
       for (int w = 0; w < COOP_WAVES; w++) wh[w][tid] += base;  // scatter cursor of wave w for this bin
     }
     __syncthreads();
+    FVH_ST(5 + 5 * pass);  // scatter cursors ready
     const bool last = (pass == SMALL_PASSES - 1);
 #pragma unroll
     for (int u = 0; u < COOP_STEPS; u++) {
@@ -807,7 +864,6 @@ __global__ __launch_bounds__(COOP_THREADS) void sort_coop_kernel(const float4* _
         if (!last) {
           st_agent(&elem[dst], (etag << 33) | ((unsigned long long)key[u] << 15) | (unsigned long long)(unsigned)id[u]);
         } else {
-          st_agent(&fin[dst], ((unsigned long long)seq << 32) | (unsigned long long)(unsigned)id[u]);
           order[dst] = id[u];
           float4 q = pts[id[u]];
           q.w = __int_as_float(id[u]);
@@ -815,75 +871,85 @@ __global__ __launch_bounds__(COOP_THREADS) void sort_coop_kernel(const float4* _
         }
       }
     }
+    FVH_ST(6 + 5 * pass);  // scatter issued
   }
 
-  // ---- boxes of the 64-point tiles (the boxes of 64 tiles are left to sort_coop_finish_kernel: a kernel boundary is the cheapest barrier) ----
-  const int ntiles = (n + 63) >> 6;
-  int failed = 0;
-  if (FVH_COOP_FIRST_SLEEP) __builtin_amdgcn_s_sleep(FVH_COOP_FIRST_SLEEP);
-  for (int t = gw; t < ntiles && !failed; t += COOP_WGS * COOP_WAVES) {
-    const int j = min(t * 64 + lane, n - 1);
-    unsigned long long v;
-    while (true) {
-      v = ld_agent(&fin[j]);
-      if (!__ballot((unsigned)(v >> 32) != seq)) break;  // (wave-uniform: all 64 entries of the tile)
-      if (coop_timed_out(st, t_start, watchdog_ticks)) { failed = 1; break; }
-      __builtin_amdgcn_s_sleep(FVH_COOP_POLL_SLEEP);
-    }
-    failed = __ballot(failed) != 0;
-    if (failed) break;
-    const float4 q = pts[(int)(unsigned)v];
-    float l3[3] = {q.x, q.y, q.z}, h3[3] = {q.x, q.y, q.z};
-#pragma unroll
-    for (int a = 0; a < 3; a++)
-#pragma unroll
-      for (int off = 32; off > 0; off >>= 1) {
-        l3[a] = fminf(l3[a], __shfl_xor(l3[a], off));
-        h3[a] = fmaxf(h3[a], __shfl_xor(h3[a], off));
-      }
-    if (lane < 8) {  // 2 x float4 = 8 floats, one store per lane
-      const float v8[8] = {l3[0], l3[1], l3[2], 0.f, h3[0], h3[1], h3[2], 0.f};
-      float out = v8[0];
-#pragma unroll
-      for (int c = 1; c < 8; c++) out = (lane == c) ? v8[c] : out;
-      reinterpret_cast<float*>(bbox1 + 2 * t)[lane] = out;
-    }
-  }
-  if (__syncthreads_or(failed)) return;
-  if (tid == 0) atomicAdd(&st->finished, 1u);
+  __syncthreads();
+  FVH_ST(13);
+  if (tid == 0) st->done_seq[wg] = seq;  // (read by the finish kernel, behind the kernel boundary)
 }
 
-// Runs right behind sort_coop_kernel on one workgroup: normally just the <= 8 super boxes; when the cooperative kernel
-// did not finish (barrier watchdog), the whole job: same order, sorted copy and both box levels.
+// Runs right behind sort_coop_kernel: the boxes of the 64-point tiles from the sorted copy (coalesced; inside the cooperative kernel they cost
+// one more hand-off) by the first `tile_wgs` workgroups, one tile per wave, and the super boxes (64 tiles = 4,096 points) straight from the
+// points by one workgroup each -- min / max are exact, so "from the points" equals "from the tile boxes", and no workgroup waits for another.
+// (One workgroup per super tile doing its 64 tiles took 8.6 us: 144 dependent wave shuffles per wave through ONE CU's LDS crossbar.)
+// When the cooperative kernel did not finish (watchdog), workgroup 0 does the whole job: same order, sorted copy and both box levels.
 __global__ __launch_bounds__(1024) void sort_coop_finish_kernel(const float4* __restrict__ pts, int n, unsigned* keysA, int* order, unsigned* keysB, int* idxB, float4* sorted,
-                                                                float4* bbox1, float4* bbox2, SortCoopState* st, unsigned* box) {
-  const bool redo = (st->finished != COOP_WGS) || (st->abort != 0);
+                                                                float4* bbox1, float4* bbox2, const SortCoopState* __restrict__ st, unsigned* box, unsigned seq, int tile_wgs) {
+  __shared__ int s_redo;
+  __shared__ float s_wl[16][3], s_wh[16][3];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  if (wv == 0) {  // (every workgroup reads the same words; nobody writes them here)
+    const bool bad = lane < COOP_WGS && st->done_seq[lane] != seq;
+    const unsigned long long any = __ballot(bad);
+    if (lane == 0) s_redo = (any != 0ull || st->abort_seq == seq) ? 1 : 0;
+  }
   __syncthreads();
-  // leave the barrier state and the cloud's bounding cube cleared for the next cloud (saves two memsets on the stream)
-  if (threadIdx.x < 3) reinterpret_cast<unsigned*>(st)[threadIdx.x] = 0u;
-  if (threadIdx.x >= 64 && threadIdx.x < 70) box[threadIdx.x - 64] = 0u;
-  if (redo) {
+  // the cloud's bounding-cube accumulators (pack_points_kernel's atomics) cleared for the next cloud: saves a memset on the stream
+  if (blockIdx.x == 0 && threadIdx.x >= 64 && threadIdx.x < 70) box[threadIdx.x - 64] = 0u;
+  if (s_redo) {
+    if (blockIdx.x != 0) return;
     sort_small_impl(pts, n, keysA, order, keysB, idxB);
     sort_small_tail(pts, order, n, sorted, bbox1, bbox2);
     return;
   }
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  const int ntiles = (n + 63) >> 6, nsuper = (ntiles + 63) >> 6;
-  for (int s2 = wv; s2 < nsuper; s2 += 16) {
-    const int t = min(s2 * 64 + lane, ntiles - 1);
-    const float4 l = bbox1[2 * t], h = bbox1[2 * t + 1];
-    float l3[3] = {l.x, l.y, l.z}, h3[3] = {h.x, h.y, h.z};
+  const int ntiles = (n + 63) >> 6;
+  const bool super = (int)blockIdx.x >= tile_wgs;
+  float l3[3], h3[3];
+  if (!super) {  // one tile per wave
+    const int t = blockIdx.x * 16 + wv;
+    if (t >= ntiles) return;  // (wave-uniform; no barrier below on this side)
+    const float4 q = sorted[min(t * 64 + lane, n - 1)];
+    l3[0] = h3[0] = q.x; l3[1] = h3[1] = q.y; l3[2] = h3[2] = q.z;
+  } else {       // 4,096 points per workgroup, four per thread (positions past the end repeat the last point, as the tiles past the end repeat the last tile)
+    const int s2 = blockIdx.x - tile_wgs;
+    float4 q[4];
 #pragma unroll
-    for (int a = 0; a < 3; a++)
+    for (int u = 0; u < 4; u++) q[u] = sorted[min(s2 * 4096 + u * 1024 + (int)threadIdx.x, n - 1)];
+    l3[0] = fminf(fminf(q[0].x, q[1].x), fminf(q[2].x, q[3].x)); h3[0] = fmaxf(fmaxf(q[0].x, q[1].x), fmaxf(q[2].x, q[3].x));
+    l3[1] = fminf(fminf(q[0].y, q[1].y), fminf(q[2].y, q[3].y)); h3[1] = fmaxf(fmaxf(q[0].y, q[1].y), fmaxf(q[2].y, q[3].y));
+    l3[2] = fminf(fminf(q[0].z, q[1].z), fminf(q[2].z, q[3].z)); h3[2] = fmaxf(fmaxf(q[0].z, q[1].z), fmaxf(q[2].z, q[3].z));
+  }
 #pragma unroll
-      for (int off = 32; off > 0; off >>= 1) {
-        l3[a] = fminf(l3[a], __shfl_xor(l3[a], off));
-        h3[a] = fmaxf(h3[a], __shfl_xor(h3[a], off));
-      }
-    if (lane == 0) {
-      bbox2[2 * s2] = make_float4(l3[0], l3[1], l3[2], 0.f);
-      bbox2[2 * s2 + 1] = make_float4(h3[0], h3[1], h3[2], 0.f);
+  for (int a = 0; a < 3; a++)
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      l3[a] = fminf(l3[a], __shfl_xor(l3[a], off));
+      h3[a] = fmaxf(h3[a], __shfl_xor(h3[a], off));
     }
+  if (!super) {
+    if (lane == 0) {
+      const int t = blockIdx.x * 16 + wv;
+      bbox1[2 * t] = make_float4(l3[0], l3[1], l3[2], 0.f);
+      bbox1[2 * t + 1] = make_float4(h3[0], h3[1], h3[2], 0.f);
+    }
+    return;
+  }
+  if (lane == 0) {
+#pragma unroll
+    for (int a = 0; a < 3; a++) { s_wl[wv][a] = l3[a]; s_wh[wv][a] = h3[a]; }
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float l[3], h[3];
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+      l[a] = s_wl[0][a]; h[a] = s_wh[0][a];
+      for (int w = 1; w < 16; w++) { l[a] = fminf(l[a], s_wl[w][a]); h[a] = fmaxf(h[a], s_wh[w][a]); }
+    }
+    const int s2 = blockIdx.x - tile_wgs;
+    bbox2[2 * s2] = make_float4(l[0], l[1], l[2], 0.f);
+    bbox2[2 * s2 + 1] = make_float4(h[0], h[1], h[2], 0.f);
   }
 }
 
