@@ -470,7 +470,7 @@ struct Engine {
     if (!counted) return !exclusive;
     std::lock_guard<std::mutex> lk(g_gangs.mu);
     if (exclusive)
-      for (Engine* o : g_gangs.engines) if (o != this && o->gang_in_flight()) return false;
+      for (Engine* o : g_gangs.engines) if (o != this && o->device == device && o->gang_in_flight()) return false;  // (another device's kernels take none of this one's CU slots)
     gang_launching.fetch_add(1, std::memory_order_acq_rel);
     return true;
   }

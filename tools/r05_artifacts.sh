@@ -58,6 +58,8 @@ if [ "$WHAT" = "stats" ] || [ "$WHAT" = "all" ]; then
   head -14 $O/prof_bundled17k_kernel_stats.md
 fi
 if [ "$WHAT" = "bench" ] || [ "$WHAT" = "all" ]; then
+  # (bench.py quotes profiles/r05_pmc.json when its stamp matches the kernels: in an "all" run that is the file made above)
+  [ "$WHAT" = "all" ] && [ -s $O/pmc.json ] && cp $O/pmc.json profiles/r05_pmc.json
   timeout 500 python bench.py > $O/bench_line.json 2> $O/bench.err < /dev/null
   echo "bench rc=$?"; cp bench_detail.json $O/bench_detail.json; wc -c $O/bench_line.json; cat $O/bench_line.json
 fi
