@@ -750,6 +750,19 @@ __device__ unsigned long long g_mtime[16][512][12];
 // CH: voxel lookups per work item the code is unrolled for -- COST_CH, or 1 for launches whose items hold a single offset (NDT D2D over a
 // few thousand source voxels, DIRECT1): the four-chunk code executed its three dead chunks masked, ~40 % of the main loop's instructions
 // on a grid with one wave per SIMD, where nothing hides an instruction (tools/count_isa.py: 2,200 -> see profiles/r05_isa_counts.txt).
+// a pointer into LDS that stays one (a 32-bit offset; reads are ds_read, waited for with lgkmcnt only)
+template <typename Real> using LdsPose = const Pose<Real> __attribute__((address_space(3)))*;
+typedef const int __attribute__((address_space(3)))* LdsInt;
+template <typename Real>
+__device__ __forceinline__ Pose<Real> lds_pose(LdsPose<Real> p, int which) {
+  Pose<Real> o;
+#pragma unroll
+  for (int k = 0; k < 9; k++) o.r[k] = p[which].r[k];
+#pragma unroll
+  for (int k = 0; k < 3; k++) o.t[k] = p[which].t[k];
+  return o;
+}
+
 template <typename Real, int MODE, bool PERSIST, int CH = COST_CH, bool GN = false>
 __global__ FVH_COST_BOUNDS void cost_kernel(CostParams P) {
   static_assert(CH == 1 || CH == COST_CH, "one or COST_CH lookups per item");
@@ -792,6 +805,18 @@ __global__ FVH_COST_BOUNDS void cost_kernel(CostParams P) {
   }
   __shared__ Pose<Real> s_pose[2];
   if (threadIdx.x == 0) { s_pose[0] = pose_cast<Real>(lin_d); s_pose[1] = pose_cast<Real>(ev_d); }
+  // The occupancy grid of a large map and the box of a sharded one are constant during a launch: staged in LDS once. Read per item
+  // through their device pointers they were dependent FLAT round trips in front of the probes -- `enabled`, then the rest of the grid,
+  // then the four occupancy words one after the other (each behind the full wait of the one before); six short-circuited loads for the box.
+  __shared__ int s_grid[8];    // b0[3], nb[3], enabled
+  __shared__ int s_region[8];  // inner_lo[3], inner_hi[3]
+  if (threadIdx.x < 8) {
+    const int t = threadIdx.x;
+    int gv = 0, rv = 0;
+    if (P.bitmap && P.grid) gv = t < 3 ? P.grid->b0[t] : (t < 6 ? P.grid->nb[t - 3] : (t == 6 ? P.grid->enabled : 0));
+    if (P.region) rv = t < 3 ? P.region->inner_lo[t] : (t < 6 ? P.region->inner_hi[t - 3] : 0);
+    s_grid[t] = gv; s_region[t] = rv;
+  }
   __syncthreads();
   // The number of source elements of an NDT D2D launch lives on the device (the source map's voxel counter) and does not change during the
   // launch: read once here. (Read per trip it was a dependent global round trip in front of every trip's first loads.)
@@ -892,42 +917,66 @@ __global__ FVH_COST_BOUNDS void cost_kernel(CostParams P) {
     // waves per SIMD the loop is bound by VALU issue (~1,650 VALU instructions per wave and trip, ~4.25 cycles each, PMC), and
     // the other wave already filled the round trips; the younger workgroup of a CU is the one that finishes late.
     // ---- round trip 1 ----
+    // (Written as ONE branch on `cached` with straight-line loads inside: as per-value selects "cached ? LDS : global" inside the
+    // slot loop every slot's loads ended at a join with a full wait -- the stored ids and offsets of the four slots were four dependent
+    // round trips behind the source element's, on every item of a cloud too large for sticky items. tools/scan_serial_loads.py, round 5.)
     float4 a4, c0 = make_float4(0, 0, 0, 0), c1 = c0;
-    if (cached) {
-      a4 = s_src[0][st];
-      if (MODE != MODE_NDT_P2D) { c0 = s_src[1][st]; c1 = s_src[2][st]; }
-    } else {
-      a4 = P.src_pts[i];
-      if (MODE != MODE_NDT_P2D && do_cost) { c0 = P.src_cov[2 * i]; c1 = P.src_cov[2 * i + 1]; }
-      if (sticky) {  // (trip 0 of a persistent launch: a linearisation, do_cost holds)
-        s_elem[st] = i; s_src[0][st] = a4;
-        if (MODE != MODE_NDT_P2D) { s_src[1][st] = c0; s_src[2][st] = c1; }
-      }
-    }
     const bool ext_fused = EXT_OK && external && fused;
     int b[CH], bo[CH];
     int ofp[CH];  // packed neighbour offsets
+#pragma unroll
+    for (int c = 0; c < CH; c++) { bo[c] = -1; b[c] = -1; ofp[c] = 0; }
+    const bool want_bo = fused && !role_b, want_ofp = do_find && !role_a, want_b = !role_a && !do_find;
+    if (cached) {
+      a4 = s_src[0][st];
+      if (MODE != MODE_NDT_P2D) { c0 = s_src[1][st]; c1 = s_src[2][st]; }
+      if (want_bo) {
+#pragma unroll
+        for (int c = 0; c < CH; c++) bo[c] = s_ids[corr_sel][c][role_a ? st + 128 : st];
+      }
+      if (want_ofp) {
+#pragma unroll
+        for (int c = 0; c < CH; c++) ofp[c] = s_ofp[c][st];
+      } else if (want_b) {  // (an error-only evaluation of a persistent launch: the stored ids of the current buffer)
+#pragma unroll
+        for (int c = 0; c < CH; c++) b[c] = s_ids[corr_sel][c][st];
+      }
+    } else {
+      const size_t row = (size_t)i * P.n_off + o_begin;
+      a4 = P.src_pts[i];
+      if (MODE != MODE_NDT_P2D && do_cost) { c0 = P.src_cov[2 * i]; c1 = P.src_cov[2 * i + 1]; }
+      // (slots past the item's end read the item's last slot again and are masked: every load below is unconditional within its group)
+      if (want_bo) {
+#pragma unroll
+        for (int c = 0; c < CH; c++) { const int v = corr_old[row + min(c, o_end - 1 - o_begin)]; bo[c] = (o_begin + c < o_end) ? v : -1; }
+      }
+      if (want_ofp) {
+#pragma unroll
+        for (int c = 0; c < CH; c++) ofp[c] = P.offsets_packed[min(o_begin + c, o_end - 1)];
+      } else if (want_b) {
+        const int* src_ids = ext_fused ? corr_new : corr_old;
+#pragma unroll
+        for (int c = 0; c < CH; c++) { const int v = src_ids[row + min(c, o_end - 1 - o_begin)]; b[c] = (o_begin + c < o_end) ? v : -1; }
+      }
+      if (sticky) {  // (trip 0 of a persistent launch: a linearisation, do_cost and do_find hold)
+        s_elem[st] = i; s_src[0][st] = a4;
+        if (MODE != MODE_NDT_P2D) { s_src[1][st] = c0; s_src[2][st] = c1; }
+        if (want_ofp) {
+#pragma unroll
+          for (int c = 0; c < CH; c++) s_ofp[c][st] = ofp[c];
+        }
+      }
+    }
     float4 q1[CH], q2[CH];
     // voxel records: of the old ids first (fused), then of the ids of this evaluation. q3 = {c_yz, c_zz, weight sqrt(n) as a double};
     // NDT does not use the weight and loads 8 bytes only
     using Q3 = typename std::conditional<MODE == MODE_VGICP, float4, float2>::type;
     Q3 q3[CH];
     // (a work item is at most CH offsets -- cost_shape() -- so this is the whole item: no chunk loop)
-#pragma unroll
-    for (int c = 0; c < CH; c++) {
-      const bool in = o_begin + c < o_end;
-      bo[c] = -1; b[c] = -1; ofp[c] = 0;
-      if (fused && !role_b) bo[c] = cached ? s_ids[corr_sel][c][role_a ? st + 128 : st] : (in ? corr_old[(size_t)i * P.n_off + o_begin + c] : -1);
-      if (role_a) {
-      } else if (do_find) {
-        if (cached) ofp[c] = s_ofp[c][st];
-        else { ofp[c] = P.offsets_packed[min(o_begin + c, o_end - 1)]; if (sticky) s_ofp[c][st] = ofp[c]; }
-      } else if (ext_fused) {
-        b[c] = in ? corr_new[(size_t)i * P.n_off + o_begin + c] : -1;
-      } else {
-        b[c] = cached ? s_ids[corr_sel][c][st] : (in ? corr_old[(size_t)i * P.n_off + o_begin + c] : -1);
-      }
-    }
+    // (the source point is consumed HERE, in front of round trip 2: its load is older than the ids', so this costs no wait of its own --
+    // consumed behind the record loads, the join of "fused" and "not fused" needs a full wait for it, which drains those loads too)
+    Vec3<Real> a = {(Real)a4.x, (Real)a4.y, (Real)a4.z};
+    asm volatile("" : "+v"(a.x), "+v"(a.y), "+v"(a.z));
     if (PERSIST) FVH_MT(gen, 1);
     // ---- round trip 2 (fused): issued before the arithmetic below, which does not need it ----
     if (fused && !role_b) {  // the records of the stored ids (bucket 0 for "none")
@@ -937,27 +986,30 @@ __global__ FVH_COST_BOUNDS void cost_kernel(CostParams P) {
         q1[c] = tf[base + 1]; q2[c] = tf[base + 2]; q3[c] = *reinterpret_cast<const Q3*>(tf + base + 3);
       }
     }
-    const Vec3<Real> a = {(Real)a4.x, (Real)a4.y, (Real)a4.z};
-    const Pose<Real>* pose_ptr = s_pose;
-    asm volatile("" : "+v"(pose_ptr));  // opaque: the pose loads stay inside the iteration instead of becoming 48 loop-invariant registers
+    // opaque: the pose loads stay inside the iteration instead of becoming 48 loop-invariant registers. The pointer keeps its LDS address
+    // space (a 32-bit offset): as a generic pointer the reads were FLAT loads, whose wait is vmcnt(0) AND lgkmcnt(0) -- every read of the
+    // pose drained the record loads that were meant to stay in flight behind the arithmetic (tools/scan_serial_loads.py, round 5)
+    LdsPose<Real> pose_ptr = (LdsPose<Real>)s_pose;
+    asm volatile("" : "+v"(pose_ptr));
     Sym3<Real> RCR = {0, 0, 0, 0, 0, 0}, RCR_old = {0, 0, 0, 0, 0, 0};
     int cx = 0, cy = 0, cz = 0;
     bool coord_ok = true;  // false: non-finite / out-of-range source point -> no correspondences (and no (int)floor(NaN))
     {
-      const Pose<Real> ev = pose_ptr[1];
+      const Pose<Real> ev = lds_pose(pose_ptr, 1);
       q = transform(ev, a);
       if (do_find && !role_a) {
         Vec3<Real> ql = q;
-        if (!fused) { const Pose<Real> lin = pose_ptr[0]; ql = transform(lin, a); }
+        if (!fused) { const Pose<Real> lin = lds_pose(pose_ptr, 0); ql = transform(lin, a); }
         const Real fx = floor(div_by(ql.x, res, inv_res) - (Real)0.5), fy = floor(div_by(ql.y, res, inv_res) - (Real)0.5), fz = floor(div_by(ql.z, res, inv_res) - (Real)0.5);
         coord_ok = voxel_index_ok(fx, fy, fz);
         cx = coord_ok ? (int)fx : 0;
         cy = coord_ok ? (int)fy : 0;
         cz = coord_ok ? (int)fz : 0;
         if (P.region) {  // (kernel argument: uniform) sharded target map: is every voxel this element can reach in the shard?
-          const VmRegion* rg = P.region;
-          asm volatile("" : "+s"(rg));  // re-read per item: six scalars must not live across the main loop
-          left_shard = coord_ok && (cx < rg->inner_lo[0] || cx > rg->inner_hi[0] || cy < rg->inner_lo[1] || cy > rg->inner_hi[1] || cz < rg->inner_lo[2] || cz > rg->inner_hi[2]);
+          LdsInt rg = (LdsInt)s_region;
+          asm volatile("" : "+v"(rg));  // re-read per item (LDS): six values must not live across the main loop
+          const int l0 = rg[0], l1 = rg[1], l2 = rg[2], h0 = rg[3], h1 = rg[4], h2 = rg[5];
+          left_shard = coord_ok && ((cx < l0) | (cx > h0) | (cy < l1) | (cy > h1) | (cz < l2) | (cz > h2));
         }
       }
     }
@@ -965,10 +1017,9 @@ __global__ FVH_COST_BOUNDS void cost_kernel(CostParams P) {
     // `lin` otherwise; the stored ids of a fused trip use `lin`
     if (MODE != MODE_NDT_P2D && do_cost) {
       const Sym3<Real> CA = {(Real)c0.x, (Real)c0.y, (Real)c0.z, (Real)c0.w, (Real)c1.x, (Real)c1.y};
-      const Pose<Real>& lin = pose_ptr[0];
       Real Rl[9];
 #pragma unroll
-      for (int k = 0; k < 9; k++) Rl[k] = lin.r[k];
+      for (int k = 0; k < 9; k++) Rl[k] = pose_ptr[0].r[k];
       if (fused) { if (!role_b) RCR_old = rotate_cov(Rl, CA); } else RCR = rotate_cov(Rl, CA);
     }
     if (PERSIST) FVH_MT(gen, 2);
@@ -990,20 +1041,23 @@ __global__ FVH_COST_BOUNDS void cost_kernel(CostParams P) {
         }
         bool filtered = false;
         if (P.bitmap) {  // (kernel argument: uniform) large map: the cache-resident occupancy bits answer the misses -- only guaranteed hits go to the table
-          const VmGrid* gptr = P.grid;
-          asm volatile("" : "+s"(gptr));  // re-read per item: nine scalars must not live across the main loop
-          const VmGrid g = *gptr;
-          if (g.enabled) {  // (0: the map's box did not fit the bitmap budget -- every lookup goes to the table as before)
+          LdsInt gp = (LdsInt)s_grid;
+          asm volatile("" : "+v"(gp));  // re-read per item (LDS): seven values must not live across the main loop
+          const int gb0 = gp[0], gb1 = gp[1], gb2 = gp[2], gn0 = gp[3], gn1 = gp[4], gn2 = gp[5];
+          if (gp[6]) {  // (enabled; 0: the map's box did not fit the bitmap budget -- every lookup goes to the table as before)
             filtered = true;
             unsigned long long w[CH];
-            unsigned bit[CH];
+            unsigned word[CH], bit[CH];  // (the bitmap budget is 32 MB = 4 M words: 32 bits index it)
 #pragma unroll
-            for (int c = 0; c < CH; c++) {
-              unsigned long long word = 0;
-              bit[c] = 0;
-              live[c] = live[c] && vm_grid_locate(g, (unsigned)(key[c] & 0x1FFFFF), (unsigned)((key[c] >> 21) & 0x1FFFFF), (unsigned)((key[c] >> 42) & 0x1FFFFF), word, bit[c]);
-              w[c] = live[c] ? P.bitmap[word] : 0ull;
+            for (int c = 0; c < CH; c++) {  // (vm_grid_locate on the staged values)
+              const unsigned ux = (unsigned)(key[c] & 0x1FFFFF), uy = (unsigned)((key[c] >> 21) & 0x1FFFFF), uz = (unsigned)((key[c] >> 42) & 0x1FFFFF);
+              const int bx = (int)(ux >> 2) - gb0, by = (int)(uy >> 2) - gb1, bz = (int)(uz >> 2) - gb2;
+              live[c] = live[c] && (unsigned)bx < (unsigned)gn0 && (unsigned)by < (unsigned)gn1 && (unsigned)bz < (unsigned)gn2;
+              word[c] = live[c] ? ((unsigned)bz * (unsigned)gn1 + (unsigned)by) * (unsigned)gn0 + (unsigned)bx : 0u;
+              bit[c] = (ux & 3u) | ((uy & 3u) << 2) | ((uz & 3u) << 4);
             }
+#pragma unroll
+            for (int c = 0; c < CH; c++) w[c] = P.bitmap[word[c]];  // unconditional (dead lookups read word 0): CH independent loads, one round trip
 #pragma unroll
             for (int c = 0; c < CH; c++) {
               live[c] = live[c] && ((w[c] >> bit[c]) & 1ull);
@@ -1014,7 +1068,10 @@ __global__ FVH_COST_BOUNDS void cost_kernel(CostParams P) {
 #pragma unroll
         for (int c = 0; c < CH; c++) {
           slot[c] = hash_slot(key[c], P.mask);
-          k0[c] = (filtered && !live[c]) ? FVH_EMPTY_KEY : P.keys[slot[c]];  // (filtered: no load at all; unfiltered: the rare dead lookup reads a valid slot, no branch)
+          // (filtered: a lookup the bitmap answered reads slot 0 -- one line for all of them -- and is not looked at; unfiltered: the rare dead
+          // lookup reads a valid slot. Either way the CH loads are unconditional and independent: one round trip)
+          const unsigned long long kv = P.keys[(filtered && !live[c]) ? 0u : slot[c]];
+          k0[c] = (filtered && !live[c]) ? FVH_EMPTY_KEY : kv;
         }
         // One-lookup items (CH == 1: 122 VGPRs, far from the cliff): the RECORD of the home slot is requested together with its key. At a
         // load factor <= 0.25 the home slot is the answer of nearly every hit, so the dependent round trip "key -> record" of a slot
@@ -1089,7 +1146,7 @@ __global__ FVH_COST_BOUNDS void cost_kernel(CostParams P) {
         }
       }
       if (fused && MODE != MODE_NDT_P2D) {  // R_ev C_A R_ev^T, while the records of changed ids are in flight
-        const Pose<Real>* pose_ptr2 = s_pose;
+        LdsPose<Real> pose_ptr2 = (LdsPose<Real>)s_pose;
         asm volatile("" : "+v"(pose_ptr2) : : "memory");  // not before this point (see the register note above)
         const Sym3<Real> CA = {(Real)c0.x, (Real)c0.y, (Real)c0.z, (Real)c0.w, (Real)c1.x, (Real)c1.y};
         Real Re[9];

@@ -732,15 +732,20 @@ __global__ __launch_bounds__(256) void cov_from_neighbors_kernel(const float4* _
   const int* nb = nbr + (size_t)i * k;
   float px[PER_LANE], py[PER_LANE], pz[PER_LANE];
   double mx = 0, my = 0, mz = 0;
+  // Two round trips for the whole gather: all indices, then all points (slots past k read a valid neighbour again and are masked). Written
+  // as "if (j < k) { p = pts[nb[j]]; ... }" the lane-dependent branch kept every load behind its own wait: ten dependent round trips,
+  // ~4 of this kernel's 8.9 us at 17k points (tools/scan_serial_loads.py).
+  int idx[PER_LANE];
+#pragma unroll
+  for (int u = 0; u < PER_LANE; u++) idx[u] = nb[min(sub + u * COV_LANES, k - 1)];
+  float4 pq[PER_LANE];
+#pragma unroll
+  for (int u = 0; u < PER_LANE; u++) pq[u] = pts[idx[u]];
 #pragma unroll
   for (int u = 0; u < PER_LANE; u++) {
-    const int j = sub + u * COV_LANES;
-    px[u] = py[u] = pz[u] = 0.f;
-    if (j < k) {
-      const float4 p = pts[nb[j]];
-      px[u] = p.x; py[u] = p.y; pz[u] = p.z;
-      mx += (double)p.x; my += (double)p.y; mz += (double)p.z;
-    }
+    const bool in = sub + u * COV_LANES < k;
+    px[u] = in ? pq[u].x : 0.f; py[u] = in ? pq[u].y : 0.f; pz[u] = in ? pq[u].z : 0.f;
+    mx = in ? mx + (double)pq[u].x : mx; my = in ? my + (double)pq[u].y : my; mz = in ? mz + (double)pq[u].z : mz;
   }
 #pragma unroll
   for (int off = 1; off < COV_LANES; off <<= 1) { mx += __shfl_xor(mx, off); my += __shfl_xor(my, off); mz += __shfl_xor(mz, off); }
