@@ -945,10 +945,11 @@ __global__ FVH_COST_BOUNDS void cost_kernel(CostParams P) {
       const size_t row = (size_t)i * P.n_off + o_begin;
       a4 = P.src_pts[i];
       if (MODE != MODE_NDT_P2D && do_cost) { c0 = P.src_cov[2 * i]; c1 = P.src_cov[2 * i + 1]; }
-      // (slots past the item's end read the item's last slot again and are masked: every load below is unconditional within its group)
+      // (slots past the item's end read the item's last slot again and are masked BEHIND the branch: a select on a loaded value inside its
+      // group would be a use of the load right behind its issue, and the next group's loads would wait for it)
       if (want_bo) {
 #pragma unroll
-        for (int c = 0; c < CH; c++) { const int v = corr_old[row + min(c, o_end - 1 - o_begin)]; bo[c] = (o_begin + c < o_end) ? v : -1; }
+        for (int c = 0; c < CH; c++) bo[c] = corr_old[row + min(c, o_end - 1 - o_begin)];
       }
       if (want_ofp) {
 #pragma unroll
@@ -956,7 +957,7 @@ __global__ FVH_COST_BOUNDS void cost_kernel(CostParams P) {
       } else if (want_b) {
         const int* src_ids = ext_fused ? corr_new : corr_old;
 #pragma unroll
-        for (int c = 0; c < CH; c++) { const int v = src_ids[row + min(c, o_end - 1 - o_begin)]; b[c] = (o_begin + c < o_end) ? v : -1; }
+        for (int c = 0; c < CH; c++) b[c] = src_ids[row + min(c, o_end - 1 - o_begin)];
       }
       if (sticky) {  // (trip 0 of a persistent launch: a linearisation, do_cost and do_find hold)
         s_elem[st] = i; s_src[0][st] = a4;
@@ -966,6 +967,11 @@ __global__ FVH_COST_BOUNDS void cost_kernel(CostParams P) {
           for (int c = 0; c < CH; c++) s_ofp[c][st] = ofp[c];
         }
       }
+    }
+#pragma unroll
+    for (int c = 0; c < CH; c++) {  // slots past the item's end hold no id (the sticky copies say so already)
+      const bool in = o_begin + c < o_end;
+      bo[c] = in ? bo[c] : -1; b[c] = in ? b[c] : -1;
     }
     float4 q1[CH], q2[CH];
     // voxel records: of the old ids first (fused), then of the ids of this evaluation. q3 = {c_yz, c_zz, weight sqrt(n) as a double};
@@ -1070,8 +1076,9 @@ __global__ FVH_COST_BOUNDS void cost_kernel(CostParams P) {
           slot[c] = hash_slot(key[c], P.mask);
           // (filtered: a lookup the bitmap answered reads slot 0 -- one line for all of them -- and is not looked at; unfiltered: the rare dead
           // lookup reads a valid slot. Either way the CH loads are unconditional and independent: one round trip)
-          const unsigned long long kv = P.keys[(filtered && !live[c]) ? 0u : slot[c]];
-          k0[c] = (filtered && !live[c]) ? FVH_EMPTY_KEY : kv;
+          // Whatever slot 0 holds cannot match DEAD_KEY, and a dead lookup never continues a probe: no select on the loaded value (it would be
+          // a use of the load right behind its issue -- the probes are meant to be in flight during the trial error below).
+          k0[c] = P.keys[(filtered && !live[c]) ? 0u : slot[c]];
         }
         // One-lookup items (CH == 1: 122 VGPRs, far from the cliff): the RECORD of the home slot is requested together with its key. At a
         // load factor <= 0.25 the home slot is the answer of nearly every hit, so the dependent round trip "key -> record" of a slot
