@@ -1161,6 +1161,7 @@ struct CostSource {
   const float4* pts; const float4* cov; const int* d_n; int n_upper;
   const int* counters2;  // source voxel map counters (D2D) or null
   const int* order;      // Morton permutation of the source (large clouds) or null
+  const float4* sorted = nullptr;  // with `order`: the cloud's Morton-ordered copy (.w = original index) -- element order[j] is sorted[j]
   int n_off_override = 0;  // > 0: correspondences per source element regardless of the handle's offset list (GICP: 1)
   bool shardable = false;  // the source elements are the points of a cloud with a Morton order: with peers attached each rank walks its tile
   bool external_find = false;  // FastGICP device LM: nn1_corr_kernel fills the correspondence buffers between the cost launches
@@ -1229,7 +1230,7 @@ int launch_cost(Engine* e, const CostSource& src, const VoxelMapDev& vm, int hos
                 const GridPlan* plan = nullptr /* align(): the layout both routes take (workgroups granted, groups, XCD confinement) */) {
   CostParams P;
   std::memset(&P, 0, sizeof(P));
-  P.src_pts = src.pts; P.src_cov = src.cov; P.d_n_src = src.d_n; P.n_src = src.n_upper; P.order = src.order;
+  P.src_pts = src.pts; P.src_cov = src.cov; P.d_n_src = src.d_n; P.n_src = src.n_upper; P.order = src.order; P.src_sorted = src.order ? src.sorted : nullptr;
   P.table = vm.table.as<uint4>(); P.keys = vm.keys_cur(); P.mask = vm.capacity - 1; P.res = vm.res; P.inv_res = 1.0 / vm.res;
   P.bitmap = vm.has_bitmap ? vm.bitmap.as<unsigned long long>() : nullptr;
   P.grid = vm.has_bitmap ? vm.grid.as<VmGrid>() : nullptr;
@@ -2050,6 +2051,7 @@ struct fvh_vgicp {
     // multi-GPU: the tiles are ranges of the Morton order whatever the size of the cloud (spatially compact shards)
     const int* order = e.sharded() ? (source.has_sorted ? source.order.as<int>() : nullptr) : coherent_order(source);
     CostSource c{source.pts.as<float4>(), source.cov.as<float4>(), nullptr, source.n, nullptr, order};
+    if (order) c.sorted = source.sorted.as<float4>();
     c.shardable = true;
     return c;
   }

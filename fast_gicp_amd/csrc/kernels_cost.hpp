@@ -87,6 +87,7 @@ struct CostParams {
   const float4* src_cov;      // null for P2D
   const int* d_n_src;         // device-side count (D2D source voxels) or null
   const int* order;           // optional Morton permutation of the source: work item w handles element order[w] (coherent lookups)
+  const float4* src_sorted;   // with `order`, optional: the Morton-ordered copy of src_pts (.w = original index): the point of element order[w] is src_sorted[w] -- a coalesced load
   int n_src;
   const uint4* table;                // voxel records (64 B per bucket)
   const unsigned long long* keys;    // voxel keys of the same buckets, dense (kernels_voxelmap.hpp)
@@ -810,6 +811,9 @@ __global__ FVH_COST_BOUNDS void cost_kernel(CostParams P) {
   // then the four occupancy words one after the other (each behind the full wait of the one before); six short-circuited loads for the box.
   __shared__ int s_grid[8];    // b0[3], nb[3], enabled
   __shared__ int s_region[8];  // inner_lo[3], inner_hi[3]
+  constexpr int OFFP_LDS = 64;
+  __shared__ int s_offp[OFFP_LDS];  // the packed neighbour offsets (DIRECT1 / 7 / 27 and small RADIUS sets): four of an item's eleven first loads
+  if (threadIdx.x >= 64 && threadIdx.x < 64 + OFFP_LDS) s_offp[threadIdx.x - 64] = ((int)threadIdx.x - 64 < P.n_off) ? P.offsets_packed[threadIdx.x - 64] : 0;
   if (threadIdx.x < 8) {
     const int t = threadIdx.x;
     int gv = 0, rv = 0;
@@ -828,7 +832,10 @@ __global__ FVH_COST_BOUNDS void cost_kernel(CostParams P) {
   // touches its own slots only (no barrier). The ids still go to the global buffers too (getters, the per-transition route after an abort).
   constexpr int STICKY_T = PERSIST ? 256 : 1;
   __shared__ float4 s_src[3][STICKY_T];
-  __shared__ int s_elem[STICKY_T];
+  // the element index of a thread's FIRST ELEM_ITS items (a thread's items are the same on every trip of a launch): on clouds walked in
+  // Morton order `order[i0]` is a dependent round trip in front of everything else the item loads -- after the first trip it is an LDS read
+  constexpr int ELEM_ITS = 2;
+  __shared__ int s_elem[PERSIST ? ELEM_ITS : 1][STICKY_T];
   __shared__ int s_ids[2][CH][STICKY_T];
   __shared__ int s_ofp[CH][STICKY_T];  // the item's packed neighbour offsets
   bool a_primed = false;  // wave roles: waves 0-1 skip the plain linearisations, so they fill their sticky slots on their FIRST fused trip, whichever that is
@@ -886,7 +893,9 @@ __global__ FVH_COST_BOUNDS void cost_kernel(CostParams P) {
   // (consecutive threads take consecutive items on purpose: spreading a workgroup's items over the cloud made the launch
   // 24 % slower -- the loop is sensitive to how many distinct cache lines a wave touches)
   // The loop bound is wave-uniform (the butterfly needs all 64 lanes); lanes past the end contribute zeros.
+  int item_no = -1;  // (wave-uniform) which of this thread's items the loop is at
   for (int wbase = w_lo + (int)lb * wstride + (split ? ((wave_id & 1) << 6) : (int)(threadIdx.x & 192)); wbase < n_items; wbase += (int)nb * wstride) {
+    item_no++;
     if (role_a && !fused) continue;  // (a plain linearisation / an error-only evaluation has no second piece of work: waves 0-1 contribute zeros)
     const int w = wbase + lane;
     ItemAcc<Real> it = {{0, 0, 0, 0, 0, 0}, {0, 0, 0}, 0};
@@ -901,7 +910,15 @@ __global__ FVH_COST_BOUNDS void cost_kernel(CostParams P) {
     const int g = w - i0 * P.groups_per_src;
     const int st = PERSIST ? (int)threadIdx.x : 0;  // this thread's sticky slot
     int i;
-    if (cached) i = s_elem[st]; else i = P.order ? P.order[i0] : i0;
+    // (sticky launches: `cached`, slot 0; others: the first ELEM_ITS items of a thread from the second trip on -- wave roles only exist on sticky launches)
+    const bool elem_cached = PERSIST && P.order != nullptr && (cached || (!split && gen > 0 && item_no < ELEM_ITS));
+    if (cached) i = s_elem[0][st];
+    else if (elem_cached) i = s_elem[item_no][st];
+    else {
+      i = P.order ? P.order[i0] : i0;
+      if (PERSIST && !sticky && P.order != nullptr && item_no < ELEM_ITS) s_elem[item_no][st] = i;
+    }
+    const float4* a4_src = P.src_sorted ? P.src_sorted + i0 : P.src_pts + i;  // (uniform choice) in Morton order the sorted copy is read contiguously
     const int o_begin = g * P.group, o_end = min(P.n_off, o_begin + P.group);
     // The loop is a chain of dependent memory round trips (0.3 us each when coalesced, 0.5-0.8 us when scattered; measured
     // with tools/main_timing.py) with ~4 us of fp64 arithmetic between them, on 2 waves per SIMD -- nothing hides a round trip
@@ -943,7 +960,7 @@ __global__ FVH_COST_BOUNDS void cost_kernel(CostParams P) {
       }
     } else {
       const size_t row = (size_t)i * P.n_off + o_begin;
-      a4 = P.src_pts[i];
+      a4 = *a4_src;
       if (MODE != MODE_NDT_P2D && do_cost) { c0 = P.src_cov[2 * i]; c1 = P.src_cov[2 * i + 1]; }
       // (slots past the item's end read the item's last slot again and are masked BEHIND the branch: a select on a loaded value inside its
       // group would be a use of the load right behind its issue, and the next group's loads would wait for it)
@@ -953,14 +970,14 @@ __global__ FVH_COST_BOUNDS void cost_kernel(CostParams P) {
       }
       if (want_ofp) {
 #pragma unroll
-        for (int c = 0; c < CH; c++) ofp[c] = P.offsets_packed[min(o_begin + c, o_end - 1)];
+        for (int c = 0; c < CH; c++) { const int oi = min(o_begin + c, o_end - 1); ofp[c] = (P.n_off <= OFFP_LDS) ? s_offp[oi] : P.offsets_packed[oi]; }
       } else if (want_b) {
         const int* src_ids = ext_fused ? corr_new : corr_old;
 #pragma unroll
         for (int c = 0; c < CH; c++) b[c] = src_ids[row + min(c, o_end - 1 - o_begin)];
       }
       if (sticky) {  // (trip 0 of a persistent launch: a linearisation, do_cost and do_find hold)
-        s_elem[st] = i; s_src[0][st] = a4;
+        s_elem[0][st] = i; s_src[0][st] = a4;
         if (MODE != MODE_NDT_P2D) { s_src[1][st] = c0; s_src[2][st] = c1; }
         if (want_ofp) {
 #pragma unroll

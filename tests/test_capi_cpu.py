@@ -79,7 +79,7 @@ def test_kernels_stay_on_the_right_side_of_the_register_cliff():
             continue
         # LDS: 5 KB of reduction scratch + LM state; the persistent instantiations add the sticky-item cache (12 + 1 + 3 CH KB): three
         # (four for the one-lookup instantiations) workgroups per CU stay far below the CU's 160 KB
-        assert v["occupancy"] >= 3 and v["vgprs"] <= 168 and v["lds"] <= (31 * 1024 if ", true, " in k else 8 * 1024), (k, v)
+        assert v["occupancy"] >= 3 and v["vgprs"] <= 168 and v["lds"] <= (32 * 1024 if ", true, " in k else 8 * 1024), (k, v)
         if ", true, " in k:
             # persistent instantiations: the LM step is inlined into the opener's once-per-trip path (7 us per launch faster than a
             # call through generic pointers); a few values live across it are spilled THERE (8 scratch instructions in the whole

@@ -19,6 +19,13 @@ if "--ndt" in sys.argv:  # the LiDAR-stream configuration: NDT D2D, DIRECT7, two
     c.set_distance_mode(capi.NDT_D2D); c.set_neighbor_search_method(capi.DIRECT7); c.set_resolution(1.0)
     c.set_target_cloud(vg.filter(workloads.lidar_frame(3), 0.25, vg.APPROXIMATE))
     c.set_source_cloud(vg.filter(workloads.lidar_frame(4), 0.25, vg.APPROXIMATE))
+elif "--synth1m" in sys.argv:  # BASELINE configs[4] on one GPU: 1M-point map <-> 100k-point scan, res 0.5, DIRECT7 (768 workgroups, two items per thread)
+    from fast_gicp_amd import workloads
+    tgt, src, _ = workloads.synthetic_pair(1_000_000, 100_000, seed=44, extent=150.0)
+    c = capi.VGICPCore(0)
+    c.set_resolution(0.5); c.set_neighbor_search_method(capi.DIRECT7)
+    c.set_target_cloud(tgt); c.find_target_neighbors(20); c.calculate_target_covariances(); c.create_target_voxelmap()
+    c.set_source_cloud(src); c.find_source_neighbors(20); c.calculate_source_covariances()
 else:
     tgt, src = preprocess.bundled_pair(os.path.join(ROOT, "data"))
     c = capi.VGICPCore(0)
@@ -30,7 +37,7 @@ for rep in range(5):
 L.fvh_debug_main_timing(None, 1)
 L.fvh_debug_persist_timing(None, 1)
 r = c.align()
-m = np.zeros((16, 512, 12), np.uint64)
+m = np.zeros((16, 512, 12), np.uint64)  # (the first 512 workgroups only)
 pt = np.zeros((16, 512, 12), np.uint64)
 L.fvh_debug_main_timing(m.ctypes.data_as(C.c_void_p), 0)
 L.fvh_debug_persist_timing(pt.ctypes.data_as(C.c_void_p), 0)
