@@ -55,11 +55,13 @@ struct CloudDev {
   DevBuf order;                        // Morton permutation: order[j] = original index of the j-th point along the curve
   DevBuf pts, cov, nbr, bbox, sorted;  // sorted: Morton-ordered copy, .w = original index; bbox: boxes of its 64-point tiles
   bool has_pts = false, has_cov = false, has_nbr = false, has_sorted = false;
+  DevBuf cov_sorted;                   // the covariances again, in Morton order (clouds the LM loop walks in that order: coalesced instead of gathered); has_cov_sorted: of the current cov
+  bool has_cov_sorted = false;
   bool nbr_tile_only = false;          // multi-GPU: the neighbour lists exist for this rank's tile only
   bool has_box = false;                // box holds the bounding cube of the CURRENT points (uploads that skip it: NDT, downsampler)
   bool box_dirty = false;              // box holds the cube of a cloud (cleared again by the cooperative sort that consumes it)
   void swap(CloudDev& o) { std::swap(*this, o); }
-  void release() { box.release(); pts.release(); cov.release(); nbr.release(); bbox.release(); bbox2.release(); sorted.release(); order.release(); }
+  void release() { box.release(); pts.release(); cov.release(); nbr.release(); bbox.release(); bbox2.release(); sorted.release(); order.release(); cov_sorted.release(); }
 };
 
 // Clouds of this size and up are walked in Morton order (PMC: 2.8x HBM over-fetch on a randomly ordered 100k scan
@@ -932,15 +934,24 @@ int calc_cov_knn(Engine* e, CloudDev& c, int method) {
     const Tile t = peer_tile(e, c.n);
     const int m = sharded ? (t.hi - t.lo) : c.n;                      // points this rank computes
     const int* subset = sharded ? c.order.as<int>() + t.lo : nullptr;  // ... its tile of the Morton order
+    // clouds the LM loop walks in Morton order: computed in that order too, and left a second time at the points' places along the curve
+    float4* cov_sorted = nullptr;
+    c.has_cov_sorted = false;
+    if (!sharded && e->precision != FVH_COMPUTE_CUDA_COMPAT && coherent_order(c)) {
+      HIP_OR_FAIL(e, c.cov_sorted.ensure(sizeof(float4) * 2 * (size_t)c.n));
+      subset = c.order.as<int>();
+      cov_sorted = c.cov_sorted.as<float4>();
+    }
     ProfScope ps(e, "cov");
     const int blocks = (int)(((long long)m * COV_LANES + 255) / 256);
     if (m > 0 && e->precision == FVH_COMPUTE_CUDA_COMPAT) {
       // FastVGICPCuda's own arithmetic: uncentred float sums in list order + Eigen's closed-form float eigen solver (kernels_cov.hpp)
       cov_from_neighbors_cuda_compat_kernel<<<(m + 255) / 256, 256, 0, e->stream>>>(c.pts.as<float4>(), m, c.k, c.nbr.as<int>(), method, c.cov.as<float4>(), subset);
     } else if (m > 0) {
-      if (c.k <= 20) cov_from_neighbors_kernel<5><<<blocks, 256, 0, e->stream>>>(c.pts.as<float4>(), m, c.k, c.nbr.as<int>(), method, c.cov.as<float4>(), subset);
-      else if (c.k <= 32) cov_from_neighbors_kernel<8><<<blocks, 256, 0, e->stream>>>(c.pts.as<float4>(), m, c.k, c.nbr.as<int>(), method, c.cov.as<float4>(), subset);
-      else cov_from_neighbors_regather_kernel<<<blocks, 256, 0, e->stream>>>(c.pts.as<float4>(), m, c.k, c.nbr.as<int>(), method, c.cov.as<float4>(), subset);
+      if (c.k <= 20) cov_from_neighbors_kernel<5><<<blocks, 256, 0, e->stream>>>(c.pts.as<float4>(), m, c.k, c.nbr.as<int>(), method, c.cov.as<float4>(), subset, cov_sorted);
+      else if (c.k <= 32) cov_from_neighbors_kernel<8><<<blocks, 256, 0, e->stream>>>(c.pts.as<float4>(), m, c.k, c.nbr.as<int>(), method, c.cov.as<float4>(), subset, cov_sorted);
+      else cov_from_neighbors_regather_kernel<<<blocks, 256, 0, e->stream>>>(c.pts.as<float4>(), m, c.k, c.nbr.as<int>(), method, c.cov.as<float4>(), subset, cov_sorted);
+      c.has_cov_sorted = cov_sorted != nullptr;
     }
   }
   HIP_OR_FAIL(e, hipGetLastError());
@@ -954,6 +965,7 @@ int calc_cov_rbf(Engine* e, CloudDev& c, double kernel_width, double max_dist, i
   if (method < 0 || method > 4) return e->fail(FVH_ERR_INVALID_ARGUMENT, "unknown regularization method");
   HIP_OR_FAIL(e, c.cov.ensure(sizeof(float4) * 2 * (size_t)std::max(c.n, 1)));
   const bool sharded = e->sharded();
+  c.has_cov_sorted = false;
   if (c.n) {
     const float md = (float)max_dist;
 #ifdef FVH_TEST_KERNELS  // test build only: FVH_RBF_MODE=0 full sweep, 2: eight queries per wave (both superseded by the one-query-per-wave sweep)
@@ -979,7 +991,10 @@ int calc_cov_rbf(Engine* e, CloudDev& c, double kernel_width, double max_dist, i
         // (single-wave workgroups, which shortened the k-NN kernel, change nothing here: 152 us either way -- this sweep keeps the VALU pipes 95 % busy)
         cov_rbf1_kernel<<<(t.hi - t.lo + 3) / 4, 256, 0, e->stream>>>(c.sorted.as<float4>(), c.bbox.as<float4>(), c.bbox2.as<float4>(), c.n, (float)kernel_width, md * md, method, c.cov.as<float4>(), t.lo, t.hi,
                                                                       e->rbf_sums.as<double>());
-        cov_rbf_finish_kernel<<<(t.hi - t.lo + 255) / 256, 256, 0, e->stream>>>(e->rbf_sums.as<double>(), c.sorted.as<float4>(), c.n, method, c.cov.as<float4>(), t.lo, t.hi);
+        float4* cov_sorted = nullptr;
+        if (!sharded && coherent_order(c)) { HIP_OR_FAIL(e, c.cov_sorted.ensure(sizeof(float4) * 2 * (size_t)c.n)); cov_sorted = c.cov_sorted.as<float4>(); }
+        cov_rbf_finish_kernel<<<(t.hi - t.lo + 255) / 256, 256, 0, e->stream>>>(e->rbf_sums.as<double>(), c.sorted.as<float4>(), c.n, method, c.cov.as<float4>(), t.lo, t.hi, cov_sorted);
+        c.has_cov_sorted = cov_sorted != nullptr;
       }
     }
   }
@@ -1002,6 +1017,7 @@ int set_cov_host(Engine* e, CloudDev& c, const double* covs9) {
   HIP_OR_FAIL(e, hipMemcpyAsync(c.cov.p, h.data(), sizeof(float4) * h.size(), hipMemcpyHostToDevice, e->stream));
   HIP_OR_FAIL(e, hipStreamSynchronize(e->stream));
   c.has_cov = true;
+  c.has_cov_sorted = false;
   return FVH_OK;
 }
 
@@ -1080,7 +1096,7 @@ int build_voxelmap(Engine* e, const CloudDev& c, VoxelMapDev& vm, double res, bo
       // from these cache-resident bits instead of a 64-byte HBM sector per probe. Four small launches after the finalize pass; maps
       // of this size are built once per localisation run, not once per registration.
       static const int bitmap_min = [] { const char* v = getenv("FVH_BITMAP_MIN_POINTS"); return v ? atoi(v) : 300000; }();
-      static const size_t bitmap_bytes = [] { const char* v = getenv("FVH_BITMAP_MAX_BYTES"); return v ? (size_t)atoll(v) : (size_t)(32u << 20); }();
+      static const size_t bitmap_bytes = [] { const char* v = getenv("FVH_BITMAP_MAX_BYTES"); return v ? std::min((size_t)atoll(v), (size_t)16 << 30) : (size_t)(32u << 20); }();  // (the LM kernel indexes the words with 32 bits)
       if (c.n >= bitmap_min && bitmap_bytes >= 8 && !shard) {  // (a shard is a fraction of the map: its keys stay cache-resident)
         HIP_OR_FAIL(e, vm.bitmap.ensure(bitmap_bytes));
         HIP_OR_FAIL(e, vm.grid.ensure(sizeof(VmGrid)));
@@ -1162,6 +1178,7 @@ struct CostSource {
   const int* counters2;  // source voxel map counters (D2D) or null
   const int* order;      // Morton permutation of the source (large clouds) or null
   const float4* sorted = nullptr;  // with `order`: the cloud's Morton-ordered copy (.w = original index) -- element order[j] is sorted[j]
+  const float4* cov_sorted = nullptr;  // with `sorted`, optional: the covariances in the same order
   int n_off_override = 0;  // > 0: correspondences per source element regardless of the handle's offset list (GICP: 1)
   bool shardable = false;  // the source elements are the points of a cloud with a Morton order: with peers attached each rank walks its tile
   bool external_find = false;  // FastGICP device LM: nn1_corr_kernel fills the correspondence buffers between the cost launches
@@ -1230,7 +1247,7 @@ int launch_cost(Engine* e, const CostSource& src, const VoxelMapDev& vm, int hos
                 const GridPlan* plan = nullptr /* align(): the layout both routes take (workgroups granted, groups, XCD confinement) */) {
   CostParams P;
   std::memset(&P, 0, sizeof(P));
-  P.src_pts = src.pts; P.src_cov = src.cov; P.d_n_src = src.d_n; P.n_src = src.n_upper; P.order = src.order; P.src_sorted = src.order ? src.sorted : nullptr;
+  P.src_pts = src.pts; P.src_cov = src.cov; P.d_n_src = src.d_n; P.n_src = src.n_upper; P.order = src.order; P.src_sorted = src.order ? src.sorted : nullptr; P.src_cov_sorted = (src.order && src.sorted) ? src.cov_sorted : nullptr;
   P.table = vm.table.as<uint4>(); P.keys = vm.keys_cur(); P.mask = vm.capacity - 1; P.res = vm.res; P.inv_res = 1.0 / vm.res;
   P.bitmap = vm.has_bitmap ? vm.bitmap.as<unsigned long long>() : nullptr;
   P.grid = vm.has_bitmap ? vm.grid.as<VmGrid>() : nullptr;
@@ -2051,7 +2068,7 @@ struct fvh_vgicp {
     // multi-GPU: the tiles are ranges of the Morton order whatever the size of the cloud (spatially compact shards)
     const int* order = e.sharded() ? (source.has_sorted ? source.order.as<int>() : nullptr) : coherent_order(source);
     CostSource c{source.pts.as<float4>(), source.cov.as<float4>(), nullptr, source.n, nullptr, order};
-    if (order) c.sorted = source.sorted.as<float4>();
+    if (order) { c.sorted = source.sorted.as<float4>(); if (source.has_cov_sorted) c.cov_sorted = source.cov_sorted.as<float4>(); }
     c.shardable = true;
     return c;
   }
@@ -2240,7 +2257,7 @@ int fvh_vgicp_gicp_swap_source_and_target(fvh_vgicp* h) {  // FastGICP::swapSour
   h->voxelmap.invalidate();
   return FVH_OK;
 }
-static void cloud_replaced(CloudDev& c) { c.has_cov = false; c.has_nbr = false; }
+static void cloud_replaced(CloudDev& c) { c.has_cov = false; c.has_nbr = false; c.has_cov_sorted = false; }
 // The Morton order of a VGICP cloud is queued right behind its upload: every neighbour search needs it (and large clouds walk the LM
 // loop in it), and the caller's next call -- find_*_neighbors as a rule -- would launch it a few microseconds of host time later
 // with the stream idle in between (kernel trace: 4 us between the pack kernel and the sort).

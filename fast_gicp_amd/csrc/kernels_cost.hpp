@@ -87,6 +87,7 @@ struct CostParams {
   const float4* src_cov;      // null for P2D
   const int* d_n_src;         // device-side count (D2D source voxels) or null
   const int* order;           // optional Morton permutation of the source: work item w handles element order[w] (coherent lookups)
+  const float4* src_cov_sorted;  // with `src_sorted`, optional: the covariances in Morton order (element order[w]: entries 2 w, 2 w + 1)
   const float4* src_sorted;   // with `order`, optional: the Morton-ordered copy of src_pts (.w = original index): the point of element order[w] is src_sorted[w] -- a coalesced load
   int n_src;
   const uint4* table;                // voxel records (64 B per bucket)
@@ -961,7 +962,10 @@ __global__ FVH_COST_BOUNDS void cost_kernel(CostParams P) {
     } else {
       const size_t row = (size_t)i * P.n_off + o_begin;
       a4 = *a4_src;
-      if (MODE != MODE_NDT_P2D && do_cost) { c0 = P.src_cov[2 * i]; c1 = P.src_cov[2 * i + 1]; }
+      if (MODE != MODE_NDT_P2D && do_cost) {
+        const float4* cv = P.src_cov_sorted ? P.src_cov_sorted + 2 * (size_t)i0 : P.src_cov + 2 * (size_t)i;  // (uniform choice)
+        c0 = cv[0]; c1 = cv[1];
+      }
       // (slots past the item's end read the item's last slot again and are masked BEHIND the branch: a select on a loaded value inside its
       // group would be a use of the load right behind its issue, and the next group's loads would wait for it)
       if (want_bo) {

@@ -709,7 +709,8 @@ constexpr int COV_LANES = 4, COV_MAX_PER_LANE = 16;  // k <= 64
 // The 64 points of a 256-thread workgroup (4 lanes each) hand their raw covariances to the FIRST wave through LDS, which
 // regularises one point per lane: the eigen-decomposition (~1,000 dependent fp64 instructions) runs once per workgroup instead of
 // once per wave with every value replicated four times. Called by all 256 threads.
-__device__ __forceinline__ void cov_regularize_dense(const Sym3<double>& C, int method, float4* __restrict__ cov, int i, bool owner /* one lane per valid point */) {
+__device__ __forceinline__ void cov_regularize_dense(const Sym3<double>& C, int method, float4* __restrict__ cov, int i, bool owner /* one lane per valid point */,
+                                                     float4* __restrict__ cov_sorted = nullptr /* optional second copy, at position pos0 + (point's number in this launch) */, int pos0 = 0) {
   __shared__ double s_c[64][6];
   __shared__ int s_i[64];
   const int p = threadIdx.x / COV_LANES;
@@ -720,12 +721,15 @@ __device__ __forceinline__ void cov_regularize_dense(const Sym3<double>& C, int 
   __syncthreads();
   if (threadIdx.x < 64 && s_i[threadIdx.x] >= 0) {
     const int t = threadIdx.x;
-    store_cov(cov, s_i[t], regularize_cov(Sym3<double>{s_c[t][0], s_c[t][1], s_c[t][2], s_c[t][3], s_c[t][4], s_c[t][5]}, method));
+    const Sym3<double> R = regularize_cov(Sym3<double>{s_c[t][0], s_c[t][1], s_c[t][2], s_c[t][3], s_c[t][4], s_c[t][5]}, method);
+    store_cov(cov, s_i[t], R);
+    if (cov_sorted) store_cov(cov_sorted, pos0 + (int)blockIdx.x * 64 + t, R);  // (64 points per workgroup, in launch order)
   }
 }
 template <int PER_LANE>  // neighbours a lane holds: k <= 4 * PER_LANE (5 for the reference's k = 20)
 __global__ __launch_bounds__(256) void cov_from_neighbors_kernel(const float4* __restrict__ pts, int n, int k, const int* __restrict__ nbr, int method,
-                                                                 float4* __restrict__ cov, const int* __restrict__ subset = nullptr /* n point indices (a rank's tile), or all */) {
+                                                                 float4* __restrict__ cov, const int* __restrict__ subset = nullptr /* n point indices (a rank's tile), or all */,
+                                                                 float4* __restrict__ cov_sorted = nullptr /* subset = the Morton order: the covariances again, in that order */) {
   const int gt = blockIdx.x * 256 + threadIdx.x;
   const int sub = gt % COV_LANES;
   const int i = subset ? subset[min(gt / COV_LANES, n - 1)] : min(gt / COV_LANES, n - 1);
@@ -765,14 +769,14 @@ __global__ __launch_bounds__(256) void cov_from_neighbors_kernel(const float4* _
   }
   const double inv = 1.0 / k;
   C.xx *= inv; C.xy *= inv; C.xz *= inv; C.yy *= inv; C.yz *= inv; C.zz *= inv;
-  cov_regularize_dense(C, method, cov, i, sub == 0 && gt / COV_LANES < n);
+  cov_regularize_dense(C, method, cov, i, sub == 0 && gt / COV_LANES < n, cov_sorted, 0);
 }
 
 // k > 32 (up to 64): the same four-lanes-per-point scheme, but the neighbours are gathered again for the centred pass instead
 // of being held in registers (the 16-per-lane instantiation of the kernel above needed 252 VGPRs + 928 spilled ones); the
 // second gather hits the lines the first one just brought in.
 __global__ __launch_bounds__(256) void cov_from_neighbors_regather_kernel(const float4* __restrict__ pts, int n, int k, const int* __restrict__ nbr, int method,
-                                                                          float4* __restrict__ cov, const int* __restrict__ subset = nullptr) {
+                                                                          float4* __restrict__ cov, const int* __restrict__ subset = nullptr, float4* __restrict__ cov_sorted = nullptr) {
   const int gt = blockIdx.x * 256 + threadIdx.x;
   const int sub = gt % COV_LANES;
   const int i = subset ? subset[min(gt / COV_LANES, n - 1)] : min(gt / COV_LANES, n - 1);
@@ -800,7 +804,7 @@ __global__ __launch_bounds__(256) void cov_from_neighbors_regather_kernel(const 
   }
   const double inv = 1.0 / k;
   C.xx *= inv; C.xy *= inv; C.xz *= inv; C.yy *= inv; C.yz *= inv; C.zz *= inv;
-  cov_regularize_dense(C, method, cov, i, sub == 0 && gt / COV_LANES < n);
+  cov_regularize_dense(C, method, cov, i, sub == 0 && gt / COV_LANES < n, cov_sorted, 0);
 }
 
 __global__ __launch_bounds__(256) void regularize_kernel(float4* __restrict__ cov, int n, int method) {
@@ -978,20 +982,22 @@ __global__ __launch_bounds__(256) void cov_rbf_tiled_kernel(const float4* __rest
 // PLANE regularisation is ~1,000 dependent fp64 instructions, and run by lane 0 of a one-query wave it cost a full wave's issue
 // slots per query -- 180 of this kernel's 300 us at 100k points.
 __device__ __forceinline__ void rbf_cov_from_sums(double W, double X, double Y, double Z, double XX, double XY, double XZ, double YY, double YZ, double ZZ, int method,
-                                                  float4* __restrict__ cov, int index) {
+                                                  float4* __restrict__ cov, int index, float4* __restrict__ cov_sorted = nullptr, int pos = 0) {
   const double iw = 1.0 / W;
   const double mx = X * iw, my = Y * iw, mz = Z * iw;
   Sym3<double> C;
   C.xx = XX * iw - mx * mx; C.xy = XY * iw - mx * my; C.xz = XZ * iw - mx * mz;
   C.yy = YY * iw - my * my; C.yz = YZ * iw - my * mz; C.zz = ZZ * iw - mz * mz;
-  store_cov(cov, index, regularize_cov(C, method));
+  const Sym3<double> R = regularize_cov(C, method);
+  store_cov(cov, index, R);
+  if (cov_sorted) store_cov(cov_sorted, pos, R);  // the same record at the point's place along the Morton curve (CloudDev::cov_sorted)
 }
-__global__ __launch_bounds__(256) void cov_rbf_finish_kernel(const double* __restrict__ sums, const float4* __restrict__ spts, int n, int method, float4* __restrict__ cov, int q_begin, int q_end) {
+__global__ __launch_bounds__(256) void cov_rbf_finish_kernel(const double* __restrict__ sums, const float4* __restrict__ spts, int n, int method, float4* __restrict__ cov, int q_begin, int q_end, float4* __restrict__ cov_sorted = nullptr) {
   const int q = q_begin + blockIdx.x * 256 + threadIdx.x;
   if (q >= min(n, q_end)) return;
   const size_t N = (size_t)n;
   rbf_cov_from_sums(sums[q], sums[N + q], sums[2 * N + q], sums[3 * N + q], sums[4 * N + q], sums[5 * N + q], sums[6 * N + q], sums[7 * N + q], sums[8 * N + q], sums[9 * N + q], method,
-                    cov, __float_as_int(spts[q].w));
+                    cov, __float_as_int(spts[q].w), cov_sorted, q);
 }
 __global__ __launch_bounds__(256) void cov_rbf1_kernel(const float4* __restrict__ spts, const float4* __restrict__ bbox1, const float4* __restrict__ bbox2, int n, float kernel_width,
                                                        float max_dist_sq, int method, float4* __restrict__ cov, int q_begin = 0, int q_end = 0x7fffffff,
