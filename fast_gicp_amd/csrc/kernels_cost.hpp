@@ -974,7 +974,11 @@ __global__ FVH_COST_BOUNDS void cost_kernel(CostParams P) {
       }
       if (want_ofp) {
 #pragma unroll
-        for (int c = 0; c < CH; c++) { const int oi = min(o_begin + c, o_end - 1); ofp[c] = (P.n_off <= OFFP_LDS) ? s_offp[oi] : P.offsets_packed[oi]; }
+        for (int c = 0; c < CH; c++) {
+          // (the table through a pointer TYPED as LDS: as two plain loads the compiler selected between the two ADDRESSES and issued one FLAT load)
+          const int oi = min(o_begin + c, o_end - 1);
+          ofp[c] = (P.n_off <= OFFP_LDS) ? ((LdsInt)s_offp)[oi] : P.offsets_packed[oi];
+        }
       } else if (want_b) {
         const int* src_ids = ext_fused ? corr_new : corr_old;
 #pragma unroll
