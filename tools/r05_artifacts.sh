@@ -6,6 +6,7 @@
 #   stats  rocprofv3 --kernel-trace --stats summaries of the same four commands
 #   bench  the default bench line
 # Every command has its own timeout and no stdin.  Usage: FVH_COMMIT=<sha> tools/r05_artifacts.sh [pmc|stats|bench|all]
+# Before sending it to the GPU box: python tools/build_variants.py knn_timing="-DFVH_KNN_TIMING"  (the pair counters of the pmc leg; ~2 GPU-minutes for `all`)
 set -u
 WHAT=${1:-all}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
