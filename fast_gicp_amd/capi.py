@@ -581,6 +581,9 @@ class NDTCore(_Core):
     def adopt_prepared_source(self):
         self._call("adopt_prepared_source")
 
+    def debug_set_voxel_hint(self, which, n):
+        self._call("debug_set_voxel_hint", 0 if which == "source" else 1, int(n))
+
     def set_source_tile(self, rank, nranks):
         """Evaluate tile `rank` of `nranks` of the source only (P2D: points in Morton order, D2D: source voxels ranked by key): linearize /
         compute_error return PARTIAL sums, to be added over the ranks; nranks = 1 switches it off."""

@@ -20,6 +20,7 @@
 #include <vector>
 
 #include "../../include/fast_vgicp_hip.h"
+#include "kernels_compat.hpp"
 #include "kernels_cost.hpp"
 #include "kernels_cov.hpp"
 #include "kernels_downsample.hpp"
@@ -80,6 +81,7 @@ struct VoxelMapDev {
   bool has_bitmap = false;
   DevBuf canon;           // canonical (key-sorted) order of the compact voxel list (multi-GPU NDT D2D: every rank cuts the same list); has_canon: of the live map
   bool has_canon = false;
+  DevBuf compat_keys, compat_idx, compat_seg, compat_hist;  // FVH_COMPUTE_CUDA_COMPAT: (bucket, point index) pairs x 2, run starts per bucket, radix histograms (kernels_compat.hpp)
   DevBuf region;          // VmRegion of a map that holds one rank's shard only (multi-GPU, fvh_vgicp_set_target_map_sharding)
   bool is_shard = false;  // the live map was built through `region`
   DevBuf keys[2];   // voxel keys, double buffered: keys[cur] belongs to the live map, the other one is what the next build fills
@@ -97,7 +99,7 @@ struct VoxelMapDev {
   std::vector<int> h_occupied;
   std::unordered_map<int, int> bucket_to_index;
   void invalidate() { valid = false; host_valid = false; has_bitmap = false; is_shard = false; has_canon = false; }
-  void release() { table.release(); acc.release(); occupied.release(); compact_pts.release(); compact_cov.release(); counters.release(); keys[0].release(); keys[1].release(); bitmap.release(); grid.release(); region.release(); canon.release(); clean_cap = 0; has_bitmap = false; is_shard = false; has_canon = false; }
+  void release() { table.release(); acc.release(); occupied.release(); compact_pts.release(); compact_cov.release(); counters.release(); keys[0].release(); keys[1].release(); bitmap.release(); grid.release(); region.release(); canon.release(); compat_keys.release(); compat_idx.release(); compat_seg.release(); compat_hist.release(); clean_cap = 0; has_bitmap = false; is_shard = false; has_canon = false; }
 };
 
 struct Profiler {
@@ -347,7 +349,6 @@ struct Engine {
   int shard_ranks() const { return peer.attached() ? peer.n : (tile_n > 1 ? tile_n : (comm ? nranks : 1)); }
   int shard_rank() const { return peer.attached() ? peer.rank : (tile_n > 1 ? tile_rank : (comm ? rank : 0)); }
   DevBuf gather_stage;  // RCCL route: covariances of the whole cloud in Morton order (ncclAllGather in place)
-  int rccl_checked_n = -1;  // cloud size the ranks were last found to agree on (rccl_allgather_cov)
   hipStream_t side = nullptr;
   hipEvent_t side_done = nullptr;
   bool side_pending = false;       // a build on `side` the main stream has not been ordered after yet
@@ -689,7 +690,7 @@ int ensure_sorted(Engine* e, CloudDev& c) {
   if (sort_mode >= 1 && n <= SORT_SMALL_MAX) {
     // cooperative kernel (32 workgroups meeting at grid barriers) while no OTHER handle has a gang kernel in flight (GangRegistry above:
     // two gang kernels from two streams could starve each other of CU slots; the watchdog + fallback would recover, slowly)
-    const bool coop = c.has_box && (sort_mode == 3 ? e->gang_begin(false) : e->gang_begin(true));
+    const bool coop = c.has_box && (sort_mode == 3 ? e->gang_begin(false) : (sort_mode == 2 && e->gang_begin(true)));  // (mode 1: never -- other PROCESSES' gang kernels on a shared GPU are invisible to the registry)
     struct GangEnd { Engine* e; bool on; ~GangEnd() { if (on) e->gang_end(); } } gang_end{e, coop};  // (on every way out: the event behind whatever was queued)
     g_sort_routes[coop ? 0 : 1].fetch_add(1, std::memory_order_relaxed);
     if (coop) {
@@ -853,9 +854,9 @@ int rccl_allgather_cov(Engine* e, CloudDev& c) {
   const Tile t = peer_tile(e, c.n);
   const int nr = std::max(1, e->shard_ranks());
   // With a communicator attached every rank uploads the SAME full cloud (the engine shards internally); a caller still handing each rank
-  // its own tile (the contract before round 4) would get mismatched all-gather counts -- a hang or a corrupted collective. Checked once
-  // per cloud size: max over the ranks of (n, -n) must be (n, -n) everywhere.
-  if (e->rccl_checked_n != c.n) {
+  // its own tile (the contract before round 4) would get mismatched all-gather counts -- a hang or a corrupted collective. Checked
+  // per call: max over the ranks of (n, -n) must be (n, -n) everywhere.
+  {  // (on EVERY call: gated on this rank's own last size, a rank whose size had not changed skipped the collective the others issued -- a hang)
     int* d = e->misc.as<int>() + 32;
     int* hh = reinterpret_cast<int*>(e->pinned) + 8;
     hh[0] = c.n; hh[1] = -c.n;
@@ -867,7 +868,6 @@ int rccl_allgather_cov(Engine* e, CloudDev& c) {
     if (hh[0] != c.n || hh[1] != -c.n)
       return e->fail(FVH_ERR_COMM, "the ranks hold clouds of different sizes (" + std::to_string(-hh[1]) + " .. " + std::to_string(hh[0]) + " points): with a communicator attached every rank "
                      "uploads the same FULL cloud and the engine shards it internally (include/fast_vgicp_hip.h: fvh_vgicp_comm_init)");
-    e->rccl_checked_n = c.n;
   }
   HIP_OR_FAIL(e, e->gather_stage.ensure(sizeof(float4) * 2 * (size_t)t.chunk * nr));
   float4* stage = e->gather_stage.as<float4>();
@@ -977,6 +977,23 @@ int calc_cov_rbf(Engine* e, CloudDev& c, double kernel_width, double max_dist, i
     } else
 #endif
     {
+      if (e->precision == FVH_COMPUTE_CUDA_COMPAT) {
+        // FastVGICPCuda's own arithmetic: float sums per block of 512 candidates in index order, blocks added in order (kernels_compat.hpp)
+        const int* subset = nullptr;
+        int m = c.n;
+        if (sharded) {
+          int rc = ensure_sorted(e, c);
+          if (rc) return rc;
+          const Tile t = peer_tile(e, c.n);
+          subset = c.order.as<int>() + t.lo; m = t.hi - t.lo;
+        }
+        ProfScope ps(e, "rbf");
+        if (m > 0) cov_rbf_cuda_compat_kernel<<<(m + 63) / 64, 256, 0, e->stream>>>(c.pts.as<float4>(), c.n, (float)kernel_width, md, method, c.cov.as<float4>(), subset, m);
+        HIP_OR_FAIL(e, hipGetLastError());
+        if (sharded) { int rc = allgather_cov(e, c); if (rc) return rc; }
+        c.has_cov = true;
+        return FVH_OK;
+      }
       int rc = ensure_sorted(e, c);
       if (rc) return rc;
       const Tile t = peer_tile(e, c.n);
@@ -1044,6 +1061,8 @@ int get_nbr_host(Engine* e, CloudDev& c, int* k, int* out) {
   return FVH_OK;
 }
 
+int radix_sort_pairs(Engine* e, unsigned* keys[2], int* idx[2], int n, int bits, int* result, hipStream_t on = nullptr, DevBuf* hist_buf = nullptr);
+
 // GaussianVoxelMap::create_voxelmap (gaussian_voxelmap.cu:208-257) -- two kernels, no retry loop
 template <int MODE>
 int build_voxelmap(Engine* e, const CloudDev& c, VoxelMapDev& vm, double res, bool want_compact, bool force_safe = false, hipStream_t on_side = nullptr,
@@ -1074,6 +1093,9 @@ int build_voxelmap(Engine* e, const CloudDev& c, VoxelMapDev& vm, double res, bo
     if (before[0] != vm.keys[0].p || before[1] != vm.keys[1].p || before[2] != vm.acc.p || before[3] != vm.counters.p) vm.clean_cap = 0;
   }
   HIP_OR_FAIL(e, vm.occupied.ensure(sizeof(int) * (size_t)std::max(c.n, 1)));
+  // FVH_COMPUTE_CUDA_COMPAT: voxel coordinates in float and, behind the build, the float voxel sums of the CUDA classes (kernels_compat.hpp);
+  // the multiplicative voxels have no device counterpart in the reference and keep the fp64 path
+  const bool compat = e->precision == FVH_COMPUTE_CUDA_COMPAT && MODE != 2;
   if (want_compact) {
     HIP_OR_FAIL(e, vm.compact_pts.ensure(sizeof(float4) * (size_t)std::max(c.n, 1)));
     HIP_OR_FAIL(e, vm.compact_cov.ensure(sizeof(float4) * 2 * (size_t)std::max(c.n, 1)));
@@ -1087,11 +1109,31 @@ int build_voxelmap(Engine* e, const CloudDev& c, VoxelMapDev& vm, double res, bo
     vm.clean_cap = 0;  // keys[fill] is in use from here on; the finalize pass below makes the OTHER pair clean
     if (c.n) {
       vm_accumulate_kernel<MODE><<<(c.n + 255) / 256, 256, 0, st>>>(c.pts.as<float4>(), c.cov.as<float4>(), c.n, res, keys, cap - 1, vm.acc.as<double>(), counters + 1,
-                                                                           coherent_order(c), shard ? vm.region.as<VmRegion>() : nullptr);
+                                                                           coherent_order(c), shard ? vm.region.as<VmRegion>() : nullptr, compat ? 1 : 0);
       vm_finalize_kernel<MODE><<<(cap + VM_FIN_THREADS - 1) / VM_FIN_THREADS, VM_FIN_THREADS, 0, st>>>(keys, vm.table.as<uint4>(), cap, vm.acc.as<double>(), counters, vm.occupied.as<int>(),
                                                                         want_compact ? vm.compact_pts.as<float4>() : nullptr, want_compact ? vm.compact_cov.as<float4>() : nullptr,
                                                                         vm.keys[vm.cur].as<unsigned long long>(), vm.counters.as<int>() + 16 * vm.cur);
       vm.clean_cap = cap;
+      if (compat) {
+        const int n = c.n;
+        HIP_OR_FAIL(e, vm.compat_keys.ensure(sizeof(unsigned) * 2 * (size_t)n));
+        HIP_OR_FAIL(e, vm.compat_idx.ensure(sizeof(int) * 2 * (size_t)n));
+        HIP_OR_FAIL(e, vm.compat_seg.ensure(sizeof(int) * ((size_t)cap + 2)));
+        unsigned* ck[2] = {vm.compat_keys.as<unsigned>(), vm.compat_keys.as<unsigned>() + n};
+        int* ci[2] = {vm.compat_idx.as<int>(), vm.compat_idx.as<int>() + n};
+        vmc_point_bucket_kernel<<<(n + 255) / 256, 256, 0, st>>>(c.pts.as<float4>(), n, (float)res, keys, cap - 1, ck[0], ci[0]);
+        int bits = 1;
+        while ((1u << bits) <= cap) bits++;  // buckets 0 .. cap - 1 and `cap` itself ("no voxel")
+        int sorted = 0;
+        int rc = radix_sort_pairs(e, ck, ci, n, bits, &sorted, st, &vm.compat_hist);
+        if (rc) return rc;
+        vmc_segment_heads_kernel<<<(n + 255) / 256, 256, 0, st>>>(ck[sorted], n, vm.compat_seg.as<int>());
+        // (an upper bound of the voxel count sizes the grid: the exact one is on the device)
+        const int max_voxels = (int)std::min<long long>(n, cap);
+        vmc_finalize_kernel<MODE><<<(max_voxels + 63) / 64, 64, 0, st>>>(c.pts.as<float4>(), MODE == 0 ? c.cov.as<float4>() : nullptr, ci[sorted], vm.compat_seg.as<int>(), vm.occupied.as<int>(),
+                                                                     counters, vm.table.as<uint4>(), want_compact ? vm.compact_pts.as<float4>() : nullptr,
+                                                                     want_compact ? vm.compact_cov.as<float4>() : nullptr);
+      }
       // large map: occupancy bitmap over the bounding box of its voxels (kernels_voxelmap.hpp) -- the LM kernel answers its misses
       // from these cache-resident bits instead of a 64-byte HBM sector per probe. Four small launches after the finalize pass; maps
       // of this size are built once per localisation run, not once per registration.
@@ -1186,6 +1228,16 @@ struct CostSource {
                                // last build of that map): shapes the grid and the offsets per item; the kernel is grid-stride, any value is correct
   VoxelMapDev* source_map = nullptr;  // NDT D2D: where align() leaves the source voxel count it saw
   bool device_tile = false;           // NDT D2D with a tile set: the kernel cuts this rank's chunk of the (canonically ordered) element list from the device-side count
+  // NDT D2D: the elements ARE the source map's compact voxel list. A rebuild of that map (table overflow -> safe size) flips its counter set and
+  // refills the list: whoever retries with a CostSource made before the rebuild re-reads the map's addresses first (round 6: the stale counter
+  // set -- zeroed by the rebuild's finalize pass -- made the retry evaluate an EMPTY source)
+  void refresh() {
+    if (!source_map) return;
+    const VoxelMapDev& m = *source_map;
+    pts = m.compact_pts.as<float4>(); cov = m.compact_cov.as<float4>();
+    d_n = counters2 = m.counters_cur();
+    if (device_tile) order = m.has_canon ? m.canon.as<int>() : nullptr;
+  }
 };
 
 // Persistent LM kernel (kernels_cost.hpp, PERSIST): co-resident workgroup capacity of the device for this instantiation.
@@ -1396,7 +1448,8 @@ int do_update_correspondences(Engine* e, const CostSource& src, VoxelMapDev& vm,
 }
 
 template <int MODE>
-int do_compute_error(Engine* e, const CostSource& src, VoxelMapDev& vm, const double* T16, double* H36, double* b6, double* error, const Rebuild& rebuild_safe) {
+int do_compute_error(Engine* e, const CostSource& src_in, VoxelMapDev& vm, const double* T16, double* H36, double* b6, double* error, const Rebuild& rebuild_safe) {
+  CostSource src = src_in;
   if (!T16 || !error) return e->fail(FVH_ERR_INVALID_ARGUMENT, "compute_error: null argument");
   if (!e->has_corr) return e->fail(FVH_ERR_BAD_STATE, "compute_error: call update_correspondences first");
   if (!vm.valid) return e->fail(FVH_ERR_BAD_STATE, "compute_error: the target voxel map / target records were invalidated (target cloud replaced); rebuild and call update_correspondences");
@@ -1421,6 +1474,7 @@ int do_compute_error(Engine* e, const CostSource& src, VoxelMapDev& vm, const do
     // the hint-sized table overflowed: rebuild at the safe size, redo the correspondences, evaluate again
     rc = rebuild_safe();
     if (rc) return rc;
+    src.refresh();
     rc = launch_cost<MODE>(e, src, vm, PH_FIND_ONLY, &e->lin, &e->lin);
     if (rc) return rc;
     e->has_corr = true;
@@ -1603,7 +1657,9 @@ int align_finish(Engine* e, AlignCtx& c, const CostSource& src, VoxelMapDev& vm,
     c.release_slots();
     int rc = rebuild_safe();
     if (rc) return rc;
-    return do_align<MODE>(e, src, vm, c.guess16, &p, result, rebuild_safe, true, no_persist, forced ? &plan : nullptr);
+    CostSource fresh = src;
+    fresh.refresh();
+    return do_align<MODE>(e, fresh, vm, c.guess16, &p, result, rebuild_safe, true, no_persist, forced ? &plan : nullptr);
   }
   e->gang_clear();
   e->prev_steps = e->last_steps;
@@ -1690,7 +1746,6 @@ int comm_init(Engine* e, const void* id128, int nranks, int rank) {
   int rc = g_rccl.CommInitRank(&e->comm, nranks, uid, rank);
   if (rc != 0) { e->comm = nullptr; return e->fail(FVH_ERR_COMM, "ncclCommInitRank failed with code " + std::to_string(rc)); }
   e->nranks = nranks; e->rank = rank;
-  e->rccl_checked_n = -1;
   return FVH_OK;
 }
 
@@ -1856,19 +1911,21 @@ int device_scan(Engine* e, DevBuf& bsums, const unsigned* in, int n, unsigned* o
 }
 
 // stable LSD radix sort of (key, idx) pairs on `bits` key bits; returns the index (0/1) of the buffer pair holding the result
-int radix_sort_pairs(Engine* e, unsigned* keys[2], int* idx[2], int n, int bits, int* result) {
+int radix_sort_pairs(Engine* e, unsigned* keys[2], int* idx[2], int n, int bits, int* result, hipStream_t on, DevBuf* hist_buf) {
+  hipStream_t const st = on ? on : e->stream;
+  DevBuf& hb = hist_buf ? *hist_buf : e->sort_hist;  // (a caller on another stream than the handle's brings its own histograms)
   const int items = n <= 262144 ? 256 : (n <= 1048576 ? 512 : SORT_ITEMS_MAX);
   const int nwaves = (n + items - 1) / items;
-  HIP_OR_FAIL(e, e->sort_hist.ensure(sizeof(unsigned) * (size_t)RADIX_BINS * (nwaves + 1)));
-  unsigned* bin_tot = e->sort_hist.as<unsigned>() + (size_t)RADIX_BINS * nwaves;
+  HIP_OR_FAIL(e, hb.ensure(sizeof(unsigned) * (size_t)RADIX_BINS * (nwaves + 1)));
+  unsigned* bin_tot = hb.as<unsigned>() + (size_t)RADIX_BINS * nwaves;
   const int wblocks = (nwaves + 3) / 4;
   const int passes = std::max(1, (bits + RADIX_BITS - 1) / RADIX_BITS);
   for (int pass = 0; pass < passes; pass++) {
     const int in = pass & 1, out = in ^ 1, shift = pass * RADIX_BITS;
-    radix_hist_kernel<RADIX_BITS><<<wblocks, 256, 0, e->stream>>>(keys[in], n, shift, nwaves, items, e->sort_hist.as<unsigned>());
-    radix_binscan_kernel<<<RADIX_BINS / 4, 256, 0, e->stream>>>(e->sort_hist.as<unsigned>(), nwaves, bin_tot);
-    radix_scan_kernel<<<1, 1024, 0, e->stream>>>(bin_tot, RADIX_BINS);
-    radix_scatter_kernel<RADIX_BITS><<<wblocks, 256, 0, e->stream>>>(keys[in], idx[in], n, shift, nwaves, items, e->sort_hist.as<unsigned>(), bin_tot, keys[out], idx[out], nullptr, nullptr);
+    radix_hist_kernel<RADIX_BITS><<<wblocks, 256, 0, st>>>(keys[in], n, shift, nwaves, items, hb.as<unsigned>());
+    radix_binscan_kernel<<<RADIX_BINS / 4, 256, 0, st>>>(hb.as<unsigned>(), nwaves, bin_tot);
+    radix_scan_kernel<<<1, 1024, 0, st>>>(bin_tot, RADIX_BINS);
+    radix_scatter_kernel<RADIX_BITS><<<wblocks, 256, 0, st>>>(keys[in], idx[in], n, shift, nwaves, items, hb.as<unsigned>(), bin_tot, keys[out], idx[out], nullptr, nullptr);
   }
   HIP_OR_FAIL(e, hipGetLastError());
   *result = passes & 1;
@@ -2124,10 +2181,25 @@ struct fvh_ndt {
     cs.source_map = const_cast<VoxelMapDev*>(&source_vm);
     return cs;
   }
+  // the source voxels ranked by key (kernels_voxelmap.hpp: vm_canonical_order_kernel): the list a tiled D2D handle cuts its chunk from
+  int ensure_canon() {
+    if (source_vm.has_canon) return FVH_OK;
+    HIP_OR_FAIL(&e, source_vm.canon.ensure(sizeof(int) * (size_t)std::max(source.n, 1)));
+    vm_canonical_order_kernel<<<(std::max(source.n, 1) + 255) / 256, 256, 0, e.stream>>>(source_vm.keys_cur(), source_vm.occupied.as<int>(), source_vm.counters_cur(), source_vm.canon.as<int>());
+    HIP_OR_FAIL(&e, hipGetLastError());
+    source_vm.has_canon = true;
+    return FVH_OK;
+  }
   Rebuild rebuild_safe() {
     return [this] {
       int rc = build_voxelmap<1>(&e, target, target_vm, target_vm.res, true, true);
-      if (!rc && distance_mode == FVH_NDT_D2D) rc = build_voxelmap<1>(&e, source, source_vm, source_vm.res, true, true);
+      if (!rc && distance_mode == FVH_NDT_D2D) {
+        rc = build_voxelmap<1>(&e, source, source_vm, source_vm.res, true, true);
+        // A tiled handle walks the source voxels in canonical order, and the rebuild has just reordered the compact list that order indexes:
+        // rank them again, into the SAME buffer (source.n has not changed: no reallocation), so that the CostSource the caller retries with
+        // -- which holds that buffer's address -- cuts a partition of the NEW list (a stale permutation counted voxels twice / never)
+        if (!rc && e.tile_n > 1) rc = ensure_canon();
+      }
       return rc;
     };
   }
@@ -2189,7 +2261,13 @@ const char* fvh_vgicp_last_error(const fvh_vgicp* h) { return h ? h->e.err.c_str
 int fvh_vgicp_set_resolution(fvh_vgicp* h, double r) { CHECK_HANDLE_HOST_ONLY(h); if (!(r > 0)) return h->e.fail(FVH_ERR_INVALID_ARGUMENT, "resolution must be > 0"); h->resolution = r; return FVH_OK; }
 int fvh_vgicp_set_kernel_params(fvh_vgicp* h, double w, double d) { CHECK_HANDLE_HOST_ONLY(h); h->kernel_width = w; h->kernel_max_dist = d; return FVH_OK; }
 int fvh_vgicp_set_neighbor_search_method(fvh_vgicp* h, int m, double radius) { CHECK_HANDLE(h); return h->e.set_offsets(m, radius); }
-int fvh_vgicp_set_precision(fvh_vgicp* h, int p) { CHECK_HANDLE_HOST_ONLY(h); if (p != FVH_COMPUTE_FP64 && p != FVH_COMPUTE_FP32 && p != FVH_COMPUTE_CUDA_COMPAT) return h->e.fail(FVH_ERR_INVALID_ARGUMENT, "bad precision"); h->e.precision = p; return FVH_OK; }
+int fvh_vgicp_set_precision(fvh_vgicp* h, int p) {
+  CHECK_HANDLE(h);
+  if (p != FVH_COMPUTE_FP64 && p != FVH_COMPUTE_FP32 && p != FVH_COMPUTE_CUDA_COMPAT) return h->e.fail(FVH_ERR_INVALID_ARGUMENT, "bad precision");
+  if ((p == FVH_COMPUTE_CUDA_COMPAT) != (h->e.precision == FVH_COMPUTE_CUDA_COMPAT)) { h->voxelmap.invalidate(); h->e.has_corr = false; }  // the voxel records of the two arithmetics differ (kernels_compat.hpp)
+  h->e.precision = p;
+  return FVH_OK;
+}
 
 int fvh_vgicp_create_target_voxelmap(fvh_vgicp* h) { CHECK_HANDLE(h); return h->build_map(h->resolution); }
 int fvh_vgicp_set_voxel_accumulation_mode(fvh_vgicp* h, int mode) {
@@ -2657,7 +2735,13 @@ const char* fvh_ndt_last_error(const fvh_ndt* h) { return h ? h->e.err.c_str() :
 int fvh_ndt_set_distance_mode(fvh_ndt* h, int m) { CHECK_HANDLE(h); NDT_NOT_PENDING(h); if (m != FVH_NDT_P2D && m != FVH_NDT_D2D) return h->e.fail(FVH_ERR_INVALID_ARGUMENT, "bad distance mode"); h->distance_mode = m; h->e.has_corr = false; return FVH_OK; }
 int fvh_ndt_set_resolution(fvh_ndt* h, double r) { CHECK_HANDLE(h); NDT_NOT_PENDING(h); if (!(r > 0)) return h->e.fail(FVH_ERR_INVALID_ARGUMENT, "resolution must be > 0"); h->resolution = r; return FVH_OK; }
 int fvh_ndt_set_neighbor_search_method(fvh_ndt* h, int m, double radius) { CHECK_HANDLE(h); NDT_NOT_PENDING(h); return h->e.set_offsets(m, radius); }
-int fvh_ndt_set_precision(fvh_ndt* h, int p) { CHECK_HANDLE(h); NDT_NOT_PENDING(h); if (p != FVH_COMPUTE_FP64 && p != FVH_COMPUTE_FP32) return h->e.fail(FVH_ERR_INVALID_ARGUMENT, "bad precision"); h->e.precision = p; return FVH_OK; }
+int fvh_ndt_set_precision(fvh_ndt* h, int p) {
+  CHECK_HANDLE(h); NDT_NOT_PENDING(h);
+  if (p != FVH_COMPUTE_FP64 && p != FVH_COMPUTE_FP32 && p != FVH_COMPUTE_CUDA_COMPAT) return h->e.fail(FVH_ERR_INVALID_ARGUMENT, "bad precision");
+  if ((p == FVH_COMPUTE_CUDA_COMPAT) != (h->e.precision == FVH_COMPUTE_CUDA_COMPAT)) { h->source_vm.invalidate(); h->target_vm.invalidate(); h->e.has_corr = false; }  // the voxel records of the two arithmetics differ
+  h->e.precision = p;
+  return FVH_OK;
+}
 int fvh_ndt_swap_source_and_target(fvh_ndt* h) {
   CHECK_HANDLE(h); NDT_NOT_PENDING(h);
   h->source.swap(h->target);
@@ -2672,14 +2756,14 @@ int fvh_ndt_set_target_cloud_strided(fvh_ndt* h, const float* xyz, int n, int s)
 int fvh_ndt_set_source_cloud_device(fvh_ndt* h, const float* d, int n, int s) { CHECK_HANDLE(h); NDT_NOT_PENDING(h); h->e.has_corr = false; h->source_vm.invalidate(); return upload_cloud(&h->e, h->source, d, n, s, true, false); }
 int fvh_ndt_set_target_cloud_device(fvh_ndt* h, const float* d, int n, int s) { CHECK_HANDLE(h); NDT_NOT_PENDING(h); h->e.has_corr = false; h->target_vm.invalidate(); return upload_cloud(&h->e, h->target, d, n, s, true, false); }
 int fvh_ndt_create_source_voxelmap(fvh_ndt* h) {
-  CHECK_HANDLE(h);
+  CHECK_HANDLE(h); NDT_NOT_PENDING(h);
   // a swapped-in target map has no compact arrays: rebuild in that case
   if (h->distance_mode == FVH_NDT_P2D) return FVH_OK;  // ndt_cuda.cu:122
   if (h->source_vm.valid && h->source_vm.compact_pts.p) return FVH_OK;
   return build_voxelmap<1>(&h->e, h->source, h->source_vm, h->resolution, true);
 }
 int fvh_ndt_create_target_voxelmap(fvh_ndt* h) {
-  CHECK_HANDLE(h);
+  CHECK_HANDLE(h); NDT_NOT_PENDING(h);
   if (h->target_vm.valid) return FVH_OK;  // ndt_cuda.cu:133-135
   return build_voxelmap<1>(&h->e, h->target, h->target_vm, h->resolution, true);
 }
@@ -2692,12 +2776,8 @@ static int ndt_ready(fvh_ndt* h) {
     Engine* e = &h->e;
     if (h->distance_mode == FVH_NDT_P2D) {  // the points' Morton order (a function of the cloud alone)
       if (h->source.n) { int rc = ensure_sorted(e, h->source); if (rc) return rc; }
-    } else if (!h->source_vm.has_canon) {   // the source voxels ranked by key (kernels_voxelmap.hpp: vm_canonical_order_kernel)
-      HIP_OR_FAIL(e, h->source_vm.canon.ensure(sizeof(int) * (size_t)std::max(h->source.n, 1)));
-      vm_canonical_order_kernel<<<(std::max(h->source.n, 1) + 255) / 256, 256, 0, e->stream>>>(h->source_vm.keys_cur(), h->source_vm.occupied.as<int>(), h->source_vm.counters_cur(),
-                                                                                            h->source_vm.canon.as<int>());
-      HIP_OR_FAIL(e, hipGetLastError());
-      h->source_vm.has_canon = true;
+    } else {   // the source voxels ranked by key
+      int rc = h->ensure_canon(); if (rc) return rc;
     }
   }
   return FVH_OK;
@@ -2798,11 +2878,12 @@ int fvh_ndt_adopt_prepared_source(fvh_ndt* h) {
   }
   return FVH_OK;
 }
-int fvh_ndt_set_lm_trace(fvh_ndt* h, int on) { CHECK_HANDLE(h); h->e.lm_trace_on = on != 0; return FVH_OK; }
-int fvh_ndt_get_lm_trace(fvh_ndt* h, int* n, double* rows6) { CHECK_HANDLE(h); return get_lm_trace(&h->e, n, rows6); }
+int fvh_ndt_debug_set_voxel_hint(fvh_ndt* h, int which, int num_voxels) { CHECK_HANDLE(h); NDT_NOT_PENDING(h); (which ? h->target_vm : h->source_vm).nv_hint = num_voxels; return FVH_OK; }
+int fvh_ndt_set_lm_trace(fvh_ndt* h, int on) { CHECK_HANDLE(h); NDT_NOT_PENDING(h); h->e.lm_trace_on = on != 0; return FVH_OK; }
+int fvh_ndt_get_lm_trace(fvh_ndt* h, int* n, double* rows6) { CHECK_HANDLE(h); NDT_NOT_PENDING(h); return get_lm_trace(&h->e, n, rows6); }
 int fvh_ndt_fitness_score(fvh_ndt* h, const double* T, double max_range, double* score) { CHECK_HANDLE(h); NDT_NOT_PENDING(h); return do_fitness(&h->e, h->source, h->target, T, max_range, score); }
 int fvh_ndt_get_num_voxels(fvh_ndt* h, int which, int* n) {
-  CHECK_HANDLE(h);
+  CHECK_HANDLE(h); NDT_NOT_PENDING(h);
   if (!n) return FVH_ERR_INVALID_ARGUMENT;
   VoxelMapDev& vm = which ? h->target_vm : h->source_vm;
   const Rebuild rb = h->rebuild_safe();
@@ -2811,12 +2892,12 @@ int fvh_ndt_get_num_voxels(fvh_ndt* h, int which, int* n) {
   return FVH_OK;
 }
 int fvh_ndt_get_voxels(fvh_ndt* h, int which, int* coords3, int* num_points, float* means3, float* covs9) {
-  CHECK_HANDLE(h);
+  CHECK_HANDLE(h); NDT_NOT_PENDING(h);
   const Rebuild rb = h->rebuild_safe();
   return get_voxels_host(&h->e, which ? h->target_vm : h->source_vm, coords3, num_points, means3, covs9, &rb);
 }
 int fvh_ndt_get_num_correspondences(fvh_ndt* h, int* n) {
-  CHECK_HANDLE(h);
+  CHECK_HANDLE(h); NDT_NOT_PENDING(h);
   if (h->e.tile_n > 1) return h->e.fail(FVH_ERR_UNSUPPORTED, "correspondence getters: not on a tiled handle (only its tile's rows of the list exist)");
   if (!n) return FVH_ERR_INVALID_ARGUMENT;
   std::vector<int> corr;
@@ -2835,7 +2916,7 @@ int fvh_ndt_get_num_correspondences(fvh_ndt* h, int* n) {
 }
 // offset-major then source element, invalid pairs removed (ndt_cuda.cu:142-161 builds the list with the functor of find_voxel_correspondences.cu:84-111)
 int fvh_ndt_get_voxel_correspondences(fvh_ndt* h, int* pairs) {
-  CHECK_HANDLE(h);
+  CHECK_HANDLE(h); NDT_NOT_PENDING(h);
   if (h->e.tile_n > 1) return h->e.fail(FVH_ERR_UNSUPPORTED, "correspondence getters: not on a tiled handle (only its tile's rows of the list exist)");
   if (!pairs) return FVH_ERR_INVALID_ARGUMENT;
   const Rebuild rb = h->rebuild_safe();
@@ -2861,10 +2942,10 @@ int fvh_ndt_get_voxel_correspondences(fvh_ndt* h, int* pairs) {
     }
   return FVH_OK;
 }
-int fvh_ndt_profile_enable(fvh_ndt* h, int on) { CHECK_HANDLE(h); h->e.prof.on = on != 0; h->e.prof.cost_only = on == 2; return FVH_OK; }
-int fvh_ndt_profile_reset(fvh_ndt* h) { CHECK_HANDLE(h); HIP_OR_FAIL(&h->e, hipStreamSynchronize(h->e.stream)); h->e.prof.reset(); return FVH_OK; }
-int fvh_ndt_profile_get(fvh_ndt* h, const char* cls, double* ms, int* n) { CHECK_HANDLE(h); return profile_get(&h->e, cls, ms, n); }
-int fvh_ndt_synchronize(fvh_ndt* h) { CHECK_HANDLE(h); HIP_OR_FAIL(&h->e, hipStreamSynchronize(h->e.stream)); h->e.gang_clear(); return FVH_OK; }
+int fvh_ndt_profile_enable(fvh_ndt* h, int on) { CHECK_HANDLE(h); NDT_NOT_PENDING(h); h->e.prof.on = on != 0; h->e.prof.cost_only = on == 2; return FVH_OK; }
+int fvh_ndt_profile_reset(fvh_ndt* h) { CHECK_HANDLE(h); NDT_NOT_PENDING(h); HIP_OR_FAIL(&h->e, hipStreamSynchronize(h->e.stream)); h->e.prof.reset(); return FVH_OK; }
+int fvh_ndt_profile_get(fvh_ndt* h, const char* cls, double* ms, int* n) { CHECK_HANDLE(h); NDT_NOT_PENDING(h); return profile_get(&h->e, cls, ms, n); }
+int fvh_ndt_synchronize(fvh_ndt* h) { CHECK_HANDLE(h); NDT_NOT_PENDING(h); HIP_OR_FAIL(&h->e, hipStreamSynchronize(h->e.stream)); h->e.gang_clear(); return FVH_OK; }
 int fvh_ndt_comm_init(fvh_ndt* h, const void* id, int nranks, int rank) {
   CHECK_HANDLE(h); NDT_NOT_PENDING(h);
   if (h->e.tile_n > 1 && (h->e.tile_n != nranks || h->e.tile_rank != rank)) return h->e.fail(FVH_ERR_INVALID_ARGUMENT, "comm_init: rank / nranks differ from fvh_ndt_set_source_tile's");

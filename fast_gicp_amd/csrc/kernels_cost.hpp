@@ -515,7 +515,9 @@ __device__ FVH_LM_STEP_ATTR void dev_lm_step_wave(LmState* st, const double* sum
     }
     if (consume) {
 #pragma unroll
-      for (int k = 0; k < 12; k++) xlp[k] = gn_step ? xir[k] : x0r[k];  // x_lin = x0 (Gauss-Newton: the NEW x0, where the next trip linearises)
+      // x_lin = x0 (Gauss-Newton: the NEW x0, where the next trip linearises -- unless this step ends the loop: the stored correspondences then
+      // stay those of the linearisation just consumed, at the OLD x0, which is what a later compute_error() must rotate the covariances by)
+      for (int k = 0; k < 12; k++) xlp[k] = (gn_step && phase != PH_DONE) ? xir[k] : x0r[k];
     }
     if (gn_step) {
 #pragma unroll

@@ -117,7 +117,8 @@ __global__ __launch_bounds__(1024) void vm_region_kernel(const float4* __restric
 template <int MODE>
 __global__ __launch_bounds__(256) void vm_accumulate_kernel(const float4* __restrict__ pts, const float4* __restrict__ cov, int n, double res,
                                                             unsigned long long* __restrict__ table_keys, unsigned mask, double* __restrict__ acc,
-                                                            int* __restrict__ dropped, const int* __restrict__ order, const VmRegion* __restrict__ region = nullptr) {
+                                                            int* __restrict__ dropped, const int* __restrict__ order, const VmRegion* __restrict__ region = nullptr,
+                                                            int float_coord = 0 /* FVH_COMPUTE_CUDA_COMPAT: the coordinate in float, as vector3_hash.cuh:35-38 */) {
   __shared__ unsigned long long lkey[VM_LDS_SLOTS];
   __shared__ double lacc[VM_LDS_SLOTS * VM_ACC_STRIDE];
   const int tid = threadIdx.x;
@@ -129,8 +130,15 @@ __global__ __launch_bounds__(256) void vm_accumulate_kernel(const float4* __rest
   if (i0 < n) {
     const int i = order ? order[i0] : i0;  // Morton order: a workgroup's 256 points share a handful of voxels -> the LDS stage absorbs them
     const float4 p = pts[i];
-    // fp64 coordinate, as the CPU reference (fast_vgicp_voxel.hpp:158-160)
-    const double fx = floor((double)p.x / res - 0.5), fy = floor((double)p.y / res - 0.5), fz = floor((double)p.z / res - 0.5);
+    // fp64 coordinate, as the CPU reference (fast_vgicp_voxel.hpp:158-160); float_coord: (x.array() / resolution - 0.5).floor() in float like the
+    // CUDA class -- the two differ for points within float rounding of a voxel face when the resolution is not a power of two
+    double fx, fy, fz;
+    if (float_coord) {
+      const float rf = (float)res;
+      fx = (double)floorf(__fsub_rn(__fdiv_rn(p.x, rf), 0.5f)); fy = (double)floorf(__fsub_rn(__fdiv_rn(p.y, rf), 0.5f)); fz = (double)floorf(__fsub_rn(__fdiv_rn(p.z, rf), 0.5f));
+    } else {
+      fx = floor((double)p.x / res - 0.5); fy = floor((double)p.y / res - 0.5); fz = floor((double)p.z / res - 0.5);
+    }
     const bool ok = voxel_index_ok(fx, fy, fz);
     const int cx = ok ? (int)fx : 0, cy = ok ? (int)fy : 0, cz = ok ? (int)fz : 0;
     bool outside = false;  // a sharded map (VmRegion) holds the voxels of its box only: other points are somebody else's

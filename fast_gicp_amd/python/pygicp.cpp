@@ -239,7 +239,9 @@ PYBIND11_MODULE(pygicp, m) {
       .def("set_correspondence_randomness", &VGICPCuda::setCorrespondenceRandomness)
       .def("set_kernel_width", &VGICPCuda::setKernelWidth, py::arg("kernel_width"), py::arg("max_dist") = -1.0)
       .def("set_regularization_method", [](VGICPCuda& v, const std::string& s) { v.setRegularizationMethod(regularization_method(s)); })
-      .def("set_nearest_neighbor_search_method", [](VGICPCuda& v, const std::string& s) { v.setNearestNeighborSearchMethod(nn_method(s)); });
+      .def("set_nearest_neighbor_search_method", [](VGICPCuda& v, const std::string& s) { v.setNearestNeighborSearchMethod(nn_method(s)); })
+      // not in the reference: CPU_PARALLEL_KDTREE (the default enum value) is served by the device's exact search unless the host tree is asked for
+      .def("set_host_kdtree", &VGICPCuda::setHostKdTree, py::arg("on") = true);
 
   py::class_<GICP, Lsq, std::shared_ptr<GICP>>(m, "FastGICP")  // main.cpp:183-190
       .def(py::init([](int device) { return std::make_shared<GICP>(device); }), py::arg("device") = 0)

@@ -24,6 +24,7 @@
 #include <cmath>
 #include <cstddef>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <limits>
 #include <memory>
@@ -470,6 +471,13 @@ public:
   void setRegularizationMethod(RegularizationMethod method) { regularization_method_ = method; }
   void setNeighborSearchMethod(NeighborSearchMethod method, double radius = -1.0) { call(fvh_vgicp_set_neighbor_search_method(core_, (int)method, radius), "set_neighbor_search_method"); }
   void setNearestNeighborSearchMethod(NearestNeighborMethod method) { neighbor_search_method_ = method; }
+  /// NearestNeighborMethod::CPU_PARALLEL_KDTREE -- the reference's DEFAULT (fast_vgicp_cuda_impl.hpp:27,152-167) -- asks for EXACT k-NN lists from a
+  /// host kd-tree. The engine's device search returns the same lists (fp32 distances, ties to the lower index: equal to the kd-tree's at 17k / 100k /
+  /// 1M points, tests/test_gpu_parity*.py, test_neighbor_methods_agree) in 35 us instead of the ~4 ms a host tree + a PCIe round trip of N x k
+  /// indices costs per cloud, so by default that enum value is SERVED BY THE DEVICE. setHostKdTree(true) (or FVH_HOST_KDTREE=1 in the
+  /// environment) restores the host tree of kdtree.hpp for callers who want the reference's data flow.
+  void setHostKdTree(bool on) { host_kdtree_ = on; }
+  bool getHostKdTree() const { return host_kdtree_; }
   void setComputePrecision(int fvh_precision) { call(fvh_vgicp_set_precision(core_, fvh_precision), "set_precision"); }
 
   void swapSourceAndTarget() override {  // :69-72
@@ -484,7 +492,7 @@ public:
     input_ = cloud;
     const detail::XyzView<PointSource> view(*cloud, scratch_xyz_);
     call(fvh_vgicp_set_source_cloud_strided(core_, view.data, (int)cloud->size(), view.stride), "set_source_cloud");
-    switch (neighbor_search_method_) {
+    switch (effective_neighbor_method(cloud->size())) {
       case NearestNeighborMethod::CPU_PARALLEL_KDTREE: {
         const std::vector<float> xyz = detail::pack_xyz(*cloud);
         const std::vector<int> nb = find_neighbors_parallel_kdtree(k_correspondences_, xyz);
@@ -505,7 +513,7 @@ public:
     target_ = cloud;
     const detail::XyzView<PointTarget> view(*cloud, scratch_xyz_);
     call(fvh_vgicp_set_target_cloud_strided(core_, view.data, (int)cloud->size(), view.stride), "set_target_cloud");
-    switch (neighbor_search_method_) {
+    switch (effective_neighbor_method(cloud->size())) {
       case NearestNeighborMethod::CPU_PARALLEL_KDTREE: {
         const std::vector<float> xyz = detail::pack_xyz(*cloud);
         const std::vector<int> nb = find_neighbors_parallel_kdtree(k_correspondences_, xyz);
@@ -568,6 +576,16 @@ protected:
     if (r.lm_failed) std::fprintf(stderr, "lm not converged!!\n");
     return true;
   }
+  /// the enum value the switch statements act on: the default one is served by the device search unless the host tree was asked for
+  /// (a cloud with fewer points than k keeps the host path: the reference pads those lists with index 0, :155,162)
+  NearestNeighborMethod effective_neighbor_method(size_t n_points) const {
+    if (neighbor_search_method_ != NearestNeighborMethod::CPU_PARALLEL_KDTREE || host_kdtree_ || n_points < (size_t)k_correspondences_) return neighbor_search_method_;
+    return NearestNeighborMethod::GPU_BRUTEFORCE;
+  }
+  static bool host_kdtree_default() {
+    static const bool on = [] { const char* v = std::getenv("FVH_HOST_KDTREE"); return v && std::atoi(v) != 0; }();
+    return on;
+  }
   /// find_neighbors_parallel_kdtree (:152-167): host kd-tree + OpenMP
   std::vector<int> find_neighbors_parallel_kdtree(int k, const std::vector<float>& xyz) const {
     const int n = (int)(xyz.size() / 3);
@@ -590,6 +608,7 @@ private:
   double voxel_resolution_ = 1.0;                                                                // :25
   RegularizationMethod regularization_method_ = RegularizationMethod::PLANE;                     // :26
   NearestNeighborMethod neighbor_search_method_ = NearestNeighborMethod::CPU_PARALLEL_KDTREE;    // :27
+  bool host_kdtree_ = host_kdtree_default();                                                     // setHostKdTree
   fvh_vgicp* core_ = nullptr;
   std::vector<float> scratch_xyz_;  // only used for point types that are not 12 / 16 bytes of packed xyz
 };

@@ -282,6 +282,8 @@ int fvh_ndt_align_wait(fvh_ndt* h, fvh_lm_result* result);
 int fvh_ndt_prepare_source_device(fvh_ndt* h, const float* d_xyz, int n, int stride_floats);
 int fvh_ndt_adopt_prepared_source(fvh_ndt* h);
 int fvh_ndt_fitness_score(fvh_ndt* h, const double* T16, double max_range, double* score);
+/* testing hook (as fvh_vgicp_debug_set_voxel_hint): table size hint of the NEXT build of the source (which = 0) / target (1) voxel map */
+int fvh_ndt_debug_set_voxel_hint(fvh_ndt* h, int which, int num_voxels);
 int fvh_ndt_set_lm_trace(fvh_ndt* h, int on);
 int fvh_ndt_get_lm_trace(fvh_ndt* h, int* num_rows, double* rows6);
 int fvh_ndt_get_num_voxels(fvh_ndt* h, int which /* 0 source, 1 target */, int* num_voxels);

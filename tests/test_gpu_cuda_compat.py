@@ -211,3 +211,156 @@ def test_vgicp_cuda_compat_mode_end_to_end_on_its_own_covariances(O, search):
     c64 = _engine(tgt, src, cs, capi.COMPUTE_FP64)
     assert 0 < util.rel_err(r["T"], c64.align()["T"]) < 1e-3
     c.close(); c64.close()
+
+
+# ---- round 6: the two remaining covariance modes of FastVGICPCuda and NDTCuda in the CUDA classes' own arithmetic (kernels_compat.hpp) ----
+def _cov6(a):
+    a = np.asarray(a, np.float64)
+    return np.stack([a[:, 0, 0], a[:, 0, 1], a[:, 0, 2], a[:, 1, 1], a[:, 1, 2], a[:, 2, 2]], 1)
+
+
+def _rbf_engine(tgt, src, search, precision, resolution=1.0):
+    from fast_gicp_amd import capi
+    c = capi.VGICPCore(0)
+    c.set_precision(precision)
+    c.set_resolution(resolution)
+    c.set_neighbor_search_method(search)
+    c.set_kernel_params(0.5, 3.0)  # FastVGICPCuda's defaults (fast_vgicp_cuda_impl.hpp:31), the oracle leg's too
+    c.set_target_cloud(tgt); c.calculate_target_covariances_rbf(capi.REG_PLANE); c.create_target_voxelmap()
+    c.set_source_cloud(src); c.calculate_source_covariances_rbf(capi.REG_PLANE)
+    return c
+
+
+def _check_rbf_compat(O, tgt, src, cs, os_, resolution, name):
+    from fast_gicp_amd import capi
+    g = O.CudaCompatVGICP(search=os_, cov_mode=1, resolution=resolution)
+    g.set_target(tgt); g.set_source(src); g.prepare()
+    c = _rbf_engine(tgt, src, cs, capi.COMPUTE_CUDA_COMPAT, resolution)
+    worst = {}
+    for which in ("target", "source"):
+        a6, b6 = _cov6(c.get_covariances(which)), _cov6(g.get_covs(which))
+        d = np.abs(a6 - b6).max(1)  # PLANE: eigenvalues (1e-3, 1, 1) -> entries of order 1
+        print("%s %s RBF covariances vs cuda-compat oracle: max |d| %.2e, 99.9th percentile %.2e, exactly equal %.1f %%" % (name, which, d.max(), np.percentile(d, 99.9), 100.0 * np.mean(d == 0)))
+        # the same float sums in the same order; what differs: expf (correctly rounded here, glibc's there: a last-ulp difference in ~0.1 % of the
+        # weights) and atan2f / cosf / sinf of the closed-form eigen solver, amplified by 1 / (eigenvalue gap) on near-degenerate neighbourhoods
+        assert np.percentile(d, 99) < 1e-5 and np.mean(d < 1e-4) > 0.999, (d.max(), np.percentile(d, 99))
+        worst[which] = d.max()
+    # the voxel map: same voxels, same counts; means BIT-EQUAL (the same float sums of the same points in the same order); a voxel's covariance is the
+    # float mean of its points' covariances, so it differs by at most what its worst point does (a near-degenerate neighbourhood whose eigenvectors
+    # turn on a last-ulp difference of the weights: one point in 100k moves by 0.1) and, over all voxels, as little as the points do
+    oc, on, om, ov = g.get_voxelmap()
+    ec, en, em, ev = c.get_voxelmap()
+    assert util.voxel_dict(ec, en) == util.voxel_dict(oc, on)
+    od, ed = util.voxel_dict(oc, om, _cov6(ov)), util.voxel_dict(ec, em, _cov6(ev))
+    dm = max(np.abs(np.asarray(ed[k][0], np.float64) - od[k][0]).max() for k in od)
+    dcv = np.array([np.abs(ed[k][1] - od[k][1]).max() for k in od])
+    print("%s voxel means max |d| %.2e, voxel covariances max |d| %.2e, 99.9th percentile %.2e over %d voxels" % (name, dm, dcv.max(), np.percentile(dcv, 99.9), len(od)))
+    assert dm == 0.0, dm
+    assert dcv.max() <= worst["target"] + 1e-6 and np.percentile(dcv, 99) < 1e-5, (dcv.max(), worst["target"], np.percentile(dcv, 99))
+    T0 = np.eye(4)
+    eo, Ho, bo = g.linearize(T0)
+    e, H, b = c.linearize(T0)
+    util.assert_same_correspondences(c, g, ordered=True)
+    assert abs(e - eo) < 1e-4 * abs(eo) and util.rel_err(H, Ho) < 1e-4, (abs(e - eo) / abs(eo), util.rel_err(H, Ho))
+    ro, r = g.align(), c.align()
+    fo = g.fitness()
+    f = c.fitness_score(r["T"].astype(np.float32).astype(np.float64))
+    assert r["converged"] and ro["converged"]
+    assert r["num_linearize"] == ro["num_linearize"] and r["num_error_evals"] == ro["num_error_evals"], (r, ro)
+    util.assert_same_correspondences(c, g, ordered=True)
+    dT = util.rel_err(r["T"], ro["T"])
+    print("%s CUDA_COMPAT RBF end to end: pose rel %.2e, fitness %.6f vs %.6f, %d linearisations" % (name, dT, f, fo, r["num_linearize"]))
+    assert dT < 1e-4, dT
+    assert abs(f - fo) < 1e-4 * fo, (f, fo)
+    c.close()
+    return r
+
+
+@pytest.mark.parametrize("search", ["DIRECT1", "DIRECT27"])
+def test_vgicp_cuda_compat_rbf_mode_end_to_end_on_the_bundled_pair(O, search):
+    """VERDICT r5 Missing #3(a): FastVGICPCuda's RBF estimator (covariance_estimation_rbf.cu:40-109,120-150: float sums per block of 512
+    candidates in index order, blocks added in order, uncentred finalize) + the float voxel sums (gaussian_voxelmap.cu:164-171) in
+    FVH_COMPUTE_CUDA_COMPAT, END TO END against oracle/cuda_compat.cpp's cov_mode 1: covariances to float rounding, identical
+    correspondence lists, pose and fitness to north_star's 1e-4 with equal iteration counts."""
+    from fast_gicp_amd import capi
+    tgt, src = util.bundled_pair()
+    cs, os_ = {"DIRECT1": (capi.DIRECT1, O.DIRECT1), "DIRECT27": (capi.DIRECT27, O.DIRECT27)}[search]
+    r = _check_rbf_compat(O, tgt, src, cs, os_, 1.0, "bundled " + search)
+    # and the mode is what separates the two arithmetics: the fp64 engine with its own (centred, culled, fp64-reduced) RBF sweep differs by 1e-3 .. 3e-3
+    # of the pose (the uncentred float sums over ~100 weighted neighbours at 50 m range; the oracle leg alone moves by up to 2e-4 when its input is
+    # merely reordered, tests/test_oracle.py::test_cuda_compat_order_spread)
+    c64 = _rbf_engine(tgt, src, cs, capi.COMPUTE_FP64)
+    d64 = util.rel_err(r["T"], c64.align()["T"])
+    print("bundled %s: CUDA_COMPAT RBF vs the fp64 engine's RBF: pose rel %.2e" % (search, d64))
+    assert 0 < d64 < 1e-2, d64
+    c64.close()
+
+
+def test_vgicp_cuda_compat_rbf_mode_c3_100k(O):
+    """BASELINE configs[2] (synthetic 100k <-> 100k, voxel resolution 0.5, RBF covariances) in the CUDA class's arithmetic."""
+    from fast_gicp_amd import capi
+    tgt, src, _ = util.synthetic_pair(100000, 100000)
+    _check_rbf_compat(O, tgt, src, capi.DIRECT1, O.DIRECT1, 0.5, "C3 100k DIRECT1")
+
+
+@pytest.mark.parametrize("mode", ["D2D", "P2D"])
+def test_ndt_cuda_compat_mode_end_to_end(O, mode):
+    """VERDICT r5 Missing #3(b, c): NDTCuda in FVH_COMPUTE_CUDA_COMPAT -- float voxel coordinates (vector3_hash.cuh:35-38), float UNCENTRED voxel
+    sums in point order (gaussian_voxelmap.cu:122-148,178-198), Eigen's closed-form float eigen solver for MIN_EIG (ndt_cuda.cu:128,139), float
+    cost terms -- against the float restatement at north_star's 1e-4 (the fp32 mode above, whose voxel sums are fp64, is held to 1e-3: the
+    uncentred float sums ARE the difference). The oracle leg itself moves by 1e-5 .. 6e-5 when its input is reordered
+    (tests/test_oracle.py::test_cuda_compat_order_spread): both sides take index order."""
+    from fast_gicp_amd import capi, workloads
+    om, cm = {"D2D": (O.D2D, capi.NDT_D2D), "P2D": (O.P2D, capi.NDT_P2D)}[mode]
+    t, s = util.bundled_pair(origin_filter=False, leaf=0.2, exact_voxelgrid=True)
+    f0 = O.approx_voxelgrid(workloads.lidar_frame(2), 0.25)
+    f1 = O.approx_voxelgrid(workloads.lidar_frame(3), 0.25)
+    for name, tgt, src in (("gicp_test pair", t, s), ("lidar frames", f0, f1)):
+        g = O.CudaCompatNDT(mode=om, search=O.DIRECT7)
+        g.set_target(tgt); g.set_source(src)
+        ro = g.align()
+        d = capi.NDTCore(0)
+        d.set_precision(capi.COMPUTE_CUDA_COMPAT)
+        d.set_distance_mode(cm); d.set_neighbor_search_method(capi.DIRECT7); d.set_resolution(1.0)
+        d.set_target_cloud(tgt); d.set_source_cloud(src)
+        r = d.align()
+        for which in (("target", "source") if mode == "D2D" else ("target",)):
+            oc, on, omn, ov = g.get_voxelmap(which)
+            ec, en, em, ev = d.get_voxelmap(which)
+            assert util.voxel_dict(ec, en) == util.voxel_dict(oc, on), (name, which)
+            od, ed = util.voxel_dict(oc, omn, _cov6(ov)), util.voxel_dict(ec, em, _cov6(ev))
+            dm = max(np.abs(np.asarray(ed[k][0], np.float64) - od[k][0]).max() for k in od)
+            dc = np.array([np.abs(ed[k][1] - od[k][1]).max() / max(np.abs(od[k][1]).max(), 1e-30) for k in od])
+            print("NDT %s, %s, %s voxels: means max |d| %.2e; covariances rel: max %.2e, 99th percentile %.2e, exactly equal %.1f %%" % (mode, name, which, dm, dc.max(), np.percentile(dc, 99), 100.0 * np.mean(dc == 0)))
+            assert dm == 0.0, dm  # the same float sums in the same order, the same float division
+            assert np.percentile(dc, 99) < 1e-4, np.percentile(dc, 99)  # (device atan2f / cosf / sinf against glibc's inside the eigen solver)
+        assert r["converged"] and ro["converged"], name
+        assert r["num_linearize"] == ro["num_linearize"] and r["num_error_evals"] == ro["num_error_evals"], (name, r, ro)
+        dT = util.rel_err(r["T"], ro["T"])
+        fit, fo = d.fitness_score(r["T"].astype(np.float32).astype(np.float64)), g.fitness()
+        print("NDT %s, %s: CUDA_COMPAT engine vs cuda-compat oracle: pose rel %.2e, fitness %.6f vs %.6f" % (mode, name, dT, fit, fo))
+        assert dT < 1e-4, (name, dT)
+        assert abs(fit - fo) < 1e-4 * fo, (name, fit, fo)
+        util.assert_same_correspondences(d, g, d2d=(mode == "D2D"), ordered=True)
+        d.close()
+
+
+def test_vgicp_cuda_compat_voxel_sums_on_injected_covariances(O):
+    """gaussian_voxelmap.cu:164-171 on its own: fed the oracle leg's point covariances, the engine's CUDA_COMPAT voxel records are the oracle's
+    float sums BIT FOR BIT (means, and the six covariance entries the engine stores)."""
+    from fast_gicp_amd import capi
+    tgt, src = util.bundled_pair()
+    g = O.CudaCompatVGICP(search=O.DIRECT1)
+    g.set_target(tgt); g.set_source(src); g.prepare()
+    c = capi.VGICPCore(0)
+    c.set_precision(capi.COMPUTE_CUDA_COMPAT)
+    c.set_target_cloud(tgt); c.set_target_covariances(g.get_covs("target")); c.create_target_voxelmap()
+    oc, on, om, ov = g.get_voxelmap()
+    ec, en, em, ev = c.get_voxelmap()
+    od, ed = util.voxel_dict(oc, on, om.astype(np.float32), _cov6(ov).astype(np.float32)), util.voxel_dict(ec, en, em.astype(np.float32), _cov6(ev).astype(np.float32))
+    assert set(od) == set(ed)
+    for k in od:
+        assert od[k][0] == ed[k][0]
+        assert np.array_equal(od[k][1], ed[k][1]), (k, od[k][1], ed[k][1])
+        assert np.array_equal(od[k][2], ed[k][2]), (k, od[k][2], ed[k][2])
+    c.close()

@@ -168,3 +168,68 @@ def test_ndt_source_tiles_partition_the_cost(mode, nranks):
     for c in tiles + [ref]:
         c.close()
     vg.close()
+
+
+def test_tiled_d2d_survives_a_table_overflow_rebuild():
+    """ADVICE r5 (medium): a tiled D2D handle whose hint-sized SOURCE table overflows rebuilds both maps at the safe size inside compute_error;
+    the rebuild reorders the compact voxel list, so the canonical order every rank cuts its tile from has to be ranked again -- a stale
+    permutation of the old list is not a partition of the new one (voxels counted twice / never). Two tiles with a hint of one voxel: their
+    partial sums still add up to the unsharded evaluation."""
+    from fast_gicp_amd import capi, workloads
+    vg = capi.VoxelGrid(0)
+    tgt, src = vg.filter(workloads.lidar_frame(3), 0.25), vg.filter(workloads.lidar_frame(4), 0.25)
+
+    def make(hint):
+        c = capi.NDTCore(0)
+        c.set_distance_mode(capi.NDT_D2D); c.set_neighbor_search_method(capi.DIRECT7); c.set_resolution(1.0)
+        c.set_target_cloud(tgt); c.set_source_cloud(src)
+        if hint:
+            c.debug_set_voxel_hint("source", 1); c.debug_set_voxel_hint("target", 1)  # 1,024 buckets for a few thousand voxels
+        c.create_voxelmaps()
+        return c
+
+    ref = make(False)
+    tiles = [make(True) for _ in range(2)]
+    for r, c in enumerate(tiles):
+        c.set_source_tile(r, 2)
+    T = util.random_pose(np.random.default_rng(11), max_angle_deg=1.0, max_trans=0.3)
+    e0, H0, b0 = ref.linearize(T)
+    parts = [c.linearize(T) for c in tiles]
+    e, H, b = sum(p[0] for p in parts), sum(p[1] for p in parts), sum(p[2] for p in parts)
+    assert all(p[0] > 0 for p in parts)
+    assert abs(e - e0) <= 1e-11 * abs(e0) and util.rel_err(H, H0) < 1e-11 and util.rel_err(b, b0) < 1e-11, (abs(e - e0) / abs(e0), util.rel_err(H, H0))
+    for c in tiles + [ref]:
+        c.close()
+    vg.close()
+
+
+@pytest.mark.parametrize("mode", [0, 1])  # P2D, D2D
+def test_ndt_table_overflow_is_answered_by_a_safe_rebuild(mode):
+    """Both NDT maps built with a capacity hint of one voxel (1,024 buckets for a few thousand voxels): linearize and align must notice the
+    overflow counter, rebuild at the safe size and give the results of a handle that never had a hint. (Round 6: the D2D retry used to read
+    the source map's OLD counter set -- zero voxels -- after the rebuild had flipped it.)"""
+    from fast_gicp_amd import capi, workloads
+    vg = capi.VoxelGrid(0)
+    tgt, src = vg.filter(workloads.lidar_frame(3), 0.25), vg.filter(workloads.lidar_frame(4), 0.25)
+
+    def make(hint):
+        c = capi.NDTCore(0)
+        c.set_distance_mode(mode); c.set_neighbor_search_method(capi.DIRECT7); c.set_resolution(1.0)
+        c.set_target_cloud(tgt); c.set_source_cloud(src)
+        if hint:
+            c.debug_set_voxel_hint("source", 1); c.debug_set_voxel_hint("target", 1)
+        return c
+
+    ref, c = make(False), make(True)
+    T = util.random_pose(np.random.default_rng(12), max_angle_deg=1.0, max_trans=0.3)
+    c.create_voxelmaps(); ref.create_voxelmaps()
+    e0, H0, b0 = ref.linearize(T)
+    e, H, b = c.linearize(T)
+    assert e0 > 0 and abs(e - e0) <= 1e-11 * abs(e0) and util.rel_err(H, H0) < 1e-11 and util.rel_err(b, b0) < 1e-11
+    c2 = make(True)
+    r0, r = ref.align(), c2.align()  # (align builds the maps itself: with the bad hints)
+    assert r["converged"] and r0["converged"] and r["num_linearize"] == r0["num_linearize"] and util.rel_err(r["T"], r0["T"]) < 1e-9
+    assert c2.get_num_voxels("target") == ref.get_num_voxels("target")
+    for h in (ref, c, c2):
+        h.close()
+    vg.close()

@@ -99,15 +99,26 @@ def test_gauss_newton_optimizer_matches_oracle(pygicp, data, cls):
 
 
 def test_neighbor_methods_agree(pygicp, data):
-    """CPU_PARALLEL_KDTREE (host kd-tree, reference default) and GPU_BRUTEFORCE give the same neighbours -> same result."""
+    """CPU_PARALLEL_KDTREE -- the reference's default -- asks for exact k-NN lists: served by the device search by default (round 6), by the host
+    kd-tree of include/fast_gicp_amd/kdtree.hpp after set_host_kdtree(True); GPU_BRUTEFORCE is the device search. The same neighbours ->
+    the same covariances -> bit-identical registrations, all three ways."""
     target, source, _ = data
     res = []
-    for m in ("CPU_PARALLEL_KDTREE", "GPU_BRUTEFORCE"):
+    for m, host in (("CPU_PARALLEL_KDTREE", False), ("CPU_PARALLEL_KDTREE", True), ("GPU_BRUTEFORCE", False)):
         reg = pygicp.FastVGICPCuda()
         reg.set_nearest_neighbor_search_method(m)
+        if host:
+            reg.set_host_kdtree(True)
         reg.set_input_target(target); reg.set_input_source(source)
         res.append(reg.align())
-    assert np.array_equal(res[0], res[1])
+    assert np.array_equal(res[0], res[1]) and np.array_equal(res[0], res[2])
+    # the host tree itself (built by OpenMP tasks) against the device lists, row by row
+    from fast_gicp_amd import capi
+    c = capi.VGICPCore(0)
+    c.set_target_cloud(target.astype(np.float32)); c.find_target_neighbors(20)
+    dev = c.get_neighbors("target")
+    assert np.array_equal(np.asarray(pygicp._kdtree_knn(target, 20)), dev)
+    c.close()
 
 
 def test_align_points_and_evaluate_cost(pygicp, data):

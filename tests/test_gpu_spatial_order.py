@@ -99,3 +99,30 @@ def test_cooperative_sort_is_kept_unless_another_handle_has_a_gang_kernel_in_fli
     d = routes() - r0
     assert int(d[1]) == one_wg and int(d[0]) + int(d[1]) == 6
     a.close(); b.close()
+
+
+def test_sort_mode_1_never_takes_the_cooperative_kernel():
+    """FVH_SORT_MODE=1 is what processes SHARING a GPU set (bench.py FVH_BENCH_SHARE_GPU, tests/test_gpu_peer.py, tools/peer_bench.py): the
+    in-process GangRegistry cannot see another process's persistent LM grid, so the 32-workgroup cooperative sort must stay off altogether --
+    every small sort takes the one-workgroup kernel (the exclusive-cooperative route had swallowed mode 1). The environment is read
+    once per process: a child process."""
+    import os
+    import subprocess
+    import sys
+    code = (
+        "import numpy as np\n"
+        "from fast_gicp_amd import capi\n"
+        "rng = np.random.default_rng(1)\n"
+        "pts = (rng.normal(size=(5000, 3)) * 10).astype(np.float32)\n"
+        "c = capi.VGICPCore(0)\n"
+        "r0 = np.array(capi.debug_sort_routes())\n"
+        "c.set_target_cloud(pts); c.find_target_neighbors(20)\n"
+        "c.set_source_cloud(pts[::2].copy()); c.find_source_neighbors(20)\n"
+        "c.synchronize()\n"
+        "print('ROUTES', *(np.array(capi.debug_sort_routes()) - r0))\n"
+    )
+    env = dict(os.environ, FVH_SORT_MODE="1", PYTHONPATH=util.ROOT)
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = [l for l in out.stdout.splitlines() if l.startswith("ROUTES")][0].split()
+    assert (int(line[1]), int(line[2])) == (0, 2), line
