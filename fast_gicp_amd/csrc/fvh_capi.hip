@@ -1692,6 +1692,11 @@ int do_align(Engine* e, const CostSource& src, VoxelMapDev& vm, const double* gu
   return align_finish<MODE>(e, c, src, vm, result, rebuild_safe);
 }
 
+// exact 1-NN of every (transformed) source point in the target (kernels_cov.hpp: nn1_rows_kernel -- four queries per wave, one per 16-lane row)
+void launch_nn1(Engine* e, const CloudDev& src, const CloudDev& tgt, const float* T12, double thr_sq, int* corr, float* best_out, const LmLink& lm) {
+  nn1_rows_kernel<<<(src.n + 15) / 16, 256, 0, e->stream>>>(src.sorted.as<float4>(), src.n, tgt.sorted.as<float4>(), tgt.bbox.as<float4>(), tgt.bbox2.as<float4>(), tgt.n, T12, thr_sq, corr, best_out, lm);
+}
+
 int do_fitness(Engine* e, CloudDev& src, CloudDev& tgt, const double* T16, double max_range, double* score) {
   if (!T16 || !score) return e->fail(FVH_ERR_INVALID_ARGUMENT, "fitness_score: null argument");
   if (!src.has_pts || !tgt.has_pts || src.n == 0 || tgt.n == 0) return e->fail(FVH_ERR_BAD_STATE, "fitness_score: clouds not set");
@@ -1721,10 +1726,15 @@ int do_fitness(Engine* e, CloudDev& src, CloudDev& tgt, const double* T16, doubl
                                                                     (double*)base);
     } else
 #endif
-    {  // one query per wave (the k = 1 search of the GICP path), then a fixed-order reduction
+    {  // the exact 1-NN search of the GICP path (64 queries per wave), then a fixed-order reduction
       HIP_OR_FAIL(e, e->fit_best.ensure(sizeof(float) * (size_t)src.n));
-      nn1_corr_kernel<<<src.n, 64, 0, e->stream>>>(src.sorted.as<float4>(), src.n, tgt.sorted.as<float4>(), tgt.bbox.as<float4>(), tgt.bbox2.as<float4>(), tgt.n,
-                                                              (const float*)(base + 16), 0.0, nullptr, e->fit_best.as<float>());
+#ifdef FVH_TEST_KERNELS
+      if (fit_mode == 3)
+        nn1_corr_kernel<<<src.n, 64, 0, e->stream>>>(src.sorted.as<float4>(), src.n, tgt.sorted.as<float4>(), tgt.bbox.as<float4>(), tgt.bbox2.as<float4>(), tgt.n,
+                                                                (const float*)(base + 16), 0.0, nullptr, e->fit_best.as<float>());
+      else
+#endif
+      launch_nn1(e, src, tgt, (const float*)(base + 16), 0.0, nullptr, e->fit_best.as<float>(), LmLink{nullptr, nullptr, nullptr, nullptr, 0});
       fitness_reduce_kernel<<<1, 1024, 0, e->stream>>>(e->fit_best.as<float>(), src.n, max_range, (double*)base);
     }
   }
@@ -1821,9 +1831,7 @@ int gicp_align(Engine* e, CloudDev& src, CloudDev& tgt, VoxelMapDev& records, co
       const bool first = (launched == 0 && s == 0);
       {
         ProfScope ps(e, "gicp_nn");
-        nn1_corr_kernel<<<src.n, 64, 0, e->stream>>>(src.sorted.as<float4>(), src.n, tgt.sorted.as<float4>(), tgt.bbox.as<float4>(), tgt.bbox2.as<float4>(), tgt.n,
-                                                                reinterpret_cast<const float*>(base + 16), thr * thr, e->corr.as<int>(), nullptr,
-                                                                first ? LmLink{nullptr, nullptr, nullptr, nullptr, 0} : link);
+        launch_nn1(e, src, tgt, reinterpret_cast<const float*>(base + 16), thr * thr, e->corr.as<int>(), nullptr, first ? LmLink{nullptr, nullptr, nullptr, nullptr, 0} : link);
       }
       rc = launch_cost<MODE_VGICP>(e, cs, records, -1, first ? &guess : nullptr, nullptr, first ? &p : nullptr);
       if (rc) return rc;
@@ -1867,15 +1875,17 @@ int gicp_update_correspondences(Engine* e, CloudDev& src, CloudDev& tgt, VoxelMa
     ProfScope ps(e, "gicp_nn");
 #ifdef FVH_TEST_KERNELS  // test build only: FVH_GICP_NN_MODE=0 selects the superseded eight-queries-per-wave search
     static const int nn_mode = [] { const char* v = getenv("FVH_GICP_NN_MODE"); return v ? atoi(v) : 1; }();
-    if (nn_mode != 1) {
+    if (nn_mode == 3) {
+      nn1_corr_kernel<<<src.n, 64, 0, e->stream>>>(src.sorted.as<float4>(), src.n, tgt.sorted.as<float4>(), tgt.bbox.as<float4>(), tgt.bbox2.as<float4>(), tgt.n,
+                                                              reinterpret_cast<const float*>(base + 16), thr * thr, e->corr.as<int>());
+    } else if (nn_mode != 1) {
       const int waves = (src.n + FIT_Q - 1) / FIT_Q;
       nn_corr_tiled_kernel<<<(waves + 3) / 4, 256, 0, e->stream>>>(src.sorted.as<float4>(), src.n, tgt.sorted.as<float4>(), tgt.bbox.as<float4>(), tgt.n, reinterpret_cast<const float*>(base + 16), thr * thr,
                                                                    e->corr.as<int>());
     } else
 #endif
     {
-      nn1_corr_kernel<<<src.n, 64, 0, e->stream>>>(src.sorted.as<float4>(), src.n, tgt.sorted.as<float4>(), tgt.bbox.as<float4>(), tgt.bbox2.as<float4>(), tgt.n,
-                                                              reinterpret_cast<const float*>(base + 16), thr * thr, e->corr.as<int>());
+      launch_nn1(e, src, tgt, reinterpret_cast<const float*>(base + 16), thr * thr, e->corr.as<int>(), nullptr, LmLink{nullptr, nullptr, nullptr, nullptr, 0});
     }
   }
   HIP_OR_FAIL(e, hipGetLastError());

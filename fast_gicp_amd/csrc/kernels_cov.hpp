@@ -1229,10 +1229,11 @@ __global__ __launch_bounds__(256) void nn_corr_tiled_kernel(const float4* __rest
 }
 #endif
 
-// Same search, ONE query per wave (like knn_tiled1_kernel: the regime is a latency chain per query, so 17k short waves
-// beat 2k long ones -- the 8-queries-per-wave sweep above took 430 us per search at 17k x 17k, 4 per GICP registration).
+// Same search, ONE query per wave (rounds 2-5; superseded by nn1_group_kernel below and kept in the test build as its cross-check:
+// FVH_FIT_MODE=3 / FVH_GICP_NN_MODE=3) -- the 8-queries-per-wave sweep above took 430 us per search at 17k x 17k, this one 98.
 // Seed = nearest tile by box distance through the two box levels, then every tile whose box can still hold a point at
 // least as near (ties resolve to the lower original index).
+#ifdef FVH_TEST_KERNELS
 __global__ __launch_bounds__(256) void nn1_corr_kernel(const float4* __restrict__ ssrc, int ns, const float4* __restrict__ stgt, const float4* __restrict__ bbox1,
                                                        const float4* __restrict__ bbox2, int nt, const float* __restrict__ T12, double thr_sq, int* __restrict__ corr,
                                                        float* __restrict__ best_out = nullptr /* getFitnessScore: squared NN distance per query, in the order of ssrc */,
@@ -1337,17 +1338,182 @@ __global__ __launch_bounds__(256) void nn1_corr_kernel(const float4* __restrict_
     if (best_out) best_out[q] = best;
   }
 }
+#endif
+
+// ------------------------------------------------------------------------------------------------
+// Exact 1-NN, FOUR queries per wave: one query per ROW of 16 lanes (DPP row operations are VALU moves -- a row all-reduce is four
+// instructions, where a 64-lane reduction through the LDS crossbar is six dependent ~100-cycle hops). Each row walks the target's two box
+// levels 16 boxes at a time and sweeps a surviving tile 16 points at a time; rows diverge freely (a row is wholly active or wholly masked,
+// and nothing in here crosses rows: no ballot, no readlane). Per (query, tile) ~16 instructions instead of ~60 + 12 crossbar hops.
+// Replaces the one-query-per-wave search above for getFitnessScore and FastGICP's correspondences (98 -> 20 us for 17k queries in 17k points,
+// 789 -> 165 us for 100k queries in the 1M-point map). Also tried in round 6 and dropped (HISTORY.md): 64 queries per wave, one per lane, tiles
+// broadcast through LDS -- the least work per distance, and 102 us anyway: the 64 queries of a Morton tile together need ~130 target tiles, each
+// of which is then swept for all 64 lanes.
+// ------------------------------------------------------------------------------------------------
+template <int CTRL>
+__device__ __forceinline__ unsigned row_dpp(unsigned v) { return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xF, 0xF, false); }
+// all-reduce over the 16 lanes of a row: lane ^ 1, lane ^ 2 (quad permutes), then the mirrors of 8 and of 16 lanes
+#define FVH_ROW_ALLREDUCE(x, OP)                                  \
+  do {                                                            \
+    x = OP(x, row_dpp<0xB1>(x));  /* quad_perm [1,0,3,2] */       \
+    x = OP(x, row_dpp<0x4E>(x));  /* quad_perm [2,3,0,1] */       \
+    x = OP(x, row_dpp<0x141>(x)); /* row_half_mirror */           \
+    x = OP(x, row_dpp<0x140>(x)); /* row_mirror */                \
+  } while (0)
+__device__ __forceinline__ unsigned u32_min(unsigned a, unsigned b) { return a < b ? a : b; }
+__device__ __forceinline__ unsigned u32_or(unsigned a, unsigned b) { return a | b; }
+__device__ __forceinline__ unsigned row_min_u32(unsigned x) { FVH_ROW_ALLREDUCE(x, u32_min); return x; }
+__device__ __forceinline__ unsigned row_or_u32(unsigned x) { FVH_ROW_ALLREDUCE(x, u32_or); return x; }
+template <int CTRL>
+__device__ __forceinline__ unsigned long long row_min_step64(unsigned long long k) {
+  const unsigned long long o = ((unsigned long long)row_dpp<CTRL>((unsigned)(k >> 32)) << 32) | row_dpp<CTRL>((unsigned)k);
+  return o < k ? o : k;
+}
+__device__ __forceinline__ unsigned long long row_min_u64(unsigned long long k) {
+  k = row_min_step64<0xB1>(k); k = row_min_step64<0x4E>(k); k = row_min_step64<0x141>(k); k = row_min_step64<0x140>(k);
+  return k;
+}
+__global__ __launch_bounds__(256) void nn1_rows_kernel(const float4* __restrict__ ssrc, int ns, const float4* __restrict__ stgt, const float4* __restrict__ bbox1,
+                                                       const float4* __restrict__ bbox2, int nt, const float* __restrict__ T12, double thr_sq, int* __restrict__ corr,
+                                                       float* __restrict__ best_out = nullptr /* getFitnessScore: squared NN distance per query, in the order of ssrc */,
+                                                       LmLink lm = LmLink{nullptr, nullptr, nullptr, nullptr, 0} /* device LM (FastGICP): pose and output buffer follow the LM state on the device */) {
+  const int rl = threadIdx.x & 15;                                  // lane within the row
+  const int q = (blockIdx.x * 256 + (int)threadIdx.x) >> 4;         // this row's query (position in the source's Morton order)
+  if (q >= ns) return;                                              // (whole rows)
+  const int ntiles = (nt + 63) >> 6, nsuper = (ntiles + 63) >> 6;
+  const float4 qv = ssrc[q];
+  float Tl[12];
+  if (lm.phase) {
+    // device-resident LM loop: this search belongs to the linearisation the NEXT cost launch will run -- at x0 into the current
+    // correspondence buffer (PH_LINEARIZE), or speculatively at the trial pose xi into the other one (fused PH_TRIAL)
+    const int phase = *lm.phase;
+    if (phase == 2 /* PH_DONE */) return;
+    const double* pose = (phase == 0 /* PH_LINEARIZE */) ? lm.x0 : lm.xi;
+    const int sel = (phase == 1 /* PH_TRIAL */) ? (*lm.corr_cur ^ 1) : *lm.corr_cur;
+    corr += (size_t)sel * lm.corr_stride;
+#pragma unroll
+    for (int r = 0; r < 3; r++) {  // trans.cast<float>() (fast_gicp_impl.hpp:121)
+      Tl[4 * r] = (float)pose[3 * r]; Tl[4 * r + 1] = (float)pose[3 * r + 1]; Tl[4 * r + 2] = (float)pose[3 * r + 2]; Tl[4 * r + 3] = (float)pose[9 + r];
+    }
+  } else {
+#pragma unroll
+    for (int j = 0; j < 12; j++) Tl[j] = T12[j];
+  }
+  const float qx = transform_row_nofma(qv, Tl + 0), qy = transform_row_nofma(qv, Tl + 4), qz = transform_row_nofma(qv, Tl + 8);
+  unsigned long long best = 0x7f800000ffffffffull;  // (distance bits, original index): +inf and the largest index -- above every candidate, below every NaN distance (never taken)
+  // the 64 points of a tile, 16 per step, against the row's query; afterwards every lane of the row holds the row's minimum
+  auto sweep = [&](int tile) __attribute__((always_inline)) {
+    const int base = tile << 6;
+    float4 p[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) p[u] = stgt[min(base + 16 * u + rl, nt - 1)];
+    unsigned long long m = best;
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      const unsigned long long key = knn_key(sqdist_nofma(p[u], qx, qy, qz), __float_as_int(p[u].w));
+      m = (base + 16 * u + rl < nt && key < m) ? key : m;
+    }
+    best = row_min_u64(m);
+  };
+  // Boxes are visited NEAREST FIRST at both levels. In index order the walk sweeps whatever passes the bound of the moment: measured on the
+  // bundled pair, 44 tiles per query pass the bound the first tile leaves (90th percentile: 156) where 5 pass the final one -- a query inside
+  // a 2 m tile box is often far from every point of it. A bound travels as its float bits (non-negative floats order like unsigned integers;
+  // a NaN bound -- a non-finite query -- lies above +inf and is never a candidate) with the box number in its low bits, so that a row
+  // minimum is an arg-min; the truncated mantissa bits only ever LOWER a bound (a box may be visited needlessly, never skipped wrongly).
+  const auto best_bits = [&]() __attribute__((always_inline)) { return (unsigned)(best >> 32); };
+  // one super tile: its 64 tile boxes, four per lane (eight loads, one round trip), then tiles in ascending bound order until the
+  // nearest remaining one lies beyond the row's minimum
+  auto process_super = [&](int sup) __attribute__((always_inline)) {
+    unsigned key[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      const int t = (sup << 6) + 16 * u + rl;
+      const int tc = min(t, ntiles - 1);
+      const float4 l4 = bbox1[2 * tc], h4 = bbox1[2 * tc + 1];
+      key[u] = (t < ntiles) ? ((__float_as_uint(point_box_sq(l4, h4, qx, qy, qz)) & ~63u) | (unsigned)(16 * u + rl)) : ~0u;
+    }
+    while (true) {
+      const unsigned m = row_min_u32(min(min(key[0], key[1]), min(key[2], key[3])));
+      if ((m & ~63u) > best_bits()) break;  // (also the end of the list: ~0u; and a NaN bound: above +inf)
+      const int tl = (int)(m & 63u);
+      sweep((sup << 6) + tl);
+#pragma unroll
+      for (int u = 0; u < 4; u++) key[u] = (16 * u + rl == tl) ? ~0u : key[u];
+    }
+  };
+  // super tiles in chunks of 256 (a 1M-point map is one chunk): sixteen bounds per lane, all loads of a chunk in flight together
+  constexpr int CHUNK = 256;
+  unsigned k2[16];
+  auto load_chunk = [&](int cb) __attribute__((always_inline)) {
+#pragma unroll
+    for (int u = 0; u < 16; u++) {
+      k2[u] = ~0u;
+      if (cb + 16 * u < nsuper) {  // (uniform)
+        const int s = cb + 16 * u + rl;
+        const int sc = min(s, nsuper - 1);
+        const float4 l4 = bbox2[2 * sc], h4 = bbox2[2 * sc + 1];
+        k2[u] = (s < nsuper) ? ((__float_as_uint(point_box_sq(l4, h4, qx, qy, qz)) & ~255u) | (unsigned)(16 * u + rl)) : ~0u;
+      }
+    }
+  };
+  auto chunk_min = [&]() __attribute__((always_inline)) {
+    unsigned m = k2[0];
+#pragma unroll
+    for (int u = 1; u < 16; u++) m = min(m, k2[u]);
+    return row_min_u32(m);
+  };
+  // ---- the super tile nearest to the query first: whatever is near is most likely in there, and the bound is tight from the start ----
+  int s_first = 0;
+  {
+    unsigned bk = ~0u;
+    for (int cb = 0; cb < nsuper; cb += CHUNK) {
+      load_chunk(cb);
+      const unsigned m = chunk_min();
+      if (m < bk) { bk = m; s_first = cb + (int)(m & 255u); }
+    }
+    s_first = min(s_first, nsuper - 1);  // (a non-finite query: every bound is NaN or the list is empty -- any super tile will do)
+  }
+  process_super(s_first);
+  // ---- then every other super tile that can still matter, nearest first within a chunk ----
+  for (int cb = 0; cb < nsuper; cb += CHUNK) {
+    if (nsuper > CHUNK) load_chunk(cb);  // (a single chunk is still in registers)
+#pragma unroll
+    for (int u = 0; u < 16; u++) k2[u] = (cb + 16 * u + rl == s_first) ? ~0u : k2[u];
+    while (true) {
+      const unsigned m = chunk_min();
+      if ((m & ~255u) > best_bits()) break;
+      const int sl = (int)(m & 255u);
+      process_super(cb + sl);
+#pragma unroll
+      for (int u = 0; u < 16; u++) k2[u] = (16 * u + rl == sl) ? ~0u : k2[u];
+    }
+  }
+  if (rl == 0) {
+    const float bd = __uint_as_float((unsigned)(best >> 32));
+    if (corr) corr[__float_as_int(qv.w)] = ((double)bd < thr_sq) ? (int)(unsigned)best : -1;
+    if (best_out) best_out[q] = bd;
+  }
+}
 
 // pcl::Registration::getFitnessScore: mean of the squared nearest-neighbour distances not above max_range. One workgroup,
 // fixed summation order (thread t sums entries t, t + 1024, ... in fp64, then a fixed tree): bit-reproducible, unlike
 // per-wave atomics. out[0] = sum, out[1] = count.
 __global__ __launch_bounds__(1024) void fitness_reduce_kernel(const float* __restrict__ best, int n, double max_range, double* __restrict__ out) {
   __shared__ double s_sum[16], s_cnt[16];
-  double sum = 0.0, cnt = 0.0;
-  for (int i = threadIdx.x; i < n; i += 1024) {
-    const double d = (double)best[i];
-    if (d <= max_range) { sum += d; cnt += 1.0; }
+  // thread t: entries t, t + 1024, ... in four interleaved partial sums (a fixed order; the loads of a round are independent -- as one
+  // dependent chain a 17k-point cloud was 17 round trips on the only workgroup of the launch)
+  double ps[4] = {0.0, 0.0, 0.0, 0.0}, pc[4] = {0.0, 0.0, 0.0, 0.0};
+  for (int i0 = threadIdx.x; i0 < n; i0 += 4096) {
+    float v[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) v[u] = best[min(i0 + 1024 * u, n - 1)];
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      const double d = (double)v[u];
+      if (i0 + 1024 * u < n && d <= max_range) { ps[u] += d; pc[u] += 1.0; }
+    }
   }
+  double sum = (ps[0] + ps[1]) + (ps[2] + ps[3]), cnt = (pc[0] + pc[1]) + (pc[2] + pc[3]);
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) { sum += __shfl_xor(sum, off); cnt += __shfl_xor(cnt, off); }
   if ((threadIdx.x & 63) == 0) { s_sum[threadIdx.x >> 6] = sum; s_cnt[threadIdx.x >> 6] = cnt; }

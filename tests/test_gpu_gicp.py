@@ -150,3 +150,48 @@ def test_device_lm_align_matches_oracle_and_the_host_loop(O, pair, max_dist):
     r2 = c.gicp_align(util.relative_pose())
     assert r2["converged"] and util.rel_err(r2["T"], r["T"]) < 1e-3
     c.close()
+
+
+@pytest.mark.parametrize("ns, nt", [(1, 1), (15, 64), (17, 65), (63, 64), (65, 129), (5000, 7001), (20000, 100000), (3000, 300000)])
+def test_row_per_query_nearest_neighbour_search_is_exact(O, ns, nt):
+    """nn1_rows_kernel (round 6: four queries per wave, one per 16-lane row, boxes visited nearest first) against the definition: the nearest
+    target point of every transformed source point in the total order (fp32 (dx dx + dy dy) + dz dz without contraction, ORIGINAL index) --
+    the oracle's kd-tree query. Ragged sizes (rows, tiles and super tiles that end mid-way; one point; more than 16 super tiles), duplicate
+    target points (ties -> lower index), source points at infinity / NaN / far enough to overflow the squared distance (no correspondence,
+    excluded from the fitness mean)."""
+    from fast_gicp_amd import capi
+    rng = np.random.default_rng(ns * 131 + nt)
+    tgt = (rng.normal(size=(nt, 3)) * np.array([30.0, 30.0, 3.0])).astype(np.float32)
+    if nt >= 129:
+        tgt[nt // 2:nt // 2 + 40] = tgt[5:45]          # exact duplicates far apart in index: ties
+    src = (rng.normal(size=(ns, 3)) * np.array([30.0, 30.0, 3.0])).astype(np.float32)
+    if ns >= 65:
+        src[7] = tgt[9]                                 # distance 0 to two target points (9 and its duplicate): the lower index wins
+        src[20] = [np.nan, 0.0, 0.0]
+        src[21] = [np.inf, 0.0, 0.0]
+        src[64] = [1e30, 0.0, 0.0]                      # finite, squared distance overflows to inf
+    T = util.random_pose(np.random.default_rng(3), max_angle_deg=3.0, max_trans=1.0)
+    if ns >= 65:
+        T = np.eye(4)                                   # (the exact-duplicate query must stay exactly on its target point)
+    Tf = T.astype(np.float32)
+    with np.errstate(invalid="ignore", over="ignore"):
+        q = ((src[:, 0:1] * Tf[:3, 0] + src[:, 1:2] * Tf[:3, 1]) + (src[:, 2:3] * Tf[:3, 2] + Tf[:3, 3])).astype(np.float32)
+    ok = np.isfinite(q).all(1)
+    expect = np.full(ns, -1, np.int64)
+    best = np.full(ns, np.inf, np.float32)
+    if ok.any():
+        idx, sq = O.knn_query(tgt, q[ok], 1)
+        expect[ok] = np.where(np.isfinite(sq[:, 0]), idx[:, 0], -1)
+        best[ok] = sq[:, 0]
+    fit_expect = float(np.sum(best[np.isfinite(best)].astype(np.float64)) / max(1, int(np.isfinite(best).sum())))
+    c = capi.VGICPCore(0)
+    c.set_target_cloud(tgt); c.set_source_cloud(src)
+    c.set_target_covariances(np.tile(np.eye(3) * 0.01, (nt, 1, 1))); c.set_source_covariances(np.tile(np.eye(3) * 0.01, (ns, 1, 1)))
+    c.gicp_update_correspondences(T)
+    corr = c.gicp_get_correspondences()
+    assert np.array_equal(corr, expect), (int((corr != expect).sum()), np.nonzero(corr != expect)[0][:10])
+    if ns >= 65:
+        assert corr[7] == 9
+    fit = c.fitness_score(T)
+    assert abs(fit - fit_expect) <= 1e-6 * max(fit_expect, 1e-30), (fit, fit_expect)
+    c.close()
