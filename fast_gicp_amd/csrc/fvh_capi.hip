@@ -307,6 +307,11 @@ struct Engine {
   int corr_kind = 0;       // 0: voxel correspondences (VGICP / NDT), 1: nearest-point correspondences (GICP)
   int corr_n_src = 0;
   int corr_sel = 0;        // which of the two correspondence buffers the host-mode calls use
+  // The rows of the stored correspondences are indexed by the element's POSITION in the walk order (clouds walked in Morton order: a wave's 64
+  // items then read and write 64 CONSECUTIVE rows instead of 64 scattered ones -- 1M-map LM launch 186 -> 169 us), else by its original index.
+  // Decided by the launch that FINDS them and kept for every later evaluation of the same list (a sort queued in between -- fitness_score,
+  // find_neighbors -- may make an order appear: the rows then stay indexed the way they were written); the getters map back to point indices.
+  bool corr_by_position = false;
   int last_steps = 0, prev_steps = 0;  // launches the last two aligns needed (odometry loops alternate directions)
   int persist_aborts = 0;               // persistent launches the watchdog turned into multi-launch retries
   int persist_backoff = 0, persist_skip = 0;  // after an abort: aligns to run on the multi-launch route before the next persistent attempt (doubles per consecutive abort)
@@ -1322,6 +1327,12 @@ int launch_cost(Engine* e, const CostSource& src, const VoxelMapDev& vm, int hos
   P.vm_counters2 = src.counters2;
   P.host_phase = host_phase;
   P.external_find = src.external_find ? 1 : 0;
+  {
+    const bool finds = host_phase < 0 || host_phase == PH_FIND_ONLY;  // (the device-resident loop finds its own lists; PH_EVAL_* read a stored one)
+    if (finds) e->corr_by_position = src.order != nullptr && !src.external_find && !src.device_tile;
+    if (e->corr_by_position && !src.order) return e->fail(FVH_ERR_BAD_STATE, "compute_error: the stored correspondences were found in the cloud's spatial order, which is gone; call update_correspondences again");
+    P.corr_by_position = e->corr_by_position ? 1 : 0;
+  }
   P.lm_trace = (e->lm_trace_on && host_phase < 0) ? e->lm_trace.as<double>() : nullptr;
   P.defer_lm = (e->comm != nullptr) ? 1 : 0;
   if (lin) P.lin = *lin;
@@ -1894,6 +1905,7 @@ int gicp_update_correspondences(Engine* e, CloudDev& src, CloudDev& tgt, VoxelMa
   e->corr_sel = 0;
   e->has_corr = true;
   e->corr_kind = 1;
+  e->corr_by_position = false;  // (nn1_rows_kernel writes the row of the ORIGINAL index)
   e->corr_n_src = src.n;
   return FVH_OK;
 }
@@ -2383,6 +2395,19 @@ int fvh_vgicp_get_voxel_means(fvh_vgicp* h, float* o) { CHECK_HANDLE(h); { int _
 int fvh_vgicp_get_voxel_covs(fvh_vgicp* h, float* o) { CHECK_HANDLE(h); { int _w = h->whole_map(); if (_w) return _w; } const Rebuild rb = h->rebuild_safe(); return get_voxels_host(&h->e, h->voxelmap, nullptr, nullptr, nullptr, o, &rb); }
 int fvh_vgicp_get_voxel_coords(fvh_vgicp* h, int* o) { CHECK_HANDLE(h); { int _w = h->whole_map(); if (_w) return _w; } const Rebuild rb = h->rebuild_safe(); return get_voxels_host(&h->e, h->voxelmap, o, nullptr, nullptr, nullptr, &rb); }
 
+// row of source point i in the stored correspondence buffer (Engine::corr_by_position: its position in the cloud's Morton order)
+static int fetch_row_of_point(Engine* e, const CloudDev& c, int n_src, std::vector<int>& row_of) {
+  row_of.resize((size_t)n_src);
+  if (!e->corr_by_position) { for (int i = 0; i < n_src; i++) row_of[(size_t)i] = i; return FVH_OK; }
+  if (!c.has_sorted || c.n != n_src) return e->fail(FVH_ERR_BAD_STATE, "correspondence getters: the spatial order the stored list was found in is gone; call update_correspondences again");
+  std::vector<int> order((size_t)n_src);
+  if (n_src) {
+    HIP_OR_FAIL(e, hipMemcpyAsync(order.data(), c.order.p, sizeof(int) * (size_t)n_src, hipMemcpyDeviceToHost, e->stream));
+    HIP_OR_FAIL(e, hipStreamSynchronize(e->stream));
+  }
+  for (int j = 0; j < n_src; j++) row_of[(size_t)order[(size_t)j]] = j;
+  return FVH_OK;
+}
 static int fetch_corr(Engine* e, int n_src, std::vector<int>& corr) {
   if (!e->has_corr) return e->fail(FVH_ERR_BAD_STATE, "no correspondences: call update_correspondences first");
   corr.resize((size_t)n_src * (e->corr_kind == 1 ? 1 : e->n_off));
@@ -2406,7 +2431,8 @@ int fvh_vgicp_get_num_correspondences(fvh_vgicp* h, int* n) {
       HIP_OR_FAIL(&h->e, hipMemcpyAsync(order.data(), h->source.order.as<int>() + t.lo, sizeof(int) * order.size(), hipMemcpyDeviceToHost, h->e.stream));
       HIP_OR_FAIL(&h->e, hipStreamSynchronize(h->e.stream));
     }
-    for (int i : order) for (int o = 0; o < h->e.n_off; o++) c += (corr[(size_t)i * h->e.n_off + o] >= 0);
+    if (h->e.corr_by_position) { for (int j = t.lo; j < t.hi; j++) for (int o = 0; o < h->e.n_off; o++) c += (corr[(size_t)j * h->e.n_off + o] >= 0); }  // (rows by position: the tile IS a range of rows)
+    else for (int i : order) for (int o = 0; o < h->e.n_off; o++) c += (corr[(size_t)i * h->e.n_off + o] >= 0);
   } else {
     for (int v : corr) c += (v >= 0);
   }
@@ -2424,10 +2450,13 @@ int fvh_vgicp_get_voxel_correspondences(fvh_vgicp* h, int* pairs) {
   std::vector<int> corr;
   rc = fetch_corr(&h->e, h->e.corr_n_src, corr);
   if (rc) return rc;
+  std::vector<int> row_of;
+  rc = fetch_row_of_point(&h->e, h->source, h->e.corr_n_src, row_of);
+  if (rc) return rc;
   size_t w = 0;
   for (int o = 0; o < h->e.n_off; o++)
     for (int i = 0; i < h->e.corr_n_src; i++) {
-      int b = corr[(size_t)i * h->e.n_off + o];
+      int b = corr[(size_t)row_of[(size_t)i] * h->e.n_off + o];
       if (b < 0) continue;
       pairs[2 * w] = i;
       pairs[2 * w + 1] = h->voxelmap.bucket_to_index[b];
@@ -2941,10 +2970,13 @@ int fvh_ndt_get_voxel_correspondences(fvh_ndt* h, int* pairs) {
     if (rc) return rc;
     nsrc = (int)h->source_vm.h_occupied.size();
   }
+  std::vector<int> row_of;  // (P2D on a large cloud: rows by Morton position; D2D: by source-voxel index)
+  rc = fetch_row_of_point(&h->e, h->source, nsrc, row_of);
+  if (rc) return rc;
   size_t w = 0;
   for (int o = 0; o < h->e.n_off; o++)
     for (int i = 0; i < nsrc; i++) {
-      const int b = corr[(size_t)i * h->e.n_off + o];
+      const int b = corr[(size_t)row_of[(size_t)i] * h->e.n_off + o];
       if (b < 0) continue;
       pairs[2 * w] = i;
       pairs[2 * w + 1] = h->target_vm.bucket_to_index[b];

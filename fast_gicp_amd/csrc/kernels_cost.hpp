@@ -132,6 +132,7 @@ struct CostParams {
   // linearise the new ones (see the main loop); 0: every wave does both for its own 64 items
   int split;
   double* lm_trace;   // setDebugPrint on the device LM: 6 doubles per trial {i, y0, yi, rho, lambda, |d|} (lsq_registration_impl.hpp:143-149), or null
+  int corr_by_position;  // the correspondence rows are indexed by the element's POSITION in the walk order (Morton), not by its original index
   int external_find;  // FastGICP on the device: the correspondences of every linearisation were found by nn1_corr_kernel right before this launch (nothing to probe here)
   PeerView peer;
   unsigned long long peer_watchdog_ticks;
@@ -962,7 +963,7 @@ __global__ FVH_COST_BOUNDS void cost_kernel(CostParams P) {
         for (int c = 0; c < CH; c++) b[c] = s_ids[corr_sel][c][st];
       }
     } else {
-      const size_t row = (size_t)i * P.n_off + o_begin;
+      const size_t row = (size_t)(P.corr_by_position ? i0 : i) * P.n_off + o_begin;
       a4 = *a4_src;
       if (MODE != MODE_NDT_P2D && do_cost) {
         const float4* cv = P.src_cov_sorted ? P.src_cov_sorted + 2 * (size_t)i0 : P.src_cov + 2 * (size_t)i;  // (uniform choice)
@@ -1154,7 +1155,7 @@ __global__ FVH_COST_BOUNDS void cost_kernel(CostParams P) {
           if (k == key[c]) r = (int)slot[c];
           else if (k != FVH_EMPTY_KEY && key[c] != DEAD_KEY) r = probe_continue(P.keys, P.mask, key[c], slot[c]);  // rare at load <= 0.25
           b[c] = r;
-          if (o_begin + c < o_end) corr_new[(size_t)i * P.n_off + o_begin + c] = r;
+          if (o_begin + c < o_end) corr_new[(size_t)(P.corr_by_position ? i0 : i) * P.n_off + o_begin + c] = r;
           if (sticky) s_ids[sel_new][c][st] = (o_begin + c < o_end) ? r : -1;
         }
       }

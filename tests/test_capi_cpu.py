@@ -88,7 +88,7 @@ def test_kernels_stay_on_the_right_side_of_the_register_cliff():
         else:
             assert v["vgpr_spill"] == 0 and v["scratch"] == 0, (k, v)
     assert res["void fvh::lm_update_kernel<false>(fvh::LmState*)"]["vgprs"] <= 168  # the wave-parallel LM step is inlined into every cost kernel
-    for name, occ in (("knn_tiled1_kernel", 8), ("nn1_corr_kernel", 8), ("cov_rbf1_kernel", 8), ("cov_from_neighbors_kernel<5>", 6), ("vm_accumulate_kernel<0>", 3),
+    for name, occ in (("knn_tiled1_kernel", 8), ("nn1_rows_kernel", 6), ("cov_rbf1_kernel", 8), ("cov_from_neighbors_kernel<5>", 6), ("vm_accumulate_kernel<0>", 3),
                       ("sort_coop_kernel", 4)):
         hit = [v for k, v in res.items() if name in k]
         assert hit, name
