@@ -39,7 +39,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 T_START = time.perf_counter()
-PMC_FILE = os.path.join(ROOT, "profiles", "r05_pmc.json")
+PMC_FILE = os.path.join(ROOT, "profiles", "r06_pmc.json")
 # the cpu_baseline legs (oracle, OpenMP): threads next to each other -- they share the voxel map and the kd-tree through the caches
 os.environ.setdefault("OMP_PROC_BIND", "close")
 os.environ.setdefault("OMP_PLACES", "cores")
@@ -50,7 +50,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--workload", default="bundled17k", choices=["bundled17k", "synth100k", "synth1m", "lidar_stream"])
+    ap.add_argument("--workload", default="bundled17k", choices=["bundled17k", "synth100k", "synth1m", "lidar_stream", "fgicp17k"])
     ap.add_argument("--search", default=None, choices=["DIRECT1", "DIRECT7", "DIRECT27"])
     ap.add_argument("--cov", default="knn", choices=["knn", "rbf", "kdtree"])
     ap.add_argument("--precision", default="fp64", choices=["fp64", "fp32"])
@@ -259,7 +259,7 @@ _PMC = {}
 
 
 def pmc_entry(key):
-    """(entry, source) of the committed PMC passes of this round (profiles/r05_pmc.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE / SQ group
+    """(entry, source) of the committed PMC passes of this round (profiles/r06_pmc.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE / SQ group
     in separate runs of THIS command, tools/r03_artifacts.sh + tools/pmc_collect.py; FETCH doubled per the gfx950 note of
     MI355X_MICROARCH.md). PMC counters cannot be collected inside a timed run, so the numbers are a committed measurement -- stamped
     with the commit and a hash of fast_gicp_amd/csrc/ they were taken at, and NOT quoted once the kernels have changed."""
@@ -271,10 +271,10 @@ def pmc_entry(key):
         _PMC["_stale"] = _PMC.get("_meta", {}).get("csrc_sha") != csrc_sha()
     meta = _PMC.get("_meta", {})
     if not meta:
-        return None, "no PMC pass committed for this round (profiles/r05_pmc.json)"
+        return None, "no PMC pass committed for this round (profiles/r06_pmc.json)"
     if _PMC["_stale"]:
         return None, "PMC pass of commit %s is older than fast_gicp_amd/csrc/ (hash %s != %s): not quoted" % (meta.get("commit"), meta.get("csrc_sha"), csrc_sha())
-    return _PMC.get(key), "committed PMC pass of commit %s (profiles/r05_pmc.json, csrc hash %s == this tree)" % (meta.get("commit"), meta.get("csrc_sha"))
+    return _PMC.get(key), "committed PMC pass of commit %s (profiles/r06_pmc.json, csrc hash %s == this tree)" % (meta.get("commit"), meta.get("csrc_sha"))
 
 
 def pmc_traffic(key):
@@ -835,7 +835,7 @@ def run_stream(args, steps, warmup, cpu_loops=15, frames_n=10):
             # second entry: the stage with real bytes in this loop, the filter. Algorithmic bytes: read N x 12 B, write M x 12 B
             b = n_raw * 12 + n_ds * 12
             ach = b / (ms / n * 1e-3) / 1e9
-            # PMC traffic of the chain = the sum over its four kernels (one FETCH_SIZE and one WRITE_SIZE pass of this command, profiles/r05_pmc.json)
+            # PMC traffic of the chain = the sum over its four kernels (one FETCH_SIZE and one WRITE_SIZE pass of this command, profiles/r06_pmc.json)
             parts = [pmc_traffic("lidar_stream_downsample_" + k)[0] for k in ("hist", "scatter", "mark", "emit")]
             ds_traffic = int(sum(parts)) if all(p is not None for p in parts) else None
             roofline_ds = {"kernel": "voxel-grid filter (ApproximateVoxelGrid, 4 launches: slot histogram, scatter, mark, emit; the two scans are recomputed per workgroup)", "bound": "hbm", "achieved": round(ach, 2),
@@ -1160,6 +1160,70 @@ def run_registration(args, workload, cov, search_name, steps, warmup, local_rank
     return out
 
 
+def run_fgicp(args, steps, warmup, local_rank=0):
+    """`bundled17k_fgicp`: FastGICP -- nearest-target-point correspondences instead of voxel lookups -- on the bundled pair in the
+    100times_reuse loop of align.cpp:87-101 (swap, new source: sort + k-NN + covariances, align), and getFitnessScore (the other half of the metric)
+    on the result. Both run the exact 1-NN search nn1_rows_kernel: per LM transition in the registration, once in the fitness score."""
+    import torch
+    from fast_gicp_amd import capi
+    tgt, src, res, desc = make_workload("bundled17k")
+    gpu = torch.device("cuda", local_rank)
+    d_clouds = [torch.from_numpy(tgt).to(gpu).contiguous(), torch.from_numpy(src).to(gpu).contiguous()]
+    ptrs, n_pts = [t.data_ptr() for t in d_clouds], [len(tgt), len(src)]
+    c = capi.VGICPCore(local_rank)
+    c.set_target_cloud_device(ptrs[0], n_pts[0], 3); c.find_target_neighbors(20); c.calculate_target_covariances(capi.REG_PLANE)
+    c.set_source_cloud_device(ptrs[1], n_pts[1], 3); c.find_source_neighbors(20); c.calculate_source_covariances(capi.REG_PLANE)
+    r = c.gicp_align()
+    T = r["T"].astype(np.float32).astype(np.float64)
+    fitness = c.fitness_score(T)
+    nxt = [0]
+
+    def step():
+        c.gicp_swap_source_and_target()
+        i = nxt[0]
+        c.set_source_cloud_device(ptrs[i], n_pts[i], 3); c.find_source_neighbors(20); c.calculate_source_covariances(capi.REG_PLANE)
+        out = c.gicp_align()
+        nxt[0] = 1 - i
+        return out
+    for _ in range(warmup):
+        r = step()
+    times, n_launch = [], 0
+    for _rep in range(REPEATS):
+        c.synchronize(); torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            r = step()
+            n_launch += r["num_launches"]
+        c.synchronize(); torch.cuda.synchronize()
+        times.append(time.perf_counter() - t0)
+    el, lo, hi = median_of(times)
+    stage = {}
+    if not args.no_profile:
+        c.profile_reset(); c.profile_enable(1)
+        for _ in range(10):
+            step()
+        for _ in range(10):
+            c.fitness_score(T)
+        c.profile_enable(0)
+        for cls in ("gicp_nn", "cost", "knn", "sort", "cov", "fitness"):
+            ms, n = c.profile_get(cls)
+            if n:
+                stage[cls] = {"total_ms": round(ms, 3), "launches": n, "avg_us": round(ms / n * 1e3, 3)}
+    roof = None
+    if "gicp_nn" in stage:
+        roof = valu_roofline("fgicp17k_nn1", "nn1_rows_kernel", stage["gicp_nn"]["avg_us"], n_pts[1], n_pts[0])
+        roof["note"] = "four queries per wave (one per 16-lane row), boxes nearest first; the full-sweep-equivalent rate is what a brute-force N x N kernel would have to sustain"
+    c.close()
+    return {"metric": "registrations/sec (100-iter reuse), FastGICP (nearest-point correspondences)", "value": round(steps / el, 3), "unit": "registrations/sec", "n_gpus": 1, "steps": steps, "warmup": warmup,
+            "repeats": REPEATS, "ms_per_step": round(el / steps * 1e3, 5), "ms_per_step_min": round(lo / steps * 1e3, 5), "ms_per_step_max": round(hi / steps * 1e3, 5),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "bundled scans (real LiDAR)", "fitness_score": round(float(fitness), 6),
+            "fitness_us": stage.get("fitness", {}).get("avg_us"),
+            "config": {"workload": desc, "method": "FastGICP (fast_gicp_impl.hpp:118-240 on the device)", "k_correspondences": 20, "covariance": "knn", "regularization": "PLANE",
+                       "loop": "100times_reuse (align.cpp:87-101)", "inputs": "resident in HBM before the timed region"},
+            "per_registration": {"kernel_launches_lm": n_launch / (steps * REPEATS), "converged": bool(r["converged"])},
+            "roofline": roof, "stages": stage}
+
+
 def run_reference_api(args, steps, warmup):
     """`bundled17k_parallel_kdtree`: what a user of the reference gets who switches libraries and changes NOTHING -- pygicp.FastVGICPCuda() with its default
     NearestNeighborMethod::CPU_PARALLEL_KDTREE (fast_vgicp_cuda_impl.hpp:27), host clouds in, the 100times_reuse loop of align.cpp:87-101 through the
@@ -1244,6 +1308,11 @@ def main():
             raise SystemExit("lidar_stream is a single-GPU workload")
         emit(run_stream(args, args.steps, args.warmup))
         return
+    if args.workload == "fgicp17k":
+        if world != 1:
+            raise SystemExit("fgicp17k is a single-GPU workload")
+        emit(run_fgicp(args, args.steps, args.warmup, local_rank))
+        return
     # test-only knobs to walk the N > 1 control flow on a single-GPU box: all ranks on device 0, gloo for the barrier
     share_gpu = os.environ.get("FVH_BENCH_SHARE_GPU") == "1"
     backend = os.environ.get("FVH_BENCH_BACKEND", "nccl")
@@ -1299,7 +1368,7 @@ def main():
 
     # ---- the other single-GPU configurations of BASELINE.json, time-boxed ----
     default_headline = args.workload == "bundled17k" and args.cov == "knn" and world == 1
-    names = [] if args.configs == "none" else (args.configs.split(",") if args.configs else (["bundled17k_rbf_kernel", "bundled17k_parallel_kdtree", "synth100k_rbf", "synth1m", "lidar_stream"] if default_headline else []))
+    names = [] if args.configs == "none" else (args.configs.split(",") if args.configs else (["bundled17k_rbf_kernel", "bundled17k_parallel_kdtree", "bundled17k_fgicp", "synth100k_rbf", "synth1m", "lidar_stream"] if default_headline else []))
     if names:
         configs = {}
         for name in names:
@@ -1311,6 +1380,8 @@ def main():
                     configs[name] = run_stream(args, 60, 5)
                 elif name == "bundled17k_parallel_kdtree":
                     configs[name] = run_reference_api(args, 60, 5)
+                elif name == "bundled17k_fgicp":
+                    configs[name] = run_fgicp(args, 60, 5, local_rank)
                 else:
                     wl, cov, search, steps, warmup, cpu_s = EXTRA_CONFIGS[name]
                     configs[name] = run_registration(args, wl, cov, search, steps, warmup, local_rank, cpu_budget=cpu_s, cpu=cpu_s > 0)
