@@ -5,7 +5,7 @@ import subprocess
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_DIR = os.path.join(_HERE, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libfast_vgicp_hip.so")
-SOURCES = [os.path.join(_HERE, "csrc", f) for f in ("fvh_capi.hip", "kernels_compat.hpp", "kernels_cost.hpp", "kernels_cov.hpp", "kernels_voxelmap.hpp", "kernels_sort.hpp", "kernels_downsample.hpp", "kernels_peer.hpp", "dev_math.hpp")]
+SOURCES = [os.path.join(_HERE, "csrc", f) for f in ("fvh_capi.hip", "host_runtime.inc.hpp", "host_stages.inc.hpp", "host_gicp.inc.hpp", "host_downsample.inc.hpp", "kernels_compat.hpp", "kernels_cost.hpp", "kernels_cov.hpp", "kernels_voxelmap.hpp", "kernels_sort.hpp", "kernels_downsample.hpp", "kernels_peer.hpp", "dev_math.hpp")]
 HEADER = os.path.join(os.path.dirname(_HERE), "include", "fast_vgicp_hip.h")
 # -disable-machine-licm: the persistent LM kernel is one big loop over LM transitions; machine LICM hoists ~25 constant
 # materialisations and thread-index-derived addresses of its epilogue into the kernel prologue, where they stay live across

@@ -30,6 +30,23 @@ class LmResult(C.Structure):
                 ("num_linearize", C.c_int), ("num_error_evals", C.c_int), ("lm_failed", C.c_int), ("num_launches", C.c_int)]
 
 
+class EngineParams(C.Structure):
+    """fvh_engine_params (include/fast_vgicp_hip.h): the routes / thresholds / watchdogs of ONE handle"""
+    _fields_ = [("struct_size", C.c_int), ("sort_mode", C.c_int), ("sort_items", C.c_int), ("sort_fused_bits", C.c_int), ("sort_two_pass_max", C.c_int),
+                ("sort_coop_watchdog_ticks", C.c_ulonglong), ("knn_nearest_first_max_points", C.c_int), ("knn_block", C.c_int), ("coherent_min_points", C.c_int),
+                ("bitmap_min_points", C.c_int), ("bitmap_max_bytes", C.c_ulonglong), ("persistent", C.c_int), ("persist_watchdog_ticks", C.c_ulonglong),
+                ("peer_watchdog_ticks", C.c_ulonglong), ("lm_everywhere", C.c_int), ("cost_prio", C.c_int), ("cost_split", C.c_int), ("cost_group_max", C.c_int),
+                ("cost_max_blocks", C.c_int), ("cost_target_items", C.c_longlong), ("zerocopy_result", C.c_int), ("host_wait_block", C.c_int),
+                ("result_query_spins", C.c_ulonglong), ("side_stream", C.c_int), ("pinned_upload_max", C.c_ulonglong), ("zerocopy_upload_max", C.c_ulonglong),
+                ("avg_fused", C.c_int)]
+
+
+def default_engine_params():
+    p = EngineParams()
+    load().fvh_default_engine_params(C.byref(p))
+    return p
+
+
 class FvhError(RuntimeError):
     pass
 
@@ -123,6 +140,21 @@ class _Core:
             raise FvhError("%s%s: status %d: %s" % (self._prefix, name, rc, msg.decode() if msg else ""))
 
     # ---- shared API ----
+    def get_engine_params(self):
+        p = EngineParams()
+        self._call("get_engine_params", C.byref(p))
+        return p
+
+    def set_engine_params(self, **fields):
+        """change some of this handle's engine parameters (names: fvh_engine_params), e.g. set_engine_params(persistent=0, sort_mode=1)"""
+        p = self.get_engine_params()
+        for k, v in fields.items():
+            if k not in dict(EngineParams._fields_) or k == "struct_size":
+                raise FvhError("unknown engine parameter %r" % k)
+            setattr(p, k, v)
+        self._call("set_engine_params", C.byref(p))
+        return p
+
     def set_resolution(self, r):
         self._call("set_resolution", C.c_double(r))
 

@@ -31,238 +31,11 @@
 using namespace fvh;
 
 namespace {
-
-constexpr int MAX_COST_BLOCKS = MAX_PARTIAL_ROWS;
-
-struct DevBuf {
-  void* p = nullptr;
-  size_t cap = 0;
-  hipError_t ensure(size_t bytes) {
-    if (bytes <= cap) return hipSuccess;
-    if (p) { hipError_t e = hipFree(p); p = nullptr; cap = 0; if (e != hipSuccess) return e; }
-    size_t want = bytes + bytes / 4 + 256;
-    hipError_t e = hipMalloc(&p, want);
-    if (e == hipSuccess) cap = want;
-    return e;
-  }
-  void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
-  template <typename T> T* as() const { return reinterpret_cast<T*>(p); }
-};
-
-struct CloudDev {
-  int n = 0, k = 0;
-  DevBuf box;                          // bounding cube {~ordered(min) x3, ordered(max) x3}, reduced by pack_points_kernel
-  DevBuf bbox2;                        // boxes of 64 consecutive tile boxes
-  DevBuf order;                        // Morton permutation: order[j] = original index of the j-th point along the curve
-  DevBuf pts, cov, nbr, bbox, sorted;  // sorted: Morton-ordered copy, .w = original index; bbox: boxes of its 64-point tiles
-  bool has_pts = false, has_cov = false, has_nbr = false, has_sorted = false;
-  DevBuf cov_sorted;                   // the covariances again, in Morton order (clouds the LM loop walks in that order: coalesced instead of gathered); has_cov_sorted: of the current cov
-  bool has_cov_sorted = false;
-  bool nbr_tile_only = false;          // multi-GPU: the neighbour lists exist for this rank's tile only
-  bool has_box = false;                // box holds the bounding cube of the CURRENT points (uploads that skip it: NDT, downsampler)
-  bool box_dirty = false;              // box holds the cube of a cloud (cleared again by the cooperative sort that consumes it)
-  void swap(CloudDev& o) { std::swap(*this, o); }
-  void release() { box.release(); pts.release(); cov.release(); nbr.release(); bbox.release(); bbox2.release(); sorted.release(); order.release(); cov_sorted.release(); }
-};
-
-// Clouds of this size and up are walked in Morton order (PMC: 2.8x HBM over-fetch on a randomly ordered 100k scan
-// against a 1M-point map). Below it everything is L2-resident and the extra index load is not worth it.
-constexpr int COHERENT_MIN_POINTS = 32768;
-inline const int* coherent_order(const CloudDev& c) {
-  static const int min_pts = [] { const char* v = getenv("FVH_COHERENT_MIN_POINTS"); return v ? atoi(v) : COHERENT_MIN_POINTS; }();
-  return (c.has_sorted && c.n >= min_pts) ? c.order.as<int>() : nullptr;
-}
-
-struct VoxelMapDev {
-  double res = 1.0;
-  unsigned capacity = 0;
-  DevBuf table, acc, occupied, compact_pts, compact_cov;
-  DevBuf bitmap, grid;    // occupancy bitmap of a large map + its VmGrid (kernels_voxelmap.hpp); has_bitmap: built for the live map
-  bool has_bitmap = false;
-  DevBuf canon;           // canonical (key-sorted) order of the compact voxel list (multi-GPU NDT D2D: every rank cuts the same list); has_canon: of the live map
-  bool has_canon = false;
-  DevBuf compat_keys, compat_idx, compat_seg, compat_hist;  // FVH_COMPUTE_CUDA_COMPAT: (bucket, point index) pairs x 2, run starts per bucket, radix histograms (kernels_compat.hpp)
-  DevBuf region;          // VmRegion of a map that holds one rank's shard only (multi-GPU, fvh_vgicp_set_target_map_sharding)
-  bool is_shard = false;  // the live map was built through `region`
-  DevBuf keys[2];   // voxel keys, double buffered: keys[cur] belongs to the live map, the other one is what the next build fills
-  DevBuf counters;  // 2 sets of 16 ints, [0] num_voxels [1] dropped; set `cur` belongs to the live map
-  int cur = 0;
-  unsigned clean_cap = 0;  // keys[cur ^ 1], counter set cur ^ 1 and acc are clean (EMPTY / 0) over this capacity; 0 = unknown
-  int* counters_cur() const { return counters.as<int>() + 16 * cur; }
-  const unsigned long long* keys_cur() const { return keys[cur].as<unsigned long long>(); }
-  bool valid = false;
-  int nv_hint = -1;      // voxel count of the last build seen through a readback; sizes the next table
-  int num_skipped = 0;   // points of the last fetched build that belong to no voxel (non-finite / out of the 21-bit range)
-  // lazily fetched host copies (getters only)
-  bool host_valid = false;
-  std::vector<uint4> h_table;
-  std::vector<int> h_occupied;
-  std::unordered_map<int, int> bucket_to_index;
-  void invalidate() { valid = false; host_valid = false; has_bitmap = false; is_shard = false; has_canon = false; }
-  void release() { table.release(); acc.release(); occupied.release(); compact_pts.release(); compact_cov.release(); counters.release(); keys[0].release(); keys[1].release(); bitmap.release(); grid.release(); region.release(); canon.release(); compat_keys.release(); compat_idx.release(); compat_seg.release(); compat_hist.release(); clean_cap = 0; has_bitmap = false; is_shard = false; has_canon = false; }
-};
-
-struct Profiler {
-  bool on = false;
-  bool cost_only = false;  // level 2: only the LM / cost launches are bracketed (two events per registration instead of twelve)
-  struct Rec { std::vector<std::pair<hipEvent_t, hipEvent_t>> ev; size_t used = 0; };
-  std::map<std::string, Rec> recs;
-  hipEvent_t begin(const char* cls, hipStream_t s, hipEvent_t* stop_out) {
-    Rec& r = recs[cls];
-    if (r.used == r.ev.size()) {
-      hipEvent_t a, b;
-      (void)hipEventCreate(&a); (void)hipEventCreate(&b);
-      r.ev.push_back({a, b});
-    }
-    auto& pr = r.ev[r.used++];
-    (void)hipEventRecord(pr.first, s);
-    *stop_out = pr.second;
-    return pr.first;
-  }
-  void reset() { for (auto& kv : recs) kv.second.used = 0; }
-  void destroy() { for (auto& kv : recs) for (auto& pr : kv.second.ev) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); } recs.clear(); }
-};
-
-// RCCL is dlopen'ed on first use so single-GPU users never load it.
-struct Rccl {
-  struct UID { char b[128]; };  // ncclUniqueId (passed by value)
-  void* lib = nullptr;
-  int (*GetUniqueId)(void*) = nullptr;
-  int (*CommInitRank)(void**, int, UID, int) = nullptr;
-  int (*CommDestroy)(void*) = nullptr;
-  int (*AllReduce)(const void*, void*, size_t, int, int, void*, hipStream_t) = nullptr;
-  int (*AllGather)(const void*, void*, size_t, int, void*, hipStream_t) = nullptr;
-  bool load() {
-    if (lib) return true;
-    // reuse the RCCL the process already has (e.g. the one torch.distributed loaded) before loading another copy
-    lib = dlopen("librccl.so", RTLD_NOW | RTLD_NOLOAD);
-    if (!lib) lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_NOLOAD);
-    // RTLD_LOCAL: a process may also hold torch's bundled RCCL; two copies with globally visible symbols
-    // interpose each other and corrupt the heap at exit
-    if (!lib) lib = dlopen("librccl.so", RTLD_NOW | RTLD_LOCAL);
-    if (!lib) lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL);
-    if (!lib) return false;
-    GetUniqueId = (decltype(GetUniqueId))dlsym(lib, "ncclGetUniqueId");
-    CommInitRank = (decltype(CommInitRank))dlsym(lib, "ncclCommInitRank");
-    CommDestroy = (decltype(CommDestroy))dlsym(lib, "ncclCommDestroy");
-    AllReduce = (decltype(AllReduce))dlsym(lib, "ncclAllReduce");
-    AllGather = (decltype(AllGather))dlsym(lib, "ncclAllGather");
-    return GetUniqueId && CommInitRank && CommDestroy && AllReduce && AllGather;
-  }
-};
-Rccl g_rccl;
-// Gang kernels (the cooperative sort, the persistent LM kernel: grids whose workgroups wait for each other) of two handles could starve
-// each other of CU slots (the watchdogs + fall-backs recover, slowly). The persistent LM launches split the slots through the SlotPool
-// below; the cooperative sort is used only while no OTHER handle has a gang kernel IN FLIGHT. "In flight" is tracked, not guessed: a
-// handle marks itself under the registry's lock before it launches one (check and mark are one atomic step across host threads), records
-// an event behind it, and is in flight until that event has fired or the handle has seen its own result (align returned / synchronize).
-// A second handle that merely exists (the reference's align.cpp keeps its NDT object alive while the VGICP rows run), or one that the
-// same thread uses in turn, costs nothing. (Round 4 used a 20 ms wall-clock window over 64 hashed slots here.)
-struct Engine;
-struct GangRegistry {
-  std::mutex mu;
-  std::vector<Engine*> engines;  // registration handles alive in this process
-} g_gangs;
-std::atomic<int> g_sort_routes[4];  // sorts queued by this process: cooperative kernel, one workgroup, two-launch passes, four-launch passes (fvh_debug_sort_routes)
-inline long long steady_ns() { return std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
-
-// Co-resident workgroup slots of a device, shared by the persistent LM launches of this process. A persistent grid must be
-// resident as a whole, so concurrent aligns (several handles driven by several host threads) SPLIT the slots instead of
-// one taking the device and the others falling back to one launch per LM transition: a launch is granted
-// min(what it wants, slots / recent concurrency, what is free). Other PROCESSES on the same GPU are invisible here: that
-// case is caught by the barrier watchdog and answered with a back-off (Engine::persist_backoff).
-struct SlotPool {
-  std::mutex mu;
-  int reserved[16] = {0}, active[16] = {0}, recent[16] = {0}, calm[16] = {0};
-  std::chrono::steady_clock::time_point last_contention[16];
-  static constexpr int DECAY_AFTER = 32;       // releases in a row that saw less concurrency than the estimate before the estimate drops by one
-  static constexpr int QUIET_RESET_MS = 20;    // no overlapping align / refusal for this long: the burst is over, the estimate starts again from what is active now
-  struct Grant { int n = 0; };  // n workgroups, spread over the chip (block b runs on XCD b % 8)
-  // (Round 4 could also confine a grant to a subset of the XCDs -- K concurrent aligns sharing the chip XCD by XCD, or a small grid on ONE
-  // XCD. Measured, profiles/r04_concurrency.txt / r04_small_grid_layouts.txt: no better than chip-wide grids of cap / K workgroups -- a
-  // hand-off costs ~1 us whether or not it crosses XCDs, and a confined launch has to leave room for the blocks that only pass through.
-  // Removed from the pool and from the kernel.)
-  Grant acquire(int dev, int cap, int want) {  // -> n == 0: use the multi-launch route
-    std::lock_guard<std::mutex> lk(mu);
-    dev &= 15;
-    const auto now = std::chrono::steady_clock::now();
-    active[dev]++;
-    // A burst of concurrent aligns (a 4-stream leg of a benchmark, a batch of parallel requests) must not throttle the lone aligns that
-    // follow it: once nothing has overlapped for QUIET_RESET_MS the estimate is what is active right now. (Round 2 never forgot --
-    // a leak; decaying only per calm release kept a lone handle at cap / 4 for its next ~100 aligns.)
-    if (active[dev] > 1) last_contention[dev] = now;
-    else if (recent[dev] > 1 && now - last_contention[dev] > std::chrono::milliseconds(QUIET_RESET_MS)) { recent[dev] = 1; calm[dev] = 0; }
-    recent[dev] = std::max(recent[dev], active[dev]);
-    static const int max_split = [] { const char* v = getenv("FVH_SLOT_MAX_SPLIT"); return v ? std::max(1, atoi(v)) : 4; }();
-    // (FVH_CONTENDED_SLOT_PCT: the part of the device the concurrent aligns may hold between them -- the rest stays free for the other
-    // streams' neighbour searches and sorts, which cannot start on a CU whose register file three resident LM workgroups fill)
-    static const int contended_pct = [] { const char* v = getenv("FVH_CONTENDED_SLOT_PCT"); return v ? std::min(100, std::max(10, atoi(v))) : 100; }();
-    const bool contended = recent[dev] > 1;
-    const int pool = contended ? cap * contended_pct / 100 : cap;
-    const int share = std::max(1, pool / std::max(1, std::min(recent[dev], max_split)));
-    Grant g;
-    g.n = std::min(std::min(want, share), std::max(0, cap - reserved[dev]));
-    if (g.n < std::min(want, 32)) {  // too little left to be worth a gang launch
-      // a refused request holds nothing and is never released: it must not stay counted in `active` (round 2 leaked it here, and
-      // every later persistent launch of the process got cap / min(recent, 4) workgroups for good). The concurrency ESTIMATE keeps
-      // the bump: the next grants shrink so that this caller gets its share on the retry; it decays slowly in release().
-      active[dev]--;
-      calm[dev] = 0;
-      last_contention[dev] = now;
-      return Grant{};
-    }
-    reserved[dev] += g.n;
-    return g;
-  }
-  void snapshot(int dev, int* res, int* act, int* rec) {
-    std::lock_guard<std::mutex> lk(mu);
-    dev &= 15;
-    *res = reserved[dev]; *act = active[dev]; *rec = recent[dev];
-  }
-  void release(int dev, const Grant& g) {
-    std::lock_guard<std::mutex> lk(mu);
-    dev &= 15;
-    reserved[dev] -= g.n;
-    active[dev]--;
-    // The estimate of the concurrency decays slowly: host threads spend half their time between aligns, so `active` at a release
-    // under-reads the contention. (Dropping it at every calm release made four 474-workgroup aligns oscillate: shares grew back to
-    // cap / 2, the third thread was refused, and 40 % of its aligns took the multi-launch route.) Under SUSTAINED but lower concurrency
-    // the estimate comes down one step per DECAY_AFTER calm releases; once nothing overlaps at all, acquire() resets it (QUIET_RESET_MS).
-    if (recent[dev] > active[dev] + 1) {
-      if (++calm[dev] >= DECAY_AFTER) { recent[dev]--; calm[dev] = 0; }
-    } else {
-      calm[dev] = 0;
-    }
-  }
-};
-SlotPool g_slots;
-// XCD-local hand-offs of the persistent LM kernel (kernels_cost.hpp: xcd_local). On by default; every launch checks that the
-// dispatcher placed the members of each group on one XCD (abort code 3 otherwise: the block -> XCD mapping is an observation, not a
-// contract), and after XCD_LOCAL_MAX_STRIKES such aborts the process stops asking for it. FVH_XCD_LOCAL=0 never asks for it.
-constexpr int XCD_LOCAL_MAX_STRIKES = 3;
-std::atomic<int> g_xcd_local_strikes{0};
-inline bool xcd_local_wanted() {
-  static const bool env_on = [] { const char* v = getenv("FVH_XCD_LOCAL"); return !v || atoi(v) != 0; }();
-  return env_on && g_xcd_local_strikes.load() < XCD_LOCAL_MAX_STRIKES;
-}
-// the layout of one cost launch: both routes of an align take the same (nb, ng), i.e. the same partition and summation order
-struct GridPlan { int nb = 0; int ng = 0; int local = 0; };
-// Grids of up to SINGLE_LEVEL_MAX_BLOCKS workgroups (NDT D2D over a few thousand source voxels, DIRECT1 at 17k points):
-//   FVH_SMALL_GRID_LAYOUT=2 (default)  chip-wide in EIGHT groups like the large grids (XCD-local rows and broadcast, one cross-XCD hand-off);
-//                        =0            chip-wide, ONE group: rows -> workgroup 0 -> broadcast, write-through hand-offs (round 3; kept for A/B runs
-//                                      and as the second layout the bit-identity tests walk). (=1, one XCD only, was measured worse and is gone.)
-// The group count is a function of the grid size alone, so that every route of an align adds the sums in the same order.
-inline int small_grid_layout() {
-  static const int v = [] { const char* e = getenv("FVH_SMALL_GRID_LAYOUT"); return (e && atoi(e) == 0) ? 0 : 2; }();
-  return v;
-}
-inline int default_groups(int nb) {
-  if (nb > SINGLE_LEVEL_MAX_BLOCKS) return TICKET_GROUPS;
-  return (small_grid_layout() == 2 && nb >= 2 * TICKET_GROUPS) ? TICKET_GROUPS : 1;
-}
+#include "host_runtime.inc.hpp"
 
 struct Engine {
   int device = 0;
+  fvh_engine_params params = env_engine_defaults();  // this handle's routes / thresholds / watchdogs (fvh_*_set_engine_params)
   hipStream_t stream = nullptr;
   std::string err;
   int align_optimizer = 0;  // optimiser of the launches being queued: 0 LM (and every host-driven evaluation), 1 Gauss-Newton (fvh_lm_params::optimizer)
@@ -359,8 +132,7 @@ struct Engine {
   bool side_pending = false;       // a build on `side` the main stream has not been ordered after yet
   bool quiet = false, was_quiet = false;  // the main stream had drained when the current API call began (set by align on return)
   hipStream_t side_stream() {
-    static const bool on = [] { const char* v = getenv("FVH_SIDE_STREAM"); return !v || atoi(v) != 0; }();
-    if (!on || comm || peer.attached()) return nullptr;
+    if (!params.side_stream || comm || peer.attached()) return nullptr;
     if (!side) {
       if (hipStreamCreateWithFlags(&side, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); side = nullptr; return nullptr; }
       if (hipEventCreateWithFlags(&side_done, hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); (void)hipStreamDestroy(side); side = nullptr; return nullptr; }
@@ -588,1548 +360,9 @@ inline void pose_to_colmajor16(const PoseD& p, double* T) {
   T[15] = 1.0;
 }
 
-// ---------------------------------------------------------------------------------------------
-// shared building blocks
-// ---------------------------------------------------------------------------------------------
-int upload_cloud(Engine* e, CloudDev& c, const float* xyz, int n, int stride, bool on_device, bool want_box = true /* the cooperative sort's bounding cube (VGICP clouds) */,
-                 hipStream_t on = nullptr /* another stream than the handle's (the prepared-source slot of an NDT handle) */) {
-  hipStream_t const st = on ? on : e->stream;
-  if (n < 0 || (n > 0 && !xyz)) return e->fail(FVH_ERR_INVALID_ARGUMENT, "set_cloud: null points");
-  if (stride != 3 && stride != 4) return e->fail(FVH_ERR_INVALID_ARGUMENT, "set_cloud: stride must be 3 or 4 floats");
-  HIP_OR_FAIL(e, c.pts.ensure(sizeof(float4) * (size_t)std::max(n, 1)));
-  c.n = n;
-  c.has_pts = true;
-  c.has_sorted = false;
-  if (n == 0) return FVH_OK;
-  unsigned* boxp = nullptr;
-  c.has_box = want_box;
-  if (want_box) {
-    const bool fresh_box = c.box.p == nullptr;
-    HIP_OR_FAIL(e, c.box.ensure(64));
-    if (fresh_box || c.box_dirty) HIP_OR_FAIL(e, hipMemsetAsync(c.box.p, 0, 64, st));  // (the cooperative sort's finish kernel leaves it cleared)
-    c.box_dirty = true;
-    boxp = c.box.as<unsigned>();
-  }
-  // widen `srcp` to float4 (+ bounding cube); `slot`: the pinned upload slot that kernel reads (its "free again" event follows it)
-  auto pack = [&](const float* srcp, int slot) -> int {
-    pack_points_kernel<<<pack_grid(n, boxp != nullptr), 256, 0, st>>>(srcp, n, stride, c.pts.as<float4>(), boxp);
-    HIP_OR_FAIL(e, hipGetLastError());
-    if (slot >= 0) { HIP_OR_FAIL(e, hipEventRecord(e->upload_done[slot], st)); e->upload_busy[slot] = true; }
-    return FVH_OK;
-  };
-  if (on_device) {
-    int rc = pack(xyz, -1);
-    if (rc) return rc;
-  } else {
-    // H2D the xyz (stride 3) / xyzi (stride 4, e.g. a KITTI .bin buffer) array into a staging buffer, then widen to float4 on device
-    const size_t bytes = sizeof(float) * stride * (size_t)n;
-    HIP_OR_FAIL(e, e->staging.ensure(bytes));
-    static const size_t pinned_max = [] { const char* v = getenv("FVH_PINNED_UPLOAD_MAX"); return v ? (size_t)atoll(v) : (size_t)(8u << 20); }();
-    if (bytes <= pinned_max && e->ensure_upload_pinned(bytes)) {
-      // the caller's (pageable) buffer is consumed by a plain memcpy into pinned memory of the handle; the copy to the device and
-      // everything after it is then truly asynchronous -- no stream synchronisation before returning (the reference's loop hands
-      // over a host cloud per registration: this took the PCIe-inclusive rate from 3,220 to the rate below)
-      const int us = (e->upload_slot ^= 1);
-      char* slot = static_cast<char*>(e->upload_pinned) + (size_t)us * e->upload_pinned_cap;
-      if (e->upload_busy[us]) { HIP_OR_FAIL(e, hipEventSynchronize(e->upload_done[us])); e->upload_busy[us] = false; }  // the upload before the last still reading this slot (normally long finished)
-      std::memcpy(slot, xyz, bytes);
-      // Small clouds: the widening kernel reads the pinned buffer itself, over PCIe (a 17k-point cloud is 0.2-0.3 MB: a few microseconds)
-      // -- a copy-engine transfer in front of it costs its own start-up plus a hand-over between the copy and the compute queue,
-      // ~20 us of a 250 us registration. Large clouds keep the copy engine (the kernel's PCIe reads would be the slower transfer).
-      static const size_t zero_copy_max = [] { const char* v = getenv("FVH_ZEROCOPY_UPLOAD_MAX"); return v ? (size_t)atoll(v) : (size_t)(1u << 20); }();
-      void* pinned_dev = nullptr;
-      if (bytes <= zero_copy_max && hipHostGetDevicePointer(&pinned_dev, slot, 0) == hipSuccess && pinned_dev) {
-        int rc = pack(static_cast<const float*>(pinned_dev), us);
-        if (rc) return rc;
-      } else {
-        (void)hipGetLastError();
-        HIP_OR_FAIL(e, hipMemcpyAsync(e->staging.p, slot, bytes, hipMemcpyHostToDevice, st));
-        HIP_OR_FAIL(e, hipEventRecord(e->upload_done[us], st));
-        e->upload_busy[us] = true;
-        int rc = pack(e->staging.as<float>(), -1);
-        if (rc) return rc;
-      }
-    } else {
-      HIP_OR_FAIL(e, hipMemcpyAsync(e->staging.p, xyz, bytes, hipMemcpyHostToDevice, st));
-      pack_points_kernel<<<pack_grid(n, boxp != nullptr), 256, 0, st>>>(e->staging.as<float>(), n, stride, c.pts.as<float4>(), boxp);
-      HIP_OR_FAIL(e, hipGetLastError());
-      HIP_OR_FAIL(e, hipStreamSynchronize(st));  // caller may free xyz on return (reference copies too)
-    }
-  }
-  return FVH_OK;
-}
-
-int set_neighbors(Engine* e, CloudDev& c, int k, const int* idx) {
-  if (!c.has_pts) return e->fail(FVH_ERR_BAD_STATE, "set_neighbors: cloud not set");
-  if (k <= 0 || !idx) return e->fail(FVH_ERR_INVALID_ARGUMENT, "set_neighbors: bad k / null");
-  // the covariance kernel gathers pts[idx]: an index outside [0, n) (e.g. a -1 pad of a k-NN on fewer than k points) must not reach it
-  for (size_t j = 0, m = (size_t)c.n * k; j < m; j++)
-    if ((unsigned)idx[j] >= (unsigned)c.n) return e->fail(FVH_ERR_INVALID_ARGUMENT, "set_neighbors: neighbour index " + std::to_string(idx[j]) + " outside [0, " + std::to_string(c.n) + ")");
-  HIP_OR_FAIL(e, c.nbr.ensure(sizeof(int) * (size_t)c.n * k));
-  HIP_OR_FAIL(e, hipMemcpyAsync(c.nbr.p, idx, sizeof(int) * (size_t)c.n * k, hipMemcpyHostToDevice, e->stream));
-  HIP_OR_FAIL(e, hipStreamSynchronize(e->stream));
-  c.k = k;
-  c.has_nbr = true;
-  return FVH_OK;
-}
-
-// Morton-sort the cloud (kernels_sort.hpp) and box its 64-point tiles; cached until the cloud changes.
-int ensure_sorted(Engine* e, CloudDev& c) {
-  e->device_search_seen = true;
-  if (c.has_sorted) return FVH_OK;
-  const int n = c.n;
-  static const int items_env = [] { const char* v = getenv("FVH_SORT_ITEMS"); return v ? atoi(v) : 0; }();
-  const int items = items_env > 0 ? items_env : (n <= 262144 ? 256 : (n <= 1048576 ? 512 : SORT_ITEMS_MAX));  // more, shorter waves for small clouds (latency-bound)
-  const int nwaves = (n + items - 1) / items;
-  const int ntiles = (n + 63) / 64;
-  HIP_OR_FAIL(e, c.sorted.ensure(sizeof(float4) * (size_t)n));
-  HIP_OR_FAIL(e, c.bbox.ensure(sizeof(float4) * 2 * (size_t)ntiles));
-  HIP_OR_FAIL(e, e->sort_keys.ensure(sizeof(unsigned) * 2 * (size_t)n + 64));
-  HIP_OR_FAIL(e, e->sort_idx.ensure(sizeof(int) * (size_t)n));
-  HIP_OR_FAIL(e, c.order.ensure(sizeof(int) * (size_t)n));
-  HIP_OR_FAIL(e, e->sort_hist.ensure(sizeof(unsigned) * (size_t)RADIX_BINS * (nwaves + 1)));
-  const int nsuper_small = (ntiles + 63) / 64;
-  HIP_OR_FAIL(e, c.bbox2.ensure(sizeof(float4) * 2 * (size_t)nsuper_small));
-  ProfScope ps(e, "sort");
-  static const int sort_mode = [] { const char* v = getenv("FVH_SORT_MODE"); return v ? atoi(v) : 2; }();  // 0: multi-kernel radix, 1: single workgroup, 2: cooperative (single-engine processes), 3: cooperative always
-  if (sort_mode >= 1 && n <= SORT_SMALL_MAX) {
-    // cooperative kernel (32 workgroups meeting at grid barriers) while no OTHER handle has a gang kernel in flight (GangRegistry above:
-    // two gang kernels from two streams could starve each other of CU slots; the watchdog + fallback would recover, slowly)
-    const bool coop = c.has_box && (sort_mode == 3 ? e->gang_begin(false) : (sort_mode == 2 && e->gang_begin(true)));  // (mode 1: never -- other PROCESSES' gang kernels on a shared GPU are invisible to the registry)
-    struct GangEnd { Engine* e; bool on; ~GangEnd() { if (on) e->gang_end(); } } gang_end{e, coop};  // (on every way out: the event behind whatever was queued)
-    g_sort_routes[coop ? 0 : 1].fetch_add(1, std::memory_order_relaxed);
-    if (coop) {
-      const bool fresh = e->sort_coop.p == nullptr;
-      HIP_OR_FAIL(e, e->sort_coop.ensure(COOP_STATE_BYTES));
-      SortCoopState* cs = e->sort_coop.as<SortCoopState>();
-      char* base = reinterpret_cast<char*>(cs);
-      unsigned* chist = reinterpret_cast<unsigned*>(cs + 1);
-      // once: tags of no launch everywhere (afterwards every launch rewrites the tagged words, and the state words are compared with the launch's number)
-      if (fresh) HIP_OR_FAIL(e, hipMemsetAsync(cs, 0, COOP_STATE_BYTES, e->stream));
-      if ((++e->sort_seq & (COOP_HTAG_MASK >> 1)) == 0) ++e->sort_seq;  // (a histogram tag of 0 is what fresh memory holds)
-      unsigned long long wd = 2'000'000ull;  // 20 ms
-      { const char* v = getenv("FVH_SORT_COOP_WATCHDOG_TICKS"); if (v) wd = strtoull(v, nullptr, 10); }  // test hook: 0 forces the fallback
-      unsigned long long* celem = reinterpret_cast<unsigned long long*>(base + COOP_ELEM_OFFSET);
-      sort_coop_kernel<<<COOP_WGS, COOP_THREADS, 0, e->stream>>>(c.pts.as<float4>(), n, c.order.as<int>(), c.sorted.as<float4>(), c.box.as<unsigned>(), chist, celem, cs, e->sort_seq, wd);
-      // tile boxes (one tile per wave) + super boxes (one workgroup each); when the cooperative kernel did not finish, workgroup 0 redoes everything
-      const int fin_tile_wgs = (ntiles + 15) / 16;
-      sort_coop_finish_kernel<<<fin_tile_wgs + nsuper_small, 1024, 0, e->stream>>>(c.pts.as<float4>(), n, e->sort_keys.as<unsigned>(), c.order.as<int>(), e->sort_keys.as<unsigned>() + n,
-                                                                                   e->sort_idx.as<int>(), c.sorted.as<float4>(), c.bbox.as<float4>(), c.bbox2.as<float4>(), cs, c.box.as<unsigned>(),
-                                                                                   e->sort_seq, fin_tile_wgs);
-      c.box_dirty = false;  // consumed and cleared by the finish kernel
-    } else {
-      sort_small_kernel<<<1, 1024, 0, e->stream>>>(c.pts.as<float4>(), n, e->sort_keys.as<unsigned>(), c.order.as<int>(), e->sort_keys.as<unsigned>() + n, e->sort_idx.as<int>());
-      gather_tiles_kernel<<<(ntiles + 3) / 4, 256, 0, e->stream>>>(c.pts.as<float4>(), c.order.as<int>(), n, c.sorted.as<float4>(), c.bbox.as<float4>());
-      super_bbox_kernel<<<(nsuper_small + 3) / 4, 256, 0, e->stream>>>(c.bbox.as<float4>(), ntiles, c.bbox2.as<float4>());
-    }
-    HIP_OR_FAIL(e, hipGetLastError());
-    c.has_sorted = true;
-    return FVH_OK;
-  }
-  // Large clouds: 27-bit Morton keys, stable LSD radix sort. Every kernel of this chain is a dependent stage of >= 5 us whatever it
-  // does (a 100k-point cloud is 400 KB of keys): the first histogram kernel computes the keys itself and both box levels come out
-  // of one launch (two stages less); clouds up to 256k points are ordered by the top 22 key bits in TWO 11-bit passes (cells of
-  // 4 x 4 x 2 fine cells: with a few points per cell the tiles are as compact as with the full key) instead of three 9-bit ones.
-  // Measured at 100k points: 75 us (15 stages) -> 73 (13) -> 71 (9): a 2,048-bin pass costs 34 us against 25 for a 512-bin one
-  // (the histogram's transposed [bin][wave] write), so the stage count alone buys little.
-  unsigned* keys[2] = {e->sort_keys.as<unsigned>(), e->sort_keys.as<unsigned>() + n};
-  const bool packed_box = c.has_box;  // the upload already reduced the bounding cube (pack_points_kernel): no memsets, no extra pass over the cloud
-  unsigned* box = packed_box ? c.box.as<unsigned>() : reinterpret_cast<unsigned*>(e->sort_keys.as<unsigned>() + 2 * (size_t)n);
-  if (!packed_box) {
-    HIP_OR_FAIL(e, hipMemsetAsync(box, 0xFF, 12, e->stream));
-    HIP_OR_FAIL(e, hipMemsetAsync(box + 3, 0, 12, e->stream));
-    cloud_bbox_kernel<<<std::min(256, (n + 255) / 256), 256, 0, e->stream>>>(c.pts.as<float4>(), n, box);
-  }
-  // Up to SORT_FUSED_MAX points: two launches per pass (kernels_sort.hpp: the scatter derives its cursors from per-workgroup digit counts),
-  // two passes over the top 2 x FVH_SORT_FUSED_BITS bits of the key. 100k points: 71 us in nine launches -> see profiles/r04_sort_fused.txt.
-  static const int fused_bits = [] { const char* v = getenv("FVH_SORT_FUSED_BITS"); const int b = v ? atoi(v) : 10; return (b == 9 || b == 10) ? b : 0; }();  // 0: the four-launch passes below. (9: the sort is 8 us shorter and the exact k-NN behind it 14 us longer -- coarser cells, looser tiles)
-  g_sort_routes[(fused_bits && n <= SORT_FUSED_MAX) ? 2 : 3].fetch_add(1, std::memory_order_relaxed);
-  if (fused_bits && n <= SORT_FUSED_MAX) {
-    const int fwaves = (n + SORT_FUSED_ITEMS - 1) / SORT_FUSED_ITEMS, fwgs = (fwaves + 3) / 4, fbins = 1 << fused_bits;
-    HIP_OR_FAIL(e, e->sort_hist.ensure(sizeof(unsigned) * (size_t)fbins * (size_t)(fwaves + fwgs)));
-    unsigned* fhist = e->sort_hist.as<unsigned>();
-    unsigned* fhist_wg = fhist + (size_t)fbins * fwaves;
-    for (int pass = 0; pass < 2; pass++) {
-      const int in = pass & 1, out = in ^ 1;
-      const int shift = 27 - (2 - pass) * fused_bits;
-      const bool first = pass == 0, last = pass == 1;
-      const float4* kp = first ? c.pts.as<float4>() : nullptr;  // first stage: keys computed on the way
-      const int* iin = first ? nullptr : e->sort_idx.as<int>();              // (first pass: the identity)
-      int* iout = first ? e->sort_idx.as<int>() : c.order.as<int>();         // the final permutation lands in the cloud's own buffer
-      const float4* gp = last ? c.pts.as<float4>() : nullptr;
-      float4* sp = last ? c.sorted.as<float4>() : nullptr;
-      if (fused_bits == 9) {
-        radix_hist_fused_kernel<9><<<fwgs, 256, 0, e->stream>>>(keys[in], n, shift, fwaves, fhist, fhist_wg, kp, box, packed_box ? 1 : 0);
-        radix_scatter_fused_kernel<9><<<fwgs, 256, 0, e->stream>>>(keys[in], iin, n, shift, fwaves, fhist, fhist_wg, keys[out], iout, gp, sp);
-      } else {
-        radix_hist_fused_kernel<10><<<fwgs, 256, 0, e->stream>>>(keys[in], n, shift, fwaves, fhist, fhist_wg, kp, box, packed_box ? 1 : 0);
-        radix_scatter_fused_kernel<10><<<fwgs, 256, 0, e->stream>>>(keys[in], iin, n, shift, fwaves, fhist, fhist_wg, keys[out], iout, gp, sp);
-      }
-    }
-    const int nsuper = (ntiles + 63) / 64;
-    HIP_OR_FAIL(e, c.bbox2.ensure(sizeof(float4) * 2 * (size_t)nsuper));
-    const int tile_wgs = (ntiles + 3) / 4;
-    tile_super_bbox_kernel<<<tile_wgs + nsuper, 256, 0, e->stream>>>(c.sorted.as<float4>(), n, c.bbox.as<float4>(), c.bbox2.as<float4>(), tile_wgs, packed_box ? c.box.as<unsigned>() : nullptr);
-    HIP_OR_FAIL(e, hipGetLastError());
-    if (packed_box) { c.has_box = false; c.box_dirty = false; }
-    c.has_sorted = true;
-    return FVH_OK;
-  }
-  static const int two_pass_max = [] { const char* v = getenv("FVH_SORT_TWO_PASS_MAX"); return v ? atoi(v) : 262144; }();
-  const bool two_pass = n <= two_pass_max;
-  const int passes = two_pass ? 2 : RADIX_PASSES, bits = two_pass ? 11 : RADIX_BITS, bins = 1 << bits;
-  HIP_OR_FAIL(e, e->sort_hist.ensure(sizeof(unsigned) * (size_t)bins * (nwaves + 1)));
-  // the final permutation must land in the cloud's own buffer
-  int* idx[2];
-  idx[passes & 1] = c.order.as<int>();
-  idx[(passes & 1) ^ 1] = e->sort_idx.as<int>();
-  const int wblocks = (nwaves + 3) / 4;
-  unsigned* hist = e->sort_hist.as<unsigned>();
-  unsigned* bin_tot = hist + (size_t)bins * nwaves;
-  for (int pass = 0; pass < passes; pass++) {
-    const int in = pass & 1, out = in ^ 1;
-    const int shift = two_pass ? (pass == 0 ? 5 : 16) : pass * RADIX_BITS;
-    const bool first = pass == 0, last = pass == passes - 1;
-    const float4* kp = first ? c.pts.as<float4>() : nullptr;  // first stage: keys computed on the way
-    if (two_pass) radix_hist_kernel<11><<<wblocks, 256, 0, e->stream>>>(keys[in], n, shift, nwaves, items, hist, kp, box, packed_box ? 1 : 0);
-    else radix_hist_kernel<RADIX_BITS><<<wblocks, 256, 0, e->stream>>>(keys[in], n, shift, nwaves, items, hist, kp, box, packed_box ? 1 : 0);
-    radix_binscan_kernel<<<bins / 4, 256, 0, e->stream>>>(hist, nwaves, bin_tot, bins);
-    radix_scan_kernel<<<1, 1024, 0, e->stream>>>(bin_tot, bins);
-    const int* iin = first ? nullptr : idx[in];
-    if (two_pass) radix_scatter_kernel<11><<<wblocks, 256, 0, e->stream>>>(keys[in], iin, n, shift, nwaves, items, hist, bin_tot, keys[out], idx[out], last ? c.pts.as<float4>() : nullptr, last ? c.sorted.as<float4>() : nullptr);
-    else radix_scatter_kernel<RADIX_BITS><<<wblocks, 256, 0, e->stream>>>(keys[in], iin, n, shift, nwaves, items, hist, bin_tot, keys[out], idx[out], last ? c.pts.as<float4>() : nullptr, last ? c.sorted.as<float4>() : nullptr);
-  }
-  const int nsuper = (ntiles + 63) / 64;
-  HIP_OR_FAIL(e, c.bbox2.ensure(sizeof(float4) * 2 * (size_t)nsuper));
-  const int tile_wgs = (ntiles + 3) / 4;
-  tile_super_bbox_kernel<<<tile_wgs + nsuper, 256, 0, e->stream>>>(c.sorted.as<float4>(), n, c.bbox.as<float4>(), c.bbox2.as<float4>(), tile_wgs, packed_box ? c.box.as<unsigned>() : nullptr);
-  HIP_OR_FAIL(e, hipGetLastError());
-  if (packed_box) { c.has_box = false; c.box_dirty = false; }  // consumed by the key kernel, zeroed again by the last kernel of the chain
-  c.has_sorted = true;
-  return FVH_OK;
-}
-
-// ---- multi-GPU: this rank's tile of a cloud = the range [lo, hi) of its Morton order (chunks of equal size, rank order) ----
-struct Tile { int lo, hi, chunk; };
-inline Tile peer_tile(const Engine* e, int n) {
-  if (!e->sharded()) return Tile{0, n, n};
-  const int nr = std::max(1, e->shard_ranks());
-  const int chunk = ((n + nr - 1) / nr + 63) & ~63;  // whole 64-point tiles of the sorted order
-  const int lo = std::min(n, e->shard_rank() * chunk);
-  return Tile{lo, std::min(n, lo + chunk), std::max(chunk, 1)};
-}
-constexpr unsigned long long PEER_WATCHDOG_TICKS = 200'000'000ull;  // 2 s of the 100 MHz clock: a peer may still be uploading / sorting its copy
-
-// After a sharded covariance estimation every rank holds its tile only: pack it into this rank's staging half, publish the
-// generation to all peers, and read the other tiles straight out of the peers' staging areas (kernels_peer.hpp).
-int peer_allgather_cov(Engine* e, CloudDev& c) {
-  Engine::PeerComm& pc = e->peer;
-  const Tile t = peer_tile(e, c.n);
-  if ((size_t)t.chunk * 32 > pc.stage_half_bytes) return e->fail(FVH_ERR_INVALID_ARGUMENT, "peer exchange: cloud larger than the max_points given to peer_export");
-  const unsigned long long gen = ++pc.stage_gen;
-  const size_t off = PEER_STAGE_OFFSET + (size_t)(gen & 1ull) * pc.stage_half_bytes;
-  const PeerView pv = pc.view(0);
-  ProfScope ps(e, "peer_gather");
-  if (t.hi > t.lo)
-    peer_pack_cov_kernel<<<(t.hi - t.lo + 255) / 256, 256, 0, e->stream>>>(c.cov.as<float4>(), c.order.as<int>(), t.lo, t.hi, reinterpret_cast<float4*>(pc.region + off));
-  peer_signal_kernel<<<1, 64, 0, e->stream>>>(pv, gen);
-  HIP_OR_FAIL(e, pc.err.ensure(64));
-  HIP_OR_FAIL(e, hipMemsetAsync(pc.err.p, 0, 4, e->stream));
-  peer_wait_kernel<<<1, 64, 0, e->stream>>>(pv, gen, PEER_WATCHDOG_TICKS, pc.err.as<int>());
-  peer_gather_cov_kernel<<<(c.n + 255) / 256, 256, 0, e->stream>>>(pv, off, c.cov.as<float4>(), c.order.as<int>(), c.n, t.chunk, pc.err.as<int>());
-  HIP_OR_FAIL(e, hipGetLastError());
-  int* h_err = reinterpret_cast<int*>(e->pinned);
-  HIP_OR_FAIL(e, hipMemcpyAsync(h_err, pc.err.p, 4, hipMemcpyDeviceToHost, e->stream));
-  HIP_OR_FAIL(e, hipStreamSynchronize(e->stream));
-  if (*h_err) return e->fail(FVH_ERR_COMM, "peer exchange: a rank did not publish its covariance tile in time (every rank must make the same sequence of calls)");
-  return FVH_OK;
-}
-
-// The same all-gather on the RCCL route (fvh_vgicp_comm_init): every rank packs the covariances of its tile into its slot of a buffer that
-// holds the whole cloud in Morton order -- tile r is the range [r chunk, (r + 1) chunk) of it --, ncclAllGather fills the other slots in
-// place (32 B per point over xGMI), and one kernel scatters the buffer back to the original point order.
-__global__ __launch_bounds__(256) void scatter_sorted_cov_kernel(const float4* __restrict__ stage, float4* __restrict__ cov, const int* __restrict__ order, int n, int lo, int hi) {
-  const int j = blockIdx.x * 256 + threadIdx.x;
-  if (j >= n || (j >= lo && j < hi)) return;  // (this rank's own tile is already in place)
-  const int i = order[j];
-  cov[2 * (size_t)i] = stage[2 * (size_t)j];
-  cov[2 * (size_t)i + 1] = stage[2 * (size_t)j + 1];
-}
-int rccl_allgather_cov(Engine* e, CloudDev& c) {
-  const Tile t = peer_tile(e, c.n);
-  const int nr = std::max(1, e->shard_ranks());
-  // With a communicator attached every rank uploads the SAME full cloud (the engine shards internally); a caller still handing each rank
-  // its own tile (the contract before round 4) would get mismatched all-gather counts -- a hang or a corrupted collective. Checked
-  // per call: max over the ranks of (n, -n) must be (n, -n) everywhere.
-  {  // (on EVERY call: gated on this rank's own last size, a rank whose size had not changed skipped the collective the others issued -- a hang)
-    int* d = e->misc.as<int>() + 32;
-    int* hh = reinterpret_cast<int*>(e->pinned) + 8;
-    hh[0] = c.n; hh[1] = -c.n;
-    HIP_OR_FAIL(e, hipMemcpyAsync(d, hh, 8, hipMemcpyHostToDevice, e->stream));
-    const int rc0 = g_rccl.AllReduce(d, d, 2, /*ncclInt32*/ 2, /*ncclMax*/ 2, e->comm, e->stream);
-    if (rc0 != 0) return e->fail(FVH_ERR_COMM, "ncclAllReduce failed with code " + std::to_string(rc0));
-    HIP_OR_FAIL(e, hipMemcpyAsync(hh, d, 8, hipMemcpyDeviceToHost, e->stream));
-    HIP_OR_FAIL(e, hipStreamSynchronize(e->stream));
-    if (hh[0] != c.n || hh[1] != -c.n)
-      return e->fail(FVH_ERR_COMM, "the ranks hold clouds of different sizes (" + std::to_string(-hh[1]) + " .. " + std::to_string(hh[0]) + " points): with a communicator attached every rank "
-                     "uploads the same FULL cloud and the engine shards it internally (include/fast_vgicp_hip.h: fvh_vgicp_comm_init)");
-  }
-  HIP_OR_FAIL(e, e->gather_stage.ensure(sizeof(float4) * 2 * (size_t)t.chunk * nr));
-  float4* stage = e->gather_stage.as<float4>();
-  ProfScope ps(e, "peer_gather");
-  if (t.hi > t.lo)
-    peer_pack_cov_kernel<<<(t.hi - t.lo + 255) / 256, 256, 0, e->stream>>>(c.cov.as<float4>(), c.order.as<int>(), t.lo, t.hi, stage + 2 * (size_t)t.lo);
-  HIP_OR_FAIL(e, hipGetLastError());
-  const int rc = g_rccl.AllGather(stage + 2 * (size_t)e->shard_rank() * t.chunk, stage, (size_t)t.chunk * 8, /*ncclFloat*/ 7, e->comm, e->stream);
-  if (rc != 0) return e->fail(FVH_ERR_COMM, "ncclAllGather failed with code " + std::to_string(rc));
-  scatter_sorted_cov_kernel<<<(c.n + 255) / 256, 256, 0, e->stream>>>(stage, c.cov.as<float4>(), c.order.as<int>(), c.n, t.lo, t.hi);
-  HIP_OR_FAIL(e, hipGetLastError());
-  return FVH_OK;
-}
-inline int allgather_cov(Engine* e, CloudDev& c) { return e->peer.attached() ? peer_allgather_cov(e, c) : rccl_allgather_cov(e, c); }
-
-int find_neighbors(Engine* e, CloudDev& c, int k) {
-  if (!c.has_pts) return e->fail(FVH_ERR_BAD_STATE, "find_neighbors: cloud not set");
-  if (k <= 0 || k > 64) return e->fail(FVH_ERR_INVALID_ARGUMENT, "find_neighbors: k must be in [1, 64]");
-  if (c.n < k) return e->fail(FVH_ERR_INVALID_ARGUMENT, "find_neighbors: fewer points than k");
-  HIP_OR_FAIL(e, c.nbr.ensure(sizeof(int) * (size_t)c.n * k));
-#ifdef FVH_TEST_KERNELS  // test build only: FVH_KNN_MODE=0 selects the superseded full LDS-tiled sweep as a cross-check of the culled search
-  static const int knn_mode = [] { const char* v = getenv("FVH_KNN_MODE"); return v ? atoi(v) : 1; }();
-  if (knn_mode == 0 && !e->sharded()) {
-    const int waves = (c.n + KNN_Q - 1) / KNN_Q;
-    ProfScope ps(e, "knn");
-    knn_bruteforce_kernel<<<(waves + 3) / 4, 256, 0, e->stream>>>(c.pts.as<float4>(), c.n, k, c.nbr.as<int>());
-  } else
-#endif
-  {
-    int rc = ensure_sorted(e, c);
-    if (rc) return rc;
-    const Tile t = peer_tile(e, c.n);  // multi-GPU: the queries of this rank's tile only (the whole sorted cloud is the candidate set: an exact, implicit halo)
-    ProfScope ps(e, "knn");
-    // small clouds: the kernel lasts as long as its slowest queries, and those are the ones the nearest-first walk shortens;
-    // the throughput-bound sizes hide them behind the other queries and keep the cheaper index-order walk (kernels_cov.hpp)
-    static const int nf_max = [] { const char* v = getenv("FVH_KNN_NEAREST_FIRST_MAX_POINTS"); return v ? atoi(v) : 65536; }();
-    // one query = one wave = one WORKGROUP: a 4-wave workgroup holds its four slots until its slowest query is done (queries take
-    // 8 us on average, 12.6 at the 90th percentile), single-wave workgroups hand each slot back at once: 39.7 -> 37 us at 17k points,
-    // 161 -> 154 us at 100k (FVH_KNN_BLOCK=256 / 128: the old shapes, for A/B runs)
-    static const int knn_block = [] { const char* v = getenv("FVH_KNN_BLOCK"); const int b = v ? atoi(v) : 64; return (b == 256 || b == 128) ? b : 64; }();
-    const int per_block = knn_block / 64;
-    if (t.hi > t.lo) {
-      if (c.n <= nf_max)
-        knn_tiled1_kernel<true><<<(t.hi - t.lo + per_block - 1) / per_block, knn_block, 0, e->stream>>>(c.sorted.as<float4>(), c.bbox.as<float4>(), c.bbox2.as<float4>(), c.n, k, c.nbr.as<int>(), t.lo, t.hi);
-      else
-        knn_tiled1_kernel<false><<<(t.hi - t.lo + per_block - 1) / per_block, knn_block, 0, e->stream>>>(c.sorted.as<float4>(), c.bbox.as<float4>(), c.bbox2.as<float4>(), c.n, k, c.nbr.as<int>(), t.lo, t.hi);
-    }
-  }
-  HIP_OR_FAIL(e, hipGetLastError());
-  c.k = k;
-  c.has_nbr = true;
-  c.nbr_tile_only = e->sharded();
-  return FVH_OK;
-}
-
-int calc_cov_knn(Engine* e, CloudDev& c, int method) {
-  if (!c.has_pts || !c.has_nbr) return e->fail(FVH_ERR_BAD_STATE, "calculate_covariances: cloud or neighbours not set");
-  if (method < 0 || method > 4) return e->fail(FVH_ERR_INVALID_ARGUMENT, "unknown regularization method");
-  if (c.k > COV_LANES * COV_MAX_PER_LANE) return e->fail(FVH_ERR_UNSUPPORTED, "calculate_covariances: more than 64 neighbours per point");
-  HIP_OR_FAIL(e, c.cov.ensure(sizeof(float4) * 2 * (size_t)std::max(c.n, 1)));
-  const bool sharded = e->sharded();
-  if (sharded) { int rc = ensure_sorted(e, c); if (rc) return rc; }
-  if (c.n) {
-    const Tile t = peer_tile(e, c.n);
-    const int m = sharded ? (t.hi - t.lo) : c.n;                      // points this rank computes
-    const int* subset = sharded ? c.order.as<int>() + t.lo : nullptr;  // ... its tile of the Morton order
-    // clouds the LM loop walks in Morton order: computed in that order too, and left a second time at the points' places along the curve
-    float4* cov_sorted = nullptr;
-    c.has_cov_sorted = false;
-    if (!sharded && e->precision != FVH_COMPUTE_CUDA_COMPAT && coherent_order(c)) {
-      HIP_OR_FAIL(e, c.cov_sorted.ensure(sizeof(float4) * 2 * (size_t)c.n));
-      subset = c.order.as<int>();
-      cov_sorted = c.cov_sorted.as<float4>();
-    }
-    ProfScope ps(e, "cov");
-    const int blocks = (int)(((long long)m * COV_LANES + 255) / 256);
-    if (m > 0 && e->precision == FVH_COMPUTE_CUDA_COMPAT) {
-      // FastVGICPCuda's own arithmetic: uncentred float sums in list order + Eigen's closed-form float eigen solver (kernels_cov.hpp)
-      cov_from_neighbors_cuda_compat_kernel<<<(m + 255) / 256, 256, 0, e->stream>>>(c.pts.as<float4>(), m, c.k, c.nbr.as<int>(), method, c.cov.as<float4>(), subset);
-    } else if (m > 0) {
-      if (c.k <= 20) cov_from_neighbors_kernel<5><<<blocks, 256, 0, e->stream>>>(c.pts.as<float4>(), m, c.k, c.nbr.as<int>(), method, c.cov.as<float4>(), subset, cov_sorted);
-      else if (c.k <= 32) cov_from_neighbors_kernel<8><<<blocks, 256, 0, e->stream>>>(c.pts.as<float4>(), m, c.k, c.nbr.as<int>(), method, c.cov.as<float4>(), subset, cov_sorted);
-      else cov_from_neighbors_regather_kernel<<<blocks, 256, 0, e->stream>>>(c.pts.as<float4>(), m, c.k, c.nbr.as<int>(), method, c.cov.as<float4>(), subset, cov_sorted);
-      c.has_cov_sorted = cov_sorted != nullptr;
-    }
-  }
-  HIP_OR_FAIL(e, hipGetLastError());
-  if (sharded && c.n) { int rc = allgather_cov(e, c); if (rc) return rc; }
-  c.has_cov = true;
-  return FVH_OK;
-}
-
-int calc_cov_rbf(Engine* e, CloudDev& c, double kernel_width, double max_dist, int method) {
-  if (!c.has_pts) return e->fail(FVH_ERR_BAD_STATE, "calculate_covariances_rbf: cloud not set");
-  if (method < 0 || method > 4) return e->fail(FVH_ERR_INVALID_ARGUMENT, "unknown regularization method");
-  HIP_OR_FAIL(e, c.cov.ensure(sizeof(float4) * 2 * (size_t)std::max(c.n, 1)));
-  const bool sharded = e->sharded();
-  c.has_cov_sorted = false;
-  if (c.n) {
-    const float md = (float)max_dist;
-#ifdef FVH_TEST_KERNELS  // test build only: FVH_RBF_MODE=0 full sweep, 2: eight queries per wave (both superseded by the one-query-per-wave sweep)
-    static const int rbf_mode = [] { const char* v = getenv("FVH_RBF_MODE"); return v ? atoi(v) : 1; }();
-    const int waves = (c.n + RBF_Q - 1) / RBF_Q;
-    if (rbf_mode == 0 && !sharded) {
-      ProfScope ps(e, "rbf");
-      cov_rbf_kernel<<<(waves + 3) / 4, 256, 0, e->stream>>>(c.pts.as<float4>(), c.n, (float)kernel_width, md * md, method, c.cov.as<float4>());
-    } else
-#endif
-    {
-      if (e->precision == FVH_COMPUTE_CUDA_COMPAT) {
-        // FastVGICPCuda's own arithmetic: float sums per block of 512 candidates in index order, blocks added in order (kernels_compat.hpp)
-        const int* subset = nullptr;
-        int m = c.n;
-        if (sharded) {
-          int rc = ensure_sorted(e, c);
-          if (rc) return rc;
-          const Tile t = peer_tile(e, c.n);
-          subset = c.order.as<int>() + t.lo; m = t.hi - t.lo;
-        }
-        ProfScope ps(e, "rbf");
-        if (m > 0) cov_rbf_cuda_compat_kernel<<<(m + 63) / 64, 256, 0, e->stream>>>(c.pts.as<float4>(), c.n, (float)kernel_width, md, method, c.cov.as<float4>(), subset, m);
-        HIP_OR_FAIL(e, hipGetLastError());
-        if (sharded) { int rc = allgather_cov(e, c); if (rc) return rc; }
-        c.has_cov = true;
-        return FVH_OK;
-      }
-      int rc = ensure_sorted(e, c);
-      if (rc) return rc;
-      const Tile t = peer_tile(e, c.n);
-      ProfScope ps(e, "rbf");
-#ifdef FVH_TEST_KERNELS
-      if (rbf_mode == 2 && !sharded) cov_rbf_tiled_kernel<<<(waves + 3) / 4, 256, 0, e->stream>>>(c.sorted.as<float4>(), c.bbox.as<float4>(), c.n, (float)kernel_width, md * md, method, c.cov.as<float4>());
-      else
-#endif
-      if (t.hi > t.lo) {
-        // sweep (one query per wave) -> ten totals per query; regularisation with one thread per query
-        HIP_OR_FAIL(e, e->rbf_sums.ensure(sizeof(double) * 10 * (size_t)c.n));
-        // (single-wave workgroups, which shortened the k-NN kernel, change nothing here: 152 us either way -- this sweep keeps the VALU pipes 95 % busy)
-        cov_rbf1_kernel<<<(t.hi - t.lo + 3) / 4, 256, 0, e->stream>>>(c.sorted.as<float4>(), c.bbox.as<float4>(), c.bbox2.as<float4>(), c.n, (float)kernel_width, md * md, method, c.cov.as<float4>(), t.lo, t.hi,
-                                                                      e->rbf_sums.as<double>());
-        float4* cov_sorted = nullptr;
-        if (!sharded && coherent_order(c)) { HIP_OR_FAIL(e, c.cov_sorted.ensure(sizeof(float4) * 2 * (size_t)c.n)); cov_sorted = c.cov_sorted.as<float4>(); }
-        cov_rbf_finish_kernel<<<(t.hi - t.lo + 255) / 256, 256, 0, e->stream>>>(e->rbf_sums.as<double>(), c.sorted.as<float4>(), c.n, method, c.cov.as<float4>(), t.lo, t.hi, cov_sorted);
-        c.has_cov_sorted = cov_sorted != nullptr;
-      }
-    }
-  }
-  HIP_OR_FAIL(e, hipGetLastError());
-  if (sharded && c.n) { int rc = allgather_cov(e, c); if (rc) return rc; }
-  c.has_cov = true;
-  return FVH_OK;
-}
-
-int set_cov_host(Engine* e, CloudDev& c, const double* covs9) {
-  if (!c.has_pts) return e->fail(FVH_ERR_BAD_STATE, "set_covariances: cloud not set");
-  if (!covs9) return e->fail(FVH_ERR_INVALID_ARGUMENT, "set_covariances: null");
-  std::vector<float4> h(2 * (size_t)c.n);
-  for (int i = 0; i < c.n; i++) {
-    const double* m = covs9 + 9 * (size_t)i;
-    h[2 * i] = make_float4((float)m[0], (float)m[1], (float)m[2], (float)m[4]);
-    h[2 * i + 1] = make_float4((float)m[5], (float)m[8], 0.f, 0.f);
-  }
-  HIP_OR_FAIL(e, c.cov.ensure(sizeof(float4) * 2 * (size_t)std::max(c.n, 1)));
-  HIP_OR_FAIL(e, hipMemcpyAsync(c.cov.p, h.data(), sizeof(float4) * h.size(), hipMemcpyHostToDevice, e->stream));
-  HIP_OR_FAIL(e, hipStreamSynchronize(e->stream));
-  c.has_cov = true;
-  c.has_cov_sorted = false;
-  return FVH_OK;
-}
-
-int get_cov_host(Engine* e, CloudDev& c, float* covs9) {
-  if (!c.has_cov) return e->fail(FVH_ERR_BAD_STATE, "get_covariances: covariances not computed");
-  std::vector<float4> h(2 * (size_t)c.n);
-  HIP_OR_FAIL(e, hipMemcpyAsync(h.data(), c.cov.p, sizeof(float4) * h.size(), hipMemcpyDeviceToHost, e->stream));
-  HIP_OR_FAIL(e, hipStreamSynchronize(e->stream));
-  for (int i = 0; i < c.n; i++) {
-    const float4 a = h[2 * i], b = h[2 * i + 1];
-    float* m = covs9 + 9 * (size_t)i;
-    m[0] = a.x; m[1] = a.y; m[2] = a.z; m[3] = a.y; m[4] = a.w; m[5] = b.x; m[6] = a.z; m[7] = b.x; m[8] = b.y;
-  }
-  return FVH_OK;
-}
-
-int get_nbr_host(Engine* e, CloudDev& c, int* k, int* out) {
-  if (!c.has_nbr) return e->fail(FVH_ERR_BAD_STATE, "get_neighbors: neighbours not set");
-  if (k) *k = c.k;
-  if (out) {
-    HIP_OR_FAIL(e, hipMemcpyAsync(out, c.nbr.p, sizeof(int) * (size_t)c.n * c.k, hipMemcpyDeviceToHost, e->stream));
-    HIP_OR_FAIL(e, hipStreamSynchronize(e->stream));
-  }
-  return FVH_OK;
-}
-
-int radix_sort_pairs(Engine* e, unsigned* keys[2], int* idx[2], int n, int bits, int* result, hipStream_t on = nullptr, DevBuf* hist_buf = nullptr);
-
-// GaussianVoxelMap::create_voxelmap (gaussian_voxelmap.cu:208-257) -- two kernels, no retry loop
-template <int MODE>
-int build_voxelmap(Engine* e, const CloudDev& c, VoxelMapDev& vm, double res, bool want_compact, bool force_safe = false, hipStream_t on_side = nullptr,
-                   bool shard = false /* only the voxels of vm.region (already computed on this stream) */,
-                   bool detached = false /* a map that is not the live one yet (prepared-source slot): the caller orders the main stream after `on_side` itself, correspondences stay valid */) {
-  hipStream_t const st = on_side ? on_side : e->stream;
-  if (!c.has_pts) return e->fail(FVH_ERR_BAD_STATE, "create_voxelmap: cloud not set");
-  if (MODE != 1 && !c.has_cov) return e->fail(FVH_ERR_BAD_STATE, "create_voxelmap: covariances not computed");
-  if (!(res > 0)) return e->fail(FVH_ERR_INVALID_ARGUMENT, "create_voxelmap: resolution must be > 0");
-  unsigned safe = 1024;
-  while (safe < 2u * (unsigned)std::max(c.n, 1)) safe <<= 1;
-  unsigned cap = safe;  // can never overflow
-  if (!force_safe && vm.nv_hint >= 0) {  // keep the table L2-resident: 4x the last voxel count
-    cap = 1024;
-    while (cap < 4u * (unsigned)vm.nv_hint) cap <<= 1;
-    cap = std::min(cap, safe);
-  }
-  vm.res = res;
-  vm.capacity = cap;
-  vm.invalidate();
-  {  // a reallocation hands back dirty memory
-    void* before[4] = {vm.keys[0].p, vm.keys[1].p, vm.acc.p, vm.counters.p};
-    HIP_OR_FAIL(e, vm.table.ensure((size_t)cap * 64));
-    HIP_OR_FAIL(e, vm.keys[0].ensure((size_t)cap * 8));
-    HIP_OR_FAIL(e, vm.keys[1].ensure((size_t)cap * 8));
-    HIP_OR_FAIL(e, vm.acc.ensure((size_t)cap * VM_ACC_BUCKET * sizeof(double)));
-    HIP_OR_FAIL(e, vm.counters.ensure(2 * 16 * sizeof(int)));
-    if (before[0] != vm.keys[0].p || before[1] != vm.keys[1].p || before[2] != vm.acc.p || before[3] != vm.counters.p) vm.clean_cap = 0;
-  }
-  HIP_OR_FAIL(e, vm.occupied.ensure(sizeof(int) * (size_t)std::max(c.n, 1)));
-  // FVH_COMPUTE_CUDA_COMPAT: voxel coordinates in float and, behind the build, the float voxel sums of the CUDA classes (kernels_compat.hpp);
-  // the multiplicative voxels have no device counterpart in the reference and keep the fp64 path
-  const bool compat = e->precision == FVH_COMPUTE_CUDA_COMPAT && MODE != 2;
-  if (want_compact) {
-    HIP_OR_FAIL(e, vm.compact_pts.ensure(sizeof(float4) * (size_t)std::max(c.n, 1)));
-    HIP_OR_FAIL(e, vm.compact_cov.ensure(sizeof(float4) * 2 * (size_t)std::max(c.n, 1)));
-  }
-  {
-    ProfScope ps(e, "voxelmap", st);
-    const int fill = vm.cur ^ 1;
-    unsigned long long* keys = vm.keys[fill].as<unsigned long long>();
-    int* counters = vm.counters.as<int>() + 16 * fill;
-    if (vm.clean_cap != cap) vm_clear_kernel<<<(cap * 10 + 255) / 256, 256, 0, st>>>(keys, vm.acc.as<double>(), cap, counters);
-    vm.clean_cap = 0;  // keys[fill] is in use from here on; the finalize pass below makes the OTHER pair clean
-    if (c.n) {
-      vm_accumulate_kernel<MODE><<<(c.n + 255) / 256, 256, 0, st>>>(c.pts.as<float4>(), c.cov.as<float4>(), c.n, res, keys, cap - 1, vm.acc.as<double>(), counters + 1,
-                                                                           coherent_order(c), shard ? vm.region.as<VmRegion>() : nullptr, compat ? 1 : 0);
-      vm_finalize_kernel<MODE><<<(cap + VM_FIN_THREADS - 1) / VM_FIN_THREADS, VM_FIN_THREADS, 0, st>>>(keys, vm.table.as<uint4>(), cap, vm.acc.as<double>(), counters, vm.occupied.as<int>(),
-                                                                        want_compact ? vm.compact_pts.as<float4>() : nullptr, want_compact ? vm.compact_cov.as<float4>() : nullptr,
-                                                                        vm.keys[vm.cur].as<unsigned long long>(), vm.counters.as<int>() + 16 * vm.cur);
-      vm.clean_cap = cap;
-      if (compat) {
-        const int n = c.n;
-        HIP_OR_FAIL(e, vm.compat_keys.ensure(sizeof(unsigned) * 2 * (size_t)n));
-        HIP_OR_FAIL(e, vm.compat_idx.ensure(sizeof(int) * 2 * (size_t)n));
-        HIP_OR_FAIL(e, vm.compat_seg.ensure(sizeof(int) * ((size_t)cap + 2)));
-        unsigned* ck[2] = {vm.compat_keys.as<unsigned>(), vm.compat_keys.as<unsigned>() + n};
-        int* ci[2] = {vm.compat_idx.as<int>(), vm.compat_idx.as<int>() + n};
-        vmc_point_bucket_kernel<<<(n + 255) / 256, 256, 0, st>>>(c.pts.as<float4>(), n, (float)res, keys, cap - 1, ck[0], ci[0]);
-        int bits = 1;
-        while ((1u << bits) <= cap) bits++;  // buckets 0 .. cap - 1 and `cap` itself ("no voxel")
-        int sorted = 0;
-        int rc = radix_sort_pairs(e, ck, ci, n, bits, &sorted, st, &vm.compat_hist);
-        if (rc) return rc;
-        vmc_segment_heads_kernel<<<(n + 255) / 256, 256, 0, st>>>(ck[sorted], n, vm.compat_seg.as<int>());
-        // (an upper bound of the voxel count sizes the grid: the exact one is on the device)
-        const int max_voxels = (int)std::min<long long>(n, cap);
-        vmc_finalize_kernel<MODE><<<(max_voxels + 63) / 64, 64, 0, st>>>(c.pts.as<float4>(), MODE == 0 ? c.cov.as<float4>() : nullptr, ci[sorted], vm.compat_seg.as<int>(), vm.occupied.as<int>(),
-                                                                     counters, vm.table.as<uint4>(), want_compact ? vm.compact_pts.as<float4>() : nullptr,
-                                                                     want_compact ? vm.compact_cov.as<float4>() : nullptr);
-      }
-      // large map: occupancy bitmap over the bounding box of its voxels (kernels_voxelmap.hpp) -- the LM kernel answers its misses
-      // from these cache-resident bits instead of a 64-byte HBM sector per probe. Four small launches after the finalize pass; maps
-      // of this size are built once per localisation run, not once per registration.
-      static const int bitmap_min = [] { const char* v = getenv("FVH_BITMAP_MIN_POINTS"); return v ? atoi(v) : 300000; }();
-      static const size_t bitmap_bytes = [] { const char* v = getenv("FVH_BITMAP_MAX_BYTES"); return v ? std::min((size_t)atoll(v), (size_t)16 << 30) : (size_t)(32u << 20); }();  // (the LM kernel indexes the words with 32 bits)
-      if (c.n >= bitmap_min && bitmap_bytes >= 8 && !shard) {  // (a shard is a fraction of the map: its keys stay cache-resident)
-        HIP_OR_FAIL(e, vm.bitmap.ensure(bitmap_bytes));
-        HIP_OR_FAIL(e, vm.grid.ensure(sizeof(VmGrid)));
-        VmGrid* g = vm.grid.as<VmGrid>();
-        vm_grid_init_kernel<<<1, 64, 0, st>>>(g);
-        vm_grid_bounds_kernel<<<64, 256, 0, st>>>(keys, vm.occupied.as<int>(), counters, g);
-        vm_grid_setup_kernel<<<1, 64, 0, st>>>(g, (unsigned long long)(bitmap_bytes / 8));
-        vm_grid_clear_kernel<<<512, 256, 0, st>>>(vm.bitmap.as<unsigned long long>(), g);
-        vm_grid_set_kernel<<<256, 256, 0, st>>>(keys, vm.occupied.as<int>(), counters, g, vm.bitmap.as<unsigned long long>());
-        vm.has_bitmap = true;
-      }
-    }
-    vm.cur = fill;
-  }
-  HIP_OR_FAIL(e, hipGetLastError());
-  if (on_side && !detached) {
-    HIP_OR_FAIL(e, hipEventRecord(e->side_done, on_side));
-    e->side_pending = true;
-  }
-  vm.valid = true;
-  vm.is_shard = shard;
-  if (!detached) e->has_corr = false;
-  return FVH_OK;
-}
-
-using Rebuild = std::function<int()>;
-
-// `rebuild_safe`: what to do when the hint-sized table of this map overflowed (counter [1]): rebuild at the safe size and
-// read again, as align / compute_error do -- the getters must never hand out a silently truncated map.
-int fetch_voxelmap_host(Engine* e, VoxelMapDev& vm, const Rebuild* rebuild_safe = nullptr) {
-  if (!vm.valid) return e->fail(FVH_ERR_BAD_STATE, "voxel map not built");
-  if (vm.host_valid) return FVH_OK;
-  int counters[3] = {0, 0, 0};
-  for (int attempt = 0;; attempt++) {
-    HIP_OR_FAIL(e, hipMemcpyAsync(counters, vm.counters_cur(), sizeof(counters), hipMemcpyDeviceToHost, e->stream));
-    HIP_OR_FAIL(e, hipStreamSynchronize(e->stream));
-    if (counters[1] == 0) break;
-    if (attempt == 1 || !rebuild_safe) return e->fail(FVH_ERR_BAD_STATE, "voxel map table overflowed (" + std::to_string(counters[1]) + " entries dropped)");
-    int rc = (*rebuild_safe)();
-    if (rc) return rc;
-  }
-  vm.nv_hint = counters[0];
-  vm.num_skipped = counters[2];
-  vm.h_occupied.resize(counters[0]);
-  vm.h_table.resize((size_t)vm.capacity * 4);
-  if (counters[0]) HIP_OR_FAIL(e, hipMemcpyAsync(vm.h_occupied.data(), vm.occupied.p, sizeof(int) * counters[0], hipMemcpyDeviceToHost, e->stream));
-  HIP_OR_FAIL(e, hipMemcpyAsync(vm.h_table.data(), vm.table.p, (size_t)vm.capacity * 64, hipMemcpyDeviceToHost, e->stream));
-  HIP_OR_FAIL(e, hipStreamSynchronize(e->stream));
-  vm.bucket_to_index.clear();
-  for (int i = 0; i < counters[0]; i++) vm.bucket_to_index[vm.h_occupied[i]] = i;
-  vm.host_valid = true;
-  return FVH_OK;
-}
-
-int get_voxels_host(Engine* e, VoxelMapDev& vm, int* coords3, int* num_points, float* means3, float* covs9, const Rebuild* rebuild_safe = nullptr) {
-  int rc = fetch_voxelmap_host(e, vm, rebuild_safe);
-  if (rc) return rc;
-  for (size_t i = 0; i < vm.h_occupied.size(); i++) {
-    const uint4* q = &vm.h_table[(size_t)vm.h_occupied[i] * 4];
-    if (coords3) {
-      unsigned long long key = (unsigned long long)q[0].x | ((unsigned long long)q[0].y << 32);
-      unpack_key(key, coords3[3 * i], coords3[3 * i + 1], coords3[3 * i + 2]);
-    }
-    if (num_points) num_points[i] = (int)q[0].z;
-    const float* f1 = reinterpret_cast<const float*>(&q[1]);
-    const float* f2 = reinterpret_cast<const float*>(&q[2]);
-    const float* f3 = reinterpret_cast<const float*>(&q[3]);
-    if (means3) { means3[3 * i] = f1[0]; means3[3 * i + 1] = f1[1]; means3[3 * i + 2] = f1[2]; }
-    if (covs9) {
-      float* m = covs9 + 9 * i;
-      m[0] = f2[0]; m[1] = f2[1]; m[2] = f2[2]; m[3] = f2[1]; m[4] = f2[3]; m[5] = f3[0]; m[6] = f2[2]; m[7] = f3[0]; m[8] = f3[1];
-    }
-  }
-  return FVH_OK;
-}
-
-struct CostSource {
-  const float4* pts; const float4* cov; const int* d_n; int n_upper;
-  const int* counters2;  // source voxel map counters (D2D) or null
-  const int* order;      // Morton permutation of the source (large clouds) or null
-  const float4* sorted = nullptr;  // with `order`: the cloud's Morton-ordered copy (.w = original index) -- element order[j] is sorted[j]
-  const float4* cov_sorted = nullptr;  // with `sorted`, optional: the covariances in the same order
-  int n_off_override = 0;  // > 0: correspondences per source element regardless of the handle's offset list (GICP: 1)
-  bool shardable = false;  // the source elements are the points of a cloud with a Morton order: with peers attached each rank walks its tile
-  bool external_find = false;  // FastGICP device LM: nn1_corr_kernel fills the correspondence buffers between the cost launches
-  int n_shape = 0;             // > 0: expected number of source elements when the exact one lives on the device (NDT D2D: source voxels, from the
-                               // last build of that map): shapes the grid and the offsets per item; the kernel is grid-stride, any value is correct
-  VoxelMapDev* source_map = nullptr;  // NDT D2D: where align() leaves the source voxel count it saw
-  bool device_tile = false;           // NDT D2D with a tile set: the kernel cuts this rank's chunk of the (canonically ordered) element list from the device-side count
-  // NDT D2D: the elements ARE the source map's compact voxel list. A rebuild of that map (table overflow -> safe size) flips its counter set and
-  // refills the list: whoever retries with a CostSource made before the rebuild re-reads the map's addresses first (round 6: the stale counter
-  // set -- zeroed by the rebuild's finalize pass -- made the retry evaluate an EMPTY source)
-  void refresh() {
-    if (!source_map) return;
-    const VoxelMapDev& m = *source_map;
-    pts = m.compact_pts.as<float4>(); cov = m.compact_cov.as<float4>();
-    d_n = counters2 = m.counters_cur();
-    if (device_tile) order = m.has_canon ? m.canon.as<int>() : nullptr;
-  }
-};
-
-// Persistent LM kernel (kernels_cost.hpp, PERSIST): co-resident workgroup capacity of the device for this instantiation.
-constexpr unsigned long long PERSIST_WATCHDOG_TICKS = 5'000'000ull;  // 50 ms of the 100 MHz wall clock
-constexpr long long PERSIST_MAX_ITEMS = 4'000'000;                   // beyond this a trip is no longer latency-bound: multi-launch path
-template <int MODE>
-int persistent_capacity(Engine* e) {
-  static std::mutex mu;
-  static int cap[16][2];  // [device][precision]; 0 = not queried yet
-  std::lock_guard<std::mutex> lk(mu);
-  const int pi = e->float_cost() ? 1 : 0, dev = e->device & 15;
-  if (cap[dev][pi] <= 0) {
-    int per_cu = 0, cus = 0;
-    hipError_t r = pi ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, cost_kernel<float, MODE, true>, 256, 0)
-                      : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, cost_kernel<double, MODE, true>, 256, 0);
-    if (r != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, e->device) != hipSuccess) return 0;
-    cap[dev][pi] = per_cu * cus;
-  }
-  return cap[dev][pi];
-}
-
-// A work item is (source element, group of offsets). Small clouds: enough items to cover the chip (target_items). Large
-// clouds: still at most COST_CH..group_max offsets per item -- one thread walking all 27 offsets of its point left 24 %
-// of the resident threads without work at 100k points and made the launch 18 % slower than 4 offsets per item
-// (measured at 100k x DIRECT27: group 27: 423 us, 14: 426, 9: 361, 7: 386, 6: 368, 5: 423, 4: 358, 3: 355, 2: 459, 1: 615).
-struct CostShape { int group, groups_per_src; long long n_walk; int blocks; int split; };
-// `mode`, `device_lm`: NDT launches of the device-resident optimiser loop whose items hold one offset and whose grid stays within one
-// workgroup per CU take the wave-role layout (kernels_cost.hpp: `split` -- 128 items per workgroup, waves 0-1 the trial error of the
-// stored ids, waves 2-3 the new linearisation). Both routes of an align call this with the same arguments: the same layout.
-inline CostShape cost_shape(const Engine* e, const CostSource& src, int mode = MODE_VGICP, bool device_lm = false) {
-  static const long long target_items = [] { const char* v = getenv("FVH_COST_TARGET_ITEMS"); return v ? atoll(v) : 256LL * 256 * 2; }();
-  static const int max_blocks = [] { const char* v = getenv("FVH_COST_MAX_BLOCKS"); int b = v ? atoi(v) : MAX_COST_BLOCKS; return b < 1 ? 1 : (b > MAX_COST_BLOCKS ? MAX_COST_BLOCKS : b); }();
-  static const int group_max = [] { const char* v = getenv("FVH_COST_GROUP_MAX"); return v ? std::min(std::max(1, atoi(v)), COST_CH) : COST_CH; }();  // the kernel keeps one item's lookups in flight together: at most COST_CH
-  const int n_off = src.n_off_override > 0 ? src.n_off_override : e->n_off;
-  CostShape s;
-  const int n_expected = src.n_shape > 0 ? std::min(src.n_shape, src.n_upper) : src.n_upper;
-  const int groups = (int)std::min<long long>(n_off, std::max<long long>((n_off + group_max - 1) / group_max, target_items / std::max(n_expected, 1)));
-  s.group = (n_off + groups - 1) / groups;
-  s.groups_per_src = (n_off + s.group - 1) / s.group;
-  s.n_walk = n_expected;
-  if (e->sharded() && src.shardable) { const Tile t = peer_tile(e, src.n_upper); s.n_walk = std::max(t.hi - t.lo, 0); }  // multi-GPU: this rank's tile
-  if (src.device_tile) s.n_walk = (n_expected + e->shard_ranks() - 1) / std::max(1, e->shard_ranks());
-  s.blocks = (int)std::max<long long>(1, std::min<long long>(max_blocks, (s.n_walk * s.groups_per_src + 255) / 256));
-  s.split = 0;
-  static const int split_on = [] { const char* v = getenv("FVH_COST_SPLIT"); return v ? atoi(v) : 1; }();
-  if (split_on && device_lm && mode != MODE_VGICP && s.group == 1) {
-    static int cus[16] = {0};
-    const int dev = e->device & 15;
-    if (cus[dev] <= 0 && hipDeviceGetAttribute(&cus[dev], hipDeviceAttributeMultiprocessorCount, e->device) != hipSuccess) cus[dev] = 0;
-    const long long wgs = (s.n_walk * s.groups_per_src + 127) / 128;
-    if (cus[dev] > 0 && wgs <= cus[dev]) { s.split = 1; s.blocks = (int)std::max<long long>(1, wgs); }
-  }
-  return s;
-}
-
-template <int MODE>
-int launch_cost(Engine* e, const CostSource& src, const VoxelMapDev& vm, int host_phase, const PoseD* lin, const PoseD* ev, const fvh_lm_params* init = nullptr,
-                bool persistent = false, unsigned long long peer_xbase = 0 /* multi-GPU: exchange counter of this launch's first sums exchange */,
-                const GridPlan* plan = nullptr /* align(): the layout both routes take (workgroups granted, groups, XCD confinement) */) {
-  CostParams P;
-  std::memset(&P, 0, sizeof(P));
-  P.src_pts = src.pts; P.src_cov = src.cov; P.d_n_src = src.d_n; P.n_src = src.n_upper; P.order = src.order; P.src_sorted = src.order ? src.sorted : nullptr; P.src_cov_sorted = (src.order && src.sorted) ? src.cov_sorted : nullptr;
-  P.table = vm.table.as<uint4>(); P.keys = vm.keys_cur(); P.mask = vm.capacity - 1; P.res = vm.res; P.inv_res = 1.0 / vm.res;
-  P.bitmap = vm.has_bitmap ? vm.bitmap.as<unsigned long long>() : nullptr;
-  P.grid = vm.has_bitmap ? vm.grid.as<VmGrid>() : nullptr;
-  P.region = vm.is_shard ? vm.region.as<VmRegion>() : nullptr;
-  const int n_off = src.n_off_override > 0 ? src.n_off_override : e->n_off;
-  P.offsets = e->offsets_dev.as<int>(); P.offsets_packed = e->offsets_dev.as<int>() + 3 * (size_t)e->n_off; P.n_off = n_off;
-  const CostShape shape = cost_shape(e, src, MODE, host_phase < 0);
-  P.group = shape.group;
-  P.split = shape.split;
-  P.groups_per_src = shape.groups_per_src;
-  {  // w / d == mulhi(w, ceil(2^32 / d)) for all w with w * d < 2^32 (d = 1: no shift-free magic, plain division is free there)
-    const unsigned long long d = (unsigned long long)shape.groups_per_src, items = (unsigned long long)std::max(src.n_upper, 1) * d;
-    P.gps_magic = (d > 1 && items * d < (1ull << 32)) ? (unsigned)(((1ull << 32) + d - 1) / d) : 0u;
-  }
-  P.corr = e->corr.as<int>();
-  P.corr_stride = (size_t)std::max(src.n_upper, 1) * n_off;
-  P.host_corr_sel = e->corr_sel;
-  P.st = e->state.as<LmState>(); P.partials = e->partials.as<double>(); P.ticket = e->ticket.as<unsigned>();
-  P.vm_counters = vm.counters_cur();
-  P.vm_counters2 = src.counters2;
-  P.host_phase = host_phase;
-  P.external_find = src.external_find ? 1 : 0;
-  {
-    const bool finds = host_phase < 0 || host_phase == PH_FIND_ONLY;  // (the device-resident loop finds its own lists; PH_EVAL_* read a stored one)
-    if (finds) e->corr_by_position = src.order != nullptr && !src.external_find && !src.device_tile;
-    if (e->corr_by_position && !src.order) return e->fail(FVH_ERR_BAD_STATE, "compute_error: the stored correspondences were found in the cloud's spatial order, which is gone; call update_correspondences again");
-    P.corr_by_position = e->corr_by_position ? 1 : 0;
-  }
-  P.lm_trace = (e->lm_trace_on && host_phase < 0) ? e->lm_trace.as<double>() : nullptr;
-  P.defer_lm = (e->comm != nullptr) ? 1 : 0;
-  if (lin) P.lin = *lin;
-  if (ev) P.ev = *ev;
-  if (init) {
-    P.init = 1;
-    P.max_iterations = init->max_iterations; P.lm_max_iterations = init->lm_max_iterations;
-    P.rotation_epsilon = init->rotation_epsilon; P.transformation_epsilon = init->transformation_epsilon; P.lm_init_lambda_factor = init->lm_init_lambda_factor;
-    P.optimizer = init->optimizer != 0 ? 1 : 0;
-  }
-  long long n_walk = src.n_upper;
-  P.item_lo = 0; P.item_hi = 0;
-  P.peer.n = 1; P.peer.rank = 0; P.peer.xbase = 0;
-  for (int i = 0; i < FVH_MAX_PEERS; i++) P.peer.region[i] = nullptr;
-  P.tile_rank = 0; P.tile_n = 1;
-  if (MODE == MODE_NDT_D2D && src.device_tile) { P.tile_rank = e->shard_rank(); P.tile_n = e->shard_ranks(); }
-  if ((MODE == MODE_VGICP || MODE == MODE_NDT_P2D) && e->sharded() && src.shardable) {
-    // multi-GPU: this rank's spatial tile of the source (a range of its Morton order) and -- peer route -- the mailboxes of all ranks
-    // (RCCL route: the sums meet between the launches, allreduce_sums)
-    const Tile t = peer_tile(e, src.n_upper);
-    P.item_lo = t.lo; P.item_hi = std::max(t.hi, 1);  // (item_hi == 0 means "everything")
-    if (t.hi <= t.lo) { P.item_lo = 0; P.item_hi = 1; n_walk = 0; P.n_src = 0; } else n_walk = t.hi - t.lo;
-    if (MODE == MODE_VGICP && e->peer.attached()) P.peer = e->peer.view(peer_xbase);
-    static const unsigned long long wd = [] { const char* v = getenv("FVH_PEER_WATCHDOG_TICKS"); return v ? strtoull(v, nullptr, 10) : PEER_WATCHDOG_TICKS; }();
-    P.peer_watchdog_ticks = wd;
-  }
-  int blocks = shape.blocks;
-  (void)n_walk;
-  {
-    // The persistent kernel needs every workgroup resident at once: its grid is clamped to what the device can hold (the
-    // kernel is grid-stride). The per-transition launches take the SAME grid, so that both routes partition the items --
-    // and therefore order the sums -- identically (bit-identical results whichever route an align takes).
-    int cap = persistent_capacity<MODE>(e);
-    if (cap <= 0) return e->fail(FVH_ERR_HIP, "cost kernel: occupancy query failed");
-    if (e->peer.attached()) cap = std::max(1, cap / std::max(1, e->peer.ranks_on_device));  // ranks sharing one GPU share its co-resident slots
-    blocks = std::min(blocks, cap);
-    if (plan && plan->nb > 0) blocks = std::min(blocks, plan->nb);
-  }
-  P.ng = (plan && plan->ng > 0) ? plan->ng : default_groups(blocks);
-  if (P.ng > blocks) P.ng = 1;  // (every group needs its first workgroup)
-  P.xcd_local = 0; P.lm_everywhere = 0;
-  {
-    // Grids of two workgroups per CU (257 .. 512 workgroups: the 17k-point headline has 474): the second workgroup of a CU loses VALU
-    // arbitration to the first (older waves win), finishes its main loop ~2 us later and keeps the whole trip waiting; s_setprio 1 for it
-    // makes the pair finish together: LM launch 136 -> 127 us (profiles/r04_priority_ab.txt). With three workgroups per CU the same
-    // priority costs 7 % (100k x 100k DIRECT27), for everybody at once it changes nothing: only this shape gets it.
-    static const int prio = [] { const char* v = getenv("FVH_COST_PRIO"); return v ? (atoi(v) != 0 ? 1 : 0) : -1; }();  // A/B knob: 0 never, 1 always (default: by the rule below)
-    int cus = 256;
-    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, e->device);
-    P.prio_from = cus;
-    P.prio_mode = prio >= 0 ? prio : ((persistent && blocks > cus && blocks <= 2 * cus) ? 1 : 0);
-    // The LM step on EVERY workgroup (each polls the group rows itself: no broadcast hand-off) for grids of at most two workgroups per
-    // CU: 17k headline 126.1 -> 123.5 us, NDT LiDAR frames 81.8 -> 79.0 us. With three per CU (100k / 1M points: 768 workgroups) the
-    // redundant steps cost more than the hand-off they replace (210.5 -> 216 us, 223 -> 227 us): those keep the collectors' broadcast.
-    // FVH_LM_EVERYWHERE: 0 never, 1 (default) by this rule, 2 always. (profiles/r04_lm_everywhere.txt)
-    static const int everywhere = [] { const char* v = getenv("FVH_LM_EVERYWHERE"); return v ? atoi(v) : 1; }();
-    P.lm_everywhere = (persistent && P.ng > 1 && (everywhere == 2 || (everywhere == 1 && blocks <= 2 * cus))) ? 1 : 0;
-  }
-  const int launch_blocks = blocks;
-  if (persistent && plan) P.xcd_local = plan->local;
-  // abort word = 0 (the last 8 bytes of the state; never covered by the state write-back)
-  if (e->abort_word_dirty) {
-    HIP_OR_FAIL(e, hipMemsetAsync(reinterpret_cast<char*>(e->state.p) + sizeof(LmState) - 8, 0, 8, e->stream));
-    e->abort_word_dirty = false;
-  }
-  if (persistent) {
-    { const char* v = getenv("FVH_PERSIST_WATCHDOG_TICKS"); P.watchdog_ticks = v ? strtoull(v, nullptr, 10) : PERSIST_WATCHDOG_TICKS; }  // test hook: 0 forces the abort + fallback path
-    // multi-GPU: workgroup 0 may legitimately wait for a late peer (up to the peer watchdog); the collectors waiting for its all-reduced
-    // row and the workgroups waiting for their broadcast must outlast that, or a 50 ms skew between ranks would look like a stuck local barrier
-    if (P.peer.n > 1 && P.watchdog_ticks) P.watchdog_ticks = std::max(P.watchdog_ticks, 2 * P.peer_watchdog_ticks);
-    static const int zc = [] { const char* v = getenv("FVH_ZEROCOPY_RESULT"); return v ? atoi(v) : 1; }();
-    P.result_host = (zc && (!e->prof.on || e->prof.cost_only)) ? e->result_dev : nullptr;  // (full stage profiling drains the stream per call anyway; the two events of level 2 do not need it)
-    e->zero_copy_armed = P.result_host != nullptr;
-    P.bcast = e->bcast.as<double>();
-    P.launch_tag = ++e->persist_seq;
-    e->last_persist_blocks = blocks;
-    (void)e->gang_begin(false);  // (the persistent launches share the chip through the SlotPool; other handles' cooperative sorts stay away while this runs)
-    {
-      ProfScope ps(e, "cost");
-      // (items of ONE offset take the instantiation unrolled for one lookup; both routes of an align pick by the same shape.
-      // Gauss-Newton aligns take their own instantiations: the Levenberg-Marquardt ones do not carry the other optimiser's code)
-#define FVH_LAUNCH_COST(PERS, GRID)                                                                                                   \
-  do {                                                                                                                                \
-    const bool f32 = e->float_cost();                                                                                                 \
-    if ((host_phase < 0 ? e->align_optimizer : 0) == 0) {                                                                             \
-      if (P.group == 1) { if (f32) cost_kernel<float, MODE, PERS, 1><<<GRID, 256, 0, e->stream>>>(P); else cost_kernel<double, MODE, PERS, 1><<<GRID, 256, 0, e->stream>>>(P); } \
-      else { if (f32) cost_kernel<float, MODE, PERS><<<GRID, 256, 0, e->stream>>>(P); else cost_kernel<double, MODE, PERS><<<GRID, 256, 0, e->stream>>>(P); }                    \
-    } else {                                                                                                                          \
-      if (P.group == 1) { if (f32) cost_kernel<float, MODE, PERS, 1, true><<<GRID, 256, 0, e->stream>>>(P); else cost_kernel<double, MODE, PERS, 1, true><<<GRID, 256, 0, e->stream>>>(P); } \
-      else { if (f32) cost_kernel<float, MODE, PERS, COST_CH, true><<<GRID, 256, 0, e->stream>>>(P); else cost_kernel<double, MODE, PERS, COST_CH, true><<<GRID, 256, 0, e->stream>>>(P); } \
-    }                                                                                                                                 \
-  } while (0)
-      FVH_LAUNCH_COST(true, launch_blocks);
-    }
-    e->gang_end();
-  } else {
-    ProfScope ps(e, "cost");
-    FVH_LAUNCH_COST(false, blocks);
-  }
-  HIP_OR_FAIL(e, hipGetLastError());
-  return FVH_OK;
-}
-
-int allreduce_sums(Engine* e) {
-  LmState* st = e->state.as<LmState>();
-  int rc = g_rccl.AllReduce(st->sums, st->sums, PART_STRIDE, /*ncclDouble*/ 8, /*ncclSum*/ 0, e->comm, e->stream);
-  if (rc != 0) return e->fail(FVH_ERR_COMM, "ncclAllReduce failed with code " + std::to_string(rc));
-  return FVH_OK;
-}
-
-template <int MODE>
-int do_update_correspondences(Engine* e, const CostSource& src, VoxelMapDev& vm, const double* T16) {
-  if (!T16) return e->fail(FVH_ERR_INVALID_ARGUMENT, "update_correspondences: null pose");
-  if (!vm.valid) return e->fail(FVH_ERR_BAD_STATE, "update_correspondences: target voxel map not built");
-  HIP_OR_FAIL(e, e->corr.ensure(2 * sizeof(int) * (size_t)std::max(src.n_upper, 1) * e->n_off));
-  e->lin = pose_from_colmajor16(T16);
-  e->corr_sel = 0;
-  int rc = launch_cost<MODE>(e, src, vm, PH_FIND_ONLY, &e->lin, &e->lin);
-  if (rc) return rc;
-  e->has_corr = true;
-  e->corr_kind = 0;
-  e->corr_n_src = src.n_upper;
-  return FVH_OK;
-}
-
-template <int MODE>
-int do_compute_error(Engine* e, const CostSource& src_in, VoxelMapDev& vm, const double* T16, double* H36, double* b6, double* error, const Rebuild& rebuild_safe) {
-  CostSource src = src_in;
-  if (!T16 || !error) return e->fail(FVH_ERR_INVALID_ARGUMENT, "compute_error: null argument");
-  if (!e->has_corr) return e->fail(FVH_ERR_BAD_STATE, "compute_error: call update_correspondences first");
-  if (!vm.valid) return e->fail(FVH_ERR_BAD_STATE, "compute_error: the target voxel map / target records were invalidated (target cloud replaced); rebuild and call update_correspondences");
-  const bool deriv = (H36 != nullptr && b6 != nullptr);
-  PoseD ev = pose_from_colmajor16(T16);
-  LmState* h = reinterpret_cast<LmState*>(e->pinned);
-  for (int attempt = 0; attempt < 2; attempt++) {
-    const bool sharded = MODE == MODE_VGICP && e->peer.attached() && src.shardable;
-    int rc = launch_cost<MODE>(e, src, vm, deriv ? PH_EVAL_DERIV : PH_EVAL_ERROR, &e->lin, &ev, nullptr, false, e->peer.x);
-    if (rc) return rc;
-    if (sharded) e->peer.x++;  // one sums exchange per evaluation, on every rank
-    if (e->comm) { rc = allreduce_sums(e); if (rc) return rc; }
-    HIP_OR_FAIL(e, hipMemcpyAsync(h, e->state.p, sizeof(LmState), hipMemcpyDeviceToHost, e->stream));
-    HIP_OR_FAIL(e, hipStreamSynchronize(e->stream));
-    if (h->aborted) {
-      e->abort_word_dirty = true;
-      e->peer.x = (e->peer.x + 8192) & ~1ull;
-      return e->fail(FVH_ERR_COMM, "compute_error: a peer rank did not deliver its sums (every rank must make the same sequence of calls)");
-    }
-    vm.nv_hint = h->vm_num_voxels;
-    if (h->vm_dropped == 0 || attempt == 1) break;
-    // the hint-sized table overflowed: rebuild at the safe size, redo the correspondences, evaluate again
-    rc = rebuild_safe();
-    if (rc) return rc;
-    src.refresh();
-    rc = launch_cost<MODE>(e, src, vm, PH_FIND_ONLY, &e->lin, &e->lin);
-    if (rc) return rc;
-    e->has_corr = true;
-  }
-  if (h->vm_dropped) return e->fail(FVH_ERR_BAD_STATE, "voxel map overflow persists after safe rebuild");
-  *error = h->sums[0];
-  if (deriv) {
-    double Hr[36];
-    unpack_sums(h->sums, Hr, b6);
-    for (int i = 0; i < 6; i++) for (int j = 0; j < 6; j++) H36[j * 6 + i] = Hr[i * 6 + j];  // column-major (symmetric)
-  }
-  return FVH_OK;
-}
-
-// What align_begin() leaves for align_finish(): an align is a launch (the persistent LM kernel) and a wait for its result; the C ABI
-// offers the two halves separately (fvh_ndt_align_async / _wait) so that the host can queue the NEXT frame's preparation on the
-// handle's second stream while the LM kernel runs.
-struct AlignCtx {
-  bool active = false;
-  fvh_lm_params p;
-  double guess16[16];
-  bool degenerate = false, persistent = false, sharded = false, no_persist = false, retried = false, forced = false;
-  long long budget = 0;
-  GridPlan plan;
-  int grant_dev = 0;
-  SlotPool::Grant grant;
-  void release_slots() { if (grant.n > 0) g_slots.release(grant_dev, grant); grant = SlotPool::Grant{}; }
-};
-
-template <int MODE>
-int do_align(Engine* e, const CostSource& src, VoxelMapDev& vm, const double* guess16, const fvh_lm_params* params, fvh_lm_result* result, const Rebuild& rebuild_safe,
-             bool retried = false, bool no_persist = false, const GridPlan* forced_plan = nullptr);
-
-// first half: validate, pick the route and the grid, launch the persistent LM kernel (the multi-launch route queues nothing here)
-template <int MODE>
-int align_begin(Engine* e, AlignCtx& c, const CostSource& src, VoxelMapDev& vm, const double* guess16, const fvh_lm_params* params,
-                bool retried = false, bool no_persist = false, const GridPlan* forced_plan = nullptr /* multi-launch retry of an aborted persistent launch: its layout */) {
-  if (!guess16) return e->fail(FVH_ERR_INVALID_ARGUMENT, "align: null argument");
-  if (!vm.valid) return e->fail(FVH_ERR_BAD_STATE, "align: target voxel map not built");
-  c = AlignCtx{};
-  fvh_lm_params& p = c.p;
-  if (params) p = *params; else fvh_default_lm_params(&p);
-  std::memcpy(c.guess16, guess16, sizeof(c.guess16));
-  e->align_optimizer = p.optimizer != 0 ? 1 : 0;  // (every launch of this align -- begin, finish, fall-backs -- takes that optimiser's instantiation)
-  c.retried = retried; c.no_persist = no_persist; c.grant_dev = e->device;
-  HIP_OR_FAIL(e, e->corr.ensure(2 * sizeof(int) * (size_t)std::max(src.n_upper, 1) * e->n_off));
-  LmState* st = e->state.as<LmState>();
-  const PoseD guess = pose_from_colmajor16(guess16);
-  c.degenerate = p.max_iterations <= 0;  // nothing to launch: only the state has to say "done"
-  if (c.degenerate) {
-    lm_init_kernel<<<1, 64, 0, e->stream>>>(st, guess, p.rotation_epsilon, p.transformation_epsilon, p.lm_init_lambda_factor, p.max_iterations, p.lm_max_iterations, e->ticket.as<unsigned>(), p.optimizer != 0 ? 1 : 0);
-    HIP_OR_FAIL(e, hipGetLastError());
-  }
-  c.budget = (long long)std::max(p.max_iterations, 0) * (1 + (long long)std::max(p.lm_max_iterations, 0)) + 1;
-  if (e->lm_trace_on) HIP_OR_FAIL(e, e->lm_trace.ensure(sizeof(double) * 6 * (size_t)std::max<long long>(c.budget, 1)));
-  e->lm_trace_rows = 0;
-  // One persistent launch for the whole LM loop when the problem is in the latency-bound regime and there is no RCCL
-  // collective between evaluations. Concurrent aligns of this process (several handles, several host threads) split the
-  // device's co-resident workgroup slots (SlotPool); after a watchdog abort -- typically ANOTHER PROCESS on the same GPU, which
-  // the pool cannot see -- the handle backs off: it skips the persistent route for 1, 2, 4, ... 64 aligns before trying again,
-  // so a shared GPU costs one 50 ms stall now and then instead of one per registration.
-  static const int persist_env = [] { const char* v = getenv("FVH_PERSISTENT"); return v ? atoi(v) : 1; }();
-  c.sharded = MODE == MODE_VGICP && e->peer.attached() && src.shardable;
-  c.persistent = persist_env != 0 && !c.degenerate && !e->comm && !no_persist && c.budget < 4000 && (long long)src.n_upper * e->n_off <= PERSIST_MAX_ITEMS;
-  if (c.persistent && !c.sharded && e->persist_skip > 0) { e->persist_skip--; c.persistent = false; }  // backing off (a sharded align must take the same route on every rank)
-  if (forced_plan) { c.plan = *forced_plan; c.forced = true; }
-  if (c.persistent) {
-    int cap = persistent_capacity<MODE>(e);
-    if (e->peer.attached()) cap = std::max(1, cap / std::max(1, e->peer.ranks_on_device));
-    const int want = std::min(cost_shape(e, src, MODE, true).blocks, std::max(cap, 1));
-    // Layouts (kernels_cost.hpp): chip-wide grids reduce per XCD (ng = 8; small ones: default_groups())
-    const bool local_ok = xcd_local_wanted();
-    c.grant = g_slots.acquire(e->device, std::max(cap, 1), want);
-    int granted = c.grant.n;
-    if (granted <= 0) {
-      if (c.sharded) granted = want;  // ranks must not diverge: take the slots anyway (the watchdog covers the rare collision)
-      else c.persistent = false;
-    }
-    c.plan = GridPlan{};
-    c.plan.nb = granted;
-    c.plan.ng = default_groups(granted);
-    c.plan.local = (c.plan.ng == TICKET_GROUPS && local_ok) ? 1 : 0;  // (one chip-wide group spans XCDs: write-through)
-  }
-  if (c.persistent) {
-    int rc = launch_cost<MODE>(e, src, vm, -1, &guess, nullptr, &p, true, e->peer.x, &c.plan);
-    if (rc) { c.release_slots(); return rc; }
-  }
-  c.active = true;
-  return FVH_OK;
-}
-
-// second half: wait for the persistent kernel's result (or run the multi-launch loop), answer aborts and table overflows, fill `result`
-template <int MODE>
-int align_finish(Engine* e, AlignCtx& c, const CostSource& src, VoxelMapDev& vm, fvh_lm_result* result, const Rebuild& rebuild_safe) {
-  if (!c.active) return e->fail(FVH_ERR_BAD_STATE, "align: nothing in flight");
-  struct Done { AlignCtx& c; ~Done() { c.release_slots(); c.active = false; } } done{c};
-  if (!result) return e->fail(FVH_ERR_INVALID_ARGUMENT, "align: null argument");
-  const fvh_lm_params& p = c.p;
-  e->align_optimizer = p.optimizer != 0 ? 1 : 0;
-  const bool persistent = c.persistent, sharded = c.sharded, degenerate = c.degenerate;
-  const long long budget = c.budget;
-  const PoseD guess = pose_from_colmajor16(c.guess16);
-  LmState* st = e->state.as<LmState>();
-  long long launched = 0;
-  int batch = e->last_steps > 0 ? std::max(e->last_steps, e->prev_steps) + 1 : 8;
-  LmState* h = reinterpret_cast<LmState*>(e->pinned);
-  if (persistent) {
-    bool have_result = false;
-    if (e->result_dev && e->zero_copy_armed) {
-      // spin on the sequence word the kernel writes after the state (mapped pinned memory); if the stream drains without it
-      // (watchdog abort) fall through to the copy
-      volatile unsigned long long* seq = reinterpret_cast<volatile unsigned long long*>(e->result_host) + sizeof(LmState) / 8;
-      static const bool block = [] { const char* v = getenv("FVH_HOST_WAIT"); return v && std::string(v) == "block"; }();  // FVH_HOST_WAIT=block: sleep in hipStreamSynchronize instead of spinning a core on the result word
-      if (block) (void)hipStreamSynchronize(e->stream);
-      // (the stream is only asked now and then -- it answers "drained" when a launch ended without its result word, i.e. aborted: every query
-      // takes the runtime's lock, which concurrent aligns of other host threads also need for their launches)
-      static const unsigned long long query_mask = [] { const char* v = getenv("FVH_RESULT_QUERY_SPINS"); unsigned long long n = v ? strtoull(v, nullptr, 10) : 1024ull; unsigned long long m = 1; while (m < n) m <<= 1; return m - 1; }();
-      for (unsigned long long spins = 0;; spins++) {
-        if (*seq == e->persist_seq) { have_result = true; break; }
-        if ((spins & query_mask) == query_mask && hipStreamQuery(e->stream) != hipErrorNotReady) { have_result = (*seq == e->persist_seq); break; }  // drained (or failed: the copy below reports it)
-      }
-      if (have_result) {
-        std::atomic_thread_fence(std::memory_order_acquire);
-        std::memcpy(h, e->result_host, sizeof(LmState) - 8);
-        h->gen = 0; h->aborted = 0;
-      }
-    }
-    if (!have_result) {
-      HIP_OR_FAIL(e, hipMemcpyAsync(h, st, sizeof(LmState), hipMemcpyDeviceToHost, e->stream));
-      HIP_OR_FAIL(e, hipStreamSynchronize(e->stream));
-    }
-    if (h->aborted || h->phase != PH_DONE) {  // the barrier watchdog fired (workgroups not co-resident): redo with one launch per transition
-      e->persist_aborts++;
-      e->abort_word_dirty = true;
-      e->persist_backoff = std::min(std::max(2 * e->persist_backoff, 1), 64);
-      e->persist_skip = e->persist_backoff;
-      // multi-GPU: an abort on ANY rank reaches every rank within a watchdog period (its mailbox stays empty), so all ranks
-      // arrive here and restart together; the exchange counter jumps past whatever this launch may have used
-      if (sharded) e->peer.x = (e->peer.x + 8192) & ~1ull;
-      if (h->aborted == 3u) g_xcd_local_strikes.fetch_add(1);  // the members of a group did not share an XCD: a few of these and the XCD-local flavour is off for good
-      const GridPlan plan = c.plan;
-      const bool retried = c.retried;
-      c.release_slots();
-      return do_align<MODE>(e, src, vm, c.guess16, &p, result, rebuild_safe, retried, true, &plan);  // the same layout: the same partition of the items, the same sums
-    }
-    launched = 1;
-    e->persist_backoff = 0;  // a clean persistent run: the device is ours again
-    if (sharded) e->peer.x += (unsigned long long)(p.optimizer ? h->num_linearize : 1 + h->num_error_evals);  // one exchange per trip
-  }
-  while (!persistent) {
-    for (int s = 0; s < batch; s++) {
-      // the first launch carries the initial guess and the LM parameters and (re)initialises the device state
-      const bool first = (launched == 0 && s == 0 && !degenerate);
-      int rc = launch_cost<MODE>(e, src, vm, -1, first ? &guess : nullptr, nullptr, first ? &p : nullptr, false, e->peer.x + (unsigned long long)(launched + s), c.forced ? &c.plan : nullptr);
-      if (rc) return rc;
-      if (e->comm) {
-        rc = allreduce_sums(e);
-        if (rc) return rc;
-        if (p.optimizer) lm_update_kernel<true><<<1, 64, 0, e->stream>>>(st); else lm_update_kernel<false><<<1, 64, 0, e->stream>>>(st);
-      }
-    }
-    launched += batch;
-    HIP_OR_FAIL(e, hipMemcpyAsync(h, st, sizeof(LmState), hipMemcpyDeviceToHost, e->stream));
-    HIP_OR_FAIL(e, hipStreamSynchronize(e->stream));
-    if (h->aborted) {  // (only the peer exchange raises it on this route)
-      e->abort_word_dirty = true;
-      e->peer.x = (e->peer.x + 8192) & ~1ull;
-      return e->fail(FVH_ERR_COMM, "align: a peer rank did not deliver its sums (every rank must make the same sequence of calls)");
-    }
-    if (h->phase == PH_DONE || launched >= budget) break;
-    batch = 3;
-  }
-  if (!persistent && sharded && h->num_linearize > 0) e->peer.x += (unsigned long long)(p.optimizer ? h->num_linearize : 1 + h->num_error_evals);  // launches after PH_DONE leave before the exchange
-  vm.nv_hint = h->vm_num_voxels;
-  if (src.source_map) src.source_map->nv_hint = h->vm_num_voxels2;
-  if (h->vm_dropped > 0) {  // hint-sized table overflowed: rebuild at the safe size and run again (rare)
-    if (c.retried) return e->fail(FVH_ERR_BAD_STATE, "voxel map overflow persists after safe rebuild");
-    const bool no_persist = c.no_persist, forced = c.forced;
-    const GridPlan plan = c.plan;
-    c.release_slots();
-    int rc = rebuild_safe();
-    if (rc) return rc;
-    CostSource fresh = src;
-    fresh.refresh();
-    return do_align<MODE>(e, fresh, vm, c.guess16, &p, result, rebuild_safe, true, no_persist, forced ? &plan : nullptr);
-  }
-  e->gang_clear();
-  e->prev_steps = e->last_steps;
-  e->last_steps = p.optimizer ? std::max(1, (int)h->num_linearize) : 1 + h->num_error_evals;  // launches this align needed: the first linearize + one fused launch per trial (Gauss-Newton: one per linearisation)
-  e->lin = h->x_lin;
-  e->corr_sel = h->corr_cur;
-  e->has_corr = true;  // correspondences of the last consumed linearisation stay valid for compute_error()
-  e->corr_kind = 0;    // voxel-bucket ids (a nearest-point list of an earlier gicp_update_correspondences is gone)
-  e->corr_n_src = src.n_upper;
-  pose_to_colmajor16(h->x0, result->T);
-  for (int i = 0; i < 6; i++) for (int j = 0; j < 6; j++) result->H[j * 6 + i] = h->final_H[i * 6 + j];
-  result->final_error = h->y0;
-  result->converged = h->converged;
-  result->nr_iterations = h->nr_iterations;
-  result->num_linearize = h->num_linearize;
-  result->num_error_evals = h->num_error_evals;
-  result->lm_failed = h->lm_failed;
-  result->num_launches = (int)launched;
-  e->lm_trace_rows = e->lm_trace_on ? h->num_error_evals : 0;
-  return FVH_OK;
-}
-
-template <int MODE>
-int do_align(Engine* e, const CostSource& src, VoxelMapDev& vm, const double* guess16, const fvh_lm_params* params, fvh_lm_result* result, const Rebuild& rebuild_safe,
-             bool retried, bool no_persist, const GridPlan* forced_plan) {
-  if (!result) return e->fail(FVH_ERR_INVALID_ARGUMENT, "align: null argument");
-  AlignCtx c;
-  int rc = align_begin<MODE>(e, c, src, vm, guess16, params, retried, no_persist, forced_plan);
-  if (rc) return rc;
-  return align_finish<MODE>(e, c, src, vm, result, rebuild_safe);
-}
-
-// exact 1-NN of every (transformed) source point in the target (kernels_cov.hpp: nn1_rows_kernel -- four queries per wave, one per 16-lane row)
-void launch_nn1(Engine* e, const CloudDev& src, const CloudDev& tgt, const float* T12, double thr_sq, int* corr, float* best_out, const LmLink& lm) {
-  nn1_rows_kernel<<<(src.n + 15) / 16, 256, 0, e->stream>>>(src.sorted.as<float4>(), src.n, tgt.sorted.as<float4>(), tgt.bbox.as<float4>(), tgt.bbox2.as<float4>(), tgt.n, T12, thr_sq, corr, best_out, lm);
-}
-
-int do_fitness(Engine* e, CloudDev& src, CloudDev& tgt, const double* T16, double max_range, double* score) {
-  if (!T16 || !score) return e->fail(FVH_ERR_INVALID_ARGUMENT, "fitness_score: null argument");
-  if (!src.has_pts || !tgt.has_pts || src.n == 0 || tgt.n == 0) return e->fail(FVH_ERR_BAD_STATE, "fitness_score: clouds not set");
-  float T12[12];
-  for (int i = 0; i < 3; i++) { for (int j = 0; j < 3; j++) T12[i * 4 + j] = (float)T16[j * 4 + i]; T12[i * 4 + 3] = (float)T16[12 + i]; }
-  char* base = (char*)e->fit.p;
-  HIP_OR_FAIL(e, hipMemsetAsync(base, 0, 16, e->stream));
-  HIP_OR_FAIL(e, hipMemcpyAsync(base + 16, T12, sizeof(T12), hipMemcpyHostToDevice, e->stream));
-#ifdef FVH_TEST_KERNELS  // test build only: FVH_FIT_MODE=0 full sweep, 2: eight queries per wave
-  static const int fit_mode = [] { const char* v = getenv("FVH_FIT_MODE"); return v ? atoi(v) : 1; }();
-#else
-  constexpr int fit_mode = 1;
-#endif
-  if (fit_mode != 0) {
-    int rc = ensure_sorted(e, src);
-    if (!rc) rc = ensure_sorted(e, tgt);
-    if (rc) return rc;
-  }
-  {
-    ProfScope ps(e, "fitness");
-#ifdef FVH_TEST_KERNELS
-    const int waves = (src.n + FIT_Q - 1) / FIT_Q;
-    if (fit_mode == 0) {
-      fitness_kernel<<<(waves + 3) / 4, 256, 0, e->stream>>>(src.pts.as<float4>(), src.n, tgt.pts.as<float4>(), tgt.n, (const float*)(base + 16), max_range, (double*)base);
-    } else if (fit_mode == 2) {
-      fitness_tiled_kernel<<<(waves + 3) / 4, 256, 0, e->stream>>>(src.sorted.as<float4>(), src.n, tgt.sorted.as<float4>(), tgt.bbox.as<float4>(), tgt.n, (const float*)(base + 16), max_range,
-                                                                    (double*)base);
-    } else
-#endif
-    {  // the exact 1-NN search of the GICP path (64 queries per wave), then a fixed-order reduction
-      HIP_OR_FAIL(e, e->fit_best.ensure(sizeof(float) * (size_t)src.n));
-#ifdef FVH_TEST_KERNELS
-      if (fit_mode == 3)
-        nn1_corr_kernel<<<src.n, 64, 0, e->stream>>>(src.sorted.as<float4>(), src.n, tgt.sorted.as<float4>(), tgt.bbox.as<float4>(), tgt.bbox2.as<float4>(), tgt.n,
-                                                                (const float*)(base + 16), 0.0, nullptr, e->fit_best.as<float>());
-      else
-#endif
-      launch_nn1(e, src, tgt, (const float*)(base + 16), 0.0, nullptr, e->fit_best.as<float>(), LmLink{nullptr, nullptr, nullptr, nullptr, 0});
-      fitness_reduce_kernel<<<1, 1024, 0, e->stream>>>(e->fit_best.as<float>(), src.n, max_range, (double*)base);
-    }
-  }
-  HIP_OR_FAIL(e, hipGetLastError());
-  double out[2];
-  HIP_OR_FAIL(e, hipMemcpyAsync(out, base, 16, hipMemcpyDeviceToHost, e->stream));
-  HIP_OR_FAIL(e, hipStreamSynchronize(e->stream));
-  *score = out[1] > 0 ? out[0] / out[1] : 1.7976931348623157e308;
-  return FVH_OK;
-}
-
-int comm_init(Engine* e, const void* id128, int nranks, int rank) {
-  if (!id128 || nranks < 1 || rank < 0 || rank >= nranks) return e->fail(FVH_ERR_INVALID_ARGUMENT, "comm_init: bad arguments");
-  if (!g_rccl.load()) return e->fail(FVH_ERR_COMM, std::string("cannot load librccl.so: ") + (dlerror() ? dlerror() : "missing symbols"));
-  if (e->comm) { g_rccl.CommDestroy(e->comm); e->comm = nullptr; }
-  Rccl::UID uid;
-  std::memcpy(uid.b, id128, 128);
-  HIP_OR_FAIL(e, hipSetDevice(e->device));
-  int rc = g_rccl.CommInitRank(&e->comm, nranks, uid, rank);
-  if (rc != 0) { e->comm = nullptr; return e->fail(FVH_ERR_COMM, "ncclCommInitRank failed with code " + std::to_string(rc)); }
-  e->nranks = nranks; e->rank = rank;
-  return FVH_OK;
-}
-
-int profile_get(Engine* e, const char* cls, double* total_ms, int* launches) {
-  if (!cls) return e->fail(FVH_ERR_INVALID_ARGUMENT, "profile_get: null class");
-  if (e->side) HIP_OR_FAIL(e, hipStreamSynchronize(e->side));  // (the map build's events may live there)
-  HIP_OR_FAIL(e, hipStreamSynchronize(e->stream));
-  double tot = 0; int n = 0;
-  auto it = e->prof.recs.find(cls);
-  if (it != e->prof.recs.end())
-    for (size_t i = 0; i < it->second.used; i++) {
-      float ms = 0;
-      if (hipEventElapsedTime(&ms, it->second.ev[i].first, it->second.ev[i].second) == hipSuccess) { tot += ms; n++; }
-    }
-  if (total_ms) *total_ms = tot;
-  if (launches) *launches = n;
-  return FVH_OK;
-}
-
-// ---------------------------------------------------------------------------------------------
-// FastGICP on the device: nearest-target-point correspondences + the VGICP cost kernel on per-point records
-// ---------------------------------------------------------------------------------------------
-// sorted clouds + per-target-point records in the voxel-bucket layout (1 MB at 17k points: rebuilt every time rather than tracked)
-int gicp_prepare(Engine* e, CloudDev& src, CloudDev& tgt, VoxelMapDev& records, double max_dist, const char* who) {
-  if (!src.has_pts || !tgt.has_pts || src.n == 0 || tgt.n == 0) return e->fail(FVH_ERR_BAD_STATE, std::string(who) + ": clouds not set");
-  if (!src.has_cov || !tgt.has_cov) return e->fail(FVH_ERR_BAD_STATE, std::string(who) + ": covariances not set");
-  if (!(max_dist > 0)) return e->fail(FVH_ERR_INVALID_ARGUMENT, std::string(who) + ": max correspondence distance must be > 0");
-  int rc = ensure_sorted(e, src);
-  if (!rc) rc = ensure_sorted(e, tgt);
-  if (rc) return rc;
-  HIP_OR_FAIL(e, records.table.ensure(sizeof(float4) * 4 * (size_t)tgt.n));
-  HIP_OR_FAIL(e, records.counters.ensure(2 * 16 * sizeof(int)));
-  HIP_OR_FAIL(e, hipMemsetAsync(records.counters.p, 0, 2 * 16 * sizeof(int), e->stream));
-  gicp_records_kernel<<<(tgt.n + 255) / 256, 256, 0, e->stream>>>(tgt.pts.as<float4>(), tgt.cov.as<float4>(), tgt.n, records.table.as<float4>());
-  records.capacity = 1; records.res = 1.0; records.valid = true;
-  HIP_OR_FAIL(e, e->corr.ensure(2 * sizeof(int) * (size_t)src.n));
-  return FVH_OK;
-}
-
-// FastGICP::computeTransformation with the whole LM loop on the device (fast_gicp_impl.hpp:118-240 driven by
-// lsq_registration_impl.hpp:53-168). Per LM transition TWO launches and no host round trip: nn1_corr_kernel searches the
-// nearest target point of every source point at the pose the LM state on the device says comes next (x0 for a linearisation,
-// the trial pose for the fused trial + speculative linearisation) and the cost kernel consumes those ids (external_find).
-// Round 1 drove this from the host: two blocking round trips per iteration.
-int gicp_align(Engine* e, CloudDev& src, CloudDev& tgt, VoxelMapDev& records, const CostSource& cs, double max_dist, const double* guess16, const fvh_lm_params* params,
-               fvh_lm_result* result) {
-  if (!guess16 || !result) return e->fail(FVH_ERR_INVALID_ARGUMENT, "gicp_align: null argument");
-  int rc = gicp_prepare(e, src, tgt, records, max_dist, "gicp_align");
-  if (rc) return rc;
-  fvh_lm_params p;
-  if (params) p = *params; else fvh_default_lm_params(&p);
-  e->align_optimizer = p.optimizer != 0 ? 1 : 0;
-  LmState* st = e->state.as<LmState>();
-  const PoseD guess = pose_from_colmajor16(guess16);
-  float T12[12];
-  for (int i = 0; i < 3; i++) { for (int j = 0; j < 3; j++) T12[i * 4 + j] = (float)guess16[j * 4 + i]; T12[i * 4 + 3] = (float)guess16[12 + i]; }
-  char* base = (char*)e->fit.p;
-  HIP_OR_FAIL(e, hipMemcpyAsync(base + 16, T12, sizeof(T12), hipMemcpyHostToDevice, e->stream));
-  const double thr = std::min(max_dist, 1.8446743e19);
-  const LmLink link{&st->phase, &st->corr_cur, st->x0.r, st->xi.r, (size_t)src.n};
-  const long long budget = (long long)std::max(p.max_iterations, 0) * (1 + (long long)std::max(p.lm_max_iterations, 0)) + 1;
-  if (e->lm_trace_on) HIP_OR_FAIL(e, e->lm_trace.ensure(sizeof(double) * 6 * (size_t)std::max<long long>(budget, 1)));
-  e->lm_trace_rows = 0;
-  LmState* h = reinterpret_cast<LmState*>(e->pinned);
-  if (p.max_iterations <= 0) {
-    lm_init_kernel<<<1, 64, 0, e->stream>>>(st, guess, p.rotation_epsilon, p.transformation_epsilon, p.lm_init_lambda_factor, p.max_iterations, p.lm_max_iterations, e->ticket.as<unsigned>(), p.optimizer != 0 ? 1 : 0);
-    HIP_OR_FAIL(e, hipGetLastError());
-  }
-  long long launched = 0;
-  int batch = e->last_steps > 0 ? std::max(e->last_steps, e->prev_steps) + 1 : 8;
-  for (;;) {
-    for (int s = 0; s < batch && p.max_iterations > 0; s++) {
-      const bool first = (launched == 0 && s == 0);
-      {
-        ProfScope ps(e, "gicp_nn");
-        launch_nn1(e, src, tgt, reinterpret_cast<const float*>(base + 16), thr * thr, e->corr.as<int>(), nullptr, first ? LmLink{nullptr, nullptr, nullptr, nullptr, 0} : link);
-      }
-      rc = launch_cost<MODE_VGICP>(e, cs, records, -1, first ? &guess : nullptr, nullptr, first ? &p : nullptr);
-      if (rc) return rc;
-    }
-    launched += batch;
-    HIP_OR_FAIL(e, hipMemcpyAsync(h, st, sizeof(LmState), hipMemcpyDeviceToHost, e->stream));
-    HIP_OR_FAIL(e, hipStreamSynchronize(e->stream));
-    if (h->phase == PH_DONE || launched >= budget || p.max_iterations <= 0) break;
-    batch = 3;
-  }
-  e->prev_steps = e->last_steps;
-  e->last_steps = p.optimizer ? std::max(1, (int)h->num_linearize) : 1 + h->num_error_evals;
-  e->lin = h->x_lin;
-  e->corr_sel = h->corr_cur;
-  e->has_corr = true;
-  e->corr_kind = 1;
-  e->corr_n_src = src.n;
-  pose_to_colmajor16(h->x0, result->T);
-  for (int i = 0; i < 6; i++) for (int j = 0; j < 6; j++) result->H[j * 6 + i] = h->final_H[i * 6 + j];
-  result->final_error = h->y0;
-  result->converged = h->converged;
-  result->nr_iterations = h->nr_iterations;
-  result->num_linearize = h->num_linearize;
-  result->num_error_evals = h->num_error_evals;
-  result->lm_failed = h->lm_failed;
-  result->num_launches = (int)(2 * launched);
-  e->lm_trace_rows = e->lm_trace_on ? h->num_error_evals : 0;
-  return FVH_OK;
-}
-
-int gicp_update_correspondences(Engine* e, CloudDev& src, CloudDev& tgt, VoxelMapDev& records, const double* T16, double max_dist) {
-  if (!T16) return e->fail(FVH_ERR_INVALID_ARGUMENT, "gicp_update_correspondences: null pose");
-  int rc = gicp_prepare(e, src, tgt, records, max_dist, "gicp_update_correspondences");
-  if (rc) return rc;
-  float T12[12];
-  for (int i = 0; i < 3; i++) { for (int j = 0; j < 3; j++) T12[i * 4 + j] = (float)T16[j * 4 + i]; T12[i * 4 + 3] = (float)T16[12 + i]; }  // trans.cast<float>()
-  char* base = (char*)e->fit.p;
-  HIP_OR_FAIL(e, hipMemcpyAsync(base + 16, T12, sizeof(T12), hipMemcpyHostToDevice, e->stream));
-  const double thr = std::min(max_dist, 1.8446743e19);  // threshold^2 must stay finite in fp64 (reference default: float max)
-  {
-    ProfScope ps(e, "gicp_nn");
-#ifdef FVH_TEST_KERNELS  // test build only: FVH_GICP_NN_MODE=0 selects the superseded eight-queries-per-wave search
-    static const int nn_mode = [] { const char* v = getenv("FVH_GICP_NN_MODE"); return v ? atoi(v) : 1; }();
-    if (nn_mode == 3) {
-      nn1_corr_kernel<<<src.n, 64, 0, e->stream>>>(src.sorted.as<float4>(), src.n, tgt.sorted.as<float4>(), tgt.bbox.as<float4>(), tgt.bbox2.as<float4>(), tgt.n,
-                                                              reinterpret_cast<const float*>(base + 16), thr * thr, e->corr.as<int>());
-    } else if (nn_mode != 1) {
-      const int waves = (src.n + FIT_Q - 1) / FIT_Q;
-      nn_corr_tiled_kernel<<<(waves + 3) / 4, 256, 0, e->stream>>>(src.sorted.as<float4>(), src.n, tgt.sorted.as<float4>(), tgt.bbox.as<float4>(), tgt.n, reinterpret_cast<const float*>(base + 16), thr * thr,
-                                                                   e->corr.as<int>());
-    } else
-#endif
-    {
-      launch_nn1(e, src, tgt, reinterpret_cast<const float*>(base + 16), thr * thr, e->corr.as<int>(), nullptr, LmLink{nullptr, nullptr, nullptr, nullptr, 0});
-    }
-  }
-  HIP_OR_FAIL(e, hipGetLastError());
-  HIP_OR_FAIL(e, hipStreamSynchronize(e->stream));  // T12 is a stack buffer
-  e->lin = pose_from_colmajor16(T16);
-  e->corr_sel = 0;
-  e->has_corr = true;
-  e->corr_kind = 1;
-  e->corr_by_position = false;  // (nn1_rows_kernel writes the row of the ORIGINAL index)
-  e->corr_n_src = src.n;
-  return FVH_OK;
-}
-
-// ---------------------------------------------------------------------------------------------
-// voxel-grid downsampling (kernels_downsample.hpp)
-// ---------------------------------------------------------------------------------------------
-struct DownsampleDev {
-  CloudDev cloud;                 // the input, widened to float4
-  DevBuf keys, idx, head, trig, scan, bsums, slots, out;
-  int out_n = 0;
-  void release() { cloud.release(); keys.release(); idx.release(); head.release(); trig.release(); scan.release(); bsums.release(); slots.release(); out.release(); }
-};
-
-// exclusive scan of n unsigned values (in -> out, may alias); the grand total lands in bsums[nb]
-int device_scan(Engine* e, DevBuf& bsums, const unsigned* in, int n, unsigned* out, const unsigned** total) {
-  const int nb = (n + SCAN_BLOCK_ITEMS - 1) / SCAN_BLOCK_ITEMS;
-  HIP_OR_FAIL(e, bsums.ensure(sizeof(unsigned) * (size_t)(nb + 1)));
-  scan_block_sums_kernel<<<nb, 256, 0, e->stream>>>(in, n, bsums.as<unsigned>());
-  radix_scan_kernel<<<1, 1024, 0, e->stream>>>(bsums.as<unsigned>(), nb + 1);
-  scan_apply_kernel<<<nb, 256, 0, e->stream>>>(in, n, bsums.as<unsigned>(), out);
-  HIP_OR_FAIL(e, hipGetLastError());
-  *total = bsums.as<unsigned>() + nb;
-  return FVH_OK;
-}
-
-// stable LSD radix sort of (key, idx) pairs on `bits` key bits; returns the index (0/1) of the buffer pair holding the result
-int radix_sort_pairs(Engine* e, unsigned* keys[2], int* idx[2], int n, int bits, int* result, hipStream_t on, DevBuf* hist_buf) {
-  hipStream_t const st = on ? on : e->stream;
-  DevBuf& hb = hist_buf ? *hist_buf : e->sort_hist;  // (a caller on another stream than the handle's brings its own histograms)
-  const int items = n <= 262144 ? 256 : (n <= 1048576 ? 512 : SORT_ITEMS_MAX);
-  const int nwaves = (n + items - 1) / items;
-  HIP_OR_FAIL(e, hb.ensure(sizeof(unsigned) * (size_t)RADIX_BINS * (nwaves + 1)));
-  unsigned* bin_tot = hb.as<unsigned>() + (size_t)RADIX_BINS * nwaves;
-  const int wblocks = (nwaves + 3) / 4;
-  const int passes = std::max(1, (bits + RADIX_BITS - 1) / RADIX_BITS);
-  for (int pass = 0; pass < passes; pass++) {
-    const int in = pass & 1, out = in ^ 1, shift = pass * RADIX_BITS;
-    radix_hist_kernel<RADIX_BITS><<<wblocks, 256, 0, st>>>(keys[in], n, shift, nwaves, items, hb.as<unsigned>());
-    radix_binscan_kernel<<<RADIX_BINS / 4, 256, 0, st>>>(hb.as<unsigned>(), nwaves, bin_tot);
-    radix_scan_kernel<<<1, 1024, 0, st>>>(bin_tot, RADIX_BINS);
-    radix_scatter_kernel<RADIX_BITS><<<wblocks, 256, 0, st>>>(keys[in], idx[in], n, shift, nwaves, items, hb.as<unsigned>(), bin_tot, keys[out], idx[out], nullptr, nullptr);
-  }
-  HIP_OR_FAIL(e, hipGetLastError());
-  *result = passes & 1;
-  return FVH_OK;
-}
-
-inline float host_ordered_to_float(unsigned u) {
-  const unsigned v = (u & 0x80000000u) ? (u & 0x7fffffffu) : ~u;
-  float f;
-  std::memcpy(&f, &v, 4);
-  return f;
-}
-
-// pcl::ApproximateVoxelGrid: the fused six-launch chain of kernels_downsample.hpp (no memset, no key / index arrays; the count
-// comes back through mapped host memory instead of a copy kernel + stream synchronisation)
-int downsample_approx(Engine* e, DownsampleDev& d, const float* xyz, int n, int stride, bool on_device, float leaf, int* out_n, bool early = false) {
-  if (n < 0 || (n > 0 && !xyz)) return e->fail(FVH_ERR_INVALID_ARGUMENT, "voxelgrid: null points");
-  if (stride != 3 && stride != 4) return e->fail(FVH_ERR_INVALID_ARGUMENT, "voxelgrid: stride must be 3 or 4 floats");
-  if (n == 0) return FVH_OK;
-  const float* d_xyz = xyz;
-  if (!on_device) {
-    HIP_OR_FAIL(e, e->staging.ensure(sizeof(float) * stride * (size_t)n));
-    HIP_OR_FAIL(e, hipMemcpyAsync(e->staging.p, xyz, sizeof(float) * stride * (size_t)n, hipMemcpyHostToDevice, e->stream));
-    d_xyz = e->staging.as<float>();
-  }
-  const int nwaves = (n + AVG_ITEMS - 1) / AVG_ITEMS, nwords = (n + 31) / 32, nblocks = (nwords + 31) / 32;
-  const int wblocks = (nwaves + 3) / 4;
-  HIP_OR_FAIL(e, d.keys.ensure(sizeof(unsigned) * ((size_t)AVG_SLOTS * nwaves + AVG_SLOTS + (size_t)AVG_SLOTS * wblocks)));  // slot x wave histogram + slot totals + per-workgroup histograms (fused chain)
-  HIP_OR_FAIL(e, d.idx.ensure(sizeof(float4) * (size_t)n));                                     // the points in slot order
-  HIP_OR_FAIL(e, d.head.ensure((size_t)n));                                                     // run heads (bytes)
-  HIP_OR_FAIL(e, d.trig.ensure(sizeof(unsigned) * (size_t)nblocks * 32));                       // trigger bits by original index (whole blocks of 32 words)
-  HIP_OR_FAIL(e, d.scan.ensure(sizeof(unsigned) * (size_t)(nblocks + 1)));                      // trigger prefix per 1024 indices
-  HIP_OR_FAIL(e, d.out.ensure(sizeof(float) * 3 * (size_t)n));
-  const bool fresh = d.slots.p == nullptr;
-  HIP_OR_FAIL(e, d.slots.ensure(sizeof(AvgState)));
-  if (fresh) HIP_OR_FAIL(e, hipMemsetAsync(d.slots.p, 0, sizeof(AvgState), e->stream));  // (the ticket re-arms itself afterwards)
-  unsigned* hist = d.keys.as<unsigned>();
-  unsigned* totals = hist + (size_t)AVG_SLOTS * nwaves;
-  unsigned* hist_wg = totals + AVG_SLOTS;
-  // up to AVG_FUSED_MAX_POINTS points: four launches -- the scatter and the emit kernel recompute the two small prefix sums themselves
-  // (kernels_downsample.hpp); FVH_AVG_FUSED=0 keeps round 2's six for A/B runs
-  static const bool fused_on = [] { const char* v = getenv("FVH_AVG_FUSED"); return !v || atoi(v) != 0; }();
-  const bool fused = fused_on && n <= AVG_FUSED_MAX_POINTS;
-  float4* sorted = d.idx.as<float4>();
-  unsigned char* head = d.head.as<unsigned char>();
-  AvgState* st = d.slots.as<AvgState>();
-  const float inv = 1.0f / leaf;
-  const unsigned long long seq = ++e->persist_seq;
-  volatile unsigned long long* hres = reinterpret_cast<volatile unsigned long long*>(e->result_host);
-  {
-    ProfScope ps(e, "downsample");
-    const int pblocks = (n + 255) / 256;
-    // early: the count travels to the host before the centroids exist and the call returns while the emit kernel runs (same-stream consumers only)
-    early = early && on_device && e->result_dev && !e->prof.on;
-    unsigned long long* final_result = (e->prof.on || early) ? nullptr : e->result_dev;
-    if (fused) {
-      avg_keys_hist_kernel<<<wblocks, 256, 0, e->stream>>>(d_xyz, n, stride, inv, nwaves, hist, d.trig.as<unsigned>(), nwords, st, hist_wg);
-      avg_scatter_kernel<<<wblocks, 256, 0, e->stream>>>(d_xyz, n, stride, inv, nwaves, hist, st, sorted, hist_wg);
-      avg_mark_kernel<<<pblocks, 256, 0, e->stream>>>(sorted, n, inv, head, d.trig.as<unsigned>(), st);
-      avg_emit_kernel<<<pblocks, 256, 0, e->stream>>>(sorted, head, n, inv, d.trig.as<unsigned>(), nullptr, st, d.out.as<float>(), final_result, seq, nwords, early ? e->result_dev : nullptr);
-    } else {
-      avg_keys_hist_kernel<<<wblocks, 256, 0, e->stream>>>(d_xyz, n, stride, inv, nwaves, hist, d.trig.as<unsigned>(), nwords, st);
-      avg_binscan_kernel<<<AVG_SLOTS / 4, 256, 0, e->stream>>>(hist, nwaves, totals, st);
-      avg_scatter_kernel<<<wblocks, 256, 0, e->stream>>>(d_xyz, n, stride, inv, nwaves, hist, st, sorted);
-      avg_mark_kernel<<<pblocks, 256, 0, e->stream>>>(sorted, n, inv, head, d.trig.as<unsigned>(), st);
-      avg_scan_kernel<<<1, 1024, 0, e->stream>>>(d.trig.as<unsigned>(), nwords, d.scan.as<unsigned>(), st, early ? e->result_dev : nullptr, seq);
-      avg_emit_kernel<<<pblocks, 256, 0, e->stream>>>(sorted, head, n, inv, d.trig.as<unsigned>(), d.scan.as<unsigned>(), st, d.out.as<float>(), final_result, seq);
-    }
-  }
-  HIP_OR_FAIL(e, hipGetLastError());
-  unsigned long long count = 0, bad = 0;
-  bool have = false;
-  if (e->result_dev && !e->prof.on) {  // spin on the sequence word the scan kernel writes after the count (mapped pinned memory)
-    for (unsigned long long spins = 0;; spins++) {
-      if (hres[2] == seq) { have = true; break; }
-      if ((spins & 0x3ff) == 0x3ff && hipStreamQuery(e->stream) != hipErrorNotReady) { have = (hres[2] == seq); break; }
-    }
-    if (have) { std::atomic_thread_fence(std::memory_order_acquire); count = hres[0]; bad = hres[1]; }
-  }
-  if (!have) {
-    unsigned h[2] = {0, 0};
-    HIP_OR_FAIL(e, hipMemcpyAsync(h, &st->trig_total, 2 * sizeof(unsigned), hipMemcpyDeviceToHost, e->stream));  // trig_total, used_slots are adjacent
-    unsigned hb = 0;
-    HIP_OR_FAIL(e, hipMemcpyAsync(&hb, &st->bad, sizeof(unsigned), hipMemcpyDeviceToHost, e->stream));
-    HIP_OR_FAIL(e, hipStreamSynchronize(e->stream));
-    count = (unsigned long long)h[0] + h[1];
-    bad = hb;
-    if (!(e->result_dev && !e->prof.on) || hb) HIP_OR_FAIL(e, hipMemsetAsync(&st->bad, 0, sizeof(unsigned), e->stream));  // the emit kernel only re-arms the flag when it reports through mapped memory
-  } else if (!on_device) {
-    HIP_OR_FAIL(e, hipStreamSynchronize(e->stream));  // the caller may free its host buffer on return; (the staging copy is long done, this only drains the emit kernel)
-  }
-  if (bad) { d.out_n = 0; return e->fail(FVH_ERR_INVALID_ARGUMENT, "voxelgrid: non-finite coordinates in the input"); }
-  d.out_n = (int)count;
-  *out_n = d.out_n;
-  return FVH_OK;
-}
-
-int downsample(Engine* e, DownsampleDev& d, int method, const float* xyz, int n, int stride, bool on_device, float leaf, int* out_n, bool early = false) {
-  if (e->stream_owner) e->stream_owner->quiet = false;  // work on a borrowed stream: its owner can no longer assume the stream has drained (Engine::quiet)
-  if (!out_n) return e->fail(FVH_ERR_INVALID_ARGUMENT, "voxelgrid: null out_n");
-  if (method != FVH_VOXELGRID_EXACT && method != FVH_VOXELGRID_APPROXIMATE) return e->fail(FVH_ERR_INVALID_ARGUMENT, "voxelgrid: unknown method");
-  if (!(leaf > 0.f)) return e->fail(FVH_ERR_INVALID_ARGUMENT, "voxelgrid: leaf size must be > 0");
-  int rc = FVH_OK;
-  d.out_n = 0;
-  *out_n = 0;
-  if (method == FVH_VOXELGRID_APPROXIMATE) return downsample_approx(e, d, xyz, n, stride, on_device, leaf, out_n, early);
-  rc = upload_cloud(e, d.cloud, xyz, n, stride, on_device, false);
-  if (rc) return rc;
-  if (n == 0) return FVH_OK;
-  ProfScope ps(e, "downsample");
-  const float inv = 1.0f / leaf;
-  const float4* pts = d.cloud.pts.as<float4>();
-  HIP_OR_FAIL(e, d.keys.ensure(sizeof(unsigned) * 2 * (size_t)n + 128));
-  HIP_OR_FAIL(e, d.idx.ensure(sizeof(int) * 2 * (size_t)n));
-  HIP_OR_FAIL(e, d.head.ensure(sizeof(unsigned) * (size_t)n));
-  HIP_OR_FAIL(e, d.scan.ensure(sizeof(unsigned) * (size_t)n));
-  HIP_OR_FAIL(e, d.out.ensure(sizeof(float) * 3 * (size_t)n));
-  unsigned* keys[2] = {d.keys.as<unsigned>(), d.keys.as<unsigned>() + n};
-  int* idx[2] = {d.idx.as<int>(), d.idx.as<int>() + n};
-  const int blocks = (n + 255) / 256;
-  unsigned* h_total = reinterpret_cast<unsigned*>(e->pinned);
-  unsigned* bad = d.keys.as<unsigned>() + 2 * (size_t)n + 8;  // set by the key kernels on a non-finite coordinate
-  int sorted = 0;
-  if (method == FVH_VOXELGRID_EXACT) {
-    HIP_OR_FAIL(e, hipMemsetAsync(bad, 0, sizeof(unsigned), e->stream));
-    // pcl::VoxelGrid: lattice over the bounding box (getMinMax3D), linear voxel index, points grouped by index
-    unsigned* box = d.keys.as<unsigned>() + 2 * (size_t)n;
-    HIP_OR_FAIL(e, hipMemsetAsync(box, 0xFF, 12, e->stream));
-    HIP_OR_FAIL(e, hipMemsetAsync(box + 3, 0, 12, e->stream));
-    cloud_bbox_kernel<<<std::min(256, blocks), 256, 0, e->stream>>>(pts, n, box);
-    HIP_OR_FAIL(e, hipMemcpyAsync(h_total, box, 24, hipMemcpyDeviceToHost, e->stream));
-    HIP_OR_FAIL(e, hipStreamSynchronize(e->stream));
-    VgGrid g;
-    long long total = 1;
-    for (int a = 0; a < 3; a++) {
-      const float mn = host_ordered_to_float(h_total[a]), mx = host_ordered_to_float(h_total[3 + a]);
-      if (!std::isfinite(mn) || !std::isfinite(mx)) return e->fail(FVH_ERR_INVALID_ARGUMENT, "voxelgrid: non-finite coordinates");
-      const float lo = std::floor(mn * inv), hi = std::floor(mx * inv);
-      if (std::fabs(lo) > 2.0e9f || std::fabs(hi) > 2.0e9f) return e->fail(FVH_ERR_INVALID_ARGUMENT, "voxelgrid: leaf size too small for the input (voxel index overflow)");
-      g.minb[a] = (int)lo;
-      g.divb[a] = (int)hi - g.minb[a] + 1;
-      total *= g.divb[a];
-      if (total > 0x7fffffffLL) return e->fail(FVH_ERR_INVALID_ARGUMENT, "voxelgrid: leaf size too small for the input (voxel index overflow)");  // PCL refuses too
-    }
-    int bits = 1;
-    while (bits < 31 && (1LL << bits) < total) bits++;
-    vg_keys_exact_kernel<<<blocks, 256, 0, e->stream>>>(pts, n, inv, g, keys[0], idx[0], bad);
-    if ((rc = radix_sort_pairs(e, keys, idx, n, bits, &sorted))) return rc;
-    vg_mark_exact_kernel<<<blocks, 256, 0, e->stream>>>(keys[sorted], n, d.head.as<unsigned>());
-    const unsigned* total_dev = nullptr;
-    if ((rc = device_scan(e, d.bsums, d.head.as<unsigned>(), n, d.scan.as<unsigned>(), &total_dev))) return rc;
-    vg_emit_kernel<false><<<blocks, 256, 0, e->stream>>>(keys[sorted], idx[sorted], pts, n, d.head.as<unsigned>(), d.scan.as<unsigned>(), nullptr, nullptr, d.out.as<float>(), nullptr, nullptr);
-    HIP_OR_FAIL(e, hipGetLastError());
-    HIP_OR_FAIL(e, hipMemcpyAsync(h_total, total_dev, sizeof(unsigned), hipMemcpyDeviceToHost, e->stream));
-    HIP_OR_FAIL(e, hipMemcpyAsync(h_total + 2, bad, sizeof(unsigned), hipMemcpyDeviceToHost, e->stream));
-    HIP_OR_FAIL(e, hipStreamSynchronize(e->stream));
-    d.out_n = (int)h_total[0];
-  } else {
-    // pcl::ApproximateVoxelGrid, slot-parallel (see kernels_downsample.hpp). Housekeeping on the stream is kept to ONE small
-    // memset and ONE 16-byte copy: the key kernel clears the trigger flags, `bad` sits behind the slot flags, the scan's
-    // spare entry is cleared by its first kernel, and the emit kernel gathers the three numbers the host needs.
-    HIP_OR_FAIL(e, d.trig.ensure(sizeof(unsigned) * (size_t)n));
-    HIP_OR_FAIL(e, d.slots.ensure(sizeof(unsigned) * (AVG_SLOTS + 1 + 1 + 4)));
-    unsigned* bad2 = d.slots.as<unsigned>() + AVG_SLOTS + 1;
-    unsigned* result = bad2 + 1;  // {trigger count, used slots, bad}
-    HIP_OR_FAIL(e, hipMemsetAsync(d.slots.p, 0, sizeof(unsigned) * (AVG_SLOTS + 2), e->stream));
-    vg_keys_approx_kernel<<<blocks, 256, 0, e->stream>>>(pts, n, inv, keys[0], idx[0], bad2, d.trig.as<unsigned>());
-    if ((rc = radix_sort_pairs(e, keys, idx, n, RADIX_BITS, &sorted))) return rc;
-    vg_mark_approx_kernel<<<blocks, 256, 0, e->stream>>>(keys[sorted], idx[sorted], pts, n, inv, d.head.as<unsigned>(), d.trig.as<unsigned>(), d.slots.as<unsigned>());
-    const unsigned* trig_total = nullptr;
-    if ((rc = device_scan(e, d.bsums, d.trig.as<unsigned>(), n, d.scan.as<unsigned>(), &trig_total))) return rc;
-    radix_scan_kernel<<<1, 1024, 0, e->stream>>>(d.slots.as<unsigned>(), AVG_SLOTS + 1);
-    vg_emit_kernel<true><<<blocks, 256, 0, e->stream>>>(keys[sorted], idx[sorted], pts, n, d.head.as<unsigned>(), d.scan.as<unsigned>(), d.slots.as<unsigned>(), trig_total, d.out.as<float>(), bad2, result);
-    HIP_OR_FAIL(e, hipGetLastError());
-    HIP_OR_FAIL(e, hipMemcpyAsync(h_total, result, 3 * sizeof(unsigned), hipMemcpyDeviceToHost, e->stream));
-    HIP_OR_FAIL(e, hipStreamSynchronize(e->stream));
-    d.out_n = (int)(h_total[0] + h_total[1]);
-  }
-  if (h_total[2]) { d.out_n = 0; return e->fail(FVH_ERR_INVALID_ARGUMENT, "voxelgrid: non-finite coordinates in the input"); }
-  *out_n = d.out_n;
-  return FVH_OK;
-}
+#include "host_stages.inc.hpp"
+#include "host_gicp.inc.hpp"
+#include "host_downsample.inc.hpp"
 
 }  // namespace
 
@@ -2145,7 +378,7 @@ struct fvh_vgicp {
   double gicp_max_dist = 3.4028234663852886e38;
   CostSource cost_source() const {
     // multi-GPU: the tiles are ranges of the Morton order whatever the size of the cloud (spatially compact shards)
-    const int* order = e.sharded() ? (source.has_sorted ? source.order.as<int>() : nullptr) : coherent_order(source);
+    const int* order = e.sharded() ? (source.has_sorted ? source.order.as<int>() : nullptr) : coherent_order(source, e.params.coherent_min_points);
     CostSource c{source.pts.as<float4>(), source.cov.as<float4>(), nullptr, source.n, nullptr, order};
     if (order) { c.sorted = source.sorted.as<float4>(); if (source.has_cov_sorted) c.cov_sorted = source.cov_sorted.as<float4>(); }
     c.shardable = true;
@@ -2189,7 +422,7 @@ struct fvh_ndt {
     const bool tiled = e.tile_n > 1;  // fvh_ndt_set_source_tile: this handle evaluates one spatial tile of the source
     if (distance_mode == FVH_NDT_P2D) {
       // P2D shards like VGICP: source POINTS by Morton tile (the order exists once the caller's align / update_correspondences sorted the cloud)
-      CostSource cs{source.pts.as<float4>(), nullptr, nullptr, source.n, nullptr, tiled ? (source.has_sorted ? source.order.as<int>() : nullptr) : coherent_order(source)};
+      CostSource cs{source.pts.as<float4>(), nullptr, nullptr, source.n, nullptr, tiled ? (source.has_sorted ? source.order.as<int>() : nullptr) : coherent_order(source, e.params.coherent_min_points)};
       cs.shardable = tiled;
       return cs;
     }
@@ -2252,6 +485,14 @@ void fvh_default_lm_params(fvh_lm_params* p) {
   if (!p) return;
   p->max_iterations = 64; p->rotation_epsilon = 2e-3; p->transformation_epsilon = 5e-4; p->lm_max_iterations = 10; p->lm_init_lambda_factor = 1e-9; p->optimizer = 0;
 }
+void fvh_default_engine_params(fvh_engine_params* p) { if (p) *p = env_engine_defaults(); }
+static int get_engine_params(Engine* e, fvh_engine_params* out) { if (!out) return e->fail(FVH_ERR_INVALID_ARGUMENT, "get_engine_params: null"); *out = e->params; return FVH_OK; }
+static int set_engine_params(Engine* e, const fvh_engine_params* p) {
+  if (!p) return e->fail(FVH_ERR_INVALID_ARGUMENT, "set_engine_params: null");
+  if (const char* why = check_engine_params(*p)) return e->fail(FVH_ERR_INVALID_ARGUMENT, why);
+  e->params = *p;
+  return FVH_OK;
+}
 int fvh_device_count(int* count) {
   if (!count) return FVH_ERR_INVALID_ARGUMENT;
   return hipGetDeviceCount(count) == hipSuccess ? FVH_OK : FVH_ERR_HIP;
@@ -2290,6 +531,9 @@ int fvh_vgicp_set_precision(fvh_vgicp* h, int p) {
   h->e.precision = p;
   return FVH_OK;
 }
+
+int fvh_vgicp_get_engine_params(fvh_vgicp* h, fvh_engine_params* out) { CHECK_HANDLE_HOST_ONLY(h); return get_engine_params(&h->e, out); }
+int fvh_vgicp_set_engine_params(fvh_vgicp* h, const fvh_engine_params* p) { CHECK_HANDLE(h); return set_engine_params(&h->e, p); }
 
 int fvh_vgicp_create_target_voxelmap(fvh_vgicp* h) { CHECK_HANDLE(h); return h->build_map(h->resolution); }
 int fvh_vgicp_set_voxel_accumulation_mode(fvh_vgicp* h, int mode) {
@@ -2363,7 +607,7 @@ static void cloud_replaced(CloudDev& c) { c.has_cov = false; c.has_nbr = false; 
 // with the stream idle in between (kernel trace: 4 us between the pack kernel and the sort).
 static int uploaded(Engine* e, CloudDev& c, int rc) {
   if (rc || c.n == 0) return rc;
-  if (!e->device_search_seen && !e->sharded() && c.n < COHERENT_MIN_POINTS) return FVH_OK;  // nobody may ever need the order: it stays lazy (ensure_sorted where it is consumed)
+  if (!e->device_search_seen && !e->sharded() && c.n < e->params.coherent_min_points) return FVH_OK;  // nobody may ever need the order: it stays lazy (ensure_sorted where it is consumed)
   return ensure_sorted(e, c);
 }
 int fvh_vgicp_set_source_cloud(fvh_vgicp* h, const float* xyz, int n) { CHECK_HANDLE_SOURCE_CHAIN(h); h->e.has_corr = false; cloud_replaced(h->source); return uploaded(&h->e, h->source, upload_cloud(&h->e, h->source, xyz, n, 3, false)); }
@@ -2781,6 +1025,8 @@ int fvh_ndt_set_precision(fvh_ndt* h, int p) {
   h->e.precision = p;
   return FVH_OK;
 }
+int fvh_ndt_get_engine_params(fvh_ndt* h, fvh_engine_params* out) { CHECK_HANDLE_HOST_ONLY(h); return get_engine_params(&h->e, out); }
+int fvh_ndt_set_engine_params(fvh_ndt* h, const fvh_engine_params* p) { CHECK_HANDLE(h); NDT_NOT_PENDING(h); return set_engine_params(&h->e, p); }
 int fvh_ndt_swap_source_and_target(fvh_ndt* h) {
   CHECK_HANDLE(h); NDT_NOT_PENDING(h);
   h->source.swap(h->target);
@@ -3016,6 +1262,8 @@ int fvh_voxelgrid_destroy(fvh_voxelgrid* h) {
   return FVH_OK;
 }
 const char* fvh_voxelgrid_last_error(const fvh_voxelgrid* h) { return h ? h->e.err.c_str() : "null handle"; }
+int fvh_voxelgrid_get_engine_params(fvh_voxelgrid* h, fvh_engine_params* out) { CHECK_HANDLE_HOST_ONLY(h); return get_engine_params(&h->e, out); }
+int fvh_voxelgrid_set_engine_params(fvh_voxelgrid* h, const fvh_engine_params* p) { CHECK_HANDLE(h); return set_engine_params(&h->e, p); }
 int fvh_voxelgrid_filter(fvh_voxelgrid* h, int method, const float* xyz, int n, float leaf, int* out_n) { CHECK_HANDLE(h); return downsample(&h->e, h->d, method, xyz, n, 3, false, leaf, out_n); }
 int fvh_voxelgrid_filter_strided(fvh_voxelgrid* h, int method, const float* xyz, int n, int stride, float leaf, int* out_n) { CHECK_HANDLE(h); return downsample(&h->e, h->d, method, xyz, n, stride, false, leaf, out_n); }
 int fvh_voxelgrid_filter_device(fvh_voxelgrid* h, int method, const float* d_xyz, int n, int stride, float leaf, int* out_n) { CHECK_HANDLE(h); return downsample(&h->e, h->d, method, d_xyz, n, stride, true, leaf, out_n); }

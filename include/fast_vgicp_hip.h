@@ -74,6 +74,49 @@ typedef struct fvh_lm_result {
 void fvh_default_lm_params(fvh_lm_params* p);
 int fvh_device_count(int* count);
 
+/* Engine parameters of a handle (round 6): the routes, thresholds and watchdogs that rounds 1-5 read from the process environment each time
+ * they were consulted. They are per-handle state now: a new handle starts from fvh_default_engine_params() -- the built-in defaults with
+ * the FVH_* environment variables of INTEGRATION.md applied ONCE per process -- and fvh_*_set_engine_params() changes one handle only.
+ * (Process-wide by nature and therefore NOT in here: how concurrent aligns split the device's co-resident workgroup slots, the XCD-local
+ * hand-offs and the small-grid layout, which every handle of a process must agree on: FVH_SLOT_MAX_SPLIT, FVH_CONTENDED_SLOT_PCT,
+ * FVH_XCD_LOCAL, FVH_SMALL_GRID_LAYOUT.) No reference counterpart. */
+typedef struct fvh_engine_params {
+  int struct_size;                       /* sizeof(fvh_engine_params) of the caller's header: set by fvh_default_engine_params, checked by the setters */
+  /* Morton sort of a cloud */
+  int sort_mode;                         /* 0 multi-kernel radix, 1 one workgroup, 2 cooperative kernel while no other handle has a gang kernel in flight (default), 3 cooperative always */
+  int sort_items;                        /* points per wave of the radix passes; 0 = by cloud size */
+  int sort_fused_bits;                   /* two-launch passes (32k..256k points): 10 (default) or 9 key bits per pass, 0 = four-launch passes */
+  int sort_two_pass_max;                 /* clouds up to this size take two 11-bit four-launch passes (262,144) */
+  unsigned long long sort_coop_watchdog_ticks; /* 100 MHz ticks before the cooperative sort gives up and the one-workgroup sort redoes it (2,000,000; 0 = at once: test hook) */
+  /* neighbour search */
+  int knn_nearest_first_max_points;      /* clouds up to this size walk the boxes nearest first (65,536) */
+  int knn_block;                         /* threads per workgroup of the k-NN kernel: 64 (default), 128, 256 */
+  /* voxel map */
+  int coherent_min_points;               /* clouds of this size and up are walked in Morton order (32,768) */
+  int bitmap_min_points;                 /* maps of this size and up get an occupancy bitmap (300,000) */
+  unsigned long long bitmap_max_bytes;   /* its budget (32 MiB) */
+  /* the LM kernel */
+  int persistent;                        /* 1 (default): one launch per align while the problem is latency-bound; 0: one launch per LM transition */
+  unsigned long long persist_watchdog_ticks; /* 100 MHz ticks a hand-off may take before the launch aborts and the align is redone per transition (5,000,000; 0: test hook) */
+  unsigned long long peer_watchdog_ticks;    /* ... for a peer rank's sums (200,000,000) */
+  int lm_everywhere;                     /* 0 never, 1 (default) on grids of at most two workgroups per CU, 2 always: every workgroup runs the LM step itself */
+  int cost_prio;                         /* -1 (default) by grid shape, 0 never, 1 always: s_setprio for the second workgroup of a CU */
+  int cost_split;                        /* 1 (default): wave roles for NDT launches of at most one workgroup per CU */
+  int cost_group_max;                    /* voxel lookups per work item, 1..4 (4) */
+  int cost_max_blocks;                   /* grid cap of a cost launch (1,024) */
+  long long cost_target_items;           /* work items a small problem is split into (131,072) */
+  int zerocopy_result;                   /* 1 (default): the final LM state travels through mapped host memory */
+  int host_wait_block;                   /* 0 (default): the host spins on the result word; 1: it sleeps in hipStreamSynchronize */
+  unsigned long long result_query_spins; /* spins between two hipStreamQuery calls while waiting (1,024) */
+  /* streams and uploads */
+  int side_stream;                       /* 1 (default): swap_source_and_target rebuilds the target map on a second stream */
+  unsigned long long pinned_upload_max;  /* host clouds up to this many bytes go through the handle's pinned staging buffer (8 MiB) */
+  unsigned long long zerocopy_upload_max;/* ... and up to this many are read by the widening kernel straight over PCIe (1 MiB) */
+  /* ApproximateVoxelGrid */
+  int avg_fused;                         /* 1 (default): four launches up to 262,144 points; 0: round 2's six */
+} fvh_engine_params;
+void fvh_default_engine_params(fvh_engine_params* p);
+
 /* ---------------------------------------------------------------------------------------------
  * FastVGICPCudaCore
  * ------------------------------------------------------------------------------------------- */
@@ -87,6 +130,8 @@ int fvh_vgicp_set_kernel_params(fvh_vgicp* h, double kernel_width, double kernel
 /* DIRECT_RADIUS: offsets up to +-511 voxels per axis (they travel packed, 10 bits each); a larger radius is FVH_ERR_INVALID_ARGUMENT */
 int fvh_vgicp_set_neighbor_search_method(fvh_vgicp* h, int method, double radius);           /* [VC]:42, [VCU]:41-94 */
 int fvh_vgicp_set_precision(fvh_vgicp* h, int precision);                                    /* new */
+int fvh_vgicp_get_engine_params(fvh_vgicp* h, fvh_engine_params* out);                       /* new: see fvh_engine_params */
+int fvh_vgicp_set_engine_params(fvh_vgicp* h, const fvh_engine_params* p);
 /* fast_gicp::VoxelAccumulationMode (gicp_settings.hpp:10) of the CPU FastVGICP (setVoxelAccumulationMode, fast_vgicp_impl.hpp:41-43;
  * the CUDA core only has the additive voxel): ADDITIVE / ADDITIVE_WEIGHTED -> AdditiveGaussianVoxel (fast_vgicp_voxel.hpp:105-122),
  * MULTIPLICATIVE -> MultiplicativeGaussianVoxel (:79-103: sum of C^-1 and C^-1 p, inverted at finalize). Takes effect at the next map build. */
@@ -254,6 +299,8 @@ int fvh_ndt_set_distance_mode(fvh_ndt* h, int mode);                            
 int fvh_ndt_set_resolution(fvh_ndt* h, double resolution);                                   /* [NC]:38 */
 int fvh_ndt_set_neighbor_search_method(fvh_ndt* h, int method, double radius);               /* [NC]:39 */
 int fvh_ndt_set_precision(fvh_ndt* h, int precision);
+int fvh_ndt_get_engine_params(fvh_ndt* h, fvh_engine_params* out);
+int fvh_ndt_set_engine_params(fvh_ndt* h, const fvh_engine_params* p);
 int fvh_ndt_swap_source_and_target(fvh_ndt* h);                                              /* [NC]:41, [NCU]:90-93 */
 int fvh_ndt_set_source_cloud(fvh_ndt* h, const float* xyz, int n);                           /* [NC]:42 (invalidates the source voxel map) */
 int fvh_ndt_set_target_cloud(fvh_ndt* h, const float* xyz, int n);                           /* [NC]:43 */
@@ -319,6 +366,8 @@ int fvh_ndt_comm_destroy(fvh_ndt* h);
 typedef struct fvh_voxelgrid fvh_voxelgrid;
 enum fvh_voxelgrid_method { FVH_VOXELGRID_EXACT = 0 /* pcl::VoxelGrid */, FVH_VOXELGRID_APPROXIMATE = 1 /* pcl::ApproximateVoxelGrid */ };
 int fvh_voxelgrid_create(int device, fvh_voxelgrid** out);
+int fvh_voxelgrid_get_engine_params(fvh_voxelgrid* h, fvh_engine_params* out);
+int fvh_voxelgrid_set_engine_params(fvh_voxelgrid* h, const fvh_engine_params* p);
 int fvh_voxelgrid_destroy(fvh_voxelgrid* h);
 const char* fvh_voxelgrid_last_error(const fvh_voxelgrid* h);
 int fvh_voxelgrid_filter(fvh_voxelgrid* h, int method, const float* xyz, int n, float leaf, int* out_n);                       /* setLeafSize(l,l,l); setInputCloud; filter */

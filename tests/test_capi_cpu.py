@@ -2,6 +2,7 @@
 include/fast_vgicp_hip.h declares (no compute calls without a GPU)."""
 import ctypes
 import os
+import sys
 import re
 
 from tests import util
@@ -38,6 +39,26 @@ def test_struct_layouts_match_header(tmp_path):
     assert ctypes.sizeof(capi.LmParams) == c_params == 48
     assert ctypes.sizeof(capi.LmResult) == c_result == 16 * 8 + 36 * 8 + 8 + 6 * 4
     assert capi.LmParams.optimizer.offset == off_opt and capi.LmParams.lm_init_lambda_factor.offset == off_lam and capi.LmResult.converged.offset == off_conv
+    # fvh_engine_params: every field at the compiler's offset, and the defaults (environment untouched here) are the documented ones
+    names = [n for n, _ in capi.EngineParams._fields_]
+    src2 = tmp_path / "ep.c"
+    src2.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "fast_vgicp_hip.h"\nint main(void) { printf("%zu", sizeof(fvh_engine_params));\n'
+                    + "".join('printf(" %%zu", offsetof(fvh_engine_params, %s));\n' % n for n in names) + 'printf("\\n"); return 0; }\n')
+    exe2 = tmp_path / "ep"
+    subprocess.check_call(["gcc", "-I", os.path.join(util.ROOT, "include"), "-o", str(exe2), str(src2)])
+    vals = list(map(int, subprocess.check_output([str(exe2)]).split()))
+    assert ctypes.sizeof(capi.EngineParams) == vals[0]
+    assert [getattr(capi.EngineParams, n).offset for n in names] == vals[1:]
+    hdr = open(os.path.join(util.ROOT, "include", "fast_vgicp_hip.h")).read()
+    body = hdr[hdr.index("typedef struct fvh_engine_params {"):hdr.index("} fvh_engine_params;")]
+    assert re.findall(r"^\s+(?:unsigned long long|long long|int)\s+(\w+);", body, flags=re.M) == names  # the mirror lists the header's fields, in order
+    clean = {k: v for k, v in os.environ.items() if not k.startswith("FVH_") or k == "FVH_LIB_PATH"}
+    out = subprocess.check_output([sys.executable, "-c", "import sys; sys.path.insert(0, %r)\nfrom fast_gicp_amd import capi\np = capi.default_engine_params()\n"
+                                   "print(p.struct_size, p.sort_mode, p.persistent, p.persist_watchdog_ticks, p.cost_group_max, p.cost_target_items, p.coherent_min_points, p.knn_block, p.cost_prio)" % util.ROOT], env=clean)
+    assert out.split() == [str(vals[0]).encode(), b"2", b"1", b"5000000", b"4", b"131072", b"32768", b"64", b"-1"]
+    env = dict(clean, FVH_SORT_MODE="1", FVH_PERSISTENT="0")  # the environment is applied to the DEFAULTS (once per process)
+    out = subprocess.check_output([sys.executable, "-c", "import sys; sys.path.insert(0, %r)\nfrom fast_gicp_amd import capi\np = capi.default_engine_params()\nprint(p.sort_mode, p.persistent)" % util.ROOT], env=env)
+    assert out.split() == [b"1", b"0"]
 
 
 def test_no_gpu_gives_loud_error_not_fallback():
@@ -132,7 +153,8 @@ def test_every_environment_knob_is_documented():
     d = os.path.join(util.ROOT, "fast_gicp_amd", "csrc")
     for f in os.listdir(d):
         src += open(os.path.join(d, f)).read()
-    read = set(re.findall(r'getenv\("(FVH_[A-Z_0-9]+)"\)', src))
+    read = set(re.findall(r'fvh_env(?:_ll|_ull)?\("(FVH_[A-Z_0-9]+)"', src))
+    assert len(re.findall(r"\bgetenv\(", src)) == 1  # ... all of them through the one helper (round 6: fvh_engine_params; VERDICT r5 #9 asked for <= 10 sites)
     doc = open(os.path.join(util.ROOT, "INTEGRATION.md")).read()
     table = doc[doc.index("the complete list"):doc.index("Removed in round 5")]
     named = set(re.findall(r"`(FVH_[A-Z_0-9]+)`", table))
