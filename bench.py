@@ -60,6 +60,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-host-leg", action="store_true", help="skip the host-clouds-in (PCIe-inclusive) repetition of the timed loop")
     ap.add_argument("--no-profile", action="store_true", help="do not bracket the cost kernel with HIP events in the timed region")
+    ap.add_argument("--no-pipelined-leg", action="store_true", help="lidar_stream: skip the pipelined side leg (its LM launches overlap with the next frame's preparation and are slower: "
+                    "a rocprofv3 --stats average over the whole command mixes the two populations, see profiles/README.md)")
     ap.add_argument("--sharded-deadline", type=int, default=240, help="--gpus > 1: seconds the extra spatially-sharded leg may take before it is abandoned")
     ap.add_argument("--streams", type=int, default=4, help="extra leg: S independent engine handles (own HIP streams, host threads) running the same loop concurrently on this GPU")
     ap.add_argument("--cpu-loops", type=int, default=0, help="oracle registrations to time (0 = auto-bound)")
@@ -870,6 +872,8 @@ def run_stream(args, steps, warmup, cpu_loops=15, frames_n=10):
     # Not `value`: kitti.cpp is a sequential loop.
     pipelined = None
     try:
+        if getattr(args, "no_pipelined_leg", False):
+            raise RuntimeError("skipped (--no-pipelined-leg)")
         vg.share_stream(None)
         vg.share_prepare_stream(ndt)
         P = max(steps, 20)
