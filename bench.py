@@ -1216,6 +1216,7 @@ def run_fgicp(args, steps, warmup, local_rank=0):
     roof = None
     if "gicp_nn" in stage:
         roof = valu_roofline("fgicp17k_nn1", "nn1_rows_kernel", stage["gicp_nn"]["avg_us"], n_pts[1], n_pts[0])
+        roof["avg_launch_us"] = stage["gicp_nn"]["avg_us"]
         roof["note"] = "four queries per wave (one per 16-lane row), boxes nearest first; the full-sweep-equivalent rate is what a brute-force N x N kernel would have to sustain"
     c.close()
     return {"metric": "registrations/sec (100-iter reuse), FastGICP (nearest-point correspondences)", "value": round(steps / el, 3), "unit": "registrations/sec", "n_gpus": 1, "steps": steps, "warmup": warmup,
