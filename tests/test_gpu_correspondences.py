@@ -161,3 +161,35 @@ def test_gicp_nearest_point_list_equals_oracle(O, pair, max_dist):
         ref = g.correspondences()[:, [0, 4]]
         assert np.array_equal(got, util.sort_rows(ref))
     c.close()
+
+
+def test_stored_correspondences_survive_a_spatial_order_that_appears_later():
+    """Round 6: on clouds walked in Morton order the correspondence rows are indexed by the element's POSITION in that walk (Engine::corr_by_position).
+    The indexing is decided by the launch that FINDS a list and kept for every later evaluation of it. Here the list is found while the source has no
+    spatial order (rows by point index); then an order appears (fitness_score sorts the source, and the handle's coherent_min_points is lowered so that
+    the cost kernel now walks in it): compute_error must still read the rows the way they were written -- same error, H, b as before -- and the getters
+    still return the same pairs; a list found WITH the order (rows by position) gives the same pairs and sums again."""
+    from fast_gicp_amd import capi
+    tgt, src, T = util.synthetic_pair(20000, 6000, seed=5, extent=30.0)
+    c = capi.VGICPCore(0)
+    c.set_resolution(0.5); c.set_neighbor_search_method(capi.DIRECT7)
+    c.set_engine_params(coherent_min_points=1 << 30)  # nothing walks in Morton order yet
+    c.set_target_cloud(tgt); c.set_target_covariances(np.tile(np.eye(3) * 0.01, (len(tgt), 1, 1))); c.create_target_voxelmap()
+    c.set_source_cloud(src); c.set_source_covariances(np.tile(np.eye(3) * 0.01, (len(src), 1, 1)))
+    c.update_correspondences(T)                       # found without an order: rows by point index
+    e0, H0, b0 = c.compute_error(T)
+    pairs0 = c.get_voxel_correspondences().copy()
+    assert len(pairs0) > 1000
+    c.set_engine_params(coherent_min_points=1000)
+    c.fitness_score(T)                                # sorts the source: from here on the cost kernel walks it in Morton order
+    e1, H1, b1 = c.compute_error(T)
+    assert abs(e1 - e0) <= 1e-12 * abs(e0) and util.rel_err(H1, H0) < 1e-12 and util.rel_err(b1, b0) < 1e-11  # (another summation order)
+    assert np.array_equal(c.get_voxel_correspondences(), pairs0)
+    c.update_correspondences(T)                       # found again, now WITH the order: rows by position
+    e2, H2, b2 = c.compute_error(T)
+    assert abs(e2 - e0) <= 1e-12 * abs(e0) and util.rel_err(H2, H0) < 1e-12
+    assert np.array_equal(c.get_voxel_correspondences(), pairs0)
+    r = c.align(T)
+    assert r["converged"]
+    assert len(c.get_voxel_correspondences()) == c.get_num_correspondences() > 1000
+    c.close()

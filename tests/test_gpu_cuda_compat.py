@@ -364,3 +364,41 @@ def test_vgicp_cuda_compat_voxel_sums_on_injected_covariances(O):
         assert np.array_equal(od[k][1], ed[k][1]), (k, od[k][1], ed[k][1])
         assert np.array_equal(od[k][2], ed[k][2]), (k, od[k][2], ed[k][2])
     c.close()
+
+
+@pytest.mark.parametrize("resolution", [0.3, 0.7])
+def test_cuda_compat_voxel_coordinates_are_float_at_a_resolution_that_is_not_a_power_of_two(O, resolution):
+    """vector3_hash.cuh:35-38 computes the voxel coordinate in FLOAT: (x / resolution - 0.5).floor(). At resolutions 1.0 / 0.5 that equals the fp64
+    coordinate of the CPU class for every float x; at 0.3 or 0.7 points within float rounding of a voxel face land in the neighbouring voxel.
+    FVH_COMPUTE_CUDA_COMPAT takes the float coordinate in the map build AND in the lookups: voxel sets, counts and the correspondence list equal the
+    cuda-compat oracle's exactly; the fp64 engine on the same data differs from them in a few voxels (the test is not vacuous)."""
+    from fast_gicp_amd import capi
+    rng = np.random.default_rng(5)
+    tgt, src = util.bundled_pair()
+    # many points EXACTLY on voxel faces in fp64 terms (multiples of the resolution plus half a voxel), where float and double division disagree most often
+    faces = (np.round(rng.uniform(-60, 60, size=(4000, 3)) / resolution) * resolution + 0.5 * resolution).astype(np.float32)
+    tgt = np.vstack([tgt, faces]).astype(np.float32)
+    src = np.vstack([src, faces[::2] + np.float32(1e-3)]).astype(np.float32)
+    g = O.CudaCompatVGICP(search=O.DIRECT7, resolution=resolution)
+    g.set_target(tgt); g.set_source(src); g.prepare()
+
+    def engine(precision):
+        c = capi.VGICPCore(0)
+        c.set_precision(precision); c.set_resolution(resolution); c.set_neighbor_search_method(capi.DIRECT7)
+        c.set_target_cloud(tgt); c.set_source_cloud(src)
+        c.set_target_covariances(g.get_covs("target")); c.set_source_covariances(g.get_covs("source"))
+        c.create_target_voxelmap()
+        return c
+    c = engine(capi.COMPUTE_CUDA_COMPAT)
+    oc, on, om, _ = g.get_voxelmap()
+    ec, en, em, _ = c.get_voxelmap()
+    assert util.voxel_dict(ec, en) == util.voxel_dict(oc, on)
+    od, ed = util.voxel_dict(oc, om.astype(np.float32)), util.voxel_dict(ec, em.astype(np.float32))
+    assert all(np.array_equal(od[k][0], ed[k][0]) for k in od)  # float sums in point order: the means bit for bit
+    T = util.random_pose(np.random.default_rng(9), max_angle_deg=1.0, max_trans=0.3)
+    g.linearize(T); c.linearize(T)
+    util.assert_same_correspondences(c, g, ordered=True)
+    c64 = engine(capi.COMPUTE_FP64)
+    dc, dn, _, _ = c64.get_voxelmap()
+    assert util.voxel_dict(dc, dn) != util.voxel_dict(oc, on), "the fp64 coordinate gave the same voxels: this data does not exercise the difference"
+    c.close(); c64.close()
