@@ -6,7 +6,7 @@
 // Float sums depend on their ORDER. The reference does not fix one (gaussian_voxelmap.cu:89-148 accumulates with atomicAdd in arrival
 // order; covariance_estimation_rbf.cu walks blocks of 512 candidates on one thread each and adds the block partials in block order, which
 // IS fixed). This mode takes the order of the oracle leg, which is the order of a sequential run of the reference's kernels: candidates and
-// points in INDEX order. A different order moves the result by what tests/test_gpu_cuda_compat.py::test_cuda_compat_order_spread
+// points in INDEX order. A different order moves the result by what tests/test_oracle.py::test_cuda_compat_order_spread
 // measures on the oracle leg itself.
 //
 // This mode is about parity, not speed: one thread per (query, block phase) / per voxel, sequential float sums.
@@ -109,7 +109,7 @@ __global__ __launch_bounds__(256) void cov_rbf_cuda_compat_kernel(const float4* 
 // kernels (kernels_voxelmap.hpp) with the voxel coordinate computed in float (vector3_hash.cuh:35-38); this pass then REPLACES the
 // mean / covariance of every voxel record by the float result:
 //   1. vmc_point_bucket_kernel: the bucket of every point (probe of the finished key table) as a sort key, original index as payload;
-//   2. a stable LSD radix sort of (bucket, index) -- radix_sort_pairs of fvh_capi.hip -- groups a voxel's points, index order kept;
+//   2. a stable LSD radix sort of (bucket, index) -- radix_sort_pairs of host_downsample.inc.hpp -- groups a voxel's points, index order kept;
 //   3. vmc_segment_heads_kernel: where each bucket's run starts;
 //   4. vmc_finalize_kernel: one thread per voxel walks its run and accumulates in float, then finalises as the reference does.
 // ------------------------------------------------------------------------------------------------

@@ -1,5 +1,5 @@
 """swap_source_and_target() right after an align builds the new target map on the engine's side stream, beside the caller's
-next source chain (fvh_capi.hip: Engine::side). The map, the poses and every getter must be what the one-stream order gives, and
+next source chain (fvh_capi.hip: Engine). The map, the poses and every getter must be what the one-stream order gives, and
 any call that is not part of the source chain must wait for the build."""
 import os
 import subprocess

@@ -60,7 +60,7 @@ def test_order_is_a_stable_morton_sort_and_tiles_are_boxed(n, key_bits, sorted_b
 def test_cooperative_sort_is_kept_unless_another_handle_has_a_gang_kernel_in_flight():
     """The one-launch cooperative sort is a gang kernel (32 co-resident workgroups): it is skipped while ANOTHER registration handle of the
     process has a gang kernel IN FLIGHT -- marked at launch under a process-wide lock, in flight until the event recorded behind it has
-    fired or that handle's align / synchronize has returned (fvh_capi.hip: GangRegistry; round 4 guessed with a 20 ms wall-clock window).
+    fired or that handle's align / synchronize has returned (csrc/host_runtime.inc.hpp: GangRegistry; round 4 guessed with a 20 ms wall-clock window).
     A second handle that merely exists (the reference's align.cpp keeps its NDT object alive while the VGICP rows run) or that the same
     thread uses in turn must not cost the first one its fast sort (it did: +38 us per registration in apps/gicp_align)."""
     from fast_gicp_amd import capi, preprocess
