@@ -152,7 +152,8 @@ def test_device_lm_align_matches_oracle_and_the_host_loop(O, pair, max_dist):
     c.close()
 
 
-@pytest.mark.parametrize("ns, nt", [(1, 1), (15, 64), (17, 65), (63, 64), (65, 129), (5000, 7001), (20000, 100000), (3000, 300000)])
+@pytest.mark.parametrize("ns, nt", [(1, 1), (15, 64), (17, 65), (63, 64), (65, 129), (5000, 7001), (20000, 100000), (3000, 300000),
+                                    (2000, 1100000)])  # (more than 256 super tiles: the chunk loop of the box walk)
 def test_row_per_query_nearest_neighbour_search_is_exact(O, ns, nt):
     """nn1_rows_kernel (round 6: four queries per wave, one per 16-lane row, boxes visited nearest first) against the definition: the nearest
     target point of every transformed source point in the total order (fp32 (dx dx + dy dy) + dz dz without contraction, ORIGINAL index) --
