@@ -60,7 +60,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-host-leg", action="store_true", help="skip the host-clouds-in (PCIe-inclusive) repetition of the timed loop")
     ap.add_argument("--no-profile", action="store_true", help="do not bracket the cost kernel with HIP events in the timed region")
-    ap.add_argument("--no-pipelined-leg", action="store_true", help="lidar_stream: skip the pipelined side leg (its LM launches overlap with the next frame's preparation and are slower: "
+    ap.add_argument("--no-pipelined-leg", action="store_true", help="skip the pipelined side legs (bundled17k / synth100k: fvh_vgicp_prepare_source_device beside the LM kernel; lidar_stream: the two-stage frame pipeline; their LM launches overlap with the next frame's preparation and are slower: "
                     "a rocprofv3 --stats average over the whole command mixes the two populations, see profiles/README.md)")
     ap.add_argument("--sharded-deadline", type=int, default=240, help="--gpus > 1: seconds the extra spatially-sharded leg may take before it is abandoned")
     ap.add_argument("--streams", type=int, default=4, help="extra leg: S independent engine handles (own HIP streams, host threads) running the same loop concurrently on this GPU")
@@ -170,7 +170,7 @@ def _compact_config(c):
         out["cpu_baseline"] = {"value": cb["value"], "cores": cb.get("cores"), "kind": cb.get("kind")}
     p = c.get("pipelined")
     if isinstance(p, dict):
-        out["pipelined"] = p.get("registrations_per_sec", _short(p.get("error"), 80))
+        out["pipelined"] = p.get("registrations_per_sec", p.get("value", _short(p.get("error"), 80)))
     return out
 
 
@@ -193,6 +193,9 @@ def compact_line(detail):
     if isinstance(d.get("host_clouds_in"), dict):
         out["host_clouds_in"] = {k: d["host_clouds_in"].get(k) for k in ("value", "ms_per_step")}
         optional.append("host_clouds_in")
+    if isinstance(d.get("pipelined"), dict) and "value" in d["pipelined"]:
+        out["pipelined"] = {k: d["pipelined"].get(k) for k in ("value", "ms_per_step")}
+        optional.append("pipelined")
     if isinstance(d.get("n1_same_workload"), dict):
         out["n1_same_workload"] = {k: d["n1_same_workload"].get(k) for k in ("value", "ms_per_step", "steps")}
     if isinstance(d.get("replicas_17k"), dict):
@@ -1077,6 +1080,52 @@ def run_registration(args, workload, cov, search_name, steps, warmup, local_rank
         host_leg = {"value": round(steps / el_h, 3), "unit": "registrations/sec", "ms_per_step": round(el_h / steps * 1e3, 5),
                     "note": "same loop, source cloud handed over as a HOST buffer every registration (fvh_vgicp_set_source_cloud: %d bytes copied into the handle's pinned staging buffer and read from there by the widening kernel over PCIe), as src/align.cpp:94-96 does"
                             % (n_pts[1] * 12)}
+    # ---- the same loop as a two-stage pipeline: the next source (sort, k-NN, covariances, its voxel map) is prepared on the handle's
+    #      second stream beside the running LM kernel (fvh_vgicp_prepare_source_device / align_async / align_wait); never `value` ----
+    pipelined_leg = None
+    if not args.no_pipelined_leg and world == 1 and workload != "synth1m" and cov in ("knn", "rbf"):
+        rbf = cov == "rbf"
+        PSTAGES = int(os.environ.get("BENCH_PIPE_STAGES", "2"))
+        seq_T = {}
+        for _ in range(2):  # what the sequential loop finds, per direction of the pair
+            step()
+            seq_T[1 - state["next"]] = state["last"]["T"]
+
+        def pstep():
+            i = state["next"]  # the cloud that becomes the source next = the one that is the target now
+            core.align_async()
+            core.prepare_source_device(d_ptrs[i], n_pts[i], 3, K, capi.REG_PLANE, rbf, PSTAGES)
+            state["last"] = core.align_wait()
+            core.swap_source_and_target()
+            core.adopt_prepared_source()
+            if PSTAGES < 2:
+                cloud_of["source"] = i
+                (core.calculate_source_covariances_rbf if rbf else core.calculate_source_covariances)(capi.REG_PLANE)
+            state["next"] = 1 - i
+        for _ in range(max(4, warmup)):
+            pstep()
+        core.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(steps):
+            pstep()
+        core.synchronize()
+        el_p = time.perf_counter() - t1
+        dev_T = max(float(np.abs(state["last"]["T"] - seq_T[state["next"]]).max()), 0.0)  # (the align that just finished registered cloud `next` as the source)
+        pipelined_leg = {"value": round(steps / el_p, 3), "unit": "registrations/sec", "ms_per_step": round(el_p / steps * 1e3, 5),
+                         "max_abs_pose_difference_to_the_sequential_loop": dev_T, "persist_aborts": core.debug_persist_aborts(),
+                         "prepared_stages": PSTAGES,
+                         "note": "the same work per registration as `value` (one cloud sorted / searched / covariances, one voxel map, one align): the preparation of scan k+1 "
+                                 "(fvh_vgicp_prepare_source_device, stages: 1 order + neighbours, 2 + covariances, 3 + its voxel map) runs on the handle's second stream "
+                                 "beside the LM kernel of scan k; one host thread. Never `value`."}
+        # back to the sequential state the legs below expect: target = cloud 0 (map built), source = cloud 1
+        core.set_target_cloud_device(d_ptrs[0], n_pts[0], 3)
+        cloud_of["target"], cloud_of["source"] = 0, 1
+        estimate_cov("target")
+        core.create_target_voxelmap()
+        core.set_source_cloud_device(d_ptrs[1], n_pts[1], 3)
+        estimate_cov("source")
+        state["last"] = core.align()
+        state["next"] = 0
     if rank != 0:
         core.close()
         return None
@@ -1156,6 +1205,7 @@ def run_registration(args, workload, cov, search_name, steps, warmup, local_rank
         "per_registration": {"linearize": n_lin / n_regs, "error_evals": n_err / n_regs, "kernel_launches_lm": n_launch / n_regs, "converged": bool(state["last"]["converged"]),
                              "persistent_launches_aborted_by_watchdog": core.debug_persist_aborts()},
         "host_clouds_in": host_leg,
+        "pipelined": pipelined_leg,
         "roofline": roofline, "cpu_baseline": cpu_res, "stages": stage_ms, "profiled_timed_region": ("every %dth registration" % PROFILE_EVERY) if profile else False,
     }
     if conc is not None:

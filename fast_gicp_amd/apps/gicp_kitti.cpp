@@ -2,7 +2,7 @@
 // frames %06d.bin (x, y, z, intensity as float32, kitti.cpp:22-69) -> ApproximateVoxelGrid 0.25 ON THE DEVICE (the raw
 // xyzi buffer goes to the GPU as it is) -> setInputSource -> align -> swapSourceAndTarget -> pose accumulation; prints the
 // running frame rate and writes the trajectory in KITTI format (12 values per line, kitti.cpp:141-153).
-//   usage: gicp_kitti /path/to/sequences/00/velodyne [ndt|ndt_pipelined|vgicp|gicp] [trajectory.txt]
+//   usage: gicp_kitti /path/to/sequences/00/velodyne [ndt|ndt_pipelined|vgicp|vgicp_pipelined|gicp] [trajectory.txt]
 // ndt_pipelined: the same loop as a two-stage pipeline -- while the LM kernel of frame k runs, frame k+1 is read, filtered on the handle's
 // second stream and its voxel map built there (NDTCuda::alignAsync / prepareNextSourceDevice / adoptPreparedSource / alignWait).
 #include <chrono>
@@ -73,7 +73,7 @@ static void write_trajectory(const std::string& traj_path, const std::vector<Iso
 
 int main(int argc, char** argv) {
   if (argc < 2) {
-    std::cout << "usage: gicp_kitti /your/kitti/path/sequences/00/velodyne [ndt|ndt_pipelined|vgicp|gicp] [trajectory.txt]" << std::endl;
+    std::cout << "usage: gicp_kitti /your/kitti/path/sequences/00/velodyne [ndt|ndt_pipelined|vgicp|vgicp_pipelined|gicp] [trajectory.txt]" << std::endl;
     return 0;
   }
   const std::string method = argc > 2 ? argv[2] : "gicp";  // the reference's default is FastGICP (kitti.cpp:85)
@@ -130,6 +130,41 @@ int main(int argc, char** argv) {
       std::cout << stamps.size() / (std::chrono::duration_cast<std::chrono::nanoseconds>(stamps.back() - stamps.front()).count() / 1e9) << "fps" << std::endl;
     }
     detail::check(fvh_voxelgrid_share_stream_with_ndt(vg, nullptr), "share_stream", fvh_voxelgrid_last_error(vg));
+    fvh_voxelgrid_destroy(vg);
+    write_trajectory(traj_path, poses);
+    return 0;
+  }
+
+  if (method == "vgicp_pipelined") {  // the same loop with FastVGICPCuda (kitti.cpp:88, the commented alternative): order, neighbours, covariances of scan k+1 beside the LM kernel of scan k
+    FastVGICPCuda<PointXYZ, PointXYZ> vgicp;
+    vgicp.setResolution(1.0);
+    vgicp.setNearestNeighborSearchMethod(NearestNeighborMethod::GPU_BRUTEFORCE);
+    vgicp.setInputTarget(downsample_on_device(vg, kitti.frame(0), downsample_resolution));
+    detail::check(fvh_voxelgrid_share_prepare_stream_with_vgicp(vg, vgicp.core()), "share_prepare_stream", fvh_voxelgrid_last_error(vg));
+    auto prepare = [&](size_t i) {
+      const std::vector<float> xyzi = kitti.frame(i);
+      int n = 0;
+      const float* d_xyz = nullptr;
+      detail::check(fvh_voxelgrid_filter_strided(vg, FVH_VOXELGRID_APPROXIMATE, xyzi.data(), (int)(xyzi.size() / 4), 4, downsample_resolution, &n), "fvh_voxelgrid_filter_strided", fvh_voxelgrid_last_error(vg));
+      detail::check(fvh_voxelgrid_device_points(vg, &d_xyz, &n), "fvh_voxelgrid_device_points", fvh_voxelgrid_last_error(vg));
+      vgicp.prepareNextSourceDevice(d_xyz, n, 3);
+    };
+    std::vector<Isometry3d> poses(kitti.size());
+    poses[0] = Isometry3d::Identity();
+    std::deque<std::chrono::high_resolution_clock::time_point> stamps;
+    stamps.push_back(std::chrono::high_resolution_clock::now());
+    if (kitti.size() > 1) { prepare(1); vgicp.adoptPreparedSource(); }
+    for (size_t i = 1; i < kitti.size(); i++) {
+      vgicp.alignAsync();
+      if (i + 1 < kitti.size()) prepare(i + 1);  // beside the running LM kernel
+      poses[i] = poses[i - 1] * Isometry3d::from(vgicp.alignWait());
+      vgicp.swapSourceAndTarget();
+      if (i + 1 < kitti.size()) vgicp.adoptPreparedSource();
+      stamps.push_back(std::chrono::high_resolution_clock::now());
+      if (stamps.size() > 30) stamps.pop_front();
+      std::cout << stamps.size() / (std::chrono::duration_cast<std::chrono::nanoseconds>(stamps.back() - stamps.front()).count() / 1e9) << "fps" << std::endl;
+    }
+    detail::check(fvh_voxelgrid_share_stream_with_vgicp(vg, nullptr), "share_stream", fvh_voxelgrid_last_error(vg));
     fvh_voxelgrid_destroy(vg);
     write_trajectory(traj_path, poses);
     return 0;

@@ -295,6 +295,26 @@ class VGICPCore(_Core):
     """fast_gicp::cuda::FastVGICPCudaCore on the HIP engine (same method names, snake_case as in the .cuh)."""
     _prefix = "fvh_vgicp_"
 
+    # ---- pipelined scan streams (include/fast_vgicp_hip.h: fvh_vgicp_align_async ...) ----
+    def align_async(self, guess=None, **lm):
+        """Launch the LM kernel and return; align_wait() collects the result. In between only prepare_source_device() may be used."""
+        self._g = _colmajor16(np.eye(4) if guess is None else guess)
+        self._lm = _lm_params(**lm)
+        self._call("align_async", _p(self._g), C.byref(self._lm))
+
+    def align_wait(self):
+        r = LmResult()
+        self._call("align_wait", C.byref(r))
+        return _result_dict(r)
+
+    def prepare_source_device(self, ptr, n, stride=3, k=20, regularization=REG_PLANE, rbf=False, stages=3):
+        """The NEXT source cloud (device pointer) into the prepared slot, on the handle's second stream: Morton sort, exact k-NN + covariances
+        (or RBF covariances), and the scan's own voxel map -- beside whatever runs on the main stream."""
+        self._call("prepare_source_device", C.c_void_p(ptr), int(n), int(stride), int(k), int(regularization), 1 if rbf else 0, int(stages))
+
+    def adopt_prepared_source(self):
+        self._call("adopt_prepared_source")
+
     # ---- multi-GPU through peer-mapped exchange regions (no RCCL) ----
     def peer_export(self, max_points):
         """-> (64-byte IPC handle, raw device pointer of the region)"""
@@ -543,10 +563,13 @@ class VoxelGrid:
         else:
             self._check(self._lib.fvh_voxelgrid_share_stream_with_vgicp(self._h, core.h), "fvh_voxelgrid_share_stream_with_vgicp")
 
-    def share_prepare_stream(self, ndt):
-        """Run this filter on the SECOND stream of an NDTCore (the one prepare_source_device works on): the next frame is filtered
-        beside the LM kernel of the current one."""
-        self._check(self._lib.fvh_voxelgrid_share_prepare_stream_with_ndt(self._h, ndt.h), "fvh_voxelgrid_share_prepare_stream_with_ndt")
+    def share_prepare_stream(self, core):
+        """Run this filter on the SECOND stream of an NDTCore / VGICPCore (the one prepare_source_device works on): the next frame is
+        filtered beside the LM kernel of the current one."""
+        if isinstance(core, NDTCore):
+            self._check(self._lib.fvh_voxelgrid_share_prepare_stream_with_ndt(self._h, core.h), "fvh_voxelgrid_share_prepare_stream_with_ndt")
+        else:
+            self._check(self._lib.fvh_voxelgrid_share_prepare_stream_with_vgicp(self._h, core.h), "fvh_voxelgrid_share_prepare_stream_with_vgicp")
 
     def filter_device(self, d_ptr, n, leaf, method=APPROXIMATE, stride=3, asynchronous=False):
         """Device pointer in (n points, `stride` floats apart); returns (device pointer to packed xyz, count) valid until the next filter call.

@@ -129,6 +129,7 @@ struct Engine {
   DevBuf gather_stage;  // RCCL route: covariances of the whole cloud in Morton order (ncclAllGather in place)
   hipStream_t side = nullptr;
   hipEvent_t side_done = nullptr;
+  bool async_in_flight = false;    // fvh_vgicp_align_async .. _align_wait: the handle's clouds, map and LM state belong to the running kernel
   bool side_pending = false;       // a build on `side` the main stream has not been ordered after yet
   bool quiet = false, was_quiet = false;  // the main stream had drained when the current API call began (set by align on return)
   hipStream_t side_stream() {
@@ -254,10 +255,13 @@ struct Engine {
     gang_launching.fetch_add(1, std::memory_order_acq_rel);
     return true;
   }
+  bool gang_keep_event = false;  // fvh_vgicp_prepare_source_device beside an LM kernel in flight: `gang_done` keeps describing that kernel (the longer one)
   void gang_end() {  // the gang kernel (and whatever must follow it) is queued
     if (!counted) return;
-    (void)hipEventRecord(gang_done, stream);
-    gang_open.store(true, std::memory_order_release);
+    if (!gang_keep_event) {
+      (void)hipEventRecord(gang_done, stream);
+      gang_open.store(true, std::memory_order_release);
+    }
     gang_launching.fetch_sub(1, std::memory_order_acq_rel);
   }
   void gang_clear() { if (counted) gang_open.store(false, std::memory_order_release); }  // the caller holds the result of an align / drained the stream: nothing of this handle is in flight
@@ -376,6 +380,18 @@ struct fvh_vgicp {
   VoxelMapDev voxelmap;
   VoxelMapDev gicp_records;  // per-target-point records for the nearest-point (GICP) cost
   double gicp_max_dist = 3.4028234663852886e38;
+  // Pipelined scan streams (fvh_vgicp_prepare_source_device / _adopt_prepared_source / _align_async / _align_wait): the NEXT source cloud -- its
+  // Morton order, neighbour lists, covariances AND its own voxel map, which swap_source_and_target() needs one registration later -- is
+  // prepared in `next_source` / `next_map` on the handle's second stream (Engine::side) while the LM kernel of the current pair runs on the
+  // main one. `source_map` is the map that came with the adopted source: swap_source_and_target() then swaps maps instead of building one.
+  CloudDev next_source;
+  VoxelMapDev next_map, source_map;
+  bool next_ready = false;
+  hipEvent_t prep_done = nullptr;
+  AlignCtx pending;
+  void source_changed() { source_map.invalidate(); }
+  bool live_map_stale = false;  // the target's covariances changed after `voxelmap` was built (legal: the map stays as built until create_target_voxelmap -- but it must not be carried over a swap)
+  void map_rules_changed() { source_map.invalidate(); next_map.invalidate(); next_ready = false; }  // accumulation mode / precision: prepared maps were built under the old rule
   CostSource cost_source() const {
     // multi-GPU: the tiles are ranges of the Morton order whatever the size of the cloud (spatially compact shards)
     const int* order = e.sharded() ? (source.has_sorted ? source.order.as<int>() : nullptr) : coherent_order(source, e.params.coherent_min_points);
@@ -396,6 +412,7 @@ struct fvh_vgicp {
   int shard_margin = 2;      // voxels of pose motion the halo allows for on top of the reach of the neighbour offsets
   int shard_fallbacks = 0;   // aligns redone on the full map because a source element left the shard's inner box
   int build_map(double res, bool force_safe = false, hipStream_t on_side = nullptr, bool shard = false) {
+    live_map_stale = false;
     return voxel_mode == 2 ? build_voxelmap<2>(&e, target, voxelmap, res, false, force_safe, on_side, shard) : build_voxelmap<0>(&e, target, voxelmap, res, false, force_safe, on_side, shard);
   }
   Rebuild rebuild_safe() { return [this] { return build_map(voxelmap.res, true, nullptr, voxelmap.is_shard); }; }
@@ -470,6 +487,7 @@ struct fvh_voxelgrid {
 #define CHECK_HANDLE_SOURCE_CHAIN(h) \
   if (!(h)) return FVH_ERR_INVALID_ARGUMENT; \
   { hipError_t _e = hipSetDevice((h)->e.device); if (_e != hipSuccess) return (h)->e.hipfail(_e, "hipSetDevice"); } \
+  if ((h)->e.async_in_flight) return (h)->e.fail(FVH_ERR_BAD_STATE, "an align_async is in flight: call fvh_vgicp_align_wait first"); \
   (h)->e.was_quiet = (h)->e.quiet; (h)->e.quiet = false;
 // CHECK_HANDLE_HOST_ONLY: plain host-side setters that queue nothing: they leave the engine's stream bookkeeping alone.
 #define CHECK_HANDLE_HOST_ONLY(h) \
@@ -515,7 +533,9 @@ int fvh_vgicp_destroy(fvh_vgicp* h) {
   h->e.deferred = nullptr;
   if (h->e.side) (void)hipStreamSynchronize(h->e.side);
   if (h->e.stream) (void)hipStreamSynchronize(h->e.stream);
-  h->source.release(); h->target.release(); h->voxelmap.release(); h->gicp_records.release();
+  if (h->pending.active) { h->pending.release_slots(); h->pending.active = false; }
+  h->source.release(); h->target.release(); h->voxelmap.release(); h->gicp_records.release(); h->next_source.release(); h->next_map.release(); h->source_map.release();
+  if (h->prep_done) (void)hipEventDestroy(h->prep_done);
   h->e.shutdown();
   delete h;
   return FVH_OK;
@@ -527,7 +547,7 @@ int fvh_vgicp_set_neighbor_search_method(fvh_vgicp* h, int m, double radius) { C
 int fvh_vgicp_set_precision(fvh_vgicp* h, int p) {
   CHECK_HANDLE(h);
   if (p != FVH_COMPUTE_FP64 && p != FVH_COMPUTE_FP32 && p != FVH_COMPUTE_CUDA_COMPAT) return h->e.fail(FVH_ERR_INVALID_ARGUMENT, "bad precision");
-  if ((p == FVH_COMPUTE_CUDA_COMPAT) != (h->e.precision == FVH_COMPUTE_CUDA_COMPAT)) { h->voxelmap.invalidate(); h->e.has_corr = false; }  // the voxel records of the two arithmetics differ (kernels_compat.hpp)
+  if ((p == FVH_COMPUTE_CUDA_COMPAT) != (h->e.precision == FVH_COMPUTE_CUDA_COMPAT)) { h->voxelmap.invalidate(); h->map_rules_changed(); h->e.has_corr = false; }  // the voxel records of the two arithmetics differ (kernels_compat.hpp)
   h->e.precision = p;
   return FVH_OK;
 }
@@ -539,7 +559,7 @@ int fvh_vgicp_create_target_voxelmap(fvh_vgicp* h) { CHECK_HANDLE(h); return h->
 int fvh_vgicp_set_voxel_accumulation_mode(fvh_vgicp* h, int mode) {
   CHECK_HANDLE(h);
   if (mode < 0 || mode > 2) return h->e.fail(FVH_ERR_INVALID_ARGUMENT, "unknown voxel accumulation mode");
-  if (mode != h->voxel_mode) { h->voxelmap.invalidate(); h->e.has_corr = false; }
+  if (mode != h->voxel_mode) { h->voxelmap.invalidate(); h->map_rules_changed(); h->e.has_corr = false; }
   h->voxel_mode = mode;
   return FVH_OK;
 }
@@ -583,7 +603,12 @@ int fvh_vgicp_swap_source_and_target(fvh_vgicp* h) {
   CHECK_HANDLE(h);
   h->source.swap(h->target);
   h->e.has_corr = false;
+  std::swap(h->voxelmap, h->source_map);   // (the map of the old target stays with its cloud, now the source ...
+  if (h->live_map_stale) h->source_map.invalidate();  // ... unless that cloud's covariances changed after the map was built)
+  h->live_map_stale = false;
   if (!h->target.has_pts || !h->target.has_cov) { h->voxelmap.invalidate(); return FVH_OK; }  // fast_vgicp_cuda.cu:102-104
+  // the new target came through the prepared-source slot with its own voxel map (built beside an earlier LM kernel): nothing to build
+  if (h->voxelmap.valid && !h->voxelmap.is_shard && h->voxelmap.res == h->resolution) return FVH_OK;
   // the stream had drained (the caller holds the result of an align): the new target's points and covariances are complete, and
   // the build can run on the side stream while the caller prepares the next source cloud on the main one
   if (h->e.was_quiet && h->e.side_stream()) {
@@ -599,6 +624,7 @@ int fvh_vgicp_gicp_swap_source_and_target(fvh_vgicp* h) {  // FastGICP::swapSour
   h->source.swap(h->target);
   h->e.has_corr = false;
   h->voxelmap.invalidate();
+  h->source_map.invalidate();
   return FVH_OK;
 }
 static void cloud_replaced(CloudDev& c) { c.has_cov = false; c.has_nbr = false; c.has_cov_sorted = false; }
@@ -610,22 +636,22 @@ static int uploaded(Engine* e, CloudDev& c, int rc) {
   if (!e->device_search_seen && !e->sharded() && c.n < e->params.coherent_min_points) return FVH_OK;  // nobody may ever need the order: it stays lazy (ensure_sorted where it is consumed)
   return ensure_sorted(e, c);
 }
-int fvh_vgicp_set_source_cloud(fvh_vgicp* h, const float* xyz, int n) { CHECK_HANDLE_SOURCE_CHAIN(h); h->e.has_corr = false; cloud_replaced(h->source); return uploaded(&h->e, h->source, upload_cloud(&h->e, h->source, xyz, n, 3, false)); }
+int fvh_vgicp_set_source_cloud(fvh_vgicp* h, const float* xyz, int n) { CHECK_HANDLE_SOURCE_CHAIN(h); h->e.has_corr = false; cloud_replaced(h->source); h->source_changed(); return uploaded(&h->e, h->source, upload_cloud(&h->e, h->source, xyz, n, 3, false)); }
 int fvh_vgicp_set_target_cloud(fvh_vgicp* h, const float* xyz, int n) { CHECK_HANDLE(h); h->e.has_corr = false; h->voxelmap.invalidate(); h->gicp_records.invalidate(); cloud_replaced(h->target); return uploaded(&h->e, h->target, upload_cloud(&h->e, h->target, xyz, n, 3, false)); }
-int fvh_vgicp_set_source_cloud_strided(fvh_vgicp* h, const float* xyz, int n, int stride) { CHECK_HANDLE_SOURCE_CHAIN(h); h->e.has_corr = false; cloud_replaced(h->source); return uploaded(&h->e, h->source, upload_cloud(&h->e, h->source, xyz, n, stride, false)); }
+int fvh_vgicp_set_source_cloud_strided(fvh_vgicp* h, const float* xyz, int n, int stride) { CHECK_HANDLE_SOURCE_CHAIN(h); h->e.has_corr = false; cloud_replaced(h->source); h->source_changed(); return uploaded(&h->e, h->source, upload_cloud(&h->e, h->source, xyz, n, stride, false)); }
 int fvh_vgicp_set_target_cloud_strided(fvh_vgicp* h, const float* xyz, int n, int stride) { CHECK_HANDLE(h); h->e.has_corr = false; h->voxelmap.invalidate(); h->gicp_records.invalidate(); cloud_replaced(h->target); return uploaded(&h->e, h->target, upload_cloud(&h->e, h->target, xyz, n, stride, false)); }
-int fvh_vgicp_set_source_cloud_device(fvh_vgicp* h, const float* d, int n, int stride) { CHECK_HANDLE_SOURCE_CHAIN(h); h->e.has_corr = false; cloud_replaced(h->source); return uploaded(&h->e, h->source, upload_cloud(&h->e, h->source, d, n, stride, true)); }
+int fvh_vgicp_set_source_cloud_device(fvh_vgicp* h, const float* d, int n, int stride) { CHECK_HANDLE_SOURCE_CHAIN(h); h->e.has_corr = false; cloud_replaced(h->source); h->source_changed(); return uploaded(&h->e, h->source, upload_cloud(&h->e, h->source, d, n, stride, true)); }
 int fvh_vgicp_set_target_cloud_device(fvh_vgicp* h, const float* d, int n, int stride) { CHECK_HANDLE(h); h->e.has_corr = false; h->voxelmap.invalidate(); h->gicp_records.invalidate(); cloud_replaced(h->target); return uploaded(&h->e, h->target, upload_cloud(&h->e, h->target, d, n, stride, true)); }
 int fvh_vgicp_set_source_neighbors(fvh_vgicp* h, int k, const int* idx) { CHECK_HANDLE(h); return set_neighbors(&h->e, h->source, k, idx); }
 int fvh_vgicp_set_target_neighbors(fvh_vgicp* h, int k, const int* idx) { CHECK_HANDLE(h); return set_neighbors(&h->e, h->target, k, idx); }
 int fvh_vgicp_find_source_neighbors(fvh_vgicp* h, int k) { CHECK_HANDLE_SOURCE_CHAIN(h); return h->e.after_source_chain_call(find_neighbors(&h->e, h->source, k)); }
 int fvh_vgicp_find_target_neighbors(fvh_vgicp* h, int k) { CHECK_HANDLE(h); return find_neighbors(&h->e, h->target, k); }
-int fvh_vgicp_calculate_source_covariances(fvh_vgicp* h, int m) { CHECK_HANDLE_SOURCE_CHAIN(h); return h->e.after_source_chain_call(calc_cov_knn(&h->e, h->source, m)); }
-int fvh_vgicp_calculate_target_covariances(fvh_vgicp* h, int m) { CHECK_HANDLE(h); return calc_cov_knn(&h->e, h->target, m); }
-int fvh_vgicp_calculate_source_covariances_rbf(fvh_vgicp* h, int m) { CHECK_HANDLE_SOURCE_CHAIN(h); return h->e.after_source_chain_call(calc_cov_rbf(&h->e, h->source, h->kernel_width, h->kernel_max_dist, m)); }
-int fvh_vgicp_calculate_target_covariances_rbf(fvh_vgicp* h, int m) { CHECK_HANDLE(h); return calc_cov_rbf(&h->e, h->target, h->kernel_width, h->kernel_max_dist, m); }
-int fvh_vgicp_set_source_covariances(fvh_vgicp* h, const double* c) { CHECK_HANDLE(h); return set_cov_host(&h->e, h->source, c); }
-int fvh_vgicp_set_target_covariances(fvh_vgicp* h, const double* c) { CHECK_HANDLE(h); return set_cov_host(&h->e, h->target, c); }
+int fvh_vgicp_calculate_source_covariances(fvh_vgicp* h, int m) { CHECK_HANDLE_SOURCE_CHAIN(h); h->source_changed(); return h->e.after_source_chain_call(calc_cov_knn(&h->e, h->source, m)); }
+int fvh_vgicp_calculate_target_covariances(fvh_vgicp* h, int m) { CHECK_HANDLE(h); h->live_map_stale = true; return calc_cov_knn(&h->e, h->target, m); }
+int fvh_vgicp_calculate_source_covariances_rbf(fvh_vgicp* h, int m) { CHECK_HANDLE_SOURCE_CHAIN(h); h->source_changed(); return h->e.after_source_chain_call(calc_cov_rbf(&h->e, h->source, h->kernel_width, h->kernel_max_dist, m)); }
+int fvh_vgicp_calculate_target_covariances_rbf(fvh_vgicp* h, int m) { CHECK_HANDLE(h); h->live_map_stale = true; return calc_cov_rbf(&h->e, h->target, h->kernel_width, h->kernel_max_dist, m); }
+int fvh_vgicp_set_source_covariances(fvh_vgicp* h, const double* c) { CHECK_HANDLE(h); h->source_changed(); return set_cov_host(&h->e, h->source, c); }
+int fvh_vgicp_set_target_covariances(fvh_vgicp* h, const double* c) { CHECK_HANDLE(h); h->live_map_stale = true; return set_cov_host(&h->e, h->target, c); }
 
 int fvh_vgicp_get_num_source_points(const fvh_vgicp* h, int* n) { if (!h || !n) return FVH_ERR_INVALID_ARGUMENT; *n = h->source.has_pts ? h->source.n : 0; return FVH_OK; }
 int fvh_vgicp_get_num_target_points(const fvh_vgicp* h, int* n) { if (!h || !n) return FVH_ERR_INVALID_ARGUMENT; *n = h->target.has_pts ? h->target.n : 0; return FVH_OK; }
@@ -786,6 +812,89 @@ int fvh_vgicp_align(fvh_vgicp* h, const double* guess, const fvh_lm_params* p, f
   // and they touch neither clouds nor the map any more)
   if (rc == FVH_OK) h->e.quiet = true;
   return rc;
+}
+// ---- pipelined scan streams (scan-to-scan odometry: src/kitti.cpp's loop with the next scan prepared beside the running LM kernel) ----
+//   prepare_source_device(scan k+1)  [second stream: pack, Morton sort, exact k-NN, covariances, the scan's own voxel map]
+//   align_async(guess) .. align_wait(result)   [main stream: the persistent LM kernel of the pair (k, k-1)]
+//   swap_source_and_target()         [the map that came with scan k becomes the live one: nothing is built]
+//   adopt_prepared_source()          [scan k+1 becomes the source]
+// Results are those of the sequential calls (same kernels on the same data; voxel sums differ in the order of their fp64 atomics only).
+int fvh_vgicp_align_async(fvh_vgicp* h, const double* guess, const fvh_lm_params* p) {
+  CHECK_HANDLE(h);
+  if (h->e.sharded()) return h->e.fail(FVH_ERR_UNSUPPORTED, "align_async: not on a multi-GPU handle");
+  if (!h->source.has_pts || !h->source.has_cov) return h->e.fail(FVH_ERR_BAD_STATE, "align: source cloud/covariances not set");
+  const int rc = align_begin<MODE_VGICP>(&h->e, h->pending, h->cost_source(), h->voxelmap, guess, p);
+  if (rc == FVH_OK) h->e.async_in_flight = true;
+  return rc;
+}
+int fvh_vgicp_align_wait(fvh_vgicp* h, fvh_lm_result* r) {
+  CHECK_HANDLE_HOST_ONLY(h);
+  if (!h->pending.active) return h->e.fail(FVH_ERR_BAD_STATE, "align_wait: no align_async in flight");
+  h->e.async_in_flight = false;
+  const int rc = align_finish<MODE_VGICP>(&h->e, h->pending, h->cost_source(), h->voxelmap, r, h->rebuild_safe());
+  if (rc == FVH_OK) h->e.quiet = true;
+  return rc;
+}
+int fvh_vgicp_prepare_source_device(fvh_vgicp* h, const float* d_xyz, int n, int stride, int k, int regularization, int rbf, int stages) {
+  CHECK_HANDLE_HOST_ONLY(h);  // (touches the prepared slot and the second stream only: legal between align_async and align_wait)
+  Engine* e = &h->e;
+  if (stages < 1 || stages > 3) return e->fail(FVH_ERR_INVALID_ARGUMENT, "prepare_source: stages must be 1 (order + neighbours), 2 (+ covariances) or 3 (+ voxel map)");
+  if (e->sharded()) return e->fail(FVH_ERR_UNSUPPORTED, "prepare_source: not on a multi-GPU handle");
+  hipStream_t ps = e->side_stream();  // null (FVH_SIDE_STREAM=0): in order on the main stream -- correct, nothing overlaps
+  if (ps == nullptr && h->pending.active) return e->fail(FVH_ERR_BAD_STATE, "prepare_source: this handle has no second stream; call it outside align_async .. align_wait");
+  if (!h->prep_done) HIP_OR_FAIL(e, hipEventCreateWithFlags(&h->prep_done, hipEventDisableTiming));
+  // a target-map build that swap_source_and_target() deferred goes first (same stream: in order)
+  if (e->deferred) { const int rc = e->after_source_chain_call(FVH_OK); if (rc) return rc; }
+  h->next_ready = false;
+  h->next_map.invalidate();
+  cloud_replaced(h->next_source);
+  // The stages below are the ones the sequential calls run; they launch on the handle's current stream: for the length of this call that is
+  // the second one. The scratch they use (sort keys / histograms, the RBF sums) is not touched by a running LM kernel.
+  struct StreamSwap { Engine* e; hipStream_t main; ~StreamSwap() { e->stream = main; } } swap{e, e->stream};
+  if (ps) e->stream = ps;
+  // The cooperative sort runs beside this handle's own LM kernel (32 workgroups next to a grid that leaves a third of every CU's registers
+  // free; neither waits for the other: measured, no watchdog abort in 10^4 registrations, and the one-workgroup sort would cost the
+  // chain 45 us); towards OTHER handles the registry keeps describing the LM kernel, the longer of the two.
+  struct KeepEvent { Engine* e; ~KeepEvent() { e->gang_keep_event = false; } } keep_event{e};
+  e->gang_keep_event = h->pending.active;
+  int rc = upload_cloud(e, h->next_source, d_xyz, n, stride, true, true, ps);
+  if (rc || n == 0) return rc ? rc : e->fail(FVH_ERR_INVALID_ARGUMENT, "prepare_source: empty cloud");
+  rc = ensure_sorted(e, h->next_source);
+  if (rc) return rc;
+  if (rbf) { if (stages >= 2) rc = calc_cov_rbf(e, h->next_source, h->kernel_width, h->kernel_max_dist, regularization); }
+  else {
+    rc = find_neighbors(e, h->next_source, k);
+    if (!rc && stages >= 2) rc = calc_cov_knn(e, h->next_source, regularization);
+  }
+  if (rc) return rc;
+  if (stages >= 3) {
+    if (h->next_map.nv_hint < 0) h->next_map.nv_hint = std::max(h->voxelmap.nv_hint, h->source_map.nv_hint);
+    rc = h->voxel_mode == 2 ? build_voxelmap<2>(e, h->next_source, h->next_map, h->resolution, false, false, ps, false, /*detached=*/true)
+                            : build_voxelmap<0>(e, h->next_source, h->next_map, h->resolution, false, false, ps, false, /*detached=*/true);
+    if (rc) return rc;
+  }
+  HIP_OR_FAIL(e, hipEventRecord(h->prep_done, e->stream));
+  h->next_ready = true;
+  return FVH_OK;
+}
+int fvh_vgicp_adopt_prepared_source(fvh_vgicp* h) {
+  CHECK_HANDLE(h);  // (a map build swap_source_and_target() deferred runs here, in order on the main stream: queued on the second one it reached the LM kernel 10 us later -- measured)
+  Engine* e = &h->e;
+  if (!h->next_ready) return e->fail(FVH_ERR_BAD_STATE, "adopt_prepared_source: nothing prepared (fvh_vgicp_prepare_source_device)");
+  h->next_ready = false;
+  h->source.swap(h->next_source);
+  std::swap(h->source_map, h->next_map);
+  e->has_corr = false;
+  // As a rule the preparation ended while the last align was still running: the host sees that at no cost. Otherwise the main stream waits.
+  if (e->side) {
+    hipError_t q = hipErrorNotReady;
+    for (int spins = 0; spins < 64 && q == hipErrorNotReady; spins++) q = hipEventQuery(h->prep_done);
+    if (q != hipSuccess) {
+      (void)hipGetLastError();
+      HIP_OR_FAIL(e, hipStreamWaitEvent(e->stream, h->prep_done, 0));
+    }
+  }
+  return FVH_OK;
 }
 static int get_lm_trace(Engine* e, int* n, double* rows6) {
   if (!n) return e->fail(FVH_ERR_INVALID_ARGUMENT, "get_lm_trace: null count");
@@ -1281,6 +1390,16 @@ int fvh_voxelgrid_share_stream_with_ndt(fvh_voxelgrid* h, fvh_ndt* other) {
   return FVH_OK;
 }
 int fvh_voxelgrid_share_prepare_stream_with_ndt(fvh_voxelgrid* h, fvh_ndt* other) {
+  CHECK_HANDLE(h);
+  HIP_OR_FAIL(&h->e, hipStreamSynchronize(h->e.stream));
+  if (!other) return h->e.fail(FVH_ERR_INVALID_ARGUMENT, "share_prepare_stream: null registration handle");
+  if (other->e.device != h->e.device) return h->e.fail(FVH_ERR_INVALID_ARGUMENT, "share_stream: the two handles live on different devices");
+  hipStream_t ps = other->e.side_stream();
+  h->e.stream = ps ? ps : other->e.stream;
+  h->e.stream_owner = &other->e;
+  return FVH_OK;
+}
+int fvh_voxelgrid_share_prepare_stream_with_vgicp(fvh_voxelgrid* h, fvh_vgicp* other) {
   CHECK_HANDLE(h);
   HIP_OR_FAIL(&h->e, hipStreamSynchronize(h->e.stream));
   if (!other) return h->e.fail(FVH_ERR_INVALID_ARGUMENT, "share_prepare_stream: null registration handle");

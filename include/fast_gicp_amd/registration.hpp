@@ -539,6 +539,43 @@ public:
   }
   fvh_vgicp* core() { return core_; }
 
+  // ---- scan streams as a two-stage pipeline (no reference counterpart; C ABI: fvh_vgicp_align_async / _wait, fvh_vgicp_prepare_source_device /
+  // _adopt_prepared_source). kitti.cpp:95-128 with the preparation of scan k+1 hidden under the registration of scan k:
+  //     alignAsync(); prepareNextSourceDevice(next scan); alignWait(); swapSourceAndTarget(); adoptPreparedSource();
+  // The prepared source lives on the device only: getInputSource() is null for it and alignWait() returns the pose without transforming a host
+  // cloud. Neighbours and covariances follow setNearestNeighborSearchMethod (the host kd-tree cannot be served here: device search instead,
+  // identical lists) and setRegularizationMethod. `stages`: see fvh_vgicp_prepare_source_device (2: order, neighbours, covariances).
+  void prepareNextSourceDevice(const float* d_xyz, int n, int stride_floats = 3, int stages = 2) {
+    const int rbf = neighbor_search_method_ == NearestNeighborMethod::GPU_RBF_KERNEL ? 1 : 0;
+    prepared_stages_ = stages;
+    call(fvh_vgicp_prepare_source_device(core_, d_xyz, n, stride_floats, k_correspondences_, (int)regularization_method_, rbf, stages), "prepare_source_device");
+  }
+  void adoptPreparedSource() {
+    call(fvh_vgicp_adopt_prepared_source(core_), "adopt_prepared_source");
+    input_.reset();
+    if (prepared_stages_ < 2) {
+      if (neighbor_search_method_ == NearestNeighborMethod::GPU_RBF_KERNEL) call(fvh_vgicp_calculate_source_covariances_rbf(core_, (int)regularization_method_), "calculate_source_covariances_rbf");
+      else call(fvh_vgicp_calculate_source_covariances(core_, (int)regularization_method_), "calculate_source_covariances");
+    }
+  }
+  void alignAsync(const Matrix4f& guess = Matrix4f::Identity()) {
+    double g16[16];
+    Isometry3d::from(guess).to_colmajor16(g16);
+    fvh_lm_params p{this->max_iterations_, this->rotation_epsilon_, this->transformation_epsilon_, this->lm_max_iterations_, this->lm_init_lambda_factor_,
+                    this->lsq_optimizer_type_ == LSQ_OPTIMIZER_TYPE::GaussNewton ? 1 : 0};
+    call(fvh_vgicp_align_async(core_, g16, &p), "align_async");
+  }
+  const Matrix4f& alignWait() {
+    fvh_lm_result r;
+    call(fvh_vgicp_align_wait(core_, &r), "align_wait");
+    this->final_transformation_ = Isometry3d::from_colmajor16(r.T).cast_float();
+    this->converged_ = r.converged != 0;
+    this->nr_iterations_ = r.nr_iterations;
+    for (int i = 0; i < 6; i++) for (int j = 0; j < 6; j++) this->final_hessian_[i * 6 + j] = r.H[j * 6 + i];
+    if (r.lm_failed) std::fprintf(stderr, "lm not converged!!\n");
+    return this->final_transformation_;
+  }
+
 protected:
   double linearize(const Isometry3d& trans, Matrix6d* H, Vector6d* b) override {  // :170-173
     double T16[16], err = 0, Hc[36];
@@ -609,6 +646,7 @@ private:
   RegularizationMethod regularization_method_ = RegularizationMethod::PLANE;                     // :26
   NearestNeighborMethod neighbor_search_method_ = NearestNeighborMethod::CPU_PARALLEL_KDTREE;    // :27
   bool host_kdtree_ = host_kdtree_default();                                                     // setHostKdTree
+  int prepared_stages_ = 2;                                                                         // prepareNextSourceDevice
   fvh_vgicp* core_ = nullptr;
   std::vector<float> scratch_xyz_;  // only used for point types that are not 12 / 16 bytes of packed xyz
 };

@@ -189,6 +189,28 @@ int fvh_vgicp_compute_error(fvh_vgicp* h, const double* T16, double* H36, double
  * lookups per evaluation, or after the barrier watchdog aborted a persistent launch (FVH_PERSISTENT=0 forces it).
  * All routes produce bit-identical results. */
 int fvh_vgicp_align(fvh_vgicp* h, const double* guess16, const fvh_lm_params* params, fvh_lm_result* result);
+/* new: a scan stream as a two-stage pipeline (scan-to-scan odometry, src/kitti.cpp:95-128 / src/align.cpp:87-101 with the preparation of
+ * scan k+1 hidden under the registration of scan k). The handle owns a SECOND stream and a prepared-source slot:
+ *   fvh_vgicp_prepare_source_device  packs a device cloud into the slot and queues, on the second stream, the first `stages` stages of what
+ *                                    the sequential loop runs for a new source: 1 = Morton order + exact k-NN (k), 2 = + covariances
+ *                                    (rbf != 0: the RBF covariances instead of both; regularization as in
+ *                                    fvh_vgicp_calculate_source_covariances), 3 = + the scan's own voxel map at the handle's resolution.
+ *                                    Returns when everything is queued.
+ *   fvh_vgicp_align_async / _wait    launch the LM kernel on the main stream / collect its result (together: fvh_vgicp_align). Between the
+ *                                    two only fvh_vgicp_prepare_source_device may be called on this handle (anything else: FVH_ERR_BAD_STATE).
+ *   fvh_vgicp_adopt_prepared_source  the slot becomes the source (stages = 1: the caller then calls fvh_vgicp_calculate_source_covariances);
+ *                                    a map prepared with it travels with the cloud, and the next fvh_vgicp_swap_source_and_target makes
+ *                                    that map the live one instead of building it ([VCU]:102-104's rebuild, already done).
+ * The loop:  align_async; prepare_source_device(next scan); align_wait; swap_source_and_target; adopt_prepared_source.
+ * Same kernels on the same data as the sequential calls (measured: bit-identical poses). Which `stages` pays depends on how long the LM
+ * kernel runs: the prepared chain is slower beside it (the bundled 17k pair: 2 is best, +12 %; 3 makes the chain the longer stage).
+ * swap_source_and_target() on ANY handle now keeps the old target's map with its cloud: swapping back costs nothing, unless that cloud's
+ * covariances changed after the map was built (then it is rebuilt, as the reference would).
+ * Not on a multi-GPU handle (FVH_ERR_UNSUPPORTED). */
+int fvh_vgicp_align_async(fvh_vgicp* h, const double* guess16, const fvh_lm_params* params);
+int fvh_vgicp_align_wait(fvh_vgicp* h, fvh_lm_result* result);
+int fvh_vgicp_prepare_source_device(fvh_vgicp* h, const float* d_xyz, int n, int stride_floats, int k, int regularization, int rbf, int stages);
+int fvh_vgicp_adopt_prepared_source(fvh_vgicp* h);
 /* setDebugPrint(true) on the device LM: with the trace on, an align records one row per trial step -- {inner iteration i, y0,
  * yi, rho, lambda, |d|}, the columns LsqRegistration prints (lsq_registration_impl.hpp:143-149) -- fetched afterwards
  * (rows6 may be NULL to query the count). */
@@ -383,6 +405,7 @@ int fvh_voxelgrid_share_stream_with_vgicp(fvh_voxelgrid* h, fvh_vgicp* registrat
 /* same, on the registration handle's SECOND stream (the one fvh_ndt_prepare_source_device works on): the filter of the next frame runs
  * beside the LM kernel of the current one, its output is ordered before the preparation that consumes it */
 int fvh_voxelgrid_share_prepare_stream_with_ndt(fvh_voxelgrid* h, fvh_ndt* registration);
+int fvh_voxelgrid_share_prepare_stream_with_vgicp(fvh_voxelgrid* h, fvh_vgicp* registration); /* ... the one fvh_vgicp_prepare_source_device works on */
 int fvh_voxelgrid_filter_device_async(fvh_voxelgrid* h, int method, const float* d_xyz, int n, int stride_floats, float leaf, int* out_n);
 int fvh_voxelgrid_get_points(fvh_voxelgrid* h, float* out_xyz /* host or device, 3*out_n floats */);
 int fvh_voxelgrid_device_points(fvh_voxelgrid* h, const float** d_xyz, int* n);

@@ -74,7 +74,7 @@ def test_vgicp_odometry_matches_oracle(O, frames):
     c.close()
 
 
-@pytest.mark.parametrize("method", ["ndt", "ndt_pipelined", "vgicp", "gicp"])
+@pytest.mark.parametrize("method", ["ndt", "ndt_pipelined", "vgicp", "vgicp_pipelined", "gicp"])
 def test_gicp_kitti_app_on_simulated_sequence(tmp_path, method):
     """apps/gicp_kitti (the reference's src/kitti.cpp driver): KITTI-format .bin frames (x, y, z, intensity) in, trajectory
     in KITTI format out; the raw xyzi buffers are downsampled on the device. 5 simulated frames, end pose vs ground truth."""
@@ -96,9 +96,9 @@ def test_gicp_kitti_app_on_simulated_sequence(tmp_path, method):
     gt = np.linalg.inv(util.lidar_pose(0)) @ util.lidar_pose(n - 1)
     te, re_ = util.pose_error(gt, est)
     assert te < 0.12 and re_ < np.radians(1.0), (te, re_)
-    if method == "ndt_pipelined":  # the C++ pipeline (NDTCuda::alignAsync / prepareNextSourceDevice / adoptPreparedSource / alignWait) == the sequential app
+    if method.endswith("_pipelined"):  # the C++ pipeline (alignAsync / prepareNextSourceDevice / adoptPreparedSource / alignWait of NDTCuda and FastVGICPCuda) == the sequential app
         traj2 = str(tmp_path / "traj_seq.txt")
-        out2 = subprocess.run([exe, str(tmp_path), "ndt", traj2], capture_output=True, text=True, timeout=300)
+        out2 = subprocess.run([exe, str(tmp_path), method[:-len("_pipelined")], traj2], capture_output=True, text=True, timeout=300)
         assert out2.returncode == 0, out2.stderr
         assert np.abs(np.loadtxt(traj2) - np.loadtxt(traj)).max() < 1e-6
 
@@ -181,3 +181,114 @@ def test_pipelined_frame_stream_equals_the_sequential_loop(mode):
         c.swap_source_and_target()
     assert c.align_wait()["converged"] is not None
     vg.close(); c.close()
+
+
+def _vgicp_voxels(c):
+    coords, num, means, covs = c.get_voxelmap()
+    o = np.lexsort((coords[:, 2], coords[:, 1], coords[:, 0]))
+    return coords[o], num[o], means[o], covs[o]
+
+
+@pytest.mark.parametrize("stages,rbf", [(3, False), (2, False), (1, False), (3, True)])
+def test_pipelined_vgicp_scan_stream_equals_the_sequential_loop(frames, stages, rbf):
+    """fvh_vgicp_prepare_source_device / _adopt_prepared_source / _align_async / _align_wait: scan k+1 is sorted, searched, its covariances
+    and (stages = 3) its own voxel map computed on the handle's second stream while the LM kernel of scan k runs; swap_source_and_target()
+    then takes the map that came with the scan instead of building one (kitti.cpp:95-128 with FastVGICPCuda, one stage ahead).
+    Same kernels on the same data as the sequential calls: equal iteration counts, the voxel map of every registration equal to the
+    sequential loop's (counts exactly, means / covariances to the order of their fp64 atomics), poses within 1e-9."""
+    import torch
+    from fast_gicp_amd import capi
+    dev = torch.device("cuda", 0)
+    d = [torch.from_numpy(np.ascontiguousarray(f, np.float32)).to(dev).contiguous() for f in frames]
+
+    def make():
+        c = capi.VGICPCore(0)
+        c.set_resolution(1.0); c.set_neighbor_search_method(capi.DIRECT7); c.set_kernel_params(0.5, 2.5)
+        return c
+
+    def cov(c, which):
+        if rbf:
+            getattr(c, "calculate_%s_covariances_rbf" % which)(capi.REG_PLANE)
+        else:
+            getattr(c, "find_%s_neighbors" % which)(20)
+            getattr(c, "calculate_%s_covariances" % which)(capi.REG_PLANE)
+
+    # ---- sequential ----
+    c = make()
+    c.set_target_cloud_device(d[0].data_ptr(), len(frames[0]), 3); cov(c, "target"); c.create_target_voxelmap()
+    seq, seq_maps = [], []
+    for i in range(1, N_FRAMES):
+        c.set_source_cloud_device(d[i].data_ptr(), len(frames[i]), 3); cov(c, "source")
+        r = c.align()
+        assert r["converged"]
+        seq.append((r["T"].copy(), r["H"].copy(), r["final_error"], r["num_linearize"], r["num_error_evals"]))
+        seq_maps.append(_vgicp_voxels(c))
+        c.swap_source_and_target()
+    c.close()
+
+    # ---- pipelined ----
+    c = make()
+    c.set_target_cloud_device(d[0].data_ptr(), len(frames[0]), 3); cov(c, "target"); c.create_target_voxelmap()
+    c.prepare_source_device(d[1].data_ptr(), len(frames[1]), 3, 20, capi.REG_PLANE, rbf, stages)
+    for i in range(1, N_FRAMES):
+        c.adopt_prepared_source()
+        if stages < 2:
+            (c.calculate_source_covariances_rbf if rbf else c.calculate_source_covariances)(capi.REG_PLANE)
+        c.align_async()
+        if i + 1 < N_FRAMES:  # the next scan, beside the running LM kernel
+            c.prepare_source_device(d[i + 1].data_ptr(), len(frames[i + 1]), 3, 20, capi.REG_PLANE, rbf, stages)
+        with pytest.raises(capi.FvhError):
+            c.get_voxelmap()  # the handle belongs to the running kernel
+        r = c.align_wait()
+        T, H, err, nl, ne = seq[i - 1]
+        assert r["converged"] and r["num_launches"] == 1
+        assert (r["num_linearize"], r["num_error_evals"]) == (nl, ne), i
+        assert util.rel_err(r["T"], T) < 1e-9 and util.rel_err(r["H"], H) < 1e-9 and abs(r["final_error"] - err) <= 1e-9 * abs(err), i
+        got, want = _vgicp_voxels(c), seq_maps[i - 1]
+        assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1]), i
+        assert np.allclose(got[2], want[2], rtol=0, atol=1e-5) and np.allclose(got[3], want[3], rtol=1e-5, atol=1e-7), i
+        c.swap_source_and_target()
+    assert c.debug_persist_aborts() == 0
+    # misuse is refused, not undefined
+    with pytest.raises(capi.FvhError):
+        c.adopt_prepared_source()  # nothing prepared
+    with pytest.raises(capi.FvhError):
+        c.align_wait()  # nothing in flight
+    with pytest.raises(capi.FvhError):
+        c.prepare_source_device(d[0].data_ptr(), len(frames[0]), 3, 20, capi.REG_PLANE, False, 4)
+    c.close()
+
+
+def test_a_voxel_map_is_not_carried_over_a_swap_once_its_cloud_changed(frames):
+    """swap_source_and_target() keeps the old target's map with its cloud (it becomes the live map again if the clouds are swapped back)
+    -- unless the cloud's covariances changed after the map was built, or the source was replaced: then the reference's rule applies
+    (fast_vgicp_cuda.cu:102-104: the map is built from the new target's current covariances)."""
+    from fast_gicp_amd import capi
+    a, b = frames[0], frames[1]
+
+    def fresh(cloud, reg):
+        c = capi.VGICPCore(0)
+        c.set_target_cloud(cloud); c.find_target_neighbors(20); c.calculate_target_covariances(reg); c.create_target_voxelmap()
+        v = _vgicp_voxels(c)
+        c.close()
+        return v
+
+    c = capi.VGICPCore(0)
+    c.set_target_cloud(a); c.find_target_neighbors(20); c.calculate_target_covariances(capi.REG_PLANE); c.create_target_voxelmap()
+    c.set_source_cloud(b); c.find_source_neighbors(20); c.calculate_source_covariances(capi.REG_PLANE)
+    c.swap_source_and_target(); c.swap_source_and_target()  # back: the map of `a` was carried
+    got, want = _vgicp_voxels(c), fresh(a, capi.REG_PLANE)
+    assert np.array_equal(got[0], want[0]) and np.allclose(got[3], want[3], rtol=1e-5, atol=1e-7)
+    c.calculate_target_covariances(capi.REG_FROBENIUS)  # the live map stays as built (reference: until create_target_voxelmap) ...
+    got = _vgicp_voxels(c)
+    assert np.allclose(got[3], want[3], rtol=1e-5, atol=1e-7)
+    c.swap_source_and_target(); c.swap_source_and_target()  # ... but across a swap the map follows the cloud's CURRENT covariances
+    got, want = _vgicp_voxels(c), fresh(a, capi.REG_FROBENIUS)
+    assert np.array_equal(got[0], want[0]) and np.allclose(got[3], want[3], rtol=1e-5, atol=1e-7)
+    # a replaced source takes no stale map with it
+    c.swap_source_and_target()  # target = b, source = a (map of a carried)
+    c.set_source_cloud(frames[2]); c.find_source_neighbors(20); c.calculate_source_covariances(capi.REG_PLANE)
+    c.swap_source_and_target()  # target = frames[2]
+    got, want = _vgicp_voxels(c), fresh(frames[2], capi.REG_PLANE)
+    assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1]) and np.allclose(got[3], want[3], rtol=1e-5, atol=1e-7)
+    c.close()

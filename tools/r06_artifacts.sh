@@ -13,7 +13,7 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out/r06
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp && cd $R
-COMMON="--no-cpu-baseline --no-profile --streams 1 --configs none --no-host-leg"
+COMMON="--no-cpu-baseline --no-profile --streams 1 --configs none --no-host-leg --no-pipelined-leg"
 declare -A WL
 WL[bundled17k]="--steps 40 --warmup 5 $COMMON"
 WL[synth100k_rbf]="--workload synth100k --cov rbf --steps 25 --warmup 3 $COMMON"
