@@ -130,6 +130,34 @@ struct Engine {
   hipStream_t side = nullptr;
   hipEvent_t side_done = nullptr;
   bool async_in_flight = false;    // fvh_vgicp_align_async .. _align_wait: the handle's clouds, map and LM state belong to the running kernel
+  // A persistent LM grid that takes more than 3/4 of the device's co-resident workgroup slots must not share the chip with another stream's
+  // kernels while it is being DISPATCHED: with every XCD nearly full the dispatcher places workgroups wherever room appears, the
+  // block -> XCD pattern the XCD-local hand-offs rely on (kernels_cost.hpp) no longer holds, and the launch ends in its watchdog (measured with
+  // the pipelined loops: 0 aborts in 400 aligns up to 82 % of the slots, 1 at 93 %, 130 at 100 % -- 50 ms each). While such a grid is in
+  // flight (`lm_crowds_chip`) the prepared-source calls and a voxel-grid filter on the prepare stream queue on the MAIN stream, behind
+  // the kernel; and such a launch first waits for a preparation that is still running (`crowd_fence`).
+  bool lm_crowds_chip = false;
+  hipEvent_t crowd_fence = nullptr;  // set by the handle for one align: the event behind a preparation it has not adopted yet
+  static bool crowds(int blocks, int capacity) { return (long long)blocks * 4 > (long long)capacity * 3; }
+  bool feeder_on_main = false;       // where the last preparation / prepare-stream filter was queued
+  hipEvent_t flip_ev = nullptr;
+  // the stream a preparation (or a filter that feeds one) is queued on: the second stream (*out = that stream), or -- no second stream, or a
+  // crowding grid in flight -- the main one (*out = null). When the choice flips, the new stream is ordered after what the old one holds.
+  int feeder_stream(hipStream_t* out) {
+    hipStream_t s2 = side_stream();
+    *out = nullptr;
+    if (!s2) return FVH_OK;
+    const bool want_main = lm_crowds_chip;
+    if (want_main != feeder_on_main) {
+      hipError_t r;
+      if (!flip_ev && (r = hipEventCreateWithFlags(&flip_ev, hipEventDisableTiming)) != hipSuccess) return hipfail(r, "hipEventCreate");
+      if ((r = hipEventRecord(flip_ev, feeder_on_main ? stream : s2)) != hipSuccess) return hipfail(r, "hipEventRecord");
+      if ((r = hipStreamWaitEvent(want_main ? stream : s2, flip_ev, 0)) != hipSuccess) return hipfail(r, "hipStreamWaitEvent");
+      feeder_on_main = want_main;
+    }
+    if (!want_main) *out = s2;
+    return FVH_OK;
+  }
   bool side_pending = false;       // a build on `side` the main stream has not been ordered after yet
   bool quiet = false, was_quiet = false;  // the main stream had drained when the current API call began (set by align on return)
   hipStream_t side_stream() {
@@ -282,6 +310,7 @@ struct Engine {
     if (peer.region) { (void)hipFree(peer.region); peer.region = nullptr; }
     peer.err.release();
     prof.destroy();
+    if (flip_ev) { (void)hipEventDestroy(flip_ev); flip_ev = nullptr; }
     gather_stage.release(); lm_trace.release(); fit_best.release(); sort_coop.release(); rbf_sums.release(); bcast.release(); offsets_dev.release(); state.release(); partials.release(); ticket.release(); corr.release(); misc.release(); fit.release(); staging.release(); sort_keys.release(); sort_idx.release(); sort_hist.release();
     if (pinned) (void)hipHostFree(pinned);
     if (upload_pinned) (void)hipHostFree(upload_pinned);
@@ -807,6 +836,7 @@ int fvh_vgicp_align(fvh_vgicp* h, const double* guess, const fvh_lm_params* p, f
     rc = h->build_map(h->resolution);
     if (rc) return rc;
   }
+  h->e.crowd_fence = h->next_ready ? h->prep_done : nullptr;  // (a preparation still running on the second stream: a grid that crowds the chip waits for it)
   const int rc = do_align<MODE_VGICP>(&h->e, h->cost_source(), h->voxelmap, guess, p, r, h->rebuild_safe());
   // the result is on the host: everything this handle queued has run (of a persistent launch only the workgroups' exit remains,
   // and they touch neither clouds nor the map any more)
@@ -823,6 +853,7 @@ int fvh_vgicp_align_async(fvh_vgicp* h, const double* guess, const fvh_lm_params
   CHECK_HANDLE(h);
   if (h->e.sharded()) return h->e.fail(FVH_ERR_UNSUPPORTED, "align_async: not on a multi-GPU handle");
   if (!h->source.has_pts || !h->source.has_cov) return h->e.fail(FVH_ERR_BAD_STATE, "align: source cloud/covariances not set");
+  h->e.crowd_fence = h->next_ready ? h->prep_done : nullptr;
   const int rc = align_begin<MODE_VGICP>(&h->e, h->pending, h->cost_source(), h->voxelmap, guess, p);
   if (rc == FVH_OK) h->e.async_in_flight = true;
   return rc;
@@ -845,6 +876,7 @@ int fvh_vgicp_prepare_source_device(fvh_vgicp* h, const float* d_xyz, int n, int
   if (!h->prep_done) HIP_OR_FAIL(e, hipEventCreateWithFlags(&h->prep_done, hipEventDisableTiming));
   // a target-map build that swap_source_and_target() deferred goes first (same stream: in order)
   if (e->deferred) { const int rc = e->after_source_chain_call(FVH_OK); if (rc) return rc; }
+  { const int rc = e->feeder_stream(&ps); if (rc) return rc; }
   h->next_ready = false;
   h->next_map.invalidate();
   cloud_replaced(h->next_source);
@@ -856,7 +888,7 @@ int fvh_vgicp_prepare_source_device(fvh_vgicp* h, const float* d_xyz, int n, int
   // free; neither waits for the other: measured, no watchdog abort in 10^4 registrations, and the one-workgroup sort would cost the
   // chain 45 us); towards OTHER handles the registry keeps describing the LM kernel, the longer of the two.
   struct KeepEvent { Engine* e; ~KeepEvent() { e->gang_keep_event = false; } } keep_event{e};
-  e->gang_keep_event = h->pending.active;
+  e->gang_keep_event = h->pending.active && ps != nullptr;
   int rc = upload_cloud(e, h->next_source, d_xyz, n, stride, true, true, ps);
   if (rc || n == 0) return rc ? rc : e->fail(FVH_ERR_INVALID_ARGUMENT, "prepare_source: empty cloud");
   rc = ensure_sorted(e, h->next_source);
@@ -1211,6 +1243,7 @@ int fvh_ndt_align(fvh_ndt* h, const double* guess, const fvh_lm_params* p, fvh_l
   int rc = fvh_ndt_create_voxelmaps(h);  // NDTCuda::computeTransformation (ndt_cuda_impl.hpp:76-79)
   if (rc) return rc;
   rc = ndt_ready(h); if (rc) return rc;
+  h->e.crowd_fence = h->next_ready ? h->prep_done : nullptr;  // (a preparation still running on the second stream: a grid that crowds the chip waits for it)
   if (h->distance_mode == FVH_NDT_P2D) return do_align<MODE_NDT_P2D>(&h->e, h->cost_source(), h->target_vm, guess, p, r, h->rebuild_safe());
   return do_align<MODE_NDT_D2D>(&h->e, h->cost_source(), h->target_vm, guess, p, r, h->rebuild_safe());
 }
@@ -1222,6 +1255,7 @@ int fvh_ndt_align_async(fvh_ndt* h, const double* guess, const fvh_lm_params* p)
   int rc = fvh_ndt_create_voxelmaps(h);
   if (rc) return rc;
   rc = ndt_ready(h); if (rc) return rc;
+  h->e.crowd_fence = h->next_ready ? h->prep_done : nullptr;
   if (h->distance_mode == FVH_NDT_P2D) return align_begin<MODE_NDT_P2D>(&h->e, h->pending, h->cost_source(), h->target_vm, guess, p);
   return align_begin<MODE_NDT_D2D>(&h->e, h->pending, h->cost_source(), h->target_vm, guess, p);
 }
@@ -1237,6 +1271,7 @@ int fvh_ndt_prepare_source_device(fvh_ndt* h, const float* d_xyz, int n, int str
   hipStream_t ps = e->side_stream();  // null (multi-GPU handle, FVH_SIDE_STREAM=0): in order on the main stream -- correct, nothing overlaps
   if (ps == nullptr && h->pending.active) return e->fail(FVH_ERR_BAD_STATE, "prepare_source: this handle has no second stream; call it outside align_async .. align_wait");
   if (!h->prep_done) HIP_OR_FAIL(e, hipEventCreateWithFlags(&h->prep_done, hipEventDisableTiming));
+  { const int rc0 = e->feeder_stream(&ps); if (rc0) return rc0; }  // (the main stream instead, behind an LM grid that crowds the chip: Engine::lm_crowds_chip)
   h->next_ready = false;
   h->next_vm.invalidate();
   int rc = upload_cloud(e, h->next_source, d_xyz, n, stride, true, false, ps);
@@ -1373,9 +1408,23 @@ int fvh_voxelgrid_destroy(fvh_voxelgrid* h) {
 const char* fvh_voxelgrid_last_error(const fvh_voxelgrid* h) { return h ? h->e.err.c_str() : "null handle"; }
 int fvh_voxelgrid_get_engine_params(fvh_voxelgrid* h, fvh_engine_params* out) { CHECK_HANDLE_HOST_ONLY(h); return get_engine_params(&h->e, out); }
 int fvh_voxelgrid_set_engine_params(fvh_voxelgrid* h, const fvh_engine_params* p) { CHECK_HANDLE(h); return set_engine_params(&h->e, p); }
-int fvh_voxelgrid_filter(fvh_voxelgrid* h, int method, const float* xyz, int n, float leaf, int* out_n) { CHECK_HANDLE(h); return downsample(&h->e, h->d, method, xyz, n, 3, false, leaf, out_n); }
-int fvh_voxelgrid_filter_strided(fvh_voxelgrid* h, int method, const float* xyz, int n, int stride, float leaf, int* out_n) { CHECK_HANDLE(h); return downsample(&h->e, h->d, method, xyz, n, stride, false, leaf, out_n); }
-int fvh_voxelgrid_filter_device(fvh_voxelgrid* h, int method, const float* d_xyz, int n, int stride, float leaf, int* out_n) { CHECK_HANDLE(h); return downsample(&h->e, h->d, method, d_xyz, n, stride, true, leaf, out_n); }
+// A filter that shares a registration handle's PREPARE stream goes where that handle's preparations go (Engine::feeder_stream): the main
+// stream while an LM grid that crowds the chip is in flight. For the length of the call only: the sharing itself stays.
+struct FilterStream {
+  Engine* e; hipStream_t saved; int rc = FVH_OK;
+  explicit FilterStream(Engine* e_) : e(e_), saved(e_->stream) {
+    Engine* o = e->stream_owner;
+    if (!o || !o->side || e->stream != o->side) return;
+    hipStream_t s = nullptr;
+    rc = o->feeder_stream(&s);
+    if (rc) e->err = o->err;
+    else e->stream = s ? s : o->stream;
+  }
+  ~FilterStream() { e->stream = saved; }
+};
+int fvh_voxelgrid_filter(fvh_voxelgrid* h, int method, const float* xyz, int n, float leaf, int* out_n) { CHECK_HANDLE(h); FilterStream fs(&h->e); if (fs.rc) return fs.rc; return downsample(&h->e, h->d, method, xyz, n, 3, false, leaf, out_n); }
+int fvh_voxelgrid_filter_strided(fvh_voxelgrid* h, int method, const float* xyz, int n, int stride, float leaf, int* out_n) { CHECK_HANDLE(h); FilterStream fs(&h->e); if (fs.rc) return fs.rc; return downsample(&h->e, h->d, method, xyz, n, stride, false, leaf, out_n); }
+int fvh_voxelgrid_filter_device(fvh_voxelgrid* h, int method, const float* d_xyz, int n, int stride, float leaf, int* out_n) { CHECK_HANDLE(h); FilterStream fs(&h->e); if (fs.rc) return fs.rc; return downsample(&h->e, h->d, method, d_xyz, n, stride, true, leaf, out_n); }
 // Extension for a device-resident pipeline (no PCL counterpart): the filter runs on the registration handle's stream, so what it
 // writes is ordered before whatever that handle queues next, and the _async call returns as soon as the COUNT is known (it comes
 // from the scan kernel, one kernel before the centroids exist): set_*_cloud_device + align are queued behind the emit kernel
@@ -1419,12 +1468,15 @@ int fvh_voxelgrid_share_stream_with_vgicp(fvh_voxelgrid* h, fvh_vgicp* other) {
 }
 int fvh_voxelgrid_filter_device_async(fvh_voxelgrid* h, int method, const float* d_xyz, int n, int stride, float leaf, int* out_n) {
   CHECK_HANDLE(h);
-  return downsample(&h->e, h->d, method, d_xyz, n, stride, true, leaf, out_n, /*early=*/h->e.stream != h->e.owned_stream);
+  const bool shared = h->e.stream != h->e.owned_stream;
+  FilterStream fs(&h->e); if (fs.rc) return fs.rc;
+  return downsample(&h->e, h->d, method, d_xyz, n, stride, true, leaf, out_n, /*early=*/shared);
 }
 int fvh_voxelgrid_get_points(fvh_voxelgrid* h, float* out_xyz) {
   CHECK_HANDLE(h);
   if (h->d.out_n == 0) return FVH_OK;
   if (!out_xyz) return h->e.fail(FVH_ERR_INVALID_ARGUMENT, "voxelgrid: null output");
+  if (h->e.stream_owner && h->e.stream_owner->feeder_on_main && h->e.stream == h->e.stream_owner->side) HIP_OR_FAIL(&h->e, hipStreamSynchronize(h->e.stream_owner->stream));  // (an _async filter that was queued there)
   HIP_OR_FAIL(&h->e, hipMemcpyAsync(out_xyz, h->d.out.p, sizeof(float) * 3 * (size_t)h->d.out_n, hipMemcpyDefault, h->e.stream));
   HIP_OR_FAIL(&h->e, hipStreamSynchronize(h->e.stream));
   return FVH_OK;

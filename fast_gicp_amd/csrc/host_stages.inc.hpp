@@ -933,6 +933,9 @@ int do_align(Engine* e, const CostSource& src, VoxelMapDev& vm, const double* gu
 template <int MODE>
 int align_begin(Engine* e, AlignCtx& c, const CostSource& src, VoxelMapDev& vm, const double* guess16, const fvh_lm_params* params,
                 bool retried = false, bool no_persist = false, const GridPlan* forced_plan = nullptr /* multi-launch retry of an aborted persistent launch: its layout */) {
+  hipEvent_t const fence = e->crowd_fence;  // (valid for this align only, whatever becomes of it)
+  e->crowd_fence = nullptr;
+  e->lm_crowds_chip = false;
   if (!guess16) return e->fail(FVH_ERR_INVALID_ARGUMENT, "align: null argument");
   if (!vm.valid) return e->fail(FVH_ERR_BAD_STATE, "align: target voxel map not built");
   c = AlignCtx{};
@@ -978,6 +981,13 @@ int align_begin(Engine* e, AlignCtx& c, const CostSource& src, VoxelMapDev& vm, 
     c.plan.nb = granted;
     c.plan.ng = default_groups(granted);
     c.plan.local = (c.plan.ng == TICKET_GROUPS && local_ok) ? 1 : 0;  // (one chip-wide group spans XCDs: write-through)
+    e->lm_crowds_chip = c.persistent && Engine::crowds(c.plan.nb, std::max(cap, 1));
+  }
+  {
+    if (c.persistent && e->lm_crowds_chip && fence && hipEventQuery(fence) != hipSuccess) {  // a preparation still runs on the second stream: this grid waits for it (Engine::lm_crowds_chip)
+      (void)hipGetLastError();
+      HIP_OR_FAIL(e, hipStreamWaitEvent(e->stream, fence, 0));
+    }
   }
   if (c.persistent) {
     int rc = launch_cost<MODE>(e, src, vm, -1, &guess, nullptr, &p, true, e->peer.x, &c.plan);
@@ -991,7 +1001,7 @@ int align_begin(Engine* e, AlignCtx& c, const CostSource& src, VoxelMapDev& vm, 
 template <int MODE>
 int align_finish(Engine* e, AlignCtx& c, const CostSource& src, VoxelMapDev& vm, fvh_lm_result* result, const Rebuild& rebuild_safe) {
   if (!c.active) return e->fail(FVH_ERR_BAD_STATE, "align: nothing in flight");
-  struct Done { AlignCtx& c; ~Done() { c.release_slots(); c.active = false; } } done{c};
+  struct Done { AlignCtx& c; Engine* e; ~Done() { c.release_slots(); c.active = false; e->lm_crowds_chip = false; } } done{c, e};
   if (!result) return e->fail(FVH_ERR_INVALID_ARGUMENT, "align: null argument");
   const fvh_lm_params& p = c.p;
   e->align_optimizer = p.optimizer != 0 ? 1 : 0;

@@ -292,3 +292,52 @@ def test_a_voxel_map_is_not_carried_over_a_swap_once_its_cloud_changed(frames):
     got, want = _vgicp_voxels(c), fresh(frames[2], capi.REG_PLANE)
     assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1]) and np.allclose(got[3], want[3], rtol=1e-5, atol=1e-7)
     c.close()
+
+
+def test_a_preparation_never_runs_beside_an_lm_grid_that_crowds_the_chip():
+    """A persistent LM grid beyond 3/4 of the device's co-resident slots relies on the block -> XCD placement of an otherwise idle chip:
+    dispatched beside another stream's kernels it ended in its watchdog (30k points x DIRECT27: 130 aborts of 50 ms in 400 pipelined
+    registrations before the rule). The prepared-source calls then queue on the main stream, behind the kernel: no aborts, one launch per
+    align, and the poses of the sequential loop."""
+    import torch
+    from fast_gicp_amd import capi, workloads
+    n = 30000
+    tgt, src, _ = workloads.synthetic_pair(n, n, seed=7)
+    dev = torch.device("cuda", 0)
+    d = [torch.from_numpy(tgt).to(dev).contiguous(), torch.from_numpy(src).to(dev).contiguous()]
+
+    def make():
+        c = capi.VGICPCore(0)
+        c.set_resolution(0.5); c.set_neighbor_search_method(capi.DIRECT27)
+        c.set_target_cloud_device(d[0].data_ptr(), n, 3); c.find_target_neighbors(20); c.calculate_target_covariances(); c.create_target_voxelmap()
+        return c
+
+    c = make()
+    seq = {}
+    c.set_source_cloud_device(d[1].data_ptr(), n, 3); c.find_source_neighbors(20); c.calculate_source_covariances()
+    nxt = 0
+    for _ in range(2):
+        r = c.align()
+        seq[1 - nxt] = r["T"].copy()
+        c.swap_source_and_target()
+        c.set_source_cloud_device(d[nxt].data_ptr(), n, 3); c.find_source_neighbors(20); c.calculate_source_covariances()
+        nxt = 1 - nxt
+    blocks, cap = c.debug_persist_grid()
+    assert blocks * 4 > cap * 3, (blocks, cap)  # (the case this test is about)
+    c.close()
+
+    c = make()
+    c.prepare_source_device(d[1].data_ptr(), n, 3, 20, capi.REG_PLANE, False, 2)
+    c.adopt_prepared_source()
+    nxt = 0
+    for it in range(60):
+        c.align_async()
+        c.prepare_source_device(d[nxt].data_ptr(), n, 3, 20, capi.REG_PLANE, False, 2)
+        r = c.align_wait()
+        assert r["converged"] and r["num_launches"] == 1, it
+        assert np.abs(r["T"] - seq[1 - nxt]).max() < 1e-9, it
+        c.swap_source_and_target()
+        c.adopt_prepared_source()
+        nxt = 1 - nxt
+    assert c.debug_persist_aborts() == 0
+    c.close()
