@@ -1319,9 +1319,43 @@ def run_reference_api(args, steps, warmup):
         return {"value": round(steps / el, 3), "ms_per_step": round(el / steps * 1e3, 5), "ms_per_step_min": round(lo / steps * 1e3, 5), "ms_per_step_max": round(hi / steps * 1e3, 5),
                 "single_ms": round(single_ms, 3), "fitness_score": round(float(fitness), 6), "converged": bool(reg.has_converged())}
 
+    def pipelined_loop(steps, warmup):
+        # the same registrations through the pipeline calls of the class (not in the reference): the numpy conversion, the staging copy and the device's
+        # sort / k-NN / covariances of the NEXT scan run while the LM kernel of the current pair does
+        reg = pygicp.FastVGICPCuda()
+        reg.set_resolution(res)
+        reg.set_neighbor_search_method("DIRECT27")
+        reg.set_input_target(clouds[0]); reg.set_input_source(clouds[1])
+        T_seq = {1: reg.align()}
+        reg.swap_source_and_target(); reg.clear_source(); reg.set_input_source(clouds[0])
+        T_seq[0] = reg.align()
+        nxt = [1]
+        last = [None]
+
+        def step():
+            reg.align_async()
+            reg.prepare_next_source(clouds[nxt[0]])
+            last[0] = reg.align_wait()
+            reg.swap_source_and_target()
+            reg.adopt_prepared_source()
+            nxt[0] = 1 - nxt[0]
+        for _ in range(max(warmup, 4)):
+            step()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        el = time.perf_counter() - t0
+        # (the align that just finished registered cloud nxt as the source)
+        return {"value": round(steps / el, 3), "ms_per_step": round(el / steps * 1e3, 5), "max_abs_pose_difference_to_the_sequential_loop": float(np.abs(last[0] - T_seq[nxt[0]]).max())}
+
     dev = loop(False, steps, warmup)
     host = loop(True, max(5, steps // 4), 2)
     out = dict(dev)
+    if not args.no_pipelined_leg:
+        try:
+            out["pipelined"] = pipelined_loop(steps, warmup)
+        except Exception as ex:  # noqa: BLE001
+            out["pipelined"] = {"error": repr(ex)}
     out.update({"metric": "registrations/sec (100-iter reuse) through the reference-API classes, default neighbour enum", "unit": "registrations/sec", "n_gpus": 1, "steps": steps, "warmup": warmup,
                 "repeats": REPEATS, "higher_is_better": True, "dtype": "f64", "data": "bundled scans (real LiDAR)",
                 "config": {"workload": desc, "method": "VGICP (pygicp.FastVGICPCuda, defaults)", "neighbor_search": "DIRECT27", "covariance": "CPU_PARALLEL_KDTREE enum, served by the device's exact k-NN",

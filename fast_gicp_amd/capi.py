@@ -312,6 +312,11 @@ class VGICPCore(_Core):
         (or RBF covariances), and the scan's own voxel map -- beside whatever runs on the main stream."""
         self._call("prepare_source_device", C.c_void_p(ptr), int(n), int(stride), int(k), int(regularization), 1 if rbf else 0, int(stages))
 
+    def prepare_source(self, xyz, k=20, regularization=REG_PLANE, rbf=False, stages=2):
+        """The same for a host cloud (N x 3 float32): consumed before the call returns."""
+        a = np.ascontiguousarray(xyz, np.float32)
+        self._call("prepare_source", _p(a), len(a), 3, int(k), int(regularization), 1 if rbf else 0, int(stages))
+
     def adopt_prepared_source(self):
         self._call("adopt_prepared_source")
 

@@ -866,7 +866,7 @@ int fvh_vgicp_align_wait(fvh_vgicp* h, fvh_lm_result* r) {
   if (rc == FVH_OK) h->e.quiet = true;
   return rc;
 }
-int fvh_vgicp_prepare_source_device(fvh_vgicp* h, const float* d_xyz, int n, int stride, int k, int regularization, int rbf, int stages) {
+static int vgicp_prepare(fvh_vgicp* h, const float* d_xyz, int n, int stride, bool on_device, int k, int regularization, int rbf, int stages) {
   CHECK_HANDLE_HOST_ONLY(h);  // (touches the prepared slot and the second stream only: legal between align_async and align_wait)
   Engine* e = &h->e;
   if (stages < 1 || stages > 3) return e->fail(FVH_ERR_INVALID_ARGUMENT, "prepare_source: stages must be 1 (order + neighbours), 2 (+ covariances) or 3 (+ voxel map)");
@@ -889,7 +889,7 @@ int fvh_vgicp_prepare_source_device(fvh_vgicp* h, const float* d_xyz, int n, int
   // chain 45 us); towards OTHER handles the registry keeps describing the LM kernel, the longer of the two.
   struct KeepEvent { Engine* e; ~KeepEvent() { e->gang_keep_event = false; } } keep_event{e};
   e->gang_keep_event = h->pending.active && ps != nullptr;
-  int rc = upload_cloud(e, h->next_source, d_xyz, n, stride, true, true, ps);
+  int rc = upload_cloud(e, h->next_source, d_xyz, n, stride, on_device, true, ps);
   if (rc || n == 0) return rc ? rc : e->fail(FVH_ERR_INVALID_ARGUMENT, "prepare_source: empty cloud");
   rc = ensure_sorted(e, h->next_source);
   if (rc) return rc;
@@ -909,6 +909,10 @@ int fvh_vgicp_prepare_source_device(fvh_vgicp* h, const float* d_xyz, int n, int
   h->next_ready = true;
   return FVH_OK;
 }
+int fvh_vgicp_prepare_source_device(fvh_vgicp* h, const float* d_xyz, int n, int stride, int k, int regularization, int rbf, int stages) { return vgicp_prepare(h, d_xyz, n, stride, true, k, regularization, rbf, stages); }
+// the same for a HOST cloud (what the reference's callers hold): consumed before the call returns (a memcpy into the handle's pinned staging
+// slot, as fvh_vgicp_set_source_cloud_strided), everything else queued on the second stream
+int fvh_vgicp_prepare_source(fvh_vgicp* h, const float* xyz, int n, int stride, int k, int regularization, int rbf, int stages) { return vgicp_prepare(h, xyz, n, stride, false, k, regularization, rbf, stages); }
 int fvh_vgicp_adopt_prepared_source(fvh_vgicp* h) {
   CHECK_HANDLE(h);  // (a map build swap_source_and_target() deferred runs here, in order on the main stream: queued on the second one it reached the LM kernel 10 us later -- measured)
   Engine* e = &h->e;

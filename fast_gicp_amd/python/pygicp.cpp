@@ -241,7 +241,14 @@ PYBIND11_MODULE(pygicp, m) {
       .def("set_regularization_method", [](VGICPCuda& v, const std::string& s) { v.setRegularizationMethod(regularization_method(s)); })
       .def("set_nearest_neighbor_search_method", [](VGICPCuda& v, const std::string& s) { v.setNearestNeighborSearchMethod(nn_method(s)); })
       // not in the reference: CPU_PARALLEL_KDTREE (the default enum value) is served by the device's exact search unless the host tree is asked for
-      .def("set_host_kdtree", &VGICPCuda::setHostKdTree, py::arg("on") = true);
+      .def("set_host_kdtree", &VGICPCuda::setHostKdTree, py::arg("on") = true)
+      // not in the reference: the scan stream as a two-stage pipeline (include/fast_vgicp_hip.h: fvh_vgicp_prepare_source / _align_async ...).
+      //   reg.align_async(); reg.prepare_next_source(next_scan); T = reg.align_wait(); reg.swap_source_and_target(); reg.adopt_prepared_source()
+      // The numpy conversion, the staging copy and the device's sort / k-NN / covariances of the next scan all run while the LM kernel of the current pair does.
+      .def("prepare_next_source", [](VGICPCuda& v, const Points& p, int stages) { v.prepareNextSource(numpy2cloud(p), stages); }, py::arg("points"), py::arg("stages") = 2)
+      .def("adopt_prepared_source", &VGICPCuda::adoptPreparedSource)
+      .def("align_async", [](VGICPCuda& v, const Mat4& initial_guess) { v.alignAsync(numpy2mat4(initial_guess)); }, py::arg("initial_guess") = identity4())
+      .def("align_wait", [](VGICPCuda& v) { return mat4_to_numpy(v.alignWait()); });
 
   py::class_<GICP, Lsq, std::shared_ptr<GICP>>(m, "FastGICP")  // main.cpp:183-190
       .def(py::init([](int device) { return std::make_shared<GICP>(device); }), py::arg("device") = 0)

@@ -548,11 +548,21 @@ public:
   void prepareNextSourceDevice(const float* d_xyz, int n, int stride_floats = 3, int stages = 2) {
     const int rbf = neighbor_search_method_ == NearestNeighborMethod::GPU_RBF_KERNEL ? 1 : 0;
     prepared_stages_ = stages;
+    prepared_cloud_.reset();
     call(fvh_vgicp_prepare_source_device(core_, d_xyz, n, stride_floats, k_correspondences_, (int)regularization_method_, rbf, stages), "prepare_source_device");
+  }
+  /// the same for a host cloud (consumed before the call returns); adoptPreparedSource() then makes it getInputSource()
+  void prepareNextSource(const PointCloudSourceConstPtr& cloud, int stages = 2) {
+    const int rbf = neighbor_search_method_ == NearestNeighborMethod::GPU_RBF_KERNEL ? 1 : 0;
+    prepared_stages_ = stages;
+    const detail::XyzView<PointSource> view(*cloud, scratch_xyz_);
+    call(fvh_vgicp_prepare_source(core_, view.data, (int)cloud->size(), view.stride, k_correspondences_, (int)regularization_method_, rbf, stages), "prepare_source");
+    prepared_cloud_ = cloud;
   }
   void adoptPreparedSource() {
     call(fvh_vgicp_adopt_prepared_source(core_), "adopt_prepared_source");
-    input_.reset();
+    input_ = prepared_cloud_;
+    prepared_cloud_.reset();
     if (prepared_stages_ < 2) {
       if (neighbor_search_method_ == NearestNeighborMethod::GPU_RBF_KERNEL) call(fvh_vgicp_calculate_source_covariances_rbf(core_, (int)regularization_method_), "calculate_source_covariances_rbf");
       else call(fvh_vgicp_calculate_source_covariances(core_, (int)regularization_method_), "calculate_source_covariances");
@@ -647,6 +657,7 @@ private:
   NearestNeighborMethod neighbor_search_method_ = NearestNeighborMethod::CPU_PARALLEL_KDTREE;    // :27
   bool host_kdtree_ = host_kdtree_default();                                                     // setHostKdTree
   int prepared_stages_ = 2;                                                                         // prepareNextSourceDevice
+  PointCloudSourceConstPtr prepared_cloud_;                                                         // prepareNextSource (host cloud): becomes input_ on adoption
   fvh_vgicp* core_ = nullptr;
   std::vector<float> scratch_xyz_;  // only used for point types that are not 12 / 16 bytes of packed xyz
 };

@@ -210,6 +210,7 @@ int fvh_vgicp_align(fvh_vgicp* h, const double* guess16, const fvh_lm_params* pa
 int fvh_vgicp_align_async(fvh_vgicp* h, const double* guess16, const fvh_lm_params* params);
 int fvh_vgicp_align_wait(fvh_vgicp* h, fvh_lm_result* result);
 int fvh_vgicp_prepare_source_device(fvh_vgicp* h, const float* d_xyz, int n, int stride_floats, int k, int regularization, int rbf, int stages);
+int fvh_vgicp_prepare_source(fvh_vgicp* h, const float* xyz, int n, int stride_floats, int k, int regularization, int rbf, int stages); /* a HOST cloud, consumed before the call returns */
 int fvh_vgicp_adopt_prepared_source(fvh_vgicp* h);
 /* setDebugPrint(true) on the device LM: with the trace on, an align records one row per trial step -- {inner iteration i, y0,
  * yi, rho, lambda, |d|}, the columns LsqRegistration prints (lsq_registration_impl.hpp:143-149) -- fetched afterwards
