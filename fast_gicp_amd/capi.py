@@ -638,6 +638,11 @@ class NDTCore(_Core):
         voxel map built, beside whatever runs on the main stream."""
         self._call("prepare_source_device", C.c_void_p(ptr), int(n), int(stride))
 
+    def prepare_source(self, xyz):
+        """The same for a host cloud (N x 3 float32): consumed before the call returns."""
+        a = np.ascontiguousarray(xyz, np.float32)
+        self._call("prepare_source", _p(a), len(a), 3)
+
     def adopt_prepared_source(self):
         self._call("adopt_prepared_source")
 

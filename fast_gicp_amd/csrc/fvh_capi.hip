@@ -1269,7 +1269,7 @@ int fvh_ndt_align_wait(fvh_ndt* h, fvh_lm_result* r) {
   if (h->distance_mode == FVH_NDT_P2D) return align_finish<MODE_NDT_P2D>(&h->e, h->pending, h->cost_source(), h->target_vm, r, h->rebuild_safe());
   return align_finish<MODE_NDT_D2D>(&h->e, h->pending, h->cost_source(), h->target_vm, r, h->rebuild_safe());
 }
-int fvh_ndt_prepare_source_device(fvh_ndt* h, const float* d_xyz, int n, int stride) {
+static int ndt_prepare(fvh_ndt* h, const float* d_xyz, int n, int stride, bool on_device) {
   CHECK_HANDLE_HOST_ONLY(h);  // (touches the prepared slot and the second stream only: legal between align_async and align_wait)
   Engine* e = &h->e;
   hipStream_t ps = e->side_stream();  // null (multi-GPU handle, FVH_SIDE_STREAM=0): in order on the main stream -- correct, nothing overlaps
@@ -1278,7 +1278,7 @@ int fvh_ndt_prepare_source_device(fvh_ndt* h, const float* d_xyz, int n, int str
   { const int rc0 = e->feeder_stream(&ps); if (rc0) return rc0; }  // (the main stream instead, behind an LM grid that crowds the chip: Engine::lm_crowds_chip)
   h->next_ready = false;
   h->next_vm.invalidate();
-  int rc = upload_cloud(e, h->next_source, d_xyz, n, stride, true, false, ps);
+  int rc = upload_cloud(e, h->next_source, d_xyz, n, stride, on_device, false, ps);
   if (rc) return rc;
   {
     // D2D registers the map itself; in both modes it is the TARGET map of the frame after (swap_source_and_target): built here it is
@@ -1291,6 +1291,8 @@ int fvh_ndt_prepare_source_device(fvh_ndt* h, const float* d_xyz, int n, int str
   h->next_ready = true;
   return FVH_OK;
 }
+int fvh_ndt_prepare_source_device(fvh_ndt* h, const float* d_xyz, int n, int stride) { return ndt_prepare(h, d_xyz, n, stride, true); }
+int fvh_ndt_prepare_source(fvh_ndt* h, const float* xyz, int n, int stride) { return ndt_prepare(h, xyz, n, stride, false); }  // a HOST cloud, consumed before the call returns
 int fvh_ndt_adopt_prepared_source(fvh_ndt* h) {
   CHECK_HANDLE(h);
   Engine* e = &h->e;

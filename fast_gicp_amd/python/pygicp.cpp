@@ -285,7 +285,12 @@ PYBIND11_MODULE(pygicp, m) {
         if (s == "P2D") n.setDistanceMode(NDTDistanceMode::P2D);
         else if (s == "D2D") n.setDistanceMode(NDTDistanceMode::D2D);
         else throw std::invalid_argument("unknown NDT distance mode " + s);
-      });
+      })
+      // not in the reference: the frame stream as a two-stage pipeline (as FastVGICPCuda's)
+      .def("prepare_next_source", [](NDT& n, const Points& p) { n.prepareNextSource(numpy2cloud(p)); }, py::arg("points"))
+      .def("adopt_prepared_source", &NDT::adoptPreparedSource)
+      .def("align_async", [](NDT& n, const Mat4& initial_guess) { n.alignAsync(numpy2mat4(initial_guess)); }, py::arg("initial_guess") = identity4())
+      .def("align_wait", [](NDT& n) { return mat4_to_numpy(n.alignWait()); });
 
   // testing hook: the host kd-tree behind NearestNeighborMethod::CPU_PARALLEL_KDTREE
   m.def("_kdtree_knn", [](const Points& points, int k) {

@@ -951,8 +951,14 @@ public:
   //     adoptPreparedSource(); alignAsync(); [filter frame k+1 on the prepare stream; prepareNextSourceDevice()]; alignWait(); swapSourceAndTarget();
   // The prepared source lives on the device only: getInputSource() is null for it and alignWait() returns the pose without
   // transforming a host cloud. Same kernels on the same data as the sequential calls: same registration.
-  void prepareNextSourceDevice(const float* d_xyz, int n, int stride_floats = 3) { call(fvh_ndt_prepare_source_device(core_, d_xyz, n, stride_floats), "prepare_source_device"); }
-  void adoptPreparedSource() { call(fvh_ndt_adopt_prepared_source(core_), "adopt_prepared_source"); input_.reset(); }
+  void prepareNextSourceDevice(const float* d_xyz, int n, int stride_floats = 3) { prepared_cloud_.reset(); call(fvh_ndt_prepare_source_device(core_, d_xyz, n, stride_floats), "prepare_source_device"); }
+  /// the same for a host cloud (consumed before the call returns); adoptPreparedSource() then makes it getInputSource()
+  void prepareNextSource(const PointCloudSourceConstPtr& cloud) {
+    const detail::XyzView<PointSource> view(*cloud, scratch_xyz_);
+    call(fvh_ndt_prepare_source(core_, view.data, (int)cloud->size(), view.stride), "prepare_source");
+    prepared_cloud_ = cloud;
+  }
+  void adoptPreparedSource() { call(fvh_ndt_adopt_prepared_source(core_), "adopt_prepared_source"); input_ = prepared_cloud_; prepared_cloud_.reset(); }
   void alignAsync(const Matrix4f& guess = Matrix4f::Identity()) {
     double g16[16];
     Isometry3d::from(guess).to_colmajor16(g16);
@@ -1017,6 +1023,7 @@ protected:
 private:
   fvh_ndt* core_ = nullptr;
   std::vector<float> scratch_xyz_;
+  PointCloudSourceConstPtr prepared_cloud_;  // prepareNextSource (host cloud): becomes input_ on adoption
 };
 
 }  // namespace fast_gicp

@@ -350,6 +350,7 @@ int fvh_ndt_align(fvh_ndt* h, const double* guess16, const fvh_lm_params* params
 int fvh_ndt_align_async(fvh_ndt* h, const double* guess16, const fvh_lm_params* params);
 int fvh_ndt_align_wait(fvh_ndt* h, fvh_lm_result* result);
 int fvh_ndt_prepare_source_device(fvh_ndt* h, const float* d_xyz, int n, int stride_floats);
+int fvh_ndt_prepare_source(fvh_ndt* h, const float* xyz, int n, int stride_floats); /* the same for a HOST cloud, consumed before the call returns */
 int fvh_ndt_adopt_prepared_source(fvh_ndt* h);
 int fvh_ndt_fitness_score(fvh_ndt* h, const double* T16, double max_range, double* score);
 /* testing hook (as fvh_vgicp_debug_set_voxel_hint): table size hint of the NEXT build of the source (which = 0) / target (1) voxel map */

@@ -312,3 +312,34 @@ def test_pipelined_calls_of_the_class_equal_the_sequential_loop():
         reg.swap_source_and_target()
         if i + 1 < 5:
             reg.adopt_prepared_source()
+
+
+def test_pipelined_calls_of_ndt_equal_the_sequential_loop():
+    """NDTCuda.align_async / prepare_next_source / align_wait / adopt_prepared_source on host clouds (not in the reference)."""
+    import pygicp
+    from tests import util
+    frames = [pygicp.downsample(util.lidar_frame(i).astype(np.float64), 0.25) for i in range(5)]
+
+    def make():
+        reg = pygicp.NDTCuda()
+        reg.set_resolution(1.0); reg.set_neighbor_search_method("DIRECT7"); reg.set_distance_mode("D2D")
+        reg.set_input_target(frames[0])
+        return reg
+
+    reg = make()
+    seq = []
+    for i in range(1, 5):
+        reg.set_input_source(frames[i])
+        seq.append(reg.align().copy())
+        reg.swap_source_and_target()
+    reg = make()
+    reg.prepare_next_source(frames[1])
+    for i in range(1, 5):
+        reg.adopt_prepared_source()
+        reg.align_async()
+        if i + 1 < 5:
+            reg.prepare_next_source(frames[i + 1])
+        T = reg.align_wait()
+        assert reg.has_converged()
+        assert np.abs(T - seq[i - 1]).max() < 1e-6, i
+        reg.swap_source_and_target()
