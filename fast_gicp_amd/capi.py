@@ -38,7 +38,7 @@ class EngineParams(C.Structure):
                 ("peer_watchdog_ticks", C.c_ulonglong), ("lm_everywhere", C.c_int), ("cost_prio", C.c_int), ("cost_split", C.c_int), ("cost_group_max", C.c_int),
                 ("cost_max_blocks", C.c_int), ("cost_target_items", C.c_longlong), ("zerocopy_result", C.c_int), ("host_wait_block", C.c_int),
                 ("result_query_spins", C.c_ulonglong), ("side_stream", C.c_int), ("pinned_upload_max", C.c_ulonglong), ("zerocopy_upload_max", C.c_ulonglong),
-                ("avg_fused", C.c_int)]
+                ("avg_fused", C.c_int), ("nn1_seed", C.c_int)]
 
 
 def default_engine_params():

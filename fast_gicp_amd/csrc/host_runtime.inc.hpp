@@ -71,6 +71,7 @@ inline const fvh_engine_params& env_engine_defaults() {
     p.pinned_upload_max = fvh_env_ull("FVH_PINNED_UPLOAD_MAX", 8ull << 20);
     p.zerocopy_upload_max = fvh_env_ull("FVH_ZEROCOPY_UPLOAD_MAX", 1ull << 20);
     p.avg_fused = fvh_env_ll("FVH_AVG_FUSED", 1) != 0 ? 1 : 0;
+    p.nn1_seed = fvh_env_ll("FVH_NN1_SEED", 1) != 0 ? 1 : 0;
     return p;
   }();
   return d;

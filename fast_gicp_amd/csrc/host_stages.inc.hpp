@@ -1125,7 +1125,8 @@ int do_align(Engine* e, const CostSource& src, VoxelMapDev& vm, const double* gu
 
 // exact 1-NN of every (transformed) source point in the target (kernels_cov.hpp: nn1_rows_kernel -- four queries per wave, one per 16-lane row)
 void launch_nn1(Engine* e, const CloudDev& src, const CloudDev& tgt, const float* T12, double thr_sq, int* corr, float* best_out, const LmLink& lm) {
-  nn1_rows_kernel<<<(src.n + 15) / 16, 256, 0, e->stream>>>(src.sorted.as<float4>(), src.n, tgt.sorted.as<float4>(), tgt.bbox.as<float4>(), tgt.bbox2.as<float4>(), tgt.n, T12, thr_sq, corr, best_out, lm);
+  nn1_rows_kernel<<<(src.n + 15) / 16, 256, 0, e->stream>>>(src.sorted.as<float4>(), src.n, tgt.sorted.as<float4>(), tgt.bbox.as<float4>(), tgt.bbox2.as<float4>(), tgt.n, T12, thr_sq, corr, best_out, lm,
+                                                            e->params.nn1_seed ? tgt.pts.as<float4>() : nullptr);
 }
 
 int do_fitness(Engine* e, CloudDev& src, CloudDev& tgt, const double* T16, double max_range, double* score) {

@@ -1373,16 +1373,18 @@ __device__ __forceinline__ unsigned long long row_min_u64(unsigned long long k) 
   k = row_min_step64<0xB1>(k); k = row_min_step64<0x4E>(k); k = row_min_step64<0x141>(k); k = row_min_step64<0x140>(k);
   return k;
 }
-__global__ __launch_bounds__(256) void nn1_rows_kernel(const float4* __restrict__ ssrc, int ns, const float4* __restrict__ stgt, const float4* __restrict__ bbox1,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 8))) void nn1_rows_kernel(const float4* __restrict__ ssrc, int ns, const float4* __restrict__ stgt, const float4* __restrict__ bbox1,
                                                        const float4* __restrict__ bbox2, int nt, const float* __restrict__ T12, double thr_sq, int* __restrict__ corr,
                                                        float* __restrict__ best_out = nullptr /* getFitnessScore: squared NN distance per query, in the order of ssrc */,
-                                                       LmLink lm = LmLink{nullptr, nullptr, nullptr, nullptr, 0} /* device LM (FastGICP): pose and output buffer follow the LM state on the device */) {
+                                                       LmLink lm = LmLink{nullptr, nullptr, nullptr, nullptr, 0} /* device LM (FastGICP): pose and output buffer follow the LM state on the device */,
+                                                       const float4* __restrict__ tpts = nullptr /* the target in ORIGINAL order: the id this row found last time seeds the bound (see below) */) {
   const int rl = threadIdx.x & 15;                                  // lane within the row
   const int q = (blockIdx.x * 256 + (int)threadIdx.x) >> 4;         // this row's query (position in the source's Morton order)
   if (q >= ns) return;                                              // (whole rows)
   const int ntiles = (nt + 63) >> 6, nsuper = (ntiles + 63) >> 6;
   const float4 qv = ssrc[q];
   float Tl[12];
+  const int* seed_ids = corr;  // what this buffer held before this search (the host-driven route: the correspondences of the last call)
   if (lm.phase) {
     // device-resident LM loop: this search belongs to the linearisation the NEXT cost launch will run -- at x0 into the current
     // correspondence buffer (PH_LINEARIZE), or speculatively at the trial pose xi into the other one (fused PH_TRIAL)
@@ -1390,6 +1392,7 @@ __global__ __launch_bounds__(256) void nn1_rows_kernel(const float4* __restrict_
     if (phase == 2 /* PH_DONE */) return;
     const double* pose = (phase == 0 /* PH_LINEARIZE */) ? lm.x0 : lm.xi;
     const int sel = (phase == 1 /* PH_TRIAL */) ? (*lm.corr_cur ^ 1) : *lm.corr_cur;
+    seed_ids = corr + (size_t)*lm.corr_cur * lm.corr_stride;  // the ids of the last accepted linearisation
     corr += (size_t)sel * lm.corr_stride;
 #pragma unroll
     for (int r = 0; r < 3; r++) {  // trans.cast<float>() (fast_gicp_impl.hpp:121)
@@ -1401,6 +1404,17 @@ __global__ __launch_bounds__(256) void nn1_rows_kernel(const float4* __restrict_
   }
   const float qx = transform_row_nofma(qv, Tl + 0), qy = transform_row_nofma(qv, Tl + 4), qz = transform_row_nofma(qv, Tl + 8);
   unsigned long long best = 0x7f800000ffffffffull;  // (distance bits, original index): +inf and the largest index -- above every candidate, below every NaN distance (never taken)
+  // Seed: between two LM transitions the pose moves by millimetres and nearly every point keeps its neighbour. The point this row found LAST
+  // time is a candidate like any other -- its key under the NEW pose is an upper bound from the start, and the walk below visits only what
+  // can still beat (or tie) it. Whatever the buffer holds (another pair's ids after a swap, nothing at all) is harmless: any index inside the
+  // target is a real candidate, anything else is ignored. The result is the minimum over the same total order: identical ids.
+  if (tpts && seed_ids) {
+    const int si = seed_ids[__float_as_int(qv.w)];
+    if ((unsigned)si < (unsigned)nt) {
+      const unsigned long long sk = knn_key(sqdist_nofma(tpts[si], qx, qy, qz), si);
+      best = sk < best ? sk : best;
+    }
+  }
   // the 64 points of a tile, 16 per step, against the row's query; afterwards every lane of the row holds the row's minimum
   auto sweep = [&](int tile) __attribute__((always_inline)) {
     const int base = tile << 6;

@@ -114,6 +114,8 @@ typedef struct fvh_engine_params {
   unsigned long long zerocopy_upload_max;/* ... and up to this many are read by the widening kernel straight over PCIe (1 MiB) */
   /* ApproximateVoxelGrid */
   int avg_fused;                         /* 1 (default): four launches up to 262,144 points; 0: round 2's six */
+  /* exact 1-NN search (FastGICP correspondences) */
+  int nn1_seed;                          /* 1 (default): the id a point found last time seeds the bound of its next search (identical ids); 0: every search from scratch */
 } fvh_engine_params;
 void fvh_default_engine_params(fvh_engine_params* p);
 
