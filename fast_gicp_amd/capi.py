@@ -97,6 +97,10 @@ def _lm_params(max_iterations=64, rotation_epsilon=2e-3, transformation_epsilon=
     return LmParams(max_iterations, rotation_epsilon, transformation_epsilon, lm_max_iterations, lm_init_lambda_factor, optimizer)
 
 
+_IDENTITY16 = np.ascontiguousarray(np.eye(4))  # the default guess / parameters of align(): built once (these calls sit between two LM kernels, with the GPU idle)
+_DEFAULT_LM = _lm_params()
+
+
 def _result_dict(r):
     # one view over the struct's 52 leading doubles (the arrays keep `r` alive): this runs between an align and the next launch,
     # with the GPU idle
@@ -202,8 +206,8 @@ class _Core:
         return self.compute_error(T, True)
 
     def align(self, guess=None, **lm):
-        g = _colmajor16(np.eye(4) if guess is None else guess)
-        p = _lm_params(**lm)
+        g = _IDENTITY16 if guess is None else _colmajor16(guess)
+        p = _lm_params(**lm) if lm else _DEFAULT_LM
         r = LmResult()
         self._call("align", _p(g), C.byref(p), C.byref(r))
         return _result_dict(r)
@@ -298,8 +302,8 @@ class VGICPCore(_Core):
     # ---- pipelined scan streams (include/fast_vgicp_hip.h: fvh_vgicp_align_async ...) ----
     def align_async(self, guess=None, **lm):
         """Launch the LM kernel and return; align_wait() collects the result. In between only prepare_source_device() may be used."""
-        self._g = _colmajor16(np.eye(4) if guess is None else guess)
-        self._lm = _lm_params(**lm)
+        self._g = _IDENTITY16 if guess is None else _colmajor16(guess)
+        self._lm = _lm_params(**lm) if lm else _DEFAULT_LM
         self._call("align_async", _p(self._g), C.byref(self._lm))
 
     def align_wait(self):
@@ -479,8 +483,8 @@ class VGICPCore(_Core):
         return self.gicp_compute_error(T, True)
 
     def gicp_align(self, guess=None, **lm):
-        g = _colmajor16(np.eye(4) if guess is None else guess)
-        p = _lm_params(**lm)
+        g = _IDENTITY16 if guess is None else _colmajor16(guess)
+        p = _lm_params(**lm) if lm else _DEFAULT_LM
         r = LmResult()
         self._call("gicp_align", _p(g), C.byref(p), C.byref(r))
         return _result_dict(r)
@@ -624,8 +628,8 @@ class NDTCore(_Core):
     def align_async(self, guess=None, **lm):
         """Launch the LM kernel and return; align_wait() collects the result. In between only prepare_source_device() (and a VoxelGrid
         that shares the prepare stream) may be used on this handle."""
-        self._g = _colmajor16(np.eye(4) if guess is None else guess)
-        self._lm = _lm_params(**lm)
+        self._g = _IDENTITY16 if guess is None else _colmajor16(guess)
+        self._lm = _lm_params(**lm) if lm else _DEFAULT_LM
         self._call("align_async", _p(self._g), C.byref(self._lm))
 
     def align_wait(self):
