@@ -283,13 +283,10 @@ struct Engine {
     gang_launching.fetch_add(1, std::memory_order_acq_rel);
     return true;
   }
-  bool gang_keep_event = false;  // fvh_vgicp_prepare_source_device beside an LM kernel in flight: `gang_done` keeps describing that kernel (the longer one)
   void gang_end() {  // the gang kernel (and whatever must follow it) is queued
     if (!counted) return;
-    if (!gang_keep_event) {
-      (void)hipEventRecord(gang_done, stream);
-      gang_open.store(true, std::memory_order_release);
-    }
+    (void)hipEventRecord(gang_done, stream);
+    gang_open.store(true, std::memory_order_release);
     gang_launching.fetch_sub(1, std::memory_order_acq_rel);
   }
   void gang_clear() { if (counted) gang_open.store(false, std::memory_order_release); }  // the caller holds the result of an align / drained the stream: nothing of this handle is in flight
@@ -884,11 +881,12 @@ static int vgicp_prepare(fvh_vgicp* h, const float* d_xyz, int n, int stride, bo
   // the second one. The scratch they use (sort keys / histograms, the RBF sums) is not touched by a running LM kernel.
   struct StreamSwap { Engine* e; hipStream_t main; ~StreamSwap() { e->stream = main; } } swap{e, e->stream};
   if (ps) e->stream = ps;
-  // The cooperative sort runs beside this handle's own LM kernel (32 workgroups next to a grid that leaves a third of every CU's registers
-  // free; neither waits for the other: measured, no watchdog abort in 10^4 registrations, and the one-workgroup sort would cost the
-  // chain 45 us); towards OTHER handles the registry keeps describing the LM kernel, the longer of the two.
-  struct KeepEvent { Engine* e; ~KeepEvent() { e->gang_keep_event = false; } } keep_event{e};
-  e->gang_keep_event = h->pending.active && ps != nullptr;
+  // Beside a running LM kernel the cloud is sorted by the multi-kernel radix passes, not by the cooperative kernel: that kernel's finish /
+  // fall-back kernel is a 1,024-thread workgroup at 120 VGPRs (it holds the whole one-workgroup sort), which fits on no CU that hosts LM
+  // workgroups -- it sat in the queue until the LM kernel ended (kernel trace: 97 us instead of 4.3), and the neighbour search and the
+  // covariances behind it ran AFTER the LM kernel instead of beside it: 5,760 registrations/s against 6,990 with the passes.
+  struct SortMode { Engine* e; int saved; ~SortMode() { e->params.sort_mode = saved; } } sort_mode{e, e->params.sort_mode};
+  if (h->pending.active && ps != nullptr) e->params.sort_mode = 0;
   int rc = upload_cloud(e, h->next_source, d_xyz, n, stride, on_device, true, ps);
   if (rc || n == 0) return rc ? rc : e->fail(FVH_ERR_INVALID_ARGUMENT, "prepare_source: empty cloud");
   rc = ensure_sorted(e, h->next_source);

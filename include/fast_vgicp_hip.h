@@ -204,8 +204,10 @@ int fvh_vgicp_align(fvh_vgicp* h, const double* guess16, const fvh_lm_params* pa
  *                                    a map prepared with it travels with the cloud, and the next fvh_vgicp_swap_source_and_target makes
  *                                    that map the live one instead of building it ([VCU]:102-104's rebuild, already done).
  * The loop:  align_async; prepare_source_device(next scan); align_wait; swap_source_and_target; adopt_prepared_source.
- * Same kernels on the same data as the sequential calls (measured: bit-identical poses). Which `stages` pays depends on how long the LM
- * kernel runs: the prepared chain is slower beside it (the bundled 17k pair: 2 is best, +12 %; 3 makes the chain the longer stage).
+ * The results are the sequential calls': with k-NN covariances bit for bit; RBF covariances are float sums in the cloud's spatial order, and a
+ * cloud prepared beside a running LM kernel is ordered by the radix passes (a finer Morton key than the cooperative sort's, whose 1,024-thread
+ * finish kernel fits on no CU that hosts LM workgroups): their last bits differ, poses agree to 1e-9. The bundled 17k pair: stages 2 is
+ * best (+37 % registrations/s over the sequential loop), 3 and 1 within 4 % of it.
  * swap_source_and_target() on ANY handle now keeps the old target's map with its cloud: swapping back costs nothing, unless that cloud's
  * covariances changed after the map was built (then it is rebuilt, as the reference would).
  * Not on a multi-GPU handle (FVH_ERR_UNSUPPORTED). */

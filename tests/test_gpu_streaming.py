@@ -195,7 +195,7 @@ def test_pipelined_vgicp_scan_stream_equals_the_sequential_loop(frames, stages, 
     and (stages = 3) its own voxel map computed on the handle's second stream while the LM kernel of scan k runs; swap_source_and_target()
     then takes the map that came with the scan instead of building one (kitti.cpp:95-128 with FastVGICPCuda, one stage ahead).
     Same kernels on the same data as the sequential calls: equal iteration counts, the voxel map of every registration equal to the
-    sequential loop's (counts exactly, means / covariances to the order of their fp64 atomics), poses within 1e-9."""
+    sequential loop's (counts exactly, means / covariances to the order of their fp64 atomics), poses within 1e-9 (RBF covariances: 1e-7, see below)."""
     import torch
     from fast_gicp_amd import capi
     dev = torch.device("cuda", 0)
@@ -243,7 +243,10 @@ def test_pipelined_vgicp_scan_stream_equals_the_sequential_loop(frames, stages, 
         T, H, err, nl, ne = seq[i - 1]
         assert r["converged"] and r["num_launches"] == 1
         assert (r["num_linearize"], r["num_error_evals"]) == (nl, ne), i
-        assert util.rel_err(r["T"], T) < 1e-9 and util.rel_err(r["H"], H) < 1e-9 and abs(r["final_error"] - err) <= 1e-9 * abs(err), i
+        # (RBF covariances are float sums over the candidates in the cloud's SPATIAL order; a preparation beside a running LM kernel orders the
+        #  cloud with the radix passes -- a finer Morton key than the cooperative sort's -- so those sums differ in their last bits: 1e-9 of H observed)
+        tol = 1e-7 if rbf else 1e-9
+        assert util.rel_err(r["T"], T) < tol and util.rel_err(r["H"], H) < tol and abs(r["final_error"] - err) <= tol * abs(err), i
         got, want = _vgicp_voxels(c), seq_maps[i - 1]
         assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1]), i
         assert np.allclose(got[2], want[2], rtol=0, atol=1e-5) and np.allclose(got[3], want[3], rtol=1e-5, atol=1e-7), i
