@@ -111,6 +111,10 @@ int ensure_sorted(Engine* e, CloudDev& c) {
     // two gang kernels from two streams could starve each other of CU slots; the watchdog + fallback would recover, slowly)
     const bool coop = c.has_box && (sort_mode == 3 ? e->gang_begin(false) : (sort_mode == 2 && e->gang_begin(true)));  // (mode 1: never -- other PROCESSES' gang kernels on a shared GPU are invisible to the registry)
     struct GangEnd { Engine* e; bool on; ~GangEnd() { if (on) e->gang_end(); } } gang_end{e, coop};  // (on every way out: the event behind whatever was queued)
+    // Mode 2, refused (another handle's gang kernel holds CU slots right now): NOT the one-workgroup sort -- 1,024 threads x 120 VGPRs fit on no CU
+    // that hosts LM workgroups, it waits in the queue until one of those kernels ends (kernel trace, HISTORY.md) -- but the radix passes below,
+    // whose 256-thread workgroups are placed anywhere (four concurrent handles: 5,710 -> 6,310 registrations/s).
+    if (coop || sort_mode != 2) {
     g_sort_routes[coop ? 0 : 1].fetch_add(1, std::memory_order_relaxed);
     if (coop) {
       const bool fresh = e->sort_coop.p == nullptr;
@@ -138,6 +142,7 @@ int ensure_sorted(Engine* e, CloudDev& c) {
     HIP_OR_FAIL(e, hipGetLastError());
     c.has_sorted = true;
     return FVH_OK;
+    }
   }
   // Large clouds: 27-bit Morton keys, stable LSD radix sort. Every kernel of this chain is a dependent stage of >= 5 us whatever it
   // does (a 100k-point cloud is 400 KB of keys): the first histogram kernel computes the keys itself and both box levels come out

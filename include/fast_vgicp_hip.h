@@ -83,7 +83,7 @@ int fvh_device_count(int* count);
 typedef struct fvh_engine_params {
   int struct_size;                       /* sizeof(fvh_engine_params) of the caller's header: set by fvh_default_engine_params, checked by the setters */
   /* Morton sort of a cloud */
-  int sort_mode;                         /* 0 multi-kernel radix, 1 one workgroup, 2 cooperative kernel while no other handle has a gang kernel in flight (default), 3 cooperative always */
+  int sort_mode;                         /* 0 multi-kernel radix, 1 one workgroup, 2 cooperative kernel while no other handle has a gang kernel in flight, else the radix passes (default), 3 cooperative always */
   int sort_items;                        /* points per wave of the radix passes; 0 = by cloud size */
   int sort_fused_bits;                   /* two-launch passes (32k..256k points): 10 (default) or 9 key bits per pass, 0 = four-launch passes */
   int sort_two_pass_max;                 /* clouds up to this size take two 11-bit four-launch passes (262,144) */
