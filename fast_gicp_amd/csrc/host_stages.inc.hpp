@@ -113,8 +113,10 @@ int ensure_sorted(Engine* e, CloudDev& c) {
     struct GangEnd { Engine* e; bool on; ~GangEnd() { if (on) e->gang_end(); } } gang_end{e, coop};  // (on every way out: the event behind whatever was queued)
     // Mode 2, refused (another handle's gang kernel holds CU slots right now): NOT the one-workgroup sort -- 1,024 threads x 120 VGPRs fit on no CU
     // that hosts LM workgroups, it waits in the queue until one of those kernels ends (kernel trace, HISTORY.md) -- but the radix passes below,
-    // whose 256-thread workgroups are placed anywhere (four concurrent handles: 5,710 -> 6,310 registrations/s).
-    if (coop || sort_mode != 2) {
+    // whose 256-thread workgroups are placed anywhere (four concurrent handles: 5,710 -> 6,310 registrations/s). Not on a multi-GPU handle: the
+    // ranks cut the SAME Morton order into tiles, and the passes sort by a finer key than the cooperative / one-workgroup sorts (two handles
+    // of one process, one refused and one not, would disagree about the tiles).
+    if (coop || sort_mode != 2 || e->sharded()) {
     g_sort_routes[coop ? 0 : 1].fetch_add(1, std::memory_order_relaxed);
     if (coop) {
       const bool fresh = e->sort_coop.p == nullptr;
