@@ -6,6 +6,43 @@ sys.path.insert(0, ROOT)
 import torch
 from fast_gicp_amd import capi, preprocess
 
+if len(sys.argv) > 2 and sys.argv[2].startswith("ndt"):
+    # the LiDAR frame stream (bench.py --workload lidar_stream): raw 118k-point frames, ApproximateVoxelGrid 0.25 on the device, NDT D2D DIRECT7
+    from tests import util
+    iters = int(sys.argv[1]); mode = sys.argv[2]
+    gpu = torch.device("cuda", 0)
+    raw = [util.lidar_frame(i) for i in range(8)]
+    d_raw = [torch.from_numpy(f).to(gpu).contiguous() for f in raw]
+    vg, c = capi.VoxelGrid(0), capi.NDTCore(0)
+    c.set_distance_mode(1); c.set_neighbor_search_method(1); c.set_resolution(1.0)
+    ptr, n = vg.filter_device(d_raw[0].data_ptr(), len(raw[0]), 0.25)
+    c.set_target_cloud_device(ptr, n, 3)
+    ts = np.zeros(iters)
+    if mode == "ndt_seq":
+        for it in range(iters):
+            i = 1 + it % 7
+            t0 = time.perf_counter()
+            ptr, n = vg.filter_device(d_raw[i].data_ptr(), len(raw[i]), 0.25)
+            c.set_source_cloud_device(ptr, n, 3)
+            c.align()
+            c.swap_source_and_target()
+            ts[it] = time.perf_counter() - t0
+    else:
+        vg.share_prepare_stream(c)
+        ptr, n = vg.filter_device(d_raw[1].data_ptr(), len(raw[1]), 0.25, asynchronous=True)
+        c.prepare_source_device(ptr, n, 3)
+        for it in range(iters):
+            i = 1 + (it + 1) % 7
+            t0 = time.perf_counter()
+            c.adopt_prepared_source()
+            c.align_async()
+            ptr, n = vg.filter_device(d_raw[i].data_ptr(), len(raw[i]), 0.25, asynchronous=True)
+            c.prepare_source_device(ptr, n, 3)
+            c.align_wait()
+            c.swap_source_and_target()
+            ts[it] = time.perf_counter() - t0
+    print(mode, "iterations", iters, "median %.1f us" % (np.median(ts) * 1e6), "mean %.1f us" % (ts.mean() * 1e6))
+    sys.exit(0)
 tgt, src = preprocess.bundled_pair(os.path.join(ROOT, "data"))
 gpu = torch.device("cuda", 0)
 cl = [tgt, src]

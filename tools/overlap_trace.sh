@@ -4,7 +4,7 @@
 set -u
 R=${GRAFT_REPO_ROOT:-$(pwd)}; O=$R/gpurun_out/overlap; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp && cd $R
-for m in seq pipe; do
+for m in ${MODES:-seq pipe}; do
   timeout 200 rocprofv3 --kernel-trace --stats -d $O/t_$m -o h -- python tools/hiccup_probe.py 600 $m > $O/$m.out 2> $O/$m.err < /dev/null
   f=$(find $O/t_$m -name "*.db" | head -1)
   if [ -n "$f" ]; then
