@@ -260,6 +260,11 @@ struct Engine {
       std::lock_guard<std::mutex> lk(g_gangs.mu);
       g_gangs.engines.push_back(this);
       counted = true;
+      // the second stream of a registration handle is made HERE, with the handle ("warming up GPU"): made by the first swap_source_and_target()
+      // it put 9 ms into the first registration of the caller's loop (apps/gicp_align: the 100times_reuse figure of a handle's first row)
+      if (side_stream()) {
+        if ((e = hipStreamSynchronize(side)) != hipSuccess) return hipfail(e, "hipStreamSynchronize");
+      }
     }
     return FVH_OK;
   }
