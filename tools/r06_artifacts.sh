@@ -19,7 +19,7 @@ WL[bundled17k]="--steps 40 --warmup 5 $COMMON"
 WL[synth100k_rbf]="--workload synth100k --cov rbf --steps 25 --warmup 3 $COMMON"
 WL[synth1m]="--workload synth1m --steps 25 --warmup 3 $COMMON"
 WL[lidar_stream]="--workload lidar_stream --steps 40 --warmup 5 --no-cpu-baseline --no-profile"
-WL[fgicp17k]="--workload fgicp17k --steps 30 --warmup 5 --no-cpu-baseline --no-profile"
+WL[fgicp17k]="--workload fgicp17k --steps 30 --warmup 5 --no-cpu-baseline --no-profile --no-pipelined-leg"
 SQ="SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_INSTS_VALU GRBM_GUI_ACTIVE"
 if [ "$WHAT" = "pmc" ] || [ "$WHAT" = "all" ]; then
   SPECS=""
