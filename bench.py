@@ -1093,7 +1093,7 @@ def run_registration(args, workload, cov, search_name, steps, warmup, local_rank
 
         def pstep():
             i = state["next"]  # the cloud that becomes the source next = the one that is the target now
-            core.align_async()
+            core.align_async()  # (first: with the preparation queued BEFORE the LM kernel the kernel's dispatch waits behind the chain's first kernels -- 7,020 -> 6,580)
             core.prepare_source_device(d_ptrs[i], n_pts[i], 3, K, capi.REG_PLANE, rbf, PSTAGES)
             state["last"] = core.align_wait()
             core.swap_source_and_target()

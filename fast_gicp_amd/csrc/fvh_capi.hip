@@ -891,7 +891,7 @@ static int vgicp_prepare(fvh_vgicp* h, const float* d_xyz, int n, int stride, bo
   // workgroups -- it sat in the queue until the LM kernel ended (kernel trace: 97 us instead of 4.3), and the neighbour search and the
   // covariances behind it ran AFTER the LM kernel instead of beside it: 5,760 registrations/s against 6,990 with the passes.
   struct SortMode { Engine* e; int saved; ~SortMode() { e->params.sort_mode = saved; } } sort_mode{e, e->params.sort_mode};
-  if (h->pending.active && ps != nullptr) e->params.sort_mode = 0;
+  if (ps != nullptr) e->params.sort_mode = 0;  // (also when the align is launched right AFTER this call: the chain then runs beside it all the same)
   int rc = upload_cloud(e, h->next_source, d_xyz, n, stride, on_device, true, ps);
   if (rc || n == 0) return rc ? rc : e->fail(FVH_ERR_INVALID_ARGUMENT, "prepare_source: empty cloud");
   rc = ensure_sorted(e, h->next_source);
