@@ -745,6 +745,7 @@ def run_stream(args, steps, warmup, cpu_loops=15, frames_n=10):
     # the filter runs on the registration handle's stream and reports its count one kernel early (fvh_voxelgrid_filter_device_async):
     # upload, map build and LM kernel are queued behind its last kernel while that kernel runs
     shared = os.environ.get("FVH_BENCH_STREAM_SYNC", "0") != "1"  # (A/B knob: 1 = the filter on its own stream, synchronous count)
+    TAKE = os.environ.get("FVH_BENCH_TAKE_FILTER_OUTPUT", "1") != "0"  # (A/B knob: 0 = device pointer + widening kernel, as before round 6's last day)
     if shared:
         vg.share_stream(ndt)
 
@@ -752,7 +753,10 @@ def run_stream(args, steps, warmup, cpu_loops=15, frames_n=10):
         state["k"] += 1
         i = seq[state["k"] % len(seq)]
         ptr, n = vg.filter_device(d_frames[i].data_ptr(), len(frames[i]), 0.25, vg.APPROXIMATE, asynchronous=shared)
-        ndt.set_source_cloud_device(ptr, n, 3)
+        if TAKE:
+            ndt.set_source_cloud_from_voxelgrid(vg)  # the filter's float4 output IS the cloud: no widening kernel (fvh_ndt_set_source_cloud_from_voxelgrid)
+        else:
+            ndt.set_source_cloud_device(ptr, n, 3)
         state["last"] = ndt.align()
         ndt.swap_source_and_target()
         state["n_ds"] += n
@@ -886,7 +890,10 @@ def run_stream(args, steps, warmup, cpu_loops=15, frames_n=10):
 
         def prepare(i):
             ptr, n = vg.filter_device(ptrs[i], lens[i], 0.25, vg.APPROXIMATE, asynchronous=True)
-            ndt.prepare_source_device(ptr, n, 3)
+            if TAKE:
+                ndt.prepare_source_from_voxelgrid(vg)
+            else:
+                ndt.prepare_source_device(ptr, n, 3)
 
         def run(count):
             r = None

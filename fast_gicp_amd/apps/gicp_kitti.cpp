@@ -111,8 +111,8 @@ int main(int argc, char** argv) {
       int n = 0;
       const float* d_xyz = nullptr;
       detail::check(fvh_voxelgrid_filter_strided(vg, FVH_VOXELGRID_APPROXIMATE, xyzi.data(), (int)(xyzi.size() / 4), 4, downsample_resolution, &n), "fvh_voxelgrid_filter_strided", fvh_voxelgrid_last_error(vg));
-      detail::check(fvh_voxelgrid_device_points(vg, &d_xyz, &n), "fvh_voxelgrid_device_points", fvh_voxelgrid_last_error(vg));
-      ndt.prepareNextSourceDevice(d_xyz, n, 3);
+      (void)d_xyz;
+      ndt.prepareNextSourceFromFilter(vg);  // (the filter's float4 output becomes the cloud: no widening kernel)
     };
     std::vector<Isometry3d> poses(kitti.size());
     poses[0] = Isometry3d::Identity();

@@ -647,6 +647,16 @@ class NDTCore(_Core):
         a = np.ascontiguousarray(xyz, np.float32)
         self._call("prepare_source", _p(a), len(a), 3)
 
+    # ---- the filter's last ApproximateVoxelGrid output becomes the cloud without a copy (fvh_ndt_*_from_voxelgrid) ----
+    def set_source_cloud_from_voxelgrid(self, vg):
+        self._call("set_source_cloud_from_voxelgrid", vg._h)
+
+    def set_target_cloud_from_voxelgrid(self, vg):
+        self._call("set_target_cloud_from_voxelgrid", vg._h)
+
+    def prepare_source_from_voxelgrid(self, vg):
+        self._call("prepare_source_from_voxelgrid", vg._h)
+
     def adopt_prepared_source(self):
         self._call("adopt_prepared_source")
 

@@ -141,6 +141,7 @@ struct Engine {
   static bool crowds(int blocks, int capacity) { return (long long)blocks * 4 > (long long)capacity * 3; }
   bool feeder_on_main = false;       // where the last preparation / prepare-stream filter was queued
   hipEvent_t flip_ev = nullptr;
+  hipEvent_t take_ev = nullptr;      // take_filter_output: orders the consuming stream after the filter's
   // the stream a preparation (or a filter that feeds one) is queued on: the second stream (*out = that stream), or -- no second stream, or a
   // crowding grid in flight -- the main one (*out = null). When the choice flips, the new stream is ordered after what the old one holds.
   int feeder_stream(hipStream_t* out) {
@@ -313,6 +314,7 @@ struct Engine {
     peer.err.release();
     prof.destroy();
     if (flip_ev) { (void)hipEventDestroy(flip_ev); flip_ev = nullptr; }
+    if (take_ev) { (void)hipEventDestroy(take_ev); take_ev = nullptr; }
     gather_stage.release(); lm_trace.release(); fit_best.release(); sort_coop.release(); rbf_sums.release(); bcast.release(); offsets_dev.release(); state.release(); partials.release(); ticket.release(); corr.release(); misc.release(); fit.release(); staging.release(); sort_keys.release(); sort_idx.release(); sort_hist.release();
     if (pinned) (void)hipHostFree(pinned);
     if (upload_pinned) (void)hipHostFree(upload_pinned);
@@ -1272,7 +1274,28 @@ int fvh_ndt_align_wait(fvh_ndt* h, fvh_lm_result* r) {
   if (h->distance_mode == FVH_NDT_P2D) return align_finish<MODE_NDT_P2D>(&h->e, h->pending, h->cost_source(), h->target_vm, r, h->rebuild_safe());
   return align_finish<MODE_NDT_D2D>(&h->e, h->pending, h->cost_source(), h->target_vm, r, h->rebuild_safe());
 }
-static int ndt_prepare(fvh_ndt* h, const float* d_xyz, int n, int stride, bool on_device) {
+// The output of the voxel-grid filter's last ApproximateVoxelGrid call becomes cloud `c` of this handle WITHOUT a copy: the emit kernel wrote
+// it as float4 too (kernels_downsample.hpp), and that buffer is swapped with the cloud's (the filter gets the cloud's old buffer as its next
+// output buffer: nothing in flight reads it -- it belonged to a cloud that was replaced or swapped out). `consumer`: the stream the
+// handle will read the cloud on; ordered after the filter's last kernel unless the host has already seen that kernel finish.
+static int take_filter_output(Engine* e, fvh_voxelgrid* vg, CloudDev& c, hipStream_t consumer) {
+  if (!vg) return e->fail(FVH_ERR_INVALID_ARGUMENT, "from_voxelgrid: null filter handle");
+  if (vg->e.device != e->device) return e->fail(FVH_ERR_INVALID_ARGUMENT, "from_voxelgrid: the two handles live on different devices");
+  if (!vg->d.out4_valid) return e->fail(FVH_ERR_BAD_STATE, "from_voxelgrid: no ApproximateVoxelGrid output to take (fvh_voxelgrid_filter* with FVH_VOXELGRID_APPROXIMATE first; an output can be taken once)");
+  if (!vg->d.out_complete && vg->d.out_stream != consumer) {
+    if (!e->take_ev) HIP_OR_FAIL(e, hipEventCreateWithFlags(&e->take_ev, hipEventDisableTiming));
+    HIP_OR_FAIL(e, hipEventRecord(e->take_ev, vg->d.out_stream));
+    HIP_OR_FAIL(e, hipStreamWaitEvent(consumer, e->take_ev, 0));
+  }
+  std::swap(c.pts, vg->d.out4);
+  vg->d.out4_valid = false;
+  c.n = vg->d.out_n;
+  c.has_pts = true;
+  c.has_sorted = false;
+  c.has_box = false;
+  return FVH_OK;
+}
+static int ndt_prepare(fvh_ndt* h, const float* d_xyz, int n, int stride, bool on_device, fvh_voxelgrid* from_filter = nullptr) {
   CHECK_HANDLE_HOST_ONLY(h);  // (touches the prepared slot and the second stream only: legal between align_async and align_wait)
   Engine* e = &h->e;
   hipStream_t ps = e->side_stream();  // null (multi-GPU handle, FVH_SIDE_STREAM=0): in order on the main stream -- correct, nothing overlaps
@@ -1281,7 +1304,7 @@ static int ndt_prepare(fvh_ndt* h, const float* d_xyz, int n, int stride, bool o
   { const int rc0 = e->feeder_stream(&ps); if (rc0) return rc0; }  // (the main stream instead, behind an LM grid that crowds the chip: Engine::lm_crowds_chip)
   h->next_ready = false;
   h->next_vm.invalidate();
-  int rc = upload_cloud(e, h->next_source, d_xyz, n, stride, on_device, false, ps);
+  int rc = from_filter ? take_filter_output(e, from_filter, h->next_source, ps ? ps : e->stream) : upload_cloud(e, h->next_source, d_xyz, n, stride, on_device, false, ps);
   if (rc) return rc;
   {
     // D2D registers the map itself; in both modes it is the TARGET map of the frame after (swap_source_and_target): built here it is
@@ -1296,6 +1319,12 @@ static int ndt_prepare(fvh_ndt* h, const float* d_xyz, int n, int stride, bool o
 }
 int fvh_ndt_prepare_source_device(fvh_ndt* h, const float* d_xyz, int n, int stride) { return ndt_prepare(h, d_xyz, n, stride, true); }
 int fvh_ndt_prepare_source(fvh_ndt* h, const float* xyz, int n, int stride) { return ndt_prepare(h, xyz, n, stride, false); }  // a HOST cloud, consumed before the call returns
+int fvh_ndt_prepare_source_from_voxelgrid(fvh_ndt* h, fvh_voxelgrid* vg) {
+  if (h && !vg) return h->e.fail(FVH_ERR_INVALID_ARGUMENT, "from_voxelgrid: null filter handle");
+  return ndt_prepare(h, nullptr, 0, 3, true, vg);
+}
+int fvh_ndt_set_source_cloud_from_voxelgrid(fvh_ndt* h, fvh_voxelgrid* vg) { CHECK_HANDLE(h); NDT_NOT_PENDING(h); h->e.has_corr = false; h->source_vm.invalidate(); return take_filter_output(&h->e, vg, h->source, h->e.stream); }
+int fvh_ndt_set_target_cloud_from_voxelgrid(fvh_ndt* h, fvh_voxelgrid* vg) { CHECK_HANDLE(h); NDT_NOT_PENDING(h); h->e.has_corr = false; h->target_vm.invalidate(); return take_filter_output(&h->e, vg, h->target, h->e.stream); }
 int fvh_ndt_adopt_prepared_source(fvh_ndt* h) {
   CHECK_HANDLE(h);
   Engine* e = &h->e;

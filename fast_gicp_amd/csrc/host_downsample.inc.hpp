@@ -8,8 +8,12 @@
 struct DownsampleDev {
   CloudDev cloud;                 // the input, widened to float4
   DevBuf keys, idx, head, trig, scan, bsums, slots, out;
+  DevBuf out4;                    // ApproximateVoxelGrid: the output again as float4 {x, y, z, 0}; fvh_ndt_*_from_voxelgrid SWAPS this buffer with the handle's cloud
+  bool out4_valid = false;        // holds the output of the last call (not yet taken)
+  hipStream_t out_stream = nullptr;  // the stream the last call ran on ...
+  bool out_complete = true;          // ... and whether the host saw its LAST kernel finish (false: an _async call returned with the count only)
   int out_n = 0;
-  void release() { cloud.release(); keys.release(); idx.release(); head.release(); trig.release(); scan.release(); bsums.release(); slots.release(); out.release(); }
+  void release() { cloud.release(); keys.release(); idx.release(); head.release(); trig.release(); scan.release(); bsums.release(); slots.release(); out.release(); out4.release(); }
 };
 
 // exclusive scan of n unsigned values (in -> out, may alias); the grand total lands in bsums[nb]
@@ -73,6 +77,8 @@ int downsample_approx(Engine* e, DownsampleDev& d, const float* xyz, int n, int 
   HIP_OR_FAIL(e, d.trig.ensure(sizeof(unsigned) * (size_t)nblocks * 32));                       // trigger bits by original index (whole blocks of 32 words)
   HIP_OR_FAIL(e, d.scan.ensure(sizeof(unsigned) * (size_t)(nblocks + 1)));                      // trigger prefix per 1024 indices
   HIP_OR_FAIL(e, d.out.ensure(sizeof(float) * 3 * (size_t)n));
+  HIP_OR_FAIL(e, d.out4.ensure(sizeof(float4) * (size_t)n));  // (after a swap this is a cloud buffer of the registration handle: grown here if the frame is larger)
+  d.out4_valid = false;
   const bool fresh = d.slots.p == nullptr;
   HIP_OR_FAIL(e, d.slots.ensure(sizeof(AvgState)));
   if (fresh) HIP_OR_FAIL(e, hipMemsetAsync(d.slots.p, 0, sizeof(AvgState), e->stream));  // (the ticket re-arms itself afterwards)
@@ -99,14 +105,14 @@ int downsample_approx(Engine* e, DownsampleDev& d, const float* xyz, int n, int 
       avg_keys_hist_kernel<<<wblocks, 256, 0, e->stream>>>(d_xyz, n, stride, inv, nwaves, hist, d.trig.as<unsigned>(), nwords, st, hist_wg);
       avg_scatter_kernel<<<wblocks, 256, 0, e->stream>>>(d_xyz, n, stride, inv, nwaves, hist, st, sorted, hist_wg);
       avg_mark_kernel<<<pblocks, 256, 0, e->stream>>>(sorted, n, inv, head, d.trig.as<unsigned>(), st);
-      avg_emit_kernel<<<pblocks, 256, 0, e->stream>>>(sorted, head, n, inv, d.trig.as<unsigned>(), nullptr, st, d.out.as<float>(), final_result, seq, nwords, early ? e->result_dev : nullptr);
+      avg_emit_kernel<<<pblocks, 256, 0, e->stream>>>(sorted, head, n, inv, d.trig.as<unsigned>(), nullptr, st, d.out.as<float>(), final_result, seq, nwords, early ? e->result_dev : nullptr, d.out4.as<float>());
     } else {
       avg_keys_hist_kernel<<<wblocks, 256, 0, e->stream>>>(d_xyz, n, stride, inv, nwaves, hist, d.trig.as<unsigned>(), nwords, st);
       avg_binscan_kernel<<<AVG_SLOTS / 4, 256, 0, e->stream>>>(hist, nwaves, totals, st);
       avg_scatter_kernel<<<wblocks, 256, 0, e->stream>>>(d_xyz, n, stride, inv, nwaves, hist, st, sorted);
       avg_mark_kernel<<<pblocks, 256, 0, e->stream>>>(sorted, n, inv, head, d.trig.as<unsigned>(), st);
       avg_scan_kernel<<<1, 1024, 0, e->stream>>>(d.trig.as<unsigned>(), nwords, d.scan.as<unsigned>(), st, early ? e->result_dev : nullptr, seq);
-      avg_emit_kernel<<<pblocks, 256, 0, e->stream>>>(sorted, head, n, inv, d.trig.as<unsigned>(), d.scan.as<unsigned>(), st, d.out.as<float>(), final_result, seq);
+      avg_emit_kernel<<<pblocks, 256, 0, e->stream>>>(sorted, head, n, inv, d.trig.as<unsigned>(), d.scan.as<unsigned>(), st, d.out.as<float>(), final_result, seq, 0, nullptr, d.out4.as<float>());
     }
   }
   HIP_OR_FAIL(e, hipGetLastError());
@@ -133,6 +139,9 @@ int downsample_approx(Engine* e, DownsampleDev& d, const float* xyz, int n, int 
   }
   if (bad) { d.out_n = 0; return e->fail(FVH_ERR_INVALID_ARGUMENT, "voxelgrid: non-finite coordinates in the input"); }
   d.out_n = (int)count;
+  d.out4_valid = d.out_n > 0;
+  d.out_stream = e->stream;
+  d.out_complete = !early;
   *out_n = d.out_n;
   return FVH_OK;
 }
@@ -144,6 +153,7 @@ int downsample(Engine* e, DownsampleDev& d, int method, const float* xyz, int n,
   if (!(leaf > 0.f)) return e->fail(FVH_ERR_INVALID_ARGUMENT, "voxelgrid: leaf size must be > 0");
   int rc = FVH_OK;
   d.out_n = 0;
+  d.out4_valid = false;
   *out_n = 0;
   if (method == FVH_VOXELGRID_APPROXIMATE) return downsample_approx(e, d, xyz, n, stride, on_device, leaf, out_n, early);
   rc = upload_cloud(e, d.cloud, xyz, n, stride, on_device, false);

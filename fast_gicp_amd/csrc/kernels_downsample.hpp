@@ -518,7 +518,8 @@ __device__ __forceinline__ void avg_emit_stage(const float4* __restrict__ sorted
 }
 __device__ __forceinline__ void avg_emit_points(const float4* __restrict__ sorted_pts, const unsigned char* __restrict__ head, int n, float inv, const unsigned* __restrict__ trigbits,
                                                 const unsigned* block_base, const unsigned* slot_rank, unsigned trig_total, float* __restrict__ out,
-                                                const float4* s_pts, const unsigned char* s_head, const unsigned short* word_prefix = nullptr /* (LDS) triggers before each word, within its block */) {
+                                                const float4* s_pts, const unsigned char* s_head, const unsigned short* word_prefix = nullptr /* (LDS) triggers before each word, within its block */,
+                                                float* __restrict__ out4 = nullptr /* the same centroids as float4 {x, y, z, 0}: the layout a registration handle keeps its clouds in */) {
   const int w0 = blockIdx.x * 256;
   const int j = w0 + threadIdx.x;
   if (j >= n || !s_head[threadIdx.x]) return;
@@ -568,6 +569,12 @@ __device__ __forceinline__ void avg_emit_points(const float4* __restrict__ sorte
   __hip_atomic_store(&out[3 * (size_t)pos], cx / cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   __hip_atomic_store(&out[3 * (size_t)pos + 1], cy / cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   __hip_atomic_store(&out[3 * (size_t)pos + 2], cz / cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (out4) {  // (fvh_ndt_*_from_voxelgrid takes this buffer over as the cloud: no widening kernel, one launch less between the filter and the voxel map)
+    __hip_atomic_store(&out4[4 * (size_t)pos], cx / cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(&out4[4 * (size_t)pos + 1], cy / cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(&out4[4 * (size_t)pos + 2], cz / cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(&out4[4 * (size_t)pos + 3], 0.f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
 }
 
 // The LAST workgroup to finish writes {count, bad flag, sequence} to mapped host memory: when the host sees the sequence
@@ -578,7 +585,7 @@ __device__ __forceinline__ void avg_emit_points(const float4* __restrict__ sorte
 __global__ __launch_bounds__(256) void avg_emit_kernel(const float4* __restrict__ sorted_pts, const unsigned char* __restrict__ head, int n, float inv, const unsigned* __restrict__ trigbits,
                                                        const unsigned* __restrict__ block_base, AvgState* __restrict__ st, float* __restrict__ out,
                                                        unsigned long long* __restrict__ host_result /* {count, bad, seq} mapped, or null */, unsigned long long seq,
-                                                       int nwords = 0, unsigned long long* __restrict__ early_result = nullptr) {
+                                                       int nwords = 0, unsigned long long* __restrict__ early_result = nullptr, float* __restrict__ out4 = nullptr) {
   __shared__ unsigned s_bb[AVG_FUSED_MAX_BLOCKS + 1], s_rank[AVG_SLOTS + 1], s_w[4];
   __shared__ float4 s_pts[AVG_WINDOW];
   __shared__ unsigned char s_head[AVG_WINDOW];
@@ -588,7 +595,7 @@ __global__ __launch_bounds__(256) void avg_emit_kernel(const float4* __restrict_
     trig_total = st->trig_total; used_slots = st->used_slots;
     avg_emit_stage(sorted_pts, head, n, s_pts, s_head);
     __syncthreads();
-    avg_emit_points(sorted_pts, head, n, inv, trigbits, block_base, st->slot_rank, trig_total, out, s_pts, s_head);
+    avg_emit_points(sorted_pts, head, n, inv, trigbits, block_base, st->slot_rank, trig_total, out, s_pts, s_head, nullptr, out4);
   } else {
     const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
     const int nblocks = (nwords + 31) / 32;
@@ -641,7 +648,7 @@ __global__ __launch_bounds__(256) void avg_emit_kernel(const float4* __restrict_
         __hip_atomic_store(&early_result[2], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
       }
     }
-    avg_emit_points(sorted_pts, head, n, inv, trigbits, s_bb, s_rank, trig_total, out, s_pts, s_head, s_wp);
+    avg_emit_points(sorted_pts, head, n, inv, trigbits, s_bb, s_rank, trig_total, out, s_pts, s_head, s_wp, out4);
   }
   if (!host_result) return;
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this workgroup's centroids are in memory (write-through stores); no L2 write-back (see avg_binscan_kernel)

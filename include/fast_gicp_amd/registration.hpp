@@ -952,6 +952,8 @@ public:
   // The prepared source lives on the device only: getInputSource() is null for it and alignWait() returns the pose without
   // transforming a host cloud. Same kernels on the same data as the sequential calls: same registration.
   void prepareNextSourceDevice(const float* d_xyz, int n, int stride_floats = 3) { prepared_cloud_.reset(); call(fvh_ndt_prepare_source_device(core_, d_xyz, n, stride_floats), "prepare_source_device"); }
+  /// the output of the filter's last ApproximateVoxelGrid call becomes the prepared source without a copy (fvh_ndt_prepare_source_from_voxelgrid)
+  void prepareNextSourceFromFilter(fvh_voxelgrid* filter) { prepared_cloud_.reset(); call(fvh_ndt_prepare_source_from_voxelgrid(core_, filter), "prepare_source_from_voxelgrid"); }
   /// the same for a host cloud (consumed before the call returns); adoptPreparedSource() then makes it getInputSource()
   void prepareNextSource(const PointCloudSourceConstPtr& cloud) {
     const detail::XyzView<PointSource> view(*cloud, scratch_xyz_);

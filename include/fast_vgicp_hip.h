@@ -356,6 +356,14 @@ int fvh_ndt_align_wait(fvh_ndt* h, fvh_lm_result* result);
 int fvh_ndt_prepare_source_device(fvh_ndt* h, const float* d_xyz, int n, int stride_floats);
 int fvh_ndt_prepare_source(fvh_ndt* h, const float* xyz, int n, int stride_floats); /* the same for a HOST cloud, consumed before the call returns */
 int fvh_ndt_adopt_prepared_source(fvh_ndt* h);
+/* new (round 6): the output of the filter's last ApproximateVoxelGrid call becomes the cloud WITHOUT a copy -- the filter's emit kernel wrote it as
+ * float4 too, and that buffer is swapped with the cloud's (what fvh_voxelgrid_device_points + fvh_ndt_set_source_cloud_device /
+ * _prepare_source_device do, minus the widening kernel and its launch: 8 of a LiDAR frame's 141 us). An output can be taken once; the filter's
+ * packed xyz (fvh_voxelgrid_get_points / _device_points) stays valid. The streams of the two handles are ordered if they differ. */
+struct fvh_voxelgrid;
+int fvh_ndt_set_source_cloud_from_voxelgrid(fvh_ndt* h, struct fvh_voxelgrid* filter);
+int fvh_ndt_set_target_cloud_from_voxelgrid(fvh_ndt* h, struct fvh_voxelgrid* filter);
+int fvh_ndt_prepare_source_from_voxelgrid(fvh_ndt* h, struct fvh_voxelgrid* filter);
 int fvh_ndt_fitness_score(fvh_ndt* h, const double* T16, double max_range, double* score);
 /* testing hook (as fvh_vgicp_debug_set_voxel_hint): table size hint of the NEXT build of the source (which = 0) / target (1) voxel map */
 int fvh_ndt_debug_set_voxel_hint(fvh_ndt* h, int which, int num_voxels);

@@ -201,3 +201,77 @@ def test_shared_stream_async_filter_feeds_the_registration(O):
         _same(async_clouds[i], ref)
     for a, b in zip(sync_poses, async_poses):
         assert util.rel_err(a, b) < 1e-9  # (two builds of each map: fp64 atomics in arrival order)
+
+
+@pytest.mark.parametrize("mode", [1, 0])  # D2D, P2D
+def test_filter_output_taken_as_the_cloud_equals_the_copied_one(mode):
+    """fvh_ndt_set_source_cloud_from_voxelgrid / _set_target_cloud_from_voxelgrid / _prepare_source_from_voxelgrid: the filter's emit kernel writes its
+    centroids as float4 too and that buffer is swapped with the cloud's -- the same cloud as device pointer + widening kernel: equal voxel maps, equal
+    registrations, frame after frame (the buffers rotate between the filter and the handle's clouds); an output can be taken once; the filter's packed
+    xyz output stays readable."""
+    import torch
+    from fast_gicp_amd import capi
+    n_frames = 6
+    raw = [util.lidar_frame(i) for i in range(n_frames)]
+    dev = torch.device("cuda", 0)
+    d_raw = [torch.from_numpy(f).to(dev).contiguous() for f in raw]
+
+    def make():
+        c = capi.NDTCore(0)
+        c.set_distance_mode(mode); c.set_neighbor_search_method(1); c.set_resolution(1.0)
+        return c
+
+    vg, c = capi.VoxelGrid(0), make()
+    ptr, n = vg.filter_device(d_raw[0].data_ptr(), len(raw[0]), 0.25)
+    c.set_target_cloud_device(ptr, n, 3)
+    seq = []
+    for i in range(1, n_frames):
+        ptr, n = vg.filter_device(d_raw[i].data_ptr(), len(raw[i]), 0.25)
+        c.set_source_cloud_device(ptr, n, 3)
+        r = c.align()
+        seq.append((r["T"].copy(), r["num_linearize"], r["num_error_evals"], n))
+        c.swap_source_and_target()
+    vg.close(); c.close()
+
+    for shared in (True, False):
+        vg, c = capi.VoxelGrid(0), make()
+        if shared:
+            vg.share_stream(c)
+        ptr, n = vg.filter_device(d_raw[0].data_ptr(), len(raw[0]), 0.25, asynchronous=shared)
+        c.set_target_cloud_from_voxelgrid(vg)
+        with pytest.raises(capi.FvhError):
+            c.set_source_cloud_from_voxelgrid(vg)  # taken already
+        for i in range(1, n_frames):
+            ptr, n = vg.filter_device(d_raw[i].data_ptr(), len(raw[i]), 0.25, asynchronous=shared)
+            c.set_source_cloud_from_voxelgrid(vg)
+            r = c.align()
+            T, nl, ne, n_ref = seq[i - 1]
+            assert n == n_ref and (r["num_linearize"], r["num_error_evals"]) == (nl, ne), i
+            assert util.rel_err(r["T"], T) < 1e-9, i
+            assert vg.get_points(n).shape == (n, 3)  # the packed output is still there
+            c.swap_source_and_target()
+        vg.close(); c.close()
+
+    # the pipelined form
+    vg, c = capi.VoxelGrid(0), make()
+    ptr, n = vg.filter_device(d_raw[0].data_ptr(), len(raw[0]), 0.25)
+    c.set_target_cloud_from_voxelgrid(vg)
+    vg.share_prepare_stream(c)
+    vg.filter_device(d_raw[1].data_ptr(), len(raw[1]), 0.25, asynchronous=True)
+    c.prepare_source_from_voxelgrid(vg)
+    for i in range(1, n_frames):
+        c.adopt_prepared_source()
+        c.align_async()
+        if i + 1 < n_frames:
+            vg.filter_device(d_raw[i + 1].data_ptr(), len(raw[i + 1]), 0.25, asynchronous=True)
+            c.prepare_source_from_voxelgrid(vg)
+        r = c.align_wait()
+        T, nl, ne, _ = seq[i - 1]
+        assert (r["num_linearize"], r["num_error_evals"]) == (nl, ne) and util.rel_err(r["T"], T) < 1e-9, i
+        c.swap_source_and_target()
+    # an exact-VoxelGrid output cannot be taken
+    vg2 = capi.VoxelGrid(0)
+    vg2.filter_device(d_raw[0].data_ptr(), len(raw[0]), 0.25, method=vg2.EXACT)
+    with pytest.raises(capi.FvhError):
+        c.set_source_cloud_from_voxelgrid(vg2)
+    vg2.close(); vg.close(); c.close()

@@ -1,7 +1,7 @@
 set -u
 R=${GRAFT_REPO_ROOT:-$(pwd)}; O=$R/gpurun_out/gap; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp && cd $R
-timeout 200 rocprofv3 --kernel-trace -d $O/t -o h -- python tools/hiccup_probe.py 300 pipe > $O/out.txt 2>&1 < /dev/null
+timeout 200 rocprofv3 --kernel-trace -d $O/t -o h -- python tools/hiccup_probe.py 300 ${MODE:-pipe} > $O/out.txt 2>&1 < /dev/null
 f=$(find $O/t -name "*.db" | head -1)
 python - "$f" <<'PY'
 import sqlite3, sys
