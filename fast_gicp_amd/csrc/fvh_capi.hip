@@ -261,11 +261,9 @@ struct Engine {
       std::lock_guard<std::mutex> lk(g_gangs.mu);
       g_gangs.engines.push_back(this);
       counted = true;
-      // the second stream of a registration handle is made HERE, with the handle ("warming up GPU"): made by the first swap_source_and_target()
-      // it put 9 ms into the first registration of the caller's loop (apps/gicp_align: the 100times_reuse figure of a handle's first row)
-      if (side_stream()) {
-        if ((e = hipStreamSynchronize(side)) != hipSuccess) return hipfail(e, "hipStreamSynchronize");
-      }
+      // (The second stream stays lazy -- made by the first call that uses it, ~9 ms once. Made here, with the handle, it took that out of a
+      // caller's first loop iteration, but every stream is a hardware queue: eight processes sharing one GPU no longer met in the mailbox
+      // self-check within 5 s, and four align-only handles of one process ran 8 x slower -- queues time-sliced under spinning kernels.)
     }
     return FVH_OK;
   }
