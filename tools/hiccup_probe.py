@@ -19,11 +19,12 @@ if len(sys.argv) > 2 and sys.argv[2].startswith("ndt"):
     c.set_target_cloud_device(ptr, n, 3)
     ts = np.zeros(iters)
     if mode == "ndt_seq":
+        vg.share_stream(c)
         for it in range(iters):
             i = 1 + it % 7
             t0 = time.perf_counter()
-            ptr, n = vg.filter_device(d_raw[i].data_ptr(), len(raw[i]), 0.25)
-            c.set_source_cloud_device(ptr, n, 3)
+            ptr, n = vg.filter_device(d_raw[i].data_ptr(), len(raw[i]), 0.25, asynchronous=True)
+            c.set_source_cloud_from_voxelgrid(vg)
             c.align()
             c.swap_source_and_target()
             ts[it] = time.perf_counter() - t0
@@ -37,7 +38,7 @@ if len(sys.argv) > 2 and sys.argv[2].startswith("ndt"):
             c.adopt_prepared_source()
             c.align_async()
             ptr, n = vg.filter_device(d_raw[i].data_ptr(), len(raw[i]), 0.25, asynchronous=True)
-            c.prepare_source_device(ptr, n, 3)
+            c.prepare_source_from_voxelgrid(vg)
             c.align_wait()
             c.swap_source_and_target()
             ts[it] = time.perf_counter() - t0
