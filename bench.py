@@ -752,7 +752,7 @@ def run_stream(args, steps, warmup, cpu_loops=15, frames_n=10):
     def step():
         state["k"] += 1
         i = seq[state["k"] % len(seq)]
-        ptr, n = vg.filter_device(d_frames[i].data_ptr(), len(frames[i]), 0.25, vg.APPROXIMATE, asynchronous=shared)
+        ptr, n = vg.filter_device(d_frames[i].data_ptr(), len(frames[i]), 0.25, vg.APPROXIMATE, asynchronous=shared, want_pointer=not TAKE)
         if TAKE:
             ndt.set_source_cloud_from_voxelgrid(vg)  # the filter's float4 output IS the cloud: no widening kernel (fvh_ndt_set_source_cloud_from_voxelgrid)
         else:
@@ -889,7 +889,7 @@ def run_stream(args, steps, warmup, cpu_loops=15, frames_n=10):
         lens = [len(f) for f in frames]
 
         def prepare(i):
-            ptr, n = vg.filter_device(ptrs[i], lens[i], 0.25, vg.APPROXIMATE, asynchronous=True)
+            ptr, n = vg.filter_device(ptrs[i], lens[i], 0.25, vg.APPROXIMATE, asynchronous=True, want_pointer=not TAKE)
             if TAKE:
                 ndt.prepare_source_from_voxelgrid(vg)
             else:

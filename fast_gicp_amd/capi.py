@@ -580,12 +580,15 @@ class VoxelGrid:
         else:
             self._check(self._lib.fvh_voxelgrid_share_prepare_stream_with_vgicp(self._h, core.h), "fvh_voxelgrid_share_prepare_stream_with_vgicp")
 
-    def filter_device(self, d_ptr, n, leaf, method=APPROXIMATE, stride=3, asynchronous=False):
+    def filter_device(self, d_ptr, n, leaf, method=APPROXIMATE, stride=3, asynchronous=False, want_pointer=True):
         """Device pointer in (n points, `stride` floats apart); returns (device pointer to packed xyz, count) valid until the next filter call.
-        asynchronous (after share_stream): the count is final on return, the points are complete in the shared stream's order only."""
+        asynchronous (after share_stream): the count is final on return, the points are complete in the shared stream's order only.
+        want_pointer=False: (0, count) -- for callers that hand the output over with NDTCore.*_from_voxelgrid (one ABI call less per frame)."""
         m = C.c_int(0)
         fn = self._lib.fvh_voxelgrid_filter_device_async if asynchronous else self._lib.fvh_voxelgrid_filter_device
         self._check(fn(self._h, int(method), C.c_void_p(d_ptr), int(n), int(stride), C.c_float(leaf), C.byref(m)), "fvh_voxelgrid_filter_device")
+        if not want_pointer:
+            return 0, m.value
         ptr = C.c_void_p()
         self._check(self._lib.fvh_voxelgrid_device_points(self._h, C.byref(ptr), C.byref(m)), "fvh_voxelgrid_device_points")
         return ptr.value or 0, m.value
